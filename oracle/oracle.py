@@ -1,0 +1,257 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by anything under stella_vslam_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_LIB = None
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> pathlib.Path:
+    so = _HERE / "liboracle.so"
+    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "orb_pattern_i8.inc", "Makefile")]
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-C", str(_HERE), "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        _LIB.orc_fast_atan2.restype = C.c_float
+        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_util_cos.restype = C.c_float
+        _LIB.orc_util_cos.argtypes = [C.c_float]
+        _LIB.orc_util_sin.restype = C.c_float
+        _LIB.orc_util_sin.argtypes = [C.c_float]
+        _LIB.orc_ic_angle.restype = C.c_float
+        _LIB.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        _LIB.orc_angle_diff.restype = C.c_float
+        _LIB.orc_angle_diff.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_hamming_32.restype = C.c_uint
+        _LIB.orc_hamming_64.restype = C.c_uint
+    return _LIB
+
+
+def _p(a, t=C.c_void_p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+# ------------------------------------------------------------------------------------------- ORB
+
+def scale_tables(scale_factor: float, num_levels: int):
+    out = [np.zeros(num_levels, np.float32) for _ in range(4)]
+    lib().orc_orb_scale_tables(C.c_float(scale_factor), num_levels, *[_p(o) for o in out])
+    return out
+
+
+def level_size(w0: int, h0: int, scale: float):
+    w, h = C.c_int(), C.c_int()
+    lib().orc_level_size(w0, h0, C.c_float(scale), C.byref(w), C.byref(h))
+    return w.value, h.value
+
+
+def level_sizes(w0: int, h0: int, scale_factor: float = 1.2, num_levels: int = 8):
+    sf = scale_tables(scale_factor, num_levels)[0]
+    return [(w0, h0)] + [level_size(w0, h0, float(sf[l])) for l in range(1, num_levels)]
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def gauss_taps(n: int = 7, sigma: float = 2.0):
+    t = np.zeros(n, np.int32)
+    lib().orc_gauss_taps_q8(n, C.c_double(sigma), _p(t))
+    return t
+
+
+def gaussian_blur7(src: np.ndarray) -> np.ndarray:
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.empty_like(src)
+    lib().orc_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast9_16(img: np.ndarray, threshold: int, nms: bool = True) -> np.ndarray:
+    """(n,3) int32 rows (x, y, score) in emission order; img may be a strided view (ROI)."""
+    assert img.dtype == np.uint8 and img.strides[1] == 1
+    cap = img.shape[0] * img.shape[1]
+    out = np.zeros((max(cap, 1), 3), np.int32)
+    n = lib().orc_fast9_16(C.c_void_p(img.ctypes.data), img.shape[1], img.shape[0], img.strides[0], threshold, int(nms),
+                           _p(out), cap)
+    return out[:n].copy()
+
+
+def umax():
+    t = np.zeros(16, np.int32)
+    lib().orc_umax(_p(t))
+    return t
+
+
+def ic_angle(img: np.ndarray, x: float, y: float) -> float:
+    assert img.dtype == np.uint8 and img.strides[1] == 1
+    return float(lib().orc_ic_angle(C.c_void_p(img.ctypes.data), img.strides[0], C.c_float(x), C.c_float(y)))
+
+
+def orb_descriptor(img: np.ndarray, x: float, y: float, angle_deg: float) -> np.ndarray:
+    assert img.dtype == np.uint8 and img.strides[1] == 1
+    d = np.zeros(32, np.uint8)
+    lib().orc_compute_orb_descriptor(C.c_void_p(img.ctypes.data), img.strides[0], C.c_float(x), C.c_float(y),
+                                     C.c_float(angle_deg), _p(d))
+    return d
+
+
+def orb_extract(img: np.ndarray, mask: np.ndarray | None = None, scale_factor: float = 1.2, num_levels: int = 8,
+                ini_thr: int = 20, min_thr: int = 7, min_area: int = 800, cap: int = 20000, want_pyramid: bool = False):
+    """Returns (keypoints[KEYPOINT_DTYPE], descriptors[n,32] u8, level_counts[L] (, pyramid list))."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+    h, w = img.shape
+    kps = np.zeros(cap, KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    counts = np.zeros(num_levels, np.int32)
+    sizes = level_sizes(w, h, scale_factor, num_levels)
+    pyr = np.zeros(sum(a * b for a, b in sizes[1:]) + 1, np.uint8) if want_pyramid else None
+    if mask is not None:
+        assert mask.dtype == np.uint8 and mask.shape == img.shape and mask.strides[1] == 1
+    rc = lib().orc_orb_extract(C.c_void_p(img.ctypes.data), w, h, img.strides[0],
+                               None if mask is None else C.c_void_p(mask.ctypes.data),
+                               0 if mask is None else mask.strides[0],
+                               C.c_float(scale_factor), num_levels, ini_thr, min_thr, C.c_uint(min_area),
+                               _p(kps), _p(desc), cap, C.byref(n), _p(pyr), _p(counts))
+    if rc != 0:
+        raise RuntimeError(f"orc_orb_extract rc={rc} n={n.value}")
+    res = (kps[:n.value].copy(), desc[:n.value].copy(), counts)
+    if want_pyramid:
+        levels, off = [img], 0
+        for (lw, lh) in sizes[1:]:
+            levels.append(pyr[off:off + lw * lh].reshape(lh, lw).copy())
+            off += lw * lh
+        res = res + (levels,)
+    return res
+
+
+# ------------------------------------------------------------------------------------------- match
+
+def hamming(a: np.ndarray, b: np.ndarray, bits64: bool = False) -> int:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    f = lib().orc_hamming_64 if bits64 else lib().orc_hamming_32
+    return int(f(_p(a), _p(b)))
+
+
+def hamming_matrix(desc1: np.ndarray, desc2: np.ndarray) -> np.ndarray:
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    desc2 = np.ascontiguousarray(desc2, np.uint8)
+    out = np.zeros((len(desc2), len(desc1)), np.uint16)
+    lib().orc_hamming_matrix(_p(desc1), len(desc1), _p(desc2), len(desc2), _p(out))
+    return out
+
+
+def angle_diff(a: float, b: float) -> float:
+    return float(lib().orc_angle_diff(C.c_float(a), C.c_float(b)))
+
+
+def brute_force_match(desc1, angle1, desc2, angle2, valid2=None, lowe_ratio: float = 0.75, check_orientation: bool = True):
+    """robust::brute_force_match; returns matched_2_in_1 (len n1, -1 = unmatched)."""
+    desc1 = np.ascontiguousarray(desc1, np.uint8)
+    desc2 = np.ascontiguousarray(desc2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32)
+    angle2 = np.ascontiguousarray(angle2, np.float32)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    out = np.full(len(desc1), -1, np.int32)
+    lib().orc_brute_force_match(_p(desc1), _p(angle1), len(desc1), _p(desc2), _p(angle2), _p(v2), len(desc2),
+                                C.c_float(lowe_ratio), int(check_orientation), _p(out))
+    return out
+
+
+MODE_BEST_ONLY, MODE_RATIO_SAME_OCTAVE = 0, 1
+
+
+def match_candidates(qdesc, tdesc, cand_off, cand_idx, t_octave=None, q_valid=None, occupied=None, q_angle=None,
+                     t_angle=None, check_orientation=False, q_xright=None, t_xright=None, q_xr_tol=None, thr=100,
+                     lowe_ratio=0.8, mode=MODE_BEST_ONLY):
+    qdesc = np.ascontiguousarray(qdesc, np.uint8)
+    tdesc = np.ascontiguousarray(tdesc, np.uint8)
+    cand_off = np.ascontiguousarray(cand_off, np.int32)
+    cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+    cv = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+    t_octave, q_valid, occupied = cv(t_octave, np.int32), cv(q_valid, np.uint8), cv(occupied, np.uint8)
+    q_angle, t_angle = cv(q_angle, np.float32), cv(t_angle, np.float32)
+    q_xright, t_xright, q_xr_tol = cv(q_xright, np.float32), cv(t_xright, np.float32), cv(q_xr_tol, np.float32)
+    out = np.full(len(qdesc), -1, np.int32)
+    lib().orc_match_candidates(_p(qdesc), len(qdesc), _p(tdesc), _p(t_octave), len(tdesc), _p(cand_off), _p(cand_idx),
+                               _p(q_valid), _p(occupied), _p(q_angle), _p(t_angle), int(check_orientation),
+                               _p(q_xright), _p(t_xright), _p(q_xr_tol), C.c_uint(thr), C.c_float(lowe_ratio), mode,
+                               _p(out))
+    return out
+
+
+def assign_keypoints_to_grid(kx, ky, bounds, cols=64, rows=48):
+    kx = np.ascontiguousarray(kx, np.float32)
+    ky = np.ascontiguousarray(ky, np.float32)
+    off = np.zeros(cols * rows + 1, np.int32)
+    items = np.zeros(max(len(kx), 1), np.int32)
+    lib().orc_assign_keypoints_to_grid(_p(kx), _p(ky), len(kx), *[C.c_float(b) for b in bounds], cols, rows, _p(off),
+                                       _p(items))
+    return off, items[:off[-1]]
+
+
+def get_keypoints_in_cell(kx, ky, octave, cell_off, cell_items, bounds, ref_x, ref_y, margin, min_level=-1,
+                          max_level=-1, cols=64, rows=48):
+    kx = np.ascontiguousarray(kx, np.float32)
+    ky = np.ascontiguousarray(ky, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    out = np.zeros(max(len(kx), 1), np.int32)
+    n = lib().orc_get_keypoints_in_cell(_p(kx), _p(ky), _p(octave), _p(cell_off), _p(cell_items),
+                                        *[C.c_float(b) for b in bounds], cols, rows, C.c_float(ref_x), C.c_float(ref_y),
+                                        C.c_float(margin), min_level, max_level, _p(out), len(out))
+    return out[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------- BA
+
+def local_ba(scene: dict, iters1: int = 5, iters2: int = 10, gain_thr: float = 1e-3, stop=None, want_trace=False):
+    """scene: dict as produced by stella_vslam_amd.synthetic.ba_scene.  `stop`: None or np.uint8[1]."""
+    P, L, E = len(scene["pose_cw"]), len(scene["points"]), len(scene["obs_pose"])
+    pose = np.ascontiguousarray(scene["pose_cw"], np.float64)
+    pts = np.ascontiguousarray(scene["points"], np.float64)
+    pose_out, pts_out = np.zeros_like(pose), np.zeros_like(pts)
+    outl = np.zeros(max(E, 1), np.uint8)
+    stats = np.zeros(8)
+    trace = np.zeros(2 * (iters1 + iters2) + 2) if want_trace else None
+    a = lambda k, t: np.ascontiguousarray(scene[k], t)
+    pf = scene.get("point_fixed")
+    pf = None if pf is None else np.ascontiguousarray(pf, np.uint8)
+    args = [a("pose_fixed", np.uint8), pf, a("obs_pose", np.int32), a("obs_point", np.int32), a("obs_uvr", np.float32),
+            a("obs_inv_sigma_sq", np.float32), a("obs_huber", np.float32), a("intr", np.float64)]
+    rc = lib().orc_local_ba(P, L, E, _p(pose), _p(args[0]), _p(pts), _p(args[1]), _p(args[2]), _p(args[3]), _p(args[4]),
+                            _p(args[5]), _p(args[6]), _p(args[7]), iters1, iters2, C.c_double(gain_thr),
+                            None if stop is None else C.c_void_p(stop.ctypes.data), _p(pose_out), _p(pts_out), _p(outl),
+                            _p(stats), _p(trace))
+    res = dict(rc=rc, pose_cw=pose_out, points=pts_out, outlier=outl[:E].copy(), stats=stats)
+    if want_trace:
+        res["trace"] = trace[:-2].reshape(-1, 2)
+    return res

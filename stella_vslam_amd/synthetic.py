@@ -1,0 +1,203 @@
+"""Deterministic synthetic workloads; numpy only, no GPU, no oracle.
+
+* frames: textured-gradient 8-bit images that yield ~2k ORB keypoints at 640x480 with the default
+  parameters, as a translating sequence (frame t+1 = frame t shifted by (3,1) px + fresh noise) so
+  that consecutive frames produce realistic match sets.
+* local-BA scenes: cameras on an arc looking at a box of points, EuRoC intrinsics
+  (reference example/euroc/EuRoC_mono.yaml:8-11), octave-dependent pixel noise, a few outliers.
+
+EuRoC / KITTI imagery is not available offline; BASELINE.json configs 2 and 4 run on these
+sequences at 752x480 / 1241x376.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+class XorShift64Star:
+    """xorshift64* (Vigna 2014) -- tiny, portable, seedable."""
+
+    def __init__(self, seed: int):
+        self.s = (seed & _M64) or 0x9E3779B97F4A7C15
+
+    def next(self) -> int:
+        x = self.s
+        x ^= x >> 12
+        x ^= (x << 25) & _M64
+        x ^= x >> 27
+        self.s = x
+        return (x * 0x2545F4914F6CDD1D) & _M64
+
+    def randint(self, lo: int, hi: int) -> int:
+        """uniform integer in [lo, hi]"""
+        return lo + self.next() % (hi - lo + 1)
+
+    def uniform(self) -> float:
+        return (self.next() >> 11) * (1.0 / (1 << 53))
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _canvas(width: int, height: int, seed: int, rects_per_mpx: float = 4883.0) -> np.ndarray:
+    """gradient base ((x+2y)>>2)&255 plus axis-aligned filled rectangles (4..40 px, random grey)."""
+    ys, xs = np.mgrid[0:height, 0:width]
+    img = (((xs + 2 * ys) >> 2) & 255).astype(np.uint8)
+    rng = XorShift64Star(seed)
+    n_rect = int(round(rects_per_mpx * width * height / 1e6))  # 1500 at 640x480
+    for _ in range(n_rect):
+        rw, rh = rng.randint(4, 40), rng.randint(4, 40)
+        x0, y0 = rng.randint(0, width - 1), rng.randint(0, height - 1)
+        g = rng.randint(0, 255)
+        img[y0:y0 + rh, x0:x0 + rw] = g
+    return img
+
+
+def frame_sequence(n_frames: int, width: int = 640, height: int = 480, seed: int = 0x5EED,
+                   shift: tuple[int, int] = (3, 1), noise: int = 3) -> np.ndarray:
+    """(n_frames, height, width) uint8.  Frame t is the canvas window at offset t*shift plus
+    uniform integer noise in [-noise, +noise] (fresh per frame)."""
+    sx, sy = shift
+    cw, ch = width + sx * (n_frames - 1), height + sy * (n_frames - 1)
+    canvas = _canvas(cw, ch, seed).astype(np.int16)
+    out = np.empty((n_frames, height, width), np.uint8)
+    idx = np.arange(width * height, dtype=np.uint64).reshape(height, width)
+    for t in range(n_frames):
+        win = canvas[t * sy:t * sy + height, t * sx:t * sx + width]
+        h = _splitmix64(idx + np.uint64(((seed + 1) * 0x10001 + t) * (width * height)))
+        nz = (h % np.uint64(2 * noise + 1)).astype(np.int16) - noise
+        out[t] = np.clip(win + nz, 0, 255).astype(np.uint8)
+    return out
+
+
+def frame(width: int = 640, height: int = 480, seed: int = 0x5EED) -> np.ndarray:
+    return frame_sequence(1, width, height, seed)[0]
+
+
+# --------------------------------------------------------------------------------------------- BA
+
+def _rodrigues(w: np.ndarray) -> np.ndarray:
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def ba_scene(num_kf: int = 20, num_lm: int = 10000, obs_per_lm: int = 6, num_fixed: int = 4, seed: int = 1234,
+             outlier_frac: float = 0.03, pose_noise=(0.02, 0.5), point_noise: float = 0.03, stereo: bool = False,
+             scale_factor: float = 1.2, num_levels: int = 8, loop: bool = False) -> dict:
+    """Synthetic local-BA problem on the flat arrays the C-ABI carries.
+
+    Cameras on an arc (radius 5 m, 18 deg span; `loop=True`: full circle for the global-BA config) looking
+    at points uniform in a 4x3x2 m box 4-8 m away.  Each point is observed by `obs_per_lm` cameras that see
+    it inside a 752x480 image.  Returns ground truth next to the perturbed initial estimate.
+    """
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.654
+    cx, cy = 367.215, 248.375
+    W, H = 752, 480
+    span = 2 * np.pi if loop else np.deg2rad(18.0)
+    radius = 5.0 if not loop else 12.0
+    Rs, ts = [], []
+    for i in range(num_kf):
+        a = -span / 2 + span * (i + 0.5) / num_kf
+        c = np.array([radius * np.sin(a), 0.05 * np.sin(3 * a), -radius * np.cos(a)])  # camera centre
+        z = -c / np.linalg.norm(c) if not loop else np.array([np.sin(a), 0, -np.cos(a)])
+        if loop:
+            z = np.array([np.sin(a), 0.0, -np.cos(a)])  # look outward along the radius
+        x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R_wc = np.stack([x, y, z], axis=1)
+        R_cw = R_wc.T
+        Rs.append(R_cw)
+        ts.append(-R_cw @ c)
+    Rs, ts = np.array(Rs), np.array(ts)
+
+    pts = np.empty((num_lm, 3))
+    obs_pose, obs_point, obs_uvr, obs_oct = [], [], [], []
+    fxb = fx * 0.11 if stereo else 0.0
+    made = 0
+    tries = 0
+    while made < num_lm:
+        tries += 1
+        if loop:
+            a = rng.uniform(0, 2 * np.pi)
+            r = radius + rng.uniform(4.0, 8.0)
+            p = np.array([r * np.sin(a) + rng.uniform(-1, 1), rng.uniform(-1.5, 1.5), -r * np.cos(a) + rng.uniform(-1, 1)])
+        else:
+            p = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(-1, 1)])
+        pc = Rs @ p + ts
+        ok = pc[:, 2] > 0.5
+        u = fx * pc[:, 0] / np.where(ok, pc[:, 2], 1) + cx
+        v = fy * pc[:, 1] / np.where(ok, pc[:, 2], 1) + cy
+        ok &= (u > 20) & (u < W - 20) & (v > 20) & (v < H - 20)
+        vis = np.flatnonzero(ok)
+        if len(vis) < 2:
+            if tries > 50 * num_lm:
+                raise RuntimeError("scene generator cannot place points")
+            continue
+        k = min(obs_per_lm, len(vis))
+        # prefer a contiguous run of cameras (covisibility is local in a real map)
+        start = rng.integers(0, len(vis) - k + 1)
+        cams = vis[start:start + k]
+        pts[made] = p
+        for c_ in cams:
+            octv = int(rng.integers(0, num_levels))
+            sig = scale_factor ** octv
+            uu = u[c_] + rng.normal(0, 1.0) * sig
+            vv = v[c_] + rng.normal(0, 1.0) * sig
+            if rng.uniform() < outlier_frac:
+                d = rng.uniform(20, 50)
+                ang = rng.uniform(0, 2 * np.pi)
+                uu += d * np.cos(ang)
+                vv += d * np.sin(ang)
+            ur = (uu - fxb / pc[c_, 2] + rng.normal(0, 1.0) * sig) if stereo else -1.0
+            obs_pose.append(c_)
+            obs_point.append(made)
+            obs_uvr.append((uu, vv, ur))
+            obs_oct.append(octv)
+        made += 1
+
+    # perturbed initial estimate
+    pose_gt = np.zeros((num_kf, 12))
+    pose_init = np.zeros((num_kf, 12))
+    fixed = np.zeros(num_kf, np.uint8)
+    fixed[:num_fixed] = 1
+    for i in range(num_kf):
+        pose_gt[i].reshape(3, 4)[:, :3] = Rs[i]
+        pose_gt[i].reshape(3, 4)[:, 3] = ts[i]
+        if fixed[i]:
+            pose_init[i] = pose_gt[i]
+            continue
+        dw = rng.normal(0, 1, 3)
+        dw *= np.deg2rad(pose_noise[1]) / np.linalg.norm(dw)
+        dR = _rodrigues(dw)
+        c = -Rs[i].T @ ts[i] + rng.normal(0, pose_noise[0] / np.sqrt(3), 3)
+        Rn = dR @ Rs[i]
+        pose_init[i].reshape(3, 4)[:, :3] = Rn
+        pose_init[i].reshape(3, 4)[:, 3] = -Rn @ c
+    pts_init = pts + rng.normal(0, point_noise / np.sqrt(3), pts.shape)
+
+    obs_oct = np.array(obs_oct)
+    inv_sigma_sq = np.ones(len(obs_oct), np.float32)
+    s = np.float32(1.0)
+    table = [np.float32(1.0)]
+    for _ in range(1, num_levels):  # orb_params.cc:63-71 recurrence in fp32
+        s = np.float32(scale_factor) * s
+        table.append(np.float32(1.0) / (s * s))
+    inv_sigma_sq = np.array(table, np.float32)[obs_oct]
+    huber = np.full(len(obs_oct), np.sqrt(np.float32(7.81473 if stereo else 5.99146)), np.float32)
+    intr = np.tile(np.array([fx, fy, cx, cy, fxb]), (num_kf, 1))
+    return dict(
+        pose_cw=pose_init, pose_gt=pose_gt, pose_fixed=fixed, points=pts_init, points_gt=pts,
+        obs_pose=np.array(obs_pose, np.int32), obs_point=np.array(obs_point, np.int32),
+        obs_uvr=np.array(obs_uvr, np.float32), obs_inv_sigma_sq=inv_sigma_sq, obs_huber=huber, intr=intr,
+    )

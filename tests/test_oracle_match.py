@@ -1,0 +1,148 @@
+"""Pins the oracle's Hamming distance on the reference's known-answer tests and checks the matcher
+restatements against straightforward Python re-statements of the same loops."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+# ---- reference test/stella_vslam/match/base.cc:11-57
+@pytest.mark.parametrize("a,b,dist", [(0b01010101, 0b01010101, 0), (0b01010101, 0b10101010, 256), (0b01100110, 0b00111100, 128)])
+def test_hamming_known_answers(a, b, dist):
+    d1, d2 = np.full(32, a, np.uint8), np.full(32, b, np.uint8)
+    assert O.hamming(d1, d2) == dist
+    assert O.hamming(d1, d2, bits64=True) == dist
+
+
+def test_hamming_random_vs_popcount():
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    M = O.hamming_matrix(a, b)
+    ref = np.unpackbits(b[:, None, :] ^ a[None, :, :], axis=2).sum(2)
+    assert np.array_equal(M, ref)
+
+
+def test_angle_diff():
+    assert O.angle_diff(10, 350) == 20
+    assert O.angle_diff(350, 10) == -20
+    assert O.angle_diff(180, 0) == 180
+    assert O.angle_diff(0, 180) == 180  # -180 <= -180 -> +360
+
+
+def _descs(rng, n, base=None, flips=0):
+    if base is None:
+        return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    out = base.copy()
+    for i in range(len(out)):
+        bits = rng.choice(256, rng.integers(0, flips + 1), replace=False)
+        for b in bits:
+            out[i, b // 8] ^= 1 << (b % 8)
+    return out
+
+
+def py_brute_force(d1, a1, d2, a2, valid2, ratio, check):
+    n1 = len(d1)
+    out = np.full(n1, -1, np.int32)
+    taken = set()
+    D = np.unpackbits(d2[:, None, :] ^ d1[None, :, :], axis=2).sum(2)
+    for j in range(len(d2)):
+        if not valid2[j]:
+            continue
+        best, second, bi = 256, 256, -1
+        for i in range(n1):
+            if i in taken:
+                continue
+            if check and abs(O.angle_diff(float(a1[i]), float(a2[j]))) > 30.0:
+                continue
+            d = int(D[j, i])
+            if d < best:
+                second, best, bi = best, d, i
+            elif d < second:
+                second = d
+        if best > 50 or bi < 0:
+            continue
+        if np.float32(ratio) * np.float32(second) < np.float32(best):
+            continue
+        out[bi] = j
+        taken.add(bi)
+    return out
+
+
+@pytest.mark.parametrize("seed,check", [(0, True), (1, False), (2, True)])
+def test_brute_force_match_vs_python(seed, check):
+    rng = np.random.default_rng(seed)
+    n1, n2 = 150, 130
+    d1 = _descs(rng, n1)
+    # d2 = noisy copies of some d1 rows (with deliberate duplicates to exercise the greedy bookkeeping)
+    src = rng.integers(0, n1 // 2, n2)
+    d2 = _descs(rng, n2, d1[src], flips=40)
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    a2 = (a1[src] + rng.normal(0, 15, n2)).astype(np.float32) % np.float32(360)
+    valid2 = (rng.uniform(size=n2) < 0.8).astype(np.uint8)
+    got = O.brute_force_match(d1, a1, d2, a2, valid2, 0.75, check)
+    exp = py_brute_force(d1, a1, d2, a2, valid2, 0.75, check)
+    assert (got >= 0).sum() > 10
+    assert np.array_equal(got, exp)
+
+
+def test_grid_and_candidates():
+    rng = np.random.default_rng(3)
+    n = 500
+    kx = rng.uniform(0, 640, n).astype(np.float32)
+    ky = rng.uniform(0, 480, n).astype(np.float32)
+    octv = rng.integers(0, 8, n).astype(np.int32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    off, items = O.assign_keypoints_to_grid(kx, ky, bounds)
+    assert off[-1] == n and sorted(items.tolist()) == list(range(n))
+    for _ in range(50):
+        rx, ry = rng.uniform(-20, 660), rng.uniform(-20, 500)
+        m = float(rng.uniform(5, 60))
+        lo, hi = int(rng.integers(-1, 4)), int(rng.integers(3, 8))
+        got = O.get_keypoints_in_cell(kx, ky, octv, off, items, bounds, rx, ry, m, lo, hi)
+        sel = (np.abs(kx - np.float32(rx)) < np.float32(m)) & (np.abs(ky - np.float32(ry)) < np.float32(m)) & (octv <= hi)
+        if lo >= 0:
+            sel &= octv >= lo
+        assert sorted(got.tolist()) == np.flatnonzero(sel).tolist()
+
+
+def test_match_candidates_modes():
+    rng = np.random.default_rng(4)
+    nt, nq = 200, 120
+    td = _descs(rng, nt)
+    src = rng.integers(0, nt, nq)
+    qd = _descs(rng, nq, td[src], flips=60)
+    t_oct = rng.integers(0, 3, nt).astype(np.int32)
+    off = [0]
+    idx = []
+    for q in range(nq):
+        c = set(rng.integers(0, nt, rng.integers(0, 12)).tolist())
+        if rng.uniform() < 0.8:
+            c.add(int(src[q]))
+        c = list(c)
+        rng.shuffle(c)
+        idx += c
+        off.append(len(idx))
+    for mode in (O.MODE_BEST_ONLY, O.MODE_RATIO_SAME_OCTAVE):
+        got = O.match_candidates(qd, td, off, idx, t_octave=t_oct, thr=100, lowe_ratio=0.8, mode=mode)
+        occ = np.zeros(nt, bool)
+        exp = np.full(nq, -1, np.int32)
+        for q in range(nq):
+            best, second, bl, sl, bi = 256, 256, -1, -1, -1
+            for t in idx[off[q]:off[q + 1]]:
+                if occ[t]:
+                    continue
+                d = O.hamming(qd[q], td[t])
+                if d < best:
+                    second, sl = best, bl
+                    best, bl, bi = d, t_oct[t], t
+                elif d < second:
+                    second, sl = d, t_oct[t]
+            if off[q] == off[q + 1] or best > 100:
+                continue
+            if mode == O.MODE_RATIO_SAME_OCTAVE and bl == sl and np.float32(best) > np.float32(0.8) * np.float32(second):
+                continue
+            exp[q] = bi
+            occ[bi] = True
+        assert (got >= 0).sum() > 20
+        assert np.array_equal(got, exp)
