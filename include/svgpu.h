@@ -1,0 +1,216 @@
+/*
+ * svgpu.h -- C ABI of the MI355X-native stella_vslam hot path (ORB front end, Hamming matchers,
+ * local bundle adjustment).  Plain pointers and sizes only; no C++/torch/OpenCV types.
+ *
+ * The reference (stella-cv/stella_vslam v0.6.0) has no FFI layer: its boundary for this path is three
+ * C++ class surfaces.  Every entry point below names the reference interface it stands behind; the
+ * C++ adaptor classes in stella_vslam_amd/host/ (same names and signatures as the reference classes)
+ * flatten the object graph, call this ABI and write the results back.  INTEGRATION.md shows the
+ * binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns an svgpu_status (0 = OK); nothing throws, nothing aborts
+ *   - "host" pointers are ordinary CPU memory; "dev" pointers are HIP device memory on the context's GPU
+ *   - `stream` arguments are a hipStream_t passed as void* (NULL = the context's own stream)
+ *   - one svgpu_ctx per (device, caller thread): two extractor instances (stereo: system.cc:427-434)
+ *     use two contexts and run concurrently
+ *   - all device entry points are asynchronous on their stream unless stated otherwise
+ */
+#ifndef SVGPU_H
+#define SVGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVGPU_ABI_VERSION 1
+
+typedef enum svgpu_status {
+    SVGPU_OK = 0,
+    SVGPU_ERR_INVALID = 1,     /* bad argument */
+    SVGPU_ERR_HIP = 2,         /* a HIP runtime call failed; svgpu_last_error() has the text */
+    SVGPU_ERR_CAPACITY = 3,    /* an output did not fit; counts are still the true totals */
+    SVGPU_ERR_NOT_CONFIGURED = 4,
+    SVGPU_ERR_NO_DEVICE = 5,
+    SVGPU_ERR_NUMERIC = 6,     /* e.g. reduced camera system not positive definite at every damping */
+    SVGPU_STOPPED = 7          /* the caller's stop flag was set before any work was done */
+} svgpu_status;
+
+typedef struct svgpu_ctx svgpu_ctx;
+
+/* cv::KeyPoint layout (28 bytes): pt.x pt.y size angle response octave class_id */
+typedef struct svgpu_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} svgpu_keypoint;
+
+/* ------------------------------------------------------------------------------------------------ core */
+int svgpu_abi_version(void);
+int svgpu_device_count(void);
+int svgpu_create(int device, svgpu_ctx** out);
+void svgpu_destroy(svgpu_ctx* ctx);
+const char* svgpu_last_error(const svgpu_ctx* ctx);
+const char* svgpu_status_string(int status);
+int svgpu_synchronize(svgpu_ctx* ctx);
+void* svgpu_stream(svgpu_ctx* ctx); /* the context's hipStream_t */
+
+/* ------------------------------------------------------------------------------------------------ ORB front end
+ * Stands behind  stella_vslam::feature::orb_extractor  (feature/orb_extractor.h:46-71):
+ *   orb_extractor(const orb_params*, unsigned min_area, descriptor_type, mask_rects)   -> svgpu_orb_configure
+ *   void extract(in_image, in_image_mask, std::vector<cv::KeyPoint>&, out_descriptors) -> svgpu_orb_extract
+ *   public member image_pyramid_ (read by match::stereo, match/stereo.cc:20-114)       -> svgpu_orb_pyramid_download
+ * and behind orb_params' scale tables (feature/orb_params.cc:41-71)                    -> svgpu_orb_scale_tables
+ */
+
+/* orb_params::calc_* : four tables of num_levels floats, computed by the reference's fp32 recurrences. */
+int svgpu_orb_scale_tables(float scale_factor, int num_levels, float* scale_factors, float* inv_scale_factors,
+                           float* level_sigma_sq, float* inv_level_sigma_sq);
+
+/* Fix the image geometry and ORB parameters; (re)allocates device workspaces for up to max_batch frames
+ * per launch.  min_area is the constructor argument (system.cc:95 default 800); its integer square
+ * root is taken as in orb_extractor.cc:20. */
+int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, float scale_factor, int num_levels,
+                        int ini_fast_thr, int min_fast_thr, unsigned min_area);
+
+/* Upper bound on keypoints per frame for the configured geometry (= number of selection-grid cells). */
+int svgpu_orb_max_keypoints(const svgpu_ctx* ctx);
+/* Level geometry of the configured pyramid. */
+int svgpu_orb_level_size(const svgpu_ctx* ctx, int level, int* width, int* height);
+
+/* extract(): one frame, host in / host out, synchronous.
+ *   img        8UC1, `stride` bytes per row, configured width x height
+ *   mask       nullable 8UC1 of the same size (0 = masked), mask_stride bytes per row
+ *   kps/desc   caller-owned, room for `cap` keypoints / cap*32 bytes
+ *   n_out      number of keypoints (true total even when > cap -> SVGPU_ERR_CAPACITY)
+ *   level_counts  nullable, num_levels ints
+ * Output order = the reference's: level-major, selection-grid cell order within a level. */
+int svgpu_orb_extract(svgpu_ctx* ctx, const uint8_t* img, int stride, const uint8_t* mask, int mask_stride,
+                      svgpu_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* level_counts);
+
+/* Throughput path: `batch` frames already resident in HBM, results left in HBM, asynchronous.
+ *   imgs_dev       batch frames, frame b at imgs_dev + b*frame_stride, rows `row_stride` bytes apart
+ *   mask_dev       nullable; mask_frame_stride 0 = one mask shared by all frames
+ *   kps_dev        batch * cap records;  desc_dev  batch * cap * 32 bytes
+ *   counts_dev     batch * (1 + num_levels) int32: [total, per-level...]; total may exceed cap (then
+ *                  only the first cap keypoints were written) */
+int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int batch, size_t frame_stride,
+                                   int row_stride, const uint8_t* mask_dev, size_t mask_frame_stride,
+                                   int mask_row_stride, svgpu_keypoint* kps_dev, uint8_t* desc_dev, int cap,
+                                   int32_t* counts_dev, void* stream);
+
+/* image_pyramid_[level] of frame `frame` of the last extract call, copied to host (level 0 is the
+ * caller's own image and is not stored).  Synchronous. */
+int svgpu_orb_pyramid_download(svgpu_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
+/* Gaussian-blurred level (the image descriptors are sampled from); debugging / tests. */
+int svgpu_orb_blurred_download(svgpu_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
+
+/* ------------------------------------------------------------------------------------------------ matchers
+ * Stand behind  stella_vslam::match::*  (match/base.h:15-91 and the six matcher classes).
+ * The reference walks frame/keyframe/landmark objects; the adaptors flatten them to descriptor rows
+ * (N x 32 bytes), angles, octaves and CSR candidate lists in the reference's scan order.
+ * Every matcher resolves the reference's SEQUENTIAL greedy bookkeeping exactly (same result as the
+ * serial loops), see DESIGN.md "greedy replay".
+ */
+
+/* compute_descriptor_distance_32 (match/base.h:20-41) for n pairs of 32-byte rows; host in/out, synchronous. */
+int svgpu_hamming_distance(svgpu_ctx* ctx, const uint8_t* a, const uint8_t* b, int n, uint32_t* dist);
+
+/* Full n2 x n1 distance matrix (uint16) -- building block / diagnostics; host in/out, synchronous. */
+int svgpu_hamming_matrix(svgpu_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, uint16_t* out);
+
+/* robust::brute_force_match (match/robust.cc:232-328).
+ *   index 1 = frame side (scanned, claimed once), index 2 = keyframe side (outer loop in index order)
+ *   valid2      nullable; 0 = keyframe keypoint without a live landmark (skipped, :258-263)
+ *   matched_2_in_1[n1]  keyframe index matched to each frame keypoint or -1; returns count in *num_matches
+ * Host in/out, synchronous. */
+int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2,
+                           const float* angle2, const uint8_t* valid2, int n2, float lowe_ratio,
+                           int check_orientation, int32_t* matched_2_in_1, int* num_matches);
+
+/* Batched, device-resident brute force: `pairs` independent (frame, keyframe) problems.
+ *   desc1_dev   pairs * cap1 * 32 bytes, angle via the keypoint records (kps1_dev, pairs*cap1) written by
+ *               svgpu_orb_extract_batch_device; n1_dev[p*n_stride] = count of pair p; likewise side 2
+ *   valid2_dev  nullable (pairs * cap2)
+ *   matched_dev pairs * cap1 int32;  num_dev pairs int32
+ * Asynchronous on `stream`. */
+int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t* desc1_dev,
+                                        const svgpu_keypoint* kps1_dev, const int32_t* n1_dev, int cap1,
+                                        const uint8_t* desc2_dev, const svgpu_keypoint* kps2_dev,
+                                        const int32_t* n2_dev, int cap2, int n_stride, const uint8_t* valid2_dev,
+                                        float lowe_ratio, int check_orientation, int32_t* matched_dev,
+                                        int32_t* num_dev, void* stream);
+
+typedef enum svgpu_match_mode {
+    SVGPU_MATCH_BEST_ONLY = 0,        /* projection::match_current_and_last_frames (match/projection.cc:95-207) */
+    SVGPU_MATCH_RATIO_SAME_OCTAVE = 1 /* projection::match_frame_and_landmarks     (match/projection.cc:13-93)  */
+} svgpu_match_mode;
+
+/* Candidate-list matcher: query q scans targets cand_idx[cand_off[q] .. cand_off[q+1]) in order.
+ *   q_valid      nullable, 0 = query skipped
+ *   occupied     nullable nt, 1 = target already holds an observed landmark (projection.cc:52-55)
+ *   q_angle/t_angle + check_orientation : |angle::diff| > 30 gate (projection.cc:179-181)
+ *   q_xright/t_xright/q_xr_tol : nullable stereo gate (projection.cc:57-62)
+ *   thr, lowe_ratio, mode : acceptance rule
+ *   match_q[nq]  target index or -1.  Host in/out, synchronous. */
+int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int32_t* t_octave,
+                           int nt, const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* q_valid,
+                           const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
+                           const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
+                           float lowe_ratio, int mode, int32_t* match_q, int* num_matches);
+
+/* ------------------------------------------------------------------------------------------------ local BA
+ * Stands behind  stella_vslam::optimize::local_bundle_adjuster::optimize(map_db, curr_keyfrm, force_stop_flag)
+ * (optimize/local_bundle_adjuster.h:23; g2o implementation optimize/local_bundle_adjuster_g2o.cc:36-431).
+ * The adaptor performs steps 1 (gather) and 7-8 (outlier list, write-back under mtx_database_) on the
+ * host exactly as the g2o/gtsam backends do and hands steps 2-6 to this call.
+ */
+typedef struct svgpu_ba_problem {
+    int32_t num_poses;               /* local + fixed keyframes */
+    int32_t num_points;              /* local landmarks (+ marker corners) */
+    int32_t num_obs;                 /* reprojection edges */
+    const double* pose_cw;           /* num_poses x 12: rows of [R|t] (3x4, row-major), world -> camera */
+    const uint8_t* pose_fixed;       /* num_poses: 1 = fixed keyframe vertex */
+    const double* points;            /* num_points x 3 */
+    const uint8_t* point_fixed;      /* nullable num_points: 1 = fixed vertex (kept-fixed marker corners) */
+    const int32_t* obs_pose;         /* num_obs */
+    const int32_t* obs_point;        /* num_obs */
+    const float* obs_uvr;            /* num_obs x 3: undistorted u, v, u_right (< 0 => monocular edge) */
+    const float* obs_inv_sigma_sq;   /* num_obs: orb_params::inv_level_sigma_sq_[octave] */
+    const float* obs_huber_delta;    /* num_obs: sqrt(chi_sq) of the Huber kernel, <= 0 => no kernel */
+    const double* intrinsics;        /* num_poses x 5: fx fy cx cy focal_x_baseline */
+    int32_t num_first_iter;          /* 5  (local_bundle_adjuster_factory.h) */
+    int32_t num_second_iter;         /* 10 */
+    double gain_threshold;           /* terminate_action gain, 1e-3 */
+} svgpu_ba_problem;
+
+typedef struct svgpu_ba_stats {
+    double chi2_initial, chi2_final;
+    int32_t iters_stage1, iters_stage2, stage2_entered, num_gated;
+    int32_t lm_trials, cholesky_failures;
+    double lambda_final;
+} svgpu_ba_stats;
+
+/* Host in/out, synchronous.
+ *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled between LM iterations
+ *               and -- reference quirk, terminate_action.cc:36-76 -- SET when the gain rule stops stage 1, so
+ *               that stage 2 is skipped exactly as in the reference.
+ *   pose_out    num_poses x 12, points_out num_points x 3, outlier_out num_obs (1 = outlier observation) */
+int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
+                   double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
+
+/* Multi-GPU variant: every rank passes the FULL pose/point arrays but only ITS SHARD of the
+ * observations; `allreduce` is called once per linearisation with a device buffer that must be summed
+ * in place across ranks (the host side binds it to RCCL, see stella_vslam_amd/distributed.py).
+ * All ranks return identical poses/points; outlier_out covers the local shard only. */
+typedef int (*svgpu_allreduce_fn)(void* user, double* dev_buf, size_t count, void* stream);
+int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, svgpu_allreduce_fn allreduce,
+                           void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out,
+                           uint8_t* outlier_out, svgpu_ba_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGPU_H */

@@ -1,0 +1,527 @@
+// HIP kernels of the ORB front end for gfx950 (wave64).  One kernel per reference routine:
+//   k_resize    <- cv::resize INTER_LINEAR chain       (feature/orb_extractor.cc:153-162)
+//   k_blur      <- cv::GaussianBlur 7x7 sigma 2        (feature/orb_extractor.cc:103)
+//   k_fast      <- per-cell cv::FAST + NMS + retry + selection-grid arg-max
+//                                                      (feature/orb_extractor.cc:164-287, 289-329)
+//   k_select    <- emission of the selected keypoints in grid-cell order (:314-326)
+//   k_describe  <- ic_angle + compute_orb_descriptor + correct_keypoint_scale
+//                                                      (feature/orb_impl.cc:68-154, orb_extractor.cc:337-345)
+// All integer stages are bit-exact by construction; the fp32 stages replicate the reference's
+// operation order with contraction disabled (-ffp-contract=off, checked in the disassembly).
+#include "svgpu_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // orb_impl.cc:51-66
+__device__ __constant__ signed char c_pattern[1024] = {
+#include "orb_pattern_i8.inc"
+};
+
+// Which level does work item `idx` belong to?  `first` = per-level first index (non-decreasing);
+// linear scan over <= 16 levels, block-uniform.
+__device__ __forceinline__ int find_level(const OrbLevel* __restrict__ L, int num_levels, int idx, int OrbLevel::*first,
+                                          int* local) {
+    int lv = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        const int f = L[l].*first;
+        if (idx >= f) lv = l;
+    }
+    *local = idx - L[lv].*first;
+    return lv;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {  // cv::BORDER_REFLECT_101
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------ resize
+// OpenCV 8-bit bilinear: horizontal int32 with 11-bit coefficients, vertical
+// ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  Coefficient tables are built on the host.
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t src_frame_stride, int src_pitch,
+                                                int sw, uint8_t* __restrict__ dst, size_t dst_frame_stride, int dst_pitch,
+                                                int dw, int dh, const short* __restrict__ xofs,
+                                                const short2* __restrict__ xa, const short2* __restrict__ yofs,
+                                                const short2* __restrict__ yb) {
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (dy >= dh || dx0 >= dw) return;
+    const uint8_t* S = src + (size_t)blockIdx.z * src_frame_stride;
+    const short2 yo = yofs[dy];
+    const short2 bb = yb[dy];
+    const uint8_t* S0 = S + (size_t)yo.x * src_pitch;
+    const uint8_t* S1 = S + (size_t)yo.y * src_pitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dx = dx0 + i;
+        if (dx < dw) {
+            const int sx = xofs[dx];
+            const short2 a = xa[dx];
+            const int sx1 = min(sx + 1, sw - 1);
+            const int r0 = S0[sx] * a.x + S0[sx1] * a.y;
+            const int r1 = S1[sx] * a.x + S1[sx1] * a.y;
+            const int v = ((((int)bb.x * (r0 >> 4)) >> 16) + (((int)bb.y * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 255) << (8 * i);
+        }
+    }
+    uint8_t* D = dst + (size_t)blockIdx.z * dst_frame_stride + (size_t)dy * dst_pitch + dx0;
+    *reinterpret_cast<uint32_t*>(D) = packed;  // pitch is a multiple of 64: in-bounds and aligned
+}
+
+// ------------------------------------------------------------------------------------------------ blur
+// Fixed-point separable 7x7, taps {18,34,48,56,48,34,18}/256, out = (sum + 32768) >> 16, reflect-101.
+// Tile = 64 x 16 output pixels per 256-thread block, staged through LDS.
+#define BT_W 64
+#define BT_H 16
+__global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
+                                              size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
+                                              size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
+    __shared__ uint8_t s_in[(BT_H + 6) * 72];
+    __shared__ uint16_t s_h[(BT_H + 6) * BT_W];
+    int tile;
+    const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::btile_first, &tile);
+    const OrbLevel lev = L[lv];
+    const int b = blockIdx.y;
+    const uint8_t* src;
+    int spitch;
+    if (lv == 0) {
+        src = img0 + (size_t)b * img0_frame_stride;
+        spitch = img0_pitch;
+    }
+    else {
+        src = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
+        spitch = lev.pitch;
+    }
+    const int x0 = (tile % lev.btiles_x) * BT_W, y0 = (tile / lev.btiles_x) * BT_H;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (BT_H + 6) * 70; i += 256) {
+        const int r = i / 70, c = i - r * 70;
+        const int sy = reflect101(y0 + r - 3, lev.h), sx = reflect101(x0 + c - 3, lev.w);
+        s_in[r * 72 + c] = src[(size_t)sy * spitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &s_in[r * 72 + c];
+        s_h[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    }
+    __syncthreads();
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const int oy = y0 + r, ox = x0 + c4;
+    if (oy < lev.h && ox < lev.w) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint16_t* q = &s_h[r * BT_W + c4 + j];
+            const uint32_t acc = 18u * ((uint32_t)q[0] + q[6 * BT_W]) + 34u * ((uint32_t)q[BT_W] + q[5 * BT_W])
+                                 + 48u * ((uint32_t)q[2 * BT_W] + q[4 * BT_W]) + 56u * q[3 * BT_W];
+            packed |= ((acc + 32768u) >> 16) << (8 * j);
+        }
+        uint8_t* D = blur + (size_t)b * blur_frame_bytes + lev.blur_off + (size_t)oy * lev.pitch + ox;
+        *reinterpret_cast<uint32_t*>(D) = packed;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ FAST
+// Arc score A(p) = max over the 16 arcs of 9 contiguous ring pixels of min(|v - p_k|) with consistent sign.
+// cv::FAST: p is a corner at threshold t  <=>  A(p) > t, and cornerScore = A(p) - 1
+// (closed form of fast.cpp / fast_score.cpp; proven equal to the literal row-buffer algorithm by
+// tests/test_oracle_orb.py::test_fast_matches_closed_form_definition).
+__device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = v - p[k];
+    int mn[16], mx[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn[k] = min(d[k], d[(k + 1) & 15]);
+        mx[k] = max(d[k], d[(k + 1) & 15]);
+    }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn4[k] = min(mn[k], mn[(k + 2) & 15]);
+        mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+    }
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int m8 = min(mn4[k], mn4[(k + 4) & 15]);
+        const int M8 = max(mx4[k], mx4[(k + 4) & 15]);
+        const int m9 = min(m8, d[(k + 8) & 15]);   // min over the arc k..k+8 of (v - p): centre brighter
+        const int M9 = max(M8, d[(k + 8) & 15]);   // max over the arc: -M9 = min of (p - v): centre darker
+        best = max(best, max(m9, -M9));
+    }
+    return best;
+}
+
+__device__ __forceinline__ bool run_of_9(uint32_t m16) {
+    uint32_t m = m16 | (m16 << 16);
+    uint32_t r = m & (m >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= m >> 8;
+    return (r & 0xFFFFu) != 0;
+}
+
+#define FP 72  // LDS pitch of the ROI arrays
+__global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells,
+                                              const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
+                                              const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                              const unsigned short* __restrict__ gtab, unsigned long long* __restrict__ keys,
+                                              int total_grid, int ini_thr, int min_thr, const uint8_t* __restrict__ mask,
+                                              size_t mask_frame_stride, int mask_pitch, int mask_w, int mask_h) {
+    __shared__ uint8_t s_img[SV_ROI_MAX * FP];
+    __shared__ uint8_t s_a[SV_ROI_MAX * FP];
+    __shared__ int s_count;
+    int local;
+    const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::cell_first, &local);
+    const OrbLevel lev = L[lv];
+    const FastCell cell = cells[blockIdx.x];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const uint8_t* M = mask ? mask + (size_t)b * mask_frame_stride : nullptr;
+    auto masked = [&](int y, int x) -> bool {  // is_in_mask (orb_extractor.cc:168-170): (int)(y * scale), (int)(x * scale)
+        int my = (int)((float)y * lev.scale), mx = (int)((float)x * lev.scale);
+        my = min(my, mask_h - 1);
+        mx = min(mx, mask_w - 1);
+        return M[(size_t)my * mask_pitch + mx] == 0;
+    };
+    if (M) {  // skip the cell if one of its corners is masked (:219-225)
+        const int y0 = cell.min_y, y1 = cell.min_y + cell.h, x0 = cell.min_x, x1 = cell.min_x + cell.w;
+        if (masked(y0, x0) || masked(y1, x0) || masked(y0, x1) || masked(y1, x1)) return;
+    }
+    const uint8_t* src;
+    int spitch;
+    if (lv == 0) {
+        src = img0 + (size_t)b * img0_frame_stride;
+        spitch = img0_pitch;
+    }
+    else {
+        src = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
+        spitch = lev.pitch;
+    }
+    src += (size_t)cell.min_y * spitch + cell.min_x;
+    const int w = cell.w, h = cell.h;
+    for (int i = tid; i < SV_ROI_MAX * FP; i += 256) {
+        const int r = i / FP, c = i - r * FP;
+        s_img[i] = (r < h && c < w) ? src[(size_t)r * spitch + c] : 0;
+        s_a[i] = 0;
+    }
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+
+    const int tq = min(ini_thr, min_thr);
+    const int lx = 3 + (tid & 63);
+    // --- arc scores for the scored band [3, w-3) x [3, h-3)
+    if (lx < w - 3) {
+        for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
+            const uint8_t* c = &s_img[ly * FP + lx];
+            const int v = c[0];
+            int p[16];
+            p[0] = c[3 * FP];
+            p[1] = c[3 * FP + 1];
+            p[2] = c[2 * FP + 2];
+            p[3] = c[FP + 3];
+            p[4] = c[3];
+            p[5] = c[-FP + 3];
+            p[6] = c[-2 * FP + 2];
+            p[7] = c[-3 * FP + 1];
+            p[8] = c[-3 * FP];
+            p[9] = c[-3 * FP - 1];
+            p[10] = c[-2 * FP - 2];
+            p[11] = c[-FP - 3];
+            p[12] = c[-3];
+            p[13] = c[FP - 3];
+            p[14] = c[2 * FP - 2];
+            p[15] = c[3 * FP - 1];
+            uint32_t bright = 0, dark = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                bright |= (uint32_t)(p[k] > v + tq) << k;
+                dark |= (uint32_t)(p[k] < v - tq) << k;
+            }
+            if (run_of_9(bright) || run_of_9(dark)) s_a[ly * FP + lx] = (uint8_t)arc_score16(v, p);
+        }
+    }
+    __syncthreads();
+
+    // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
+    const int gx_off = lev.gtab_x_off, gy_off = lev.gtab_y_off;
+    unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int t = pass == 0 ? ini_thr : min_thr;
+        int found = 0;
+        if (lx < w - 3) {
+            for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
+                const uint8_t* a = &s_a[ly * FP + lx];
+                const int A = a[0];
+                if (A <= t) continue;
+                const int s = A - 1;
+                bool keep = true;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int n = a[dy * FP + dx];
+                        const int sn = n > t ? n - 1 : 0;
+                        keep = keep && (s > sn);
+                    }
+                if (!keep) continue;
+                ++found;
+                const int x_level = cell.min_x + lx, y_level = cell.min_y + ly;
+                if (M && masked(y_level, x_level)) continue;  // keypoint filter (:246-256), after the retry decision
+                const int gx = gtab[gx_off + x_level - SV_PATCH_RADIUS], gy = gtab[gy_off + y_level - SV_PATCH_RADIUS];
+                const uint32_t order = (uint32_t)cell.order_base | ((uint32_t)ly << 7) | (uint32_t)lx;
+                const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (0xFFFFFFFFu - order);
+                atomicMax(&K[gy * lev.grid_x + gx], key);
+            }
+        }
+        if (found) atomicAdd(&s_count, found);
+        __syncthreads();
+        if (s_count > 0) break;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ select
+// One block per frame: walk the selection grids level by level in cell-index order, compact the
+// non-empty cells (this IS the output order of distribute_keypoints + extract), clear the keys.
+__global__ __launch_bounds__(256) void k_select(const OrbLevel* __restrict__ L, int num_levels, unsigned long long* __restrict__ keys,
+                                                int total_grid, int4* __restrict__ sel, int32_t* __restrict__ counts) {
+    __shared__ int s_wave[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* K = keys + (size_t)b * total_grid;
+    int4* S = sel + (size_t)b * total_grid;
+    int running = 0;
+    for (int lv = 0; lv < num_levels; ++lv) {
+        const OrbLevel lev = L[lv];
+        const int n = lev.grid_x * lev.grid_y;
+        const int level_start = running;
+        for (int base = 0; base < n; base += 256) {
+            const int idx = base + tid;
+            unsigned long long key = 0;
+            if (idx < n) {
+                key = K[lev.grid_first + idx];
+                if (key) K[lev.grid_first + idx] = 0;
+            }
+            const unsigned long long bal = __ballot(key != 0);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < wave) woff += s_wave[k];
+                total += s_wave[k];
+            }
+            if (key) {
+                const uint32_t order = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+                const int lx = order & 127, ly = (order >> 7) & 127, cid = order >> 14;
+                const int cells_x = lev.cells_x;
+                const int ci = cid / cells_x, cj = cid - ci * cells_x;
+                int4 r;
+                r.x = SV_PATCH_RADIUS + cj * SV_CELL + lx;
+                r.y = SV_PATCH_RADIUS + ci * SV_CELL + ly;
+                r.z = lv;
+                r.w = (int)(key >> 32);
+                S[running + woff + before] = r;
+            }
+            running += total;
+            __syncthreads();
+        }
+        if (tid == 0) counts[b * (1 + num_levels) + 1 + lv] = running - level_start;
+    }
+    if (tid == 0) counts[b * (1 + num_levels)] = running;
+}
+
+// ------------------------------------------------------------------------------------------------ describe
+__device__ __forceinline__ float dev_fast_atan2(float y, float x) {  // cv::fastAtan2 (atan_f32), degrees
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ float dev_cos_poly(float v) {  // util/trigonometric.h:17-24
+    const float c1 = 0.99940307f, c2 = -0.49558072f, c3 = 0.03679168f;
+    const float v2 = v * v;
+    return c1 + v2 * (c2 + c3 * v2);
+}
+__device__ __forceinline__ float dev_util_cos(float v) {  // util/trigonometric.h:26-42
+    constexpr float PI_ = 3.14159265358979f;
+    constexpr float PI_2 = PI_ / 2.0f;
+    constexpr float TWO_PI = 2.0f * PI_;
+    constexpr float INV_TWO_PI = 1.0f / TWO_PI;
+    constexpr float THREE_PI_2 = 3.0f * PI_2;
+    v = v - (float)(int)floorf(v * INV_TWO_PI) * TWO_PI;
+    v = (0.0f < v) ? v : -v;
+    if (v < PI_2) return dev_cos_poly(v);
+    else if (v < PI_) return -dev_cos_poly(PI_ - v);
+    else if (v < THREE_PI_2) return -dev_cos_poly(v - PI_);
+    else return dev_cos_poly(TWO_PI - v);
+}
+__device__ __forceinline__ float dev_util_sin(float v) {
+    constexpr float PI_2 = 3.14159265358979f / 2.0f;
+    return dev_util_cos(PI_2 - v);
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one wave per keypoint, 4 keypoints per block
+__global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L, int num_levels, const int4* __restrict__ sel,
+                                                  int total_grid, const int32_t* __restrict__ counts,
+                                                  const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
+                                                  const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                  const uint8_t* __restrict__ blur, size_t blur_frame_bytes,
+                                                  svgpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = counts[b * (1 + num_levels)];
+    if (i >= n || i >= cap) return;
+    const int4 s = sel[(size_t)b * total_grid + i];
+    const int x = s.x, y = s.y, lv = s.z;
+    const OrbLevel lev = L[lv];
+    const uint8_t* I;
+    int ipitch;
+    if (lv == 0) {
+        I = img0 + (size_t)b * img0_frame_stride;
+        ipitch = img0_pitch;
+    }
+    else {
+        I = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
+        ipitch = lev.pitch;
+    }
+    // ---- intensity centroid on the un-blurred level (orb_impl.cc:68-91); lanes = columns, two row halves
+    int m10 = 0, m01 = 0;
+    {
+        const int ul = lane & 31, u = ul - 15, au = u < 0 ? -u : u;
+        if (ul < 31) {
+            const uint8_t* c = I + (size_t)y * ipitch + x + u;
+            if (lane < 32) {
+                for (int v = 0; v <= 15; ++v)
+                    if (au <= c_umax[v]) {
+                        const int val = c[-(ptrdiff_t)v * ipitch];
+                        m10 += u * val;
+                        m01 -= v * val;
+                    }
+            }
+            else {
+                for (int v = 1; v <= 15; ++v)
+                    if (au <= c_umax[v]) {
+                        const int val = c[(ptrdiff_t)v * ipitch];
+                        m10 += u * val;
+                        m01 += v * val;
+                    }
+            }
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = dev_fast_atan2((float)m01, (float)m10);
+
+    // ---- rotated BRIEF on the blurred level (orb_impl.cc:93-154)
+    const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
+    const float ca = dev_util_cos(rad), sa = dev_util_sin(rad);
+    const uint8_t* B = blur + (size_t)b * blur_frame_bytes + lev.blur_off + (size_t)y * lev.pitch + x;
+    const int bp = lev.pitch;
+    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pair = r * 64 + lane;
+        const char4 q = reinterpret_cast<const char4*>(c_pattern)[pair];
+        const float x0 = (float)q.x, y0 = (float)q.y, x1 = (float)q.z, y1 = (float)q.w;
+        const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
+        const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
+        const int a = B[(ptrdiff_t)r0 * bp + c0];
+        const int bb = B[(ptrdiff_t)r1 * bp + c1];
+        bits[r] = __ballot(a < bb);
+    }
+    uint8_t* D = desc + ((size_t)b * cap + i) * 32;
+    if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+    if (lane == 0) {
+        svgpu_keypoint k;
+        k.x = (float)x;
+        k.y = (float)y;
+        if (lv != 0) {  // correct_keypoint_scale (orb_extractor.cc:337-345)
+            k.x = k.x * lev.scale;
+            k.y = k.y * lev.scale;
+        }
+        k.size = lev.kp_size;
+        k.angle = angle;
+        k.response = (float)s.w;
+        k.octave = lv;
+        k.class_id = -1;
+        kps[(size_t)b * cap + i] = k;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ launchers
+void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride, int src_pitch, int sw, int sh,
+                      uint8_t* dst, size_t dst_frame_stride, int dst_pitch, int dw, int dh, const short* xofs,
+                      const short2* xa, const short2* yofs, const short2* yb, int batch) {
+    (void)sh;
+    dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, batch);
+    hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, src_frame_stride, src_pitch, sw, dst, dst_frame_stride, dst_pitch, dw,
+                       dh, xofs, xa, yofs, yb);
+}
+
+void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
+                    size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
+                    size_t blur_frame_bytes, int batch) {
+    hipLaunchKernelGGL(k_blur, dim3(total_tiles, batch), dim3(256), 0, s, levels, num_levels, img0, img0_frame_stride,
+                       img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+}
+
+void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const FastCell* cells, int num_cells,
+                    const uint8_t* img0, size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr,
+                    size_t pyr_frame_bytes, const unsigned short* gtab, unsigned long long* keys, int total_grid,
+                    int ini_thr, int min_thr, const uint8_t* mask, size_t mask_frame_stride, int mask_pitch, int mask_w,
+                    int mask_h, int batch) {
+    if (num_cells == 0) return;
+    hipLaunchKernelGGL(k_fast, dim3(num_cells, batch), dim3(256), 0, s, levels, num_levels, cells, img0, img0_frame_stride,
+                       img0_pitch, pyr, pyr_frame_bytes, gtab, keys, total_grid, ini_thr, min_thr, mask, mask_frame_stride,
+                       mask_pitch, mask_w, mask_h);
+}
+
+void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,
+                      int4* sel, int32_t* counts, int batch) {
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(256), 0, s, levels, num_levels, keys, total_grid, sel, counts);
+}
+
+void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
+                        const int32_t* counts, const uint8_t* img0, size_t img0_frame_stride, int img0_pitch,
+                        const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur, size_t blur_frame_bytes,
+                        svgpu_keypoint* kps, uint8_t* desc, int cap, int batch) {
+    if (total_grid == 0) return;
+    hipLaunchKernelGGL(k_describe, dim3((total_grid + 3) / 4, batch), dim3(256), 0, s, levels, num_levels, sel, total_grid,
+                       counts, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, kps, desc, cap);
+}

@@ -1,0 +1,92 @@
+// Context lifetime, error reporting, scratch management.
+#include "svgpu_internal.h"
+
+int sv_set_error(svgpu_ctx* ctx, int status, const char* what, hipError_t e) {
+    if (ctx) {
+        ctx->last_error = what ? what : "";
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return status;
+}
+
+int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return SVGPU_OK;
+    if (ctx->d_scratch) {
+        SV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SV_HIP(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    SV_HIP(ctx, hipMalloc(&ctx->d_scratch, want));
+    ctx->scratch_bytes = want;
+    return SVGPU_OK;
+}
+
+extern "C" {
+
+int svgpu_abi_version(void) { return SVGPU_ABI_VERSION; }
+
+int svgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int svgpu_create(int device, svgpu_ctx** out) {
+    if (!out) return SVGPU_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return SVGPU_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return SVGPU_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return SVGPU_ERR_HIP;
+    svgpu_ctx* ctx = new (std::nothrow) svgpu_ctx();
+    if (!ctx) return SVGPU_ERR_INVALID;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return SVGPU_ERR_HIP;
+    }
+    *out = ctx;
+    return SVGPU_OK;
+}
+
+void svgpu_destroy(svgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    sv_orb_release(ctx);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* svgpu_last_error(const svgpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+const char* svgpu_status_string(int status) {
+    switch (status) {
+        case SVGPU_OK: return "ok";
+        case SVGPU_ERR_INVALID: return "invalid argument";
+        case SVGPU_ERR_HIP: return "HIP runtime error";
+        case SVGPU_ERR_CAPACITY: return "output capacity exceeded";
+        case SVGPU_ERR_NOT_CONFIGURED: return "not configured";
+        case SVGPU_ERR_NO_DEVICE: return "no HIP device";
+        case SVGPU_ERR_NUMERIC: return "numerical failure";
+        case SVGPU_STOPPED: return "stopped by caller";
+        default: return "unknown status";
+    }
+}
+
+int svgpu_synchronize(svgpu_ctx* ctx) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SVGPU_OK;
+}
+
+void* svgpu_stream(svgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+}  // extern "C"

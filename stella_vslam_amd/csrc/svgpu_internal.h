@@ -1,0 +1,116 @@
+// Internal declarations shared by the svgpu translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "svgpu.h"
+
+#define SV_MAX_LEVELS 16
+#define SV_PATCH_RADIUS 19  // orb_extractor.h:107 orb_patch_radius_
+#define SV_CELL 64          // orb_extractor.cc:173 cell_size
+#define SV_OVERLAP 6        // orb_extractor.cc:172 overlap
+#define SV_ROI_MAX 70       // SV_CELL + SV_OVERLAP
+
+// ---- per-level geometry, read by every ORB kernel (lives in device memory, one array per context)
+struct OrbLevel {
+    int w, h;               // level size in pixels
+    int pitch;              // row pitch (bytes) of the stored pyramid / blurred level
+    int has_cells;          // 0 if the level is too small for a 19-px border
+    long long pyr_off;      // byte offset of this level inside one frame's pyramid block (levels >= 1)
+    long long blur_off;     // byte offset inside one frame's blurred block (all levels)
+    int xtab_off, ytab_off; // resize coefficient tables (level produced from level-1)
+    int cell_first, cell_count;     // FAST cells of this level in the cell table
+    int cells_x;                    // num_cols of the FAST cell lattice (orb_extractor.cc:186)
+    int grid_x, grid_y, grid_first; // selection grid (distribute_keypoints) and its offset in the key array
+    int gtab_x_off, gtab_y_off;     // region coordinate -> grid index lookup tables
+    int btile_first, btiles_x, btiles_y;  // blur tiles
+    float scale;            // scale_factors_[level]
+    float kp_size;          // (float)(unsigned)(31 * scale)
+};
+
+struct FastCell {
+    short min_x, min_y;  // ROI origin in level coordinates
+    short w, h;          // ROI size (<= 70)
+    short ci, cj;        // cell row / column (i, j in orb_extractor.cc:199-217)
+    int order_base;      // (ci * num_cols + cj) << 14 : emission order prefix
+};
+
+struct OrbConfig {
+    int width = 0, height = 0, max_batch = 0, num_levels = 0;
+    float scale_factor = 0;
+    int ini_thr = 0, min_thr = 0;
+    unsigned min_area_sqrt = 0;
+    float scale_factors[SV_MAX_LEVELS];
+    OrbLevel levels[SV_MAX_LEVELS];
+    std::vector<FastCell> cells;
+    int total_grid = 0;    // sum of grid cells over levels = max keypoints per frame
+    int total_btiles = 0;
+    size_t pyr_frame_bytes = 0, blur_frame_bytes = 0;
+    bool configured = false;
+};
+
+struct svgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    OrbConfig orb;
+    // device resources of the ORB path
+    OrbLevel* d_levels = nullptr;
+    FastCell* d_cells = nullptr;
+    short* d_xofs = nullptr;        // per level >= 1: source column
+    short2* d_xa = nullptr;         // (a0, a1) 11-bit coefficients
+    short2* d_yofs = nullptr;       // (row0, row1) clamped
+    short2* d_yb = nullptr;         // (b0, b1)
+    unsigned short* d_gtab = nullptr;
+    uint8_t* d_pyr = nullptr;       // max_batch * pyr_frame_bytes
+    uint8_t* d_blur = nullptr;      // max_batch * blur_frame_bytes
+    unsigned long long* d_keys = nullptr;  // max_batch * total_grid
+    int4* d_sel = nullptr;          // max_batch * total_grid  (x, y, level, response)
+    // staging for the host-buffer entry points
+    uint8_t* d_img = nullptr;
+    uint8_t* d_mask = nullptr;
+    svgpu_keypoint* d_kps = nullptr;
+    uint8_t* d_desc = nullptr;
+    int32_t* d_counts = nullptr;
+    int last_batch = 0;
+    const uint8_t* last_imgs = nullptr;  // level-0 of the last call (device)
+    size_t last_frame_stride = 0;
+    int last_row_stride = 0;
+    // generic scratch (matchers, BA)
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+int sv_set_error(svgpu_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
+int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes);
+void sv_orb_release(svgpu_ctx* ctx);
+
+#define SV_HIP(ctx, call)                                                   \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return sv_set_error((ctx), SVGPU_ERR_HIP, #call, _e); \
+    } while (0)
+
+// ---- kernel launchers (orb_kernels.hip)
+void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride, int src_pitch, int sw, int sh,
+                      uint8_t* dst, size_t dst_frame_stride, int dst_pitch, int dw, int dh, const short* xofs,
+                      const short2* xa, const short2* yofs, const short2* yb, int batch);
+void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
+                    size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
+                    size_t blur_frame_bytes, int batch);
+void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const FastCell* cells, int num_cells,
+                    const uint8_t* img0, size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr,
+                    size_t pyr_frame_bytes, const unsigned short* gtab, unsigned long long* keys, int total_grid,
+                    int ini_thr, int min_thr, const uint8_t* mask, size_t mask_frame_stride, int mask_pitch, int mask_w,
+                    int mask_h, int batch);
+void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,
+                      int4* sel, int32_t* counts, int batch);
+void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
+                        const int32_t* counts, const uint8_t* img0, size_t img0_frame_stride, int img0_pitch,
+                        const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur, size_t blur_frame_bytes,
+                        svgpu_keypoint* kps, uint8_t* desc, int cap, int batch);

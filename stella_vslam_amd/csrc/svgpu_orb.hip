@@ -1,0 +1,380 @@
+// Host side of the ORB front end: geometry / coefficient tables (bit-identical to the reference's
+// host arithmetic), device workspace layout, launch sequence.
+//   orb_params scale tables        feature/orb_params.cc:41-71
+//   level sizes                    feature/orb_extractor.cc:157-159
+//   cv::resize coefficient tables  OpenCV 4.x imgproc/src/resize.cpp (see oracle/orb_oracle.c header)
+//   FAST cell lattice              feature/orb_extractor.cc:179-217
+//   selection grid                 feature/orb_extractor.cc:292-305
+#include <cmath>
+
+#include "svgpu_internal.h"
+
+#pragma clang fp contract(off)
+#pragma STDC FP_CONTRACT OFF
+
+namespace {
+
+inline int cv_floor_f(float v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+inline int cv_round_f(float v) { return (int)lrintf(v); }  // round half to even (default rounding mode)
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <class T>
+int upload(svgpu_ctx* ctx, T** dptr, const std::vector<T>& v) {
+    if (*dptr) {
+        SV_HIP(ctx, hipFree(*dptr));
+        *dptr = nullptr;
+    }
+    const size_t n = v.empty() ? 1 : v.size();
+    SV_HIP(ctx, hipMalloc((void**)dptr, n * sizeof(T)));
+    if (!v.empty()) SV_HIP(ctx, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SVGPU_OK;
+}
+
+template <class T>
+void free_dev(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace
+
+void sv_orb_release(svgpu_ctx* ctx) {
+    free_dev(ctx->d_levels);
+    free_dev(ctx->d_cells);
+    free_dev(ctx->d_xofs);
+    free_dev(ctx->d_xa);
+    free_dev(ctx->d_yofs);
+    free_dev(ctx->d_yb);
+    free_dev(ctx->d_gtab);
+    free_dev(ctx->d_pyr);
+    free_dev(ctx->d_blur);
+    free_dev(ctx->d_keys);
+    free_dev(ctx->d_sel);
+    free_dev(ctx->d_img);
+    free_dev(ctx->d_mask);
+    free_dev(ctx->d_kps);
+    free_dev(ctx->d_desc);
+    free_dev(ctx->d_counts);
+    ctx->orb.configured = false;
+}
+
+extern "C" {
+
+int svgpu_orb_scale_tables(float scale_factor, int num_levels, float* scale_factors, float* inv_scale_factors,
+                           float* level_sigma_sq, float* inv_level_sigma_sq) {
+    if (num_levels < 1) return SVGPU_ERR_INVALID;
+    // orb_params.cc:41-71 -- four independent fp32 recurrences
+    float s = 1.0f, inv = 1.0f;
+    for (int l = 0; l < num_levels; ++l) {
+        if (l > 0) {
+            s = scale_factor * s;
+            inv = (1.0f / scale_factor) * inv;
+        }
+        if (scale_factors) scale_factors[l] = s;
+        if (inv_scale_factors) inv_scale_factors[l] = inv;
+        if (level_sigma_sq) level_sigma_sq[l] = l == 0 ? 1.0f : s * s;
+        if (inv_level_sigma_sq) inv_level_sigma_sq[l] = l == 0 ? 1.0f : 1.0f / (s * s);
+    }
+    return SVGPU_OK;
+}
+
+int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, float scale_factor, int num_levels,
+                        int ini_fast_thr, int min_fast_thr, unsigned min_area) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    if (width < 8 || height < 8 || width > 16384 || height > 16384 || max_batch < 1 || num_levels < 1
+        || num_levels > SV_MAX_LEVELS || !(scale_factor > 1.0f))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_orb_configure: bad geometry/parameters");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    sv_orb_release(ctx);
+    OrbConfig& C = ctx->orb;
+    C = OrbConfig();
+    C.width = width;
+    C.height = height;
+    C.max_batch = max_batch;
+    C.num_levels = num_levels;
+    C.scale_factor = scale_factor;
+    C.ini_thr = ini_fast_thr < 0 ? 0 : (ini_fast_thr > 255 ? 255 : ini_fast_thr);  // cv::FAST clamps (fast.cpp)
+    C.min_thr = min_fast_thr < 0 ? 0 : (min_fast_thr > 255 ? 255 : min_fast_thr);
+    C.min_area_sqrt = (unsigned)std::sqrt((double)min_area);  // orb_extractor.cc:20 (unsigned member)
+    svgpu_orb_scale_tables(scale_factor, num_levels, C.scale_factors, nullptr, nullptr, nullptr);
+
+    std::vector<short> xofs;
+    std::vector<short2> xa, yofs, yb;
+    std::vector<unsigned short> gtab;
+    size_t pyr_off = 0, blur_off = 0;
+    int grid_first = 0, btile_first = 0;
+    for (int l = 0; l < num_levels; ++l) {
+        OrbLevel& L = C.levels[l];
+        memset(&L, 0, sizeof(L));
+        const float s = C.scale_factors[l];
+        if (l == 0) {
+            L.w = width;
+            L.h = height;
+        }
+        else {  // orb_extractor.cc:157-159
+            const double scale = (double)s;
+            L.w = (int)std::round(width * 1.0 / scale);
+            L.h = (int)std::round(height * 1.0 / scale);
+        }
+        if (L.w < 2 || L.h < 2) return sv_set_error(ctx, SVGPU_ERR_INVALID, "pyramid level smaller than 2 px");
+        L.pitch = (int)align_up(L.w, 64);
+        L.scale = s;
+        L.kp_size = (float)(unsigned)(31u * s);  // orb_extractor.cc:274
+        L.blur_off = (long long)blur_off;
+        blur_off += align_up((size_t)L.pitch * L.h, 256);
+        if (l > 0) {
+            L.pyr_off = (long long)pyr_off;
+            pyr_off += align_up((size_t)L.pitch * L.h, 256);
+            // ---- resize tables (level l from level l-1)
+            const OrbLevel& P = C.levels[l - 1];
+            const double inv_scale_x = (double)L.w / P.w, inv_scale_y = (double)L.h / P.h;
+            const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+            L.xtab_off = (int)xofs.size();
+            L.ytab_off = (int)yofs.size();
+            for (int dx = 0; dx < L.w; ++dx) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_f(fx);
+                fx -= sx;
+                if (sx < 0) {
+                    fx = 0;
+                    sx = 0;
+                }
+                if (sx >= P.w - 1) {
+                    fx = 0;
+                    sx = P.w - 1;
+                }
+                xofs.push_back((short)sx);
+                short2 a;
+                a.x = (short)cv_round_f((1.f - fx) * 2048);
+                a.y = (short)cv_round_f(fx * 2048);
+                xa.push_back(a);
+            }
+            for (int dy = 0; dy < L.h; ++dy) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor_f(fy);
+                fy -= sy;
+                short2 o, bb;
+                o.x = (short)(sy < 0 ? 0 : (sy > P.h - 1 ? P.h - 1 : sy));
+                o.y = (short)(sy + 1 < 0 ? 0 : (sy + 1 > P.h - 1 ? P.h - 1 : sy + 1));
+                bb.x = (short)cv_round_f((1.f - fy) * 2048);
+                bb.y = (short)cv_round_f(fy * 2048);
+                yofs.push_back(o);
+                yb.push_back(bb);
+            }
+        }
+        // ---- blur tiles
+        L.btile_first = btile_first;
+        L.btiles_x = (L.w + 63) / 64;
+        L.btiles_y = (L.h + 15) / 16;
+        btile_first += L.btiles_x * L.btiles_y;
+        // ---- FAST cell lattice and selection grid
+        L.cell_first = (int)C.cells.size();
+        L.grid_first = grid_first;
+        L.gtab_x_off = L.gtab_y_off = (int)gtab.size();
+        if (L.w > 2 * SV_PATCH_RADIUS && L.h > 2 * SV_PATCH_RADIUS) {
+            L.has_cells = 1;
+            const unsigned min_bx = SV_PATCH_RADIUS, min_by = SV_PATCH_RADIUS;
+            const unsigned max_bx = L.w - SV_PATCH_RADIUS, max_by = L.h - SV_PATCH_RADIUS;
+            const unsigned rw = max_bx - min_bx, rh = max_by - min_by;
+            const unsigned num_cols = rw / SV_CELL + 1, num_rows = rh / SV_CELL + 1;
+            L.cells_x = (int)num_cols;
+            for (unsigned i = 0; i < num_rows; ++i) {
+                const unsigned min_y = min_by + i * SV_CELL;
+                if (max_by - SV_OVERLAP <= min_y) continue;
+                unsigned max_y = min_y + SV_CELL + SV_OVERLAP;
+                if (max_by < max_y) max_y = max_by;
+                for (unsigned j = 0; j < num_cols; ++j) {
+                    const unsigned min_x = min_bx + j * SV_CELL;
+                    if (max_bx - SV_OVERLAP <= min_x) continue;
+                    unsigned max_x = min_x + SV_CELL + SV_OVERLAP;
+                    if (max_bx < max_x) max_x = max_bx;
+                    FastCell c;
+                    c.min_x = (short)min_x;
+                    c.min_y = (short)min_y;
+                    c.w = (short)(max_x - min_x);
+                    c.h = (short)(max_y - min_y);
+                    c.ci = (short)i;
+                    c.cj = (short)j;
+                    c.order_base = (int)((i * num_cols + j) << 14);
+                    C.cells.push_back(c);
+                }
+            }
+            // distribute_keypoints (:292-305)
+            const double scaled_min_area_sqrt = C.min_area_sqrt / s;  // fp32 division, widened
+            const unsigned gx = (unsigned)std::ceil((int)rw / scaled_min_area_sqrt);
+            const unsigned gy = (unsigned)std::ceil((int)rh / scaled_min_area_sqrt);
+            const double delta_x = (double)(int)rw / gx, delta_y = (double)(int)rh / gy;
+            L.grid_x = (int)gx;
+            L.grid_y = (int)gy;
+            L.gtab_x_off = (int)gtab.size();
+            for (unsigned x = 0; x < rw; ++x) {
+                unsigned ix = (unsigned)((float)x / delta_x);
+                gtab.push_back((unsigned short)(ix < gx ? ix : gx - 1));
+            }
+            L.gtab_y_off = (int)gtab.size();
+            for (unsigned y = 0; y < rh; ++y) {
+                unsigned iy = (unsigned)((float)y / delta_y);
+                gtab.push_back((unsigned short)(iy < gy ? iy : gy - 1));
+            }
+            grid_first += (int)(gx * gy);
+        }
+        L.cell_count = (int)C.cells.size() - L.cell_first;
+    }
+    C.total_grid = grid_first;
+    C.total_btiles = btile_first;
+    C.pyr_frame_bytes = pyr_off ? pyr_off : 256;
+    C.blur_frame_bytes = blur_off;
+
+    std::vector<OrbLevel> lv(C.levels, C.levels + num_levels);
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_levels, lv))) return rc;
+    if ((rc = upload(ctx, &ctx->d_cells, C.cells))) return rc;
+    if ((rc = upload(ctx, &ctx->d_xofs, xofs))) return rc;
+    if ((rc = upload(ctx, &ctx->d_xa, xa))) return rc;
+    if ((rc = upload(ctx, &ctx->d_yofs, yofs))) return rc;
+    if ((rc = upload(ctx, &ctx->d_yb, yb))) return rc;
+    if ((rc = upload(ctx, &ctx->d_gtab, gtab))) return rc;
+    const size_t B = (size_t)max_batch, G = (size_t)(C.total_grid > 0 ? C.total_grid : 1);
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, B * C.pyr_frame_bytes));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * C.blur_frame_bytes));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_keys, B * G * sizeof(unsigned long long)));
+    SV_HIP(ctx, hipMemset(ctx->d_keys, 0, B * G * sizeof(unsigned long long)));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_sel, B * G * sizeof(int4)));
+    // staging for the single-frame host entry point
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_img, (size_t)C.levels[0].pitch * height));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_mask, (size_t)C.levels[0].pitch * height));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_kps, G * sizeof(svgpu_keypoint)));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_desc, G * 32));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_counts, (1 + SV_MAX_LEVELS) * sizeof(int32_t)));
+    C.configured = true;
+    return SVGPU_OK;
+}
+
+int svgpu_orb_max_keypoints(const svgpu_ctx* ctx) { return (ctx && ctx->orb.configured) ? ctx->orb.total_grid : -1; }
+
+int svgpu_orb_level_size(const svgpu_ctx* ctx, int level, int* width, int* height) {
+    if (!ctx || !ctx->orb.configured) return SVGPU_ERR_NOT_CONFIGURED;
+    if (level < 0 || level >= ctx->orb.num_levels) return SVGPU_ERR_INVALID;
+    if (width) *width = ctx->orb.levels[level].w;
+    if (height) *height = ctx->orb.levels[level].h;
+    return SVGPU_OK;
+}
+
+int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int batch, size_t frame_stride,
+                                   int row_stride, const uint8_t* mask_dev, size_t mask_frame_stride,
+                                   int mask_row_stride, svgpu_keypoint* kps_dev, uint8_t* desc_dev, int cap,
+                                   int32_t* counts_dev, void* stream) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    OrbConfig& C = ctx->orb;
+    if (!C.configured) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_orb_configure has not been called");
+    if (!imgs_dev || !kps_dev || !desc_dev || !counts_dev || batch < 1 || batch > C.max_batch || cap < 1
+        || row_stride < C.width)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_orb_extract_batch_device: bad arguments");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int Lc = C.num_levels;
+    // 1. pyramid: chained bilinear resize (level l from level l-1)
+    for (int l = 1; l < Lc; ++l) {
+        const OrbLevel& D = C.levels[l];
+        const OrbLevel& P = C.levels[l - 1];
+        const uint8_t* src = l == 1 ? imgs_dev : ctx->d_pyr + P.pyr_off;
+        const size_t sfs = l == 1 ? frame_stride : C.pyr_frame_bytes;
+        const int sp = l == 1 ? row_stride : P.pitch;
+        sv_launch_resize(s, src, sfs, sp, P.w, P.h, ctx->d_pyr + D.pyr_off, C.pyr_frame_bytes, D.pitch, D.w, D.h,
+                         ctx->d_xofs + D.xtab_off, ctx->d_xa + D.xtab_off, ctx->d_yofs + D.ytab_off, ctx->d_yb + D.ytab_off,
+                         batch);
+    }
+    // 2. blurred copy of every level
+    sv_launch_blur(s, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
+                   ctx->d_blur, C.blur_frame_bytes, batch);
+    // 3. FAST per cell + selection-grid arg-max
+    sv_launch_fast(s, ctx->d_levels, Lc, ctx->d_cells, (int)C.cells.size(), imgs_dev, frame_stride, row_stride, ctx->d_pyr,
+                   C.pyr_frame_bytes, ctx->d_gtab, ctx->d_keys, C.total_grid, C.ini_thr, C.min_thr, mask_dev,
+                   mask_frame_stride, mask_row_stride, C.width, C.height, batch);
+    // 4. ordered compaction (+ key reset for the next call)
+    sv_launch_select(s, ctx->d_levels, Lc, ctx->d_keys, C.total_grid, ctx->d_sel, counts_dev, batch);
+    // 5. orientation, descriptor, scale correction
+    sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
+                       ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch);
+    SV_HIP(ctx, hipGetLastError());
+    ctx->last_batch = batch;
+    ctx->last_imgs = imgs_dev;
+    ctx->last_frame_stride = frame_stride;
+    ctx->last_row_stride = row_stride;
+    return SVGPU_OK;
+}
+
+int svgpu_orb_extract(svgpu_ctx* ctx, const uint8_t* img, int stride, const uint8_t* mask, int mask_stride,
+                      svgpu_keypoint* kps, uint8_t* desc, int cap, int* n_out, int* level_counts) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    OrbConfig& C = ctx->orb;
+    if (!C.configured) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_orb_configure has not been called");
+    if (!img || !n_out || stride < C.width || cap < 0 || (cap > 0 && (!kps || !desc)) || (mask && mask_stride < C.width))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_orb_extract: bad arguments");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int pitch = C.levels[0].pitch;
+    SV_HIP(ctx, hipMemcpy2DAsync(ctx->d_img, pitch, img, stride, C.width, C.height, hipMemcpyHostToDevice, s));
+    if (mask) SV_HIP(ctx, hipMemcpy2DAsync(ctx->d_mask, pitch, mask, mask_stride, C.width, C.height, hipMemcpyHostToDevice, s));
+    const int icap = C.total_grid > 0 ? C.total_grid : 1;
+    int rc = svgpu_orb_extract_batch_device(ctx, ctx->d_img, 1, (size_t)pitch * C.height, pitch, mask ? ctx->d_mask : nullptr, 0,
+                                            pitch, ctx->d_kps, ctx->d_desc, icap, ctx->d_counts, s);
+    if (rc) return rc;
+    int32_t counts[1 + SV_MAX_LEVELS];
+    SV_HIP(ctx, hipMemcpyAsync(counts, ctx->d_counts, (1 + C.num_levels) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    const int n = counts[0];
+    *n_out = n;
+    if (level_counts)
+        for (int l = 0; l < C.num_levels; ++l) level_counts[l] = counts[1 + l];
+    const int m = n < cap ? n : cap;
+    if (m > 0) {
+        SV_HIP(ctx, hipMemcpyAsync(kps, ctx->d_kps, (size_t)m * sizeof(svgpu_keypoint), hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipMemcpyAsync(desc, ctx->d_desc, (size_t)m * 32, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return n > cap ? sv_set_error(ctx, SVGPU_ERR_CAPACITY, "svgpu_orb_extract: more keypoints than cap") : SVGPU_OK;
+}
+
+static int download_level(svgpu_ctx* ctx, const uint8_t* base, size_t frame_bytes, long long off, int frame, int level,
+                          uint8_t* dst, int dst_stride) {
+    OrbConfig& C = ctx->orb;
+    const OrbLevel& L = C.levels[level];
+    if (!dst || dst_stride < L.w) return sv_set_error(ctx, SVGPU_ERR_INVALID, "download: bad destination");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SV_HIP(ctx, hipMemcpy2D(dst, dst_stride, base + (size_t)frame * frame_bytes + off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return SVGPU_OK;
+}
+
+int svgpu_orb_pyramid_download(svgpu_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    OrbConfig& C = ctx->orb;
+    if (!C.configured || ctx->last_batch == 0) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "no extract call yet");
+    if (frame < 0 || frame >= ctx->last_batch || level < 0 || level >= C.num_levels)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "pyramid_download: bad frame/level");
+    if (level == 0) {
+        if (!dst || dst_stride < C.width) return sv_set_error(ctx, SVGPU_ERR_INVALID, "download: bad destination");
+        SV_HIP(ctx, hipSetDevice(ctx->device));
+        SV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SV_HIP(ctx, hipMemcpy2D(dst, dst_stride, ctx->last_imgs + (size_t)frame * ctx->last_frame_stride, ctx->last_row_stride,
+                                C.width, C.height, hipMemcpyDeviceToHost));
+        return SVGPU_OK;
+    }
+    return download_level(ctx, ctx->d_pyr, C.pyr_frame_bytes, C.levels[level].pyr_off, frame, level, dst, dst_stride);
+}
+
+int svgpu_orb_blurred_download(svgpu_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    OrbConfig& C = ctx->orb;
+    if (!C.configured || ctx->last_batch == 0) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "no extract call yet");
+    if (frame < 0 || frame >= ctx->last_batch || level < 0 || level >= C.num_levels)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "blurred_download: bad frame/level");
+    return download_level(ctx, ctx->d_blur, C.blur_frame_bytes, C.levels[level].blur_off, frame, level, dst, dst_stride);
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""GPU parity: HIP ORB front end (through the C ABI) vs the CPU oracle -- bit-exact keypoints and descriptors."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stella_vslam_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    from stella_vslam_amd import feature
+    return feature
+
+
+def _assert_same(kg, dg, ko, do):
+    assert len(kg) == len(ko)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(kg[f], ko[f]), f
+    assert np.array_equal(dg, do)
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 0x5EED), (752, 480, 7), (1241, 376, 8), (320, 240, 9), (203, 157, 10)])
+def test_extract_bit_exact(F, w, h, seed):
+    img = S.frame(w, h, seed)
+    ext = F.orb_extractor(F.orb_params())
+    kg, dg = ext.extract(img)
+    ko, do, counts, pyr = O.orb_extract(img, want_pyramid=True)
+    assert len(ko) > 50
+    # intermediate stages first (sharper failure messages)
+    for l, (a, b) in enumerate(zip(ext.image_pyramid_, pyr)):
+        assert np.array_equal(a, b), f"pyramid level {l}"
+    for l, a in enumerate(ext.blurred_pyramid()):
+        assert np.array_equal(a, O.gaussian_blur7(pyr[l])), f"blurred level {l}"
+    assert np.array_equal(ext.level_counts_, counts)
+    _assert_same(kg, dg, ko, do)
+
+
+def test_extract_params_and_strided_input(F):
+    big = S.frame(700, 500, 3)
+    view = big[10:490, 30:670]  # non-contiguous rows (stride 700)
+    p = F.orb_params("t", 1.3, 6, 25, 9)
+    ext = F.orb_extractor(p, min_area=1000)
+    kg, dg = ext.extract(view)
+    ko, do, _ = O.orb_extract(np.ascontiguousarray(view), scale_factor=1.3, num_levels=6, ini_thr=25, min_thr=9, min_area=1000)
+    assert len(ko) > 50
+    _assert_same(kg, dg, ko, do)
+
+
+def test_extract_masks(F):
+    img = S.frame(960, 480, 21)
+    h, w = img.shape
+    mask = np.ones((h, w), np.uint8)
+    mask[0:h // 4] = 0
+    mask[3 * h // 4:h - 1] = 0
+    ext = F.orb_extractor(F.orb_params(), min_area=1000)
+    kg, dg = ext.extract(img, mask)
+    ko, do, _ = O.orb_extract(img, mask=mask, min_area=1000)
+    _assert_same(kg, dg, ko, do)
+    assert (kg["y"] >= h // 4).all() and (kg["y"] <= 3 * h // 4).all()
+    # rectangle mask (orb_extractor.cc:138-151)
+    ext2 = F.orb_extractor(F.orb_params(), min_area=1000, mask_rects=[[0.0, 0.25, 0.0, 1.0], [0.75, 1.0, 0.0, 1.0]])
+    kg2, dg2 = ext2.extract(img)
+    ko2, do2, _ = O.orb_extract(img, mask=ext2._rectangle_mask(w, h), min_area=1000)
+    _assert_same(kg2, dg2, ko2, do2)
+    assert len(kg2) > 0 and (kg2["x"] > 0.25 * w - 1).all() and (kg2["x"] < 0.75 * w + 1).all()
+
+
+def test_toy_rectangle_and_empty(F):
+    img = np.full((600, 600), 255, np.uint8)
+    img[300:, 300:] = 0
+    ext = F.orb_extractor(F.orb_params(), min_area=1000)
+    kg, dg = ext.extract(img)
+    ko, do, _ = O.orb_extract(img, min_area=1000)
+    _assert_same(kg, dg, ko, do)
+    sf = ext.orb_params_.scale_factors_
+    assert len(kg) > 0
+    assert (np.abs(kg["x"] - 300) <= 2.0 * sf[kg["octave"]]).all() and (np.abs(kg["y"] - 300) <= 2.0 * sf[kg["octave"]]).all()
+    k0, d0 = ext.extract(np.full((600, 600), 90, np.uint8))
+    assert len(k0) == 0 and d0.shape == (0, 32)
+    # reuse after an empty frame must still be exact (selection keys are reset in-kernel)
+    kg, dg = ext.extract(img)
+    _assert_same(kg, dg, ko, do)
+
+
+def test_repeatable_and_two_contexts(F):
+    img = S.frame(640, 480, 77)
+    e1 = F.orb_extractor(F.orb_params())
+    e2 = F.orb_extractor(F.orb_params())  # second context, as the stereo pair does (system.cc:427-434)
+    a = e1.extract(img)
+    b = e2.extract(img)
+    c = e1.extract(img)
+    _assert_same(a[0], a[1], b[0], b[1])
+    _assert_same(a[0], a[1], c[0], c[1])
