@@ -1,0 +1,54 @@
+// Kernel-argument structs of the matcher kernels (internal).
+#pragma once
+#include <cstdint>
+
+#define BF_K 16  // per-query candidate prefix kept by k_bf_topk
+
+struct BfProblem {
+    // side 1 = frame (scanned), side 2 = keyframe (queries); `pairs` independent problems, row p at p*cap
+    const uint32_t* desc1;
+    const uint32_t* desc2;
+    const float* angle1;  // element (p*cap1 + i) * angle_stride
+    const float* angle2;
+    int angle_stride;     // 1 for plain float arrays, 7 when pointing at svgpu_keypoint::angle
+    const int32_t* n1_dev;  // nullable: per-pair counts in device memory (index p * n_stride)
+    const int32_t* n2_dev;
+    int n_stride;
+    int n1, n2;           // used when the *_dev pointers are null
+    int cap1, cap2;
+    const uint8_t* valid2;  // nullable
+    float lowe_ratio;
+    int check_orientation;
+    uint32_t* topk;       // pairs * cap2 * BF_K
+    int32_t* cnt;         // pairs * cap2
+    int32_t* matched;     // pairs * cap1
+    int32_t* num;         // pairs
+};
+
+struct CandProblem {
+    const uint32_t* qdesc;
+    const uint32_t* tdesc;
+    const int32_t* t_octave;  // nullable
+    int nq, nt;
+    const int32_t* cand_off;
+    const int32_t* cand_idx;
+    const uint8_t* q_valid;   // nullable
+    const uint8_t* occupied;  // nullable
+    const float* q_angle;
+    const float* t_angle;
+    int check_orientation;
+    const float* q_xright;    // nullable trio
+    const float* t_xright;
+    const float* q_xr_tol;
+    unsigned thr;
+    float lowe_ratio;
+    int mode;
+    uint16_t* dist;           // one per CSR entry
+    int32_t* match_q;
+    int32_t* num;
+};
+
+void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out);
+void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const uint32_t* d2, int n2, uint16_t* out);
+void sv_launch_bf(hipStream_t s, const BfProblem& P, int pairs, int* g_owner, int* g_match);
+void sv_launch_cand(hipStream_t s, const CandProblem& P, int* owner, int* match);

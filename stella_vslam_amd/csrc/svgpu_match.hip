@@ -1,0 +1,245 @@
+// Host side of the matchers: staging of host buffers into the context's scratch arena, launches.
+#include "svgpu_internal.h"
+#include "match_kernels.h"
+
+namespace {
+
+// bump allocator over ctx->d_scratch (256-byte aligned pieces)
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(void* p) : base((char*)p) {}
+    template <class T>
+    T* take(size_t n) {
+        T* r = (T*)(base + off);
+        off += (n * sizeof(T) + 255) & ~size_t(255);
+        return r;
+    }
+};
+inline size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+}  // namespace
+
+extern "C" {
+
+int svgpu_hamming_distance(svgpu_ctx* ctx, const uint8_t* a, const uint8_t* b, int n, uint32_t* dist) {
+    if (!ctx || n < 0 || (n > 0 && (!a || !b || !dist))) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_hamming_distance");
+    if (n == 0) return SVGPU_OK;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nb = (size_t)n * 32;
+    int rc = sv_ensure_scratch(ctx, 2 * pad(nb) + pad((size_t)n * 4));
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    uint32_t* da = A.take<uint32_t>((size_t)n * 8);
+    uint32_t* db = A.take<uint32_t>((size_t)n * 8);
+    uint32_t* dd = A.take<uint32_t>(n);
+    hipStream_t s = ctx->stream;
+    SV_HIP(ctx, hipMemcpyAsync(da, a, nb, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(db, b, nb, hipMemcpyHostToDevice, s));
+    sv_launch_hamming_pairs(s, da, db, n, dd);
+    SV_HIP(ctx, hipMemcpyAsync(dist, dd, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    return SVGPU_OK;
+}
+
+int svgpu_hamming_matrix(svgpu_ctx* ctx, const uint8_t* desc1, int n1, const uint8_t* desc2, int n2, uint16_t* out) {
+    if (!ctx || n1 < 0 || n2 < 0) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_hamming_matrix");
+    if (n1 == 0 || n2 == 0) return SVGPU_OK;
+    if (!desc1 || !desc2 || !out) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_hamming_matrix: null pointer");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sv_ensure_scratch(ctx, pad((size_t)n1 * 32) + pad((size_t)n2 * 32) + pad((size_t)n1 * n2 * 2));
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    uint32_t* d1 = A.take<uint32_t>((size_t)n1 * 8);
+    uint32_t* d2 = A.take<uint32_t>((size_t)n2 * 8);
+    uint16_t* dm = A.take<uint16_t>((size_t)n1 * n2);
+    hipStream_t s = ctx->stream;
+    SV_HIP(ctx, hipMemcpyAsync(d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    sv_launch_hamming_matrix(s, d1, n1, d2, n2, dm);
+    SV_HIP(ctx, hipMemcpyAsync(out, dm, (size_t)n1 * n2 * 2, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    return SVGPU_OK;
+}
+
+int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t* desc1_dev,
+                                        const svgpu_keypoint* kps1_dev, const int32_t* n1_dev, int cap1,
+                                        const uint8_t* desc2_dev, const svgpu_keypoint* kps2_dev,
+                                        const int32_t* n2_dev, int cap2, int n_stride, const uint8_t* valid2_dev,
+                                        float lowe_ratio, int check_orientation, int32_t* matched_dev,
+                                        int32_t* num_dev, void* stream) {
+    if (!ctx || pairs < 1 || !desc1_dev || !kps1_dev || !n1_dev || !desc2_dev || !kps2_dev || !n2_dev || cap1 < 1 || cap2 < 1
+        || cap1 > 65535 || cap2 > 65535 || !matched_dev || !num_dev)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce_batch_device: bad arguments");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = pad((size_t)pairs * cap2 * BF_K * 4) + pad((size_t)pairs * cap2 * 4) + pad((size_t)pairs * cap1 * 4)
+                        + pad((size_t)pairs * cap2 * 4);
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    BfProblem P{};
+    P.desc1 = (const uint32_t*)desc1_dev;
+    P.desc2 = (const uint32_t*)desc2_dev;
+    P.angle1 = &kps1_dev->angle;
+    P.angle2 = &kps2_dev->angle;
+    P.angle_stride = sizeof(svgpu_keypoint) / sizeof(float);
+    P.n1_dev = n1_dev;
+    P.n2_dev = n2_dev;
+    P.n_stride = n_stride;
+    P.cap1 = cap1;
+    P.cap2 = cap2;
+    P.valid2 = valid2_dev;
+    P.lowe_ratio = lowe_ratio;
+    P.check_orientation = check_orientation;
+    P.topk = A.take<uint32_t>((size_t)pairs * cap2 * BF_K);
+    P.cnt = A.take<int32_t>((size_t)pairs * cap2);
+    int* g_owner = A.take<int>((size_t)pairs * cap1);
+    int* g_match = A.take<int>((size_t)pairs * cap2);
+    P.matched = matched_dev;
+    P.num = num_dev;
+    sv_launch_bf(stream ? (hipStream_t)stream : ctx->stream, P, pairs, g_owner, g_match);
+    SV_HIP(ctx, hipGetLastError());
+    return SVGPU_OK;
+}
+
+int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2,
+                           const float* angle2, const uint8_t* valid2, int n2, float lowe_ratio,
+                           int check_orientation, int32_t* matched_2_in_1, int* num_matches) {
+    if (!ctx || n1 < 0 || n2 < 0 || n1 > 65535 || n2 > 65535 || !num_matches)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce: bad sizes");
+    *num_matches = 0;
+    if (n1 > 0 && !matched_2_in_1) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce: null output");
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    if (n1 == 0 || n2 == 0) return SVGPU_OK;
+    if (!desc1 || !desc2 || (check_orientation && (!angle1 || !angle2)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce: null input");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = pad((size_t)n1 * 32) + pad((size_t)n2 * 32) + pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + pad(n2)
+                        + pad((size_t)n2 * BF_K * 4) + pad((size_t)n2 * 4) + 2 * pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + 256;
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    uint32_t* d1 = A.take<uint32_t>((size_t)n1 * 8);
+    uint32_t* d2 = A.take<uint32_t>((size_t)n2 * 8);
+    float* a1 = A.take<float>(n1);
+    float* a2 = A.take<float>(n2);
+    uint8_t* v2 = A.take<uint8_t>(n2);
+    BfProblem P{};
+    P.topk = A.take<uint32_t>((size_t)n2 * BF_K);
+    P.cnt = A.take<int32_t>(n2);
+    P.matched = A.take<int32_t>(n1);
+    int* g_owner = A.take<int>(n1);
+    int* g_match = A.take<int>(n2);
+    P.num = A.take<int32_t>(1);
+    hipStream_t s = ctx->stream;
+    SV_HIP(ctx, hipMemcpyAsync(d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    if (angle1) SV_HIP(ctx, hipMemcpyAsync(a1, angle1, (size_t)n1 * 4, hipMemcpyHostToDevice, s));
+    else SV_HIP(ctx, hipMemsetAsync(a1, 0, (size_t)n1 * 4, s));
+    if (angle2) SV_HIP(ctx, hipMemcpyAsync(a2, angle2, (size_t)n2 * 4, hipMemcpyHostToDevice, s));
+    else SV_HIP(ctx, hipMemsetAsync(a2, 0, (size_t)n2 * 4, s));
+    if (valid2) SV_HIP(ctx, hipMemcpyAsync(v2, valid2, n2, hipMemcpyHostToDevice, s));
+    P.desc1 = d1;
+    P.desc2 = d2;
+    P.angle1 = a1;
+    P.angle2 = a2;
+    P.angle_stride = 1;
+    P.n1 = n1;
+    P.n2 = n2;
+    P.cap1 = n1;
+    P.cap2 = n2;
+    P.valid2 = valid2 ? v2 : nullptr;
+    P.lowe_ratio = lowe_ratio;
+    P.check_orientation = check_orientation;
+    sv_launch_bf(s, P, 1, g_owner, g_match);
+    SV_HIP(ctx, hipGetLastError());
+    int32_t num = 0;
+    SV_HIP(ctx, hipMemcpyAsync(matched_2_in_1, P.matched, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    *num_matches = num;
+    return SVGPU_OK;
+}
+
+int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int32_t* t_octave,
+                           int nt, const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* q_valid,
+                           const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
+                           const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
+                           float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
+    if (!ctx || nq < 0 || nt < 0 || !num_matches || (mode != SVGPU_MATCH_BEST_ONLY && mode != SVGPU_MATCH_RATIO_SAME_OCTAVE))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_candidates: bad arguments");
+    *num_matches = 0;
+    if (nq == 0) return SVGPU_OK;
+    if (!match_q || !cand_off) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_candidates: null pointer");
+    for (int q = 0; q < nq; ++q) match_q[q] = -1;
+    const int nc = cand_off[nq];
+    if (nc == 0 || nt == 0) return SVGPU_OK;
+    if (!qdesc || !tdesc || !cand_idx || (check_orientation && (!q_angle || !t_angle))
+        || ((q_xright || t_xright || q_xr_tol) && !(q_xright && t_xright && q_xr_tol)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_candidates: inconsistent inputs");
+    for (int q = 0; q < nq; ++q)
+        if (cand_off[q + 1] < cand_off[q]) return sv_set_error(ctx, SVGPU_ERR_INVALID, "cand_off not monotone");
+    for (int c = 0; c < nc; ++c)
+        if (cand_idx[c] < 0 || cand_idx[c] >= nt) return sv_set_error(ctx, SVGPU_ERR_INVALID, "cand_idx out of range");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = pad((size_t)nq * 32) + pad((size_t)nt * 32) + 3 * pad((size_t)nt * 4) + pad(nt) + pad((size_t)(nq + 1) * 4)
+                        + pad((size_t)nc * 4) + pad(nq) + 3 * pad((size_t)nq * 4) + pad((size_t)nc * 2) + 2 * pad((size_t)nq * 4)
+                        + pad((size_t)nt * 4) + 512;
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    hipStream_t s = ctx->stream;
+    CandProblem P{};
+#define UP(dst, T, src, n)                                                                          \
+    T* dst = nullptr;                                                                               \
+    if (src) {                                                                                      \
+        dst = A.take<T>(n);                                                                         \
+        SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+    }
+    UP(d_q, uint8_t, qdesc, (size_t)nq * 32)
+    UP(d_t, uint8_t, tdesc, (size_t)nt * 32)
+    UP(d_toct, int32_t, t_octave, nt)
+    UP(d_off, int32_t, cand_off, nq + 1)
+    UP(d_idx, int32_t, cand_idx, nc)
+    UP(d_qv, uint8_t, q_valid, nq)
+    UP(d_occ, uint8_t, occupied, nt)
+    UP(d_qa, float, q_angle, nq)
+    UP(d_ta, float, t_angle, nt)
+    UP(d_qx, float, q_xright, nq)
+    UP(d_tx, float, t_xright, nt)
+    UP(d_qtol, float, q_xr_tol, nq)
+#undef UP
+    P.qdesc = (const uint32_t*)d_q;
+    P.tdesc = (const uint32_t*)d_t;
+    P.t_octave = d_toct;
+    P.nq = nq;
+    P.nt = nt;
+    P.cand_off = d_off;
+    P.cand_idx = d_idx;
+    P.q_valid = d_qv;
+    P.occupied = d_occ;
+    P.q_angle = d_qa;
+    P.t_angle = d_ta;
+    P.check_orientation = check_orientation;
+    P.q_xright = d_qx;
+    P.t_xright = d_tx;
+    P.q_xr_tol = d_qtol;
+    P.thr = thr;
+    P.lowe_ratio = lowe_ratio;
+    P.mode = mode;
+    P.dist = A.take<uint16_t>(nc);
+    P.match_q = A.take<int32_t>(nq);
+    P.num = A.take<int32_t>(1);
+    int* owner = A.take<int>(nt);
+    int* match = A.take<int>(nq);
+    sv_launch_cand(s, P, owner, match);
+    SV_HIP(ctx, hipGetLastError());
+    int32_t num = 0;
+    SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    *num_matches = num;
+    return SVGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""Python mirror of stella_vslam::match::* over the C ABI (flat-array form).
+
+The reference matchers take frame / keyframe / landmark objects (match/robust.h, match/projection.h).
+Here a "frame observation" is the flat part of data::frame_observation (data/frame_observation.h:12-38):
+`descriptors` (N x 32 uint8) and `keypts` (structured array with at least `angle`, `octave`).
+Constructor arguments and thresholds are the reference's (match/base.h:15-17,81-91).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+from .feature import Context
+
+HAMMING_DIST_THR_LOW = 50
+HAMMING_DIST_THR_HIGH = 100
+MAX_HAMMING_DIST = 256
+
+MATCH_BEST_ONLY = 0
+MATCH_RATIO_SAME_OCTAVE = 1
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, t):
+    return None if a is None else np.ascontiguousarray(a, t)
+
+
+def compute_descriptor_distance_32(ctx: Context, desc_1: np.ndarray, desc_2: np.ndarray) -> np.ndarray:
+    """match/base.h:20-41 for n row pairs."""
+    a = np.ascontiguousarray(desc_1, np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(desc_2, np.uint8).reshape(-1, 32)
+    out = np.zeros(len(a), np.uint32)
+    ctx.check(lib().svgpu_hamming_distance(ctx.handle, _p(a), _p(b), len(a), _p(out)), "svgpu_hamming_distance")
+    return out
+
+
+def hamming_matrix(ctx: Context, desc1: np.ndarray, desc2: np.ndarray) -> np.ndarray:
+    d1, d2 = _c(desc1, np.uint8), _c(desc2, np.uint8)
+    out = np.zeros((len(d2), len(d1)), np.uint16)
+    ctx.check(lib().svgpu_hamming_matrix(ctx.handle, _p(d1), len(d1), _p(d2), len(d2), _p(out)), "svgpu_hamming_matrix")
+    return out
+
+
+class base:
+    def __init__(self, lowe_ratio: float, check_orientation: bool, ctx: Context | None = None):
+        self.lowe_ratio_ = float(lowe_ratio)
+        self.check_orientation_ = bool(check_orientation)
+        self.ctx = ctx or Context()
+
+
+class robust(base):
+    """match/robust.h.  brute_force_match (match/robust.cc:232-328): returns the (idx_1, idx_2) pairs sorted by idx_1."""
+
+    def brute_force_match(self, desc_1, angle_1, desc_2, angle_2, lm_valid_2=None):
+        d1, d2 = _c(desc_1, np.uint8), _c(desc_2, np.uint8)
+        a1, a2 = _c(angle_1, np.float32), _c(angle_2, np.float32)
+        v2 = _c(lm_valid_2, np.uint8)
+        out = np.full(len(d1), -1, np.int32)
+        num = C.c_int(0)
+        self.ctx.check(lib().svgpu_match_bruteforce(self.ctx.handle, _p(d1), _p(a1), len(d1), _p(d2), _p(a2), _p(v2), len(d2),
+                                                    C.c_float(self.lowe_ratio_), int(self.check_orientation_), _p(out),
+                                                    C.byref(num)), "svgpu_match_bruteforce")
+        idx1 = np.flatnonzero(out >= 0)
+        assert len(idx1) == num.value
+        return [(int(i), int(out[i])) for i in idx1], out
+
+
+class projection(base):
+    """match/projection.h on flattened inputs: the caller supplies, per query (landmark / last-frame keypoint),
+    the candidate keypoint indices that get_keypoints_in_cell returned (data/common.cc:127-190), as CSR."""
+
+    def match_candidates(self, qdesc, tdesc, cand_off, cand_idx, mode, thr, t_octave=None, q_valid=None, occupied=None,
+                         q_angle=None, t_angle=None, q_xright=None, t_xright=None, q_xr_tol=None):
+        qd, td = _c(qdesc, np.uint8), _c(tdesc, np.uint8)
+        off, idx = _c(cand_off, np.int32), _c(cand_idx, np.int32)
+        toct, qv, occ = _c(t_octave, np.int32), _c(q_valid, np.uint8), _c(occupied, np.uint8)
+        qa, ta = _c(q_angle, np.float32), _c(t_angle, np.float32)
+        qx, tx, qt = _c(q_xright, np.float32), _c(t_xright, np.float32), _c(q_xr_tol, np.float32)
+        out = np.full(len(qd), -1, np.int32)
+        num = C.c_int(0)
+        self.ctx.check(lib().svgpu_match_candidates(self.ctx.handle, _p(qd), len(qd), _p(td), _p(toct), len(td), _p(off), _p(idx),
+                                                    _p(qv), _p(occ), _p(qa), _p(ta), int(self.check_orientation_), _p(qx),
+                                                    _p(tx), _p(qt), C.c_uint(thr), C.c_float(self.lowe_ratio_), mode, _p(out),
+                                                    C.byref(num)), "svgpu_match_candidates")
+        return out, num.value

@@ -1,0 +1,122 @@
+"""GPU parity: HIP matchers (through the C ABI) vs the CPU oracle -- identical match lists."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stella_vslam_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    from stella_vslam_amd import match
+    return match
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from stella_vslam_amd import feature
+    return feature.Context()
+
+
+def _noisy(rng, base, flips):
+    out = base.copy()
+    for i in range(len(out)):
+        for b in rng.choice(256, rng.integers(0, flips + 1), replace=False):
+            out[i, b // 8] ^= 1 << (b % 8)
+    return out
+
+
+def test_hamming_known_answers_and_random(M, ctx):
+    a = np.stack([np.full(32, 0b01010101, np.uint8), np.full(32, 0b01010101, np.uint8), np.full(32, 0b01100110, np.uint8)])
+    b = np.stack([np.full(32, 0b01010101, np.uint8), np.full(32, 0b10101010, np.uint8), np.full(32, 0b00111100, np.uint8)])
+    assert list(M.compute_descriptor_distance_32(ctx, a, b)) == [0, 256, 128]  # reference test/stella_vslam/match/base.cc:11-57
+    rng = np.random.default_rng(0)
+    d1 = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (333, 32), dtype=np.uint8)
+    assert np.array_equal(M.hamming_matrix(ctx, d1, d2), O.hamming_matrix(d1, d2))
+
+
+@pytest.mark.parametrize("seed,n1,n2,check,ratio", [(0, 150, 130, True, 0.75), (1, 2000, 2100, True, 0.75), (2, 2000, 1900, False, 0.9),
+                                                    (3, 37, 300, True, 0.6), (4, 3000, 5, False, 1.0)])
+def test_brute_force_matches_oracle(M, ctx, seed, n1, n2, check, ratio):
+    rng = np.random.default_rng(seed)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    src = rng.integers(0, max(n1 // 2, 1), n2)  # duplicates on purpose: exercises the greedy bookkeeping
+    d2 = _noisy(rng, d1[src], 45)
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    a2 = ((a1[src] + rng.normal(0, 15, n2)) % 360).astype(np.float32)
+    valid2 = (rng.uniform(size=n2) < 0.85).astype(np.uint8)
+    pairs, out = M.robust(ratio, check, ctx).brute_force_match(d1, a1, d2, a2, valid2)
+    exp = O.brute_force_match(d1, a1, d2, a2, valid2, ratio, check)
+    assert (exp >= 0).sum() >= min(n1, n2) // 8
+    assert np.array_equal(out, exp)
+
+
+def test_brute_force_adversarial_prefix_exhaustion(M, ctx):
+    """Many queries share the same few good targets: the K-prefix of late queries is fully consumed and
+    the exact full-row fallback must kick in."""
+    rng = np.random.default_rng(5)
+    n1, n2 = 400, 300
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    d1[:40] = _noisy(rng, np.repeat(d1[:1], 40, 0), 6)       # a cluster of 40 near-identical frame descriptors
+    d2 = _noisy(rng, np.repeat(d1[:1], n2, 0), 10)           # every query likes exactly that cluster
+    a = np.zeros(max(n1, n2), np.float32)
+    pairs, out = M.robust(1.0, False, ctx).brute_force_match(d1, a[:n1], d2, a[:n2], None)
+    exp = O.brute_force_match(d1, a[:n1], d2, a[:n2], None, 1.0, False)
+    assert (exp >= 0).sum() >= 30
+    assert np.array_equal(out, exp)
+
+
+def test_brute_force_on_real_descriptors(M, ctx):
+    seq = S.frame_sequence(2)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    pairs, out = M.robust(0.75, True, ctx).brute_force_match(d1, k1["angle"], d0, k0["angle"], None)
+    exp = O.brute_force_match(d1, k1["angle"], d0, k0["angle"], None, 0.75, True)
+    assert (exp >= 0).sum() > 1000
+    assert np.array_equal(out, exp)
+    assert pairs == [(int(i), int(exp[i])) for i in np.flatnonzero(exp >= 0)]
+
+
+def test_brute_force_empty(M, ctx):
+    d = np.zeros((0, 32), np.uint8)
+    a = np.zeros(0, np.float32)
+    x = np.zeros((5, 32), np.uint8)
+    pairs, out = M.robust(0.75, True, ctx).brute_force_match(d, a, x, np.zeros(5, np.float32))
+    assert pairs == [] and len(out) == 0
+    pairs, out = M.robust(0.75, True, ctx).brute_force_match(x, np.zeros(5, np.float32), d, a)
+    assert pairs == [] and (out == -1).all()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_candidate_matcher_matches_oracle(M, ctx, mode, seed):
+    """projection-style matching on realistic inputs: targets = keypoints of frame t+1, queries = keypoints of
+    frame t 'reprojected' by the known shift, candidates from the reference's grid lookup."""
+    seq = S.frame_sequence(2, seed=0x5EED + seed)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    off_g, items = O.assign_keypoints_to_grid(k1["x"], k1["y"], bounds)
+    sf = O.scale_tables(1.2, 8)[0]
+    rng = np.random.default_rng(seed)
+    cand_off, cand_idx = [0], []
+    for q in range(len(k0)):
+        lvl = int(k0["octave"][q])
+        c = O.get_keypoints_in_cell(k1["x"], k1["y"], k1["octave"], off_g, items, bounds, float(k0["x"][q]) - 3.0,
+                                    float(k0["y"][q]) - 1.0, 15.0 * float(sf[lvl]), max(0, lvl - 1), min(7, lvl + 1))
+        cand_idx += c.tolist()
+        cand_off.append(len(cand_idx))
+    occupied = (rng.uniform(size=len(k1)) < 0.05).astype(np.uint8)
+    q_valid = (rng.uniform(size=len(k0)) < 0.9).astype(np.uint8)
+    xr_t = np.where(rng.uniform(size=len(k1)) < 0.5, k1["x"] - 20.0, -1.0).astype(np.float32)
+    xr_q = (k0["x"] - 3.0 - 20.0 + rng.normal(0, 6, len(k0))).astype(np.float32)
+    tol = (15.0 * sf[k0["octave"]]).astype(np.float32)
+    kw = dict(t_octave=k1["octave"], q_valid=q_valid, occupied=occupied, q_angle=k0["angle"], t_angle=k1["angle"],
+              q_xright=xr_q, t_xright=xr_t, q_xr_tol=tol)
+    got, num = M.projection(0.8, True, ctx).match_candidates(d0, d1, cand_off, cand_idx, mode, 100, **kw)
+    exp = O.match_candidates(d0, d1, cand_off, cand_idx, check_orientation=True, thr=100, lowe_ratio=0.8, mode=mode, **kw)
+    assert (exp >= 0).sum() > 800
+    assert np.array_equal(got, exp) and num == (exp >= 0).sum()
