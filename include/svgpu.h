@@ -57,6 +57,13 @@ const char* svgpu_status_string(int status);
 int svgpu_synchronize(svgpu_ctx* ctx);
 void* svgpu_stream(svgpu_ctx* ctx); /* the context's hipStream_t */
 
+/* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's roofline
+ * object).  svgpu_profile_select brackets every later launch of the named kernel class (NULL = off);
+ * svgpu_profile_read synchronises and returns the accumulated device time and the number of launches. */
+const char* svgpu_profile_kernels(void); /* comma-separated class names */
+int svgpu_profile_select(svgpu_ctx* ctx, const char* kernel_name);
+int svgpu_profile_read(svgpu_ctx* ctx, double* total_ms, long long* launches);
+
 /* ------------------------------------------------------------------------------------------------ ORB front end
  * Stands behind  stella_vslam::feature::orb_extractor  (feature/orb_extractor.h:46-71):
  *   orb_extractor(const orb_params*, unsigned min_area, descriptor_type, mask_rects)   -> svgpu_orb_configure

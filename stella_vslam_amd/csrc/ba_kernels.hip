@@ -1,0 +1,569 @@
+// HIP kernels of local bundle adjustment for gfx950 (fp64 throughout, as g2o).
+//   k_ba_lin_lm / k_ba_lin_pose   linearizeOplus + constructQuadraticForm of every active edge
+//                                 (optimize/internal/se3/perspective_reproj_edge.h:67-120,173-238; g2o base_binary_edge)
+//   k_ba_dinv / k_ba_schur / k_ba_rhs / k_ba_chol / k_ba_update   BlockSolver_6_3::solve (Schur complement over the
+//                                 marginalised landmarks) + LinearSolver (dense LL^T) + back-substitution + oplus
+//   k_ba_chi2                     computeActiveErrors + activeRobustChi2
+//   k_ba_gate                     chi2 / depth gate (optimize/local_bundle_adjuster_g2o.cc:323-344, 354-375)
+// Every reduction runs in a fixed order (no floating-point atomics): results are run-to-run reproducible.
+#include "svgpu_internal.h"
+#include "ba_kernels.h"
+
+namespace {
+
+struct EdgeLin {
+    double r[3];   // error (obs - projection); r[2] = 0 for monocular edges
+    double A[9];   // d e / d landmark  (rows 0..D-1)
+    double B[18];  // d e / d pose      (rows 0..D-1), update = [omega, upsilon] applied on the left
+    double w;      // rho' * inv_sigma_sq
+    double chi;    // e^T Omega e (not robustified)
+    double z;
+    int D;
+};
+
+__device__ __forceinline__ void cam_point(const double* __restrict__ T, const double* __restrict__ X, double* pc) {
+    pc[0] = T[0] * X[0] + T[1] * X[1] + T[2] * X[2] + T[3];
+    pc[1] = T[4] * X[0] + T[5] * X[1] + T[6] * X[2] + T[7];
+    pc[2] = T[8] * X[0] + T[9] * X[1] + T[10] * X[2] + T[11];
+}
+
+// error only (computeError); returns chi2 = e^T Omega e
+__device__ __forceinline__ double edge_error(const double* __restrict__ T, const double* __restrict__ X, const double* __restrict__ K,
+                                             const float* __restrict__ uvr, double w0, double* r, double* z_out) {
+    double pc[3];
+    cam_point(T, X, pc);
+    const double u = K[0] * pc[0] / pc[2] + K[2];
+    const double v = K[1] * pc[1] / pc[2] + K[3];
+    r[0] = (double)uvr[0] - u;
+    r[1] = (double)uvr[1] - v;
+    r[2] = uvr[2] < 0.f ? 0.0 : (double)uvr[2] - (u - K[4] / pc[2]);
+    if (z_out) *z_out = pc[2];
+    return (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w0;
+}
+
+__device__ __forceinline__ void huber(double e, double delta, double* rho0, double* rho1) {  // g2o RobustKernelHuber
+    const double dsqr = delta * delta;
+    if (e <= dsqr) {
+        *rho0 = e;
+        *rho1 = 1.0;
+    }
+    else {
+        const double sqrte = sqrt(e);
+        *rho0 = 2 * sqrte * delta - dsqr;
+        *rho1 = delta / sqrte;
+    }
+}
+
+__device__ __forceinline__ void edge_linearize(const BaDev& D, int e, EdgeLin& o) {
+    const int p = D.e_pose[e], l = D.e_point[e];
+    const double* T = D.pose_cur + (size_t)p * 12;
+    const double* X = D.pt_cur + (size_t)l * 3;
+    const double* K = D.intr + (size_t)p * 5;
+    const float* uvr = D.e_uvr + (size_t)e * 3;
+    const double w0 = (double)D.e_w[e];
+    double pc[3];
+    cam_point(T, X, pc);
+    const double fx = K[0], fy = K[1], fxb = K[4];
+    const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z;
+    const double u = fx * x / z + K[2], v = fy * y / z + K[3];
+    const bool stereo = !(uvr[2] < 0.f);
+    o.D = stereo ? 3 : 2;
+    o.z = z;
+    o.r[0] = (double)uvr[0] - u;
+    o.r[1] = (double)uvr[1] - v;
+    o.r[2] = stereo ? (double)uvr[2] - (u - fxb / z) : 0.0;
+    o.chi = (o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2]) * w0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o.A[c] = -fx * T[c] / z + fx * x * T[8 + c] / z_sq;
+        o.A[3 + c] = -fy * T[4 + c] / z + fy * y * T[8 + c] / z_sq;
+        o.A[6 + c] = stereo ? o.A[c] - fxb * T[8 + c] / z_sq : 0.0;
+    }
+    o.B[0] = x * y / z_sq * fx;
+    o.B[1] = -(1.0 + (x * x / z_sq)) * fx;
+    o.B[2] = y / z * fx;
+    o.B[3] = -1.0 / z * fx;
+    o.B[4] = 0.0;
+    o.B[5] = x / z_sq * fx;
+    o.B[6] = (1.0 + y * y / z_sq) * fy;
+    o.B[7] = -x * y / z_sq * fy;
+    o.B[8] = -x / z * fy;
+    o.B[9] = 0.0;
+    o.B[10] = -1.0 / z * fy;
+    o.B[11] = y / z_sq * fy;
+    if (stereo) {
+        o.B[12] = o.B[0] - fxb * y / z_sq;
+        o.B[13] = o.B[1] + fxb * x / z_sq;
+        o.B[14] = o.B[2];
+        o.B[15] = o.B[3];
+        o.B[16] = 0.0;
+        o.B[17] = o.B[5] - fxb / z_sq;
+    }
+    else {
+#pragma unroll
+        for (int k = 12; k < 18; ++k) o.B[k] = 0.0;
+    }
+    double rho1 = 1.0;
+    if (D.e_robust[e]) {
+        double rho0;
+        huber(o.chi, (double)D.e_huber[e], &rho0, &rho1);
+    }
+    o.w = w0 * rho1;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum of one double per thread (256 threads), fixed order; result valid in thread 0
+__device__ __forceinline__ double block_sum_d(double v, double* s4) {
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = s4[0] + s4[1] + s4[2] + s4[3];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ linearise
+// thread per landmark: Hll, bl and the Hpl block W of every coupled edge
+__global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= D.L) return;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    const bool lfree = D.pt_free[l];
+    for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
+        if (D.e_level[e]) continue;
+        const int slot = D.pose_slot[D.e_pose[e]];
+        if (!lfree && slot < 0) continue;
+        EdgeLin o;
+        edge_linearize(D, e, o);
+        if (lfree) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
+                const double wr = -o.w * o.r[d];
+                b[0] += a0 * wr;
+                b[1] += a1 * wr;
+                b[2] += a2 * wr;
+                H[0] += a0 * o.w * a0;
+                H[1] += a0 * o.w * a1;
+                H[2] += a0 * o.w * a2;
+                H[3] += a1 * o.w * a1;
+                H[4] += a1 * o.w * a2;
+                H[5] += a2 * o.w * a2;
+            }
+            if (slot >= 0) {
+                double* Wd = D.W + (size_t)e * 18;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        Wd[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
+            }
+        }
+    }
+    if (lfree) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) D.Hll[(size_t)l * 6 + k] = H[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D.bl[(size_t)l * 3 + k] = b[k];
+    }
+}
+
+// workgroup per free pose: Hpp (6x6) and bp over all its active edges, tree-reduced in a fixed order
+__global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D) {
+    __shared__ double s4[4];
+    const int s = blockIdx.x;
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += 256) {
+        const int e = D.pe_idx[q];
+        EdgeLin o;
+        edge_linearize(D, e, o);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                acc[k] += o.B[i] * o.w * o.B[j] + o.B[6 + i] * o.w * o.B[6 + j] + o.B[12 + i] * o.w * o.B[12 + j];
+                ++k;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc[21 + i] += o.B[i] * (-o.w * o.r[0]) + o.B[6 + i] * (-o.w * o.r[1]) + o.B[12 + i] * (-o.w * o.r[2]);
+    }
+    double out[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) out[k] = block_sum_d(acc[k], s4);
+    if (threadIdx.x == 0) {
+        double* H = D.Hpp + (size_t)s * 36;
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) {
+                H[6 * i + j] = out[k];
+                H[6 * j + i] = out[k];
+                ++k;
+            }
+        for (int i = 0; i < 6; ++i) D.bp[(size_t)s * 6 + i] = out[21 + i];
+    }
+}
+
+// max |diagonal| over all active vertices (computeLambdaInit); non-negative doubles order like their bit patterns
+__global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double m = 0.0;
+    if (i < D.L && D.pt_free[i]) m = fmax(fabs(D.Hll[(size_t)i * 6]), fmax(fabs(D.Hll[(size_t)i * 6 + 3]), fabs(D.Hll[(size_t)i * 6 + 5])));
+    if (i < D.nP)
+        for (int j = 0; j < 6; ++j) m = fmax(m, fabs(D.Hpp[(size_t)i * 36 + 7 * j]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long*>(D.red + D.red_flag_off + 1), (unsigned long long)__double_as_longlong(m));
+}
+
+// ------------------------------------------------------------------------------------------------ solve
+// thread per landmark: Dinv = (Hll + lambda I)^-1 and Y = W * Dinv of its coupled edges
+__global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= D.L || !D.pt_free[l]) return;
+    const double* H = D.Hll + (size_t)l * 6;
+    const double a = H[0] + D.lambda, b = H[1], c = H[2], d = H[3] + D.lambda, e_ = H[4], f = H[5] + D.lambda;
+    const double c00 = d * f - e_ * e_, c01 = e_ * c - b * f, c02 = b * e_ - d * c;
+    const double det = a * c00 + b * c01 + c * c02;
+    double I[6];
+    if (det == 0.0 || !isfinite(det)) {
+        D.red[D.red_flag_off] = 1.0;  // benign race: any writer sets the same value
+#pragma unroll
+        for (int k = 0; k < 6; ++k) I[k] = 0.0;
+    }
+    else {
+        const double id = 1.0 / det;
+        I[0] = c00 * id;
+        I[1] = c01 * id;
+        I[2] = c02 * id;
+        I[3] = (a * f - c * c) * id;
+        I[4] = (b * c - a * e_) * id;
+        I[5] = (a * d - b * b) * id;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) D.Dinv[(size_t)l * 6 + k] = I[k];
+    for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
+        if (D.e_level[e] || D.pose_slot[D.e_pose[e]] < 0) continue;
+        const double* Wd = D.W + (size_t)e * 18;
+        double* Yd = D.Y + (size_t)e * 18;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double w0 = Wd[3 * i], w1 = Wd[3 * i + 1], w2 = Wd[3 * i + 2];
+            Yd[3 * i] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+            Yd[3 * i + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+            Yd[3 * i + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+        }
+    }
+}
+
+// one wave per upper block (a <= b) of the reduced system: S_ab = [a==b](Hpp_a + lambda I) - sum Y_i W_j^T
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blk >= D.NB) return;
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    for (int q = D.blk_off[blk] + lane; q < D.blk_off[blk + 1]; q += 64) {
+        const int2 pr = D.blk_pairs[q];
+        const double* Yd = D.Y + (size_t)pr.x * 18;
+        const double* Wd = D.W + (size_t)pr.y * 18;
+        double y[18], w[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            y[k] = Yd[k];
+            w[k] = Wd[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
+    }
+    const int2 ab = D.blk_ab[blk];
+    double mine = 0.0;  // lane k < 36 ends up owning element k
+#pragma unroll
+    for (int k = 0; k < 36; ++k) {
+        const double t = wave_sum_d(acc[k]);
+        if (lane == k) mine = t;
+    }
+    if (lane < 36) {
+        const int i = lane / 6, j = lane - 6 * i;
+        double v = -mine;
+        if (ab.x == ab.y) {
+            v += D.Hpp[(size_t)ab.x * 36 + lane];
+            if (i == j) v += D.lambda;
+        }
+        const size_t n = D.n;
+        D.S[(size_t)(6 * ab.x + i) * n + 6 * ab.y + j] = v;
+        if (ab.x != ab.y) D.S[(size_t)(6 * ab.y + j) * n + 6 * ab.x + i] = v;
+    }
+}
+
+// workgroup per free pose: g_a = bp_a - sum_e Y_e bl_l(e)  -> row n of S
+__global__ __launch_bounds__(256) void k_ba_rhs(BaDev D) {
+    __shared__ double s4[4];
+    const int s = blockIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += 256) {
+        const int e = D.pe_idx[q];
+        const int l = D.e_point[e];
+        if (!D.pt_free[l]) continue;
+        const double* Yd = D.Y + (size_t)e * 18;
+        const double* b = D.bl + (size_t)l * 3;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] += Yd[3 * i] * b[0] + Yd[3 * i + 1] * b[1] + Yd[3 * i + 2] * b[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double t = block_sum_d(acc[i], s4);
+        if (threadIdx.x == 0) D.S[(size_t)D.n * D.n + 6 * s + i] = D.bp[(size_t)s * 6 + i] - t;
+    }
+}
+
+// Dense LL^T of the reduced system with the right-hand side carried as row n, then L^T x = y.
+// One workgroup; A (n+1 rows x n cols) lives in LDS (pitch ld) when it fits, otherwise in global memory.
+template <bool IN_LDS>
+__global__ __launch_bounds__(1024) void k_ba_chol(BaDev D) {
+    extern __shared__ double s_A[];
+    __shared__ int s_fail;
+    const int n = D.n, tid = threadIdx.x, nt = blockDim.x;
+    const int ld = IN_LDS ? (n | 1) : n;
+    double* A = IN_LDS ? s_A : D.S;
+    if (IN_LDS)
+        for (int i = tid; i < (n + 1) * n; i += nt) A[(i / n) * ld + (i % n)] = D.S[i];
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double djj = A[j * ld + j];
+        if (!(djj > 0.0)) {
+            if (tid == 0) s_fail = 1;
+            break;  // uniform: every thread read the same value
+        }
+        const double d = sqrt(djj);
+        __syncthreads();
+        for (int i = j + tid; i <= n; i += nt) A[i * ld + j] = (i == j) ? d : A[i * ld + j] / d;
+        __syncthreads();
+        const int m = n - j;  // rows j+1..n (incl. rhs), cols j+1..n-1
+        for (int q = tid; q < m * (m - 1); q += nt) {
+            const int i = j + 1 + q / (m - 1), k = j + 1 + q % (m - 1);
+            if (k <= i) A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) D.red[D.red_flag_off] = 1.0;
+        for (int i = tid; i < n; i += nt) D.dp[i] = 0.0;
+        return;
+    }
+    // back substitution L^T x = y (y = row n), column oriented
+    for (int i = n - 1; i >= 0; --i) {
+        const double xi = A[n * ld + i] / A[i * ld + i];
+        __syncthreads();
+        if (tid == 0) A[n * ld + i] = xi;
+        for (int k = tid; k < i; k += nt) A[n * ld + k] -= A[i * ld + k] * xi;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += nt) D.dp[i] = A[n * ld + i];
+}
+
+// thread per landmark: dl = Dinv (bl - sum W^T dp), trial point, partial of delta^T(lambda delta + b)
+__global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {
+    __shared__ double s4[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    double sc = 0.0;
+    if (l < D.L) {
+        double X[3] = {D.pt_cur[(size_t)l * 3], D.pt_cur[(size_t)l * 3 + 1], D.pt_cur[(size_t)l * 3 + 2]};
+        if (D.pt_free[l]) {
+            const double* b = D.bl + (size_t)l * 3;
+            double c[3] = {b[0], b[1], b[2]};
+            for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
+                if (D.e_level[e]) continue;
+                const int slot = D.pose_slot[D.e_pose[e]];
+                if (slot < 0) continue;
+                const double* Wd = D.W + (size_t)e * 18;
+                const double* x = D.dp + (size_t)slot * 6;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    c[0] -= Wd[3 * i] * x[i];
+                    c[1] -= Wd[3 * i + 1] * x[i];
+                    c[2] -= Wd[3 * i + 2] * x[i];
+                }
+            }
+            const double* I = D.Dinv + (size_t)l * 6;
+            const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
+            const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
+            const double d2 = I[2] * c[0] + I[4] * c[1] + I[5] * c[2];
+            X[0] += d0;
+            X[1] += d1;
+            X[2] += d2;
+            sc = d0 * (D.lambda * d0 + b[0]) + d1 * (D.lambda * d1 + b[1]) + d2 * (D.lambda * d2 + b[2]);
+        }
+        D.pt_trial[(size_t)l * 3] = X[0];
+        D.pt_trial[(size_t)l * 3 + 1] = X[1];
+        D.pt_trial[(size_t)l * 3 + 2] = X[2];
+    }
+    const double t = block_sum_d(sc, s4);
+    if (threadIdx.x == 0) D.red[D.red_scale_off + blockIdx.x] = t;
+}
+
+// thread per pose: trial = exp(dp) * cur (g2o SE3Quat::exp, shot_vertex.h:55-58)
+__global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0) {
+    __shared__ double s4[4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double sc = 0.0;
+    if (p < D.P) {
+        const double* T = D.pose_cur + (size_t)p * 12;
+        double* O = D.pose_trial + (size_t)p * 12;
+        const int slot = D.pose_slot[p];
+        if (slot < 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) O[k] = T[k];
+        }
+        else {
+            const double* u = D.dp + (size_t)slot * 6;
+            const double* bpv = D.bp + (size_t)slot * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sc += u[k] * (D.lambda * u[k] + bpv[k]);
+            const double wx = u[0], wy = u[1], wz = u[2];
+            const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+            const double Om[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+            double O2[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) O2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
+            double a, b, c, d;
+            if (theta < 0.00001) {
+                a = 1.0;
+                b = 0.5;
+                c = 0.5;
+                d = 1.0 / 6.0;
+            }
+            else {
+                const double st = sin(theta), ct = cos(theta);
+                a = st / theta;
+                b = (1 - ct) / (theta * theta);
+                c = b;
+                d = (theta - st) / (theta * theta * theta);
+            }
+            double R[9], V[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double I = (k % 4 == 0) ? 1.0 : 0.0;
+                R[k] = I + a * Om[k] + b * O2[k];
+                V[k] = I + c * Om[k] + d * O2[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) O[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+                O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + V[3 * i] * u[3] + V[3 * i + 1] * u[4]
+                               + V[3 * i + 2] * u[5];
+            }
+        }
+    }
+    const double t = block_sum_d(sc, s4);
+    if (threadIdx.x == 0) D.red[D.red_scale_off + scale_slot0 + blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------------ errors
+__global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache) {
+    __shared__ double s4[4];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (e < D.E && !D.e_level[e]) {
+        const int p = D.e_pose[e], l = D.e_point[e];
+        const double* T = (use_trial ? D.pose_trial : D.pose_cur) + (size_t)p * 12;
+        const double* X = (use_trial ? D.pt_trial : D.pt_cur) + (size_t)l * 3;
+        double r[3];
+        const double chi = edge_error(T, X, D.intr + (size_t)p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
+        if (store_cache) D.e_chi[e] = chi;
+        if (D.e_robust[e]) {
+            double rho0, rho1;
+            huber(chi, (double)D.e_huber[e], &rho0, &rho1);
+            v = rho0;
+        }
+        else v = chi;
+    }
+    const double t = block_sum_d(v, s4);
+    if (threadIdx.x == 0) D.red[D.red_chi_off + blockIdx.x] = t;
+}
+
+// chi2 / depth gate on the cached chi2 (stale for excluded edges, exactly as g2o's cached _error)
+__global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_t* __restrict__ outlier_out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= D.E) return;
+    const int p = D.e_pose[e], l = D.e_point[e];
+    double pc[3];
+    cam_point(D.pose_cur + (size_t)p * 12, D.pt_cur + (size_t)l * 3, pc);
+    const bool mono = D.e_uvr[(size_t)e * 3 + 2] < 0.f;
+    const double thr = mono ? (double)5.99146f : (double)7.81473f;
+    const bool out = thr < D.e_chi[e] || !(0.0 < pc[2]);
+    if (set_levels) {
+        if (out) D.e_level[e] = 1;
+        D.e_robust[e] = 0;
+    }
+    if (outlier_out) outlier_out[e] = out ? 1 : 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ launchers
+void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+    SvProfScope ps(ctx, s, "ba_linearize");
+    hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
+    if (D.nP > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP), dim3(256), 0, s, D);
+}
+
+void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
+    const int m = D.L > D.nP ? D.L : D.nP;
+    hipLaunchKernelGGL(k_ba_maxdiag, dim3((m + 255) / 256), dim3(256), 0, s, D);
+}
+
+void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+    {
+        SvProfScope ps(ctx, s, "ba_schur");
+        hipLaunchKernelGGL(k_ba_dinv, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
+        if (D.nP > 0) {
+            (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
+            hipLaunchKernelGGL(k_ba_schur, dim3((D.NB + 3) / 4), dim3(256), 0, s, D);
+            hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(256), 0, s, D);
+        }
+    }
+    if (D.nP > 0) {
+        SvProfScope ps(ctx, s, "ba_solve");
+        if (D.chol_in_lds) {
+            const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)k_ba_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_ba_chol<true>, dim3(1), dim3(D.n <= 48 ? 256 : 1024), lds, s, D);
+        }
+        else hipLaunchKernelGGL(k_ba_chol<false>, dim3(1), dim3(1024), 0, s, D);
+    }
+    SvProfScope ps(ctx, s, "ba_update");
+    hipLaunchKernelGGL(k_ba_update_lm, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
+    hipLaunchKernelGGL(k_ba_update_pose, dim3((D.P + 255) / 256), dim3(256), 0, s, D, (D.L + 255) / 256);
+}
+
+void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache) {
+    SvProfScope ps(ctx, s, "ba_chi2");
+    hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache);
+}
+
+void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out) {
+    hipLaunchKernelGGL(k_ba_gate, dim3((D.E + 255) / 256), dim3(256), 0, s, D, set_levels, outlier_out);
+}

@@ -324,14 +324,19 @@ void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const u
     if (n1 <= 0 || n2 <= 0) return;
     hipLaunchKernelGGL(k_hamming_matrix, dim3((n2 + 255) / 256), dim3(256), 0, s, d1, n1, d2, n2, out);
 }
-void sv_launch_bf(hipStream_t s, const BfProblem& P, int pairs, int* g_owner, int* g_match) {
+void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P, int pairs, int* g_owner, int* g_match) {
     if (pairs <= 0) return;
-    hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + 255) / 256, pairs), dim3(256), 0, s, P);
+    {
+        SvProfScope ps(ctx, s, "k_bf_topk");
+        hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + 255) / 256, pairs), dim3(256), 0, s, P);
+    }
+    SvProfScope ps(ctx, s, "k_bf_replay");
     const size_t lds = (size_t)(P.cap1 + P.cap2) * sizeof(int);
     const int use_lds = lds <= 96 * 1024;
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(256), use_lds ? lds : 0, s, P, g_owner, g_match, use_lds);
 }
-void sv_launch_cand(hipStream_t s, const CandProblem& P, int* owner, int* match) {
+void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match) {
+    SvProfScope ps(ctx, s, "k_cand");
     if (P.nq > 0) hipLaunchKernelGGL(k_cand_dist, dim3(P.nq), dim3(64), 0, s, P);
     hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(256), 0, s, P, owner, match);
 }

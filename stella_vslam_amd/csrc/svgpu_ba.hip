@@ -1,0 +1,436 @@
+// Host side of local bundle adjustment: problem flattening, structure (CSR) construction, and the
+// Levenberg-Marquardt control flow of g2o restated around the device kernels.
+//   two-stage schedule                 optimize/local_bundle_adjuster_g2o.cc:306-348
+//   OptimizationAlgorithmLevenberg     g2o (pinned 20230223_git): lambda init 1e-5 * max diag, rho test, 10 trials
+//   terminate_action                   optimize/terminate_action.cc:36-76 (writes through the force-stop pointer)
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "svgpu_internal.h"
+#include "ba_kernels.h"
+
+void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
+
+namespace {
+
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(void* p) : base((char*)p) {}
+    template <class T>
+    T* take(size_t n) {
+        T* r = (T*)(base + off);
+        off += (n * sizeof(T) + 255) & ~size_t(255);
+        return r;
+    }
+};
+inline size_t pad(size_t b) { return (b + 255) & ~size_t(255); }
+
+struct HostStructure {
+    std::vector<int> pose_slot, slot_pose;
+    std::vector<uint8_t> pt_free;
+    std::vector<int> pe_off, pe_idx;
+    std::vector<int> blk_off;
+    std::vector<int2> blk_pairs, blk_ab;
+    int nP = 0, nL = 0;
+};
+
+// initializeOptimization(level 0): active vertices = endpoints of active edges; free = active and not fixed.
+void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, const std::vector<int>& e_point,
+                     const std::vector<int>& lm_off, const std::vector<uint8_t>& level, HostStructure& H) {
+    const int P = pr.num_poses, L = pr.num_points, E = pr.num_obs;
+    std::vector<uint8_t> pa(P, 0), la(L, 0);
+    for (int e = 0; e < E; ++e)
+        if (!level[e]) {
+            pa[e_pose[e]] = 1;
+            la[e_point[e]] = 1;
+        }
+    H.pose_slot.assign(P, -1);
+    H.slot_pose.clear();
+    for (int p = 0; p < P; ++p)
+        if (pa[p] && !pr.pose_fixed[p]) {
+            H.pose_slot[p] = (int)H.slot_pose.size();
+            H.slot_pose.push_back(p);
+        }
+    H.nP = (int)H.slot_pose.size();
+    H.pt_free.assign(L, 0);
+    H.nL = 0;
+    for (int l = 0; l < L; ++l)
+        if (la[l] && !(pr.point_fixed && pr.point_fixed[l])) {
+            H.pt_free[l] = 1;
+            ++H.nL;
+        }
+    // pose -> active edges
+    H.pe_off.assign(H.nP + 1, 0);
+    for (int e = 0; e < E; ++e)
+        if (!level[e] && H.pose_slot[e_pose[e]] >= 0) H.pe_off[H.pose_slot[e_pose[e]] + 1]++;
+    for (int s = 0; s < H.nP; ++s) H.pe_off[s + 1] += H.pe_off[s];
+    H.pe_idx.resize(H.pe_off[H.nP]);
+    {
+        std::vector<int> fill(H.pe_off.begin(), H.pe_off.end() - 1);
+        for (int e = 0; e < E; ++e)
+            if (!level[e] && H.pose_slot[e_pose[e]] >= 0) H.pe_idx[fill[H.pose_slot[e_pose[e]]]++] = e;
+    }
+    // upper blocks (a <= b) of the reduced system and their (edge, edge) pairs: count, then fill
+    const size_t nb_dense = (size_t)H.nP * (H.nP + 1) / 2;
+    auto bidx = [&](int a, int b) { return (size_t)a * H.nP - (size_t)a * (a - 1) / 2 + (b - a); };  // a <= b
+    std::vector<int> cnt(nb_dense + 1, 0);
+    std::vector<int> tmp;  // coupled edges of one landmark
+    auto for_pairs = [&](auto&& f) {
+        for (int l = 0; l < L; ++l) {
+            if (!H.pt_free[l]) continue;
+            tmp.clear();
+            for (int e = lm_off[l]; e < lm_off[l + 1]; ++e)
+                if (!level[e] && H.pose_slot[e_pose[e]] >= 0) tmp.push_back(e);
+            for (size_t i = 0; i < tmp.size(); ++i)
+                for (size_t j = i; j < tmp.size(); ++j) {
+                    int e1 = tmp[i], e2 = tmp[j];
+                    int a = H.pose_slot[e_pose[e1]], b = H.pose_slot[e_pose[e2]];
+                    if (a > b) {
+                        std::swap(a, b);
+                        std::swap(e1, e2);
+                    }
+                    f(a, b, e1, e2);
+                    if (a == b && e1 != e2) f(a, b, e2, e1);  // two observations from one pose: both cross terms
+                }
+        }
+    };
+    for_pairs([&](int a, int b, int, int) { cnt[bidx(a, b)]++; });
+    // keep every diagonal block (it carries Hpp + lambda I) and every non-empty off-diagonal block
+    H.blk_ab.clear();
+    H.blk_off.assign(1, 0);
+    std::vector<int> dense_to_blk(nb_dense, -1);
+    for (int a = 0; a < H.nP; ++a)
+        for (int b = a; b < H.nP; ++b) {
+            const size_t k = bidx(a, b);
+            if (a == b || cnt[k] > 0) {
+                dense_to_blk[k] = (int)H.blk_ab.size();
+                int2 ab;
+                ab.x = a;
+                ab.y = b;
+                H.blk_ab.push_back(ab);
+                H.blk_off.push_back(H.blk_off.back() + cnt[k]);
+            }
+        }
+    H.blk_pairs.resize(H.blk_off.back());
+    std::vector<int> fill(H.blk_off.begin(), H.blk_off.end() - 1);
+    for_pairs([&](int a, int b, int e1, int e2) {
+        int2 p;
+        p.x = e1;
+        p.y = e2;
+        H.blk_pairs[fill[dense_to_blk[bidx(a, b)]]++] = p;
+    });
+}
+
+}  // namespace
+
+static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allreduce_fn allreduce, void* ar_user,
+                         volatile uint8_t* stop, double* pose_out, double* points_out, uint8_t* outlier_out,
+                         svgpu_ba_stats* stats) {
+    if (!ctx || !pr || !pose_out || !points_out) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: null argument");
+    const int P = pr->num_poses, L = pr->num_points, E = pr->num_obs;
+    if (P < 0 || L < 0 || E < 0 || (P > 0 && (!pr->pose_cw || !pr->pose_fixed || !pr->intrinsics)) || (L > 0 && !pr->points)
+        || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || !outlier_out)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: inconsistent problem");
+    for (int e = 0; e < E; ++e)
+        if (pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L)
+            return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+    if (allreduce) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: not available in this build");
+    (void)ar_user;
+    svgpu_ba_stats st;
+    memset(&st, 0, sizeof(st));
+    memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
+    memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+    if (E > 0) memset(outlier_out, 0, E);
+    if (stats) *stats = st;
+    if (stop && *stop) return SVGPU_STOPPED;  // local_bundle_adjuster_g2o.cc:308-310
+    if (E == 0 || P == 0 || L == 0) return SVGPU_OK;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    // ---- sort the observations by landmark (stable): landmark-major kernels then read contiguous runs
+    std::vector<int> lm_off(L + 1, 0), perm(E);
+    for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
+    for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
+    {
+        std::vector<int> fill(lm_off.begin(), lm_off.end() - 1);
+        for (int e = 0; e < E; ++e) perm[fill[pr->obs_point[e]]++] = e;
+    }
+    std::vector<int> e_pose(E), e_point(E);
+    std::vector<float> e_uvr(3 * (size_t)E), e_w(E), e_hub(E);
+    std::vector<uint8_t> level(E, 0), robust(E, 0);
+    for (int k = 0; k < E; ++k) {
+        const int e = perm[k];
+        e_pose[k] = pr->obs_pose[e];
+        e_point[k] = pr->obs_point[e];
+        e_uvr[3 * k] = pr->obs_uvr[3 * e];
+        e_uvr[3 * k + 1] = pr->obs_uvr[3 * e + 1];
+        e_uvr[3 * k + 2] = pr->obs_uvr[3 * e + 2];
+        e_w[k] = pr->obs_inv_sigma_sq[e];
+        e_hub[k] = pr->obs_huber_delta ? pr->obs_huber_delta[e] : 0.f;
+        robust[k] = e_hub[k] > 0.f;
+    }
+
+    // ---- device arena
+    const int nPmax = P, nmax = 6 * nPmax;
+    const int nb_chi = (E + 255) / 256, nb_lm = (L + 255) / 256, nb_pose = (P + 255) / 256;
+    const size_t pairs_max_guess = 0;  // pair lists are sized after build_structure (second arena piece)
+    (void)pairs_max_guess;
+    size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
+                  + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
+                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E)
+                  + 3 * pad(sizeof(double) * 6 * L) + 2 * pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
+                  + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (size_t)(nmax + 1) * nmax) + pad(sizeof(double) * nmax)
+                  + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E) + 4096;
+    // worst-case pair storage: sum over landmarks of k(k+1)/2 (+ duplicates never exceed k^2)
+    size_t pair_cap = 0;
+    for (int l = 0; l < L; ++l) {
+        const size_t k = lm_off[l + 1] - lm_off[l];
+        pair_cap += k * k;
+    }
+    const size_t nb_cap = (size_t)P * (P + 1) / 2;
+    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1));
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    BaDev D;
+    memset(&D, 0, sizeof(D));
+    D.P = P;
+    D.L = L;
+    D.E = E;
+    D.pose_cur = A.take<double>(12 * (size_t)P);
+    D.pose_trial = A.take<double>(12 * (size_t)P);
+    D.pt_cur = A.take<double>(3 * (size_t)L);
+    D.pt_trial = A.take<double>(3 * (size_t)L);
+    int* d_e_pose = A.take<int>(E);
+    int* d_e_point = A.take<int>(E);
+    float* d_e_uvr = A.take<float>(3 * (size_t)E);
+    float* d_e_w = A.take<float>(E);
+    float* d_e_hub = A.take<float>(E);
+    D.e_level = A.take<uint8_t>(E);
+    D.e_robust = A.take<uint8_t>(E);
+    D.e_chi = A.take<double>(E);
+    double* d_intr = A.take<double>(5 * (size_t)P);
+    int* d_pose_slot = A.take<int>(P);
+    uint8_t* d_pt_free = A.take<uint8_t>(L);
+    int* d_lm_off = A.take<int>(L + 1);
+    int* d_pe_off = A.take<int>(P + 1);
+    int* d_pe_idx = A.take<int>(E);
+    D.W = A.take<double>(18 * (size_t)E);
+    D.Y = A.take<double>(18 * (size_t)E);
+    D.Hll = A.take<double>(6 * (size_t)L);
+    D.Dinv = A.take<double>(6 * (size_t)L);
+    D.bl = A.take<double>(3 * (size_t)L);
+    D.dl = A.take<double>(3 * (size_t)L);
+    D.Hpp = A.take<double>(36 * (size_t)P);
+    D.bp = A.take<double>(6 * (size_t)P);
+    D.S = A.take<double>((size_t)(nmax + 1) * nmax);
+    D.dp = A.take<double>(nmax);
+    D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
+    uint8_t* d_outlier = A.take<uint8_t>(E);
+    int2* d_blk_pairs = A.take<int2>(pair_cap);
+    int2* d_blk_ab = A.take<int2>(nb_cap);
+    int* d_blk_off = A.take<int>(nb_cap + 1);
+    if (A.off > ctx->scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: internal arena overflow");
+    D.e_pose = d_e_pose;
+    D.e_point = d_e_point;
+    D.e_uvr = d_e_uvr;
+    D.e_w = d_e_w;
+    D.e_huber = d_e_hub;
+    D.intr = d_intr;
+    D.pose_slot = d_pose_slot;
+    D.pt_free = d_pt_free;
+    D.lm_off = d_lm_off;
+    D.pe_off = d_pe_off;
+    D.pe_idx = d_pe_idx;
+    D.blk_pairs = d_blk_pairs;
+    D.blk_ab = d_blk_ab;
+    D.blk_off = d_blk_off;
+    D.red_chi_off = 0;
+    D.red_chi_n = nb_chi;
+    D.red_scale_off = nb_chi;
+    D.red_scale_n = nb_lm + nb_pose;
+    D.red_flag_off = nb_chi + nb_lm + nb_pose;
+    const int red_total = nb_chi + nb_lm + nb_pose + 8;
+    std::vector<double> red_host(red_total);
+
+#define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
+    H2D(D.pose_cur, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
+    H2D(D.pt_cur, pr->points, sizeof(double) * 3 * (size_t)L);
+    H2D(d_e_pose, e_pose.data(), 4 * (size_t)E);
+    H2D(d_e_point, e_point.data(), 4 * (size_t)E);
+    H2D(d_e_uvr, e_uvr.data(), 12 * (size_t)E);
+    H2D(d_e_w, e_w.data(), 4 * (size_t)E);
+    H2D(d_e_hub, e_hub.data(), 4 * (size_t)E);
+    H2D(D.e_level, level.data(), E);
+    H2D(D.e_robust, robust.data(), E);
+    H2D(d_intr, pr->intrinsics, sizeof(double) * 5 * (size_t)P);
+    H2D(d_lm_off, lm_off.data(), 4 * (size_t)(L + 1));
+    SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
+
+    HostStructure HS;
+    auto upload_structure = [&]() -> int {
+        build_structure(*pr, e_pose, e_point, lm_off, level, HS);
+        D.nP = HS.nP;
+        D.n = 6 * HS.nP;
+        D.NB = (int)HS.blk_ab.size();
+        D.chol_in_lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 256;
+        H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
+        H2D(d_pt_free, HS.pt_free.data(), L);
+        H2D(d_pe_off, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
+        if (!HS.pe_idx.empty()) H2D(d_pe_idx, HS.pe_idx.data(), 4 * HS.pe_idx.size());
+        H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
+        if (!HS.blk_ab.empty()) H2D(d_blk_ab, HS.blk_ab.data(), 8 * HS.blk_ab.size());
+        if (!HS.blk_pairs.empty()) H2D(d_blk_pairs, HS.blk_pairs.data(), 8 * HS.blk_pairs.size());
+        return SVGPU_OK;
+    };
+
+    // chi2 of the active set at the current / trial state (fixed-order sum of the per-block partials)
+    auto chi2 = [&](int use_trial, int store_cache, double* out) -> int {
+        sv_ba_chi2(ctx, s, D, use_trial, store_cache);
+        SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red + D.red_chi_off, 8 * (size_t)nb_chi, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        double sum = 0;
+        for (int i = 0; i < nb_chi; ++i) sum += red_host[i];
+        *out = sum;
+        return SVGPU_OK;
+    };
+
+    uint8_t aux_flag = 0;  // g2o installs its own flag when the caller passes none (see svgpu.h)
+    volatile uint8_t* flag = stop ? stop : &aux_flag;
+    double lambda = 0, last_chi = 0;
+
+    // SparseOptimizer::optimize(iterations) with the terminate_action hook
+    auto optimize = [&](int iterations, int* iters_done) -> int {
+        *iters_done = 0;
+        int r = upload_structure();
+        if (r) return r;
+        if (HS.nP + HS.nL == 0) return SVGPU_OK;
+        bool ok = true;
+        double ni = 2;
+        for (int it = 0; it < iterations && !*flag && ok; ++it) {
+            double current_chi;
+            if ((r = chi2(0, 0, &current_chi))) return r;
+            sv_ba_linearize(ctx, s, D);
+            if (it == 0) {  // computeLambdaInit
+                SV_HIP(ctx, hipMemsetAsync(D.red + D.red_flag_off, 0, 16, s));
+                sv_ba_maxdiag(s, D);
+                double fl[2];
+                SV_HIP(ctx, hipMemcpyAsync(fl, D.red + D.red_flag_off, 16, hipMemcpyDeviceToHost, s));
+                SV_HIP(ctx, hipStreamSynchronize(s));
+                lambda = 1e-5 * fl[1];
+                ni = 2;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                D.lambda = lambda;
+                SV_HIP(ctx, hipMemsetAsync(D.red + D.red_flag_off, 0, 8, s));
+                sv_ba_solve(ctx, s, D);
+                sv_ba_chi2(ctx, s, D, 1, 0);
+                SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red, 8 * (size_t)red_total, hipMemcpyDeviceToHost, s));
+                SV_HIP(ctx, hipStreamSynchronize(s));
+                double temp_chi = 0, scale = 0;
+                for (int i = 0; i < nb_chi; ++i) temp_chi += red_host[D.red_chi_off + i];
+                for (int i = 0; i < nb_lm + nb_pose; ++i) scale += red_host[D.red_scale_off + i];
+                const bool ok2 = red_host[D.red_flag_off] == 0.0;
+                ++st.lm_trials;
+                if (!ok2) {
+                    temp_chi = DBL_MAX;
+                    ++st.cholesky_failures;
+                }
+                rho = current_chi - temp_chi;
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && std::isfinite(temp_chi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha);
+                    ni = 2;
+                    current_chi = temp_chi;
+                    std::swap(D.pose_cur, D.pose_trial);  // accept: the trial state becomes the estimate
+                    std::swap(D.pt_cur, D.pt_trial);
+                }
+                else {
+                    lambda *= ni;
+                    ni *= 2;
+                    if (!std::isfinite(lambda)) break;
+                }
+                ++qmax;
+            } while (rho < 0 && qmax < 10 && !*flag);
+            if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) ok = false;
+            ++*iters_done;
+            // postIteration: terminate_action (chi2 of the current estimate = current_chi)
+            if (it == 0) last_chi = current_chi;
+            else {
+                const double gain = (last_chi - current_chi) / current_chi;
+                last_chi = current_chi;
+                if (gain >= 0 && gain < pr->gain_threshold) *flag = 1;
+            }
+        }
+        // errors cached by the last computeActiveErrors (used by the gate and the outlier list)
+        double dummy;
+        if (*iters_done > 0 && (r = chi2(0, 1, &dummy))) return r;
+        return SVGPU_OK;
+    };
+
+    double chi0 = 0;
+    {
+        int r = upload_structure();
+        if (r) return r;
+        if ((r = chi2(0, 1, &chi0))) return r;
+    }
+    st.chi2_initial = chi0;
+    int it1 = 0, it2 = 0;
+    rc = optimize(pr->num_first_iter, &it1);
+    if (rc) return rc;
+    st.iters_stage1 = it1;
+    bool run_robust = true;
+    if (stop && *stop) run_robust = false;  // :317-321 (only the CALLER's flag is consulted here)
+    if (run_robust) {
+        st.stage2_entered = 1;
+        sv_ba_gate(s, D, 1, nullptr);
+        SV_HIP(ctx, hipMemcpyAsync(level.data(), D.e_level, E, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        int gated = 0;
+        for (int e = 0; e < E; ++e) gated += level[e];
+        st.num_gated = gated;
+        rc = optimize(pr->num_second_iter, &it2);
+        if (rc) return rc;
+        st.iters_stage2 = it2;
+    }
+    // ---- outlier list, final chi2, read-back
+    sv_ba_gate(s, D, 0, d_outlier);
+    std::vector<uint8_t> outl(E);
+    SV_HIP(ctx, hipMemcpyAsync(outl.data(), d_outlier, E, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(pose_out, D.pose_cur, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(points_out, D.pt_cur, sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToHost, s));
+    double chi1 = 0;
+    {
+        int r = chi2(0, 0, &chi1);
+        if (r) return r;
+    }
+    for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
+    st.chi2_final = chi1;
+    st.lambda_final = lambda;
+    if (stats) *stats = st;
+#undef H2D
+    return SVGPU_OK;
+}
+
+extern "C" {
+
+int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
+                   double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats) {
+    return local_ba_impl(ctx, problem, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
+}
+
+int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, svgpu_allreduce_fn allreduce,
+                           void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out,
+                           uint8_t* outlier_out, svgpu_ba_stats* stats) {
+    if (!allreduce) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: allreduce callback is required");
+    return local_ba_impl(ctx, shard, allreduce, allreduce_user, stop, pose_out, points_out, outlier_out, stats);
+}
+
+}  // extern "C"

@@ -26,7 +26,59 @@ int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes) {
     return SVGPU_OK;
 }
 
+void sv_prof_begin(svgpu_ctx* ctx, hipStream_t s, const char* name) {
+    SvProf& P = ctx->prof;
+    if (P.name != name) return;
+    if (P.used + 2 > P.ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            P.ev.push_back(e);
+        }
+    }
+    (void)hipEventRecord(P.ev[P.used], s);
+}
+void sv_prof_end(svgpu_ctx* ctx, hipStream_t s, const char* name) {
+    SvProf& P = ctx->prof;
+    if (P.name != name || P.used + 2 > P.ev.size()) return;
+    (void)hipEventRecord(P.ev[P.used + 1], s);
+    P.used += 2;
+}
+
 extern "C" {
+
+const char* svgpu_profile_kernels(void) {
+    return "k_resize,k_blur,k_fast,k_select,k_describe,k_bf_topk,k_bf_replay,k_cand,ba_linearize,ba_schur,ba_solve,ba_update,ba_chi2";
+}
+
+int svgpu_profile_select(svgpu_ctx* ctx, const char* kernel_name) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipDeviceSynchronize());
+    ctx->prof.name = kernel_name ? kernel_name : "";
+    ctx->prof.used = 0;
+    ctx->prof.total_ms = 0;
+    ctx->prof.launches = 0;
+    return SVGPU_OK;
+}
+
+int svgpu_profile_read(svgpu_ctx* ctx, double* total_ms, long long* launches) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipDeviceSynchronize());
+    SvProf& P = ctx->prof;
+    for (size_t i = 0; i + 1 < P.used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, P.ev[i], P.ev[i + 1]) == hipSuccess) {
+            P.total_ms += ms;
+            P.launches += 1;
+        }
+    }
+    P.used = 0;
+    if (total_ms) *total_ms = P.total_ms;
+    if (launches) *launches = P.launches;
+    return SVGPU_OK;
+}
 
 int svgpu_abi_version(void) { return SVGPU_ABI_VERSION; }
 
@@ -59,6 +111,7 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     sv_orb_release(ctx);
+    for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -54,10 +54,20 @@ struct OrbConfig {
     bool configured = false;
 };
 
+// Optional per-kernel timing with HIP events on the launch stream (svgpu_profile_select / _read).
+struct SvProf {
+    std::string name;  // kernel class being bracketed; empty = off
+    std::vector<hipEvent_t> ev;  // start/stop pairs
+    size_t used = 0;
+    double total_ms = 0;
+    long long launches = 0;
+};
+
 struct svgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
+    SvProf prof;
     OrbConfig orb;
     // device resources of the ORB path
     OrbLevel* d_levels = nullptr;
@@ -87,6 +97,19 @@ struct svgpu_ctx {
 };
 
 int sv_set_error(svgpu_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
+void sv_prof_begin(svgpu_ctx* ctx, hipStream_t s, const char* name);
+void sv_prof_end(svgpu_ctx* ctx, hipStream_t s, const char* name);
+struct SvProfScope {  // brackets the launches issued inside its lifetime when `name` is the selected kernel class
+    svgpu_ctx* c;
+    hipStream_t s;
+    const char* n;
+    SvProfScope(svgpu_ctx* ctx, hipStream_t st, const char* name) : c(ctx), s(st), n(name) {
+        if (!c->prof.name.empty()) sv_prof_begin(c, s, n);
+    }
+    ~SvProfScope() {
+        if (!c->prof.name.empty()) sv_prof_end(c, s, n);
+    }
+};
 int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes);
 void sv_orb_release(svgpu_ctx* ctx);
 

@@ -97,7 +97,7 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
     int* g_match = A.take<int>((size_t)pairs * cap2);
     P.matched = matched_dev;
     P.num = num_dev;
-    sv_launch_bf(stream ? (hipStream_t)stream : ctx->stream, P, pairs, g_owner, g_match);
+    sv_launch_bf(ctx, stream ? (hipStream_t)stream : ctx->stream, P, pairs, g_owner, g_match);
     SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
 }
@@ -151,7 +151,7 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
     P.valid2 = valid2 ? v2 : nullptr;
     P.lowe_ratio = lowe_ratio;
     P.check_orientation = check_orientation;
-    sv_launch_bf(s, P, 1, g_owner, g_match);
+    sv_launch_bf(ctx, s, P, 1, g_owner, g_match);
     SV_HIP(ctx, hipGetLastError());
     int32_t num = 0;
     SV_HIP(ctx, hipMemcpyAsync(matched_2_in_1, P.matched, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
@@ -232,7 +232,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     P.num = A.take<int32_t>(1);
     int* owner = A.take<int>(nt);
     int* match = A.take<int>(nq);
-    sv_launch_cand(s, P, owner, match);
+    sv_launch_cand(ctx, s, P, owner, match);
     SV_HIP(ctx, hipGetLastError());
     int32_t num = 0;
     SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));

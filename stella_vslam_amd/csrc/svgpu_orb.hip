@@ -2,7 +2,7 @@
 // host arithmetic), device workspace layout, launch sequence.
 //   orb_params scale tables        feature/orb_params.cc:41-71
 //   level sizes                    feature/orb_extractor.cc:157-159
-//   cv::resize coefficient tables  OpenCV 4.x imgproc/src/resize.cpp (see oracle/orb_oracle.c header)
+//   cv::resize coefficient tables  OpenCV 4.x imgproc/src/resize.cpp (8-bit fixed point, 11-bit coefficients)
 //   FAST cell lattice              feature/orb_extractor.cc:179-217
 //   selection grid                 feature/orb_extractor.cc:292-305
 #include <cmath>
@@ -279,6 +279,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     const int Lc = C.num_levels;
     // 1. pyramid: chained bilinear resize (level l from level l-1)
     for (int l = 1; l < Lc; ++l) {
+        SvProfScope ps(ctx, s, "k_resize");
         const OrbLevel& D = C.levels[l];
         const OrbLevel& P = C.levels[l - 1];
         const uint8_t* src = l == 1 ? imgs_dev : ctx->d_pyr + P.pyr_off;
@@ -289,15 +290,25 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
                          batch);
     }
     // 2. blurred copy of every level
-    sv_launch_blur(s, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
-                   ctx->d_blur, C.blur_frame_bytes, batch);
+    {
+        SvProfScope ps(ctx, s, "k_blur");
+        sv_launch_blur(s, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
+                       ctx->d_blur, C.blur_frame_bytes, batch);
+    }
     // 3. FAST per cell + selection-grid arg-max
-    sv_launch_fast(s, ctx->d_levels, Lc, ctx->d_cells, (int)C.cells.size(), imgs_dev, frame_stride, row_stride, ctx->d_pyr,
+    {
+        SvProfScope ps(ctx, s, "k_fast");
+        sv_launch_fast(s, ctx->d_levels, Lc, ctx->d_cells, (int)C.cells.size(), imgs_dev, frame_stride, row_stride, ctx->d_pyr,
                    C.pyr_frame_bytes, ctx->d_gtab, ctx->d_keys, C.total_grid, C.ini_thr, C.min_thr, mask_dev,
-                   mask_frame_stride, mask_row_stride, C.width, C.height, batch);
+                       mask_frame_stride, mask_row_stride, C.width, C.height, batch);
+    }
     // 4. ordered compaction (+ key reset for the next call)
-    sv_launch_select(s, ctx->d_levels, Lc, ctx->d_keys, C.total_grid, ctx->d_sel, counts_dev, batch);
+    {
+        SvProfScope ps(ctx, s, "k_select");
+        sv_launch_select(s, ctx->d_levels, Lc, ctx->d_keys, C.total_grid, ctx->d_sel, counts_dev, batch);
+    }
     // 5. orientation, descriptor, scale correction
+    SvProfScope ps(ctx, s, "k_describe");
     sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
                        ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch);
     SV_HIP(ctx, hipGetLastError());

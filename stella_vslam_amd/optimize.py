@@ -1,0 +1,68 @@
+"""Python mirror of stella_vslam::optimize::local_bundle_adjuster over the C ABI.
+
+Reference interface: optimize/local_bundle_adjuster.h:15-24 -- optimize(map_db, curr_keyfrm, force_stop_flag);
+created by local_bundle_adjuster_factory (backend "g2o" / "gtsam"; this one registers as "hip").  The object
+graph gather (local_bundle_adjuster_g2o.cc:38-147) and the write-back (:352-430) are host-side steps of the C++
+adaptor (stella_vslam_amd/host/local_bundle_adjuster_hip.h); the flat problem they exchange is what
+`optimize_flat` takes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+from .feature import Context
+
+
+class _BaProblem(C.Structure):
+    _fields_ = [("num_poses", C.c_int32), ("num_points", C.c_int32), ("num_obs", C.c_int32),
+                ("pose_cw", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p), ("point_fixed", C.c_void_p),
+                ("obs_pose", C.c_void_p), ("obs_point", C.c_void_p), ("obs_uvr", C.c_void_p),
+                ("obs_inv_sigma_sq", C.c_void_p), ("obs_huber_delta", C.c_void_p), ("intrinsics", C.c_void_p),
+                ("num_first_iter", C.c_int32), ("num_second_iter", C.c_int32), ("gain_threshold", C.c_double)]
+
+
+class _BaStats(C.Structure):
+    _fields_ = [("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("iters_stage1", C.c_int32),
+                ("iters_stage2", C.c_int32), ("stage2_entered", C.c_int32), ("num_gated", C.c_int32),
+                ("lm_trials", C.c_int32), ("cholesky_failures", C.c_int32), ("lambda_final", C.c_double)]
+
+
+def local_bundle_adjuster_factory_create(backend: str = "hip", **kw):
+    """optimize/local_bundle_adjuster_factory.h:17-32 -- the backend switch."""
+    if backend != "hip":
+        raise RuntimeError(f"Invalid backend: {backend} (this build provides 'hip' only)")
+    return local_bundle_adjuster(**kw)
+
+
+class local_bundle_adjuster:
+    def __init__(self, num_first_iter: int = 5, num_second_iter: int = 10, ctx: Context | None = None):
+        self.num_first_iter_ = num_first_iter
+        self.num_second_iter_ = num_second_iter
+        self.ctx = ctx or Context()
+
+    def optimize_flat(self, scene: dict, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
+        """scene keys: pose_cw (P,12) f64, pose_fixed (P) u8, points (L,3) f64, [point_fixed (L) u8], obs_pose / obs_point (E) i32,
+        obs_uvr (E,3) f32, obs_inv_sigma_sq (E) f32, obs_huber (E) f32, intr (P,5) f64.
+        force_stop_flag: None or a writable uint8[1] (the caller's abort flag; may be SET by the terminate rule)."""
+        a = lambda k, t: np.ascontiguousarray(scene[k], t)
+        pose, pts = a("pose_cw", np.float64), a("points", np.float64)
+        keep = [pose, pts, a("pose_fixed", np.uint8), a("obs_pose", np.int32), a("obs_point", np.int32), a("obs_uvr", np.float32),
+                a("obs_inv_sigma_sq", np.float32), a("obs_huber", np.float32), a("intr", np.float64)]
+        pf = scene.get("point_fixed")
+        pf = None if pf is None else np.ascontiguousarray(pf, np.uint8)
+        P, L, E = len(pose), len(pts), len(keep[3])
+        ptr = lambda x: None if x is None else x.ctypes.data
+        prob = _BaProblem(P, L, E, ptr(pose), ptr(keep[2]), ptr(pts), ptr(pf), ptr(keep[3]), ptr(keep[4]), ptr(keep[5]),
+                          ptr(keep[6]), ptr(keep[7]), ptr(keep[8]), self.num_first_iter_, self.num_second_iter_, gain_threshold)
+        pose_out, pts_out = np.zeros_like(pose), np.zeros_like(pts)
+        outl = np.zeros(max(E, 1), np.uint8)
+        st = _BaStats()
+        rc = lib().svgpu_local_ba(self.ctx.handle, C.byref(prob), None if force_stop_flag is None else C.c_void_p(force_stop_flag.ctypes.data),
+                                  C.c_void_p(pose_out.ctypes.data), C.c_void_p(pts_out.ctypes.data), C.c_void_p(outl.ctypes.data),
+                                  C.byref(st))
+        self.ctx.check(rc, "svgpu_local_ba", ok=(0, 7))
+        return dict(rc=rc, pose_cw=pose_out, points=pts_out, outlier=outl[:E].copy(),
+                    stats={f: getattr(st, f) for f, _ in _BaStats._fields_})
