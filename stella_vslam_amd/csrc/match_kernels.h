@@ -19,6 +19,8 @@ struct BfProblem {
     const uint8_t* valid2;  // nullable
     float lowe_ratio;
     int check_orientation;
+    unsigned dmax;        // candidates farther than this are never listed (see k_bf_topk)
+    int exhaustive;       // 1 when dmax >= 256: the list is a plain prefix of all candidates
     uint32_t* topk;       // pairs * cap2 * BF_K
     int32_t* cnt;         // pairs * cap2
     int32_t* matched;     // pairs * cap1

@@ -63,19 +63,24 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ brute force
-// One thread per query (keyframe keypoint idx_2); candidates (frame keypoints idx_1) stream through LDS.
-// topk[q][k] = (dist << 16 | idx_1) ascending = the reference's scan preference (strict '<' => lowest index wins ties).
+// Block = 64 queries (keyframe keypoints idx_2) x 4 candidate quarters: wave w scans quarter w of the frame
+// keypoints idx_1 for its 64 queries.  The candidate index is wave-uniform, so candidate descriptors and
+// angles arrive through the scalar cache (s_load) and never touch LDS; each lane keeps the BF_K smallest
+// (dist << 16 | idx_1) keys of its quarter in registers, the four sorted lists are merged through LDS.
+// Ascending key order = the reference's scan preference (strict '<' => lowest index wins ties).
 __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
-    __shared__ uint32_t s_d[256 * 8];
-    __shared__ float s_a[256];
+    __shared__ uint32_t s_l[4 * 64 * (BF_K + 1)];
+    __shared__ int s_c[4 * 64];
     const int pair = blockIdx.y;
     const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= n2c) return;
-    const uint32_t* D1 = P.desc1 + (size_t)pair * P.cap1 * 8;
-    const uint32_t* D2 = P.desc2 + (size_t)pair * P.cap2 * 8;
+    if (blockIdx.x * 64 >= n2c) return;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const uint32_t* __restrict__ D1 = P.desc1 + (size_t)pair * P.cap1 * 8;
+    const uint32_t* __restrict__ D2 = P.desc2 + (size_t)pair * P.cap2 * 8;
+    const float* __restrict__ A1 = P.angle1 + (size_t)pair * P.cap1 * P.angle_stride;
     const bool active = j < n2c && (!P.valid2 || P.valid2[(size_t)pair * P.cap2 + j]);
     uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float qa = 0.f;
@@ -88,36 +93,89 @@ __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
 #pragma unroll
     for (int k = 0; k < BF_K; ++k) L[k] = 0xFFFFFFFFu;
     int cnt = 0;
-    for (int base = 0; base < n1c; base += 256) {
-        const int m = min(256, n1c - base);
-        __syncthreads();
-        for (int i = threadIdx.x; i < m * 8; i += 256) s_d[i] = D1[(size_t)base * 8 + i];
-        if ((int)threadIdx.x < m) s_a[threadIdx.x] = P.angle1[((size_t)pair * P.cap1 + base + threadIdx.x) * P.angle_stride];
-        __syncthreads();
-        if (!active) continue;
-        for (int i = 0; i < m; ++i) {
-            if (P.check_orientation && fabsf(angle_diff(s_a[i], qa)) > 30.0f) continue;
-            const uint32_t key = (hamming256(q, &s_d[i * 8]) << 16) | (uint32_t)(base + i);
-            ++cnt;
-            if (key < L[BF_K - 1]) {
+    const int chunk = (n1c + 3) / 4;
+    const int i0 = __builtin_amdgcn_readfirstlane(part * chunk);
+    const int i1 = min(n1c, i0 + chunk);
+    const bool ori = P.check_orientation != 0;
+    // Only candidates with dist <= dmax can influence a decision (best must be <= 50, and the ratio test
+    // lowe_ratio * second < best can only reject when second < 50 / lowe_ratio): everything farther is never listed.
+    const unsigned dmax = P.dmax;
+    auto consider = [&](int i, unsigned d, float ca) {
+        if (d <= dmax) {  // rare: wave-level branch is almost never taken for unrelated descriptors
+            bool pass = active;
+            if (ori) pass = pass && !(fabsf(angle_diff(ca, qa)) > 30.0f);
+            if (pass) {
+                ++cnt;
+                const uint32_t key = (d << 16) | (uint32_t)i;
+                if (key < L[BF_K - 1]) {
 #pragma unroll
-                for (int k = BF_K - 1; k > 0; --k) L[k] = max(L[k - 1], min(L[k], key));
-                L[0] = min(L[0], key);
+                    for (int k = BF_K - 1; k > 0; --k) L[k] = max(L[k - 1], min(L[k], key));
+                    L[0] = min(L[0], key);
+                }
             }
         }
-    }
-    if (j < n2c) {
-        uint32_t* T = P.topk + ((size_t)pair * P.cap2 + j) * BF_K;
+    };
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {  // 4 candidates per trip: the scalar loads are issued back to back
+        uint32_t c[4][8];
+        float ca[4];
 #pragma unroll
-        for (int k = 0; k < BF_K; ++k) T[k] = L[k];
-        P.cnt[(size_t)pair * P.cap2 + j] = active ? cnt : 0;
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[u][k] = D1[(size_t)(i + u) * 8 + k];
+            ca[u] = A1[(size_t)(i + u) * P.angle_stride];
+        }
+        unsigned d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d[u] += __popc(q[k] ^ c[u][k]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) consider(i + u, d[u], ca[u]);
+    }
+    for (; i < i1; ++i) {
+        unsigned d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ D1[(size_t)i * 8 + k]);
+        consider(i, d, A1[(size_t)i * P.angle_stride]);
+    }
+    // merge the four quarter lists of each query (lane of wave 0 does a 4-way merge of sorted lists)
+    uint32_t* mine = &s_l[(part * 64 + lane) * (BF_K + 1)];
+#pragma unroll
+    for (int k = 0; k < BF_K; ++k) mine[k] = L[k];
+    mine[BF_K] = 0xFFFFFFFFu;  // sentinel
+    s_c[part * 64 + lane] = cnt;
+    __syncthreads();
+    if (part == 0 && j < n2c) {
+        const uint32_t* l0 = &s_l[(0 * 64 + lane) * (BF_K + 1)];
+        const uint32_t* l1 = &s_l[(1 * 64 + lane) * (BF_K + 1)];
+        const uint32_t* l2 = &s_l[(2 * 64 + lane) * (BF_K + 1)];
+        const uint32_t* l3 = &s_l[(3 * 64 + lane) * (BF_K + 1)];
+        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        uint32_t* T = P.topk + ((size_t)pair * P.cap2 + j) * BF_K;
+        for (int k = 0; k < BF_K; ++k) {
+            const uint32_t v0 = l0[p0], v1 = l1[p1], v2 = l2[p2], v3 = l3[p3];
+            const uint32_t m = min(min(v0, v1), min(v2, v3));
+            if (m == 0xFFFFFFFFu) {
+                T[k] = m;
+                continue;
+            }
+            if (m == v0) ++p0;
+            else if (m == v1) ++p1;
+            else if (m == v2) ++p2;
+            else ++p3;
+            T[k] = m;
+        }
+        P.cnt[(size_t)pair * P.cap2 + j] = s_c[lane] + s_c[64 + lane] + s_c[128 + lane] + s_c[192 + lane];
     }
 }
 
 // decision of one query given the owner table; returns idx_1 or -1
 __device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uint32_t* __restrict__ T, int cnt,
                          const int* owner) {
-    if (cnt == 0) return -1;
+    if (cnt == 0) return -1;  // no candidate within dmax: best > dmax >= 50
     const int m = min(cnt, BF_K);
     const bool truncated = cnt > BF_K;
     uint32_t a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu;
@@ -130,18 +188,19 @@ __device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uin
             break;
         }
     }
-    const unsigned d_last = T[m - 1] >> 16;
+    // The list holds the (at most BF_K) nearest of the candidates with dist <= dmax; if it is not truncated,
+    // every unlisted candidate is farther than dmax.
+    const unsigned d_beyond = truncated ? (T[m - 1] >> 16) : P.dmax + 1;  // lower bound on any unlisted distance
     if (a0 != 0xFFFFFFFFu) {
         const unsigned best = a0 >> 16;
         if (HAMMING_DIST_THR_LOW < best) return -1;
         if (a1 != 0xFFFFFFFFu) return (P.lowe_ratio * (float)(a1 >> 16) < (float)best) ? -1 : (int)(a0 & 0xFFFFu);
-        if (!truncated) return (P.lowe_ratio * (float)MAX_HAMMING_DIST < (float)best) ? -1 : (int)(a0 & 0xFFFFu);
-        // second best lies beyond the prefix: its distance is >= d_last
-        if (!(P.lowe_ratio * (float)d_last < (float)best) && P.lowe_ratio >= 0.f) return (int)(a0 & 0xFFFFu);
+        if (P.exhaustive && !truncated) return (P.lowe_ratio * (float)MAX_HAMMING_DIST < (float)best) ? -1 : (int)(a0 & 0xFFFFu);
+        // second best is unlisted: its distance is >= d_beyond
+        if (P.lowe_ratio >= 0.f && !(P.lowe_ratio * (float)d_beyond < (float)best)) return (int)(a0 & 0xFFFFu);
     }
     else {
-        if (!truncated) return -1;
-        if (d_last > HAMMING_DIST_THR_LOW) return -1;  // everything else is at least that far
+        if (d_beyond > HAMMING_DIST_THR_LOW) return -1;  // everything unlisted is at least that far
     }
     // ---- undecidable from the prefix: exact serial scan of this row (robust.cc:271-298)
     const uint32_t* D1 = P.desc1 + (size_t)pair * P.cap1 * 8;
@@ -324,11 +383,17 @@ void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const u
     if (n1 <= 0 || n2 <= 0) return;
     hipLaunchKernelGGL(k_hamming_matrix, dim3((n2 + 255) / 256), dim3(256), 0, s, d1, n1, d2, n2, out);
 }
-void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P, int pairs, int* g_owner, int* g_match) {
+void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs, int* g_owner, int* g_match) {
     if (pairs <= 0) return;
+    BfProblem P = P0;
+    // dmax: smallest cutoff such that lowe_ratio * (dmax + 1) >= 50 certainly holds (two units of slack for fp32 rounding)
+    if (P.lowe_ratio > 0.f && 50.0f / P.lowe_ratio + 2.0f < 256.0f) P.dmax = (unsigned)(50.0f / P.lowe_ratio) + 2u;
+    else P.dmax = 256u;
+    if (P.dmax < 50u) P.dmax = 50u;
+    P.exhaustive = P.dmax >= 256u;
     {
         SvProfScope ps(ctx, s, "k_bf_topk");
-        hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + 255) / 256, pairs), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + 63) / 64, pairs), dim3(256), 0, s, P);
     }
     SvProfScope ps(ctx, s, "k_bf_replay");
     const size_t lds = (size_t)(P.cap1 + P.cap2) * sizeof(int);

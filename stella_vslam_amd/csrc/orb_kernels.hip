@@ -421,24 +421,21 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     // ---- intensity centroid on the un-blurred level (orb_impl.cc:68-91); lanes = columns, two row halves
     int m10 = 0, m01 = 0;
     {
-        const int ul = lane & 31, u = ul - 15, au = u < 0 ? -u : u;
+        // lanes 0..30 take the rows v = 0,-1..-15, lanes 32..62 the rows v = 1..15; lane & 31 = column u + 15.
+        // All 16 row loads are issued unconditionally (clamped column) so that they overlap; the disc mask
+        // u_max_[|v|] is applied to the accumulation only.
+        const int ul = lane & 31, u = min(ul, 30) - 15, au = u < 0 ? -u : u;
+        const int sgn = lane < 32 ? -1 : 1;
+        const uint8_t* c = I + (size_t)y * ipitch + x + u;
+        int val[16];
+#pragma unroll
+        for (int v = 0; v <= 15; ++v) val[v] = c[(ptrdiff_t)(sgn * v) * ipitch];
         if (ul < 31) {
-            const uint8_t* c = I + (size_t)y * ipitch + x + u;
-            if (lane < 32) {
-                for (int v = 0; v <= 15; ++v)
-                    if (au <= c_umax[v]) {
-                        const int val = c[-(ptrdiff_t)v * ipitch];
-                        m10 += u * val;
-                        m01 -= v * val;
-                    }
-            }
-            else {
-                for (int v = 1; v <= 15; ++v)
-                    if (au <= c_umax[v]) {
-                        const int val = c[(ptrdiff_t)v * ipitch];
-                        m10 += u * val;
-                        m01 += v * val;
-                    }
+#pragma unroll
+            for (int v = 0; v <= 15; ++v) {
+                const bool in = au <= c_umax[v] && (v > 0 || lane < 32);
+                m10 += in ? u * val[v] : 0;
+                m01 += in ? sgn * v * val[v] : 0;
             }
         }
     }
