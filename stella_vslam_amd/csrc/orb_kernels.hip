@@ -74,14 +74,91 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 
 // ------------------------------------------------------------------------------------------------ blur
 // Fixed-point separable 7x7, taps {18,34,48,56,48,34,18}/256, out = (sum + 32768) >> 16, reflect-101.
-// Tile = 64 x 16 output pixels per 256-thread block, staged through LDS.
-#define BT_W 64
-#define BT_H 16
+// Streaming form, no LDS: a thread owns 4 adjacent columns and walks BLUR_ROWS rows downwards, keeping the last
+// seven rows of horizontal sums in registers.  A wave reads/writes 256 contiguous bytes per row.
+#define BLUR_ROWS 32
+#define BLUR_TW 256                 // tile width  = 64 threads x 4 px
+#define BLUR_TH (4 * BLUR_ROWS)     // tile height = 4 strips
+#define BLUR_EDGE_ROWS 8            // rows per thread in the (slow, gather-based) edge tiles
+struct BlurRow {  // the 12 source bytes [x0-4, x0+8) of one row (fast path) or pixels x0-3..x0+6 packed (edge path)
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ BlurRow blur_load(const uint8_t* __restrict__ row, int x0, int w, bool fast) {
+    BlurRow r;
+    if (fast) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(row + x0 - 4);
+        r.w0 = p[0];
+        r.w1 = p[1];
+        r.w2 = p[2];
+    }
+    else {  // image border: gather with reflect-101 into the same byte layout
+        uint32_t b[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) b[k] = row[reflect101(x0 - 4 + k, w)];
+        r.w0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        r.w1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        r.w2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
+    return r;
+}
+__device__ __forceinline__ void blur_hsum(const BlurRow& r, uint32_t (&h)[4]) {
+    uint32_t b[10];  // pixels x0-3 .. x0+6
+    b[0] = (r.w0 >> 8) & 255;
+    b[1] = (r.w0 >> 16) & 255;
+    b[2] = r.w0 >> 24;
+    b[3] = r.w1 & 255;
+    b[4] = (r.w1 >> 8) & 255;
+    b[5] = (r.w1 >> 16) & 255;
+    b[6] = r.w1 >> 24;
+    b[7] = r.w2 & 255;
+    b[8] = (r.w2 >> 8) & 255;
+    b[9] = (r.w2 >> 16) & 255;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = 18u * (b[j] + b[j + 6]) + 34u * (b[j + 1] + b[j + 5]) + 48u * (b[j + 2] + b[j + 4]) + 56u * b[j + 3];
+}
+
+// one thread: columns x0..x0+3, rows ys..ye-1
+template <bool FAST_PATH>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int spitch, int w, int h, uint8_t* __restrict__ dst,
+                                           int dpitch, int x0, int ys, int ye) {
+    auto row_ptr = [&](int y) { return src + (size_t)reflect101(y, h) * spitch; };
+    uint32_t H[7][4];
+    {
+        BlurRow r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = blur_load(row_ptr(ys - 3 + k), x0, w, FAST_PATH);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) blur_hsum(r[k], H[k]);
+    }
+    uint8_t* D = dst + x0;
+    BlurRow n0 = blur_load(row_ptr(ys + 3), x0, w, FAST_PATH);  // two rows of loads stay in flight ahead of the arithmetic
+    BlurRow n1 = blur_load(row_ptr(ys + 4), x0, w, FAST_PATH);
+    for (int y = ys; y < ye; ++y) {
+        const BlurRow cur = n0;
+        n0 = n1;
+        n1 = blur_load(row_ptr(y + 5), x0, w, FAST_PATH);
+        blur_hsum(cur, H[6]);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t acc = 18u * (H[0][j] + H[6][j]) + 34u * (H[1][j] + H[5][j]) + 48u * (H[2][j] + H[4][j]) + 56u * H[3][j];
+            packed |= ((acc + 32768u) >> 16) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(D + (size_t)y * dpitch) = packed;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) H[k][j] = H[k + 1][j];
+    }
+}
+
+// Tiles [0, btiles_x*btiles_y) of a level are interior tiles (aligned 12-byte windows, branch-free); the
+// last tile of the level is the EDGE tile: its threads redo the column groups that touch the left/right
+// image border with the generic reflect-101 gather.  Keeping the two roles in different workgroups keeps
+// every wave on a single code path.
 __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
                                               size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
                                               size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
-    __shared__ uint8_t s_in[(BT_H + 6) * 72];
-    __shared__ uint16_t s_h[(BT_H + 6) * BT_W];
     int tile;
     const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::btile_first, &tile);
     const OrbLevel lev = L[lv];
@@ -96,33 +173,31 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
         src = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
         spitch = lev.pitch;
     }
-    const int x0 = (tile % lev.btiles_x) * BT_W, y0 = (tile / lev.btiles_x) * BT_H;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < (BT_H + 6) * 70; i += 256) {
-        const int r = i / 70, c = i - r * 70;
-        const int sy = reflect101(y0 + r - 3, lev.h), sx = reflect101(x0 + c - 3, lev.w);
-        s_in[r * 72 + c] = src[(size_t)sy * spitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &s_in[r * 72 + c];
-        s_h[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-    }
-    __syncthreads();
-    const int r = tid >> 4, c4 = (tid & 15) * 4;
-    const int oy = y0 + r, ox = x0 + c4;
-    if (oy < lev.h && ox < lev.w) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint16_t* q = &s_h[r * BT_W + c4 + j];
-            const uint32_t acc = 18u * ((uint32_t)q[0] + q[6 * BT_W]) + 34u * ((uint32_t)q[BT_W] + q[5 * BT_W])
-                                 + 48u * ((uint32_t)q[2 * BT_W] + q[4 * BT_W]) + 56u * q[3 * BT_W];
-            packed |= ((acc + 32768u) >> 16) << (8 * j);
+    uint8_t* dst = blur + (size_t)b * blur_frame_bytes + lev.blur_off;
+    const bool aligned = ((((size_t)src) | (size_t)spitch) & 3) == 0;
+    const int main_tiles = lev.btiles_x * lev.btiles_y;
+    if (tile < main_tiles) {
+        const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
+        const int ys = (tile / lev.btiles_x) * BLUR_TH + (threadIdx.x >> 6) * BLUR_ROWS;
+        if (x0 >= lev.w || ys >= lev.h) return;
+        const bool interior = x0 >= 4 && x0 + 6 < lev.w;
+        if (aligned) {
+            if (interior) blur_strip<true>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
         }
-        uint8_t* D = blur + (size_t)b * blur_frame_bytes + lev.blur_off + (size_t)oy * lev.pitch + ox;
-        *reinterpret_cast<uint32_t*>(D) = packed;
+        else blur_strip<false>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
+    }
+    else if (aligned) {
+        // edge groups: x0 = 0 and every group with x0 + 6 >= w (at most two); thread = (strip, which)
+        const int which = threadIdx.x & 3, strip = (tile - main_tiles) * 64 + (threadIdx.x >> 2);
+        const int ys = strip * BLUR_EDGE_ROWS;
+        const int last = ((lev.w - 1) >> 2) << 2;
+        int x0;
+        if (which == 0) x0 = 0;
+        else if (which == 1) x0 = last;
+        else if (which == 2) x0 = last - 4;
+        else return;
+        if (ys >= lev.h || x0 < 0 || (which != 0 && (x0 == 0 || x0 + 6 < lev.w))) return;
+        blur_strip<false>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_EDGE_ROWS, lev.h));
     }
 }
 
@@ -168,16 +243,17 @@ __device__ __forceinline__ bool run_of_9(uint32_t m16) {
     return (r & 0xFFFFu) != 0;
 }
 
-#define FP 72  // LDS pitch of the ROI arrays
+#define FP 76  // LDS pitch of the ROI arrays: 3 skew bytes + 70 + padding to a multiple of 4
 __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells,
                                               const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
                                               const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                               const unsigned short* __restrict__ gtab, unsigned long long* __restrict__ keys,
                                               int total_grid, int ini_thr, int min_thr, const uint8_t* __restrict__ mask,
                                               size_t mask_frame_stride, int mask_pitch, int mask_w, int mask_h) {
-    __shared__ uint8_t s_img[SV_ROI_MAX * FP];
-    __shared__ uint8_t s_a[SV_ROI_MAX * FP];
-    __shared__ int s_count;
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[SV_ROI_MAX * FP + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[SV_ROI_MAX * FP];
+    __shared__ unsigned short s_q[SV_CELL * SV_CELL];
+    __shared__ int s_count, s_qn;
     int local;
     const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::cell_first, &local);
     const OrbLevel lev = L[lv];
@@ -205,82 +281,122 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         src = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
         spitch = lev.pitch;
     }
-    src += (size_t)cell.min_y * spitch + cell.min_x;
     const int w = cell.w, h = cell.h;
-    for (int i = tid; i < SV_ROI_MAX * FP; i += 256) {
-        const int r = i / FP, c = i - r * FP;
-        s_img[i] = (r < h && c < w) ? src[(size_t)r * spitch + c] : 0;
-        s_a[i] = 0;
+    // ROI -> LDS.  The ROI starts at x = 19 + 64j, i.e. 3 bytes past a 16-byte boundary: load the aligned words that
+    // cover it (the 3 leading bytes are real pixels of the border band) and address the LDS copy with a +3 skew.
+    const uint8_t* rsrc = src + (size_t)cell.min_y * spitch + (cell.min_x - 3);
+    uint8_t* const s_img = s_raw + 3;
+    if (((((size_t)src) | (size_t)spitch) & 3) == 0) {
+        const int words = (w + 3 + 3) >> 2;  // bytes [-3, w) rounded up to words; the row pitch (multiple of 64) covers it
+        for (int i = tid; i < SV_ROI_MAX * (FP / 4); i += 256) {
+            const int r = i / (FP / 4), c = i - r * (FP / 4);
+            uint32_t v = 0;
+            if (r < h && c < words) v = *reinterpret_cast<const uint32_t*>(rsrc + (size_t)r * spitch + 4 * c);
+            reinterpret_cast<uint32_t*>(s_raw)[i] = v;
+            reinterpret_cast<uint32_t*>(s_a)[i] = 0;
+        }
     }
-    if (tid == 0) s_count = 0;
+    else {
+        for (int i = tid; i < SV_ROI_MAX * FP; i += 256) {
+            const int r = i / FP, c = i - r * FP;
+            s_raw[i] = (r < h && c < w + 3) ? rsrc[(size_t)r * spitch + c] : 0;
+            s_a[i] = 0;
+        }
+    }
+    if (tid == 0) {
+        s_count = 0;
+        s_qn = 0;
+    }
     __syncthreads();
 
     const int tq = min(ini_thr, min_thr);
     const int lx = 3 + (tid & 63);
-    // --- arc scores for the scored band [3, w-3) x [3, h-3)
-    if (lx < w - 3) {
-        for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
+    auto load_ring = [&](const uint8_t* c, int (&p)[16]) {
+        p[0] = c[3 * FP];
+        p[1] = c[3 * FP + 1];
+        p[2] = c[2 * FP + 2];
+        p[3] = c[FP + 3];
+        p[4] = c[3];
+        p[5] = c[-FP + 3];
+        p[6] = c[-2 * FP + 2];
+        p[7] = c[-3 * FP + 1];
+        p[8] = c[-3 * FP];
+        p[9] = c[-3 * FP - 1];
+        p[10] = c[-2 * FP - 2];
+        p[11] = c[-FP - 3];
+        p[12] = c[-3];
+        p[13] = c[FP - 3];
+        p[14] = c[2 * FP - 2];
+        p[15] = c[3 * FP - 1];
+    };
+    // --- pass A: every pixel of the scored band [3, w-3) x [3, h-3): is there a 9-arc at the lower threshold?
+    //     Candidates (a few percent of the pixels) are compacted into an LDS queue so that the expensive
+    //     arc score below runs on full waves instead of on the union of sparse lanes.
+    for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
+        bool cand = false;
+        if (lx < w - 3) {
             const uint8_t* c = &s_img[ly * FP + lx];
             const int v = c[0];
             int p[16];
-            p[0] = c[3 * FP];
-            p[1] = c[3 * FP + 1];
-            p[2] = c[2 * FP + 2];
-            p[3] = c[FP + 3];
-            p[4] = c[3];
-            p[5] = c[-FP + 3];
-            p[6] = c[-2 * FP + 2];
-            p[7] = c[-3 * FP + 1];
-            p[8] = c[-3 * FP];
-            p[9] = c[-3 * FP - 1];
-            p[10] = c[-2 * FP - 2];
-            p[11] = c[-FP - 3];
-            p[12] = c[-3];
-            p[13] = c[FP - 3];
-            p[14] = c[2 * FP - 2];
-            p[15] = c[3 * FP - 1];
+            load_ring(c, p);
             uint32_t bright = 0, dark = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 bright |= (uint32_t)(p[k] > v + tq) << k;
                 dark |= (uint32_t)(p[k] < v - tq) << k;
             }
-            if (run_of_9(bright) || run_of_9(dark)) s_a[ly * FP + lx] = (uint8_t)arc_score16(v, p);
+            cand = run_of_9(bright) || run_of_9(dark);
         }
+        const unsigned long long bal = __ballot(cand);
+        if (bal) {
+            int base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&s_qn, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (cand) s_q[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
+        }
+    }
+    __syncthreads();
+    // --- pass B: arc score of the candidates
+    for (int i = tid; i < s_qn; i += 256) {
+        const int ly = s_q[i] >> 7, qx = s_q[i] & 127;
+        const uint8_t* c = &s_img[ly * FP + qx];
+        int p[16];
+        load_ring(c, p);
+        s_a[ly * FP + qx] = (uint8_t)arc_score16(c[0], p);
     }
     __syncthreads();
 
     // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
     const int gx_off = lev.gtab_x_off, gy_off = lev.gtab_y_off;
     unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
+    const int qn = s_qn;
     for (int pass = 0; pass < 2; ++pass) {
         const int t = pass == 0 ? ini_thr : min_thr;
         int found = 0;
-        if (lx < w - 3) {
-            for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
-                const uint8_t* a = &s_a[ly * FP + lx];
-                const int A = a[0];
-                if (A <= t) continue;
-                const int s = A - 1;
-                bool keep = true;
+        for (int i = tid; i < qn; i += 256) {  // only queued pixels can have A > t (t >= tq)
+            const int ly = s_q[i] >> 7, qx = s_q[i] & 127;
+            const uint8_t* a = &s_a[ly * FP + qx];
+            const int A = a[0];
+            if (A <= t) continue;
+            const int s = A - 1;
+            bool keep = true;
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (dx == 0 && dy == 0) continue;
-                        const int n = a[dy * FP + dx];
-                        const int sn = n > t ? n - 1 : 0;
-                        keep = keep && (s > sn);
-                    }
-                if (!keep) continue;
-                ++found;
-                const int x_level = cell.min_x + lx, y_level = cell.min_y + ly;
-                if (M && masked(y_level, x_level)) continue;  // keypoint filter (:246-256), after the retry decision
-                const int gx = gtab[gx_off + x_level - SV_PATCH_RADIUS], gy = gtab[gy_off + y_level - SV_PATCH_RADIUS];
-                const uint32_t order = (uint32_t)cell.order_base | ((uint32_t)ly << 7) | (uint32_t)lx;
-                const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (0xFFFFFFFFu - order);
-                atomicMax(&K[gy * lev.grid_x + gx], key);
-            }
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int n = a[dy * FP + dx];
+                    const int sn = n > t ? n - 1 : 0;
+                    keep = keep && (s > sn);
+                }
+            if (!keep) continue;
+            ++found;
+            const int x_level = cell.min_x + qx, y_level = cell.min_y + ly;
+            if (M && masked(y_level, x_level)) continue;  // keypoint filter (:246-256), after the retry decision
+            const int gx = gtab[gx_off + x_level - SV_PATCH_RADIUS], gy = gtab[gy_off + y_level - SV_PATCH_RADIUS];
+            const uint32_t order = (uint32_t)cell.order_base | ((uint32_t)ly << 7) | (uint32_t)qx;
+            const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (0xFFFFFFFFu - order);
+            atomicMax(&K[gy * lev.grid_x + gx], key);
         }
         if (found) atomicAdd(&s_count, found);
         __syncthreads();
