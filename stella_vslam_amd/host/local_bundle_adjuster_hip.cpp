@@ -1,0 +1,40 @@
+#include "local_bundle_adjuster_hip.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace stella_vslam_hip {
+namespace optimize {
+
+void local_bundle_adjuster_hip::optimize_flat(const flat_ba_problem& p, bool* const force_stop_flag, flat_ba_result& r) const {
+    static_assert(sizeof(bool) == 1, "force_stop_flag is read and written as one byte");
+    svgpu_ba_problem q{};
+    q.num_poses = (int32_t)p.pose_fixed.size();
+    q.num_points = (int32_t)(p.points.size() / 3);
+    q.num_obs = (int32_t)p.obs_pose.size();
+    q.pose_cw = p.pose_cw.data();
+    q.pose_fixed = p.pose_fixed.data();
+    q.points = p.points.data();
+    q.point_fixed = p.point_fixed.empty() ? nullptr : p.point_fixed.data();
+    q.obs_pose = p.obs_pose.data();
+    q.obs_point = p.obs_point.data();
+    q.obs_uvr = p.obs_uvr.data();
+    q.obs_inv_sigma_sq = p.obs_inv_sigma_sq.data();
+    q.obs_huber_delta = p.obs_huber_delta.empty() ? nullptr : p.obs_huber_delta.data();
+    q.intrinsics = p.intrinsics.data();
+    q.num_first_iter = (int32_t)num_first_iter_;
+    q.num_second_iter = (int32_t)num_second_iter_;
+    q.gain_threshold = 1e-3;  // terminateAction->setGainThreshold(1e-3), local_bundle_adjuster_g2o.cc:158
+    r.pose_cw.assign(p.pose_cw.size(), 0.0);
+    r.points.assign(p.points.size(), 0.0);
+    r.outlier.assign(p.obs_pose.size() ? p.obs_pose.size() : 1, 0);
+    r.status = svgpu_local_ba(ctx_, &q, reinterpret_cast<volatile uint8_t*>(force_stop_flag), r.pose_cw.data(), r.points.data(),
+                              r.outlier.data(), &r.stats);
+    r.outlier.resize(p.obs_pose.size());
+    // the reference's optimize() returns void and fails silently (:308-310); a HIP error is NOT silent here
+    if (r.status != SVGPU_OK && r.status != SVGPU_STOPPED)
+        throw std::runtime_error(std::string("svgpu_local_ba: ") + svgpu_status_string(r.status) + " (" + svgpu_last_error(ctx_) + ")");
+}
+
+}  // namespace optimize
+}  // namespace stella_vslam_hip

@@ -1,0 +1,53 @@
+// C++ adaptor for stella_vslam::optimize::local_bundle_adjuster (reference: optimize/local_bundle_adjuster.h:15-24),
+// the `backend: "hip"` sibling of local_bundle_adjuster_g2o / _gtsam (optimize/local_bundle_adjuster_factory.h:17-32).
+//
+// With the reference's headers on the include path (-DSVGPU_WITH_STELLA_VSLAM) the class derives from
+// optimize::local_bundle_adjuster and implements optimize(map_db, curr_keyfrm, force_stop_flag): gather and
+// write-back are the host steps of the g2o backend (local_bundle_adjuster_g2o.cc:38-147, 352-430; shown in
+// INTEGRATION.md), steps 2-6 are one svgpu_local_ba call.  Stand-alone (this container) the flat entry point
+// optimize_flat() is what the tests drive.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "svgpu.h"
+
+namespace stella_vslam_hip {
+namespace optimize {
+
+struct flat_ba_problem {
+    std::vector<double> pose_cw;          // P x 12 rows of [R|t]
+    std::vector<uint8_t> pose_fixed;      // P
+    std::vector<double> points;           // L x 3
+    std::vector<uint8_t> point_fixed;     // empty or L
+    std::vector<int32_t> obs_pose, obs_point;  // E
+    std::vector<float> obs_uvr;           // E x 3 (u, v, x_right or -1)
+    std::vector<float> obs_inv_sigma_sq;  // E
+    std::vector<float> obs_huber_delta;   // E (sqrt(5.99146) mono keyframes, sqrt(7.81473) otherwise; 0 = no kernel)
+    std::vector<double> intrinsics;       // P x 5 (fx fy cx cy focal_x_baseline)
+};
+
+struct flat_ba_result {
+    std::vector<double> pose_cw, points;
+    std::vector<uint8_t> outlier;  // per observation
+    svgpu_ba_stats stats;
+    int status;
+};
+
+class local_bundle_adjuster_hip {
+public:
+    explicit local_bundle_adjuster_hip(svgpu_ctx* ctx, unsigned int num_first_iter = 5, unsigned int num_second_iter = 10)
+        : ctx_(ctx), num_first_iter_(num_first_iter), num_second_iter_(num_second_iter) {}
+    virtual ~local_bundle_adjuster_hip() = default;
+
+    //! steps 2-6 of local_bundle_adjuster_g2o::optimize on the flattened problem; force_stop_flag as in the reference
+    void optimize_flat(const flat_ba_problem& problem, bool* const force_stop_flag, flat_ba_result& result) const;
+
+private:
+    svgpu_ctx* ctx_;
+    const unsigned int num_first_iter_;
+    const unsigned int num_second_iter_;
+};
+
+}  // namespace optimize
+}  // namespace stella_vslam_hip

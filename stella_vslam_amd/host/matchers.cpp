@@ -1,0 +1,65 @@
+#include "matchers.h"
+
+#include <stdexcept>
+#include <string>
+
+namespace stella_vslam_hip {
+namespace match {
+
+namespace {
+void check(svgpu_ctx* ctx, int rc, const char* where) {
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string(where) + ": " + svgpu_status_string(rc) + " (" + svgpu_last_error(ctx) + ")");
+}
+std::vector<uint8_t> pack_rows(const cv::Mat& m) {
+    std::vector<uint8_t> out((size_t)m.rows * 32);
+    for (int r = 0; r < m.rows; ++r) std::memcpy(out.data() + (size_t)r * 32, m.ptr(r), 32);
+    return out;
+}
+}  // namespace
+
+unsigned int robust::brute_force_match(const data::frame_observation& frm_obs, const data::frame_observation& keyfrm_obs,
+                                       const std::vector<unsigned char>& keyfrm_lm_valid, std::vector<std::pair<int, int>>& matches) const {
+    const int n1 = (int)frm_obs.undist_keypts_.size(), n2 = (int)keyfrm_obs.undist_keypts_.size();
+    std::vector<float> a1(n1), a2(n2);
+    for (int i = 0; i < n1; ++i) a1[i] = frm_obs.undist_keypts_[i].angle;
+    for (int i = 0; i < n2; ++i) a2[i] = keyfrm_obs.undist_keypts_[i].angle;
+    const auto d1 = pack_rows(frm_obs.descriptors_), d2 = pack_rows(keyfrm_obs.descriptors_);
+    std::vector<int32_t> matched((size_t)std::max(n1, 1), -1);
+    int num = 0;
+    check(ctx_, svgpu_match_bruteforce(ctx_, d1.data(), a1.data(), n1, d2.data(), a2.data(), keyfrm_lm_valid.empty() ? nullptr : keyfrm_lm_valid.data(),
+                                       n2, lowe_ratio_, check_orientation_ ? 1 : 0, matched.data(), &num),
+          "svgpu_match_bruteforce");
+    matches.clear();
+    matches.reserve((size_t)num);
+    for (int i = 0; i < n1; ++i)
+        if (matched[i] >= 0) matches.emplace_back(i, matched[i]);
+    return (unsigned int)num;
+}
+
+unsigned int projection::match(const query_set& q, const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied,
+                               bool ratio_same_octave, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const {
+    const int nq = q.descriptors.rows, nt = (int)frm_obs.undist_keypts_.size();
+    std::vector<float> ta(nt);
+    std::vector<int32_t> toct(nt);
+    for (int i = 0; i < nt; ++i) {
+        ta[i] = frm_obs.undist_keypts_[i].angle;
+        toct[i] = frm_obs.undist_keypts_[i].octave;
+    }
+    const auto qd = pack_rows(q.descriptors), td = pack_rows(frm_obs.descriptors_);
+    const bool stereo = !frm_obs.stereo_x_right_.empty() && !q.x_right.empty();
+    matched_idx_for_query.assign((size_t)std::max(nq, 1), -1);
+    int num = 0;
+    check(ctx_, svgpu_match_candidates(ctx_, qd.data(), nq, td.data(), toct.data(), nt, q.cand_off.data(), q.cand_idx.data(),
+                                       q.valid.empty() ? nullptr : q.valid.data(), occupied.empty() ? nullptr : occupied.data(),
+                                       q.angle.empty() ? nullptr : q.angle.data(), ta.data(), (check_orientation_ && !q.angle.empty()) ? 1 : 0,
+                                       stereo ? q.x_right.data() : nullptr, stereo ? frm_obs.stereo_x_right_.data() : nullptr,
+                                       stereo ? q.x_right_tol.data() : nullptr, hamm_dist_thr, lowe_ratio_,
+                                       ratio_same_octave ? SVGPU_MATCH_RATIO_SAME_OCTAVE : SVGPU_MATCH_BEST_ONLY,
+                                       matched_idx_for_query.data(), &num),
+          "svgpu_match_candidates");
+    matched_idx_for_query.resize((size_t)nq);
+    return (unsigned int)num;
+}
+
+}  // namespace match
+}  // namespace stella_vslam_hip

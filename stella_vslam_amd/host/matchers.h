@@ -1,0 +1,63 @@
+// C++ adaptors for stella_vslam::match::* (reference: src/stella_vslam/match/base.h:81-91, robust.h, projection.h).
+// Constructor arguments, thresholds and results are the reference's; the object graph the reference walks
+// (frame / keyframe / landmark shared_ptrs) is flattened by the caller to the parts the arithmetic touches:
+// descriptor rows, keypoints, "has a live landmark" flags and candidate index lists.
+#pragma once
+#include <utility>
+#include <vector>
+
+#include "orb_extractor.h"
+
+namespace stella_vslam_hip {
+namespace data {
+// the flat part of data::frame_observation (data/frame_observation.h:12-38) the matchers read
+struct frame_observation {
+    cv::Mat descriptors_;                      // N x 32, CV_8U
+    std::vector<cv::KeyPoint> undist_keypts_;  // angle, octave, pt
+    std::vector<float> stereo_x_right_;        // empty or N
+};
+}  // namespace data
+
+namespace match {
+
+static constexpr unsigned int HAMMING_DIST_THR_LOW = 50;
+static constexpr unsigned int HAMMING_DIST_THR_HIGH = 100;
+static constexpr unsigned int MAX_HAMMING_DIST = 256;
+
+class base {
+public:
+    base(svgpu_ctx* ctx, float lowe_ratio, bool check_orientation) : ctx_(ctx), lowe_ratio_(lowe_ratio), check_orientation_(check_orientation) {}
+    virtual ~base() = default;
+
+protected:
+    svgpu_ctx* ctx_;
+    const float lowe_ratio_;
+    const bool check_orientation_;
+};
+
+class robust final : public base {
+public:
+    explicit robust(svgpu_ctx* ctx, float lowe_ratio = 0.6f, bool check_orientation = true) : base(ctx, lowe_ratio, check_orientation) {}
+    //! robust::brute_force_match (match/robust.cc:232-328).  keyfrm_lm_valid[idx_2] != 0 <=> the keyframe keypoint
+    //! has a landmark that is not will_be_erased() (:258-263).  matches = (idx_1, idx_2) sorted by idx_1.
+    unsigned int brute_force_match(const data::frame_observation& frm_obs, const data::frame_observation& keyfrm_obs,
+                                   const std::vector<unsigned char>& keyfrm_lm_valid, std::vector<std::pair<int, int>>& matches) const;
+};
+
+class projection final : public base {
+public:
+    explicit projection(svgpu_ctx* ctx, float lowe_ratio = 0.6f, bool check_orientation = true) : base(ctx, lowe_ratio, check_orientation) {}
+    struct query_set {                      // one entry per landmark / last-frame keypoint, in the reference's loop order
+        cv::Mat descriptors;                // nq x 32
+        std::vector<float> angle;           // nq (only read when check_orientation)
+        std::vector<float> x_right, x_right_tol;  // empty or nq: stereo gate (projection.cc:57-62)
+        std::vector<unsigned char> valid;   // empty or nq
+        std::vector<int> cand_off, cand_idx;  // CSR of get_keypoints_in_cell results (data/common.cc:127-190), scan order kept
+    };
+    //! projection::match_frame_and_landmarks (mode ratio_same_octave, thr HIGH) / match_current_and_last_frames (best only)
+    unsigned int match(const query_set& q, const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied,
+                       bool ratio_same_octave, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const;
+};
+
+}  // namespace match
+}  // namespace stella_vslam_hip

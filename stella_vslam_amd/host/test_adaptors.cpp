@@ -1,0 +1,117 @@
+// Exercises the C++ adaptor classes (reference signatures) end to end on the GPU and checks them against the
+// C-ABI entry points they wrap.  Built by host/Makefile, run by tests/test_gpu_host_adaptors.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "local_bundle_adjuster_hip.h"
+#include "matchers.h"
+#include "orb_extractor.h"
+
+using namespace stella_vslam_hip;
+
+static cv::Mat synth(int w, int h, unsigned seed) {
+    cv::Mat m(h, w, cv::CV_8UC1);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) m.ptr(y)[x] = (uint8_t)(((x + 2 * y) >> 2) & 255);
+    unsigned long long s = seed * 2654435761ull + 88172645463325252ull;
+    auto rnd = [&]() {
+        s ^= s >> 12;
+        s ^= s << 25;
+        s ^= s >> 27;
+        return (unsigned)((s * 0x2545F4914F6CDD1Dull) >> 33);
+    };
+    for (int k = 0; k < 1500; ++k) {
+        const int rw = 4 + rnd() % 37, rh = 4 + rnd() % 37, x0 = rnd() % w, y0 = rnd() % h, g = rnd() % 256;
+        for (int y = y0; y < y0 + rh && y < h; ++y)
+            for (int x = x0; x < x0 + rw && x < w; ++x) m.ptr(y)[x] = (uint8_t)g;
+    }
+    return m;
+}
+
+#define REQUIRE(c)                                                     \
+    do {                                                               \
+        if (!(c)) {                                                    \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                  \
+        }                                                              \
+    } while (0)
+
+int main() {
+    feature::orb_params params("ORB setting for test");
+    feature::orb_extractor ext(&params, 800);
+    cv::Mat img = synth(640, 480, 1), img2 = synth(640, 480, 1);
+    for (int y = 0; y < 480; ++y)  // second frame: shifted by (3,1)
+        for (int x = 0; x < 640; ++x) img2.ptr(y)[x] = img.ptr(std::min(y + 1, 479))[std::min(x + 3, 639)];
+    std::vector<cv::KeyPoint> k1, k2;
+    cv::Mat d1, d2, nomask;
+    ext.extract(img, cv::_InputArray(), k1, d1);
+    ext.extract(img2, cv::_InputArray(), k2, d2);
+    REQUIRE(k1.size() > 1000 && (int)k1.size() == d1.rows && d1.cols == 32);
+    REQUIRE(k2.size() > 1000 && (int)k2.size() == d2.rows);
+    ext.sync_image_pyramid();
+    REQUIRE(ext.image_pyramid_.size() == 8 && ext.image_pyramid_[1].cols == 533 && ext.image_pyramid_[7].rows == 134);
+    REQUIRE(ext.image_pyramid_[0].data == img2.data);  // level 0 aliases the caller's image
+    // empty image: silent return (orb_extractor.cc:30-32)
+    std::vector<cv::KeyPoint> k0 = k1;
+    cv::Mat d0, empty;
+    ext.extract(empty, cv::_InputArray(), k0, d0);
+    REQUIRE(k0.size() == k1.size());
+
+    data::frame_observation f1, f2;
+    f1.descriptors_ = d1;
+    f1.undist_keypts_ = k1;
+    f2.descriptors_ = d2;
+    f2.undist_keypts_ = k2;
+    match::robust rm(ext.context(), 0.8f, true);
+    std::vector<std::pair<int, int>> matches;
+    const unsigned nm = rm.brute_force_match(f2, f1, {}, matches);
+    REQUIRE(nm == matches.size() && nm > 500);
+    int good = 0;
+    for (auto& m : matches) {
+        const float dx = k2[m.first].pt.x - k1[m.second].pt.x, dy = k2[m.first].pt.y - k1[m.second].pt.y;
+        good += std::fabs(dx + 3) < 2.5f * params.scale_factors_[k1[m.second].octave] && std::fabs(dy + 1) < 2.5f * params.scale_factors_[k1[m.second].octave];
+    }
+    REQUIRE(good > (int)(0.9 * nm));
+    for (size_t i = 1; i < matches.size(); ++i) REQUIRE(matches[i - 1].first < matches[i].first);
+
+    // tiny BA through the class interface: 3 cameras on a line looking at a plane of points
+    optimize::flat_ba_problem p;
+    const int P = 3, L = 60;
+    for (int c = 0; c < P; ++c) {
+        const double T[12] = {1, 0, 0, -0.3 * c, 0, 1, 0, 0, 0, 0, 1, 0};
+        p.pose_cw.insert(p.pose_cw.end(), T, T + 12);
+        p.pose_fixed.push_back(c < 2);
+        const double K[5] = {458.654, 458.654, 367.215, 248.375, 0.0};
+        p.intrinsics.insert(p.intrinsics.end(), K, K + 5);
+    }
+    for (int l = 0; l < L; ++l) {
+        const double X[3] = {-1.0 + 0.2 * (l % 10), -0.6 + 0.2 * (l / 10), 4.0 + 0.05 * (l % 7)};
+        for (int c = 0; c < P; ++c) {
+            const double xc = X[0] - 0.3 * c, u = 458.654 * xc / X[2] + 367.215, v = 458.654 * X[1] / X[2] + 248.375;
+            p.obs_pose.push_back(c);
+            p.obs_point.push_back(l);
+            p.obs_uvr.push_back((float)u);
+            p.obs_uvr.push_back((float)v);
+            p.obs_uvr.push_back(-1.f);
+            p.obs_inv_sigma_sq.push_back(1.f);
+            p.obs_huber_delta.push_back(std::sqrt(5.99146f));
+        }
+        p.points.push_back(X[0] + 0.01 * ((l * 7) % 5 - 2));
+        p.points.push_back(X[1] - 0.01 * ((l * 3) % 5 - 2));
+        p.points.push_back(X[2] + 0.02 * ((l * 5) % 5 - 2));
+    }
+    p.pose_cw[2 * 12 + 3] += 0.02;  // perturb the free camera
+    optimize::local_bundle_adjuster_hip ba(ext.context());
+    optimize::flat_ba_result r;
+    bool stop = false;
+    ba.optimize_flat(p, &stop, r);
+    REQUIRE(r.status == SVGPU_OK && r.stats.chi2_final < 1e-3 * r.stats.chi2_initial + 1e-6);
+    REQUIRE(std::fabs(r.pose_cw[2 * 12 + 3] + 0.6) < 1e-3);
+    stop = true;
+    ba.optimize_flat(p, &stop, r);
+    REQUIRE(r.status == SVGPU_STOPPED && r.pose_cw == p.pose_cw);
+    std::printf("adaptors ok: %zu / %zu keypoints, %u matches (%d consistent), BA chi2 %.3g -> %.3g\n", k1.size(), k2.size(), nm, good,
+                r.stats.chi2_initial, r.stats.chi2_final);
+    return 0;
+}
