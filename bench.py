@@ -138,10 +138,8 @@ def main() -> int:
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from stella_vslam_amd.distributed import max_over_ranks
+    dt = max_over_ranks(dt)  # MAX over ranks (RCCL when world > 1)
     ms, n = C.c_double(), C.c_longlong()
     L.svgpu_profile_read(ctx.handle, C.byref(ms), C.byref(n))
     L.svgpu_profile_select(ctx.handle, None)

@@ -208,14 +208,19 @@ typedef struct svgpu_ba_stats {
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
 
-/* Multi-GPU variant: every rank passes the FULL pose/point arrays but only ITS SHARD of the
- * observations; `allreduce` is called once per linearisation with a device buffer that must be summed
- * in place across ranks (the host side binds it to RCCL, see stella_vslam_amd/distributed.py).
- * All ranks return identical poses/points; outlier_out covers the local shard only. */
+/* Multi-GPU variant.  Every rank passes the FULL pose / point arrays and ITS SHARD of the observations; the shard
+ * must be BY LANDMARK (all observations of one landmark on one rank, e.g. obs_point % world == rank) so that the
+ * Schur complement of a landmark is formed locally.  Per damping trial the partial reduced camera systems
+ * ((6P+1) x 6P doubles) are summed with ONE all-reduce and solved redundantly on every rank; per linearisation the
+ * pose blocks Hpp/bp (42 doubles per free pose) and a few scalars (chi2, step scale, flags) are summed as well.
+ * `allreduce(user, dev_buf, count, stream)` must sum `count` doubles in place across ranks on `stream`
+ * (stella_vslam_amd/distributed.py binds it to torch.distributed / RCCL).  All ranks return identical poses and
+ * points; outlier_out covers the local shard.  The stop flag must be raised consistently on all ranks (it is
+ * OR-reduced at every iteration boundary). */
 typedef int (*svgpu_allreduce_fn)(void* user, double* dev_buf, size_t count, void* stream);
-int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, svgpu_allreduce_fn allreduce,
-                           void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out,
-                           uint8_t* outlier_out, svgpu_ba_stats* stats);
+int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world,
+                           svgpu_allreduce_fn allreduce, void* allreduce_user, volatile uint8_t* stop, double* pose_out,
+                           double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
 
 #ifdef __cplusplus
 }

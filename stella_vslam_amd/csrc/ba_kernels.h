@@ -47,11 +47,16 @@ struct BaDev {
     int red_scale_off, red_scale_n;  // per-block partial sums of delta^T (lambda delta + b)
     int red_flag_off;                // [0] cholesky failure flag, [1] max diagonal
     double lambda;
+    double lambda_diag;      // damping added to the diagonal of S by THIS rank (lambda, or 0 on ranks > 0 of a sharded solve)
+    const double* Hpp_full;  // pose blocks summed over all ranks (== Hpp when not sharded): lambda init
+    const double* bp_full;   // same for bp: step-scale term
+    int scale_pose;          // 1 = this rank contributes the pose part of delta^T(lambda delta + b)
     int chol_in_lds;
 };
 
 struct svgpu_ctx;
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
-void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Dinv/Y, Schur, reduced solve, back-substitution, trial state
+void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Dinv/Y, Schur complement, right-hand side
+void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // reduced solve, back-substitution, trial state
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache);
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
     double m = 0.0;
     if (i < D.L && D.pt_free[i]) m = fmax(fabs(D.Hll[(size_t)i * 6]), fmax(fabs(D.Hll[(size_t)i * 6 + 3]), fabs(D.Hll[(size_t)i * 6 + 5])));
     if (i < D.nP)
-        for (int j = 0; j < 6; ++j) m = fmax(m, fabs(D.Hpp[(size_t)i * 36 + 7 * j]));
+        for (int j = 0; j < 6; ++j) m = fmax(m, fabs(D.Hpp_full[(size_t)i * 36 + 7 * j]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.0)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
         double v = -mine;
         if (ab.x == ab.y) {
             v += D.Hpp[(size_t)ab.x * 36 + lane];
-            if (i == j) v += D.lambda;
+            if (i == j) v += D.lambda_diag;
         }
         const size_t n = D.n;
         D.S[(size_t)(6 * ab.x + i) * n + 6 * ab.y + j] = v;
@@ -432,9 +432,10 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0
         }
         else {
             const double* u = D.dp + (size_t)slot * 6;
-            const double* bpv = D.bp + (size_t)slot * 6;
+            const double* bpv = D.bp_full + (size_t)slot * 6;
+            if (D.scale_pose)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) sc += u[k] * (D.lambda * u[k] + bpv[k]);
+                for (int k = 0; k < 6; ++k) sc += u[k] * (D.lambda * u[k] + bpv[k]);
             const double wx = u[0], wy = u[1], wz = u[2];
             const double theta = sqrt(wx * wx + wy * wy + wz * wz);
             const double Om[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
@@ -531,16 +532,19 @@ void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
     hipLaunchKernelGGL(k_ba_maxdiag, dim3((m + 255) / 256), dim3(256), 0, s, D);
 }
 
-void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
-    {
-        SvProfScope ps(ctx, s, "ba_schur");
-        hipLaunchKernelGGL(k_ba_dinv, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
-        if (D.nP > 0) {
-            (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
-            hipLaunchKernelGGL(k_ba_schur, dim3((D.NB + 3) / 4), dim3(256), 0, s, D);
-            hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(256), 0, s, D);
-        }
+// phase 1: Dinv / Y, (partial) reduced camera system S with the right-hand side in row n
+void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+    SvProfScope ps(ctx, s, "ba_schur");
+    hipLaunchKernelGGL(k_ba_dinv, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
+    if (D.nP > 0) {
+        (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
+        hipLaunchKernelGGL(k_ba_schur, dim3((D.NB + 3) / 4), dim3(256), 0, s, D);
+        hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(256), 0, s, D);
     }
+}
+
+// phase 2: reduced solve, back-substitution, trial state
+void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP > 0) {
         SvProfScope ps(ctx, s, "ba_solve");
         if (D.chol_in_lds) {
@@ -561,9 +565,9 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache) {
     SvProfScope ps(ctx, s, "ba_chi2");
-    hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache);
+    if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache);
 }
 
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out) {
-    hipLaunchKernelGGL(k_ba_gate, dim3((D.E + 255) / 256), dim3(256), 0, s, D, set_levels, outlier_out);
+    if (D.E > 0) hipLaunchKernelGGL(k_ba_gate, dim3((D.E + 255) / 256), dim3(256), 0, s, D, set_levels, outlier_out);
 }

@@ -38,7 +38,8 @@ struct HostStructure {
 
 // initializeOptimization(level 0): active vertices = endpoints of active edges; free = active and not fixed.
 void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, const std::vector<int>& e_point,
-                     const std::vector<int>& lm_off, const std::vector<uint8_t>& level, HostStructure& H) {
+                     const std::vector<int>& lm_off, const std::vector<uint8_t>& level, const std::vector<uint8_t>* pose_active_global,
+                     HostStructure& H) {
     const int P = pr.num_poses, L = pr.num_points, E = pr.num_obs;
     std::vector<uint8_t> pa(P, 0), la(L, 0);
     for (int e = 0; e < E; ++e)
@@ -46,6 +47,7 @@ void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose,
             pa[e_pose[e]] = 1;
             la[e_point[e]] = 1;
         }
+    if (pose_active_global) pa = *pose_active_global;  // sharded solve: activity summed over all ranks
     H.pose_slot.assign(P, -1);
     H.slot_pose.clear();
     for (int p = 0; p < P; ++p)
@@ -125,8 +127,8 @@ void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose,
 
 }  // namespace
 
-static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allreduce_fn allreduce, void* ar_user,
-                         volatile uint8_t* stop, double* pose_out, double* points_out, uint8_t* outlier_out,
+static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, int world, svgpu_allreduce_fn allreduce,
+                         void* ar_user, volatile uint8_t* stop, double* pose_out, double* points_out, uint8_t* outlier_out,
                          svgpu_ba_stats* stats) {
     if (!ctx || !pr || !pose_out || !points_out) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: null argument");
     const int P = pr->num_poses, L = pr->num_points, E = pr->num_obs;
@@ -136,16 +138,19 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
     for (int e = 0; e < E; ++e)
         if (pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L)
             return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
-    if (allreduce) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: not available in this build");
-    (void)ar_user;
+    const bool sharded = allreduce != nullptr;
+    if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
     svgpu_ba_stats st;
     memset(&st, 0, sizeof(st));
     memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
     if (E > 0) memset(outlier_out, 0, E);
     if (stats) *stats = st;
-    if (stop && *stop) return SVGPU_STOPPED;  // local_bundle_adjuster_g2o.cc:308-310
-    if (E == 0 || P == 0 || L == 0) return SVGPU_OK;
+    if (!sharded) {
+        if (stop && *stop) return SVGPU_STOPPED;  // local_bundle_adjuster_g2o.cc:308-310
+        if (E == 0 || P == 0 || L == 0) return SVGPU_OK;
+    }
+    else if (P == 0 || L == 0) return SVGPU_OK;  // same on every rank
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
@@ -182,7 +187,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
                   + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E)
                   + 3 * pad(sizeof(double) * 6 * L) + 2 * pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
                   + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (size_t)(nmax + 1) * nmax) + pad(sizeof(double) * nmax)
-                  + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E) + 4096;
+                  + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E + 1) + pad(8 * 42 * (size_t)P)
+                  + pad(8 * (size_t)(64 + world + 1)) + pad(8 * ((size_t)(P > 4 * L ? P : 4 * L) + 8)) + 4096;
     // worst-case pair storage: sum over landmarks of k(k+1)/2 (+ duplicates never exceed k^2)
     size_t pair_cap = 0;
     for (int l = 0; l < L; ++l) {
@@ -228,7 +234,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
     D.S = A.take<double>((size_t)(nmax + 1) * nmax);
     D.dp = A.take<double>(nmax);
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
-    uint8_t* d_outlier = A.take<uint8_t>(E);
+    uint8_t* d_outlier = A.take<uint8_t>(E + 1);
+    double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
+    double* d_sc = A.take<double>(64 + (size_t)(world > 0 ? world : 1));  // sharded: scalar exchange buffer
+    double* d_xch = A.take<double>((size_t)(P > 4 * L ? P : 4 * L) + 8);    // sharded: pose-activity / point exchange
     int2* d_blk_pairs = A.take<int2>(pair_cap);
     int2* d_blk_ab = A.take<int2>(nb_cap);
     int* d_blk_off = A.take<int>(nb_cap + 1);
@@ -269,13 +278,59 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
     H2D(d_lm_off, lm_off.data(), 4 * (size_t)(L + 1));
     SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
 
+    // ---- exchange helpers (sharded solve; no-ops otherwise)
+    auto allreduce_dev = [&](double* dev, size_t n) -> int {
+        if (!sharded || n == 0) return SVGPU_OK;
+        return allreduce(ar_user, dev, n, (void*)s) == 0 ? SVGPU_OK : sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed");
+    };
+    auto allreduce_host = [&](double* v, int n) -> int {  // sum n host doubles over the ranks
+        if (!sharded) return SVGPU_OK;
+        H2D(d_sc, v, 8 * (size_t)n);
+        int r = allreduce_dev(d_sc, n);
+        if (r) return r;
+        SV_HIP(ctx, hipMemcpyAsync(v, d_sc, 8 * (size_t)n, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        return SVGPU_OK;
+    };
+    std::vector<double> xch_host((size_t)(P > 4 * L ? P : 4 * L) + 8);
+    std::vector<uint8_t> owned(L, 0);  // landmarks whose observations live on this rank
+    for (int k = 0; k < E; ++k) owned[e_point[k]] = 1;
+    if (sharded) {  // contract check: a landmark's observations must not be split over ranks
+        for (int l = 0; l < L; ++l) xch_host[l] = owned[l];
+        H2D(d_xch, xch_host.data(), 8 * (size_t)L);
+        int r = allreduce_dev(d_xch, L);
+        if (r) return r;
+        SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * (size_t)L, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        for (int l = 0; l < L; ++l)
+            if (xch_host[l] > 1.5) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: observations must be sharded by landmark");
+    }
+
     HostStructure HS;
+    std::vector<uint8_t> pose_active;
     auto upload_structure = [&]() -> int {
-        build_structure(*pr, e_pose, e_point, lm_off, level, HS);
+        const std::vector<uint8_t>* pa_override = nullptr;
+        if (sharded) {  // a pose is active if ANY rank holds an active observation of it
+            for (int p = 0; p < P; ++p) xch_host[p] = 0;
+            for (int e = 0; e < E; ++e)
+                if (!level[e]) xch_host[e_pose[e]] = 1;
+            H2D(d_xch, xch_host.data(), 8 * (size_t)P);
+            int r = allreduce_dev(d_xch, P);
+            if (r) return r;
+            SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * (size_t)P, hipMemcpyDeviceToHost, s));
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            pose_active.assign(P, 0);
+            for (int p = 0; p < P; ++p) pose_active[p] = xch_host[p] > 0.5;
+            pa_override = &pose_active;
+        }
+        build_structure(*pr, e_pose, e_point, lm_off, level, pa_override, HS);
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
         D.NB = (int)HS.blk_ab.size();
         D.chol_in_lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 256;
+        D.Hpp_full = sharded ? d_HB_full : D.Hpp;
+        D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
+        D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
         H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
         H2D(d_pt_free, HS.pt_free.data(), L);
         H2D(d_pe_off, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
@@ -286,19 +341,30 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
         return SVGPU_OK;
     };
 
-    // chi2 of the active set at the current / trial state (fixed-order sum of the per-block partials)
+    uint8_t aux_flag = 0;  // g2o installs its own flag when the caller passes none (see svgpu.h)
+    volatile uint8_t* flag = stop ? stop : &aux_flag;
+
+    // chi2 of the active set at the current / trial state (fixed-order sum of the per-block partials); in a
+    // sharded solve the sum runs over all ranks and the stop flags are OR-reduced on the way
     auto chi2 = [&](int use_trial, int store_cache, double* out) -> int {
-        sv_ba_chi2(ctx, s, D, use_trial, store_cache);
-        SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red + D.red_chi_off, 8 * (size_t)nb_chi, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipStreamSynchronize(s));
         double sum = 0;
-        for (int i = 0; i < nb_chi; ++i) sum += red_host[i];
+        if (E > 0) {
+            sv_ba_chi2(ctx, s, D, use_trial, store_cache);
+            SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red + D.red_chi_off, 8 * (size_t)nb_chi, hipMemcpyDeviceToHost, s));
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            for (int i = 0; i < nb_chi; ++i) sum += red_host[i];
+        }
+        if (sharded) {
+            double v[2] = {sum, (double)(*flag ? 1 : 0)};
+            int r = allreduce_host(v, 2);
+            if (r) return r;
+            sum = v[0];
+            if (v[1] > 0.5) *flag = 1;
+        }
         *out = sum;
         return SVGPU_OK;
     };
 
-    uint8_t aux_flag = 0;  // g2o installs its own flag when the caller passes none (see svgpu.h)
-    volatile uint8_t* flag = stop ? stop : &aux_flag;
     double lambda = 0, last_chi = 0;
 
     // SparseOptimizer::optimize(iterations) with the terminate_action hook
@@ -306,35 +372,61 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
         *iters_done = 0;
         int r = upload_structure();
         if (r) return r;
-        if (HS.nP + HS.nL == 0) return SVGPU_OK;
+        if (!sharded && HS.nP + HS.nL == 0) return SVGPU_OK;
         bool ok = true;
         double ni = 2;
-        for (int it = 0; it < iterations && !*flag && ok; ++it) {
+        for (int it = 0; it < iterations && ok; ++it) {
+            if (!sharded && *flag) break;
             double current_chi;
             if ((r = chi2(0, 0, &current_chi))) return r;
+            if (*flag) break;  // sharded: the flag was just OR-reduced, every rank leaves together
             sv_ba_linearize(ctx, s, D);
+            if (sharded && HS.nP > 0) {
+                SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
+                SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
+                if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP))) return r;
+            }
             if (it == 0) {  // computeLambdaInit
                 SV_HIP(ctx, hipMemsetAsync(D.red + D.red_flag_off, 0, 16, s));
                 sv_ba_maxdiag(s, D);
                 double fl[2];
                 SV_HIP(ctx, hipMemcpyAsync(fl, D.red + D.red_flag_off, 16, hipMemcpyDeviceToHost, s));
                 SV_HIP(ctx, hipStreamSynchronize(s));
-                lambda = 1e-5 * fl[1];
+                double max_diag = fl[1];
+                if (sharded) {  // max over ranks through a sum of one-hot slots
+                    std::vector<double> slots(world, 0.0);
+                    slots[rank] = max_diag;
+                    if ((r = allreduce_host(slots.data(), world))) return r;
+                    for (double v : slots) max_diag = std::max(max_diag, v);
+                }
+                lambda = 1e-5 * max_diag;
                 ni = 2;
             }
             double rho = 0;
             int qmax = 0;
             do {
                 D.lambda = lambda;
+                D.lambda_diag = (!sharded || rank == 0) ? lambda : 0.0;
                 SV_HIP(ctx, hipMemsetAsync(D.red + D.red_flag_off, 0, 8, s));
+                sv_ba_reduce(ctx, s, D);
+                if (HS.nP > 0 && (r = allreduce_dev(D.S, (size_t)(D.n + 1) * D.n))) return r;
                 sv_ba_solve(ctx, s, D);
-                sv_ba_chi2(ctx, s, D, 1, 0);
+                if (E > 0) sv_ba_chi2(ctx, s, D, 1, 0);
                 SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red, 8 * (size_t)red_total, hipMemcpyDeviceToHost, s));
                 SV_HIP(ctx, hipStreamSynchronize(s));
                 double temp_chi = 0, scale = 0;
-                for (int i = 0; i < nb_chi; ++i) temp_chi += red_host[D.red_chi_off + i];
+                if (E > 0)
+                    for (int i = 0; i < nb_chi; ++i) temp_chi += red_host[D.red_chi_off + i];
                 for (int i = 0; i < nb_lm + nb_pose; ++i) scale += red_host[D.red_scale_off + i];
-                const bool ok2 = red_host[D.red_flag_off] == 0.0;
+                bool ok2 = red_host[D.red_flag_off] == 0.0;
+                if (sharded) {
+                    double v[4] = {temp_chi, scale, ok2 ? 0.0 : 1.0, (double)(*flag ? 1 : 0)};
+                    if ((r = allreduce_host(v, 4))) return r;
+                    temp_chi = v[0];
+                    scale = v[1];
+                    ok2 = v[2] < 0.5;
+                    if (v[3] > 0.5) *flag = 1;
+                }
                 ++st.lm_trials;
                 if (!ok2) {
                     temp_chi = DBL_MAX;
@@ -382,34 +474,62 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, svgpu_allre
         if ((r = chi2(0, 1, &chi0))) return r;
     }
     st.chi2_initial = chi0;
+    if (sharded && stop && *stop) {  // the flag was OR-reduced inside chi2(): every rank returns together
+        if (stats) *stats = st;
+        return SVGPU_STOPPED;
+    }
     int it1 = 0, it2 = 0;
     rc = optimize(pr->num_first_iter, &it1);
     if (rc) return rc;
     st.iters_stage1 = it1;
+    if (sharded) {  // agree on the caller flags before the stage-2 decision
+        double v[1] = {(double)((stop && *stop) ? 1 : 0)};
+        if ((rc = allreduce_host(v, 1))) return rc;
+        if (stop && v[0] > 0.5) *stop = 1;
+    }
     bool run_robust = true;
     if (stop && *stop) run_robust = false;  // :317-321 (only the CALLER's flag is consulted here)
     if (run_robust) {
         st.stage2_entered = 1;
-        sv_ba_gate(s, D, 1, nullptr);
-        SV_HIP(ctx, hipMemcpyAsync(level.data(), D.e_level, E, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipStreamSynchronize(s));
-        int gated = 0;
+        if (E > 0) {
+            sv_ba_gate(s, D, 1, nullptr);
+            SV_HIP(ctx, hipMemcpyAsync(level.data(), D.e_level, E, hipMemcpyDeviceToHost, s));
+            SV_HIP(ctx, hipStreamSynchronize(s));
+        }
+        double gated = 0;
         for (int e = 0; e < E; ++e) gated += level[e];
-        st.num_gated = gated;
+        if (sharded && (rc = allreduce_host(&gated, 1))) return rc;
+        st.num_gated = (int32_t)gated;
         rc = optimize(pr->num_second_iter, &it2);
         if (rc) return rc;
         st.iters_stage2 = it2;
     }
     // ---- outlier list, final chi2, read-back
-    sv_ba_gate(s, D, 0, d_outlier);
     std::vector<uint8_t> outl(E);
-    SV_HIP(ctx, hipMemcpyAsync(outl.data(), d_outlier, E, hipMemcpyDeviceToHost, s));
+    if (E > 0) {
+        sv_ba_gate(s, D, 0, d_outlier);
+        SV_HIP(ctx, hipMemcpyAsync(outl.data(), d_outlier, E, hipMemcpyDeviceToHost, s));
+    }
     SV_HIP(ctx, hipMemcpyAsync(pose_out, D.pose_cur, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipMemcpyAsync(points_out, D.pt_cur, sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToHost, s));
     double chi1 = 0;
     {
         int r = chi2(0, 0, &chi1);
         if (r) return r;
+    }
+    if (sharded) {  // every rank ends with every landmark: owners contribute their points, the rest zeros
+        for (int l = 0; l < L; ++l) {
+            for (int k = 0; k < 3; ++k) xch_host[3 * (size_t)l + k] = owned[l] ? points_out[3 * (size_t)l + k] : 0.0;
+            xch_host[3 * (size_t)L + l] = owned[l];
+        }
+        H2D(d_xch, xch_host.data(), 8 * 4 * (size_t)L);
+        int r = allreduce_dev(d_xch, 4 * (size_t)L);
+        if (r) return r;
+        SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * 4 * (size_t)L, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        for (int l = 0; l < L; ++l)
+            if (xch_host[3 * (size_t)L + l] > 0.5)
+                for (int k = 0; k < 3; ++k) points_out[3 * (size_t)l + k] = xch_host[3 * (size_t)l + k];
     }
     for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
     st.chi2_final = chi1;
@@ -423,14 +543,14 @@ extern "C" {
 
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats) {
-    return local_ba_impl(ctx, problem, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
+    return local_ba_impl(ctx, problem, 0, 1, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
 }
 
-int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, svgpu_allreduce_fn allreduce,
+int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world, svgpu_allreduce_fn allreduce,
                            void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out,
                            uint8_t* outlier_out, svgpu_ba_stats* stats) {
     if (!allreduce) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: allreduce callback is required");
-    return local_ba_impl(ctx, shard, allreduce, allreduce_user, stop, pose_out, points_out, outlier_out, stats);
+    return local_ba_impl(ctx, shard, rank, world, allreduce, allreduce_user, stop, pose_out, points_out, outlier_out, stats);
 }
 
 }  // extern "C"

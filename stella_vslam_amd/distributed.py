@@ -1,0 +1,79 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo"
+on CPU for tests).  PyTorch is only the launcher / collective provider here; the data path is the C ABI.
+
+* extract + match shard by frame (no data-path collective): `frame_shard`, `max_over_ranks`
+* local / global BA shards by landmark with one all-reduce of the reduced camera system per damping trial:
+  `shard_by_landmark`, `make_allreduce_callback` (the `svgpu_allreduce_fn` the library calls back into)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def frame_shard(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced shard of n_items for `rank` (first n % world ranks get one extra)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of a python float (the benchmark's time reduction)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_by_landmark(scene: dict, rank: int, world: int) -> dict:
+    """Observation shard of a flat BA problem: all observations of landmark l go to rank l % world.
+    Poses, points and intrinsics stay complete on every rank (what svgpu_local_ba_sharded expects)."""
+    keep = (np.asarray(scene["obs_point"]) % world) == rank
+    out = dict(scene)
+    for k in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma_sq", "obs_huber"):
+        out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
+    out["_obs_index"] = np.flatnonzero(keep)
+    return out
+
+
+class _CudaBuf:
+    """Minimal __cuda_array_interface__ carrier so that torch can wrap a raw device pointer without copying."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def make_allreduce_callback(group=None):
+    """Returns (callback, keepalive): `callback` is a C function pointer of type svgpu_allreduce_fn that sums
+    `count` doubles in place across the ranks of `group` with torch.distributed.all_reduce.
+    With the nccl backend the buffer is device memory and the collective is enqueued on the library's stream;
+    with gloo (CPU tests) the buffer is host memory."""
+    import torch
+    import torch.distributed as dist
+
+    def _cb(user, buf, count, stream):
+        try:
+            if dist.get_backend(group) == "nccl":
+                t = torch.as_tensor(_CudaBuf(buf, count), device="cuda")
+                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+                with torch.cuda.stream(ext):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+                t = torch.from_numpy(a)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            print("allreduce callback failed:", e, file=sys.stderr)
+            return 1
+
+    cb = ALLREDUCE_FN(_cb)
+    return cb, (cb, _cb)

@@ -43,7 +43,13 @@ class local_bundle_adjuster:
         self.num_second_iter_ = num_second_iter
         self.ctx = ctx or Context()
 
-    def optimize_flat(self, scene: dict, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
+    def optimize_flat_sharded(self, shard: dict, rank: int, world: int, allreduce_cb, force_stop_flag: np.ndarray | None = None,
+                              gain_threshold: float = 1e-3):
+        """Multi-GPU variant: `shard` holds this rank's observations (distributed.shard_by_landmark) and the complete
+        pose / point arrays; `allreduce_cb` is a svgpu_allreduce_fn (distributed.make_allreduce_callback)."""
+        return self.optimize_flat(shard, force_stop_flag, gain_threshold, _sharded=(rank, world, allreduce_cb))
+
+    def optimize_flat(self, scene: dict, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3, _sharded=None):
         """scene keys: pose_cw (P,12) f64, pose_fixed (P) u8, points (L,3) f64, [point_fixed (L) u8], obs_pose / obs_point (E) i32,
         obs_uvr (E,3) f32, obs_inv_sigma_sq (E) f32, obs_huber (E) f32, intr (P,5) f64.
         force_stop_flag: None or a writable uint8[1] (the caller's abort flag; may be SET by the terminate rule)."""
@@ -60,9 +66,13 @@ class local_bundle_adjuster:
         pose_out, pts_out = np.zeros_like(pose), np.zeros_like(pts)
         outl = np.zeros(max(E, 1), np.uint8)
         st = _BaStats()
-        rc = lib().svgpu_local_ba(self.ctx.handle, C.byref(prob), None if force_stop_flag is None else C.c_void_p(force_stop_flag.ctypes.data),
-                                  C.c_void_p(pose_out.ctypes.data), C.c_void_p(pts_out.ctypes.data), C.c_void_p(outl.ctypes.data),
-                                  C.byref(st))
+        stop = None if force_stop_flag is None else C.c_void_p(force_stop_flag.ctypes.data)
+        outs = (C.c_void_p(pose_out.ctypes.data), C.c_void_p(pts_out.ctypes.data), C.c_void_p(outl.ctypes.data), C.byref(st))
+        if _sharded is None:
+            rc = lib().svgpu_local_ba(self.ctx.handle, C.byref(prob), stop, *outs)
+        else:
+            rank, world, cb = _sharded
+            rc = lib().svgpu_local_ba_sharded(self.ctx.handle, C.byref(prob), rank, world, cb, None, stop, *outs)
         self.ctx.check(rc, "svgpu_local_ba", ok=(0, 7))
         return dict(rc=rc, pose_cw=pose_out, points=pts_out, outlier=outl[:E].copy(),
                     stats={f: getattr(st, f) for f, _ in _BaStats._fields_})
