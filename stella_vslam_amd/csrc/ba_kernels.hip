@@ -117,12 +117,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// block-wide sum of one double per thread (256 threads), fixed order; result valid in thread 0
-__device__ __forceinline__ double block_sum_d(double v, double* s4) {
+// block-wide sum of one double per thread (blockDim.x <= 1024), fixed order; result valid in every thread
+__device__ __forceinline__ double block_sum_d(double v, double* sw /* 16 doubles */) {
     v = wave_sum_d(v);
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = v;
     __syncthreads();
-    const double r = s4[0] + s4[1] + s4[2] + s4[3];
+    double r = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 0; k < nw; ++k) r += sw[k];
     __syncthreads();
     return r;
 }
@@ -174,14 +176,14 @@ __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
 }
 
 // workgroup per free pose: Hpp (6x6) and bp over all its active edges, tree-reduced in a fixed order
-__global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D) {
-    __shared__ double s4[4];
+__global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D) {
     const int s = blockIdx.x;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += 256) {
+    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += blockDim.x) {
         const int e = D.pe_idx[q];
+        if (D.e_level[e]) continue;  // lists are built once per call; excluded edges stay listed
         EdgeLin o;
         edge_linearize(D, e, o);
         int k = 0;
@@ -197,10 +199,23 @@ __global__ __launch_bounds__(256) void k_ba_lin_pose(BaDev D) {
         for (int i = 0; i < 6; ++i)
             acc[21 + i] += o.B[i] * (-o.w * o.r[0]) + o.B[6 + i] * (-o.w * o.r[1]) + o.B[12 + i] * (-o.w * o.r[2]);
     }
-    double out[27];
+    // fixed-order reduction: shuffles inside each wave, then the wave partials in wave order
+    __shared__ double s_w[16][27];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) out[k] = block_sum_d(acc[k], s4);
+    for (int k = 0; k < 27; ++k) {
+        const double t = wave_sum_d(acc[k]);
+        if (lane == 0) s_w[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double t = 0.0;
+        for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
+        s_w[0][threadIdx.x] = t;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const double* out = s_w[0];
         double* H = D.Hpp + (size_t)s * 36;
         int k = 0;
         for (int i = 0; i < 6; ++i)
@@ -266,41 +281,50 @@ __global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {
     }
 }
 
-// one wave per upper block (a <= b) of the reduced system: S_ab = [a==b](Hpp_a + lambda I) - sum Y_i W_j^T
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (blk >= D.NB) return;
+// one 512-thread workgroup per upper block (a <= b) of the reduced system:
+//   S_ab = [a==b](Hpp_a + lambda I) - sum over the block's (edge, edge) pairs of Y_i W_j^T
+// threads stride over the pairs, waves are tree-reduced with shuffles, the 8 wave partials are added in wave order
+#define SCHUR_THREADS 512
+__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D) {
+    __shared__ double s_part[SCHUR_THREADS / 64][36];
+    const int blk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int q = D.blk_off[blk] + lane; q < D.blk_off[blk + 1]; q += 64) {
+    for (int q = D.blk_off[blk] + threadIdx.x; q < D.blk_off[blk + 1]; q += SCHUR_THREADS) {
         const int2 pr = D.blk_pairs[q];
-        const double* Yd = D.Y + (size_t)pr.x * 18;
-        const double* Wd = D.W + (size_t)pr.y * 18;
+        const double2* Yd = reinterpret_cast<const double2*>(D.Y + (size_t)pr.x * 18);
+        const double2* Wd = reinterpret_cast<const double2*>(D.W + (size_t)pr.y * 18);
         double y[18], w[18];
 #pragma unroll
-        for (int k = 0; k < 18; ++k) {
-            y[k] = Yd[k];
-            w[k] = Wd[k];
+        for (int k = 0; k < 9; ++k) {
+            const double2 a = Yd[k], b = Wd[k];
+            y[2 * k] = a.x;
+            y[2 * k + 1] = a.y;
+            w[2 * k] = b.x;
+            w[2 * k + 1] = b.y;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
     }
-    const int2 ab = D.blk_ab[blk];
-    double mine = 0.0;  // lane k < 36 ends up owning element k
 #pragma unroll
     for (int k = 0; k < 36; ++k) {
         const double t = wave_sum_d(acc[k]);
-        if (lane == k) mine = t;
+        if (lane == 0) s_part[wave][k] = t;
     }
-    if (lane < 36) {
-        const int i = lane / 6, j = lane - 6 * i;
-        double v = -mine;
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const int2 ab = D.blk_ab[blk];
+        const int i = threadIdx.x / 6, j = threadIdx.x - 6 * i;
+        double sum = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < SCHUR_THREADS / 64; ++wv) sum += s_part[wv][threadIdx.x];
+        double v = -sum;
         if (ab.x == ab.y) {
-            v += D.Hpp[(size_t)ab.x * 36 + lane];
+            v += D.Hpp[(size_t)ab.x * 36 + threadIdx.x];
             if (i == j) v += D.lambda_diag;
         }
         const size_t n = D.n;
@@ -310,53 +334,150 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev D) {
 }
 
 // workgroup per free pose: g_a = bp_a - sum_e Y_e bl_l(e)  -> row n of S
-__global__ __launch_bounds__(256) void k_ba_rhs(BaDev D) {
-    __shared__ double s4[4];
+__global__ __launch_bounds__(1024) void k_ba_rhs(BaDev D) {
     const int s = blockIdx.x;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += 256) {
+    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += blockDim.x) {
         const int e = D.pe_idx[q];
         const int l = D.e_point[e];
-        if (!D.pt_free[l]) continue;
+        if (!D.pt_free[l] || D.e_level[e]) continue;
         const double* Yd = D.Y + (size_t)e * 18;
         const double* b = D.bl + (size_t)l * 3;
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc[i] += Yd[3 * i] * b[0] + Yd[3 * i + 1] * b[1] + Yd[3 * i + 2] * b[2];
     }
+    __shared__ double s_w[16][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const double t = block_sum_d(acc[i], s4);
-        if (threadIdx.x == 0) D.S[(size_t)D.n * D.n + 6 * s + i] = D.bp[(size_t)s * 6 + i] - t;
+        const double t = wave_sum_d(acc[i]);
+        if (lane == 0) s_w[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double t = 0.0;
+        for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
+        D.S[(size_t)D.n * D.n + 6 * s + threadIdx.x] = D.bp[(size_t)s * 6 + threadIdx.x] - t;
     }
 }
 
 // Dense LL^T of the reduced system with the right-hand side carried as row n, then L^T x = y.
-// One workgroup; A (n+1 rows x n cols) lives in LDS (pitch ld) when it fits, otherwise in global memory.
-template <bool IN_LDS>
-__global__ __launch_bounds__(1024) void k_ba_chol(BaDev D) {
+// One 256-thread workgroup, A ((n+1) x n, pitch ld) in LDS.  Blocked right-looking factorisation, panel width 16:
+//   (1) wave 0 factors the 16x16 diagonal block (wave-synchronous, no workgroup barrier),
+//   (2) every row below solves its 16 panel entries against it (thread per row),
+//   (3) rank-16 update of the trailing matrix on a 16x16 thread lattice,
+// i.e. 3 workgroup barriers per 16 columns instead of 3 per column.  Row n (the right-hand side) rides along, so
+// after the factorisation it holds L^-1 g; wave 0 finishes with the back substitution.
+#define CHOL_NB 16
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void k_ba_chol_lds(BaDev D) {
     extern __shared__ double s_A[];
     __shared__ int s_fail;
-    const int n = D.n, tid = threadIdx.x, nt = blockDim.x;
-    const int ld = IN_LDS ? (n | 1) : n;
-    double* A = IN_LDS ? s_A : D.S;
-    if (IN_LDS)
-        for (int i = tid; i < (n + 1) * n; i += nt) A[(i / n) * ld + (i % n)] = D.S[i];
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63;
+    const int ld = n | 1;
+    double* A = s_A;
+    for (int i = tid; i < (n + 1) * n; i += 256) A[(i / n) * ld + (i % n)] = D.S[i];
     if (tid == 0) s_fail = 0;
     __syncthreads();
+    for (int jb = 0; jb < n; jb += CHOL_NB) {
+        const int je = min(jb + CHOL_NB, n);
+        if (tid < 64) {  // (1) diagonal block
+            bool bad = false;
+            for (int j = jb; j < je; ++j) {
+                const double djj = A[j * ld + j];
+                if (!(djj > 0.0)) {
+                    bad = true;
+                    break;  // wave-uniform
+                }
+                const double d = sqrt(djj);
+                wave_lds_sync();
+                for (int i = j + lane; i < je; i += 64) A[i * ld + j] = (i == j) ? d : A[i * ld + j] / d;
+                wave_lds_sync();
+                const int k = j + 1 + (lane & 15);
+                for (int i = j + 1 + (lane >> 4); i < je; i += 4)
+                    if (k <= i) A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+                wave_lds_sync();
+            }
+            if (bad && lane == 0) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) break;
+        for (int i = je + tid; i <= n; i += 256) {  // (2) panel rows (row n = right-hand side)
+            double x[CHOL_NB];
+#pragma unroll
+            for (int c = 0; c < CHOL_NB; ++c) x[c] = (jb + c < je) ? A[i * ld + jb + c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CHOL_NB; ++c) {
+                if (jb + c < je) {
+                    double v = x[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= x[k] * A[(jb + c) * ld + jb + k];
+                    x[c] = v / A[(jb + c) * ld + jb + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CHOL_NB; ++c)
+                if (jb + c < je) A[i * ld + jb + c] = x[c];
+        }
+        __syncthreads();
+        {  // (3) trailing update: rows je..n, columns je..min(i, n-1)
+            const int ti = tid >> 4, tj = tid & 15, w = je - jb;
+            for (int i = je + ti; i <= n; i += 16) {
+                const int kmax = i < n ? i : n - 1;
+                for (int k = je + tj; k <= kmax; k += 16) {
+                    double v = A[i * ld + k];
+                    for (int c = 0; c < w; ++c) v -= A[i * ld + jb + c] * A[k * ld + jb + c];
+                    A[i * ld + k] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (s_fail) {
+        if (tid == 0) D.red[D.red_flag_off] = 1.0;
+        for (int i = tid; i < n; i += 256) D.dp[i] = 0.0;
+        return;
+    }
+    if (tid < 64) {  // back substitution L^T x = y (y = row n), column oriented, wave-synchronous
+        for (int i = n - 1; i >= 0; --i) {
+            const double xi = A[n * ld + i] / A[i * ld + i];
+            wave_lds_sync();
+            if (lane == 0) A[n * ld + i] = xi;
+            for (int k = lane; k < i; k += 64) A[n * ld + k] -= A[i * ld + k] * xi;
+            wave_lds_sync();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) D.dp[i] = A[n * ld + i];
+}
+
+// Fallback for systems that do not fit LDS (n > ~140): same arithmetic on the global copy, one column per step.
+__global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
+    __shared__ int s_fail;
+    const int n = D.n, tid = threadIdx.x, nt = blockDim.x, ld = n;
+    double* A = D.S;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    const int t16i = tid >> 4, t16j = tid & 15, tstep = nt >> 4;
     for (int j = 0; j < n; ++j) {
-        const double djj = A[j * ld + j];
+        const double djj = A[(size_t)j * ld + j];
         if (!(djj > 0.0)) {
             if (tid == 0) s_fail = 1;
-            break;  // uniform: every thread read the same value
+            break;
         }
         const double d = sqrt(djj);
         __syncthreads();
-        for (int i = j + tid; i <= n; i += nt) A[i * ld + j] = (i == j) ? d : A[i * ld + j] / d;
+        for (int i = j + tid; i <= n; i += nt) A[(size_t)i * ld + j] = (i == j) ? d : A[(size_t)i * ld + j] / d;
         __syncthreads();
-        const int m = n - j;  // rows j+1..n (incl. rhs), cols j+1..n-1
-        for (int q = tid; q < m * (m - 1); q += nt) {
-            const int i = j + 1 + q / (m - 1), k = j + 1 + q % (m - 1);
-            if (k <= i) A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+        for (int i = j + 1 + t16i; i <= n; i += tstep) {
+            const double lij = A[(size_t)i * ld + j];
+            const int kmax = i < n ? i : n - 1;
+            for (int k = j + 1 + t16j; k <= kmax; k += 16) A[(size_t)i * ld + k] -= lij * A[(size_t)k * ld + j];
         }
         __syncthreads();
     }
@@ -366,20 +487,19 @@ __global__ __launch_bounds__(1024) void k_ba_chol(BaDev D) {
         for (int i = tid; i < n; i += nt) D.dp[i] = 0.0;
         return;
     }
-    // back substitution L^T x = y (y = row n), column oriented
     for (int i = n - 1; i >= 0; --i) {
-        const double xi = A[n * ld + i] / A[i * ld + i];
+        const double xi = A[(size_t)n * ld + i] / A[(size_t)i * ld + i];
         __syncthreads();
-        if (tid == 0) A[n * ld + i] = xi;
-        for (int k = tid; k < i; k += nt) A[n * ld + k] -= A[i * ld + k] * xi;
+        if (tid == 0) A[(size_t)n * ld + i] = xi;
+        for (int k = tid; k < i; k += nt) A[(size_t)n * ld + k] -= A[(size_t)i * ld + k] * xi;
         __syncthreads();
     }
-    for (int i = tid; i < n; i += nt) D.dp[i] = A[n * ld + i];
+    for (int i = tid; i < n; i += nt) D.dp[i] = A[(size_t)n * ld + i];
 }
 
 // thread per landmark: dl = Dinv (bl - sum W^T dp), trial point, partial of delta^T(lambda delta + b)
 __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {
-    __shared__ double s4[4];
+    __shared__ double s4[16];
     const int l = blockIdx.x * 256 + threadIdx.x;
     double sc = 0.0;
     if (l < D.L) {
@@ -419,7 +539,7 @@ __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {
 
 // thread per pose: trial = exp(dp) * cur (g2o SE3Quat::exp, shot_vertex.h:55-58)
 __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0) {
-    __shared__ double s4[4];
+    __shared__ double s4[16];
     const int p = blockIdx.x * 256 + threadIdx.x;
     double sc = 0.0;
     if (p < D.P) {
@@ -480,7 +600,7 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0
 
 // ------------------------------------------------------------------------------------------------ errors
 __global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache) {
-    __shared__ double s4[4];
+    __shared__ double s4[16];
     const int e = blockIdx.x * 256 + threadIdx.x;
     double v = 0.0;
     if (e < D.E && !D.e_level[e]) {
@@ -518,13 +638,33 @@ __global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_
     if (outlier_out) outlier_out[e] = out ? 1 : 0;
 }
 
+// W / Y of edges that left the active set (excluded by the gate, or whose landmark became inactive) are zeroed once
+// per stage, so that the (edge, edge) pair lists built for the first stage stay valid: such pairs contribute 0.
+__global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= D.E) return;
+    if (!D.e_level[e] && D.pt_free[D.e_point[e]]) return;
+    double2* Wd = reinterpret_cast<double2*>(D.W + (size_t)e * 18);
+    double2* Yd = reinterpret_cast<double2*>(D.Y + (size_t)e * 18);
+    const double2 z = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        Wd[k] = z;
+        Yd[k] = z;
+    }
+}
+
 }  // namespace
+
+void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
+    if (D.E > 0) hipLaunchKernelGGL(k_ba_zero_inactive, dim3((D.E + 255) / 256), dim3(256), 0, s, D);
+}
 
 // ------------------------------------------------------------------------------------------------ launchers
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_linearize");
     hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
-    if (D.nP > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP), dim3(256), 0, s, D);
+    if (D.nP > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP), dim3(1024), 0, s, D);
 }
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
@@ -538,8 +678,8 @@ void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     hipLaunchKernelGGL(k_ba_dinv, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
     if (D.nP > 0) {
         (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
-        hipLaunchKernelGGL(k_ba_schur, dim3((D.NB + 3) / 4), dim3(256), 0, s, D);
-        hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(256), 0, s, D);
+        hipLaunchKernelGGL(k_ba_schur, dim3(D.NB), dim3(SCHUR_THREADS), 0, s, D);
+        hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(1024), 0, s, D);
     }
 }
 
@@ -551,12 +691,12 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
             const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)k_ba_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+                (void)hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(k_ba_chol<true>, dim3(1), dim3(D.n <= 48 ? 256 : 1024), lds, s, D);
+            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(256), lds, s, D);
         }
-        else hipLaunchKernelGGL(k_ba_chol<false>, dim3(1), dim3(1024), 0, s, D);
+        else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
     }
     SvProfScope ps(ctx, s, "ba_update");
     hipLaunchKernelGGL(k_ba_update_lm, dim3((D.L + 255) / 256), dim3(256), 0, s, D);

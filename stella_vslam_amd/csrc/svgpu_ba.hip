@@ -7,10 +7,14 @@
 #include <cfloat>
 #include <cmath>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
+void sv_ba_zero_inactive(hipStream_t s, const BaDev& D);
 
 namespace {
 
@@ -35,6 +39,34 @@ struct HostStructure {
     std::vector<int2> blk_pairs, blk_ab;
     int nP = 0, nL = 0;
 };
+
+// pose / landmark activity under the current edge levels (the cheap first half of build_structure)
+void activity_only(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, const std::vector<int>& e_point,
+                   const std::vector<uint8_t>& level, const std::vector<uint8_t>* pose_active_global, HostStructure& H) {
+    const int P = pr.num_poses, L = pr.num_points, E = pr.num_obs;
+    std::vector<uint8_t> pa(P, 0), la(L, 0);
+    for (int e = 0; e < E; ++e)
+        if (!level[e]) {
+            pa[e_pose[e]] = 1;
+            la[e_point[e]] = 1;
+        }
+    if (pose_active_global) pa = *pose_active_global;
+    H.pose_slot.assign(P, -1);
+    H.slot_pose.clear();
+    for (int p = 0; p < P; ++p)
+        if (pa[p] && !pr.pose_fixed[p]) {
+            H.pose_slot[p] = (int)H.slot_pose.size();
+            H.slot_pose.push_back(p);
+        }
+    H.nP = (int)H.slot_pose.size();
+    H.pt_free.assign(L, 0);
+    H.nL = 0;
+    for (int l = 0; l < L; ++l)
+        if (la[l] && !(pr.point_fixed && pr.point_fixed[l])) {
+            H.pt_free[l] = 1;
+            ++H.nL;
+        }
+}
 
 // initializeOptimization(level 0): active vertices = endpoints of active edges; free = active and not fixed.
 void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, const std::vector<int>& e_point,
@@ -142,6 +174,14 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
     svgpu_ba_stats st;
     memset(&st, 0, sizeof(st));
+    const bool trace = std::getenv("SVGPU_BA_TRACE") != nullptr;
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ba] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
+        t_start = now;
+    };
     memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
     if (E > 0) memset(outlier_out, 0, E);
@@ -177,6 +217,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
         robust[k] = e_hub[k] > 0.f;
     }
 
+    lap("sort observations");
     // ---- device arena
     const int nPmax = P, nmax = 6 * nPmax;
     const int nb_chi = (E + 255) / 256, nb_lm = (L + 255) / 256, nb_pose = (P + 255) / 256;
@@ -306,7 +347,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
             if (xch_host[l] > 1.5) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: observations must be sharded by landmark");
     }
 
+    lap("arena + uploads");
     HostStructure HS;
+    bool have_lists = false;
     std::vector<uint8_t> pose_active;
     auto upload_structure = [&]() -> int {
         const std::vector<uint8_t>* pa_override = nullptr;
@@ -323,7 +366,22 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
             for (int p = 0; p < P; ++p) pose_active[p] = xch_host[p] > 0.5;
             pa_override = &pose_active;
         }
-        build_structure(*pr, e_pose, e_point, lm_off, level, pa_override, HS);
+        // Activity of poses / landmarks under the current levels (cheap), then the expensive part -- pose->edge lists
+        // and (edge, edge) pair lists -- only when the free-pose numbering changed.  Lists built for an earlier stage
+        // stay valid: edges excluded since then are skipped by level (lin_pose, rhs) or contribute W = Y = 0 (pairs).
+        auto tb0 = std::chrono::steady_clock::now();
+        HostStructure probe;
+        activity_only(*pr, e_pose, e_point, level, pa_override, probe);
+        const bool reuse = have_lists && probe.pose_slot == HS.pose_slot;
+        if (reuse) {
+            HS.pt_free = probe.pt_free;
+            HS.nL = probe.nL;
+        }
+        else {
+            build_structure(*pr, e_pose, e_point, lm_off, level, pa_override, HS);
+            have_lists = true;
+        }
+        if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.blk_pairs.size(), HS.blk_ab.size());
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
         D.NB = (int)HS.blk_ab.size();
@@ -331,13 +389,16 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
-        H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
         H2D(d_pt_free, HS.pt_free.data(), L);
-        H2D(d_pe_off, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
-        if (!HS.pe_idx.empty()) H2D(d_pe_idx, HS.pe_idx.data(), 4 * HS.pe_idx.size());
-        H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
-        if (!HS.blk_ab.empty()) H2D(d_blk_ab, HS.blk_ab.data(), 8 * HS.blk_ab.size());
-        if (!HS.blk_pairs.empty()) H2D(d_blk_pairs, HS.blk_pairs.data(), 8 * HS.blk_pairs.size());
+        if (!reuse) {
+            H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
+            H2D(d_pe_off, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
+            if (!HS.pe_idx.empty()) H2D(d_pe_idx, HS.pe_idx.data(), 4 * HS.pe_idx.size());
+            H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
+            if (!HS.blk_ab.empty()) H2D(d_blk_ab, HS.blk_ab.data(), 8 * HS.blk_ab.size());
+            if (!HS.blk_pairs.empty()) H2D(d_blk_pairs, HS.blk_pairs.data(), 8 * HS.blk_pairs.size());
+        }
+        else sv_ba_zero_inactive(s, D);
         return SVGPU_OK;
     };
 
@@ -474,6 +535,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
         if ((r = chi2(0, 1, &chi0))) return r;
     }
     st.chi2_initial = chi0;
+    lap("structure + chi2_0");
     if (sharded && stop && *stop) {  // the flag was OR-reduced inside chi2(): every rank returns together
         if (stats) *stats = st;
         return SVGPU_STOPPED;
@@ -482,6 +544,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
     rc = optimize(pr->num_first_iter, &it1);
     if (rc) return rc;
     st.iters_stage1 = it1;
+    lap("stage 1");
     if (sharded) {  // agree on the caller flags before the stage-2 decision
         double v[1] = {(double)((stop && *stop) ? 1 : 0)};
         if ((rc = allreduce_host(v, 1))) return rc;
@@ -503,6 +566,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
         rc = optimize(pr->num_second_iter, &it2);
         if (rc) return rc;
         st.iters_stage2 = it2;
+        lap("stage 2");
     }
     // ---- outlier list, final chi2, read-back
     std::vector<uint8_t> outl(E);
@@ -533,6 +597,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
     }
     for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
     st.chi2_final = chi1;
+    lap("read-back");
     st.lambda_final = lambda;
     if (stats) *stats = st;
 #undef H2D
