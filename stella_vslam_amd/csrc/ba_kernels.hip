@@ -368,92 +368,217 @@ __global__ __launch_bounds__(1024) void k_ba_rhs(BaDev D) {
 //   (3) rank-16 update of the trailing matrix on a 16x16 thread lattice,
 // i.e. 3 workgroup barriers per 16 columns instead of 3 per column.  Row n (the right-hand side) rides along, so
 // after the factorisation it holds L^-1 g; wave 0 finishes with the back substitution.
-#define CHOL_NB 16
+#define CHOL_THREADS 512
+#define CHOL_NB 8
+// broadcast a double from a compile-time lane through SGPRs (v_readlane_b32 x2) -- no LDS round trip
+template <int LANE>
+__device__ __forceinline__ double bcast_d(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(x) in fp64: fp32 hardware seed + two Newton steps (relative error ~1e-16 for normal fp32-range x)
+__device__ __forceinline__ double fast_rsqrt_d(double x) {
+    if (!(x > 1e-30 && x < 1e30)) return rsqrt(x);
+    double y = (double)__frsqrt_rn((float)x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+template <int J>
+struct ChoStep {  // one column of the register-resident 16x16 factorisation (compile-time recursion keeps lanes constant)
+    __device__ static __forceinline__ void run(double (&r)[CHOL_NB], double (&invd)[CHOL_NB], bool& bad, int lane) {
+        const double djj = bcast_d<J>(r[J]);
+        bad = bad || !(djj > 0.0);
+        const double inv = fast_rsqrt_d(djj);
+        invd[J] = inv;
+        if (lane == J) r[J] = djj * inv;
+        else if (lane > J) r[J] *= inv;
+        upd<J + 1>(r, lane);
+        ChoStep<J + 1>::run(r, invd, bad, lane);
+    }
+    template <int K>
+    __device__ static __forceinline__ void upd(double (&r)[CHOL_NB], int lane) {
+        if constexpr (K < CHOL_NB) {
+            const double lkj = bcast_d<K>(r[J]);
+            if (lane >= K) r[K] -= r[J] * lkj;
+            upd<K + 1>(r, lane);
+        }
+    }
+};
+template <>
+struct ChoStep<CHOL_NB> {
+    __device__ static __forceinline__ void run(double (&)[CHOL_NB], double (&)[CHOL_NB], bool&, int) {}
+};
+template <int I>
+struct InvStep {  // row I of the forward substitutions L x = e_lane
+    __device__ static __forceinline__ void run(const double (&r)[CHOL_NB], const double (&invd)[CHOL_NB], double (&x)[CHOL_NB], int lane) {
+        double acc = (I == lane) ? 1.0 : 0.0;
+        dot<0>(r, x, acc);
+        x[I] = (I >= lane) ? acc * invd[I] : 0.0;
+        InvStep<I + 1>::run(r, invd, x, lane);
+    }
+    template <int K>
+    __device__ static __forceinline__ void dot(const double (&r)[CHOL_NB], const double (&x)[CHOL_NB], double& acc) {
+        if constexpr (K < I) {
+            acc -= bcast_d<I>(r[K]) * x[K];
+            dot<K + 1>(r, x, acc);
+        }
+    }
+};
+template <>
+struct InvStep<CHOL_NB> {
+    __device__ static __forceinline__ void run(const double (&)[CHOL_NB], const double (&)[CHOL_NB], double (&)[CHOL_NB], int) {}
+};
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void k_ba_chol_lds(BaDev D) {
+__global__ __launch_bounds__(CHOL_THREADS) void k_ba_chol_lds(BaDev D) {
     extern __shared__ double s_A[];
+    __shared__ double s_X[CHOL_NB][CHOL_NB + 1];  // inverse of the current diagonal block of L
+    __shared__ double s_invd[1024];               // 1 / L_ii
     __shared__ int s_fail;
-    const int n = D.n, tid = threadIdx.x, lane = tid & 63;
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
     const int ld = n | 1;
     double* A = s_A;
-    for (int i = tid; i < (n + 1) * n; i += 256) A[(i / n) * ld + (i % n)] = D.S[i];
+    for (int r = tid / n, c = tid % n; r <= n; r += (c + nt) / n, c = (c + nt) % n) A[r * ld + c] = D.S[(size_t)r * n + c];
     if (tid == 0) s_fail = 0;
     __syncthreads();
+    long long tmark = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0};
+#define CHOL_LAP(slot)                                        \
+    {                                                         \
+        const long long now = __builtin_amdgcn_s_memtime();   \
+        t_acc[slot] += now - tmark;                           \
+        tmark = now;                                          \
+    }
     for (int jb = 0; jb < n; jb += CHOL_NB) {
-        const int je = min(jb + CHOL_NB, n);
-        if (tid < 64) {  // (1) diagonal block
+        const int je = min(jb + CHOL_NB, n), w = je - jb;
+        if (tid < 64) {
+            // (1) diagonal block in registers: lane i < 16 holds row i (lanes beyond the block hold identity rows)
+            double r[CHOL_NB];
+#pragma unroll
+            for (int c = 0; c < CHOL_NB; ++c) r[c] = (lane < w && c <= lane) ? A[(jb + lane) * ld + jb + c] : (c == lane ? 1.0 : 0.0);
+            double invd[CHOL_NB];
             bool bad = false;
-            for (int j = jb; j < je; ++j) {
-                const double djj = A[j * ld + j];
-                if (!(djj > 0.0)) {
-                    bad = true;
-                    break;  // wave-uniform
+            ChoStep<0>::run(r, invd, bad, lane);
+            // X = L^-1 (lower triangular): lane c solves L x = e_c by forward substitution, L_ik broadcast from lane i
+            double x[CHOL_NB];
+            InvStep<0>::run(r, invd, x, lane);
+            if (lane < CHOL_NB) {
+#pragma unroll
+                for (int i = 0; i < CHOL_NB; ++i) s_X[i][lane] = x[i];
+                if (lane < w) {
+#pragma unroll
+                    for (int c = 0; c < CHOL_NB; ++c)
+                        if (c <= lane) A[(jb + lane) * ld + jb + c] = r[c];
+                    double mine = invd[0];
+#pragma unroll
+                    for (int c = 1; c < CHOL_NB; ++c) mine = (lane == c) ? invd[c] : mine;
+                    s_invd[jb + lane] = mine;
                 }
-                const double d = sqrt(djj);
-                wave_lds_sync();
-                for (int i = j + lane; i < je; i += 64) A[i * ld + j] = (i == j) ? d : A[i * ld + j] / d;
-                wave_lds_sync();
-                const int k = j + 1 + (lane & 15);
-                for (int i = j + 1 + (lane >> 4); i < je; i += 4)
-                    if (k <= i) A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
-                wave_lds_sync();
             }
             if (bad && lane == 0) s_fail = 1;
         }
         __syncthreads();
+        CHOL_LAP(0)
         if (s_fail) break;
-        for (int i = je + tid; i <= n; i += 256) {  // (2) panel rows (row n = right-hand side)
-            double x[CHOL_NB];
+        // (2) panel: L21 = A21 * L11^-T, one thread per row (row n = right-hand side); no dependent chain
+        for (int i = je + tid; i <= n; i += nt) {
+            double a[CHOL_NB], o[CHOL_NB];
 #pragma unroll
-            for (int c = 0; c < CHOL_NB; ++c) x[c] = (jb + c < je) ? A[i * ld + jb + c] : 0.0;
+            for (int k = 0; k < CHOL_NB; ++k) a[k] = A[i * ld + min(jb + k, n - 1)];
 #pragma unroll
-            for (int c = 0; c < CHOL_NB; ++c) {
-                if (jb + c < je) {
-                    double v = x[c];
+            for (int k = 0; k < CHOL_NB; ++k) a[k] = (k < w) ? a[k] : 0.0;
 #pragma unroll
-                    for (int k = 0; k < c; ++k) v -= x[k] * A[(jb + c) * ld + jb + k];
-                    x[c] = v / A[(jb + c) * ld + jb + c];
-                }
+            for (int c = 0; c < CHOL_NB; ++c) {  // s_X rows/cols beyond the block are those of the identity: harmless
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k <= c; ++k) v += a[k] * s_X[c][k];
+                o[c] = v;
             }
 #pragma unroll
             for (int c = 0; c < CHOL_NB; ++c)
-                if (jb + c < je) A[i * ld + jb + c] = x[c];
+                if (c < w) A[i * ld + jb + c] = o[c];
         }
         __syncthreads();
-        {  // (3) trailing update: rows je..n, columns je..min(i, n-1)
-            const int ti = tid >> 4, tj = tid & 15, w = je - jb;
-            for (int i = je + ti; i <= n; i += 16) {
+        CHOL_LAP(1)
+        {  // (3) trailing update: rows je..n, columns je..min(i, n-1); the 2 x 16 panel values are loaded up front
+            const int ti = tid >> 4, tj = tid & 15, tstep = nt >> 4;
+            for (int i = je + ti; i <= n; i += tstep) {
                 const int kmax = i < n ? i : n - 1;
+                double li[CHOL_NB];
+#pragma unroll
+                for (int c = 0; c < CHOL_NB; ++c) li[c] = A[i * ld + min(jb + c, n - 1)];
+#pragma unroll
+                for (int c = 0; c < CHOL_NB; ++c) li[c] = (c < w) ? li[c] : 0.0;
                 for (int k = je + tj; k <= kmax; k += 16) {
+                    double lk[CHOL_NB];
+#pragma unroll
+                    for (int c = 0; c < CHOL_NB; ++c) lk[c] = A[k * ld + min(jb + c, n - 1)];
                     double v = A[i * ld + k];
-                    for (int c = 0; c < w; ++c) v -= A[i * ld + jb + c] * A[k * ld + jb + c];
+#pragma unroll
+                    for (int c = 0; c < CHOL_NB; ++c) v -= li[c] * lk[c];
                     A[i * ld + k] = v;
                 }
             }
         }
         __syncthreads();
+        CHOL_LAP(2)
     }
     if (s_fail) {
         if (tid == 0) D.red[D.red_flag_off] = 1.0;
-        for (int i = tid; i < n; i += 256) D.dp[i] = 0.0;
+        for (int i = tid; i < n; i += nt) D.dp[i] = 0.0;
         return;
     }
-    if (tid < 64) {  // back substitution L^T x = y (y = row n), column oriented, wave-synchronous
-        for (int i = n - 1; i >= 0; --i) {
-            const double xi = A[n * ld + i] / A[i * ld + i];
-            wave_lds_sync();
-            if (lane == 0) A[n * ld + i] = xi;
-            for (int k = lane; k < i; k += 64) A[n * ld + k] -= A[i * ld + k] * xi;
-            wave_lds_sync();
+    if (tid < 64) {
+        // back substitution L^T x = y (y = row n) in wave 0: y and 1/L_ii live in registers (lane k holds entries
+        // k, k+64, k+128), x_i is broadcast with v_readlane, row i-1 of L is prefetched while row i is applied
+        double y[3], iv[3], l[3], l1[3], l2[3];
+        auto row = [&](int i, double (&dst)[3]) {  // entries k < i of row i of L (lanes hold k, k+64, k+128)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int k = lane + 64 * q;
+                dst[q] = A[max(i, 0) * ld + min(k, n - 1)];
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = lane + 64 * q;
+            y[q] = k < n ? A[n * ld + k] : 0.0;
+            iv[q] = k < n ? s_invd[k] : 0.0;
         }
+        row(n - 1, l);
+        row(n - 2, l1);
+        for (int i = n - 1; i >= 0; --i) {
+            row(i - 2, l2);  // two rows of LDS latency are hidden behind the arithmetic
+            const int qi = i >> 6, li = i & 63;
+            const double ysel = qi == 0 ? y[0] : (qi == 1 ? y[1] : y[2]);
+            const double isel = qi == 0 ? iv[0] : (qi == 1 ? iv[1] : iv[2]);
+            const double prod = ysel * isel;
+            const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(prod), li),
+                                               __builtin_amdgcn_readlane(__double2loint(prod), li));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int k = lane + 64 * q;
+                if (k == i) y[q] = xi;
+                else if (k < i) y[q] -= l[q] * xi;
+                l[q] = l1[q];
+                l1[q] = l2[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = lane + 64 * q;
+            if (k < n) D.dp[k] = y[q];
+        }
+        CHOL_LAP(3)
+        if (lane == 0)
+            for (int q = 0; q < 4; ++q) D.red[D.red_flag_off + 2 + q] = (double)t_acc[q];
     }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) D.dp[i] = A[n * ld + i];
 }
 
 // Fallback for systems that do not fit LDS (n > ~140): same arithmetic on the global copy, one column per step.
@@ -694,7 +819,7 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
                 (void)hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(256), lds, s, D);
+            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
         }
         else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
     }

@@ -385,7 +385,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
         D.NB = (int)HS.blk_ab.size();
-        D.chol_in_lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 256;
+        D.chol_in_lds = D.n <= 192 && sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 12 * 1024;
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
@@ -480,6 +480,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
                     for (int i = 0; i < nb_chi; ++i) temp_chi += red_host[D.red_chi_off + i];
                 for (int i = 0; i < nb_lm + nb_pose; ++i) scale += red_host[D.red_scale_off + i];
                 bool ok2 = red_host[D.red_flag_off] == 0.0;
+                if (trace) std::fprintf(stderr, "[ba]     chol cycles diag %.0f panel %.0f trail %.0f back %.0f\n", red_host[D.red_flag_off + 2], red_host[D.red_flag_off + 3], red_host[D.red_flag_off + 4], red_host[D.red_flag_off + 5]);
                 if (sharded) {
                     double v[4] = {temp_chi, scale, ok2 ? 0.0 : 1.0, (double)(*flag ? 1 : 0)};
                     if ((r = allreduce_host(v, 4))) return r;
