@@ -2,7 +2,7 @@
 #pragma once
 #include <cstdint>
 
-#define BF_K 16  // per-query candidate prefix kept by k_bf_topk
+#define BF_K 16  // per-query candidate prefix kept by k_bf_topk (candidates within dmax only; exact fallback when exhausted)
 
 struct BfProblem {
     // side 1 = frame (scanned), side 2 = keyframe (queries); `pairs` independent problems, row p at p*cap
@@ -21,6 +21,12 @@ struct BfProblem {
     int check_orientation;
     unsigned dmax;        // candidates farther than this are never listed (see k_bf_topk)
     int exhaustive;       // 1 when dmax >= 256: the list is a plain prefix of all candidates
+    // angle-bin sorted copies (k_bf_binsort): descriptors, angles, original indices, bin starts (362 per pair and side)
+    uint32_t *sd1, *sd2;
+    float *sa1, *sa2;
+    int *si1, *si2;
+    int *bs1, *bs2;
+    int* prune_ok;        // pairs * 2: every angle of the side lies in [0, 360]
     uint32_t* topk;       // pairs * cap2 * BF_K
     int32_t* cnt;         // pairs * cap2
     int32_t* matched;     // pairs * cap1

@@ -63,50 +63,143 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ brute force
-// Block = 64 queries (keyframe keypoints idx_2) x 4 candidate quarters: wave w scans quarter w of the frame
-// keypoints idx_1 for its 64 queries.  The candidate index is wave-uniform, so candidate descriptors and
-// angles arrive through the scalar cache (s_load) and never touch LDS; each lane keeps the BF_K smallest
-// (dist << 16 | idx_1) keys of its quarter in registers, the four sorted lists are merged through LDS.
+// ---- orientation pruning.  v_xor + v_bcnt_u32_b32 cost ~9 cycles per wave and 32-bit word on gfx950, so a full
+// 2.4k x 2.4k x 256-bit brute force is VALU-bound near 180 us per 64 pairs; the only real lever is to do fewer
+// distance evaluations.  With check_orientation the reference rejects every pair whose angles differ by more
+// than 30 degrees BEFORE looking at the descriptors (robust.cc:279), so both sides are first bucketed into 360
+// one-degree angle bins (k_bf_binsort: LDS histogram + scan + scatter into angle-sorted copies); a block of
+// queries then scans only the candidate bins within 31 bins of its own bin range (a superset of the pairs that pass
+// the exact gate, which is still evaluated per pair).  Results are keyed by ORIGINAL indices and the per-query
+// lists are sets, so the outcome is identical to the unpruned scan.
+#define BF_BINS 360
+__global__ __launch_bounds__(256) void k_bf_binsort(BfProblem P) {
+    __shared__ int s_hist[BF_BINS + 2];
+    __shared__ int s_start[BF_BINS + 2];
+    __shared__ int s_bad;
+    const int pair = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+    const int cap = side == 0 ? P.cap1 : P.cap2;
+    const int nraw = side == 0 ? (P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1) : (P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2);
+    const int n = min(nraw, cap);
+    const uint32_t* D = (side == 0 ? P.desc1 : P.desc2) + (size_t)pair * cap * 8;
+    const float* A = (side == 0 ? P.angle1 : P.angle2) + (size_t)pair * cap * P.angle_stride;
+    uint32_t* SD = (side == 0 ? P.sd1 : P.sd2) + (size_t)pair * cap * 8;
+    float* SA = (side == 0 ? P.sa1 : P.sa2) + (size_t)pair * cap;
+    int* SI = (side == 0 ? P.si1 : P.si2) + (size_t)pair * cap;
+    int* BS = (side == 0 ? P.bs1 : P.bs2) + (size_t)pair * (BF_BINS + 2);
+    for (int b = tid; b < BF_BINS + 2; b += 256) s_hist[b] = 0;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    auto bin_of = [&](float a, bool& ok) {
+        ok = a >= 0.f && a <= 360.f;
+        return ok ? min((int)a, BF_BINS - 1) : 0;
+    };
+    for (int i = tid; i < n; i += 256) {
+        bool ok;
+        const int b = bin_of(A[(size_t)i * P.angle_stride], ok);
+        if (!ok) s_bad = 1;
+        atomicAdd(&s_hist[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 0; b < BF_BINS; ++b) {
+            s_start[b] = run;
+            run += s_hist[b];
+        }
+        s_start[BF_BINS] = s_start[BF_BINS + 1] = run;
+    }
+    __syncthreads();
+    for (int b = tid; b < BF_BINS + 2; b += 256) {
+        BS[b] = s_start[b];
+        s_hist[b] = 0;  // reused as the per-bin cursor
+    }
+    if (tid == 0) P.prune_ok[pair * 2 + side] = s_bad ? 0 : 1;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        bool ok;
+        const float a = A[(size_t)i * P.angle_stride];
+        const int b = bin_of(a, ok);
+        const int dst = s_start[b] + atomicAdd(&s_hist[b], 1);
+        const uint4 lo = *reinterpret_cast<const uint4*>(D + (size_t)i * 8), hi = *reinterpret_cast<const uint4*>(D + (size_t)i * 8 + 4);
+        *reinterpret_cast<uint4*>(SD + (size_t)dst * 8) = lo;
+        *reinterpret_cast<uint4*>(SD + (size_t)dst * 8 + 4) = hi;
+        SA[dst] = a;
+        SI[dst] = i;
+    }
+}
+
+// Block = 256 queries (keyframe keypoints idx_2, in angle-bin order), one per lane.  The candidate range (frame
+// keypoints idx_1 whose bin is within 31 of the block's bins; everything when pruning is off) streams through
+// double-buffered LDS tiles shared by the four waves; a candidate descriptor is two broadcast ds_read_b128
+// (conflict-free: every lane reads the same address), compared with v_xor / v_bcnt_u32_b32.  Each query keeps its
+// BF_K smallest (dist << 16 | original idx_1) keys among the candidates within dmax.
 // Ascending key order = the reference's scan preference (strict '<' => lowest index wins ties).
+#define BF_QB 256
+#define BF_TILE 128
 __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
-    __shared__ uint32_t s_l[4 * 64 * (BF_K + 1)];
-    __shared__ int s_c[4 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_d[2][BF_TILE * 8];
+    __shared__ float s_a[2][BF_TILE];
+    __shared__ int s_i[2][BF_TILE];
     const int pair = blockIdx.y;
     const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
-    if (blockIdx.x * 64 >= n2c) return;
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const uint32_t* __restrict__ D1 = P.desc1 + (size_t)pair * P.cap1 * 8;
-    const uint32_t* __restrict__ D2 = P.desc2 + (size_t)pair * P.cap2 * 8;
-    const float* __restrict__ A1 = P.angle1 + (size_t)pair * P.cap1 * P.angle_stride;
-    const bool active = j < n2c && (!P.valid2 || P.valid2[(size_t)pair * P.cap2 + j]);
-    uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float qa = 0.f;
-    if (active) {
+    if (blockIdx.x * BF_QB >= n2c) return;
+    const int tid = threadIdx.x;
+    const uint32_t* __restrict__ D1 = P.sd1 + (size_t)pair * P.cap1 * 8;
+    const float* __restrict__ A1 = P.sa1 + (size_t)pair * P.cap1;
+    const int* __restrict__ I1 = P.si1 + (size_t)pair * P.cap1;
+    const uint32_t* __restrict__ D2 = P.sd2 + (size_t)pair * P.cap2 * 8;
+    const float* __restrict__ A2 = P.sa2 + (size_t)pair * P.cap2;
+    const int* __restrict__ I2 = P.si2 + (size_t)pair * P.cap2;
+    const int* __restrict__ BS1 = P.bs1 + (size_t)pair * (BF_BINS + 2);
+    const bool ori = P.check_orientation != 0;
+    // ---- this lane's query
+    const int r = blockIdx.x * BF_QB + tid, rr = min(r, n2c - 1);
+    const int j = I2[rr];
+    const bool active = r < n2c && (!P.valid2 || P.valid2[(size_t)pair * P.cap2 + j]);
+    uint32_t q[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) q[k] = D2[(size_t)j * 8 + k];
-        qa = P.angle2[((size_t)pair * P.cap2 + j) * P.angle_stride];
-    }
+    for (int k = 0; k < 8; ++k) q[k] = D2[(size_t)rr * 8 + k];
+    const float qa = A2[rr];
     uint32_t L[BF_K];
 #pragma unroll
     for (int k = 0; k < BF_K; ++k) L[k] = 0xFFFFFFFFu;
     int cnt = 0;
-    const int chunk = (n1c + 3) / 4;
-    const int i0 = __builtin_amdgcn_readfirstlane(part * chunk);
-    const int i1 = min(n1c, i0 + chunk);
-    const bool ori = P.check_orientation != 0;
+    // ---- candidate ranges of the block (block-uniform): up to two runs of the angle-sorted side 1
+    int seg_lo[2] = {0, 0}, seg_hi[2] = {n1c, 0};
+    if (ori && P.prune_ok[pair * 2] && P.prune_ok[pair * 2 + 1]) {
+        const int r_lo = blockIdx.x * BF_QB, r_hi = min(r_lo + BF_QB - 1, n2c - 1);
+        const int b_lo = min((int)A2[r_lo], BF_BINS - 1) - 31, b_hi = min((int)A2[r_hi], BF_BINS - 1) + 31;
+        if (b_hi - b_lo + 1 < BF_BINS) {
+            if (b_lo < 0) {
+                seg_lo[0] = BS1[b_lo + BF_BINS];
+                seg_hi[0] = n1c;
+                seg_lo[1] = 0;
+                seg_hi[1] = BS1[b_hi + 1];
+            }
+            else if (b_hi >= BF_BINS) {
+                seg_lo[0] = BS1[b_lo];
+                seg_hi[0] = n1c;
+                seg_lo[1] = 0;
+                seg_hi[1] = BS1[b_hi - BF_BINS + 1];
+            }
+            else {
+                seg_lo[0] = BS1[b_lo];
+                seg_hi[0] = BS1[b_hi + 1];
+            }
+        }
+    }
     // Only candidates with dist <= dmax can influence a decision (best must be <= 50, and the ratio test
     // lowe_ratio * second < best can only reject when second < 50 / lowe_ratio): everything farther is never listed.
     const unsigned dmax = P.dmax;
-    auto consider = [&](int i, unsigned d, float ca) {
-        if (d <= dmax) {  // rare: wave-level branch is almost never taken for unrelated descriptors
+    auto consider = [&](int idx, unsigned d, float ca) {
+        if (d <= dmax) {
             bool pass = active;
             if (ori) pass = pass && !(fabsf(angle_diff(ca, qa)) > 30.0f);
             if (pass) {
                 ++cnt;
-                const uint32_t key = (d << 16) | (uint32_t)i;
+                const uint32_t key = (d << 16) | (uint32_t)idx;
                 if (key < L[BF_K - 1]) {
 #pragma unroll
                     for (int k = BF_K - 1; k > 0; --k) L[k] = max(L[k - 1], min(L[k], key));
@@ -115,60 +208,54 @@ __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
             }
         }
     };
-    int i = i0;
-    for (; i + 4 <= i1; i += 4) {  // 4 candidates per trip: the scalar loads are issued back to back
-        uint32_t c[4][8];
-        float ca[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c[u][k] = D1[(size_t)(i + u) * 8 + k];
-            ca[u] = A1[(size_t)(i + u) * P.angle_stride];
+    // tile loader: 128 descriptors = 1024 dwords = one uint4 per thread (tail entries all-ones: far from everything)
+    auto load_tile = [&](int buf, int base, int end) {
+        const int m = min(BF_TILE, end - base);
+        uint4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (tid * 4 < m * 8) v = *reinterpret_cast<const uint4*>(D1 + (size_t)base * 8 + tid * 4);
+        reinterpret_cast<uint4*>(s_d[buf])[tid] = v;
+        if (tid < BF_TILE) {
+            s_a[buf][tid] = tid < m ? A1[base + tid] : 0.f;
+            s_i[buf][tid] = tid < m ? I1[base + tid] : 0;
         }
-        unsigned d[4];
+    };
+    int buf = 0;
+    for (int sg = 0; sg < 2; ++sg) {
+        const int lo = seg_lo[sg], hi = seg_hi[sg];
+        if (lo >= hi) continue;
+        __syncthreads();
+        load_tile(buf, lo, hi);
+        __syncthreads();
+        for (int base = lo; base < hi; base += BF_TILE, buf ^= 1) {
+            if (base + BF_TILE < hi) load_tile(buf ^ 1, base + BF_TILE, hi);  // next tile lands while this one is consumed
+            const int m = min(BF_TILE, hi - base);
+            const uint32_t* T = s_d[buf];
+            for (int i = 0; i < m; i += 4) {  // 4 candidates per trip
+                uint4 c[4][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            d[u] = 0;
+                for (int u = 0; u < 4; ++u) {
+                    c[u][0] = *reinterpret_cast<const uint4*>(T + (i + u) * 8);
+                    c[u][1] = *reinterpret_cast<const uint4*>(T + (i + u) * 8 + 4);
+                }
+                unsigned d[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) d[u] += __popc(q[k] ^ c[u][k]);
-        }
+                for (int u = 0; u < 4; ++u)
+                    d[u] = __popc(q[0] ^ c[u][0].x) + __popc(q[1] ^ c[u][0].y) + __popc(q[2] ^ c[u][0].z) + __popc(q[3] ^ c[u][0].w)
+                           + __popc(q[4] ^ c[u][1].x) + __popc(q[5] ^ c[u][1].y) + __popc(q[6] ^ c[u][1].z) + __popc(q[7] ^ c[u][1].w);
+                if (min(min(d[0], d[1]), min(d[2], d[3])) <= dmax) {  // rarely-taken wave-level branch
 #pragma unroll
-        for (int u = 0; u < 4; ++u) consider(i + u, d[u], ca[u]);
-    }
-    for (; i < i1; ++i) {
-        unsigned d = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ D1[(size_t)i * 8 + k]);
-        consider(i, d, A1[(size_t)i * P.angle_stride]);
-    }
-    // merge the four quarter lists of each query (lane of wave 0 does a 4-way merge of sorted lists)
-    uint32_t* mine = &s_l[(part * 64 + lane) * (BF_K + 1)];
-#pragma unroll
-    for (int k = 0; k < BF_K; ++k) mine[k] = L[k];
-    mine[BF_K] = 0xFFFFFFFFu;  // sentinel
-    s_c[part * 64 + lane] = cnt;
-    __syncthreads();
-    if (part == 0 && j < n2c) {
-        const uint32_t* l0 = &s_l[(0 * 64 + lane) * (BF_K + 1)];
-        const uint32_t* l1 = &s_l[(1 * 64 + lane) * (BF_K + 1)];
-        const uint32_t* l2 = &s_l[(2 * 64 + lane) * (BF_K + 1)];
-        const uint32_t* l3 = &s_l[(3 * 64 + lane) * (BF_K + 1)];
-        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        uint32_t* T = P.topk + ((size_t)pair * P.cap2 + j) * BF_K;
-        for (int k = 0; k < BF_K; ++k) {
-            const uint32_t v0 = l0[p0], v1 = l1[p1], v2 = l2[p2], v3 = l3[p3];
-            const uint32_t m = min(min(v0, v1), min(v2, v3));
-            if (m == 0xFFFFFFFFu) {
-                T[k] = m;
-                continue;
+                    for (int u = 0; u < 4; ++u)
+                        if (i + u < m) consider(s_i[buf][i + u], d[u], s_a[buf][i + u]);
+                }
             }
-            if (m == v0) ++p0;
-            else if (m == v1) ++p1;
-            else if (m == v2) ++p2;
-            else ++p3;
-            T[k] = m;
+            __syncthreads();
         }
-        P.cnt[(size_t)pair * P.cap2 + j] = s_c[lane] + s_c[64 + lane] + s_c[128 + lane] + s_c[192 + lane];
+    }
+    if (r < n2c) {
+        uint32_t* T = P.topk + ((size_t)pair * P.cap2 + j) * BF_K;
+#pragma unroll
+        for (int k = 0; k < BF_K; k += 4) *reinterpret_cast<uint4*>(T + k) = make_uint4(L[k], L[k + 1], L[k + 2], L[k + 3]);
+        P.cnt[(size_t)pair * P.cap2 + j] = active ? cnt : 0;
     }
 }
 
@@ -393,7 +480,8 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     P.exhaustive = P.dmax >= 256u;
     {
         SvProfScope ps(ctx, s, "k_bf_topk");
-        hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + 63) / 64, pairs), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_bf_binsort, dim3(pairs, 2), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + BF_QB - 1) / BF_QB, pairs), dim3(256), 0, s, P);
     }
     SvProfScope ps(ctx, s, "k_bf_replay");
     const size_t lds = (size_t)(P.cap1 + P.cap2) * sizeof(int);

@@ -18,6 +18,24 @@ struct Arena {
 };
 inline size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 
+// scratch for the angle-bin sorted copies of both sides (see k_bf_binsort)
+inline size_t sort_bytes(int pairs, int cap1, int cap2) {
+    const size_t p = (size_t)pairs;
+    return pad(p * cap1 * 32) + pad(p * cap2 * 32) + 2 * pad(p * cap1 * 4) + 2 * pad(p * cap2 * 4) + 2 * pad(p * 362 * 4) + pad(p * 2 * 4);
+}
+inline void take_sort(Arena& A, BfProblem& P, int pairs, int cap1, int cap2) {
+    const size_t p = (size_t)pairs;
+    P.sd1 = A.take<uint32_t>(p * cap1 * 8);
+    P.sd2 = A.take<uint32_t>(p * cap2 * 8);
+    P.sa1 = A.take<float>(p * cap1);
+    P.si1 = A.take<int>(p * cap1);
+    P.sa2 = A.take<float>(p * cap2);
+    P.si2 = A.take<int>(p * cap2);
+    P.bs1 = A.take<int>(p * 362);
+    P.bs2 = A.take<int>(p * 362);
+    P.prune_ok = A.take<int>(p * 2);
+}
+
 }  // namespace
 
 extern "C" {
@@ -73,7 +91,7 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce_batch_device: bad arguments");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = pad((size_t)pairs * cap2 * BF_K * 4) + pad((size_t)pairs * cap2 * 4) + pad((size_t)pairs * cap1 * 4)
-                        + pad((size_t)pairs * cap2 * 4);
+                        + pad((size_t)pairs * cap2 * 4) + sort_bytes(pairs, cap1, cap2);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -95,6 +113,7 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
     P.cnt = A.take<int32_t>((size_t)pairs * cap2);
     int* g_owner = A.take<int>((size_t)pairs * cap1);
     int* g_match = A.take<int>((size_t)pairs * cap2);
+    take_sort(A, P, pairs, cap1, cap2);
     P.matched = matched_dev;
     P.num = num_dev;
     sv_launch_bf(ctx, stream ? (hipStream_t)stream : ctx->stream, P, pairs, g_owner, g_match);
@@ -115,7 +134,8 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce: null input");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = pad((size_t)n1 * 32) + pad((size_t)n2 * 32) + pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + pad(n2)
-                        + pad((size_t)n2 * BF_K * 4) + pad((size_t)n2 * 4) + 2 * pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + 256;
+                        + pad((size_t)n2 * BF_K * 4) + pad((size_t)n2 * 4) + 2 * pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + 256
+                        + sort_bytes(1, n1, n2);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -131,6 +151,7 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
     int* g_owner = A.take<int>(n1);
     int* g_match = A.take<int>(n2);
     P.num = A.take<int32_t>(1);
+    take_sort(A, P, 1, n1, n2);
     hipStream_t s = ctx->stream;
     SV_HIP(ctx, hipMemcpyAsync(d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
     SV_HIP(ctx, hipMemcpyAsync(d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
