@@ -267,7 +267,7 @@ __device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uin
     const bool truncated = cnt > BF_K;
     uint32_t a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu;
     for (int k = 0; k < m; ++k) {
-        const uint32_t key = T[k];
+        const uint32_t key = T[k];  // sorted ascending; usually m <= 3
         if (owner[key & 0xFFFFu] < j) continue;  // claimed by an earlier query (already_matched_indices_1)
         if (a0 == 0xFFFFFFFFu) a0 = key;
         else {
@@ -289,35 +289,56 @@ __device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uin
     else {
         if (d_beyond > HAMMING_DIST_THR_LOW) return -1;  // everything unlisted is at least that far
     }
-    // ---- undecidable from the prefix: exact serial scan of this row (robust.cc:271-298)
+    return -3;  // undecidable from the prefix: the workgroup scans this row exactly (bf_full_row)
+}
+
+// Exact decision of one query by a cooperative scan of the whole row (robust.cc:271-314): every thread takes a
+// strided share of the candidates, (best key, second distance) are combined with LDS atomicMin.
+__device__ int bf_full_row(const BfProblem& P, int pair, int j, int n1c, const int* owner, uint32_t* s_best, uint32_t* s_second) {
     const uint32_t* D1 = P.desc1 + (size_t)pair * P.cap1 * 8;
     const uint32_t* D2 = P.desc2 + ((size_t)pair * P.cap2 + j) * 8;
     uint32_t q[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) q[k] = D2[k];
     const float qa = P.angle2[((size_t)pair * P.cap2 + j) * P.angle_stride];
-    unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
-    int best_idx = -1;
-    for (int i = 0; i < n1c; ++i) {
+    if (threadIdx.x == 0) {
+        *s_best = 0xFFFFFFFFu;
+        *s_second = MAX_HAMMING_DIST;
+    }
+    __syncthreads();
+    uint32_t k1 = 0xFFFFFFFFu;       // smallest (dist << 16 | idx) of this thread's share
+    unsigned d2 = MAX_HAMMING_DIST;  // second smallest distance of this thread's share
+    for (int i = threadIdx.x; i < n1c; i += blockDim.x) {
         if (owner[i] < j) continue;
         if (P.check_orientation && fabsf(angle_diff(P.angle1[((size_t)pair * P.cap1 + i) * P.angle_stride], qa)) > 30.0f) continue;
-        const unsigned d = hamming256(q, D1 + (size_t)i * 8);
-        if (d < best) {
-            second = best;
-            best = d;
-            best_idx = i;
+        const uint32_t key = (hamming256(q, D1 + (size_t)i * 8) << 16) | (uint32_t)i;
+        if (key < k1) {
+            d2 = min(d2, k1 >> 16);
+            k1 = key;
         }
-        else if (d < second) second = d;
+        else d2 = min(d2, key >> 16);
     }
-    if (HAMMING_DIST_THR_LOW < best || best_idx < 0) return -1;
+    if (k1 != 0xFFFFFFFFu) atomicMin(s_best, k1);
+    __syncthreads();
+    const uint32_t kb = *s_best;
+    const unsigned mine = (k1 == kb) ? d2 : min(d2, k1 == 0xFFFFFFFFu ? MAX_HAMMING_DIST : (k1 >> 16));
+    if (mine < MAX_HAMMING_DIST) atomicMin(s_second, mine);
+    __syncthreads();
+    const unsigned second = *s_second;
+    __syncthreads();
+    if (kb == 0xFFFFFFFFu) return -1;
+    const unsigned best = kb >> 16;
+    if (HAMMING_DIST_THR_LOW < best) return -1;
     if (P.lowe_ratio * (float)second < (float)best) return -1;
-    return best_idx;
+    return (int)(kb & 0xFFFFu);
 }
 
 // One workgroup per pair.  owner[n1] / match[n2] live in LDS when they fit, else in global scratch.
-__global__ __launch_bounds__(256) void k_bf_replay(BfProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds) {
+__global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds) {
     extern __shared__ int s_mem[];
-    __shared__ int s_changed;
+    __shared__ int s_changed, s_nund;
+    __shared__ int s_und[1024];  // one slot per thread of a stride: can never overflow
+    __shared__ uint32_t s_best, s_second;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
@@ -326,35 +347,56 @@ __global__ __launch_bounds__(256) void k_bf_replay(BfProblem P, int* __restrict_
     int* match = use_lds ? s_mem + P.cap1 : g_match + (size_t)pair * P.cap2;
     const uint32_t* T = P.topk + (size_t)pair * P.cap2 * BF_K;
     const int* C = P.cnt + (size_t)pair * P.cap2;
-    for (int i = tid; i < n1c; i += 256) owner[i] = 0x7FFFFFFF;
-    for (int j = tid; j < n2c; j += 256) match[j] = -2;  // "unknown": forces at least one full sweep
+    for (int i = tid; i < n1c; i += blockDim.x) owner[i] = 0x7FFFFFFF;
+    for (int j = tid; j < n2c; j += blockDim.x) match[j] = -2;  // "unknown": forces at least one full sweep
     __syncthreads();
     for (int sweep = 0; sweep <= n2c; ++sweep) {
-        if (tid == 0) s_changed = 0;
+        if (tid == 0) {
+            s_changed = 0;
+            s_nund = 0;
+        }
         __syncthreads();
         int local_changed = 0;
-        // decisions against the owner table of the previous sweep; results parked in registers via match2 pass
-        for (int j = tid; j < n2c; j += 256) {
-            const int d = bf_decide(P, pair, j, n1c, T + (size_t)j * BF_K, C[j], owner);
-            if (d != match[j]) local_changed = 1;
-            // stash the new decision in the sign-safe upper half: decisions only read `owner`, not `match`
-            match[j] = d;
+        // decisions against the owner table of the previous sweep (decisions read `owner`, never `match`)
+        for (int j0 = 0; j0 < n2c; j0 += blockDim.x) {
+            const int j = j0 + tid;
+            int d = -1;
+            if (j < n2c) {
+                d = bf_decide(P, pair, j, n1c, T + (size_t)j * BF_K, C[j], owner);
+                if (d == -3) {  // rare: prefix exhausted
+                    s_und[atomicAdd(&s_nund, 1)] = j;
+                }
+            }
+            __syncthreads();
+            const int nund = s_nund;
+            for (int u = 0; u < nund; ++u) {
+                const int ju = s_und[u];
+                const int du = bf_full_row(P, pair, ju, n1c, owner, &s_best, &s_second);
+                if (ju == j) d = du;
+            }
+            __syncthreads();
+            if (tid == 0) s_nund = 0;
+            if (j < n2c) {
+                if (d != match[j]) local_changed = 1;
+                match[j] = d;
+            }
+            __syncthreads();
         }
         if (local_changed) s_changed = 1;
         __syncthreads();
         if (!s_changed) break;
-        for (int i = tid; i < n1c; i += 256) owner[i] = 0x7FFFFFFF;
+        for (int i = tid; i < n1c; i += blockDim.x) owner[i] = 0x7FFFFFFF;
         __syncthreads();
-        for (int j = tid; j < n2c; j += 256)
+        for (int j = tid; j < n2c; j += blockDim.x)
             if (match[j] >= 0) atomicMin(&owner[match[j]], j);
         __syncthreads();
     }
     // write-out: matched_2_in_1[idx_1] = idx_2 (robust.cc:317-325), unique by construction
     int32_t* out = P.matched + (size_t)pair * P.cap1;
-    for (int i = tid; i < P.cap1; i += 256) out[i] = -1;
+    for (int i = tid; i < P.cap1; i += blockDim.x) out[i] = -1;
     __syncthreads();
     int local = 0;
-    for (int j = tid; j < n2c; j += 256)
+    for (int j = tid; j < n2c; j += blockDim.x)
         if (match[j] >= 0) {
             out[match[j]] = j;
             ++local;
@@ -486,7 +528,7 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     SvProfScope ps(ctx, s, "k_bf_replay");
     const size_t lds = (size_t)(P.cap1 + P.cap2) * sizeof(int);
     const int use_lds = lds <= 96 * 1024;
-    hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(256), use_lds ? lds : 0, s, P, g_owner, g_match, use_lds);
+    hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), use_lds ? lds : 0, s, P, g_owner, g_match, use_lds);
 }
 void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match) {
     SvProfScope ps(ctx, s, "k_cand");
