@@ -72,6 +72,74 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     *reinterpret_cast<uint32_t*>(D) = packed;  // pitch is a multiple of 64: in-bounds and aligned
 }
 
+// Whole pyramid in ONE launch.  A workgroup owns a horizontal band of one frame through all levels: for level
+// l = 1..L-1 it computes the rows of that level it owns plus the few halo rows its own next level reads
+// (rows[band][l] = [lo, hi), built on the host), with a workgroup barrier between levels.  Halo rows are
+// recomputed by neighbouring bands with identical arithmetic, so the duplicate stores write identical bytes.
+// This removes the six dependent kernel boundaries of the chained cv::resize calls.
+#define PYR_THREADS 1024
+#define PYR_MAXW 4096  // widest level whose column tables are staged in LDS
+__global__ __launch_bounds__(PYR_THREADS) void k_pyramid(const OrbLevel* __restrict__ L, int num_levels, const int2* __restrict__ band_rows,
+                                                         const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
+                                                         uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                         const short* __restrict__ xofs, const short2* __restrict__ xa,
+                                                         const short2* __restrict__ yofs, const short2* __restrict__ yb) {
+    __shared__ short s_xo[PYR_MAXW];
+    __shared__ short2 s_xa[PYR_MAXW];
+    const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    uint8_t* P = pyr + (size_t)b * pyr_frame_bytes;
+    for (int l = 1; l < num_levels; ++l) {
+        const OrbLevel lev = L[l], prev = L[l - 1];
+        const uint8_t* S = l == 1 ? img0 + (size_t)b * img0_frame_stride : P + prev.pyr_off;
+        const int sp = l == 1 ? img0_pitch : prev.pitch;
+        uint8_t* Dst = P + lev.pyr_off;
+        const int2 rr = band_rows[band * num_levels + l];
+        const int groups = (lev.w + 3) >> 2, ntask = (rr.y - rr.x) * groups;
+        // column tables of this level -> LDS (one coalesced pass), so that the per-pixel chain is a single global round trip
+        const bool in_lds = lev.w <= PYR_MAXW;
+        if (in_lds)
+            for (int x = tid; x < lev.w; x += PYR_THREADS) {
+                s_xo[x] = xofs[lev.xtab_off + x];
+                s_xa[x] = xa[lev.xtab_off + x];
+            }
+        __syncthreads();
+        for (int t = tid; t < ntask; t += PYR_THREADS) {
+            const int row = t / groups, g = t - row * groups;
+            const int dy = rr.x + row, dx0 = g * 4;
+            const short2 yo = yofs[lev.ytab_off + dy], bb = yb[lev.ytab_off + dy];
+            const uint8_t* S0 = S + (size_t)yo.x * sp;
+            const uint8_t* S1 = S + (size_t)yo.y * sp;
+            int sx[4], sx1[4];
+            short2 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dx = min(dx0 + i, lev.w - 1);
+                sx[i] = in_lds ? s_xo[dx] : xofs[lev.xtab_off + dx];
+                a[i] = in_lds ? s_xa[dx] : xa[lev.xtab_off + dx];
+                sx1[i] = min(sx[i] + 1, prev.w - 1);
+            }
+            int p00[4], p01[4], p10[4], p11[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // 16 independent byte loads
+                p00[i] = S0[sx[i]];
+                p01[i] = S0[sx1[i]];
+                p10[i] = S1[sx[i]];
+                p11[i] = S1[sx1[i]];
+            }
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r0 = p00[i] * a[i].x + p01[i] * a[i].y;
+                const int r1 = p10[i] * a[i].x + p11[i] * a[i].y;
+                const int v = ((((int)bb.x * (r0 >> 4)) >> 16) + (((int)bb.y * (r1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 255) << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(Dst + (size_t)dy * lev.pitch + dx0) = packed;
+        }
+        __syncthreads();  // level l of this band (and its halo) is complete and visible to the whole workgroup
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ blur
 // Fixed-point separable 7x7, taps {18,34,48,56,48,34,18}/256, out = (sum + 32768) >> 16, reflect-101.
 // Streaming form, no LDS: a thread owns 4 adjacent columns and walks BLUR_ROWS rows downwards, keeping the last
@@ -605,6 +673,13 @@ void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride
     dim3 block(64, 4), grid((dw + 255) / 256, (dh + 3) / 4, batch);
     hipLaunchKernelGGL(k_resize, grid, block, 0, s, src, src_frame_stride, src_pitch, sw, dst, dst_frame_stride, dst_pitch, dw,
                        dh, xofs, xa, yofs, yb);
+}
+
+void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, const int2* band_rows, int bands, const uint8_t* img0,
+                       size_t img0_frame_stride, int img0_pitch, uint8_t* pyr, size_t pyr_frame_bytes, const short* xofs,
+                       const short2* xa, const short2* yofs, const short2* yb, int batch) {
+    hipLaunchKernelGGL(k_pyramid, dim3(bands, batch), dim3(PYR_THREADS), 0, s, levels, num_levels, band_rows, img0, img0_frame_stride,
+                       img0_pitch, pyr, pyr_frame_bytes, xofs, xa, yofs, yb);
 }
 
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,

@@ -76,6 +76,8 @@ struct svgpu_ctx {
     short2* d_xa = nullptr;         // (a0, a1) 11-bit coefficients
     short2* d_yofs = nullptr;       // (row0, row1) clamped
     short2* d_yb = nullptr;         // (b0, b1)
+    int2* d_band_rows = nullptr;    // [bands][levels]: rows of each level a pyramid band computes
+    int pyr_bands = 0;
     unsigned short* d_gtab = nullptr;
     uint8_t* d_pyr = nullptr;       // max_batch * pyr_frame_bytes
     uint8_t* d_blur = nullptr;      // max_batch * blur_frame_bytes
@@ -123,6 +125,9 @@ void sv_orb_release(svgpu_ctx* ctx);
 void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride, int src_pitch, int sw, int sh,
                       uint8_t* dst, size_t dst_frame_stride, int dst_pitch, int dw, int dh, const short* xofs,
                       const short2* xa, const short2* yofs, const short2* yb, int batch);
+void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, const int2* band_rows, int bands, const uint8_t* img0,
+                       size_t img0_frame_stride, int img0_pitch, uint8_t* pyr, size_t pyr_frame_bytes, const short* xofs,
+                       const short2* xa, const short2* yofs, const short2* yb, int batch);
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
                     size_t blur_frame_bytes, int batch);

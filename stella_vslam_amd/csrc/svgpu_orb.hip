@@ -5,6 +5,7 @@
 //   cv::resize coefficient tables  OpenCV 4.x imgproc/src/resize.cpp (8-bit fixed point, 11-bit coefficients)
 //   FAST cell lattice              feature/orb_extractor.cc:179-217
 //   selection grid                 feature/orb_extractor.cc:292-305
+#include <algorithm>
 #include <cmath>
 
 #include "svgpu_internal.h"
@@ -48,6 +49,7 @@ void sv_orb_release(svgpu_ctx* ctx) {
     free_dev(ctx->d_xa);
     free_dev(ctx->d_yofs);
     free_dev(ctx->d_yb);
+    free_dev(ctx->d_band_rows);
     free_dev(ctx->d_gtab);
     free_dev(ctx->d_pyr);
     free_dev(ctx->d_blur);
@@ -229,6 +231,41 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     C.pyr_frame_bytes = pyr_off ? pyr_off : 256;
     C.blur_frame_bytes = blur_off;
 
+    // ---- pyramid bands: band k owns rows [k*h/K, (k+1)*h/K) of every level; bottom-up it also needs the source rows
+    //      of everything it computes at the next level (two taps per output row, clamped -- the yofs table)
+    const int bands = 16;
+    std::vector<int2> band_rows((size_t)bands * num_levels);
+    for (int k = 0; k < bands; ++k) {
+        int need_lo = 0, need_hi = 0;
+        for (int l = num_levels - 1; l >= 1; --l) {
+            const OrbLevel& Lv = C.levels[l];
+            int lo = (int)((long long)k * Lv.h / bands), hi = (int)((long long)(k + 1) * Lv.h / bands);
+            if (l < num_levels - 1 && need_hi > need_lo) {
+                lo = std::min(lo, need_lo);
+                hi = std::max(hi, need_hi);
+            }
+            int2 r;
+            r.x = lo;
+            r.y = hi;
+            band_rows[(size_t)k * num_levels + l] = r;
+            // rows of level l-1 read by rows [lo, hi) of level l
+            need_lo = 1 << 30;
+            need_hi = 0;
+            for (int dy = lo; dy < hi; ++dy) {
+                const short2 o = yofs[Lv.ytab_off + dy];
+                need_lo = std::min(need_lo, (int)o.x);
+                need_hi = std::max(need_hi, (int)o.y + 1);
+            }
+        }
+        int2 z;
+        z.x = z.y = 0;
+        band_rows[(size_t)k * num_levels] = z;
+    }
+    ctx->pyr_bands = bands;
+    {
+        int rcb;
+        if ((rcb = upload(ctx, &ctx->d_band_rows, band_rows))) return rcb;
+    }
     std::vector<OrbLevel> lv(C.levels, C.levels + num_levels);
     int rc;
     if ((rc = upload(ctx, &ctx->d_levels, lv))) return rc;
@@ -277,17 +314,11 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const int Lc = C.num_levels;
-    // 1. pyramid: chained bilinear resize (level l from level l-1)
-    for (int l = 1; l < Lc; ++l) {
+    // 1. pyramid: chained bilinear resize (level l from level l-1), all levels in one launch (banded, see k_pyramid)
+    if (Lc > 1) {
         SvProfScope ps(ctx, s, "k_resize");
-        const OrbLevel& D = C.levels[l];
-        const OrbLevel& P = C.levels[l - 1];
-        const uint8_t* src = l == 1 ? imgs_dev : ctx->d_pyr + P.pyr_off;
-        const size_t sfs = l == 1 ? frame_stride : C.pyr_frame_bytes;
-        const int sp = l == 1 ? row_stride : P.pitch;
-        sv_launch_resize(s, src, sfs, sp, P.w, P.h, ctx->d_pyr + D.pyr_off, C.pyr_frame_bytes, D.pitch, D.w, D.h,
-                         ctx->d_xofs + D.xtab_off, ctx->d_xa + D.xtab_off, ctx->d_yofs + D.ytab_off, ctx->d_yb + D.ytab_off,
-                         batch);
+        sv_launch_pyramid(s, ctx->d_levels, Lc, ctx->d_band_rows, ctx->pyr_bands, imgs_dev, frame_stride, row_stride, ctx->d_pyr,
+                          C.pyr_frame_bytes, ctx->d_xofs, ctx->d_xa, ctx->d_yofs, ctx->d_yb, batch);
     }
     // 2. blurred copy of every level
     {
