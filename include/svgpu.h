@@ -152,10 +152,15 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
 
 typedef enum svgpu_match_mode {
     SVGPU_MATCH_BEST_ONLY = 0,        /* projection::match_current_and_last_frames (match/projection.cc:95-207) */
-    SVGPU_MATCH_RATIO_SAME_OCTAVE = 1 /* projection::match_frame_and_landmarks     (match/projection.cc:13-93)  */
+    SVGPU_MATCH_RATIO_SAME_OCTAVE = 1,/* projection::match_frame_and_landmarks     (match/projection.cc:13-93)  */
+    SVGPU_MATCH_RATIO = 2,            /* bow_tree::match_frame_and_keyframe / match_keyframes (match/bow_tree.cc:169-366) */
+    SVGPU_MATCH_TRIANGULATION = 3     /* bow_tree / robust ::match_for_triangulation (match/bow_tree.cc:11-167, robust.cc:14-146) */
 } svgpu_match_mode;
 
 /* Candidate-list matcher: query q scans targets cand_idx[cand_off[q] .. cand_off[q+1]) in order.
+ *   cand_skip    nullable, one byte per CSR entry: non-zero drops that (query, target) pair -- gates the caller evaluated
+ *                on its object graph (epipolar constraint base.h:67-79, chi-square reprojection gate fuse.cc:92-119,
+ *                "keypoint already has a landmark" bow_tree.cc:72-76)
  *   q_valid      nullable, 0 = query skipped
  *   occupied     nullable nt, 1 = target already holds an observed landmark (projection.cc:52-55)
  *   q_angle/t_angle + check_orientation : |angle::diff| > 30 gate (projection.cc:179-181)
@@ -163,8 +168,8 @@ typedef enum svgpu_match_mode {
  *   thr, lowe_ratio, mode : acceptance rule
  *   match_q[nq]  target index or -1.  Host in/out, synchronous. */
 int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int32_t* t_octave,
-                           int nt, const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* q_valid,
-                           const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
+                           int nt, const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* cand_skip,
+                           const uint8_t* q_valid, const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
                            const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                            float lowe_ratio, int mode, int32_t* match_q, int* num_matches);
 

@@ -112,7 +112,7 @@ int orc_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, con
 }
 
 /* ---------------------------------------------------------------- candidate-list matchers */
-enum { ORC_MODE_BEST_ONLY = 0, ORC_MODE_RATIO_SAME_OCTAVE = 1 };
+enum { ORC_MODE_BEST_ONLY = 0, ORC_MODE_RATIO_SAME_OCTAVE = 1, ORC_MODE_RATIO = 2, ORC_MODE_TRIANGULATION = 3 };
 
 /* Queries are processed in index order; each scans its CSR candidate list in order.
  *   skip candidate if occupied[t]                       (projection.cc:52-55 / :167-170)
@@ -120,9 +120,14 @@ enum { ORC_MODE_BEST_ONLY = 0, ORC_MODE_RATIO_SAME_OCTAVE = 1 };
  *   skip if check_orientation and |diff(q_angle[q], t_angle[t])| > 30      (:179-181)
  * mode RATIO_SAME_OCTAVE keeps best/second and their octaves (:68-79), accepts if best <= thr and not
  * (best_octave == second_octave && best > ratio*second) (:82-90).  mode BEST_ONLY accepts if
- * best <= thr (:191-197).  An accepted query occupies its target.  match_q[q] = t or -1. */
+ * best <= thr (:191-197).  mode RATIO = bow_tree::match_frame_and_keyframe (match/bow_tree.cc:200-237): best <= thr and not
+ * lowe_ratio * second < best.  mode TRIANGULATION = bow_tree / robust ::match_for_triangulation (match/bow_tree.cc:66-140,
+ * match/robust.cc:56-130): best starts AT thr, a candidate farther than thr or than the current best is skipped before the
+ * (precomputed, cand_skip) epipolar gates, '<' updates, then the plain ratio test.  cand_skip[c] != 0 drops CSR entry c
+ * (per-pair gates the caller evaluated: epipolar constraint, chi-square reprojection gate of fuse.cc:92-119, ...).
+ * An accepted query occupies its target.  match_q[q] = t or -1. */
 int orc_match_candidates(const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int32_t* t_octave, int nt,
-                         const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* q_valid,
+                         const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* cand_skip, const uint8_t* q_valid,
                          const uint8_t* occupied_init, const float* q_angle, const float* t_angle, int check_orientation,
                          const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                          float lowe_ratio, int mode, int32_t* match_q) {
@@ -133,7 +138,7 @@ int orc_match_candidates(const uint8_t* qdesc, int nq, const uint8_t* tdesc, con
         match_q[q] = -1;
         if (q_valid && !q_valid[q]) continue;
         if (cand_off[q + 1] == cand_off[q]) continue;
-        unsigned best = ORC_MAX_HAMMING_DIST, second = ORC_MAX_HAMMING_DIST;
+        unsigned best = mode == ORC_MODE_TRIANGULATION ? thr : ORC_MAX_HAMMING_DIST, second = ORC_MAX_HAMMING_DIST;
         int best_lvl = -1, second_lvl = -1, best_idx = -1;
         for (int c = cand_off[q]; c < cand_off[q + 1]; ++c) {
             const int t = cand_idx[c];
@@ -144,6 +149,8 @@ int orc_match_candidates(const uint8_t* qdesc, int nq, const uint8_t* tdesc, con
             }
             if (check_orientation && fabsf(orc_angle_diff(q_angle[q], t_angle[t])) > 30.0) continue;
             const unsigned d = orc_hamming_32(qdesc + 32 * (size_t)q, tdesc + 32 * (size_t)t);
+            if (mode == ORC_MODE_TRIANGULATION && (thr < d || best < d)) continue;
+            if (cand_skip && cand_skip[c]) continue;
             if (d < best) {
                 second = best;
                 best = d;
@@ -164,8 +171,15 @@ int orc_match_candidates(const uint8_t* qdesc, int nq, const uint8_t* tdesc, con
                 ++num;
             }
         }
-        else {
+        else if (mode == ORC_MODE_BEST_ONLY) {
             if (thr < best) continue;
+            match_q[q] = best_idx;
+            occ[best_idx] = 1;
+            ++num;
+        }
+        else {  /* RATIO, TRIANGULATION */
+            if (thr < best || best_idx < 0) continue;
+            if (lowe_ratio * second < (float)best) continue;
             match_q[q] = best_idx;
             occ[best_idx] = 1;
             ++num;

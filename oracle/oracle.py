@@ -187,10 +187,10 @@ def brute_force_match(desc1, angle1, desc2, angle2, valid2=None, lowe_ratio: flo
     return out
 
 
-MODE_BEST_ONLY, MODE_RATIO_SAME_OCTAVE = 0, 1
+MODE_BEST_ONLY, MODE_RATIO_SAME_OCTAVE, MODE_RATIO, MODE_TRIANGULATION = 0, 1, 2, 3
 
 
-def match_candidates(qdesc, tdesc, cand_off, cand_idx, t_octave=None, q_valid=None, occupied=None, q_angle=None,
+def match_candidates(qdesc, tdesc, cand_off, cand_idx, cand_skip=None, t_octave=None, q_valid=None, occupied=None, q_angle=None,
                      t_angle=None, check_orientation=False, q_xright=None, t_xright=None, q_xr_tol=None, thr=100,
                      lowe_ratio=0.8, mode=MODE_BEST_ONLY):
     qdesc = np.ascontiguousarray(qdesc, np.uint8)
@@ -199,11 +199,12 @@ def match_candidates(qdesc, tdesc, cand_off, cand_idx, t_octave=None, q_valid=No
     cand_idx = np.ascontiguousarray(cand_idx, np.int32)
     cv = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
     t_octave, q_valid, occupied = cv(t_octave, np.int32), cv(q_valid, np.uint8), cv(occupied, np.uint8)
+    cand_skip = cv(cand_skip, np.uint8)
     q_angle, t_angle = cv(q_angle, np.float32), cv(t_angle, np.float32)
     q_xright, t_xright, q_xr_tol = cv(q_xright, np.float32), cv(t_xright, np.float32), cv(q_xr_tol, np.float32)
     out = np.full(len(qdesc), -1, np.int32)
     lib().orc_match_candidates(_p(qdesc), len(qdesc), _p(tdesc), _p(t_octave), len(tdesc), _p(cand_off), _p(cand_idx),
-                               _p(q_valid), _p(occupied), _p(q_angle), _p(t_angle), int(check_orientation),
+                               _p(cand_skip), _p(q_valid), _p(occupied), _p(q_angle), _p(t_angle), int(check_orientation),
                                _p(q_xright), _p(t_xright), _p(q_xr_tol), C.c_uint(thr), C.c_float(lowe_ratio), mode,
                                _p(out))
     return out

@@ -40,6 +40,7 @@ struct CandProblem {
     int nq, nt;
     const int32_t* cand_off;
     const int32_t* cand_idx;
+    const uint8_t* cand_skip; // nullable, per CSR entry
     const uint8_t* q_valid;   // nullable
     const uint8_t* occupied;  // nullable
     const float* q_angle;

@@ -419,8 +419,8 @@ __global__ void k_cand_dist(CandProblem P) {
     for (int k = 0; k < 8; ++k) qd[k] = P.qdesc[(size_t)q * 8 + k];
     for (int c = lo + threadIdx.x; c < hi; c += blockDim.x) {
         const int t = P.cand_idx[c];
-        bool gated = false;
-        if (P.t_xright && 0.f < P.t_xright[t]) {
+        bool gated = P.cand_skip && P.cand_skip[c];
+        if (!gated && P.t_xright && 0.f < P.t_xright[t]) {
             const float err = fabsf(P.q_xright[q] - P.t_xright[t]);
             if (P.q_xr_tol[q] < err) gated = true;
         }
@@ -433,13 +433,15 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
     if (P.q_valid && !P.q_valid[q]) return -1;
     const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
     if (lo == hi) return -1;
-    unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+    const bool tri = P.mode == SVGPU_MATCH_TRIANGULATION;
+    unsigned best = tri ? P.thr : MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
     int best_lvl = -1, second_lvl = -1, best_idx = -1;
     for (int c = lo; c < hi; ++c) {
         const unsigned d = P.dist[c];
         if (d == 0xFFFFu) continue;
         const int t = P.cand_idx[c];
         if (owner[t] < q) continue;  // occupied before this query (initially, or by an earlier query)
+        if (tri && (P.thr < d || best < d)) continue;  // bow_tree.cc:96-98 / robust.cc:89-91
         if (d < best) {
             second = best;
             best = d;
@@ -459,7 +461,13 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
         }
         return -1;
     }
-    if (P.thr < best) return -1;
+    if (P.mode == SVGPU_MATCH_BEST_ONLY) {
+        if (P.thr < best) return -1;
+        return best_idx;
+    }
+    // RATIO / TRIANGULATION: plain Lowe test (bow_tree.cc:226-233, :133-140)
+    if (P.thr < best || best_idx < 0) return -1;
+    if (P.lowe_ratio * (float)second < (float)best) return -1;
     return best_idx;
 }
 

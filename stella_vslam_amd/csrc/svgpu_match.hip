@@ -183,11 +183,11 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
 }
 
 int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int32_t* t_octave,
-                           int nt, const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* q_valid,
-                           const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
+                           int nt, const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* cand_skip,
+                           const uint8_t* q_valid, const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
                            const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                            float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
-    if (!ctx || nq < 0 || nt < 0 || !num_matches || (mode != SVGPU_MATCH_BEST_ONLY && mode != SVGPU_MATCH_RATIO_SAME_OCTAVE))
+    if (!ctx || nq < 0 || nt < 0 || !num_matches || (mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_TRIANGULATION))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_candidates: bad arguments");
     *num_matches = 0;
     if (nq == 0) return SVGPU_OK;
@@ -204,7 +204,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
         if (cand_idx[c] < 0 || cand_idx[c] >= nt) return sv_set_error(ctx, SVGPU_ERR_INVALID, "cand_idx out of range");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = pad((size_t)nq * 32) + pad((size_t)nt * 32) + 3 * pad((size_t)nt * 4) + pad(nt) + pad((size_t)(nq + 1) * 4)
-                        + pad((size_t)nc * 4) + pad(nq) + 3 * pad((size_t)nq * 4) + pad((size_t)nc * 2) + 2 * pad((size_t)nq * 4)
+                        + pad((size_t)nc * 4) + pad(nc) + pad(nq) + 3 * pad((size_t)nq * 4) + pad((size_t)nc * 2) + 2 * pad((size_t)nq * 4)
                         + pad((size_t)nt * 4) + 512;
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
@@ -222,6 +222,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     UP(d_toct, int32_t, t_octave, nt)
     UP(d_off, int32_t, cand_off, nq + 1)
     UP(d_idx, int32_t, cand_idx, nc)
+    UP(d_skip, uint8_t, cand_skip, nc)
     UP(d_qv, uint8_t, q_valid, nq)
     UP(d_occ, uint8_t, occupied, nt)
     UP(d_qa, float, q_angle, nq)
@@ -237,6 +238,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     P.nt = nt;
     P.cand_off = d_off;
     P.cand_idx = d_idx;
+    P.cand_skip = d_skip;
     P.q_valid = d_qv;
     P.occupied = d_occ;
     P.q_angle = d_qa;

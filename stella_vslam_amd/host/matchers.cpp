@@ -37,7 +37,7 @@ unsigned int robust::brute_force_match(const data::frame_observation& frm_obs, c
 }
 
 unsigned int projection::match(const query_set& q, const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied,
-                               bool ratio_same_octave, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const {
+                               int mode, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const {
     const int nq = q.descriptors.rows, nt = (int)frm_obs.undist_keypts_.size();
     std::vector<float> ta(nt);
     std::vector<int32_t> toct(nt);
@@ -50,11 +50,11 @@ unsigned int projection::match(const query_set& q, const data::frame_observation
     matched_idx_for_query.assign((size_t)std::max(nq, 1), -1);
     int num = 0;
     check(ctx_, svgpu_match_candidates(ctx_, qd.data(), nq, td.data(), toct.data(), nt, q.cand_off.data(), q.cand_idx.data(),
-                                       q.valid.empty() ? nullptr : q.valid.data(), occupied.empty() ? nullptr : occupied.data(),
+                                       q.cand_skip.empty() ? nullptr : q.cand_skip.data(), q.valid.empty() ? nullptr : q.valid.data(), occupied.empty() ? nullptr : occupied.data(),
                                        q.angle.empty() ? nullptr : q.angle.data(), ta.data(), (check_orientation_ && !q.angle.empty()) ? 1 : 0,
                                        stereo ? q.x_right.data() : nullptr, stereo ? frm_obs.stereo_x_right_.data() : nullptr,
                                        stereo ? q.x_right_tol.data() : nullptr, hamm_dist_thr, lowe_ratio_,
-                                       ratio_same_octave ? SVGPU_MATCH_RATIO_SAME_OCTAVE : SVGPU_MATCH_BEST_ONLY,
+                                       mode,
                                        matched_idx_for_query.data(), &num),
           "svgpu_match_candidates");
     matched_idx_for_query.resize((size_t)nq);

@@ -53,10 +53,12 @@ public:
         std::vector<float> x_right, x_right_tol;  // empty or nq: stereo gate (projection.cc:57-62)
         std::vector<unsigned char> valid;   // empty or nq
         std::vector<int> cand_off, cand_idx;  // CSR of get_keypoints_in_cell results (data/common.cc:127-190), scan order kept
+        std::vector<unsigned char> cand_skip; // empty or one per CSR entry: pair gates evaluated by the caller (epipolar, chi-square)
     };
-    //! projection::match_frame_and_landmarks (mode ratio_same_octave, thr HIGH) / match_current_and_last_frames (best only)
+    //! mode = svgpu_match_mode: projection::match_frame_and_landmarks (RATIO_SAME_OCTAVE, thr HIGH), match_current_and_last_frames
+    //! and fuse::detect_duplication (BEST_ONLY), bow_tree::match_frame_and_keyframe (RATIO), *::match_for_triangulation (TRIANGULATION)
     unsigned int match(const query_set& q, const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied,
-                       bool ratio_same_octave, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const;
+                       int mode, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const;
 };
 
 }  // namespace match

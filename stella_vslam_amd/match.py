@@ -20,6 +20,8 @@ MAX_HAMMING_DIST = 256
 
 MATCH_BEST_ONLY = 0
 MATCH_RATIO_SAME_OCTAVE = 1
+MATCH_RATIO = 2          # bow_tree::match_frame_and_keyframe / match_keyframes
+MATCH_TRIANGULATION = 3  # bow_tree / robust ::match_for_triangulation
 
 
 def _p(a):
@@ -74,17 +76,18 @@ class projection(base):
     """match/projection.h on flattened inputs: the caller supplies, per query (landmark / last-frame keypoint),
     the candidate keypoint indices that get_keypoints_in_cell returned (data/common.cc:127-190), as CSR."""
 
-    def match_candidates(self, qdesc, tdesc, cand_off, cand_idx, mode, thr, t_octave=None, q_valid=None, occupied=None,
+    def match_candidates(self, qdesc, tdesc, cand_off, cand_idx, mode, thr, cand_skip=None, t_octave=None, q_valid=None, occupied=None,
                          q_angle=None, t_angle=None, q_xright=None, t_xright=None, q_xr_tol=None):
         qd, td = _c(qdesc, np.uint8), _c(tdesc, np.uint8)
         off, idx = _c(cand_off, np.int32), _c(cand_idx, np.int32)
         toct, qv, occ = _c(t_octave, np.int32), _c(q_valid, np.uint8), _c(occupied, np.uint8)
+        skip = _c(cand_skip, np.uint8)
         qa, ta = _c(q_angle, np.float32), _c(t_angle, np.float32)
         qx, tx, qt = _c(q_xright, np.float32), _c(t_xright, np.float32), _c(q_xr_tol, np.float32)
         out = np.full(len(qd), -1, np.int32)
         num = C.c_int(0)
         self.ctx.check(lib().svgpu_match_candidates(self.ctx.handle, _p(qd), len(qd), _p(td), _p(toct), len(td), _p(off), _p(idx),
-                                                    _p(qv), _p(occ), _p(qa), _p(ta), int(self.check_orientation_), _p(qx),
+                                                    _p(skip), _p(qv), _p(occ), _p(qa), _p(ta), int(self.check_orientation_), _p(qx),
                                                     _p(tx), _p(qt), C.c_uint(thr), C.c_float(self.lowe_ratio_), mode, _p(out),
                                                     C.byref(num)), "svgpu_match_candidates")
         return out, num.value

@@ -120,3 +120,31 @@ def test_candidate_matcher_matches_oracle(M, ctx, mode, seed):
     exp = O.match_candidates(d0, d1, cand_off, cand_idx, check_orientation=True, thr=100, lowe_ratio=0.8, mode=mode, **kw)
     assert (exp >= 0).sum() > 800
     assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+
+
+@pytest.mark.parametrize("mode,thr,ratio", [(2, 50, 0.7), (3, 50, 0.95), (0, 50, 0.6)])
+def test_candidate_matcher_bow_triangulation_fuse_modes(M, ctx, mode, thr, ratio):
+    """bow_tree (RATIO), match_for_triangulation (TRIANGULATION) and fuse (BEST_ONLY + per-pair skip mask standing for the
+    chi-square / epipolar gates the adaptor evaluates) on bucketed candidates, as FBoW node buckets would give them."""
+    seq = S.frame_sequence(2, seed=0x5EED + 11)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    rng = np.random.default_rng(mode)
+    # synthetic "vocabulary nodes": bucket both frames by a coarse spatial hash of the (shift-compensated) position
+    b0 = ((k0["x"] - 3) // 40).astype(int) * 100 + ((k0["y"] - 1) // 40).astype(int) + 1000 * k0["octave"]
+    b1 = (k1["x"] // 40).astype(int) * 100 + (k1["y"] // 40).astype(int) + 1000 * k1["octave"]
+    order = np.argsort(b0, kind="stable")  # queries in node order, as the merge-join of the two std::maps visits them
+    buckets = {}
+    for i, b in enumerate(b1):
+        buckets.setdefault(int(b), []).append(i)
+    cand_off, cand_idx = [0], []
+    for q in order:
+        cand_idx += buckets.get(int(b0[q]), [])
+        cand_off.append(len(cand_idx))
+    skip = (rng.uniform(size=len(cand_idx)) < 0.1).astype(np.uint8)
+    qd, qa = d0[order], k0["angle"][order]
+    kw = dict(cand_skip=skip, t_octave=k1["octave"], q_angle=qa, t_angle=k1["angle"])
+    got, num = M.projection(ratio, True, ctx).match_candidates(qd, d1, cand_off, cand_idx, mode, thr, **kw)
+    exp = O.match_candidates(qd, d1, cand_off, cand_idx, check_orientation=True, thr=thr, lowe_ratio=ratio, mode=mode, **kw)
+    assert (exp >= 0).sum() > 300
+    assert np.array_equal(got, exp) and num == (exp >= 0).sum()

@@ -146,3 +146,48 @@ def test_match_candidates_modes():
             occ[bi] = True
         assert (got >= 0).sum() > 20
         assert np.array_equal(got, exp)
+
+
+def test_match_candidates_ratio_and_triangulation_modes():
+    """bow_tree::match_frame_and_keyframe (RATIO) and *::match_for_triangulation (TRIANGULATION: best starts at the
+    threshold, farther-than-best candidates are skipped before the pair gates) vs literal Python loops."""
+    rng = np.random.default_rng(7)
+    nt, nq = 180, 140
+    td = _descs(rng, nt)
+    src = rng.integers(0, nt, nq)
+    qd = _descs(rng, nq, td[src], flips=50)
+    off, idx = [0], []
+    for q in range(nq):
+        c = set(rng.integers(0, nt, rng.integers(0, 10)).tolist()) | ({int(src[q])} if rng.uniform() < 0.85 else set())
+        c = list(c)
+        rng.shuffle(c)
+        idx += c
+        off.append(len(idx))
+    skip = (rng.uniform(size=len(idx)) < 0.15).astype(np.uint8)
+    for mode in (O.MODE_RATIO, O.MODE_TRIANGULATION):
+        got = O.match_candidates(qd, td, off, idx, cand_skip=skip, thr=50, lowe_ratio=0.9, mode=mode)
+        occ = np.zeros(nt, bool)
+        exp = np.full(nq, -1, np.int32)
+        for q in range(nq):
+            best, second, bi = (50 if mode == O.MODE_TRIANGULATION else 256), 256, -1
+            for c in range(off[q], off[q + 1]):
+                t = idx[c]
+                if occ[t]:
+                    continue
+                d = O.hamming(qd[q], td[t])
+                if mode == O.MODE_TRIANGULATION and (50 < d or best < d):
+                    continue
+                if skip[c]:
+                    continue
+                if d < best:
+                    second, best, bi = best, d, t
+                elif d < second:
+                    second = d
+            if off[q] == off[q + 1] or best > 50 or bi < 0:
+                continue
+            if np.float32(0.9) * np.float32(second) < np.float32(best):
+                continue
+            exp[q] = bi
+            occ[bi] = True
+        assert (exp >= 0).sum() > 15
+        assert np.array_equal(got, exp)
