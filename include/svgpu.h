@@ -173,6 +173,16 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
                            const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                            float lowe_ratio, int mode, int32_t* match_q, int* num_matches);
 
+/* match::stereo::compute (match/stereo.cc:20-114): for every left keypoint the closest right keypoint in its row band
+ * (rows +-2*scale, octave +-1, disparity in [0, focal_x_baseline / true_baseline], Hamming < 75), then the 11x11 L1 patch
+ * slide (+-5 px) on the keypoint's pyramid level with parabolic sub-pixel refinement, finally the 2x-median correlation
+ * filter.  The two pyramids are those of the LAST extract call on ctx_left / ctx_right (both contexts on one device;
+ * the reference reads extractor_left_->image_pyramid_ / extractor_right_->image_pyramid_, system.cc:443-447).
+ * stereo_x_right / depths: n_left floats, -1 where no match.  Host in/out, synchronous. */
+int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_keypoint* kps_left, const uint8_t* desc_left,
+                       int n_left, const svgpu_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths);
+
 /* ------------------------------------------------------------------------------------------------ local BA
  * Stands behind  stella_vslam::optimize::local_bundle_adjuster::optimize(map_db, curr_keyfrm, force_stop_flag)
  * (optimize/local_bundle_adjuster.h:23; g2o implementation optimize/local_bundle_adjuster_g2o.cc:36-431).

@@ -259,3 +259,132 @@ int orc_get_keypoints_in_cell(const float* kx, const float* ky, const int32_t* o
         }
     return n;
 }
+
+/* ---------------------------------------------------------------- match::stereo (match/stereo.cc:20-251)
+ * kp arrays use the 28-byte cv::KeyPoint layout (x, y, size, angle, response, octave, class_id).
+ * pyr_left / pyr_right: per level pointer, width, height, stride.  hamm_dist_thr = (100 + 50) / 2 (stereo.h:99). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_kp28;
+
+static int cmp_pair_ii(const void* a, const void* b) {
+    const int* p = (const int*)a;
+    const int* q = (const int*)b;
+    if (p[0] != q[0]) return p[0] < q[0] ? -1 : 1;
+    return p[1] < q[1] ? -1 : (p[1] > q[1]);
+}
+
+void orc_stereo_match(const orc_kp28* kl, const uint8_t* dl, int nl, const orc_kp28* kr, const uint8_t* dr, int nr,
+                      const uint8_t* const* pyr_left, const uint8_t* const* pyr_right, const int* lw, const int* lh, const int* ls_l,
+                      const int* ls_r, const float* scale_factors, const float* inv_scale_factors, int num_levels,
+                      float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {
+    const float min_disp = 0.0f, max_disp = focal_x_baseline / true_baseline;
+    const unsigned thr = (ORC_HAMMING_DIST_THR_HIGH + ORC_HAMMING_DIST_THR_LOW) / 2;
+    const int rows0 = lh[0];
+    (void)num_levels;
+    /* get_right_keypoint_indices_in_each_row(2.0): CSR rows -> right indices, in index order */
+    int* cnt = (int*)calloc(rows0 + 1, sizeof(int));
+    for (int i = 0; i < nr; ++i) {
+        const float r = 2.0f * scale_factors[kr[i].octave];
+        int max_r = (int)ceil((double)(kr[i].y + r)), min_r = (int)floor((double)(kr[i].y - r));
+        for (int row = min_r; row <= max_r; ++row)
+            if (row >= 0 && row < rows0) cnt[row + 1]++; /* the reference's .at() would throw outside */
+    }
+    for (int r = 0; r < rows0; ++r) cnt[r + 1] += cnt[r];
+    int* items = (int*)malloc(sizeof(int) * (cnt[rows0] + 1));
+    int* fill = (int*)calloc(rows0 + 1, sizeof(int));
+    for (int i = 0; i < nr; ++i) {
+        const float r = 2.0f * scale_factors[kr[i].octave];
+        int max_r = (int)ceil((double)(kr[i].y + r)), min_r = (int)floor((double)(kr[i].y - r));
+        for (int row = min_r; row <= max_r; ++row)
+            if (row >= 0 && row < rows0) items[cnt[row] + fill[row]++] = i;
+    }
+    free(fill);
+    int* pairs = (int*)malloc(sizeof(int) * 2 * (nl + 1));
+    int npairs = 0;
+    for (int il = 0; il < nl; ++il) {
+        stereo_x_right[il] = -1.0f;
+        depths[il] = -1.0f;
+    }
+    for (int il = 0; il < nl; ++il) {
+        const int lvl = kl[il].octave;
+        const float y_left = kl[il].y, x_left = kl[il].x;
+        const int row = (int)y_left;
+        if (row < 0 || row >= rows0) continue;
+        if (cnt[row + 1] == cnt[row]) continue;
+        const float min_x_right = x_left - max_disp, max_x_right = x_left - min_disp;
+        if (max_x_right < 0) continue;
+        unsigned best_idx = 0, best = thr;
+        for (int c = cnt[row]; c < cnt[row + 1]; ++c) {
+            const int ir = items[c];
+            if (kr[ir].octave < lvl - 1 || kr[ir].octave > lvl + 1) continue;
+            const float xr = kr[ir].x;
+            if (xr < min_x_right || max_x_right < xr) continue;
+            const unsigned d = orc_hamming_32(dl + 32 * (size_t)il, dr + 32 * (size_t)ir);
+            if (d < best) {
+                best_idx = ir;
+                best = d;
+            }
+        }
+        if (thr <= best) continue;
+        /* compute_subpixel_disparity (:180-251) */
+        const float x_right = kr[best_idx].x;
+        const float isf = inv_scale_factors[lvl];
+        const int sxl = (int)lrintf(kl[il].x * isf), syl = (int)lrintf(kl[il].y * isf), sxr = (int)lrintf(x_right * isf);
+        const int win = 5, slide = 5;
+        const int ini_x = sxr - slide - win, end_x = sxr + slide + win;
+        if (ini_x < 0 || lw[lvl] <= end_x) continue;
+        if (syl - win < 0 || syl + win >= lh[lvl] || sxl - win < 0 || sxl + win >= lw[lvl]) continue; /* rowRange/colRange would assert */
+        const uint8_t* PL = pyr_left[lvl];
+        const uint8_t* PR = pyr_right[lvl];
+        float best_corr = 3.402823466e+38f;
+        int best_off = 0;
+        float corr[11];
+        const float lc = (float)PL[(size_t)syl * ls_l[lvl] + sxl];
+        for (int off = -slide; off <= slide; ++off) {
+            const float rc = (float)PR[(size_t)syl * ls_r[lvl] + sxr + off];
+            double acc = 0; /* cv::norm(NORM_L1) of CV_32F accumulates in double */
+            for (int dy = -win; dy <= win; ++dy)
+                for (int dx = -win; dx <= win; ++dx) {
+                    const float a = (float)PL[(size_t)(syl + dy) * ls_l[lvl] + sxl + dx] - lc;
+                    const float b = (float)PR[(size_t)(syl + dy) * ls_r[lvl] + sxr + off + dx] - rc;
+                    acc += fabs((double)(a - b));
+                }
+            const float c = (float)acc;
+            if (c < best_corr) {
+                best_corr = c;
+                best_off = off;
+            }
+            corr[slide + off] = c;
+        }
+        if (best_off == -slide || best_off == slide) continue;
+        const float c1 = corr[slide + best_off - 1], c2 = corr[slide + best_off], c3 = corr[slide + best_off + 1];
+        const float x_delta = (float)((c1 - c3) / (2.0 * (c1 + c3) - 4.0 * c2));
+        if (x_delta < -1.0 || 1.0 < x_delta) continue;
+        float best_x_right = scale_factors[lvl] * (sxr + best_off + x_delta);
+        float best_disp = kl[il].x - best_x_right;
+        if (best_disp < min_disp || max_disp <= best_disp) continue;
+        if (best_disp <= 0.0f) {
+            best_disp = 0.01f;
+            best_x_right = x_left - best_disp;
+        }
+        depths[il] = focal_x_baseline / best_disp;
+        stereo_x_right[il] = best_x_right;
+        pairs[2 * npairs] = (int)best_corr; /* std::pair<int, int>: the float correlation is narrowed to int */
+        pairs[2 * npairs + 1] = il;
+        ++npairs;
+    }
+    qsort(pairs, npairs, 2 * sizeof(int), cmp_pair_ii);
+    const int median_i = npairs / 2;
+    const float median_corr = npairs == 0 ? 0.0f : (float)pairs[2 * median_i];
+    const float corr_thr = (float)(2.0 * median_corr);
+    for (int i = median_i; i < npairs; ++i)
+        if (corr_thr < (float)pairs[2 * i]) {
+            stereo_x_right[pairs[2 * i + 1]] = -1;
+            depths[pairs[2 * i + 1]] = -1;
+        }
+    free(pairs);
+    free(items);
+    free(cnt);
+}

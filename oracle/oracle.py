@@ -232,6 +232,30 @@ def get_keypoints_in_cell(kx, ky, octave, cell_off, cell_items, bounds, ref_x, r
     return out[:n].copy()
 
 
+def stereo_match(kps_left, desc_left, kps_right, desc_right, pyr_left, pyr_right, focal_x_baseline, true_baseline,
+                 scale_factor=1.2):
+    """match::stereo::compute: returns (stereo_x_right, depths)."""
+    L = len(pyr_left)
+    sf, isf, _, _ = scale_tables(scale_factor, L)
+    kl = np.ascontiguousarray(kps_left)
+    kr = np.ascontiguousarray(kps_right)
+    dl = np.ascontiguousarray(desc_left, np.uint8)
+    dr = np.ascontiguousarray(desc_right, np.uint8)
+    pl = [np.ascontiguousarray(a) for a in pyr_left]
+    pr = [np.ascontiguousarray(a) for a in pyr_right]
+    PL = (C.c_void_p * L)(*[a.ctypes.data for a in pl])
+    PR = (C.c_void_p * L)(*[a.ctypes.data for a in pr])
+    lw = np.array([a.shape[1] for a in pl], np.int32)
+    lh = np.array([a.shape[0] for a in pl], np.int32)
+    lsl = np.array([a.strides[0] for a in pl], np.int32)
+    lsr = np.array([a.strides[0] for a in pr], np.int32)
+    xr = np.zeros(max(len(kl), 1), np.float32)
+    dp = np.zeros(max(len(kl), 1), np.float32)
+    lib().orc_stereo_match(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), PL, PR, _p(lw), _p(lh), _p(lsl), _p(lsr), _p(sf), _p(isf), L,
+                           C.c_float(focal_x_baseline), C.c_float(true_baseline), _p(xr), _p(dp))
+    return xr[:len(kl)].copy(), dp[:len(kl)].copy()
+
+
 # ------------------------------------------------------------------------------------------- BA
 
 def local_ba(scene: dict, iters1: int = 5, iters2: int = 10, gain_thr: float = 1e-3, stop=None, want_trace=False):

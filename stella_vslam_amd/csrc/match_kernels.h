@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include "svgpu.h"
+
 #define BF_K 16  // per-query candidate prefix kept by k_bf_topk (candidates within dmax only; exact fallback when exhausted)
 
 struct BfProblem {
@@ -56,6 +58,24 @@ struct CandProblem {
     int32_t* match_q;
     int32_t* num;
 };
+
+struct StereoProblem {
+    const svgpu_keypoint* kl;
+    const svgpu_keypoint* kr;
+    const uint32_t* dl;
+    const uint32_t* dr;
+    int nl, nr, num_levels;
+    const uint8_t* lev_l[16];  // pyramid level base pointers / pitches of the two extractors
+    const uint8_t* lev_r[16];
+    int pitch_l[16], pitch_r[16], w[16], h[16];
+    float sf[16], isf[16];
+    float fxb, min_disp, max_disp;
+    unsigned thr;
+    float* xr;    // nl
+    float* depth; // nl
+    float* corr;  // nl: best L1 correlation (integer valued) or -1
+};
+void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P);
 
 void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out);
 void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const uint32_t* d2, int n2, uint16_t* out);

@@ -510,7 +510,125 @@ __global__ __launch_bounds__(256) void k_cand_replay(CandProblem P, int* __restr
     if (tid == 0) *P.num = s_changed;
 }
 
+// ------------------------------------------------------------------------------------------------ stereo
+// match::stereo::compute (match/stereo.cc:20-251), one wave per left keypoint.
+//   phase 1: lanes stride over the right keypoints: row-band membership (get_right_keypoint_indices_in_each_row, margin 2),
+//            octave +-1, disparity range, Hamming; wave-min of (dist << 16 | idx) = the reference's first strict minimum
+//   phase 2: 11 patch offsets x 121 pixels, integer L1 sums (exact: cv::norm accumulates integer-valued floats in double),
+//            parabola in double as the reference's mixed float/double expression.
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
+    const int il = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (il >= P.nl) return;
+    const svgpu_keypoint k = P.kl[il];
+    const int lvl = k.octave;
+    float out_xr = -1.0f, out_depth = -1.0f, out_corr = -1.0f;
+    const int row = (int)k.y;
+    const float min_x_right = k.x - P.max_disp, max_x_right = k.x - P.min_disp;
+    uint32_t best = 0xFFFFFFFFu;
+    if (!(max_x_right < 0)) {
+        uint32_t q[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) q[w] = P.dl[(size_t)il * 8 + w];
+        for (int ir = lane; ir < P.nr; ir += 64) {
+            const svgpu_keypoint r = P.kr[ir];
+            const float rad = 2.0f * P.sf[r.octave];
+            const int max_r = (int)ceil((double)(r.y + rad)), min_r = (int)floor((double)(r.y - rad));
+            if (row < min_r || row > max_r) continue;
+            if (r.octave < lvl - 1 || r.octave > lvl + 1) continue;
+            if (r.x < min_x_right || max_x_right < r.x) continue;
+            const unsigned d = hamming256(q, P.dr + (size_t)ir * 8);
+            if (d < P.thr) best = min(best, (d << 16) | (uint32_t)ir);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
+    if (best != 0xFFFFFFFFu) {
+        const float x_right = P.kr[best & 0xFFFFu].x;
+        const float isf = P.isf[lvl];
+        const int sxl = __float2int_rn(k.x * isf), syl = __float2int_rn(k.y * isf), sxr = __float2int_rn(x_right * isf);
+        const int ini_x = sxr - 10, end_x = sxr + 10;
+        const bool ok = !(ini_x < 0 || P.w[lvl] <= end_x) && syl - 5 >= 0 && syl + 5 < P.h[lvl] && sxl - 5 >= 0 && sxl + 5 < P.w[lvl];
+        if (ok) {
+            const uint8_t* PL = P.lev_l[lvl];
+            const uint8_t* PR = P.lev_r[lvl];
+            const int pl = P.pitch_l[lvl], pr = P.pitch_r[lvl];
+            const int lc = PL[(size_t)syl * pl + sxl];
+            // this lane's (up to) two patch pixels
+            int a[2], dy[2], dx[2];
+            bool has[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int p = lane + 64 * t;
+                has[t] = p < 121;
+                dy[t] = has[t] ? p / 11 - 5 : 0;
+                dx[t] = has[t] ? p % 11 - 5 : 0;
+                a[t] = has[t] ? (int)PL[(size_t)(syl + dy[t]) * pl + sxl + dx[t]] - lc : 0;
+            }
+            float corr[11];
+            float best_corr = 3.402823466e+38f;
+            int best_off = 0;
+#pragma unroll
+            for (int o = 0; o < 11; ++o) {
+                const int off = o - 5;
+                const int rc = PR[(size_t)syl * pr + sxr + off];
+                int acc = 0;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (has[t]) {
+                        const int b = (int)PR[(size_t)(syl + dy[t]) * pr + sxr + off + dx[t]] - rc;
+                        acc += abs(a[t] - b);
+                    }
+                const float c = (float)wave_sum_i(acc);
+                corr[o] = c;
+                if (c < best_corr) {
+                    best_corr = c;
+                    best_off = off;
+                }
+            }
+            if (best_off != -5 && best_off != 5) {
+                float c1 = corr[0], c2 = corr[1], c3 = corr[2];
+#pragma unroll
+                for (int o = 1; o < 10; ++o)
+                    if (o == best_off + 5) {
+                        c1 = corr[o - 1];
+                        c2 = corr[o];
+                        c3 = corr[o + 1];
+                    }
+                const float x_delta = (float)((double)(c1 - c3) / (2.0 * (double)(c1 + c3) - 4.0 * (double)c2));
+                if (!((double)x_delta < -1.0 || 1.0 < (double)x_delta)) {
+                    float best_x_right = P.sf[lvl] * ((float)(sxr + best_off) + x_delta);
+                    float best_disp = k.x - best_x_right;
+                    if (!(best_disp < P.min_disp || P.max_disp <= best_disp)) {
+                        if (best_disp <= 0.0f) {
+                            best_disp = 0.01f;
+                            best_x_right = k.x - best_disp;
+                        }
+                        out_depth = P.fxb / best_disp;
+                        out_xr = best_x_right;
+                        out_corr = best_corr;
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        P.xr[il] = out_xr;
+        P.depth[il] = out_depth;
+        P.corr[il] = out_corr;
+    }
+}
+
 }  // namespace
+
+void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P) {
+    SvProfScope ps(ctx, s, "k_stereo");
+    if (P.nl > 0) hipLaunchKernelGGL(k_stereo, dim3((P.nl + 3) / 4), dim3(256), 0, s, P);
+}
 
 void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out) {
     if (n <= 0) return;

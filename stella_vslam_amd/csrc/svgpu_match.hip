@@ -1,4 +1,7 @@
 // Host side of the matchers: staging of host buffers into the context's scratch arena, launches.
+#include <algorithm>
+#include <utility>
+
 #include "svgpu_internal.h"
 #include "match_kernels.h"
 
@@ -262,6 +265,103 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipStreamSynchronize(s));
     *num_matches = num;
+    return SVGPU_OK;
+}
+
+int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_keypoint* kps_left, const uint8_t* desc_left,
+                       int n_left, const svgpu_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                       float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {
+    svgpu_ctx* ctx = ctx_left;
+    if (!ctx_left || !ctx_right || n_left < 0 || n_right < 0 || n_right > 65535)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match: bad arguments");
+    if (n_left == 0) return SVGPU_OK;
+    if (!kps_left || !desc_left || !stereo_x_right || !depths || (n_right > 0 && (!kps_right || !desc_right)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match: null pointer");
+    const OrbConfig& CL = ctx_left->orb;
+    const OrbConfig& CR = ctx_right->orb;
+    if (!CL.configured || !CR.configured || ctx_left->last_batch == 0 || ctx_right->last_batch == 0)
+        return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_stereo_match: both contexts need a previous extract call");
+    if (ctx_left->device != ctx_right->device || CL.width != CR.width || CL.height != CR.height || CL.num_levels != CR.num_levels
+        || CL.scale_factor != CR.scale_factor)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match: the two extractors must share device, geometry and ORB parameters");
+    for (int i = 0; i < n_left; ++i) {
+        stereo_x_right[i] = -1.0f;
+        depths[i] = -1.0f;
+        if (kps_left[i].octave < 0 || kps_left[i].octave >= CL.num_levels) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match: octave out of range");
+    }
+    for (int i = 0; i < n_right; ++i)
+        if (kps_right[i].octave < 0 || kps_right[i].octave >= CL.num_levels) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match: octave out of range");
+    if (n_right == 0) return SVGPU_OK;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipStreamSynchronize(ctx_right->stream));  // the right pyramid must be complete
+    const size_t need = pad((size_t)n_left * 28) + pad((size_t)n_right * 28) + pad((size_t)n_left * 32) + pad((size_t)n_right * 32)
+                        + 3 * pad((size_t)n_left * 4) + 256;
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    StereoProblem P{};
+    svgpu_keypoint* dkl = A.take<svgpu_keypoint>(n_left);
+    svgpu_keypoint* dkr = A.take<svgpu_keypoint>(n_right);
+    uint32_t* ddl = A.take<uint32_t>((size_t)n_left * 8);
+    uint32_t* ddr = A.take<uint32_t>((size_t)n_right * 8);
+    P.xr = A.take<float>(n_left);
+    P.depth = A.take<float>(n_left);
+    P.corr = A.take<float>(n_left);
+    hipStream_t s = ctx->stream;
+    SV_HIP(ctx, hipMemcpyAsync(dkl, kps_left, (size_t)n_left * 28, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(dkr, kps_right, (size_t)n_right * 28, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(ddl, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(ddr, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice, s));
+    P.kl = dkl;
+    P.kr = dkr;
+    P.dl = ddl;
+    P.dr = ddr;
+    P.nl = n_left;
+    P.nr = n_right;
+    P.num_levels = CL.num_levels;
+    float inv[SV_MAX_LEVELS];
+    svgpu_orb_scale_tables(CL.scale_factor, CL.num_levels, P.sf, inv, nullptr, nullptr);
+    for (int l = 0; l < CL.num_levels; ++l) {
+        P.isf[l] = inv[l];
+        P.w[l] = CL.levels[l].w;
+        P.h[l] = CL.levels[l].h;
+        if (l == 0) {
+            P.lev_l[0] = ctx_left->last_imgs;
+            P.pitch_l[0] = ctx_left->last_row_stride;
+            P.lev_r[0] = ctx_right->last_imgs;
+            P.pitch_r[0] = ctx_right->last_row_stride;
+        }
+        else {
+            P.lev_l[l] = ctx_left->d_pyr + CL.levels[l].pyr_off;
+            P.pitch_l[l] = CL.levels[l].pitch;
+            P.lev_r[l] = ctx_right->d_pyr + CR.levels[l].pyr_off;
+            P.pitch_r[l] = CR.levels[l].pitch;
+        }
+    }
+    P.fxb = focal_x_baseline;
+    P.min_disp = 0.0f;                                // stereo.cc:18
+    P.max_disp = focal_x_baseline / true_baseline;    // stereo.cc:18
+    P.thr = 75;                                       // (HAMMING_DIST_THR_HIGH + HAMMING_DIST_THR_LOW) / 2, stereo.h:99
+    sv_launch_stereo(ctx, s, P);
+    SV_HIP(ctx, hipGetLastError());
+    std::vector<float> corr(n_left);
+    SV_HIP(ctx, hipMemcpyAsync(stereo_x_right, P.xr, (size_t)n_left * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(depths, P.depth, (size_t)n_left * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(corr.data(), P.corr, (size_t)n_left * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    // median filter of the correlations (stereo.cc:94-113); std::pair<int, int> as in the reference
+    std::vector<std::pair<int, int>> correlation_and_idx_left;
+    for (int i = 0; i < n_left; ++i)
+        if (stereo_x_right[i] != -1.0f || depths[i] != -1.0f) correlation_and_idx_left.emplace_back((int)corr[i], i);
+    std::sort(correlation_and_idx_left.begin(), correlation_and_idx_left.end());
+    const size_t median_i = correlation_and_idx_left.size() / 2;
+    const float median_correlation = correlation_and_idx_left.empty() ? 0.0f : (float)correlation_and_idx_left[median_i].first;
+    const float correlation_thr = (float)(2.0 * median_correlation);
+    for (size_t i = median_i; i < correlation_and_idx_left.size(); ++i)
+        if (correlation_thr < (float)correlation_and_idx_left[i].first) {
+            stereo_x_right[correlation_and_idx_left[i].second] = -1;
+            depths[correlation_and_idx_left[i].second] = -1;
+        }
     return SVGPU_OK;
 }
 

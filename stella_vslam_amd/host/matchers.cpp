@@ -61,5 +61,18 @@ unsigned int projection::match(const query_set& q, const data::frame_observation
     return (unsigned int)num;
 }
 
+void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
+    const int nl = (int)keypts_left_.size(), nr = (int)keypts_right_.size();
+    stereo_x_right.assign((size_t)nl, -1.0f);
+    depths.assign((size_t)nl, -1.0f);
+    if (nl == 0) return;
+    const auto dl = pack_rows(descs_left_), dr = pack_rows(descs_right_);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(svgpu_keypoint), "KeyPoint layout");
+    check(el_->context(), svgpu_stereo_match(el_->context(), er_->context(), reinterpret_cast<const svgpu_keypoint*>(keypts_left_.data()),
+                                              dl.data(), nl, reinterpret_cast<const svgpu_keypoint*>(keypts_right_.data()), dr.data(), nr,
+                                              focal_x_baseline_, true_baseline_, stereo_x_right.data(), depths.data()),
+          "svgpu_stereo_match");
+}
+
 }  // namespace match
 }  // namespace stella_vslam_hip

@@ -61,5 +61,28 @@ public:
                        int mode, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const;
 };
 
+//! match::stereo (match/stereo.h): same constructor roles; the image pyramids are the two extractors' (their last extract call)
+class stereo {
+public:
+    stereo(const feature::orb_extractor* extractor_left, const feature::orb_extractor* extractor_right,
+           const std::vector<cv::KeyPoint>& keypts_left, const std::vector<cv::KeyPoint>& keypts_right, const cv::Mat& descs_left,
+           const cv::Mat& descs_right, float focal_x_baseline, float true_baseline)
+        : el_(extractor_left), er_(extractor_right), keypts_left_(keypts_left), keypts_right_(keypts_right), descs_left_(descs_left),
+          descs_right_(descs_right), focal_x_baseline_(focal_x_baseline), true_baseline_(true_baseline) {}
+    virtual ~stereo() = default;
+    //! Compute stereo matching in subpixel order (match/stereo.cc:20-114)
+    void compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const;
+
+private:
+    const feature::orb_extractor* el_;
+    const feature::orb_extractor* er_;
+    const std::vector<cv::KeyPoint>& keypts_left_;
+    const std::vector<cv::KeyPoint>& keypts_right_;
+    const cv::Mat& descs_left_;
+    const cv::Mat& descs_right_;
+    const float focal_x_baseline_;
+    const float true_baseline_;
+};
+
 }  // namespace match
 }  // namespace stella_vslam_hip

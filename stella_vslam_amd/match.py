@@ -91,3 +91,25 @@ class projection(base):
                                                     _p(tx), _p(qt), C.c_uint(thr), C.c_float(self.lowe_ratio_), mode, _p(out),
                                                     C.byref(num)), "svgpu_match_candidates")
         return out, num.value
+
+
+class stereo:
+    """match/stereo.h: stereo(left_pyramid, right_pyramid, keypts_left, keypts_right, descs_left, descs_right, scale_factors,
+    inv_scale_factors, focal_x_baseline, true_baseline).compute() -> (stereo_x_right, depths).  The two pyramids are taken
+    from the extractors that produced the keypoints (their last extract call), as system.cc:443-447 does."""
+
+    def __init__(self, extractor_left, extractor_right, keypts_left, keypts_right, descs_left, descs_right,
+                 focal_x_baseline: float, true_baseline: float):
+        self.el, self.er = extractor_left, extractor_right
+        self.kl, self.kr = np.ascontiguousarray(keypts_left), np.ascontiguousarray(keypts_right)
+        self.dl, self.dr = _c(descs_left, np.uint8), _c(descs_right, np.uint8)
+        self.focal_x_baseline_, self.true_baseline_ = float(focal_x_baseline), float(true_baseline)
+
+    def compute(self):
+        n = len(self.kl)
+        xr, dp = np.full(max(n, 1), -1, np.float32), np.full(max(n, 1), -1, np.float32)
+        ctx = self.el.ctx
+        ctx.check(lib().svgpu_stereo_match(ctx.handle, self.er.ctx.handle, _p(self.kl), _p(self.dl), n, _p(self.kr), _p(self.dr),
+                                           len(self.kr), C.c_float(self.focal_x_baseline_), C.c_float(self.true_baseline_),
+                                           _p(xr), _p(dp)), "svgpu_stereo_match")
+        return xr[:n].copy(), dp[:n].copy()

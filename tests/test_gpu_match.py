@@ -148,3 +148,23 @@ def test_candidate_matcher_bow_triangulation_fuse_modes(M, ctx, mode, thr, ratio
     exp = O.match_candidates(qd, d1, cand_off, cand_idx, check_orientation=True, thr=thr, lowe_ratio=ratio, mode=mode, **kw)
     assert (exp >= 0).sum() > 300
     assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+
+
+@pytest.mark.parametrize("disp", [12, 31])
+def test_stereo_matches_oracle(M, disp):
+    """match::stereo::compute on a synthetic rectified pair (right image = scene shifted by `disp` px): sub-pixel x_right
+    and depths bit-identical to the oracle, and the recovered disparity is the true one."""
+    from stella_vslam_amd import feature
+    big = S.frame(640 + 64, 480, 5)
+    left, right = np.ascontiguousarray(big[:, 8:648]), np.ascontiguousarray(big[:, 8 + disp:648 + disp])
+    el, er = feature.orb_extractor(feature.orb_params()), feature.orb_extractor(feature.orb_params())
+    kl, dl = el.extract(left)
+    kr, dr = er.extract(right)
+    fxb, tb = 458.654 * 0.11, 0.11
+    xr, dp = M.stereo(el, er, kl, kr, dl, dr, fxb, tb).compute()
+    pl, pr = el.image_pyramid_, er.image_pyramid_
+    xo, do = O.stereo_match(kl, dl, kr, dr, pl, pr, fxb, tb)
+    ok = xo >= 0
+    assert ok.sum() > 800
+    assert np.array_equal(xr, xo) and np.array_equal(dp, do)
+    assert abs(np.median((kl["x"] - xr)[ok]) - disp) < 0.05

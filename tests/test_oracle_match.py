@@ -191,3 +191,20 @@ def test_match_candidates_ratio_and_triangulation_modes():
             occ[bi] = True
         assert (exp >= 0).sum() > 15
         assert np.array_equal(got, exp)
+
+
+def test_stereo_oracle_recovers_disparity():
+    """match::stereo restatement on a synthetic rectified pair: sub-pixel disparity equals the known shift, depth = fxb / d."""
+    from stella_vslam_amd import synthetic as S
+    big = S.frame(640 + 64, 480, 5)
+    for disp in (12, 31):
+        left, right = np.ascontiguousarray(big[:, 8:648]), np.ascontiguousarray(big[:, 8 + disp:648 + disp])
+        kl, dl, _, pl = O.orb_extract(left, want_pyramid=True)
+        kr, dr, _, pr = O.orb_extract(right, want_pyramid=True)
+        fxb = 458.654 * 0.11
+        xr, dp = O.stereo_match(kl, dl, kr, dr, pl, pr, fxb, 0.11)
+        ok = xr >= 0
+        assert ok.sum() > 800 and (dp[~ok] == -1).all()
+        d = (kl["x"] - xr)[ok]
+        assert abs(np.median(d) - disp) < 0.05 and np.percentile(np.abs(d - disp), 95) < 1.5
+        assert np.allclose(dp[ok], np.float32(fxb) / d, rtol=1e-6)
