@@ -147,6 +147,16 @@ def main() -> int:
     launches_per_step = max(n.value, 1) / args.steps
     bytes_per_launch = alg[dominant] / launches_per_step
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes of this same command (FETCH_SIZE and
+    # WRITE_SIZE in separate passes, tools/pmc_traffic.py -> profiles/*_traffic.json); null when no pass was recorded
+    traffic = None
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if files and B == 64 and world == 1:
+            traffic = json.load(open(files[-1]))["kernels"].get(dominant, {}).get("total")
+    except Exception:
+        traffic = None
 
     result = {
         "metric": "frames/s ORB-extract+match @640x480,2k kpts",
@@ -166,7 +176,7 @@ def main() -> int:
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": round(n_kp, 1),
                    "matches_per_pair": round(n_match, 1), "parallelism": f"frames sharded x{world}, no collective"},
         "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(achieved / 8000.0, 5), "traffic": None,
+                     "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(bytes_per_launch), "mean_launch_ms": round(k_ms, 5),
                      "per_kernel_ms_per_step": {k: round(v[0], 4) for k, v in per_kernel.items()}},
     }

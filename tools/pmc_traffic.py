@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes as MI355X_MICROARCH.md prescribes) of
+`bench.py` into profiles/<tag>_traffic.json: mean HBM-side bytes per launch of every kernel.
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x
+(guide, section HBM); the kernels here read 4 B/lane or bytes, an access width the guide lists as uncalibrated, so the raw
+value is kept and the caveat is recorded in the file.
+usage: tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_traffic.json
+"""
+import json, sys
+import pandas as pd
+
+def per_kernel(d, counter):
+    t = pd.read_csv(f"{d}/p_counter_collection.csv")
+    t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+    t = t[t.Counter_Name == counter]
+    return t.groupby("k")["Counter_Value"].mean()
+
+f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"unit": "bytes per launch (FETCH_SIZE / WRITE_SIZE KiB x 1024, mean over the launches of the run)",
+       "caveat": "gfx950: FETCH_SIZE halves wide 16 B/lane streams; these kernels use 4 B/lane or byte accesses (uncalibrated width), "
+                 "values kept raw; Infinity-Cache hits are included", "kernels": {}}
+alias = {"k_pyramid": "k_resize"}
+for k in sorted(set(f.index) | set(w.index)):
+    if not k.startswith("k_"):
+        continue
+    fe, wr = float(f.get(k, 0)) * 1024, float(w.get(k, 0)) * 1024
+    out["kernels"][alias.get(k, k)] = {"fetch": round(fe), "write": round(wr), "total": round(fe + wr)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
