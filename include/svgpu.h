@@ -213,6 +213,8 @@ typedef struct svgpu_ba_stats {
     int32_t iters_stage1, iters_stage2, stage2_entered, num_gated;
     int32_t lm_trials, cholesky_failures;
     double lambda_final;
+    int32_t stopped_by_terminate_action; /* the gain rule (not the caller) raised the stop flag (global_bundle_adjuster.cc:341) */
+    int32_t reserved;
 } svgpu_ba_stats;
 
 /* Host in/out, synchronous.
@@ -222,6 +224,15 @@ typedef struct svgpu_ba_stats {
  *   pose_out    num_poses x 12, points_out num_points x 3, outlier_out num_obs (1 = outlier observation) */
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
+
+/* Global BA core (optimize/global_bundle_adjuster.cc:26-192, 279-412): the same graph over ALL keyframes (spanning root
+ * fixed), ONE Levenberg-Marquardt run of problem->num_first_iter iterations with the terminate rule, optional Huber
+ * (obs_huber_delta), no outlier gate (num_second_iter is ignored).  The caller applies the reference's post-conditions
+ * (`force_stop_flag && *force_stop_flag && !stats->stopped_by_terminate_action` => discard, :341-343).
+ * Reduced systems beyond the on-chip solver (6 * free poses > 192) are factorised with rocSOLVER dpotrf/dpotrs
+ * (loaded on first use; the reference uses a sparse CSparse Cholesky there).  Host in/out, synchronous. */
+int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
+                    double* points_out, svgpu_ba_stats* stats);
 
 /* Multi-GPU variant.  Every rank passes the FULL pose / point arrays and ITS SHARD of the observations; the shard
  * must be BY LANDMARK (all observations of one landmark on one rank, e.g. obs_point % world == rank) so that the

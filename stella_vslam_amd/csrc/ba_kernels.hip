@@ -6,6 +6,8 @@
 //   k_ba_chi2                     computeActiveErrors + activeRobustChi2
 //   k_ba_gate                     chi2 / depth gate (optimize/local_bundle_adjuster_g2o.cc:323-344, 354-375)
 // Every reduction runs in a fixed order (no floating-point atomics): results are run-to-run reproducible.
+#include <dlfcn.h>
+
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
 
@@ -808,6 +810,47 @@ void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     }
 }
 
+// ---- large reduced systems: rocSOLVER dpotrf / dpotrs, resolved with dlopen on first use so that the library has no
+//      link-time dependency on rocBLAS for the common (local BA) case
+namespace {
+struct RocSolver {
+    void* h_blas = nullptr;
+    void* h_solver = nullptr;
+    void* handle = nullptr;
+    int (*create_handle)(void**) = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
+    int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
+    int* d_info = nullptr;
+    bool tried = false, ok = false;
+};
+RocSolver g_rs;
+bool rocsolver_ready() {
+    if (g_rs.tried) return g_rs.ok;
+    g_rs.tried = true;
+    g_rs.h_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rs.h_blas) g_rs.h_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    g_rs.h_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rs.h_solver) g_rs.h_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rs.h_blas || !g_rs.h_solver) return false;
+    g_rs.create_handle = (int (*)(void**))dlsym(g_rs.h_blas, "rocblas_create_handle");
+    g_rs.set_stream = (int (*)(void*, hipStream_t))dlsym(g_rs.h_blas, "rocblas_set_stream");
+    g_rs.dpotrf = (int (*)(void*, int, int, double*, int, int*))dlsym(g_rs.h_solver, "rocsolver_dpotrf");
+    g_rs.dpotrs = (int (*)(void*, int, int, int, double*, int, double*, int))dlsym(g_rs.h_solver, "rocsolver_dpotrs");
+    if (!g_rs.create_handle || !g_rs.set_stream || !g_rs.dpotrf || !g_rs.dpotrs) return false;
+    if (g_rs.create_handle(&g_rs.handle) != 0) return false;
+    if (hipMalloc((void**)&g_rs.d_info, sizeof(int)) != hipSuccess) return false;
+    g_rs.ok = true;
+    return true;
+}
+__global__ void k_ba_potrf_info(const int* info, BaDev D) {
+    if (*info != 0) {
+        D.red[D.red_flag_off] = 1.0;
+        for (int i = 0; i < D.n; ++i) D.dp[i] = 0.0;
+    }
+}
+}  // namespace
+
 // phase 2: reduced solve, back-substitution, trial state
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP > 0) {
@@ -820,6 +863,16 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
                 attr_set = true;
             }
             hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
+        }
+        else if (rocsolver_ready()) {
+            // S is symmetric and fully stored, so its row-major image is a valid column-major matrix (lda = n); the right-hand
+            // side is row n of the (n+1) x n buffer = a contiguous vector right behind the matrix
+            const int rocblas_fill_lower = 122;  // rocblas_fill_lower
+            g_rs.set_stream(g_rs.handle, s);
+            g_rs.dpotrf(g_rs.handle, rocblas_fill_lower, D.n, D.S, D.n, g_rs.d_info);
+            g_rs.dpotrs(g_rs.handle, rocblas_fill_lower, D.n, 1, D.S, D.n, D.S + (size_t)D.n * D.n, D.n);
+            (void)hipMemcpyAsync(D.dp, D.S + (size_t)D.n * D.n, sizeof(double) * D.n, hipMemcpyDeviceToDevice, s);
+            hipLaunchKernelGGL(k_ba_potrf_info, dim3(1), dim3(1), 0, s, g_rs.d_info, D);
         }
         else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
     }

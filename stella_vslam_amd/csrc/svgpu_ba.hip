@@ -159,13 +159,13 @@ void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose,
 
 }  // namespace
 
-static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, int world, svgpu_allreduce_fn allreduce,
-                         void* ar_user, volatile uint8_t* stop, double* pose_out, double* points_out, uint8_t* outlier_out,
+static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single_stage, int rank, int world,
+                         svgpu_allreduce_fn allreduce, void* ar_user, volatile uint8_t* stop, double* pose_out, double* points_out, uint8_t* outlier_out,
                          svgpu_ba_stats* stats) {
     if (!ctx || !pr || !pose_out || !points_out) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: null argument");
     const int P = pr->num_poses, L = pr->num_points, E = pr->num_obs;
     if (P < 0 || L < 0 || E < 0 || (P > 0 && (!pr->pose_cw || !pr->pose_fixed || !pr->intrinsics)) || (L > 0 && !pr->points)
-        || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || !outlier_out)))
+        || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || (!outlier_out && !single_stage))))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: inconsistent problem");
     for (int e = 0; e < E; ++e)
         if (pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L)
@@ -184,7 +184,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
     };
     memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
-    if (E > 0) memset(outlier_out, 0, E);
+    if (E > 0 && outlier_out) memset(outlier_out, 0, E);
     if (stats) *stats = st;
     if (!sharded) {
         if (stop && *stop) return SVGPU_STOPPED;  // local_bundle_adjuster_g2o.cc:308-310
@@ -520,7 +520,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
             else {
                 const double gain = (last_chi - current_chi) / current_chi;
                 last_chi = current_chi;
-                if (gain >= 0 && gain < pr->gain_threshold) *flag = 1;
+                if (gain >= 0 && gain < pr->gain_threshold) {
+                    *flag = 1;
+                    st.stopped_by_terminate_action = 1;
+                }
             }
         }
         // errors cached by the last computeActiveErrors (used by the gate and the outlier list)
@@ -551,7 +554,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
         if ((rc = allreduce_host(v, 1))) return rc;
         if (stop && v[0] > 0.5) *stop = 1;
     }
-    bool run_robust = true;
+    bool run_robust = !single_stage;
     if (stop && *stop) run_robust = false;  // :317-321 (only the CALLER's flag is consulted here)
     if (run_robust) {
         st.stage2_entered = 1;
@@ -571,7 +574,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
     }
     // ---- outlier list, final chi2, read-back
     std::vector<uint8_t> outl(E);
-    if (E > 0) {
+    if (E > 0 && outlier_out) {
         sv_ba_gate(s, D, 0, d_outlier);
         SV_HIP(ctx, hipMemcpyAsync(outl.data(), d_outlier, E, hipMemcpyDeviceToHost, s));
     }
@@ -596,7 +599,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, int rank, i
             if (xch_host[3 * (size_t)L + l] > 0.5)
                 for (int k = 0; k < 3; ++k) points_out[3 * (size_t)l + k] = xch_host[3 * (size_t)l + k];
     }
-    for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
+    if (outlier_out)
+        for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
     st.chi2_final = chi1;
     lap("read-back");
     st.lambda_final = lambda;
@@ -609,14 +613,19 @@ extern "C" {
 
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats) {
-    return local_ba_impl(ctx, problem, 0, 1, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
+    return local_ba_impl(ctx, problem, false, 0, 1, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
+}
+
+int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out, double* points_out,
+                    svgpu_ba_stats* stats) {
+    return local_ba_impl(ctx, problem, true, 0, 1, nullptr, nullptr, stop, pose_out, points_out, nullptr, stats);
 }
 
 int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world, svgpu_allreduce_fn allreduce,
                            void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out,
                            uint8_t* outlier_out, svgpu_ba_stats* stats) {
     if (!allreduce) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: allreduce callback is required");
-    return local_ba_impl(ctx, shard, rank, world, allreduce, allreduce_user, stop, pose_out, points_out, outlier_out, stats);
+    return local_ba_impl(ctx, shard, false, rank, world, allreduce, allreduce_user, stop, pose_out, points_out, outlier_out, stats);
 }
 
 }  // extern "C"

@@ -27,7 +27,8 @@ class _BaProblem(C.Structure):
 class _BaStats(C.Structure):
     _fields_ = [("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("iters_stage1", C.c_int32),
                 ("iters_stage2", C.c_int32), ("stage2_entered", C.c_int32), ("num_gated", C.c_int32),
-                ("lm_trials", C.c_int32), ("cholesky_failures", C.c_int32), ("lambda_final", C.c_double)]
+                ("lm_trials", C.c_int32), ("cholesky_failures", C.c_int32), ("lambda_final", C.c_double),
+                ("stopped_by_terminate_action", C.c_int32), ("reserved", C.c_int32)]
 
 
 def local_bundle_adjuster_factory_create(backend: str = "hip", **kw):
@@ -43,13 +44,23 @@ class local_bundle_adjuster:
         self.num_second_iter_ = num_second_iter
         self.ctx = ctx or Context()
 
+    def optimize_global_flat(self, scene: dict, num_iter: int = 10, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
+        """global_bundle_adjuster core: one LM run of `num_iter` iterations over the whole graph (no outlier stage)."""
+        saved = self.num_first_iter_
+        self.num_first_iter_ = num_iter
+        try:
+            return self.optimize_flat(scene, force_stop_flag, gain_threshold, _global=True)
+        finally:
+            self.num_first_iter_ = saved
+
     def optimize_flat_sharded(self, shard: dict, rank: int, world: int, allreduce_cb, force_stop_flag: np.ndarray | None = None,
                               gain_threshold: float = 1e-3):
         """Multi-GPU variant: `shard` holds this rank's observations (distributed.shard_by_landmark) and the complete
         pose / point arrays; `allreduce_cb` is a svgpu_allreduce_fn (distributed.make_allreduce_callback)."""
         return self.optimize_flat(shard, force_stop_flag, gain_threshold, _sharded=(rank, world, allreduce_cb))
 
-    def optimize_flat(self, scene: dict, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3, _sharded=None):
+    def optimize_flat(self, scene: dict, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3, _sharded=None,
+                      _global=False):
         """scene keys: pose_cw (P,12) f64, pose_fixed (P) u8, points (L,3) f64, [point_fixed (L) u8], obs_pose / obs_point (E) i32,
         obs_uvr (E,3) f32, obs_inv_sigma_sq (E) f32, obs_huber (E) f32, intr (P,5) f64.
         force_stop_flag: None or a writable uint8[1] (the caller's abort flag; may be SET by the terminate rule)."""
@@ -68,7 +79,9 @@ class local_bundle_adjuster:
         st = _BaStats()
         stop = None if force_stop_flag is None else C.c_void_p(force_stop_flag.ctypes.data)
         outs = (C.c_void_p(pose_out.ctypes.data), C.c_void_p(pts_out.ctypes.data), C.c_void_p(outl.ctypes.data), C.byref(st))
-        if _sharded is None:
+        if _global:
+            rc = lib().svgpu_global_ba(self.ctx.handle, C.byref(prob), stop, outs[0], outs[1], outs[3])
+        elif _sharded is None:
             rc = lib().svgpu_local_ba(self.ctx.handle, C.byref(prob), stop, *outs)
         else:
             rank, world, cb = _sharded

@@ -156,3 +156,18 @@ def test_local_ba_sharded_matches_single(ba, world):
     assert _rel(results[0]["pose_cw"], single["pose_cw"]) < 1e-9
     assert _rel(results[0]["points"], single["points"]) < 1e-9
     assert np.array_equal(outl, single["outlier"])
+
+
+@pytest.mark.parametrize("kw", [dict(num_kf=10, num_lm=800, obs_per_lm=5, num_fixed=1, seed=31),
+                                dict(num_kf=40, num_lm=3000, obs_per_lm=6, num_fixed=1, seed=32, loop=True)])
+def test_global_ba_matches_oracle(ba, kw):
+    """global_bundle_adjuster core: one LM run over the whole graph, only the spanning root fixed.  The second case has
+    6 * 39 = 234 reduced unknowns (> 192) and goes through the rocSOLVER dpotrf/dpotrs path."""
+    sc = S.ba_scene(**kw)
+    got = ba.optimize_global_flat(sc, num_iter=10)
+    ref = O.local_ba(sc, iters1=10, iters2=0)  # the oracle's gate after stage 1 does not move any vertex
+    assert got["stats"]["iters_stage1"] == ref["stats"][2] and got["stats"]["stage2_entered"] == 0
+    assert got["stats"]["chi2_initial"] == pytest.approx(ref["stats"][0], rel=1e-9)
+    assert _rel(got["pose_cw"], ref["pose_cw"]) < TOL and _rel(got["points"], ref["points"]) < TOL
+    assert got["stats"]["chi2_final"] < 0.5 * got["stats"]["chi2_initial"]
+    assert got["stats"]["stopped_by_terminate_action"] in (0, 1)
