@@ -225,6 +225,22 @@ typedef struct svgpu_ba_stats {
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
 
+/* ------------------------------------------------------------------------------------------------ pose optimizer
+ * Stands behind  stella_vslam::optimize::pose_optimizer::optimize  (optimize/pose_optimizer.h; g2o implementation
+ * optimize/pose_optimizer_g2o.cc:38-175; factory defaults 2 / 2 / 10, optimize/pose_optimizer_factory.h:18-26): motion-only
+ * BA of one frame against its n observed landmarks -- (num_trials_robust + num_trials) rounds of <= num_each_iter LM
+ * iterations, each followed by the chi-square (5.99146 / 7.81473) re-classification of every observation; Huber kernels
+ * are dropped after round num_trials_robust.  Fewer than 5 observations => *num_valid = 0 and the pose is returned unchanged.
+ *   pose_cw / pose_out   3x4 [R|t] row-major; pos_w n x 3; uvr n x 3 f32 (u_right < 0 => monocular edge)
+ *   huber_delta          per observation (sqrt(5.99146) for monocular cameras else sqrt(7.81473)); <= 0 => no kernel
+ *   reset_stop_flag_each_round  0 = literal g2o behaviour (the terminate action's flag, once raised by the gain rule, also
+ *                        suppresses the LM iterations of the later rounds); 1 = reset it before every round
+ * The whole optimisation is ONE single-workgroup kernel launch.  Host in/out, synchronous. */
+int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w, const float* uvr,
+                        const float* inv_sigma_sq, const float* huber_delta, const double* intrinsics /* fx fy cx cy fxb */,
+                        int num_trials_robust, int num_trials, int num_each_iter, int reset_stop_flag_each_round,
+                        double* pose_out, uint8_t* outlier_flags, int* num_valid, int* lm_iterations);
+
 /* Global BA core (optimize/global_bundle_adjuster.cc:26-192, 279-412): the same graph over ALL keyframes (spanning root
  * fixed), ONE Levenberg-Marquardt run of problem->num_first_iter iterations with the terminate rule, optional Huber
  * (obs_huber_delta), no outlier gate (num_second_iter is ignored).  The caller applies the reference's post-conditions

@@ -715,3 +715,194 @@ int orc_local_ba(int P, int L, int E, const double* pose_cw, const uint8_t* pose
     free(B.point_slot);
     return rc;
 }
+
+
+/* ---------------------------------------------------------------- pose_optimizer (motion-only BA)
+ * optimize/pose_optimizer_g2o.cc:38-175; unary edges optimize/internal/se3/perspective_pose_opt_edge.h:68-110 (mono) and the
+ * stereo variant; wrapper pose_opt_edge_wrapper.h (Huber delta = sqrt(chi_sq) by camera setup, level 0/1 = inlier/outlier).
+ *   n observations of FIXED 3-D points: pos_w (n x 3), uvr (n x 3 f32, u_right < 0 => mono), inv_sigma_sq, huber (per obs)
+ *   (num_trials_robust + num_trials) rounds of: initializeOptimization (level-0 edges) -> optimize(num_each_iter) -> chi-square
+ *   re-classification of EVERY edge at the current pose; kernels are removed after round num_trials_robust.
+ * No force-stop flag is installed by the reference, so g2o's terminate action keeps its own flag; SparseOptimizer::optimize
+ * never sends the "iteration -1" reset, hence once the gain rule has fired the later rounds run zero LM iterations
+ * (reset_flag_each_round = 0, the literal behaviour; 1 = reset per round, the behaviour if g2o did send that reset).
+ * Returns num_valid (0 when fewer than 5 observations), pose_out 3x4 row-major, outlier[n]. */
+int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const float* uvr, const float* inv_sigma_sq,
+                      const float* huber_delta, const double* intr, int num_trials_robust, int num_trials, int num_each_iter,
+                      double gain_thr, int reset_flag_each_round, double* pose_out, uint8_t* outlier, double* stats) {
+    se3q T;
+    {
+        const double R[9] = {pose_cw[0], pose_cw[1], pose_cw[2], pose_cw[4], pose_cw[5], pose_cw[6], pose_cw[8], pose_cw[9], pose_cw[10]};
+        quat_from_R(R, T.q);
+        T.t[0] = pose_cw[3];
+        T.t[1] = pose_cw[7];
+        T.t[2] = pose_cw[11];
+        quat_normalize(&T);
+    }
+    memcpy(pose_out, pose_cw, sizeof(double) * 12);
+    for (int i = 0; i < n; ++i) outlier[i] = 0;
+    if (stats) memset(stats, 0, sizeof(double) * 4);
+    if (n < 5) return 0;
+    uint8_t* level = (uint8_t*)calloc(n, 1);
+    uint8_t* robust = (uint8_t*)malloc(n);
+    double* err = (double*)calloc(3 * (size_t)n, sizeof(double));
+    for (int i = 0; i < n; ++i) robust[i] = (num_trials_robust != 0) && huber_delta[i] > 0;
+#define PO_ERR(i, Tq)                                                                     \
+    {                                                                                     \
+        double pc_[3];                                                                    \
+        se3_map((Tq), &pos_w[3 * (i)], pc_);                                              \
+        const double u_ = intr[0] * pc_[0] / pc_[2] + intr[2], v_ = intr[1] * pc_[1] / pc_[2] + intr[3]; \
+        err[3 * (i)] = (double)uvr[3 * (i)] - u_;                                         \
+        err[3 * (i) + 1] = (double)uvr[3 * (i) + 1] - v_;                                 \
+        err[3 * (i) + 2] = uvr[3 * (i) + 2] < 0 ? 0.0 : (double)uvr[3 * (i) + 2] - (u_ - intr[4] / pc_[2]); \
+    }
+#define PO_CHI(i) ((err[3 * (i)] * err[3 * (i)] + err[3 * (i) + 1] * err[3 * (i) + 1] + err[3 * (i) + 2] * err[3 * (i) + 2]) * (double)inv_sigma_sq[i])
+    uint8_t flag = 0;
+    double last_chi = 0;
+    int num_bad = 0, total_iters = 0;
+    for (int trial = 0; trial < num_trials_robust + num_trials; ++trial) {
+        if (reset_flag_each_round) flag = 0;
+        int nact = 0;
+        for (int i = 0; i < n; ++i) nact += !level[i];
+        /* ---- optimizer.optimize(num_each_iter) */
+        int ok = 1;
+        double lambda = 0, ni = 2;
+        for (int it = 0; it < num_each_iter && !flag && ok && nact > 0; ++it) {
+            double H[36] = {0}, b[6] = {0}, cur = 0;
+            for (int i = 0; i < n; ++i) {
+                if (level[i]) continue;
+                PO_ERR(i, &T)
+                double pc[3];
+                se3_map(&T, &pos_w[3 * i], pc);
+                const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z, fx = intr[0], fy = intr[1], fxb = intr[4];
+                const int stereo = !(uvr[3 * i + 2] < 0);
+                double J[18];
+                J[0] = x * y / z_sq * fx;
+                J[1] = -(1.0 + (x * x / z_sq)) * fx;
+                J[2] = y / z * fx;
+                J[3] = -1.0 / z * fx;
+                J[4] = 0;
+                J[5] = x / z_sq * fx;
+                J[6] = (1.0 + y * y / z_sq) * fy;
+                J[7] = -x * y / z_sq * fy;
+                J[8] = -x / z * fy;
+                J[9] = 0.0;
+                J[10] = -1.0 / z * fy;
+                J[11] = y / z_sq * fy;
+                J[12] = stereo ? J[0] - fxb * y / z_sq : 0;
+                J[13] = stereo ? J[1] + fxb * x / z_sq : 0;
+                J[14] = stereo ? J[2] : 0;
+                J[15] = stereo ? J[3] : 0;
+                J[16] = 0;
+                J[17] = stereo ? J[5] - fxb / z_sq : 0;
+                const double chi = PO_CHI(i);
+                double w = (double)inv_sigma_sq[i], rho[2] = {chi, 1.0};
+                if (robust[i]) huber(chi, (double)huber_delta[i], rho);
+                cur += robust[i] ? rho[0] : chi;
+                w *= rho[1];
+                for (int a = 0; a < 6; ++a) {
+                    double s = 0;
+                    for (int d = 0; d < 3; ++d) s += J[6 * d + a] * (-w * err[3 * i + d]);
+                    b[a] += s;
+                    for (int c = 0; c < 6; ++c) {
+                        double h = 0;
+                        for (int d = 0; d < 3; ++d) h += J[6 * d + a] * w * J[6 * d + c];
+                        H[6 * a + c] += h;
+                    }
+                }
+            }
+            if (it == 0) {
+                double md = 0;
+                for (int a = 0; a < 6; ++a) md = fmax(md, fabs(H[7 * a]));
+                lambda = 1e-5 * md;
+                ni = 2;
+            }
+            double rho_ = 0;
+            int qmax = 0;
+            do {
+                const se3q bak = T;
+                double A[36], x6[6];
+                memcpy(A, H, sizeof(A));
+                for (int a = 0; a < 6; ++a) A[7 * a] += lambda;
+                memcpy(x6, b, sizeof(x6));
+                const int ok2 = chol_factor(A, 6) == 0;
+                if (ok2) chol_solve(A, 6, x6);
+                else memset(x6, 0, sizeof(x6));
+                se3q ex;
+                se3_exp(x6, &ex);
+                se3_mul(&ex, &T, &T);
+                double tmp = 0;
+                for (int i = 0; i < n; ++i) {
+                    if (level[i]) continue;
+                    PO_ERR(i, &T)
+                    const double chi = PO_CHI(i);
+                    double r2[2] = {chi, 1.0};
+                    if (robust[i]) huber(chi, (double)huber_delta[i], r2);
+                    tmp += robust[i] ? r2[0] : chi;
+                }
+                if (!ok2) tmp = DBL_MAX;
+                rho_ = cur - tmp;
+                double scale = 1e-3;
+                for (int a = 0; a < 6; ++a) scale += x6[a] * (lambda * x6[a] + b[a]);
+                rho_ /= scale;
+                if (rho_ > 0 && isfinite(tmp)) {
+                    double alpha = 1. - pow((2 * rho_ - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    cur = tmp;
+                }
+                else {
+                    lambda *= ni;
+                    ni *= 2;
+                    T = bak;
+                    if (!isfinite(lambda)) break;
+                }
+                ++qmax;
+            } while (rho_ < 0 && qmax < 10 && !flag);
+            if (qmax == 10 || rho_ == 0 || !isfinite(lambda)) ok = 0;
+            ++total_iters;
+            if (it == 0) last_chi = cur;
+            else {
+                const double gain = (last_chi - cur) / cur;
+                last_chi = cur;
+                if (gain >= 0 && gain < gain_thr) flag = 1;
+            }
+        }
+        /* ---- re-classification at the current pose (:127-160) */
+        num_bad = 0;
+        for (int i = 0; i < n; ++i) {
+            PO_ERR(i, &T)
+            const float thr = uvr[3 * i + 2] < 0 ? 5.99146f : 7.81473f;
+            if ((double)thr < PO_CHI(i)) {
+                outlier[i] = 1;
+                level[i] = 1;
+                ++num_bad;
+            }
+            else {
+                outlier[i] = 0;
+                level[i] = 0;
+            }
+            if (num_trials != 0 && trial + 1 == num_trials_robust) robust[i] = 0;
+        }
+        if (n - num_bad < 5) break;
+    }
+#undef PO_ERR
+#undef PO_CHI
+    double R[9];
+    quat_to_R(T.q, R);
+    for (int i = 0; i < 3; ++i) {
+        pose_out[4 * i] = R[3 * i];
+        pose_out[4 * i + 1] = R[3 * i + 1];
+        pose_out[4 * i + 2] = R[3 * i + 2];
+        pose_out[4 * i + 3] = T.t[i];
+    }
+    if (stats) {
+        stats[0] = total_iters;
+        stats[1] = num_bad;
+    }
+    free(level);
+    free(robust);
+    free(err);
+    return n - num_bad;
+}

@@ -280,3 +280,22 @@ def local_ba(scene: dict, iters1: int = 5, iters2: int = 10, gain_thr: float = 1
     if want_trace:
         res["trace"] = trace[:-2].reshape(-1, 2)
     return res
+
+
+def pose_optimize(pose_cw, pos_w, uvr, inv_sigma_sq, huber, intr, num_trials_robust=2, num_trials=2, num_each_iter=10,
+                  gain_thr=1e-3, reset_flag_each_round=False):
+    """pose_optimizer_g2o::optimize on flat arrays; returns (num_valid, pose 3x4 flat, outlier flags, stats)."""
+    pose = np.ascontiguousarray(pose_cw, np.float64).reshape(12)
+    pw = np.ascontiguousarray(pos_w, np.float64)
+    uv = np.ascontiguousarray(uvr, np.float32)
+    w = np.ascontiguousarray(inv_sigma_sq, np.float32)
+    hb = np.ascontiguousarray(huber, np.float32)
+    K = np.ascontiguousarray(intr, np.float64).reshape(5)
+    n = len(pw)
+    out = np.zeros(12)
+    outl = np.zeros(max(n, 1), np.uint8)
+    st = np.zeros(4)
+    lib().orc_pose_optimize.restype = C.c_int
+    nv = lib().orc_pose_optimize(_p(pose), n, _p(pw), _p(uv), _p(w), _p(hb), _p(K), num_trials_robust, num_trials, num_each_iter,
+                                 C.c_double(gain_thr), int(reset_flag_each_round), _p(out), _p(outl), _p(st))
+    return nv, out, outl[:n].copy(), st

@@ -54,7 +54,25 @@ struct BaDev {
     int chol_in_lds;
 };
 
+// motion-only BA (pose_optimizer): everything lives in ONE persistent single-workgroup kernel
+struct PoseOptDev {
+    int n;
+    const double* pos_w;      // n x 3 (fixed landmarks)
+    const float* uvr;         // n x 3
+    const float* inv_sigma_sq;
+    const float* huber;
+    double intr[5];
+    double pose_in[12];
+    int num_trials_robust, num_trials, num_each_iter, reset_flag_each_round;
+    double gain_thr;
+    double* pose_out;         // 12
+    uint8_t* outlier;         // n
+    int* result;              // [0] num_valid, [1] LM iterations run, [2] num_bad
+    uint8_t* level;           // n (scratch)
+    uint8_t* robust;          // n (scratch)
+};
 struct svgpu_ctx;
+void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P);
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Dinv/Y, Schur complement, right-hand side
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // reduced solve, back-substitution, trial state

@@ -765,6 +765,258 @@ __global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_
     if (outlier_out) outlier_out[e] = out ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------ pose optimizer
+// pose_optimizer_g2o::optimize (optimize/pose_optimizer_g2o.cc:38-175) as ONE persistent workgroup: the problem is a single
+// 6-dof vertex with <= a few thousand unary edges, i.e. launch-latency-bound if it were split into kernels.  All LM
+// rounds, the 6x6 solves (thread 0) and the chi-square re-classification run on the device; the reductions are
+// fixed-order (shuffles + wave partials in LDS).
+#define PO_THREADS 512
+__device__ __forceinline__ void po_reduce(double* vals, int nv, double (*s_part)[32], double* s_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < nv; ++k) {
+        const double t = wave_sum_d(vals[k]);
+        if (lane == 0) s_part[wave][k] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) {
+        double t = 0.0;
+        for (int w = 0; w < PO_THREADS / 64; ++w) t += s_part[w][threadIdx.x];
+        s_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void po_exp_mul(const double* u, const double* T, double* O) {  // O = exp(u) * T, as k_ba_update_pose
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double Om[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) O2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
+    double a, b, c, d;
+    if (theta < 0.00001) {
+        a = 1.0;
+        b = 0.5;
+        c = 0.5;
+        d = 1.0 / 6.0;
+    }
+    else {
+        const double st = sin(theta), ct = cos(theta);
+        a = st / theta;
+        b = (1 - ct) / (theta * theta);
+        c = b;
+        d = (theta - st) / (theta * theta * theta);
+    }
+    double R[9], V[9];
+    for (int k = 0; k < 9; ++k) {
+        const double I = (k % 4 == 0) ? 1.0 : 0.0;
+        R[k] = I + a * Om[k] + b * O2[k];
+        V[k] = I + c * Om[k] + d * O2[k];
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) O[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
+        O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+    }
+}
+__device__ __forceinline__ bool po_chol6(const double* H, double lambda, const double* b, double* x) {  // (H + lambda I) x = b
+    double A[36];
+    for (int i = 0; i < 36; ++i) A[i] = H[i];
+    for (int i = 0; i < 6; ++i) A[7 * i] += lambda;
+    for (int j = 0; j < 6; ++j) {
+        double d = A[7 * j];
+        for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[7 * j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double sum = A[6 * i + j];
+            for (int k = 0; k < j; ++k) sum -= A[6 * i + k] * A[6 * j + k];
+            A[6 * i + j] = sum / d;
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        double sum = b[i];
+        for (int k = 0; k < i; ++k) sum -= A[6 * i + k] * x[k];
+        x[i] = sum / A[7 * i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double sum = x[i];
+        for (int k = i + 1; k < 6; ++k) sum -= A[6 * k + i] * x[k];
+        x[i] = sum / A[7 * i];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
+    __shared__ double s_part[PO_THREADS / 64][32];
+    __shared__ double s_red[32];
+    __shared__ double s_T[12], s_Tt[12], s_x[6];
+    __shared__ int s_ctl[4];  // [0] accept, [1] continue trials, [2] ok2
+    const int tid = threadIdx.x, n = P.n;
+    if (tid < 12) s_T[tid] = P.pose_in[tid];
+    for (int i = tid; i < n; i += PO_THREADS) {
+        P.level[i] = 0;
+        P.robust[i] = (P.num_trials_robust != 0) && P.huber[i] > 0.f;
+        P.outlier[i] = 0;
+    }
+    __syncthreads();
+    auto chi_at = [&](int i, const double* T, double* r, double* pc) {
+        cam_point(T, P.pos_w + (size_t)i * 3, pc);
+        const double u = P.intr[0] * pc[0] / pc[2] + P.intr[2], v = P.intr[1] * pc[1] / pc[2] + P.intr[3];
+        const float* o = P.uvr + (size_t)i * 3;
+        r[0] = (double)o[0] - u;
+        r[1] = (double)o[1] - v;
+        r[2] = o[2] < 0.f ? 0.0 : (double)o[2] - (u - P.intr[4] / pc[2]);
+        return (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)P.inv_sigma_sq[i];
+    };
+    bool flag = false;      // the terminate action's own stop flag (no caller flag exists in this path)
+    double last_chi = 0.0;  // terminate_action::_lastChi persists across optimize() calls
+    int num_bad = 0, total_iters = 0;
+    const int rounds = P.num_trials_robust + P.num_trials;
+    for (int trial = 0; trial < rounds; ++trial) {
+        if (P.reset_flag_each_round) flag = false;
+        bool ok = true;
+        double lambda = 0.0, ni = 2.0;
+        for (int it = 0; it < P.num_each_iter && !flag && ok; ++it) {
+            // ---- linearise at s_T: H (21 unique), b (6), robust chi2, active count
+            double acc[29];
+            for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+            for (int i = tid; i < n; i += PO_THREADS) {
+                if (P.level[i]) continue;
+                double r[3], pc[3];
+                const double chi = chi_at(i, s_T, r, pc);
+                const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z, fx = P.intr[0], fy = P.intr[1], fxb = P.intr[4];
+                const bool stereo = !(P.uvr[(size_t)i * 3 + 2] < 0.f);
+                double J[18];
+                J[0] = x * y / z_sq * fx;
+                J[1] = -(1.0 + (x * x / z_sq)) * fx;
+                J[2] = y / z * fx;
+                J[3] = -1.0 / z * fx;
+                J[4] = 0.0;
+                J[5] = x / z_sq * fx;
+                J[6] = (1.0 + y * y / z_sq) * fy;
+                J[7] = -x * y / z_sq * fy;
+                J[8] = -x / z * fy;
+                J[9] = 0.0;
+                J[10] = -1.0 / z * fy;
+                J[11] = y / z_sq * fy;
+                J[12] = stereo ? J[0] - fxb * y / z_sq : 0.0;
+                J[13] = stereo ? J[1] + fxb * x / z_sq : 0.0;
+                J[14] = stereo ? J[2] : 0.0;
+                J[15] = stereo ? J[3] : 0.0;
+                J[16] = 0.0;
+                J[17] = stereo ? J[5] - fxb / z_sq : 0.0;
+                double rho0 = chi, rho1 = 1.0;
+                if (P.robust[i]) huber(chi, (double)P.huber[i], &rho0, &rho1);
+                const double w = (double)P.inv_sigma_sq[i] * rho1;
+                int k = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int c = a; c < 6; ++c) {
+                        acc[k] += J[a] * w * J[c] + J[6 + a] * w * J[6 + c] + J[12 + a] * w * J[12 + c];
+                        ++k;
+                    }
+                for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * (-w * r[0]) + J[6 + a] * (-w * r[1]) + J[12 + a] * (-w * r[2]);
+                acc[27] += rho0;
+                acc[28] += 1.0;
+            }
+            po_reduce(acc, 29, s_part, s_red);
+            if (s_red[28] == 0.0) break;  // no active edge: nothing to optimise in this round (uniform)
+            double H[36], b[6];
+            {
+                int k = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int c = a; c < 6; ++c) {
+                        H[6 * a + c] = H[6 * c + a] = s_red[k];
+                        ++k;
+                    }
+                for (int a = 0; a < 6; ++a) b[a] = s_red[21 + a];
+            }
+            double cur = s_red[27];
+            __syncthreads();
+            if (it == 0) {
+                double md = 0.0;
+                for (int a = 0; a < 6; ++a) md = fmax(md, fabs(H[7 * a]));
+                lambda = 1e-5 * md;
+                ni = 2.0;
+            }
+            double rho = 0.0;
+            int qmax = 0;
+            do {
+                if (tid == 0) {
+                    double x[6] = {0, 0, 0, 0, 0, 0};
+                    const bool ok2 = po_chol6(H, lambda, b, x);
+                    if (!ok2)
+                        for (int a = 0; a < 6; ++a) x[a] = 0.0;
+                    for (int a = 0; a < 6; ++a) s_x[a] = x[a];
+                    po_exp_mul(x, s_T, s_Tt);
+                    s_ctl[2] = ok2 ? 1 : 0;
+                }
+                __syncthreads();
+                double tmp[1] = {0.0};
+                for (int i = tid; i < n; i += PO_THREADS) {
+                    if (P.level[i]) continue;
+                    double r[3], pc[3];
+                    const double chi = chi_at(i, s_Tt, r, pc);
+                    double rho0 = chi, rho1 = 1.0;
+                    if (P.robust[i]) huber(chi, (double)P.huber[i], &rho0, &rho1);
+                    tmp[0] += rho0;
+                }
+                po_reduce(tmp, 1, s_part, s_red);
+                double temp_chi = s_red[0];
+                if (!s_ctl[2]) temp_chi = 1.7976931348623157e308;
+                double scale = 1e-3;
+                for (int a = 0; a < 6; ++a) scale += s_x[a] * (lambda * s_x[a] + b[a]);
+                rho = (cur - temp_chi) / scale;
+                __syncthreads();
+                if (rho > 0 && isfinite(temp_chi)) {
+                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2.0;
+                    cur = temp_chi;
+                    if (tid < 12) s_T[tid] = s_Tt[tid];
+                    __syncthreads();
+                }
+                else {
+                    lambda *= ni;
+                    ni *= 2.0;
+                    if (!isfinite(lambda)) break;
+                }
+                ++qmax;
+            } while (rho < 0 && qmax < 10 && !flag);
+            if (qmax == 10 || rho == 0 || !isfinite(lambda)) ok = false;
+            ++total_iters;
+            if (it == 0) last_chi = cur;
+            else {
+                const double gain = (last_chi - cur) / cur;
+                last_chi = cur;
+                if (gain >= 0 && gain < P.gain_thr) flag = true;
+            }
+        }
+        // ---- chi-square re-classification of every edge at the current pose (:127-160)
+        double bad[1] = {0.0};
+        for (int i = tid; i < n; i += PO_THREADS) {
+            double r[3], pc[3];
+            const double chi = chi_at(i, s_T, r, pc);
+            const double thr = P.uvr[(size_t)i * 3 + 2] < 0.f ? (double)5.99146f : (double)7.81473f;
+            const bool out = thr < chi;
+            P.outlier[i] = out;
+            P.level[i] = out;
+            bad[0] += out;
+            if (P.num_trials != 0 && trial + 1 == P.num_trials_robust) P.robust[i] = 0;
+        }
+        po_reduce(bad, 1, s_part, s_red);
+        num_bad = (int)s_red[0];
+        __syncthreads();
+        if (n - num_bad < 5) break;
+    }
+    if (tid < 12) P.pose_out[tid] = s_T[tid];
+    if (tid == 0) {
+        P.result[0] = n - num_bad;
+        P.result[1] = total_iters;
+        P.result[2] = num_bad;
+    }
+}
+
 // W / Y of edges that left the active set (excluded by the gate, or whose landmark became inactive) are zeroed once
 // per stage, so that the (edge, edge) pair lists built for the first stage stay valid: such pairs contribute 0.
 __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
@@ -782,6 +1034,11 @@ __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
 }
 
 }  // namespace
+
+void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P) {
+    SvProfScope ps(ctx, s, "k_pose_opt");
+    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_THREADS), 0, s, P);
+}
 
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
     if (D.E > 0) hipLaunchKernelGGL(k_ba_zero_inactive, dim3((D.E + 255) / 256), dim3(256), 0, s, D);

@@ -616,6 +616,63 @@ int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uin
     return local_ba_impl(ctx, problem, false, 0, 1, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
 }
 
+int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w, const float* uvr,
+                        const float* inv_sigma_sq, const float* huber_delta, const double* intrinsics, int num_trials_robust,
+                        int num_trials, int num_each_iter, int reset_stop_flag_each_round, double* pose_out,
+                        uint8_t* outlier_flags, int* num_valid, int* lm_iterations) {
+    if (!ctx || !pose_cw || !pose_out || !num_valid || n < 0 || num_trials_robust < 0 || num_trials < 0 || num_each_iter < 0
+        || (n > 0 && (!pos_w || !uvr || !inv_sigma_sq || !huber_delta || !intrinsics || !outlier_flags)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_pose_optimize: bad arguments");
+    memcpy(pose_out, pose_cw, sizeof(double) * 12);
+    *num_valid = 0;
+    if (lm_iterations) *lm_iterations = 0;
+    for (int i = 0; i < n; ++i) outlier_flags[i] = 0;
+    if (n < 5) return SVGPU_OK;  // pose_optimizer_g2o.cc:109-111
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = pad(24 * (size_t)n) + pad(12 * (size_t)n) + 2 * pad(4 * (size_t)n) + 3 * pad(n) + pad(96) + pad(16) + 1024;
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    PoseOptDev P;
+    memset(&P, 0, sizeof(P));
+    double* d_pos = A.take<double>(3 * (size_t)n);
+    float* d_uvr = A.take<float>(3 * (size_t)n);
+    float* d_w = A.take<float>(n);
+    float* d_h = A.take<float>(n);
+    P.outlier = A.take<uint8_t>(n);
+    P.level = A.take<uint8_t>(n);
+    P.robust = A.take<uint8_t>(n);
+    P.pose_out = A.take<double>(12);
+    P.result = A.take<int>(4);
+    hipStream_t s = ctx->stream;
+    SV_HIP(ctx, hipMemcpyAsync(d_pos, pos_w, 24 * (size_t)n, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d_uvr, uvr, 12 * (size_t)n, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d_w, inv_sigma_sq, 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d_h, huber_delta, 4 * (size_t)n, hipMemcpyHostToDevice, s));
+    P.n = n;
+    P.pos_w = d_pos;
+    P.uvr = d_uvr;
+    P.inv_sigma_sq = d_w;
+    P.huber = d_h;
+    memcpy(P.intr, intrinsics, sizeof(double) * 5);
+    memcpy(P.pose_in, pose_cw, sizeof(double) * 12);
+    P.num_trials_robust = num_trials_robust;
+    P.num_trials = num_trials;
+    P.num_each_iter = num_each_iter;
+    P.reset_flag_each_round = reset_stop_flag_each_round;
+    P.gain_thr = 1e-3;  // terminateAction->setGainThreshold(1e-3), pose_optimizer_g2o.cc:55
+    sv_pose_opt(ctx, s, P);
+    SV_HIP(ctx, hipGetLastError());
+    int result[4] = {0, 0, 0, 0};
+    SV_HIP(ctx, hipMemcpyAsync(pose_out, P.pose_out, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(outlier_flags, P.outlier, n, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(result, P.result, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    *num_valid = result[0];
+    if (lm_iterations) *lm_iterations = result[1];
+    return SVGPU_OK;
+}
+
 int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out, double* points_out,
                     svgpu_ba_stats* stats) {
     return local_ba_impl(ctx, problem, true, 0, 1, nullptr, nullptr, stop, pose_out, points_out, nullptr, stats);

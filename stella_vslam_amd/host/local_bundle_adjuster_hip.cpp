@@ -36,5 +36,19 @@ void local_bundle_adjuster_hip::optimize_flat(const flat_ba_problem& p, bool* co
         throw std::runtime_error(std::string("svgpu_local_ba: ") + svgpu_status_string(r.status) + " (" + svgpu_last_error(ctx_) + ")");
 }
 
+unsigned int pose_optimizer_hip::optimize_flat(const double* cam_pose_cw, const std::vector<double>& pos_w, const std::vector<float>& obs_uvr,
+                                               const std::vector<float>& inv_sigma_sq, const std::vector<float>& huber_delta,
+                                               const double* intrinsics, double* optimized_pose_cw, std::vector<uint8_t>& outlier_flags) const {
+    const int n = (int)inv_sigma_sq.size();
+    outlier_flags.assign((size_t)(n > 0 ? n : 1), 0);
+    int num_valid = 0;
+    const int rc = svgpu_pose_optimize(ctx_, cam_pose_cw, n, pos_w.data(), obs_uvr.data(), inv_sigma_sq.data(), huber_delta.data(), intrinsics,
+                                       (int)num_trials_robust_, (int)num_trials_, (int)num_each_iter_, 0, optimized_pose_cw,
+                                       outlier_flags.data(), &num_valid, nullptr);
+    outlier_flags.resize((size_t)n);
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_pose_optimize: ") + svgpu_status_string(rc) + " (" + svgpu_last_error(ctx_) + ")");
+    return (unsigned int)num_valid;
+}
+
 }  // namespace optimize
 }  // namespace stella_vslam_hip

@@ -49,5 +49,23 @@ private:
     const unsigned int num_second_iter_;
 };
 
+//! optimize::pose_optimizer sibling (optimize/pose_optimizer.h, g2o defaults of pose_optimizer_factory.h:18-26).  The binding gathers,
+//! per keypoint with a live landmark, the landmark position, the undistorted keypoint (+ stereo x_right), inv_level_sigma_sq
+//! and the Huber delta (pose_optimizer_g2o.cc:86-106) and scatters outlier flags back by keypoint index.
+class pose_optimizer_hip {
+public:
+    explicit pose_optimizer_hip(svgpu_ctx* ctx, unsigned int num_trials_robust = 2, unsigned int num_trials = 2, unsigned int num_each_iter = 10)
+        : ctx_(ctx), num_trials_robust_(num_trials_robust), num_trials_(num_trials), num_each_iter_(num_each_iter) {}
+    virtual ~pose_optimizer_hip() = default;
+    //! returns the number of valid observations; optimized_pose_cw 3x4 row-major
+    unsigned int optimize_flat(const double* cam_pose_cw, const std::vector<double>& pos_w, const std::vector<float>& obs_uvr,
+                               const std::vector<float>& inv_sigma_sq, const std::vector<float>& huber_delta, const double* intrinsics,
+                               double* optimized_pose_cw, std::vector<uint8_t>& outlier_flags) const;
+
+private:
+    svgpu_ctx* ctx_;
+    const unsigned int num_trials_robust_, num_trials_, num_each_iter_;
+};
+
 }  // namespace optimize
 }  // namespace stella_vslam_hip

@@ -89,3 +89,28 @@ class local_bundle_adjuster:
         self.ctx.check(rc, "svgpu_local_ba", ok=(0, 7))
         return dict(rc=rc, pose_cw=pose_out, points=pts_out, outlier=outl[:E].copy(),
                     stats={f: getattr(st, f) for f, _ in _BaStats._fields_})
+
+
+class pose_optimizer:
+    """optimize/pose_optimizer.h (g2o backend defaults of pose_optimizer_factory.h:18-26): motion-only BA of one frame."""
+
+    def __init__(self, num_trials_robust: int = 2, num_trials: int = 2, num_each_iter: int = 10, ctx: Context | None = None,
+                 reset_stop_flag_each_round: bool = False):
+        self.num_trials_robust_, self.num_trials_, self.num_each_iter_ = num_trials_robust, num_trials, num_each_iter
+        self.reset_stop_flag_each_round_ = reset_stop_flag_each_round
+        self.ctx = ctx or Context()
+
+    def optimize_flat(self, pose_cw, pos_w, uvr, inv_sigma_sq, huber, intr):
+        """Returns (num_valid_obs, optimized pose 3x4 flat, outlier_flags, lm_iterations)."""
+        pose = np.ascontiguousarray(pose_cw, np.float64).reshape(12)
+        pw, uv = np.ascontiguousarray(pos_w, np.float64), np.ascontiguousarray(uvr, np.float32)
+        w, hb = np.ascontiguousarray(inv_sigma_sq, np.float32), np.ascontiguousarray(huber, np.float32)
+        K = np.ascontiguousarray(intr, np.float64).reshape(5)
+        n = len(pw)
+        out, outl = np.zeros(12), np.zeros(max(n, 1), np.uint8)
+        nv, it = C.c_int(0), C.c_int(0)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self.ctx.check(lib().svgpu_pose_optimize(self.ctx.handle, p(pose), n, p(pw), p(uv), p(w), p(hb), p(K), self.num_trials_robust_,
+                                                 self.num_trials_, self.num_each_iter_, int(self.reset_stop_flag_each_round_), p(out),
+                                                 p(outl), C.byref(nv), C.byref(it)), "svgpu_pose_optimize")
+        return nv.value, out, outl[:n].copy(), it.value

@@ -171,3 +171,22 @@ def test_global_ba_matches_oracle(ba, kw):
     assert _rel(got["pose_cw"], ref["pose_cw"]) < TOL and _rel(got["points"], ref["points"]) < TOL
     assert got["stats"]["chi2_final"] < 0.5 * got["stats"]["chi2_initial"]
     assert got["stats"]["stopped_by_terminate_action"] in (0, 1)
+
+
+@pytest.mark.parametrize("seed,stereo,reset", [(4, False, False), (5, False, True), (6, True, False)])
+def test_pose_optimizer_matches_oracle(ba, seed, stereo, reset):
+    """pose_optimizer (motion-only BA) as one persistent kernel vs the oracle: same LM iteration count, identical outlier flags,
+    pose within 1e-4 relative."""
+    from stella_vslam_amd import optimize
+    from tests.test_oracle_ba import _pose_problem
+    pr = _pose_problem(seed, stereo=stereo)
+    po = optimize.pose_optimizer(ctx=ba.ctx, reset_stop_flag_each_round=reset)
+    nv, pose, outl, iters = po.optimize_flat(pr["pose_cw"], pr["pos_w"], pr["uvr"], pr["inv_sigma_sq"], pr["huber"], pr["intr"])
+    nvo, poseo, outlo, st = O.pose_optimize(pr["pose_cw"], pr["pos_w"], pr["uvr"], pr["inv_sigma_sq"], pr["huber"], pr["intr"],
+                                            reset_flag_each_round=reset)
+    assert iters == st[0] and nv == nvo
+    assert np.array_equal(outl, outlo)
+    assert _rel(pose, poseo) < TOL
+    assert np.abs(pose - pr["pose_gt"]).max() < np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
+    nv0, pose0, outl0, it0 = po.optimize_flat(pr["pose_cw"], pr["pos_w"][:3], pr["uvr"][:3], pr["inv_sigma_sq"][:3], pr["huber"][:3], pr["intr"])
+    assert nv0 == 0 and np.array_equal(pose0, pr["pose_cw"].reshape(12))

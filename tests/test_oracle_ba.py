@@ -112,3 +112,23 @@ def test_stop_flag_quirk():
     flag[:] = 1
     res = O.local_ba(sc, stop=flag)
     assert res["rc"] == 1 and np.allclose(res["pose_cw"], sc["pose_cw"], atol=1e-12)
+
+
+def _pose_problem(seed, n=1200, outlier_frac=0.1, stereo=False):
+    sc = S.ba_scene(num_kf=3, num_lm=n, obs_per_lm=3, num_fixed=0, seed=seed, outlier_frac=outlier_frac, stereo=stereo)
+    sel = sc["obs_pose"] == 1
+    return dict(pose_cw=sc["pose_cw"][1], pose_gt=sc["pose_gt"][1], pos_w=sc["points_gt"][sc["obs_point"][sel]], uvr=sc["obs_uvr"][sel],
+                inv_sigma_sq=sc["obs_inv_sigma_sq"][sel], huber=sc["obs_huber"][sel], intr=sc["intr"][1])
+
+
+@pytest.mark.parametrize("reset", [False, True])
+def test_pose_optimizer_oracle(reset):
+    """Motion-only BA restatement: recovers the ground-truth pose, flags the injected outliers, fewer than 5 observations -> 0."""
+    pr = _pose_problem(4)
+    nv, pose, outl, st = O.pose_optimize(pr["pose_cw"], pr["pos_w"], pr["uvr"], pr["inv_sigma_sq"], pr["huber"], pr["intr"],
+                                         reset_flag_each_round=reset)
+    assert np.abs(pose - pr["pose_gt"]).max() < 0.1 * np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
+    assert nv == len(outl) - outl.sum() and 0.05 * len(outl) < outl.sum() < 0.2 * len(outl)
+    assert st[0] >= 2
+    nv0, pose0, outl0, _ = O.pose_optimize(pr["pose_cw"], pr["pos_w"][:4], pr["uvr"][:4], pr["inv_sigma_sq"][:4], pr["huber"][:4], pr["intr"])
+    assert nv0 == 0 and np.array_equal(pose0, pr["pose_cw"]) and outl0.sum() == 0
