@@ -9,6 +9,7 @@
 // All integer stages are bit-exact by construction; the fp32 stages replicate the reference's
 // operation order with contraction disabled (-ffp-contract=off, checked in the disassembly).
 #include "svgpu_internal.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -148,18 +149,60 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid(const OrbLevel* __restr
 #define BLUR_TW 256                 // tile width  = 64 threads x 4 px
 #define BLUR_TH (4 * BLUR_ROWS)     // tile height = 4 strips
 #define BLUR_EDGE_ROWS 8            // rows per thread in the (slow, gather-based) edge tiles
-struct BlurRow {  // the 12 source bytes [x0-4, x0+8) of one row (fast path) or pixels x0-3..x0+6 packed (edge path)
+struct BlurRow {  // the 12 source bytes of pixels [x0-4, x0+8) of one row, image borders already reflected
     uint32_t w0, w1, w2;
 };
-__device__ __forceinline__ BlurRow blur_load(const uint8_t* __restrict__ row, int x0, int w, bool fast) {
+// How a thread fetches its rows.  BLUR_INTERIOR: three aligned words.  BLUR_EDGE: the column group touches the left or
+// right image border of an aligned level; the reflected bytes are picked out of the neighbouring aligned words with
+// v_perm_b32 selectors computed once per thread.  BLUR_GATHER: byte gather (caller images with an odd pitch / base,
+// levels narrower than 16 px).
+enum { BLUR_INTERIOR = 0, BLUR_EDGE = 1, BLUR_GATHER = 2 };
+struct BlurEdge {
+    bool left, hi_p1;
+    uint32_t sel1, sel2;
+};
+__device__ __forceinline__ uint32_t blur_selector(int xbase, int lo_base, int w) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = xbase + k, sx = x < w ? x : 2 * (w - 1) - x;
+        s |= (uint32_t)min(max(sx - lo_base, 0), 7) << (8 * k);  // clamped entries belong to output columns >= w (row padding)
+    }
+    return s;
+}
+__device__ __forceinline__ BlurEdge blur_edge_ctx(int x0, int w) {
+    BlurEdge e;
+    e.left = x0 == 0;
+    e.hi_p1 = x0 + 4 < w;
+    e.sel1 = blur_selector(x0, x0 - 4, w);
+    e.sel2 = blur_selector(x0 + 4, e.hi_p1 ? x0 : x0 - 4, w);
+    return e;
+}
+template <int MODE>
+__device__ __forceinline__ BlurRow blur_load(const uint8_t* __restrict__ row, int x0, int w, const BlurEdge& e) {
     BlurRow r;
-    if (fast) {
+    if (MODE == BLUR_INTERIOR) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(row + x0 - 4);
         r.w0 = p[0];
         r.w1 = p[1];
         r.w2 = p[2];
     }
-    else {  // image border: gather with reflect-101 into the same byte layout
+    else if (MODE == BLUR_EDGE) {
+        if (e.left) {  // pixels -4..-1 are pixels 4,3,2,1
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(row);
+            r.w1 = p[0];
+            r.w2 = p[1];
+            r.w0 = __builtin_amdgcn_perm(r.w2, r.w1, 0x01020304u);
+        }
+        else {  // pixels >= w are pixels 2(w-1)-x, all inside the words at x0-4, x0 (and x0+4 when that word starts inside the row)
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + x0 - 4);
+            const uint32_t pm1 = p[0], p0 = p[1], p1 = e.hi_p1 ? p[2] : 0u;
+            r.w0 = pm1;
+            r.w1 = __builtin_amdgcn_perm(p0, pm1, e.sel1);
+            r.w2 = e.hi_p1 ? __builtin_amdgcn_perm(p1, p0, e.sel2) : __builtin_amdgcn_perm(p0, pm1, e.sel2);
+        }
+    }
+    else {
         uint32_t b[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) b[k] = row[reflect101(x0 - 4 + k, w)];
@@ -169,70 +212,98 @@ __device__ __forceinline__ BlurRow blur_load(const uint8_t* __restrict__ row, in
     }
     return r;
 }
-__device__ __forceinline__ void blur_hsum(const BlurRow& r, uint32_t (&h)[4]) {
-    uint32_t b[10];  // pixels x0-3 .. x0+6
-    b[0] = (r.w0 >> 8) & 255;
-    b[1] = (r.w0 >> 16) & 255;
-    b[2] = r.w0 >> 24;
-    b[3] = r.w1 & 255;
-    b[4] = (r.w1 >> 8) & 255;
-    b[5] = (r.w1 >> 16) & 255;
-    b[6] = r.w1 >> 24;
-    b[7] = r.w2 & 255;
-    b[8] = (r.w2 >> 8) & 255;
-    b[9] = (r.w2 >> 16) & 255;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+// Horizontal 7-tap sums of the 4 owned columns for TWO image rows at once: pixel k of row a and of row b travel as the
+// two 16-bit halves of one register (v_perm_b32 gathers them), so every packed multiply-add serves both rows.
+// 256 * 255 = 65280 fits 16 bits exactly.
+__device__ __forceinline__ void blur_hpair(const BlurRow& a, const BlurRow& b, u16x2 (&hp)[4]) {
+    u16x2 q[10];  // pixels x0-3 .. x0+6
+#define SV_PK(WA, WB, K) as_u16x2(__builtin_amdgcn_perm(WB, WA, 0x0c000c00u | ((4u + K) << 16) | K))
+    q[0] = SV_PK(a.w0, b.w0, 1u);
+    q[1] = SV_PK(a.w0, b.w0, 2u);
+    q[2] = SV_PK(a.w0, b.w0, 3u);
+    q[3] = SV_PK(a.w1, b.w1, 0u);
+    q[4] = SV_PK(a.w1, b.w1, 1u);
+    q[5] = SV_PK(a.w1, b.w1, 2u);
+    q[6] = SV_PK(a.w1, b.w1, 3u);
+    q[7] = SV_PK(a.w2, b.w2, 0u);
+    q[8] = SV_PK(a.w2, b.w2, 1u);
+    q[9] = SV_PK(a.w2, b.w2, 2u);
+#undef SV_PK
+    const u16x2 t18 = {18, 18}, t34 = {34, 34}, t48 = {48, 48}, t56 = {56, 56};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = 18u * (b[j] + b[j + 6]) + 34u * (b[j + 1] + b[j + 5]) + 48u * (b[j + 2] + b[j + 4]) + 56u * b[j + 3];
+    for (int j = 0; j < 4; ++j) hp[j] = t18 * (q[j] + q[j + 6]) + t34 * (q[j + 1] + q[j + 5]) + t48 * (q[j + 2] + q[j + 4]) + t56 * q[j + 3];
+}
+__device__ __forceinline__ uint32_t blur_dot(u16x2 h, uint32_t taps, uint32_t acc) { return __builtin_amdgcn_udot2(h, as_u16x2(taps), acc, false); }
+__device__ __forceinline__ uint32_t blur_pack(const uint32_t (&acc)[4]) {  // byte 2 of each accumulator = (acc >> 16) & 255
+    const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
+    return lo | hi;
 }
 
-// one thread: columns x0..x0+3, rows ys..ye-1
-template <bool FAST_PATH>
+// one thread: columns x0..x0+3, rows ys..ye-1 (ys even).  Rows are handled in pairs (ys-4, ys-3), (ys-2, ys-1), ...; four pairs
+// of horizontal sums stay in registers and every iteration adds one pair and emits two output rows, each as four
+// 2-element dot products (v_dot2_u32_u16) against the vertically paired taps.
+template <int MODE>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int spitch, int w, int h, uint8_t* __restrict__ dst,
                                            int dpitch, int x0, int ys, int ye) {
     auto row_ptr = [&](int y) { return src + (size_t)reflect101(y, h) * spitch; };
-    uint32_t H[7][4];
+    BlurEdge edge = {};
+    if (MODE == BLUR_EDGE) edge = blur_edge_ctx(x0, w);
+    auto load_pair = [&](int y, BlurRow& a, BlurRow& b) {
+        a = blur_load<MODE>(row_ptr(y), x0, w, edge);
+        b = blur_load<MODE>(row_ptr(y + 1), x0, w, edge);
+    };
+    u16x2 A[4], B[4], C[4], D[4], E[4];
     {
-        BlurRow r[6];
+        BlurRow r[8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) r[k] = blur_load(row_ptr(ys - 3 + k), x0, w, FAST_PATH);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) blur_hsum(r[k], H[k]);
+        for (int k = 0; k < 4; ++k) load_pair(ys - 4 + 2 * k, r[2 * k], r[2 * k + 1]);
+        blur_hpair(r[0], r[1], A);
+        blur_hpair(r[2], r[3], B);
+        blur_hpair(r[4], r[5], C);
+        blur_hpair(r[6], r[7], D);
     }
-    uint8_t* D = dst + x0;
-    BlurRow n0 = blur_load(row_ptr(ys + 3), x0, w, FAST_PATH);  // two rows of loads stay in flight ahead of the arithmetic
-    BlurRow n1 = blur_load(row_ptr(ys + 4), x0, w, FAST_PATH);
-    for (int y = ys; y < ye; ++y) {
-        const BlurRow cur = n0;
-        n0 = n1;
-        n1 = blur_load(row_ptr(y + 5), x0, w, FAST_PATH);
-        blur_hsum(cur, H[6]);
-        uint32_t packed = 0;
+    uint8_t* Dp = dst + x0;
+    BlurRow n0, n1;
+    load_pair(ys + 4, n0, n1);
+    for (int y = ys; y < ye; y += 2) {
+        const BlurRow c0 = n0, c1 = n1;
+        load_pair(y + 6, n0, n1);  // one pair of rows of loads stays in flight ahead of the arithmetic
+        blur_hpair(c0, c1, E);
+        uint32_t acc[4];
+        // row y: taps 18 34 48 56 48 34 18 over rows y-3 .. y+3 = A.hi | B | C | D
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc[j] = blur_dot(D[j], 34u | (18u << 16), blur_dot(C[j], 56u | (48u << 16), blur_dot(B[j], 34u | (48u << 16), blur_dot(A[j], 18u << 16, 32768u))));
+        *reinterpret_cast<uint32_t*>(Dp + (size_t)y * dpitch) = blur_pack(acc);
+        if (y + 1 < ye) {  // row y+1: rows y-2 .. y+4 = B | C | D | E.lo
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = blur_dot(E[j], 18u, blur_dot(D[j], 48u | (34u << 16), blur_dot(C[j], 48u | (56u << 16), blur_dot(B[j], 18u | (34u << 16), 32768u))));
+            *reinterpret_cast<uint32_t*>(Dp + (size_t)(y + 1) * dpitch) = blur_pack(acc);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t acc = 18u * (H[0][j] + H[6][j]) + 34u * (H[1][j] + H[5][j]) + 48u * (H[2][j] + H[4][j]) + 56u * H[3][j];
-            packed |= ((acc + 32768u) >> 16) << (8 * j);
+            A[j] = B[j];
+            B[j] = C[j];
+            C[j] = D[j];
+            D[j] = E[j];
         }
-        *reinterpret_cast<uint32_t*>(D + (size_t)y * dpitch) = packed;
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) H[k][j] = H[k + 1][j];
     }
 }
 
-// Tiles [0, btiles_x*btiles_y) of a level are interior tiles (aligned 12-byte windows, branch-free); the
-// last tile of the level is the EDGE tile: its threads redo the column groups that touch the left/right
-// image border with the generic reflect-101 gather.  Keeping the two roles in different workgroups keeps
-// every wave on a single code path.
-__global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
-                                              size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
-                                              size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
-    int tile;
+// Tiles [0, btiles_x*btiles_y) of a level are interior tiles (aligned 12-byte windows, branch-free); the remaining tiles
+// of the level are EDGE tiles whose threads do the column groups that touch the left/right image border.  Keeping the
+// two roles in different workgroups keeps every wave on a single code path.  Sources that are not 4-byte aligned
+// (caller images) or narrower than 16 px go through k_blur_gather instead (host decision, sv_launch_blur).
+__device__ __forceinline__ void blur_locate(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
+                                            size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
+                                            size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes, OrbLevel& lev,
+                                            int& tile, const uint8_t*& src, int& spitch, uint8_t*& dst) {
     const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::btile_first, &tile);
-    const OrbLevel lev = L[lv];
+    lev = L[lv];
     const int b = blockIdx.y;
-    const uint8_t* src;
-    int spitch;
     if (lv == 0) {
         src = img0 + (size_t)b * img0_frame_stride;
         spitch = img0_pitch;
@@ -241,20 +312,28 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
         src = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
         spitch = lev.pitch;
     }
-    uint8_t* dst = blur + (size_t)b * blur_frame_bytes + lev.blur_off;
-    const bool aligned = ((((size_t)src) | (size_t)spitch) & 3) == 0;
+    dst = blur + (size_t)b * blur_frame_bytes + lev.blur_off;
+}
+__device__ __forceinline__ bool blur_streamable(const uint8_t* src, int spitch, int w) {
+    return ((((size_t)src) | (size_t)spitch) & 3) == 0 && w >= 16;
+}
+__global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
+                                              size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
+                                              size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
+    OrbLevel lev;
+    int tile, spitch;
+    const uint8_t* src;
+    uint8_t* dst;
+    blur_locate(L, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, lev, tile, src, spitch, dst);
+    if (!blur_streamable(src, spitch, lev.w)) return;  // k_blur_gather's level
     const int main_tiles = lev.btiles_x * lev.btiles_y;
     if (tile < main_tiles) {
         const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
         const int ys = (tile / lev.btiles_x) * BLUR_TH + (threadIdx.x >> 6) * BLUR_ROWS;
         if (x0 >= lev.w || ys >= lev.h) return;
-        const bool interior = x0 >= 4 && x0 + 6 < lev.w;
-        if (aligned) {
-            if (interior) blur_strip<true>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
-        }
-        else blur_strip<false>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
+        if (x0 >= 4 && x0 + 6 < lev.w) blur_strip<BLUR_INTERIOR>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
     }
-    else if (aligned) {
+    else {
         // edge groups: x0 = 0 and every group with x0 + 6 >= w (at most two); thread = (strip, which)
         const int which = threadIdx.x & 3, strip = (tile - main_tiles) * 64 + (threadIdx.x >> 2);
         const int ys = strip * BLUR_EDGE_ROWS;
@@ -265,8 +344,22 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
         else if (which == 2) x0 = last - 4;
         else return;
         if (ys >= lev.h || x0 < 0 || (which != 0 && (x0 == 0 || x0 + 6 < lev.w))) return;
-        blur_strip<false>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_EDGE_ROWS, lev.h));
+        blur_strip<BLUR_EDGE>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_EDGE_ROWS, lev.h));
     }
+}
+__global__ __launch_bounds__(256) void k_blur_gather(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
+                                                     size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
+                                                     size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
+    OrbLevel lev;
+    int tile, spitch;
+    const uint8_t* src;
+    uint8_t* dst;
+    blur_locate(L, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, lev, tile, src, spitch, dst);
+    if (blur_streamable(src, spitch, lev.w) || tile >= lev.btiles_x * lev.btiles_y) return;
+    const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
+    const int ys = (tile / lev.btiles_x) * BLUR_TH + (threadIdx.x >> 6) * BLUR_ROWS;
+    if (x0 >= lev.w || ys >= lev.h) return;
+    blur_strip<BLUR_GATHER>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
 }
 
 // ------------------------------------------------------------------------------------------------ FAST
@@ -274,41 +367,30 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
 // cv::FAST: p is a corner at threshold t  <=>  A(p) > t, and cornerScore = A(p) - 1
 // (closed form of fast.cpp / fast_score.cpp; proven equal to the literal row-buffer algorithm by
 // tests/test_oracle_orb.py::test_fast_matches_closed_form_definition).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
-    int d[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = v - p[k];
-    int mn[16], mx[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        mn[k] = min(d[k], d[(k + 1) & 15]);
-        mx[k] = max(d[k], d[(k + 1) & 15]);
-    }
-    int mn4[16], mx4[16];
+    // packed form: e[k] = (v - p_k, p_k - v) as two int16 halves, so that one v_pk_min_i16 serves the "centre brighter"
+    // and the "centre darker" arcs at once.  The 16 arcs of 9 are the 8 windows of 8 starting at odd k, each extended
+    // by its left or its right neighbour.
+    s16x2 e[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        mn4[k] = min(mn[k], mn[(k + 2) & 15]);
-        mx4[k] = max(mx[k], mx[(k + 2) & 15]);
+        const int d = v - p[k];
+        e[k] = s16x2{(short)d, (short)-d};
     }
-    int best = 0;
+    s16x2 m2[8], m4[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int m8 = min(mn4[k], mn4[(k + 4) & 15]);
-        const int M8 = max(mx4[k], mx4[(k + 4) & 15]);
-        const int m9 = min(m8, d[(k + 8) & 15]);   // min over the arc k..k+8 of (v - p): centre brighter
-        const int M9 = max(M8, d[(k + 8) & 15]);   // max over the arc: -M9 = min of (p - v): centre darker
-        best = max(best, max(m9, -M9));
+    for (int j = 0; j < 8; ++j) m2[j] = __builtin_elementwise_min(e[2 * j + 1], e[(2 * j + 2) & 15]);  // window 2 at k = 2j+1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m4[j] = __builtin_elementwise_min(m2[j], m2[(j + 1) & 7]);             // window 4 at k = 2j+1
+    s16x2 best = s16x2{0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const s16x2 m8 = __builtin_elementwise_min(m4[j], m4[(j + 2) & 7]);                            // window 8 at k = 2j+1
+        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, e[2 * j]));               // arc 2j .. 2j+8
+        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, e[(2 * j + 9) & 15]));    // arc 2j+1 .. 2j+9
     }
-    return best;
-}
-
-__device__ __forceinline__ bool run_of_9(uint32_t m16) {
-    uint32_t m = m16 | (m16 << 16);
-    uint32_t r = m & (m >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= m >> 8;
-    return (r & 0xFFFFu) != 0;
+    return max((int)best.x, (int)best.y);
 }
 
 #define FP 76  // LDS pitch of the ROI arrays: 3 skew bytes + 70 + padding to a multiple of 4
@@ -317,7 +399,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
                                               const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                               const unsigned short* __restrict__ gtab, unsigned long long* __restrict__ keys,
                                               int total_grid, int ini_thr, int min_thr, const uint8_t* __restrict__ mask,
-                                              size_t mask_frame_stride, int mask_pitch, int mask_w, int mask_h) {
+                                              size_t mask_frame_stride, int mask_pitch, int mask_w, int mask_h, int dbg_stop) {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[SV_ROI_MAX * FP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_a[SV_ROI_MAX * FP];
     __shared__ unsigned short s_q[SV_CELL * SV_CELL];
@@ -376,6 +458,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         s_qn = 0;
     }
     __syncthreads();
+    if (dbg_stop == 1) return;
 
     const int tq = min(ini_thr, min_thr);
     const int lx = 3 + (tid & 63);
@@ -397,33 +480,32 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         p[14] = c[2 * FP - 2];
         p[15] = c[3 * FP - 1];
     };
-    // --- pass A: every pixel of the scored band [3, w-3) x [3, h-3): is there a 9-arc at the lower threshold?
-    //     Candidates (a few percent of the pixels) are compacted into an LDS queue so that the expensive
-    //     arc score below runs on full waves instead of on the union of sparse lanes.
+    // --- pass A: every pixel of the scored band [3, w-3) x [3, h-3) takes a 5-pixel quick test at the lower threshold.
+    //     Nine contiguous ring pixels always contain at least one pixel of every opposite pair (k, k + 8), so a
+    //     9-arc brighter than v + t needs (p0 | p8) and (p4 | p12) brighter (same for darker): a necessary condition
+    //     that ~90 % of the pixels fail.  Survivors are compacted into an LDS queue so that the expensive arc score
+    //     below runs on full waves; it is exact, so queueing a superset of the corners is harmless.
     for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
         bool cand = false;
         if (lx < w - 3) {
             const uint8_t* c = &s_img[ly * FP + lx];
             const int v = c[0];
-            int p[16];
-            load_ring(c, p);
-            uint32_t bright = 0, dark = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                bright |= (uint32_t)(p[k] > v + tq) << k;
-                dark |= (uint32_t)(p[k] < v - tq) << k;
-            }
-            cand = run_of_9(bright) || run_of_9(dark);
+            const int hi = v + tq, lo = v - tq;
+            const int p0 = c[3 * FP], p8 = c[-3 * FP], p4 = c[3], p12 = c[-3];
+            const int xb = max(min(hi - p0, hi - p8), min(hi - p4, hi - p12));  // < 0: both pairs have a brighter pixel
+            const int xd = max(min(p0 - lo, p8 - lo), min(p4 - lo, p12 - lo));  // < 0: both pairs have a darker pixel
+            cand = min(xb, xd) < 0;
         }
         const unsigned long long bal = __ballot(cand);
         if (bal) {
             int base = 0;
             if ((tid & 63) == 0) base = atomicAdd(&s_qn, __popcll(bal));
-            base = __shfl(base, 0, 64);
+            base = __builtin_amdgcn_readfirstlane(base);
             if (cand) s_q[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
         }
     }
     __syncthreads();
+    if (dbg_stop == 2) return;
     // --- pass B: arc score of the candidates
     for (int i = tid; i < s_qn; i += 256) {
         const int ly = s_q[i] >> 7, qx = s_q[i] & 127;
@@ -433,6 +515,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         s_a[ly * FP + qx] = (uint8_t)arc_score16(c[0], p);
     }
     __syncthreads();
+    if (dbg_stop == 3) return;
 
     // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
     const int gx_off = lev.gtab_x_off, gy_off = lev.gtab_y_off;
@@ -577,13 +660,45 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-// one wave per keypoint, 4 keypoints per block
+// Stage a (2R+1)-row patch whose top-left pixel is g into the wave's LDS slab with 8-byte loads.  The slab row pitch
+// PITCH >= 2R+1+7 leaves room for the misalignment of g; returns the LDS offset of the patch's (row 0, col 0).
+// Rows are read from the 8-byte boundary at or below g, i.e. up to 7 bytes before and PITCH-2R-1 bytes after the
+// patch; keypoints keep 19 px to every image border, so those bytes belong to the previous / next image row.
+template <int R, int PITCH>
+__device__ __forceinline__ int stage_patch(const uint8_t* g, int gpitch, uint8_t* slab, int lane) {
+    constexpr int ROWS = 2 * R + 1, LPR = PITCH / 8, RPI = 64 / LPR;
+    if (gpitch & 7) {  // caller-owned image with an odd pitch: rows do not keep their 8-byte phase, byte path
+        for (int i = lane; i < ROWS * ROWS; i += 64) {
+            const int r = i / ROWS, c = i - r * ROWS;
+            slab[r * PITCH + c] = g[(ptrdiff_t)r * gpitch + c];
+        }
+        return 0;
+    }
+    const int mis = (int)((size_t)g & 7);
+    const uint8_t* ga = g - mis;
+    const int lr = lane / LPR, lj = lane - lr * LPR;
+#pragma unroll
+    for (int r0 = 0; r0 < ROWS; r0 += RPI) {
+        const int r = r0 + lr;
+        if (lr < RPI && r < ROWS)
+            *reinterpret_cast<uint2*>(slab + r * PITCH + 8 * lj) = *reinterpret_cast<const uint2*>(ga + (ptrdiff_t)r * gpitch + 8 * lj);
+    }
+    return mis;
+}
+
+#define DESC_R 18          // largest |rounded rotated pattern coordinate| (pattern radius 18.38)
+#define DESC_BP 48         // LDS pitch of the blurred patch: 37 + 7 rounded up to 8
+#define DESC_IP 40         // LDS pitch of the un-blurred 31 x 31 patch
+#define DESC_SLAB (37 * DESC_BP + 31 * DESC_IP + 8)
+// one wave per keypoint, 4 keypoints per block.  Both patches are staged in LDS with a handful of wide loads; the
+// 16 + 8 byte gathers per lane then hit LDS instead of the texture-address path.
 __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L, int num_levels, const int4* __restrict__ sel,
                                                   int total_grid, const int32_t* __restrict__ counts,
                                                   const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
                                                   const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                   const uint8_t* __restrict__ blur, size_t blur_frame_bytes,
                                                   svgpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_slab[4][DESC_SLAB];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -602,18 +717,25 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         I = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
         ipitch = lev.pitch;
     }
+    uint8_t* const slab_b = s_slab[threadIdx.x >> 6];
+    uint8_t* const slab_i = slab_b + 37 * DESC_BP;
+    const uint8_t* Bg = blur + (size_t)b * blur_frame_bytes + lev.blur_off;
+    const int mis_i = stage_patch<15, DESC_IP>(I + (size_t)(y - 15) * ipitch + (x - 15), ipitch, slab_i, lane);
+    const int mis_b = stage_patch<DESC_R, DESC_BP>(Bg + (size_t)(y - DESC_R) * lev.pitch + (x - DESC_R), lev.pitch, slab_b, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- intensity centroid on the un-blurred level (orb_impl.cc:68-91); lanes = columns, two row halves
     int m10 = 0, m01 = 0;
     {
         // lanes 0..30 take the rows v = 0,-1..-15, lanes 32..62 the rows v = 1..15; lane & 31 = column u + 15.
-        // All 16 row loads are issued unconditionally (clamped column) so that they overlap; the disc mask
-        // u_max_[|v|] is applied to the accumulation only.
+        // The disc mask u_max_[|v|] is applied to the accumulation only.
         const int ul = lane & 31, u = min(ul, 30) - 15, au = u < 0 ? -u : u;
         const int sgn = lane < 32 ? -1 : 1;
-        const uint8_t* c = I + (size_t)y * ipitch + x + u;
+        const uint8_t* c = slab_i + mis_i + 15 * DESC_IP + 15 + u;
         int val[16];
 #pragma unroll
-        for (int v = 0; v <= 15; ++v) val[v] = c[(ptrdiff_t)(sgn * v) * ipitch];
+        for (int v = 0; v <= 15; ++v) val[v] = c[sgn * v * DESC_IP];
         if (ul < 31) {
 #pragma unroll
             for (int v = 0; v <= 15; ++v) {
@@ -630,8 +752,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     // ---- rotated BRIEF on the blurred level (orb_impl.cc:93-154)
     const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
     const float ca = dev_util_cos(rad), sa = dev_util_sin(rad);
-    const uint8_t* B = blur + (size_t)b * blur_frame_bytes + lev.blur_off + (size_t)y * lev.pitch + x;
-    const int bp = lev.pitch;
+    const uint8_t* B = slab_b + mis_b + DESC_R * DESC_BP + DESC_R;
     unsigned long long bits[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -640,8 +761,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         const float x0 = (float)q.x, y0 = (float)q.y, x1 = (float)q.z, y1 = (float)q.w;
         const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
         const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
-        const int a = B[(ptrdiff_t)r0 * bp + c0];
-        const int bb = B[(ptrdiff_t)r1 * bp + c1];
+        const int a = B[r0 * DESC_BP + c0];
+        const int bb = B[r1 * DESC_BP + c1];
         bits[r] = __ballot(a < bb);
     }
     uint8_t* D = desc + ((size_t)b * cap + i) * 32;
@@ -684,9 +805,12 @@ void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, co
 
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
-                    size_t blur_frame_bytes, int batch) {
+                    size_t blur_frame_bytes, int batch, bool need_gather) {
     hipLaunchKernelGGL(k_blur, dim3(total_tiles, batch), dim3(256), 0, s, levels, num_levels, img0, img0_frame_stride,
                        img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+    if (need_gather)
+        hipLaunchKernelGGL(k_blur_gather, dim3(total_tiles, batch), dim3(256), 0, s, levels, num_levels, img0, img0_frame_stride,
+                           img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
 }
 
 void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const FastCell* cells, int num_cells,
@@ -697,7 +821,7 @@ void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const
     if (num_cells == 0) return;
     hipLaunchKernelGGL(k_fast, dim3(num_cells, batch), dim3(256), 0, s, levels, num_levels, cells, img0, img0_frame_stride,
                        img0_pitch, pyr, pyr_frame_bytes, gtab, keys, total_grid, ini_thr, min_thr, mask, mask_frame_stride,
-                       mask_pitch, mask_w, mask_h);
+                       mask_pitch, mask_w, mask_h, getenv("SVGPU_DBG_FAST_STOP") ? atoi(getenv("SVGPU_DBG_FAST_STOP")) : 0);
 }
 
 void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,

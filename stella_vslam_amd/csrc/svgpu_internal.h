@@ -130,7 +130,7 @@ void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, co
                        const short2* xa, const short2* yofs, const short2* yb, int batch);
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
-                    size_t blur_frame_bytes, int batch);
+                    size_t blur_frame_bytes, int batch, bool need_gather);
 void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const FastCell* cells, int num_cells,
                     const uint8_t* img0, size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr,
                     size_t pyr_frame_bytes, const unsigned short* gtab, unsigned long long* keys, int total_grid,

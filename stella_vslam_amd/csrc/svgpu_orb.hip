@@ -276,8 +276,8 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     if ((rc = upload(ctx, &ctx->d_yb, yb))) return rc;
     if ((rc = upload(ctx, &ctx->d_gtab, gtab))) return rc;
     const size_t B = (size_t)max_batch, G = (size_t)(C.total_grid > 0 ? C.total_grid : 1);
-    SV_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, B * C.pyr_frame_bytes));
-    SV_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * C.blur_frame_bytes));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, B * C.pyr_frame_bytes + 256));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * C.blur_frame_bytes + 256));
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_keys, B * G * sizeof(unsigned long long)));
     SV_HIP(ctx, hipMemset(ctx->d_keys, 0, B * G * sizeof(unsigned long long)));
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_sel, B * G * sizeof(int4)));
@@ -323,8 +323,11 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     // 2. blurred copy of every level
     {
         SvProfScope ps(ctx, s, "k_blur");
+        // levels the streaming kernel cannot take (caller image not 4-byte aligned, level narrower than 16 px) -> gather kernel
+        bool need_gather = (((size_t)imgs_dev | (size_t)frame_stride | (size_t)row_stride) & 3) != 0;
+        for (int l = 0; l < Lc; ++l) need_gather = need_gather || C.levels[l].w < 16;
         sv_launch_blur(s, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
-                       ctx->d_blur, C.blur_frame_bytes, batch);
+                       ctx->d_blur, C.blur_frame_bytes, batch, need_gather);
     }
     // 3. FAST per cell + selection-grid arg-max
     {

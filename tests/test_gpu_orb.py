@@ -93,3 +93,44 @@ def test_repeatable_and_two_contexts(F):
     c = e1.extract(img)
     _assert_same(a[0], a[1], b[0], b[1])
     _assert_same(a[0], a[1], c[0], c[1])
+
+
+def test_batch_device_unaligned_images(F):
+    """Caller-owned device images whose base / pitch are not 4-byte aligned take the gather variants of the blur and
+    of the patch staging (k_blur_gather, stage_patch byte path): same bits as the aligned streaming kernels."""
+    import ctypes as C
+    import torch
+    from stella_vslam_amd._lib import lib
+    W, H, B = 322, 243, 3
+    imgs = [S.frame(W, H, 20 + i) for i in range(B)]
+    L = lib()
+    p = F.orb_params()
+    NL = p.num_levels_
+    results = []
+    for base_off, pitch in ((0, 324), (1, 323)):
+        ctx = F.Context(0)
+        ctx.check(L.svgpu_orb_configure(ctx.handle, W, H, B, C.c_float(p.scale_factor_), NL, p.ini_fast_thr_, p.min_fast_thr_, C.c_uint(800)), "cfg")
+        cap = L.svgpu_orb_max_keypoints(ctx.handle)
+        frame_stride = pitch * H + 5 if base_off else pitch * H
+        host = np.zeros(base_off + B * frame_stride + 64, np.uint8)
+        for i, im in enumerate(imgs):
+            v = host[base_off + i * frame_stride: base_off + i * frame_stride + pitch * H].reshape(H, pitch)
+            v[:, :W] = im
+        dev = torch.from_numpy(host).cuda()
+        kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+        desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        counts = torch.zeros(B * (1 + NL), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(dev.data_ptr() + base_off), B, C.c_size_t(frame_stride), pitch, None,
+                                                   C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), cap,
+                                                   C.c_void_p(counts.data_ptr()), None), "extract")
+        ctx.synchronize()
+        results.append((kps.cpu().numpy().reshape(B, cap, 28), desc.cpu().numpy().reshape(B, cap, 32), counts.cpu().numpy().reshape(B, 1 + NL)))
+    (ka, da, ca), (ku, du, cu) = results
+    assert np.array_equal(ca, cu)
+    for i in range(B):
+        n = ca[i, 0]
+        ko, do, cnt = O.orb_extract(imgs[i])
+        assert n == len(ko) and np.array_equal(cnt, ca[i, 1:])
+        assert np.array_equal(ka[i, :n], ku[i, :n]) and np.array_equal(da[i, :n], du[i, :n])
+        assert np.array_equal(da[i, :n], do)
