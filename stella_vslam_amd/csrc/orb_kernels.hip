@@ -39,6 +39,9 @@ __device__ __forceinline__ int reflect101(int p, int len) {  // cv::BORDER_REFLE
     return p;
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+
 // ------------------------------------------------------------------------------------------------ resize
 // OpenCV 8-bit bilinear: horizontal int32 with 11-bit coefficients, vertical
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  Coefficient tables are built on the host.
@@ -141,6 +144,134 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid(const OrbLevel* __restr
     }
 }
 
+// LDS-resident variant (the one normally launched): level 1 is computed straight from the caller's image in global
+// memory; every further level is computed from the previous level's rows in LDS, and each level row is stored to
+// global memory once by the band that owns it, so the chained levels wait on LDS latency instead of on global round
+// trips.  A thread produces 4 adjacent output pixels.  Per source row it reads two 8-byte windows (dword aligned,
+// positions from the packed column-group record built on the host), lifts each (S[sx], S[sx+1]) byte pair into two
+// 16-bit halves with one v_perm_b32 and forms S[sx]*a0 + S[sx+1]*a1 with one v_dot2_u32_u16.
+// LDS map (dynamic): [images of levels >= 1 (the band's rows), pitch = w rounded up to 4][32-byte column-group records]
+// [8-byte row records of the band's rows].  The host picks the band count so that this fits (svgpu_orb_configure).
+enum { PYR_SRC_LDS = 0, PYR_SRC_GLOBAL_WORDS = 1, PYR_SRC_GLOBAL_BYTES = 2 };
+template <int SRC>
+__device__ __forceinline__ uint32_t pyr_group(const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1, const uint4 e,
+                                              const uint2 e2, uint32_t b0, uint32_t b1, int last_word, int pw) {
+    const uint32_t coef[4] = {e.z, e.w, e2.x, e2.y};
+    const int i0 = e.x & 0xffff, i2 = e.x >> 16;
+    uint32_t w0[2][2], w1[2][2];
+    if (SRC != PYR_SRC_GLOBAL_BYTES) {
+        const uint32_t* R0 = reinterpret_cast<const uint32_t*>(row0);
+        const uint32_t* R1 = reinterpret_cast<const uint32_t*>(row1);
+        // global rows: the word after the last one of the row may lie outside the caller's buffer; it only ever
+        // carries a zero weight, so the clamped duplicate is as good
+        const int j0 = SRC == PYR_SRC_LDS ? i0 + 1 : min(i0 + 1, last_word), j2 = SRC == PYR_SRC_LDS ? i2 + 1 : min(i2 + 1, last_word);
+        w0[0][0] = R0[i0];
+        w0[0][1] = R0[j0];
+        w0[1][0] = R0[i2];
+        w0[1][1] = R0[j2];
+        w1[0][0] = R1[i0];
+        w1[0][1] = R1[j0];
+        w1[1][0] = R1[i2];
+        w1[1][1] = R1[j2];
+    }
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t k = (e.y >> (8 * i)) & 255u;
+        uint32_t q0, q1;
+        if (SRC != PYR_SRC_GLOBAL_BYTES) {
+            const uint32_t sel = 0x0c010c00u + k * 0x00010001u;  // bytes (k, zero, k + 1, zero) of the 8-byte window
+            q0 = __builtin_amdgcn_perm(w0[i >> 1][1], w0[i >> 1][0], sel);
+            q1 = __builtin_amdgcn_perm(w1[i >> 1][1], w1[i >> 1][0], sel);
+        }
+        else {
+            const int sx = 4 * (i < 2 ? i0 : i2) + (int)k, sx1 = min(sx + 1, pw - 1);
+            q0 = (uint32_t)row0[sx] | ((uint32_t)row0[sx1] << 16);
+            q1 = (uint32_t)row1[sx] | ((uint32_t)row1[sx1] << 16);
+        }
+        const uint32_t r0 = __builtin_amdgcn_udot2(as_u16x2(q0), as_u16x2(coef[i]), 0u, false);
+        const uint32_t r1 = __builtin_amdgcn_udot2(as_u16x2(q1), as_u16x2(coef[i]), 0u, false);
+        v[i] = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2;  // 2048 * 32640 < 2^32, factors < 2^24
+    }
+    return (v[0] & 255u) | ((v[1] & 255u) << 8) | ((v[2] & 255u) << 16) | (v[3] << 24);
+}
+
+__global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __restrict__ L, int num_levels, const int2* __restrict__ band_rows,
+                                                             int bands, const uint8_t* __restrict__ img0, size_t img0_frame_stride,
+                                                             int img0_pitch, uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                             const uint32_t* __restrict__ xg, const short4* __restrict__ yrow) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    __shared__ int s_img[SV_MAX_LEVELS], s_xt[SV_MAX_LEVELS], s_yt[SV_MAX_LEVELS + 1];
+    const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int2* BR = band_rows + (size_t)band * num_levels;
+    if (tid == 0) {
+        int off = 0;
+        for (int l = 1; l < num_levels; ++l) {
+            s_img[l] = off;
+            off += (BR[l].y - BR[l].x) * ((L[l].w + 3) & ~3);
+        }
+        off = (off + 15) & ~15;
+        for (int l = 1; l < num_levels; ++l) {
+            s_xt[l] = off;
+            off += ((L[l].w + 3) >> 2) * 32;
+        }
+        s_yt[0] = off;
+        for (int l = 1; l < num_levels; ++l) {
+            s_yt[l] = off;
+            off += (BR[l].y - BR[l].x) * 8;
+        }
+        s_yt[num_levels] = off;
+    }
+    __syncthreads();
+    // ---- column-group records of all levels (contiguous in global memory and in LDS), row records of the band's rows
+    {
+        const int first = L[1].xg_off * 8, words = (s_yt[0] - s_xt[1]) >> 2;
+        uint32_t* D = reinterpret_cast<uint32_t*>(s_mem + s_xt[1]);
+        for (int i = tid; i < words; i += PYR_THREADS) D[i] = xg[first + i];
+        const int rows = (s_yt[num_levels] - s_yt[0]) >> 3;
+        for (int i = tid; i < rows; i += PYR_THREADS) {
+            int l = 1;
+            while (l + 1 < num_levels && s_yt[0] + 8 * i >= s_yt[l + 1]) ++l;
+            const int r = i - ((s_yt[l] - s_yt[0]) >> 3);
+            reinterpret_cast<short4*>(s_mem + s_yt[0])[i] = yrow[L[l].ytab_off + BR[l].x + r];
+        }
+    }
+    __syncthreads();
+    uint8_t* P = pyr + (size_t)b * pyr_frame_bytes;
+    const uint8_t* I0 = img0 + (size_t)b * img0_frame_stride;
+    const bool words0 = ((((size_t)I0) | (size_t)img0_pitch) & 3) == 0;
+    for (int l = 1; l < num_levels; ++l) {
+        const OrbLevel lev = L[l];
+        const int pw = L[l - 1].w, sp = (pw + 3) & ~3, dpw = ((lev.w + 3) & ~3) >> 2;  // LDS pitches (bytes, dwords)
+        const int src_lo = BR[l - 1].x, lo = BR[l].x, hi = BR[l].y;
+        const int own_lo = (int)((long long)band * lev.h / bands), own_hi = (int)((long long)(band + 1) * lev.h / bands);
+        const uint8_t* S = s_mem + (l > 1 ? s_img[l - 1] : 0);
+        uint32_t* Dl = reinterpret_cast<uint32_t*>(s_mem + s_img[l]);
+        const uint4* xt = reinterpret_cast<const uint4*>(s_mem + s_xt[l]);
+        const short4* yt = reinterpret_cast<const short4*>(s_mem + s_yt[l]);
+        uint8_t* Dg = P + lev.pyr_off;
+        const int groups = (lev.w + 3) >> 2, ntask = (hi - lo) * groups, last_word = (pw - 1) >> 2;
+        const float inv = 1.0f / (float)groups;
+        for (int t = tid; t < ntask; t += PYR_THREADS) {
+            const int row = (int)(((float)t + 0.5f) * inv), g = t - __mul24(row, groups);
+            const short4 ye = yt[row];
+            const uint4 e = xt[2 * g];
+            const uint2 e2 = reinterpret_cast<const uint2*>(xt + 2 * g + 1)[0];
+            uint32_t packed;
+            if (l > 1)
+                packed = pyr_group<PYR_SRC_LDS>(S + __mul24(ye.x - src_lo, sp), S + __mul24(ye.y - src_lo, sp), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
+            else if (words0)
+                packed = pyr_group<PYR_SRC_GLOBAL_WORDS>(I0 + (size_t)ye.x * img0_pitch, I0 + (size_t)ye.y * img0_pitch, e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
+            else
+                packed = pyr_group<PYR_SRC_GLOBAL_BYTES>(I0 + (size_t)ye.x * img0_pitch, I0 + (size_t)ye.y * img0_pitch, e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
+            Dl[__mul24(row, dpw) + g] = packed;
+            const int dy = lo + row;
+            if (dy >= own_lo && dy < own_hi) *reinterpret_cast<uint32_t*>(Dg + (size_t)dy * lev.pitch + 4 * g) = packed;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ blur
 // Fixed-point separable 7x7, taps {18,34,48,56,48,34,18}/256, out = (sum + 32768) >> 16, reflect-101.
 // Streaming form, no LDS: a thread owns 4 adjacent columns and walks BLUR_ROWS rows downwards, keeping the last
@@ -212,8 +343,6 @@ __device__ __forceinline__ BlurRow blur_load(const uint8_t* __restrict__ row, in
     }
     return r;
 }
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 // Horizontal 7-tap sums of the 4 owned columns for TWO image rows at once: pixel k of row a and of row b travel as the
 // two 16-bit halves of one register (v_perm_b32 gathers them), so every packed multiply-add serves both rows.
 // 256 * 255 = 65280 fits 16 bits exactly.
@@ -796,9 +925,17 @@ void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride
                        dh, xofs, xa, yofs, yb);
 }
 
+hipError_t sv_pyramid_prepare() {  // once per device: allow the LDS-resident pyramid its large dynamic allocation
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SV_PYR_LDS_MAX);
+}
 void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, const int2* band_rows, int bands, const uint8_t* img0,
                        size_t img0_frame_stride, int img0_pitch, uint8_t* pyr, size_t pyr_frame_bytes, const short* xofs,
-                       const short2* xa, const short2* yofs, const short2* yb, int batch) {
+                       const short2* xa, const short2* yofs, const short2* yb, const uint32_t* xg, const short4* yrow, int batch, size_t lds_bytes) {
+    if (lds_bytes > 0) {
+        hipLaunchKernelGGL(k_pyramid_lds, dim3(bands, batch), dim3(PYR_THREADS), lds_bytes, s, levels, num_levels, band_rows, bands, img0,
+                           img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, xg, yrow);
+        return;
+    }
     hipLaunchKernelGGL(k_pyramid, dim3(bands, batch), dim3(PYR_THREADS), 0, s, levels, num_levels, band_rows, img0, img0_frame_stride,
                        img0_pitch, pyr, pyr_frame_bytes, xofs, xa, yofs, yb);
 }

@@ -24,6 +24,7 @@ struct OrbLevel {
     long long pyr_off;      // byte offset of this level inside one frame's pyramid block (levels >= 1)
     long long blur_off;     // byte offset inside one frame's blurred block (all levels)
     int xtab_off, ytab_off; // resize coefficient tables (level produced from level-1)
+    int xg_off;             // first 32-byte column-group record of this level in the packed table of k_pyramid_lds
     int cell_first, cell_count;     // FAST cells of this level in the cell table
     int cells_x;                    // num_cols of the FAST cell lattice (orb_extractor.cc:186)
     int grid_x, grid_y, grid_first; // selection grid (distribute_keypoints) and its offset in the key array
@@ -76,8 +77,11 @@ struct svgpu_ctx {
     short2* d_xa = nullptr;         // (a0, a1) 11-bit coefficients
     short2* d_yofs = nullptr;       // (row0, row1) clamped
     short2* d_yb = nullptr;         // (b0, b1)
+    uint32_t* d_xg = nullptr;       // k_pyramid_lds: 8 words per group of 4 output columns (see build in svgpu_orb.hip)
+    short4* d_yrow = nullptr;       // k_pyramid_lds: (row0, row1, b0, b1) per output row
     int2* d_band_rows = nullptr;    // [bands][levels]: rows of each level a pyramid band computes
     int pyr_bands = 0;
+    size_t pyr_lds_bytes = 0;       // dynamic LDS of k_pyramid_lds for this configuration; 0 = use the global-memory variant
     unsigned short* d_gtab = nullptr;
     uint8_t* d_pyr = nullptr;       // max_batch * pyr_frame_bytes
     uint8_t* d_blur = nullptr;      // max_batch * blur_frame_bytes
@@ -124,10 +128,14 @@ void sv_orb_release(svgpu_ctx* ctx);
 // ---- kernel launchers (orb_kernels.hip)
 void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride, int src_pitch, int sw, int sh,
                       uint8_t* dst, size_t dst_frame_stride, int dst_pitch, int dw, int dh, const short* xofs,
-                      const short2* xa, const short2* yofs, const short2* yb, int batch);
+                      const short2* xa, const short2* yofs, const short2* yb, const uint32_t* xg, const short4* yrow, int batch, size_t lds_bytes);
+#define SV_PYR_LDS_MAX (156 * 1024)  // dynamic LDS budget of k_pyramid_lds (160 KB per CU minus its static tables)
+hipError_t sv_pyramid_prepare();
 void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, const int2* band_rows, int bands, const uint8_t* img0,
                        size_t img0_frame_stride, int img0_pitch, uint8_t* pyr, size_t pyr_frame_bytes, const short* xofs,
-                       const short2* xa, const short2* yofs, const short2* yb, int batch);
+                       const short2* xa, const short2* yofs, const short2* yb, const uint32_t* xg, const short4* yrow, int batch, size_t lds_bytes);
+#define SV_PYR_LDS_MAX (156 * 1024)  // dynamic LDS budget of k_pyramid_lds (160 KB per CU minus its static tables)
+hipError_t sv_pyramid_prepare();
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
                     size_t blur_frame_bytes, int batch, bool need_gather);

@@ -7,6 +7,7 @@
 //   selection grid                 feature/orb_extractor.cc:292-305
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "svgpu_internal.h"
 
@@ -49,6 +50,8 @@ void sv_orb_release(svgpu_ctx* ctx) {
     free_dev(ctx->d_xa);
     free_dev(ctx->d_yofs);
     free_dev(ctx->d_yb);
+    free_dev(ctx->d_xg);
+    free_dev(ctx->d_yrow);
     free_dev(ctx->d_band_rows);
     free_dev(ctx->d_gtab);
     free_dev(ctx->d_pyr);
@@ -107,6 +110,9 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     std::vector<short> xofs;
     std::vector<short2> xa, yofs, yb;
     std::vector<unsigned short> gtab;
+    std::vector<uint32_t> xg;   // packed column-group records of k_pyramid_lds
+    std::vector<short4> yrow;
+    bool xg_ok = true;          // false: a level shrinks by more than 3x, the byte windows of the records do not fit
     size_t pyr_off = 0, blur_off = 0;
     int grid_first = 0, btile_first = 0;
     for (int l = 0; l < num_levels; ++l) {
@@ -166,6 +172,32 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
                 bb.y = (short)cv_round_f(fy * 2048);
                 yofs.push_back(o);
                 yb.push_back(bb);
+            }
+            // ---- packed records for k_pyramid_lds.  One record per 4 output columns c..c+3 (columns past w-1 repeat w-1):
+            //      w0 = dword index of sx[c] | dword index of sx[c+2] << 16 (two 8-byte windows per source row),
+            //      w1 = byte index inside its window of sx[c], sx[c+1] (window 0), sx[c+2], sx[c+3] (window 1),
+            //      w2..w5 = (a0 | a1 << 16) of the four columns.  sx+1 is always the next byte (its weight is 0 when clamped).
+            L.xg_off = (int)(xg.size() / 8);
+            for (int c = 0; c < L.w; c += 4) {
+                int sxs[4];
+                for (int i = 0; i < 4; ++i) sxs[i] = xofs[L.xtab_off + std::min(c + i, L.w - 1)];
+                const int base0 = sxs[0] >> 2, base2 = sxs[2] >> 2;
+                const int k[4] = {sxs[0] - 4 * base0, sxs[1] - 4 * base0, sxs[2] - 4 * base2, sxs[3] - 4 * base2};
+                for (int i = 0; i < 4; ++i) xg_ok = xg_ok && k[i] >= 0 && k[i] <= 6;
+                xg.push_back((uint32_t)base0 | ((uint32_t)base2 << 16));
+                xg.push_back((uint32_t)(k[0] & 255) | ((uint32_t)(k[1] & 255) << 8) | ((uint32_t)(k[2] & 255) << 16) | ((uint32_t)(k[3] & 255) << 24));
+                for (int i = 0; i < 4; ++i) {
+                    const short2 a = xa[L.xtab_off + std::min(c + i, L.w - 1)];
+                    xg_ok = xg_ok && a.x >= 0 && a.y >= 0;
+                    xg.push_back((uint32_t)(unsigned short)a.x | ((uint32_t)(unsigned short)a.y << 16));
+                }
+                xg.push_back(0);
+                xg.push_back(0);
+            }
+            for (int dy = 0; dy < L.h; ++dy) {
+                const short2 o = yofs[L.ytab_off + dy], c = yb[L.ytab_off + dy];
+                xg_ok = xg_ok && c.x >= 0 && c.y >= 0;
+                yrow.push_back(make_short4(o.x, o.y, c.x, c.y));
             }
         }
         // ---- blur tiles
@@ -232,36 +264,63 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     C.blur_frame_bytes = blur_off;
 
     // ---- pyramid bands: band k owns rows [k*h/K, (k+1)*h/K) of every level; bottom-up it also needs the source rows
-    //      of everything it computes at the next level (two taps per output row, clamped -- the yofs table)
-    const int bands = 16;
-    std::vector<int2> band_rows((size_t)bands * num_levels);
-    for (int k = 0; k < bands; ++k) {
-        int need_lo = 0, need_hi = 0;
-        for (int l = num_levels - 1; l >= 1; --l) {
-            const OrbLevel& Lv = C.levels[l];
-            int lo = (int)((long long)k * Lv.h / bands), hi = (int)((long long)(k + 1) * Lv.h / bands);
-            if (l < num_levels - 1 && need_hi > need_lo) {
-                lo = std::min(lo, need_lo);
-                hi = std::max(hi, need_hi);
+    //      of everything it computes at the next level (two taps per output row, clamped -- the yofs table).
+    //      K is the smallest count (>= 16) whose per-band LDS footprint fits k_pyramid_lds; none fits -> global variant.
+    auto make_bands = [&](int bands, std::vector<int2>& band_rows) -> size_t {
+        band_rows.assign((size_t)bands * num_levels, int2{0, 0});
+        size_t worst = 0;
+        for (int k = 0; k < bands; ++k) {
+            int need_lo = 0, need_hi = 0;
+            for (int l = num_levels - 1; l >= 1; --l) {
+                const OrbLevel& Lv = C.levels[l];
+                int lo = (int)((long long)k * Lv.h / bands), hi = (int)((long long)(k + 1) * Lv.h / bands);
+                if (l < num_levels - 1 && need_hi > need_lo) {
+                    lo = std::min(lo, need_lo);
+                    hi = std::max(hi, need_hi);
+                }
+                band_rows[(size_t)k * num_levels + l] = int2{lo, hi};
+                // rows of level l-1 read by rows [lo, hi) of level l
+                need_lo = 1 << 30;
+                need_hi = 0;
+                for (int dy = lo; dy < hi; ++dy) {
+                    const short2 o = yofs[Lv.ytab_off + dy];
+                    need_lo = std::min(need_lo, (int)o.x);
+                    need_hi = std::max(need_hi, (int)o.y + 1);
+                }
             }
-            int2 r;
-            r.x = lo;
-            r.y = hi;
-            band_rows[(size_t)k * num_levels + l] = r;
-            // rows of level l-1 read by rows [lo, hi) of level l
-            need_lo = 1 << 30;
-            need_hi = 0;
-            for (int dy = lo; dy < hi; ++dy) {
-                const short2 o = yofs[Lv.ytab_off + dy];
-                need_lo = std::min(need_lo, (int)o.x);
-                need_hi = std::max(need_hi, (int)o.y + 1);
+            if (need_hi > need_lo) band_rows[(size_t)k * num_levels] = int2{need_lo, need_hi};  // level-0 rows the band reads
+            size_t bytes = 0;  // must mirror the LDS map of k_pyramid_lds
+            for (int l = 1; l < num_levels; ++l) {
+                const int2 r = band_rows[(size_t)k * num_levels + l];
+                bytes += (size_t)(r.y - r.x) * (size_t)((C.levels[l].w + 3) & ~3);
             }
+            bytes = (bytes + 15) & ~(size_t)15;
+            for (int l = 1; l < num_levels; ++l) {
+                const int2 r = band_rows[(size_t)k * num_levels + l];
+                bytes += (size_t)((C.levels[l].w + 3) / 4) * 32 + (size_t)(r.y - r.x) * 8;
+            }
+            worst = std::max(worst, bytes);
         }
-        int2 z;
-        z.x = z.y = 0;
-        band_rows[(size_t)k * num_levels] = z;
+        return worst;
+    };
+    std::vector<int2> band_rows;
+    // few, tall bands recompute the fewest halo rows; small batches need more bands to fill the 256 CUs
+    int bands = std::max(8, std::min(32, (512 + max_batch - 1) / std::max(max_batch, 1)));
+    if (const char* e = getenv("SVGPU_PYR_BANDS")) bands = std::max(1, atoi(e));
+    size_t lds = 0;
+    for (;; bands += 2) {
+        lds = make_bands(bands, band_rows);
+        if (lds <= SV_PYR_LDS_MAX && xg_ok) break;
+        if (bands >= 256 || !xg_ok) {  // very wide images: chain the levels through global memory instead (k_pyramid)
+            bands = 16;
+            make_bands(bands, band_rows);
+            lds = 0;
+            break;
+        }
     }
     ctx->pyr_bands = bands;
+    ctx->pyr_lds_bytes = lds;
+    if (lds) SV_HIP(ctx, sv_pyramid_prepare());
     {
         int rcb;
         if ((rcb = upload(ctx, &ctx->d_band_rows, band_rows))) return rcb;
@@ -274,6 +333,8 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     if ((rc = upload(ctx, &ctx->d_xa, xa))) return rc;
     if ((rc = upload(ctx, &ctx->d_yofs, yofs))) return rc;
     if ((rc = upload(ctx, &ctx->d_yb, yb))) return rc;
+    if ((rc = upload(ctx, &ctx->d_xg, xg))) return rc;
+    if ((rc = upload(ctx, &ctx->d_yrow, yrow))) return rc;
     if ((rc = upload(ctx, &ctx->d_gtab, gtab))) return rc;
     const size_t B = (size_t)max_batch, G = (size_t)(C.total_grid > 0 ? C.total_grid : 1);
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, B * C.pyr_frame_bytes + 256));
@@ -318,7 +379,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     if (Lc > 1) {
         SvProfScope ps(ctx, s, "k_resize");
         sv_launch_pyramid(s, ctx->d_levels, Lc, ctx->d_band_rows, ctx->pyr_bands, imgs_dev, frame_stride, row_stride, ctx->d_pyr,
-                          C.pyr_frame_bytes, ctx->d_xofs, ctx->d_xa, ctx->d_yofs, ctx->d_yb, batch);
+                          C.pyr_frame_bytes, ctx->d_xofs, ctx->d_xa, ctx->d_yofs, ctx->d_yb, ctx->d_xg, ctx->d_yrow, batch, ctx->pyr_lds_bytes);
     }
     // 2. blurred copy of every level
     {
