@@ -4,7 +4,8 @@
 
 #include "svgpu.h"
 
-#define BF_K 16  // per-query candidate prefix kept by k_bf_topk (candidates within dmax only; exact fallback when exhausted)
+#define BF_K 16     // per-query candidate prefix kept by k_bf_topk (candidates within dmax only; exact fallback when exhausted)
+#define BF_LIST 16  // row stride of the per-query candidate lists (>= BF_K and >= MF_SLOTS of k_bf_mfma)
 
 struct BfProblem {
     // side 1 = frame (scanned), side 2 = keyframe (queries); `pairs` independent problems, row p at p*cap
@@ -23,13 +24,14 @@ struct BfProblem {
     int check_orientation;
     unsigned dmax;        // candidates farther than this are never listed (see k_bf_topk)
     int exhaustive;       // 1 when dmax >= 256: the list is a plain prefix of all candidates
+    int list_k;           // entries a list row holds at most (BF_K from k_bf_topk, MF_SLOTS from k_bf_mfma), rows are sorted
     // angle-bin sorted copies (k_bf_binsort): descriptors, angles, original indices, bin starts (362 per pair and side)
     uint32_t *sd1, *sd2;
     float *sa1, *sa2;
     int *si1, *si2;
     int *bs1, *bs2;
     int* prune_ok;        // pairs * 2: every angle of the side lies in [0, 360]
-    uint32_t* topk;       // pairs * cap2 * BF_K
+    uint32_t* topk;       // pairs * cap2 * BF_LIST
     int32_t* cnt;         // pairs * cap2
     int32_t* matched;     // pairs * cap1
     int32_t* num;         // pairs

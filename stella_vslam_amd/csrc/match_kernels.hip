@@ -13,6 +13,8 @@
 // converges in a handful of sweeps.  For brute force the candidates of a query are its K smallest
 // (distance, index) pairs; the rare case where that prefix cannot decide falls back to a full scan.
 #include "svgpu_internal.h"
+#include <algorithm>
+#include <cstdlib>
 #include "match_kernels.h"
 
 namespace {
@@ -252,22 +254,340 @@ __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
         }
     }
     if (r < n2c) {
-        uint32_t* T = P.topk + ((size_t)pair * P.cap2 + j) * BF_K;
+        uint32_t* T = P.topk + ((size_t)pair * P.cap2 + j) * BF_LIST;
 #pragma unroll
         for (int k = 0; k < BF_K; k += 4) *reinterpret_cast<uint4*>(T + k) = make_uint4(L[k], L[k + 1], L[k + 2], L[k + 3]);
         P.cnt[(size_t)pair * P.cap2 + j] = active ? cnt : 0;
     }
 }
 
-// decision of one query given the owner table; returns idx_1 or -1
-__device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uint32_t* __restrict__ T, int cnt,
-                         const int* owner) {
+// ------------------------------------------------------------------------------------------------ brute force on the matrix cores
+// All-pairs Hamming distance IS a matrix product: with both descriptors mapped bit -> {+1, -1} (int8),
+//     sum_k q'_k t'_k = 256 - 2 hamming(q, t),
+// so v_mfma_i32_32x32x32_i8 produces 1024 exact distances per 8 instructions (~0.3 cycles per distance and SIMD,
+// against ~1.2 for v_xor / v_bcnt_u32_b32) and "distance <= dmax" is one uniform threshold on the accumulator.
+// Both sides arrive angle-bin sorted (k_bf_binsort), so a block of 256 consecutive queries only visits the targets
+// within 31 bins of its own bins, and each of its four waves (64 queries: two 32-row A tiles expanded to int8 once,
+// 64 registers) skips the tiles outside its own, narrower window.  Targets are fetched 256 at a time into LDS (one
+// global round trip per chunk) and expanded 32 at a time: 256 threads turn one dword each (8 nibbles -> 8 dwords of
+// +-1 bytes) into the layout [k-step][lane] x 16 B, so that a B fragment is one conflict-free ds_read_b128 and serves
+// both A tiles; sharing the expanded tile between the four waves keeps the operand traffic in LDS (a wave streaming
+// its own 8 KB per patch from L2 is bandwidth-bound).  Both operands use the same (k-step, lane half, byte) -> bit
+// map, which is all the MFMA needs (the dot product does not care how the hardware orders k inside the instruction).
+// Only distances <= dmax can influence a decision (see k_bf_topk); well under 1 % of the pairs qualify, about a dozen
+// per 64 x 32 patch.  Every accumulator register is tested against the threshold; the hit lanes append
+// (row, dist, original idx_1, target angle) to a per-wave queue with ballot ranks (no atomics, no LDS reads on the
+// way).  When the queue fills, the wave drains it with all lanes busy: exact orientation gate, then a slot in the
+// query's row (rows are private to the wave); a full row keeps its MF_SLOTS smallest keys (wave-cooperative
+// replace-the-maximum, rare).  Rows are sorted and written out once per block, so k_bf_replay gets exactly what
+// k_bf_topk would give it: the nearest candidates in scan-preference order plus the count of all candidates.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define MF_QW 64       // queries per wave
+#define MF_QB 256      // queries per block (4 waves)
+#define MF_TT 32       // targets per MFMA tile
+#define MF_CH 256      // targets per fetched chunk
+#define MF_SLOTS 16    // list slots per query (= P.list_k of this path)
+#define MF_WQ 128      // per-wave hit queue entries; drained when fewer than 64 are free
+__device__ __forceinline__ uint32_t mf_expand_pm1(uint32_t nibble) {  // bit b -> byte b = +1 (bit clear) / -1 (bit set)
+    uint32_t m = (nibble * 0x00204081u) & 0x01010101u;  // byte b = bit b
+    m |= m << 1;                                         // smear every set byte to 0xFF with three full-rate shift-ors;
+    asm("" : "+v"(m));                                   // the empty asm keeps the compiler from folding them back into
+    m |= m << 2;                                         // m * 255, a quarter-rate 32-bit multiply
+    asm("" : "+v"(m));
+    m |= m << 4;
+    return m | 0x01010101u;
+}
+// candidate window (in angle-sorted target positions) of the sorted queries [r_lo, r_hi]: up to two runs
+__device__ __forceinline__ void mf_window(const float* __restrict__ A2s, const int* __restrict__ BS1, int r_lo, int r_hi, int n1c,
+                                          bool prune, int (&lo)[2], int (&hi)[2]) {
+    lo[0] = 0;
+    hi[0] = n1c;
+    lo[1] = hi[1] = 0;
+    if (!prune) return;
+    const int b_lo = min((int)A2s[r_lo], BF_BINS - 1) - 31, b_hi = min((int)A2s[r_hi], BF_BINS - 1) + 31;
+    if (b_hi - b_lo + 1 >= BF_BINS) return;
+    if (b_lo < 0) {
+        lo[0] = BS1[b_lo + BF_BINS];
+        hi[0] = n1c;
+        lo[1] = 0;
+        hi[1] = BS1[b_hi + 1];
+    }
+    else if (b_hi >= BF_BINS) {
+        lo[0] = BS1[b_lo];
+        hi[0] = n1c;
+        lo[1] = 0;
+        hi[1] = BS1[b_hi - BF_BINS + 1];
+    }
+    else {
+        lo[0] = BS1[b_lo];
+        hi[0] = BS1[b_hi + 1];
+    }
+}
+struct MfShared {
+    uint32_t raw[8][MF_CH];          // fetched chunk, dword-transposed: raw[k-step][target]
+    float rang[MF_CH];               // target angles / original indices of the chunk
+    int ridx[MF_CH];
+    uint32_t b[2][MF_TT * 64];       // expanded tile: [buffer][k-step 8][lane 64][4 dwords]
+    uint32_t list[MF_QB][MF_SLOTS];
+    int cnt[MF_QB];
+    uint32_t rowmax[MF_QB];          // largest key of a FULL row once it has been scanned (else all-ones): cheap reject of far candidates
+    float qa[MF_QB];                 // query angle, or -1000 for rows that must never match (past n2, !valid2)
+    uint2 wq[4][MF_WQ];              // (row << 24 | dist << 16 | idx_1, target angle bits)
+};
+// Drain the wave's hit queue into its rows.  Called by all 64 lanes of the wave.
+__device__ __forceinline__ void mf_drain(MfShared& S, int wave, int lane, int n, bool ori) {
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        bool live = e < n;
+        uint32_t key = 0;
+        int ql = 0, slot = 0;
+        if (live) {
+            const uint2 ent = S.wq[wave][e];
+            ql = (int)(ent.x >> 24) + wave * MF_QW;
+            key = ent.x & 0x00FFFFFFu;
+            const float qa = S.qa[ql];
+            live = qa > -500.f;
+            if (ori) live = live && !(fabsf(angle_diff(__uint_as_float(ent.y), qa)) > 30.0f);
+            if (live) slot = atomicAdd(&S.cnt[ql], 1);  // several lanes may hold hits of the same row
+            if (live && slot < MF_SLOTS) S.list[ql][slot] = key;
+        }
+        // rare in general, common for queries with dozens of near-identical candidates: the row is full -> keep its MF_SLOTS
+        // smallest keys.  Keys not below the row's current maximum are dropped right away (counted, not listed).
+        unsigned long long ov = __ballot(live && slot >= MF_SLOTS && key < S.rowmax[ql]);
+        while (ov) {
+            const int src = __ffsll((long long)ov) - 1;
+            ov &= ov - 1;
+            const uint32_t k = __shfl(key, src, 64);
+            const int row = __shfl(ql, src, 64);
+            uint32_t* R = S.list[row];
+            if (k >= S.rowmax[row]) continue;  // an earlier entry of this batch lowered the maximum
+            uint32_t v = lane < MF_SLOTS ? R[lane] : 0u;
+            int arg = lane;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const uint32_t ovv = __shfl_xor(v, off, 64);
+                const int oa = __shfl_xor(arg, off, 64);
+                if (ovv > v || (ovv == v && oa < arg)) {
+                    v = ovv;
+                    arg = oa;
+                }
+            }
+            v = __shfl(v, 0, 64);
+            arg = __shfl(arg, 0, 64);
+            // replace the maximum, then the new maximum of the row = max(k, largest of the other slots)
+            uint32_t w = (lane < MF_SLOTS && lane != arg) ? R[lane] : 0u;
+            if (k < v) {
+                if (lane == 0) R[arg] = k;
+                w = lane == arg ? k : w;
+            }
+            else w = lane == arg ? v : w;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) w = max(w, (uint32_t)__shfl_xor(w, off, 64));
+            if (lane == 0) S.rowmax[row] = w;
+        }
+    }
+}
+__global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
+    __shared__ __attribute__((aligned(16))) MfShared S;
+    const int pair = blockIdx.y;
+    const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
+    const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
+    const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qb = blockIdx.x * MF_QB, q0 = qb + wave * MF_QW;
+    if (qb >= n2c) return;
+    const uint32_t* __restrict__ D1 = P.sd1 + (size_t)pair * P.cap1 * 8;
+    const float* __restrict__ A1 = P.sa1 + (size_t)pair * P.cap1;
+    const int* __restrict__ I1 = P.si1 + (size_t)pair * P.cap1;
+    const uint32_t* __restrict__ D2 = P.sd2 + (size_t)pair * P.cap2 * 8;
+    const float* __restrict__ A2 = P.sa2 + (size_t)pair * P.cap2;
+    const int* __restrict__ I2 = P.si2 + (size_t)pair * P.cap2;
+    const int* __restrict__ BS1 = P.bs1 + (size_t)pair * (BF_BINS + 2);
+    const bool ori = P.check_orientation != 0;
+    const bool prune = ori && P.prune_ok[pair * 2] && P.prune_ok[pair * 2 + 1];
+    S.cnt[tid] = 0;
+    S.rowmax[tid] = 0xFFFFFFFFu;
+    int my_j = 0;  // original idx_2 of this thread's query row (flush)
+    {
+        const int q = qb + tid;
+        bool live = q < n2c;
+        if (live) {
+            my_j = I2[q];
+            live = !P.valid2 || P.valid2[(size_t)pair * P.cap2 + my_j];
+        }
+        S.qa[tid] = live ? A2[q] : -1000.f;
+    }
+    // ---- A fragments: rows = sorted queries q0 + 32a + (lane & 31), k-step s, lane half h -> bits [32s + 16h, +16)
+    const int h = lane >> 5;
+    v4i A[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int q = min(q0 + 32 * a + (lane & 31), n2c - 1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint32_t half = (D2[(size_t)q * 8 + s] >> (16 * h)) & 0xFFFFu;
+            A[a][s] = v4i{(int)mf_expand_pm1(half & 15u), (int)mf_expand_pm1((half >> 4) & 15u), (int)mf_expand_pm1((half >> 8) & 15u),
+                          (int)mf_expand_pm1(half >> 12)};
+        }
+    }
+    // ---- candidate windows: the block's (targets to stage) and this wave's (tiles to multiply)
+    int blo[2], bhi[2], wlo[2], whi[2];
+    mf_window(A2, BS1, qb, min(qb + MF_QB, n2c) - 1, n1c, prune, blo, bhi);
+    const bool wave_live = q0 < n2c;
+    mf_window(A2, BS1, min(q0, n2c - 1), min(q0 + MF_QW, n2c) - 1, n1c, prune, wlo, whi);
+    const int lt = tid & 31, lw = tid >> 5;  // expansion role: target lt of the tile, descriptor dword lw (= k-step)
+    auto expand = [&](int buf, int tile, int valid) {  // tile of the chunk in S.raw -> S.b[buf]; columns >= valid stay zero (never a hit)
+        uint4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+        if (lt < valid) {
+            const uint32_t w = S.raw[lw][tile * MF_TT + lt];
+            lo.x = mf_expand_pm1(w & 15u);
+            lo.y = mf_expand_pm1((w >> 4) & 15u);
+            lo.z = mf_expand_pm1((w >> 8) & 15u);
+            lo.w = mf_expand_pm1((w >> 12) & 15u);
+            hi.x = mf_expand_pm1((w >> 16) & 15u);
+            hi.y = mf_expand_pm1((w >> 20) & 15u);
+            hi.z = mf_expand_pm1((w >> 24) & 15u);
+            hi.w = mf_expand_pm1(w >> 28);
+        }
+        uint4* B = reinterpret_cast<uint4*>(S.b[buf]) + lw * 64;
+        B[lt] = lo;        // lane half 0: bits [32 lw, +16)
+        B[32 + lt] = hi;   // lane half 1: bits [32 lw + 16, +16)
+    };
+    const int thr = 256 - 2 * (int)P.dmax;  // hit <=> 256 - 2 d >= thr; the launcher keeps dmax < 128, so zero columns never hit
+    int wq_n = 0;                           // entries in this wave's hit queue (wave-uniform)
+    for (int sg = 0; sg < 2; ++sg) {
+        const int lo = blo[sg], hi = bhi[sg];
+        for (int cbase = lo; cbase < hi; cbase += MF_CH) {
+            const int cn = min(MF_CH, hi - cbase), ntiles = (cn + MF_TT - 1) / MF_TT;
+            __syncthreads();  // every wave is done with the previous chunk
+            if (tid < cn) {   // one descriptor per thread: two 16-byte loads, scattered into the transposed layout
+                const uint4 d0 = *reinterpret_cast<const uint4*>(D1 + (size_t)(cbase + tid) * 8);
+                const uint4 d1 = *reinterpret_cast<const uint4*>(D1 + (size_t)(cbase + tid) * 8 + 4);
+                S.rang[tid] = A1[cbase + tid];
+                S.ridx[tid] = I1[cbase + tid];
+                S.raw[0][tid] = d0.x;
+                S.raw[1][tid] = d0.y;
+                S.raw[2][tid] = d0.z;
+                S.raw[3][tid] = d0.w;
+                S.raw[4][tid] = d1.x;
+                S.raw[5][tid] = d1.y;
+                S.raw[6][tid] = d1.z;
+                S.raw[7][tid] = d1.w;
+            }
+            __syncthreads();
+            expand(0, 0, min(MF_TT, cn));
+            __syncthreads();
+            for (int t = 0, buf = 0; t < ntiles; ++t, buf ^= 1) {
+                if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
+                const int base = cbase + t * MF_TT, tend = min(base + MF_TT, hi);
+                const bool mine = wave_live && ((base < whi[0] && tend > wlo[0]) || (base < whi[1] && tend > wlo[1]));
+                if (mine) {
+                    const v4i* Bf = reinterpret_cast<const v4i*>(S.b[buf]) + lane;
+                    v16i acc[2] = {};
+                    v4i b = Bf[0];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const v4i bn = Bf[(s < 7 ? s + 1 : 7) * 64];  // next fragment is in flight while the two MFMAs of this one issue
+                        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc[1], 0, 0, 0);
+                        b = bn;
+                    }
+                    const int col = t * MF_TT + (lane & 31);
+                    const uint32_t ta = __float_as_uint(S.rang[col]);
+                    const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24) | (256u << 15);
+                    // Append the hits of the patch to the wave's queue.  One round unless the patch alone holds more hits than
+                    // the queue has room for (adversarial inputs): then the queue is drained and the walk repeated for the rest.
+                    for (int off = 0;;) {
+                        const int cap = MF_WQ - wq_n;
+                        int run = 0;
+#pragma unroll
+                        for (int r = 0; r < 32; ++r) {
+                            const int dot = acc[r >> 4][r & 15];
+                            const bool hit = dot >= thr;
+                            const unsigned long long m = __ballot(hit);
+                            if (m) {  // wave-uniform skip for the registers without a hit
+                                if (hit) {
+                                    int dd = dot;
+                                    asm volatile("" : "+v"(dd));  // keeps the key arithmetic of all 32 registers from being hoisted above the skips
+                                    const int pq = run - off + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                                    // row inside the wave: 32 (r >> 4) + (r & 3) + 8 ((r & 15) >> 2) + 4 h (C/D map of the 32x32 shapes);
+                                    // dist << 16 = (256 - dot) << 15 (dot is even), 256 << 15 is folded into ti
+                                    const uint32_t row = (uint32_t)(32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2)) << 24;
+                                    if ((unsigned)pq < (unsigned)cap) S.wq[wave][wq_n + pq] = make_uint2(ti + row - ((uint32_t)dd << 15), ta);
+                                }
+                                run += __popcll(m);
+                            }
+                        }
+                        const int rem = __builtin_amdgcn_readfirstlane(run) - off;  // hits of the patch not stored before this round
+                        if (rem <= cap) {
+                            wq_n += rem;
+                            break;
+                        }
+                        mf_drain(S, wave, lane, MF_WQ, ori);
+                        wq_n = 0;
+                        off += cap;
+                    }
+                    if (wq_n > MF_WQ - 64) {  // typical patches add a dozen hits: keep room for the next one
+                        mf_drain(S, wave, lane, wq_n, ori);
+                        wq_n = 0;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    mf_drain(S, wave, lane, wq_n, ori);
+    __syncthreads();
+    // ---- flush: one thread per query: sort the row (ascending (dist, idx_1) = the reference's scan preference) in registers
+    //      with a 16-input bitonic network (a data-dependent insertion sort in LDS costs a full row ~250 dependent LDS
+    //      round trips, and the wave waits for its slowest lane), then four 16-byte stores.
+    if (qb + tid < n2c) {
+        const int cnt = S.cnt[tid], c = min(cnt, MF_SLOTS);
+        uint32_t v[MF_SLOTS];
+        const uint4* R = reinterpret_cast<const uint4*>(S.list[tid]);
+#pragma unroll
+        for (int i = 0; i < MF_SLOTS / 4; ++i) {
+            const uint4 x = R[i];
+            v[4 * i] = x.x;
+            v[4 * i + 1] = x.y;
+            v[4 * i + 2] = x.z;
+            v[4 * i + 3] = x.w;
+        }
+#pragma unroll
+        for (int i = 0; i < MF_SLOTS; ++i) v[i] = i < c ? v[i] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 2; k <= MF_SLOTS; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+                for (int i = 0; i < MF_SLOTS; ++i) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const uint32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+                        const bool up = (i & k) == 0;
+                        v[i] = up ? lo : hi;
+                        v[l] = up ? hi : lo;
+                    }
+                }
+        uint4* G = reinterpret_cast<uint4*>(P.topk + ((size_t)pair * P.cap2 + my_j) * BF_LIST);
+#pragma unroll
+        for (int i = 0; i < MF_SLOTS / 4; ++i) G[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        P.cnt[(size_t)pair * P.cap2 + my_j] = cnt;
+    }
+}
+
+// decision of one query given the owner table; returns idx_1 or -1.  `head` = the first four keys of the row (kept in
+// registers by the caller across sweeps: most rows hold one to three candidates), `tail` = keys 4.. of the row (the
+// caller's LDS copy, or the row in global memory).
+__device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uint4 head, const uint32_t* tail, int cnt, const int* owner) {
     if (cnt == 0) return -1;  // no candidate within dmax: best > dmax >= 50
-    const int m = min(cnt, BF_K);
-    const bool truncated = cnt > BF_K;
+    const int m = min(cnt, P.list_k);
+    const bool truncated = cnt > P.list_k;
+    auto key_at = [&](int k) -> uint32_t { return k == 0 ? head.x : k == 1 ? head.y : k == 2 ? head.z : k == 3 ? head.w : tail[k - 4]; };
     uint32_t a0 = 0xFFFFFFFFu, a1 = 0xFFFFFFFFu;
     for (int k = 0; k < m; ++k) {
-        const uint32_t key = T[k];  // sorted ascending; usually m <= 3
+        const uint32_t key = key_at(k);  // sorted ascending; usually m <= 3
         if (owner[key & 0xFFFFu] < j) continue;  // claimed by an earlier query (already_matched_indices_1)
         if (a0 == 0xFFFFFFFFu) a0 = key;
         else {
@@ -275,9 +595,9 @@ __device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uin
             break;
         }
     }
-    // The list holds the (at most BF_K) nearest of the candidates with dist <= dmax; if it is not truncated,
+    // The list holds the (at most list_k) nearest of the candidates with dist <= dmax; if it is not truncated,
     // every unlisted candidate is farther than dmax.
-    const unsigned d_beyond = truncated ? (T[m - 1] >> 16) : P.dmax + 1;  // lower bound on any unlisted distance
+    const unsigned d_beyond = truncated ? (key_at(m - 1) >> 16) : P.dmax + 1;  // lower bound on any unlisted distance
     if (a0 != 0xFFFFFFFFu) {
         const unsigned best = a0 >> 16;
         if (HAMMING_DIST_THR_LOW < best) return -1;
@@ -333,70 +653,144 @@ __device__ int bf_full_row(const BfProblem& P, int pair, int j, int n1c, const i
     return (int)(kb & 0xFFFFu);
 }
 
-// One workgroup per pair.  owner[n1] / match[n2] live in LDS when they fit, else in global scratch.
-__global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds) {
+// One workgroup per pair.  owner[n1] / match[n2] live in LDS when they fit, else in global scratch.  A thread owns the
+// queries j = tid + u * blockDim; count and first four keys of the rows of its first BF_RC queries stay in registers, the rest of long rows in an LDS pool
+// across the sweeps (enough for 4096 keypoints; further queries re-read their rows from global memory every sweep),
+// so a sweep is LDS traffic and a handful of barriers.
+#define BF_RC 4
+__global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds, int pool_rows) {
     extern __shared__ int s_mem[];
-    __shared__ int s_changed, s_nund;
+    __shared__ int s_changed, s_nund, s_any_und, s_pool_n;
     __shared__ int s_und[1024];  // one slot per thread of a stride: can never overflow
     __shared__ uint32_t s_best, s_second;
-    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int pair = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
     int* owner = use_lds ? s_mem : g_owner + (size_t)pair * P.cap1;
     int* match = use_lds ? s_mem + P.cap1 : g_match + (size_t)pair * P.cap2;
-    const uint32_t* T = P.topk + (size_t)pair * P.cap2 * BF_K;
+    uint32_t* pool = reinterpret_cast<uint32_t*>(s_mem + (use_lds ? ((P.cap1 + P.cap2 + 3) & ~3) : 0));  // pool_rows x (BF_LIST - 4) keys, 16-byte aligned
+    const uint32_t* T = P.topk + (size_t)pair * P.cap2 * BF_LIST;
     const int* C = P.cnt + (size_t)pair * P.cap2;
-    for (int i = tid; i < n1c; i += blockDim.x) owner[i] = 0x7FFFFFFF;
-    for (int j = tid; j < n2c; j += blockDim.x) match[j] = -2;  // "unknown": forces at least one full sweep
+    for (int i = tid; i < n1c; i += nthr) owner[i] = 0x7FFFFFFF;
+    for (int j = tid; j < n2c; j += nthr) match[j] = -2;  // "unknown": forces at least one full sweep
+    uint4 head[BF_RC];
+    int hcnt[BF_RC];
+    const uint32_t* tail[BF_RC];
+    if (tid == 0) s_pool_n = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BF_RC; ++u) {
+        const int j = u * nthr + tid;
+        hcnt[u] = 0;
+        head[u] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        tail[u] = nullptr;
+        if (j < n2c) {
+            const uint32_t* R = T + (size_t)j * BF_LIST;
+            hcnt[u] = C[j];
+            head[u] = *reinterpret_cast<const uint4*>(R);
+            tail[u] = R + 4;
+            if (hcnt[u] > 4 && pool_rows > 0) {  // long rows (groups of look-alike keypoints) are walked deep every sweep: keep them in LDS
+                const int slot = atomicAdd(&s_pool_n, 1);
+                if (slot < pool_rows) {
+                    uint32_t* D = pool + (size_t)slot * (BF_LIST - 4);
+#pragma unroll
+                    for (int i = 0; i < (BF_LIST - 4) / 4; ++i) reinterpret_cast<uint4*>(D)[i] = reinterpret_cast<const uint4*>(R + 4)[i];
+                    tail[u] = D;
+                }
+            }
+        }
+    }
     __syncthreads();
     for (int sweep = 0; sweep <= n2c; ++sweep) {
         if (tid == 0) {
             s_changed = 0;
+            s_any_und = 0;
             s_nund = 0;
         }
         __syncthreads();
-        int local_changed = 0;
         // decisions against the owner table of the previous sweep (decisions read `owner`, never `match`)
-        for (int j0 = 0; j0 < n2c; j0 += blockDim.x) {
-            const int j = j0 + tid;
-            int d = -1;
+        int dec[BF_RC];
+        bool und = false;
+#pragma unroll
+        for (int u = 0; u < BF_RC; ++u) {
+            const int j = u * nthr + tid;
+            dec[u] = -1;
             if (j < n2c) {
-                d = bf_decide(P, pair, j, n1c, T + (size_t)j * BF_K, C[j], owner);
-                if (d == -3) {  // rare: prefix exhausted
-                    s_und[atomicAdd(&s_nund, 1)] = j;
-                }
+                dec[u] = bf_decide(P, pair, j, n1c, head[u], tail[u], hcnt[u], owner);
+                und = und || dec[u] == -3;
             }
-            __syncthreads();
-            const int nund = s_nund;
-            for (int u = 0; u < nund; ++u) {
-                const int ju = s_und[u];
-                const int du = bf_full_row(P, pair, ju, n1c, owner, &s_best, &s_second);
-                if (ju == j) d = du;
+        }
+        if (und) s_any_und = 1;
+        bool changed = false;
+        for (int j = BF_RC * nthr + tid; j < n2c; j += nthr) {  // queries beyond the register-cached ones (more than 4096 keypoints)
+            int d = bf_decide(P, pair, j, n1c, *reinterpret_cast<const uint4*>(T + (size_t)j * BF_LIST), T + (size_t)j * BF_LIST + 4, C[j], owner);
+            if (d == -3) {  // resolved in the exact pass below; the previous decision old >= -2 is parked as -(old + 10) <= -8
+                s_any_und = 1;
+                match[j] = -(match[j] + 10);
             }
-            __syncthreads();
-            if (tid == 0) s_nund = 0;
-            if (j < n2c) {
-                if (d != match[j]) local_changed = 1;
+            else {
+                changed = changed || d != match[j];
                 match[j] = d;
             }
-            __syncthreads();
         }
-        if (local_changed) s_changed = 1;
+        __syncthreads();
+        if (s_any_und) {  // rare: some prefix was exhausted -> exact cooperative scans, one stride of queries at a time
+            for (int j0 = 0; j0 < n2c; j0 += nthr) {
+                const int j = j0 + tid, u = j0 / nthr;
+                bool need = false;
+                if (j < n2c) {
+                    if (u < BF_RC) need = (u == 0 ? dec[0] : u == 1 ? dec[1] : u == 2 ? dec[2] : dec[3]) == -3;
+                    else need = match[j] <= -8;
+                }
+                if (need) s_und[atomicAdd(&s_nund, 1)] = j;
+                __syncthreads();
+                const int nund = s_nund;
+                int mine = -3;
+                for (int k = 0; k < nund; ++k) {
+                    const int ju = s_und[k];
+                    const int du = bf_full_row(P, pair, ju, n1c, owner, &s_best, &s_second);
+                    if (ju == j) mine = du;
+                }
+                __syncthreads();
+                if (tid == 0) s_nund = 0;
+                if (need) {
+                    if (u < BF_RC) {
+#pragma unroll
+                        for (int v = 0; v < BF_RC; ++v)
+                            if (v == u) dec[v] = mine;
+                    }
+                    else {
+                        changed = changed || mine != -match[j] - 10;
+                        match[j] = mine;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BF_RC; ++u) {
+            const int j = u * nthr + tid;
+            if (j < n2c) {
+                changed = changed || dec[u] != match[j];
+                match[j] = dec[u];
+            }
+        }
+        if (changed) s_changed = 1;
         __syncthreads();
         if (!s_changed) break;
-        for (int i = tid; i < n1c; i += blockDim.x) owner[i] = 0x7FFFFFFF;
+        for (int i = tid; i < n1c; i += nthr) owner[i] = 0x7FFFFFFF;
         __syncthreads();
-        for (int j = tid; j < n2c; j += blockDim.x)
+        for (int j = tid; j < n2c; j += nthr)
             if (match[j] >= 0) atomicMin(&owner[match[j]], j);
         __syncthreads();
     }
     // write-out: matched_2_in_1[idx_1] = idx_2 (robust.cc:317-325), unique by construction
     int32_t* out = P.matched + (size_t)pair * P.cap1;
-    for (int i = tid; i < P.cap1; i += blockDim.x) out[i] = -1;
+    for (int i = tid; i < P.cap1; i += nthr) out[i] = -1;
     __syncthreads();
     int local = 0;
-    for (int j = tid; j < n2c; j += blockDim.x)
+    for (int j = tid; j < n2c; j += nthr)
         if (match[j] >= 0) {
             out[match[j]] = j;
             ++local;
@@ -646,15 +1040,34 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     else P.dmax = 256u;
     if (P.dmax < 50u) P.dmax = 50u;
     P.exhaustive = P.dmax >= 256u;
+    // Candidate lists.  Normal case: distances on the matrix cores (k_bf_mfma).  The VALU kernel (k_bf_topk, keeps the
+    // BF_K nearest per query) serves cutoffs of 128 and more, where all-zero padding columns could pass the MFMA
+    // threshold and the lists would be dense anyway (lowe_ratio < 0.4; dmax = 256 means every pair is a candidate).
+    static const bool force_valu = getenv("SVGPU_BF_VALU") != nullptr;
     {
         SvProfScope ps(ctx, s, "k_bf_topk");
         hipLaunchKernelGGL(k_bf_binsort, dim3(pairs, 2), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + BF_QB - 1) / BF_QB, pairs), dim3(256), 0, s, P);
+        if (P.dmax >= 128u || force_valu) {
+            P.list_k = BF_K;
+            hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + BF_QB - 1) / BF_QB, pairs), dim3(256), 0, s, P);
+        }
+        else {
+            P.list_k = MF_SLOTS;
+            hipLaunchKernelGGL(k_bf_mfma, dim3((P.cap2 + MF_QB - 1) / MF_QB, pairs), dim3(256), 0, s, P);
+        }
     }
     SvProfScope ps(ctx, s, "k_bf_replay");
-    const size_t lds = (size_t)(P.cap1 + P.cap2) * sizeof(int);
+    size_t lds = (size_t)((P.cap1 + P.cap2 + 3) & ~3) * sizeof(int);
     const int use_lds = lds <= 96 * 1024;
-    hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), use_lds ? lds : 0, s, P, g_owner, g_match, use_lds);
+    if (!use_lds) lds = 0;
+    const int pool_rows = (int)std::min<size_t>(1024, (128 * 1024 - lds) / ((BF_LIST - 4) * sizeof(uint32_t)));
+    lds += (size_t)pool_rows * (BF_LIST - 4) * sizeof(uint32_t);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
 }
 void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match) {
     SvProfScope ps(ctx, s, "k_cand");

@@ -93,7 +93,7 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
         || cap1 > 65535 || cap2 > 65535 || !matched_dev || !num_dev)
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce_batch_device: bad arguments");
     SV_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t need = pad((size_t)pairs * cap2 * BF_K * 4) + pad((size_t)pairs * cap2 * 4) + pad((size_t)pairs * cap1 * 4)
+    const size_t need = pad((size_t)pairs * cap2 * BF_LIST * 4) + pad((size_t)pairs * cap2 * 4) + pad((size_t)pairs * cap1 * 4)
                         + pad((size_t)pairs * cap2 * 4) + sort_bytes(pairs, cap1, cap2);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
@@ -112,7 +112,7 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
     P.valid2 = valid2_dev;
     P.lowe_ratio = lowe_ratio;
     P.check_orientation = check_orientation;
-    P.topk = A.take<uint32_t>((size_t)pairs * cap2 * BF_K);
+    P.topk = A.take<uint32_t>((size_t)pairs * cap2 * BF_LIST);
     P.cnt = A.take<int32_t>((size_t)pairs * cap2);
     int* g_owner = A.take<int>((size_t)pairs * cap1);
     int* g_match = A.take<int>((size_t)pairs * cap2);
@@ -137,7 +137,7 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce: null input");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = pad((size_t)n1 * 32) + pad((size_t)n2 * 32) + pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + pad(n2)
-                        + pad((size_t)n2 * BF_K * 4) + pad((size_t)n2 * 4) + 2 * pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + 256
+                        + pad((size_t)n2 * BF_LIST * 4) + pad((size_t)n2 * 4) + 2 * pad((size_t)n1 * 4) + pad((size_t)n2 * 4) + 256
                         + sort_bytes(1, n1, n2);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
@@ -148,7 +148,7 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
     float* a2 = A.take<float>(n2);
     uint8_t* v2 = A.take<uint8_t>(n2);
     BfProblem P{};
-    P.topk = A.take<uint32_t>((size_t)n2 * BF_K);
+    P.topk = A.take<uint32_t>((size_t)n2 * BF_LIST);
     P.cnt = A.take<int32_t>(n2);
     P.matched = A.take<int32_t>(n1);
     int* g_owner = A.take<int>(n1);
