@@ -145,8 +145,9 @@ def main() -> int:
     L.svgpu_profile_select(ctx.handle, None)
     k_ms = ms.value / max(n.value, 1)  # mean duration of one launch of the dominant kernel
     launches_per_step = max(n.value, 1) / args.steps
-    bytes_per_launch = alg[dominant] / launches_per_step
-    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+    bytes_per_launch = alg[dominant] / launches_per_step   # bytes, or integer operations for the MFMA-bound kernel
+    bound, unit, peak = ROOFS.get(dominant, ("hbm", "GB/s", 8000.0))
+    achieved = bytes_per_launch / (k_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
     # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes of this same command (FETCH_SIZE and
     # WRITE_SIZE in separate passes, tools/pmc_traffic.py -> profiles/*_traffic.json); null when no pass was recorded
     traffic = None
@@ -175,9 +176,10 @@ def main() -> int:
                                "offline), ORB extract + brute-force match vs previous frame",
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": round(n_kp, 1),
                    "matches_per_pair": round(n_match, 1), "parallelism": f"frames sharded x{world}, no collective"},
-        "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "mean_launch_ms": round(k_ms, 5),
+        "roofline": {"kernel": dominant, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                     "frac": round(achieved / peak, 5), "traffic": traffic,
+                     ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_ops_per_launch"): int(bytes_per_launch),
+                     "mean_launch_ms": round(k_ms, 5),
                      "per_kernel_ms_per_step": {k: round(v[0], 4) for k, v in per_kernel.items()}},
     }
 
@@ -196,16 +198,23 @@ def main() -> int:
     return 0
 
 
+# Roofline that bounds each kernel class.  Everything streams bytes (HBM, 8 TB/s) except the brute-force distance kernel,
+# which computes the reference's all-pairs 256-bit Hamming distances on the matrix cores: int8 MFMA, dense peak = 2 x the
+# 2.5 PFLOP/s bf16 figure of MI355X_MICROARCH.md (its measured 32x32x32 i8 rate is 4.4 POP/s).
+ROOFS = {"k_bf_topk": ("mfma", "TFLOP/s", 5000.0)}
+
+
 def algorithmic_bytes(level_px, n_kp, B):
-    """ALGORITHMIC bytes per step for each kernel class, for B frames."""
+    """ALGORITHMIC bytes (k_bf_topk: integer operations) per step for each kernel class, for B frames."""
     pyr = sum(level_px[:-1]) + sum(level_px[1:])          # read L0..L6, write L1..L7
     fast = sum(level_px)                                    # every level read once
     blur = 2 * sum(level_px)                                # read + write every level
     desc = n_kp * (749 + 512 + 32 + 28)                     # IC-angle patch + BRIEF samples + descriptor + record
     select = n_kp * 16 + 8 * 2463
-    bf = 2 * n_kp * 32 + n_kp * 4                           # compulsory: both descriptor sets + matches
+    bf_ops = 2 * 256 * n_kp * n_kp                          # all pairs x 256 bit positions x (multiply, add): the work of robust.cc:271-314
+    sort = 2 * 2 * n_kp * (32 + 4 + 4)                      # both sides: read + write descriptors, angles, indices
     return {"k_resize": pyr * B, "k_blur": blur * B, "k_fast": fast * B, "k_select": select * B, "k_describe": desc * B,
-            "k_bf_topk": bf * B, "k_bf_replay": (n_kp * 16 * 4 + n_kp * 8) * B}
+            "k_bf_binsort": sort * B, "k_bf_topk": bf_ops * B, "k_bf_replay": (n_kp * 16 * 4 + n_kp * 8) * B}
 
 
 def bench_local_ba(ctx):

@@ -1045,8 +1045,11 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     // threshold and the lists would be dense anyway (lowe_ratio < 0.4; dmax = 256 means every pair is a candidate).
     static const bool force_valu = getenv("SVGPU_BF_VALU") != nullptr;
     {
-        SvProfScope ps(ctx, s, "k_bf_topk");
+        SvProfScope ps(ctx, s, "k_bf_binsort");
         hipLaunchKernelGGL(k_bf_binsort, dim3(pairs, 2), dim3(256), 0, s, P);
+    }
+    {
+        SvProfScope ps(ctx, s, "k_bf_topk");
         if (P.dmax >= 128u || force_valu) {
             P.list_k = BF_K;
             hipLaunchKernelGGL(k_bf_topk, dim3((P.cap2 + BF_QB - 1) / BF_QB, pairs), dim3(256), 0, s, P);

@@ -42,6 +42,25 @@ __device__ __forceinline__ int reflect101(int p, int len) {  // cv::BORDER_REFLE
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
+// XCD-aware work mapping.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and every XCD has its own L2:
+// with the plain (x = work item, y = frame) grid each XCD touches every frame and the same image lines are fetched
+// from HBM up to eight times.  This remaps the linear id so that all workgroups of a frame run on one XCD (frame f ->
+// XCD f % 8); batches that are not a multiple of 8 keep the plain order for the remainder frames.
+__device__ __forceinline__ void xcd_frame_map(int per_frame, int batch, int& item, int& frame) {
+    const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const int full = (batch / 8) * 8, lim = full * per_frame;
+    if (lin < lim) {
+        const int xcd = lin & 7, idx = lin >> 3;
+        frame = (idx / per_frame) * 8 + xcd;
+        item = idx % per_frame;
+    }
+    else {
+        const int r = lin - lim;
+        frame = full + r / per_frame;
+        item = r % per_frame;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ resize
 // OpenCV 8-bit bilinear: horizontal int32 with 11-bit coefficients, vertical
 // ((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2.  Coefficient tables are built on the host.
@@ -430,9 +449,10 @@ __device__ __forceinline__ void blur_locate(const OrbLevel* __restrict__ L, int 
                                             size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
                                             size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes, OrbLevel& lev,
                                             int& tile, const uint8_t*& src, int& spitch, uint8_t*& dst) {
-    const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::btile_first, &tile);
+    int b, item;
+    xcd_frame_map(gridDim.x, gridDim.y, item, b);
+    const int lv = find_level(L, num_levels, item, &OrbLevel::btile_first, &tile);
     lev = L[lv];
-    const int b = blockIdx.y;
     if (lv == 0) {
         src = img0 + (size_t)b * img0_frame_stride;
         spitch = img0_pitch;
@@ -522,22 +542,24 @@ __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
     return max((int)best.x, (int)best.y);
 }
 
-#define FP 76  // LDS pitch of the ROI arrays: 3 skew bytes + 70 + padding to a multiple of 4
+#define FAST_KT 12  // selection-grid cells per dimension cached in LDS (a 70-px ROI spans at most ~10 at the coarsest level)
+#define FP 80  // LDS pitch of the ROI arrays: 3 skew bytes + 70, rounded up to whole 16-byte chunks
 __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells,
                                               const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
                                               const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                               const unsigned short* __restrict__ gtab, unsigned long long* __restrict__ keys,
                                               int total_grid, int ini_thr, int min_thr, const uint8_t* __restrict__ mask,
-                                              size_t mask_frame_stride, int mask_pitch, int mask_w, int mask_h, int dbg_stop) {
+                                              size_t mask_frame_stride, int mask_pitch, int mask_w, int mask_h) {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[SV_ROI_MAX * FP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_a[SV_ROI_MAX * FP];
     __shared__ unsigned short s_q[SV_CELL * SV_CELL];
+    __shared__ unsigned long long s_key[FAST_KT * FAST_KT];  // per-block arg-max of the selection-grid cells the ROI touches
     __shared__ int s_count, s_qn;
-    int local;
-    const int lv = find_level(L, num_levels, blockIdx.x, &OrbLevel::cell_first, &local);
+    int local, b, ci;
+    xcd_frame_map(gridDim.x, gridDim.y, ci, b);
+    const int lv = find_level(L, num_levels, ci, &OrbLevel::cell_first, &local);
     const OrbLevel lev = L[lv];
-    const FastCell cell = cells[blockIdx.x];
-    const int b = blockIdx.y;
+    const FastCell cell = cells[ci];
     const int tid = threadIdx.x;
     const uint8_t* M = mask ? mask + (size_t)b * mask_frame_stride : nullptr;
     auto masked = [&](int y, int x) -> bool {  // is_in_mask (orb_extractor.cc:168-170): (int)(y * scale), (int)(x * scale)
@@ -565,8 +587,19 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     // cover it (the 3 leading bytes are real pixels of the border band) and address the LDS copy with a +3 skew.
     const uint8_t* rsrc = src + (size_t)cell.min_y * spitch + (cell.min_x - 3);
     uint8_t* const s_img = s_raw + 3;
-    if (((((size_t)src) | (size_t)spitch) & 3) == 0) {
-        const int words = (w + 3 + 3) >> 2;  // bytes [-3, w) rounded up to words; the row pitch (multiple of 64) covers it
+    if (((((size_t)rsrc) | (size_t)spitch) & 15) == 0) {
+        // 16-byte chunks: the ROI (with its 3 leading bytes) starts on a 16-byte boundary and ends at least 16 px before
+        // the row end, so whole chunks stay inside the image row
+        for (int i = tid; i < SV_ROI_MAX * (FP / 16); i += 256) {
+            const int r = i / (FP / 16), c = i - r * (FP / 16);
+            uint4 v = {0, 0, 0, 0};
+            if (r < h && 16 * c < w + 3) v = *reinterpret_cast<const uint4*>(rsrc + (size_t)r * spitch + 16 * c);
+            reinterpret_cast<uint4*>(s_raw)[i] = v;
+            reinterpret_cast<uint4*>(s_a)[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    else if (((((size_t)src) | (size_t)spitch) & 3) == 0) {
+        const int words = (w + 3 + 3) >> 2;  // bytes [-3, w) rounded up to words; the row pitch (multiple of 4) covers it
         for (int i = tid; i < SV_ROI_MAX * (FP / 4); i += 256) {
             const int r = i / (FP / 4), c = i - r * (FP / 4);
             uint32_t v = 0;
@@ -586,8 +619,8 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         s_count = 0;
         s_qn = 0;
     }
+    if (tid < FAST_KT * FAST_KT) s_key[tid] = 0ull;
     __syncthreads();
-    if (dbg_stop == 1) return;
 
     const int tq = min(ini_thr, min_thr);
     const int lx = 3 + (tid & 63);
@@ -634,7 +667,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         }
     }
     __syncthreads();
-    if (dbg_stop == 2) return;
     // --- pass B: arc score of the candidates
     for (int i = tid; i < s_qn; i += 256) {
         const int ly = s_q[i] >> 7, qx = s_q[i] & 127;
@@ -644,12 +676,12 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         s_a[ly * FP + qx] = (uint8_t)arc_score16(c[0], p);
     }
     __syncthreads();
-    if (dbg_stop == 3) return;
 
     // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
     const int gx_off = lev.gtab_x_off, gy_off = lev.gtab_y_off;
     unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
     const int qn = s_qn;
+    const int gx0 = gtab[gx_off + cell.min_x + 3 - SV_PATCH_RADIUS], gy0 = gtab[gy_off + cell.min_y + 3 - SV_PATCH_RADIUS];  // grid cell of the first scored pixel
     for (int pass = 0; pass < 2; ++pass) {
         const int t = pass == 0 ? ini_thr : min_thr;
         int found = 0;
@@ -676,12 +708,19 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             const int gx = gtab[gx_off + x_level - SV_PATCH_RADIUS], gy = gtab[gy_off + y_level - SV_PATCH_RADIUS];
             const uint32_t order = (uint32_t)cell.order_base | ((uint32_t)ly << 7) | (uint32_t)qx;
             const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (0xFFFFFFFFu - order);
-            atomicMax(&K[gy * lev.grid_x + gx], key);
+            // arg-max per selection-grid cell: first inside the block (LDS), one global atomic per touched cell afterwards
+            const int kx = gx - gx0, ky = gy - gy0;
+            if ((unsigned)kx < FAST_KT && (unsigned)ky < FAST_KT) atomicMax(&s_key[ky * FAST_KT + kx], key);
+            else atomicMax(&K[gy * lev.grid_x + gx], key);
         }
         if (found) atomicAdd(&s_count, found);
         __syncthreads();
         if (s_count > 0) break;
         __syncthreads();
+    }
+    if (tid < FAST_KT * FAST_KT) {
+        const unsigned long long key = s_key[tid];
+        if (key) atomicMax(&K[(gy0 + tid / FAST_KT) * lev.grid_x + gx0 + tid % FAST_KT], key);
     }
 }
 
@@ -828,9 +867,10 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
                                                   const uint8_t* __restrict__ blur, size_t blur_frame_bytes,
                                                   svgpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap) {
     __shared__ __attribute__((aligned(16))) uint8_t s_slab[4][DESC_SLAB];
-    const int b = blockIdx.y;
+    int b, blk;
+    xcd_frame_map(gridDim.x, gridDim.y, blk, b);
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blk * 4 + (threadIdx.x >> 6);
     const int n = counts[b * (1 + num_levels)];
     if (i >= n || i >= cap) return;
     const int4 s = sel[(size_t)b * total_grid + i];
@@ -958,7 +998,7 @@ void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const
     if (num_cells == 0) return;
     hipLaunchKernelGGL(k_fast, dim3(num_cells, batch), dim3(256), 0, s, levels, num_levels, cells, img0, img0_frame_stride,
                        img0_pitch, pyr, pyr_frame_bytes, gtab, keys, total_grid, ini_thr, min_thr, mask, mask_frame_stride,
-                       mask_pitch, mask_w, mask_h, getenv("SVGPU_DBG_FAST_STOP") ? atoi(getenv("SVGPU_DBG_FAST_STOP")) : 0);
+                       mask_pitch, mask_w, mask_h);
 }
 
 void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,

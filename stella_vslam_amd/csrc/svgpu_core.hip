@@ -48,7 +48,7 @@ void sv_prof_end(svgpu_ctx* ctx, hipStream_t s, const char* name) {
 extern "C" {
 
 const char* svgpu_profile_kernels(void) {
-    return "k_resize,k_blur,k_fast,k_select,k_describe,k_bf_topk,k_bf_replay,k_cand,k_stereo,ba_linearize,ba_schur,ba_solve,ba_update,ba_chi2,k_pose_opt";
+    return "k_resize,k_blur,k_fast,k_select,k_describe,k_bf_binsort,k_bf_topk,k_bf_replay,k_cand,k_stereo,ba_linearize,ba_schur,ba_solve,ba_update,ba_chi2,k_pose_opt";
 }
 
 int svgpu_profile_select(svgpu_ctx* ctx, const char* kernel_name) {

@@ -19,7 +19,7 @@ f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZ
 out = {"unit": "bytes per launch (FETCH_SIZE / WRITE_SIZE KiB x 1024, mean over the launches of the run)",
        "caveat": "gfx950: FETCH_SIZE halves wide 16 B/lane streams; these kernels use 4 B/lane or byte accesses (uncalibrated width), "
                  "values kept raw; Infinity-Cache hits are included", "kernels": {}}
-alias = {"k_pyramid": "k_resize"}
+alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
 for k in sorted(set(f.index) | set(w.index)):
     if not k.startswith("k_"):
         continue
