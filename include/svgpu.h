@@ -154,7 +154,9 @@ typedef enum svgpu_match_mode {
     SVGPU_MATCH_BEST_ONLY = 0,        /* projection::match_current_and_last_frames (match/projection.cc:95-207) */
     SVGPU_MATCH_RATIO_SAME_OCTAVE = 1,/* projection::match_frame_and_landmarks     (match/projection.cc:13-93)  */
     SVGPU_MATCH_RATIO = 2,            /* bow_tree::match_frame_and_keyframe / match_keyframes (match/bow_tree.cc:169-366) */
-    SVGPU_MATCH_TRIANGULATION = 3     /* bow_tree / robust ::match_for_triangulation (match/bow_tree.cc:11-167, robust.cc:14-146) */
+    SVGPU_MATCH_TRIANGULATION = 3,    /* bow_tree / robust ::match_for_triangulation (match/bow_tree.cc:11-167, robust.cc:14-146) */
+    SVGPU_MATCH_AREA = 4              /* area::match_in_consistent_area (match/area.cc:8-98): ratio test; a closer later query takes
+                                         the target from its holder (occupied / stereo inputs are not used) */
 } svgpu_match_mode;
 
 /* Candidate-list matcher: query q scans targets cand_idx[cand_off[q] .. cand_off[q+1]) in order.

@@ -112,7 +112,7 @@ int orc_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, con
 }
 
 /* ---------------------------------------------------------------- candidate-list matchers */
-enum { ORC_MODE_BEST_ONLY = 0, ORC_MODE_RATIO_SAME_OCTAVE = 1, ORC_MODE_RATIO = 2, ORC_MODE_TRIANGULATION = 3 };
+enum { ORC_MODE_BEST_ONLY = 0, ORC_MODE_RATIO_SAME_OCTAVE = 1, ORC_MODE_RATIO = 2, ORC_MODE_TRIANGULATION = 3, ORC_MODE_AREA = 4 };
 
 /* Queries are processed in index order; each scans its CSR candidate list in order.
  *   skip candidate if occupied[t]                       (projection.cc:52-55 / :167-170)
@@ -125,13 +125,56 @@ enum { ORC_MODE_BEST_ONLY = 0, ORC_MODE_RATIO_SAME_OCTAVE = 1, ORC_MODE_RATIO = 
  * match/robust.cc:56-130): best starts AT thr, a candidate farther than thr or than the current best is skipped before the
  * (precomputed, cand_skip) epipolar gates, '<' updates, then the plain ratio test.  cand_skip[c] != 0 drops CSR entry c
  * (per-pair gates the caller evaluated: epipolar constraint, chi-square reprojection gate of fuse.cc:92-119, ...).
- * An accepted query occupies its target.  match_q[q] = t or -1. */
+ * An accepted query occupies its target.  match_q[q] = t or -1.
+ * mode AREA = area::match_in_consistent_area (match/area.cc:8-98): targets are never occupied; a candidate is skipped when the
+ * target's current match is at least as close (matched_dists_in_frm_2, :47-50); best <= thr, ratio test (:63-70); an accepted
+ * query TAKES the target from its previous holder, whose match is cleared (:77-88). */
 int orc_match_candidates(const uint8_t* qdesc, int nq, const uint8_t* tdesc, const int32_t* t_octave, int nt,
                          const int32_t* cand_off, const int32_t* cand_idx, const uint8_t* cand_skip, const uint8_t* q_valid,
                          const uint8_t* occupied_init, const float* q_angle, const float* t_angle, int check_orientation,
                          const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                          float lowe_ratio, int mode, int32_t* match_q) {
     int num = 0;
+    if (mode == ORC_MODE_AREA) {
+        unsigned* mdist = (unsigned*)malloc(sizeof(unsigned) * (nt > 0 ? nt : 1));
+        int* holder = (int*)malloc(sizeof(int) * (nt > 0 ? nt : 1));
+        for (int t = 0; t < nt; ++t) {
+            mdist[t] = ORC_MAX_HAMMING_DIST;
+            holder[t] = -1;
+        }
+        for (int q = 0; q < nq; ++q) match_q[q] = -1;
+        for (int q = 0; q < nq; ++q) {
+            if (q_valid && !q_valid[q]) continue;
+            unsigned best = ORC_MAX_HAMMING_DIST, second = ORC_MAX_HAMMING_DIST;
+            int best_idx = -1;
+            for (int c = cand_off[q]; c < cand_off[q + 1]; ++c) {
+                const int t = cand_idx[c];
+                if (cand_skip && cand_skip[c]) continue;
+                if (check_orientation && fabsf(orc_angle_diff(q_angle[q], t_angle[t])) > 30.0) continue;
+                const unsigned d = orc_hamming_32(qdesc + 32 * (size_t)q, tdesc + 32 * (size_t)t);
+                if (mdist[t] <= d) continue;
+                if (d < best) {
+                    second = best;
+                    best = d;
+                    best_idx = t;
+                }
+                else if (d < second) second = d;
+            }
+            if (thr < best || best_idx < 0) continue;
+            if ((float)second * lowe_ratio < (float)best) continue;
+            if (0 <= holder[best_idx]) {
+                match_q[holder[best_idx]] = -1;
+                --num;
+            }
+            match_q[q] = best_idx;
+            holder[best_idx] = q;
+            mdist[best_idx] = best;
+            ++num;
+        }
+        free(mdist);
+        free(holder);
+        return num;
+    }
     uint8_t* occ = (uint8_t*)calloc(nt > 0 ? nt : 1, 1);
     if (occupied_init) memcpy(occ, occupied_init, nt);
     for (int q = 0; q < nq; ++q) {

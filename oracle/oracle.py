@@ -187,7 +187,7 @@ def brute_force_match(desc1, angle1, desc2, angle2, valid2=None, lowe_ratio: flo
     return out
 
 
-MODE_BEST_ONLY, MODE_RATIO_SAME_OCTAVE, MODE_RATIO, MODE_TRIANGULATION = 0, 1, 2, 3
+MODE_BEST_ONLY, MODE_RATIO_SAME_OCTAVE, MODE_RATIO, MODE_TRIANGULATION, MODE_AREA = 0, 1, 2, 3, 4
 
 
 def match_candidates(qdesc, tdesc, cand_off, cand_idx, cand_skip=None, t_octave=None, q_valid=None, occupied=None, q_angle=None,

@@ -83,4 +83,4 @@ void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b
 void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const uint32_t* d2, int n2, uint16_t* out);
 struct svgpu_ctx;
 void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P, int pairs, int* g_owner, int* g_match);
-void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match);
+void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match, unsigned* mdist);

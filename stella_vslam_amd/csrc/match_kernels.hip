@@ -904,6 +904,81 @@ __global__ __launch_bounds__(256) void k_cand_replay(CandProblem P, int* __restr
     if (tid == 0) *P.num = s_changed;
 }
 
+// area::match_in_consistent_area (match/area.cc:8-98) on the same CSR lists and distances (mode SVGPU_MATCH_AREA).
+// Its state is not monotone (a later, closer query takes a target away from its holder), so the loop over the queries
+// stays sequential: ONE wave walks the queries in order, its lanes stride over the candidates of the current query
+// (distances are precomputed), wave-reduce (best (dist, scan position), second distance), lane 0 applies the update.
+// The initialiser calls this once per frame pair on level-0 keypoints only.
+__global__ __launch_bounds__(64) void k_area_replay(CandProblem P, int* __restrict__ g_holder, int* __restrict__ g_match,
+                                                    unsigned* __restrict__ g_mdist, int use_lds) {
+    extern __shared__ int s_area[];
+    const int lane = threadIdx.x;
+    int* holder = use_lds ? s_area : g_holder;
+    unsigned* mdist = use_lds ? reinterpret_cast<unsigned*>(s_area + P.nt) : g_mdist;
+    int* match = use_lds ? s_area + 2 * P.nt : g_match;
+    for (int t = lane; t < P.nt; t += 64) {
+        holder[t] = -1;
+        mdist[t] = MAX_HAMMING_DIST;
+    }
+    for (int q = lane; q < P.nq; q += 64) match[q] = -1;
+    __syncthreads();
+    // state in global memory (inputs too large for LDS): device-scope atomics keep lane 0's updates visible to the other lanes
+    auto ld = [&](const unsigned* p) -> unsigned {
+        return use_lds ? *p : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto st = [&](unsigned* p, unsigned v) {
+        if (use_lds) *p = v;
+        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    for (int q = 0; q < P.nq; ++q) {
+        if (P.q_valid && !P.q_valid[q]) continue;
+        const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
+        if (lo == hi) continue;
+        uint32_t k1 = 0xFFFFFFFFu;       // smallest (dist << 20 | scan position) of this lane's share: strict '<' keeps the first
+        unsigned d2 = MAX_HAMMING_DIST;  // second smallest distance of this lane's share
+        for (int c = lo + lane; c < hi; c += 64) {
+            const unsigned d = P.dist[c];
+            if (d == 0xFFFFu) continue;                 // cand_skip / orientation gate (:40-42)
+            if (ld(&mdist[P.cand_idx[c]]) <= d) continue;    // the current holder of that target is at least as close (:47-50)
+            const uint32_t key = (d << 20) | (uint32_t)min(c - lo, 0xFFFFF);
+            if (key < k1) {
+                d2 = min(d2, k1 >> 20);
+                k1 = key;
+            }
+            else d2 = min(d2, d);
+        }
+        uint32_t kb = k1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kb = min(kb, (uint32_t)__shfl_xor(kb, off, 64));
+        unsigned second = (k1 == kb) ? d2 : min(d2, k1 == 0xFFFFFFFFu ? MAX_HAMMING_DIST : (k1 >> 20));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) second = min(second, (unsigned)__shfl_xor(second, off, 64));
+        if (kb == 0xFFFFFFFFu) continue;
+        const unsigned best = kb >> 20;
+        if (P.thr < best) continue;                                   // HAMMING_DIST_THR_LOW (:58-60)
+        if ((float)second * P.lowe_ratio < (float)best) continue;     // ratio test (:63-65)
+        const int t = P.cand_idx[lo + (int)(kb & 0xFFFFFu)];
+        if (lane == 0) {                                              // take the target from its previous holder (:72-86)
+            const int prev = (int)ld(reinterpret_cast<unsigned*>(&holder[t]));
+            if (0 <= prev) st(reinterpret_cast<unsigned*>(&match[prev]), 0xFFFFFFFFu);
+            st(reinterpret_cast<unsigned*>(&match[q]), (unsigned)t);
+            st(reinterpret_cast<unsigned*>(&holder[t]), (unsigned)q);
+            st(&mdist[t], best);
+        }
+        __syncthreads();  // single wave: orders lane 0's LDS / global writes before the next query's reads
+    }
+    int local = 0;
+    __syncthreads();
+    for (int q = lane; q < P.nq; q += 64) {
+        const int m = (int)ld(reinterpret_cast<const unsigned*>(&match[q]));
+        P.match_q[q] = m;
+        local += m >= 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_xor(local, off, 64);
+    if (lane == 0) *P.num = local;
+}
+
 // ------------------------------------------------------------------------------------------------ stereo
 // match::stereo::compute (match/stereo.cc:20-251), one wave per left keypoint.
 //   phase 1: lanes stride over the right keypoints: row-band membership (get_right_keypoint_indices_in_each_row, margin 2),
@@ -1072,8 +1147,14 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     }
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
 }
-void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match) {
+void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match, unsigned* mdist) {
     SvProfScope ps(ctx, s, "k_cand");
     if (P.nq > 0) hipLaunchKernelGGL(k_cand_dist, dim3(P.nq), dim3(64), 0, s, P);
+    if (P.mode == SVGPU_MATCH_AREA) {
+        const size_t lds = (size_t)(2 * P.nt + P.nq) * sizeof(int);
+        const int use_lds = lds <= 60 * 1024;
+        hipLaunchKernelGGL(k_area_replay, dim3(1), dim3(64), use_lds ? lds : 0, s, P, owner, match, mdist, use_lds);
+        return;
+    }
     hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(256), 0, s, P, owner, match);
 }

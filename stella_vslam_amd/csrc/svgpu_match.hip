@@ -190,7 +190,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
                            const uint8_t* q_valid, const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
                            const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                            float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
-    if (!ctx || nq < 0 || nt < 0 || !num_matches || (mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_TRIANGULATION))
+    if (!ctx || nq < 0 || nt < 0 || !num_matches || (mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_candidates: bad arguments");
     *num_matches = 0;
     if (nq == 0) return SVGPU_OK;
@@ -208,7 +208,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     SV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = pad((size_t)nq * 32) + pad((size_t)nt * 32) + 3 * pad((size_t)nt * 4) + pad(nt) + pad((size_t)(nq + 1) * 4)
                         + pad((size_t)nc * 4) + pad(nc) + pad(nq) + 3 * pad((size_t)nq * 4) + pad((size_t)nc * 2) + 2 * pad((size_t)nq * 4)
-                        + pad((size_t)nt * 4) + 512;
+                        + 2 * pad((size_t)nt * 4) + 512;
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -258,7 +258,8 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     P.num = A.take<int32_t>(1);
     int* owner = A.take<int>(nt);
     int* match = A.take<int>(nq);
-    sv_launch_cand(ctx, s, P, owner, match);
+    unsigned* mdist = A.take<unsigned>(nt);
+    sv_launch_cand(ctx, s, P, owner, match, mdist);
     SV_HIP(ctx, hipGetLastError());
     int32_t num = 0;
     SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));

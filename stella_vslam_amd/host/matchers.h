@@ -61,6 +61,18 @@ public:
                        int mode, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const;
 };
 
+//! match::area (match/area.h): the monocular initialiser's matcher on the same flattened inputs.  query_set = the keypoints of
+//! frame 1 in index order; cand list of idx_1 = frm_2.get_keypoints_in_cell(prev_matched_pts[idx_1], margin, 0, 0), empty for
+//! keypoints above level 0 (match/area.cc:17-32).  The caller refreshes prev_matched_pts from the result (:91-95).
+class area final : public base {
+public:
+    using base::base;
+    unsigned int match_in_consistent_area(const projection::query_set& frm_1, const data::frame_observation& frm_2_obs,
+                                          std::vector<int>& matched_indices_2_in_frm_1) const {
+        return projection(ctx_, lowe_ratio_, check_orientation_).match(frm_1, frm_2_obs, {}, SVGPU_MATCH_AREA, 50, matched_indices_2_in_frm_1);
+    }
+};
+
 //! match::stereo (match/stereo.h): same constructor roles; the image pyramids are the two extractors' (their last extract call)
 class stereo {
 public:

@@ -22,6 +22,7 @@ MATCH_BEST_ONLY = 0
 MATCH_RATIO_SAME_OCTAVE = 1
 MATCH_RATIO = 2          # bow_tree::match_frame_and_keyframe / match_keyframes
 MATCH_TRIANGULATION = 3  # bow_tree / robust ::match_for_triangulation
+MATCH_AREA = 4           # area::match_in_consistent_area
 
 
 def _p(a):
@@ -91,6 +92,17 @@ class projection(base):
                                                     _p(tx), _p(qt), C.c_uint(thr), C.c_float(self.lowe_ratio_), mode, _p(out),
                                                     C.byref(num)), "svgpu_match_candidates")
         return out, num.value
+
+
+class area(base):
+    """match/area.h (the monocular initialiser's matcher).  match_in_consistent_area (match/area.cc:8-98) on flattened inputs:
+    level-0 keypoints of frame 1 are the queries, the candidate list of query idx_1 is
+    frm_2.get_keypoints_in_cell(prev_matched_pts[idx_1], margin, 0, 0) (empty for keypoints of higher levels), as CSR.
+    Returns matched_indices_2_in_frm_1 and the number of matches; the caller then refreshes prev_matched_pts (:91-95)."""
+
+    def match_in_consistent_area(self, desc_1, angle_1, desc_2, angle_2, cand_off, cand_idx):
+        out, num = projection.match_candidates(self, desc_1, desc_2, cand_off, cand_idx, MATCH_AREA, 50, q_angle=angle_1, t_angle=angle_2)
+        return out, num
 
 
 class stereo:

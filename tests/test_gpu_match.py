@@ -170,3 +170,41 @@ def test_stereo_matches_oracle(M, disp):
     assert ok.sum() > 800
     assert np.array_equal(xr, xo) and np.array_equal(dp, do)
     assert abs(np.median((kl["x"] - xr)[ok]) - disp) < 0.05
+
+
+@pytest.mark.parametrize("seed,check", [(0, True), (1, False)])
+def test_area_matcher_matches_oracle(M, ctx, seed, check):
+    """area::match_in_consistent_area (the initialiser's matcher): level-0 keypoints of frame t against the keypoints of
+    frame t+1 inside a window around the previous match; a closer later query takes a target from its holder."""
+    seq = S.frame_sequence(2, seed=0x5EED + 11 * seed)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    off_g, items = O.assign_keypoints_to_grid(k1["x"], k1["y"], bounds)
+    cand_off, cand_idx = [0], []
+    for q in range(len(k0)):
+        if k0["octave"][q] == 0:  # match/area.cc:21-24
+            c = O.get_keypoints_in_cell(k1["x"], k1["y"], k1["octave"], off_g, items, bounds, float(k0["x"][q]), float(k0["y"][q]), 60.0, 0, 0)
+            cand_idx += c.tolist()
+        cand_off.append(len(cand_idx))
+    got, num = M.area(0.9, check, ctx).match_in_consistent_area(d0, k0["angle"], d1, k1["angle"], cand_off, cand_idx)
+    exp = O.match_candidates(d0, d1, cand_off, cand_idx, q_angle=k0["angle"], t_angle=k1["angle"], check_orientation=check, thr=50,
+                             lowe_ratio=0.9, mode=O.MODE_AREA)
+    assert (exp >= 0).sum() > 100
+    assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+
+
+def test_area_matcher_contested_targets(M, ctx):
+    """Many queries compete for few targets: the take-over bookkeeping (matched_dists_in_frm_2) decides."""
+    rng = np.random.default_rng(3)
+    n1, n2 = 500, 120
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    src = rng.integers(0, n2, n1)
+    d1 = np.stack([_noisy(rng, d2[s:s + 1], int(rng.integers(0, 40)))[0] for s in src])
+    a = np.zeros(n1, np.float32)
+    cand_off = np.arange(n1 + 1, dtype=np.int32) * n2
+    cand_idx = np.tile(np.arange(n2, dtype=np.int32), n1)
+    got, num = M.area(0.95, False, ctx).match_in_consistent_area(d1, a, d2, a[:n2], cand_off, cand_idx)
+    exp = O.match_candidates(d1, d2, cand_off, cand_idx, thr=50, lowe_ratio=0.95, mode=O.MODE_AREA)
+    assert 30 < (exp >= 0).sum() <= n2
+    assert np.array_equal(got, exp) and num == (exp >= 0).sum()

@@ -208,3 +208,69 @@ def test_stereo_oracle_recovers_disparity():
         d = (kl["x"] - xr)[ok]
         assert abs(np.median(d) - disp) < 0.05 and np.percentile(np.abs(d - disp), 95) < 1.5
         assert np.allclose(dp[ok], np.float32(fxb) / d, rtol=1e-6)
+
+
+def _area_python(d1, a1, d2, a2, cand_off, cand_idx, ratio, check):
+    """Literal transcription of match/area.cc:8-98 on the flattened inputs (the reference's loop, one statement per line)."""
+    n1, n2 = len(d1), len(d2)
+    matched_2_in_1 = [-1] * n1
+    matched_dists_2 = [256] * n2
+    matched_1_in_2 = [-1] * n2
+    num = 0
+    for i1 in range(n1):
+        idxs = cand_idx[cand_off[i1]:cand_off[i1 + 1]]
+        if len(idxs) == 0:
+            continue
+        best, second, best_i2 = 256, 256, -1
+        for i2 in idxs:
+            if check and abs(O.angle_diff(float(a1[i1]), float(a2[i2]))) > 30.0:
+                continue
+            d = O.hamming(d1[i1], d2[i2])
+            if matched_dists_2[i2] <= d:
+                continue
+            if d < best:
+                second, best, best_i2 = best, d, i2
+            elif d < second:
+                second = d
+        if 50 < best:
+            continue
+        if np.float32(second) * np.float32(ratio) < np.float32(best):
+            continue
+        prev = matched_1_in_2[best_i2]
+        if 0 <= prev:
+            matched_2_in_1[prev] = -1
+            num -= 1
+        matched_2_in_1[i1] = best_i2
+        matched_1_in_2[best_i2] = i1
+        matched_dists_2[best_i2] = best
+        num += 1
+    return np.array(matched_2_in_1, np.int32), num
+
+
+@pytest.mark.parametrize("seed,check", [(0, True), (1, False)])
+def test_area_mode_vs_python(seed, check):
+    """mode AREA = area::match_in_consistent_area: later, closer queries take a target from its holder."""
+    rng = np.random.default_rng(seed)
+    n1, n2 = 300, 260
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    src = rng.integers(0, n2 // 3, n1)  # many frame-1 keypoints compete for the same frame-2 keypoints
+    d1 = d2[src].copy()
+    for i in range(n1):  # 0..40 flipped bits: later queries are often closer than the current holder
+        for b in rng.choice(256, int(rng.integers(0, 41)), replace=False):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    a2 = rng.uniform(0, 360, n2).astype(np.float32)
+    a1 = ((a2[src] + rng.normal(0, 12, n1)) % 360).astype(np.float32)
+    cand_off, cand_idx = [0], []
+    for i in range(n1):
+        if i % 7 == 3:  # keypoints above level 0 have no candidates
+            cand_off.append(len(cand_idx))
+            continue
+        c = set(rng.integers(0, n2, int(rng.integers(0, 40))).tolist()) | {int(src[i])}
+        cand_idx += sorted(c)
+        cand_off.append(len(cand_idx))
+    exp, num = _area_python(d1, a1, d2, a2, cand_off, cand_idx, 0.9, check)
+    got = O.match_candidates(d1, d2, cand_off, cand_idx, q_angle=a1, t_angle=a2, check_orientation=check, thr=50, lowe_ratio=0.9,
+                             mode=O.MODE_AREA)
+    assert num > 40 and (exp >= 0).sum() == num
+    assert np.array_equal(got, exp)
+    assert len(set(got[got >= 0].tolist())) == (got >= 0).sum()  # a target ends with exactly one holder
