@@ -204,7 +204,10 @@ typedef struct svgpu_ba_problem {
     const float* obs_uvr;            /* num_obs x 3: undistorted u, v, u_right (< 0 => monocular edge) */
     const float* obs_inv_sigma_sq;   /* num_obs: orb_params::inv_level_sigma_sq_[octave] */
     const float* obs_huber_delta;    /* num_obs: sqrt(chi_sq) of the Huber kernel, <= 0 => no kernel */
-    const double* intrinsics;        /* num_poses x 5: fx fy cx cy focal_x_baseline */
+    const double* intrinsics;        /* num_poses x 5: fx fy cx cy focal_x_baseline (perspective / fisheye / radial-division cameras:
+                                        all use the perspective edge on undistorted keypoints, reproj_edge_wrapper.h:64-201);
+                                        {0, 0, cols, rows, 0} selects the equirectangular edge (equirectangular_reproj_edge.h:64-134,
+                                        monocular only, no depth gate) */
     int32_t num_first_iter;          /* 5  (local_bundle_adjuster_factory.h) */
     int32_t num_second_iter;         /* 10 */
     double gain_threshold;           /* terminate_action gain, 1e-3 */
@@ -239,7 +242,7 @@ int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uin
  *                        suppresses the LM iterations of the later rounds); 1 = reset it before every round
  * The whole optimisation is ONE single-workgroup kernel launch.  Host in/out, synchronous. */
 int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w, const float* uvr,
-                        const float* inv_sigma_sq, const float* huber_delta, const double* intrinsics /* fx fy cx cy fxb */,
+                        const float* inv_sigma_sq, const float* huber_delta, const double* intrinsics /* fx fy cx cy fxb, or 0 0 cols rows 0 = equirectangular */,
                         int num_trials_robust, int num_trials, int num_each_iter, int reset_stop_flag_each_round,
                         double* pose_out, uint8_t* outlier_flags, int* num_valid, int* lm_iterations);
 

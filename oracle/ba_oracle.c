@@ -174,16 +174,54 @@ typedef struct {
     int nP, nL;
 } ba_t;
 
+/* Camera model of a pose.  The flat problem carries fx fy cx cy fxb per pose; fx == fy == 0 selects the EQUIRECTANGULAR model
+ * with cols = K[2], rows = K[3] (optimize/internal/se3/equirectangular_reproj_edge.h:64-134, always monocular,
+ * reproj_edge_wrapper.h:143-162; depth_is_positive() is constant true for it, :247-249). */
+static inline int cam_is_equirect(const double* K) { return K[0] == 0.0 && K[1] == 0.0; }
+static inline void equirect_project(const double* K, const double* pc, double* u, double* v) { /* cam_project, :128-132 */
+    const double theta = atan2(pc[0], pc[2]);
+    const double phi = -asin(pc[1] / sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]));
+    *u = K[2] * (0.5 + theta / (2 * M_PI));
+    *v = K[3] * (0.5 - phi / M_PI);
+}
+/* linearizeOplus (:70-126): rows of d error / d [rx ry rz tx ty tz] (Bj, 2 x 6) and d error / d landmark (A, 2 x 3; Rcw = rows of R) */
+static inline void equirect_jacobians(const double* K, const double* pc, const double* Rcw, double* A, double* Bj) {
+    const double x = pc[0], y = pc[1], z = pc[2], L = sqrt(x * x + y * y + z * z);
+    const double dX[9] = {0, z, -y, 1, 0, 0, Rcw ? Rcw[0] : 0, Rcw ? Rcw[1] : 0, Rcw ? Rcw[2] : 0};
+    const double dY[9] = {-z, 0, x, 0, 1, 0, Rcw ? Rcw[3] : 0, Rcw ? Rcw[4] : 0, Rcw ? Rcw[5] : 0};
+    const double dZ[9] = {y, -x, 0, 0, 0, 1, Rcw ? Rcw[6] : 0, Rcw ? Rcw[7] : 0, Rcw ? Rcw[8] : 0};
+    const double c0 = -(K[2] / (2 * M_PI)) * (1.0 / (x * x + z * z));
+    const double c1 = -(K[3] / M_PI) * (1.0 / (L * sqrt(x * x + z * z)));
+    for (int k = 0; k < 9; ++k) {
+        const double dL = (1.0 / L) * (x * dX[k] + y * dY[k] + z * dZ[k]);
+        const double j0 = c0 * (z * dX[k] - x * dZ[k]);
+        const double j1 = c1 * (L * dY[k] - y * dL);
+        if (k < 6) {
+            Bj[k] = j0;
+            Bj[6 + k] = j1;
+        }
+        else if (A) {
+            A[k - 6] = j0;
+            A[3 + k - 6] = j1;
+        }
+    }
+}
+static inline int depth_ok(const double* K, const double* pc) { return cam_is_equirect(K) || 0.0 < pc[2]; }
+
 static void edge_error(const ba_t* B, int e, double* err, double* pc_out) {
     const int p = B->obs_pose[e], l = B->obs_point[e];
     double pc[3];
     se3_map(&B->pose[p], &B->pt[3 * l], pc);
     const double* K = &B->intr[5 * p];
-    const double u = K[0] * pc[0] / pc[2] + K[2];
-    const double v = K[1] * pc[1] / pc[2] + K[3];
+    double u, v;
+    if (cam_is_equirect(K)) equirect_project(K, pc, &u, &v);
+    else {
+        u = K[0] * pc[0] / pc[2] + K[2];
+        v = K[1] * pc[1] / pc[2] + K[3];
+    }
     err[0] = (double)B->obs_uvr[3 * e] - u;
     err[1] = (double)B->obs_uvr[3 * e + 1] - v;
-    if (B->obs_uvr[3 * e + 2] < 0) err[2] = 0.0;
+    if (B->obs_uvr[3 * e + 2] < 0 || cam_is_equirect(K)) err[2] = 0.0;
     else err[2] = (double)B->obs_uvr[3 * e + 2] - (u - K[4] / pc[2]);
     if (pc_out) memcpy(pc_out, pc, sizeof(pc));
 }
@@ -313,9 +351,9 @@ static void build_system(const ba_t* B, lin_t* S) {
         const int p = B->obs_pose[e], l = B->obs_point[e];
         const int ps = B->pose_slot[p], lsl = B->point_slot[l];
         if (ps < 0 && lsl < 0) continue;
-        const int stereo = !(B->obs_uvr[3 * e + 2] < 0);
-        const int D = stereo ? 3 : 2;
         const double* K = &B->intr[5 * p];
+        const int stereo = !(B->obs_uvr[3 * e + 2] < 0) && !cam_is_equirect(K);
+        const int D = stereo ? 3 : 2;
         const double fx = K[0], fy = K[1], fxb = K[4];
         double pc[3], R[9];
         se3_map(&B->pose[p], &B->pt[3 * l], pc);
@@ -345,6 +383,11 @@ static void build_system(const ba_t* B, lin_t* S) {
         Bj[15] = Bj[3];
         Bj[16] = 0;
         Bj[17] = Bj[5] - fxb / z_sq;
+        if (cam_is_equirect(K)) {
+            memset(A, 0, sizeof(A));
+            memset(Bj, 0, sizeof(Bj));
+            equirect_jacobians(K, pc, R, A, Bj);
+        }
         const double* r = &B->err[3 * e];
         double w = (double)B->obs_inv_sigma_sq[e];
         double rw = w; /* weight on the residual in b: rho' * omega */
@@ -672,7 +715,7 @@ int orc_local_ba(int P, int L, int E, const double* pose_cw, const uint8_t* pose
                 se3_map(&B.pose[obs_pose[e]], &B.pt[3 * obs_point[e]], pc);
                 const int mono = obs_uvr[3 * e + 2] < 0;
                 const float thr = mono ? 5.99146f : 7.81473f;
-                if ((double)thr < chi || !(0.0 < pc[2])) {
+                if ((double)thr < chi || !depth_ok(&B.intr[5 * obs_pose[e]], pc)) {
                     B.level[e] = 1;
                     st[5] += 1;
                 }
@@ -686,7 +729,7 @@ int orc_local_ba(int P, int L, int E, const double* pose_cw, const uint8_t* pose
             se3_map(&B.pose[obs_pose[e]], &B.pt[3 * obs_point[e]], pc);
             const int mono = obs_uvr[3 * e + 2] < 0;
             const float thr = mono ? 5.99146f : 7.81473f;
-            outlier_out[e] = ((double)thr < chi || !(0.0 < pc[2])) ? 1 : 0;
+            outlier_out[e] = ((double)thr < chi || !depth_ok(&B.intr[5 * obs_pose[e]], pc)) ? 1 : 0;
         }
         /* chi2 over the finally-active set */
         st[1] = active_robust_chi2(&B);
@@ -751,10 +794,11 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
     {                                                                                     \
         double pc_[3];                                                                    \
         se3_map((Tq), &pos_w[3 * (i)], pc_);                                              \
-        const double u_ = intr[0] * pc_[0] / pc_[2] + intr[2], v_ = intr[1] * pc_[1] / pc_[2] + intr[3]; \
+        double u_ = intr[0] * pc_[0] / pc_[2] + intr[2], v_ = intr[1] * pc_[1] / pc_[2] + intr[3]; \
+        if (cam_is_equirect(intr)) equirect_project(intr, pc_, &u_, &v_);                 \
         err[3 * (i)] = (double)uvr[3 * (i)] - u_;                                         \
         err[3 * (i) + 1] = (double)uvr[3 * (i) + 1] - v_;                                 \
-        err[3 * (i) + 2] = uvr[3 * (i) + 2] < 0 ? 0.0 : (double)uvr[3 * (i) + 2] - (u_ - intr[4] / pc_[2]); \
+        err[3 * (i) + 2] = (uvr[3 * (i) + 2] < 0 || cam_is_equirect(intr)) ? 0.0 : (double)uvr[3 * (i) + 2] - (u_ - intr[4] / pc_[2]); \
     }
 #define PO_CHI(i) ((err[3 * (i)] * err[3 * (i)] + err[3 * (i) + 1] * err[3 * (i) + 1] + err[3 * (i) + 2] * err[3 * (i) + 2]) * (double)inv_sigma_sq[i])
     uint8_t flag = 0;
@@ -775,7 +819,7 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
                 double pc[3];
                 se3_map(&T, &pos_w[3 * i], pc);
                 const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z, fx = intr[0], fy = intr[1], fxb = intr[4];
-                const int stereo = !(uvr[3 * i + 2] < 0);
+                const int stereo = !(uvr[3 * i + 2] < 0) && !cam_is_equirect(intr);
                 double J[18];
                 J[0] = x * y / z_sq * fx;
                 J[1] = -(1.0 + (x * x / z_sq)) * fx;
@@ -795,6 +839,10 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
                 J[15] = stereo ? J[3] : 0;
                 J[16] = 0;
                 J[17] = stereo ? J[5] - fxb / z_sq : 0;
+                if (cam_is_equirect(intr)) { /* equirectangular_pose_opt_edge.h:70-118 */
+                    memset(J, 0, sizeof(J));
+                    equirect_jacobians(intr, pc, NULL, NULL, J);
+                }
                 const double chi = PO_CHI(i);
                 double w = (double)inv_sigma_sq[i], rho[2] = {chi, 1.0};
                 if (robust[i]) huber(chi, (double)huber_delta[i], rho);

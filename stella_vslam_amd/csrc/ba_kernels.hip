@@ -29,17 +29,57 @@ __device__ __forceinline__ void cam_point(const double* __restrict__ T, const do
     pc[2] = T[8] * X[0] + T[9] * X[1] + T[10] * X[2] + T[11];
 }
 
+// Camera model of a pose.  The flat problem carries fx fy cx cy fxb per pose; fx == fy == 0 selects the EQUIRECTANGULAR model
+// with cols = K[2], rows = K[3] (optimize/internal/se3/equirectangular_reproj_edge.h:64-134: always monocular, and
+// depth_is_positive() is constant true for it, reproj_edge_wrapper.h:247-249).
+__device__ __forceinline__ bool cam_is_equirect(const double* __restrict__ K) { return K[0] == 0.0 && K[1] == 0.0; }
+__device__ __forceinline__ void equirect_project(const double* __restrict__ K, const double* pc, double* u, double* v) {  // cam_project, :128-132
+    constexpr double PI = 3.14159265358979323846;
+    const double theta = atan2(pc[0], pc[2]);
+    const double phi = -asin(pc[1] / sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]));
+    *u = K[2] * (0.5 + theta / (2 * PI));
+    *v = K[3] * (0.5 - phi / PI);
+}
+// linearizeOplus (:70-126): d error / d [rx ry rz tx ty tz] (Bj: rows 0, 1 of a D x 6 block) and, when Rcw != nullptr,
+// d error / d landmark (A: rows 0, 1 of a D x 3 block; Rcw = [R|t] rows, stride 4)
+__device__ __forceinline__ void equirect_jacobians(const double* __restrict__ K, const double* pc, const double* __restrict__ Rcw, double* A,
+                                                   double* Bj) {
+    constexpr double PI = 3.14159265358979323846;
+    const double x = pc[0], y = pc[1], z = pc[2], L = sqrt(x * x + y * y + z * z);
+    const double dX[9] = {0, z, -y, 1, 0, 0, Rcw ? Rcw[0] : 0, Rcw ? Rcw[1] : 0, Rcw ? Rcw[2] : 0};
+    const double dY[9] = {-z, 0, x, 0, 1, 0, Rcw ? Rcw[4] : 0, Rcw ? Rcw[5] : 0, Rcw ? Rcw[6] : 0};
+    const double dZ[9] = {y, -x, 0, 0, 0, 1, Rcw ? Rcw[8] : 0, Rcw ? Rcw[9] : 0, Rcw ? Rcw[10] : 0};
+    const double c0 = -(K[2] / (2 * PI)) * (1.0 / (x * x + z * z));
+    const double c1 = -(K[3] / PI) * (1.0 / (L * sqrt(x * x + z * z)));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double dL = (1.0 / L) * (x * dX[k] + y * dY[k] + z * dZ[k]);
+        const double j0 = c0 * (z * dX[k] - x * dZ[k]);
+        const double j1 = c1 * (L * dY[k] - y * dL);
+        if (k < 6) {
+            Bj[k] = j0;
+            Bj[6 + k] = j1;
+        }
+        else if (A) {
+            A[k - 6] = j0;
+            A[3 + k - 6] = j1;
+        }
+    }
+}
+
 // error only (computeError); returns chi2 = e^T Omega e
 __device__ __forceinline__ double edge_error(const double* __restrict__ T, const double* __restrict__ X, const double* __restrict__ K,
                                              const float* __restrict__ uvr, double w0, double* r, double* z_out) {
     double pc[3];
     cam_point(T, X, pc);
-    const double u = K[0] * pc[0] / pc[2] + K[2];
-    const double v = K[1] * pc[1] / pc[2] + K[3];
+    const bool eq = cam_is_equirect(K);
+    double u = K[0] * pc[0] / pc[2] + K[2];
+    double v = K[1] * pc[1] / pc[2] + K[3];
+    if (eq) equirect_project(K, pc, &u, &v);
     r[0] = (double)uvr[0] - u;
     r[1] = (double)uvr[1] - v;
-    r[2] = uvr[2] < 0.f ? 0.0 : (double)uvr[2] - (u - K[4] / pc[2]);
-    if (z_out) *z_out = pc[2];
+    r[2] = (uvr[2] < 0.f || eq) ? 0.0 : (double)uvr[2] - (u - K[4] / pc[2]);
+    if (z_out) *z_out = eq ? 1.0 : pc[2];
     return (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * w0;
 }
 
@@ -67,10 +107,12 @@ __device__ __forceinline__ void edge_linearize(const BaDev& D, int e, EdgeLin& o
     cam_point(T, X, pc);
     const double fx = K[0], fy = K[1], fxb = K[4];
     const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z;
-    const double u = fx * x / z + K[2], v = fy * y / z + K[3];
-    const bool stereo = !(uvr[2] < 0.f);
+    const bool eq = cam_is_equirect(K);
+    double u = fx * x / z + K[2], v = fy * y / z + K[3];
+    if (eq) equirect_project(K, pc, &u, &v);
+    const bool stereo = !(uvr[2] < 0.f) && !eq;
     o.D = stereo ? 3 : 2;
-    o.z = z;
+    o.z = eq ? 1.0 : z;
     o.r[0] = (double)uvr[0] - u;
     o.r[1] = (double)uvr[1] - v;
     o.r[2] = stereo ? (double)uvr[2] - (u - fxb / z) : 0.0;
@@ -105,6 +147,7 @@ __device__ __forceinline__ void edge_linearize(const BaDev& D, int e, EdgeLin& o
 #pragma unroll
         for (int k = 12; k < 18; ++k) o.B[k] = 0.0;
     }
+    if (eq) equirect_jacobians(K, pc, T, o.A, o.B);  // rows 0, 1; row 2 is already zero (monocular)
     double rho1 = 1.0;
     if (D.e_robust[e]) {
         double rho0;
@@ -757,7 +800,7 @@ __global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_
     cam_point(D.pose_cur + (size_t)p * 12, D.pt_cur + (size_t)l * 3, pc);
     const bool mono = D.e_uvr[(size_t)e * 3 + 2] < 0.f;
     const double thr = mono ? (double)5.99146f : (double)7.81473f;
-    const bool out = thr < D.e_chi[e] || !(0.0 < pc[2]);
+    const bool out = thr < D.e_chi[e] || !(cam_is_equirect(D.intr + (size_t)p * 5) || 0.0 < pc[2]);
     if (set_levels) {
         if (out) D.e_level[e] = 1;
         D.e_robust[e] = 0;
@@ -861,11 +904,13 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     __syncthreads();
     auto chi_at = [&](int i, const double* T, double* r, double* pc) {
         cam_point(T, P.pos_w + (size_t)i * 3, pc);
-        const double u = P.intr[0] * pc[0] / pc[2] + P.intr[2], v = P.intr[1] * pc[1] / pc[2] + P.intr[3];
+        double u = P.intr[0] * pc[0] / pc[2] + P.intr[2], v = P.intr[1] * pc[1] / pc[2] + P.intr[3];
+        const bool eq = cam_is_equirect(P.intr);
+        if (eq) equirect_project(P.intr, pc, &u, &v);
         const float* o = P.uvr + (size_t)i * 3;
         r[0] = (double)o[0] - u;
         r[1] = (double)o[1] - v;
-        r[2] = o[2] < 0.f ? 0.0 : (double)o[2] - (u - P.intr[4] / pc[2]);
+        r[2] = (o[2] < 0.f || eq) ? 0.0 : (double)o[2] - (u - P.intr[4] / pc[2]);
         return (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]) * (double)P.inv_sigma_sq[i];
     };
     bool flag = false;      // the terminate action's own stop flag (no caller flag exists in this path)
@@ -885,7 +930,8 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 double r[3], pc[3];
                 const double chi = chi_at(i, s_T, r, pc);
                 const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z, fx = P.intr[0], fy = P.intr[1], fxb = P.intr[4];
-                const bool stereo = !(P.uvr[(size_t)i * 3 + 2] < 0.f);
+                const bool eq = cam_is_equirect(P.intr);
+                const bool stereo = !(P.uvr[(size_t)i * 3 + 2] < 0.f) && !eq;
                 double J[18];
                 J[0] = x * y / z_sq * fx;
                 J[1] = -(1.0 + (x * x / z_sq)) * fx;
@@ -905,6 +951,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 J[15] = stereo ? J[3] : 0.0;
                 J[16] = 0.0;
                 J[17] = stereo ? J[5] - fxb / z_sq : 0.0;
+                if (eq) equirect_jacobians(P.intr, pc, nullptr, nullptr, J);  // equirectangular_pose_opt_edge.h:70-118 (rows 0, 1)
                 double rho0 = chi, rho1 = 1.0;
                 if (P.robust[i]) huber(chi, (double)P.huber[i], &rho0, &rho1);
                 const double w = (double)P.inv_sigma_sq[i] * rho1;

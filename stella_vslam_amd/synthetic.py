@@ -92,12 +92,14 @@ def _rodrigues(w: np.ndarray) -> np.ndarray:
 
 def ba_scene(num_kf: int = 20, num_lm: int = 10000, obs_per_lm: int = 6, num_fixed: int = 4, seed: int = 1234,
              outlier_frac: float = 0.03, pose_noise=(0.02, 0.5), point_noise: float = 0.03, stereo: bool = False,
-             scale_factor: float = 1.2, num_levels: int = 8, loop: bool = False) -> dict:
+             scale_factor: float = 1.2, num_levels: int = 8, loop: bool = False, equirect: bool = False) -> dict:
     """Synthetic local-BA problem on the flat arrays the C-ABI carries.
 
     Cameras on an arc (radius 5 m, 18 deg span; `loop=True`: full circle for the global-BA config) looking
     at points uniform in a 4x3x2 m box 4-8 m away.  Each point is observed by `obs_per_lm` cameras that see
     it inside a 752x480 image.  Returns ground truth next to the perturbed initial estimate.
+    `equirect=True`: the cameras are 1920x960 equirectangular (camera/equirectangular.h: u = cols (0.5 + atan2(x, z) / 2 pi),
+    v = rows (0.5 + asin(y / |p|) / pi)); a point is visible from every camera; intrinsics rows are {0, 0, cols, rows, 0}.
     """
     rng = np.random.default_rng(seed)
     fx = fy = 458.654
@@ -139,6 +141,11 @@ def ba_scene(num_kf: int = 20, num_lm: int = 10000, obs_per_lm: int = 6, num_fix
         u = fx * pc[:, 0] / np.where(ok, pc[:, 2], 1) + cx
         v = fy * pc[:, 1] / np.where(ok, pc[:, 2], 1) + cy
         ok &= (u > 20) & (u < W - 20) & (v > 20) & (v < H - 20)
+        if equirect:
+            ok = np.linalg.norm(pc, axis=1) > 0.5
+            u = 1920.0 * (0.5 + np.arctan2(pc[:, 0], pc[:, 2]) / (2 * np.pi))
+            v = 960.0 * (0.5 + np.arcsin(pc[:, 1] / np.linalg.norm(pc, axis=1)) / np.pi)
+            ok &= (u > 60) & (u < 1920 - 60)  # keep clear of the +-pi seam (the reference's error is a plain difference)
         vis = np.flatnonzero(ok)
         if len(vis) < 2:
             if tries > 50 * num_lm:
@@ -195,7 +202,7 @@ def ba_scene(num_kf: int = 20, num_lm: int = 10000, obs_per_lm: int = 6, num_fix
         table.append(np.float32(1.0) / (s * s))
     inv_sigma_sq = np.array(table, np.float32)[obs_oct]
     huber = np.full(len(obs_oct), np.sqrt(np.float32(7.81473 if stereo else 5.99146)), np.float32)
-    intr = np.tile(np.array([fx, fy, cx, cy, fxb]), (num_kf, 1))
+    intr = np.tile(np.array([0.0, 0.0, 1920.0, 960.0, 0.0] if equirect else [fx, fy, cx, cy, fxb]), (num_kf, 1))
     return dict(
         pose_cw=pose_init, pose_gt=pose_gt, pose_fixed=fixed, points=pts_init, points_gt=pts,
         obs_pose=np.array(obs_pose, np.int32), obs_point=np.array(obs_point, np.int32),

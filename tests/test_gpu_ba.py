@@ -23,7 +23,9 @@ def _rel(a, b):
 @pytest.mark.parametrize("kw", [dict(num_kf=6, num_lm=300, obs_per_lm=4, num_fixed=2, seed=3),
                                 dict(num_kf=10, num_lm=1500, obs_per_lm=5, num_fixed=3, seed=5),
                                 dict(num_kf=12, num_lm=900, obs_per_lm=6, num_fixed=2, seed=6, stereo=True),
-                                dict(num_kf=20, num_lm=10000, obs_per_lm=6, num_fixed=4, seed=1234)])
+                                dict(num_kf=20, num_lm=10000, obs_per_lm=6, num_fixed=4, seed=1234),
+                                # equirectangular cameras (intrinsics rows {0, 0, cols, rows, 0}): equirectangular_reproj_edge.h:64-134
+                                dict(num_kf=8, num_lm=1200, obs_per_lm=5, num_fixed=2, seed=8, equirect=True)])
 def test_local_ba_matches_oracle(ba, kw):
     sc = S.ba_scene(**kw)
     got = ba.optimize_flat(sc)
@@ -190,3 +192,18 @@ def test_pose_optimizer_matches_oracle(ba, seed, stereo, reset):
     assert np.abs(pose - pr["pose_gt"]).max() < np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
     nv0, pose0, outl0, it0 = po.optimize_flat(pr["pose_cw"], pr["pos_w"][:3], pr["uvr"][:3], pr["inv_sigma_sq"][:3], pr["huber"][:3], pr["intr"])
     assert nv0 == 0 and np.array_equal(pose0, pr["pose_cw"].reshape(12))
+
+
+def test_pose_optimizer_equirectangular_matches_oracle():
+    """equirectangular_pose_opt_edge.h:64-127 through the same persistent kernel."""
+    from stella_vslam_amd import optimize
+    sc = S.ba_scene(num_kf=3, num_lm=1000, obs_per_lm=3, num_fixed=0, seed=6, outlier_frac=0.1, equirect=True)
+    sel = sc["obs_pose"] == 1
+    pr = dict(pose_cw=sc["pose_cw"][1], pose_gt=sc["pose_gt"][1], pos_w=sc["points_gt"][sc["obs_point"][sel]], uvr=sc["obs_uvr"][sel],
+              inv_sigma_sq=sc["obs_inv_sigma_sq"][sel], huber=sc["obs_huber"][sel], intr=sc["intr"][1])
+    nv, pose, outl, iters = optimize.pose_optimizer().optimize_flat(pr["pose_cw"], pr["pos_w"], pr["uvr"], pr["inv_sigma_sq"], pr["huber"],
+                                                                    pr["intr"])
+    rnv, rpose, routl, rst = O.pose_optimize(pr["pose_cw"], pr["pos_w"], pr["uvr"], pr["inv_sigma_sq"], pr["huber"], pr["intr"])
+    assert nv == rnv and iters == int(rst[0]) and np.array_equal(outl, routl)
+    assert _rel(pose, rpose) < TOL
+    assert np.abs(pose - pr["pose_gt"]).max() < 0.1 * np.abs(pr["pose_cw"] - pr["pose_gt"]).max()

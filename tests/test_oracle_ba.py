@@ -132,3 +132,55 @@ def test_pose_optimizer_oracle(reset):
     assert st[0] >= 2
     nv0, pose0, outl0, _ = O.pose_optimize(pr["pose_cw"], pr["pos_w"][:4], pr["uvr"][:4], pr["inv_sigma_sq"][:4], pr["huber"][:4], pr["intr"])
     assert nv0 == 0 and np.array_equal(pose0, pr["pose_cw"]) and outl0.sum() == 0
+
+
+def _equirect_exact_obs(sc):
+    R = sc["pose_gt"].reshape(-1, 3, 4)
+    pc = np.einsum("eij,ej->ei", R[sc["obs_pose"], :, :3], sc["points_gt"][sc["obs_point"]]) + R[sc["obs_pose"], :, 3]
+    u = 1920.0 * (0.5 + np.arctan2(pc[:, 0], pc[:, 2]) / (2 * np.pi))
+    v = 960.0 * (0.5 + np.arcsin(pc[:, 1] / np.linalg.norm(pc, axis=1)) / np.pi)
+    return u, v
+
+
+def test_equirectangular_edges_recover_ground_truth_and_minimum():
+    """Equirectangular cameras (intrinsics rows {0, 0, cols, rows, 0}; equirectangular_reproj_edge.h:64-134): noise-free
+    observations bring the LM restatement back to the ground truth (which checks projection AND the analytic Jacobians:
+    wrong Jacobians stall LM), and with noise the end point is a stationary point of the independent numpy cost."""
+    sc = S.ba_scene(num_kf=8, num_lm=300, obs_per_lm=5, num_fixed=2, seed=7, outlier_frac=0.0, equirect=True)
+    assert (sc["intr"][:, :2] == 0).all() and (sc["obs_uvr"][:, 2] < 0).all()
+    u, v = _equirect_exact_obs(sc)
+    noisy = sc["obs_uvr"].copy()
+    sc["obs_uvr"][:, 0], sc["obs_uvr"][:, 1] = u, v
+    res = O.local_ba(sc, iters1=10, iters2=10)
+    assert res["stats"][1] < 1e-3 * res["stats"][0]
+    assert _rel_pose_err(res["pose_cw"], sc["pose_gt"]) < 2e-4
+    assert res["outlier"].sum() == 0
+    # noisy observations: compare the reached cost with a numerical-gradient check of the numpy cost
+    sc["obs_uvr"] = noisy
+    res = O.local_ba(sc, iters1=30, iters2=0)
+
+    def cost(pose_cw, pts):
+        R = pose_cw.reshape(-1, 3, 4)
+        pc = np.einsum("eij,ej->ei", R[sc["obs_pose"], :, :3], pts[sc["obs_point"]]) + R[sc["obs_pose"], :, 3]
+        uu = 1920.0 * (0.5 + np.arctan2(pc[:, 0], pc[:, 2]) / (2 * np.pi))
+        vv = 960.0 * (0.5 + np.arcsin(pc[:, 1] / np.linalg.norm(pc, axis=1)) / np.pi)
+        e2 = ((sc["obs_uvr"][:, 0] - uu) ** 2 + (sc["obs_uvr"][:, 1] - vv) ** 2) * sc["obs_inv_sigma_sq"]
+        d = float(sc["obs_huber"][0])
+        return np.where(e2 <= d * d, e2, 2 * d * np.sqrt(e2) - d * d).sum()
+
+    c0 = cost(res["pose_cw"], res["points"])
+    assert c0 < 0.5 * cost(sc["pose_cw"], sc["points"])
+    assert c0 <= cost(sc["pose_gt"], sc["points_gt"])            # a (local) minimum of the noisy cost lies below the ground truth's cost
+    rng = np.random.default_rng(0)
+    for _ in range(5):                                             # stationary: small random moves of the points do not lower it
+        dp = rng.normal(0, 1e-4, res["points"].shape)
+        assert cost(res["pose_cw"], res["points"] + dp) > c0 * (1 - 1e-6)
+
+
+def test_pose_optimizer_oracle_equirectangular():
+    sc = S.ba_scene(num_kf=3, num_lm=800, obs_per_lm=3, num_fixed=0, seed=4, outlier_frac=0.1, equirect=True)
+    sel = sc["obs_pose"] == 1
+    pos_w, uvr = sc["points_gt"][sc["obs_point"][sel]], sc["obs_uvr"][sel]
+    nv, pose, outl, st = O.pose_optimize(sc["pose_cw"][1], pos_w, uvr, sc["obs_inv_sigma_sq"][sel], sc["obs_huber"][sel], sc["intr"][1])
+    assert np.abs(pose - sc["pose_gt"][1]).max() < 0.1 * np.abs(sc["pose_cw"][1] - sc["pose_gt"][1]).max()
+    assert nv == len(outl) - outl.sum() and 0.05 * len(outl) < outl.sum() < 0.2 * len(outl)
