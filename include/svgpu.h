@@ -175,6 +175,21 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
                            const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                            float lowe_ratio, int mode, int32_t* match_q, int* num_matches);
 
+/* The same matcher with the candidate lists built ON THE DEVICE: data::assign_keypoints_to_grid (data/common.cc:83-108)
+ * bins the target keypoints, and query q gets the result of
+ *     get_keypoints_in_cell(q_xy[q], q_margin[q], q_min_level[q], q_max_level[q])            (data/common.cc:127-190)
+ * in the reference's order (cells column-major inside the window, keypoints of a cell in index order, level bounds < 0 =
+ * unbounded, strictly inside the margin square).  This is the loop that dominates projection::* / fuse on the CPU.
+ *   t_xy          nt x 2 undistorted keypoint positions; t_octave nt
+ *   grid          image bounds min_x max_x min_y max_y (camera::base img_bounds) and num_grid_cols / rows (default 64 x 48)
+ *   everything else as svgpu_match_candidates (no cand_skip: pair gates that need the object graph use the CSR entry point). */
+int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const float* q_xy, const float* q_margin,
+                         const int32_t* q_min_level, const int32_t* q_max_level, const uint8_t* q_valid, const float* q_angle,
+                         const float* q_xright, const float* q_xr_tol, const uint8_t* tdesc, const float* t_xy,
+                         const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_angle, const float* t_xright,
+                         float min_x, float max_x, float min_y, float max_y, int grid_cols, int grid_rows,
+                         int check_orientation, unsigned thr, float lowe_ratio, int mode, int32_t* match_q, int* num_matches);
+
 /* match::stereo::compute (match/stereo.cc:20-114): for every left keypoint the closest right keypoint in its row band
  * (rows +-2*scale, octave +-1, disparity in [0, focal_x_baseline / true_baseline], Hamming < 75), then the 11x11 L1 patch
  * slide (+-5 px) on the keypoint's pyramid level with parabolic sub-pixel refinement, finally the 2x-median correlation

@@ -61,6 +61,29 @@ struct CandProblem {
     int32_t* num;
 };
 
+// Device-side candidate lists: data::assign_keypoints_to_grid + data::get_keypoints_in_cell (data/common.cc:83-190)
+struct GridProblem {
+    const float* t_xy;        // nt x 2 undistorted keypoint positions
+    const int32_t* t_octave;  // nt
+    int nt;
+    float min_x, min_y;
+    double inv_w, inv_h;      // (double)cols / (max_x - min_x), (double)rows / (max_y - min_y)
+    int cols, rows;
+    int32_t* cell_of;         // nt: col * rows + row, or -1 outside the grid
+    int32_t* cell_off;        // cols * rows + 1
+    int32_t* cell_items;      // nt
+    const float* q_xy;        // nq x 2 reference points
+    const float* q_margin;    // nq
+    const int32_t* q_min_level;  // nq, < 0 = unbounded
+    const int32_t* q_max_level;
+    const uint8_t* q_valid;   // nullable
+    int nq;
+    int32_t* cand_off;        // nq + 1 (counts, then their exclusive scan)
+    int32_t* cand_idx;        // filled by the second walk
+};
+void sv_launch_grid_build(hipStream_t s, const GridProblem& G);                 // cell_of, cell_off, cell_items, cand_off (scanned)
+void sv_launch_grid_fill(hipStream_t s, const GridProblem& G);                  // cand_idx
+
 struct StereoProblem {
     const svgpu_keypoint* kl;
     const svgpu_keypoint* kr;

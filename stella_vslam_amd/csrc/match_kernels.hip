@@ -904,6 +904,94 @@ __global__ __launch_bounds__(256) void k_cand_replay(CandProblem P, int* __restr
     if (tid == 0) *P.num = s_changed;
 }
 
+// ------------------------------------------------------------------------------------------------ grid candidate lists
+// data::assign_keypoints_to_grid (data/common.cc:83-108) and data::get_keypoints_in_cell (:127-190) on the device, so that the
+// projection-family matchers need no host-built CSR: cells are x-major (col * rows + row), a cell lists its keypoints in
+// index order, a query scans cells col-major inside its window and keeps keypoints of the wanted levels strictly inside
+// the margin square -- the reference's candidate ORDER, which decides ties downstream.
+__global__ void k_grid_assign(GridProblem G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.nt) return;
+    const int cx = (int)floor((double)(G.t_xy[2 * i] - G.min_x) * G.inv_w), cy = (int)floor((double)(G.t_xy[2 * i + 1] - G.min_y) * G.inv_h);
+    int c = -1;
+    if (0 <= cx && cx < G.cols && 0 <= cy && cy < G.rows) {
+        c = cx * G.rows + cy;
+        atomicAdd(&G.cell_off[c], 1);  // counts; scanned in place afterwards
+    }
+    G.cell_of[i] = c;
+}
+// in-place exclusive scan of data[0..n) with the total written to data[n]; single workgroup
+__global__ __launch_bounds__(1024) void k_exclusive_scan(int32_t* __restrict__ data, int n) {
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? data[i] : 0;
+        s_part[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            const int add = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += add;
+            __syncthreads();
+        }
+        const int carry = s_carry;
+        if (i < n) data[i] = carry + s_part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s_part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) data[n] = s_carry;
+}
+// stable placement: rank inside the cell = number of earlier keypoints of the same cell
+__global__ void k_grid_place(GridProblem G) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G.nt) return;
+    const int c = G.cell_of[i];
+    if (c < 0) return;
+    int rank = 0;
+    for (int j = 0; j < i; ++j) rank += G.cell_of[j] == c;
+    G.cell_items[G.cell_off[c] + rank] = i;
+}
+template <bool FILL>
+__global__ void k_grid_walk(GridProblem G) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= G.nq) return;
+    int n = 0;
+    int32_t* out = FILL ? G.cand_idx + G.cand_off[q] : nullptr;
+    const bool live = !G.q_valid || G.q_valid[q];
+    if (live) {
+        const float ref_x = G.q_xy[2 * q], ref_y = G.q_xy[2 * q + 1], margin = G.q_margin[q];
+        const int min_level = G.q_min_level ? G.q_min_level[q] : -1, max_level = G.q_max_level ? G.q_max_level[q] : -1;
+        int lo_x = (int)floor((double)(ref_x - G.min_x - margin) * G.inv_w), hi_x = (int)ceil((double)(ref_x - G.min_x + margin) * G.inv_w);
+        int lo_y = (int)floor((double)(ref_y - G.min_y - margin) * G.inv_h), hi_y = (int)ceil((double)(ref_y - G.min_y + margin) * G.inv_h);
+        lo_x = max(lo_x, 0);
+        lo_y = max(lo_y, 0);
+        hi_x = min(hi_x, G.cols - 1);
+        hi_y = min(hi_y, G.rows - 1);
+        if (lo_x < G.cols && 0 <= hi_x && lo_y < G.rows && 0 <= hi_y)
+            for (int cx = lo_x; cx <= hi_x; ++cx)
+                for (int cy = lo_y; cy <= hi_y; ++cy) {
+                    const int c = cx * G.rows + cy;
+                    for (int k = G.cell_off[c]; k < G.cell_off[c + 1]; ++k) {
+                        const int idx = G.cell_items[k];
+                        const int oct = G.t_octave[idx];
+                        if (0 <= min_level && oct < min_level) continue;
+                        if (0 <= max_level && max_level < oct) continue;
+                        const float dx = G.t_xy[2 * idx] - ref_x, dy = G.t_xy[2 * idx + 1] - ref_y;
+                        if (fabsf(dx) < margin && fabsf(dy) < margin) {
+                            if (FILL) out[n] = idx;
+                            ++n;
+                        }
+                    }
+                }
+    }
+    if (!FILL) G.cand_off[q] = n;
+}
+
 // area::match_in_consistent_area (match/area.cc:8-98) on the same CSR lists and distances (mode SVGPU_MATCH_AREA).
 // Its state is not monotone (a later, closer query takes a target away from its holder), so the loop over the queries
 // stays sequential: ONE wave walks the queries in order, its lanes stride over the candidates of the current query
@@ -1146,6 +1234,18 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
         attr_done = true;
     }
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
+}
+void sv_launch_grid_build(hipStream_t s, const GridProblem& G) {
+    const int nc = G.cols * G.rows;
+    (void)hipMemsetAsync(G.cell_off, 0, (size_t)(nc + 1) * sizeof(int32_t), s);
+    if (G.nt > 0) hipLaunchKernelGGL(k_grid_assign, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cell_off, nc);
+    if (G.nt > 0) hipLaunchKernelGGL(k_grid_place, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
+    if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<false>, dim3((G.nq + 63) / 64), dim3(64), 0, s, G);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cand_off, G.nq);
+}
+void sv_launch_grid_fill(hipStream_t s, const GridProblem& G) {
+    if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<true>, dim3((G.nq + 63) / 64), dim3(64), 0, s, G);
 }
 void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match, unsigned* mdist) {
     SvProfScope ps(ctx, s, "k_cand");

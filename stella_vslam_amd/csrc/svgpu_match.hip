@@ -269,6 +269,126 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     return SVGPU_OK;
 }
 
+int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const float* q_xy, const float* q_margin,
+                         const int32_t* q_min_level, const int32_t* q_max_level, const uint8_t* q_valid, const float* q_angle,
+                         const float* q_xright, const float* q_xr_tol, const uint8_t* tdesc, const float* t_xy,
+                         const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_angle, const float* t_xright,
+                         float min_x, float max_x, float min_y, float max_y, int grid_cols, int grid_rows,
+                         int check_orientation, unsigned thr, float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
+    if (!ctx || nq < 0 || nt < 0 || !num_matches || mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA || grid_cols < 1 || grid_rows < 1
+        || (size_t)grid_cols * grid_rows > (size_t(1) << 22) || !(min_x < max_x) || !(min_y < max_y))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: bad arguments");
+    *num_matches = 0;
+    if (nq == 0) return SVGPU_OK;
+    if (!match_q) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: null pointer");
+    for (int q = 0; q < nq; ++q) match_q[q] = -1;
+    if (nt == 0) return SVGPU_OK;
+    if (!qdesc || !q_xy || !q_margin || !tdesc || !t_xy || !t_octave || (check_orientation && (!q_angle || !t_angle))
+        || ((q_xright || t_xright || q_xr_tol) && !(q_xright && t_xright && q_xr_tol)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: inconsistent inputs");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int ncell = grid_cols * grid_rows;
+    const size_t need1 = pad((size_t)nq * 32) + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 4 * pad((size_t)nt * 4) + pad(nt) + pad((size_t)nq * 8)
+                         + 6 * pad((size_t)nq * 4) + pad(nq) + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4)
+                         + 2 * pad((size_t)nt * 4) + 1024;
+    int total = 0;
+    // Pass 0 builds the grid and the list sizes and reads the total back; the scratch arena may then have to grow for the
+    // lists, which discards its contents, so pass 1 repeats the (cheap) uploads and the grid build in the final arena.
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t need = need1 + (pass ? pad((size_t)total * 4) + pad((size_t)total * 2) : 0);
+        const bool regrow = need > ctx->scratch_bytes;  // pass 1 without regrowth: the arena of pass 0 is still valid, same layout
+        int rc = sv_ensure_scratch(ctx, need);
+        if (rc) return rc;
+        Arena A(ctx->d_scratch);
+        CandProblem P{};
+        GridProblem G{};
+#define UP(dst, T, src, n)                                                                          \
+    T* dst = nullptr;                                                                               \
+    if (src) {                                                                                      \
+        dst = A.take<T>(n);                                                                         \
+        if (!pass || regrow) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+    }
+        UP(d_q, uint8_t, qdesc, (size_t)nq * 32)
+        UP(d_t, uint8_t, tdesc, (size_t)nt * 32)
+        UP(d_txy, float, t_xy, (size_t)nt * 2)
+        UP(d_toct, int32_t, t_octave, nt)
+        UP(d_occ, uint8_t, occupied, nt)
+        UP(d_ta, float, t_angle, nt)
+        UP(d_tx, float, t_xright, nt)
+        UP(d_qxy, float, q_xy, (size_t)nq * 2)
+        UP(d_qm, float, q_margin, nq)
+        UP(d_qlo, int32_t, q_min_level, nq)
+        UP(d_qhi, int32_t, q_max_level, nq)
+        UP(d_qv, uint8_t, q_valid, nq)
+        UP(d_qa, float, q_angle, nq)
+        UP(d_qx, float, q_xright, nq)
+        UP(d_qtol, float, q_xr_tol, nq)
+#undef UP
+        G.t_xy = d_txy;
+        G.t_octave = d_toct;
+        G.nt = nt;
+        G.min_x = min_x;
+        G.min_y = min_y;
+        G.inv_w = (double)grid_cols / (max_x - min_x);  // float difference, double quotient: data/common.cc:86-87 via camera::base
+        G.inv_h = (double)grid_rows / (max_y - min_y);
+        G.cols = grid_cols;
+        G.rows = grid_rows;
+        G.cell_of = A.take<int32_t>(nt);
+        G.cell_off = A.take<int32_t>(ncell + 1);
+        G.cell_items = A.take<int32_t>(nt);
+        G.q_xy = d_qxy;
+        G.q_margin = d_qm;
+        G.q_min_level = d_qlo;
+        G.q_max_level = d_qhi;
+        G.q_valid = d_qv;
+        G.nq = nq;
+        G.cand_off = A.take<int32_t>(nq + 1);
+        P.match_q = A.take<int32_t>(nq);
+        P.num = A.take<int32_t>(1);
+        int* owner = A.take<int>(nt);
+        int* match = A.take<int>(nq);
+        unsigned* mdist = A.take<unsigned>(nt);
+        if (!pass || regrow) sv_launch_grid_build(s, G);
+        if (!pass) {
+            SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            if (total == 0) return SVGPU_OK;
+            continue;
+        }
+        G.cand_idx = A.take<int32_t>(total);
+        P.dist = A.take<uint16_t>(total);
+        sv_launch_grid_fill(s, G);
+        P.qdesc = (const uint32_t*)d_q;
+        P.tdesc = (const uint32_t*)d_t;
+        P.t_octave = d_toct;
+        P.nq = nq;
+        P.nt = nt;
+        P.cand_off = G.cand_off;
+        P.cand_idx = G.cand_idx;
+        P.cand_skip = nullptr;
+        P.q_valid = d_qv;
+        P.occupied = d_occ;
+        P.q_angle = d_qa;
+        P.t_angle = d_ta;
+        P.check_orientation = check_orientation;
+        P.q_xright = d_qx;
+        P.t_xright = d_tx;
+        P.q_xr_tol = d_qtol;
+        P.thr = thr;
+        P.lowe_ratio = lowe_ratio;
+        P.mode = mode;
+        sv_launch_cand(ctx, s, P, owner, match, mdist);
+        SV_HIP(ctx, hipGetLastError());
+        int32_t num = 0;
+        SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        *num_matches = num;
+    }
+    return SVGPU_OK;
+}
+
 int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_keypoint* kps_left, const uint8_t* desc_left,
                        int n_left, const svgpu_keypoint* kps_right, const uint8_t* desc_right, int n_right,
                        float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {

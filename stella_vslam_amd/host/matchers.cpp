@@ -61,6 +61,41 @@ unsigned int projection::match(const query_set& q, const data::frame_observation
     return (unsigned int)num;
 }
 
+unsigned int projection::match_in_cells(const query_set& q, const std::vector<cv::Point2f>& ref_pts, const std::vector<float>& margins,
+                                        const std::vector<int>& min_levels, const std::vector<int>& max_levels,
+                                        const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied,
+                                        const float img_bounds[4], int num_grid_cols, int num_grid_rows, int mode, unsigned int hamm_dist_thr,
+                                        std::vector<int>& matched_idx_for_query) const {
+    const int nq = q.descriptors.rows, nt = (int)frm_obs.undist_keypts_.size();
+    std::vector<float> ta(nt), txy(2 * (size_t)nt), qxy(2 * (size_t)nq);
+    std::vector<int32_t> toct(nt), qlo(min_levels.begin(), min_levels.end()), qhi(max_levels.begin(), max_levels.end());
+    for (int i = 0; i < nt; ++i) {
+        ta[i] = frm_obs.undist_keypts_[i].angle;
+        toct[i] = frm_obs.undist_keypts_[i].octave;
+        txy[2 * i] = frm_obs.undist_keypts_[i].pt.x;
+        txy[2 * i + 1] = frm_obs.undist_keypts_[i].pt.y;
+    }
+    for (int i = 0; i < nq; ++i) {
+        qxy[2 * i] = ref_pts[i].x;
+        qxy[2 * i + 1] = ref_pts[i].y;
+    }
+    const auto qd = pack_rows(q.descriptors), td = pack_rows(frm_obs.descriptors_);
+    const bool stereo = !frm_obs.stereo_x_right_.empty() && !q.x_right.empty();
+    matched_idx_for_query.assign((size_t)std::max(nq, 1), -1);
+    int num = 0;
+    check(ctx_, svgpu_match_in_cells(ctx_, qd.data(), nq, qxy.data(), margins.data(), qlo.empty() ? nullptr : qlo.data(),
+                                     qhi.empty() ? nullptr : qhi.data(), q.valid.empty() ? nullptr : q.valid.data(),
+                                     q.angle.empty() ? nullptr : q.angle.data(), stereo ? q.x_right.data() : nullptr,
+                                     stereo ? q.x_right_tol.data() : nullptr, td.data(), txy.data(), toct.data(), nt,
+                                     occupied.empty() ? nullptr : occupied.data(), ta.data(), stereo ? frm_obs.stereo_x_right_.data() : nullptr,
+                                     img_bounds[0], img_bounds[1], img_bounds[2], img_bounds[3], num_grid_cols, num_grid_rows,
+                                     (check_orientation_ && !q.angle.empty()) ? 1 : 0, hamm_dist_thr, lowe_ratio_, mode,
+                                     matched_idx_for_query.data(), &num),
+          "svgpu_match_in_cells");
+    matched_idx_for_query.resize((size_t)nq);
+    return (unsigned int)num;
+}
+
 void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
     const int nl = (int)keypts_left_.size(), nr = (int)keypts_right_.size();
     stereo_x_right.assign((size_t)nl, -1.0f);

@@ -59,6 +59,15 @@ public:
     //! and fuse::detect_duplication (BEST_ONLY), bow_tree::match_frame_and_keyframe (RATIO), *::match_for_triangulation (TRIANGULATION)
     unsigned int match(const query_set& q, const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied,
                        int mode, unsigned int hamm_dist_thr, std::vector<int>& matched_idx_for_query) const;
+
+    //! Same, with the candidate lists built on the device: query i scans
+    //! frm.get_keypoints_in_cell(ref_pts[i].x, ref_pts[i].y, margins[i], min_levels[i], max_levels[i]) (data/common.cc:127-190);
+    //! q.cand_off / q.cand_idx / q.cand_skip are ignored.  img_bounds = {min_x, max_x, min_y, max_y} of camera::base.
+    unsigned int match_in_cells(const query_set& q, const std::vector<cv::Point2f>& ref_pts, const std::vector<float>& margins,
+                                const std::vector<int>& min_levels, const std::vector<int>& max_levels,
+                                const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied, const float img_bounds[4],
+                                int num_grid_cols, int num_grid_rows, int mode, unsigned int hamm_dist_thr,
+                                std::vector<int>& matched_idx_for_query) const;
 };
 
 //! match::area (match/area.h): the monocular initialiser's matcher on the same flattened inputs.  query_set = the keypoints of

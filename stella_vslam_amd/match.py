@@ -94,6 +94,27 @@ class projection(base):
         return out, num.value
 
 
+    def match_in_cells(self, qdesc, q_xy, q_margin, tdesc, t_xy, t_octave, bounds, mode, thr, q_min_level=None, q_max_level=None,
+                       q_valid=None, occupied=None, q_angle=None, t_angle=None, q_xright=None, t_xright=None, q_xr_tol=None,
+                       grid_cols=64, grid_rows=48):
+        """Same matcher, candidate lists built on the device: query q scans frm.get_keypoints_in_cell(q_xy[q], q_margin[q],
+        q_min_level[q], q_max_level[q]) (data/common.cc:127-190) over the grid of data::assign_keypoints_to_grid."""
+        qd, td = _c(qdesc, np.uint8), _c(tdesc, np.uint8)
+        qxy, txy, qm = _c(q_xy, np.float32), _c(t_xy, np.float32), _c(q_margin, np.float32)
+        toct, qlo, qhi = _c(t_octave, np.int32), _c(q_min_level, np.int32), _c(q_max_level, np.int32)
+        qv, occ = _c(q_valid, np.uint8), _c(occupied, np.uint8)
+        qa, ta = _c(q_angle, np.float32), _c(t_angle, np.float32)
+        qx, tx, qt = _c(q_xright, np.float32), _c(t_xright, np.float32), _c(q_xr_tol, np.float32)
+        out = np.full(len(qd), -1, np.int32)
+        num = C.c_int(0)
+        self.ctx.check(lib().svgpu_match_in_cells(self.ctx.handle, _p(qd), len(qd), _p(qxy), _p(qm), _p(qlo), _p(qhi), _p(qv), _p(qa), _p(qx),
+                                                  _p(qt), _p(td), _p(txy), _p(toct), len(td), _p(occ), _p(ta), _p(tx),
+                                                  C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
+                                                  grid_cols, grid_rows, int(self.check_orientation_ and qa is not None and ta is not None), C.c_uint(thr),
+                                                  C.c_float(self.lowe_ratio_), mode, _p(out), C.byref(num)), "svgpu_match_in_cells")
+        return out, num.value
+
+
 class area(base):
     """match/area.h (the monocular initialiser's matcher).  match_in_consistent_area (match/area.cc:8-98) on flattened inputs:
     level-0 keypoints of frame 1 are the queries, the candidate list of query idx_1 is

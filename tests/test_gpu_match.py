@@ -208,3 +208,44 @@ def test_area_matcher_contested_targets(M, ctx):
     exp = O.match_candidates(d1, d2, cand_off, cand_idx, thr=50, lowe_ratio=0.95, mode=O.MODE_AREA)
     assert 30 < (exp >= 0).sum() <= n2
     assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+
+
+@pytest.mark.parametrize("mode,seed", [(0, 0), (1, 1), (2, 2)])
+def test_match_in_cells_builds_the_reference_candidate_lists(M, ctx, mode, seed):
+    """Candidate lists built on the device (assign_keypoints_to_grid + get_keypoints_in_cell, data/common.cc:83-190) give the
+    same matches as the oracle run on the CSR that the oracle's own grid functions produce (same order, same ties)."""
+    seq = S.frame_sequence(2, seed=0x5EED + 3 * seed)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    off_g, items = O.assign_keypoints_to_grid(k1["x"], k1["y"], bounds)
+    sf = O.scale_tables(1.2, 8)[0]
+    rng = np.random.default_rng(seed)
+    q_xy = np.stack([k0["x"] - 3.0 + rng.normal(0, 2, len(k0)), k0["y"] - 1.0 + rng.normal(0, 2, len(k0))], 1).astype(np.float32)
+    q_xy[::50] += 700.0                                        # some reference points far outside the image
+    q_margin = (15.0 * sf[k0["octave"]]).astype(np.float32)
+    q_lo = np.maximum(0, k0["octave"] - 1).astype(np.int32)
+    q_hi = np.minimum(7, k0["octave"] + 1).astype(np.int32)
+    q_lo[::7] = -1                                             # unbounded below / above for some queries
+    q_hi[::11] = -1
+    cand_off, cand_idx = [0], []
+    for q in range(len(k0)):
+        c = O.get_keypoints_in_cell(k1["x"], k1["y"], k1["octave"], off_g, items, bounds, float(q_xy[q, 0]), float(q_xy[q, 1]),
+                                    float(q_margin[q]), int(q_lo[q]), int(q_hi[q]))
+        cand_idx += c.tolist()
+        cand_off.append(len(cand_idx))
+    occupied = (rng.uniform(size=len(k1)) < 0.05).astype(np.uint8)
+    q_valid = (rng.uniform(size=len(k0)) < 0.9).astype(np.uint8)
+    kw = dict(q_valid=q_valid, occupied=occupied, q_angle=k0["angle"], t_angle=k1["angle"])
+    t_xy = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    got, num = M.projection(0.8, True, ctx).match_in_cells(d0, q_xy, q_margin, d1, t_xy, k1["octave"], bounds, mode, 100,
+                                                           q_min_level=q_lo, q_max_level=q_hi, **kw)
+    exp = O.match_candidates(d0, d1, cand_off, cand_idx, check_orientation=True, thr=100, lowe_ratio=0.8, mode=mode, t_octave=k1["octave"], **kw)
+    assert (exp >= 0).sum() > 800
+    assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+    # same call again (scratch arena already large enough: single-pass path) and an empty window everywhere
+    got2, _ = M.projection(0.8, True, ctx).match_in_cells(d0, q_xy, q_margin, d1, t_xy, k1["octave"], bounds, mode, 100,
+                                                          q_min_level=q_lo, q_max_level=q_hi, **kw)
+    assert np.array_equal(got2, exp)
+    none, n0 = M.projection(0.8, True, ctx).match_in_cells(d0, q_xy + 5000.0, q_margin, d1, t_xy, k1["octave"], bounds, mode, 100)
+    assert n0 == 0 and (none == -1).all()
