@@ -1161,10 +1161,10 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
         SvProfScope ps(ctx, s, "ba_solve");
         if (D.chol_in_lds) {
             const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-                attr_set = true;
+            static size_t attr_bytes = 0;  // dynamic LDS above 64 KB must be allowed explicitly; ask for what this system needs
+            if (lds > attr_bytes) {
+                if (hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_bytes = lds;
+                else (void)hipGetLastError();  // do not leave a sticky error behind; an impossible size fails the launch below
             }
             hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
         }

@@ -1230,7 +1230,8 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     lds += (size_t)pool_rows * (BF_LIST - 4) * sizeof(uint32_t);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+            (void)hipGetLastError();  // never leave a sticky error behind
         attr_done = true;
     }
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);

@@ -15,6 +15,9 @@
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D);
+size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap);
+int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int2* pairs_out,
+                      std::vector<int>& dense_off_host);
 
 namespace {
 
@@ -36,7 +39,8 @@ struct HostStructure {
     std::vector<uint8_t> pt_free;
     std::vector<int> pe_off, pe_idx;
     std::vector<int> blk_off;
-    std::vector<int2> blk_pairs, blk_ab;
+    std::vector<int2> blk_ab;
+    size_t num_pairs = 0;  // the pairs themselves live on the device only
     int nP = 0, nL = 0;
 };
 
@@ -106,55 +110,26 @@ void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose,
         for (int e = 0; e < E; ++e)
             if (!level[e] && H.pose_slot[e_pose[e]] >= 0) H.pe_idx[fill[H.pose_slot[e_pose[e]]]++] = e;
     }
-    // upper blocks (a <= b) of the reduced system and their (edge, edge) pairs: count, then fill
-    const size_t nb_dense = (size_t)H.nP * (H.nP + 1) / 2;
-    auto bidx = [&](int a, int b) { return (size_t)a * H.nP - (size_t)a * (a - 1) / 2 + (b - a); };  // a <= b
-    std::vector<int> cnt(nb_dense + 1, 0);
-    std::vector<int> tmp;  // coupled edges of one landmark
-    auto for_pairs = [&](auto&& f) {
-        for (int l = 0; l < L; ++l) {
-            if (!H.pt_free[l]) continue;
-            tmp.clear();
-            for (int e = lm_off[l]; e < lm_off[l + 1]; ++e)
-                if (!level[e] && H.pose_slot[e_pose[e]] >= 0) tmp.push_back(e);
-            for (size_t i = 0; i < tmp.size(); ++i)
-                for (size_t j = i; j < tmp.size(); ++j) {
-                    int e1 = tmp[i], e2 = tmp[j];
-                    int a = H.pose_slot[e_pose[e1]], b = H.pose_slot[e_pose[e2]];
-                    if (a > b) {
-                        std::swap(a, b);
-                        std::swap(e1, e2);
-                    }
-                    f(a, b, e1, e2);
-                    if (a == b && e1 != e2) f(a, b, e2, e1);  // two observations from one pose: both cross terms
-                }
-        }
-    };
-    for_pairs([&](int a, int b, int, int) { cnt[bidx(a, b)]++; });
-    // keep every diagonal block (it carries Hpp + lambda I) and every non-empty off-diagonal block
+    // the (edge, edge) pair lists of the upper blocks (a <= b) are built on the device: sv_ba_build_pairs + compact_blocks
+}
+
+// dense block offsets (from the device) -> kept blocks: every diagonal block (it carries Hpp + lambda I) and every non-empty
+// off-diagonal block, in (a, b) order; the sorted pair array needs no compaction (empty blocks hold no pairs)
+void compact_blocks(const std::vector<int>& dense_off, HostStructure& H) {
     H.blk_ab.clear();
-    H.blk_off.assign(1, 0);
-    std::vector<int> dense_to_blk(nb_dense, -1);
+    H.blk_off.clear();
+    size_t k = 0;
     for (int a = 0; a < H.nP; ++a)
-        for (int b = a; b < H.nP; ++b) {
-            const size_t k = bidx(a, b);
-            if (a == b || cnt[k] > 0) {
-                dense_to_blk[k] = (int)H.blk_ab.size();
+        for (int b = a; b < H.nP; ++b, ++k)
+            if (a == b || dense_off[k + 1] > dense_off[k]) {
                 int2 ab;
                 ab.x = a;
                 ab.y = b;
                 H.blk_ab.push_back(ab);
-                H.blk_off.push_back(H.blk_off.back() + cnt[k]);
+                H.blk_off.push_back(dense_off[k]);
             }
-        }
-    H.blk_pairs.resize(H.blk_off.back());
-    std::vector<int> fill(H.blk_off.begin(), H.blk_off.end() - 1);
-    for_pairs([&](int a, int b, int e1, int e2) {
-        int2 p;
-        p.x = e1;
-        p.y = e2;
-        H.blk_pairs[fill[dense_to_blk[bidx(a, b)]]++] = p;
-    });
+    H.blk_off.push_back(dense_off.empty() ? 0 : dense_off.back());
+    H.num_pairs = (size_t)(dense_off.empty() ? 0 : dense_off.back());
 }
 
 }  // namespace
@@ -237,7 +212,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         pair_cap += k * k;
     }
     const size_t nb_cap = (size_t)P * (P + 1) / 2;
-    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1));
+    const size_t pair_scratch = sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap);
+    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -282,6 +258,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int2* d_blk_pairs = A.take<int2>(pair_cap);
     int2* d_blk_ab = A.take<int2>(nb_cap);
     int* d_blk_off = A.take<int>(nb_cap + 1);
+    char* d_pair_scratch = A.take<char>(pair_scratch);
     if (A.off > ctx->scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: internal arena overflow");
     D.e_pose = d_e_pose;
     D.e_point = d_e_point;
@@ -381,10 +358,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             build_structure(*pr, e_pose, e_point, lm_off, level, pa_override, HS);
             have_lists = true;
         }
-        if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.blk_pairs.size(), HS.blk_ab.size());
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
-        D.NB = (int)HS.blk_ab.size();
         D.chol_in_lds = D.n <= 192 && sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 12 * 1024;
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
@@ -394,11 +369,16 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
             H2D(d_pe_off, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
             if (!HS.pe_idx.empty()) H2D(d_pe_idx, HS.pe_idx.data(), 4 * HS.pe_idx.size());
+            std::vector<int> dense_off;
+            int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, dense_off);
+            if (rp) return rp;
+            compact_blocks(dense_off, HS);
             H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
             if (!HS.blk_ab.empty()) H2D(d_blk_ab, HS.blk_ab.data(), 8 * HS.blk_ab.size());
-            if (!HS.blk_pairs.empty()) H2D(d_blk_pairs, HS.blk_pairs.data(), 8 * HS.blk_pairs.size());
         }
         else sv_ba_zero_inactive(s, D);
+        D.NB = (int)HS.blk_ab.size();
+        if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size());
         return SVGPU_OK;
     };
 
