@@ -54,10 +54,12 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         return 2
+    local_rank %= torch.cuda.device_count()  # one rank per GPU on a real node; lets the multi-rank path be exercised on fewer GPUs
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm; BENCH_DIST_BACKEND=gloo only exists to test the multi-rank control flow on a single GPU
+        dist.init_process_group(os.environ.get("BENCH_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from stella_vslam_amd import feature, synthetic
     from stella_vslam_amd._lib import lib
