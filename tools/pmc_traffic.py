@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes as MI355X_MICROARCH.md prescribes) of
 `bench.py` into profiles/<tag>_traffic.json: mean HBM-side bytes per launch of every kernel.
-FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x
-(guide, section HBM); the kernels here read 4 B/lane or bytes, an access width the guide lists as uncalibrated, so the raw
-value is kept and the caveat is recorded in the file.
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a streaming read
+(MI355X_MICROARCH.md, section HBM, states it for 16 B/lane; tools/ubench/pmc_calib.hip measured the same factor for 1, 4, 8
+and 16 B/lane on this toolchain -- profiles/r01_pmc_calibration.json) and WRITE_SIZE is exact: fetch is doubled here.
 usage: tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_traffic.json
 """
 import json, sys
@@ -16,14 +16,15 @@ def per_kernel(d, counter):
     return t.groupby("k")["Counter_Value"].mean()
 
 f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"unit": "bytes per launch (FETCH_SIZE / WRITE_SIZE KiB x 1024, mean over the launches of the run)",
-       "caveat": "gfx950: FETCH_SIZE halves wide 16 B/lane streams; these kernels use 4 B/lane or byte accesses (uncalibrated width), "
-                 "values kept raw; Infinity-Cache hits are included", "kernels": {}}
+FETCH_CORRECTION = 2.0  # profiles/r01_pmc_calibration.json
+out = {"unit": "bytes per launch (FETCH_SIZE KiB x 1024 x 2, WRITE_SIZE KiB x 1024; mean over the launches of the run)",
+       "caveat": "gfx950: FETCH_SIZE counts half of the streamed bytes at every access width (calibrated, factor 2 applied); "
+                 "Infinity-Cache hits are included", "kernels": {}}
 alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
 for k in sorted(set(f.index) | set(w.index)):
     if not k.startswith("k_"):
         continue
-    fe, wr = float(f.get(k, 0)) * 1024, float(w.get(k, 0)) * 1024
+    fe, wr = float(f.get(k, 0)) * 1024 * FETCH_CORRECTION, float(w.get(k, 0)) * 1024
     out["kernels"][alias.get(k, k)] = {"fetch": round(fe), "write": round(wr), "total": round(fe + wr)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
