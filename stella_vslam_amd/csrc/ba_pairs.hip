@@ -79,8 +79,8 @@ __global__ void k_pair_offsets(const unsigned* __restrict__ keys, int n, int nb_
 
 size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap) {
     size_t t1 = 0, t2 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
                                        (unsigned long long*)nullptr, (int)pair_cap);
     const size_t t = t1 > t2 ? t1 : t2;
     return ((t + 255) & ~size_t(255)) + 2 * (((size_t)(L + 2) * 4 + 255) & ~size_t(255)) + (((pair_cap * 4) + 255) & ~size_t(255)) * 2
@@ -101,8 +101,8 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
         return (void*)r;
     };
     size_t t1 = 0, t2 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
-    hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
                                        (unsigned long long*)nullptr, (int)pair_cap);
     const size_t tbytes = t1 > t2 ? t1 : t2;
     void* temp = take(tbytes);

@@ -56,7 +56,7 @@ struct CandProblem {
     unsigned thr;
     float lowe_ratio;
     int mode;
-    uint16_t* dist;           // one per CSR entry
+    uint32_t* dist;           // one per CSR entry: (distance << 22) | target index, 0xFFFFFFFF = gated out (targets < 2^22)
     int32_t* match_q;
     int32_t* num;
 };

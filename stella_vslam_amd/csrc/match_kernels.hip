@@ -819,7 +819,7 @@ __global__ void k_cand_dist(CandProblem P) {
             if (P.q_xr_tol[q] < err) gated = true;
         }
         if (!gated && P.check_orientation && fabsf(angle_diff(P.q_angle[q], P.t_angle[t])) > 30.0f) gated = true;
-        P.dist[c] = gated ? (uint16_t)0xFFFF : (uint16_t)hamming256(qd, P.tdesc + (size_t)t * 8);
+        P.dist[c] = gated ? 0xFFFFFFFFu : ((uint32_t)hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
     }
 }
 
@@ -830,12 +830,12 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
     const bool tri = P.mode == SVGPU_MATCH_TRIANGULATION;
     unsigned best = tri ? P.thr : MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
     int best_lvl = -1, second_lvl = -1, best_idx = -1;
-    for (int c = lo; c < hi; ++c) {
-        const unsigned d = P.dist[c];
-        if (d == 0xFFFFu) continue;
-        const int t = P.cand_idx[c];
-        if (owner[t] < q) continue;  // occupied before this query (initially, or by an earlier query)
-        if (tri && (P.thr < d || best < d)) continue;  // bow_tree.cc:96-98 / robust.cc:89-91
+    auto visit = [&](uint32_t e) {
+        if (e == 0xFFFFFFFFu) return;
+        const unsigned d = e >> 22;
+        const int t = (int)(e & 0x3FFFFFu);
+        if (owner[t] < q) return;  // occupied before this query (initially, or by an earlier query)
+        if (tri && (P.thr < d || best < d)) return;  // bow_tree.cc:96-98 / robust.cc:89-91
         if (d < best) {
             second = best;
             best = d;
@@ -847,6 +847,14 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
             second_lvl = P.t_octave ? P.t_octave[t] : 0;
             second = d;
         }
+    };
+    for (int c = lo; c < hi; c += 4) {  // four independent loads in flight per trip: the walk is latency-bound
+        const uint32_t e0 = P.dist[c], e1 = c + 1 < hi ? P.dist[c + 1] : 0xFFFFFFFFu, e2 = c + 2 < hi ? P.dist[c + 2] : 0xFFFFFFFFu,
+                       e3 = c + 3 < hi ? P.dist[c + 3] : 0xFFFFFFFFu;
+        visit(e0);
+        visit(e1);
+        visit(e2);
+        visit(e3);
     }
     if (P.mode == SVGPU_MATCH_RATIO_SAME_OCTAVE) {
         if (best <= P.thr) {
@@ -865,20 +873,23 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
     return best_idx;
 }
 
-__global__ __launch_bounds__(256) void k_cand_replay(CandProblem P, int* __restrict__ owner, int* __restrict__ match) {
+__global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds) {
+    extern __shared__ int s_cand[];
     __shared__ int s_changed;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int* owner = use_lds ? s_cand : g_owner;
+    int* match = use_lds ? s_cand + P.nt : g_match;
     auto reset_owner = [&]() {
-        for (int t = tid; t < P.nt; t += 256) owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;
+        for (int t = tid; t < P.nt; t += nthr) owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;
     };
     reset_owner();
-    for (int q = tid; q < P.nq; q += 256) match[q] = -2;
+    for (int q = tid; q < P.nq; q += nthr) match[q] = -2;
     __syncthreads();
     for (int sweep = 0; sweep <= P.nq; ++sweep) {
         if (tid == 0) s_changed = 0;
         __syncthreads();
         int local_changed = 0;
-        for (int q = tid; q < P.nq; q += 256) {
+        for (int q = tid; q < P.nq; q += nthr) {
             const int d = cand_decide(P, q, owner);
             if (d != match[q]) local_changed = 1;
             match[q] = d;
@@ -888,12 +899,12 @@ __global__ __launch_bounds__(256) void k_cand_replay(CandProblem P, int* __restr
         if (!s_changed) break;
         reset_owner();
         __syncthreads();
-        for (int q = tid; q < P.nq; q += 256)
+        for (int q = tid; q < P.nq; q += nthr)
             if (match[q] >= 0) atomicMin(&owner[match[q]], q);
         __syncthreads();
     }
     int local = 0;
-    for (int q = tid; q < P.nq; q += 256) {
+    for (int q = tid; q < P.nq; q += nthr) {
         P.match_q[q] = match[q];
         local += match[q] >= 0;
     }
@@ -946,22 +957,29 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(int32_t* __restrict__ d
     }
     if (tid == 0) data[n] = s_carry;
 }
-// stable placement: rank inside the cell = number of earlier keypoints of the same cell
-__global__ void k_grid_place(GridProblem G) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G.nt) return;
-    const int c = G.cell_of[i];
-    if (c < 0) return;
+// stable placement: rank inside the cell = number of earlier keypoints of the same cell (cell ids stream through LDS tiles)
+__global__ __launch_bounds__(256) void k_grid_place(GridProblem G) {
+    __shared__ int s_cell[1024];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = i < G.nt ? G.cell_of[i] : -1;
+    const int last = min(blockIdx.x * 256 + 255, G.nt - 1);  // tiles beyond the block's last keypoint hold no earlier keypoint
     int rank = 0;
-    for (int j = 0; j < i; ++j) rank += G.cell_of[j] == c;
-    G.cell_items[G.cell_off[c] + rank] = i;
+    for (int base = 0; base <= last; base += 1024) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 1024; k += 256) s_cell[k] = base + k < G.nt ? G.cell_of[base + k] : -2;
+        __syncthreads();
+        const int m = min(1024, i - base);  // earlier keypoints only
+        for (int k = 0; k < m; ++k) rank += s_cell[k] == c;
+    }
+    if (c >= 0) G.cell_items[G.cell_off[c] + rank] = i;
 }
+// one wave per query: the lanes take the cells of the window (column-major = the reference's scan order), count their
+// keypoints that pass the level and margin tests, and a wave prefix sum gives every cell its place in the query's list
 template <bool FILL>
-__global__ void k_grid_walk(GridProblem G) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_grid_walk(GridProblem G) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= G.nq) return;
-    int n = 0;
-    int32_t* out = FILL ? G.cand_idx + G.cand_off[q] : nullptr;
+    int total = 0;
     const bool live = !G.q_valid || G.q_valid[q];
     if (live) {
         const float ref_x = G.q_xy[2 * q], ref_y = G.q_xy[2 * q + 1], margin = G.q_margin[q];
@@ -972,24 +990,45 @@ __global__ void k_grid_walk(GridProblem G) {
         lo_y = max(lo_y, 0);
         hi_x = min(hi_x, G.cols - 1);
         hi_y = min(hi_y, G.rows - 1);
-        if (lo_x < G.cols && 0 <= hi_x && lo_y < G.rows && 0 <= hi_y)
-            for (int cx = lo_x; cx <= hi_x; ++cx)
-                for (int cy = lo_y; cy <= hi_y; ++cy) {
-                    const int c = cx * G.rows + cy;
-                    for (int k = G.cell_off[c]; k < G.cell_off[c + 1]; ++k) {
-                        const int idx = G.cell_items[k];
+        if (lo_x < G.cols && 0 <= hi_x && lo_y < G.rows && 0 <= hi_y && lo_x <= hi_x && lo_y <= hi_y) {
+            const int ny = hi_y - lo_y + 1, ncell = (hi_x - lo_x + 1) * ny;
+            int32_t* out = FILL ? G.cand_idx + G.cand_off[q] : nullptr;
+            for (int base = 0; base < ncell; base += 64) {
+                const int k = base + lane;
+                int n = 0, c = 0;
+                if (k < ncell) {
+                    c = (lo_x + k / ny) * G.rows + lo_y + k % ny;
+                    for (int it = G.cell_off[c]; it < G.cell_off[c + 1]; ++it) {
+                        const int idx = G.cell_items[it];
                         const int oct = G.t_octave[idx];
                         if (0 <= min_level && oct < min_level) continue;
                         if (0 <= max_level && max_level < oct) continue;
                         const float dx = G.t_xy[2 * idx] - ref_x, dy = G.t_xy[2 * idx + 1] - ref_y;
-                        if (fabsf(dx) < margin && fabsf(dy) < margin) {
-                            if (FILL) out[n] = idx;
-                            ++n;
-                        }
+                        if (fabsf(dx) < margin && fabsf(dy) < margin) ++n;
                     }
                 }
+                int incl = n;  // inclusive prefix sum over the lanes
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += v;
+                }
+                if (FILL && n > 0) {
+                    int o = total + incl - n;
+                    for (int it = G.cell_off[c]; it < G.cell_off[c + 1]; ++it) {
+                        const int idx = G.cell_items[it];
+                        const int oct = G.t_octave[idx];
+                        if (0 <= min_level && oct < min_level) continue;
+                        if (0 <= max_level && max_level < oct) continue;
+                        const float dx = G.t_xy[2 * idx] - ref_x, dy = G.t_xy[2 * idx + 1] - ref_y;
+                        if (fabsf(dx) < margin && fabsf(dy) < margin) out[o++] = idx;
+                    }
+                }
+                total += __shfl(incl, 63, 64);
+            }
+        }
     }
-    if (!FILL) G.cand_off[q] = n;
+    if (!FILL && lane == 0) G.cand_off[q] = total;
 }
 
 // area::match_in_consistent_area (match/area.cc:8-98) on the same CSR lists and distances (mode SVGPU_MATCH_AREA).
@@ -1025,9 +1064,10 @@ __global__ __launch_bounds__(64) void k_area_replay(CandProblem P, int* __restri
         uint32_t k1 = 0xFFFFFFFFu;       // smallest (dist << 20 | scan position) of this lane's share: strict '<' keeps the first
         unsigned d2 = MAX_HAMMING_DIST;  // second smallest distance of this lane's share
         for (int c = lo + lane; c < hi; c += 64) {
-            const unsigned d = P.dist[c];
-            if (d == 0xFFFFu) continue;                 // cand_skip / orientation gate (:40-42)
-            if (ld(&mdist[P.cand_idx[c]]) <= d) continue;    // the current holder of that target is at least as close (:47-50)
+            const uint32_t ent = P.dist[c];
+            if (ent == 0xFFFFFFFFu) continue;           // cand_skip / orientation gate (:40-42)
+            const unsigned d = ent >> 22;
+            if (ld(&mdist[ent & 0x3FFFFFu]) <= d) continue;  // the current holder of that target is at least as close (:47-50)
             const uint32_t key = (d << 20) | (uint32_t)min(c - lo, 0xFFFFF);
             if (key < k1) {
                 d2 = min(d2, k1 >> 20);
@@ -1242,11 +1282,11 @@ void sv_launch_grid_build(hipStream_t s, const GridProblem& G) {
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_assign, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cell_off, nc);
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_place, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
-    if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<false>, dim3((G.nq + 63) / 64), dim3(64), 0, s, G);
+    if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<false>, dim3((G.nq + 3) / 4), dim3(256), 0, s, G);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cand_off, G.nq);
 }
 void sv_launch_grid_fill(hipStream_t s, const GridProblem& G) {
-    if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<true>, dim3((G.nq + 63) / 64), dim3(64), 0, s, G);
+    if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<true>, dim3((G.nq + 3) / 4), dim3(256), 0, s, G);
 }
 void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match, unsigned* mdist) {
     SvProfScope ps(ctx, s, "k_cand");
@@ -1257,5 +1297,9 @@ void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* ow
         hipLaunchKernelGGL(k_area_replay, dim3(1), dim3(64), use_lds ? lds : 0, s, P, owner, match, mdist, use_lds);
         return;
     }
-    hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(256), 0, s, P, owner, match);
+    {
+        const size_t lds = (size_t)(P.nt + P.nq) * sizeof(int);
+        const int use_lds = lds <= 60 * 1024;
+        hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(1024), use_lds ? lds : 0, s, P, owner, match, use_lds);
+    }
 }

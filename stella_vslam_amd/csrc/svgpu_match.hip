@@ -190,7 +190,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
                            const uint8_t* q_valid, const uint8_t* occupied, const float* q_angle, const float* t_angle, int check_orientation,
                            const float* q_xright, const float* t_xright, const float* q_xr_tol, unsigned thr,
                            float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
-    if (!ctx || nq < 0 || nt < 0 || !num_matches || (mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA))
+    if (!ctx || nq < 0 || nt < 0 || nt >= (1 << 22) || !num_matches || (mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_candidates: bad arguments");
     *num_matches = 0;
     if (nq == 0) return SVGPU_OK;
@@ -207,7 +207,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
         if (cand_idx[c] < 0 || cand_idx[c] >= nt) return sv_set_error(ctx, SVGPU_ERR_INVALID, "cand_idx out of range");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     const size_t need = pad((size_t)nq * 32) + pad((size_t)nt * 32) + 3 * pad((size_t)nt * 4) + pad(nt) + pad((size_t)(nq + 1) * 4)
-                        + pad((size_t)nc * 4) + pad(nc) + pad(nq) + 3 * pad((size_t)nq * 4) + pad((size_t)nc * 2) + 2 * pad((size_t)nq * 4)
+                        + pad((size_t)nc * 4) + pad(nc) + pad(nq) + 3 * pad((size_t)nq * 4) + pad((size_t)nc * 4) + 2 * pad((size_t)nq * 4)
                         + 2 * pad((size_t)nt * 4) + 512;
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
@@ -253,7 +253,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     P.thr = thr;
     P.lowe_ratio = lowe_ratio;
     P.mode = mode;
-    P.dist = A.take<uint16_t>(nc);
+    P.dist = A.take<uint32_t>(nc);
     P.match_q = A.take<int32_t>(nq);
     P.num = A.take<int32_t>(1);
     int* owner = A.take<int>(nt);
@@ -275,7 +275,7 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
                          const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_angle, const float* t_xright,
                          float min_x, float max_x, float min_y, float max_y, int grid_cols, int grid_rows,
                          int check_orientation, unsigned thr, float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
-    if (!ctx || nq < 0 || nt < 0 || !num_matches || mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA || grid_cols < 1 || grid_rows < 1
+    if (!ctx || nq < 0 || nt < 0 || nt >= (1 << 22) || !num_matches || mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA || grid_cols < 1 || grid_rows < 1
         || (size_t)grid_cols * grid_rows > (size_t(1) << 22) || !(min_x < max_x) || !(min_y < max_y))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: bad arguments");
     *num_matches = 0;
@@ -296,7 +296,7 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
     // Pass 0 builds the grid and the list sizes and reads the total back; the scratch arena may then have to grow for the
     // lists, which discards its contents, so pass 1 repeats the (cheap) uploads and the grid build in the final arena.
     for (int pass = 0; pass < 2; ++pass) {
-        const size_t need = need1 + (pass ? pad((size_t)total * 4) + pad((size_t)total * 2) : 0);
+        const size_t need = need1 + (pass ? 2 * pad((size_t)total * 4) : 0);
         const bool regrow = need > ctx->scratch_bytes;  // pass 1 without regrowth: the arena of pass 0 is still valid, same layout
         int rc = sv_ensure_scratch(ctx, need);
         if (rc) return rc;
@@ -357,7 +357,7 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
             continue;
         }
         G.cand_idx = A.take<int32_t>(total);
-        P.dist = A.take<uint16_t>(total);
+        P.dist = A.take<uint32_t>(total);
         sv_launch_grid_fill(s, G);
         P.qdesc = (const uint32_t*)d_q;
         P.tdesc = (const uint32_t*)d_t;
