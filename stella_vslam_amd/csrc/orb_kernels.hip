@@ -554,6 +554,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __shared__ __attribute__((aligned(16))) uint8_t s_a[SV_ROI_MAX * FP];
     __shared__ unsigned short s_q[SV_CELL * SV_CELL];
     __shared__ unsigned long long s_key[FAST_KT * FAST_KT];  // per-block arg-max of the selection-grid cells the ROI touches
+    __shared__ unsigned short s_gx[SV_ROI_MAX], s_gy[SV_ROI_MAX];  // selection-grid column / row of every ROI column / row
     __shared__ int s_count, s_qn;
     int local, b, ci;
     xcd_frame_map(gridDim.x, gridDim.y, ci, b);
@@ -620,6 +621,8 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         s_qn = 0;
     }
     if (tid < FAST_KT * FAST_KT) s_key[tid] = 0ull;
+    if (tid < w) s_gx[tid] = gtab[lev.gtab_x_off + cell.min_x + tid - SV_PATCH_RADIUS];
+    else if (tid >= 128 && tid - 128 < h) s_gy[tid - 128] = gtab[lev.gtab_y_off + cell.min_y + (tid - 128) - SV_PATCH_RADIUS];
     __syncthreads();
 
     const int tq = min(ini_thr, min_thr);
@@ -678,10 +681,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __syncthreads();
 
     // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
-    const int gx_off = lev.gtab_x_off, gy_off = lev.gtab_y_off;
     unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
     const int qn = s_qn;
-    const int gx0 = gtab[gx_off + cell.min_x + 3 - SV_PATCH_RADIUS], gy0 = gtab[gy_off + cell.min_y + 3 - SV_PATCH_RADIUS];  // grid cell of the first scored pixel
+    const int gx0 = s_gx[3], gy0 = s_gy[3];  // grid cell of the first scored pixel
     for (int pass = 0; pass < 2; ++pass) {
         const int t = pass == 0 ? ini_thr : min_thr;
         int found = 0;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             ++found;
             const int x_level = cell.min_x + qx, y_level = cell.min_y + ly;
             if (M && masked(y_level, x_level)) continue;  // keypoint filter (:246-256), after the retry decision
-            const int gx = gtab[gx_off + x_level - SV_PATCH_RADIUS], gy = gtab[gy_off + y_level - SV_PATCH_RADIUS];
+            const int gx = s_gx[qx], gy = s_gy[ly];
             const uint32_t order = (uint32_t)cell.order_base | ((uint32_t)ly << 7) | (uint32_t)qx;
             const unsigned long long key = ((unsigned long long)(uint32_t)s << 32) | (0xFFFFFFFFu - order);
             // arg-max per selection-grid cell: first inside the block (LDS), one global atomic per touched cell afterwards

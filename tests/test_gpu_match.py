@@ -41,7 +41,9 @@ def test_hamming_known_answers_and_random(M, ctx):
 @pytest.mark.parametrize("seed,n1,n2,check,ratio", [(0, 150, 130, True, 0.75), (1, 2000, 2100, True, 0.75), (2, 2000, 1900, False, 0.9),
                                                     (3, 37, 300, True, 0.6), (4, 3000, 5, False, 1.0),
                                                     # lowe_ratio < 0.4: cutoff >= 128, the VALU top-K kernel instead of the MFMA one; 0.1: every pair is a candidate
-                                                    (5, 900, 800, True, 0.35), (6, 500, 600, False, 0.1)])
+                                                    (5, 900, 800, True, 0.35), (6, 500, 600, False, 0.1),
+                                                    # more than 4096 queries: rows beyond the replay's register cache
+                                                    (7, 5200, 4700, True, 0.8)])
 def test_brute_force_matches_oracle(M, ctx, seed, n1, n2, check, ratio):
     rng = np.random.default_rng(seed)
     d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)

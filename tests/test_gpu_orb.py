@@ -21,7 +21,7 @@ def _assert_same(kg, dg, ko, do):
     assert np.array_equal(dg, do)
 
 
-@pytest.mark.parametrize("w,h,seed", [(640, 480, 0x5EED), (752, 480, 7), (1241, 376, 8), (320, 240, 9), (203, 157, 10)])
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 0x5EED), (752, 480, 7), (1241, 376, 8), (320, 240, 9), (203, 157, 10), (1920, 1080, 11)])
 def test_extract_bit_exact(F, w, h, seed):
     img = S.frame(w, h, seed)
     ext = F.orb_extractor(F.orb_params())
