@@ -111,6 +111,95 @@ int main() {
     stop = true;
     ba.optimize_flat(p, &stop, r);
     REQUIRE(r.status == SVGPU_STOPPED && r.pose_cw == p.pose_cw);
+
+    // projection-family matcher with the candidate lists built on the device: frame-1 keypoints "reprojected" by the known shift
+    // into frame 2, window 15 px x scale, levels +-1 (projection.cc:30-35); and the same queries through host-built lists
+    {
+        match::projection pm(ext.context(), 0.8f, true);
+        match::projection::query_set q;
+        q.descriptors = d1;
+        std::vector<cv::Point2f> ref;
+        std::vector<float> margins;
+        std::vector<int> lo, hi;
+        for (auto& k : k1) {
+            q.angle.push_back(k.angle);
+            ref.push_back(cv::Point2f{k.pt.x - 3.f, k.pt.y - 1.f});
+            margins.push_back(15.f * params.scale_factors_[k.octave]);
+            lo.push_back(std::max(0, k.octave - 1));
+            hi.push_back(std::min(7, k.octave + 1));
+        }
+        const float bounds[4] = {0.f, 640.f, 0.f, 480.f};
+        std::vector<int> m_cells;
+        const unsigned nc = pm.match_in_cells(q, ref, margins, lo, hi, f2, {}, bounds, 64, 48, SVGPU_MATCH_RATIO_SAME_OCTAVE, 100, m_cells);
+        REQUIRE(nc > 800 && m_cells.size() == k1.size());
+        int consistent = 0;
+        for (size_t i = 0; i < m_cells.size(); ++i)
+            if (m_cells[i] >= 0) consistent += std::fabs(k2[m_cells[i]].pt.x - ref[i].x) < margins[i] && std::fabs(k2[m_cells[i]].pt.y - ref[i].y) < margins[i];
+        REQUIRE(consistent == (int)nc);  // every match lies inside its query's window
+        // area matcher (initialiser): level-0 keypoints only, window 60 px, all candidates in index order
+        match::projection::query_set qa;
+        qa.descriptors = d1;
+        qa.cand_off.push_back(0);
+        for (auto& k : k1) {
+            qa.angle.push_back(k.angle);
+            if (k.octave == 0)
+                for (size_t j = 0; j < k2.size(); ++j)
+                    if (k2[j].octave == 0 && std::fabs(k2[j].pt.x - k.pt.x) < 60.f && std::fabs(k2[j].pt.y - k.pt.y) < 60.f) qa.cand_idx.push_back((int)j);
+            qa.cand_off.push_back((int)qa.cand_idx.size());
+        }
+        std::vector<int> m_area;
+        const unsigned na = match::area(ext.context(), 0.9f, true).match_in_consistent_area(qa, f2, m_area);
+        REQUIRE(na > 100 && m_area.size() == k1.size());
+        std::vector<char> taken(k2.size(), 0);
+        for (int t : m_area)
+            if (t >= 0) {
+                REQUIRE(!taken[t]);  // a target ends with exactly one holder
+                taken[t] = 1;
+            }
+        std::printf("projection in cells: %u matches, area: %u matches\n", nc, na);
+    }
+    // stereo: right image = left shifted by 20 px -> the recovered disparity is 20
+    {
+        feature::orb_extractor ext_r(&params, 800);
+        cv::Mat right(480, 640, cv::CV_8UC1);
+        for (int y = 0; y < 480; ++y)
+            for (int x = 0; x < 640; ++x) right.ptr(y)[x] = img.ptr(y)[std::min(x + 20, 639)];
+        std::vector<cv::KeyPoint> kl, kr;
+        cv::Mat dl, dr;
+        ext.extract(img, cv::_InputArray(), kl, dl);
+        ext_r.extract(right, cv::_InputArray(), kr, dr);
+        std::vector<float> xr, depth;
+        match::stereo(&ext, &ext_r, kl, kr, dl, dr, 458.654f * 0.11f, 0.11f).compute(xr, depth);
+        REQUIRE(xr.size() == kl.size());
+        int ok = 0, tot = 0;
+        for (size_t i = 0; i < xr.size(); ++i)
+            if (xr[i] >= 0) {
+                ++tot;
+                ok += std::fabs((kl[i].pt.x - xr[i]) - 20.f) < 0.5f;
+            }
+        std::printf("stereo: %d of %d matched keypoints at the true disparity\n", ok, tot);
+        REQUIRE(tot > 500 && 2 * ok > tot);  // the rectangle texture is self-similar along rows: the majority, not all, lock on
+    }
+    // motion-only BA: perturbed camera 2 against the 60 exact observations of the scene above
+    {
+        std::vector<double> pos_w;
+        std::vector<float> uvr, w, hub;
+        for (int l = 0; l < L; ++l) {
+            const double X[3] = {-1.0 + 0.2 * (l % 10), -0.6 + 0.2 * (l / 10), 4.0 + 0.05 * (l % 7)};
+            pos_w.insert(pos_w.end(), X, X + 3);
+            uvr.push_back((float)(458.654 * (X[0] - 0.6) / X[2] + 367.215));
+            uvr.push_back((float)(458.654 * X[1] / X[2] + 248.375));
+            uvr.push_back(-1.f);
+            w.push_back(1.f);
+            hub.push_back(std::sqrt(5.99146f));
+        }
+        const double T0[12] = {1, 0, 0, -0.57, 0, 1, 0, 0.01, 0, 0, 1, -0.02}, K[5] = {458.654, 458.654, 367.215, 248.375, 0.0};
+        double T1[12];
+        std::vector<uint8_t> flags;
+        const unsigned good_obs = optimize::pose_optimizer_hip(ext.context()).optimize_flat(T0, pos_w, uvr, w, hub, K, T1, flags);
+        REQUIRE(good_obs == (unsigned)L && std::fabs(T1[3] + 0.6) < 1e-4 && std::fabs(T1[7]) < 1e-4 && std::fabs(T1[11]) < 1e-4);
+        std::printf("pose optimizer: %u inliers, t = (%.5f %.5f %.5f)\n", good_obs, T1[3], T1[7], T1[11]);
+    }
     std::printf("adaptors ok: %zu / %zu keypoints, %u matches (%d consistent), BA chi2 %.3g -> %.3g\n", k1.size(), k2.size(), nm, good,
                 r.stats.chi2_initial, r.stats.chi2_final);
     return 0;
