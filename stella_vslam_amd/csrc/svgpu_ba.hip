@@ -280,7 +280,15 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.red_scale_n = nb_lm + nb_pose;
     D.red_flag_off = nb_chi + nb_lm + nb_pose;
     const int red_total = nb_chi + nb_lm + nb_pose + 8;
-    std::vector<double> red_host(red_total);
+    // per-trial read-back (partial sums, flags) lands in page-locked memory: no staging copy on the D2H path
+    if (ctx->pinned_doubles < (size_t)red_total) {
+        if (ctx->h_pinned) SV_HIP(ctx, hipHostFree(ctx->h_pinned));
+        ctx->h_pinned = nullptr;
+        ctx->pinned_doubles = 0;
+        SV_HIP(ctx, hipHostMalloc((void**)&ctx->h_pinned, sizeof(double) * (size_t)red_total * 2, hipHostMallocDefault));
+        ctx->pinned_doubles = (size_t)red_total * 2;
+    }
+    double* const red_host = ctx->h_pinned;
 
 #define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
     H2D(D.pose_cur, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
@@ -391,7 +399,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         double sum = 0;
         if (E > 0) {
             sv_ba_chi2(ctx, s, D, use_trial, store_cache);
-            SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red + D.red_chi_off, 8 * (size_t)nb_chi, hipMemcpyDeviceToHost, s));
+            SV_HIP(ctx, hipMemcpyAsync(red_host, D.red + D.red_chi_off, 8 * (size_t)nb_chi, hipMemcpyDeviceToHost, s));
             SV_HIP(ctx, hipStreamSynchronize(s));
             for (int i = 0; i < nb_chi; ++i) sum += red_host[i];
         }
@@ -416,10 +424,15 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if (!sharded && HS.nP + HS.nL == 0) return SVGPU_OK;
         bool ok = true;
         double ni = 2;
+        double current_chi = 0;
         for (int it = 0; it < iterations && ok; ++it) {
             if (!sharded && *flag) break;
-            double current_chi;
-            if ((r = chi2(0, 0, &current_chi))) return r;
+            // activeRobustChi2 of the estimate.  After an accepted step it IS the trial's chi2 of the previous iteration (same
+            // state, same fixed-order sum), so only the first iteration -- and the sharded solve, whose call also
+            // OR-reduces the stop flags -- computes it again.
+            if (it == 0 || sharded) {
+                if ((r = chi2(0, 0, &current_chi))) return r;
+            }
             if (*flag) break;  // sharded: the flag was just OR-reduced, every rank leaves together
             sv_ba_linearize(ctx, s, D);
             if (sharded && HS.nP > 0) {
@@ -453,7 +466,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                 if (HS.nP > 0 && (r = allreduce_dev(D.S, (size_t)(D.n + 1) * D.n))) return r;
                 sv_ba_solve(ctx, s, D);
                 if (E > 0) sv_ba_chi2(ctx, s, D, 1, 0);
-                SV_HIP(ctx, hipMemcpyAsync(red_host.data(), D.red, 8 * (size_t)red_total, hipMemcpyDeviceToHost, s));
+                SV_HIP(ctx, hipMemcpyAsync(red_host, D.red, 8 * (size_t)red_total, hipMemcpyDeviceToHost, s));
                 SV_HIP(ctx, hipStreamSynchronize(s));
                 double temp_chi = 0, scale = 0;
                 if (E > 0)

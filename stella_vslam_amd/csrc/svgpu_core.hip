@@ -113,6 +113,7 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     sv_orb_release(ctx);
     for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

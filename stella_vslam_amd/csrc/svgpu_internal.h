@@ -99,6 +99,8 @@ struct svgpu_ctx {
     int last_row_stride = 0;
     // generic scratch (matchers, BA)
     void* d_scratch = nullptr;
+    double* h_pinned = nullptr;     // page-locked read-back buffer of the BA loops (small per-trial partial sums)
+    size_t pinned_doubles = 0;
     size_t scratch_bytes = 0;
 };
 
