@@ -176,43 +176,58 @@ __device__ __forceinline__ double block_sum_d(double v, double* sw /* 16 doubles
 
 // ------------------------------------------------------------------------------------------------ linearise
 // thread per landmark: Hll, bl and the Hpl block W of every coupled edge
+// 8 lanes per landmark: lane `sub` linearises the observations sub, sub + 8, ... of the landmark (a landmark has ~6), the
+// partial Hll / bl are combined with a fixed xor-shuffle tree (deterministic), lane 0 of the group stores them.  With one
+// thread per landmark the 10 k-landmark problem filled 40 workgroups; this fills 8x as many.
+#define LM_LANES 8
+__device__ __forceinline__ double group_sum8(double v) {
+#pragma unroll
+    for (int off = 1; off < LM_LANES; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= D.L) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
+    const bool in_range = t / LM_LANES < D.L;
     double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     const bool lfree = D.pt_free[l];
-    for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
-        if (D.e_level[e]) continue;
-        const int slot = D.pose_slot[D.e_pose[e]];
-        if (!lfree && slot < 0) continue;
-        EdgeLin o;
-        edge_linearize(D, e, o);
-        if (lfree) {
+    if (in_range)
+        for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
+            if (D.e_level[e]) continue;
+            const int slot = D.pose_slot[D.e_pose[e]];
+            if (!lfree && slot < 0) continue;
+            EdgeLin o;
+            edge_linearize(D, e, o);
+            if (lfree) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
-                const double wr = -o.w * o.r[d];
-                b[0] += a0 * wr;
-                b[1] += a1 * wr;
-                b[2] += a2 * wr;
-                H[0] += a0 * o.w * a0;
-                H[1] += a0 * o.w * a1;
-                H[2] += a0 * o.w * a2;
-                H[3] += a1 * o.w * a1;
-                H[4] += a1 * o.w * a2;
-                H[5] += a2 * o.w * a2;
-            }
-            if (slot >= 0) {
-                double* Wd = D.W + (size_t)e * 18;
+                for (int d = 0; d < 3; ++d) {
+                    const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
+                    const double wr = -o.w * o.r[d];
+                    b[0] += a0 * wr;
+                    b[1] += a1 * wr;
+                    b[2] += a2 * wr;
+                    H[0] += a0 * o.w * a0;
+                    H[1] += a0 * o.w * a1;
+                    H[2] += a0 * o.w * a2;
+                    H[3] += a1 * o.w * a1;
+                    H[4] += a1 * o.w * a2;
+                    H[5] += a2 * o.w * a2;
+                }
+                if (slot >= 0) {
+                    double* Wd = D.W + (size_t)e * 18;
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+                    for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        Wd[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
+                        for (int j = 0; j < 3; ++j)
+                            Wd[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
+                }
             }
         }
-    }
-    if (lfree) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) H[k] = group_sum8(H[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[k] = group_sum8(b[k]);
+    if (in_range && lfree && sub == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) D.Hll[(size_t)l * 6 + k] = H[k];
 #pragma unroll
@@ -220,13 +235,18 @@ __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
     }
 }
 
-// workgroup per free pose: Hpp (6x6) and bp over all its active edges, tree-reduced in a fixed order
-__global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D) {
-    const int s = blockIdx.x;
+// LP_SPLIT workgroups per free pose: each linearises a contiguous share of the pose's active edges and tree-reduces its 27
+// sums (21 of Hpp, 6 of bp) in a fixed order; the workgroup that finishes last adds the LP_SPLIT partials in share order,
+// so the result does not depend on which one that is.
+#define LP_SPLIT 4
+__global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restrict__ part, unsigned* __restrict__ ticket) {
+    const int s = blockIdx.x, share = blockIdx.y;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += blockDim.x) {
+    const int lo = D.pe_off[s], n = D.pe_off[s + 1] - lo;
+    const int q0 = lo + (int)((long long)n * share / LP_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / LP_SPLIT);
+    for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
         const int e = D.pe_idx[q];
         if (D.e_level[e]) continue;  // lists are built once per call; excluded edges stay listed
         EdgeLin o;
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D) {
     }
     // fixed-order reduction: shuffles inside each wave, then the wave partials in wave order
     __shared__ double s_w[16][27];
+    __shared__ bool s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -253,13 +274,26 @@ __global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D) {
         if (lane == 0) s_w[wave][k] = t;
     }
     __syncthreads();
+    double* my = part + ((size_t)s * LP_SPLIT + share) * 27;
     if (threadIdx.x < 27) {
         double t = 0.0;
         for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
+        my[threadIdx.x] = t;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&ticket[s], 1u) == LP_SPLIT - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 27) {
+        double t = 0.0;
+        for (int h = 0; h < LP_SPLIT; ++h) t += __hip_atomic_load(part + ((size_t)s * LP_SPLIT + h) * 27 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_w[0][threadIdx.x] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        ticket[s] = 0;  // ready for the next launch
         const double* out = s_w[0];
         double* H = D.Hpp + (size_t)s * 36;
         int k = 0;
@@ -286,10 +320,9 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
         atomicMax(reinterpret_cast<unsigned long long*>(D.red + D.red_flag_off + 1), (unsigned long long)__double_as_longlong(m));
 }
 
-// ------------------------------------------------------------------------------------------------ solve
-// thread per landmark: Dinv = (Hll + lambda I)^-1 and Y = W * Dinv of its coupled edges
-__global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {  // 8 lanes per landmark, as k_ba_lin_lm: every lane inverts, lane `sub` maps its edges
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int l = t / LM_LANES, sub = t % LM_LANES;
     if (l >= D.L || !D.pt_free[l]) return;
     const double* H = D.Hll + (size_t)l * 6;
     const double a = H[0] + D.lambda, b = H[1], c = H[2], d = H[3] + D.lambda, e_ = H[4], f = H[5] + D.lambda;
@@ -310,9 +343,11 @@ __global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {
         I[4] = (b * c - a * e_) * id;
         I[5] = (a * d - b * b) * id;
     }
+    if (sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) D.Dinv[(size_t)l * 6 + k] = I[k];
-    for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
+        for (int k = 0; k < 6; ++k) D.Dinv[(size_t)l * 6 + k] = I[k];
+    }
+    for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
         if (D.e_level[e] || D.pose_slot[D.e_pose[e]] < 0) continue;
         const double* Wd = D.W + (size_t)e * 18;
         double* Yd = D.Y + (size_t)e * 18;
@@ -323,6 +358,10 @@ __global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {
             Yd[3 * i + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
             Yd[3 * i + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
         }
+        const double* bl = D.bl + (size_t)l * 3;  // the edge's share of Hpl Hll^-1 bl, summed per pose by k_ba_rhs
+        double* ge = D.GE + (size_t)e * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ge[i] = Yd[3 * i] * bl[0] + Yd[3 * i + 1] * bl[1] + Yd[3 * i + 2] * bl[2];
     }
 }
 
@@ -386,10 +425,9 @@ __global__ __launch_bounds__(1024) void k_ba_rhs(BaDev D) {
         const int e = D.pe_idx[q];
         const int l = D.e_point[e];
         if (!D.pt_free[l] || D.e_level[e]) continue;
-        const double* Yd = D.Y + (size_t)e * 18;
-        const double* b = D.bl + (size_t)l * 3;
+        const double* ge = D.GE + (size_t)e * 6;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] += Yd[3 * i] * b[0] + Yd[3 * i + 1] * b[1] + Yd[3 * i + 2] * b[2];
+        for (int i = 0; i < 6; ++i) acc[i] += ge[i];
     }
     __shared__ double s_w[16][6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1094,8 +1132,8 @@ void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
 // ------------------------------------------------------------------------------------------------ launchers
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_linearize");
-    hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
-    if (D.nP > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP), dim3(1024), 0, s, D);
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
+    if (D.nP > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP, LP_SPLIT), dim3(1024), 0, s, D, D.lp_part, D.lp_ticket);
 }
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
@@ -1106,7 +1144,7 @@ void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
 // phase 1: Dinv / Y, (partial) reduced camera system S with the right-hand side in row n
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_schur");
-    hipLaunchKernelGGL(k_ba_dinv, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
     if (D.nP > 0) {
         (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
         hipLaunchKernelGGL(k_ba_schur, dim3(D.NB), dim3(SCHUR_THREADS), 0, s, D);
