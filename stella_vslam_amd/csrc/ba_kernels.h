@@ -35,7 +35,7 @@ struct BaDev {
     double* W;     // E x 18: Hpl block (6x3, row-major) of every edge with free pose and free landmark, else 0
     double* Y;     // E x 18: W * Dinv
     double* lp_part;     // P x LP_SPLIT x 27: partial pose blocks of k_ba_lin_pose
-    unsigned* lp_ticket; // P: arrival counters of k_ba_lin_pose (zero between launches)
+    double* sc_part;     // NB x SCHUR_SPLIT x 36: partial blocks of k_ba_schur
     double* GE;    // E x 6: Y * bl of the edge, written by k_ba_dinv
     double* Hll;   // L x 6 (xx xy xz yy yz zz)
     double* bl;    // L x 3

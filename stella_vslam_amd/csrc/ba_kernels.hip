@@ -236,10 +236,9 @@ __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
 }
 
 // LP_SPLIT workgroups per free pose: each linearises a contiguous share of the pose's active edges and tree-reduces its 27
-// sums (21 of Hpp, 6 of bp) in a fixed order; the workgroup that finishes last adds the LP_SPLIT partials in share order,
-// so the result does not depend on which one that is.
+// sums (21 of Hpp, 6 of bp) in a fixed order; k_ba_lin_pose_fin adds the LP_SPLIT partials in share order.
 #define LP_SPLIT 4
-__global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restrict__ part, unsigned* __restrict__ ticket) {
+__global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restrict__ part) {
     const int s = blockIdx.x, share = blockIdx.y;
     double acc[27];
 #pragma unroll
@@ -266,7 +265,6 @@ __global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restric
     }
     // fixed-order reduction: shuffles inside each wave, then the wave partials in wave order
     __shared__ double s_w[16][27];
-    __shared__ bool s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -274,36 +272,33 @@ __global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restric
         if (lane == 0) s_w[wave][k] = t;
     }
     __syncthreads();
-    double* my = part + ((size_t)s * LP_SPLIT + share) * 27;
     if (threadIdx.x < 27) {
         double t = 0.0;
         for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
-        my[threadIdx.x] = t;
+        part[((size_t)s * LP_SPLIT + share) * 27 + threadIdx.x] = t;
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&ticket[s], 1u) == LP_SPLIT - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
+}
+// adds the LP_SPLIT partials of a pose in share order (a second launch is far cheaper than a device-scope fence per
+// workgroup: agent-scope release on gfx950 writes the XCD's L2 back)
+__global__ __launch_bounds__(64) void k_ba_lin_pose_fin(BaDev D, const double* __restrict__ part) {
+    __shared__ double s_o[27];
+    const int s = blockIdx.x;
     if (threadIdx.x < 27) {
         double t = 0.0;
-        for (int h = 0; h < LP_SPLIT; ++h) t += __hip_atomic_load(part + ((size_t)s * LP_SPLIT + h) * 27 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_w[0][threadIdx.x] = t;
+        for (int h = 0; h < LP_SPLIT; ++h) t += part[((size_t)s * LP_SPLIT + h) * 27 + threadIdx.x];
+        s_o[threadIdx.x] = t;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        ticket[s] = 0;  // ready for the next launch
-        const double* out = s_w[0];
         double* H = D.Hpp + (size_t)s * 36;
         int k = 0;
         for (int i = 0; i < 6; ++i)
             for (int j = i; j < 6; ++j) {
-                H[6 * i + j] = out[k];
-                H[6 * j + i] = out[k];
+                H[6 * i + j] = s_o[k];
+                H[6 * j + i] = s_o[k];
                 ++k;
             }
-        for (int i = 0; i < 6; ++i) D.bp[(size_t)s * 6 + i] = out[21 + i];
+        for (int i = 0; i < 6; ++i) D.bp[(size_t)s * 6 + i] = s_o[21 + i];
     }
 }
 
@@ -369,14 +364,17 @@ __global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {  // 8 lanes per land
 //   S_ab = [a==b](Hpp_a + lambda I) - sum over the block's (edge, edge) pairs of Y_i W_j^T
 // threads stride over the pairs, waves are tree-reduced with shuffles, the 8 wave partials are added in wave order
 #define SCHUR_THREADS 512
-__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D) {
+#define SCHUR_SPLIT 4  // workgroups per block: contiguous shares of its pair list, combined in share order by k_ba_schur_fin
+__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D, double* __restrict__ part) {
     __shared__ double s_part[SCHUR_THREADS / 64][36];
-    const int blk = blockIdx.x;
+    const int blk = blockIdx.x, share = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    for (int q = D.blk_off[blk] + threadIdx.x; q < D.blk_off[blk + 1]; q += SCHUR_THREADS) {
+    const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
+    const int q0 = lo + (int)((long long)np * share / SCHUR_SPLIT), q1 = lo + (int)((long long)np * (share + 1) / SCHUR_SPLIT);
+    for (int q = q0 + threadIdx.x; q < q1; q += SCHUR_THREADS) {
         const int2 pr = D.blk_pairs[q];
         const double2* Yd = reinterpret_cast<const double2*>(D.Y + (size_t)pr.x * 18);
         const double2* Wd = reinterpret_cast<const double2*>(D.W + (size_t)pr.y * 18);
@@ -401,11 +399,19 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D) {
     }
     __syncthreads();
     if (threadIdx.x < 36) {
-        const int2 ab = D.blk_ab[blk];
-        const int i = threadIdx.x / 6, j = threadIdx.x - 6 * i;
         double sum = 0.0;
 #pragma unroll
         for (int wv = 0; wv < SCHUR_THREADS / 64; ++wv) sum += s_part[wv][threadIdx.x];
+        part[((size_t)blk * SCHUR_SPLIT + share) * 36 + threadIdx.x] = sum;
+    }
+}
+__global__ __launch_bounds__(64) void k_ba_schur_fin(BaDev D, const double* __restrict__ part) {
+    const int blk = blockIdx.x;
+    if (threadIdx.x < 36) {
+        const int2 ab = D.blk_ab[blk];
+        const int i = threadIdx.x / 6, j = threadIdx.x - 6 * i;
+        double sum = 0.0;
+        for (int h = 0; h < SCHUR_SPLIT; ++h) sum += part[((size_t)blk * SCHUR_SPLIT + h) * 36 + threadIdx.x];
         double v = -sum;
         if (ab.x == ab.y) {
             v += D.Hpp[(size_t)ab.x * 36 + threadIdx.x];
@@ -706,28 +712,37 @@ __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
 }
 
 // thread per landmark: dl = Dinv (bl - sum W^T dp), trial point, partial of delta^T(lambda delta + b)
-__global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {
+__global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {  // 8 lanes per landmark (32 landmarks per workgroup), as k_ba_lin_lm
     __shared__ double s4[16];
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
+    const bool in_range = t / LM_LANES < D.L;
     double sc = 0.0;
-    if (l < D.L) {
-        double X[3] = {D.pt_cur[(size_t)l * 3], D.pt_cur[(size_t)l * 3 + 1], D.pt_cur[(size_t)l * 3 + 2]};
-        if (D.pt_free[l]) {
-            const double* b = D.bl + (size_t)l * 3;
-            double c[3] = {b[0], b[1], b[2]};
-            for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
-                if (D.e_level[e]) continue;
-                const int slot = D.pose_slot[D.e_pose[e]];
-                if (slot < 0) continue;
-                const double* Wd = D.W + (size_t)e * 18;
-                const double* x = D.dp + (size_t)slot * 6;
+    const bool lfree = in_range && D.pt_free[l];
+    double c[3] = {0.0, 0.0, 0.0};
+    if (lfree)
+        for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
+            if (D.e_level[e]) continue;
+            const int slot = D.pose_slot[D.e_pose[e]];
+            if (slot < 0) continue;
+            const double* Wd = D.W + (size_t)e * 18;
+            const double* x = D.dp + (size_t)slot * 6;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    c[0] -= Wd[3 * i] * x[i];
-                    c[1] -= Wd[3 * i + 1] * x[i];
-                    c[2] -= Wd[3 * i + 2] * x[i];
-                }
+            for (int i = 0; i < 6; ++i) {
+                c[0] -= Wd[3 * i] * x[i];
+                c[1] -= Wd[3 * i + 1] * x[i];
+                c[2] -= Wd[3 * i + 2] * x[i];
             }
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
+    if (in_range && sub == 0) {
+        double X[3] = {D.pt_cur[(size_t)l * 3], D.pt_cur[(size_t)l * 3 + 1], D.pt_cur[(size_t)l * 3 + 2]};
+        if (lfree) {
+            const double* b = D.bl + (size_t)l * 3;
+            c[0] += b[0];
+            c[1] += b[1];
+            c[2] += b[2];
             const double* I = D.Dinv + (size_t)l * 6;
             const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
             const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
@@ -741,8 +756,8 @@ __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {
         D.pt_trial[(size_t)l * 3 + 1] = X[1];
         D.pt_trial[(size_t)l * 3 + 2] = X[2];
     }
-    const double t = block_sum_d(sc, s4);
-    if (threadIdx.x == 0) D.red[D.red_scale_off + blockIdx.x] = t;
+    const double tsum = block_sum_d(sc, s4);
+    if (threadIdx.x == 0) D.red[D.red_scale_off + blockIdx.x] = tsum;
 }
 
 // thread per pose: trial = exp(dp) * cur (g2o SE3Quat::exp, shot_vertex.h:55-58)
@@ -1133,7 +1148,10 @@ void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_linearize");
     if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
-    if (D.nP > 0) hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP, LP_SPLIT), dim3(1024), 0, s, D, D.lp_part, D.lp_ticket);
+    if (D.nP > 0) {
+        hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP, LP_SPLIT), dim3(1024), 0, s, D, D.lp_part);
+        hipLaunchKernelGGL(k_ba_lin_pose_fin, dim3(D.nP), dim3(64), 0, s, D, D.lp_part);
+    }
 }
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
@@ -1147,7 +1165,8 @@ void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.L > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
     if (D.nP > 0) {
         (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
-        hipLaunchKernelGGL(k_ba_schur, dim3(D.NB), dim3(SCHUR_THREADS), 0, s, D);
+        hipLaunchKernelGGL(k_ba_schur, dim3(D.NB, SCHUR_SPLIT), dim3(SCHUR_THREADS), 0, s, D, D.sc_part);
+        hipLaunchKernelGGL(k_ba_schur_fin, dim3(D.NB), dim3(64), 0, s, D, D.sc_part);
         hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(1024), 0, s, D);
     }
 }
@@ -1219,8 +1238,8 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
         else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
     }
     SvProfScope ps(ctx, s, "ba_update");
-    hipLaunchKernelGGL(k_ba_update_lm, dim3((D.L + 255) / 256), dim3(256), 0, s, D);
-    hipLaunchKernelGGL(k_ba_update_pose, dim3((D.P + 255) / 256), dim3(256), 0, s, D, (D.L + 255) / 256);
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_update_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
+    hipLaunchKernelGGL(k_ba_update_pose, dim3((D.P + 255) / 256), dim3(256), 0, s, D, (D.L * LM_LANES + 255) / 256);
 }
 
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache) {

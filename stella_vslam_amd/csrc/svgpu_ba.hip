@@ -195,12 +195,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     lap("sort observations");
     // ---- device arena
     const int nPmax = P, nmax = 6 * nPmax;
-    const int nb_chi = (E + 255) / 256, nb_lm = (L + 255) / 256, nb_pose = (P + 255) / 256;
+    const int nb_chi = (E + 255) / 256, nb_lm = (8 * L + 255) / 256 /* k_ba_update_lm: 8 lanes per landmark */, nb_pose = (P + 255) / 256;
     const size_t pairs_max_guess = 0;  // pair lists are sized after build_structure (second arena piece)
     (void)pairs_max_guess;
     size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
                   + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
-                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E) + pad(sizeof(double) * 27 * 4 * (size_t)P) + pad(4 * (size_t)P) + pad(sizeof(double) * 6 * E)
+                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E) + pad(sizeof(double) * 27 * 4 * (size_t)P) + pad(4 * (size_t)P) + pad(sizeof(double) * 36 * 4 * ((size_t)P * (P + 1) / 2 + 1)) + pad(4 * ((size_t)P * (P + 1) / 2 + 1)) + pad(sizeof(double) * 6 * E)
                   + 3 * pad(sizeof(double) * 6 * L) + 2 * pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
                   + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (size_t)(nmax + 1) * nmax) + pad(sizeof(double) * nmax)
                   + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E + 1) + pad(8 * 42 * (size_t)P)
@@ -217,6 +217,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
+    const size_t nb_cap_early = (size_t)P * (P + 1) / 2 + 1;
     BaDev D;
     memset(&D, 0, sizeof(D));
     D.P = P;
@@ -243,8 +244,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.W = A.take<double>(18 * (size_t)E);
     D.Y = A.take<double>(18 * (size_t)E);
     D.lp_part = A.take<double>(27 * 4 * (size_t)P);
-    D.lp_ticket = A.take<unsigned>(P);
-    if (P > 0) SV_HIP(ctx, hipMemsetAsync(D.lp_ticket, 0, 4 * (size_t)P, s));
+    D.sc_part = A.take<double>(36 * 4 * nb_cap_early);
     D.GE = A.take<double>(6 * (size_t)E);
     D.Hll = A.take<double>(6 * (size_t)L);
     D.Dinv = A.take<double>(6 * (size_t)L);
