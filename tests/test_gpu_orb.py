@@ -134,3 +134,42 @@ def test_batch_device_unaligned_images(F):
         assert n == len(ko) and np.array_equal(cnt, ca[i, 1:])
         assert np.array_equal(ka[i, :n], ku[i, :n]) and np.array_equal(da[i, :n], du[i, :n])
         assert np.array_equal(da[i, :n], do)
+
+
+def test_noise_image_and_tiny_image(F):
+    """Uniform noise (a corner candidate at most pixels: the FAST queue, the selection grid and the descriptor stage all run
+    at their densest) and an image barely larger than the 19-px borders (single partial FAST cell, levels without cells)."""
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    ext = F.orb_extractor(F.orb_params())
+    kg, dg = ext.extract(noise)
+    ko, do, _ = O.orb_extract(noise)
+    assert len(ko) > 300
+    _assert_same(kg, dg, ko, do)
+    tiny = S.frame(64, 52, 3)
+    ext2 = F.orb_extractor(F.orb_params("tiny", 1.2, 4, 20, 7), min_area=100)
+    kg, dg = ext2.extract(tiny)
+    ko, do, _ = O.orb_extract(tiny, num_levels=4, min_area=100)
+    _assert_same(kg, dg, ko, do)
+
+
+def test_two_extractors_on_two_threads(F):
+    """The stereo front end runs two extractor instances concurrently on two threads (system.cc:427-434): two contexts, two
+    streams, the library calls release the GIL -- results stay bit-identical to the single-threaded ones."""
+    import threading
+    imgs = [S.frame(640, 480, 30), S.frame(640, 480, 31)]
+    exts = [F.orb_extractor(F.orb_params()), F.orb_extractor(F.orb_params())]
+    ref = [exts[i].extract(imgs[i]) for i in range(2)]
+    out = [None, None]
+
+    def work(i):
+        for _ in range(10):
+            out[i] = exts[i].extract(imgs[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        _assert_same(out[i][0], out[i][1], ref[i][0], ref[i][1])
