@@ -15,7 +15,6 @@
 
 namespace {
 
-__device__ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // orb_impl.cc:51-66
 __device__ __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern_i8.inc"
 };
@@ -830,38 +829,47 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-// Stage a (2R+1)-row patch whose top-left pixel is g into the wave's LDS slab with 8-byte loads.  The slab row pitch
-// PITCH >= 2R+1+7 leaves room for the misalignment of g; returns the LDS offset of the patch's (row 0, col 0).
-// Rows are read from the 8-byte boundary at or below g, i.e. up to 7 bytes before and PITCH-2R-1 bytes after the
-// patch; keypoints keep 19 px to every image border, so those bytes belong to the previous / next image row.
-template <int R, int PITCH>
-__device__ __forceinline__ int stage_patch(const uint8_t* g, int gpitch, uint8_t* slab, int lane) {
-    constexpr int ROWS = 2 * R + 1, LPR = PITCH / 8, RPI = 64 / LPR;
-    if (gpitch & 7) {  // caller-owned image with an odd pitch: rows do not keep their 8-byte phase, byte path
-        for (int i = lane; i < ROWS * ROWS; i += 64) {
-            const int r = i / ROWS, c = i - r * ROWS;
-            slab[r * PITCH + c] = g[(ptrdiff_t)r * gpitch + c];
+// ---- orientation + descriptors.  One wave per keypoint, DESC_KPW keypoints per wave one after the other (the rBRIEF pattern
+// and the disc weights stay in registers across them).  Per keypoint:
+//   * the 31 x 31 un-blurred and 37 x 37 blurred patches are copied to LDS with a handful of 8-byte loads issued at the
+//     patch's own (arbitrary) byte address -- global memory takes unaligned accesses -- so that patch column 0 sits at
+//     byte 0 of every LDS row;
+//   * intensity centroid (orb_impl.cc:68-91) on dwords: a lane takes (row, 4 columns) items, v_dot4_u32_u8 against the
+//     disc mask and against (u + 15) x mask gives sum I and sum (u + 15) I of its 4 pixels; m10 = sum u I, m01 = sum v I
+//     are exact integers, so the order of summation is free;
+//   * fastAtan2, util::cos / sin, 4 ballot rounds x 64 rotated pairs read from the blurred patch in LDS (orb_impl.cc:93-154).
+// (A three-phase variant that computes the angle / cos / sin of 64 keypoints lane-parallel issues half the instructions
+// per keypoint but measured slower, 121-136 us against 109: the longer per-wave chains of dependent patch fetches cost
+// more than the saved issue slots.)
+#define DESC_KPW 4
+#define DESC_IP 32                     // LDS row pitch of the 31 x 31 patch (8 dwords)
+#define DESC_BP 40                     // LDS row pitch of the 37 x 37 patch
+#define DESC_R 18                      // largest |rounded rotated pattern coordinate| (pattern radius 18.38)
+#define DESC_SLAB (31 * DESC_IP + 37 * DESC_BP + 16)
+struct IcWeights {
+    uint32_t w1[256], wu[256];  // per (row, dword) item: disc mask bytes, (u + 15) x mask bytes
+};
+constexpr IcWeights make_ic_weights() {
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // orb_impl.cc:51-66
+    IcWeights t{};
+    for (int row = 0; row < 31; ++row)
+        for (int j = 0; j < 8; ++j) {
+            uint32_t w1 = 0, wu = 0;
+            const int v = row - 15, av = v < 0 ? -v : v;
+            for (int k = 0; k < 4; ++k) {
+                const int col = 4 * j + k, u = col - 15, au = u < 0 ? -u : u;
+                if (col < 31 && au <= umax[av]) {
+                    w1 |= 1u << (8 * k);
+                    wu |= (uint32_t)(u + 15) << (8 * k);
+                }
+            }
+            t.w1[row * 8 + j] = w1;
+            t.wu[row * 8 + j] = wu;
         }
-        return 0;
-    }
-    const int mis = (int)((size_t)g & 7);
-    const uint8_t* ga = g - mis;
-    const int lr = lane / LPR, lj = lane - lr * LPR;
-#pragma unroll
-    for (int r0 = 0; r0 < ROWS; r0 += RPI) {
-        const int r = r0 + lr;
-        if (lr < RPI && r < ROWS)
-            *reinterpret_cast<uint2*>(slab + r * PITCH + 8 * lj) = *reinterpret_cast<const uint2*>(ga + (ptrdiff_t)r * gpitch + 8 * lj);
-    }
-    return mis;
+    return t;
 }
+__device__ __constant__ IcWeights c_icw = make_ic_weights();
 
-#define DESC_R 18          // largest |rounded rotated pattern coordinate| (pattern radius 18.38)
-#define DESC_BP 48         // LDS pitch of the blurred patch: 37 + 7 rounded up to 8
-#define DESC_IP 40         // LDS pitch of the un-blurred 31 x 31 patch
-#define DESC_SLAB (37 * DESC_BP + 31 * DESC_IP + 8)
-// one wave per keypoint, 4 keypoints per block.  Both patches are staged in LDS with a handful of wide loads; the
-// 16 + 8 byte gathers per lane then hit LDS instead of the texture-address path.
 __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L, int num_levels, const int4* __restrict__ sel,
                                                   int total_grid, const int32_t* __restrict__ counts,
                                                   const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
@@ -871,87 +879,123 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     __shared__ __attribute__((aligned(16))) uint8_t s_slab[4][DESC_SLAB];
     int b, blk;
     xcd_frame_map(gridDim.x, gridDim.y, blk, b);
-    const int lane = threadIdx.x & 63;
-    const int i = blk * 4 + (threadIdx.x >> 6);
-    const int n = counts[b * (1 + num_levels)];
-    if (i >= n || i >= cap) return;
-    const int4 s = sel[(size_t)b * total_grid + i];
-    const int x = s.x, y = s.y, lv = s.z;
-    const OrbLevel lev = L[lv];
-    const uint8_t* I;
-    int ipitch;
-    if (lv == 0) {
-        I = img0 + (size_t)b * img0_frame_stride;
-        ipitch = img0_pitch;
-    }
-    else {
-        I = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
-        ipitch = lev.pitch;
-    }
-    uint8_t* const slab_b = s_slab[threadIdx.x >> 6];
-    uint8_t* const slab_i = slab_b + 37 * DESC_BP;
-    const uint8_t* Bg = blur + (size_t)b * blur_frame_bytes + lev.blur_off;
-    const int mis_i = stage_patch<15, DESC_IP>(I + (size_t)(y - 15) * ipitch + (x - 15), ipitch, slab_i, lane);
-    const int mis_b = stage_patch<DESC_R, DESC_BP>(Bg + (size_t)(y - DESC_R) * lev.pitch + (x - DESC_R), lev.pitch, slab_b, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- intensity centroid on the un-blurred level (orb_impl.cc:68-91); lanes = columns, two row halves
-    int m10 = 0, m01 = 0;
-    {
-        // lanes 0..30 take the rows v = 0,-1..-15, lanes 32..62 the rows v = 1..15; lane & 31 = column u + 15.
-        // The disc mask u_max_[|v|] is applied to the accumulation only.
-        const int ul = lane & 31, u = min(ul, 30) - 15, au = u < 0 ? -u : u;
-        const int sgn = lane < 32 ? -1 : 1;
-        const uint8_t* c = slab_i + mis_i + 15 * DESC_IP + 15 + u;
-        int val[16];
-#pragma unroll
-        for (int v = 0; v <= 15; ++v) val[v] = c[sgn * v * DESC_IP];
-        if (ul < 31) {
-#pragma unroll
-            for (int v = 0; v <= 15; ++v) {
-                const bool in = au <= c_umax[v] && (v > 0 || lane < 32);
-                m10 += in ? u * val[v] : 0;
-                m01 += in ? sgn * v * val[v] : 0;
-            }
-        }
-    }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = dev_fast_atan2((float)m01, (float)m10);
-
-    // ---- rotated BRIEF on the blurred level (orb_impl.cc:93-154)
-    const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
-    const float ca = dev_util_cos(rad), sa = dev_util_sin(rad);
-    const uint8_t* B = slab_b + mis_b + DESC_R * DESC_BP + DESC_R;
-    unsigned long long bits[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = min(counts[b * (1 + num_levels)], cap);
+    const int i0 = (blk * 4 + wave) * DESC_KPW;
+    if (i0 >= n) return;
+    uint8_t* const slab_i = s_slab[wave];
+    uint8_t* const slab_b = slab_i + 31 * DESC_IP;
+    // rBRIEF pattern of this lane's four pairs as floats; disc weights of this lane's (row, dword) items
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int pair = r * 64 + lane;
-        const char4 q = reinterpret_cast<const char4*>(c_pattern)[pair];
-        const float x0 = (float)q.x, y0 = (float)q.y, x1 = (float)q.z, y1 = (float)q.w;
-        const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
-        const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
-        const int a = B[r0 * DESC_BP + c0];
-        const int bb = B[r1 * DESC_BP + c1];
-        bits[r] = __ballot(a < bb);
+        const char4 q = reinterpret_cast<const char4*>(c_pattern)[r * 64 + lane];
+        px0[r] = (float)q.x;
+        py0[r] = (float)q.y;
+        px1[r] = (float)q.z;
+        py1[r] = (float)q.w;
     }
-    uint8_t* D = desc + ((size_t)b * cap + i) * 32;
-    if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-    if (lane == 0) {
-        svgpu_keypoint k;
-        k.x = (float)x;
-        k.y = (float)y;
-        if (lv != 0) {  // correct_keypoint_scale (orb_extractor.cc:337-345)
-            k.x = k.x * lev.scale;
-            k.y = k.y * lev.scale;
+    uint32_t w1[4], wu[4];
+    int rowv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int item = lane + 64 * m;  // items 248..255 carry zero weights
+        w1[m] = c_icw.w1[item];
+        wu[m] = c_icw.wu[item];
+        rowv[m] = (item >> 3) - 15;
+    }
+    for (int kk = 0; kk < DESC_KPW; ++kk) {
+        const int i = i0 + kk;
+        if (i >= n) break;
+        const int4 s = sel[(size_t)b * total_grid + i];
+        const int x = s.x, y = s.y, lv = s.z;
+        const OrbLevel lev = L[lv];
+        const uint8_t* I;
+        int ipitch;
+        if (lv == 0) {
+            I = img0 + (size_t)b * img0_frame_stride;
+            ipitch = img0_pitch;
         }
-        k.size = lev.kp_size;
-        k.angle = angle;
-        k.response = (float)s.w;
-        k.octave = lv;
-        k.class_id = -1;
-        kps[(size_t)b * cap + i] = k;
+        else {
+            I = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
+            ipitch = lev.pitch;
+        }
+        // ---- patches -> LDS.  Keypoints keep 19 px to every border: the 32- / 40-byte rows stay inside the image rows
+        // (the blurred rows may run 3 bytes into the row padding / next row, never past the buffer: 256 bytes of slack).
+        {
+            const uint8_t* g = I + (size_t)(y - 15) * ipitch + (x - 15);
+            const int part = lane & 3;
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 16) {
+                const int r = r0 + (lane >> 2);
+                if (r < 31) {
+                    uint2 v;
+                    __builtin_memcpy(&v, g + (ptrdiff_t)r * ipitch + 8 * part, 8);  // unaligned 8-byte global load
+                    *reinterpret_cast<uint2*>(slab_i + r * DESC_IP + 8 * part) = v;
+                }
+            }
+            const uint8_t* gb = blur + (size_t)b * blur_frame_bytes + lev.blur_off + (size_t)(y - DESC_R) * lev.pitch + (x - DESC_R);
+            const int br = lane / 5, bpart = lane - 5 * br;  // 5 x 8 bytes per row, 12 rows per pass
+#pragma unroll
+            for (int r0 = 0; r0 < 48; r0 += 12) {
+                const int r = r0 + br;
+                if (br < 12 && r < 37) {
+                    uint2 v;
+                    __builtin_memcpy(&v, gb + (ptrdiff_t)r * lev.pitch + 8 * bpart, 8);
+                    *reinterpret_cast<uint2*>(slab_b + r * DESC_BP + 8 * bpart) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- intensity centroid
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int item = lane + 64 * m;
+            const uint32_t px = item < 248 ? reinterpret_cast<const uint32_t*>(slab_i)[item] : 0u;
+            const int s1 = (int)__builtin_amdgcn_udot4(px, w1[m], 0u, false), su = (int)__builtin_amdgcn_udot4(px, wu[m], 0u, false);
+            m10 += su - 15 * s1;
+            m01 += rowv[m] * s1;
+        }
+        m10 = wave_sum(m10);
+        m01 = wave_sum(m01);
+        const float angle = dev_fast_atan2((float)m01, (float)m10);
+
+        // ---- rotated BRIEF on the blurred level (orb_impl.cc:93-154)
+        const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
+        const float ca = dev_util_cos(rad), sa = dev_util_sin(rad);
+        const uint8_t* B = slab_b + DESC_R * DESC_BP + DESC_R;
+        unsigned long long bits[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x0 = px0[r], y0 = py0[r], x1 = px1[r], y1 = py1[r];
+            const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
+            const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
+            const int a = B[r0 * DESC_BP + c0];
+            const int bb = B[r1 * DESC_BP + c1];
+            bits[r] = __ballot(a < bb);
+        }
+        uint8_t* D = desc + ((size_t)b * cap + i) * 32;
+        if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        if (lane == 0) {
+            svgpu_keypoint k;
+            k.x = (float)x;
+            k.y = (float)y;
+            if (lv != 0) {  // correct_keypoint_scale (orb_extractor.cc:337-345)
+                k.x = k.x * lev.scale;
+                k.y = k.y * lev.scale;
+            }
+            k.size = lev.kp_size;
+            k.angle = angle;
+            k.response = (float)s.w;
+            k.octave = lv;
+            k.class_id = -1;
+            kps[(size_t)b * cap + i] = k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next keypoint overwrites the slab
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1013,6 +1057,6 @@ void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, c
                         const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur, size_t blur_frame_bytes,
                         svgpu_keypoint* kps, uint8_t* desc, int cap, int batch) {
     if (total_grid == 0) return;
-    hipLaunchKernelGGL(k_describe, dim3((total_grid + 3) / 4, batch), dim3(256), 0, s, levels, num_levels, sel, total_grid,
+    hipLaunchKernelGGL(k_describe, dim3((total_grid + 4 * DESC_KPW - 1) / (4 * DESC_KPW), batch), dim3(256), 0, s, levels, num_levels, sel, total_grid,
                        counts, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, kps, desc, cap);
 }
