@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __shared__ unsigned short s_q[SV_CELL * SV_CELL];
     __shared__ unsigned long long s_key[FAST_KT * FAST_KT];  // per-block arg-max of the selection-grid cells the ROI touches
     __shared__ unsigned short s_gx[SV_ROI_MAX], s_gy[SV_ROI_MAX];  // selection-grid column / row of every ROI column / row
-    __shared__ int s_count, s_qn;
+    __shared__ int s_count, s_wq[4];
     int local, b, ci;
     xcd_frame_map(gridDim.x, gridDim.y, ci, b);
     const int lv = find_level(L, num_levels, ci, &OrbLevel::cell_first, &local);
@@ -617,7 +617,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     }
     if (tid == 0) {
         s_count = 0;
-        s_qn = 0;
     }
     if (tid < FAST_KT * FAST_KT) s_key[tid] = 0ull;
     if (tid < w) s_gx[tid] = gtab[lev.gtab_x_off + cell.min_x + tid - SV_PATCH_RADIUS];
@@ -649,6 +648,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     9-arc brighter than v + t needs (p0 | p8) and (p4 | p12) brighter (same for darker): a necessary condition
     //     that ~90 % of the pixels fail.  Survivors are compacted into an LDS queue so that the expensive arc score
     //     below runs on full waves; it is exact, so queueing a superset of the corners is harmless.
+    //     Every wave owns a quarter of the queue (it scores 16 rows x 64 columns) and counts in a register: no atomics.
+    int wq = 0;
+    unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
     for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
         bool cand = false;
         if (lx < w - 3) {
@@ -662,16 +664,21 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         }
         const unsigned long long bal = __ballot(cand);
         if (bal) {
-            int base = 0;
-            if ((tid & 63) == 0) base = atomicAdd(&s_qn, __popcll(bal));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (cand) s_q[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
+            if (cand) my_q[wq + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
+            wq += __popcll(bal);
         }
     }
+    if ((tid & 63) == 0) s_wq[tid >> 6] = wq;
     __syncthreads();
+    const int o1 = s_wq[0], o2 = o1 + s_wq[1], o3 = o2 + s_wq[2], qn = o3 + s_wq[3];
+    auto qent = [&](int i) -> int {  // flat candidate index -> queue entry (y << 7 | x)
+        const int seg = (i >= o1) + (i >= o2) + (i >= o3);
+        const int off = seg == 0 ? 0 : seg == 1 ? o1 : seg == 2 ? o2 : o3;
+        return s_q[seg * (SV_CELL * SV_CELL / 4) + i - off];
+    };
     // --- pass B: arc score of the candidates
-    for (int i = tid; i < s_qn; i += 256) {
-        const int ly = s_q[i] >> 7, qx = s_q[i] & 127;
+    for (int i = tid; i < qn; i += 256) {
+        const int e = qent(i), ly = e >> 7, qx = e & 127;
         const uint8_t* c = &s_img[ly * FP + qx];
         int p[16];
         load_ring(c, p);
@@ -681,13 +688,12 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
 
     // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
     unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
-    const int qn = s_qn;
     const int gx0 = s_gx[3], gy0 = s_gy[3];  // grid cell of the first scored pixel
     for (int pass = 0; pass < 2; ++pass) {
         const int t = pass == 0 ? ini_thr : min_thr;
         int found = 0;
         for (int i = tid; i < qn; i += 256) {  // only queued pixels can have A > t (t >= tq)
-            const int ly = s_q[i] >> 7, qx = s_q[i] & 127;
+            const int e = qent(i), ly = e >> 7, qx = e & 127;
             const uint8_t* a = &s_a[ly * FP + qx];
             const int A = a[0];
             if (A <= t) continue;
