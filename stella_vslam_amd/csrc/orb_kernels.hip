@@ -734,51 +734,52 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
 // ------------------------------------------------------------------------------------------------ select
 // One block per frame: walk the selection grids level by level in cell-index order, compact the
 // non-empty cells (this IS the output order of distribute_keypoints + extract), clear the keys.
-__global__ __launch_bounds__(256) void k_select(const OrbLevel* __restrict__ L, int num_levels, unsigned long long* __restrict__ keys,
-                                                int total_grid, int4* __restrict__ sel, int32_t* __restrict__ counts) {
-    __shared__ int s_wave[4];
+__global__ __launch_bounds__(1024) void k_select(const OrbLevel* __restrict__ L, int num_levels, unsigned long long* __restrict__ keys,
+                                                 int total_grid, int4* __restrict__ sel, int32_t* __restrict__ counts) {
+    __shared__ int s_wave[16], s_lvcnt[SV_MAX_LEVELS];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* K = keys + (size_t)b * total_grid;
     int4* S = sel + (size_t)b * total_grid;
+    if (tid < SV_MAX_LEVELS) s_lvcnt[tid] = 0;
     int running = 0;
-    for (int lv = 0; lv < num_levels; ++lv) {
-        const OrbLevel lev = L[lv];
-        const int n = lev.grid_x * lev.grid_y;
-        const int level_start = running;
-        for (int base = 0; base < n; base += 256) {
-            const int idx = base + tid;
-            unsigned long long key = 0;
-            if (idx < n) {
-                key = K[lev.grid_first + idx];
-                if (key) K[lev.grid_first + idx] = 0;
-            }
-            const unsigned long long bal = __ballot(key != 0);
-            const int before = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wave[wave] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, total = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < wave) woff += s_wave[k];
-                total += s_wave[k];
-            }
-            if (key) {
-                const uint32_t order = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
-                const int lx = order & 127, ly = (order >> 7) & 127, cid = order >> 14;
-                const int cells_x = lev.cells_x;
-                const int ci = cid / cells_x, cj = cid - ci * cells_x;
-                int4 r;
-                r.x = SV_PATCH_RADIUS + cj * SV_CELL + lx;
-                r.y = SV_PATCH_RADIUS + ci * SV_CELL + ly;
-                r.z = lv;
-                r.w = (int)(key >> 32);
-                S[running + woff + before] = r;
-            }
-            running += total;
-            __syncthreads();
+    // the grids of all levels are contiguous (grid_first ascending): one flat pass in cell-index order, 1024 cells per trip
+    for (int base = 0; base < total_grid; base += 1024) {
+        const int idx = base + tid;
+        unsigned long long key = 0;
+        if (idx < total_grid) {
+            key = K[idx];
+            if (key) K[idx] = 0;
         }
-        if (tid == 0) counts[b * (1 + num_levels) + 1 + lv] = running - level_start;
+        const unsigned long long bal = __ballot(key != 0);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();  // s_wave of the previous trip has been consumed; s_lvcnt is initialised
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < wave) woff += s_wave[k];
+            total += s_wave[k];
+        }
+        if (key) {
+            int lv = 0;
+            while (lv + 1 < num_levels && idx >= L[lv + 1].grid_first) ++lv;
+            const uint32_t order = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+            const int lx = order & 127, ly = (order >> 7) & 127, cid = order >> 14;
+            const int cells_x = L[lv].cells_x;
+            const int ci = cid / cells_x, cj = cid - ci * cells_x;
+            int4 r;
+            r.x = SV_PATCH_RADIUS + cj * SV_CELL + lx;
+            r.y = SV_PATCH_RADIUS + ci * SV_CELL + ly;
+            r.z = lv;
+            r.w = (int)(key >> 32);
+            S[running + woff + before] = r;
+            atomicAdd(&s_lvcnt[lv], 1);
+        }
+        running += total;
     }
+    __syncthreads();
+    if (tid < num_levels) counts[b * (1 + num_levels) + 1 + tid] = s_lvcnt[tid];
     if (tid == 0) counts[b * (1 + num_levels)] = running;
 }
 
@@ -1055,7 +1056,7 @@ void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const
 
 void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,
                       int4* sel, int32_t* counts, int batch) {
-    hipLaunchKernelGGL(k_select, dim3(batch), dim3(256), 0, s, levels, num_levels, keys, total_grid, sel, counts);
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(1024), 0, s, levels, num_levels, keys, total_grid, sel, counts);
 }
 
 void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
