@@ -477,7 +477,8 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
     const int main_tiles = lev.btiles_x * lev.btiles_y;
     if (tile < main_tiles) {
         const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
-        const int ys = (tile / lev.btiles_x) * BLUR_TH + (threadIdx.x >> 6) * BLUR_ROWS;
+        // the strip's first row is the same for the whole wave: say so, and the row pointers of blur_strip become scalar
+        const int ys = __builtin_amdgcn_readfirstlane((tile / lev.btiles_x) * BLUR_TH + (int)(threadIdx.x >> 6) * BLUR_ROWS);
         if (x0 >= lev.w || ys >= lev.h) return;
         if (x0 >= 4 && x0 + 6 < lev.w) blur_strip<BLUR_INTERIOR>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
     }
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     Every wave owns a quarter of the queue (it scores 16 rows x 64 columns) and counts in a register: no atomics.
     int wq = 0;
     unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
-    for (int ly = 3 + (tid >> 6); ly < h - 3; ly += 4) {
+    for (int ly = __builtin_amdgcn_readfirstlane(3 + (tid >> 6)); ly < h - 3; ly += 4) {  // wave-uniform row
         bool cand = false;
         if (lx < w - 3) {
             const uint8_t* c = &s_img[ly * FP + lx];
