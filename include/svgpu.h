@@ -190,6 +190,80 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
                          float min_x, float max_x, float min_y, float max_y, int grid_cols, int grid_rows,
                          int check_orientation, unsigned thr, float lowe_ratio, int mode, int32_t* match_q, int* num_matches);
 
+/* ------------------------------------------------------------------------------ frame observation / reprojection
+ * The host steps either side of extract and match, on the device so that a tracked frame
+ * goes extractor -> undistort -> bearings -> grid -> landmark reprojection -> cell matcher without per-query host work. */
+typedef enum svgpu_camera_model { /* camera/base.h:24-29 model_type_t, same values */
+    SVGPU_CAM_PERSPECTIVE = 0,
+    SVGPU_CAM_FISHEYE = 1,
+    SVGPU_CAM_EQUIRECTANGULAR = 2,
+    SVGPU_CAM_RADIAL_DIVISION = 3
+} svgpu_camera_model;
+
+/* camera::base + the model's parameters (camera/perspective.h:57-73, fisheye.h:51-67, radial_division.h:49-61,
+ * equirectangular.h).  dist: perspective k1 k2 p1 p2 k3 | fisheye k1 k2 k3 k4 | radial_division distortion | unused.
+ * min_x..max_y = img_bounds_ (camera/base.h image_bounds, floats); svgpu_camera_image_bounds fills them. */
+typedef struct svgpu_camera {
+    int32_t model;
+    int32_t pad_;
+    double cols, rows;
+    double fx, fy, cx, cy;
+    double dist[5];
+    double focal_x_baseline;
+    float min_x, max_x, min_y, max_y;
+} svgpu_camera;
+
+/* camera::*::compute_image_bounds (perspective.cc:70-96, fisheye.cc:68-134, radial_division.cc:57-81,
+ * equirectangular.cc:32-36): undistorts the image corners on the device and writes cam->min_x .. max_y. */
+int svgpu_camera_image_bounds(svgpu_ctx* ctx, svgpu_camera* cam);
+
+/* data::frame_observation from the extractor's keypoints (system.cc:384-395):
+ *   undist_kps   camera::*::undistort_keypoints   (cv::undistortPoints / cv::fisheye::undistortPoints restated with the
+ *                reference's CV_32F camera matrix and criteria; radial_division closed form; equirectangular copy)
+ *   bearings     camera::*::convert_keypoints_to_bearings, n x 3 doubles
+ *   cell_off / cell_items   data::assign_keypoints_to_grid (data/common.cc:83-108) as CSR over cell = col * grid_rows + row:
+ *                cell_off has grid_cols * grid_rows + 1 entries, cell_items cell_off[last] <= n keypoint indices (index order
+ *                inside a cell, as the reference's push_back order)
+ * Any output may be NULL.  Host in/out, synchronous. */
+int svgpu_frame_observation(svgpu_ctx* ctx, const svgpu_camera* cam, const svgpu_keypoint* kps, int n, int grid_cols,
+                            int grid_rows, svgpu_keypoint* undist_kps, double* bearings, int32_t* cell_off, int32_t* cell_items);
+
+/* camera::*::convert_keypoints_to_bearings (camera/base.cc:160-164) alone, for callers that hold UNDISTORTED keypoints. */
+int svgpu_keypoints_to_bearings(svgpu_ctx* ctx, const svgpu_camera* cam, const svgpu_keypoint* undist_kps, int n, double* bearings);
+
+/* data::frame::can_observe (data/frame.cc:59-85) for n landmarks at once -- the loop of
+ * tracking_module::search_local_landmarks (tracking_module.cc:554-594) and relocalizer.cc:345:
+ * camera::*::reproject_to_image, landmark::is_inside_in_orb_scale (margins 1.3 and 1/1.3), the viewing-angle test
+ * against ray_cos_thr and landmark::predict_scale_level (data/landmark.cc:336-353).
+ *   rot_cw 9 doubles row-major, trans_cw 3, trans_wc 3 (the frame's camera centre, frame.cc:29)
+ *   pos_w / mean_normal n x 3 doubles; min_valid_dist / max_valid_dist n floats
+ *   skip     nullable n bytes: non-zero = landmark not offered (already tracked, will_be_erased, temporal-ratio rule)
+ *   visible n bytes; reproj n x 2 doubles; x_right n floats; pred_scale_level n ints (-1 where not visible). */
+int svgpu_reproject_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw,
+                              const double* trans_wc, int n, const double* pos_w, const double* mean_normal,
+                              const float* min_valid_dist, const float* max_valid_dist, const uint8_t* skip, float ray_cos_thr,
+                              int num_levels, float log_scale_factor, uint8_t* visible, double* reproj, float* x_right,
+                              int32_t* pred_scale_level);
+
+/* can_observe + projection::match_frame_and_landmarks (match/projection.cc:13-93) in one call, nothing returning to the
+ * host in between: the visible landmarks become the queries of the cell matcher (window margin * scale_factors[pred level],
+ * levels pred-1 .. pred+1, stereo gate against x_right when t_xright is given, SVGPU_MATCH_RATIO_SAME_OCTAVE rule with
+ * thr = HAMMING_DIST_THR_HIGH) over the frame's keypoints binned on the device.
+ *   lm_desc n x 32; scale_factors num_levels floats (orb_params::scale_factors_)
+ *   frame side: tdesc nt x 32, t_xy nt x 2 undistorted positions, t_octave nt, occupied nullable (keypoint already holds an
+ *   observed landmark, projection.cc:52-55), t_xright nullable (frm_obs.stereo_x_right_)
+ *   match_lm n: keypoint index or -1 (the frm.add_landmark calls, in landmark order); visible / reproj / x_right /
+ *   pred_scale_level as svgpu_reproject_landmarks (nullable). */
+int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw,
+                                    const double* trans_wc, int n, const double* pos_w, const double* mean_normal,
+                                    const float* min_valid_dist, const float* max_valid_dist, const uint8_t* skip,
+                                    const uint8_t* lm_desc, float ray_cos_thr, int num_levels, const float* scale_factors,
+                                    float log_scale_factor, float margin, const uint8_t* tdesc, const float* t_xy,
+                                    const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_xright,
+                                    int grid_cols, int grid_rows, unsigned thr, float lowe_ratio, int32_t* match_lm,
+                                    int* num_matches, uint8_t* visible, double* reproj, float* x_right,
+                                    int32_t* pred_scale_level);
+
 /* match::stereo::compute (match/stereo.cc:20-114): for every left keypoint the closest right keypoint in its row band
  * (rows +-2*scale, octave +-1, disparity in [0, focal_x_baseline / true_baseline], Hamming < 75), then the 11x11 L1 patch
  * slide (+-5 px) on the keypoint's pyramid level with parabolic sub-pixel refinement, finally the 2x-median correlation

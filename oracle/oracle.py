@@ -26,7 +26,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> pathlib.Path:
     so = _HERE / "liboracle.so"
-    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "orb_pattern_i8.inc", "Makefile")]
+    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "orb_pattern_i8.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-C", str(_HERE), "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -254,6 +254,74 @@ def stereo_match(kps_left, desc_left, kps_right, desc_right, pyr_left, pyr_right
     lib().orc_stereo_match(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), PL, PR, _p(lw), _p(lh), _p(lsl), _p(lsr), _p(sf), _p(isf), L,
                            C.c_float(focal_x_baseline), C.c_float(true_baseline), _p(xr), _p(dp))
     return xr[:len(kl)].copy(), dp[:len(kl)].copy()
+
+
+# ------------------------------------------------------------------------------------------- frame observation
+
+class Camera(C.Structure):
+    """camera::base + model parameters, laid out as include/svgpu.h's svgpu_camera."""
+    _fields_ = [("model", C.c_int32), ("pad_", C.c_int32), ("cols", C.c_double), ("rows", C.c_double), ("fx", C.c_double),
+                ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("dist", C.c_double * 5),
+                ("focal_x_baseline", C.c_double), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float)]
+
+
+CAM_PERSPECTIVE, CAM_FISHEYE, CAM_EQUIRECTANGULAR, CAM_RADIAL_DIVISION = 0, 1, 2, 3
+
+
+def make_camera(model, cols, rows, fx=0.0, fy=0.0, cx=0.0, cy=0.0, dist=(), focal_x_baseline=0.0):
+    """Camera with img_bounds_ filled by compute_image_bounds, as the reference's constructors do."""
+    cam = Camera()
+    cam.model, cam.cols, cam.rows = int(model), float(cols), float(rows)
+    cam.fx, cam.fy, cam.cx, cam.cy = float(fx), float(fy), float(cx), float(cy)
+    for i, d in enumerate(dist):
+        cam.dist[i] = float(d)
+    cam.focal_x_baseline = float(focal_x_baseline)
+    b = np.zeros(4, np.float32)
+    lib().orc_image_bounds(C.byref(cam), _p(b))
+    cam.min_x, cam.max_x, cam.min_y, cam.max_y = [float(v) for v in b]
+    return cam
+
+
+def undistort_keypoints(cam, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    lib().orc_undistort_keypoints(C.byref(cam), len(xy), _p(xy), _p(out))
+    return out
+
+
+def keypoints_to_bearings(cam, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros((len(xy), 3), np.float64)
+    lib().orc_keypoints_to_bearings(C.byref(cam), len(xy), _p(xy), _p(out))
+    return out
+
+
+def distort_points_for_tests(cam, xy_norm):
+    xy_norm = np.ascontiguousarray(xy_norm, np.float64).reshape(-1, 2)
+    out = np.zeros((len(xy_norm), 2), np.float32)
+    lib().orc_test_distort_points(C.byref(cam), len(xy_norm), _p(xy_norm), _p(out))
+    return out
+
+
+def can_observe(cam, rot_cw, trans_cw, pos_w, mean_normal, min_valid_dist, max_valid_dist, ray_cos_thr=0.5, num_levels=8,
+                log_scale_factor=float(np.log(np.float32(1.2)))):
+    """data::frame::can_observe over n landmarks: (visible u8, reproj n x 2 f64, x_right f32, pred_scale_level i32)."""
+    R = np.ascontiguousarray(rot_cw, np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(trans_cw, np.float64).reshape(3)
+    twc = np.ascontiguousarray(-R.T @ t)  # frame::update_pose_params: trans_wc_ = -rot_wc_ * trans_cw_
+    pw = np.ascontiguousarray(pos_w, np.float64).reshape(-1, 3)
+    nv = np.ascontiguousarray(mean_normal, np.float64).reshape(-1, 3)
+    mn = np.ascontiguousarray(min_valid_dist, np.float32)
+    mx = np.ascontiguousarray(max_valid_dist, np.float32)
+    n = len(pw)
+    vis = np.zeros(n, np.uint8)
+    rp = np.zeros((n, 2), np.float64)
+    xr = np.zeros(n, np.float32)
+    lv = np.zeros(n, np.int32)
+    lib().orc_can_observe(C.byref(cam), _p(R), _p(t), _p(twc), n, _p(pw), _p(nv), _p(mn), _p(mx), C.c_float(ray_cos_thr),
+                          C.c_uint(num_levels), C.c_float(log_scale_factor), _p(vis), _p(rp), _p(xr), _p(lv))
+    return vis, rp, xr, lv
 
 
 # ------------------------------------------------------------------------------------------- BA

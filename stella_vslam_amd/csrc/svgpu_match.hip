@@ -1,9 +1,11 @@
 // Host side of the matchers: staging of host buffers into the context's scratch arena, launches.
 #include <algorithm>
+#include <cmath>
 #include <utility>
 
 #include "svgpu_internal.h"
 #include "match_kernels.h"
+#include "frame_kernels.h"
 
 namespace {
 
@@ -37,6 +39,117 @@ inline void take_sort(Arena& A, BfProblem& P, int pairs, int cap1, int cap2) {
     P.bs1 = A.take<int>(p * 362);
     P.bs2 = A.take<int>(p * 362);
     P.prune_ok = A.take<int>(p * 2);
+}
+
+// The frame side of the cell matcher (keypoints that get binned) -- host pointers.
+struct InCellsFrame {
+    const uint8_t* tdesc;
+    const float* t_xy;
+    const int32_t* t_octave;
+    int nt;
+    const uint8_t* occupied;
+    const float* t_angle;
+    const float* t_xright;
+    float min_x, max_x, min_y, max_y;
+    int grid_cols, grid_rows;
+};
+
+// Candidate lists built on the device + candidate matcher.  `stage(A, fresh, P, G)` places the query-side arrays in the
+// arena (uploading or generating them when `fresh`) and points P / G at them; `finish(P)` enqueues extra read-backs.
+// Pass 0 builds the grid and the list sizes and reads the total back; the scratch arena may then have to grow for the
+// lists, which discards its contents, so pass 1 repeats the (cheap) staging and the grid build in the final arena.
+template <class Stage, class Finish>
+int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_bytes, int check_orientation, unsigned thr, float lowe_ratio,
+                  int mode, Stage&& stage, Finish&& finish, int32_t* match_q, int* num_matches) {
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int nt = F.nt, ncell = F.grid_cols * F.grid_rows;
+    const size_t need1 = query_bytes + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 4 * pad((size_t)nt * 4) + pad(nt)
+                         + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4) + 2 * pad((size_t)nt * 4) + 1024;
+    int total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const size_t need = need1 + (pass ? 2 * pad((size_t)total * 4) : 0);
+        const bool regrow = need > ctx->scratch_bytes;  // pass 1 without regrowth: the arena of pass 0 is still valid, same layout
+        int rc = sv_ensure_scratch(ctx, need);
+        if (rc) return rc;
+        const bool fresh = !pass || regrow;
+        Arena A(ctx->d_scratch);
+        CandProblem P{};
+        GridProblem G{};
+#define UP(dst, T, src, n)                                                                          \
+    T* dst = nullptr;                                                                               \
+    if (src) {                                                                                      \
+        dst = A.take<T>(n);                                                                         \
+        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+    }
+        UP(d_t, uint8_t, F.tdesc, (size_t)nt * 32)
+        UP(d_txy, float, F.t_xy, (size_t)nt * 2)
+        UP(d_toct, int32_t, F.t_octave, nt)
+        UP(d_occ, uint8_t, F.occupied, nt)
+        UP(d_ta, float, F.t_angle, nt)
+        UP(d_tx, float, F.t_xright, nt)
+#undef UP
+        rc = stage(A, fresh, P, G);
+        if (rc) return rc;
+        G.t_xy = d_txy;
+        G.t_octave = d_toct;
+        G.nt = nt;
+        G.min_x = F.min_x;
+        G.min_y = F.min_y;
+        G.inv_w = (double)F.grid_cols / (F.max_x - F.min_x);  // float difference, double quotient: data/common.cc:86-87 via camera::base
+        G.inv_h = (double)F.grid_rows / (F.max_y - F.min_y);
+        G.cols = F.grid_cols;
+        G.rows = F.grid_rows;
+        G.cell_of = A.take<int32_t>(nt);
+        G.cell_off = A.take<int32_t>(ncell + 1);
+        G.cell_items = A.take<int32_t>(nt);
+        G.nq = nq;
+        G.cand_off = A.take<int32_t>(nq + 1);
+        P.match_q = A.take<int32_t>(nq);
+        P.num = A.take<int32_t>(1);
+        int* owner = A.take<int>(nt);
+        int* match = A.take<int>(nq);
+        unsigned* mdist = A.take<unsigned>(nt);
+        if (fresh) sv_launch_grid_build(s, G);
+        if (!pass) {
+            SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            if (total == 0) {
+                rc = finish(P);
+                if (rc) return rc;
+                SV_HIP(ctx, hipStreamSynchronize(s));
+                return SVGPU_OK;
+            }
+            continue;
+        }
+        G.cand_idx = A.take<int32_t>(total);
+        P.dist = A.take<uint32_t>(total);
+        sv_launch_grid_fill(s, G);
+        P.tdesc = (const uint32_t*)d_t;
+        P.t_octave = d_toct;
+        P.nq = nq;
+        P.nt = nt;
+        P.cand_off = G.cand_off;
+        P.cand_idx = G.cand_idx;
+        P.cand_skip = nullptr;
+        P.occupied = d_occ;
+        P.t_angle = d_ta;
+        P.check_orientation = check_orientation;
+        P.t_xright = P.q_xright ? d_tx : nullptr;
+        P.thr = thr;
+        P.lowe_ratio = lowe_ratio;
+        P.mode = mode;
+        sv_launch_cand(ctx, s, P, owner, match, mdist);
+        SV_HIP(ctx, hipGetLastError());
+        int32_t num = 0;
+        SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
+        rc = finish(P);
+        if (rc) return rc;
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        *num_matches = num;
+    }
+    return SVGPU_OK;
 }
 
 }  // namespace
@@ -286,107 +399,312 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
     if (!qdesc || !q_xy || !q_margin || !tdesc || !t_xy || !t_octave || (check_orientation && (!q_angle || !t_angle))
         || ((q_xright || t_xright || q_xr_tol) && !(q_xright && t_xright && q_xr_tol)))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: inconsistent inputs");
-    SV_HIP(ctx, hipSetDevice(ctx->device));
+    InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, min_x, max_x, min_y, max_y, grid_cols, grid_rows};
+    const size_t qbytes = pad((size_t)nq * 32) + pad((size_t)nq * 8) + 6 * pad((size_t)nq * 4) + pad(nq);
     hipStream_t s = ctx->stream;
-    const int ncell = grid_cols * grid_rows;
-    const size_t need1 = pad((size_t)nq * 32) + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 4 * pad((size_t)nt * 4) + pad(nt) + pad((size_t)nq * 8)
-                         + 6 * pad((size_t)nq * 4) + pad(nq) + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4)
-                         + 2 * pad((size_t)nt * 4) + 1024;
-    int total = 0;
-    // Pass 0 builds the grid and the list sizes and reads the total back; the scratch arena may then have to grow for the
-    // lists, which discards its contents, so pass 1 repeats the (cheap) uploads and the grid build in the final arena.
-    for (int pass = 0; pass < 2; ++pass) {
-        const size_t need = need1 + (pass ? 2 * pad((size_t)total * 4) : 0);
-        const bool regrow = need > ctx->scratch_bytes;  // pass 1 without regrowth: the arena of pass 0 is still valid, same layout
-        int rc = sv_ensure_scratch(ctx, need);
-        if (rc) return rc;
-        Arena A(ctx->d_scratch);
-        CandProblem P{};
-        GridProblem G{};
+    return in_cells_core(
+        ctx, nq, F, qbytes, check_orientation, thr, lowe_ratio, mode,
+        [&](Arena& A, bool fresh, CandProblem& P, GridProblem& G) -> int {
 #define UP(dst, T, src, n)                                                                          \
     T* dst = nullptr;                                                                               \
     if (src) {                                                                                      \
         dst = A.take<T>(n);                                                                         \
-        if (!pass || regrow) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
     }
-        UP(d_q, uint8_t, qdesc, (size_t)nq * 32)
-        UP(d_t, uint8_t, tdesc, (size_t)nt * 32)
-        UP(d_txy, float, t_xy, (size_t)nt * 2)
-        UP(d_toct, int32_t, t_octave, nt)
-        UP(d_occ, uint8_t, occupied, nt)
-        UP(d_ta, float, t_angle, nt)
-        UP(d_tx, float, t_xright, nt)
-        UP(d_qxy, float, q_xy, (size_t)nq * 2)
-        UP(d_qm, float, q_margin, nq)
-        UP(d_qlo, int32_t, q_min_level, nq)
-        UP(d_qhi, int32_t, q_max_level, nq)
-        UP(d_qv, uint8_t, q_valid, nq)
-        UP(d_qa, float, q_angle, nq)
-        UP(d_qx, float, q_xright, nq)
-        UP(d_qtol, float, q_xr_tol, nq)
+            UP(d_q, uint8_t, qdesc, (size_t)nq * 32)
+            UP(d_qxy, float, q_xy, (size_t)nq * 2)
+            UP(d_qm, float, q_margin, nq)
+            UP(d_qlo, int32_t, q_min_level, nq)
+            UP(d_qhi, int32_t, q_max_level, nq)
+            UP(d_qv, uint8_t, q_valid, nq)
+            UP(d_qa, float, q_angle, nq)
+            UP(d_qx, float, q_xright, nq)
+            UP(d_qtol, float, q_xr_tol, nq)
 #undef UP
-        G.t_xy = d_txy;
-        G.t_octave = d_toct;
-        G.nt = nt;
-        G.min_x = min_x;
-        G.min_y = min_y;
-        G.inv_w = (double)grid_cols / (max_x - min_x);  // float difference, double quotient: data/common.cc:86-87 via camera::base
-        G.inv_h = (double)grid_rows / (max_y - min_y);
-        G.cols = grid_cols;
-        G.rows = grid_rows;
-        G.cell_of = A.take<int32_t>(nt);
-        G.cell_off = A.take<int32_t>(ncell + 1);
-        G.cell_items = A.take<int32_t>(nt);
-        G.q_xy = d_qxy;
-        G.q_margin = d_qm;
-        G.q_min_level = d_qlo;
-        G.q_max_level = d_qhi;
-        G.q_valid = d_qv;
-        G.nq = nq;
-        G.cand_off = A.take<int32_t>(nq + 1);
-        P.match_q = A.take<int32_t>(nq);
-        P.num = A.take<int32_t>(1);
-        int* owner = A.take<int>(nt);
-        int* match = A.take<int>(nq);
-        unsigned* mdist = A.take<unsigned>(nt);
-        if (!pass || regrow) sv_launch_grid_build(s, G);
-        if (!pass) {
-            SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
-            SV_HIP(ctx, hipStreamSynchronize(s));
-            if (total == 0) return SVGPU_OK;
-            continue;
-        }
-        G.cand_idx = A.take<int32_t>(total);
-        P.dist = A.take<uint32_t>(total);
-        sv_launch_grid_fill(s, G);
-        P.qdesc = (const uint32_t*)d_q;
-        P.tdesc = (const uint32_t*)d_t;
-        P.t_octave = d_toct;
-        P.nq = nq;
-        P.nt = nt;
-        P.cand_off = G.cand_off;
-        P.cand_idx = G.cand_idx;
-        P.cand_skip = nullptr;
-        P.q_valid = d_qv;
-        P.occupied = d_occ;
-        P.q_angle = d_qa;
-        P.t_angle = d_ta;
-        P.check_orientation = check_orientation;
-        P.q_xright = d_qx;
-        P.t_xright = d_tx;
-        P.q_xr_tol = d_qtol;
-        P.thr = thr;
-        P.lowe_ratio = lowe_ratio;
-        P.mode = mode;
-        sv_launch_cand(ctx, s, P, owner, match, mdist);
-        SV_HIP(ctx, hipGetLastError());
-        int32_t num = 0;
-        SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipStreamSynchronize(s));
-        *num_matches = num;
+            G.q_xy = d_qxy;
+            G.q_margin = d_qm;
+            G.q_min_level = d_qlo;
+            G.q_max_level = d_qhi;
+            G.q_valid = d_qv;
+            P.qdesc = (const uint32_t*)d_q;
+            P.q_valid = d_qv;
+            P.q_angle = d_qa;
+            P.q_xright = d_qx;
+            P.q_xr_tol = d_qtol;
+            return SVGPU_OK;
+        },
+        [&](const CandProblem&) -> int { return SVGPU_OK; }, match_q, num_matches);
+}
+
+int svgpu_camera_image_bounds(svgpu_ctx* ctx, svgpu_camera* cam) {
+    if (!ctx || !cam || cam->model < SVGPU_CAM_PERSPECTIVE || cam->model > SVGPU_CAM_RADIAL_DIVISION)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_camera_image_bounds: bad arguments");
+    const float cols = (float)cam->cols, rows = (float)cam->rows;
+    const int nd = cam->model == SVGPU_CAM_PERSPECTIVE ? 5 : cam->model == SVGPU_CAM_FISHEYE ? 4 : cam->model == SVGPU_CAM_RADIAL_DIVISION ? 1 : 0;
+    bool none = true;
+    for (int i = 0; i < nd; ++i) none = none && cam->dist[i] == 0;
+    if (none) {  // "any distortion does not exist"
+        cam->min_x = 0.0f, cam->max_x = cols, cam->min_y = 0.0f, cam->max_y = rows;
+        return SVGPU_OK;
+    }
+    bool wide = false;
+    if (cam->model == SVGPU_CAM_FISHEYE) {  // fisheye.cc:76-83 (issue #83): corners beyond 90 degrees
+        const double pwx = (0.0 - cam->cx) / cam->fx, pwy = (0.0 - cam->cy) / cam->fy;
+        wide = std::sqrt(pwx * pwx + pwy * pwy) > M_PI / 2;
+    }
+    svgpu_keypoint q[4] = {}, u[4];
+    if (wide) {
+        q[0].x = (float)cam->cx, q[0].y = 0.f, q[1].x = cols, q[1].y = (float)cam->cy, q[2].x = 0.f, q[2].y = (float)cam->cy, q[3].x = (float)cam->cx, q[3].y = rows;
+    }
+    else {
+        q[0].x = 0.f, q[0].y = 0.f, q[1].x = cols, q[1].y = 0.f, q[2].x = 0.f, q[2].y = rows, q[3].x = cols, q[3].y = rows;
+    }
+    int rc = svgpu_frame_observation(ctx, cam, q, 4, 1, 1, u, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (wide) {  // fisheye.cc:98-116
+        constexpr float deg_thr = 5.0;
+        const float tx = cam->fx / std::tan(deg_thr * M_PI / 180.0), ty = cam->fy / std::tan(deg_thr * M_PI / 180.0);
+        const float mnx = -tx + cam->cx, mxx = tx + cam->cx, mny = -ty + cam->cy, mxy = ty + cam->cy;
+        const float a = u[2].x, b = u[1].x, c = u[0].y, d = u[3].y;
+        cam->min_x = (a < mnx || a > cam->cx) ? mnx : a;
+        cam->max_x = (b > mxx || b < cam->cx) ? mxx : b;
+        cam->min_y = (c < mny || c > cam->cy) ? mny : c;
+        cam->max_y = (d > mxy || d < cam->cy) ? mxy : d;
+    }
+    else {
+        cam->min_x = std::min(u[0].x, u[2].x);
+        cam->max_x = std::max(u[1].x, u[3].x);
+        cam->min_y = std::min(u[0].y, u[1].y);
+        cam->max_y = std::max(u[2].y, u[3].y);
     }
     return SVGPU_OK;
+}
+
+int svgpu_frame_observation(svgpu_ctx* ctx, const svgpu_camera* cam, const svgpu_keypoint* kps, int n, int grid_cols,
+                            int grid_rows, svgpu_keypoint* undist_kps, double* bearings, int32_t* cell_off, int32_t* cell_items) {
+    if (!ctx || !cam || n < 0 || cam->model < SVGPU_CAM_PERSPECTIVE || cam->model > SVGPU_CAM_RADIAL_DIVISION || grid_cols < 1 || grid_rows < 1
+        || (size_t)grid_cols * grid_rows > (size_t(1) << 22) || (n > 0 && !kps))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_frame_observation: bad arguments");
+    const bool want_grid = cell_off != nullptr;
+    if (want_grid && (!(cam->min_x < cam->max_x) || !(cam->min_y < cam->max_y)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_frame_observation: image bounds are not set (svgpu_camera_image_bounds)");
+    const int ncell = grid_cols * grid_rows;
+    if (n == 0) {
+        if (want_grid) std::memset(cell_off, 0, (size_t)(ncell + 1) * sizeof(int32_t));
+        return SVGPU_OK;
+    }
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t need = 2 * pad((size_t)n * 28) + pad((size_t)n * 8) + pad((size_t)n * 24) + 2 * pad((size_t)n * 4) + pad((size_t)(ncell + 1) * 4) + 1024;
+    int rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    FrameObsProblem P{};
+    P.cam = *cam;
+    svgpu_keypoint* d_in = A.take<svgpu_keypoint>(n);
+    P.kps = d_in;
+    P.n = n;
+    P.undist = undist_kps ? A.take<svgpu_keypoint>(n) : nullptr;
+    P.undist_xy = A.take<float>((size_t)n * 2);
+    P.bearings = bearings ? A.take<double>((size_t)n * 3) : nullptr;
+    SV_HIP(ctx, hipMemcpyAsync(d_in, kps, (size_t)n * sizeof(svgpu_keypoint), hipMemcpyHostToDevice, s));
+    sv_launch_frame_observation(s, P);
+    if (undist_kps) SV_HIP(ctx, hipMemcpyAsync(undist_kps, P.undist, (size_t)n * sizeof(svgpu_keypoint), hipMemcpyDeviceToHost, s));
+    if (bearings) SV_HIP(ctx, hipMemcpyAsync(bearings, P.bearings, (size_t)n * 24, hipMemcpyDeviceToHost, s));
+    if (want_grid) {
+        GridProblem G{};
+        G.t_xy = P.undist_xy;
+        G.nt = n;
+        G.min_x = cam->min_x;
+        G.min_y = cam->min_y;
+        G.inv_w = (double)grid_cols / (cam->max_x - cam->min_x);
+        G.inv_h = (double)grid_rows / (cam->max_y - cam->min_y);
+        G.cols = grid_cols;
+        G.rows = grid_rows;
+        G.cell_of = A.take<int32_t>(n);
+        G.cell_off = A.take<int32_t>(ncell + 1);
+        G.cell_items = A.take<int32_t>(n);
+        G.nq = 0;
+        G.cand_off = A.take<int32_t>(1);
+        sv_launch_grid_build(s, G);
+        SV_HIP(ctx, hipMemcpyAsync(cell_off, G.cell_off, (size_t)(ncell + 1) * 4, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        if (cell_items && cell_off[ncell] > 0)
+            SV_HIP(ctx, hipMemcpyAsync(cell_items, G.cell_items, (size_t)cell_off[ncell] * 4, hipMemcpyDeviceToHost, s));
+    }
+    SV_HIP(ctx, hipGetLastError());
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    return SVGPU_OK;
+}
+
+int svgpu_keypoints_to_bearings(svgpu_ctx* ctx, const svgpu_camera* cam, const svgpu_keypoint* undist_kps, int n, double* bearings) {
+    if (!ctx || !cam || n < 0 || cam->model < SVGPU_CAM_PERSPECTIVE || cam->model > SVGPU_CAM_RADIAL_DIVISION || (n > 0 && (!undist_kps || !bearings)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_keypoints_to_bearings: bad arguments");
+    if (n == 0) return SVGPU_OK;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = sv_ensure_scratch(ctx, pad((size_t)n * 28) + pad((size_t)n * 24) + 256);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    FrameObsProblem P{};
+    P.cam = *cam;
+    svgpu_keypoint* d_in = A.take<svgpu_keypoint>(n);
+    P.kps = d_in;
+    P.n = n;
+    P.already_undistorted = 1;
+    P.bearings = A.take<double>((size_t)n * 3);
+    SV_HIP(ctx, hipMemcpyAsync(d_in, undist_kps, (size_t)n * sizeof(svgpu_keypoint), hipMemcpyHostToDevice, s));
+    sv_launch_frame_observation(s, P);
+    SV_HIP(ctx, hipGetLastError());
+    SV_HIP(ctx, hipMemcpyAsync(bearings, P.bearings, (size_t)n * 24, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    return SVGPU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// Shared argument checks + ReprojProblem fill of the two reprojection entry points (host-side scalars only).
+int fill_reproj(svgpu_ctx* ctx, const char* who, ReprojProblem& R, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw,
+                const double* trans_wc, int n, const double* pos_w, const double* mean_normal, const float* min_valid_dist,
+                const float* max_valid_dist, float ray_cos_thr, int num_levels, float log_scale_factor) {
+    if (!ctx || !cam || n < 0 || cam->model < SVGPU_CAM_PERSPECTIVE || cam->model > SVGPU_CAM_RADIAL_DIVISION || !rot_cw || !trans_cw || !trans_wc
+        || num_levels < 1 || num_levels > SV_MAX_LEVELS || !(log_scale_factor > 0.f)
+        || (n > 0 && (!pos_w || !mean_normal || !min_valid_dist || !max_valid_dist)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, who);
+    R.cam = *cam;
+    std::memcpy(R.rot_cw, rot_cw, sizeof R.rot_cw);
+    std::memcpy(R.trans_cw, trans_cw, sizeof R.trans_cw);
+    std::memcpy(R.trans_wc, trans_wc, sizeof R.trans_wc);
+    R.n = n;
+    R.ray_cos_thr = ray_cos_thr;
+    R.num_levels = (unsigned)num_levels;
+    R.log_scale_factor = log_scale_factor;
+    return SVGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int svgpu_reproject_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw,
+                              const double* trans_wc, int n, const double* pos_w, const double* mean_normal,
+                              const float* min_valid_dist, const float* max_valid_dist, const uint8_t* skip, float ray_cos_thr,
+                              int num_levels, float log_scale_factor, uint8_t* visible, double* reproj, float* x_right,
+                              int32_t* pred_scale_level) {
+    ReprojProblem R{};
+    int rc = fill_reproj(ctx, "svgpu_reproject_landmarks: bad arguments", R, cam, rot_cw, trans_cw, trans_wc, n, pos_w, mean_normal, min_valid_dist,
+                         max_valid_dist, ray_cos_thr, num_levels, log_scale_factor);
+    if (rc) return rc;
+    if (n == 0) return SVGPU_OK;
+    if (!visible || !reproj || !x_right || !pred_scale_level) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_reproject_landmarks: null output");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t need = 2 * pad((size_t)n * 24) + 4 * pad((size_t)n * 4) + 2 * pad(n) + pad((size_t)n * 16) + 1024;
+    rc = sv_ensure_scratch(ctx, need);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    double* d_pw = A.take<double>((size_t)n * 3);
+    double* d_nv = A.take<double>((size_t)n * 3);
+    float* d_mn = A.take<float>(n);
+    float* d_mx = A.take<float>(n);
+    uint8_t* d_skip = skip ? A.take<uint8_t>(n) : nullptr;
+    R.visible = A.take<uint8_t>(n);
+    R.reproj = A.take<double>((size_t)n * 2);
+    R.x_right = A.take<float>(n);
+    R.pred_level = A.take<int32_t>(n);
+    SV_HIP(ctx, hipMemcpyAsync(d_pw, pos_w, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d_nv, mean_normal, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d_mn, min_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipMemcpyAsync(d_mx, max_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (skip) SV_HIP(ctx, hipMemcpyAsync(d_skip, skip, n, hipMemcpyHostToDevice, s));
+    R.pos_w = d_pw, R.mean_normal = d_nv, R.min_valid_dist = d_mn, R.max_valid_dist = d_mx, R.skip = d_skip;
+    sv_launch_reproject(s, R);
+    SV_HIP(ctx, hipGetLastError());
+    SV_HIP(ctx, hipMemcpyAsync(visible, R.visible, n, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(reproj, R.reproj, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(x_right, R.x_right, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(pred_scale_level, R.pred_level, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    return SVGPU_OK;
+}
+
+int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw,
+                                    const double* trans_wc, int n, const double* pos_w, const double* mean_normal,
+                                    const float* min_valid_dist, const float* max_valid_dist, const uint8_t* skip,
+                                    const uint8_t* lm_desc, float ray_cos_thr, int num_levels, const float* scale_factors,
+                                    float log_scale_factor, float margin, const uint8_t* tdesc, const float* t_xy,
+                                    const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_xright,
+                                    int grid_cols, int grid_rows, unsigned thr, float lowe_ratio, int32_t* match_lm,
+                                    int* num_matches, uint8_t* visible, double* reproj, float* x_right,
+                                    int32_t* pred_scale_level) {
+    ReprojProblem R{};
+    int rc = fill_reproj(ctx, "svgpu_match_frame_and_landmarks: bad arguments", R, cam, rot_cw, trans_cw, trans_wc, n, pos_w, mean_normal,
+                         min_valid_dist, max_valid_dist, ray_cos_thr, num_levels, log_scale_factor);
+    if (rc) return rc;
+    if (nt < 0 || nt >= (1 << 22) || !num_matches || !scale_factors || grid_cols < 1 || grid_rows < 1 || (size_t)grid_cols * grid_rows > (size_t(1) << 22)
+        || !(cam->min_x < cam->max_x) || !(cam->min_y < cam->max_y) || (n > 0 && (!lm_desc || !match_lm)) || (nt > 0 && (!tdesc || !t_xy || !t_octave)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_frame_and_landmarks: bad arguments");
+    *num_matches = 0;
+    if (n == 0) return SVGPU_OK;
+    for (int i = 0; i < n; ++i) match_lm[i] = -1;
+    if (nt == 0)  // no keypoints: only the observability outputs are meaningful
+        return (visible && reproj && x_right && pred_scale_level)
+                   ? svgpu_reproject_landmarks(ctx, cam, rot_cw, trans_cw, trans_wc, n, pos_w, mean_normal, min_valid_dist, max_valid_dist, skip,
+                                               ray_cos_thr, num_levels, log_scale_factor, visible, reproj, x_right, pred_scale_level)
+                   : SVGPU_OK;
+    R.margin = margin;
+    for (int l = 0; l < num_levels; ++l) R.scale_factors[l] = scale_factors[l];
+    InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, nullptr, t_xright, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    const size_t qbytes = pad((size_t)n * 32) + 2 * pad((size_t)n * 24) + 8 * pad((size_t)n * 4) + 2 * pad(n) + pad((size_t)n * 16) + pad((size_t)n * 8);
+    hipStream_t s = ctx->stream;
+    return in_cells_core(
+        ctx, n, F, qbytes, 0, thr, lowe_ratio, SVGPU_MATCH_RATIO_SAME_OCTAVE,
+        [&](Arena& A, bool fresh, CandProblem& P, GridProblem& G) -> int {
+            uint8_t* d_q = A.take<uint8_t>((size_t)n * 32);
+            double* d_pw = A.take<double>((size_t)n * 3);
+            double* d_nv = A.take<double>((size_t)n * 3);
+            float* d_mn = A.take<float>(n);
+            float* d_mx = A.take<float>(n);
+            uint8_t* d_skip = skip ? A.take<uint8_t>(n) : nullptr;
+            R.visible = A.take<uint8_t>(n);
+            R.reproj = A.take<double>((size_t)n * 2);
+            R.x_right = A.take<float>(n);
+            R.pred_level = A.take<int32_t>(n);
+            R.q_xy = A.take<float>((size_t)n * 2);
+            R.q_margin = A.take<float>(n);
+            R.q_min_level = A.take<int32_t>(n);
+            R.q_max_level = A.take<int32_t>(n);
+            R.pos_w = d_pw, R.mean_normal = d_nv, R.min_valid_dist = d_mn, R.max_valid_dist = d_mx, R.skip = d_skip;
+            if (fresh) {
+                SV_HIP(ctx, hipMemcpyAsync(d_q, lm_desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+                SV_HIP(ctx, hipMemcpyAsync(d_pw, pos_w, (size_t)n * 24, hipMemcpyHostToDevice, s));
+                SV_HIP(ctx, hipMemcpyAsync(d_nv, mean_normal, (size_t)n * 24, hipMemcpyHostToDevice, s));
+                SV_HIP(ctx, hipMemcpyAsync(d_mn, min_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
+                SV_HIP(ctx, hipMemcpyAsync(d_mx, max_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
+                if (skip) SV_HIP(ctx, hipMemcpyAsync(d_skip, skip, n, hipMemcpyHostToDevice, s));
+                sv_launch_reproject(s, R);
+            }
+            G.q_xy = R.q_xy;
+            G.q_margin = R.q_margin;
+            G.q_min_level = R.q_min_level;
+            G.q_max_level = R.q_max_level;
+            G.q_valid = R.visible;
+            P.qdesc = (const uint32_t*)d_q;
+            P.q_valid = R.visible;
+            if (t_xright) {  // projection.cc:57-62: |lm_to_x_right - stereo_x_right| against margin * scale
+                P.q_xright = R.x_right;
+                P.q_xr_tol = R.q_margin;
+            }
+            return SVGPU_OK;
+        },
+        [&](const CandProblem&) -> int {
+            if (visible) SV_HIP(ctx, hipMemcpyAsync(visible, R.visible, n, hipMemcpyDeviceToHost, s));
+            if (reproj) SV_HIP(ctx, hipMemcpyAsync(reproj, R.reproj, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+            if (x_right) SV_HIP(ctx, hipMemcpyAsync(x_right, R.x_right, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+            if (pred_scale_level) SV_HIP(ctx, hipMemcpyAsync(pred_scale_level, R.pred_level, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+            return SVGPU_OK;
+        },
+        match_lm, num_matches);
 }
 
 int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_keypoint* kps_left, const uint8_t* desc_left,

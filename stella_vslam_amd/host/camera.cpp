@@ -1,0 +1,79 @@
+#include "camera.h"
+
+#include <stdexcept>
+
+namespace stella_vslam_hip {
+namespace camera {
+
+namespace {
+void check(svgpu_ctx* ctx, int rc, const char* where) {
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string(where) + ": " + svgpu_last_error(ctx));
+}
+static_assert(sizeof(cv::KeyPoint) == sizeof(svgpu_keypoint), "KeyPoint layout");
+static_assert(sizeof(Vec3_t) == 24 && sizeof(Vec2_t) == 16, "Eigen-compatible packing");
+}  // namespace
+
+base::base(svgpu_ctx* ctx, model_type_t model, unsigned int cols, unsigned int rows, double fx, double fy, double cx, double cy,
+           const std::vector<double>& dist, double focal_x_baseline)
+    : model_type_(model), cols_(cols), rows_(rows), focal_x_baseline_(focal_x_baseline), ctx_(ctx), c_{} {
+    c_.model = (int32_t)model;
+    c_.cols = cols;
+    c_.rows = rows;
+    c_.fx = fx, c_.fy = fy, c_.cx = cx, c_.cy = cy;
+    for (size_t i = 0; i < dist.size() && i < 5; ++i) c_.dist[i] = dist[i];
+    c_.focal_x_baseline = focal_x_baseline;
+    img_bounds_ = compute_image_bounds();
+    c_.min_x = img_bounds_.min_x_, c_.max_x = img_bounds_.max_x_, c_.min_y = img_bounds_.min_y_, c_.max_y = img_bounds_.max_y_;
+}
+
+image_bounds base::compute_image_bounds() const {
+    svgpu_camera c = c_;
+    check(ctx_, svgpu_camera_image_bounds(ctx_, &c), "svgpu_camera_image_bounds");
+    return image_bounds{c.min_x, c.max_x, c.min_y, c.max_y};
+}
+
+void base::undistort_keypoints(const std::vector<cv::KeyPoint>& dist_keypts, std::vector<cv::KeyPoint>& undist_keypts) const {
+    undist_keypts.resize(dist_keypts.size());
+    check(ctx_, svgpu_frame_observation(ctx_, &c_, reinterpret_cast<const svgpu_keypoint*>(dist_keypts.data()), (int)dist_keypts.size(), 1, 1,
+                                        reinterpret_cast<svgpu_keypoint*>(undist_keypts.data()), nullptr, nullptr, nullptr),
+          "svgpu_frame_observation");
+}
+
+void base::convert_keypoints_to_bearings(const std::vector<cv::KeyPoint>& undist_keypts, std::vector<Vec3_t>& bearings) const {
+    bearings.resize(undist_keypts.size());
+    check(ctx_, svgpu_keypoints_to_bearings(ctx_, &c_, reinterpret_cast<const svgpu_keypoint*>(undist_keypts.data()), (int)undist_keypts.size(),
+                                            reinterpret_cast<double*>(bearings.data())),
+          "svgpu_keypoints_to_bearings");
+}
+
+void base::observe(const std::vector<cv::KeyPoint>& dist_keypts, unsigned int num_grid_cols, unsigned int num_grid_rows,
+                   std::vector<cv::KeyPoint>& undist_keypts, std::vector<Vec3_t>& bearings, std::vector<int>& cell_off,
+                   std::vector<int>& cell_items) const {
+    const size_t n = dist_keypts.size();
+    undist_keypts.resize(n);
+    bearings.resize(n);
+    cell_off.assign((size_t)num_grid_cols * num_grid_rows + 1, 0);
+    cell_items.assign(n ? n : 1, 0);
+    check(ctx_, svgpu_frame_observation(ctx_, &c_, reinterpret_cast<const svgpu_keypoint*>(dist_keypts.data()), (int)n, (int)num_grid_cols,
+                                        (int)num_grid_rows, reinterpret_cast<svgpu_keypoint*>(undist_keypts.data()),
+                                        reinterpret_cast<double*>(bearings.data()), cell_off.data(), cell_items.data()),
+          "svgpu_frame_observation");
+    cell_items.resize((size_t)cell_off.back());
+}
+
+void base::can_observe(const Mat33_t& rot_cw, const Vec3_t& trans_cw, const Vec3_t& trans_wc, const landmark_set& lms, float ray_cos_thr,
+                       unsigned int num_levels, float log_scale_factor, observability& out) const {
+    const int n = (int)lms.pos_w.size();
+    out.visible.assign((size_t)n, 0);
+    out.reproj.assign((size_t)n, Vec2_t{0, 0});
+    out.x_right.assign((size_t)n, 0.f);
+    out.pred_scale_level.assign((size_t)n, -1);
+    check(ctx_, svgpu_reproject_landmarks(ctx_, &c_, rot_cw.data(), trans_cw.data(), trans_wc.data(), n, reinterpret_cast<const double*>(lms.pos_w.data()),
+                                          reinterpret_cast<const double*>(lms.mean_normal.data()), lms.min_valid_dist.data(), lms.max_valid_dist.data(),
+                                          lms.skip.empty() ? nullptr : lms.skip.data(), ray_cos_thr, (int)num_levels, log_scale_factor,
+                                          out.visible.data(), reinterpret_cast<double*>(out.reproj.data()), out.x_right.data(), out.pred_scale_level.data()),
+          "svgpu_reproject_landmarks");
+}
+
+}  // namespace camera
+}  // namespace stella_vslam_hip

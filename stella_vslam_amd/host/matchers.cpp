@@ -96,6 +96,41 @@ unsigned int projection::match_in_cells(const query_set& q, const std::vector<cv
     return (unsigned int)num;
 }
 
+unsigned int projection::match_frame_and_landmarks(const camera::base& cam, const Mat33_t& rot_cw, const Vec3_t& trans_cw, const Vec3_t& trans_wc,
+                                                   const camera::landmark_set& lms, const data::frame_observation& frm_obs,
+                                                   const std::vector<unsigned char>& occupied, const feature::orb_params& orb_params,
+                                                   unsigned int num_grid_cols, unsigned int num_grid_rows, float margin,
+                                                   std::vector<int>& matched_idx_for_landmark, camera::observability& obs, float ray_cos_thr) const {
+    const int n = (int)lms.pos_w.size(), nt = (int)frm_obs.undist_keypts_.size();
+    std::vector<float> txy(2 * (size_t)nt);
+    std::vector<int32_t> toct(nt);
+    for (int i = 0; i < nt; ++i) {
+        toct[i] = frm_obs.undist_keypts_[i].octave;
+        txy[2 * i] = frm_obs.undist_keypts_[i].pt.x;
+        txy[2 * i + 1] = frm_obs.undist_keypts_[i].pt.y;
+    }
+    const auto qd = pack_rows(lms.descriptors), td = pack_rows(frm_obs.descriptors_);
+    matched_idx_for_landmark.assign((size_t)std::max(n, 1), -1);
+    obs.visible.assign((size_t)n, 0);
+    obs.reproj.assign((size_t)n, Vec2_t{0, 0});
+    obs.x_right.assign((size_t)n, 0.f);
+    obs.pred_scale_level.assign((size_t)n, -1);
+    int num = 0;
+    check(ctx_, svgpu_match_frame_and_landmarks(ctx_, &cam.c_abi(), rot_cw.data(), trans_cw.data(), trans_wc.data(), n,
+                                                reinterpret_cast<const double*>(lms.pos_w.data()), reinterpret_cast<const double*>(lms.mean_normal.data()),
+                                                lms.min_valid_dist.data(), lms.max_valid_dist.data(), lms.skip.empty() ? nullptr : lms.skip.data(),
+                                                qd.data(), ray_cos_thr, (int)orb_params.num_levels_, orb_params.scale_factors_.data(),
+                                                orb_params.log_scale_factor_, margin, td.data(), txy.data(), toct.data(), nt,
+                                                occupied.empty() ? nullptr : occupied.data(),
+                                                frm_obs.stereo_x_right_.empty() ? nullptr : frm_obs.stereo_x_right_.data(), (int)num_grid_cols,
+                                                (int)num_grid_rows, HAMMING_DIST_THR_HIGH, lowe_ratio_, matched_idx_for_landmark.data(), &num,
+                                                obs.visible.data(), reinterpret_cast<double*>(obs.reproj.data()), obs.x_right.data(),
+                                                obs.pred_scale_level.data()),
+          "svgpu_match_frame_and_landmarks");
+    matched_idx_for_landmark.resize((size_t)n);
+    return (unsigned int)num;
+}
+
 void stereo::compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
     const int nl = (int)keypts_left_.size(), nr = (int)keypts_right_.size();
     stereo_x_right.assign((size_t)nl, -1.0f);

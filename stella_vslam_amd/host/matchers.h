@@ -6,6 +6,7 @@
 #include <utility>
 #include <vector>
 
+#include "camera.h"
 #include "orb_extractor.h"
 
 namespace stella_vslam_hip {
@@ -68,6 +69,16 @@ public:
                                 const data::frame_observation& frm_obs, const std::vector<unsigned char>& occupied, const float img_bounds[4],
                                 int num_grid_cols, int num_grid_rows, int mode, unsigned int hamm_dist_thr,
                                 std::vector<int>& matched_idx_for_query) const;
+
+    //! projection::match_frame_and_landmarks (match/projection.cc:13-93) fused with the observability loop that feeds it
+    //! (tracking_module.cc:554-594 -> data/frame.cc:59-85): nothing returns to the host between reprojection, window lookup
+    //! (get_keypoints_in_cell) and matching.  matched_idx_for_landmark[i] = idx of frm.add_landmark(lm_i, idx) or -1; `obs` gets
+    //! the lm_to_reproj / lm_to_x_right / lm_to_scale values (callers bump increase_num_observable from obs.visible).
+    unsigned int match_frame_and_landmarks(const camera::base& cam, const Mat33_t& rot_cw, const Vec3_t& trans_cw, const Vec3_t& trans_wc,
+                                           const camera::landmark_set& lms, const data::frame_observation& frm_obs,
+                                           const std::vector<unsigned char>& occupied, const feature::orb_params& orb_params,
+                                           unsigned int num_grid_cols, unsigned int num_grid_rows, float margin,
+                                           std::vector<int>& matched_idx_for_landmark, camera::observability& obs, float ray_cos_thr = 0.5f) const;
 };
 
 //! match::area (match/area.h): the monocular initialiser's matcher on the same flattened inputs.  query_set = the keypoints of

@@ -180,6 +180,59 @@ int main() {
         std::printf("stereo: %d of %d matched keypoints at the true disparity\n", ok, tot);
         REQUIRE(tot > 500 && 2 * ok > tot);  // the rectangle texture is self-similar along rows: the majority, not all, lock on
     }
+    // frame observation + observability + fused landmark matcher: landmarks placed along the bearings of frame 1's keypoints
+    // must reproject onto those keypoints and match them
+    {
+        camera::perspective cam(ext.context(), 640, 480, 458.654, 457.296, 320.0, 240.0, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0);
+        REQUIRE(cam.img_bounds_.min_x_ < 0.f && cam.img_bounds_.max_x_ > 640.f);
+        std::vector<cv::KeyPoint> und;
+        std::vector<Vec3_t> brg, brg2;
+        std::vector<int> cell_off, cell_items;
+        cam.observe(k1, 64, 48, und, brg, cell_off, cell_items);
+        REQUIRE(und.size() == k1.size() && brg.size() == k1.size() && cell_off.size() == 64 * 48 + 1 && (size_t)cell_off.back() == cell_items.size());
+        REQUIRE(cell_items.size() > k1.size() / 2);
+        cam.convert_keypoints_to_bearings(und, brg2);
+        REQUIRE(std::memcmp(brg.data(), brg2.data(), brg.size() * sizeof(Vec3_t)) == 0);
+        std::vector<cv::KeyPoint> und2;
+        cam.undistort_keypoints(k1, und2);
+        REQUIRE(std::memcmp(und.data(), und2.data(), und.size() * sizeof(cv::KeyPoint)) == 0);
+        camera::landmark_set lms;
+        const Mat33_t R = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const Vec3_t t = {0.1, -0.05, 0.2}, twc = {-0.1, 0.05, -0.2};
+        const int n = (int)k1.size();
+        lms.descriptors.create(n, 32, cv::CV_8U);
+        for (int i = 0; i < n; ++i) {
+            const double depth = 3.0 + (i % 50) * 0.1;
+            const Vec3_t pc = {brg[i][0] / brg[i][2] * depth, brg[i][1] / brg[i][2] * depth, depth};
+            const Vec3_t pw = {pc[0] - t[0], pc[1] - t[1], pc[2] - t[2]};
+            const double d = std::sqrt((pw[0] - twc[0]) * (pw[0] - twc[0]) + (pw[1] - twc[1]) * (pw[1] - twc[1]) + (pw[2] - twc[2]) * (pw[2] - twc[2]));
+            lms.pos_w.push_back(pw);
+            lms.mean_normal.push_back(Vec3_t{(pw[0] - twc[0]) / d, (pw[1] - twc[1]) / d, (pw[2] - twc[2]) / d});
+            const float mx = (float)(d * 1.1 * params.scale_factors_[und[i].octave]);
+            lms.max_valid_dist.push_back(mx);
+            lms.min_valid_dist.push_back(mx / params.scale_factors_[7]);
+            std::memcpy(lms.descriptors.ptr(i), d1.ptr(i), 32);
+        }
+        camera::observability ob;
+        cam.can_observe(R, t, twc, lms, 0.5f, params.num_levels_, params.log_scale_factor_, ob);
+        int vis = 0, close = 0;
+        for (int i = 0; i < n; ++i)
+            if (ob.visible[i]) {
+                ++vis;
+                close += std::fabs(ob.reproj[i][0] - und[i].pt.x) < 1e-3 && std::fabs(ob.reproj[i][1] - und[i].pt.y) < 1e-3 && ob.pred_scale_level[i] == std::min(7, und[i].octave + 1);
+            }
+        REQUIRE(vis > n * 9 / 10 && close == vis);
+        data::frame_observation fo;
+        fo.descriptors_ = d1;
+        fo.undist_keypts_ = und;
+        std::vector<int> mi;
+        camera::observability ob2;
+        const unsigned nmf = match::projection(ext.context(), 0.8f, true).match_frame_and_landmarks(cam, R, t, twc, lms, fo, {}, params, 64, 48, 5.0f, mi, ob2);
+        int self = 0;
+        for (int i = 0; i < n; ++i) self += mi[i] == i;
+        REQUIRE(nmf > (unsigned)vis * 8 / 10 && (unsigned)self > nmf * 95 / 100 && ob2.visible == ob.visible);
+        std::printf("frame observation: %d keypoints, %d landmarks visible, %u matched (%d onto their own keypoint)\n", n, vis, nmf, self);
+    }
     // motion-only BA: perturbed camera 2 against the 60 exact observations of the scene above
     {
         std::vector<double> pos_w;

@@ -115,6 +115,40 @@ class projection(base):
         return out, num.value
 
 
+    def match_frame_and_landmarks(self, camera, rot_cw, trans_cw, pos_w, mean_normal, min_valid_dist, max_valid_dist, lm_desc,
+                                  frm_obs, scale_factors, log_scale_factor, margin=5.0, skip=None, occupied=None, ray_cos_thr=0.5,
+                                  trans_wc=None):
+        """tracking_module::search_local_landmarks' observability loop (tracking_module.cc:554-594 -> data/frame.cc:59-85)
+        followed by projection::match_frame_and_landmarks (match/projection.cc:13-93) as ONE device pass: the landmarks come in
+        as flat arrays (position, mean viewing direction, valid distance range, representative descriptor), `skip` marks the
+        ones the caller's object graph excludes, `occupied` the keypoints that already hold an observed landmark.
+        Returns (match_lm, num_matches, visible, reproj, x_right, pred_scale_level); match_lm[i] = keypoint index given to
+        frm.add_landmark(lm_i, idx) or -1."""
+        R = np.ascontiguousarray(rot_cw, np.float64).reshape(3, 3)
+        t = np.ascontiguousarray(trans_cw, np.float64).reshape(3)
+        twc = np.ascontiguousarray(-R.T @ t if trans_wc is None else trans_wc, np.float64)
+        pw = np.ascontiguousarray(pos_w, np.float64).reshape(-1, 3)
+        nv = np.ascontiguousarray(mean_normal, np.float64).reshape(-1, 3)
+        mn, mx = _c(min_valid_dist, np.float32), _c(max_valid_dist, np.float32)
+        qd = _c(lm_desc, np.uint8)
+        sk, occ = _c(skip, np.uint8), _c(occupied, np.uint8)
+        sf = _c(scale_factors, np.float32)
+        td = _c(frm_obs.descriptors_, np.uint8)
+        txy = np.ascontiguousarray(np.stack([frm_obs.undist_keypts_["x"], frm_obs.undist_keypts_["y"]], 1), np.float32)
+        toct = _c(frm_obs.undist_keypts_["octave"], np.int32)
+        tx = _c(frm_obs.stereo_x_right_, np.float32)
+        n = len(pw)
+        out = np.full(n, -1, np.int32)
+        num = C.c_int(0)
+        vis, rp, xr, lv = np.zeros(n, np.uint8), np.zeros((n, 2), np.float64), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        self.ctx.check(lib().svgpu_match_frame_and_landmarks(
+            self.ctx.handle, C.byref(camera.c_), _p(R), _p(t), _p(twc), n, _p(pw), _p(nv), _p(mn), _p(mx), _p(sk), _p(qd),
+            C.c_float(ray_cos_thr), len(sf), _p(sf), C.c_float(log_scale_factor), C.c_float(margin), _p(td), _p(txy), _p(toct), len(td),
+            _p(occ), _p(tx), frm_obs.num_grid_cols_, frm_obs.num_grid_rows_, C.c_uint(HAMMING_DIST_THR_HIGH), C.c_float(self.lowe_ratio_),
+            _p(out), C.byref(num), _p(vis), _p(rp), _p(xr), _p(lv)), "svgpu_match_frame_and_landmarks")
+        return out, num.value, vis, rp, xr, lv
+
+
 class area(base):
     """match/area.h (the monocular initialiser's matcher).  match_in_consistent_area (match/area.cc:8-98) on flattened inputs:
     level-0 keypoints of frame 1 are the queries, the candidate list of query idx_1 is

@@ -5,7 +5,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle as O
-from stella_vslam_amd import feature, match as M, optimize, synthetic as S
+from stella_vslam_amd import camera as CAM, data as D, feature, match as M, optimize, synthetic as S
 
 
 def timeit(f, n, warm=2):
@@ -57,6 +57,56 @@ c, exp = timeit(cpu_projection, 3, 1)
 assert np.array_equal(got, exp)
 out["projection_match_in_cells_ms"] = {"gpu": round(g, 3), "cpu_oracle_incl_python_list_building": round(c, 3), "queries": int(len(k0)),
                                        "matches": int(num)}
+# ---- frame observation (undistort + bearings + grid) and the fused can_observe + match_frame_and_landmarks pass
+EU = dict(fx=458.654, fy=457.296, cx=320.0, cy=240.0, k=(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0))
+cam = CAM.perspective("euroc-like", "Monocular", "Gray", 640, 480, 20.0, EU["fx"], EU["fy"], EU["cx"], EU["cy"], *EU["k"], ctx=ctx)
+ocam = O.make_camera(O.CAM_PERSPECTIVE, 640, 480, EU["fx"], EU["fy"], EU["cx"], EU["cy"], EU["k"])
+g, obs = timeit(lambda: D.frame_observation(cam, k1, d1), 100)
+
+
+def cpu_observation():
+    und = O.undistort_keypoints(ocam, np.stack([k1["x"], k1["y"]], 1))
+    return und, O.keypoints_to_bearings(ocam, und), O.assign_keypoints_to_grid(und[:, 0], und[:, 1], (ocam.min_x, ocam.max_x, ocam.min_y, ocam.max_y))
+
+
+c, (und_c, brg_c, _) = timeit(cpu_observation, 20, 1)
+assert np.array_equal(np.stack([obs.undist_keypts_["x"], obs.undist_keypts_["y"]], 1), und_c) and np.array_equal(obs.bearings_, brg_c)
+out["frame_observation_ms"] = {"gpu": round(g, 3), "cpu_oracle": round(c, 3), "keypoints": int(len(k1))}
+rng = np.random.default_rng(0)
+nl = 4000                                     # a typical local map seen from this frame
+pick = rng.integers(0, len(k1), nl)
+depth = rng.uniform(2, 9, nl)
+pw = obs.bearings_[pick] / obs.bearings_[pick, 2:3] * depth[:, None] + rng.normal(0, 0.01, (nl, 3))
+nv = pw / np.linalg.norm(pw, axis=1, keepdims=True)
+mx = (np.linalg.norm(pw, axis=1) * rng.uniform(0.85, 1.15, nl) * sf[k1["octave"][pick]]).astype(np.float32)
+mn = (mx / sf[7]).astype(np.float32)
+lmd = d1[pick].copy()
+lmd[:, rng.integers(0, 32)] ^= 0x55
+lsf = float(np.log(np.float32(1.2)))
+g, r = timeit(lambda: proj.match_frame_and_landmarks(cam, np.eye(3), np.zeros(3), pw, nv, mn, mx, lmd, obs, sf, lsf, margin=5.0), 50)
+
+
+def cpu_track():
+    vis, rp, xr, lv = O.can_observe(ocam, np.eye(3), np.zeros(3), pw, nv, mn, mx, 0.5, 8, lsf)
+    u = obs.undist_keypts_
+    b = (ocam.min_x, ocam.max_x, ocam.min_y, ocam.max_y)
+    off_g, items = O.assign_keypoints_to_grid(u["x"], u["y"], b)
+    lvq = np.where(vis == 1, lv, 0)
+    qm = (np.float32(5.0) * sf[lvq]).astype(np.float32)
+    cand_off, cand_idx = [0], []
+    for q in range(nl):
+        if vis[q]:
+            cand_idx += O.get_keypoints_in_cell(u["x"], u["y"], u["octave"], off_g, items, b, float(np.float32(rp[q, 0])), float(np.float32(rp[q, 1])),
+                                                float(qm[q]), max(0, int(lv[q]) - 1), min(7, int(lv[q]) + 1)).tolist()
+        cand_off.append(len(cand_idx))
+    return O.match_candidates(lmd, obs.descriptors_, cand_off, cand_idx, check_orientation=False, thr=100, lowe_ratio=0.8, mode=1,
+                              t_octave=u["octave"], q_valid=vis)
+
+
+c, exp = timeit(cpu_track, 3, 1)
+assert np.array_equal(r[0], exp)
+out["can_observe_plus_match_frame_and_landmarks_ms"] = {"gpu": round(g, 3), "cpu_oracle_incl_python_list_building": round(c, 3), "landmarks": nl,
+                                                        "visible": int(r[2].sum()), "matches": int(r[1])}
 # ---- stereo
 big = S.frame(640 + 64, 480, 5)
 left, right = np.ascontiguousarray(big[:, 8:648]), np.ascontiguousarray(big[:, 8 + 20:648 + 20])
