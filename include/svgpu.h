@@ -264,6 +264,25 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
                                     int* num_matches, uint8_t* visible, double* reproj, float* x_right,
                                     int32_t* pred_scale_level);
 
+/* ------------------------------------------------------------------------------ landmark refresh (batched)
+ * data::landmark::compute_descriptor (data/landmark.cc:199-254) for n landmarks: the representative descriptor is the
+ * observation whose row of the k x k Hamming matrix has the smallest lower median (sorted index (unsigned)(0.5 (k-1)); first
+ * row wins ties).  obs_off: n + 1 CSR offsets (obs_off[0] = 0, every landmark >= 1 observation, in the iteration order of the
+ * reference's observations_ map with will_be_erased keyframes already dropped), obs_desc: obs_off[n] x 32 descriptor rows.
+ *   best_obs[l]  index inside landmark l's list;  descriptor  n x 32. */
+int svgpu_landmarks_compute_descriptor(svgpu_ctx* ctx, int n, const int32_t* obs_off, const uint8_t* obs_desc, int32_t* best_obs,
+                                       uint8_t* descriptor);
+
+/* data::landmark::update_mean_normal_and_obs_scale_variance (data/landmark.cc:256-318) for n landmarks:
+ *   mean_normal = normalized( sum over observations of normalized(pos_w - keyfrm->get_trans_wc()) )   (summed in list order)
+ *   max_valid_dist = |pos_w - ref_trans_wc| * ref_scale_factor ;  min_valid_dist = max_valid_dist * inv_scale_factor_last
+ * obs_trans_wc: obs_off[n] x 3 doubles (camera centre of each observing keyframe); ref_trans_wc n x 3 (the landmark's reference
+ * keyframe); ref_scale_factor[l] = scale_factors_[octave of its keypoint there]; inv_scale_factor_last =
+ * inv_scale_factors_[num_levels - 1]. */
+int svgpu_landmarks_update_geometry(svgpu_ctx* ctx, int n, const int32_t* obs_off, const double* obs_trans_wc, const double* pos_w,
+                                    const double* ref_trans_wc, const float* ref_scale_factor, float inv_scale_factor_last,
+                                    double* mean_normal, float* max_valid_dist, float* min_valid_dist);
+
 /* match::stereo::compute (match/stereo.cc:20-114): for every left keypoint the closest right keypoint in its row band
  * (rows +-2*scale, octave +-1, disparity in [0, focal_x_baseline / true_baseline], Hamming < 75), then the 11x11 L1 patch
  * slide (+-5 px) on the keypoint's pyramid level with parabolic sub-pixel refinement, finally the 2x-median correlation

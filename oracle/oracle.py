@@ -26,7 +26,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> pathlib.Path:
     so = _HERE / "liboracle.so"
-    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "orb_pattern_i8.inc", "Makefile")]
+    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "landmark_oracle.c", "orb_pattern_i8.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-C", str(_HERE), "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -322,6 +322,32 @@ def can_observe(cam, rot_cw, trans_cw, pos_w, mean_normal, min_valid_dist, max_v
     lib().orc_can_observe(C.byref(cam), _p(R), _p(t), _p(twc), n, _p(pw), _p(nv), _p(mn), _p(mx), C.c_float(ray_cos_thr),
                           C.c_uint(num_levels), C.c_float(log_scale_factor), _p(vis), _p(rp), _p(xr), _p(lv))
     return vis, rp, xr, lv
+
+
+# ------------------------------------------------------------------------------------------- landmark refresh
+
+def landmarks_compute_descriptor(obs_off, obs_desc):
+    """landmark::compute_descriptor per CSR row: (best index inside the row, n x 32 representative descriptors)."""
+    off = np.ascontiguousarray(obs_off, np.int32)
+    d = np.ascontiguousarray(obs_desc, np.uint8).reshape(-1, 32)
+    n = len(off) - 1
+    best = np.zeros(n, np.int32)
+    out = np.zeros((n, 32), np.uint8)
+    lib().orc_landmarks_compute_descriptor(n, _p(off), _p(d), _p(best), _p(out))
+    return best, out
+
+
+def landmarks_update_geometry(obs_off, obs_trans_wc, pos_w, ref_trans_wc, ref_scale_factor, inv_scale_factor_last):
+    """landmark::update_mean_normal_and_obs_scale_variance per CSR row: (mean_normal n x 3, max_valid_dist, min_valid_dist)."""
+    off = np.ascontiguousarray(obs_off, np.int32)
+    c = np.ascontiguousarray(obs_trans_wc, np.float64).reshape(-1, 3)
+    p = np.ascontiguousarray(pos_w, np.float64).reshape(-1, 3)
+    r = np.ascontiguousarray(ref_trans_wc, np.float64).reshape(-1, 3)
+    sfr = np.ascontiguousarray(ref_scale_factor, np.float32)
+    n = len(off) - 1
+    mnrm, mx, mn = np.zeros((n, 3), np.float64), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lib().orc_landmarks_update_geometry(n, _p(off), _p(c), _p(p), _p(r), _p(sfr), C.c_float(inv_scale_factor_last), _p(mnrm), _p(mx), _p(mn))
+    return mnrm, mx, mn
 
 
 # ------------------------------------------------------------------------------------------- BA

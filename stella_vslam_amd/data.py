@@ -5,9 +5,13 @@ keypoints, convert them to bearings and bin them into the matcher grid -- one de
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from . import camera as _camera
+from ._lib import lib
+from .feature import Context
 
 
 class frame_observation:
@@ -27,3 +31,34 @@ class frame_observation:
     def indices_in_cell(self, col: int, row: int) -> np.ndarray:
         c = col * self.num_grid_rows_ + row
         return self.cell_items_[self.cell_off_[c]:self.cell_off_[c + 1]]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def landmarks_compute_descriptor(ctx: Context, obs_off, obs_desc):
+    """data::landmark::compute_descriptor (data/landmark.cc:199-254) for every CSR row of observations at once:
+    returns (best_obs, descriptors) -- the index inside each landmark's list and the n x 32 representative descriptors."""
+    off = np.ascontiguousarray(obs_off, np.int32)
+    d = np.ascontiguousarray(obs_desc, np.uint8).reshape(-1, 32)
+    n = len(off) - 1
+    best, out = np.zeros(n, np.int32), np.zeros((n, 32), np.uint8)
+    ctx.check(lib().svgpu_landmarks_compute_descriptor(ctx.handle, n, _p(off), _p(d), _p(best), _p(out)), "svgpu_landmarks_compute_descriptor")
+    return best, out
+
+
+def landmarks_update_mean_normal_and_obs_scale_variance(ctx: Context, obs_off, obs_trans_wc, pos_w, ref_trans_wc, ref_scale_factor,
+                                                        inv_scale_factor_last):
+    """data::landmark::update_mean_normal_and_obs_scale_variance (data/landmark.cc:285-318) for every landmark at once:
+    returns (mean_normal n x 3, max_valid_dist, min_valid_dist)."""
+    off = np.ascontiguousarray(obs_off, np.int32)
+    c = np.ascontiguousarray(obs_trans_wc, np.float64).reshape(-1, 3)
+    p = np.ascontiguousarray(pos_w, np.float64).reshape(-1, 3)
+    r = np.ascontiguousarray(ref_trans_wc, np.float64).reshape(-1, 3)
+    sfr = np.ascontiguousarray(ref_scale_factor, np.float32)
+    n = len(off) - 1
+    mnrm, mx, mn = np.zeros((n, 3), np.float64), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    ctx.check(lib().svgpu_landmarks_update_geometry(ctx.handle, n, _p(off), _p(c), _p(p), _p(r), _p(sfr), C.c_float(inv_scale_factor_last),
+                                                    _p(mnrm), _p(mx), _p(mn)), "svgpu_landmarks_update_geometry")
+    return mnrm, mx, mn

@@ -1,5 +1,7 @@
 #include "camera.h"
 
+#include <algorithm>
+#include <cstring>
 #include <stdexcept>
 
 namespace stella_vslam_hip {
@@ -76,4 +78,34 @@ void base::can_observe(const Mat33_t& rot_cw, const Vec3_t& trans_cw, const Vec3
 }
 
 }  // namespace camera
+
+namespace data {
+void compute_descriptors(svgpu_ctx* ctx, const std::vector<int>& obs_off, const cv::Mat& obs_desc, std::vector<int>& best_obs, cv::Mat& descriptors) {
+    const int n = (int)obs_off.size() - 1;
+    best_obs.assign((size_t)std::max(n, 1), 0);
+    if (n <= 0) return;
+    std::vector<uint8_t> packed((size_t)obs_desc.rows * 32);
+    for (int i = 0; i < obs_desc.rows; ++i) std::memcpy(&packed[(size_t)i * 32], obs_desc.ptr(i), 32);
+    descriptors.create(n, 32, cv::CV_8U);
+    const int rc = svgpu_landmarks_compute_descriptor(ctx, n, obs_off.data(), packed.data(), best_obs.data(), descriptors.ptr(0));
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_landmarks_compute_descriptor: ") + svgpu_last_error(ctx));
+    best_obs.resize((size_t)n);
+}
+
+void update_mean_normal_and_obs_scale_variance(svgpu_ctx* ctx, const std::vector<int>& obs_off, const std::vector<Vec3_t>& obs_trans_wc,
+                                               const std::vector<Vec3_t>& pos_w, const std::vector<Vec3_t>& ref_trans_wc,
+                                               const std::vector<float>& ref_scale_factor, float inv_scale_factor_last,
+                                               std::vector<Vec3_t>& mean_normal, std::vector<float>& max_valid_dist,
+                                               std::vector<float>& min_valid_dist) {
+    const int n = (int)pos_w.size();
+    mean_normal.assign((size_t)n, Vec3_t{0, 0, 0});
+    max_valid_dist.assign((size_t)n, 0.f);
+    min_valid_dist.assign((size_t)n, 0.f);
+    const int rc = svgpu_landmarks_update_geometry(ctx, n, obs_off.data(), reinterpret_cast<const double*>(obs_trans_wc.data()),
+                                                   reinterpret_cast<const double*>(pos_w.data()), reinterpret_cast<const double*>(ref_trans_wc.data()),
+                                                   ref_scale_factor.data(), inv_scale_factor_last, reinterpret_cast<double*>(mean_normal.data()),
+                                                   max_valid_dist.data(), min_valid_dist.data());
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_landmarks_update_geometry: ") + svgpu_last_error(ctx));
+}
+}  // namespace data
 }  // namespace stella_vslam_hip

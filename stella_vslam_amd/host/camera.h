@@ -95,4 +95,19 @@ public:
 };
 
 }  // namespace camera
+
+namespace data {
+//! data::landmark::compute_descriptor (data/landmark.cc:199-254) for many landmarks at once.  obs_off: CSR offsets over the
+//! landmarks; obs_desc: one descriptor row per observation, in the iteration order of observations_ with will_be_erased
+//! keyframes dropped.  best_obs[l] indexes landmark l's own list; descriptors row l = its new descriptor_.
+void compute_descriptors(svgpu_ctx* ctx, const std::vector<int>& obs_off, const cv::Mat& obs_desc, std::vector<int>& best_obs, cv::Mat& descriptors);
+//! data::landmark::update_mean_normal_and_obs_scale_variance (data/landmark.cc:285-318) for many landmarks at once.
+//! obs_trans_wc: keyfrm->get_trans_wc() per observation; ref_trans_wc / ref_scale_factor: the reference keyframe's centre and
+//! scale_factors_[octave of the landmark's keypoint there]; inv_scale_factor_last = inv_scale_factors_[num_levels_ - 1].
+void update_mean_normal_and_obs_scale_variance(svgpu_ctx* ctx, const std::vector<int>& obs_off, const std::vector<Vec3_t>& obs_trans_wc,
+                                               const std::vector<Vec3_t>& pos_w, const std::vector<Vec3_t>& ref_trans_wc,
+                                               const std::vector<float>& ref_scale_factor, float inv_scale_factor_last,
+                                               std::vector<Vec3_t>& mean_normal, std::vector<float>& max_valid_dist,
+                                               std::vector<float>& min_valid_dist);
+}  // namespace data
 }  // namespace stella_vslam_hip

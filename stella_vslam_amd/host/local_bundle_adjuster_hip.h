@@ -49,6 +49,25 @@ private:
     const unsigned int num_second_iter_;
 };
 
+//! optimize::global_bundle_adjuster sibling (optimize/global_bundle_adjuster.h:23-55; constructor defaults num_iter = 10,
+//! use_huber_kernel = true).  optimize_flat() is global_bundle_adjuster::optimize (global_bundle_adjuster.cc:279-412) between its
+//! gather (all landmarks of `keyfrms`, root keyframe fixed: the caller fills pose_fixed / huber deltas, or zeroes the deltas when
+//! use_huber_kernel is false) and its write-back maps: ONE LM run of num_iter iterations with terminate_action(1e-3), no outlier
+//! stage.  Returns false exactly where the reference does: the caller's force_stop_flag is up and it was not the gain rule that
+//! raised it (:341-343) -- the result must then be discarded.
+class global_bundle_adjuster_hip {
+public:
+    explicit global_bundle_adjuster_hip(svgpu_ctx* ctx, unsigned int num_iter = 10, bool use_huber_kernel = true)
+        : ctx_(ctx), num_iter_(num_iter), use_huber_kernel_(use_huber_kernel) {}
+    virtual ~global_bundle_adjuster_hip() = default;
+    bool optimize_flat(const flat_ba_problem& problem, bool* const force_stop_flag, flat_ba_result& result) const;
+
+private:
+    svgpu_ctx* ctx_;
+    const unsigned int num_iter_;
+    const bool use_huber_kernel_;
+};
+
 //! optimize::pose_optimizer sibling (optimize/pose_optimizer.h, g2o defaults of pose_optimizer_factory.h:18-26).  The binding gathers,
 //! per keypoint with a live landmark, the landmark position, the undistorted keypoint (+ stereo x_right), inv_level_sigma_sq
 //! and the Huber delta (pose_optimizer_g2o.cc:86-106) and scatters outlier flags back by keypoint index.

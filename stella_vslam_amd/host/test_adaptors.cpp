@@ -111,6 +111,17 @@ int main() {
     stop = true;
     ba.optimize_flat(p, &stop, r);
     REQUIRE(r.status == SVGPU_STOPPED && r.pose_cw == p.pose_cw);
+    {   // global BA sibling: one LM run; a raised flag that the gain rule did not raise => "discard" (false)
+        optimize::global_bundle_adjuster_hip gba(ext.context(), 10, true);
+        optimize::flat_ba_result g;
+        bool gstop = false;
+        REQUIRE(gba.optimize_flat(p, &gstop, g) && g.stats.chi2_final < 1e-3 * g.stats.chi2_initial + 1e-6);
+        REQUIRE(std::fabs(g.pose_cw[2 * 12 + 3] + 0.6) < 1e-3 && g.stats.iters_stage2 == 0);
+        const bool by_gain_rule = g.stats.stopped_by_terminate_action != 0;
+        REQUIRE(gstop == by_gain_rule);  // terminate_action raises the caller's flag when the gain rule stops the run
+        gstop = true;
+        REQUIRE(!gba.optimize_flat(p, &gstop, g));
+    }
 
     // projection-family matcher with the candidate lists built on the device: frame-1 keypoints "reprojected" by the known shift
     // into frame 2, window 15 px x scale, levels +-1 (projection.cc:30-35); and the same queries through host-built lists
@@ -231,6 +242,33 @@ int main() {
         int self = 0;
         for (int i = 0; i < n; ++i) self += mi[i] == i;
         REQUIRE(nmf > (unsigned)vis * 8 / 10 && (unsigned)self > nmf * 95 / 100 && ob2.visible == ob.visible);
+        // landmark refresh: three observations per landmark = its keypoint's descriptor with 0 / 1 / 2 bits flipped -> row 1 (one
+        // flip away from both others) has the smallest median? medians: row0 {0,1,2}->1, row1 {0,1,1}->1, row2 {0,1,2}->1: first wins
+        {
+            std::vector<int> off(1, 0), best;
+            cv::Mat od(3 * 100, 32, cv::CV_8U), rep;
+            std::vector<Vec3_t> cams, pos, refc, mnrm;
+            std::vector<float> rsf, mxd, mnd;
+            for (int l = 0; l < 100; ++l) {
+                for (int o = 0; o < 3; ++o) {
+                    std::memcpy(od.ptr(3 * l + o), d1.ptr(l), 32);
+                    if (o >= 1) od.ptr(3 * l + o)[0] ^= 1;
+                    if (o == 2) od.ptr(3 * l + o)[5] ^= 4;
+                    cams.push_back(Vec3_t{(double)o, 0.0, 0.0});
+                }
+                off.push_back(3 * (l + 1));
+                pos.push_back(Vec3_t{1.0, 0.0, 4.0 + 0.01 * l});
+                refc.push_back(Vec3_t{1.0, 0.0, 0.0});
+                rsf.push_back(params.scale_factors_[2]);
+            }
+            data::compute_descriptors(ext.context(), off, od, best, rep);
+            data::update_mean_normal_and_obs_scale_variance(ext.context(), off, cams, pos, refc, rsf, params.inv_scale_factors_[7], mnrm, mxd, mnd);
+            bool okl = rep.rows == 100;
+            for (int l = 0; l < 100 && okl; ++l)
+                okl = best[l] == 0 && std::memcmp(rep.ptr(l), d1.ptr(l), 32) == 0 && std::fabs(mnrm[l][0]) < 1e-12 && mnrm[l][2] > 0.99
+                      && mxd[l] == (float)((4.0 + 0.01 * l) * params.scale_factors_[2]) && mnd[l] == mxd[l] * params.inv_scale_factors_[7];
+            REQUIRE(okl);
+        }
         std::printf("frame observation: %d keypoints, %d landmarks visible, %u matched (%d onto their own keypoint)\n", n, vis, nmf, self);
     }
     // motion-only BA: perturbed camera 2 against the 60 exact observations of the scene above
