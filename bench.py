@@ -65,7 +65,7 @@ def main() -> int:
     from stella_vslam_amd._lib import lib
 
     B = args.batch
-    ctx = feature.Context(local_rank)
+    ctx = feature.Context(local_rank, priority=1)  # extraction is the longer leg of the two-stream pipeline: it gets the CUs first
     L = lib()
     params = feature.orb_params()
     NL = params.num_levels_
@@ -88,9 +88,9 @@ def main() -> int:
     NBUF = 2
     with torch.cuda.stream(stream):
         frames = torch.from_numpy(frames_np).cuda()
-        bufs = [dict(kps=torch.zeros((B + 1) * cap * 28, dtype=torch.uint8, device="cuda"),
-                     desc=torch.zeros((B + 1) * cap * 32, dtype=torch.uint8, device="cuda"),
-                     counts=torch.zeros((B + 1) * (1 + NL), dtype=torch.int32, device="cuda"),
+        bufs = [dict(kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"),
+                     desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+                     counts=torch.zeros(B * (1 + NL), dtype=torch.int32, device="cuda"),
                      matched=torch.zeros(B * cap, dtype=torch.int32, device="cuda"),
                      nmatch=torch.zeros(B, dtype=torch.int32, device="cuda"),
                      ev_ext=torch.cuda.Event(), ev_match=torch.cuda.Event(), used=False) for _ in range(NBUF)]
@@ -108,17 +108,13 @@ def main() -> int:
         ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(frames.data_ptr()), B, C.c_size_t(W * H), W, None,
                                                    C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()),
                                                    cap, C.c_void_p(counts.data_ptr()), None), "extract_batch")
-        with torch.cuda.stream(stream):  # ring: slot B := slot 0, so that pair t = (slot t+1, slot t), t = 0..B-1
-            kps[B * cap * 28:].copy_(kps[:cap * 28], non_blocking=True)
-            desc[B * cap * 32:].copy_(desc[:cap * 32], non_blocking=True)
-            counts[B * nc:].copy_(counts[:nc], non_blocking=True)
-            bf["ev_ext"].record(stream)
+        bf["ev_ext"].record(stream)
         stream_b.wait_event(bf["ev_ext"])
-        ctx.check(L.svgpu_match_bruteforce_batch_device(
-            ctx.handle, B, C.c_void_p(desc.data_ptr() + cap * 32), C.c_void_p(kps.data_ptr() + cap * 28),
-            C.c_void_p(counts.data_ptr() + nc * 4), cap, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()),
-            C.c_void_p(counts.data_ptr()), cap, nc, None, C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()),
-            C.c_void_p(bf["nmatch"].data_ptr()), C.c_void_p(stream_b.cuda_stream)), "match_batch")
+        # pair t = (frame (t + 1) % B, keyframe = frame t), t = 0..B-1, straight from the extractor's batch layout
+        ctx.check(L.svgpu_match_consecutive_batch_device(
+            ctx.handle, B, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()), C.c_void_p(counts.data_ptr()), cap, nc, None,
+            C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()), C.c_void_p(bf["nmatch"].data_ptr()),
+            C.c_void_p(stream_b.cuda_stream)), "match_batch")
         bf["ev_match"].record(stream_b)
 
     def sync_all():
@@ -133,7 +129,7 @@ def main() -> int:
     for _ in range(max(args.warmup, 1)):
         step()
     sync_all()
-    n_kp = bufs[0]["counts"].view(B + 1, nc)[:B, 0].float().mean().item()
+    n_kp = bufs[0]["counts"].view(B, nc)[:, 0].float().mean().item()
     n_match = bufs[0]["nmatch"].float().mean().item()
     alg = algorithmic_bytes(level_px, n_kp, B)
     per_kernel = {}

@@ -51,6 +51,9 @@ typedef struct svgpu_keypoint {
 int svgpu_abi_version(void);
 int svgpu_device_count(void);
 int svgpu_create(int device, svgpu_ctx** out);
+/* Same with a stream priority hint: > 0 highest, < 0 lowest, 0 default.  A pipeline that runs extraction and matching of
+ * consecutive batches on two streams gives the longer leg (extraction) the higher priority (bench.py). */
+int svgpu_create_with_priority(int device, int priority, svgpu_ctx** out);
 void svgpu_destroy(svgpu_ctx* ctx);
 const char* svgpu_last_error(const svgpu_ctx* ctx);
 const char* svgpu_status_string(int status);
@@ -149,6 +152,13 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
                                         const int32_t* n2_dev, int cap2, int n_stride, const uint8_t* valid2_dev,
                                         float lowe_ratio, int check_orientation, int32_t* matched_dev,
                                         int32_t* num_dev, void* stream);
+
+/* The same matcher over a RING of `frames` extractor outputs that already sit in one device batch (the layout
+ * svgpu_orb_extract_batch_device writes): pair t = robust::brute_force_match(frame (t + 1) % frames, keyframe = frame t),
+ * t = 0 .. frames-1, without copying any slot.  matched_dev: frames x cap, row t indexed by the keypoints of frame (t+1) % frames. */
+int svgpu_match_consecutive_batch_device(svgpu_ctx* ctx, int frames, const uint8_t* desc_dev, const svgpu_keypoint* kps_dev,
+                                         const int32_t* n_dev, int cap, int n_stride, const uint8_t* valid_dev, float lowe_ratio,
+                                         int check_orientation, int32_t* matched_dev, int32_t* num_dev, void* stream);
 
 typedef enum svgpu_match_mode {
     SVGPU_MATCH_BEST_ONLY = 0,        /* projection::match_current_and_last_frames (match/projection.cc:95-207) */

@@ -19,6 +19,7 @@ struct BfProblem {
     int n_stride;
     int n1, n2;           // used when the *_dev pointers are null
     int cap1, cap2;
+    int ring1;            // 0: side-1 row of pair p is row p; R > 0: it is row (p + 1) % R (frame t+1 against frame t in a ring of R frames)
     const uint8_t* valid2;  // nullable
     float lowe_ratio;
     int check_orientation;
@@ -36,6 +37,8 @@ struct BfProblem {
     int32_t* matched;     // pairs * cap1
     int32_t* num;         // pairs
 };
+
+__host__ __device__ inline int bf_row1(const BfProblem& P, int pair) { return P.ring1 ? (pair + 1 == P.ring1 ? 0 : pair + 1) : pair; }
 
 struct CandProblem {
     const uint32_t* qdesc;

@@ -80,10 +80,11 @@ __global__ __launch_bounds__(256) void k_bf_binsort(BfProblem P) {
     __shared__ int s_bad;
     const int pair = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
     const int cap = side == 0 ? P.cap1 : P.cap2;
-    const int nraw = side == 0 ? (P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1) : (P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2);
+    const int row = side == 0 ? bf_row1(P, pair) : pair;  // where this side of the pair lives in the caller's arrays
+    const int nraw = side == 0 ? (P.n1_dev ? P.n1_dev[row * P.n_stride] : P.n1) : (P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2);
     const int n = min(nraw, cap);
-    const uint32_t* D = (side == 0 ? P.desc1 : P.desc2) + (size_t)pair * cap * 8;
-    const float* A = (side == 0 ? P.angle1 : P.angle2) + (size_t)pair * cap * P.angle_stride;
+    const uint32_t* D = (side == 0 ? P.desc1 : P.desc2) + (size_t)row * cap * 8;
+    const float* A = (side == 0 ? P.angle1 : P.angle2) + (size_t)row * cap * P.angle_stride;
     uint32_t* SD = (side == 0 ? P.sd1 : P.sd2) + (size_t)pair * cap * 8;
     float* SA = (side == 0 ? P.sa1 : P.sa2) + (size_t)pair * cap;
     int* SI = (side == 0 ? P.si1 : P.si2) + (size_t)pair * cap;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
     __shared__ float s_a[2][BF_TILE];
     __shared__ int s_i[2][BF_TILE];
     const int pair = blockIdx.y;
-    const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
+    const int n1 = P.n1_dev ? P.n1_dev[bf_row1(P, pair) * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
     if (blockIdx.x * BF_QB >= n2c) return;
@@ -391,7 +392,7 @@ __device__ __forceinline__ void mf_drain(MfShared& S, int wave, int lane, int n,
 __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
     __shared__ __attribute__((aligned(16))) MfShared S;
     const int pair = blockIdx.y;
-    const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
+    const int n1 = P.n1_dev ? P.n1_dev[bf_row1(P, pair) * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -615,7 +616,7 @@ __device__ int bf_decide(const BfProblem& P, int pair, int j, int n1c, const uin
 // Exact decision of one query by a cooperative scan of the whole row (robust.cc:271-314): every thread takes a
 // strided share of the candidates, (best key, second distance) are combined with LDS atomicMin.
 __device__ int bf_full_row(const BfProblem& P, int pair, int j, int n1c, const int* owner, uint32_t* s_best, uint32_t* s_second) {
-    const uint32_t* D1 = P.desc1 + (size_t)pair * P.cap1 * 8;
+    const uint32_t* D1 = P.desc1 + (size_t)bf_row1(P, pair) * P.cap1 * 8;
     const uint32_t* D2 = P.desc2 + ((size_t)pair * P.cap2 + j) * 8;
     uint32_t q[8];
 #pragma unroll
@@ -630,7 +631,7 @@ __device__ int bf_full_row(const BfProblem& P, int pair, int j, int n1c, const i
     unsigned d2 = MAX_HAMMING_DIST;  // second smallest distance of this thread's share
     for (int i = threadIdx.x; i < n1c; i += blockDim.x) {
         if (owner[i] < j) continue;
-        if (P.check_orientation && fabsf(angle_diff(P.angle1[((size_t)pair * P.cap1 + i) * P.angle_stride], qa)) > 30.0f) continue;
+        if (P.check_orientation && fabsf(angle_diff(P.angle1[((size_t)bf_row1(P, pair) * P.cap1 + i) * P.angle_stride], qa)) > 30.0f) continue;
         const uint32_t key = (hamming256(q, D1 + (size_t)i * 8) << 16) | (uint32_t)i;
         if (key < k1) {
             d2 = min(d2, k1 >> 16);
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
     __shared__ int s_und[1024];  // one slot per thread of a stride: can never overflow
     __shared__ uint32_t s_best, s_second;
     const int pair = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int n1 = P.n1_dev ? P.n1_dev[pair * P.n_stride] : P.n1;
+    const int n1 = P.n1_dev ? P.n1_dev[bf_row1(P, pair) * P.n_stride] : P.n1;
     const int n2 = P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2;
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
     int* owner = use_lds ? s_mem : g_owner + (size_t)pair * P.cap1;

@@ -88,7 +88,7 @@ int svgpu_device_count(void) {
     return n;
 }
 
-int svgpu_create(int device, svgpu_ctx** out) {
+int svgpu_create_with_priority(int device, int priority, svgpu_ctx** out) {
     if (!out) return SVGPU_ERR_INVALID;
     *out = nullptr;
     int n = 0;
@@ -98,22 +98,35 @@ int svgpu_create(int device, svgpu_ctx** out) {
     svgpu_ctx* ctx = new (std::nothrow) svgpu_ctx();
     if (!ctx) return SVGPU_ERR_INVALID;
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
+    int least = 0, greatest = 0;  // numerically: greatest priority = lowest number
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int prio = priority > 0 ? greatest : priority < 0 ? least : 0;
+    // the auxiliary stream carries the blur of a batch beside its FAST pass (svgpu_orb_extract*): same priority
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess
+        || hipStreamCreateWithPriority(&ctx->stream_aux, hipStreamNonBlocking, prio) != hipSuccess
+        || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
+        || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        svgpu_destroy(ctx);
         return SVGPU_ERR_HIP;
     }
     *out = ctx;
     return SVGPU_OK;
 }
 
+int svgpu_create(int device, svgpu_ctx** out) { return svgpu_create_with_priority(device, 0, out); }
+
 void svgpu_destroy(svgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_aux) (void)hipStreamSynchronize(ctx->stream_aux);
     sv_orb_release(ctx);
     for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

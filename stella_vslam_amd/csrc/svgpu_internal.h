@@ -67,6 +67,8 @@ struct SvProf {
 struct svgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_aux = nullptr;  // blur of a batch runs here beside FAST + selection on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
     SvProf prof;
     OrbConfig orb;

@@ -196,12 +196,13 @@ int svgpu_hamming_matrix(svgpu_ctx* ctx, const uint8_t* desc1, int n1, const uin
     return SVGPU_OK;
 }
 
-int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t* desc1_dev,
-                                        const svgpu_keypoint* kps1_dev, const int32_t* n1_dev, int cap1,
-                                        const uint8_t* desc2_dev, const svgpu_keypoint* kps2_dev,
-                                        const int32_t* n2_dev, int cap2, int n_stride, const uint8_t* valid2_dev,
-                                        float lowe_ratio, int check_orientation, int32_t* matched_dev,
-                                        int32_t* num_dev, void* stream) {
+}  // extern "C"
+
+namespace {
+int bf_batch_device(svgpu_ctx* ctx, int pairs, int ring1, const uint8_t* desc1_dev, const svgpu_keypoint* kps1_dev, const int32_t* n1_dev,
+                    int cap1, const uint8_t* desc2_dev, const svgpu_keypoint* kps2_dev, const int32_t* n2_dev, int cap2, int n_stride,
+                    const uint8_t* valid2_dev, float lowe_ratio, int check_orientation, int32_t* matched_dev, int32_t* num_dev,
+                    void* stream) {
     if (!ctx || pairs < 1 || !desc1_dev || !kps1_dev || !n1_dev || !desc2_dev || !kps2_dev || !n2_dev || cap1 < 1 || cap2 < 1
         || cap1 > 65535 || cap2 > 65535 || !matched_dev || !num_dev)
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce_batch_device: bad arguments");
@@ -222,6 +223,7 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
     P.n_stride = n_stride;
     P.cap1 = cap1;
     P.cap2 = cap2;
+    P.ring1 = ring1;
     P.valid2 = valid2_dev;
     P.lowe_ratio = lowe_ratio;
     P.check_orientation = check_orientation;
@@ -235,6 +237,27 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
     sv_launch_bf(ctx, stream ? (hipStream_t)stream : ctx->stream, P, pairs, g_owner, g_match);
     SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t* desc1_dev,
+                                        const svgpu_keypoint* kps1_dev, const int32_t* n1_dev, int cap1,
+                                        const uint8_t* desc2_dev, const svgpu_keypoint* kps2_dev,
+                                        const int32_t* n2_dev, int cap2, int n_stride, const uint8_t* valid2_dev,
+                                        float lowe_ratio, int check_orientation, int32_t* matched_dev,
+                                        int32_t* num_dev, void* stream) {
+    return bf_batch_device(ctx, pairs, 0, desc1_dev, kps1_dev, n1_dev, cap1, desc2_dev, kps2_dev, n2_dev, cap2, n_stride, valid2_dev, lowe_ratio,
+                           check_orientation, matched_dev, num_dev, stream);
+}
+
+int svgpu_match_consecutive_batch_device(svgpu_ctx* ctx, int frames, const uint8_t* desc_dev, const svgpu_keypoint* kps_dev,
+                                         const int32_t* n_dev, int cap, int n_stride, const uint8_t* valid_dev, float lowe_ratio,
+                                         int check_orientation, int32_t* matched_dev, int32_t* num_dev, void* stream) {
+    if (frames < 2) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_consecutive_batch_device: needs at least two frames");
+    return bf_batch_device(ctx, frames, frames, desc_dev, kps_dev, n_dev, cap, desc_dev, kps_dev, n_dev, cap, n_stride, valid_dev, lowe_ratio,
+                           check_orientation, matched_dev, num_dev, stream);
 }
 
 int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2,

@@ -381,15 +381,23 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
         sv_launch_pyramid(s, ctx->d_levels, Lc, ctx->d_band_rows, ctx->pyr_bands, imgs_dev, frame_stride, row_stride, ctx->d_pyr,
                           C.pyr_frame_bytes, ctx->d_xofs, ctx->d_xa, ctx->d_yofs, ctx->d_yb, ctx->d_xg, ctx->d_yrow, batch, ctx->pyr_lds_bytes);
     }
-    // 2. blurred copy of every level
+    // 2. blurred copy of every level -- on the auxiliary stream, beside steps 3-4: the blur waits on memory where FAST is bound by
+    //    instruction issue, so the two share the CUs well; step 5 joins them
+    static const bool fork_blur = getenv("SVGPU_FORK_BLUR") != nullptr;  // opt-in, see DESIGN.md section 6
+    hipStream_t sb = (ctx->stream_aux && fork_blur) ? ctx->stream_aux : s;
+    if (sb != s) {
+        SV_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+        SV_HIP(ctx, hipStreamWaitEvent(sb, ctx->ev_fork, 0));
+    }
     {
-        SvProfScope ps(ctx, s, "k_blur");
+        SvProfScope ps(ctx, sb, "k_blur");
         // levels the streaming kernel cannot take (caller image not 4-byte aligned, level narrower than 16 px) -> gather kernel
         bool need_gather = (((size_t)imgs_dev | (size_t)frame_stride | (size_t)row_stride) & 3) != 0;
         for (int l = 0; l < Lc; ++l) need_gather = need_gather || C.levels[l].w < 16;
-        sv_launch_blur(s, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
+        sv_launch_blur(sb, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
                        ctx->d_blur, C.blur_frame_bytes, batch, need_gather);
     }
+    if (sb != s) SV_HIP(ctx, hipEventRecord(ctx->ev_join, sb));
     // 3. FAST per cell + selection-grid arg-max
     {
         SvProfScope ps(ctx, s, "k_fast");
@@ -403,6 +411,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
         sv_launch_select(s, ctx->d_levels, Lc, ctx->d_keys, C.total_grid, ctx->d_sel, counts_dev, batch);
     }
     // 5. orientation, descriptor, scale correction
+    if (sb != s) SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     SvProfScope ps(ctx, s, "k_describe");
     sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
                        ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch);

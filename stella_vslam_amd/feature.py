@@ -19,9 +19,9 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 class Context:
     """One svgpu_ctx: a device, a stream and the workspaces configured on it."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, priority: int = 0):
         self._h = C.c_void_p()
-        rc = lib().svgpu_create(device, C.byref(self._h))
+        rc = lib().svgpu_create_with_priority(device, priority, C.byref(self._h))
         if rc:
             raise SvgpuError(rc, "svgpu_create")
         self.device = device
