@@ -293,6 +293,21 @@ int svgpu_landmarks_update_geometry(svgpu_ctx* ctx, int n, const int32_t* obs_of
                                     const double* ref_trans_wc, const float* ref_scale_factor, float inv_scale_factor_last,
                                     double* mean_normal, float* max_valid_dist, float* min_valid_dist);
 
+/* ------------------------------------------------------------------------------ BoW transform (tree descent)
+ * data::bow_vocabulary_util::compute_bow (data/bow_vocabulary.cc:18-24): per descriptor, descend the vocabulary tree choosing the
+ * child with the smallest Hamming distance (first child wins ties) down to a leaf; word_id / weight = the leaf's, node_id = the
+ * node passed at depth `node_level` (DBoW2's transform(.., levelsup = 4) records depth L - levelsup, clamped at 0 = root; the
+ * bucket key of match::bow_tree).  The binding accumulates bow_vec (word -> weight, then the vocabulary's normalisation) and
+ * bow_feat_vec (node -> feature indices in order) from these arrays.
+ * Flat tree: node 0 = root, children of node i = children[child_off[i] .. child_off[i+1]) (none => leaf), ids strictly > 0;
+ * node_desc n_nodes x 32, node_weight / word_id per node.  The vocabulary stays resident on ctx's device until freed. */
+typedef struct svgpu_vocabulary svgpu_vocabulary;
+int svgpu_bow_vocabulary_upload(svgpu_ctx* ctx, int n_nodes, const int32_t* child_off, const int32_t* children, const uint8_t* node_desc,
+                                const float* node_weight, const int32_t* word_id, svgpu_vocabulary** out);
+void svgpu_bow_vocabulary_free(svgpu_vocabulary* vocab);
+int svgpu_bow_transform(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int node_level, int32_t* word_id,
+                        float* weight, int32_t* node_id);
+
 /* match::stereo::compute (match/stereo.cc:20-114): for every left keypoint the closest right keypoint in its row band
  * (rows +-2*scale, octave +-1, disparity in [0, focal_x_baseline / true_baseline], Hamming < 75), then the 11x11 L1 patch
  * slide (+-5 px) on the keypoint's pyramid level with parabolic sub-pixel refinement, finally the 2x-median correlation

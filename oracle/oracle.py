@@ -26,7 +26,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> pathlib.Path:
     so = _HERE / "liboracle.so"
-    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "landmark_oracle.c", "orb_pattern_i8.inc", "Makefile")]
+    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "landmark_oracle.c", "bow_oracle.c", "orb_pattern_i8.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-C", str(_HERE), "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -322,6 +322,23 @@ def can_observe(cam, rot_cw, trans_cw, pos_w, mean_normal, min_valid_dist, max_v
     lib().orc_can_observe(C.byref(cam), _p(R), _p(t), _p(twc), n, _p(pw), _p(nv), _p(mn), _p(mx), C.c_float(ray_cos_thr),
                           C.c_uint(num_levels), C.c_float(log_scale_factor), _p(vis), _p(rp), _p(xr), _p(lv))
     return vis, rp, xr, lv
+
+
+# ------------------------------------------------------------------------------------------- BoW
+
+def bow_transform(tree, desc, node_level):
+    """Vocabulary-tree descent per descriptor: (word_id, weight, node id at `node_level`).  tree = dict(child_off, children,
+    node_desc, node_weight, word_id)."""
+    off = np.ascontiguousarray(tree["child_off"], np.int32)
+    ch = np.ascontiguousarray(tree["children"], np.int32)
+    nd = np.ascontiguousarray(tree["node_desc"], np.uint8)
+    nw = np.ascontiguousarray(tree["node_weight"], np.float32)
+    wi = np.ascontiguousarray(tree["word_id"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(d)
+    ow, owt, on = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    lib().orc_bow_transform(len(off) - 1, _p(off), _p(ch), _p(nd), _p(nw), _p(wi), int(node_level), n, _p(d), _p(ow), _p(owt), _p(on))
+    return ow, owt, on
 
 
 # ------------------------------------------------------------------------------------------- landmark refresh

@@ -62,3 +62,51 @@ def landmarks_update_mean_normal_and_obs_scale_variance(ctx: Context, obs_off, o
     ctx.check(lib().svgpu_landmarks_update_geometry(ctx.handle, n, _p(off), _p(c), _p(p), _p(r), _p(sfr), C.c_float(inv_scale_factor_last),
                                                     _p(mnrm), _p(mx), _p(mn)), "svgpu_landmarks_update_geometry")
     return mnrm, mx, mn
+
+
+class bow_vocabulary:
+    """data/bow_vocabulary.h on a flat tree (node 0 = root; `child_off` / `children` CSR; `node_desc` n x 32; `node_weight`,
+    `word_id` per node; `depth` = L).  transform() is compute_bow (data/bow_vocabulary.cc:18-24): the tree descent runs on the
+    device, the two sparse maps are assembled here as DBoW2 does (TF-IDF weights summed per word, then L1-normalised)."""
+
+    def __init__(self, ctx: Context, child_off, children, node_desc, node_weight, word_id, depth: int):
+        self.ctx = ctx
+        self.depth_ = int(depth)
+        off, ch = np.ascontiguousarray(child_off, np.int32), np.ascontiguousarray(children, np.int32)
+        nd = np.ascontiguousarray(node_desc, np.uint8).reshape(-1, 32)
+        nw, wi = np.ascontiguousarray(node_weight, np.float32), np.ascontiguousarray(word_id, np.int32)
+        self._h = C.c_void_p()
+        ctx.check(lib().svgpu_bow_vocabulary_upload(ctx.handle, len(off) - 1, _p(off), _p(ch), _p(nd), _p(nw), _p(wi), C.byref(self._h)),
+                  "svgpu_bow_vocabulary_upload")
+
+    def descend(self, descriptors, levels_up: int = 4):
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word, weight, node = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        self.ctx.check(lib().svgpu_bow_transform(self.ctx.handle, self._h, _p(d), n, max(self.depth_ - levels_up, 0), _p(word), _p(weight), _p(node)),
+                       "svgpu_bow_transform")
+        return word, weight, node
+
+    def transform(self, descriptors, levels_up: int = 4):
+        """-> (bow_vec: {word_id: weight}, bow_feat_vec: {node_id: [feature indices]})"""
+        word, weight, node = self.descend(descriptors, levels_up)
+        bow_vec, feat = {}, {}
+        for i in range(len(word)):
+            if weight[i] > 0:  # DBoW2 skips zero-weight words (stop words)
+                bow_vec[int(word[i])] = bow_vec.get(int(word[i]), 0.0) + float(weight[i])
+                feat.setdefault(int(node[i]), []).append(i)
+        norm = sum(abs(v) for _, v in sorted(bow_vec.items()))
+        if norm > 0.0:
+            bow_vec = {k: v / norm for k, v in bow_vec.items()}
+        return dict(sorted(bow_vec.items())), dict(sorted(feat.items()))
+
+    def close(self):
+        if self._h:
+            lib().svgpu_bow_vocabulary_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,79 @@
+"""CPU: the oracle's vocabulary-tree descent (oracle/bow_oracle.c) against a literal Python walk (DBoW2
+TemplatedVocabulary::transform semantics: min Hamming child, first wins ties, node id at level L - levelsup)."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+def make_tree(rng, k=10, depth=3, prune=0.1, dup=0.05):
+    """Random k-ary vocabulary of the given depth; a fraction of the inner nodes is cut short (unbalanced tree: leaf above the
+    last level) and a fraction of the children repeats a sibling's descriptor (distance ties)."""
+    desc, weight, word, kids = [np.zeros(32, np.uint8)], [0.0], [-1], [[]]
+    frontier = [(0, 0)]
+    while frontier:
+        node, lvl = frontier.pop(0)
+        if lvl == depth or (lvl > 0 and rng.uniform() < prune):
+            continue
+        for c in range(k):
+            d = desc[node].copy()
+            flips = rng.integers(0, 256, 40 >> lvl if lvl < 3 else 5)
+            for b in flips:
+                d[b // 8] ^= 1 << (b % 8)
+            if c > 0 and rng.uniform() < dup:
+                d = desc[kids[node][rng.integers(0, c)]].copy()
+            desc.append(d)
+            weight.append(0.0)
+            word.append(-1)
+            kids.append([])
+            kids[node].append(len(desc) - 1)
+            frontier.append((len(desc) - 1, lvl + 1))
+    nw = 0
+    for i, ch in enumerate(kids):
+        if not ch:
+            word[i] = nw
+            weight[i] = float(rng.uniform(0.0, 5.0)) if rng.uniform() > 0.02 else 0.0  # a few stop words
+            nw += 1
+    off = np.concatenate([[0], np.cumsum([len(c) for c in kids])]).astype(np.int32)
+    children = np.array([c for ch in kids for c in ch], np.int32)
+    return dict(child_off=off, children=children, node_desc=np.array(desc, np.uint8), node_weight=np.array(weight, np.float32),
+                word_id=np.array(word, np.int32), depth=depth, kids=kids)
+
+
+def literal(tree, d, node_level):
+    bits = lambda a: np.unpackbits(a)
+    cur, lvl, nid = 0, 0, 0
+    while tree["kids"][cur]:
+        lvl += 1
+        ch = tree["kids"][cur]
+        best, bd = ch[0], int((bits(d) != bits(tree["node_desc"][ch[0]])).sum())
+        for c in ch[1:]:
+            dd = int((bits(d) != bits(tree["node_desc"][c])).sum())
+            if dd < bd:
+                best, bd = c, dd
+        cur = best
+        if lvl == node_level:
+            nid = cur
+    return tree["word_id"][cur], tree["node_weight"][cur], nid
+
+
+def test_descent_against_literal_walk():
+    rng = np.random.default_rng(0)
+    tree = make_tree(rng, k=10, depth=3)
+    leaves = np.flatnonzero(tree["word_id"] >= 0)
+    q = tree["node_desc"][rng.choice(leaves, 400)].copy()
+    fl = rng.integers(0, 256, (400, 6))
+    for j in range(6):
+        q[np.arange(400), fl[:, j] // 8] ^= (1 << (fl[:, j] % 8)).astype(np.uint8)
+    for node_level in (0, 1, 2, 3, 5):
+        w, wt, nid = O.bow_transform(tree, q, node_level)
+        for i in range(0, 400, 7):
+            lw, lwt, ln = literal(tree, q[i], node_level)
+            assert (w[i], wt[i], nid[i]) == (lw, lwt, ln)
+        if node_level in (0, 5):
+            assert (nid == 0).all()          # level 0 = root; a level deeper than the tree is never reached
+    w, wt, nid = O.bow_transform(tree, q, 1)
+    assert len(np.unique(nid)) >= 8 and len(np.unique(w)) > 100
+    # a single-node vocabulary: every feature maps to the root word
+    one = dict(child_off=[0, 0], children=np.zeros(0, np.int32), node_desc=np.zeros((1, 32), np.uint8), node_weight=[1.5], word_id=[0])
+    w, wt, nid = O.bow_transform(one, q[:3], 2)
+    assert (w == 0).all() and (wt == 1.5).all() and (nid == 0).all()
