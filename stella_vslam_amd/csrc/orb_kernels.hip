@@ -518,28 +518,28 @@ __global__ __launch_bounds__(256) void k_blur_gather(const OrbLevel* __restrict_
 // tests/test_oracle_orb.py::test_fast_matches_closed_form_definition).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
-    // packed form: e[k] = (v - p_k, p_k - v) as two int16 halves, so that one v_pk_min_i16 serves the "centre brighter"
-    // and the "centre darker" arcs at once.  The 16 arcs of 9 are the 8 windows of 8 starting at odd k, each extended
-    // by its left or its right neighbour.
+    // A(v) = max(0, max over the 16 arcs of 9 of min_k (v - p_k), max over arcs of min_k (p_k - v)).
+    // min / max commute with adding a constant, so the centre value stays out of the packed part: every ring pixel becomes the pair
+    // E_k = (p_k, ~p_k) = (p_k, -p_k - 1) in the two int16 halves of one register -- a single 24-bit multiply-add from the byte --
+    // and one v_pk_min_i16 per window serves the "centre darker" (min p) and the "centre brighter" (-max p - 1) arcs at once:
+    //   brighter arcs: v - max p = v + 1 + hi,   darker arcs: min p - v = lo - v.
+    // The 16 arcs of 9 are the 8 windows of 8 starting at odd k, each extended by its left or its right neighbour.
     s16x2 e[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int d = v - p[k];
-        e[k] = s16x2{(short)d, (short)-d};
-    }
+    for (int k = 0; k < 16; ++k) e[k] = __builtin_bit_cast(s16x2, __mul24(p[k], -65535) + (int)0xFFFF0000);  // (0xFFFF - p) << 16 | p
     s16x2 m2[8], m4[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) m2[j] = __builtin_elementwise_min(e[2 * j + 1], e[(2 * j + 2) & 15]);  // window 2 at k = 2j+1
 #pragma unroll
     for (int j = 0; j < 8; ++j) m4[j] = __builtin_elementwise_min(m2[j], m2[(j + 1) & 7]);             // window 4 at k = 2j+1
-    s16x2 best = s16x2{0, 0};
+    s16x2 best = s16x2{(short)-32768, (short)-32768};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const s16x2 m8 = __builtin_elementwise_min(m4[j], m4[(j + 2) & 7]);                            // window 8 at k = 2j+1
         best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, e[2 * j]));               // arc 2j .. 2j+8
         best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, e[(2 * j + 9) & 15]));    // arc 2j+1 .. 2j+9
     }
-    return max((int)best.x, (int)best.y);
+    return max(max((int)best.x - v, v + 1 + (int)best.y), 0);
 }
 
 #define FAST_KT 12  // selection-grid cells per dimension cached in LDS (a 70-px ROI spans at most ~10 at the coarsest level)
@@ -652,20 +652,20 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     Every wave owns a quarter of the queue (it scores 16 rows x 64 columns) and counts in a register: no atomics.
     int wq = 0;
     unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
+    const bool in_band = lx < w - 3;
+    const unsigned long long band = __builtin_amdgcn_ballot_w64(in_band);
     for (int ly = __builtin_amdgcn_readfirstlane(3 + (tid >> 6)); ly < h - 3; ly += 4) {  // wave-uniform row
-        bool cand = false;
-        if (lx < w - 3) {
-            const uint8_t* c = &s_img[ly * FP + lx];
-            const int v = c[0];
-            const int hi = v + tq, lo = v - tq;
-            const int p0 = c[3 * FP], p8 = c[-3 * FP], p4 = c[3], p12 = c[-3];
-            const int xb = max(min(hi - p0, hi - p8), min(hi - p4, hi - p12));  // < 0: both pairs have a brighter pixel
-            const int xd = max(min(p0 - lo, p8 - lo), min(p4 - lo, p12 - lo));  // < 0: both pairs have a darker pixel
-            cand = min(xb, xd) < 0;
-        }
-        const unsigned long long bal = __ballot(cand);
+        // every lane reads (columns beyond the band stay inside the zero-padded FP-byte LDS row); the band test joins the ballot.
+        //   brighter on both opposite pairs  <=>  min(max(p0, p8), max(p4, p12)) > v + t
+        //   darker   on both opposite pairs  <=>  max(min(p0, p8), min(p4, p12)) < v - t
+        const uint8_t* c = &s_img[ly * FP + lx];
+        const int v = c[0];
+        const int p0 = c[3 * FP], p8 = c[-3 * FP], p4 = c[3], p12 = c[-3];
+        const int up = min(max(p0, p8), max(p4, p12)), dn = max(min(p0, p8), min(p4, p12));
+        const bool hit = max(up - v, v - dn) > tq;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit) & band;  // scalar and: no per-lane re-materialisation
         if (bal) {
-            if (cand) my_q[wq + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
+            if (hit && in_band) my_q[wq + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
             wq += __popcll(bal);
         }
     }
@@ -699,16 +699,12 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             const int A = a[0];
             if (A <= t) continue;
             const int s = A - 1;
-            bool keep = true;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int n = a[dy * FP + dx];
-                    const int sn = n > t ? n - 1 : 0;
-                    keep = keep && (s > sn);
-                }
+            // s > (n > t ? n - 1 : 0) for all 8 neighbours  <=>  every neighbour's A is below this one's (A > t >= 1 makes the
+            // "n <= t" branch always true and n <= t < A)
+            const int n0 = max(max((int)a[-FP - 1], (int)a[-FP]), (int)a[-FP + 1]);
+            const int n1 = max(max((int)a[-1], (int)a[1]), (int)a[FP - 1]);
+            const int n2 = max(max((int)a[FP], (int)a[FP + 1]), n0);
+            const bool keep = max(n1, n2) < A;
             if (!keep) continue;
             ++found;
             const int x_level = cell.min_x + qx, y_level = cell.min_y + ly;
