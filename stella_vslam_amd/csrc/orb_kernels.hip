@@ -536,8 +536,8 @@ __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const s16x2 m8 = __builtin_elementwise_min(m4[j], m4[(j + 2) & 7]);                            // window 8 at k = 2j+1
-        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, e[2 * j]));               // arc 2j .. 2j+8
-        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, e[(2 * j + 9) & 15]));    // arc 2j+1 .. 2j+9
+        // arcs 2j .. 2j+8 and 2j+1 .. 2j+9: max(min(m8, a), min(m8, b)) = min(m8, max(a, b))
+        best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8, __builtin_elementwise_max(e[2 * j], e[(2 * j + 9) & 15])));
     }
     return max(max((int)best.x - v, v + 1 + (int)best.y), 0);
 }
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __shared__ unsigned short s_q[SV_CELL * SV_CELL];
     __shared__ unsigned long long s_key[FAST_KT * FAST_KT];  // per-block arg-max of the selection-grid cells the ROI touches
     __shared__ unsigned short s_gx[SV_ROI_MAX], s_gy[SV_ROI_MAX];  // selection-grid column / row of every ROI column / row
-    __shared__ int s_count, s_wq[4];
+    __shared__ int s_count;
     int local, b, ci;
     xcd_frame_map(gridDim.x, gridDim.y, ci, b);
     const int lv = find_level(L, num_levels, ci, &OrbLevel::cell_first, &local);
@@ -665,21 +665,16 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         const bool hit = max(up - v, v - dn) > tq;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit) & band;  // scalar and: no per-lane re-materialisation
         if (bal) {
-            if (hit && in_band) my_q[wq + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)((ly << 7) | lx);
+            if (hit && in_band)  // v_mbcnt: set bits of the ballot below this lane
+                my_q[wq + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)((ly << 7) | lx);
             wq += __popcll(bal);
         }
     }
-    if ((tid & 63) == 0) s_wq[tid >> 6] = wq;
-    __syncthreads();
-    const int o1 = s_wq[0], o2 = o1 + s_wq[1], o3 = o2 + s_wq[2], qn = o3 + s_wq[3];
-    auto qent = [&](int i) -> int {  // flat candidate index -> queue entry (y << 7 | x)
-        const int seg = (i >= o1) + (i >= o2) + (i >= o3);
-        const int off = seg == 0 ? 0 : seg == 1 ? o1 : seg == 2 ? o2 : o3;
-        return s_q[seg * (SV_CELL * SV_CELL / 4) + i - off];
-    };
+    // every wave scores and filters ITS quarter of the queue (rows are dealt round-robin, so the quarters are balanced): no index mapping
+    const int lane = tid & 63;
     // --- pass B: arc score of the candidates
-    for (int i = tid; i < qn; i += 256) {
-        const int e = qent(i), ly = e >> 7, qx = e & 127;
+    for (int i = lane; i < wq; i += 64) {
+        const int e = my_q[i], ly = e >> 7, qx = e & 127;
         const uint8_t* c = &s_img[ly * FP + qx];
         int p[16];
         load_ring(c, p);
@@ -693,8 +688,8 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     for (int pass = 0; pass < 2; ++pass) {
         const int t = pass == 0 ? ini_thr : min_thr;
         int found = 0;
-        for (int i = tid; i < qn; i += 256) {  // only queued pixels can have A > t (t >= tq)
-            const int e = qent(i), ly = e >> 7, qx = e & 127;
+        for (int i = lane; i < wq; i += 64) {  // only queued pixels can have A > t (t >= tq)
+            const int e = my_q[i], ly = e >> 7, qx = e & 127;
             const uint8_t* a = &s_a[ly * FP + qx];
             const int A = a[0];
             if (A <= t) continue;
@@ -849,7 +844,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 #define DESC_IP 32                     // LDS row pitch of the 31 x 31 patch (8 dwords)
 #define DESC_BP 40                     // LDS row pitch of the 37 x 37 patch
 #define DESC_R 18                      // largest |rounded rotated pattern coordinate| (pattern radius 18.38)
-#define DESC_SLAB (31 * DESC_IP + 37 * DESC_BP + 16)
+#define DESC_SLAB (DESC_KPW * 37 * DESC_BP + 16)
 struct IcWeights {
     uint32_t w1[256], wu[256];  // per (row, dword) item: disc mask bytes, (u + 15) x mask bytes
 };
@@ -887,8 +882,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     const int n = min(counts[b * (1 + num_levels)], cap);
     const int i0 = (blk * 4 + wave) * DESC_KPW;
     if (i0 >= n) return;
-    uint8_t* const slab_i = s_slab[wave];
-    uint8_t* const slab_b = slab_i + 31 * DESC_IP;
+    uint8_t* const slab = s_slab[wave];  // DESC_KPW un-blurred 31 x 32 patches, later overwritten by DESC_KPW blurred 37 x 40 patches
     // rBRIEF pattern of this lane's four pairs as floats; disc weights of this lane's (row, dword) items
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
@@ -908,98 +902,121 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         wu[m] = c_icw.wu[item];
         rowv[m] = (item >> 3) - 15;
     }
-    for (int kk = 0; kk < DESC_KPW; ++kk) {
-        const int i = i0 + kk;
-        if (i >= n) break;
-        const int4 s = sel[(size_t)b * total_grid + i];
-        const int x = s.x, y = s.y, lv = s.z;
-        const OrbLevel lev = L[lv];
-        const uint8_t* I;
-        int ipitch;
-        if (lv == 0) {
-            I = img0 + (size_t)b * img0_frame_stride;
-            ipitch = img0_pitch;
-        }
-        else {
-            I = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
-            ipitch = lev.pitch;
-        }
-        // ---- patches -> LDS.  Keypoints keep 19 px to every border: the 32- / 40-byte rows stay inside the image rows
-        // (the blurred rows may run 3 bytes into the row padding / next row, never past the buffer: 256 bytes of slack).
-        {
-            const uint8_t* g = I + (size_t)(y - 15) * ipitch + (x - 15);
-            const int part = lane & 3;
+    const int nk = min(DESC_KPW, n - i0);  // keypoints of this wave (wave-uniform)
+    const int4* const S = sel + (size_t)b * total_grid + i0;
+    const uint8_t* const I0 = img0 + (size_t)b * img0_frame_stride;
+    const uint8_t* const PY = pyr + (size_t)b * pyr_frame_bytes;
+    const uint8_t* const BL = blur + (size_t)b * blur_frame_bytes;
+    const int part = lane & 3, prow = lane >> 2;          // 31 x 31 patch: 4 x 8 bytes per row, 16 rows per pass
+    const int br = lane / 5, bpart = lane - 5 * br;       // 37 x 37 patch: 5 x 8 bytes per row, 12 rows per pass
+    // ---- phase 1: the un-blurred patches of ALL keypoints of the wave -> LDS (loads issued back to back), then their moments.
+    // Keypoints keep 19 px to every border: the 32- / 40-byte rows stay inside the image rows (the blurred rows may run 3 bytes
+    // into the row padding / next row, never past the buffer: 256 bytes of slack).
+    uint2 vi[DESC_KPW][2];
 #pragma unroll
-            for (int r0 = 0; r0 < 32; r0 += 16) {
-                const int r = r0 + (lane >> 2);
-                if (r < 31) {
-                    uint2 v;
-                    __builtin_memcpy(&v, g + (ptrdiff_t)r * ipitch + 8 * part, 8);  // unaligned 8-byte global load
-                    *reinterpret_cast<uint2*>(slab_i + r * DESC_IP + 8 * part) = v;
-                }
+    for (int kk = 0; kk < DESC_KPW; ++kk)
+        if (kk < nk) {
+            const int4 s = S[kk];
+            const uint8_t* const g = (s.z == 0 ? I0 + (size_t)(s.y - 15) * img0_pitch : PY + L[s.z].pyr_off + (size_t)(s.y - 15) * L[s.z].pitch) + (s.x - 15);
+            const int ipitch = s.z == 0 ? img0_pitch : L[s.z].pitch;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (16 * h + prow < 31) __builtin_memcpy(&vi[kk][h], g + (ptrdiff_t)(16 * h + prow) * ipitch + 8 * part, 8);  // unaligned 8-byte load
+        }
+#pragma unroll
+    for (int kk = 0; kk < DESC_KPW; ++kk)
+        if (kk < nk) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (16 * h + prow < 31) *reinterpret_cast<uint2*>(slab + kk * (31 * DESC_IP) + (16 * h + prow) * DESC_IP + 8 * part) = vi[kk][h];
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the blurred patches are requested now and land while the moments and the angle are computed
+    uint2 vb[DESC_KPW][4];
+#pragma unroll
+    for (int kk = 0; kk < DESC_KPW; ++kk)
+        if (kk < nk) {
+            const int4 s = S[kk];
+            const uint8_t* const gb = BL + L[s.z].blur_off + (size_t)(s.y - DESC_R) * L[s.z].pitch + (s.x - DESC_R);
+            const int bpitch = L[s.z].pitch;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                if (br < 12 && 12 * h + br < 37) __builtin_memcpy(&vb[kk][h], gb + (ptrdiff_t)(12 * h + br) * bpitch + 8 * bpart, 8);
+        }
+    int my10 = 0, my01 = 0;  // lane kk keeps the moments of keypoint kk
+#pragma unroll
+    for (int kk = 0; kk < DESC_KPW; ++kk)
+        if (kk < nk) {
+            int m10 = 0, m01 = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int item = lane + 64 * m;
+                const uint32_t px = item < 248 ? reinterpret_cast<const uint32_t*>(slab + kk * (31 * DESC_IP))[item] : 0u;
+                const int s1 = (int)__builtin_amdgcn_udot4(px, w1[m], 0u, false), su = (int)__builtin_amdgcn_udot4(px, wu[m], 0u, false);
+                m10 += su - 15 * s1;
+                m01 += rowv[m] * s1;
             }
-            const uint8_t* gb = blur + (size_t)b * blur_frame_bytes + lev.blur_off + (size_t)(y - DESC_R) * lev.pitch + (x - DESC_R);
-            const int br = lane / 5, bpart = lane - 5 * br;  // 5 x 8 bytes per row, 12 rows per pass
-#pragma unroll
-            for (int r0 = 0; r0 < 48; r0 += 12) {
-                const int r = r0 + br;
-                if (br < 12 && r < 37) {
-                    uint2 v;
-                    __builtin_memcpy(&v, gb + (ptrdiff_t)r * lev.pitch + 8 * bpart, 8);
-                    *reinterpret_cast<uint2*>(slab_b + r * DESC_BP + 8 * bpart) = v;
-                }
+            m10 = wave_sum(m10);
+            m01 = wave_sum(m01);
+            if (lane == kk) {
+                my10 = m10;
+                my01 = m01;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- intensity centroid
-        int m10 = 0, m01 = 0;
+    // ---- phase 2: orientation of all keypoints at once (lane kk works for keypoint kk; the other lanes idle along)
+    const float angle = dev_fast_atan2((float)my01, (float)my10);
+    const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
+    const float ca_l = dev_util_cos(rad), sa_l = dev_util_sin(rad);
+    // ---- phase 3: blurred patches -> LDS (same region), rotated BRIEF (orb_impl.cc:93-154)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int item = lane + 64 * m;
-            const uint32_t px = item < 248 ? reinterpret_cast<const uint32_t*>(slab_i)[item] : 0u;
-            const int s1 = (int)__builtin_amdgcn_udot4(px, w1[m], 0u, false), su = (int)__builtin_amdgcn_udot4(px, wu[m], 0u, false);
-            m10 += su - 15 * s1;
-            m01 += rowv[m] * s1;
-        }
-        m10 = wave_sum(m10);
-        m01 = wave_sum(m01);
-        const float angle = dev_fast_atan2((float)m01, (float)m10);
-
-        // ---- rotated BRIEF on the blurred level (orb_impl.cc:93-154)
-        const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
-        const float ca = dev_util_cos(rad), sa = dev_util_sin(rad);
-        const uint8_t* B = slab_b + DESC_R * DESC_BP + DESC_R;
-        unsigned long long bits[4];
+    for (int kk = 0; kk < DESC_KPW; ++kk)
+        if (kk < nk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float x0 = px0[r], y0 = py0[r], x1 = px1[r], y1 = py1[r];
-            const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
-            const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
-            const int a = B[r0 * DESC_BP + c0];
-            const int bb = B[r1 * DESC_BP + c1];
-            bits[r] = __ballot(a < bb);
+            for (int h = 0; h < 4; ++h)
+                if (br < 12 && 12 * h + br < 37) *reinterpret_cast<uint2*>(slab + kk * (37 * DESC_BP) + (12 * h + br) * DESC_BP + 8 * bpart) = vb[kk][h];
         }
-        uint8_t* D = desc + ((size_t)b * cap + i) * 32;
-        if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        if (lane == 0) {
-            svgpu_keypoint k;
-            k.x = (float)x;
-            k.y = (float)y;
-            if (lv != 0) {  // correct_keypoint_scale (orb_extractor.cc:337-345)
-                k.x = k.x * lev.scale;
-                k.y = k.y * lev.scale;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kk = 0; kk < DESC_KPW; ++kk)
+        if (kk < nk) {
+            const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ca_l), kk));
+            const float sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa_l), kk));
+            const uint8_t* B = slab + kk * (37 * DESC_BP) + DESC_R * DESC_BP + DESC_R;
+            unsigned long long bits[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x0 = px0[r], y0 = py0[r], x1 = px1[r], y1 = py1[r];
+                const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
+                const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
+                const int a = B[r0 * DESC_BP + c0];
+                const int bb = B[r1 * DESC_BP + c1];
+                bits[r] = __builtin_amdgcn_ballot_w64(a < bb);
             }
-            k.size = lev.kp_size;
-            k.angle = angle;
-            k.response = (float)s.w;
-            k.octave = lv;
-            k.class_id = -1;
-            kps[(size_t)b * cap + i] = k;
+            uint8_t* D = desc + ((size_t)b * cap + i0 + kk) * 32;
+            if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next keypoint overwrites the slab
-        __builtin_amdgcn_wave_barrier();
+    if (lane < nk) {  // lane kk writes the record of keypoint kk
+        const int4 s = S[lane];
+        const int lv = s.z;
+        svgpu_keypoint k;
+        k.x = (float)s.x;
+        k.y = (float)s.y;
+        if (lv != 0) {  // correct_keypoint_scale (orb_extractor.cc:337-345)
+            k.x = k.x * L[lv].scale;
+            k.y = k.y * L[lv].scale;
+        }
+        k.size = L[lv].kp_size;
+        k.angle = angle;
+        k.response = (float)s.w;
+        k.octave = lv;
+        k.class_id = -1;
+        kps[(size_t)b * cap + i0 + lane] = k;
     }
 }
 
