@@ -71,3 +71,16 @@ def test_batch_extract_then_ring_match_equals_oracle(priority):
         assert (exp >= 0).sum() > (600 if f == kf + 1 else 50)
         assert np.array_equal(ring_matched[t, :n1], exp) and ring_n[t] == (exp >= 0).sum(), t
         assert np.array_equal(two_matched[t, :n1], exp) and two_n[t] == ring_n[t], t
+
+
+def test_opt_in_paths_keep_parity_in_a_fresh_process():
+    """The switches read once per process -- SVGPU_FORK_BLUR (blur on the auxiliary stream beside FAST) and SVGPU_BF_VALU (the
+    non-MFMA distance kernel) -- must not change a single bit: re-run the device-resident pipeline test under both."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"SVGPU_FORK_BLUR": "1"}, {"SVGPU_BF_VALU": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_pipeline.py", "-k", "ring_match and 0"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-1000:])
+        assert "1 passed" in r.stdout, r.stdout[-500:]
