@@ -878,7 +878,9 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     __shared__ __attribute__((aligned(16))) uint8_t s_slab[4][DESC_SLAB];
     int b, blk;
     xcd_frame_map(gridDim.x, gridDim.y, blk, b);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything addressed through it (selection entries, level records) then comes in through
+    // scalar loads issued together, instead of one dependent vector-load round trip per keypoint and field
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = min(counts[b * (1 + num_levels)], cap);
     const int i0 = (blk * 4 + wave) * DESC_KPW;
     if (i0 >= n) return;
@@ -912,16 +914,29 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     // ---- phase 1: the un-blurred patches of ALL keypoints of the wave -> LDS (loads issued back to back), then their moments.
     // Keypoints keep 19 px to every border: the 32- / 40-byte rows stay inside the image rows (the blurred rows may run 3 bytes
     // into the row padding / next row, never past the buffer: 256 bytes of slack).
+    // selection entries and level records of all keypoints first (scalar loads, unconditional so that they are issued together;
+    // slots beyond the wave's last keypoint repeat it and are never used)
+    int4 sv[DESC_KPW];
+#pragma unroll
+    for (int kk = 0; kk < DESC_KPW; ++kk) sv[kk] = S[kk];  // the selection buffer is padded by DESC_KPW entries (svgpu_orb.hip)
+    const uint8_t* gi[DESC_KPW];
+    const uint8_t* gbl[DESC_KPW];
+    int pit_i[DESC_KPW], pit_b[DESC_KPW];
+#pragma unroll
+    for (int kk = 0; kk < DESC_KPW; ++kk) {
+        const int lv = kk < nk ? sv[kk].z : 0;  // slots past the wave's last keypoint hold stale entries: keep their level index in range
+        pit_b[kk] = L[lv].pitch;
+        pit_i[kk] = lv == 0 ? img0_pitch : pit_b[kk];
+        gi[kk] = (lv == 0 ? I0 : PY + L[lv].pyr_off) + (size_t)(sv[kk].y - 15) * pit_i[kk] + (sv[kk].x - 15);
+        gbl[kk] = BL + L[lv].blur_off + (size_t)(sv[kk].y - DESC_R) * pit_b[kk] + (sv[kk].x - DESC_R);
+    }
     uint2 vi[DESC_KPW][2];
 #pragma unroll
     for (int kk = 0; kk < DESC_KPW; ++kk)
         if (kk < nk) {
-            const int4 s = S[kk];
-            const uint8_t* const g = (s.z == 0 ? I0 + (size_t)(s.y - 15) * img0_pitch : PY + L[s.z].pyr_off + (size_t)(s.y - 15) * L[s.z].pitch) + (s.x - 15);
-            const int ipitch = s.z == 0 ? img0_pitch : L[s.z].pitch;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                if (16 * h + prow < 31) __builtin_memcpy(&vi[kk][h], g + (ptrdiff_t)(16 * h + prow) * ipitch + 8 * part, 8);  // unaligned 8-byte load
+                if (16 * h + prow < 31) __builtin_memcpy(&vi[kk][h], gi[kk] + (ptrdiff_t)(16 * h + prow) * pit_i[kk] + 8 * part, 8);  // unaligned 8-byte load
         }
 #pragma unroll
     for (int kk = 0; kk < DESC_KPW; ++kk)
@@ -938,12 +953,9 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
 #pragma unroll
     for (int kk = 0; kk < DESC_KPW; ++kk)
         if (kk < nk) {
-            const int4 s = S[kk];
-            const uint8_t* const gb = BL + L[s.z].blur_off + (size_t)(s.y - DESC_R) * L[s.z].pitch + (s.x - DESC_R);
-            const int bpitch = L[s.z].pitch;
 #pragma unroll
             for (int h = 0; h < 4; ++h)
-                if (br < 12 && 12 * h + br < 37) __builtin_memcpy(&vb[kk][h], gb + (ptrdiff_t)(12 * h + br) * bpitch + 8 * bpart, 8);
+                if (br < 12 && 12 * h + br < 37) __builtin_memcpy(&vb[kk][h], gbl[kk] + (ptrdiff_t)(12 * h + br) * pit_b[kk] + 8 * bpart, 8);
         }
     int my10 = 0, my01 = 0;  // lane kk keeps the moments of keypoint kk
 #pragma unroll
@@ -1002,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
             if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
         }
     if (lane < nk) {  // lane kk writes the record of keypoint kk
-        const int4 s = S[lane];
+        const int4 s = S[lane];  // its own (vector) load: keeps the wave-uniform copies above in scalar registers
         const int lv = s.z;
         svgpu_keypoint k;
         k.x = (float)s.x;

@@ -341,7 +341,7 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * C.blur_frame_bytes + 256));
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_keys, B * G * sizeof(unsigned long long)));
     SV_HIP(ctx, hipMemset(ctx->d_keys, 0, B * G * sizeof(unsigned long long)));
-    SV_HIP(ctx, hipMalloc((void**)&ctx->d_sel, B * G * sizeof(int4)));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_sel, (B * G + 8) * sizeof(int4)));  // + slack: k_describe reads whole groups of DESC_KPW entries
     // staging for the single-frame host entry point
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_img, (size_t)C.levels[0].pitch * height));
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_mask, (size_t)C.levels[0].pitch * height));
