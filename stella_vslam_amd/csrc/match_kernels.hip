@@ -978,7 +978,7 @@ __global__ __launch_bounds__(256) void k_grid_place(GridProblem G) {
 // keypoints that pass the level and margin tests, and a wave prefix sum gives every cell its place in the query's list
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_grid_walk(GridProblem G) {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // scalar: per-query data via scalar loads
     if (q >= G.nq) return;
     int total = 0;
     const bool live = !G.q_valid || G.q_valid[q];
@@ -1120,7 +1120,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
-    const int il = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int il = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // scalar: per-keypoint data via scalar loads
     if (il >= P.nl) return;
     const svgpu_keypoint k = P.kl[il];
     const int lvl = k.octave;

@@ -402,18 +402,25 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
         b = blur_load<MODE>(row_ptr(y + 1), x0, w, edge);
     };
     u16x2 A[4], B[4], C[4], D[4], E[4];
+    BlurRow n0, n1;
     {
+        // the ten rows the first output pair needs: all loads issued before the first use (the empty asm ties every loaded word
+        // to one point, so the compiler cannot wait for one row pair before requesting the next)
         BlurRow r[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_pair(ys - 4 + 2 * k, r[2 * k], r[2 * k + 1]);
+        load_pair(ys + 4, n0, n1);
+        if (MODE == BLUR_INTERIOR) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(r[k].w0), "+v"(r[k].w1), "+v"(r[k].w2));
+            asm volatile("" : "+v"(n0.w0), "+v"(n0.w1), "+v"(n0.w2), "+v"(n1.w0), "+v"(n1.w1), "+v"(n1.w2));
+        }
         blur_hpair(r[0], r[1], A);
         blur_hpair(r[2], r[3], B);
         blur_hpair(r[4], r[5], C);
         blur_hpair(r[6], r[7], D);
     }
     uint8_t* Dp = dst + x0;
-    BlurRow n0, n1;
-    load_pair(ys + 4, n0, n1);
     for (int y = ys; y < ye; y += 2) {
         const BlurRow c0 = n0, c1 = n1;
         load_pair(y + 6, n0, n1);  // one pair of rows of loads stays in flight ahead of the arithmetic
