@@ -680,6 +680,7 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
     const uint32_t* tail[BF_RC];
     if (tid == 0) s_pool_n = 0;
     __syncthreads();
+    // heads and counts of this thread's BF_RC rows first (independent loads, issued together), the long rows' tails afterwards
 #pragma unroll
     for (int u = 0; u < BF_RC; ++u) {
         const int j = u * nthr + tid;
@@ -691,17 +692,20 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
             hcnt[u] = C[j];
             head[u] = *reinterpret_cast<const uint4*>(R);
             tail[u] = R + 4;
-            if (hcnt[u] > 4 && pool_rows > 0) {  // long rows (groups of look-alike keypoints) are walked deep every sweep: keep them in LDS
-                const int slot = atomicAdd(&s_pool_n, 1);
-                if (slot < pool_rows) {
-                    uint32_t* D = pool + (size_t)slot * (BF_LIST - 4);
-#pragma unroll
-                    for (int i = 0; i < (BF_LIST - 4) / 4; ++i) reinterpret_cast<uint4*>(D)[i] = reinterpret_cast<const uint4*>(R + 4)[i];
-                    tail[u] = D;
-                }
-            }
         }
     }
+#pragma unroll
+    for (int u = 0; u < BF_RC; ++u)
+        if (hcnt[u] > 4 && pool_rows > 0) {  // long rows (groups of look-alike keypoints) are walked deep every sweep: keep them in LDS
+            const int slot = atomicAdd(&s_pool_n, 1);
+            if (slot < pool_rows) {
+                const uint32_t* R4 = tail[u];
+                uint32_t* D = pool + (size_t)slot * (BF_LIST - 4);
+#pragma unroll
+                for (int i = 0; i < (BF_LIST - 4) / 4; ++i) reinterpret_cast<uint4*>(D)[i] = reinterpret_cast<const uint4*>(R4)[i];
+                tail[u] = D;
+            }
+        }
     __syncthreads();
     for (int sweep = 0; sweep <= n2c; ++sweep) {
         if (tid == 0) {

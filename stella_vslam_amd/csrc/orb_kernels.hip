@@ -394,7 +394,7 @@ __device__ __forceinline__ uint32_t blur_pack(const uint32_t (&acc)[4]) {  // by
 template <int MODE>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int spitch, int w, int h, uint8_t* __restrict__ dst,
                                            int dpitch, int x0, int ys, int ye) {
-    auto row_ptr = [&](int y) { return src + (size_t)reflect101(y, h) * spitch; };
+    auto row_ptr = [&](int y) { return src + __umul24(reflect101(y, h), spitch); };  // < 2^24 each: full-rate multiply, 32-bit offset
     BlurEdge edge = {};
     if (MODE == BLUR_EDGE) edge = blur_edge_ctx(x0, w);
     auto load_pair = [&](int y, BlurRow& a, BlurRow& b) {
@@ -430,12 +430,12 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc[j] = blur_dot(D[j], 34u | (18u << 16), blur_dot(C[j], 56u | (48u << 16), blur_dot(B[j], 34u | (48u << 16), blur_dot(A[j], 18u << 16, 32768u))));
-        *reinterpret_cast<uint32_t*>(Dp + (size_t)y * dpitch) = blur_pack(acc);
+        *reinterpret_cast<uint32_t*>(Dp + __umul24(y, dpitch)) = blur_pack(acc);
         if (y + 1 < ye) {  // row y+1: rows y-2 .. y+4 = B | C | D | E.lo
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[j] = blur_dot(E[j], 18u, blur_dot(D[j], 48u | (34u << 16), blur_dot(C[j], 48u | (56u << 16), blur_dot(B[j], 18u | (34u << 16), 32768u))));
-            *reinterpret_cast<uint32_t*>(Dp + (size_t)(y + 1) * dpitch) = blur_pack(acc);
+            *reinterpret_cast<uint32_t*>(Dp + __umul24(y + 1, dpitch)) = blur_pack(acc);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -830,9 +830,15 @@ __device__ __forceinline__ float dev_util_sin(float v) {
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    // row scans with DPP adds (one VALU instruction each, no LDS round trip), then the row totals across rows; the wave total
+    // lands in lane 63 and is broadcast through a scalar register.  Integer adds: any order gives the same sum.
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // ---- orientation + descriptors.  One wave per keypoint, DESC_KPW keypoints per wave one after the other (the rBRIEF pattern
@@ -943,7 +949,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         if (kk < nk) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                if (16 * h + prow < 31) __builtin_memcpy(&vi[kk][h], gi[kk] + (ptrdiff_t)(16 * h + prow) * pit_i[kk] + 8 * part, 8);  // unaligned 8-byte load
+                if (16 * h + prow < 31) __builtin_memcpy(&vi[kk][h], gi[kk] + (__umul24(16 * h + prow, pit_i[kk]) + 8 * part), 8);  // unaligned 8-byte load
         }
 #pragma unroll
     for (int kk = 0; kk < DESC_KPW; ++kk)
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         if (kk < nk) {
 #pragma unroll
             for (int h = 0; h < 4; ++h)
-                if (br < 12 && 12 * h + br < 37) __builtin_memcpy(&vb[kk][h], gbl[kk] + (ptrdiff_t)(12 * h + br) * pit_b[kk] + 8 * bpart, 8);
+                if (br < 12 && 12 * h + br < 37) __builtin_memcpy(&vb[kk][h], gbl[kk] + (__umul24(12 * h + br, pit_b[kk]) + 8 * bpart), 8);
         }
     int my10 = 0, my01 = 0;  // lane kk keeps the moments of keypoint kk
 #pragma unroll
@@ -974,8 +980,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
                 const int item = lane + 64 * m;
                 const uint32_t px = item < 248 ? reinterpret_cast<const uint32_t*>(slab + kk * (31 * DESC_IP))[item] : 0u;
                 const int s1 = (int)__builtin_amdgcn_udot4(px, w1[m], 0u, false), su = (int)__builtin_amdgcn_udot4(px, wu[m], 0u, false);
-                m10 += su - 15 * s1;
-                m01 += rowv[m] * s1;
+                m10 += su - __mul24(15, s1);  // 24-bit multiplies: v_mul_lo_u32 is quarter rate
+                m01 += __mul24(rowv[m], s1);
             }
             m10 = wave_sum(m10);
             m01 = wave_sum(m01);
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         if (kk < nk) {
 #pragma unroll
             for (int h = 0; h < 4; ++h)
-                if (br < 12 && 12 * h + br < 37) *reinterpret_cast<uint2*>(slab + kk * (37 * DESC_BP) + (12 * h + br) * DESC_BP + 8 * bpart) = vb[kk][h];
+                if (br < 12 && 12 * h + br < 37) *reinterpret_cast<uint2*>(slab + kk * (37 * DESC_BP) + __mul24(12 * h + br, DESC_BP) + 8 * bpart) = vb[kk][h];
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1013,8 +1019,8 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
                 const float x0 = px0[r], y0 = py0[r], x1 = px1[r], y1 = py1[r];
                 const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
                 const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
-                const int a = B[r0 * DESC_BP + c0];
-                const int bb = B[r1 * DESC_BP + c1];
+                const int a = B[__mul24(r0, DESC_BP) + c0];
+                const int bb = B[__mul24(r1, DESC_BP) + c1];
                 bits[r] = __builtin_amdgcn_ballot_w64(a < bb);
             }
             uint8_t* D = desc + ((size_t)b * cap + i0 + kk) * 32;
