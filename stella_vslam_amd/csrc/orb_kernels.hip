@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         for (int i = tid; i < SV_ROI_MAX * (FP / 16); i += 256) {
             const int r = i / (FP / 16), c = i - r * (FP / 16);
             uint4 v = {0, 0, 0, 0};
-            if (r < h && 16 * c < w + 3) v = *reinterpret_cast<const uint4*>(rsrc + (size_t)r * spitch + 16 * c);
+            if (r < h && 16 * c < w + 3) v = *reinterpret_cast<const uint4*>(rsrc + (__umul24(r, spitch) + 16 * c));
             reinterpret_cast<uint4*>(s_raw)[i] = v;
             reinterpret_cast<uint4*>(s_a)[i] = make_uint4(0, 0, 0, 0);
         }
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         for (int i = tid; i < SV_ROI_MAX * (FP / 4); i += 256) {
             const int r = i / (FP / 4), c = i - r * (FP / 4);
             uint32_t v = 0;
-            if (r < h && c < words) v = *reinterpret_cast<const uint32_t*>(rsrc + (size_t)r * spitch + 4 * c);
+            if (r < h && c < words) v = *reinterpret_cast<const uint32_t*>(rsrc + (__umul24(r, spitch) + 4 * c));
             reinterpret_cast<uint32_t*>(s_raw)[i] = v;
             reinterpret_cast<uint32_t*>(s_a)[i] = 0;
         }
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     else {
         for (int i = tid; i < SV_ROI_MAX * FP; i += 256) {
             const int r = i / FP, c = i - r * FP;
-            s_raw[i] = (r < h && c < w + 3) ? rsrc[(size_t)r * spitch + c] : 0;
+            s_raw[i] = (r < h && c < w + 3) ? rsrc[__umul24(r, spitch) + c] : 0;
             s_a[i] = 0;
         }
     }
@@ -1017,10 +1017,14 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x0 = px0[r], y0 = py0[r], x1 = px1[r], y1 = py1[r];
-                const int r0 = __float2int_rn(x0 * sa + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sa);
-                const int r1 = __float2int_rn(x1 * sa + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sa);
-                const int a = B[__mul24(r0, DESC_BP) + c0];
-                const int bb = B[__mul24(r1, DESC_BP) + c1];
+                // cvRound = round half to even: adding 1.5 * 2^23 leaves the rounded integer in the low mantissa bits (|coordinate| < 2^22),
+                // one add instead of v_rndne + v_cvt; the 24-bit multiply sees 0x400000 + row, the constant folds into the LDS base
+                constexpr float RN = 12582912.0f;
+                constexpr int RK = 0x400000 * DESC_BP + 0x4B400000;
+                const int r0 = __float_as_int((x0 * sa + y0 * ca) + RN), c0 = __float_as_int((x0 * ca - y0 * sa) + RN);
+                const int r1 = __float_as_int((x1 * sa + y1 * ca) + RN), c1 = __float_as_int((x1 * ca - y1 * sa) + RN);
+                const int a = B[__mul24(r0, DESC_BP) + c0 - RK];
+                const int bb = B[__mul24(r1, DESC_BP) + c1 - RK];
                 bits[r] = __builtin_amdgcn_ballot_w64(a < bb);
             }
             uint8_t* D = desc + ((size_t)b * cap + i0 + kk) * 32;
