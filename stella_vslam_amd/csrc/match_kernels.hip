@@ -480,7 +480,6 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
             expand(0, 0, min(MF_TT, cn));
             __syncthreads();
             for (int t = 0, buf = 0; t < ntiles; ++t, buf ^= 1) {
-                if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                 const int base = cbase + t * MF_TT, tend = min(base + MF_TT, hi);
                 const bool mine = wave_live && ((base < whi[0] && tend > wlo[0]) || (base < whi[1] && tend > wlo[1]));
                 if (mine) {
@@ -494,6 +493,8 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                         acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc[1], 0, 0, 0);
                         b = bn;
                     }
+                    // the next tile's +-1 expansion is pure VALU / LDS work: issued here it runs in the shadow of the 16 MFMAs above
+                    if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                     const int col = t * MF_TT + (lane & 31);
                     const uint32_t ta = __float_as_uint(S.rang[col]);
                     const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24) | (256u << 15);
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                         wq_n = 0;
                     }
                 }
+                else if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                 __syncthreads();
             }
         }
