@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
             const uint8_t* PL = P.lev_l[lvl];
             const uint8_t* PR = P.lev_r[lvl];
             const int pl = P.pitch_l[lvl], pr = P.pitch_r[lvl];
-            const int lc = PL[(size_t)syl * pl + sxl];
+            const int lc = PL[__umul24(syl, pl) + sxl];
             // this lane's (up to) two patch pixels
             int a[2], dy[2], dx[2];
             bool has[2];
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
                 has[t] = p < 121;
                 dy[t] = has[t] ? p / 11 - 5 : 0;
                 dx[t] = has[t] ? p % 11 - 5 : 0;
-                a[t] = has[t] ? (int)PL[(size_t)(syl + dy[t]) * pl + sxl + dx[t]] - lc : 0;
+                a[t] = has[t] ? (int)PL[__umul24(syl + dy[t], pl) + sxl + dx[t]] - lc : 0;
             }
             float corr[11];
             float best_corr = 3.402823466e+38f;
@@ -1179,12 +1179,12 @@ __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
 #pragma unroll
             for (int o = 0; o < 11; ++o) {
                 const int off = o - 5;
-                const int rc = PR[(size_t)syl * pr + sxr + off];
+                const int rc = PR[__umul24(syl, pr) + sxr + off];
                 int acc = 0;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                     if (has[t]) {
-                        const int b = (int)PR[(size_t)(syl + dy[t]) * pr + sxr + off + dx[t]] - rc;
+                        const int b = (int)PR[__umul24(syl + dy[t], pr) + sxr + off + dx[t]] - rc;
                         acc += abs(a[t] - b);
                     }
                 const float c = (float)wave_sum_i(acc);

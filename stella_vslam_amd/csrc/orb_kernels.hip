@@ -279,12 +279,12 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
             if (l > 1)
                 packed = pyr_group<PYR_SRC_LDS>(S + __mul24(ye.x - src_lo, sp), S + __mul24(ye.y - src_lo, sp), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
             else if (words0)
-                packed = pyr_group<PYR_SRC_GLOBAL_WORDS>(I0 + (size_t)ye.x * img0_pitch, I0 + (size_t)ye.y * img0_pitch, e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
+                packed = pyr_group<PYR_SRC_GLOBAL_WORDS>(I0 + __umul24(ye.x, img0_pitch), I0 + __umul24(ye.y, img0_pitch), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
             else
-                packed = pyr_group<PYR_SRC_GLOBAL_BYTES>(I0 + (size_t)ye.x * img0_pitch, I0 + (size_t)ye.y * img0_pitch, e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
+                packed = pyr_group<PYR_SRC_GLOBAL_BYTES>(I0 + __umul24(ye.x, img0_pitch), I0 + __umul24(ye.y, img0_pitch), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
             Dl[__mul24(row, dpw) + g] = packed;
             const int dy = lo + row;
-            if (dy >= own_lo && dy < own_hi) *reinterpret_cast<uint32_t*>(Dg + (size_t)dy * lev.pitch + 4 * g) = packed;
+            if (dy >= own_lo && dy < own_hi) *reinterpret_cast<uint32_t*>(Dg + (__umul24(dy, lev.pitch) + 4 * g)) = packed;
         }
         __syncthreads();
     }
