@@ -1,6 +1,7 @@
 #include "camera.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 
@@ -106,6 +107,41 @@ void update_mean_normal_and_obs_scale_variance(svgpu_ctx* ctx, const std::vector
                                                    ref_scale_factor.data(), inv_scale_factor_last, reinterpret_cast<double*>(mean_normal.data()),
                                                    max_valid_dist.data(), min_valid_dist.data());
     if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_landmarks_update_geometry: ") + svgpu_last_error(ctx));
+}
+
+bow_vocabulary_hip::bow_vocabulary_hip(svgpu_ctx* ctx, const std::vector<int>& child_off, const std::vector<int>& children, const cv::Mat& node_desc,
+                                       const std::vector<float>& node_weight, const std::vector<int>& word_id, int depth)
+    : ctx_(ctx), depth_(depth) {
+    const int n = (int)child_off.size() - 1;
+    std::vector<uint8_t> packed((size_t)node_desc.rows * 32);
+    for (int i = 0; i < node_desc.rows; ++i) std::memcpy(&packed[(size_t)i * 32], node_desc.ptr(i), 32);
+    const int rc = svgpu_bow_vocabulary_upload(ctx, n, child_off.data(), children.data(), packed.data(), node_weight.data(), word_id.data(), &vocab_);
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_bow_vocabulary_upload: ") + svgpu_last_error(ctx));
+}
+
+bow_vocabulary_hip::~bow_vocabulary_hip() { svgpu_bow_vocabulary_free(vocab_); }
+
+void bow_vocabulary_hip::compute_bow(const cv::Mat& descriptors, std::map<unsigned int, double>& bow_vec,
+                                     std::map<unsigned int, std::vector<unsigned int>>& bow_feat_vec, int levels_up) const {
+    bow_vec.clear();
+    bow_feat_vec.clear();
+    const int n = descriptors.rows;
+    if (n == 0) return;
+    std::vector<uint8_t> packed((size_t)n * 32);
+    for (int i = 0; i < n; ++i) std::memcpy(&packed[(size_t)i * 32], descriptors.ptr(i), 32);
+    std::vector<int32_t> word((size_t)n), node((size_t)n);
+    std::vector<float> weight((size_t)n);
+    const int rc = svgpu_bow_transform(ctx_, vocab_, packed.data(), n, std::max(depth_ - levels_up, 0), word.data(), weight.data(), node.data());
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_bow_transform: ") + svgpu_last_error(ctx_));
+    for (int i = 0; i < n; ++i)
+        if (weight[(size_t)i] > 0.f) {  // zero-weight words (stop words) are skipped
+            bow_vec[(unsigned int)word[(size_t)i]] += (double)weight[(size_t)i];
+            bow_feat_vec[(unsigned int)node[(size_t)i]].push_back((unsigned int)i);
+        }
+    double norm = 0.0;
+    for (const auto& kv : bow_vec) norm += std::fabs(kv.second);
+    if (norm > 0.0)
+        for (auto& kv : bow_vec) kv.second /= norm;
 }
 }  // namespace data
 }  // namespace stella_vslam_hip

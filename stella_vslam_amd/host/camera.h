@@ -3,6 +3,7 @@
 // img_bounds_ is filled in the constructor (compute_image_bounds) as the reference does.
 #pragma once
 #include <array>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -109,5 +110,25 @@ void update_mean_normal_and_obs_scale_variance(svgpu_ctx* ctx, const std::vector
                                                const std::vector<float>& ref_scale_factor, float inv_scale_factor_last,
                                                std::vector<Vec3_t>& mean_normal, std::vector<float>& max_valid_dist,
                                                std::vector<float>& min_valid_dist);
+
+//! data::bow_vocabulary (data/bow_vocabulary.h) on a flat tree kept resident on the device: node 0 = root, children of node i =
+//! children[child_off[i] .. child_off[i+1]) (none = leaf), node_desc n x 32, weight / word id per node, `depth` = L.
+//! compute_bow() is bow_vocabulary_util::compute_bow (data/bow_vocabulary.cc:18-24): the descent runs on the device, the two sparse
+//! maps are assembled here (weights summed per word, L1-normalised as the ORB vocabulary's TF-IDF / L1 setting prescribes).
+class bow_vocabulary_hip {
+public:
+    bow_vocabulary_hip(svgpu_ctx* ctx, const std::vector<int>& child_off, const std::vector<int>& children, const cv::Mat& node_desc,
+                       const std::vector<float>& node_weight, const std::vector<int>& word_id, int depth);
+    ~bow_vocabulary_hip();
+    bow_vocabulary_hip(const bow_vocabulary_hip&) = delete;
+    bow_vocabulary_hip& operator=(const bow_vocabulary_hip&) = delete;
+    void compute_bow(const cv::Mat& descriptors, std::map<unsigned int, double>& bow_vec,
+                     std::map<unsigned int, std::vector<unsigned int>>& bow_feat_vec, int levels_up = 4) const;
+
+private:
+    svgpu_ctx* ctx_;
+    svgpu_vocabulary* vocab_ = nullptr;
+    int depth_;
+};
 }  // namespace data
 }  // namespace stella_vslam_hip

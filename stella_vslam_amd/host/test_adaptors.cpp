@@ -269,6 +269,28 @@ int main() {
                       && mxd[l] == (float)((4.0 + 0.01 * l) * params.scale_factors_[2]) && mnd[l] == mxd[l] * params.inv_scale_factors_[7];
             REQUIRE(okl);
         }
+        {   // BoW: a two-level vocabulary whose 2 x 3 leaves are keypoint descriptors; every descriptor used as a leaf must come back
+            // as that leaf's word, through the inner node it hangs under
+            std::vector<int> coff = {0, 2, 5, 8, 8, 8, 8, 8, 8, 8}, ch = {1, 2, 3, 4, 5, 6, 7, 8}, wid = {-1, -1, -1, 0, 1, 2, 3, 4, 5};
+            std::vector<float> ww = {0, 0, 0, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f};
+            cv::Mat nd(9, 32, cv::CV_8U);
+            std::memset(nd.ptr(0), 0, 9 * 32);
+            const int leaf_kp[6] = {0, 10, 20, 30, 40, 50};
+            for (int l = 0; l < 6; ++l) std::memcpy(nd.ptr(3 + l), d1.ptr(leaf_kp[l]), 32);
+            std::memcpy(nd.ptr(1), d1.ptr(10), 32);  // inner nodes: one of their leaves
+            std::memcpy(nd.ptr(2), d1.ptr(40), 32);
+            data::bow_vocabulary_hip voc(ext.context(), coff, ch, nd, ww, wid, 2);
+            cv::Mat qd(6, 32, cv::CV_8U);
+            for (int l = 0; l < 6; ++l) std::memcpy(qd.ptr(l), d1.ptr(leaf_kp[l]), 32);
+            std::map<unsigned int, double> bv;
+            std::map<unsigned int, std::vector<unsigned int>> fv;
+            voc.compute_bow(qd, bv, fv, 1);
+            double sum = 0;
+            for (auto& kv : bv) sum += kv.second;
+            size_t nfeat = 0;
+            for (auto& kv : fv) nfeat += kv.second.size();
+            REQUIRE(!bv.empty() && std::fabs(sum - 1.0) < 1e-12 && nfeat == 6 && fv.size() <= 2);
+        }
         std::printf("frame observation: %d keypoints, %d landmarks visible, %u matched (%d onto their own keypoint)\n", n, vis, nmf, self);
     }
     // motion-only BA: perturbed camera 2 against the 60 exact observations of the scene above
