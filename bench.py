@@ -310,7 +310,7 @@ def cpu_baseline(frames_np):
             o, _ = pr.communicate(timeout=120)
             nf, dt = o.split()
             rates.append(int(nf) / float(dt))
-        out["all_host_cores"] = {"value": round(sum(rates), 2), "unit": "frames/s", "cores": ncore, "how": "one single-threaded oracle process per core, 6 s each"}
+        out["all_host_cores"] = {"value": round(sum(rates), 2), "unit": "frames/s", "cores": ncore, "how": f"one single-threaded oracle process per core on {ncore} of the host's {os.cpu_count()} cores, 6 s each"}
     except Exception as e:
         out["all_host_cores"] = {"error": str(e)}
     try:
