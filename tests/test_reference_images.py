@@ -78,3 +78,40 @@ def test_device_equals_oracle_on_the_reference_images(name):
     ko, do, _ = O.orb_extract(img, mask=m, min_area=1000)
     assert len(kg) == len(ko) and np.array_equal(kg, ko) and np.array_equal(dg, do)
     assert ok(kg)
+
+
+# ---- the reference's three toy samples at their own sizes (orb_extractor.cc:25-77 and 330-357): white image, black rectangle,
+#      every keypoint within 2 x scale of the rectangle's free corner (cv::rectangle fills both corner points inclusively)
+TOYS = {"toy_sample_1": ((600, 600), (300, 300, 600, 600), (300, 300)),          # (rows, cols), (x0, y0, x1, y1), corner (x, y)
+        "toy_sample_2": ((2000, 2000), (0, 0, 1800, 1800), (1800, 1800)),
+        "toy_sample_3": ((1200, 600), (300, 600, 600, 1200), (300, 600))}
+
+
+def _toy(name):
+    (rows, cols), (x0, y0, x1, y1), corner = TOYS[name]
+    img = np.full((rows, cols), 255, np.uint8)
+    img[y0:min(y1 + 1, rows), x0:min(x1 + 1, cols)] = 0
+    return img, corner
+
+
+def _near_corner(k, corner):
+    sf = O.scale_tables(1.2, 8)[0]
+    tol = 2.0 * sf[k["octave"]]
+    return (np.abs(k["x"] - corner[0]) <= tol).all() and (np.abs(k["y"] - corner[1]) <= tol).all()
+
+
+@pytest.mark.parametrize("name", list(TOYS))
+def test_oracle_toy_samples(name):
+    img, corner = _toy(name)
+    k, d, _ = O.orb_extract(img, min_area=1000)
+    assert len(k) > 0 and d.shape == (len(k), 32) and _near_corner(k, corner)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(TOYS))
+def test_device_toy_samples_equal_oracle(name):
+    from stella_vslam_amd import feature as F
+    img, corner = _toy(name)
+    kg, dg = F.orb_extractor(F.orb_params("ORB setting for test"), min_area=1000).extract(img)
+    ko, do, _ = O.orb_extract(img, min_area=1000)
+    assert len(kg) == len(ko) > 0 and np.array_equal(kg, ko) and np.array_equal(dg, do) and _near_corner(kg, corner)
