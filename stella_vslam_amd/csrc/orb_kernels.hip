@@ -15,7 +15,9 @@
 
 namespace {
 
-__device__ __constant__ signed char c_pattern[1024] = {
+// the rBRIEF pattern (small integers) stored as floats: k_describe keeps its pairs as floats, so one 16-byte load per pair replaces a byte
+// unpack + 4 converts per wave
+__device__ __constant__ float c_pattern_f[1024] = {
 #include "orb_pattern_i8.inc"
 };
 
@@ -902,11 +904,11 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const char4 q = reinterpret_cast<const char4*>(c_pattern)[r * 64 + lane];
-        px0[r] = (float)q.x;
-        py0[r] = (float)q.y;
-        px1[r] = (float)q.z;
-        py1[r] = (float)q.w;
+        const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[r * 64 + lane];
+        px0[r] = q.x;
+        py0[r] = q.y;
+        px1[r] = q.z;
+        py1[r] = q.w;
     }
     uint32_t w1[4], wu[4];
     int rowv[4];
