@@ -352,13 +352,30 @@ typedef struct svgpu_ba_stats {
     int32_t lm_trials, cholesky_failures;
     double lambda_final;
     int32_t stopped_by_terminate_action; /* the gain rule (not the caller) raised the stop flag (global_bundle_adjuster.cc:341) */
-    int32_t reserved;
+    int32_t pcg_iterations;              /* total PCG iterations over all damping trials (0 with the Cholesky solvers) */
 } svgpu_ba_stats;
 
-/* Host in/out, synchronous.
- *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled between LM iterations
- *               and -- reference quirk, terminate_action.cc:36-76 -- SET when the gain rule stops stage 1, so
- *               that stage 2 is skipped exactly as in the reference.
+/* Linear solver of the reduced camera system (BlockSolver_6_3 + LinearSolverEigen / LinearSolverCSparse in the reference,
+ * optimize/local_bundle_adjuster_g2o.cc:151-164, optimize/global_bundle_adjuster.cc:66-85):
+ *   AUTO      on-chip dense LL^T up to 6 * free poses = 192, block-Jacobi PCG on the block-sparse system above
+ *   CHOLESKY  force the on-chip LL^T (falls back to PCG when the system does not fit the LDS)
+ *   PCG       force the PCG (also on small systems)
+ *   DENSE     dense image + rocSOLVER dpotrf / dpotrs (loaded on first use)
+ * pcg_tolerance: relative residual |r| / |g| (<= 0: 1e-10); pcg_max_iterations <= 0: max(2000, 4 n).  A solve that hits the
+ * cap is taken as an inexact step when the residual fell below 1e-6, else the damping trial counts as a solver failure. */
+typedef enum svgpu_ba_solver {
+    SVGPU_BA_SOLVER_AUTO = 0,
+    SVGPU_BA_SOLVER_CHOLESKY = 1,
+    SVGPU_BA_SOLVER_PCG = 2,
+    SVGPU_BA_SOLVER_DENSE = 3
+} svgpu_ba_solver;
+int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations);
+
+/* Host in/out, synchronous.  The Levenberg-Marquardt loop (damping trials, rho test, terminate_action) runs on the device; the
+ * host enqueues the trials of a stage and reads the control block back once per stage (plus once per rejected trial).
+ *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled at every damping-trial boundary
+ *               (mirrored into page-locked memory while the host waits) and -- reference quirk, terminate_action.cc:36-76 --
+ *               SET when the gain rule stops stage 1, so that stage 2 is skipped exactly as in the reference.
  *   pose_out    num_poses x 12, points_out num_points x 3, outlier_out num_obs (1 = outlier observation) */
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
@@ -383,24 +400,43 @@ int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const doub
  * fixed), ONE Levenberg-Marquardt run of problem->num_first_iter iterations with the terminate rule, optional Huber
  * (obs_huber_delta), no outlier gate (num_second_iter is ignored).  The caller applies the reference's post-conditions
  * (`force_stop_flag && *force_stop_flag && !stats->stopped_by_terminate_action` => discard, :341-343).
- * Reduced systems beyond the on-chip solver (6 * free poses > 192) are factorised with rocSOLVER dpotrf/dpotrs
- * (loaded on first use; the reference uses a sparse CSparse Cholesky there).  Host in/out, synchronous. */
+ * Reduced systems beyond the on-chip solver (6 * free poses > 192) are solved by the block-Jacobi PCG on the block-sparse
+ * Schur complement (svgpu_ba_set_solver; the reference uses a sparse CSparse Cholesky there).  Host in/out, synchronous. */
 int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                     double* points_out, svgpu_ba_stats* stats);
 
 /* Multi-GPU variant.  Every rank passes the FULL pose / point arrays and ITS SHARD of the observations; the shard
  * must be BY LANDMARK (all observations of one landmark on one rank, e.g. obs_point % world == rank) so that the
- * Schur complement of a landmark is formed locally.  Per damping trial the partial reduced camera systems
- * ((6P+1) x 6P doubles) are summed with ONE all-reduce and solved redundantly on every rank; per linearisation the
- * pose blocks Hpp/bp (42 doubles per free pose) and a few scalars (chi2, step scale, flags) are summed as well.
- * `allreduce(user, dev_buf, count, stream)` must sum `count` doubles in place across ranks on `stream`
- * (stella_vslam_amd/distributed.py binds it to torch.distributed / RCCL).  All ranks return identical poses and
- * points; outlier_out covers the local shard.  The stop flag must be raised consistently on all ranks (it is
- * OR-reduced at every iteration boundary). */
+ * Schur complement of a landmark is formed locally.  Per damping trial the kept 6x6 blocks of the partial reduced camera
+ * systems and their right-hand sides (36 * blocks + 6 * free poses doubles) are summed with ONE all-reduce and solved
+ * redundantly on every rank; per linearisation the pose blocks Hpp/bp (42 doubles per free pose) and per trial four scalars
+ * (chi2, step scale, solver failure, stop votes) are summed as well.  All collectives are enqueued on the context's stream:
+ * the damping loop never waits for the host.
+ *   allreduce == NULL   the context's own RCCL communicator is used (svgpu_comm_init below: no Python, no callback)
+ *   allreduce != NULL   `allreduce(user, dev_buf, count, stream)` must sum `count` doubles in place across ranks, ordered on
+ *                       `stream` (stella_vslam_amd/distributed.py binds it to torch.distributed: RCCL, or gloo in CPU-side tests)
+ * All ranks return identical poses and points; outlier_out covers the local shard.  A rank's stop flag is a VOTE: the votes are
+ * summed inside the per-trial all-reduce and every rank acts on the sum only, so ranks never diverge between two collectives
+ * however the callers' flags are raised. */
 typedef int (*svgpu_allreduce_fn)(void* user, double* dev_buf, size_t count, void* stream);
 int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world,
                            svgpu_allreduce_fn allreduce, void* allreduce_user, volatile uint8_t* stop, double* pose_out,
                            double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
+/* svgpu_global_ba over the same sharding (BASELINE config 5: landmark-sharded global BA at 1/2/4/8 GPUs). */
+int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world,
+                            svgpu_allreduce_fn allreduce, void* allreduce_user, volatile uint8_t* stop, double* pose_out,
+                            double* points_out, svgpu_ba_stats* stats);
+
+/* ------------------------------------------------------------------------------------------------ RCCL communicator
+ * One communicator per context (= per GPU / process), RCCL over xGMI, loaded with dlopen on first use.  Rank 0 calls
+ * svgpu_comm_unique_id and hands the 128 bytes (ncclUniqueId) to the other ranks through whatever channel the host
+ * application has (the reference has none: a multi-process launcher passes it via its own rendezvous; bench.py and the tests
+ * broadcast it with torch.distributed); every rank then calls svgpu_comm_init. */
+int svgpu_comm_unique_id(uint8_t* id128);
+int svgpu_comm_init(svgpu_ctx* ctx, int rank, int world, const uint8_t* id128);
+void svgpu_comm_destroy(svgpu_ctx* ctx);
+/* Sum of `count` doubles in place over the communicator, ordered on `stream` (NULL = the context's stream). */
+int svgpu_comm_allreduce_f64(svgpu_ctx* ctx, double* dev_buf, size_t count, void* stream);
 
 #ifdef __cplusplus
 }

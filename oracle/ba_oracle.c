@@ -284,8 +284,33 @@ static void build_index(ba_t* B) {
     free(la);
 }
 
-/* dense LL^T, in place in the lower triangle; returns 0 on success */
-static int chol_factor(double* A, int n) {
+/* dense LL^T, in place in the lower triangle; returns 0 on success.
+ * Rows are walked inside their envelope only: first[i] = column of the first non-zero of row i of the INPUT matrix.  Entries left
+ * of the envelope stay exactly zero through the factorisation, and a skipped term of the inner products is an exact 0 * x, so the
+ * factor is bit-identical to the plain dense loops (checked by tests/test_oracle_ba.py) -- it only makes the 3000 x 3000 reduced
+ * systems of the global-BA configuration (500 keyframes on a loop: a band plus the loop-closure corner) affordable on one core. */
+static int chol_factor_env(double* A, int n, int* first) {
+    for (int i = 0; i < n; ++i) {
+        int f = 0;
+        while (f < i && A[(size_t)i * n + f] == 0.0) ++f;
+        first[i] = f;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int fi = first[i];
+        for (int j = fi; j < i; ++j) {
+            double s = A[(size_t)i * n + j];
+            const int k0 = fi > first[j] ? fi : first[j];
+            for (int k = k0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / A[(size_t)j * n + j];
+        }
+        double d = A[(size_t)i * n + i];
+        for (int k = fi; k < i; ++k) d -= A[(size_t)i * n + k] * A[(size_t)i * n + k];
+        if (!(d > 0)) return -1;
+        A[(size_t)i * n + i] = sqrt(d);
+    }
+    return 0;
+}
+static int chol_factor(double* A, int n) { /* small systems (pose optimizer 6x6): no envelope bookkeeping */
     for (int j = 0; j < n; ++j) {
         double d = A[(size_t)j * n + j];
         for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
@@ -300,6 +325,19 @@ static int chol_factor(double* A, int n) {
     }
     return 0;
 }
+static void chol_solve_env(const double* Lm, int n, const int* first, double* b) {
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = first[i]; k < i; ++k) s -= Lm[(size_t)i * n + k] * b[k];
+        b[i] = s / Lm[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k)
+            if (first[k] <= i) s -= Lm[(size_t)k * n + i] * b[k];
+        b[i] = s / Lm[(size_t)i * n + i];
+    }
+}
 static void chol_solve(const double* Lm, int n, double* b) {
     for (int i = 0; i < n; ++i) {
         double s = b[i];
@@ -311,6 +349,32 @@ static void chol_solve(const double* Lm, int n, double* b) {
         for (int k = i + 1; k < n; ++k) s -= Lm[(size_t)k * n + i] * b[k];
         b[i] = s / Lm[(size_t)i * n + i];
     }
+}
+
+/* test hook: both factorisations on the same matrix (tests/test_oracle_ba.py checks bit equality) */
+int orc_chol_envelope_check(const double* A_in, int n, const double* b_in, double* x_env, double* x_dense) {
+    double* A1 = (double*)malloc(sizeof(double) * (size_t)n * n);
+    double* A2 = (double*)malloc(sizeof(double) * (size_t)n * n);
+    int* first = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+    memcpy(A1, A_in, sizeof(double) * (size_t)n * n);
+    memcpy(A2, A_in, sizeof(double) * (size_t)n * n);
+    memcpy(x_env, b_in, sizeof(double) * n);
+    memcpy(x_dense, b_in, sizeof(double) * n);
+    const int r1 = chol_factor_env(A1, n, first), r2 = chol_factor(A2, n);
+    if (!r1) chol_solve_env(A1, n, first, x_env);
+    if (!r2) chol_solve(A2, n, x_dense);
+    int same = r1 == r2;
+    if (!r1 && !r2)
+        for (int i = 0; i < n && same; ++i)
+            for (int j = 0; j <= i; ++j)
+                if (A1[(size_t)i * n + j] != A2[(size_t)i * n + j]) {
+                    same = 0;
+                    break;
+                }
+    free(A1);
+    free(A2);
+    free(first);
+    return same ? (r1 ? 1 : 0) : -1;
 }
 
 static int inv3(const double* A, double* Ai) {
@@ -490,8 +554,10 @@ static int solve_system(const ba_t* B, lin_t* S, double lambda, const int* lm_ed
         }
     }
     if (n > 0) {
-        if (chol_factor(Hs, n)) fail = 1;
-        else chol_solve(Hs, n, bs);
+        int* first = (int*)malloc(sizeof(int) * (size_t)(n + 1));
+        if (chol_factor_env(Hs, n, first)) fail = 1;
+        else chol_solve_env(Hs, n, first, bs);
+        free(first);
     }
     memcpy(S->xp, bs, sizeof(double) * n);
     for (int l = 0; l < B->L; ++l) {

@@ -2,15 +2,36 @@
 #pragma once
 #include <cstdint>
 
+// Levenberg-Marquardt control block, resident in device memory.  The whole damping loop of
+// OptimizationAlgorithmLevenberg::solve and the terminate_action hook run on the device (k_ba_begin / k_ba_prepare /
+// k_ba_decide): the host enqueues "steps" (one damping trial each, preceded by a linearisation when the previous trial
+// closed an LM iteration) and reads this block back once per batch of steps instead of twice per trial.
+//   phase 0  the next step starts an LM iteration: linearise, (iteration 0: lambda init), then run a trial
+//   phase 1  a linearisation is in place; run (another) damping trial
+//   phase 2  optimize() has finished: every kernel of the remaining steps returns at once
+struct BaCtl {
+    double lambda, ni, current_chi, last_chi, temp_chi, scale, rho, chi_begin;
+    double gain_thr, pcg_rr0, pcg_tol2, pad0;
+    unsigned long long max_diag_bits;  // bit pattern of the largest |diagonal| (non-negative doubles order like integers)
+    int cur;                           // which of the two state buffers holds the estimate (the other receives the trial)
+    int it, it_max, qmax, phase, ok;
+    int stop;                          // the optimizer's force-stop flag as the device sees it
+    int stopped_by_terminate;
+    int lm_trials, solve_failures, solve_failed;
+    int pcg_done, pcg_fail, pcg_it, pcg_max_it, pcg_total_it, pcg_solves;
+    int pad1;
+};
+
 struct BaDev {
     int P, L, E;   // poses (free + fixed), landmarks, observation edges (sorted by landmark)
     int nP;        // free, active poses = rows/6 of the reduced system
     int n;         // 6 * nP
-    // state: [R|t] rows (12 doubles per pose), 3 doubles per landmark; cur = linearisation point, trial = cur (+) delta
-    double* pose_cur;
-    double* pose_trial;
-    double* pt_cur;
-    double* pt_trial;
+    BaCtl* ctl;
+    const volatile int* stop_mirror;  // page-locked host word the caller's force_stop_flag is mirrored into while the host waits
+    const double* xsum;               // sharded solve: {chi2, step scale, solver failures, stop votes} summed over the ranks; else null
+    // state: [R|t] rows (12 doubles per pose), 3 doubles per landmark; buffer ctl->cur = linearisation point, the other = cur (+) delta
+    double* pose_buf[2];
+    double* pt_buf[2];
     // observations
     const int* e_pose;
     const int* e_point;
@@ -42,19 +63,32 @@ struct BaDev {
     double* Dinv;  // L x 6
     double* Hpp;   // nP x 36
     double* bp;    // nP x 6
-    double* S;     // (n + 1) x n: reduced system, row n = right-hand side (then L^-1 g)
+    double* Sblk;  // NB x 36: the kept upper blocks (a <= b) of the reduced camera system, row-major 6x6 each, in blk_ab order
+    double* g;     // n: right-hand side of the reduced system (directly behind Sblk: one all-reduce covers both)
+    double* S;     // dense (n + 1) x n image, only for the rocSOLVER path (solver = dense)
     double* dp;    // n
     double* dl;    // L x 3
     double* red;   // reduction scratch / read-back: see offsets below
     int red_chi_off, red_chi_n;      // per-block partial sums of the robust chi2
     int red_scale_off, red_scale_n;  // per-block partial sums of delta^T (lambda delta + b)
-    int red_flag_off;                // [0] cholesky failure flag, [1] max diagonal
-    double lambda;
-    double lambda_diag;      // damping added to the diagonal of S by THIS rank (lambda, or 0 on ranks > 0 of a sharded solve)
+    int red_flag_off;                // [2..5] cycle counters of the on-chip Cholesky
+    int add_lambda;          // 1 = THIS rank adds the damping to the diagonal of S (rank 0 only in a sharded solve)
     const double* Hpp_full;  // pose blocks summed over all ranks (== Hpp when not sharded): lambda init
     const double* bp_full;   // same for bp: step-scale term
     int scale_pose;          // 1 = this rank contributes the pose part of delta^T(lambda delta + b)
     int chol_in_lds;
+    int world, rank;         // sharded solve (world > 1): lambda init takes the max over the ranks' one-hot slots
+    double* maxslots;        // world doubles (sharded)
+    // block-row view of the kept blocks for the PCG solver: row a lists (block index | transposed << 30, column b)
+    const int* prow_off;     // nP + 1
+    const int2* prow_ent;
+    const int* diag_blk;     // nP: index of block (a, a)
+    double* pcg_Minv;        // nP x 36: inverse diagonal blocks (block-Jacobi preconditioner)
+    double* pcg_rws;         // 2 sets x 3 vectors x n: r, w = S u, s (neighbour-visible, double-buffered)
+    double* pcg_own;         // 2 x n: u, p of the own rows
+    double* pcg_parts;       // 2 x nparts x 4: per-workgroup partial sums (gamma, delta, |r|^2)
+    double* pcg_scal;        // 2 x 4: (gamma, alpha) of the previous iteration
+    int pcg_nparts;
 };
 
 // motion-only BA (pose_optimizer): everything lives in ONE persistent single-workgroup kernel
@@ -79,5 +113,15 @@ void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P);
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Dinv/Y, Schur complement, right-hand side
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // reduced solve, back-substitution, trial state
-void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache);
+void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded);
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out);
+void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale);   // this rank's partial sums -> 4 doubles (sharded solve)
+void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in);       // start of SparseOptimizer::optimize(it_max)
+void sv_ba_prepare(hipStream_t s, const BaDev& D);                              // lambda init (iteration 0) + start of a trial
+void sv_ba_decide(hipStream_t s, const BaDev& D);                               // rho test, damping update, terminate_action
+void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);          // rocSOLVER dpotrf / dpotrs (solver = dense)
+void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);               // back-substitution, trial state
+// block-Jacobi PCG on the block-sparse reduced camera system (ba_pcg.hip)
+void sv_pcg_init(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
+void sv_pcg_iterate(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int first_it, int count);
+enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, SV_BA_SOLVER_DENSE = 3 };

@@ -96,10 +96,14 @@ __device__ __forceinline__ void huber(double e, double delta, double* rho0, doub
     }
 }
 
-__device__ __forceinline__ void edge_linearize(const BaDev& D, int e, EdgeLin& o) {
+// the two state buffers: ctl->cur holds the estimate (linearisation point), the other one receives the trial state
+__device__ __forceinline__ const double* st_pose(const BaDev& D, int trial) { return (D.ctl->cur ^ trial) ? D.pose_buf[1] : D.pose_buf[0]; }
+__device__ __forceinline__ const double* st_pt(const BaDev& D, int trial) { return (D.ctl->cur ^ trial) ? D.pt_buf[1] : D.pt_buf[0]; }
+
+__device__ __forceinline__ void edge_linearize(const BaDev& D, const double* __restrict__ pose_cur, const double* __restrict__ pt_cur, int e, EdgeLin& o) {
     const int p = D.e_pose[e], l = D.e_point[e];
-    const double* T = D.pose_cur + (size_t)p * 12;
-    const double* X = D.pt_cur + (size_t)l * 3;
+    const double* T = pose_cur + (size_t)p * 12;
+    const double* X = pt_cur + (size_t)l * 3;
     const double* K = D.intr + (size_t)p * 5;
     const float* uvr = D.e_uvr + (size_t)e * 3;
     const double w0 = (double)D.e_w[e];
@@ -186,6 +190,9 @@ __device__ __forceinline__ double group_sum8(double v) {
     return v;
 }
 __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
+    if (D.ctl->phase != 0) return;
+    const double* pose_cur = st_pose(D, 0);
+    const double* pt_cur = st_pt(D, 0);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
     const bool in_range = t / LM_LANES < D.L;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
             const int slot = D.pose_slot[D.e_pose[e]];
             if (!lfree && slot < 0) continue;
             EdgeLin o;
-            edge_linearize(D, e, o);
+            edge_linearize(D, pose_cur, pt_cur, e, o);
             if (lfree) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
@@ -237,8 +244,12 @@ __global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
 
 // LP_SPLIT workgroups per free pose: each linearises a contiguous share of the pose's active edges and tree-reduces its 27
 // sums (21 of Hpp, 6 of bp) in a fixed order; k_ba_lin_pose_fin adds the LP_SPLIT partials in share order.
-#define LP_SPLIT 4
-__global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restrict__ part) {
+#define LP_SPLIT 8
+#define LP_THREADS 512  // 1024 threads capped the kernel at 128 VGPRs: 240 bytes per lane went to scratch
+__global__ __launch_bounds__(LP_THREADS) void k_ba_lin_pose(BaDev D, double* __restrict__ part) {
+    if (D.ctl->phase != 0) return;
+    const double* pose_cur = st_pose(D, 0);
+    const double* pt_cur = st_pt(D, 0);
     const int s = blockIdx.x, share = blockIdx.y;
     double acc[27];
 #pragma unroll
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restric
         const int e = D.pe_idx[q];
         if (D.e_level[e]) continue;  // lists are built once per call; excluded edges stay listed
         EdgeLin o;
-        edge_linearize(D, e, o);
+        edge_linearize(D, pose_cur, pt_cur, e, o);
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(1024) void k_ba_lin_pose(BaDev D, double* __restric
 // adds the LP_SPLIT partials of a pose in share order (a second launch is far cheaper than a device-scope fence per
 // workgroup: agent-scope release on gfx950 writes the XCD's L2 back)
 __global__ __launch_bounds__(64) void k_ba_lin_pose_fin(BaDev D, const double* __restrict__ part) {
+    if (D.ctl->phase != 0) return;
     __shared__ double s_o[27];
     const int s = blockIdx.x;
     if (threadIdx.x < 27) {
@@ -304,6 +316,7 @@ __global__ __launch_bounds__(64) void k_ba_lin_pose_fin(BaDev D, const double* _
 
 // max |diagonal| over all active vertices (computeLambdaInit); non-negative doubles order like their bit patterns
 __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
+    if (D.ctl->phase != 0 || D.ctl->it != 0) return;  // computeLambdaInit: first iteration of an optimize() call only
     const int i = blockIdx.x * 256 + threadIdx.x;
     double m = 0.0;
     if (i < D.L && D.pt_free[i]) m = fmax(fabs(D.Hll[(size_t)i * 6]), fmax(fabs(D.Hll[(size_t)i * 6 + 3]), fabs(D.Hll[(size_t)i * 6 + 5])));
@@ -312,20 +325,27 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.0)
-        atomicMax(reinterpret_cast<unsigned long long*>(D.red + D.red_flag_off + 1), (unsigned long long)__double_as_longlong(m));
+        atomicMax(&D.ctl->max_diag_bits, (unsigned long long)__double_as_longlong(m));
+}
+// sharded solve: every rank publishes its maximum in its own slot; the slots are summed over the ranks (one-hot => the sum IS
+// the slot vector) and k_ba_prepare takes the largest
+__global__ void k_ba_maxslot(BaDev D) {
+    const int r = threadIdx.x;
+    if (r < D.world) D.maxslots[r] = (r == D.rank) ? __longlong_as_double((long long)D.ctl->max_diag_bits) : 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {  // 8 lanes per landmark, as k_ba_lin_lm: every lane inverts, lane `sub` maps its edges
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int l = t / LM_LANES, sub = t % LM_LANES;
-    if (l >= D.L || !D.pt_free[l]) return;
+    if (D.ctl->phase != 1 || l >= D.L || !D.pt_free[l]) return;
+    const double lambda = D.ctl->lambda;
     const double* H = D.Hll + (size_t)l * 6;
-    const double a = H[0] + D.lambda, b = H[1], c = H[2], d = H[3] + D.lambda, e_ = H[4], f = H[5] + D.lambda;
+    const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e_ = H[4], f = H[5] + lambda;
     const double c00 = d * f - e_ * e_, c01 = e_ * c - b * f, c02 = b * e_ - d * c;
     const double det = a * c00 + b * c01 + c * c02;
     double I[6];
     if (det == 0.0 || !isfinite(det)) {
-        D.red[D.red_flag_off] = 1.0;  // benign race: any writer sets the same value
+        D.ctl->solve_failed = 1;  // benign race: any writer sets the same value
 #pragma unroll
         for (int k = 0; k < 6; ++k) I[k] = 0.0;
     }
@@ -364,16 +384,19 @@ __global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {  // 8 lanes per land
 //   S_ab = [a==b](Hpp_a + lambda I) - sum over the block's (edge, edge) pairs of Y_i W_j^T
 // threads stride over the pairs, waves are tree-reduced with shuffles, the 8 wave partials are added in wave order
 #define SCHUR_THREADS 512
-#define SCHUR_SPLIT 4  // workgroups per block: contiguous shares of its pair list, combined in share order by k_ba_schur_fin
+#define SCHUR_SPLIT 4  // workgroups per block (few blocks, long pair lists): contiguous shares of the pair list, combined in
+                       // share order by k_ba_schur_fin; with thousands of blocks (global BA) one workgroup per block: gridDim.y = 1
 __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D, double* __restrict__ part) {
+    if (D.ctl->phase != 1) return;
     __shared__ double s_part[SCHUR_THREADS / 64][36];
     const int blk = blockIdx.x, share = blockIdx.y;
+    const int nsplit = gridDim.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
     const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
-    const int q0 = lo + (int)((long long)np * share / SCHUR_SPLIT), q1 = lo + (int)((long long)np * (share + 1) / SCHUR_SPLIT);
+    const int q0 = lo + (int)((long long)np * share / nsplit), q1 = lo + (int)((long long)np * (share + 1) / nsplit);
     for (int q = q0 + threadIdx.x; q < q1; q += SCHUR_THREADS) {
         const int2 pr = D.blk_pairs[q];
         const double2* Yd = reinterpret_cast<const double2*>(D.Y + (size_t)pr.x * 18);
@@ -402,29 +425,30 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D, double* __r
         double sum = 0.0;
 #pragma unroll
         for (int wv = 0; wv < SCHUR_THREADS / 64; ++wv) sum += s_part[wv][threadIdx.x];
-        part[((size_t)blk * SCHUR_SPLIT + share) * 36 + threadIdx.x] = sum;
+        part[((size_t)blk * nsplit + share) * 36 + threadIdx.x] = sum;
     }
 }
-__global__ __launch_bounds__(64) void k_ba_schur_fin(BaDev D, const double* __restrict__ part) {
-    const int blk = blockIdx.x;
-    if (threadIdx.x < 36) {
+// S_ab (row-major 6x6) -> Sblk[blk]: 256 threads finish 7 blocks (36 entries each) per workgroup
+__global__ __launch_bounds__(256) void k_ba_schur_fin(BaDev D, const double* __restrict__ part, int nsplit) {
+    if (D.ctl->phase != 1) return;
+    const int blk = blockIdx.x * 7 + threadIdx.x / 36, t = threadIdx.x % 36;
+    if (threadIdx.x < 252 && blk < D.NB) {
         const int2 ab = D.blk_ab[blk];
-        const int i = threadIdx.x / 6, j = threadIdx.x - 6 * i;
+        const int i = t / 6, j = t - 6 * i;
         double sum = 0.0;
-        for (int h = 0; h < SCHUR_SPLIT; ++h) sum += part[((size_t)blk * SCHUR_SPLIT + h) * 36 + threadIdx.x];
+        for (int h = 0; h < nsplit; ++h) sum += part[((size_t)blk * nsplit + h) * 36 + t];
         double v = -sum;
         if (ab.x == ab.y) {
-            v += D.Hpp[(size_t)ab.x * 36 + threadIdx.x];
-            if (i == j) v += D.lambda_diag;
+            v += D.Hpp[(size_t)ab.x * 36 + t];
+            if (i == j && D.add_lambda) v += D.ctl->lambda;
         }
-        const size_t n = D.n;
-        D.S[(size_t)(6 * ab.x + i) * n + 6 * ab.y + j] = v;
-        if (ab.x != ab.y) D.S[(size_t)(6 * ab.y + j) * n + 6 * ab.x + i] = v;
+        D.Sblk[(size_t)blk * 36 + t] = v;
     }
 }
 
 // workgroup per free pose: g_a = bp_a - sum_e Y_e bl_l(e)  -> row n of S
 __global__ __launch_bounds__(1024) void k_ba_rhs(BaDev D) {
+    if (D.ctl->phase != 1) return;
     const int s = blockIdx.x;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += blockDim.x) {
@@ -446,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_ba_rhs(BaDev D) {
     if (threadIdx.x < 6) {
         double t = 0.0;
         for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
-        D.S[(size_t)D.n * D.n + 6 * s + threadIdx.x] = D.bp[(size_t)s * 6 + threadIdx.x] - t;
+        D.g[6 * s + threadIdx.x] = D.bp[(size_t)s * 6 + threadIdx.x] - t;
     }
 }
 
@@ -531,11 +555,21 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ba_chol_lds(BaDev D) {
     __shared__ double s_X[CHOL_NB][CHOL_NB + 1];  // inverse of the current diagonal block of L
     __shared__ double s_invd[1024];               // 1 / L_ii
     __shared__ int s_fail;
+    if (D.ctl->phase != 1) return;
     const int n = D.n, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
     const int ld = n | 1;
     double* A = s_A;
-    for (int r = tid / n, c = tid % n; r <= n; r += (c + nt) / n, c = (c + nt) % n) A[r * ld + c] = D.S[(size_t)r * n + c];
+    // the lower triangle of the reduced system from its kept upper blocks: S[6a+i][6b+j] = blk[i][j] (a <= b) sits at row 6b+j,
+    // column 6a+i; blocks that were not kept are zero; row n = the right-hand side
+    for (int k = tid; k < (n + 1) * ld; k += nt) A[k] = 0.0;
     if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int k = tid; k < D.NB * 36; k += nt) {
+        const int blk = k / 36, t = k - 36 * blk, i = t / 6, j = t - 6 * i;
+        const int2 ab = D.blk_ab[blk];
+        A[(6 * ab.y + j) * ld + 6 * ab.x + i] = D.Sblk[k];
+    }
+    for (int c = tid; c < n; c += nt) A[n * ld + c] = D.g[c];
     __syncthreads();
     long long tmark = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0};
 #define CHOL_LAP(slot)                                        \
@@ -619,7 +653,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ba_chol_lds(BaDev D) {
         CHOL_LAP(2)
     }
     if (s_fail) {
-        if (tid == 0) D.red[D.red_flag_off] = 1.0;
+        if (tid == 0) D.ctl->solve_failed = 1;
         for (int i = tid; i < n; i += nt) D.dp[i] = 0.0;
         return;
     }
@@ -672,6 +706,7 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ba_chol_lds(BaDev D) {
 
 // Fallback for systems that do not fit LDS (n > ~140): same arithmetic on the global copy, one column per step.
 __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
+    if (D.ctl->phase != 1) return;
     __shared__ int s_fail;
     const int n = D.n, tid = threadIdx.x, nt = blockDim.x, ld = n;
     double* A = D.S;
@@ -697,7 +732,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
     }
     __syncthreads();
     if (s_fail) {
-        if (tid == 0) D.red[D.red_flag_off] = 1.0;
+        if (tid == 0) D.ctl->solve_failed = 1;
         for (int i = tid; i < n; i += nt) D.dp[i] = 0.0;
         return;
     }
@@ -714,6 +749,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
 // thread per landmark: dl = Dinv (bl - sum W^T dp), trial point, partial of delta^T(lambda delta + b)
 __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {  // 8 lanes per landmark (32 landmarks per workgroup), as k_ba_lin_lm
     __shared__ double s4[16];
+    if (D.ctl->phase != 1) return;
+    const double lambda = D.ctl->lambda;
+    const double* pt_cur = st_pt(D, 0);
+    double* pt_trial = const_cast<double*>(st_pt(D, 1));
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
     const bool in_range = t / LM_LANES < D.L;
@@ -737,7 +776,7 @@ __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {  // 8 lanes per
 #pragma unroll
     for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
     if (in_range && sub == 0) {
-        double X[3] = {D.pt_cur[(size_t)l * 3], D.pt_cur[(size_t)l * 3 + 1], D.pt_cur[(size_t)l * 3 + 2]};
+        double X[3] = {pt_cur[(size_t)l * 3], pt_cur[(size_t)l * 3 + 1], pt_cur[(size_t)l * 3 + 2]};
         if (lfree) {
             const double* b = D.bl + (size_t)l * 3;
             c[0] += b[0];
@@ -750,11 +789,11 @@ __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {  // 8 lanes per
             X[0] += d0;
             X[1] += d1;
             X[2] += d2;
-            sc = d0 * (D.lambda * d0 + b[0]) + d1 * (D.lambda * d1 + b[1]) + d2 * (D.lambda * d2 + b[2]);
+            sc = d0 * (lambda * d0 + b[0]) + d1 * (lambda * d1 + b[1]) + d2 * (lambda * d2 + b[2]);
         }
-        D.pt_trial[(size_t)l * 3] = X[0];
-        D.pt_trial[(size_t)l * 3 + 1] = X[1];
-        D.pt_trial[(size_t)l * 3 + 2] = X[2];
+        pt_trial[(size_t)l * 3] = X[0];
+        pt_trial[(size_t)l * 3 + 1] = X[1];
+        pt_trial[(size_t)l * 3 + 2] = X[2];
     }
     const double tsum = block_sum_d(sc, s4);
     if (threadIdx.x == 0) D.red[D.red_scale_off + blockIdx.x] = tsum;
@@ -763,11 +802,13 @@ __global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {  // 8 lanes per
 // thread per pose: trial = exp(dp) * cur (g2o SE3Quat::exp, shot_vertex.h:55-58)
 __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0) {
     __shared__ double s4[16];
+    if (D.ctl->phase != 1) return;
+    const double lambda = D.ctl->lambda;
     const int p = blockIdx.x * 256 + threadIdx.x;
     double sc = 0.0;
     if (p < D.P) {
-        const double* T = D.pose_cur + (size_t)p * 12;
-        double* O = D.pose_trial + (size_t)p * 12;
+        const double* T = st_pose(D, 0) + (size_t)p * 12;
+        double* O = const_cast<double*>(st_pose(D, 1)) + (size_t)p * 12;
         const int slot = D.pose_slot[p];
         if (slot < 0) {
 #pragma unroll
@@ -778,7 +819,7 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0
             const double* bpv = D.bp_full + (size_t)slot * 6;
             if (D.scale_pose)
 #pragma unroll
-                for (int k = 0; k < 6; ++k) sc += u[k] * (D.lambda * u[k] + bpv[k]);
+                for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpv[k]);
             const double wx = u[0], wy = u[1], wz = u[2];
             const double theta = sqrt(wx * wx + wy * wy + wz * wz);
             const double Om[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
@@ -822,14 +863,15 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0
 }
 
 // ------------------------------------------------------------------------------------------------ errors
-__global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache) {
+__global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache, int guarded) {
+    if (guarded && D.ctl->phase != 1) return;
     __shared__ double s4[16];
     const int e = blockIdx.x * 256 + threadIdx.x;
     double v = 0.0;
     if (e < D.E && !D.e_level[e]) {
         const int p = D.e_pose[e], l = D.e_point[e];
-        const double* T = (use_trial ? D.pose_trial : D.pose_cur) + (size_t)p * 12;
-        const double* X = (use_trial ? D.pt_trial : D.pt_cur) + (size_t)l * 3;
+        const double* T = st_pose(D, use_trial) + (size_t)p * 12;
+        const double* X = st_pt(D, use_trial) + (size_t)l * 3;
         double r[3];
         const double chi = edge_error(T, X, D.intr + (size_t)p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
         if (store_cache) D.e_chi[e] = chi;
@@ -850,7 +892,7 @@ __global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_
     if (e >= D.E) return;
     const int p = D.e_pose[e], l = D.e_point[e];
     double pc[3];
-    cam_point(D.pose_cur + (size_t)p * 12, D.pt_cur + (size_t)l * 3, pc);
+    cam_point(st_pose(D, 0) + (size_t)p * 12, st_pt(D, 0) + (size_t)l * 3, pc);
     const bool mono = D.e_uvr[(size_t)e * 3 + 2] < 0.f;
     const double thr = mono ? (double)5.99146f : (double)7.81473f;
     const bool out = thr < D.e_chi[e] || !(cam_is_equirect(D.intr + (size_t)p * 5) || 0.0 < pc[2]);
@@ -1133,6 +1175,159 @@ __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LM control on the device
+// fixed-order sum of n doubles by one 256-thread workgroup (strided partial sums, shuffle tree, wave partials in wave order)
+__device__ __forceinline__ double ctl_sum(const double* __restrict__ v, int n, double* sw) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) t += v[i];
+    return block_sum_d(t, sw);
+}
+
+// this rank's partial sums folded to out4 = {chi2, step scale, solver failure, stop vote}: the payload of the per-trial
+// all-reduce of a sharded solve
+__global__ __launch_bounds__(256) void k_ba_fold(BaDev D, double* __restrict__ out4, int with_scale) {
+    __shared__ double sw[16];
+    const double chi = D.E > 0 ? ctl_sum(D.red + D.red_chi_off, D.red_chi_n, sw) : 0.0;
+    const double sc = with_scale ? ctl_sum(D.red + D.red_scale_off, D.red_scale_n, sw) : 0.0;
+    if (threadIdx.x == 0) {
+        out4[0] = chi;
+        out4[1] = sc;
+        out4[2] = with_scale ? (double)D.ctl->solve_failed : 0.0;
+        out4[3] = (D.ctl->stop || *D.stop_mirror) ? 1.0 : 0.0;
+    }
+}
+
+// SparseOptimizer::optimize(it_max) starts: activeRobustChi2 of the estimate (its partial sums were just written by k_ba_chi2),
+// fresh OptimizationAlgorithmLevenberg state; the loop condition `it < iterations && !terminate()` is evaluated for it = 0
+__global__ __launch_bounds__(256) void k_ba_begin(BaDev D, int it_max, int stop_in) {
+    __shared__ double sw[16];
+    double chi = 0.0;
+    int stop = stop_in;
+    if (D.xsum) {
+        chi = D.xsum[0];
+        stop |= D.xsum[3] > 0.5;
+    }
+    else {
+        if (D.E > 0) chi = ctl_sum(D.red + D.red_chi_off, D.red_chi_n, sw);
+        stop |= *D.stop_mirror != 0;
+    }
+    if (threadIdx.x == 0) {
+        BaCtl& c = *D.ctl;
+        c.current_chi = c.chi_begin = chi;
+        c.it = 0;
+        c.it_max = it_max;
+        c.qmax = 0;
+        c.ni = 2.0;
+        c.ok = 1;
+        c.stop = stop;
+        c.max_diag_bits = 0ull;
+        c.solve_failed = 0;
+        c.phase = (it_max > 0 && !stop) ? 0 : 2;
+    }
+}
+
+// after the linearisation of a step: computeLambdaInit on the first iteration, then the trial kernels may run
+__global__ void k_ba_prepare(BaDev D) {
+    BaCtl& c = *D.ctl;
+    if (c.phase == 2) return;
+    if (c.phase == 0) {
+        if (c.it == 0) {
+            double md = __longlong_as_double((long long)c.max_diag_bits);
+            if (D.world > 1) {
+                md = 0.0;
+                for (int r = 0; r < D.world; ++r) md = fmax(md, D.maxslots[r]);
+            }
+            c.lambda = 1e-5 * md;
+            c.ni = 2.0;
+        }
+        c.qmax = 0;
+        c.rho = 0.0;
+        c.phase = 1;
+    }
+    c.solve_failed = 0;
+    c.pcg_done = 0;
+    c.pcg_fail = 0;
+    c.pcg_it = 0;
+}
+
+// end of a damping trial (OptimizationAlgorithmLevenberg::solve, the do { } while (rho < 0 && qmax < 10 && !terminate()) body)
+// and, when the trial closes the LM iteration, the terminate_action hook (optimize/terminate_action.cc:36-76)
+__global__ __launch_bounds__(256) void k_ba_decide(BaDev D) {
+    if (D.ctl->phase != 1) return;
+    __shared__ double sw[16];
+    double temp_chi, scale;
+    int failed, stop_now;
+    if (D.xsum) {
+        temp_chi = D.xsum[0];
+        scale = D.xsum[1];
+        failed = D.xsum[2] > 0.5;
+        stop_now = D.xsum[3] > 0.5;
+    }
+    else {
+        temp_chi = D.E > 0 ? ctl_sum(D.red + D.red_chi_off, D.red_chi_n, sw) : 0.0;
+        scale = ctl_sum(D.red + D.red_scale_off, D.red_scale_n, sw);
+        failed = D.ctl->solve_failed;
+        stop_now = D.ctl->stop || *D.stop_mirror != 0;
+    }
+    if (threadIdx.x != 0) return;
+    BaCtl& c = *D.ctl;
+    ++c.lm_trials;
+    if (failed) {
+        temp_chi = 1.7976931348623157e308;
+        ++c.solve_failures;
+    }
+    double rho = c.current_chi - temp_chi;
+    scale += 1e-3;
+    rho /= scale;
+    c.temp_chi = temp_chi;
+    c.scale = scale;
+    bool lambda_bad = false;
+    if (rho > 0 && isfinite(temp_chi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        c.lambda *= fmax(1. / 3., alpha);
+        c.ni = 2.0;
+        c.current_chi = temp_chi;
+        c.cur ^= 1;  // accept: the trial state becomes the estimate
+    }
+    else {
+        c.lambda *= c.ni;
+        c.ni *= 2.0;
+        lambda_bad = !isfinite(c.lambda);
+    }
+    ++c.qmax;
+    c.rho = rho;
+    c.stop = stop_now;
+    if (!lambda_bad && rho < 0 && c.qmax < 10 && !stop_now) return;  // another trial on the same linearisation (phase stays 1)
+    if (c.qmax == 10 || rho == 0 || !isfinite(c.lambda)) c.ok = 0;
+    // postIteration: terminate_action on the chi2 of the estimate
+    if (c.it == 0) c.last_chi = c.current_chi;
+    else {
+        const double gain = (c.last_chi - c.current_chi) / c.current_chi;
+        c.last_chi = c.current_chi;
+        if (gain >= 0 && gain < c.gain_thr) {
+            c.stop = 1;
+            c.stopped_by_terminate = 1;
+        }
+    }
+    ++c.it;
+    c.phase = (c.it < c.it_max && !c.stop && c.ok) ? 0 : 2;
+}
+
+// dense (n + 1) x n image of the block-sparse system for the rocSOLVER path
+__global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
+    if (D.ctl->phase != 1) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const size_t n = D.n;
+    if (k < D.NB * 36) {
+        const int blk = k / 36, t = k - 36 * blk, i = t / 6, j = t - 6 * i;
+        const int2 ab = D.blk_ab[blk];
+        D.S[(size_t)(6 * ab.x + i) * n + 6 * ab.y + j] = D.Sblk[k];
+        D.S[(size_t)(6 * ab.y + j) * n + 6 * ab.x + i] = D.Sblk[k];
+    }
+    if (k < D.n) D.S[n * n + k] = D.g[k];
+}
+
 }  // namespace
 
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P) {
@@ -1149,7 +1344,7 @@ void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_linearize");
     if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
     if (D.nP > 0) {
-        hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP, LP_SPLIT), dim3(1024), 0, s, D, D.lp_part);
+        hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP, LP_SPLIT), dim3(LP_THREADS), 0, s, D, D.lp_part);
         hipLaunchKernelGGL(k_ba_lin_pose_fin, dim3(D.nP), dim3(64), 0, s, D, D.lp_part);
     }
 }
@@ -1157,22 +1352,31 @@ void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
     const int m = D.L > D.nP ? D.L : D.nP;
     hipLaunchKernelGGL(k_ba_maxdiag, dim3((m + 255) / 256), dim3(256), 0, s, D);
+    if (D.world > 1) hipLaunchKernelGGL(k_ba_maxslot, dim3(1), dim3(64 > D.world ? 64 : D.world), 0, s, D);
 }
 
-// phase 1: Dinv / Y, (partial) reduced camera system S with the right-hand side in row n
+void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale) { hipLaunchKernelGGL(k_ba_fold, dim3(1), dim3(256), 0, s, D, out4, with_scale); }
+void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(256), 0, s, D, it_max, stop_in); }
+void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }
+void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D); }
+
+int sv_ba_schur_split(const BaDev& D) { return D.NB >= 1024 ? 1 : SCHUR_SPLIT; }
+int sv_ba_lin_pose_split() { return LP_SPLIT; }
+
+// phase 1: Dinv / Y, (partial) reduced camera system: kept upper blocks Sblk + right-hand side g
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_schur");
     if (D.L > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
     if (D.nP > 0) {
-        (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
-        hipLaunchKernelGGL(k_ba_schur, dim3(D.NB, SCHUR_SPLIT), dim3(SCHUR_THREADS), 0, s, D, D.sc_part);
-        hipLaunchKernelGGL(k_ba_schur_fin, dim3(D.NB), dim3(64), 0, s, D, D.sc_part);
+        const int split = sv_ba_schur_split(D);
+        hipLaunchKernelGGL(k_ba_schur, dim3(D.NB, split), dim3(SCHUR_THREADS), 0, s, D, D.sc_part);
+        hipLaunchKernelGGL(k_ba_schur_fin, dim3((D.NB + 6) / 7), dim3(256), 0, s, D, D.sc_part, split);
         hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(1024), 0, s, D);
     }
 }
 
-// ---- large reduced systems: rocSOLVER dpotrf / dpotrs, resolved with dlopen on first use so that the library has no
-//      link-time dependency on rocBLAS for the common (local BA) case
+// ---- dense factorisation of large reduced systems: rocSOLVER dpotrf / dpotrs, resolved with dlopen on first use so that the
+//      library has no link-time dependency on rocBLAS (solver = dense; the default for large systems is the PCG of ba_pcg.hip)
 namespace {
 struct RocSolver {
     void* h_blas = nullptr;
@@ -1205,46 +1409,57 @@ bool rocsolver_ready() {
     return true;
 }
 __global__ void k_ba_potrf_info(const int* info, BaDev D) {
+    if (D.ctl->phase != 1) return;
     if (*info != 0) {
-        D.red[D.red_flag_off] = 1.0;
+        D.ctl->solve_failed = 1;
         for (int i = 0; i < D.n; ++i) D.dp[i] = 0.0;
     }
 }
 }  // namespace
 
-// phase 2: reduced solve, back-substitution, trial state
+// on-chip dense LL^T (n <= 192)
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
-    if (D.nP > 0) {
-        SvProfScope ps(ctx, s, "ba_solve");
-        if (D.chol_in_lds) {
-            const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
-            static size_t attr_bytes = 0;  // dynamic LDS above 64 KB must be allowed explicitly; ask for what this system needs
-            if (lds > attr_bytes) {
-                if (hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_bytes = lds;
-                else (void)hipGetLastError();  // do not leave a sticky error behind; an impossible size fails the launch below
-            }
-            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
-        }
-        else if (rocsolver_ready()) {
-            // S is symmetric and fully stored, so its row-major image is a valid column-major matrix (lda = n); the right-hand
-            // side is row n of the (n+1) x n buffer = a contiguous vector right behind the matrix
-            const int rocblas_fill_lower = 122;  // rocblas_fill_lower
-            g_rs.set_stream(g_rs.handle, s);
-            g_rs.dpotrf(g_rs.handle, rocblas_fill_lower, D.n, D.S, D.n, g_rs.d_info);
-            g_rs.dpotrs(g_rs.handle, rocblas_fill_lower, D.n, 1, D.S, D.n, D.S + (size_t)D.n * D.n, D.n);
-            (void)hipMemcpyAsync(D.dp, D.S + (size_t)D.n * D.n, sizeof(double) * D.n, hipMemcpyDeviceToDevice, s);
-            hipLaunchKernelGGL(k_ba_potrf_info, dim3(1), dim3(1), 0, s, g_rs.d_info, D);
-        }
-        else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
+    if (D.nP <= 0) return;
+    SvProfScope ps(ctx, s, "ba_solve");
+    const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
+    static size_t attr_bytes = 0;  // dynamic LDS above 64 KB must be allowed explicitly; ask for what this system needs
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_bytes = lds;
+        else (void)hipGetLastError();  // do not leave a sticky error behind; an impossible size fails the launch below
     }
+    hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
+}
+
+// dense image + rocSOLVER (or, without it, the one-workgroup global-memory factorisation)
+void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+    if (D.nP <= 0) return;
+    SvProfScope ps(ctx, s, "ba_solve");
+    (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
+    hipLaunchKernelGGL(k_ba_expand_dense, dim3((D.NB * 36 + 255) / 256), dim3(256), 0, s, D);
+    if (rocsolver_ready()) {
+        // S is symmetric and fully stored, so its row-major image is a valid column-major matrix (lda = n); the right-hand
+        // side is row n of the (n+1) x n buffer = a contiguous vector right behind the matrix.  (The library calls are not
+        // guarded by the control block: on a finished problem they factor a stale matrix and the result is ignored.)
+        const int rocblas_fill_lower = 122;  // rocblas_fill_lower
+        g_rs.set_stream(g_rs.handle, s);
+        g_rs.dpotrf(g_rs.handle, rocblas_fill_lower, D.n, D.S, D.n, g_rs.d_info);
+        g_rs.dpotrs(g_rs.handle, rocblas_fill_lower, D.n, 1, D.S, D.n, D.S + (size_t)D.n * D.n, D.n);
+        (void)hipMemcpyAsync(D.dp, D.S + (size_t)D.n * D.n, sizeof(double) * D.n, hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(k_ba_potrf_info, dim3(1), dim3(1), 0, s, g_rs.d_info, D);
+    }
+    else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
+}
+
+// back-substitution, trial state
+void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_update");
     if (D.L > 0) hipLaunchKernelGGL(k_ba_update_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
     hipLaunchKernelGGL(k_ba_update_pose, dim3((D.P + 255) / 256), dim3(256), 0, s, D, (D.L * LM_LANES + 255) / 256);
 }
 
-void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache) {
+void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded) {
     SvProfScope ps(ctx, s, "ba_chi2");
-    if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache);
+    if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache, guarded);
 }
 
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out) {

@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <dlfcn.h>
 
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
@@ -115,13 +116,13 @@ void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose,
 
 // dense block offsets (from the device) -> kept blocks: every diagonal block (it carries Hpp + lambda I) and every non-empty
 // off-diagonal block, in (a, b) order; the sorted pair array needs no compaction (empty blocks hold no pairs)
-void compact_blocks(const std::vector<int>& dense_off, HostStructure& H) {
+void compact_blocks(const std::vector<int>& dense_off, const std::vector<uint8_t>& present, HostStructure& H) {
     H.blk_ab.clear();
     H.blk_off.clear();
     size_t k = 0;
     for (int a = 0; a < H.nP; ++a)
         for (int b = a; b < H.nP; ++b, ++k)
-            if (a == b || dense_off[k + 1] > dense_off[k]) {
+            if (a == b || present[k]) {
                 int2 ab;
                 ab.x = a;
                 ab.y = b;
@@ -133,6 +134,52 @@ void compact_blocks(const std::vector<int>& dense_off, HostStructure& H) {
 }
 
 }  // namespace
+
+// ---- in-library collectives: RCCL resolved with dlopen on first use (no link-time dependency, nothing of Python in the data path)
+namespace {
+struct NcclId {
+    char internal[128];  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)
+};
+struct Rccl {
+    void* h = nullptr;
+    int (*get_unique_id)(NcclId*) = nullptr;
+    int (*comm_init_rank)(void**, int, NcclId, int) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*get_error_string)(int) = nullptr;
+    bool tried = false, ok = false;
+};
+Rccl g_rccl;
+bool rccl_ready() {
+    if (g_rccl.tried) return g_rccl.ok;
+    g_rccl.tried = true;
+    // a process that already carries an RCCL (torch's) keeps using that copy
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names)
+        if (!g_rccl.h) g_rccl.h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* nm : names)
+        if (!g_rccl.h) g_rccl.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl.h) return false;
+    g_rccl.get_unique_id = (int (*)(NcclId*))dlsym(g_rccl.h, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (int (*)(void**, int, NcclId, int))dlsym(g_rccl.h, "ncclCommInitRank");
+    g_rccl.comm_destroy = (int (*)(void*))dlsym(g_rccl.h, "ncclCommDestroy");
+    g_rccl.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.h, "ncclAllReduce");
+    g_rccl.get_error_string = (const char* (*)(int))dlsym(g_rccl.h, "ncclGetErrorString");
+    g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_reduce;
+    return g_rccl.ok;
+}
+// svgpu_allreduce_fn bound to the context's communicator: sum of `count` doubles, in place, on `stream`
+int rccl_allreduce_cb(void* user, double* dev_buf, size_t count, void* stream) {
+    svgpu_ctx* ctx = (svgpu_ctx*)user;
+    if (!ctx || !ctx->comm || !g_rccl.ok) return 1;
+    return g_rccl.all_reduce(dev_buf, dev_buf, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, (hipStream_t)stream);
+}
+}  // namespace
+
+void sv_comm_release(svgpu_ctx* ctx) {
+    if (ctx && ctx->comm && g_rccl.ok) g_rccl.comm_destroy(ctx->comm);
+    if (ctx) ctx->comm = nullptr;
+}
 
 static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single_stage, int rank, int world,
                          svgpu_allreduce_fn allreduce, void* ar_user, volatile uint8_t* stop, double* pose_out, double* points_out, uint8_t* outlier_out,
@@ -147,6 +194,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
     const bool sharded = allreduce != nullptr;
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
+    if (!sharded) {
+        world = 1;
+        rank = 0;
+    }
     svgpu_ba_stats st;
     memset(&st, 0, sizeof(st));
     const bool trace = std::getenv("SVGPU_BA_TRACE") != nullptr;
@@ -193,40 +244,54 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     }
 
     lap("sort observations");
+    // ---- solver choice (svgpu_ba_set_solver; SVGPU_BA_SOLVER overrides for experiments)
+    int solver_opt = ctx->ba_solver;
+    if (const char* ev = std::getenv("SVGPU_BA_SOLVER")) {
+        if (!strcmp(ev, "cholesky")) solver_opt = SV_BA_SOLVER_CHOLESKY;
+        else if (!strcmp(ev, "pcg")) solver_opt = SV_BA_SOLVER_PCG;
+        else if (!strcmp(ev, "dense")) solver_opt = SV_BA_SOLVER_DENSE;
+    }
     // ---- device arena
     const int nPmax = P, nmax = 6 * nPmax;
     const int nb_chi = (E + 255) / 256, nb_lm = (8 * L + 255) / 256 /* k_ba_update_lm: 8 lanes per landmark */, nb_pose = (P + 255) / 256;
-    const size_t pairs_max_guess = 0;  // pair lists are sized after build_structure (second arena piece)
-    (void)pairs_max_guess;
+    const size_t nb_cap = (size_t)P * (P + 1) / 2;
+    const size_t sc_part_blocks = std::max(nb_cap + 1, 4 * std::min(nb_cap + 1, (size_t)1024));
+    const size_t xch_doubles = std::max(std::max((size_t)P, 4 * (size_t)L), nb_cap) + 8;
+    const size_t nparts_max = (size_t)(P + 3) / 4 + 1;
+    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE;
     size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
                   + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
-                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E) + pad(sizeof(double) * 27 * 4 * (size_t)P) + pad(4 * (size_t)P) + pad(sizeof(double) * 36 * 4 * ((size_t)P * (P + 1) / 2 + 1)) + pad(4 * ((size_t)P * (P + 1) / 2 + 1)) + pad(sizeof(double) * 6 * E)
+                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E)
+                  + pad(sizeof(double) * 27 * 8 * (size_t)P) + pad(sizeof(double) * 36 * sc_part_blocks) + pad(sizeof(double) * 6 * E)
                   + 3 * pad(sizeof(double) * 6 * L) + 2 * pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
-                  + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (size_t)(nmax + 1) * nmax) + pad(sizeof(double) * nmax)
+                  + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (36 * nb_cap + 6 * (size_t)P + 8)) + pad(sizeof(double) * nmax)
+                  + (want_dense ? pad(sizeof(double) * (size_t)(nmax + 1) * nmax) : 0)
                   + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E + 1) + pad(8 * 42 * (size_t)P)
-                  + pad(8 * (size_t)(64 + world + 1)) + pad(8 * ((size_t)(P > 4 * L ? P : 4 * L) + 8)) + 4096;
+                  + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
+                  + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
+                  + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     // worst-case pair storage: sum over landmarks of k(k+1)/2 (+ duplicates never exceed k^2)
     size_t pair_cap = 0;
     for (int l = 0; l < L; ++l) {
         const size_t k = lm_off[l + 1] - lm_off[l];
         pair_cap += k * k;
     }
-    const size_t nb_cap = (size_t)P * (P + 1) / 2;
     const size_t pair_scratch = sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap);
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
-    const size_t nb_cap_early = (size_t)P * (P + 1) / 2 + 1;
     BaDev D;
     memset(&D, 0, sizeof(D));
     D.P = P;
     D.L = L;
     D.E = E;
-    D.pose_cur = A.take<double>(12 * (size_t)P);
-    D.pose_trial = A.take<double>(12 * (size_t)P);
-    D.pt_cur = A.take<double>(3 * (size_t)L);
-    D.pt_trial = A.take<double>(3 * (size_t)L);
+    D.world = world;
+    D.rank = rank;
+    D.pose_buf[0] = A.take<double>(12 * (size_t)P);
+    D.pose_buf[1] = A.take<double>(12 * (size_t)P);
+    D.pt_buf[0] = A.take<double>(3 * (size_t)L);
+    D.pt_buf[1] = A.take<double>(3 * (size_t)L);
     int* d_e_pose = A.take<int>(E);
     int* d_e_point = A.take<int>(E);
     float* d_e_uvr = A.take<float>(3 * (size_t)E);
@@ -243,8 +308,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int* d_pe_idx = A.take<int>(E);
     D.W = A.take<double>(18 * (size_t)E);
     D.Y = A.take<double>(18 * (size_t)E);
-    D.lp_part = A.take<double>(27 * 4 * (size_t)P);
-    D.sc_part = A.take<double>(36 * 4 * nb_cap_early);
+    D.lp_part = A.take<double>(27 * 8 * (size_t)P);
+    D.sc_part = A.take<double>(36 * sc_part_blocks);
     D.GE = A.take<double>(6 * (size_t)E);
     D.Hll = A.take<double>(6 * (size_t)L);
     D.Dinv = A.take<double>(6 * (size_t)L);
@@ -252,13 +317,23 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.dl = A.take<double>(3 * (size_t)L);
     D.Hpp = A.take<double>(36 * (size_t)P);
     D.bp = A.take<double>(6 * (size_t)P);
-    D.S = A.take<double>((size_t)(nmax + 1) * nmax);
+    D.Sblk = A.take<double>(36 * nb_cap + 6 * (size_t)P + 8);
+    D.S = want_dense ? A.take<double>((size_t)(nmax + 1) * nmax) : nullptr;
     D.dp = A.take<double>(nmax);
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
     uint8_t* d_outlier = A.take<uint8_t>(E + 1);
     double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
-    double* d_sc = A.take<double>(64 + (size_t)(world > 0 ? world : 1));  // sharded: scalar exchange buffer
-    double* d_xch = A.take<double>((size_t)(P > 4 * L ? P : 4 * L) + 8);    // sharded: pose-activity / point exchange
+    double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
+    double* d_xch = A.take<double>(xch_doubles);                  // sharded: pose-activity / block-presence / point exchange
+    D.ctl = (BaCtl*)A.take<char>(sizeof(BaCtl));
+    int* d_prow_off = A.take<int>(P + 1);
+    int2* d_prow_ent = A.take<int2>(2 * (nb_cap + 1));
+    int* d_diag_blk = A.take<int>(P);
+    D.pcg_Minv = A.take<double>(36 * (size_t)P);
+    D.pcg_rws = A.take<double>(6 * (size_t)nmax + 8);
+    D.pcg_own = A.take<double>(2 * (size_t)nmax + 8);
+    D.pcg_parts = A.take<double>(2 * 4 * nparts_max);
+    D.pcg_scal = A.take<double>(8);
     int2* d_blk_pairs = A.take<int2>(pair_cap);
     int2* d_blk_ab = A.take<int2>(nb_cap);
     int* d_blk_off = A.take<int>(nb_cap + 1);
@@ -278,25 +353,60 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.blk_pairs = d_blk_pairs;
     D.blk_ab = d_blk_ab;
     D.blk_off = d_blk_off;
+    D.prow_off = d_prow_off;
+    D.prow_ent = d_prow_ent;
+    D.diag_blk = d_diag_blk;
+    D.maxslots = d_sc + 8;
+    D.xsum = sharded ? d_sc : nullptr;
     D.red_chi_off = 0;
     D.red_chi_n = nb_chi;
     D.red_scale_off = nb_chi;
     D.red_scale_n = nb_lm + nb_pose;
     D.red_flag_off = nb_chi + nb_lm + nb_pose;
-    const int red_total = nb_chi + nb_lm + nb_pose + 8;
-    // per-trial read-back (partial sums, flags) lands in page-locked memory: no staging copy on the D2H path
-    if (ctx->pinned_doubles < (size_t)red_total) {
+    // page-locked block: the control block's read-back copy + the word the caller's stop flag is mirrored into for the device
+    const size_t pinned_need = (sizeof(BaCtl) + 7) / 8 + 16;
+    if (ctx->pinned_doubles < pinned_need) {
         if (ctx->h_pinned) SV_HIP(ctx, hipHostFree(ctx->h_pinned));
         ctx->h_pinned = nullptr;
         ctx->pinned_doubles = 0;
-        SV_HIP(ctx, hipHostMalloc((void**)&ctx->h_pinned, sizeof(double) * (size_t)red_total * 2, hipHostMallocDefault));
-        ctx->pinned_doubles = (size_t)red_total * 2;
+        SV_HIP(ctx, hipHostMalloc((void**)&ctx->h_pinned, sizeof(double) * pinned_need, hipHostMallocMapped));
+        ctx->pinned_doubles = pinned_need;
     }
-    double* const red_host = ctx->h_pinned;
+    if (!ctx->ev_ba) SV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ba, hipEventDisableTiming));
+    BaCtl* const h_ctl = (BaCtl*)ctx->h_pinned;
+    volatile int* const h_mirror = (volatile int*)(ctx->h_pinned + pinned_need - 8);
+    *h_mirror = 0;
+    {
+        void* dptr = nullptr;
+        SV_HIP(ctx, hipHostGetDevicePointer(&dptr, (void*)h_mirror, 0));
+        D.stop_mirror = (const volatile int*)dptr;
+    }
+
+    uint8_t aux_flag = 0;  // g2o installs its own flag when the caller passes none (see svgpu.h)
+    volatile uint8_t* flag = stop ? stop : &aux_flag;
+    *h_mirror = *flag ? 1 : 0;
+    // Wait for the stream.  While the device works, the caller's force_stop_flag (set asynchronously by the tracking thread,
+    // mapping_module.h:232) is mirrored into the page-locked word k_ba_decide / k_ba_begin poll at every trial boundary.  The
+    // host itself never branches on the caller's flag between two collectives of a sharded solve: every rank acts on the
+    // all-reduced votes inside the control block only.
+    auto wait_stream = [&]() -> int {
+        SV_HIP(ctx, hipEventRecord(ctx->ev_ba, s));
+        for (;;) {
+            if (*flag) *h_mirror = 1;
+            const hipError_t q = hipEventQuery(ctx->ev_ba);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return sv_set_error(ctx, SVGPU_ERR_HIP, "hipEventQuery", q);
+        }
+        return SVGPU_OK;
+    };
+    auto read_ctl = [&]() -> int {
+        SV_HIP(ctx, hipMemcpyAsync(h_ctl, D.ctl, sizeof(BaCtl), hipMemcpyDeviceToHost, s));
+        return wait_stream();
+    };
 
 #define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
-    H2D(D.pose_cur, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
-    H2D(D.pt_cur, pr->points, sizeof(double) * 3 * (size_t)L);
+    H2D(D.pose_buf[0], pr->pose_cw, sizeof(double) * 12 * (size_t)P);
+    H2D(D.pt_buf[0], pr->points, sizeof(double) * 3 * (size_t)L);
     H2D(d_e_pose, e_pose.data(), 4 * (size_t)E);
     H2D(d_e_point, e_point.data(), 4 * (size_t)E);
     H2D(d_e_uvr, e_uvr.data(), 12 * (size_t)E);
@@ -307,31 +417,34 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     H2D(d_intr, pr->intrinsics, sizeof(double) * 5 * (size_t)P);
     H2D(d_lm_off, lm_off.data(), 4 * (size_t)(L + 1));
     SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
+    BaCtl ctl0;
+    memset(&ctl0, 0, sizeof(ctl0));
+    ctl0.gain_thr = pr->gain_threshold;
+    ctl0.pcg_tol2 = ctx->pcg_tol * ctx->pcg_tol;
+    ctl0.phase = 2;
+    H2D(D.ctl, &ctl0, sizeof(BaCtl));
+    SV_HIP(ctx, hipMemsetAsync(d_sc, 0, 8 * (64 + (size_t)world), s));
 
     // ---- exchange helpers (sharded solve; no-ops otherwise)
     auto allreduce_dev = [&](double* dev, size_t n) -> int {
         if (!sharded || n == 0) return SVGPU_OK;
         return allreduce(ar_user, dev, n, (void*)s) == 0 ? SVGPU_OK : sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed");
     };
-    auto allreduce_host = [&](double* v, int n) -> int {  // sum n host doubles over the ranks
-        if (!sharded) return SVGPU_OK;
-        H2D(d_sc, v, 8 * (size_t)n);
-        int r = allreduce_dev(d_sc, n);
+    std::vector<double> xch_host(xch_doubles);
+    auto allreduce_host = [&](size_t n) -> int {  // xch_host[0..n) summed over the ranks (set-up steps only)
+        H2D(d_xch, xch_host.data(), 8 * n);
+        int r = allreduce_dev(d_xch, n);
         if (r) return r;
-        SV_HIP(ctx, hipMemcpyAsync(v, d_sc, 8 * (size_t)n, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * n, hipMemcpyDeviceToHost, s));
         SV_HIP(ctx, hipStreamSynchronize(s));
         return SVGPU_OK;
     };
-    std::vector<double> xch_host((size_t)(P > 4 * L ? P : 4 * L) + 8);
     std::vector<uint8_t> owned(L, 0);  // landmarks whose observations live on this rank
     for (int k = 0; k < E; ++k) owned[e_point[k]] = 1;
     if (sharded) {  // contract check: a landmark's observations must not be split over ranks
         for (int l = 0; l < L; ++l) xch_host[l] = owned[l];
-        H2D(d_xch, xch_host.data(), 8 * (size_t)L);
-        int r = allreduce_dev(d_xch, L);
+        int r = allreduce_host(L);
         if (r) return r;
-        SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * (size_t)L, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipStreamSynchronize(s));
         for (int l = 0; l < L; ++l)
             if (xch_host[l] > 1.5) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: observations must be sharded by landmark");
     }
@@ -340,17 +453,15 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     HostStructure HS;
     bool have_lists = false;
     std::vector<uint8_t> pose_active;
+    int solver = SV_BA_SOLVER_CHOLESKY;
     auto upload_structure = [&]() -> int {
         const std::vector<uint8_t>* pa_override = nullptr;
         if (sharded) {  // a pose is active if ANY rank holds an active observation of it
             for (int p = 0; p < P; ++p) xch_host[p] = 0;
             for (int e = 0; e < E; ++e)
                 if (!level[e]) xch_host[e_pose[e]] = 1;
-            H2D(d_xch, xch_host.data(), 8 * (size_t)P);
-            int r = allreduce_dev(d_xch, P);
+            int r = allreduce_host(P);
             if (r) return r;
-            SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * (size_t)P, hipMemcpyDeviceToHost, s));
-            SV_HIP(ctx, hipStreamSynchronize(s));
             pose_active.assign(P, 0);
             for (int p = 0; p < P; ++p) pose_active[p] = xch_host[p] > 0.5;
             pa_override = &pose_active;
@@ -373,9 +484,13 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
         D.chol_in_lds = D.n <= 192 && sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 12 * 1024;
+        solver = solver_opt;
+        if (solver == SV_BA_SOLVER_AUTO) solver = D.chol_in_lds ? SV_BA_SOLVER_CHOLESKY : SV_BA_SOLVER_PCG;
+        if (solver == SV_BA_SOLVER_CHOLESKY && !D.chol_in_lds) solver = SV_BA_SOLVER_PCG;
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
+        D.add_lambda = (!sharded || rank == 0) ? 1 : 0;
         H2D(d_pt_free, HS.pt_free.data(), L);
         if (!reuse) {
             H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
@@ -384,175 +499,172 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             std::vector<int> dense_off;
             int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, dense_off);
             if (rp) return rp;
-            compact_blocks(dense_off, HS);
+            std::vector<uint8_t> present(dense_off.size() ? dense_off.size() - 1 : 0, 0);
+            for (size_t k = 0; k < present.size(); ++k) present[k] = dense_off[k + 1] > dense_off[k];
+            if (sharded && !present.empty()) {  // the kept-block list must be the same on every rank: union of the local patterns
+                for (size_t k = 0; k < present.size(); ++k) xch_host[k] = present[k];
+                int r = allreduce_host(present.size());
+                if (r) return r;
+                for (size_t k = 0; k < present.size(); ++k) present[k] = xch_host[k] > 0.5;
+            }
+            compact_blocks(dense_off, present, HS);
             H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
             if (!HS.blk_ab.empty()) H2D(d_blk_ab, HS.blk_ab.data(), 8 * HS.blk_ab.size());
+            // block rows for the PCG: row a lists its kept blocks (a, b) and, transposed, (b, a)
+            const int NB = (int)HS.blk_ab.size();
+            std::vector<int> prow_off(HS.nP + 1, 0), diag(HS.nP, 0);
+            for (int k = 0; k < NB; ++k) {
+                const int2 ab = HS.blk_ab[k];
+                prow_off[ab.x + 1]++;
+                if (ab.x != ab.y) prow_off[ab.y + 1]++;
+                else diag[ab.x] = k;
+            }
+            for (int a = 0; a < HS.nP; ++a) prow_off[a + 1] += prow_off[a];
+            std::vector<int2> prow_ent(prow_off[HS.nP]);
+            {
+                // blk_ab is sorted by (a, b): filling row a with its transposed blocks (c, a), c < a, first (they arrive in c order)
+                // and its own blocks (a, b), b >= a, afterwards leaves every row sorted by column
+                std::vector<int> fill(prow_off.begin(), prow_off.end() - 1);
+                for (int k = 0; k < NB; ++k) {
+                    const int2 ab = HS.blk_ab[k];
+                    if (ab.x != ab.y) {
+                        int2 e2;
+                        e2.x = k | (1 << 30);
+                        e2.y = ab.x;
+                        prow_ent[fill[ab.y]++] = e2;
+                    }
+                }
+                for (int k = 0; k < NB; ++k) {
+                    const int2 ab = HS.blk_ab[k];
+                    int2 e1;
+                    e1.x = k;
+                    e1.y = ab.y;
+                    prow_ent[fill[ab.x]++] = e1;
+                }
+            }
+            H2D(d_prow_off, prow_off.data(), 4 * prow_off.size());
+            if (!prow_ent.empty()) H2D(d_prow_ent, prow_ent.data(), 8 * prow_ent.size());
+            if (!diag.empty()) H2D(d_diag_blk, diag.data(), 4 * diag.size());
+            SV_HIP(ctx, hipStreamSynchronize(s));  // the host vectors above go out of scope
         }
         else sv_ba_zero_inactive(s, D);
         D.NB = (int)HS.blk_ab.size();
-        if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size());
+        D.g = D.Sblk + 36 * (size_t)D.NB;
+        D.pcg_nparts = (HS.nP + 3) / 4;
+        if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks, n = %d, solver %d)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size(), D.n, solver);
         return SVGPU_OK;
     };
 
-    uint8_t aux_flag = 0;  // g2o installs its own flag when the caller passes none (see svgpu.h)
-    volatile uint8_t* flag = stop ? stop : &aux_flag;
-
-    // chi2 of the active set at the current / trial state (fixed-order sum of the per-block partials); in a
-    // sharded solve the sum runs over all ranks and the stop flags are OR-reduced on the way
-    auto chi2 = [&](int use_trial, int store_cache, double* out) -> int {
-        double sum = 0;
-        if (E > 0) {
-            sv_ba_chi2(ctx, s, D, use_trial, store_cache);
-            SV_HIP(ctx, hipMemcpyAsync(red_host, D.red + D.red_chi_off, 8 * (size_t)nb_chi, hipMemcpyDeviceToHost, s));
-            SV_HIP(ctx, hipStreamSynchronize(s));
-            for (int i = 0; i < nb_chi; ++i) sum += red_host[i];
-        }
+    // activeRobustChi2 of the estimate -> partial sums on the device (a sharded solve folds them and sums over the ranks,
+    // the stop votes ride along)
+    auto chi2_begin = [&](int store_cache) -> int {
+        sv_ba_chi2(ctx, s, D, 0, store_cache, 0);
         if (sharded) {
-            double v[2] = {sum, (double)(*flag ? 1 : 0)};
-            int r = allreduce_host(v, 2);
-            if (r) return r;
-            sum = v[0];
-            if (v[1] > 0.5) *flag = 1;
+            sv_ba_fold(s, D, d_sc, 0);
+            return allreduce_dev(d_sc, 4);
         }
-        *out = sum;
         return SVGPU_OK;
     };
 
-    double lambda = 0, last_chi = 0;
+    // one damping trial (preceded by the linearisation when the control block asks for one); everything is guarded by the control
+    // block on the device, so a step enqueued behind a finished optimisation costs a dozen empty launches
+    const int pcg_max_it = ctx->pcg_max_it > 0 ? ctx->pcg_max_it : 0;
+    auto enqueue_step = [&](bool* finished_seen) -> int {
+        int r;
+        sv_ba_linearize(ctx, s, D);
+        if (sharded && HS.nP > 0) {
+            SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
+            SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
+            if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP))) return r;
+        }
+        sv_ba_maxdiag(s, D);
+        if (sharded && (r = allreduce_dev(D.maxslots, (size_t)world))) return r;
+        sv_ba_prepare(s, D);
+        sv_ba_reduce(ctx, s, D);
+        if (HS.nP > 0 && (r = allreduce_dev(D.Sblk, 36 * (size_t)D.NB + (size_t)D.n))) return r;
+        if (HS.nP > 0) {
+            if (solver == SV_BA_SOLVER_CHOLESKY) sv_ba_solve(ctx, s, D);
+            else if (solver == SV_BA_SOLVER_DENSE) sv_ba_solve_dense(ctx, s, D);
+            else {
+                // PCG: iterations are enqueued in chunks; the control block says when the solve (or the whole optimisation) is over
+                sv_pcg_init(ctx, s, D);
+                int it0 = 0, chunk = 96;
+                for (;;) {
+                    sv_pcg_iterate(ctx, s, D, it0, chunk);
+                    it0 += chunk;
+                    if ((r = read_ctl())) return r;
+                    if (h_ctl->phase != 1) {
+                        *finished_seen = h_ctl->phase == 2;
+                        break;
+                    }
+                    if (h_ctl->pcg_done) break;
+                    chunk = std::min(chunk + chunk / 2, 768);
+                }
+            }
+        }
+        sv_ba_update(ctx, s, D);
+        sv_ba_chi2(ctx, s, D, 1, 0, 1);
+        if (sharded) {
+            sv_ba_fold(s, D, d_sc, 1);
+            if ((r = allreduce_dev(d_sc, 4))) return r;
+        }
+        sv_ba_decide(s, D);
+        return SVGPU_OK;
+    };
 
-    // SparseOptimizer::optimize(iterations) with the terminate_action hook
+    // SparseOptimizer::optimize(iterations) with the terminate_action hook; the Levenberg-Marquardt loop itself runs on the device
+    int pcg_mi = 0;
+    bool first_stage = true;
     auto optimize = [&](int iterations, int* iters_done) -> int {
         *iters_done = 0;
         int r = upload_structure();
         if (r) return r;
-        if (!sharded && HS.nP + HS.nL == 0) return SVGPU_OK;
-        bool ok = true;
-        double ni = 2;
-        double current_chi = 0;
-        for (int it = 0; it < iterations && ok; ++it) {
-            if (!sharded && *flag) break;
-            // activeRobustChi2 of the estimate.  After an accepted step it IS the trial's chi2 of the previous iteration (same
-            // state, same fixed-order sum), so only the first iteration -- and the sharded solve, whose call also
-            // OR-reduces the stop flags -- computes it again.
-            if (it == 0 || sharded) {
-                if ((r = chi2(0, 0, &current_chi))) return r;
-            }
-            if (*flag) break;  // sharded: the flag was just OR-reduced, every rank leaves together
-            sv_ba_linearize(ctx, s, D);
-            if (sharded && HS.nP > 0) {
-                SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
-                SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
-                if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP))) return r;
-            }
-            if (it == 0) {  // computeLambdaInit
-                SV_HIP(ctx, hipMemsetAsync(D.red + D.red_flag_off, 0, 16, s));
-                sv_ba_maxdiag(s, D);
-                double fl[2];
-                SV_HIP(ctx, hipMemcpyAsync(fl, D.red + D.red_flag_off, 16, hipMemcpyDeviceToHost, s));
-                SV_HIP(ctx, hipStreamSynchronize(s));
-                double max_diag = fl[1];
-                if (sharded) {  // max over ranks through a sum of one-hot slots
-                    std::vector<double> slots(world, 0.0);
-                    slots[rank] = max_diag;
-                    if ((r = allreduce_host(slots.data(), world))) return r;
-                    for (double v : slots) max_diag = std::max(max_diag, v);
-                }
-                lambda = 1e-5 * max_diag;
-                ni = 2;
-            }
-            double rho = 0;
-            int qmax = 0;
-            do {
-                D.lambda = lambda;
-                D.lambda_diag = (!sharded || rank == 0) ? lambda : 0.0;
-                SV_HIP(ctx, hipMemsetAsync(D.red + D.red_flag_off, 0, 8, s));
-                sv_ba_reduce(ctx, s, D);
-                if (HS.nP > 0 && (r = allreduce_dev(D.S, (size_t)(D.n + 1) * D.n))) return r;
-                sv_ba_solve(ctx, s, D);
-                if (E > 0) sv_ba_chi2(ctx, s, D, 1, 0);
-                SV_HIP(ctx, hipMemcpyAsync(red_host, D.red, 8 * (size_t)red_total, hipMemcpyDeviceToHost, s));
-                SV_HIP(ctx, hipStreamSynchronize(s));
-                double temp_chi = 0, scale = 0;
-                if (E > 0)
-                    for (int i = 0; i < nb_chi; ++i) temp_chi += red_host[D.red_chi_off + i];
-                for (int i = 0; i < nb_lm + nb_pose; ++i) scale += red_host[D.red_scale_off + i];
-                bool ok2 = red_host[D.red_flag_off] == 0.0;
-                if (trace) std::fprintf(stderr, "[ba]     chol cycles diag %.0f panel %.0f trail %.0f back %.0f\n", red_host[D.red_flag_off + 2], red_host[D.red_flag_off + 3], red_host[D.red_flag_off + 4], red_host[D.red_flag_off + 5]);
-                if (sharded) {
-                    double v[4] = {temp_chi, scale, ok2 ? 0.0 : 1.0, (double)(*flag ? 1 : 0)};
-                    if ((r = allreduce_host(v, 4))) return r;
-                    temp_chi = v[0];
-                    scale = v[1];
-                    ok2 = v[2] < 0.5;
-                    if (v[3] > 0.5) *flag = 1;
-                }
-                ++st.lm_trials;
-                if (!ok2) {
-                    temp_chi = DBL_MAX;
-                    ++st.cholesky_failures;
-                }
-                rho = current_chi - temp_chi;
-                scale += 1e-3;
-                rho /= scale;
-                if (rho > 0 && std::isfinite(temp_chi)) {
-                    double alpha = 1. - std::pow((2 * rho - 1), 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    lambda *= std::max(1. / 3., alpha);
-                    ni = 2;
-                    current_chi = temp_chi;
-                    std::swap(D.pose_cur, D.pose_trial);  // accept: the trial state becomes the estimate
-                    std::swap(D.pt_cur, D.pt_trial);
-                }
-                else {
-                    lambda *= ni;
-                    ni *= 2;
-                    if (!std::isfinite(lambda)) break;
-                }
-                ++qmax;
-            } while (rho < 0 && qmax < 10 && !*flag);
-            if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) ok = false;
-            ++*iters_done;
-            // postIteration: terminate_action (chi2 of the current estimate = current_chi)
-            if (it == 0) last_chi = current_chi;
-            else {
-                const double gain = (last_chi - current_chi) / current_chi;
-                last_chi = current_chi;
-                if (gain >= 0 && gain < pr->gain_threshold) {
-                    *flag = 1;
-                    st.stopped_by_terminate_action = 1;
-                }
-            }
+        const bool nothing = !sharded && HS.nP + HS.nL == 0;
+        // the PCG iteration cap depends on the size of the reduced system of this stage
+        pcg_mi = pcg_max_it > 0 ? pcg_max_it : std::max(2000, 4 * D.n);
+        SV_HIP(ctx, hipMemcpyAsync(&D.ctl->pcg_max_it, &pcg_mi, sizeof(int), hipMemcpyHostToDevice, s));
+        if ((r = chi2_begin(first_stage ? 1 : 0))) return r;
+        first_stage = false;
+        sv_ba_begin(s, D, nothing ? 0 : iterations, (int)(sharded ? 0 : (*flag ? 1 : 0)));
+        // The steps of the whole stage are enqueued before the first read-back (the common case -- every first trial accepted --
+        // costs ONE synchronisation per stage); rejected trials consume steps, so the loop tops up until the device reports phase 2.
+        const int max_steps = 10 * std::max(iterations, 1);
+        const bool trace2 = trace && std::getenv("SVGPU_BA_TRACE")[0] == '2';  // one step per read-back, printed
+        int steps = 0, todo = nothing ? 0 : (trace2 ? 1 : iterations);
+        for (;;) {
+            bool finished = false;
+            for (int k = 0; k < todo && !finished; ++k, ++steps)
+                if ((r = enqueue_step(&finished))) return r;
+            if ((r = read_ctl())) return r;
+            if (trace2) std::fprintf(stderr, "[ba]     step %3d: it %d phase %d chi2 %.9g temp %.9g lambda %.6g rho %.4g qmax %d pcg_it %d fail %d\n", steps, h_ctl->it, h_ctl->phase, h_ctl->current_chi, h_ctl->temp_chi, h_ctl->lambda, h_ctl->rho, h_ctl->qmax, h_ctl->pcg_it, h_ctl->solve_failures);
+            if (h_ctl->phase == 2 || steps >= max_steps) break;
+            todo = trace2 ? 1 : std::max(1, std::min(h_ctl->it_max - h_ctl->it, max_steps - steps));
         }
+        *iters_done = h_ctl->it;
         // errors cached by the last computeActiveErrors (used by the gate and the outlier list)
-        double dummy;
-        if (*iters_done > 0 && (r = chi2(0, 1, &dummy))) return r;
+        if (*iters_done > 0) sv_ba_chi2(ctx, s, D, 0, 1, 0);
+        if (h_ctl->stopped_by_terminate) {
+            *flag = 1;  // terminate_action writes through the optimizer's force-stop pointer
+            st.stopped_by_terminate_action = 1;
+        }
+        else if (h_ctl->stop) *flag = 1;  // sharded: another rank's caller raised it
         return SVGPU_OK;
     };
 
-    double chi0 = 0;
-    {
-        int r = upload_structure();
-        if (r) return r;
-        if ((r = chi2(0, 1, &chi0))) return r;
-    }
-    st.chi2_initial = chi0;
-    lap("structure + chi2_0");
-    if (sharded && stop && *stop) {  // the flag was OR-reduced inside chi2(): every rank returns together
-        if (stats) *stats = st;
-        return SVGPU_STOPPED;
-    }
+    st.chi2_initial = 0;
     int it1 = 0, it2 = 0;
     rc = optimize(pr->num_first_iter, &it1);
     if (rc) return rc;
+    st.chi2_initial = h_ctl->chi_begin;
     st.iters_stage1 = it1;
     lap("stage 1");
-    if (sharded) {  // agree on the caller flags before the stage-2 decision
-        double v[1] = {(double)((stop && *stop) ? 1 : 0)};
-        if ((rc = allreduce_host(v, 1))) return rc;
-        if (stop && v[0] > 0.5) *stop = 1;
+    if (sharded && stop && h_ctl->stop && it1 == 0 && !h_ctl->stopped_by_terminate) {  // raised before any work, agreed by all ranks
+        st.lm_trials = h_ctl->lm_trials;
+        if (stats) *stats = st;
+        return SVGPU_STOPPED;
     }
     bool run_robust = !single_stage;
-    if (stop && *stop) run_robust = false;  // :317-321 (only the CALLER's flag is consulted here)
+    if (stop && (sharded ? h_ctl->stop != 0 : *stop != 0)) run_robust = false;  // :317-321 (only the CALLER's flag is consulted here)
     if (run_robust) {
         st.stage2_entered = 1;
         if (E > 0) {
@@ -562,7 +674,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         }
         double gated = 0;
         for (int e = 0; e < E; ++e) gated += level[e];
-        if (sharded && (rc = allreduce_host(&gated, 1))) return rc;
+        if (sharded) {
+            xch_host[0] = gated;
+            if ((rc = allreduce_host(1))) return rc;
+            gated = xch_host[0];
+        }
         st.num_gated = (int32_t)gated;
         rc = optimize(pr->num_second_iter, &it2);
         if (rc) return rc;
@@ -575,32 +691,32 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         sv_ba_gate(s, D, 0, d_outlier);
         SV_HIP(ctx, hipMemcpyAsync(outl.data(), d_outlier, E, hipMemcpyDeviceToHost, s));
     }
-    SV_HIP(ctx, hipMemcpyAsync(pose_out, D.pose_cur, sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(points_out, D.pt_cur, sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToHost, s));
-    double chi1 = 0;
-    {
-        int r = chi2(0, 0, &chi1);
-        if (r) return r;
-    }
+    if ((rc = chi2_begin(0))) return rc;
+    sv_ba_begin(s, D, 0, 0);  // folds the chi2 of the final estimate into the control block (phase 2: nothing else happens)
+    if ((rc = read_ctl())) return rc;
+    const int cur = h_ctl->cur & 1;
+    SV_HIP(ctx, hipMemcpyAsync(pose_out, D.pose_buf[cur], sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(points_out, D.pt_buf[cur], sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
     if (sharded) {  // every rank ends with every landmark: owners contribute their points, the rest zeros
         for (int l = 0; l < L; ++l) {
             for (int k = 0; k < 3; ++k) xch_host[3 * (size_t)l + k] = owned[l] ? points_out[3 * (size_t)l + k] : 0.0;
             xch_host[3 * (size_t)L + l] = owned[l];
         }
-        H2D(d_xch, xch_host.data(), 8 * 4 * (size_t)L);
-        int r = allreduce_dev(d_xch, 4 * (size_t)L);
+        int r = allreduce_host(4 * (size_t)L);
         if (r) return r;
-        SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * 4 * (size_t)L, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipStreamSynchronize(s));
         for (int l = 0; l < L; ++l)
             if (xch_host[3 * (size_t)L + l] > 0.5)
                 for (int k = 0; k < 3; ++k) points_out[3 * (size_t)l + k] = xch_host[3 * (size_t)l + k];
     }
     if (outlier_out)
         for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
-    st.chi2_final = chi1;
+    st.chi2_final = h_ctl->chi_begin;
+    st.lm_trials = h_ctl->lm_trials;
+    st.cholesky_failures = h_ctl->solve_failures;
+    st.pcg_iterations = h_ctl->pcg_total_it;
     lap("read-back");
-    st.lambda_final = lambda;
+    st.lambda_final = h_ctl->lambda;
     if (stats) *stats = st;
 #undef H2D
     return SVGPU_OK;
@@ -678,8 +794,67 @@ int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile ui
 int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world, svgpu_allreduce_fn allreduce,
                            void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out,
                            uint8_t* outlier_out, svgpu_ba_stats* stats) {
-    if (!allreduce) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: allreduce callback is required");
+    if (!ctx) return SVGPU_ERR_INVALID;
+    if (!allreduce) {  // the context's own RCCL communicator (svgpu_comm_init)
+        if (!ctx->comm) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: no all-reduce callback and no communicator (svgpu_comm_init)");
+        if (rank != ctx->comm_rank || world != ctx->comm_world) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: rank / world differ from the communicator's");
+        allreduce = rccl_allreduce_cb;
+        allreduce_user = ctx;
+    }
     return local_ba_impl(ctx, shard, false, rank, world, allreduce, allreduce_user, stop, pose_out, points_out, outlier_out, stats);
+}
+
+int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world, svgpu_allreduce_fn allreduce,
+                            void* allreduce_user, volatile uint8_t* stop, double* pose_out, double* points_out, svgpu_ba_stats* stats) {
+    if (!ctx) return SVGPU_ERR_INVALID;
+    if (!allreduce) {
+        if (!ctx->comm) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_global_ba_sharded: no all-reduce callback and no communicator (svgpu_comm_init)");
+        if (rank != ctx->comm_rank || world != ctx->comm_world) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_global_ba_sharded: rank / world differ from the communicator's");
+        allreduce = rccl_allreduce_cb;
+        allreduce_user = ctx;
+    }
+    return local_ba_impl(ctx, shard, true, rank, world, allreduce, allreduce_user, stop, pose_out, points_out, nullptr, stats);
+}
+
+int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations) {
+    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || solver > SVGPU_BA_SOLVER_DENSE) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
+    ctx->ba_solver = solver;
+    ctx->pcg_tol = pcg_tolerance > 0 ? pcg_tolerance : 1e-10;
+    ctx->pcg_max_it = pcg_max_iterations > 0 ? pcg_max_iterations : 0;
+    return SVGPU_OK;
+}
+
+int svgpu_comm_unique_id(uint8_t* id128) {
+    if (!id128) return SVGPU_ERR_INVALID;
+    if (!rccl_ready()) return SVGPU_ERR_HIP;
+    NcclId id;
+    if (g_rccl.get_unique_id(&id) != 0) return SVGPU_ERR_HIP;
+    memcpy(id128, id.internal, 128);
+    return SVGPU_OK;
+}
+
+int svgpu_comm_init(svgpu_ctx* ctx, int rank, int world, const uint8_t* id128) {
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_comm_init: bad arguments");
+    if (!rccl_ready()) return sv_set_error(ctx, SVGPU_ERR_HIP, "svgpu_comm_init: librccl.so could not be loaded");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    sv_comm_release(ctx);
+    NcclId id;
+    memcpy(id.internal, id128, 128);
+    const int r = g_rccl.comm_init_rank(&ctx->comm, world, id, rank);
+    if (r != 0) {
+        ctx->comm = nullptr;
+        return sv_set_error(ctx, SVGPU_ERR_HIP, g_rccl.get_error_string ? g_rccl.get_error_string(r) : "ncclCommInitRank failed");
+    }
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return SVGPU_OK;
+}
+
+void svgpu_comm_destroy(svgpu_ctx* ctx) { sv_comm_release(ctx); }
+
+int svgpu_comm_allreduce_f64(svgpu_ctx* ctx, double* dev_buf, size_t count, void* stream) {
+    if (!ctx || !ctx->comm) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_comm_allreduce_f64: no communicator");
+    return rccl_allreduce_cb(ctx, dev_buf, count, stream ? stream : (void*)ctx->stream) == 0 ? SVGPU_OK : sv_set_error(ctx, SVGPU_ERR_HIP, "ncclAllReduce failed");
 }
 
 }  // extern "C"

@@ -124,6 +124,8 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    sv_comm_release(ctx);
+    if (ctx->ev_ba) (void)hipEventDestroy(ctx->ev_ba);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);

@@ -104,7 +104,15 @@ struct svgpu_ctx {
     double* h_pinned = nullptr;     // page-locked read-back buffer of the BA loops (small per-trial partial sums)
     size_t pinned_doubles = 0;
     size_t scratch_bytes = 0;
+    // bundle adjustment
+    hipEvent_t ev_ba = nullptr;     // completion event the BA host loop polls (while mirroring the caller's stop flag)
+    int ba_solver = 0;              // svgpu_ba_solver
+    double pcg_tol = 1e-10;         // relative residual of the reduced-system PCG
+    int pcg_max_it = 0;             // 0 = max(2000, 4 n)
+    void* comm = nullptr;           // ncclComm_t of svgpu_comm_init (RCCL, loaded with dlopen)
+    int comm_rank = 0, comm_world = 1;
 };
+void sv_comm_release(svgpu_ctx* ctx);
 
 int sv_set_error(svgpu_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
 void sv_prof_begin(svgpu_ctx* ctx, hipStream_t s, const char* name);

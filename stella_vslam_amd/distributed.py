@@ -50,11 +50,11 @@ class _CudaBuf:
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def make_allreduce_callback(group=None):
+def make_allreduce_callback(group=None, host_buffers: bool = False):
     """Returns (callback, keepalive): `callback` is a C function pointer of type svgpu_allreduce_fn that sums
     `count` doubles in place across the ranks of `group` with torch.distributed.all_reduce.
-    With the nccl backend the buffer is device memory and the collective is enqueued on the library's stream;
-    with gloo (CPU tests) the buffer is host memory."""
+    The buffer is always device memory.  With the nccl backend the collective is enqueued on the library's stream; with a
+    host-side backend (gloo) the payload is staged through the host."""
     import torch
     import torch.distributed as dist
 
@@ -65,10 +65,19 @@ def make_allreduce_callback(group=None):
                 ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
                 with torch.cuda.stream(ext):
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            else:
+            elif host_buffers:  # CPU-side plumbing tests only: the caller (not the library) passes host memory
                 a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
-                t = torch.from_numpy(a)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM, group=group)
+            else:
+                # the library always hands over DEVICE memory (svgpu.h): with a host-side backend (gloo: CPU-side tests of the
+                # multi-rank control flow on one GPU) the payload makes the round trip through the host, ordered on the stream
+                t = torch.as_tensor(_CudaBuf(buf, count), device="cuda")
+                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+                with torch.cuda.stream(ext):
+                    h = t.cpu()          # synchronises with `ext` (everything enqueued before the callback has finished)
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                    t.copy_(h)
+                    ext.synchronize()
             return 0
         except Exception as e:  # never let an exception cross the C boundary
             import sys
@@ -77,3 +86,22 @@ def make_allreduce_callback(group=None):
 
     cb = ALLREDUCE_FN(_cb)
     return cb, (cb, _cb)
+
+
+def init_comm(ctx, group=None) -> None:
+    """Create the context's own RCCL communicator (svgpu_comm_init): rank 0 draws the ncclUniqueId, torch.distributed (any
+    backend) only carries those 128 bytes to the other ranks.  Afterwards svgpu_local_ba_sharded / svgpu_global_ba_sharded
+    run with allreduce = NULL: RCCL calls on the library's stream, no Python in the damping loop."""
+    import torch
+    import torch.distributed as dist
+    from ._lib import lib
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ident = np.zeros(128, np.uint8)
+    if rank == 0:
+        ctx.check(lib().svgpu_comm_unique_id(C.c_void_p(ident.ctypes.data)), "svgpu_comm_unique_id")
+    t = torch.from_numpy(ident)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0, group=group)
+    ident = t.cpu().numpy().copy()
+    ctx.check(lib().svgpu_comm_init(ctx.handle, rank, world, C.c_void_p(ident.ctypes.data)), "svgpu_comm_init")

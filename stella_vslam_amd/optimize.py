@@ -28,7 +28,7 @@ class _BaStats(C.Structure):
     _fields_ = [("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("iters_stage1", C.c_int32),
                 ("iters_stage2", C.c_int32), ("stage2_entered", C.c_int32), ("num_gated", C.c_int32),
                 ("lm_trials", C.c_int32), ("cholesky_failures", C.c_int32), ("lambda_final", C.c_double),
-                ("stopped_by_terminate_action", C.c_int32), ("reserved", C.c_int32)]
+                ("stopped_by_terminate_action", C.c_int32), ("pcg_iterations", C.c_int32)]
 
 
 def local_bundle_adjuster_factory_create(backend: str = "hip", **kw):
@@ -38,11 +38,20 @@ def local_bundle_adjuster_factory_create(backend: str = "hip", **kw):
     return local_bundle_adjuster(**kw)
 
 
+SOLVER_AUTO, SOLVER_CHOLESKY, SOLVER_PCG, SOLVER_DENSE = 0, 1, 2, 3  # svgpu_ba_solver
+
+
 class local_bundle_adjuster:
     def __init__(self, num_first_iter: int = 5, num_second_iter: int = 10, ctx: Context | None = None):
         self.num_first_iter_ = num_first_iter
         self.num_second_iter_ = num_second_iter
         self.ctx = ctx or Context()
+
+    def set_solver(self, solver: int = SOLVER_AUTO, pcg_tolerance: float = 1e-10, pcg_max_iterations: int = 0):
+        """Linear solver of the reduced camera system (svgpu_ba_set_solver): on-chip LL^T / block-Jacobi PCG / rocSOLVER."""
+        self.ctx.check(lib().svgpu_ba_set_solver(self.ctx.handle, int(solver), C.c_double(pcg_tolerance), int(pcg_max_iterations)),
+                       "svgpu_ba_set_solver")
+        return self
 
     def optimize_global_flat(self, scene: dict, num_iter: int = 10, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
         """global_bundle_adjuster core: one LM run of `num_iter` iterations over the whole graph (no outlier stage)."""
@@ -53,11 +62,22 @@ class local_bundle_adjuster:
         finally:
             self.num_first_iter_ = saved
 
-    def optimize_flat_sharded(self, shard: dict, rank: int, world: int, allreduce_cb, force_stop_flag: np.ndarray | None = None,
+    def optimize_flat_sharded(self, shard: dict, rank: int, world: int, allreduce_cb=None, force_stop_flag: np.ndarray | None = None,
                               gain_threshold: float = 1e-3):
         """Multi-GPU variant: `shard` holds this rank's observations (distributed.shard_by_landmark) and the complete
-        pose / point arrays; `allreduce_cb` is a svgpu_allreduce_fn (distributed.make_allreduce_callback)."""
+        pose / point arrays; `allreduce_cb` is a svgpu_allreduce_fn (distributed.make_allreduce_callback) or None = the
+        context's own RCCL communicator (distributed.init_comm)."""
         return self.optimize_flat(shard, force_stop_flag, gain_threshold, _sharded=(rank, world, allreduce_cb))
+
+    def optimize_global_flat_sharded(self, shard: dict, rank: int, world: int, allreduce_cb=None, num_iter: int = 10,
+                                     force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
+        """svgpu_global_ba_sharded: the single-stage global-BA run over landmark shards."""
+        saved = self.num_first_iter_
+        self.num_first_iter_ = num_iter
+        try:
+            return self.optimize_flat(shard, force_stop_flag, gain_threshold, _sharded=(rank, world, allreduce_cb), _global=True)
+        finally:
+            self.num_first_iter_ = saved
 
     def optimize_flat(self, scene: dict, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3, _sharded=None,
                       _global=False):
@@ -79,7 +99,10 @@ class local_bundle_adjuster:
         st = _BaStats()
         stop = None if force_stop_flag is None else C.c_void_p(force_stop_flag.ctypes.data)
         outs = (C.c_void_p(pose_out.ctypes.data), C.c_void_p(pts_out.ctypes.data), C.c_void_p(outl.ctypes.data), C.byref(st))
-        if _global:
+        if _global and _sharded is not None:
+            rank, world, cb = _sharded
+            rc = lib().svgpu_global_ba_sharded(self.ctx.handle, C.byref(prob), rank, world, cb, None, stop, outs[0], outs[1], outs[3])
+        elif _global:
             rc = lib().svgpu_global_ba(self.ctx.handle, C.byref(prob), stop, outs[0], outs[1], outs[3])
         elif _sharded is None:
             rc = lib().svgpu_local_ba(self.ctx.handle, C.byref(prob), stop, *outs)

@@ -208,3 +208,93 @@ def ba_scene(num_kf: int = 20, num_lm: int = 10000, obs_per_lm: int = 6, num_fix
         obs_pose=np.array(obs_pose, np.int32), obs_point=np.array(obs_point, np.int32),
         obs_uvr=np.array(obs_uvr, np.float32), obs_inv_sigma_sq=inv_sigma_sq, obs_huber=huber, intr=intr,
     )
+
+
+def ba_scene_large(num_kf: int = 500, num_lm: int = 200000, obs_per_lm: int = 6, num_fixed: int = 1, seed: int = 5005,
+                   outlier_frac: float = 0.03, pose_noise=(0.02, 0.5), point_noise: float = 0.03, scale_factor: float = 1.2,
+                   num_levels: int = 8) -> dict:
+    """BASELINE config 5 (global BA): `num_kf` keyframes on a closed loop (radius 12 m, looking outward), `num_lm` landmarks in a
+    ring 4-8 m outside it, every landmark observed by a contiguous run of `obs_per_lm` of the cameras that see it inside a
+    752x480 image (covisibility is local, and the run may wrap around camera 0: the loop closure).  Same model, noise and
+    outputs as `ba_scene(loop=True)`, generated with array operations (the per-landmark Python loop of `ba_scene` needs minutes
+    at 200 k landmarks); its random stream differs, so the two generators do not produce the same scene for the same seed."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 458.654
+    cx, cy = 367.215, 248.375
+    W, H = 752, 480
+    radius = 12.0
+    ang = -np.pi + 2 * np.pi * (np.arange(num_kf) + 0.5) / num_kf
+    c = np.stack([radius * np.sin(ang), 0.05 * np.sin(3 * ang), -radius * np.cos(ang)], 1)
+    z = np.stack([np.sin(ang), np.zeros(num_kf), -np.cos(ang)], 1)
+    x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    Rs = np.stack([x, y, z], axis=1)                      # R_cw rows = camera axes in world coordinates
+    ts = -np.einsum("kij,kj->ki", Rs, c)
+
+    pts = np.empty((num_lm, 3))
+    cams = np.empty((num_lm, obs_per_lm), np.int64)
+    made = 0
+    half = np.arctan((W / 2 - 20) / fx)                   # cameras whose optical axis is within the half-FOV see the point
+    span = max(int(half / (2 * np.pi / num_kf)), obs_per_lm)
+    while made < num_lm:
+        m = int((num_lm - made) * 1.25) + 64
+        a = rng.uniform(-np.pi, np.pi, m)
+        r = radius + rng.uniform(4.0, 8.0, m)
+        p = np.stack([r * np.sin(a) + rng.uniform(-1, 1, m), rng.uniform(-1.5, 1.5, m), -r * np.cos(a) + rng.uniform(-1, 1, m)], 1)
+        centre = np.floor((np.arctan2(p[:, 0], -p[:, 2]) + np.pi) / (2 * np.pi) * num_kf).astype(np.int64)
+        # a run of obs_per_lm consecutive cameras starting anywhere in the window of cameras around the point's bearing; runs with a
+        # camera that does not see the point inside the image are drawn again
+        start = centre - span + (rng.uniform(0, 1, m) * (2 * span - obs_per_lm + 2)).astype(np.int64)
+        cand = (start[:, None] + np.arange(obs_per_lm)[None, :]) % num_kf
+        pc = np.einsum("mkij,mj->mki", Rs[cand], p) + ts[cand]
+        ok = pc[..., 2] > 0.5
+        zz = np.where(ok, pc[..., 2], 1.0)
+        u = fx * pc[..., 0] / zz + cx
+        v = fy * pc[..., 1] / zz + cy
+        ok &= (u > 20) & (u < W - 20) & (v > 20) & (v < H - 20)
+        idx = np.flatnonzero(ok.all(1))[: num_lm - made]
+        pts[made:made + len(idx)] = p[idx]
+        cams[made:made + len(idx)] = cand[idx]
+        made += len(idx)
+
+    obs_point = np.repeat(np.arange(num_lm, dtype=np.int32), obs_per_lm)
+    obs_pose = cams.reshape(-1).astype(np.int32)
+    E = len(obs_pose)
+    pc = np.einsum("eij,ej->ei", Rs[obs_pose], pts[obs_point]) + ts[obs_pose]
+    octv = rng.integers(0, num_levels, E)
+    sig = scale_factor ** octv
+    uu = fx * pc[:, 0] / pc[:, 2] + cx + rng.normal(0, 1.0, E) * sig
+    vv = fy * pc[:, 1] / pc[:, 2] + cy + rng.normal(0, 1.0, E) * sig
+    out = rng.uniform(0, 1, E) < outlier_frac
+    d = rng.uniform(20, 50, E)
+    th = rng.uniform(0, 2 * np.pi, E)
+    uu = uu + np.where(out, d * np.cos(th), 0.0)
+    vv = vv + np.where(out, d * np.sin(th), 0.0)
+    obs_uvr = np.stack([uu, vv, np.full(E, -1.0)], 1).astype(np.float32)
+
+    pose_gt = np.concatenate([Rs, ts[:, :, None]], axis=2).reshape(num_kf, 12)
+    fixed = np.zeros(num_kf, np.uint8)
+    fixed[:num_fixed] = 1
+    dw = rng.normal(0, 1, (num_kf, 3))
+    dw *= np.deg2rad(pose_noise[1]) / np.linalg.norm(dw, axis=1, keepdims=True)
+    cn = c + rng.normal(0, pose_noise[0] / np.sqrt(3), (num_kf, 3))
+    pose_init = pose_gt.copy()
+    for i in range(num_kf):
+        if fixed[i]:
+            continue
+        Rn = _rodrigues(dw[i]) @ Rs[i]
+        pose_init[i].reshape(3, 4)[:, :3] = Rn
+        pose_init[i].reshape(3, 4)[:, 3] = -Rn @ cn[i]
+    pts_init = pts + rng.normal(0, point_noise / np.sqrt(3), pts.shape)
+
+    sfac = np.float32(1.0)
+    table = [np.float32(1.0)]
+    for _ in range(1, num_levels):  # orb_params.cc:63-71 recurrence in fp32
+        sfac = np.float32(scale_factor) * sfac
+        table.append(np.float32(1.0) / (sfac * sfac))
+    inv_sigma_sq = np.array(table, np.float32)[octv]
+    huber = np.full(E, np.sqrt(np.float32(5.99146)), np.float32)
+    intr = np.tile(np.array([fx, fy, cx, cy, 0.0]), (num_kf, 1))
+    return dict(pose_cw=pose_init, pose_gt=pose_gt, pose_fixed=fixed, points=pts_init, points_gt=pts, obs_pose=obs_pose,
+                obs_point=obs_point, obs_uvr=obs_uvr, obs_inv_sigma_sq=inv_sigma_sq, obs_huber=huber, intr=intr)

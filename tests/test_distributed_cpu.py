@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
         dist.all_gather_object(allv, mine)
         assert sorted(sum(allv, [])) == list(range(11))
         # 3. the C-callable all-reduce sums host doubles in place (gloo path of the callback)
-        cb, keep = D.make_allreduce_callback()
+        cb, keep = D.make_allreduce_callback(host_buffers=True)
         buf = np.arange(5, dtype=np.float64) * (rank + 1)
         rc = cb(None, buf.ctypes.data, buf.size, None)
         assert rc == 0 and np.array_equal(buf, np.arange(5) * sum(range(1, world + 1)))

@@ -184,3 +184,26 @@ def test_pose_optimizer_oracle_equirectangular():
     nv, pose, outl, st = O.pose_optimize(sc["pose_cw"][1], pos_w, uvr, sc["obs_inv_sigma_sq"][sel], sc["obs_huber"][sel], sc["intr"][1])
     assert np.abs(pose - sc["pose_gt"][1]).max() < 0.1 * np.abs(sc["pose_cw"][1] - sc["pose_gt"][1]).max()
     assert nv == len(outl) - outl.sum() and 0.05 * len(outl) < outl.sum() < 0.2 * len(outl)
+
+
+def test_envelope_cholesky_is_bit_identical_to_dense():
+    """The oracle factors the reduced camera system inside each row's envelope (affordable at the 3000 x 3000 systems of the
+    global-BA configuration); it must produce the very bits of the plain dense loops."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    for n, band in ((60, 12), (180, 36), (96, 96)):
+        A = np.zeros((n, n))
+        for i in range(n):
+            for j in range(max(0, i - band), i + 1):
+                A[i, j] = A[j, i] = rng.normal()
+        A[n - 6:, :6] = rng.normal(size=(6, 6))  # loop-closure corner
+        A[:6, n - 6:] = A[n - 6:, :6].T
+        A[5, 3] = A[3, 5] = 0.0                  # a structural zero inside the envelope
+        A += np.eye(n) * (np.abs(A).sum(1).max() + 1.0)
+        b = rng.normal(size=n)
+        xe, xd = np.zeros(n), np.zeros(n)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        rc = O.lib().orc_chol_envelope_check(p(np.ascontiguousarray(A)), n, p(b), p(xe), p(xd))
+        assert rc == 0
+        assert np.array_equal(xe, xd)
+        assert np.allclose(A @ xe, b, rtol=1e-9, atol=1e-9)
