@@ -357,9 +357,10 @@ typedef struct svgpu_ba_stats {
 
 /* Linear solver of the reduced camera system (BlockSolver_6_3 + LinearSolverEigen / LinearSolverCSparse in the reference,
  * optimize/local_bundle_adjuster_g2o.cc:151-164, optimize/global_bundle_adjuster.cc:66-85):
- *   AUTO      on-chip dense LL^T up to 6 * free poses = 192, block-Jacobi PCG on the block-sparse system above
- *   CHOLESKY  force the on-chip LL^T (falls back to PCG when the system does not fit the LDS)
- *   PCG       force the PCG (also on small systems)
+ *   AUTO      dense LL^T in one workgroup's LDS while it fits (6 * free poses <= ~135), PCG above
+ *   PCG       block-Jacobi PCG on the block-sparse Schur complement: inside ONE workgroup (blocks, block rows, vectors all in
+ *             its LDS) while the kept 6x6 blocks fit ~150 KB and 6 * free poses <= 512, else one kernel launch per iteration
+ *   CHOLESKY  the LDS LL^T (larger systems fall back to PCG)
  *   DENSE     dense image + rocSOLVER dpotrf / dpotrs (loaded on first use)
  * pcg_tolerance: relative residual |r| / |g| (<= 0: 1e-10); pcg_max_iterations <= 0: max(2000, 4 n).  A solve that hits the
  * cap is taken as an inexact step when the residual fell below 1e-6, else the damping trial counts as a solver failure. */
@@ -367,7 +368,8 @@ typedef enum svgpu_ba_solver {
     SVGPU_BA_SOLVER_AUTO = 0,
     SVGPU_BA_SOLVER_CHOLESKY = 1,
     SVGPU_BA_SOLVER_PCG = 2,
-    SVGPU_BA_SOLVER_DENSE = 3
+    SVGPU_BA_SOLVER_DENSE = 3,
+    SVGPU_BA_SOLVER_PCG_MULTI = 4 /* PCG with one kernel launch per iteration even when the system would fit one workgroup's LDS */
 } svgpu_ba_solver;
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations);
 

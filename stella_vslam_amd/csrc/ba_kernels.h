@@ -54,13 +54,12 @@ struct BaDev {
     const int2* blk_ab;    // NB
     // linear system
     double* W;     // E x 18: Hpl block (6x3, row-major) of every edge with free pose and free landmark, else 0
-    double* Y;     // E x 18: W * Dinv
-    double* lp_part;     // P x LP_SPLIT x 27: partial pose blocks of k_ba_lin_pose
-    double* sc_part;     // NB x SCHUR_SPLIT x 36: partial blocks of k_ba_schur
-    double* GE;    // E x 6: Y * bl of the edge, written by k_ba_dinv
+    double* lp_part;     // nP x LIN_SPLIT x 27: partial pose blocks of k_ba_lin
+    double* sc_part;     // NB x nshare x 36: partial blocks of k_ba_schur_rhs
+    double* rhs_part;    // nP x RHS_SPLIT x 6: partial sums of W Hll^-1 bl
+    int nshare;          // shares per block of the reduced system (pairs per share ~200)
     double* Hll;   // L x 6 (xx xy xz yy yz zz)
     double* bl;    // L x 3
-    double* Dinv;  // L x 6
     double* Hpp;   // nP x 36
     double* bp;    // nP x 6
     double* Sblk;  // NB x 36: the kept upper blocks (a <= b) of the reduced camera system, row-major 6x6 each, in blk_ab order
@@ -110,9 +109,13 @@ struct PoseOptDev {
 };
 struct svgpu_ctx;
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P);
-void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
-void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Dinv/Y, Schur complement, right-hand side
-void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // reduced solve, back-substitution, trial state
+void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int do_prepare);
+void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Schur complement blocks + right-hand side
+void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // on-chip dense LL^T
+size_t sv_ba_pcg_lds_bytes(const BaDev& D);
+void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // PCG with the whole system in one workgroup's LDS
+int sv_ba_lin_split();
+int sv_ba_rhs_split();
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded);
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out);
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale);   // this rank's partial sums -> 4 doubles (sharded solve)
@@ -124,4 +127,4 @@ void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);               
 // block-Jacobi PCG on the block-sparse reduced camera system (ba_pcg.hip)
 void sv_pcg_init(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
 void sv_pcg_iterate(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int first_it, int count);
-enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, SV_BA_SOLVER_DENSE = 3 };
+enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, SV_BA_SOLVER_DENSE = 3, SV_BA_SOLVER_PCG_MULTI = 4, SV_BA_SOLVER_PCG_LDS = 5 /* internal */ };

@@ -189,137 +189,11 @@ __device__ __forceinline__ double group_sum8(double v) {
     for (int off = 1; off < LM_LANES; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-__global__ __launch_bounds__(256) void k_ba_lin_lm(BaDev D) {
-    if (D.ctl->phase != 0) return;
-    const double* pose_cur = st_pose(D, 0);
-    const double* pt_cur = st_pt(D, 0);
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
-    const bool in_range = t / LM_LANES < D.L;
-    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    const bool lfree = D.pt_free[l];
-    if (in_range)
-        for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
-            if (D.e_level[e]) continue;
-            const int slot = D.pose_slot[D.e_pose[e]];
-            if (!lfree && slot < 0) continue;
-            EdgeLin o;
-            edge_linearize(D, pose_cur, pt_cur, e, o);
-            if (lfree) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
-                    const double wr = -o.w * o.r[d];
-                    b[0] += a0 * wr;
-                    b[1] += a1 * wr;
-                    b[2] += a2 * wr;
-                    H[0] += a0 * o.w * a0;
-                    H[1] += a0 * o.w * a1;
-                    H[2] += a0 * o.w * a2;
-                    H[3] += a1 * o.w * a1;
-                    H[4] += a1 * o.w * a2;
-                    H[5] += a2 * o.w * a2;
-                }
-                if (slot >= 0) {
-                    double* Wd = D.W + (size_t)e * 18;
-#pragma unroll
-                    for (int i = 0; i < 6; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            Wd[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
-                }
-            }
-        }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) H[k] = group_sum8(H[k]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) b[k] = group_sum8(b[k]);
-    if (in_range && lfree && sub == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) D.Hll[(size_t)l * 6 + k] = H[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) D.bl[(size_t)l * 3 + k] = b[k];
-    }
-}
-
-// LP_SPLIT workgroups per free pose: each linearises a contiguous share of the pose's active edges and tree-reduces its 27
-// sums (21 of Hpp, 6 of bp) in a fixed order; k_ba_lin_pose_fin adds the LP_SPLIT partials in share order.
-#define LP_SPLIT 8
-#define LP_THREADS 512  // 1024 threads capped the kernel at 128 VGPRs: 240 bytes per lane went to scratch
-__global__ __launch_bounds__(LP_THREADS) void k_ba_lin_pose(BaDev D, double* __restrict__ part) {
-    if (D.ctl->phase != 0) return;
-    const double* pose_cur = st_pose(D, 0);
-    const double* pt_cur = st_pt(D, 0);
-    const int s = blockIdx.x, share = blockIdx.y;
-    double acc[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    const int lo = D.pe_off[s], n = D.pe_off[s + 1] - lo;
-    const int q0 = lo + (int)((long long)n * share / LP_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / LP_SPLIT);
-    for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
-        const int e = D.pe_idx[q];
-        if (D.e_level[e]) continue;  // lists are built once per call; excluded edges stay listed
-        EdgeLin o;
-        edge_linearize(D, pose_cur, pt_cur, e, o);
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int j = i; j < 6; ++j) {
-                acc[k] += o.B[i] * o.w * o.B[j] + o.B[6 + i] * o.w * o.B[6 + j] + o.B[12 + i] * o.w * o.B[12 + j];
-                ++k;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-            acc[21 + i] += o.B[i] * (-o.w * o.r[0]) + o.B[6 + i] * (-o.w * o.r[1]) + o.B[12 + i] * (-o.w * o.r[2]);
-    }
-    // fixed-order reduction: shuffles inside each wave, then the wave partials in wave order
-    __shared__ double s_w[16][27];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        const double t = wave_sum_d(acc[k]);
-        if (lane == 0) s_w[wave][k] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < 27) {
-        double t = 0.0;
-        for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
-        part[((size_t)s * LP_SPLIT + share) * 27 + threadIdx.x] = t;
-    }
-}
-// adds the LP_SPLIT partials of a pose in share order (a second launch is far cheaper than a device-scope fence per
-// workgroup: agent-scope release on gfx950 writes the XCD's L2 back)
-__global__ __launch_bounds__(64) void k_ba_lin_pose_fin(BaDev D, const double* __restrict__ part) {
-    if (D.ctl->phase != 0) return;
-    __shared__ double s_o[27];
-    const int s = blockIdx.x;
-    if (threadIdx.x < 27) {
-        double t = 0.0;
-        for (int h = 0; h < LP_SPLIT; ++h) t += part[((size_t)s * LP_SPLIT + h) * 27 + threadIdx.x];
-        s_o[threadIdx.x] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* H = D.Hpp + (size_t)s * 36;
-        int k = 0;
-        for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) {
-                H[6 * i + j] = s_o[k];
-                H[6 * j + i] = s_o[k];
-                ++k;
-            }
-        for (int i = 0; i < 6; ++i) D.bp[(size_t)s * 6 + i] = s_o[21 + i];
-    }
-}
-
 // max |diagonal| over all active vertices (computeLambdaInit); non-negative doubles order like their bit patterns
 __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
     if (D.ctl->phase != 0 || D.ctl->it != 0) return;  // computeLambdaInit: first iteration of an optimize() call only
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (the landmark part of the maximum is taken by k_ba_lin)
     double m = 0.0;
-    if (i < D.L && D.pt_free[i]) m = fmax(fabs(D.Hll[(size_t)i * 6]), fmax(fabs(D.Hll[(size_t)i * 6 + 3]), fabs(D.Hll[(size_t)i * 6 + 5])));
     if (i < D.nP)
         for (int j = 0; j < 6; ++j) m = fmax(m, fabs(D.Hpp_full[(size_t)i * 36 + 7 * j]));
 #pragma unroll
@@ -332,146 +206,6 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag(BaDev D) {
 __global__ void k_ba_maxslot(BaDev D) {
     const int r = threadIdx.x;
     if (r < D.world) D.maxslots[r] = (r == D.rank) ? __longlong_as_double((long long)D.ctl->max_diag_bits) : 0.0;
-}
-
-__global__ __launch_bounds__(256) void k_ba_dinv(BaDev D) {  // 8 lanes per landmark, as k_ba_lin_lm: every lane inverts, lane `sub` maps its edges
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int l = t / LM_LANES, sub = t % LM_LANES;
-    if (D.ctl->phase != 1 || l >= D.L || !D.pt_free[l]) return;
-    const double lambda = D.ctl->lambda;
-    const double* H = D.Hll + (size_t)l * 6;
-    const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e_ = H[4], f = H[5] + lambda;
-    const double c00 = d * f - e_ * e_, c01 = e_ * c - b * f, c02 = b * e_ - d * c;
-    const double det = a * c00 + b * c01 + c * c02;
-    double I[6];
-    if (det == 0.0 || !isfinite(det)) {
-        D.ctl->solve_failed = 1;  // benign race: any writer sets the same value
-#pragma unroll
-        for (int k = 0; k < 6; ++k) I[k] = 0.0;
-    }
-    else {
-        const double id = 1.0 / det;
-        I[0] = c00 * id;
-        I[1] = c01 * id;
-        I[2] = c02 * id;
-        I[3] = (a * f - c * c) * id;
-        I[4] = (b * c - a * e_) * id;
-        I[5] = (a * d - b * b) * id;
-    }
-    if (sub == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) D.Dinv[(size_t)l * 6 + k] = I[k];
-    }
-    for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
-        if (D.e_level[e] || D.pose_slot[D.e_pose[e]] < 0) continue;
-        const double* Wd = D.W + (size_t)e * 18;
-        double* Yd = D.Y + (size_t)e * 18;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double w0 = Wd[3 * i], w1 = Wd[3 * i + 1], w2 = Wd[3 * i + 2];
-            Yd[3 * i] = w0 * I[0] + w1 * I[1] + w2 * I[2];
-            Yd[3 * i + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
-            Yd[3 * i + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
-        }
-        const double* bl = D.bl + (size_t)l * 3;  // the edge's share of Hpl Hll^-1 bl, summed per pose by k_ba_rhs
-        double* ge = D.GE + (size_t)e * 6;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ge[i] = Yd[3 * i] * bl[0] + Yd[3 * i + 1] * bl[1] + Yd[3 * i + 2] * bl[2];
-    }
-}
-
-// one 512-thread workgroup per upper block (a <= b) of the reduced system:
-//   S_ab = [a==b](Hpp_a + lambda I) - sum over the block's (edge, edge) pairs of Y_i W_j^T
-// threads stride over the pairs, waves are tree-reduced with shuffles, the 8 wave partials are added in wave order
-#define SCHUR_THREADS 512
-#define SCHUR_SPLIT 4  // workgroups per block (few blocks, long pair lists): contiguous shares of the pair list, combined in
-                       // share order by k_ba_schur_fin; with thousands of blocks (global BA) one workgroup per block: gridDim.y = 1
-__global__ __launch_bounds__(SCHUR_THREADS) void k_ba_schur(BaDev D, double* __restrict__ part) {
-    if (D.ctl->phase != 1) return;
-    __shared__ double s_part[SCHUR_THREADS / 64][36];
-    const int blk = blockIdx.x, share = blockIdx.y;
-    const int nsplit = gridDim.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
-    const int q0 = lo + (int)((long long)np * share / nsplit), q1 = lo + (int)((long long)np * (share + 1) / nsplit);
-    for (int q = q0 + threadIdx.x; q < q1; q += SCHUR_THREADS) {
-        const int2 pr = D.blk_pairs[q];
-        const double2* Yd = reinterpret_cast<const double2*>(D.Y + (size_t)pr.x * 18);
-        const double2* Wd = reinterpret_cast<const double2*>(D.W + (size_t)pr.y * 18);
-        double y[18], w[18];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const double2 a = Yd[k], b = Wd[k];
-            y[2 * k] = a.x;
-            y[2 * k + 1] = a.y;
-            w[2 * k] = b.x;
-            w[2 * k + 1] = b.y;
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
-    }
-#pragma unroll
-    for (int k = 0; k < 36; ++k) {
-        const double t = wave_sum_d(acc[k]);
-        if (lane == 0) s_part[wave][k] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < 36) {
-        double sum = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < SCHUR_THREADS / 64; ++wv) sum += s_part[wv][threadIdx.x];
-        part[((size_t)blk * nsplit + share) * 36 + threadIdx.x] = sum;
-    }
-}
-// S_ab (row-major 6x6) -> Sblk[blk]: 256 threads finish 7 blocks (36 entries each) per workgroup
-__global__ __launch_bounds__(256) void k_ba_schur_fin(BaDev D, const double* __restrict__ part, int nsplit) {
-    if (D.ctl->phase != 1) return;
-    const int blk = blockIdx.x * 7 + threadIdx.x / 36, t = threadIdx.x % 36;
-    if (threadIdx.x < 252 && blk < D.NB) {
-        const int2 ab = D.blk_ab[blk];
-        const int i = t / 6, j = t - 6 * i;
-        double sum = 0.0;
-        for (int h = 0; h < nsplit; ++h) sum += part[((size_t)blk * nsplit + h) * 36 + t];
-        double v = -sum;
-        if (ab.x == ab.y) {
-            v += D.Hpp[(size_t)ab.x * 36 + t];
-            if (i == j && D.add_lambda) v += D.ctl->lambda;
-        }
-        D.Sblk[(size_t)blk * 36 + t] = v;
-    }
-}
-
-// workgroup per free pose: g_a = bp_a - sum_e Y_e bl_l(e)  -> row n of S
-__global__ __launch_bounds__(1024) void k_ba_rhs(BaDev D) {
-    if (D.ctl->phase != 1) return;
-    const int s = blockIdx.x;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = D.pe_off[s] + threadIdx.x; q < D.pe_off[s + 1]; q += blockDim.x) {
-        const int e = D.pe_idx[q];
-        const int l = D.e_point[e];
-        if (!D.pt_free[l] || D.e_level[e]) continue;
-        const double* ge = D.GE + (size_t)e * 6;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] += ge[i];
-    }
-    __shared__ double s_w[16][6];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double t = wave_sum_d(acc[i]);
-        if (lane == 0) s_w[wave][i] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        double t = 0.0;
-        for (int wv = 0; wv < nw; ++wv) t += s_w[wv][threadIdx.x];
-        D.g[6 * s + threadIdx.x] = D.bp[(size_t)s * 6 + threadIdx.x] - t;
-    }
 }
 
 // Dense LL^T of the reduced system with the right-hand side carried as row n, then L^T x = y.
@@ -744,122 +478,6 @@ __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
         __syncthreads();
     }
     for (int i = tid; i < n; i += nt) D.dp[i] = A[(size_t)n * ld + i];
-}
-
-// thread per landmark: dl = Dinv (bl - sum W^T dp), trial point, partial of delta^T(lambda delta + b)
-__global__ __launch_bounds__(256) void k_ba_update_lm(BaDev D) {  // 8 lanes per landmark (32 landmarks per workgroup), as k_ba_lin_lm
-    __shared__ double s4[16];
-    if (D.ctl->phase != 1) return;
-    const double lambda = D.ctl->lambda;
-    const double* pt_cur = st_pt(D, 0);
-    double* pt_trial = const_cast<double*>(st_pt(D, 1));
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
-    const bool in_range = t / LM_LANES < D.L;
-    double sc = 0.0;
-    const bool lfree = in_range && D.pt_free[l];
-    double c[3] = {0.0, 0.0, 0.0};
-    if (lfree)
-        for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
-            if (D.e_level[e]) continue;
-            const int slot = D.pose_slot[D.e_pose[e]];
-            if (slot < 0) continue;
-            const double* Wd = D.W + (size_t)e * 18;
-            const double* x = D.dp + (size_t)slot * 6;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                c[0] -= Wd[3 * i] * x[i];
-                c[1] -= Wd[3 * i + 1] * x[i];
-                c[2] -= Wd[3 * i + 2] * x[i];
-            }
-        }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
-    if (in_range && sub == 0) {
-        double X[3] = {pt_cur[(size_t)l * 3], pt_cur[(size_t)l * 3 + 1], pt_cur[(size_t)l * 3 + 2]};
-        if (lfree) {
-            const double* b = D.bl + (size_t)l * 3;
-            c[0] += b[0];
-            c[1] += b[1];
-            c[2] += b[2];
-            const double* I = D.Dinv + (size_t)l * 6;
-            const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
-            const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
-            const double d2 = I[2] * c[0] + I[4] * c[1] + I[5] * c[2];
-            X[0] += d0;
-            X[1] += d1;
-            X[2] += d2;
-            sc = d0 * (lambda * d0 + b[0]) + d1 * (lambda * d1 + b[1]) + d2 * (lambda * d2 + b[2]);
-        }
-        pt_trial[(size_t)l * 3] = X[0];
-        pt_trial[(size_t)l * 3 + 1] = X[1];
-        pt_trial[(size_t)l * 3 + 2] = X[2];
-    }
-    const double tsum = block_sum_d(sc, s4);
-    if (threadIdx.x == 0) D.red[D.red_scale_off + blockIdx.x] = tsum;
-}
-
-// thread per pose: trial = exp(dp) * cur (g2o SE3Quat::exp, shot_vertex.h:55-58)
-__global__ __launch_bounds__(256) void k_ba_update_pose(BaDev D, int scale_slot0) {
-    __shared__ double s4[16];
-    if (D.ctl->phase != 1) return;
-    const double lambda = D.ctl->lambda;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    double sc = 0.0;
-    if (p < D.P) {
-        const double* T = st_pose(D, 0) + (size_t)p * 12;
-        double* O = const_cast<double*>(st_pose(D, 1)) + (size_t)p * 12;
-        const int slot = D.pose_slot[p];
-        if (slot < 0) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) O[k] = T[k];
-        }
-        else {
-            const double* u = D.dp + (size_t)slot * 6;
-            const double* bpv = D.bp_full + (size_t)slot * 6;
-            if (D.scale_pose)
-#pragma unroll
-                for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpv[k]);
-            const double wx = u[0], wy = u[1], wz = u[2];
-            const double theta = sqrt(wx * wx + wy * wy + wz * wz);
-            const double Om[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-            double O2[9];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) O2[3 * i + j] = Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j] + Om[3 * i + 2] * Om[6 + j];
-            double a, b, c, d;
-            if (theta < 0.00001) {
-                a = 1.0;
-                b = 0.5;
-                c = 0.5;
-                d = 1.0 / 6.0;
-            }
-            else {
-                const double st = sin(theta), ct = cos(theta);
-                a = st / theta;
-                b = (1 - ct) / (theta * theta);
-                c = b;
-                d = (theta - st) / (theta * theta * theta);
-            }
-            double R[9], V[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double I = (k % 4 == 0) ? 1.0 : 0.0;
-                R[k] = I + a * Om[k] + b * O2[k];
-                V[k] = I + c * Om[k] + d * O2[k];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) O[4 * i + j] = R[3 * i] * T[j] + R[3 * i + 1] * T[4 + j] + R[3 * i + 2] * T[8 + j];
-                O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + V[3 * i] * u[3] + V[3 * i + 1] * u[4]
-                               + V[3 * i + 2] * u[5];
-            }
-        }
-    }
-    const double t = block_sum_d(sc, s4);
-    if (threadIdx.x == 0) D.red[D.red_scale_off + scale_slot0 + blockIdx.x] = t;
 }
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -1159,6 +777,547 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     }
 }
 
+// ================================================================================================ fused trial pipeline
+// One damping trial = k_ba_lin (+ k_ba_lin_fin) when a linearisation is due, then k_ba_schur_rhs, k_ba_sys_fin, the solver,
+// k_ba_update, k_ba_chi2, k_ba_decide: 8 launches instead of 14 (a launch of a trivial kernel costs ~4.7 us on this part when
+// its first instruction depends on a word the previous kernel wrote).  Y = W Hll^-1 and Y bl are no longer materialised
+// (E x 192 bytes per trial): the 3x3 inverse is recomputed where it is used.
+
+// 64-lane sum of a double with DPP row scans (VALU only; __shfl_xor on a double is two ds_bpermute round trips per step).
+// Fixed order => bit-reproducible.  The total is returned in every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_d<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_d<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_d<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_d<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_d<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_d<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// (Hll + lambda I)^-1 of a landmark, 6 unique entries; all zero (and *ok = false) when the block is singular
+__device__ __forceinline__ bool lm_dinv(const double* __restrict__ H, double lambda, double* I) {
+    const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e_ = H[4], f = H[5] + lambda;
+    const double c00 = d * f - e_ * e_, c01 = e_ * c - b * f, c02 = b * e_ - d * c;
+    const double det = a * c00 + b * c01 + c * c02;
+    if (det == 0.0 || !isfinite(det)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) I[k] = 0.0;
+        return false;
+    }
+    const double id = 1.0 / det;
+    I[0] = c00 * id;
+    I[1] = c01 * id;
+    I[2] = c02 * id;
+    I[3] = (a * f - c * c) * id;
+    I[4] = (b * c - a * e_) * id;
+    I[5] = (a * d - b * b) * id;
+    return true;
+}
+
+// linearisation: blocks [0, nb_lm) = landmark side (Hll, bl, W; 8 lanes per landmark), the rest = pose side (LIN_SPLIT
+// workgroups per free pose, partial Hpp / bp)
+#define LIN_SPLIT 16
+__global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
+    if (D.ctl->phase != 0) return;
+    const double* pose_cur = st_pose(D, 0);
+    const double* pt_cur = st_pt(D, 0);
+    if ((int)blockIdx.x < nb_lm) {
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
+        const bool in_range = t / LM_LANES < D.L;
+        double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+        const bool lfree = D.pt_free[l];
+        if (in_range)
+            for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
+                if (D.e_level[e]) continue;
+                const int slot = D.pose_slot[D.e_pose[e]];
+                if (!lfree && slot < 0) continue;
+                EdgeLin o;
+                edge_linearize(D, pose_cur, pt_cur, e, o);
+                if (lfree) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
+                        const double wr = -o.w * o.r[d];
+                        b[0] += a0 * wr;
+                        b[1] += a1 * wr;
+                        b[2] += a2 * wr;
+                        H[0] += a0 * o.w * a0;
+                        H[1] += a0 * o.w * a1;
+                        H[2] += a0 * o.w * a2;
+                        H[3] += a1 * o.w * a1;
+                        H[4] += a1 * o.w * a2;
+                        H[5] += a2 * o.w * a2;
+                    }
+                    if (slot >= 0) {
+                        double* Wd = D.W + (size_t)e * 18;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                Wd[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
+                    }
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H[k] = group_sum8(H[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b[k] = group_sum8(b[k]);
+        double m = 0.0;
+        if (in_range && lfree && sub == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) D.Hll[(size_t)l * 6 + k] = H[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) D.bl[(size_t)l * 3 + k] = b[k];
+            m = fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5])));
+        }
+        if (D.ctl->it == 0) {  // computeLambdaInit: the landmark part of max |diagonal| (uniform branch)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+            if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(&D.ctl->max_diag_bits, (unsigned long long)__double_as_longlong(m));
+        }
+        return;
+    }
+    const int u = blockIdx.x - nb_lm, s = u / LIN_SPLIT, share = u - s * LIN_SPLIT;
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    const int lo = D.pe_off[s], n = D.pe_off[s + 1] - lo;
+    const int q0 = lo + (int)((long long)n * share / LIN_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / LIN_SPLIT);
+    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+        const int e = D.pe_idx[q];
+        if (D.e_level[e]) continue;  // lists are built once per call; excluded edges stay listed
+        EdgeLin o;
+        edge_linearize(D, pose_cur, pt_cur, e, o);
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = i; j < 6; ++j) {
+                acc[k] += o.B[i] * o.w * o.B[j] + o.B[6 + i] * o.w * o.B[6 + j] + o.B[12 + i] * o.w * o.B[12 + j];
+                ++k;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            acc[21 + i] += o.B[i] * (-o.w * o.r[0]) + o.B[6 + i] * (-o.w * o.r[1]) + o.B[12 + i] * (-o.w * o.r[2]);
+    }
+    __shared__ double s_w[4][27];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const double t = wave_sum_dpp(acc[k]);
+        if (lane == 0) s_w[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) D.lp_part[((size_t)s * LIN_SPLIT + share) * 27 + threadIdx.x] = ((s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + s_w[2][threadIdx.x]) + s_w[3][threadIdx.x];
+}
+
+// one workgroup: pose blocks from their LIN_SPLIT partials (share order), then -- unless the pose blocks still have to be summed
+// over the ranks of a sharded solve -- the pose part of computeLambdaInit and the start-of-trial bookkeeping (k_ba_prepare)
+__device__ __forceinline__ void ctl_prepare(BaDev& D, double max_diag) {
+    BaCtl& c = *D.ctl;
+    if (c.phase == 0) {
+        if (c.it == 0) {
+            c.lambda = 1e-5 * max_diag;
+            c.ni = 2.0;
+        }
+        c.qmax = 0;
+        c.rho = 0.0;
+        c.phase = 1;
+    }
+    c.solve_failed = 0;
+    c.pcg_done = 0;
+    c.pcg_fail = 0;
+    c.pcg_it = 0;
+}
+__global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare) {
+    const int phase = D.ctl->phase;
+    if (phase == 2) return;
+    __shared__ double s_m[4];
+    double m = 0.0;
+    if (phase == 0) {
+        for (int item = threadIdx.x; item < D.nP * 27; item += 256) {
+            const int s = item / 27, k = item - 27 * s;
+            double t = 0.0;
+            for (int h = 0; h < LIN_SPLIT; ++h) t += D.lp_part[((size_t)s * LIN_SPLIT + h) * 27 + k];
+            if (k < 21) {
+                int i = 0, base = 0;  // k -> (i, j), i <= j, rows of 6, 5, 4, ... entries
+                while (k >= base + (6 - i)) {
+                    base += 6 - i;
+                    ++i;
+                }
+                const int j = i + (k - base);
+                D.Hpp[(size_t)s * 36 + 6 * i + j] = t;
+                D.Hpp[(size_t)s * 36 + 6 * j + i] = t;
+                if (i == j) m = fmax(m, fabs(t));
+            }
+            else D.bp[(size_t)s * 6 + (k - 21)] = t;
+        }
+    }
+    if (!do_prepare) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+        m = fmax(m, __longlong_as_double((long long)D.ctl->max_diag_bits));
+        ctl_prepare(D, m);
+    }
+}
+
+// Reduced camera system, one WAVE per work unit (4 units per workgroup, no workgroup barrier):
+//   units [0, NB * nshare)        share `sh` of block (a, b): sum over its (edge, edge) pairs of W_i Hll^-1 W_j^T -> sc_part
+//   units [.., + nP * RHS_SPLIT)  share of a pose's edges: sum of W_e Hll^-1 bl -> rhs_part
+// A lane walks several pairs and the 36 (6) sums are reduced once per wave: with one pair per thread the 36 shuffle reductions
+// cost more than the 162 multiply-adds of the pair.
+#define RHS_SPLIT 16
+__global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, double* __restrict__ rhs_part) {
+    if (D.ctl->phase != 1) return;
+    const double lambda = D.ctl->lambda;
+    const int lane = threadIdx.x & 63, unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_schur = D.NB * nshare;
+    if (unit < n_schur) {
+        const int blk = unit / nshare, share = unit - blk * nshare;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+        const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
+        const int q0 = lo + (int)((long long)np * share / nshare), q1 = lo + (int)((long long)np * (share + 1) / nshare);
+        for (int q = q0 + lane; q < q1; q += 64) {
+            const int2 pr = D.blk_pairs[q];
+            const int l = D.e_point[pr.x];
+            double I[6];
+            lm_dinv(D.Hll + (size_t)l * 6, lambda, I);
+            const double2* Wi = reinterpret_cast<const double2*>(D.W + (size_t)pr.x * 18);
+            const double2* Wj = reinterpret_cast<const double2*>(D.W + (size_t)pr.y * 18);
+            double wi[18], w[18], y[18];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double2 a = Wi[k], b = Wj[k];
+                wi[2 * k] = a.x;
+                wi[2 * k + 1] = a.y;
+                w[2 * k] = b.x;
+                w[2 * k + 1] = b.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double w0 = wi[3 * i], w1 = wi[3 * i + 1], w2 = wi[3 * i + 2];
+                y[3 * i] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+                y[3 * i + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+                y[3 * i + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
+        }
+        double mine = 0.0;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {
+            const double t = wave_sum_dpp(acc[k]);
+            mine = (lane == k) ? t : mine;
+        }
+        if (lane < 36) D.sc_part[(size_t)unit * 36 + lane] = mine;
+        return;
+    }
+    const int ru = unit - n_schur;
+    if (ru >= D.nP * RHS_SPLIT) return;
+    const int s = ru / RHS_SPLIT, share = ru - s * RHS_SPLIT;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int lo = D.pe_off[s], n = D.pe_off[s + 1] - lo;
+    const int q0 = lo + (int)((long long)n * share / RHS_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / RHS_SPLIT);
+    for (int q = q0 + lane; q < q1; q += 64) {
+        const int e = D.pe_idx[q];
+        const int l = D.e_point[e];
+        if (!D.pt_free[l] || D.e_level[e]) continue;
+        double I[6];
+        lm_dinv(D.Hll + (size_t)l * 6, lambda, I);
+        const double* bl = D.bl + (size_t)l * 3;
+        const double d0 = I[0] * bl[0] + I[1] * bl[1] + I[2] * bl[2];
+        const double d1 = I[1] * bl[0] + I[3] * bl[1] + I[4] * bl[2];
+        const double d2 = I[2] * bl[0] + I[4] * bl[1] + I[5] * bl[2];
+        const double* Wd = D.W + (size_t)e * 18;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] += Wd[3 * i] * d0 + Wd[3 * i + 1] * d1 + Wd[3 * i + 2] * d2;
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double t = wave_sum_dpp(acc[k]);
+        mine = (lane == k) ? t : mine;
+    }
+    if (lane < 6) rhs_part[(size_t)ru * 6 + lane] = mine;
+}
+
+// kept blocks S_ab = [a == b](Hpp_a + lambda I) - sum of the shares, right-hand side g_a = bp_a - sum of the shares
+__global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const double* __restrict__ rhs_part) {
+    if (D.ctl->phase != 1) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < D.NB * 36) {
+        const int blk = k / 36, t = k - 36 * blk;
+        double sum = 0.0;
+        for (int h = 0; h < nshare; ++h) sum += D.sc_part[((size_t)blk * nshare + h) * 36 + t];
+        const int2 ab = D.blk_ab[blk];
+        double v = -sum;
+        if (ab.x == ab.y) {
+            v += D.Hpp[(size_t)ab.x * 36 + t];
+            if (t % 7 == 0 && D.add_lambda) v += D.ctl->lambda;
+        }
+        D.Sblk[k] = v;
+    }
+    else if (k - D.NB * 36 < D.n) {
+        const int r = k - D.NB * 36;
+        const int s = r / 6, i = r - 6 * s;
+        double sum = 0.0;
+        for (int h = 0; h < RHS_SPLIT; ++h) sum += rhs_part[((size_t)s * RHS_SPLIT + h) * 6 + i];
+        D.g[r] = D.bp[r] - sum;
+    }
+}
+
+// Block-Jacobi preconditioned conjugate gradients on the reduced camera system with EVERYTHING in the LDS of one workgroup: the
+// kept 6x6 blocks (36 doubles each), the block-row lists, the inverse diagonal blocks and the five vectors.  A local-BA system
+// (6 * free keyframes <= a few hundred unknowns, <= ~450 blocks) converges to 1e-10 in a few dozen iterations of ~0.4 us each;
+// the dense LL^T this replaces (k_ba_chol_lds) spent 70 us per trial in 12 barrier-separated panel steps.
+// Dynamic LDS layout (doubles): blk[36 NB] | Minv[36 nP] | x r z p q [5 n] | part[6 nent] | wsum[48]; then ints: rowoff[nP + 1], ent[2 nent]
+#define PL_THREADS 512
+__global__ __launch_bounds__(PL_THREADS) void k_ba_pcg_lds(BaDev D, int nent) {
+    if (D.ctl->phase != 1) return;
+    extern __shared__ double s_d[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = D.n, nP = D.nP, NB = D.NB;
+    double* blk = s_d;
+    double* Minv = blk + 36 * NB;
+    double* x = Minv + 36 * nP;
+    double* r = x + n;
+    double* z = r + n;
+    double* p = z + n;
+    double* q = p + n;
+    double* part = q + n;
+    double* wsum = part + 6 * nent;
+    int* rowoff = reinterpret_cast<int*>(wsum + 48);
+    int2* ent = reinterpret_cast<int2*>(rowoff + ((nP + 2) & ~1));
+    __shared__ int s_bad;
+    for (int k = tid; k < 36 * NB; k += PL_THREADS) blk[k] = D.Sblk[k];
+    for (int k = tid; k <= nP; k += PL_THREADS) rowoff[k] = D.prow_off[k];
+    for (int k = tid; k < nent; k += PL_THREADS) ent[k] = D.prow_ent[k];
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    // inverse diagonal blocks (thread per block row: LL^T, L^-1, L^-T L^-1)
+    if (tid < nP) {
+        const double* B = blk + 36 * D.diag_blk[tid];
+        double L[36], X[36];
+        bool bad = false;
+        for (int j = 0; j < 6; ++j) {
+            double d = B[7 * j];
+            for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+            if (!(d > 0.0)) {
+                bad = true;
+                d = 1.0;
+            }
+            d = sqrt(d);
+            L[7 * j] = d;
+            for (int i = j + 1; i < 6; ++i) {
+                double sum = B[6 * j + i];
+                for (int k = 0; k < j; ++k) sum -= L[6 * i + k] * L[6 * j + k];
+                L[6 * i + j] = sum / d;
+            }
+        }
+        for (int c = 0; c < 6; ++c)
+            for (int i = 0; i < 6; ++i) {
+                double sum = (i == c) ? 1.0 : 0.0;
+                for (int k = c; k < i; ++k) sum -= L[6 * i + k] * X[6 * k + c];
+                X[6 * i + c] = (i >= c) ? sum / L[7 * i] : 0.0;
+            }
+        double* M = Minv + 36 * tid;
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) {
+                double sum = 0.0;
+                for (int k = (i > j ? i : j); k < 6; ++k) sum += X[6 * k + i] * X[6 * k + j];
+                M[6 * i + j] = sum;
+            }
+        if (bad) s_bad = 1;
+    }
+    if (tid < n) {
+        x[tid] = 0.0;
+        r[tid] = D.g[tid];
+    }
+    __syncthreads();
+    // fixed-order block-wide sum of one value per thread; result in every thread
+    auto bsum = [&](double v, int slot) -> double {
+        const double t = wave_sum_dpp(v);
+        if (lane == 0) wsum[slot * 8 + wave] = t;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < PL_THREADS / 64; ++w) tot += wsum[slot * 8 + w];
+        return tot;
+    };
+    auto precond = [&](int row) -> double {  // z_row = sum_j Minv[a][i][j] r[6 a + j]
+        const int a = row / 6, i = row - 6 * a;
+        const double* M = Minv + 36 * a + 6 * i;
+        const double* ra = r + 6 * a;
+        return M[0] * ra[0] + M[1] * ra[1] + M[2] * ra[2] + M[3] * ra[3] + M[4] * ra[4] + M[5] * ra[5];
+    };
+    double zi = 0.0, ri = 0.0;
+    if (tid < n) {
+        ri = r[tid];
+        zi = precond(tid);
+        z[tid] = zi;
+        p[tid] = zi;
+    }
+    double rz = bsum(ri * zi, 0);
+    const double rr0 = bsum(ri * ri, 1);
+    const double tol2 = D.ctl->pcg_tol2;
+    const int max_it = D.ctl->pcg_max_it;
+    int it = 0, fail = s_bad ? 1 : 0;
+    double rr = rr0;
+    __syncthreads();
+    while (!fail && rr > tol2 * rr0 && it < max_it) {
+        // q = S p: one task per (row entry, component), then the entries of a row in list order
+        for (int t = tid; t < 6 * nent; t += PL_THREADS) {
+            const int e = t / 6, i = t - 6 * e;
+            const int2 en = ent[e];
+            const double* B = blk + 36 * (en.x & 0x3fffffff);
+            const double* pb = p + 6 * en.y;
+            double v;
+            if (en.x >> 30 & 1) v = B[i] * pb[0] + B[6 + i] * pb[1] + B[12 + i] * pb[2] + B[18 + i] * pb[3] + B[24 + i] * pb[4] + B[30 + i] * pb[5];
+            else v = B[6 * i] * pb[0] + B[6 * i + 1] * pb[1] + B[6 * i + 2] * pb[2] + B[6 * i + 3] * pb[3] + B[6 * i + 4] * pb[4] + B[6 * i + 5] * pb[5];
+            part[t] = v;
+        }
+        __syncthreads();
+        double qi = 0.0, pi = 0.0;
+        if (tid < n) {
+            const int a = tid / 6, i = tid - 6 * a;
+            for (int e = rowoff[a]; e < rowoff[a + 1]; ++e) qi += part[6 * e + i];
+            pi = p[tid];
+        }
+        const double pq = bsum(pi * qi, 2);
+        if (!(pq > 0.0) || !isfinite(pq)) {  // not positive definite / NaN input (uniform)
+            fail = 1;
+            break;
+        }
+        const double alpha = rz / pq;
+        if (tid < n) {
+            x[tid] += alpha * pi;
+            ri = r[tid] - alpha * qi;
+            r[tid] = ri;
+        }
+        __syncthreads();
+        if (tid < n) {
+            zi = precond(tid);
+            z[tid] = zi;
+        }
+        const double rz_new = bsum(tid < n ? ri * zi : 0.0, 3);
+        rr = bsum(tid < n ? ri * ri : 0.0, 4);
+        const double beta = rz_new / rz;
+        rz = rz_new;
+        if (tid < n) p[tid] = zi + beta * pi;
+        ++it;
+        __syncthreads();
+    }
+    if (tid < n) D.dp[tid] = fail ? 0.0 : x[tid];
+    if (tid == 0) {
+        BaCtl& c = *D.ctl;
+        c.pcg_it = it;
+        c.pcg_total_it += it;
+        c.pcg_solves += 1;
+        c.pcg_done = it + 1;
+        if (fail) {
+            c.pcg_fail = 1;
+            c.solve_failed = 1;
+        }
+        else if (rr > tol2 * rr0) {  // iteration cap: an inexact step is acceptable when the residual fell by 1e-6
+            c.pcg_fail = 2;
+            if (!(rr <= 1e-12 * rr0)) c.solve_failed = 1;
+        }
+    }
+}
+
+// back-substitution and trial state: blocks [0, nb_lm) = landmarks (8 lanes each), the rest = poses
+__global__ __launch_bounds__(256) void k_ba_update(BaDev D, int nb_lm) {
+    if (D.ctl->phase != 1) return;
+    __shared__ double s4[16];
+    const double lambda = D.ctl->lambda;
+    double sc = 0.0;
+    if ((int)blockIdx.x < nb_lm) {
+        const double* pt_cur = st_pt(D, 0);
+        double* pt_trial = const_cast<double*>(st_pt(D, 1));
+        const int t = blockIdx.x * 256 + threadIdx.x;
+        const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
+        const bool in_range = t / LM_LANES < D.L;
+        const bool lfree = in_range && D.pt_free[l];
+        double c[3] = {0.0, 0.0, 0.0};
+        if (lfree)
+            for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
+                if (D.e_level[e]) continue;
+                const int slot = D.pose_slot[D.e_pose[e]];
+                if (slot < 0) continue;
+                const double* Wd = D.W + (size_t)e * 18;
+                const double* xp = D.dp + (size_t)slot * 6;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    c[0] -= Wd[3 * i] * xp[i];
+                    c[1] -= Wd[3 * i + 1] * xp[i];
+                    c[2] -= Wd[3 * i + 2] * xp[i];
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
+        if (in_range && sub == 0) {
+            double X[3] = {pt_cur[(size_t)l * 3], pt_cur[(size_t)l * 3 + 1], pt_cur[(size_t)l * 3 + 2]};
+            if (lfree) {
+                const double* b = D.bl + (size_t)l * 3;
+                c[0] += b[0];
+                c[1] += b[1];
+                c[2] += b[2];
+                double I[6];
+                if (!lm_dinv(D.Hll + (size_t)l * 6, lambda, I)) D.ctl->solve_failed = 1;  // benign race: every writer stores 1
+                const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
+                const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
+                const double d2 = I[2] * c[0] + I[4] * c[1] + I[5] * c[2];
+                X[0] += d0;
+                X[1] += d1;
+                X[2] += d2;
+                sc = d0 * (lambda * d0 + b[0]) + d1 * (lambda * d1 + b[1]) + d2 * (lambda * d2 + b[2]);
+            }
+            pt_trial[(size_t)l * 3] = X[0];
+            pt_trial[(size_t)l * 3 + 1] = X[1];
+            pt_trial[(size_t)l * 3 + 2] = X[2];
+        }
+    }
+    else {
+        const int p = (blockIdx.x - nb_lm) * 256 + threadIdx.x;
+        if (p < D.P) {
+            const double* T = st_pose(D, 0) + (size_t)p * 12;
+            double* O = const_cast<double*>(st_pose(D, 1)) + (size_t)p * 12;
+            const int slot = D.pose_slot[p];
+            if (slot < 0) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) O[k] = T[k];
+            }
+            else {
+                const double* u = D.dp + (size_t)slot * 6;
+                const double* bpv = D.bp_full + (size_t)slot * 6;
+                if (D.scale_pose)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpv[k]);
+                po_exp_mul(u, T, O);
+            }
+        }
+    }
+    const double tsum = block_sum_d(sc, s4);
+    if (threadIdx.x == 0) D.red[D.red_scale_off + blockIdx.x] = tsum;
+}
+
 // W / Y of edges that left the active set (excluded by the gate, or whose landmark became inactive) are zeroed once
 // per stage, so that the (edge, edge) pair lists built for the first stage stay valid: such pairs contribute 0.
 __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
@@ -1166,13 +1325,9 @@ __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
     if (e >= D.E) return;
     if (!D.e_level[e] && D.pt_free[D.e_point[e]]) return;
     double2* Wd = reinterpret_cast<double2*>(D.W + (size_t)e * 18);
-    double2* Yd = reinterpret_cast<double2*>(D.Y + (size_t)e * 18);
     const double2 z = {0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        Wd[k] = z;
-        Yd[k] = z;
-    }
+    for (int k = 0; k < 9; ++k) Wd[k] = z;
 }
 
 // ------------------------------------------------------------------------------------------------ LM control on the device
@@ -1340,18 +1495,18 @@ void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+static inline int nb_lm_blocks(const BaDev& D) { return (D.L * LM_LANES + 255) / 256; }
+
+// linearisation (+ pose blocks from their partials; unless the blocks must first be summed over ranks: lambda init and trial start)
+void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int do_prepare) {
     SvProfScope ps(ctx, s, "ba_linearize");
-    if (D.L > 0) hipLaunchKernelGGL(k_ba_lin_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
-    if (D.nP > 0) {
-        hipLaunchKernelGGL(k_ba_lin_pose, dim3(D.nP, LP_SPLIT), dim3(LP_THREADS), 0, s, D, D.lp_part);
-        hipLaunchKernelGGL(k_ba_lin_pose_fin, dim3(D.nP), dim3(64), 0, s, D, D.lp_part);
-    }
+    const int nb = nb_lm_blocks(D);
+    hipLaunchKernelGGL(k_ba_lin, dim3(nb + D.nP * LIN_SPLIT), dim3(256), 0, s, D, nb);
+    hipLaunchKernelGGL(k_ba_lin_fin, dim3(1), dim3(256), 0, s, D, do_prepare);
 }
 
-void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
-    const int m = D.L > D.nP ? D.L : D.nP;
-    hipLaunchKernelGGL(k_ba_maxdiag, dim3((m + 255) / 256), dim3(256), 0, s, D);
+void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {  // sharded solve only: pose part over the summed blocks + the rank's slot
+    if (D.nP > 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D.nP + 255) / 256), dim3(256), 0, s, D);
     if (D.world > 1) hipLaunchKernelGGL(k_ba_maxslot, dim3(1), dim3(64 > D.world ? 64 : D.world), 0, s, D);
 }
 
@@ -1360,19 +1515,34 @@ void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLa
 void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }
 void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D); }
 
-int sv_ba_schur_split(const BaDev& D) { return D.NB >= 1024 ? 1 : SCHUR_SPLIT; }
-int sv_ba_lin_pose_split() { return LP_SPLIT; }
+int sv_ba_lin_split() { return LIN_SPLIT; }
+int sv_ba_rhs_split() { return RHS_SPLIT; }
 
-// phase 1: Dinv / Y, (partial) reduced camera system: kept upper blocks Sblk + right-hand side g
+// reduced camera system: shares of the blocks and of the right-hand side, then the kept blocks Sblk and g
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_schur");
-    if (D.L > 0) hipLaunchKernelGGL(k_ba_dinv, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
-    if (D.nP > 0) {
-        const int split = sv_ba_schur_split(D);
-        hipLaunchKernelGGL(k_ba_schur, dim3(D.NB, split), dim3(SCHUR_THREADS), 0, s, D, D.sc_part);
-        hipLaunchKernelGGL(k_ba_schur_fin, dim3((D.NB + 6) / 7), dim3(256), 0, s, D, D.sc_part, split);
-        hipLaunchKernelGGL(k_ba_rhs, dim3(D.nP), dim3(1024), 0, s, D);
+    if (D.nP <= 0) return;
+    const int units = D.NB * D.nshare + D.nP * RHS_SPLIT;
+    hipLaunchKernelGGL(k_ba_schur_rhs, dim3((units + 3) / 4), dim3(256), 0, s, D, D.nshare, D.rhs_part);
+    hipLaunchKernelGGL(k_ba_sys_fin, dim3((D.NB * 36 + D.n + 255) / 256), dim3(256), 0, s, D, D.nshare, D.rhs_part);
+}
+
+// LDS-resident PCG: bytes of dynamic LDS for this system, 0 = does not fit (n > 512 or more than ~150 KB)
+size_t sv_ba_pcg_lds_bytes(const BaDev& D) {
+    const size_t nent = 2 * (size_t)D.NB - D.nP;
+    const size_t bytes = 8 * (36 * (size_t)D.NB + 36 * (size_t)D.nP + 5 * (size_t)D.n + 6 * nent + 48) + 4 * (size_t)((D.nP + 2) & ~1) + 8 * nent;
+    return (D.n <= PL_THREADS && bytes <= 150 * 1024) ? bytes : 0;
+}
+void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+    if (D.nP <= 0) return;
+    SvProfScope ps(ctx, s, "ba_solve");
+    const size_t lds = sv_ba_pcg_lds_bytes(D);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)k_ba_pcg_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_bytes = lds;
+        else (void)hipGetLastError();
     }
+    hipLaunchKernelGGL(k_ba_pcg_lds, dim3(1), dim3(PL_THREADS), lds, s, D, 2 * D.NB - D.nP);
 }
 
 // ---- dense factorisation of large reduced systems: rocSOLVER dpotrf / dpotrs, resolved with dlopen on first use so that the
@@ -1453,8 +1623,8 @@ void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 // back-substitution, trial state
 void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_update");
-    if (D.L > 0) hipLaunchKernelGGL(k_ba_update_lm, dim3((D.L * LM_LANES + 255) / 256), dim3(256), 0, s, D);
-    hipLaunchKernelGGL(k_ba_update_pose, dim3((D.P + 255) / 256), dim3(256), 0, s, D, (D.L * LM_LANES + 255) / 256);
+    const int nb = nb_lm_blocks(D);
+    hipLaunchKernelGGL(k_ba_update, dim3(nb + (D.P + 255) / 256), dim3(256), 0, s, D, nb);
 }
 
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded) {

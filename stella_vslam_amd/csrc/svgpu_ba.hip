@@ -250,32 +250,33 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if (!strcmp(ev, "cholesky")) solver_opt = SV_BA_SOLVER_CHOLESKY;
         else if (!strcmp(ev, "pcg")) solver_opt = SV_BA_SOLVER_PCG;
         else if (!strcmp(ev, "dense")) solver_opt = SV_BA_SOLVER_DENSE;
+        else if (!strcmp(ev, "pcg_multi")) solver_opt = SV_BA_SOLVER_PCG_MULTI;
     }
     // ---- device arena
     const int nPmax = P, nmax = 6 * nPmax;
     const int nb_chi = (E + 255) / 256, nb_lm = (8 * L + 255) / 256 /* k_ba_update_lm: 8 lanes per landmark */, nb_pose = (P + 255) / 256;
     const size_t nb_cap = (size_t)P * (P + 1) / 2;
-    const size_t sc_part_blocks = std::max(nb_cap + 1, 4 * std::min(nb_cap + 1, (size_t)1024));
-    const size_t xch_doubles = std::max(std::max((size_t)P, 4 * (size_t)L), nb_cap) + 8;
-    const size_t nparts_max = (size_t)(P + 3) / 4 + 1;
-    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE;
-    size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
-                  + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
-                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + 2 * pad(sizeof(double) * 18 * E)
-                  + pad(sizeof(double) * 27 * 8 * (size_t)P) + pad(sizeof(double) * 36 * sc_part_blocks) + pad(sizeof(double) * 6 * E)
-                  + 3 * pad(sizeof(double) * 6 * L) + 2 * pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
-                  + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (36 * nb_cap + 6 * (size_t)P + 8)) + pad(sizeof(double) * nmax)
-                  + (want_dense ? pad(sizeof(double) * (size_t)(nmax + 1) * nmax) : 0)
-                  + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E + 1) + pad(8 * 42 * (size_t)P)
-                  + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
-                  + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
-                  + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     // worst-case pair storage: sum over landmarks of k(k+1)/2 (+ duplicates never exceed k^2)
     size_t pair_cap = 0;
     for (int l = 0; l < L; ++l) {
         const size_t k = lm_off[l + 1] - lm_off[l];
         pair_cap += k * k;
     }
+    const size_t sc_part_blocks = pair_cap / 192 + nb_cap + 16;  // NB * nshare <= pairs / 192 + NB
+    const size_t xch_doubles = std::max(std::max((size_t)P, 4 * (size_t)L), nb_cap) + 8;
+    const size_t nparts_max = (size_t)(P + 3) / 4 + 1;
+    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE;
+    size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
+                  + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
+                  + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + pad(sizeof(double) * 18 * E)
+                  + pad(sizeof(double) * 27 * 16 * (size_t)P) + pad(sizeof(double) * 36 * sc_part_blocks) + pad(sizeof(double) * 6 * 16 * (size_t)P)
+                  + pad(sizeof(double) * 6 * L) + pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
+                  + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (36 * nb_cap + 6 * (size_t)P + 8)) + pad(sizeof(double) * nmax)
+                  + (want_dense ? pad(sizeof(double) * (size_t)(nmax + 1) * nmax) : 0)
+                  + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E + 1) + pad(8 * 42 * (size_t)P)
+                  + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
+                  + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
+                  + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     const size_t pair_scratch = sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap);
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch);
     int rc = sv_ensure_scratch(ctx, need);
@@ -307,14 +308,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int* d_pe_off = A.take<int>(P + 1);
     int* d_pe_idx = A.take<int>(E);
     D.W = A.take<double>(18 * (size_t)E);
-    D.Y = A.take<double>(18 * (size_t)E);
-    D.lp_part = A.take<double>(27 * 8 * (size_t)P);
+    D.lp_part = A.take<double>(27 * 16 * (size_t)P);
     D.sc_part = A.take<double>(36 * sc_part_blocks);
-    D.GE = A.take<double>(6 * (size_t)E);
+    D.rhs_part = A.take<double>(6 * 16 * (size_t)P);
     D.Hll = A.take<double>(6 * (size_t)L);
-    D.Dinv = A.take<double>(6 * (size_t)L);
     D.bl = A.take<double>(3 * (size_t)L);
-    D.dl = A.take<double>(3 * (size_t)L);
     D.Hpp = A.take<double>(36 * (size_t)P);
     D.bp = A.take<double>(6 * (size_t)P);
     D.Sblk = A.take<double>(36 * nb_cap + 6 * (size_t)P + 8);
@@ -485,8 +483,6 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.n = 6 * HS.nP;
         D.chol_in_lds = D.n <= 192 && sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 12 * 1024;
         solver = solver_opt;
-        if (solver == SV_BA_SOLVER_AUTO) solver = D.chol_in_lds ? SV_BA_SOLVER_CHOLESKY : SV_BA_SOLVER_PCG;
-        if (solver == SV_BA_SOLVER_CHOLESKY && !D.chol_in_lds) solver = SV_BA_SOLVER_PCG;
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
@@ -551,6 +547,15 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.NB = (int)HS.blk_ab.size();
         D.g = D.Sblk + 36 * (size_t)D.NB;
         D.pcg_nparts = (HS.nP + 3) / 4;
+        D.nshare = D.NB > 0 ? (int)std::min<size_t>(16, std::max<size_t>(1, (HS.num_pairs / (size_t)D.NB + 191) / 192)) : 1;
+        // solver of this stage: PCG inside one workgroup's LDS when the blocks fit, else one launch per PCG iteration
+        const bool lds_ok = sv_ba_pcg_lds_bytes(D) > 0;
+        // AUTO: dense LL^T in LDS while it fits (n <= ~135: 70 us per trial against 88 us for the LDS-resident PCG at n = 96), the
+        // LDS-resident PCG up to 512 unknowns / ~150 KB of blocks, the one-launch-per-iteration PCG beyond
+        if (solver == SV_BA_SOLVER_AUTO && D.chol_in_lds) solver = SV_BA_SOLVER_CHOLESKY;
+        if (solver == SV_BA_SOLVER_CHOLESKY && !D.chol_in_lds) solver = SV_BA_SOLVER_AUTO;
+        if (solver == SV_BA_SOLVER_AUTO || solver == SV_BA_SOLVER_PCG) solver = lds_ok ? SV_BA_SOLVER_PCG_LDS : SV_BA_SOLVER_PCG_MULTI;
+        if (sv_ba_lin_split() > 16 || sv_ba_rhs_split() > 16) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: partial-sum buffers too small for the kernel splits");
         if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks, n = %d, solver %d)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size(), D.n, solver);
         return SVGPU_OK;
     };
@@ -571,19 +576,22 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     const int pcg_max_it = ctx->pcg_max_it > 0 ? ctx->pcg_max_it : 0;
     auto enqueue_step = [&](bool* finished_seen) -> int {
         int r;
-        sv_ba_linearize(ctx, s, D);
-        if (sharded && HS.nP > 0) {
-            SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
-            SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
-            if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP))) return r;
+        sv_ba_linearize(ctx, s, D, sharded ? 0 : 1);
+        if (sharded) {  // pose blocks summed over the ranks before the damping is initialised from their diagonal
+            if (HS.nP > 0) {
+                SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
+                SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
+                if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP))) return r;
+            }
+            sv_ba_maxdiag(s, D);
+            if ((r = allreduce_dev(D.maxslots, (size_t)world))) return r;
+            sv_ba_prepare(s, D);
         }
-        sv_ba_maxdiag(s, D);
-        if (sharded && (r = allreduce_dev(D.maxslots, (size_t)world))) return r;
-        sv_ba_prepare(s, D);
         sv_ba_reduce(ctx, s, D);
         if (HS.nP > 0 && (r = allreduce_dev(D.Sblk, 36 * (size_t)D.NB + (size_t)D.n))) return r;
         if (HS.nP > 0) {
             if (solver == SV_BA_SOLVER_CHOLESKY) sv_ba_solve(ctx, s, D);
+            else if (solver == SV_BA_SOLVER_PCG_LDS) sv_ba_solve_pcg_lds(ctx, s, D);
             else if (solver == SV_BA_SOLVER_DENSE) sv_ba_solve_dense(ctx, s, D);
             else {
                 // PCG: iterations are enqueued in chunks; the control block says when the solve (or the whole optimisation) is over
@@ -817,7 +825,7 @@ int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int r
 }
 
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations) {
-    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || solver > SVGPU_BA_SOLVER_DENSE) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
+    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || solver > SVGPU_BA_SOLVER_PCG_MULTI) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
     ctx->ba_solver = solver;
     ctx->pcg_tol = pcg_tolerance > 0 ? pcg_tolerance : 1e-10;
     ctx->pcg_max_it = pcg_max_iterations > 0 ? pcg_max_iterations : 0;

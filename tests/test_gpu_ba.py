@@ -232,14 +232,16 @@ def test_pose_optimizer_equirectangular_matches_oracle():
     assert np.abs(pose - pr["pose_gt"]).max() < 0.1 * np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
 
 
-@pytest.mark.parametrize("solver", ["pcg", "dense"])
+@pytest.mark.parametrize("solver", ["pcg", "pcg_multi", "dense"])
 @pytest.mark.parametrize("kw", [dict(num_kf=10, num_lm=1500, obs_per_lm=5, num_fixed=3, seed=5),
                                 dict(num_kf=20, num_lm=10000, obs_per_lm=6, num_fixed=4, seed=1234)])
 def test_local_ba_alternative_solvers_match_oracle(kw, solver):
-    """The reduced camera system solved by the PCG (north_star: "Schur-complement J^T J build + PCG solve") and by the dense
-    rocSOLVER path instead of the on-chip LL^T: same LM schedule, same outliers, poses within tolerance."""
+    """A local-BA sized reduced camera system is factored by the dense LL^T in LDS by default.  The other solvers -- the PCG that
+    lives in one workgroup's LDS (north_star: "Schur-complement J^T J build + PCG solve"), the one-launch-per-iteration PCG of the
+    global-BA sizes, dense rocSOLVER -- must walk the same LM schedule to the same poses and outliers."""
     from stella_vslam_amd import optimize
-    adj = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_PCG if solver == "pcg" else optimize.SOLVER_DENSE)
+    code = dict(pcg=optimize.SOLVER_PCG, pcg_multi=optimize.SOLVER_PCG_MULTI, dense=optimize.SOLVER_DENSE)[solver]
+    adj = optimize.local_bundle_adjuster().set_solver(code)
     sc = S.ba_scene(**kw)
     got = adj.optimize_flat(sc)
     ref = O.local_ba(sc)
@@ -248,7 +250,7 @@ def test_local_ba_alternative_solvers_match_oracle(kw, solver):
     _assert_poses(got["pose_cw"], ref["pose_cw"])
     assert _rel(got["points"], ref["points"]) < TOL
     assert np.array_equal(got["outlier"], ref["outlier"])
-    assert (gs["pcg_iterations"] > 0) == (solver == "pcg") and gs["cholesky_failures"] == 0
+    assert (gs["pcg_iterations"] > 0) == (solver != "dense") and gs["cholesky_failures"] == 0
 
 
 def test_global_ba_config5_matches_oracle():
