@@ -274,6 +274,117 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
                                     int* num_matches, uint8_t* visible, double* reproj, float* x_right,
                                     int32_t* pred_scale_level);
 
+/* ------------------------------------------------------------------------------ function-specific matchers
+ * One entry point per reference method: candidate generation (reprojection + grid cells, or BoW buckets), the method's own pair
+ * gates and the exact sequential bookkeeping all run on the device; the adaptor classes of stella_vslam_amd/host/ flatten the
+ * frame / keyframe / landmark objects into these arrays and write the results back.  Common conventions:
+ *   landmarks (queries)  pos_w n x 3 doubles, `valid` 0 = not offered (null, will_be_erased, already matched ...: the method's own
+ *                        `continue` tests on the object graph), min/max_valid_dist (landmark::get_min/max_valid_distance),
+ *                        mean_normal n x 3 (get_obs_mean_normal), lm_desc n x 32 (get_descriptor)
+ *   keypoint side        tdesc nt x 32, t_xy nt x 2 undistorted positions, t_octave, t_angle, t_xright (stereo_x_right_, nullable),
+ *                        binned on the device by data::assign_keypoints_to_grid over cam->min_x .. max_y and grid_cols x grid_rows
+ *   scale_factors / inv_level_sigma_sq   orb_params tables of num_levels floats, log_scale_factor = orb_params::log_scale_factor_
+ *   outputs              per query the matched keypoint index or -1, in query order; the adaptor replays them onto the objects
+ * All host in/out, synchronous. */
+
+/* camera::*::reproject_to_bearing (perspective.cc:150-170, fisheye.cc:189-209, equirectangular.cc:75-80, radial_division.cc:135-156):
+ * used by the triangulation matchers for the epipole of keyframe 1 in keyframe 2.  Pure host function. */
+int svgpu_reproject_to_bearing(const svgpu_camera* cam, const double* rot_cw, const double* trans_cw, const double* pos_w, double* bearing,
+                               int* valid);
+
+/* projection::match_current_and_last_frames (match/projection.cc:95-207): the landmarks of the last frame's keypoints reprojected
+ * with the current pose guess; level window from the keypoint's octave in the last frame and the forward / backward motion test
+ * (:108-157; is_monocular = camera setup Monocular, true_baseline = camera::base::true_baseline_); gates: keypoint already holds an
+ * observed landmark (`occupied`), stereo x_right, orientation; best <= HAMMING_DIST_THR_HIGH.
+ *   lm_has_observation  nullable (all 1): 0 = the landmark carries no observation, so the keypoint it is attached to stays open for
+ *                       later landmarks (`curr_lm && curr_lm->has_observation()`, :167-170) and a later match overwrites it
+ *   match_last[i]       keypoint of the current frame matched to landmark i (curr_frm.add_landmark(lm, best_idx) in order) */
+int svgpu_match_current_and_last_frames(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw, const double* rot_lw,
+                                        const double* trans_lw, int is_monocular, float true_baseline, int n_last, const double* pos_w,
+                                        const uint8_t* valid, const uint8_t* lm_desc, const int32_t* octave_last, const float* angle_last,
+                                        const uint8_t* lm_has_observation, int num_levels, const float* scale_factors, float margin,
+                                        const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, const float* t_angle, int nt,
+                                        const uint8_t* occupied, const float* t_xright, int grid_cols, int grid_rows, int check_orientation,
+                                        int32_t* match_last, int* num_matches);
+
+/* projection::match_frame_and_keyframe (match/projection.cc:209-319; relocalisation): the keyframe's landmarks into the frame;
+ * double-precision distance-range test (:233-241), landmark::predict_scale_level, window [l-1, l+1]; gates: frame keypoint already
+ * holds a landmark (`occupied` = frm_landmarks non-null), orientation against the KEYFRAME keypoint's angle; best <= hamm_dist_thr.
+ *   valid  = landmark non-null, not will_be_erased, not in already_matched_lms */
+int svgpu_match_frame_and_keyframe_projection(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw, int n_kf,
+                                              const double* pos_w, const uint8_t* valid, const float* min_valid_dist, const float* max_valid_dist,
+                                              const uint8_t* lm_desc, const float* angle_kf, int num_levels, const float* scale_factors,
+                                              float log_scale_factor, float margin, unsigned hamm_dist_thr, const uint8_t* tdesc, const float* t_xy,
+                                              const int32_t* t_octave, const float* t_angle, int nt, const uint8_t* occupied, int grid_cols,
+                                              int grid_rows, int check_orientation, int32_t* match_kf, int* num_matches);
+
+/* projection::match_by_Sim3_transform (match/projection.cc:321-416; loop detection): sim3_cw 4x4 row-major; converted to SE3 as the
+ * reference does (:326-330); distance range, viewing-angle test dot(v, normal) >= 0.5 |v|, predicted level; candidates skip keypoints
+ * that already hold a landmark (`occupied` = matched_lms_in_keyfrm non-null); best <= HAMMING_DIST_THR_LOW, no orientation test.
+ *   valid  = landmark not will_be_erased and not already in matched_lms_in_keyfrm */
+int svgpu_match_by_sim3_transform(svgpu_ctx* ctx, const svgpu_camera* cam, const double* sim3_cw, int n, const double* pos_w, const uint8_t* valid,
+                                  const float* min_valid_dist, const float* max_valid_dist, const double* mean_normal, const uint8_t* lm_desc,
+                                  int num_levels, const float* scale_factors, float log_scale_factor, float margin, const uint8_t* tdesc,
+                                  const float* t_xy, const int32_t* t_octave, int nt, const uint8_t* occupied, int grid_cols, int grid_rows,
+                                  int32_t* match_lm, int* num_matches);
+
+/* projection::match_keyframes_mutually (match/projection.cc:418-629): landmarks of keyframe 1 into keyframe 2 through the similarity
+ * (s_12, rot_12, trans_12) and vice versa, two independent passes (no bookkeeping inside a pass), then the cross-check.
+ *   valid1 / valid2   landmark non-null, not will_be_erased, not already matched between the two keyframes (:441-450, 466-468)
+ *   desc*, xy*, octave*   the keyframes' own keypoints (the side that is searched in the other pass)
+ *   matched_2_in_1 / matched_1_in_2   the two passes; mutual_2_in_1[i] = idx_2 where both agree (:598-610), num_matches counts those.
+ * As in the reference, both passes test "inside the image" with keyframe 2's camera (:477, 550). */
+int svgpu_match_keyframes_mutually(svgpu_ctx* ctx, const svgpu_camera* cam1, const svgpu_camera* cam2, const double* rot_1w, const double* trans_1w,
+                                   const double* rot_2w, const double* trans_2w, float s_12, const double* rot_12, const double* trans_12,
+                                   int n1, const double* pos_w1, const uint8_t* valid1, const float* min_valid1, const float* max_valid1,
+                                   const uint8_t* lm_desc1, const uint8_t* desc1, const float* xy1, const int32_t* octave1,
+                                   int n2, const double* pos_w2, const uint8_t* valid2, const float* min_valid2, const float* max_valid2,
+                                   const uint8_t* lm_desc2, const uint8_t* desc2, const float* xy2, const int32_t* octave2,
+                                   int num_levels, const float* scale_factors, float log_scale_factor, float margin, int grid_cols, int grid_rows,
+                                   int32_t* matched_2_in_1, int32_t* matched_1_in_2, int32_t* mutual_2_in_1, int* num_matches);
+
+/* fuse::detect_duplication<T> (match/fuse.cc:11-154): landmarks_to_check reprojected into a keyframe; distance range, viewing angle,
+ * predicted level; per candidate the optional chi-square reprojection gate (do_reprojection_matching: 5.99146 / 7.81473 against the
+ * squared error times inv_level_sigma_sq of the keypoint's octave, 3 dof when the keypoint has a stereo x_right, :92-119) and
+ * `already_matched_idx_in_keyfrm`; best <= HAMMING_DIST_THR_LOW.
+ *   valid     = landmark non-null, not will_be_erased, not observed in the keyframe (:27-35)
+ *   best_idx  per landmark the keyframe keypoint it fuses with, or -1; the adaptor sorts them into duplicated_lms_in_keyfrm /
+ *             new_connections by keyfrm->get_landmark(best_idx) (:130-147) */
+int svgpu_fuse_detect_duplication(svgpu_ctx* ctx, const svgpu_camera* cam, const double* rot_cw, const double* trans_cw, int n, const double* pos_w,
+                                  const uint8_t* valid, const float* min_valid_dist, const float* max_valid_dist, const double* mean_normal,
+                                  const uint8_t* lm_desc, int num_levels, const float* scale_factors, const float* inv_level_sigma_sq,
+                                  float log_scale_factor, float margin, int do_reprojection_matching, const uint8_t* tdesc, const float* t_xy,
+                                  const int32_t* t_octave, const float* t_xright, int nt, int grid_cols, int grid_rows, int32_t* best_idx,
+                                  int* num_fused);
+
+/* robust::match_for_triangulation (match/robust.cc:14-146) and bow_tree::match_for_triangulation (match/bow_tree.cc:11-167).
+ * Keypoints WITHOUT a landmark on both sides (has_lm* = 1 excludes); per pair: orientation, Hamming <= 50 and <= the running best,
+ * the epipole test (cos > 0.99862953475 rejected unless one of the two is a stereo keypoint, xright* >= 0) and
+ * check_epipolar_constraint(bearing_1, bearing_2, E_12, ...) in fp64 (match/base.h:67-79) with the threshold
+ * residual_rad_thr * scale_factors[octave1]; strict '<' updates, Lowe ratio, a keypoint of keyframe 2 is taken once.
+ *   node1 / node2   both NULL: robust (all keypoints of keyframe 2 are candidates, queries in index order);
+ *                   both given: bow_tree -- the bow_feat_vec_ node of every keypoint (svgpu_bow_transform's node_id, < 0 = none); the
+ *                   merge-join of the two maps (:37-40, 142-153) runs on the device: queries in (node, index) order, candidates = the
+ *                   keypoints of keyframe 2 in the same node, index order
+ *   epipole_in_2 / valid_epipole   svgpu_reproject_to_bearing(cam2, rot_2w, trans_2w, keyfrm_1 camera centre)   (:22-27)
+ *   matched_2_in_1[i]   keypoint of keyframe 2 or -1 (the reference returns the pairs sorted by i). */
+int svgpu_match_for_triangulation(svgpu_ctx* ctx, const uint8_t* desc1, const float* angle1, const int32_t* octave1, const double* bearings1,
+                                  const uint8_t* has_lm1, const float* xright1, int n1, const uint8_t* desc2, const float* angle2,
+                                  const double* bearings2, const uint8_t* has_lm2, const float* xright2, int n2, const int32_t* node1,
+                                  const int32_t* node2, const double* E_12, const double* epipole_in_2, int valid_epipole, const float* scale_factors,
+                                  int num_levels, float residual_rad_thr, float lowe_ratio, int check_orientation, int32_t* matched_2_in_1,
+                                  int* num_matches);
+
+/* bow_tree::match_frame_and_keyframe (match/bow_tree.cc:169-256) and bow_tree::match_keyframes (:258-366).
+ * Side 1 = the keyframe whose landmarks are handed over (queries: valid1 = keypoint holds a live landmark), side 2 = the frame /
+ * the other keyframe (valid2 nullable = every keypoint, or "holds a live landmark" for match_keyframes; occupied2 nullable = keypoints
+ * that must not be matched from the start).  Device-side merge-join of the node ids as above; per pair orientation; best / second
+ * best with strict '<', best <= HAMMING_DIST_THR_LOW, Lowe ratio; a side-2 keypoint is taken once.
+ *   match_1to2[i]   side-2 keypoint matched to side-1 keypoint i, or -1. */
+int svgpu_bow_match(svgpu_ctx* ctx, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, const int32_t* node1, int n1,
+                    const uint8_t* desc2, const float* angle2, const uint8_t* valid2, const int32_t* node2, int n2, const uint8_t* occupied2,
+                    float lowe_ratio, int check_orientation, int32_t* match_1to2, int* num_matches);
+
 /* ------------------------------------------------------------------------------ landmark refresh (batched)
  * data::landmark::compute_descriptor (data/landmark.cc:199-254) for n landmarks: the representative descriptor is the
  * observation whose row of the k x k Hamming matrix has the smallest lower median (sorted index (unsigned)(0.5 (k-1)); first

@@ -226,6 +226,11 @@ static int reproject_to_image(const orc_camera* c, const double* R, const double
     return c->min_x < reproj[0] && reproj[0] < c->max_x && c->min_y < reproj[1] && reproj[1] < c->max_y;
 }
 
+/* exported for oracle/match2_oracle.c (the projection-family matchers call camera_->reproject_to_image themselves) */
+int orc_reproject_to_image(const orc_camera* c, const double* R, const double* t, const double* pw, double* reproj, float* x_right) {
+    return reproject_to_image(c, R, t, pw, reproj, x_right);
+}
+
 /* frame::can_observe for n landmarks.
  *   rot_cw 9 (row-major), trans_cw 3, trans_wc 3 (camera centre in world)
  *   pos_w n x 3, mean_normal n x 3, min_valid_dist / max_valid_dist n floats

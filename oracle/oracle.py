@@ -26,7 +26,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> pathlib.Path:
     so = _HERE / "liboracle.so"
-    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "landmark_oracle.c", "bow_oracle.c", "orb_pattern_i8.inc", "Makefile")]
+    srcs = [_HERE / n for n in ("orb_oracle.c", "match_oracle.c", "ba_oracle.c", "frame_oracle.c", "landmark_oracle.c", "bow_oracle.c", "match2_oracle.c", "orb_pattern_i8.inc", "Makefile")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-C", str(_HERE), "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -410,3 +410,113 @@ def pose_optimize(pose_cw, pos_w, uvr, inv_sigma_sq, huber, intr, num_trials_rob
     nv = lib().orc_pose_optimize(_p(pose), n, _p(pw), _p(uv), _p(w), _p(hb), _p(K), num_trials_robust, num_trials, num_each_iter,
                                  C.c_double(gain_thr), int(reset_flag_each_round), _p(out), _p(outl), _p(st))
     return nv, out, outl[:n].copy(), st
+
+
+# ------------------------------------------------------------------------------------------- per-method matcher oracles (match2_oracle.c)
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def _c(a, t):
+    return None if a is None else np.ascontiguousarray(a, t)
+
+
+def reproject_to_bearing(cam, rot_cw, trans_cw, pos_w):
+    b = np.zeros(3)
+    v = lib().orc_reproject_to_bearing(C.byref(cam), _p(_f64(rot_cw)), _p(_f64(trans_cw)), _p(_f64(pos_w)), _p(b))
+    return b, bool(v)
+
+
+def match_for_triangulation(lowe_ratio, check_orientation, desc1, angle1, octave1, bearings1, has_lm1, desc2, angle2, bearings2, has_lm2, E_12,
+                            epipole_in_2, valid_epipole, scale_factors, residual_rad_thr, xright1=None, xright2=None, node1=None, node2=None):
+    d1, d2, sf = _c(desc1, np.uint8), _c(desc2, np.uint8), _c(scale_factors, np.float32)
+    out = np.full(len(d1), -1, np.int32)
+    num = lib().orc_match_for_triangulation(
+        _p(d1), _p(_c(angle1, np.float32)), _p(_c(octave1, np.int32)), _p(_f64(bearings1)), _p(_c(has_lm1, np.uint8)), _p(_c(xright1, np.float32)), len(d1),
+        _p(d2), _p(_c(angle2, np.float32)), _p(_f64(bearings2)), _p(_c(has_lm2, np.uint8)), _p(_c(xright2, np.float32)), len(d2), _p(_c(node1, np.int32)),
+        _p(_c(node2, np.int32)), _p(_f64(E_12)), _p(_f64(epipole_in_2)), int(valid_epipole), _p(sf), C.c_float(residual_rad_thr), C.c_float(lowe_ratio),
+        int(check_orientation), _p(out))
+    return out, num
+
+
+def bow_match(lowe_ratio, check_orientation, desc1, angle1, valid1, node1, desc2, angle2, node2, valid2=None, occupied2=None):
+    d1, d2 = _c(desc1, np.uint8), _c(desc2, np.uint8)
+    out = np.full(len(d1), -1, np.int32)
+    num = lib().orc_bow_match(_p(d1), _p(_c(angle1, np.float32)), _p(_c(valid1, np.uint8)), _p(_c(node1, np.int32)), len(d1), _p(d2),
+                              _p(_c(angle2, np.float32)), _p(_c(valid2, np.uint8)), _p(_c(node2, np.int32)), len(d2), _p(_c(occupied2, np.uint8)),
+                              C.c_float(lowe_ratio), int(check_orientation), _p(out))
+    return out, num
+
+
+def match_current_and_last_frames(check_orientation, cam, rot_cw, trans_cw, rot_lw, trans_lw, pos_w, valid, lm_desc, octave_last, angle_last, scale_factors,
+                                  margin, tdesc, t_xy, t_octave, t_angle, occupied=None, t_xright=None, lm_has_observation=None, is_monocular=True,
+                                  true_baseline=0.0, grid_cols=64, grid_rows=48):
+    pw = _f64(pos_w, (-1, 3))
+    n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+    out = np.full(n, -1, np.int32)
+    num = lib().orc_match_current_and_last_frames(
+        C.byref(cam), _p(_f64(rot_cw)), _p(_f64(trans_cw)), _p(_f64(rot_lw)), _p(_f64(trans_lw)), int(is_monocular), C.c_float(true_baseline), n, _p(pw),
+        _p(_c(valid, np.uint8)), _p(_c(lm_desc, np.uint8)), _p(_c(octave_last, np.int32)), _p(_c(angle_last, np.float32)), _p(_c(lm_has_observation, np.uint8)),
+        len(sf), _p(sf), C.c_float(margin), _p(td), _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)), _p(_c(t_angle, np.float32)), len(td),
+        _p(_c(occupied, np.uint8)), _p(_c(t_xright, np.float32)), grid_cols, grid_rows, int(check_orientation), _p(out))
+    return out, num
+
+
+def match_frame_and_keyframe_projection(check_orientation, cam, rot_cw, trans_cw, pos_w, valid, min_valid_dist, max_valid_dist, lm_desc, angle_kf,
+                                        scale_factors, log_scale_factor, margin, hamm_dist_thr, tdesc, t_xy, t_octave, t_angle, occupied=None,
+                                        grid_cols=64, grid_rows=48):
+    pw = _f64(pos_w, (-1, 3))
+    n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+    out = np.full(n, -1, np.int32)
+    num = lib().orc_match_frame_and_keyframe_projection(
+        C.byref(cam), _p(_f64(rot_cw)), _p(_f64(trans_cw)), n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(min_valid_dist, np.float32)),
+        _p(_c(max_valid_dist, np.float32)), _p(_c(lm_desc, np.uint8)), _p(_c(angle_kf, np.float32)), len(sf), _p(sf), C.c_float(log_scale_factor),
+        C.c_float(margin), C.c_uint(hamm_dist_thr), _p(td), _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)), _p(_c(t_angle, np.float32)), len(td),
+        _p(_c(occupied, np.uint8)), grid_cols, grid_rows, int(check_orientation), _p(out))
+    return out, num
+
+
+def match_by_sim3_transform(cam, sim3_cw, pos_w, valid, min_valid_dist, max_valid_dist, mean_normal, lm_desc, scale_factors, log_scale_factor, margin, tdesc,
+                            t_xy, t_octave, occupied=None, grid_cols=64, grid_rows=48):
+    pw = _f64(pos_w, (-1, 3))
+    n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+    out = np.full(n, -1, np.int32)
+    num = lib().orc_match_by_sim3_transform(
+        C.byref(cam), _p(_f64(sim3_cw)), n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(min_valid_dist, np.float32)), _p(_c(max_valid_dist, np.float32)),
+        _p(_f64(mean_normal)), _p(_c(lm_desc, np.uint8)), len(sf), _p(sf), C.c_float(log_scale_factor), C.c_float(margin), _p(td), _p(_c(t_xy, np.float32)),
+        _p(_c(t_octave, np.int32)), len(td), _p(_c(occupied, np.uint8)), grid_cols, grid_rows, _p(out))
+    return out, num
+
+
+def match_keyframes_mutually(cam1, cam2, rot_1w, trans_1w, rot_2w, trans_2w, s_12, rot_12, trans_12, kf1, kf2, scale_factors, log_scale_factor, margin,
+                             grid_cols=64, grid_rows=48):
+    sf = _c(scale_factors, np.float32)
+
+    def side(k):
+        pw = _f64(k["pos_w"], (-1, 3))
+        return [len(pw), _p(pw), _p(_c(k["valid"], np.uint8)), _p(_c(k["min_valid_dist"], np.float32)), _p(_c(k["max_valid_dist"], np.float32)),
+                _p(_c(k["lm_desc"], np.uint8)), _p(_c(k["desc"], np.uint8)), _p(_c(k["xy"], np.float32)), _p(_c(k["octave"], np.int32))]
+    n1, n2 = len(kf1["pos_w"]), len(kf2["pos_w"])
+    m21, m12, mut = np.full(n1, -1, np.int32), np.full(n2, -1, np.int32), np.full(n1, -1, np.int32)
+    num = lib().orc_match_keyframes_mutually(
+        C.byref(cam1), C.byref(cam2), _p(_f64(rot_1w)), _p(_f64(trans_1w)), _p(_f64(rot_2w)), _p(_f64(trans_2w)), C.c_float(s_12), _p(_f64(rot_12)),
+        _p(_f64(trans_12)), *side(kf1), *side(kf2), len(sf), _p(sf), C.c_float(log_scale_factor), C.c_float(margin), grid_cols, grid_rows, _p(m21), _p(m12),
+        _p(mut))
+    return m21, m12, mut, num
+
+
+def fuse_detect_duplication(cam, rot_cw, trans_cw, pos_w, valid, min_valid_dist, max_valid_dist, mean_normal, lm_desc, scale_factors, inv_level_sigma_sq,
+                            log_scale_factor, margin, tdesc, t_xy, t_octave, t_xright=None, do_reprojection_matching=False, grid_cols=64, grid_rows=48):
+    pw = _f64(pos_w, (-1, 3))
+    n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+    out = np.full(n, -1, np.int32)
+    num = lib().orc_fuse_detect_duplication(
+        C.byref(cam), _p(_f64(rot_cw)), _p(_f64(trans_cw)), n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(min_valid_dist, np.float32)),
+        _p(_c(max_valid_dist, np.float32)), _p(_f64(mean_normal)), _p(_c(lm_desc, np.uint8)), len(sf), _p(sf), _p(_c(inv_level_sigma_sq, np.float32)),
+        C.c_float(log_scale_factor), C.c_float(margin), int(do_reprojection_matching), _p(td), _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)),
+        _p(_c(t_xright, np.float32)), len(td), grid_cols, grid_rows, _p(out))
+    return out, num

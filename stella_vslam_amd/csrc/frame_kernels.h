@@ -41,5 +41,14 @@ struct ReprojProblem {
     float* q_margin;
     int32_t* q_min_level;
     int32_t* q_max_level;
+    // variants of the projection-family matchers (all zero = data::frame::can_observe, data/frame.cc:59-85)
+    int dist_mode;               // 0: float margins 1.3f / (1/1.3)f (landmark::is_inside_in_orb_scale); 1: the double-precision test of
+                                 //    match/projection.cc:233-241, 357-365, fuse.cc:52-61; 2: no distance test (projection.cc:128-135)
+    int normal_mode;             // 0: ray_cos < ray_cos_thr (frame.cc:76-80); 1: dot(v, normal) < 0.5 |v| (projection.cc:370-372, fuse.cc:67-69); 2: none
+    int center_mode;             // 0: |pos_w - trans_wc|; 1: |rot pos_w + trans| (match_keyframes_mutually, projection.cc:487, 555: the
+                                 //    Sim3-transformed point; rot_cw then carries the scale)
+    const int32_t* q_level;      // nullable: scale level given per query (octave of the last frame's keypoint, projection.cc:138) instead
+                                 //    of landmark::predict_scale_level
+    int window_mode;             // level window of the grid lookup: 0 [l-1, l+1]; 1 [l, l+1] (assume_forward, :141-143); 2 [l-1, l] (:145-147)
 };
 void sv_launch_reproject(hipStream_t s, const ReprojProblem& P);

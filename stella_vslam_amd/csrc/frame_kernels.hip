@@ -172,16 +172,34 @@ __global__ void __launch_bounds__(256) k_can_observe(ReprojProblem P) {
             else vis = c.min_x < rx && rx < c.max_x && c.min_y < ry && ry < c.max_y;
         }
     }
-    if (vis) {  // data/frame.cc:68-84
-        const double vx = pw0 - P.trans_wc[0], vy = pw1 - P.trans_wc[1], vz = pw2 - P.trans_wc[2];
+    if (vis && P.q_level) level = P.q_level[i];  // match_current_and_last_frames: in-image is the only visibility test
+    else if (vis) {  // data/frame.cc:68-84 and the per-matcher variants (frame_kernels.h)
+        double vx = pw0 - P.trans_wc[0], vy = pw1 - P.trans_wc[1], vz = pw2 - P.trans_wc[2];
+        if (P.center_mode == 1) {  // the point in the (similarity-transformed) camera frame
+            const double* R = P.rot_cw;
+            vx = (R[0] * pw0 + R[1] * pw1 + R[2] * pw2) + P.trans_cw[0];
+            vy = (R[3] * pw0 + R[4] * pw1 + R[5] * pw2) + P.trans_cw[1];
+            vz = (R[6] * pw0 + R[7] * pw1 + R[8] * pw2) + P.trans_cw[2];
+        }
         const double dist = sqrt((vx * vx + vy * vy) + vz * vz);
         const float fdist = (float)dist, far_ = (float)1.3, near_ = (float)(1.0 / 1.3);
         const float maxv = P.max_valid_dist[i];
-        const float max_dist = far_ * maxv, min_dist = near_ * P.min_valid_dist[i];  // landmark.h:88-92
-        vis = (min_dist <= fdist && fdist <= max_dist);
-        if (vis) {
+        if (P.dist_mode == 0) {
+            const float max_dist = far_ * maxv, min_dist = near_ * P.min_valid_dist[i];  // landmark.h:88-92
+            vis = (min_dist <= fdist && fdist <= max_dist);
+        }
+        else if (P.dist_mode == 1) {
+            const double margin_far = 1.3, margin_near = 1.0 / margin_far;
+            const double max_d = margin_far * (double)maxv, min_d = margin_near * (double)P.min_valid_dist[i];
+            vis = !(dist < min_d || max_d < dist);
+        }
+        if (vis && P.normal_mode == 0) {
             const double ray_cos = ((vx * P.mean_normal[3 * i] + vy * P.mean_normal[3 * i + 1]) + vz * P.mean_normal[3 * i + 2]) / dist;
             vis = !(ray_cos < P.ray_cos_thr);
+        }
+        else if (vis && P.normal_mode == 1) {
+            const double dot = (vx * P.mean_normal[3 * i] + vy * P.mean_normal[3 * i + 1]) + vz * P.mean_normal[3 * i + 2];
+            vis = !(dot < 0.5 * dist);
         }
         if (vis) {  // landmark.cc:336-353; std::log(float): fp64 log rounded to fp32
             const float ratio = maxv / fdist;
@@ -203,8 +221,8 @@ __global__ void __launch_bounds__(256) k_can_observe(ReprojProblem P) {
         P.q_xy[2 * i] = (float)rx;
         P.q_xy[2 * i + 1] = (float)ry;
         P.q_margin[i] = P.margin * P.scale_factors[lv];
-        P.q_min_level[i] = max(0, lv - 1);
-        P.q_max_level[i] = (int)min(P.num_levels - 1u, (unsigned)lv + 1u);
+        P.q_min_level[i] = P.window_mode == 1 ? lv : max(0, lv - 1);
+        P.q_max_level[i] = P.window_mode == 2 ? lv : (int)min(P.num_levels - 1u, (unsigned)lv + 1u);
     }
 }
 

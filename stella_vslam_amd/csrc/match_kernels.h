@@ -4,6 +4,7 @@
 
 #include "svgpu.h"
 
+struct svgpu_ctx;
 #define BF_K 16     // per-query candidate prefix kept by k_bf_topk (candidates within dmax only; exact fallback when exhausted)
 #define BF_LIST 16  // row stride of the per-query candidate lists (>= BF_K and >= MF_SLOTS of k_bf_mfma)
 
@@ -59,6 +60,16 @@ struct CandProblem {
     unsigned thr;
     float lowe_ratio;
     int mode;
+    const uint8_t* q_blocks;  // nullable: 0 = an accepted query does NOT occupy its target for later queries (the landmark it
+                              // carries has no observation: `curr_lm && curr_lm->has_observation()`, projection.cc:167-170)
+    int no_claims;            // 1 = queries are independent (projection::match_keyframes_mutually, :498-510: no bookkeeping at all)
+    // fuse::detect_duplication's reprojection gate (fuse.cc:92-119), evaluated per CSR entry
+    int chi_gate;
+    const double* q_reproj;   // nq x 2
+    const float* q_reproj_xr; // nq
+    const float* t_xy;        // nt x 2 undistorted keypoints
+    const float* chi_t_xright;// nullable: stereo_x_right_ of the keyframe
+    float inv_level_sigma_sq[16];
     uint32_t* dist;           // one per CSR entry: (distance << 22) | target index, 0xFFFFFFFF = gated out (targets < 2^22)
     int32_t* match_q;
     int32_t* num;
@@ -107,6 +118,47 @@ void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P);
 
 void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out);
 void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const uint32_t* d2, int n2, uint16_t* out);
-struct svgpu_ctx;
 void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P, int pairs, int* g_owner, int* g_match);
 void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match, unsigned* mdist);
+
+// Bucketed candidate lists (bucket_kernels.hip): bow_tree::* and robust::match_for_triangulation
+struct BucketProblem {
+    int n1, n2;
+    const uint32_t* desc1;     // n1 x 8
+    const uint32_t* desc2;     // n2 x 8
+    const float* angle1;       // nullable when check_orientation == 0
+    const float* angle2;
+    const uint8_t* valid1;     // nullable: 0 = side-1 keypoint is not a query
+    const uint8_t* valid2;     // nullable: 0 = side-2 keypoint is never a candidate
+    int check_orientation;
+    // triangulation gates (match/robust.cc:56-117, bow_tree.cc:66-130)
+    int tri;
+    unsigned thr;              // Hamming cut-off applied in the scan (tri only)
+    const int32_t* octave1;
+    const double* bearings1;   // n1 x 3
+    const double* bearings2;
+    const float* xright1;      // nullable
+    const float* xright2;
+    double E12[9];
+    double epipole[3];
+    int valid_epipole;
+    float scale_factors[16];
+    float residual_rad_thr;
+    // (node, index) orders and rows
+    const unsigned* key1;      // n1 sorted node ids of side 1
+    const int* q_idx;          // n1: row -> side-1 keypoint
+    const unsigned* key2;      // n2 sorted node ids of side 2
+    const int* t_sorted;       // n2: position in the sorted side 2 -> keypoint
+    int* row_lo;
+    int* row_hi;
+    uint8_t* q_valid;          // n1 rows
+    int32_t* cand_off;         // n1 + 1
+    int32_t* cand_idx;
+};
+size_t sv_bucket_sort_bytes(int n);
+int sv_bucket_sort(svgpu_ctx* ctx, hipStream_t s, const int32_t* node_dev, int n, void* scratch, size_t scratch_bytes, unsigned* keys_out, int* idx_out);
+void sv_bucket_rows(hipStream_t s, const BucketProblem& B);
+void sv_bucket_count(hipStream_t s, const BucketProblem& B);
+void sv_bucket_fill(hipStream_t s, const BucketProblem& B);
+void sv_bucket_gather_rows(hipStream_t s, const BucketProblem& B, uint32_t* qdesc_rows, float* qangle_rows);
+void sv_bucket_scatter(hipStream_t s, const BucketProblem& B, const int32_t* match_rows, int32_t* match_q);

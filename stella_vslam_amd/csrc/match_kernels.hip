@@ -826,6 +826,19 @@ __global__ void k_cand_dist(CandProblem P) {
             if (P.q_xr_tol[q] < err) gated = true;
         }
         if (!gated && P.check_orientation && fabsf(angle_diff(P.q_angle[q], P.t_angle[t])) > 30.0f) gated = true;
+        if (!gated && P.chi_gate) {  // fuse.cc:92-119: chi-square test of the reprojection error at the keypoint's scale
+            const double e_x = P.q_reproj[2 * q] - (double)P.t_xy[2 * t], e_y = P.q_reproj[2 * q + 1] - (double)P.t_xy[2 * t + 1];
+            const double inv_sigma_sq = (double)P.inv_level_sigma_sq[(unsigned)P.t_octave[t]];
+            if (P.chi_t_xright && P.chi_t_xright[t] >= 0.f) {
+                const float e_xr = P.q_reproj_xr[q] - P.chi_t_xright[t];
+                const double err = (e_x * e_x + e_y * e_y) + (double)(e_xr * e_xr);
+                if ((double)7.81473f < err * inv_sigma_sq) gated = true;
+            }
+            else {
+                const double err = e_x * e_x + e_y * e_y;
+                if ((double)5.99146f < err * inv_sigma_sq) gated = true;
+            }
+        }
         P.dist[c] = gated ? 0xFFFFFFFFu : ((uint32_t)hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
     }
 }
@@ -906,8 +919,9 @@ __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __rest
         if (!s_changed) break;
         reset_owner();
         __syncthreads();
-        for (int q = tid; q < P.nq; q += nthr)
-            if (match[q] >= 0) atomicMin(&owner[match[q]], q);
+        if (!P.no_claims)
+            for (int q = tid; q < P.nq; q += nthr)
+                if (match[q] >= 0 && (!P.q_blocks || P.q_blocks[q])) atomicMin(&owner[match[q]], q);
         __syncthreads();
     }
     int local = 0;

@@ -3,156 +3,9 @@
 #include <cmath>
 #include <utility>
 
-#include "svgpu_internal.h"
-#include "match_kernels.h"
-#include "frame_kernels.h"
+#include "svgpu_match_common.h"
 
-namespace {
-
-// bump allocator over ctx->d_scratch (256-byte aligned pieces)
-struct Arena {
-    char* base;
-    size_t off = 0;
-    explicit Arena(void* p) : base((char*)p) {}
-    template <class T>
-    T* take(size_t n) {
-        T* r = (T*)(base + off);
-        off += (n * sizeof(T) + 255) & ~size_t(255);
-        return r;
-    }
-};
-inline size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
-
-// scratch for the angle-bin sorted copies of both sides (see k_bf_binsort)
-inline size_t sort_bytes(int pairs, int cap1, int cap2) {
-    const size_t p = (size_t)pairs;
-    return pad(p * cap1 * 32) + pad(p * cap2 * 32) + 2 * pad(p * cap1 * 4) + 2 * pad(p * cap2 * 4) + 2 * pad(p * 362 * 4) + pad(p * 2 * 4);
-}
-inline void take_sort(Arena& A, BfProblem& P, int pairs, int cap1, int cap2) {
-    const size_t p = (size_t)pairs;
-    P.sd1 = A.take<uint32_t>(p * cap1 * 8);
-    P.sd2 = A.take<uint32_t>(p * cap2 * 8);
-    P.sa1 = A.take<float>(p * cap1);
-    P.si1 = A.take<int>(p * cap1);
-    P.sa2 = A.take<float>(p * cap2);
-    P.si2 = A.take<int>(p * cap2);
-    P.bs1 = A.take<int>(p * 362);
-    P.bs2 = A.take<int>(p * 362);
-    P.prune_ok = A.take<int>(p * 2);
-}
-
-// The frame side of the cell matcher (keypoints that get binned) -- host pointers.
-struct InCellsFrame {
-    const uint8_t* tdesc;
-    const float* t_xy;
-    const int32_t* t_octave;
-    int nt;
-    const uint8_t* occupied;
-    const float* t_angle;
-    const float* t_xright;
-    float min_x, max_x, min_y, max_y;
-    int grid_cols, grid_rows;
-};
-
-// Candidate lists built on the device + candidate matcher.  `stage(A, fresh, P, G)` places the query-side arrays in the
-// arena (uploading or generating them when `fresh`) and points P / G at them; `finish(P)` enqueues extra read-backs.
-// Pass 0 builds the grid and the list sizes and reads the total back; the scratch arena may then have to grow for the
-// lists, which discards its contents, so pass 1 repeats the (cheap) staging and the grid build in the final arena.
-template <class Stage, class Finish>
-int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_bytes, int check_orientation, unsigned thr, float lowe_ratio,
-                  int mode, Stage&& stage, Finish&& finish, int32_t* match_q, int* num_matches) {
-    SV_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const int nt = F.nt, ncell = F.grid_cols * F.grid_rows;
-    const size_t need1 = query_bytes + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 4 * pad((size_t)nt * 4) + pad(nt)
-                         + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4) + 2 * pad((size_t)nt * 4) + 1024;
-    int total = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        const size_t need = need1 + (pass ? 2 * pad((size_t)total * 4) : 0);
-        const bool regrow = need > ctx->scratch_bytes;  // pass 1 without regrowth: the arena of pass 0 is still valid, same layout
-        int rc = sv_ensure_scratch(ctx, need);
-        if (rc) return rc;
-        const bool fresh = !pass || regrow;
-        Arena A(ctx->d_scratch);
-        CandProblem P{};
-        GridProblem G{};
-#define UP(dst, T, src, n)                                                                          \
-    T* dst = nullptr;                                                                               \
-    if (src) {                                                                                      \
-        dst = A.take<T>(n);                                                                         \
-        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
-    }
-        UP(d_t, uint8_t, F.tdesc, (size_t)nt * 32)
-        UP(d_txy, float, F.t_xy, (size_t)nt * 2)
-        UP(d_toct, int32_t, F.t_octave, nt)
-        UP(d_occ, uint8_t, F.occupied, nt)
-        UP(d_ta, float, F.t_angle, nt)
-        UP(d_tx, float, F.t_xright, nt)
-#undef UP
-        rc = stage(A, fresh, P, G);
-        if (rc) return rc;
-        G.t_xy = d_txy;
-        G.t_octave = d_toct;
-        G.nt = nt;
-        G.min_x = F.min_x;
-        G.min_y = F.min_y;
-        G.inv_w = (double)F.grid_cols / (F.max_x - F.min_x);  // float difference, double quotient: data/common.cc:86-87 via camera::base
-        G.inv_h = (double)F.grid_rows / (F.max_y - F.min_y);
-        G.cols = F.grid_cols;
-        G.rows = F.grid_rows;
-        G.cell_of = A.take<int32_t>(nt);
-        G.cell_off = A.take<int32_t>(ncell + 1);
-        G.cell_items = A.take<int32_t>(nt);
-        G.nq = nq;
-        G.cand_off = A.take<int32_t>(nq + 1);
-        P.match_q = A.take<int32_t>(nq);
-        P.num = A.take<int32_t>(1);
-        int* owner = A.take<int>(nt);
-        int* match = A.take<int>(nq);
-        unsigned* mdist = A.take<unsigned>(nt);
-        if (fresh) sv_launch_grid_build(s, G);
-        if (!pass) {
-            SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
-            SV_HIP(ctx, hipStreamSynchronize(s));
-            if (total == 0) {
-                rc = finish(P);
-                if (rc) return rc;
-                SV_HIP(ctx, hipStreamSynchronize(s));
-                return SVGPU_OK;
-            }
-            continue;
-        }
-        G.cand_idx = A.take<int32_t>(total);
-        P.dist = A.take<uint32_t>(total);
-        sv_launch_grid_fill(s, G);
-        P.tdesc = (const uint32_t*)d_t;
-        P.t_octave = d_toct;
-        P.nq = nq;
-        P.nt = nt;
-        P.cand_off = G.cand_off;
-        P.cand_idx = G.cand_idx;
-        P.cand_skip = nullptr;
-        P.occupied = d_occ;
-        P.t_angle = d_ta;
-        P.check_orientation = check_orientation;
-        P.t_xright = P.q_xright ? d_tx : nullptr;
-        P.thr = thr;
-        P.lowe_ratio = lowe_ratio;
-        P.mode = mode;
-        sv_launch_cand(ctx, s, P, owner, match, mdist);
-        SV_HIP(ctx, hipGetLastError());
-        int32_t num = 0;
-        SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
-        rc = finish(P);
-        if (rc) return rc;
-        SV_HIP(ctx, hipStreamSynchronize(s));
-        *num_matches = num;
-    }
-    return SVGPU_OK;
-}
-
-}  // namespace
+using namespace svm;
 
 extern "C" {
 

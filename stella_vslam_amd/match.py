@@ -180,3 +180,142 @@ class stereo:
                                            len(self.kr), C.c_float(self.focal_x_baseline_), C.c_float(self.true_baseline_),
                                            _p(xr), _p(dp)), "svgpu_stereo_match")
         return xr[:n].copy(), dp[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------- function-specific matchers
+# Flat-array mirrors of the reference methods whose candidate generation and gates run on the device (include/svgpu.h,
+# "function-specific matchers").  Argument names are the C ABI's; `cam` is a camera.base (its svgpu_camera carries img_bounds_).
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def _call(ctx, fn_name, args):
+    ctx.check(getattr(lib(), fn_name)(ctx.handle, *args), fn_name)
+
+
+class projection_flat(base):
+    """match::projection's methods other than match_frame_and_landmarks, on flat arrays (match/projection.cc:95-629)."""
+
+    def match_current_and_last_frames(self, cam, rot_cw, trans_cw, rot_lw, trans_lw, pos_w, valid, lm_desc, octave_last, angle_last,
+                                      scale_factors, margin, tdesc, t_xy, t_octave, t_angle, occupied=None, t_xright=None,
+                                      lm_has_observation=None, is_monocular=True, true_baseline=0.0, grid_cols=64, grid_rows=48):
+        pw = _f64(pos_w, (-1, 3))
+        n, sf = len(pw), _c(scale_factors, np.float32)
+        td = _c(tdesc, np.uint8)
+        out, num = np.full(n, -1, np.int32), C.c_int(0)
+        a = [C.byref(cam.c_), _p(_f64(rot_cw)), _p(_f64(trans_cw)), _p(_f64(rot_lw)), _p(_f64(trans_lw)), int(is_monocular), C.c_float(true_baseline),
+             n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(lm_desc, np.uint8)), _p(_c(octave_last, np.int32)), _p(_c(angle_last, np.float32)),
+             _p(_c(lm_has_observation, np.uint8)), len(sf), _p(sf), C.c_float(margin), _p(td), _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)),
+             _p(_c(t_angle, np.float32)), len(td), _p(_c(occupied, np.uint8)), _p(_c(t_xright, np.float32)), grid_cols, grid_rows,
+             int(self.check_orientation_), _p(out), C.byref(num)]
+        keep = a  # noqa: F841  (the temporaries stay alive until the call returns)
+        _call(self.ctx, "svgpu_match_current_and_last_frames", a)
+        return out, num.value
+
+    def match_frame_and_keyframe(self, cam, rot_cw, trans_cw, pos_w, valid, min_valid_dist, max_valid_dist, lm_desc, angle_kf, scale_factors,
+                                 log_scale_factor, margin, hamm_dist_thr, tdesc, t_xy, t_octave, t_angle, occupied=None, grid_cols=64, grid_rows=48):
+        pw = _f64(pos_w, (-1, 3))
+        n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+        out, num = np.full(n, -1, np.int32), C.c_int(0)
+        _call(self.ctx, "svgpu_match_frame_and_keyframe_projection",
+              [C.byref(cam.c_), _p(_f64(rot_cw)), _p(_f64(trans_cw)), n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(min_valid_dist, np.float32)),
+               _p(_c(max_valid_dist, np.float32)), _p(_c(lm_desc, np.uint8)), _p(_c(angle_kf, np.float32)), len(sf), _p(sf), C.c_float(log_scale_factor),
+               C.c_float(margin), C.c_uint(hamm_dist_thr), _p(td), _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)), _p(_c(t_angle, np.float32)),
+               len(td), _p(_c(occupied, np.uint8)), grid_cols, grid_rows, int(self.check_orientation_), _p(out), C.byref(num)])
+        return out, num.value
+
+    def match_by_Sim3_transform(self, cam, sim3_cw, pos_w, valid, min_valid_dist, max_valid_dist, mean_normal, lm_desc, scale_factors, log_scale_factor,
+                                margin, tdesc, t_xy, t_octave, occupied=None, grid_cols=64, grid_rows=48):
+        pw = _f64(pos_w, (-1, 3))
+        n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+        out, num = np.full(n, -1, np.int32), C.c_int(0)
+        _call(self.ctx, "svgpu_match_by_sim3_transform",
+              [C.byref(cam.c_), _p(_f64(sim3_cw)), n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(min_valid_dist, np.float32)), _p(_c(max_valid_dist, np.float32)),
+               _p(_f64(mean_normal)), _p(_c(lm_desc, np.uint8)), len(sf), _p(sf), C.c_float(log_scale_factor), C.c_float(margin), _p(td),
+               _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)), len(td), _p(_c(occupied, np.uint8)), grid_cols, grid_rows, _p(out), C.byref(num)])
+        return out, num.value
+
+    def match_keyframes_mutually(self, cam1, cam2, rot_1w, trans_1w, rot_2w, trans_2w, s_12, rot_12, trans_12, kf1, kf2, scale_factors,
+                                 log_scale_factor, margin, grid_cols=64, grid_rows=48):
+        """kf1 / kf2: dicts with pos_w, valid, min_valid_dist, max_valid_dist, lm_desc (the keyframe's landmarks, one per keypoint) and
+        desc, xy, octave (its keypoints)."""
+        sf = _c(scale_factors, np.float32)
+
+        def side(k):
+            pw = _f64(k["pos_w"], (-1, 3))
+            return [len(pw), _p(pw), _p(_c(k["valid"], np.uint8)), _p(_c(k["min_valid_dist"], np.float32)), _p(_c(k["max_valid_dist"], np.float32)),
+                    _p(_c(k["lm_desc"], np.uint8)), _p(_c(k["desc"], np.uint8)), _p(_c(k["xy"], np.float32)), _p(_c(k["octave"], np.int32))]
+        n1, n2 = len(kf1["pos_w"]), len(kf2["pos_w"])
+        m21, m12, mut, num = np.full(n1, -1, np.int32), np.full(n2, -1, np.int32), np.full(n1, -1, np.int32), C.c_int(0)
+        _call(self.ctx, "svgpu_match_keyframes_mutually",
+              [C.byref(cam1.c_), C.byref(cam2.c_), _p(_f64(rot_1w)), _p(_f64(trans_1w)), _p(_f64(rot_2w)), _p(_f64(trans_2w)), C.c_float(s_12), _p(_f64(rot_12)),
+               _p(_f64(trans_12))] + side(kf1) + side(kf2) + [len(sf), _p(sf), C.c_float(log_scale_factor), C.c_float(margin), grid_cols, grid_rows, _p(m21),
+                                                             _p(m12), _p(mut), C.byref(num)])
+        return m21, m12, mut, num.value
+
+
+class fuse:
+    """match/fuse.h: detect_duplication on flat arrays (match/fuse.cc:11-154)."""
+
+    def __init__(self, lowe_ratio: float = 0.6, ctx: Context | None = None):
+        self.lowe_ratio_ = float(lowe_ratio)
+        self.ctx = ctx or Context()
+
+    def detect_duplication(self, cam, rot_cw, trans_cw, pos_w, valid, min_valid_dist, max_valid_dist, mean_normal, lm_desc, scale_factors,
+                           inv_level_sigma_sq, log_scale_factor, margin, tdesc, t_xy, t_octave, t_xright=None, do_reprojection_matching=False,
+                           grid_cols=64, grid_rows=48):
+        pw = _f64(pos_w, (-1, 3))
+        n, sf, td = len(pw), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+        out, num = np.full(n, -1, np.int32), C.c_int(0)
+        _call(self.ctx, "svgpu_fuse_detect_duplication",
+              [C.byref(cam.c_), _p(_f64(rot_cw)), _p(_f64(trans_cw)), n, _p(pw), _p(_c(valid, np.uint8)), _p(_c(min_valid_dist, np.float32)),
+               _p(_c(max_valid_dist, np.float32)), _p(_f64(mean_normal)), _p(_c(lm_desc, np.uint8)), len(sf), _p(sf), _p(_c(inv_level_sigma_sq, np.float32)),
+               C.c_float(log_scale_factor), C.c_float(margin), int(do_reprojection_matching), _p(td), _p(_c(t_xy, np.float32)), _p(_c(t_octave, np.int32)),
+               _p(_c(t_xright, np.float32)), len(td), grid_cols, grid_rows, _p(out), C.byref(num)])
+        return out, num.value
+
+
+def reproject_to_bearing(cam, rot_cw, trans_cw, pos_w):
+    """camera::*::reproject_to_bearing -> (bearing 3, valid)."""
+    b, v = np.zeros(3), C.c_int(0)
+    lib().svgpu_reproject_to_bearing(C.byref(cam.c_), _p(_f64(rot_cw)), _p(_f64(trans_cw)), _p(_f64(pos_w)), _p(b), C.byref(v))
+    return b, bool(v.value)
+
+
+def match_for_triangulation(ctx, lowe_ratio, check_orientation, desc1, angle1, octave1, bearings1, has_lm1, desc2, angle2, bearings2, has_lm2, E_12,
+                            epipole_in_2, valid_epipole, scale_factors, residual_rad_thr, xright1=None, xright2=None, node1=None, node2=None):
+    """robust::match_for_triangulation (node1 = node2 = None) / bow_tree::match_for_triangulation (bow_feat_vec_ node ids given)."""
+    d1, d2, sf = _c(desc1, np.uint8), _c(desc2, np.uint8), _c(scale_factors, np.float32)
+    out, num = np.full(len(d1), -1, np.int32), C.c_int(0)
+    ctx.check(lib().svgpu_match_for_triangulation(
+        ctx.handle, _p(d1), _p(_c(angle1, np.float32)), _p(_c(octave1, np.int32)), _p(_f64(bearings1)), _p(_c(has_lm1, np.uint8)), _p(_c(xright1, np.float32)),
+        len(d1), _p(d2), _p(_c(angle2, np.float32)), _p(_f64(bearings2)), _p(_c(has_lm2, np.uint8)), _p(_c(xright2, np.float32)), len(d2),
+        _p(_c(node1, np.int32)), _p(_c(node2, np.int32)), _p(_f64(E_12)), _p(_f64(epipole_in_2)), int(valid_epipole), _p(sf), len(sf),
+        C.c_float(residual_rad_thr), C.c_float(lowe_ratio), int(check_orientation), _p(out), C.byref(num)), "svgpu_match_for_triangulation")
+    return out, num.value
+
+
+class bow_tree(base):
+    """match/bow_tree.h on flat arrays: side 1 hands its landmarks over (the keyframe), side 2 receives them (frame / other keyframe);
+    node ids = bow_feat_vec_ membership of every keypoint (data.bow_vocabulary.descend)."""
+
+    def match(self, desc1, angle1, valid1, node1, desc2, angle2, node2, valid2=None, occupied2=None):
+        d1, d2 = _c(desc1, np.uint8), _c(desc2, np.uint8)
+        out, num = np.full(len(d1), -1, np.int32), C.c_int(0)
+        self.ctx.check(lib().svgpu_bow_match(self.ctx.handle, _p(d1), _p(_c(angle1, np.float32)), _p(_c(valid1, np.uint8)), _p(_c(node1, np.int32)),
+                                             len(d1), _p(d2), _p(_c(angle2, np.float32)), _p(_c(valid2, np.uint8)), _p(_c(node2, np.int32)), len(d2),
+                                             _p(_c(occupied2, np.uint8)), C.c_float(self.lowe_ratio_), int(self.check_orientation_), _p(out),
+                                             C.byref(num)), "svgpu_bow_match")
+        return out, num.value
+
+    # bow_tree.cc:169-256: matched_lms_in_frm[match[i]] = keyfrm landmark i
+    match_frame_and_keyframe = match
+    # bow_tree.cc:258-366 (valid2 = keypoints of keyframe 2 that hold a live landmark)
+    match_keyframes = match
+
+    def match_for_triangulation(self, **kw):
+        return match_for_triangulation(self.ctx, self.lowe_ratio_, self.check_orientation_, **kw)

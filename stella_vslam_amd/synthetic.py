@@ -298,3 +298,90 @@ def ba_scene_large(num_kf: int = 500, num_lm: int = 200000, obs_per_lm: int = 6,
     intr = np.tile(np.array([fx, fy, cx, cy, 0.0]), (num_kf, 1))
     return dict(pose_cw=pose_init, pose_gt=pose_gt, pose_fixed=fixed, points=pts_init, points_gt=pts, obs_pose=obs_pose,
                 obs_point=obs_point, obs_uvr=obs_uvr, obs_inv_sigma_sq=inv_sigma_sq, obs_huber=huber, intr=intr)
+
+
+# --------------------------------------------------------------------------------------------- map scenes for the matchers
+
+def _look_at(center, target):
+    z = target - center
+    z /= np.linalg.norm(z)
+    x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R_cw = np.stack([x, y, z], 0)
+    return R_cw, -R_cw @ center
+
+
+def orb_tables(scale_factor: float = 1.2, num_levels: int = 8):
+    """orb_params tables by the reference's fp32 recurrences (feature/orb_params.cc:41-71)."""
+    sf = np.ones(num_levels, np.float32)
+    for l in range(1, num_levels):
+        sf[l] = np.float32(scale_factor) * sf[l - 1]
+    inv_sf = np.float32(1.0) / sf
+    sigma_sq = sf * sf
+    return dict(scale_factors=sf, inv_scale_factors=inv_sf, level_sigma_sq=sigma_sq, inv_level_sigma_sq=np.float32(1.0) / sigma_sq,
+                log_scale_factor=float(np.log(np.float32(scale_factor))), num_levels=num_levels)
+
+
+def map_scene(seed: int = 7, n_lm: int = 1500, n_extra: int = 600, stereo: bool = False, width: int = 752, height: int = 480,
+              baseline_shift: float = 0.35, pixel_noise: float = 1.0, flip_bits: int = 36, obs_prob: float = 0.8, num_levels: int = 8) -> dict:
+    """Two views of one set of landmarks, flattened the way the matcher entry points take them (SURVEY 8(d) has no matcher
+    workload of its own; this is the smallest map that exercises every gate of match::*):
+      * cameras 1 and 2 (EuRoC pinhole intrinsics, no distortion) `baseline_shift` metres apart, looking at a slab of points
+      * every landmark has a random 256-bit descriptor; a view that observes it (probability `obs_prob`) gets a keypoint at the
+        projection + N(0, pixel_noise) px, an octave around the level its depth predicts, an angle that differs by a few degrees
+        between the views, and the landmark's descriptor with up to `flip_bits` random bit flips
+      * `n_extra` clutter keypoints per view (random position / descriptor / octave)
+    Returns dict(views=[v1, v2], landmarks=..., tables=orb tables, K=(fx, fy, cx, cy, fxb)); a view holds rot_cw, trans_cw, xy (n x 2
+    f32 undistorted), octave, angle, desc, x_right (stereo) and lm (index of the landmark its keypoint observes or -1)."""
+    rng = np.random.default_rng(seed)
+    T = orb_tables(1.2, num_levels)
+    fx = fy = 458.654
+    cx, cy = 367.215, 248.375
+    fxb = fx * 0.11 if stereo else 0.0
+    pts = np.stack([rng.uniform(-3.2, 3.2, n_lm), rng.uniform(-2.0, 2.0, n_lm), rng.uniform(4.0, 9.0, n_lm)], 1)
+    lm_desc = rng.integers(0, 256, (n_lm, 32), dtype=np.uint8)
+    centers = [np.array([0.0, 0.0, 0.0]), np.array([baseline_shift, 0.03, 0.06])]
+    target = np.array([0.0, 0.0, 6.5])
+    views = []
+    base_angle = rng.uniform(0, 360, n_lm).astype(np.float32)
+    ref_dist = np.linalg.norm(pts - centers[0], axis=1)
+    ref_oct = rng.integers(0, num_levels - 2, n_lm)
+    max_valid = (ref_dist * T["scale_factors"][ref_oct]).astype(np.float32)
+    min_valid = (max_valid * T["inv_scale_factors"][num_levels - 1]).astype(np.float32)
+    for v in range(2):
+        R, t = _look_at(centers[v], target)
+        pc = pts @ R.T + t
+        u = fx * pc[:, 0] / pc[:, 2] + cx
+        w = fy * pc[:, 1] / pc[:, 2] + cy
+        inside = (pc[:, 2] > 0.1) & (u > 5) & (u < width - 5) & (w > 5) & (w < height - 5)
+        seen = inside & (rng.uniform(0, 1, n_lm) < obs_prob)
+        ids = np.flatnonzero(seen)
+        dist = np.linalg.norm(pts[ids] - centers[v], axis=1)
+        pred = np.ceil(np.log(max_valid[ids] / dist) / T["log_scale_factor"]).astype(int)
+        octave = np.clip(pred + rng.integers(-1, 2, len(ids)), 0, num_levels - 1)
+        xy = np.stack([u[ids], w[ids]], 1) + rng.normal(0, pixel_noise, (len(ids), 2)) * T["scale_factors"][octave][:, None]
+        angle = np.mod(base_angle[ids] + rng.normal(0, 6.0, len(ids)), 360.0)
+        desc = lm_desc[ids].copy()
+        nflip = rng.integers(0, flip_bits + 1, len(ids))
+        for k in range(len(ids)):
+            bits = rng.choice(256, nflip[k], replace=False)
+            np.bitwise_xor.at(desc[k], bits >> 3, (1 << (bits & 7)).astype(np.uint8))
+        xr = (xy[:, 0] - fxb / pc[ids, 2] + rng.normal(0, 0.5, len(ids))) if stereo else np.full(len(ids), -1.0)
+        if stereo:
+            xr[rng.uniform(0, 1, len(ids)) < 0.25] = -1.0   # keypoints without a stereo match
+        # clutter
+        exy = np.stack([rng.uniform(0, width, n_extra), rng.uniform(0, height, n_extra)], 1)
+        all_xy = np.concatenate([xy, exy]).astype(np.float32)
+        all_oct = np.concatenate([octave, rng.integers(0, num_levels, n_extra)]).astype(np.int32)
+        all_ang = np.concatenate([angle, rng.uniform(0, 360, n_extra)]).astype(np.float32)
+        all_desc = np.concatenate([desc, rng.integers(0, 256, (n_extra, 32), dtype=np.uint8)])
+        all_xr = np.concatenate([xr, np.full(n_extra, -1.0)]).astype(np.float32)
+        all_lm = np.concatenate([ids, np.full(n_extra, -1)]).astype(np.int64)
+        perm = rng.permutation(len(all_xy))   # keypoint order is unrelated to landmark order
+        views.append(dict(rot_cw=R, trans_cw=t, center=centers[v], xy=all_xy[perm], octave=all_oct[perm], angle=all_ang[perm],
+                          desc=np.ascontiguousarray(all_desc[perm]), x_right=all_xr[perm], lm=all_lm[perm]))
+    normal = pts - centers[0]
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    return dict(views=views, tables=T, K=(fx, fy, cx, cy, fxb), width=width, height=height,
+                landmarks=dict(pos_w=pts, desc=lm_desc, min_valid_dist=min_valid, max_valid_dist=max_valid, mean_normal=normal))
