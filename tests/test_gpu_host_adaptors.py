@@ -17,7 +17,20 @@ def test_cpp_adaptors_end_to_end():
     assert "adaptors ok" in out.stdout
 
 
+@pytest.mark.gpu
+def test_cpp_drop_in_classes_on_a_toy_map():
+    """host/drop_in: match::hip::{robust, bow_tree, projection, fuse, area} and optimize::local_bundle_adjuster_hip with the reference's own
+    signatures (data::frame&, shared_ptr<keyframe>, map_database*), driven on a toy map built from the stand-in data:: classes."""
+    exe = ROOT / "stella_vslam_amd" / "host" / "test_drop_in"
+    if not exe.exists():
+        subprocess.check_call(["make", "-C", str(exe.parent)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "drop-in classes ok" in out.stdout
+
+
 def test_cpp_adaptors_compile_against_standin_headers():
     """CPU-only: the adaptor library and its test program build with plain g++ (no OpenCV / g2o / HIP headers)."""
     subprocess.check_call(["make", "-C", str(ROOT / "stella_vslam_amd" / "host"), "-B"], stdout=subprocess.DEVNULL)
     assert (ROOT / "stella_vslam_amd" / "host" / "libsvgpu_host.so").exists()
+    assert (ROOT / "stella_vslam_amd" / "host" / "test_drop_in").exists()
