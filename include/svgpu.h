@@ -429,6 +429,16 @@ int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_ke
                        int n_left, const svgpu_keypoint* kps_right, const uint8_t* desc_right, int n_right,
                        float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths);
 
+/* The same for `pairs` stereo pairs at once, everything resident in HBM (BASELINE config 4: KITTI stereo batches): the keypoints /
+ * descriptors / counts are the outputs of svgpu_orb_extract_batch_device on ctx_left and ctx_right (pair p at p * cap records,
+ * count at n_*_dev[p * n_stride]), the pyramids those calls left in the two contexts.  The 2 x median correlation filter runs on the
+ * device as well (rank-size/2 value by bisection).  stereo_x_right_dev / depths_dev: pairs * cap floats (-1 = no match).
+ * Asynchronous on `stream` (NULL = ctx_left's); the caller orders it behind both extractions. */
+int svgpu_stereo_match_batch_device(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, int pairs, const svgpu_keypoint* kps_left_dev, const uint8_t* desc_left_dev,
+                                    const int32_t* n_left_dev, const svgpu_keypoint* kps_right_dev, const uint8_t* desc_right_dev,
+                                    const int32_t* n_right_dev, int cap, int n_stride, float focal_x_baseline, float true_baseline,
+                                    float* stereo_x_right_dev, float* depths_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ local BA
  * Stands behind  stella_vslam::optimize::local_bundle_adjuster::optimize(map_db, curr_keyfrm, force_stop_flag)
  * (optimize/local_bundle_adjuster.h:23; g2o implementation optimize/local_bundle_adjuster_g2o.cc:36-431).

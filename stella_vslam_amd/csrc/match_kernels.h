@@ -113,8 +113,16 @@ struct StereoProblem {
     float* xr;    // nl
     float* depth; // nl
     float* corr;  // nl: best L1 correlation (integer valued) or -1
+    // batched, device-resident form (svgpu_stereo_match_batch_device): pair p = blockIdx.y reads its keypoints / descriptors at
+    // p * cap, its counts at n*_dev[p * n_stride], its pyramids at p * frame strides; all zero / null = one pair described above
+    const int32_t* nl_dev;
+    const int32_t* nr_dev;
+    int n_stride, cap;
+    size_t img_stride_l, img_stride_r;   // level 0 (the callers' images)
+    size_t pyr_stride_l, pyr_stride_r;   // levels >= 1 (the extractors' pyramid blocks)
 };
-void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P);
+void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P, int pairs = 1);
+void sv_launch_stereo_median(hipStream_t s, const StereoProblem& P, int pairs);  // 2 x median correlation filter (stereo.cc:94-113) on the device
 
 void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out);
 void sv_launch_hamming_matrix(hipStream_t s, const uint32_t* d1, int n1, const uint32_t* d2, int n2, uint16_t* out);

@@ -1141,6 +1141,13 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 }
 __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
     const int il = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // scalar: per-keypoint data via scalar loads
+    const int pair = blockIdx.y;
+    if (P.nl_dev) {  // batched form: this pair's slice of every array
+        P.nl = min(P.nl_dev[(size_t)pair * P.n_stride], P.cap);
+        P.nr = min(P.nr_dev[(size_t)pair * P.n_stride], P.cap);
+        const size_t o = (size_t)pair * P.cap;
+        P.kl += o, P.kr += o, P.dl += o * 8, P.dr += o * 8, P.xr += o, P.depth += o, P.corr += o;
+    }
     if (il >= P.nl) return;
     const svgpu_keypoint k = P.kl[il];
     const int lvl = k.octave;
@@ -1172,8 +1179,8 @@ __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
         const int ini_x = sxr - 10, end_x = sxr + 10;
         const bool ok = !(ini_x < 0 || P.w[lvl] <= end_x) && syl - 5 >= 0 && syl + 5 < P.h[lvl] && sxl - 5 >= 0 && sxl + 5 < P.w[lvl];
         if (ok) {
-            const uint8_t* PL = P.lev_l[lvl];
-            const uint8_t* PR = P.lev_r[lvl];
+            const uint8_t* PL = P.lev_l[lvl] + (size_t)pair * (lvl == 0 ? P.img_stride_l : P.pyr_stride_l);
+            const uint8_t* PR = P.lev_r[lvl] + (size_t)pair * (lvl == 0 ? P.img_stride_r : P.pyr_stride_r);
             const int pl = P.pitch_l[lvl], pr = P.pitch_r[lvl];
             const int lc = PL[__umul24(syl, pl) + sxl];
             // this lane's (up to) two patch pixels
@@ -1241,11 +1248,55 @@ __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
     }
 }
 
+// stereo.cc:94-113 per pair: median of the kept correlations = the element of rank size / 2 in ascending order; matches whose
+// correlation exceeds twice the median are dropped.  Correlations are integers below 2^16 (121 absolute differences of bytes, twice),
+// so the rank-size/2 VALUE is found by bisection on the value with a counting pass per step: no sort, one workgroup per pair.
+__global__ __launch_bounds__(256) void k_stereo_median(StereoProblem P) {
+    __shared__ int s_cnt[4];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int nl = P.nl_dev ? min(P.nl_dev[(size_t)pair * P.n_stride], P.cap) : P.nl;
+    const size_t o = P.nl_dev ? (size_t)pair * P.cap : 0;
+    float* xr = P.xr + o;
+    float* depth = P.depth + o;
+    const float* corr = P.corr + o;
+    auto count_le = [&](int v) -> int {  // kept matches with correlation <= v (v < 0: all kept matches)
+        int c = 0;
+        for (int i = tid; i < nl; i += 256)
+            if (xr[i] != -1.0f || depth[i] != -1.0f) c += (v < 0 || (int)corr[i] <= v) ? 1 : 0;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
+        __syncthreads();
+        return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    };
+    const int kept = count_le(-1);
+    if (kept == 0) return;
+    const int rank = kept / 2;  // 0-based rank of the median in ascending order
+    int lo = 0, hi = 1 << 17;   // smallest v with count_le(v) > rank
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (count_le(mid) > rank) hi = mid;
+        else lo = mid + 1;
+    }
+    const float thr = (float)(2.0 * (double)(float)lo);
+    // The reference walks the sorted list from the median on, so only elements at or behind the median rank are tested; an element
+    // in front of it has a correlation <= the median and can never exceed twice the (non-negative) median.
+    for (int i = tid; i < nl; i += 256)
+        if ((xr[i] != -1.0f || depth[i] != -1.0f) && thr < (float)(int)corr[i]) {
+            xr[i] = -1.0f;
+            depth[i] = -1.0f;
+        }
+}
+
 }  // namespace
 
-void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P) {
+void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P, int pairs) {
     SvProfScope ps(ctx, s, "k_stereo");
-    if (P.nl > 0) hipLaunchKernelGGL(k_stereo, dim3((P.nl + 3) / 4), dim3(256), 0, s, P);
+    const int nl = P.nl_dev ? P.cap : P.nl;
+    if (nl > 0 && pairs > 0) hipLaunchKernelGGL(k_stereo, dim3((nl + 3) / 4, pairs), dim3(256), 0, s, P);
+}
+void sv_launch_stereo_median(hipStream_t s, const StereoProblem& P, int pairs) {
+    if (pairs > 0) hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, P);
 }
 
 void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out) {

@@ -658,25 +658,78 @@ int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_ke
     P.max_disp = focal_x_baseline / true_baseline;    // stereo.cc:18
     P.thr = 75;                                       // (HAMMING_DIST_THR_HIGH + HAMMING_DIST_THR_LOW) / 2, stereo.h:99
     sv_launch_stereo(ctx, s, P);
+    sv_launch_stereo_median(s, P, 1);  // median filter of the correlations (stereo.cc:94-113) on the device
     SV_HIP(ctx, hipGetLastError());
-    std::vector<float> corr(n_left);
     SV_HIP(ctx, hipMemcpyAsync(stereo_x_right, P.xr, (size_t)n_left * 4, hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipMemcpyAsync(depths, P.depth, (size_t)n_left * 4, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(corr.data(), P.corr, (size_t)n_left * 4, hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipStreamSynchronize(s));
-    // median filter of the correlations (stereo.cc:94-113); std::pair<int, int> as in the reference
-    std::vector<std::pair<int, int>> correlation_and_idx_left;
-    for (int i = 0; i < n_left; ++i)
-        if (stereo_x_right[i] != -1.0f || depths[i] != -1.0f) correlation_and_idx_left.emplace_back((int)corr[i], i);
-    std::sort(correlation_and_idx_left.begin(), correlation_and_idx_left.end());
-    const size_t median_i = correlation_and_idx_left.size() / 2;
-    const float median_correlation = correlation_and_idx_left.empty() ? 0.0f : (float)correlation_and_idx_left[median_i].first;
-    const float correlation_thr = (float)(2.0 * median_correlation);
-    for (size_t i = median_i; i < correlation_and_idx_left.size(); ++i)
-        if (correlation_thr < (float)correlation_and_idx_left[i].first) {
-            stereo_x_right[correlation_and_idx_left[i].second] = -1;
-            depths[correlation_and_idx_left[i].second] = -1;
+    return SVGPU_OK;
+}
+
+int svgpu_stereo_match_batch_device(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, int pairs, const svgpu_keypoint* kps_left_dev, const uint8_t* desc_left_dev,
+                                    const int32_t* n_left_dev, const svgpu_keypoint* kps_right_dev, const uint8_t* desc_right_dev,
+                                    const int32_t* n_right_dev, int cap, int n_stride, float focal_x_baseline, float true_baseline,
+                                    float* stereo_x_right_dev, float* depths_dev, void* stream) {
+    svgpu_ctx* ctx = ctx_left;
+    if (!ctx_left || !ctx_right || pairs < 0 || cap < 0 || cap > 65535 || n_stride < 1 || !(true_baseline > 0.f)
+        || (pairs > 0 && cap > 0 && (!kps_left_dev || !desc_left_dev || !n_left_dev || !kps_right_dev || !desc_right_dev || !n_right_dev || !stereo_x_right_dev || !depths_dev)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match_batch_device: bad arguments");
+    if (pairs == 0 || cap == 0) return SVGPU_OK;
+    const OrbConfig& CL = ctx_left->orb;
+    const OrbConfig& CR = ctx_right->orb;
+    if (!CL.configured || !CR.configured || ctx_left->last_batch < pairs || ctx_right->last_batch < pairs)
+        return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_stereo_match_batch_device: both contexts need a previous batch extraction of >= `pairs` frames");
+    if (ctx_left->device != ctx_right->device || CL.width != CR.width || CL.height != CR.height || CL.num_levels != CR.num_levels
+        || CL.scale_factor != CR.scale_factor)
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match_batch_device: the two extractors must share device, geometry and ORB parameters");
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = sv_ensure_scratch(ctx, pad((size_t)pairs * cap * 4) + 256);
+    if (rc) return rc;
+    Arena A(ctx->d_scratch);
+    StereoProblem P{};
+    P.kl = kps_left_dev;
+    P.kr = kps_right_dev;
+    P.dl = (const uint32_t*)desc_left_dev;
+    P.dr = (const uint32_t*)desc_right_dev;
+    P.nl_dev = n_left_dev;
+    P.nr_dev = n_right_dev;
+    P.n_stride = n_stride;
+    P.cap = cap;
+    P.xr = stereo_x_right_dev;
+    P.depth = depths_dev;
+    P.corr = A.take<float>((size_t)pairs * cap);
+    P.num_levels = CL.num_levels;
+    float inv[SV_MAX_LEVELS];
+    svgpu_orb_scale_tables(CL.scale_factor, CL.num_levels, P.sf, inv, nullptr, nullptr);
+    for (int l = 0; l < CL.num_levels; ++l) {
+        P.isf[l] = inv[l];
+        P.w[l] = CL.levels[l].w;
+        P.h[l] = CL.levels[l].h;
+        if (l == 0) {
+            P.lev_l[0] = ctx_left->last_imgs;
+            P.pitch_l[0] = ctx_left->last_row_stride;
+            P.lev_r[0] = ctx_right->last_imgs;
+            P.pitch_r[0] = ctx_right->last_row_stride;
         }
+        else {
+            P.lev_l[l] = ctx_left->d_pyr + CL.levels[l].pyr_off;
+            P.pitch_l[l] = CL.levels[l].pitch;
+            P.lev_r[l] = ctx_right->d_pyr + CR.levels[l].pyr_off;
+            P.pitch_r[l] = CR.levels[l].pitch;
+        }
+    }
+    P.img_stride_l = ctx_left->last_frame_stride;
+    P.img_stride_r = ctx_right->last_frame_stride;
+    P.pyr_stride_l = CL.pyr_frame_bytes;
+    P.pyr_stride_r = CR.pyr_frame_bytes;
+    P.fxb = focal_x_baseline;
+    P.min_disp = 0.0f;
+    P.max_disp = focal_x_baseline / true_baseline;
+    P.thr = 75;
+    sv_launch_stereo(ctx, s, P, pairs);
+    sv_launch_stereo_median(s, P, pairs);
+    SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
 }
 

@@ -251,3 +251,42 @@ def test_match_in_cells_builds_the_reference_candidate_lists(M, ctx, mode, seed)
     assert np.array_equal(got2, exp)
     none, n0 = M.projection(0.8, True, ctx).match_in_cells(d0, q_xy + 5000.0, q_margin, d1, t_xy, k1["octave"], bounds, mode, 100)
     assert n0 == 0 and (none == -1).all()
+
+
+def test_stereo_batch_device_matches_oracle():
+    """BASELINE config 4 shape: stereo pairs at the KITTI geometry (1241 x 376, ini_fast_threshold 12), both images of every pair extracted in
+    device-resident batches on two contexts, match::stereo::compute for all pairs in ONE launch (+ the median filter on the device).
+    x_right / depth bits equal the oracle's per pair; the oracle runs on its own extraction and its own pyramids."""
+    from stella_vslam_amd import feature, pipeline
+    W, H, B, disp = 1241, 376, 3, 17
+    big = S.frame_sequence(B, W + 64, H, seed=0x5EED + 4)
+    left = np.ascontiguousarray(big[:, :, 8:8 + W])
+    right = np.ascontiguousarray(big[:, :, 8 + disp:8 + disp + W])
+    p = feature.orb_params(ini_fast_thr=12)
+    el, er = pipeline.BatchExtractor(W, H, B, p), pipeline.BatchExtractor(W, H, B, p)
+    el.upload(left)
+    er.upload(right)
+    el.extract()
+    er.extract()
+    er.ctx.synchronize()
+    fxb, tb = 718.856 * 0.537, 0.537   # KITTI 00-02: fx = 718.856, baseline 0.537 m
+    xr_t, dp_t = pipeline.stereo_batch(el, er, fxb, tb)
+    outl, outr = el.download(), er.download()
+    xr = xr_t.cpu().numpy().reshape(B, el.cap)
+    dp = dp_t.cpu().numpy().reshape(B, el.cap)
+    sizes = O.level_sizes(W, H)
+    for b in range(B):
+        pyr = []
+        for img in (left[b], right[b]):
+            lv = [img]
+            for l in range(1, 8):
+                lv.append(O.resize_linear(lv[-1], *sizes[l]))
+            pyr.append(lv)
+        ko, do, _ = O.orb_extract(left[b], ini_thr=12)
+        kro, dro, _ = O.orb_extract(right[b], ini_thr=12)
+        assert np.array_equal(outl[b][0], ko) and np.array_equal(outl[b][1], do) and np.array_equal(outr[b][0], kro)
+        xo, dpo = O.stereo_match(ko, do, kro, dro, pyr[0], pyr[1], fxb, tb)
+        n = len(ko)
+        assert (xo >= 0).sum() > 800
+        assert np.array_equal(xr[b, :n], xo) and np.array_equal(dp[b, :n], dpo)
+        assert abs(np.median((ko["x"] - xo)[xo >= 0]) - disp) < 0.1
