@@ -9,18 +9,30 @@ One "step" = one pass of the front end over a batch of B synthetic frames reside
 Frames shard one batch per GPU (no data-path collective; RCCL is used for the barrier and the MAX of the
 per-rank times only) -> "scaling": "weak".  Rank 0 prints ONE JSON line.
 
+`python bench.py --gpus N` without a torchrun environment starts its own N ranks (torch.distributed.run, 127.0.0.1) and
+relays rank 0's line.
+
 Extra objects on that line:
-  roofline      dominant kernel (picked by a per-kernel HIP-event pre-pass), timed with HIP events on the
-                launch stream over the timed region: achieved = algorithmic bytes per launch / mean launch time
-  cpu_baseline  the oracle ("port" of the reference CPU path), single thread, on a bounded sample
-  local_ba      LM iterations/s of the local-BA path on the 20 KF / 10k landmark / ~60k observation scene
+  roofline      dominant kernel (picked by a per-kernel HIP-event pre-pass), timed with HIP events on the launch stream over
+                the timed region: achieved = algorithmic bytes per launch / mean launch time; `kernels` = the same figures for
+                EVERY kernel class of the step from the pre-pass (describe and the matcher kernels the north_star's 0.6 bar
+                names included); traffic / valu_issue from the committed PMC passes, only while the kernel sources still
+                hash to what those passes measured
+  latency       one frame at a time through the host-buffer entry points (what tracking_module calls per frame)
+  stereo        BASELINE config 4 shape: stereo pairs at 1241x376, both extractions + match::stereo::compute per step
+  local_ba      LM iterations/s on config 3 (20 KF / 10k landmarks / ~60k observations), with its own roofline
+  global_ba     LM iterations/s on config 5 (500 KF / 200k landmarks / 1.2M observations; block-Jacobi PCG); with N > 1 the
+                landmark-sharded solve over the library's own RCCL communicator (svgpu_comm_init), all ranks, same problem
+  cpu_baseline  the oracle ("port" of the reference CPU path), single thread, on bounded samples
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,6 +43,32 @@ sys.path.insert(0, ROOT)
 
 W, H = 640, 480
 LOWE, CHECK_ORI = 0.8, 1  # module/frame_tracker.cc:98
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA = 2 x the 2.5 PFLOP/s bf16 figure (measured ceiling >= 3.94 POP/s)
+
+
+def csrc_hash() -> str:
+    """sha256 over the kernel / host sources of libsvgpu: PMC-derived figures are only reported for the sources they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "stella_vslam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves and relay rank 0's JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main() -> int:
@@ -41,7 +79,11 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (the latency-bound matcher kernels amortise over a larger batch: 64 -> 256 is +7 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the latency / stereo legs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -54,7 +96,8 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         return 2
-    local_rank %= torch.cuda.device_count()  # one rank per GPU on a real node; lets the multi-rank path be exercised on fewer GPUs
+    n_dev = torch.cuda.device_count()
+    local_rank %= n_dev  # one rank per GPU on a real node; lets the multi-rank path be exercised on fewer GPUs
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,31 +211,40 @@ def main() -> int:
     k_ms = ms.value / max(n.value, 1)  # mean duration of one launch of the dominant kernel
     launches_per_step = max(n.value, 1) / args.steps
     bytes_per_launch = alg[dominant] / launches_per_step   # bytes, or integer operations for the MFMA-bound kernel
-    bound, unit, peak = ROOFS.get(dominant, ("hbm", "GB/s", 8000.0))
+    bound, unit, peak = ROOFS.get(dominant, ("hbm", "GB/s", HBM_PEAK_GBS))
     achieved = bytes_per_launch / (k_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
-    # HBM-side bytes per launch of that kernel from the rocprofv3 PMC passes of this same command (FETCH_SIZE and
-    # WRITE_SIZE in separate passes, tools/pmc_traffic.py -> profiles/*_traffic.json); null when no pass was recorded
-    traffic = None
-    try:
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        tj = json.load(open(files[-1])) if files else {}
-        if tj.get("batch", 64) == B and world == 1:  # the PMC passes were taken at one batch size
-            traffic = tj["kernels"].get(dominant, {}).get("total")
-    except Exception:
-        traffic = None
-    # VALU-issue view of the same kernel from a SQ_INSTS_VALU / GRBM_GUI_ACTIVE pass (tools/pmc_valu.py): the front-end kernels are
-    # bound by integer instruction issue, not by bytes, so this is the fraction that says how close the kernel is to ITS roof
-    valu = None
-    try:
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_issue.json")))
-        vj = json.load(open(files[-1])) if files else {}
-        if vj.get("batch") == B and world == 1 and dominant in vj["kernels"]:
-            kv = vj["kernels"][dominant]
-            valu = {"wave_insts_per_launch": kv["valu_wave_insts"], "cycles_per_wave_inst": vj["cycles_per_valu_wave_inst"],
-                    "simds": vj["simds"], "kernel_cycles": kv["kernel_cycles"], "frac": kv["valu_issue_frac"]}
-    except Exception:
-        valu = None
+
+    # PMC-derived figures (rocprofv3 passes of this same command, tools/pmc_traffic.py / tools/pmc_valu.py) are valid only for the
+    # kernel sources they were taken on: every profiles/*_traffic.json / *_valu_issue.json carries the csrc hash of its run
+    src_hash = csrc_hash()
+    traffic_json, valu_json = load_profile_json("*_traffic.json", src_hash, B, world), load_profile_json("*_valu_issue.json", src_hash, B, world)
+
+    def traffic_of(name):
+        return None if traffic_json is None else traffic_json["kernels"].get(name, {}).get("total")
+
+    def valu_of(name):
+        if valu_json is None or name not in valu_json["kernels"]:
+            return None
+        kv = valu_json["kernels"][name]
+        return {"wave_insts_per_launch": kv["valu_wave_insts"], "cycles_per_wave_inst": valu_json["cycles_per_valu_wave_inst"],
+                "simds": valu_json["simds"], "kernel_cycles": kv["kernel_cycles"], "frac": kv["valu_issue_frac"]}
+
+    kernels = []
+    for name, (kms, kn) in per_kernel.items():
+        if kn == 0:
+            continue
+        b_, u_, p_ = ROOFS.get(name, ("hbm", "GB/s", HBM_PEAK_GBS))
+        per_launch = alg[name] / kn
+        ach = per_launch / (kms / kn * 1e-3) / (1e9 if b_ == "hbm" else 1e12)
+        entry = {"kernel": name, "bound": b_, "unit": u_, "peak": p_, "achieved": round(ach, 2), "frac": round(ach / p_, 5),
+                 "mean_launch_ms": round(kms / kn, 5), "launches_per_step": kn,
+                 ("algorithmic_bytes_per_launch" if b_ == "hbm" else "algorithmic_ops_per_launch"): int(per_launch),
+                 "traffic": traffic_of(name)}
+        if name == "k_bf_topk":
+            # the distance kernel multiplies only the candidate pairs inside the +-30 degree angle windows of robust.cc:279
+            entry["note"] = ("algorithmic ops = all N1 x N2 pairs x 256 bit positions x 2 (the reference's work); the kernel multiplies only the "
+                             "pairs inside the orientation windows (~22-28 % of them), so the matrix pipe's own utilisation is ~ frac x 0.25")
+        kernels.append(entry)
 
     result = {
         "metric": "frames/s ORB-extract+match @640x480,2k kpts",
@@ -212,19 +264,39 @@ def main() -> int:
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": round(n_kp, 1),
                    "matches_per_pair": round(n_match, 1), "parallelism": f"frames sharded x{world}, no collective; extraction and matcher on two HIP streams"},
         "roofline": {"kernel": dominant, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                     "frac": round(achieved / peak, 5), "traffic": traffic, "valu_issue": valu,
+                     "frac": round(achieved / peak, 5), "traffic": traffic_of(dominant), "valu_issue": valu_of(dominant),
                      ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_ops_per_launch"): int(bytes_per_launch),
-                     "mean_launch_ms": round(k_ms, 5),
-                     "per_kernel_ms_per_step": {k: round(v[0], 4) for k, v in per_kernel.items()}},
+                     "mean_launch_ms": round(k_ms, 5), "csrc_hash": src_hash,
+                     "pmc_profiles_match_sources": traffic_json is not None,
+                     "per_kernel_ms_per_step": {k: round(v[0], 4) for k, v in per_kernel.items()},
+                     "kernels": kernels},
     }
 
-    if rank == 0 and world == 1 and not args.no_ba:
+    # free the front-end buffers before the other legs
+    del bufs, frames
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_extra:
+        for key, fn in (("latency", lambda: bench_latency(ctx, frames_np)), ("stereo", lambda: bench_stereo(local_rank))):
+            try:
+                result[key] = fn()
+            except Exception as e:  # a secondary leg must never hide the headline number
+                result[key] = {"error": repr(e)}
+    if not args.no_ba:
+        if rank == 0 and world == 1:
+            try:
+                result["local_ba"] = bench_local_ba(ctx)
+            except Exception as e:
+                result["local_ba"] = {"error": repr(e)}
         try:
-            result["local_ba"] = bench_local_ba(ctx)
-        except Exception as e:  # the BA leg must never hide the headline number
-            result["local_ba"] = {"error": str(e)}
+            gb = bench_global_ba(local_rank, rank, world)
+            if rank == 0:
+                result["global_ba"] = gb
+        except Exception as e:
+            if rank == 0:
+                result["global_ba"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(frames_np)
+        result["cpu_baseline"] = cpu_baseline(frames_np, want_ba=not args.no_ba)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -233,10 +305,23 @@ def main() -> int:
     return 0
 
 
+def load_profile_json(pattern, src_hash, B, world):
+    """Latest profiles/<pattern> whose `csrc_hash` equals the hash of the sources being run (and whose batch / rank count match)."""
+    import glob
+    try:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+            j = json.load(open(f))
+            if j.get("csrc_hash") == src_hash and j.get("batch", 64) == B and world == 1:
+                return j
+    except Exception:
+        pass
+    return None
+
+
 # Roofline that bounds each kernel class.  Everything streams bytes (HBM, 8 TB/s) except the brute-force distance kernel,
 # which computes the reference's all-pairs 256-bit Hamming distances on the matrix cores: int8 MFMA, dense peak = 2 x the
 # 2.5 PFLOP/s bf16 figure of MI355X_MICROARCH.md (its measured 32x32x32 i8 rate is 4.4 POP/s).
-ROOFS = {"k_bf_topk": ("mfma", "TFLOP/s", 5000.0)}
+ROOFS = {"k_bf_topk": ("mfma", "TFLOP/s", I8_MFMA_PEAK_TOPS)}
 
 
 def algorithmic_bytes(level_px, n_kp, B):
@@ -252,6 +337,77 @@ def algorithmic_bytes(level_px, n_kp, B):
             "k_bf_binsort": sort * B, "k_bf_topk": bf_ops * B, "k_bf_replay": (n_kp * 16 * 4 + n_kp * 8) * B}
 
 
+def bench_latency(ctx, frames_np):
+    """What tracking_module does per frame: ONE frame through the host-buffer entry points (H2D of the image, D2H of keypoints and
+    descriptors, then robust::brute_force_match against the previous frame, host in / host out)."""
+    from stella_vslam_amd import feature, match
+    ext = feature.orb_extractor(feature.orb_params(), ctx=feature.Context(ctx.device))
+    m = match.robust(LOWE, bool(CHECK_ORI), ext.ctx)
+    k0, d0 = ext.extract(frames_np[0])
+    k1, d1 = ext.extract(frames_np[1])
+    m.brute_force_match(d1, k1["angle"], d0, k0["angle"])
+    reps = 30
+    t0 = time.perf_counter()
+    for i in range(reps):
+        k1, d1 = ext.extract(frames_np[1 + (i & 1)])
+    t1 = time.perf_counter()
+    for i in range(reps):
+        m.brute_force_match(d1, k1["angle"], d0, k0["angle"])
+    t2 = time.perf_counter()
+    e, b = (t1 - t0) / reps * 1e3, (t2 - t1) / reps * 1e3
+    return {"what": "single 640x480 frame, host buffers in and out (PCIe included): svgpu_orb_extract, then svgpu_match_bruteforce vs the previous frame",
+            "extract_ms": round(e, 4), "match_ms": round(b, 4), "frames_per_s": round(1e3 / (e + b), 1)}
+
+
+def bench_stereo(device):
+    """BASELINE config 4 shape (KITTI 00 stereo: 1241x376, ini_fast_threshold 12; fx 718.856, baseline 0.537 m): both images of 8 pairs
+    extracted in device-resident batches on two contexts / streams, then match::stereo::compute for the 8 pairs in one launch."""
+    import torch
+    from stella_vslam_amd import feature, pipeline, synthetic
+    Wk, Hk, P, disp = 1241, 376, 8, 17
+    big = synthetic.frame_sequence(P, Wk + 64, Hk, seed=0x5EED + 4)
+    prm = feature.orb_params(ini_fast_thr=12)
+    el = pipeline.BatchExtractor(Wk, Hk, P, prm, device=device, priority=1)
+    er = pipeline.BatchExtractor(Wk, Hk, P, prm, device=device, priority=1)
+    el.upload(np.ascontiguousarray(big[:, :, 8:8 + Wk]))
+    er.upload(np.ascontiguousarray(big[:, :, 8 + disp:8 + disp + Wk]))
+    ev = torch.cuda.Event()
+    out = None
+
+    def one():
+        nonlocal out
+        el.extract()
+        er.extract()
+        ev.record(er.stream)
+        el.stream.wait_event(ev)
+        out = pipeline.stereo_batch(el, er, 718.856 * 0.537, 0.537, out=out)
+    for _ in range(3):
+        one()
+    el.ctx.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    el.ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    xr = out[0].cpu().numpy().reshape(P, el.cap)
+    n_kp = float(el.counts.cpu().numpy().reshape(P, el.nc)[:, 0].mean())
+    return {"what": "8 stereo pairs 1241x376 (ini_fast_threshold 12) per step: left + right ORB extraction on two contexts, stereo::compute for all pairs in one launch, resident in HBM",
+            "pairs_per_s": round(P / dt, 1), "ms_per_step": round(dt * 1e3, 4), "keypoints_per_image": round(n_kp, 1),
+            "stereo_matches_per_pair": round(float((xr >= 0).sum(1).mean()), 1)}
+
+
+def ba_roofline(sc, iters, seconds, free_poses):
+    """compulsory bytes per LM iteration = E x 29 + L x 48 + P_free x 112 (observations, landmark state + Hll/bl, pose blocks)."""
+    E, Lm = len(sc["obs_pose"]), len(sc["points"])
+    per_iter = E * 29 + Lm * 48 + free_poses * 112
+    ach = per_iter * iters / seconds / 1e9
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(ach, 3), "frac": round(ach / HBM_PEAK_GBS, 6),
+            "algorithmic_bytes_per_iteration": int(per_iter),
+            "note": "whole optimize() call incl. host set-up divided by its LM iterations; at these sizes an iteration is a chain of dependent "
+                    "launches (latency-bound), not a byte stream"}
+
+
 def bench_local_ba(ctx):
     from stella_vslam_amd import optimize, synthetic
     sc = synthetic.ba_scene()  # 20 KF / 10k landmarks / ~60k observations, seed 1234
@@ -265,10 +421,52 @@ def bench_local_ba(ctx):
     dt = time.perf_counter() - t0
     return {"metric": "local-BA LM iterations/s @20 KF / 10k landmarks / %d obs" % len(sc["obs_pose"]),
             "value": round(iters / dt, 2), "unit": "iters/s", "ms_per_call": round(dt / reps * 1e3, 3),
-            "iters_per_call": iters / reps, "dtype": "f64"}
+            "iters_per_call": iters / reps, "dtype": "f64", "lm_trials_per_call": res["stats"]["lm_trials"],
+            "roofline": ba_roofline(sc, iters, dt, int((np.asarray(sc["pose_fixed"]) == 0).sum()))}
 
 
-def cpu_baseline(frames_np):
+def bench_global_ba(device, rank, world):
+    """BASELINE config 5.  One rank: svgpu_global_ba.  N ranks: every rank holds the same scene, takes the observations of the landmarks
+    l % N == rank and runs svgpu_global_ba_sharded over the library's own RCCL communicator."""
+    import torch
+    from stella_vslam_amd import distributed, feature, optimize, synthetic
+    sc = synthetic.ba_scene_large()   # 500 KF / 200k landmarks / 1.2M observations (seed 5005)
+    ctx = feature.Context(device)
+    ba = optimize.local_bundle_adjuster(ctx=ctx)
+    if world > 1:
+        import torch.distributed as dist
+        use_lib_comm = dist.get_backend() == "nccl" and torch.cuda.device_count() >= world
+        cb = None
+        keep = None
+        if use_lib_comm:
+            distributed.init_comm(ctx)
+        else:
+            cb, keep = distributed.make_allreduce_callback()
+        shard = distributed.shard_by_landmark(sc, rank, world)
+        run = lambda: ba.optimize_global_flat_sharded(shard, rank, world, cb, num_iter=10)
+    else:
+        run = lambda: ba.optimize_global_flat(sc, num_iter=10)
+    res = run()  # warm-up
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    reps, iters = 3, 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = run()
+        iters += res["stats"]["iters_stage1"]
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = distributed.max_over_ranks(dt)
+    free = int((np.asarray(sc["pose_fixed"]) == 0).sum())
+    return {"metric": "global-BA LM iterations/s @500 KF / 200k landmarks / %d obs" % len(sc["obs_pose"]), "value": round(iters / dt, 2), "unit": "iters/s",
+            "ms_per_call": round(dt / reps * 1e3, 2), "iters_per_call": iters / reps, "dtype": "f64", "n_gpus": world,
+            "sharding": "none" if world == 1 else "observations by landmark (l % N), all-reduce of the kept Schur blocks per damping trial over RCCL",
+            "pcg_iterations_per_call": res["stats"]["pcg_iterations"], "chi2_final": res["stats"]["chi2_final"],
+            "roofline": ba_roofline(sc, iters, dt, free)}
+
+
+def cpu_baseline(frames_np, want_ba=True):
     """Oracle (CPU restatement of the reference path), 1 thread, bounded sample (~10-20 s)."""
     from oracle import oracle as O
     n = len(frames_np)
@@ -295,7 +493,6 @@ def cpu_baseline(frames_np):
     # context figure: the same port on ALL host cores, frame-parallel (frames are independent; one process per core,
     # each on its own slice of the sequence) -- the reference's optional OpenMP pragmas parallelise inside a frame instead
     try:
-        import subprocess
         ncore = max(1, min(os.cpu_count() or 1, 16))
         code = ("import sys,time; sys.path.insert(0, %r); from oracle import oracle as O; from stella_vslam_amd import synthetic as S; import numpy as np;"
                 "seq=S.frame_sequence(6,640,480,seed=0x5EED+int(sys.argv[1])); O.orb_extract(seq[0]); t0=time.perf_counter(); n=0; prev=None\n"
@@ -313,15 +510,22 @@ def cpu_baseline(frames_np):
         out["all_host_cores"] = {"value": round(sum(rates), 2), "unit": "frames/s", "cores": ncore, "how": f"one single-threaded oracle process per core on {ncore} of the host's {os.cpu_count()} cores, 6 s each"}
     except Exception as e:
         out["all_host_cores"] = {"error": str(e)}
-    try:
-        from stella_vslam_amd import synthetic
-        sc = synthetic.ba_scene()
-        t0 = time.perf_counter()
-        r = O.local_ba(sc)
-        dt = time.perf_counter() - t0
-        out["local_ba"] = {"value": round((r["stats"][2] + r["stats"][3]) / dt, 3), "unit": "iters/s", "ms_per_call": round(dt * 1e3, 1)}
-    except Exception as e:
-        out["local_ba"] = {"error": str(e)}
+    if want_ba:
+        try:
+            from stella_vslam_amd import synthetic
+            sc = synthetic.ba_scene()
+            t0 = time.perf_counter()
+            r = O.local_ba(sc)
+            dt = time.perf_counter() - t0
+            out["local_ba"] = {"value": round((r["stats"][2] + r["stats"][3]) / dt, 3), "unit": "iters/s", "ms_per_call": round(dt * 1e3, 1), "cores": 1, "kind": "port"}
+            sg = synthetic.ba_scene_large()
+            t0 = time.perf_counter()
+            r = O.local_ba(sg, iters1=10, iters2=0)
+            dt = time.perf_counter() - t0
+            out["global_ba"] = {"value": round(r["stats"][2] / dt, 3), "unit": "iters/s", "ms_per_call": round(dt * 1e3, 1), "cores": 1, "kind": "port",
+                                "sample": "one call on the config-5 scene (500 KF / 200k landmarks); the oracle factors the reduced system with an envelope Cholesky"}
+        except Exception as e:
+            out["local_ba"] = {"error": str(e)}
     return out
 
 

@@ -6,8 +6,10 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE reports exact
 and 16 B/lane on this toolchain -- profiles/r01_pmc_calibration.json) and WRITE_SIZE is exact: fetch is doubled here.
 usage: tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/r01_traffic.json [frames per launch, default 256]
 """
-import json, sys
+import json, os, sys
 import pandas as pd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # the kernel sources these counters were taken on: bench.py reports them only while the sources still hash to this
 
 def per_kernel(d, counter):
     t = pd.read_csv(f"{d}/p_counter_collection.csv")
@@ -17,7 +19,7 @@ def per_kernel(d, counter):
 
 f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 FETCH_CORRECTION = 2.0  # profiles/r01_pmc_calibration.json
-out = {"batch": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "unit": "bytes per launch (FETCH_SIZE KiB x 1024 x 2, WRITE_SIZE KiB x 1024; mean over the launches of the run)",
+out = {"csrc_hash": csrc_hash(), "batch": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "unit": "bytes per launch (FETCH_SIZE KiB x 1024 x 2, WRITE_SIZE KiB x 1024; mean over the launches of the run)",
        "caveat": "gfx950: FETCH_SIZE counts half of the streamed bytes at every access width (calibrated, factor 2 applied); "
                  "Infinity-Cache hits are included", "kernels": {}}
 alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}

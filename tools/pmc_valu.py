@@ -5,15 +5,17 @@ launch, the kernel's duration in shader cycles (GRBM_GUI_ACTIVE is summed over t
 VALU issue slots those instructions fill at 4 cycles per wave64 integer / packed-16 instruction on 256 CUs x 4 SIMDs
 (measured: SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles for these kernels; tools/ubench/bcnt.hip: 4.6 cycles per xor/bcnt).
 usage: tools/pmc_valu.py gpurun_out/pmc_gi profiles/r01_valu_issue.json [frames per launch]"""
-import json, sys
+import json, os, sys
 import pandas as pd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # the kernel sources these counters were taken on: bench.py reports them only while the sources still hash to this
 
 t = pd.read_csv(f"{sys.argv[1]}/p_counter_collection.csv")
 t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
 g = t.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
 alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
 SIMDS, CYC = 256 * 4, 4
-out = {"batch": int(sys.argv[3]) if len(sys.argv) > 3 else 256, "simds": SIMDS, "cycles_per_valu_wave_inst": CYC,
+out = {"csrc_hash": csrc_hash(), "batch": int(sys.argv[3]) if len(sys.argv) > 3 else 256, "simds": SIMDS, "cycles_per_valu_wave_inst": CYC,
        "note": "valu_issue_frac = SQ_INSTS_VALU * 4 / (1024 SIMDs * kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; both legs of the "
                "two-stream pipeline run while a kernel is measured, so its cycles include the share the other stream's kernels take",
        "kernels": {}}
