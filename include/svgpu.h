@@ -15,6 +15,10 @@
  *   - one svgpu_ctx per (device, caller thread): two extractor instances (stereo: system.cc:427-434)
  *     use two contexts and run concurrently
  *   - all device entry points are asynchronous on their stream unless stated otherwise
+ *   - a context owns ONE set of scratch buffers (pyramid, score maps, candidate lists, BA arenas), reused by every call without a
+ *     fence of its own: all calls on one context must be ordered on ONE stream at a time (the context's, or one caller stream).
+ *     To move a context to another stream, synchronise the old one first; for concurrent streams use one context per stream
+ *     (bench.py: an extraction context and a matching context, ordered by events on the buffers they hand over)
  */
 #ifndef SVGPU_H
 #define SVGPU_H

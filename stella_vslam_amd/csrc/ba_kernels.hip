@@ -1537,11 +1537,7 @@ void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP <= 0) return;
     SvProfScope ps(ctx, s, "ba_solve");
     const size_t lds = sv_ba_pcg_lds_bytes(D);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)k_ba_pcg_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_bytes = lds;
-        else (void)hipGetLastError();
-    }
+    (void)sv_allow_dynamic_lds((const void*)k_ba_pcg_lds, lds);
     hipLaunchKernelGGL(k_ba_pcg_lds, dim3(1), dim3(PL_THREADS), lds, s, D, 2 * D.NB - D.nP);
 }
 
@@ -1592,11 +1588,7 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP <= 0) return;
     SvProfScope ps(ctx, s, "ba_solve");
     const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
-    static size_t attr_bytes = 0;  // dynamic LDS above 64 KB must be allowed explicitly; ask for what this system needs
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute((const void*)k_ba_chol_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_bytes = lds;
-        else (void)hipGetLastError();  // do not leave a sticky error behind; an impossible size fails the launch below
-    }
+    (void)sv_allow_dynamic_lds((const void*)k_ba_chol_lds, lds);  // dynamic LDS above 64 KB must be allowed explicitly
     hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
 }
 

@@ -1340,12 +1340,7 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     if (!use_lds) lds = 0;
     const int pool_rows = (int)std::min<size_t>(1024, (128 * 1024 - lds) / ((BF_LIST - 4) * sizeof(uint32_t)));
     lds += (size_t)pool_rows * (BF_LIST - 4) * sizeof(uint32_t);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf_replay), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
-            (void)hipGetLastError();  // never leave a sticky error behind
-        attr_done = true;
-    }
+    (void)sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_bf_replay), 144 * 1024);
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
 }
 void sv_launch_grid_build(hipStream_t s, const GridProblem& G) {

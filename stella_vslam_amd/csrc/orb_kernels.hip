@@ -1064,7 +1064,7 @@ void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride
 }
 
 hipError_t sv_pyramid_prepare() {  // once per device: allow the LDS-resident pyramid its large dynamic allocation
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SV_PYR_LDS_MAX);
+    return sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_pyramid_lds), SV_PYR_LDS_MAX);
 }
 void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, const int2* band_rows, int bands, const uint8_t* img0,
                        size_t img0_frame_stride, int img0_pitch, uint8_t* pyr, size_t pyr_frame_bytes, const short* xofs,

@@ -12,6 +12,25 @@ int sv_set_error(svgpu_ctx* ctx, int status, const char* what, hipError_t e) {
     return status;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one process may drive several GPUs from several threads
+// (one svgpu_ctx each), so the largest size granted so far is tracked per (device, kernel) under a mutex.
+#include <map>
+#include <mutex>
+hipError_t sv_allow_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mtx;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mtx);
+    size_t& g = granted[std::make_pair(dev, kernel)];
+    if (bytes <= g) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) g = bytes;
+    else (void)hipGetLastError();  // never leave a sticky error behind: an impossible size fails the launch that needs it
+    return e;
+}
+
 int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return SVGPU_OK;
     if (ctx->d_scratch) {

@@ -129,6 +129,7 @@ struct SvProfScope {  // brackets the launches issued inside its lifetime when `
     }
 };
 int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes);
+hipError_t sv_allow_dynamic_lds(const void* kernel, size_t bytes);  // per (device, kernel), thread-safe
 void sv_orb_release(svgpu_ctx* ctx);
 
 #define SV_HIP(ctx, call)                                                   \

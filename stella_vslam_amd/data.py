@@ -79,11 +79,22 @@ class bow_vocabulary:
         ctx.check(lib().svgpu_bow_vocabulary_upload(ctx.handle, len(off) - 1, _p(off), _p(ch), _p(nd), _p(nw), _p(wi), C.byref(self._h)),
                   "svgpu_bow_vocabulary_upload")
 
+    @classmethod
+    def load_fbow(cls, ctx: Context, path: str) -> "bow_vocabulary":
+        """bow_vocabulary_util::load (data/bow_vocabulary.cc:26-47) for an .fbow file; see read_fbow for what is unverified.
+        NOTE fbow::Vocabulary::transform(features, level, ...) counts `level` DOWN from the root, DBoW2's levelsup counts UP from
+        the leaves: a vocabulary loaded from .fbow records the node at depth `levels_up` (compute_bow passes 4 to both)."""
+        t = read_fbow(path)
+        v = cls(ctx, t["child_off"], t["children"], t["node_desc"], t["node_weight"], t["word_id"], t["depth"])
+        v.level_from_root_ = True
+        return v
+
     def descend(self, descriptors, levels_up: int = 4):
         d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
         n = len(d)
         word, weight, node = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32)
-        self.ctx.check(lib().svgpu_bow_transform(self.ctx.handle, self._h, _p(d), n, max(self.depth_ - levels_up, 0), _p(word), _p(weight), _p(node)),
+        level = min(levels_up, self.depth_) if getattr(self, "level_from_root_", False) else max(self.depth_ - levels_up, 0)
+        self.ctx.check(lib().svgpu_bow_transform(self.ctx.handle, self._h, _p(d), n, level, _p(word), _p(weight), _p(node)),
                        "svgpu_bow_transform")
         return word, weight, node
 
@@ -110,3 +121,100 @@ class bow_vocabulary:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------------------------------- .fbow vocabulary files
+# data::bow_vocabulary_util::load (data/bow_vocabulary.cc:26-47) hands the path to fbow::Vocabulary::readFromFile in the default
+# (FBoW) build.  FBoW is an un-vendored submodule (3rd/FBoW is empty in the checkout studied; the reference pins stella-cv/FBoW),
+# so the layout below restates the published fbow/vocabulary.h and has NOT been checked against a real orb_vocab.fbow here
+# (none is available offline): treat it as unverified until a real file has been read with it.
+#   uint64 magic 55824124 | struct params (120 bytes) | _total_size bytes of blocks
+#   params: char desc_name[50]; u32 alignment, nblocks; u64 desc_size_wp, block_size_wp, feature_off, child_off, total_size;
+#           i32 desc_type, desc_size; u32 k                                   (natural C alignment, little endian)
+#   block:  u16 N | u16 is_leaf | u32 parent | pad | N descriptors (desc_size_wp apart, from feature_off) |
+#           N x {u32 id_or_childblock (MSB = leaf), f32 weight} from child_off
+FBOW_MAGIC = 55824124
+_FBOW_PARAMS = np.dtype([("desc_name", "S50"), ("_pad0", "V2"), ("alignment", "<u4"), ("nblocks", "<u4"), ("_pad1", "V4"), ("desc_size_wp", "<u8"),
+                         ("block_size_wp", "<u8"), ("feature_off", "<u8"), ("child_off", "<u8"), ("total_size", "<u8"), ("desc_type", "<i4"),
+                         ("desc_size", "<i4"), ("k", "<u4"), ("_pad2", "V4")])
+assert _FBOW_PARAMS.itemsize == 120
+
+
+def read_fbow(path: str) -> dict:
+    """-> the flat tree svgpu_bow_vocabulary_upload takes (node 0 = a virtual root whose children are block 0's nodes; nodes in
+    breadth-first order with siblings in block order, so that node ids at one depth sort like fbow's path-bit node ids)."""
+    raw = np.fromfile(path, np.uint8)
+    if len(raw) < 128 or int(raw[:8].view("<u8")[0]) != FBOW_MAGIC:
+        raise ValueError(f"{path}: not an fbow vocabulary (bad signature)")
+    P = raw[8:128].view(_FBOW_PARAMS)[0]
+    if int(P["desc_size"]) != 32 or int(P["desc_type"]) != 0:
+        raise ValueError(f"{path}: only 32-byte CV_8UC1 (ORB) vocabularies are supported (desc_size {P['desc_size']}, type {P['desc_type']})")
+    bs, fo, co, dw, nb = (int(P[k]) for k in ("block_size_wp", "feature_off", "child_off", "desc_size_wp", "nblocks"))
+    data = raw[128:128 + int(P["total_size"])]
+    if len(data) != int(P["total_size"]) or nb * bs > len(data):
+        raise ValueError(f"{path}: truncated")
+    desc, weight, word, kids = [np.zeros(32, np.uint8)], [0.0], [-1], [[]]
+    queue, depth, seen = [(0, 0, 0)], 0, set()      # (block, parent node, depth of the block's nodes - 1)
+    while queue:
+        blk, parent, d = queue.pop(0)
+        if blk >= nb or blk in seen:
+            raise ValueError(f"{path}: corrupt block graph at block {blk}")
+        seen.add(blk)
+        b = data[blk * bs:(blk + 1) * bs]
+        n = int(b[:2].view("<u2")[0])
+        info = b[co:co + 8 * n].view(np.dtype([("id", "<u4"), ("w", "<f4")]))
+        depth = max(depth, d + 1)
+        for i in range(n):
+            node = len(desc)
+            kids[parent].append(node)
+            desc.append(b[fo + i * dw:fo + i * dw + 32].copy())
+            kids.append([])
+            if int(info["id"][i]) & 0x80000000:
+                weight.append(float(info["w"][i]))
+                word.append(int(info["id"][i]) & 0x7FFFFFFF)
+            else:
+                weight.append(0.0)
+                word.append(-1)
+                queue.append((int(info["id"][i]) & 0x7FFFFFFF, node, d + 1))
+    off = np.zeros(len(desc) + 1, np.int32)
+    off[1:] = np.cumsum([len(k) for k in kids])
+    return dict(child_off=off, children=np.array([c for k in kids for c in k], np.int32), node_desc=np.stack(desc), node_weight=np.array(weight, np.float32),
+                word_id=np.array(word, np.int32), depth=depth, k=int(P["k"]), desc_name=bytes(P["desc_name"]).split(b"\0")[0].decode())
+
+
+def write_fbow(path: str, child_off, children, node_desc, node_weight, word_id, k: int, alignment: int = 8, desc_name: str = "orb") -> None:
+    """Inverse of read_fbow (fixtures / converting a flat tree to a file the reference build can load)."""
+    up = lambda v: (v + alignment - 1) // alignment * alignment
+    dw, fo = up(32), up(8)
+    co = fo + k * dw
+    bs = up(co + 8 * k)
+    blocks, queue = [], [(0, 0)]   # (node whose children form the block, parent block)
+    index = {0: 0}
+    while queue:
+        node, parent = queue.pop(0)
+        ch = [int(c) for c in children[child_off[node]:child_off[node + 1]]]
+        assert 0 < len(ch) <= k
+        b = np.zeros(bs, np.uint8)
+        b[:2] = np.array([len(ch)], "<u2").view(np.uint8)
+        leaf = all(child_off[c] == child_off[c + 1] for c in ch)
+        b[2:4] = np.array([1 if leaf else 0], "<u2").view(np.uint8)
+        b[4:8] = np.array([parent], "<u4").view(np.uint8)
+        me = len(blocks)
+        blocks.append(b)
+        for i, c in enumerate(ch):
+            b[fo + i * dw:fo + i * dw + 32] = node_desc[c]
+            if child_off[c] == child_off[c + 1]:
+                ident, w = 0x80000000 | int(word_id[c]), float(node_weight[c])
+            else:
+                index[c] = len(blocks) + len(queue)
+                queue.append((c, me))
+                ident, w = index[c], 0.0
+            b[co + 8 * i:co + 8 * i + 4] = np.array([ident], "<u4").view(np.uint8)
+            b[co + 8 * i + 4:co + 8 * i + 8] = np.array([w], "<f4").view(np.uint8)
+    P = np.zeros(1, _FBOW_PARAMS)
+    P["desc_name"], P["alignment"], P["nblocks"], P["desc_size_wp"], P["block_size_wp"] = desc_name.encode(), alignment, len(blocks), dw, bs
+    P["feature_off"], P["child_off"], P["total_size"], P["desc_type"], P["desc_size"], P["k"] = fo, co, bs * len(blocks), 0, 32, k
+    with open(path, "wb") as f:
+        f.write(np.array([FBOW_MAGIC], "<u8").tobytes())
+        f.write(P.tobytes())
+        f.write(np.concatenate(blocks).tobytes())

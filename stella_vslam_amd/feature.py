@@ -114,8 +114,10 @@ class orb_extractor:
         if self._rect_mask is None:
             m = np.full((rows, cols), 255, np.uint8)
             for r in self.mask_rects_:
-                x_min, x_max = int(round(cols * r[0])), int(round(cols * r[1]))
-                y_min, y_max = int(round(rows * r[2])), int(round(rows * r[3]))
+                # std::round of a FLOAT product (orb_extractor.cc:145-148): half away from zero, not Python's banker's rounding on doubles
+                rnd = lambda n, f: int(np.floor(np.float32(n) * np.float32(f) + np.float32(0.5)))
+                x_min, x_max = rnd(cols, r[0]), rnd(cols, r[1])
+                y_min, y_max = rnd(rows, r[2]), rnd(rows, r[3])
                 m[max(y_min, 0):y_max + 1, max(x_min, 0):x_max + 1] = 0
             self._rect_mask = m
         return self._rect_mask

@@ -1,11 +1,8 @@
-// C++ adaptor for stella_vslam::optimize::local_bundle_adjuster (reference: optimize/local_bundle_adjuster.h:15-24),
-// the `backend: "hip"` sibling of local_bundle_adjuster_g2o / _gtsam (optimize/local_bundle_adjuster_factory.h:17-32).
-//
-// With the reference's headers on the include path (-DSVGPU_WITH_STELLA_VSLAM) the class derives from
-// optimize::local_bundle_adjuster and implements optimize(map_db, curr_keyfrm, force_stop_flag): gather and
-// write-back are the host steps of the g2o backend (local_bundle_adjuster_g2o.cc:38-147, 352-430; shown in
-// INTEGRATION.md), steps 2-6 are one svgpu_local_ba call.  Stand-alone (this container) the flat entry point
-// optimize_flat() is what the tests drive.
+// Flat-problem adaptors for stella_vslam::optimize::{local_bundle_adjuster, global_bundle_adjuster, pose_optimizer} over the C ABI:
+// optimize_flat() is steps 2-6 of local_bundle_adjuster_g2o::optimize (optimize/local_bundle_adjuster_g2o.cc:149-348) on a problem the
+// caller has already gathered into arrays.  The class that DERIVES from optimize::local_bundle_adjuster and does the gather
+// (:38-147) and the write-back (:352-430) itself -- the `backend: "hip"` sibling of local_bundle_adjuster_g2o / _gtsam -- is
+// stella_vslam::optimize::local_bundle_adjuster_hip in host/drop_in/hip_backend.h.
 #pragma once
 #include <cstdint>
 #include <vector>

@@ -77,3 +77,31 @@ def test_descent_against_literal_walk():
     one = dict(child_off=[0, 0], children=np.zeros(0, np.int32), node_desc=np.zeros((1, 32), np.uint8), node_weight=[1.5], word_id=[0])
     w, wt, nid = O.bow_transform(one, q[:3], 2)
     assert (w == 0).all() and (wt == 1.5).all() and (nid == 0).all()
+
+
+def test_fbow_file_round_trip(tmp_path):
+    """.fbow reader (stella_vslam_amd/data.py:read_fbow, layout restated from fbow/vocabulary.h -- unverified against a real file):
+    a written vocabulary reads back to the identical flat tree, whatever the alignment, and bad files are refused."""
+    import pytest
+    from stella_vslam_amd import data
+    rng = np.random.default_rng(3)
+    tree = make_tree(rng, k=6, depth=3, prune=0.15)
+    for align in (8, 32):
+        p = str(tmp_path / f"v{align}.fbow")
+        data.write_fbow(p, tree["child_off"], tree["children"], tree["node_desc"], tree["node_weight"], tree["word_id"], k=6, alignment=align)
+        back = data.read_fbow(p)
+        for key in ("child_off", "children", "node_desc", "node_weight", "word_id"):
+            assert np.array_equal(back[key], tree[key]), key
+        assert back["depth"] == 3 and back["k"] == 6 and back["desc_name"] == "orb"
+        q = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+        a, b = O.bow_transform(back, q, 2), O.bow_transform(tree, q, 2)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    raw = np.fromfile(p, np.uint8)
+    bad = raw.copy()
+    bad[0] ^= 1
+    bad.tofile(str(tmp_path / "bad.fbow"))
+    with pytest.raises(ValueError, match="signature"):
+        data.read_fbow(str(tmp_path / "bad.fbow"))
+    raw[:len(raw) - 100].tofile(str(tmp_path / "short.fbow"))
+    with pytest.raises(ValueError, match="truncated"):
+        data.read_fbow(str(tmp_path / "short.fbow"))
