@@ -112,6 +112,7 @@ void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P);
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int do_prepare);
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // Schur complement blocks + right-hand side
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // on-chip dense LL^T
+size_t sv_ba_chol_bytes(int n);                                    // its dynamic LDS
 size_t sv_ba_pcg_lds_bytes(const BaDev& D);
 void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // PCG with the whole system in one workgroup's LDS
 int sv_ba_lin_split();

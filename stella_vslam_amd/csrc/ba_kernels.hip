@@ -208,94 +208,56 @@ __global__ void k_ba_maxslot(BaDev D) {
     if (r < D.world) D.maxslots[r] = (r == D.rank) ? __longlong_as_double((long long)D.ctl->max_diag_bits) : 0.0;
 }
 
-// Dense LL^T of the reduced system with the right-hand side carried as row n, then L^T x = y.
-// One 256-thread workgroup, A ((n+1) x n, pitch ld) in LDS.  Blocked right-looking factorisation, panel width 16:
-//   (1) wave 0 factors the 16x16 diagonal block (wave-synchronous, no workgroup barrier),
-//   (2) every row below solves its 16 panel entries against it (thread per row),
-//   (3) rank-16 update of the trailing matrix on a 16x16 thread lattice,
-// i.e. 3 workgroup barriers per 16 columns instead of 3 per column.  Row n (the right-hand side) rides along, so
-// after the factorisation it holds L^-1 g; wave 0 finishes with the back substitution.
-#define CHOL_THREADS 512
-#define CHOL_NB 8
-// broadcast a double from a compile-time lane through SGPRs (v_readlane_b32 x2) -- no LDS round trip
-template <int LANE>
-__device__ __forceinline__ double bcast_d(double v) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
-    return __hiloint2double(hi, lo);
+// Dense block LDL^T of the reduced system (3x3 pivots) with the right-hand side carried as row n, then the back substitution.
+// One workgroup; everything here is a chain of short dependent steps, so the design minimises the LENGTH of that chain:
+//  * the matrix lives in REGISTERS: it is cut into 3x3 tiles (n = 6 nP is a multiple of 3; tile row R-1 is the right-hand side)
+//    and thread t owns tile t of the lower triangle for the whole factorisation -- the trailing update never reads or writes its
+//    own operand in LDS; tiles are numbered column by column, so the waves retire one after the other;
+//  * step j needs ONE barrier: the owner of the diagonal tile (j, j) inverts it (adjugate / determinant: one reciprocal, no square
+//    root -- S = L' D L'^T with D_j = the pivot tiles, so W_j = D_j^-1 is all the update needs) and publishes W_j; after the barrier
+//    every owner of a tile (I, K), K > j, subtracts A_Ij W_j A_Kj^T, where the UNSCALED panel tiles A_*j were published by their
+//    owners at the end of the previous step (the tiles of column j+1 are final after update j);
+//  * the owner of (j+1, j+1) goes from its update straight into the inversion (its wave runs at raised priority);
+//  * the right-hand side row rides along (z = L'^-1 g), and x_I = W_I (z_I - sum_{M > I} A_MI^T x_M) is back-substituted by wave 0
+//    from the published tiles, three rows per dependent step.
+// A non-positive leading minor of a pivot tile (the system is not positive definite) fails the trial, as a failed LL^T would.
+// 35 us at n = 96 (74 us for the 16-column-panel LL^T with its operand in LDS that this replaces): ~1500 cycles per step,
+// the latencies behind it are measured by tools/ubench/latency.hip (profiles/r02_ubench_latency.json).
+#define CHOL_MAX_THREADS 1024
+__device__ __forceinline__ double rcp_nr(double x) {  // 1 / x: hardware seed, two Newton steps
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
 }
-// 1/sqrt(x) in fp64: fp32 hardware seed + two Newton steps (relative error ~1e-16 for normal fp32-range x)
-__device__ __forceinline__ double fast_rsqrt_d(double x) {
-    if (!(x > 1e-30 && x < 1e30)) return rsqrt(x);
-    double y = (double)__frsqrt_rn((float)x);
-    y = y * (1.5 - 0.5 * x * y * y);
-    y = y * (1.5 - 0.5 * x * y * y);
-    return y;
+// tiles of the lower triangle in COLUMN-major order (column K: I = K .. R-1): the tiles that are still being updated at step j
+// (K > j) are a suffix of the tile list, so whole waves retire as the factorisation advances
+__device__ __forceinline__ void tile_of(int t, int R, int& I, int& K) {
+    const float b = 2.f * (float)R + 1.f;
+    int k = (int)((b - sqrtf(fmaxf(b * b - 8.f * (float)t, 0.f))) * 0.5f);
+    k = min(max(k, 0), R - 1);
+    while (k > 0 && k * R - k * (k - 1) / 2 > t) --k;
+    while (k < R - 1 && (k + 1) * R - (k + 1) * k / 2 <= t) ++k;
+    K = k;
+    I = k + t - (k * R - k * (k - 1) / 2);
 }
-template <int J>
-struct ChoStep {  // one column of the register-resident 16x16 factorisation (compile-time recursion keeps lanes constant)
-    __device__ static __forceinline__ void run(double (&r)[CHOL_NB], double (&invd)[CHOL_NB], bool& bad, int lane) {
-        const double djj = bcast_d<J>(r[J]);
-        bad = bad || !(djj > 0.0);
-        const double inv = fast_rsqrt_d(djj);
-        invd[J] = inv;
-        if (lane == J) r[J] = djj * inv;
-        else if (lane > J) r[J] *= inv;
-        upd<J + 1>(r, lane);
-        ChoStep<J + 1>::run(r, invd, bad, lane);
-    }
-    template <int K>
-    __device__ static __forceinline__ void upd(double (&r)[CHOL_NB], int lane) {
-        if constexpr (K < CHOL_NB) {
-            const double lkj = bcast_d<K>(r[J]);
-            if (lane >= K) r[K] -= r[J] * lkj;
-            upd<K + 1>(r, lane);
-        }
-    }
-};
-template <>
-struct ChoStep<CHOL_NB> {
-    __device__ static __forceinline__ void run(double (&)[CHOL_NB], double (&)[CHOL_NB], bool&, int) {}
-};
-template <int I>
-struct InvStep {  // row I of the forward substitutions L x = e_lane
-    __device__ static __forceinline__ void run(const double (&r)[CHOL_NB], const double (&invd)[CHOL_NB], double (&x)[CHOL_NB], int lane) {
-        double acc = (I == lane) ? 1.0 : 0.0;
-        dot<0>(r, x, acc);
-        x[I] = (I >= lane) ? acc * invd[I] : 0.0;
-        InvStep<I + 1>::run(r, invd, x, lane);
-    }
-    template <int K>
-    __device__ static __forceinline__ void dot(const double (&r)[CHOL_NB], const double (&x)[CHOL_NB], double& acc) {
-        if constexpr (K < I) {
-            acc -= bcast_d<I>(r[K]) * x[K];
-            dot<K + 1>(r, x, acc);
-        }
-    }
-};
-template <>
-struct InvStep<CHOL_NB> {
-    __device__ static __forceinline__ void run(const double (&)[CHOL_NB], const double (&)[CHOL_NB], double (&)[CHOL_NB], int) {}
-};
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_lane wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
-__global__ __launch_bounds__(CHOL_THREADS) void k_ba_chol_lds(BaDev D) {
-    extern __shared__ double s_A[];
-    __shared__ double s_X[CHOL_NB][CHOL_NB + 1];  // inverse of the current diagonal block of L
-    __shared__ double s_invd[1024];               // 1 / L_ii
+template <int TPT>  // tiles per thread
+__global__ __launch_bounds__(CHOL_MAX_THREADS) void k_ba_chol_tile(BaDev D) {
+    extern __shared__ double s_A[];  // (n + 3) rows x ld: the published (unscaled) tiles below the diagonal, row n = z (rows n+1, n+2: padding)
+    __shared__ double s_W[64][6];    // inverse pivot tiles: w00 w10 w11 w20 w21 w22
     __shared__ int s_fail;
     if (D.ctl->phase != 1) return;
     const int n = D.n, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
-    const int ld = n | 1;
+    const int ld = n | 1, R = n / 3 + 1, NT = R * (R + 1) / 2;
     double* A = s_A;
     // the lower triangle of the reduced system from its kept upper blocks: S[6a+i][6b+j] = blk[i][j] (a <= b) sits at row 6b+j,
     // column 6a+i; blocks that were not kept are zero; row n = the right-hand side
-    for (int k = tid; k < (n + 1) * ld; k += nt) A[k] = 0.0;
+    for (int k = tid; k < (n + 3) * ld; k += nt) A[k] = 0.0;
     if (tid == 0) s_fail = 0;
     __syncthreads();
     for (int k = tid; k < D.NB * 36; k += nt) {
@@ -305,136 +267,167 @@ __global__ __launch_bounds__(CHOL_THREADS) void k_ba_chol_lds(BaDev D) {
     }
     for (int c = tid; c < n; c += nt) A[n * ld + c] = D.g[c];
     __syncthreads();
-    long long tmark = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0};
-#define CHOL_LAP(slot)                                        \
-    {                                                         \
-        const long long now = __builtin_amdgcn_s_memtime();   \
-        t_acc[slot] += now - tmark;                           \
-        tmark = now;                                          \
+    int tI[TPT], tK[TPT];
+    double C[TPT][3][3];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+        const int t = tid + q * nt;
+        if (t < NT) tile_of(t, R, tI[q], tK[q]);
+        else tI[q] = tK[q] = -1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) C[q][r][c] = t < NT ? A[(3 * tI[q] + r) * ld + min(3 * tK[q] + c, n - 1)] : 0.0;
     }
-    for (int jb = 0; jb < n; jb += CHOL_NB) {
-        const int je = min(jb + CHOL_NB, n), w = je - jb;
-        if (tid < 64) {
-            // (1) diagonal block in registers: lane i < 16 holds row i (lanes beyond the block hold identity rows)
-            double r[CHOL_NB];
+    for (int j = 0; j < R - 1; ++j) {
+        // ---- the pivot tile's inverse (one thread)
 #pragma unroll
-            for (int c = 0; c < CHOL_NB; ++c) r[c] = (lane < w && c <= lane) ? A[(jb + lane) * ld + jb + c] : (c == lane ? 1.0 : 0.0);
-            double invd[CHOL_NB];
-            bool bad = false;
-            ChoStep<0>::run(r, invd, bad, lane);
-            // X = L^-1 (lower triangular): lane c solves L x = e_c by forward substitution, L_ik broadcast from lane i
-            double x[CHOL_NB];
-            InvStep<0>::run(r, invd, x, lane);
-            if (lane < CHOL_NB) {
+        for (int q = 0; q < TPT; ++q)
+            if (tI[q] == j && tK[q] == j) {
+                const double c00 = C[q][0][0], c10 = C[q][1][0], c11 = C[q][1][1], c20 = C[q][2][0], c21 = C[q][2][1], c22 = C[q][2][2];
+                const double m00 = fma(c11, c22, -(c21 * c21)), m10 = fma(c21, c20, -(c10 * c22)), m20 = fma(c10, c21, -(c11 * c20));
+                const double m11 = fma(c00, c22, -(c20 * c20)), m21 = fma(c10, c20, -(c00 * c21)), m22 = fma(c00, c11, -(c10 * c10));
+                const double det = fma(c20, m20, fma(c10, m10, c00 * m00));
+                if (!(c00 > 0.0) || !(m22 > 0.0) || !(det > 0.0)) s_fail = 1;  // leading minors
+                const double rd = rcp_nr(det);
+                double* w = s_W[j];
+                w[0] = m00 * rd;
+                w[1] = m10 * rd;
+                w[2] = m11 * rd;
+                w[3] = m20 * rd;
+                w[4] = m21 * rd;
+                w[5] = m22 * rd;
+            }
+        __syncthreads();
+        // ---- trailing update; the tiles of column j + 1 are final afterwards and are published.  All LDS reads of the step are
+        // issued back to back and awaited once (left alone the scheduler strings them out between the multiply-adds: five
+        // round trips instead of one on the critical path); the failure flag is read with them and tested after the update.
+        bool next_pivot = false;
 #pragma unroll
-                for (int i = 0; i < CHOL_NB; ++i) s_X[i][lane] = x[i];
-                if (lane < w) {
+        for (int q = 0; q < TPT; ++q) next_pivot = next_pivot || (tI[q] == j + 1 && tK[q] == j + 1);
+        if (__any(next_pivot)) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        const int failed = __hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool act[TPT], any_act = false;
 #pragma unroll
-                    for (int c = 0; c < CHOL_NB; ++c)
-                        if (c <= lane) A[(jb + lane) * ld + jb + c] = r[c];
-                    double mine = invd[0];
+        for (int q = 0; q < TPT; ++q) {
+            act[q] = tK[q] > j;
+            any_act = any_act || act[q];
+        }
+        if (any_act) {
+            double w[6], a[TPT][3][3], b[TPT][3][3];
 #pragma unroll
-                    for (int c = 1; c < CHOL_NB; ++c) mine = (lane == c) ? invd[c] : mine;
-                    s_invd[jb + lane] = mine;
+            for (int e = 0; e < 6; ++e) w[e] = s_W[j][e];
+#pragma unroll
+            for (int q = 0; q < TPT; ++q) {
+                const double* la = A + (3 * max(tI[q], 0)) * ld + 3 * j;
+                const double* lb = A + (3 * max(tK[q], 0)) * ld + 3 * j;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        a[q][r][k] = la[r * ld + k];
+                        b[q][r][k] = lb[r * ld + k];
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+                const double w00 = w[0], w10 = w[1], w11 = w[2], w20 = w[3], w21 = w[4], w22 = w[5];
+#pragma unroll
+            for (int q = 0; q < TPT; ++q)
+                if (act[q]) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const double t0 = fma(a[q][r][2], w20, fma(a[q][r][1], w10, a[q][r][0] * w00));
+                        const double t1 = fma(a[q][r][2], w21, fma(a[q][r][1], w11, a[q][r][0] * w10));
+                        const double t2 = fma(a[q][r][2], w22, fma(a[q][r][1], w21, a[q][r][0] * w20));
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) C[q][r][c] = fma(-t2, b[q][c][2], fma(-t1, b[q][c][1], fma(-t0, b[q][c][0], C[q][r][c])));
+                    }
+                    if (tK[q] == j + 1 && tI[q] > j + 1) {
+                        double* o = A + (3 * tI[q]) * ld + 3 * (j + 1);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) o[r * ld + c] = C[q][r][c];
+                    }
                 }
-            }
-            if (bad && lane == 0) s_fail = 1;
         }
-        __syncthreads();
-        CHOL_LAP(0)
-        if (s_fail) break;
-        // (2) panel: L21 = A21 * L11^-T, one thread per row (row n = right-hand side); no dependent chain
-        for (int i = je + tid; i <= n; i += nt) {
-            double a[CHOL_NB], o[CHOL_NB];
-#pragma unroll
-            for (int k = 0; k < CHOL_NB; ++k) a[k] = A[i * ld + min(jb + k, n - 1)];
-#pragma unroll
-            for (int k = 0; k < CHOL_NB; ++k) a[k] = (k < w) ? a[k] : 0.0;
-#pragma unroll
-            for (int c = 0; c < CHOL_NB; ++c) {  // s_X rows/cols beyond the block are those of the identity: harmless
-                double v = 0.0;
-#pragma unroll
-                for (int k = 0; k <= c; ++k) v += a[k] * s_X[c][k];
-                o[c] = v;
-            }
-#pragma unroll
-            for (int c = 0; c < CHOL_NB; ++c)
-                if (c < w) A[i * ld + jb + c] = o[c];
-        }
-        __syncthreads();
-        CHOL_LAP(1)
-        {  // (3) trailing update: rows je..n, columns je..min(i, n-1); the 2 x 16 panel values are loaded up front
-            const int ti = tid >> 4, tj = tid & 15, tstep = nt >> 4;
-            for (int i = je + ti; i <= n; i += tstep) {
-                const int kmax = i < n ? i : n - 1;
-                double li[CHOL_NB];
-#pragma unroll
-                for (int c = 0; c < CHOL_NB; ++c) li[c] = A[i * ld + min(jb + c, n - 1)];
-#pragma unroll
-                for (int c = 0; c < CHOL_NB; ++c) li[c] = (c < w) ? li[c] : 0.0;
-                for (int k = je + tj; k <= kmax; k += 16) {
-                    double lk[CHOL_NB];
-#pragma unroll
-                    for (int c = 0; c < CHOL_NB; ++c) lk[c] = A[k * ld + min(jb + c, n - 1)];
-                    double v = A[i * ld + k];
-#pragma unroll
-                    for (int c = 0; c < CHOL_NB; ++c) v -= li[c] * lk[c];
-                    A[i * ld + k] = v;
-                }
-            }
-        }
-        __syncthreads();
-        CHOL_LAP(2)
+        if (failed) break;
     }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
     if (s_fail) {
         if (tid == 0) D.ctl->solve_failed = 1;
         for (int i = tid; i < n; i += nt) D.dp[i] = 0.0;
         return;
     }
     if (tid < 64) {
-        // back substitution L^T x = y (y = row n) in wave 0: y and 1/L_ii live in registers (lane k holds entries
-        // k, k+64, k+128), x_i is broadcast with v_readlane, row i-1 of L is prefetched while row i is applied
-        double y[3], iv[3], l[3], l1[3], l2[3];
-        auto row = [&](int i, double (&dst)[3]) {  // entries k < i of row i of L (lanes hold k, k+64, k+128)
+        // x_I = W_I (z_I - sum_{M > I} A_MI^T x_M), I = R-2 .. 0.  Lane k < 63 holds entries k, k + 63, k + 126 of z (63 = 21 blocks:
+        // a block never straddles two registers, so every register index below is a compile-time constant); the three finished
+        // entries of block I are broadcast with v_readlane, x_I is computed by every lane, and the lanes holding earlier entries
+        // subtract their share sum_r A[3 I + r][k] x_I[r].  The rows and W of block I - 1 are loaded while block I is applied.
+        double z0, z1, z2;
+        {
+            const int k = min(lane, 62);
+            z0 = k < n ? A[n * ld + k] : 0.0;
+            z1 = k + 63 < n ? A[n * ld + k + 63] : 0.0;
+            z2 = k + 126 < n ? A[n * ld + k + 126] : 0.0;
+        }
+        struct Blk {
+            double r0[3], r1[3], r2[3], w[6];  // rows 3 I + {0, 1, 2} at this lane's entries (register q), the inverse pivot tile
+        };
+        auto fetch = [&](int I, int Q, Blk& b) {  // Q = I / 21: only registers q <= Q are still open
+            const int Ic = max(I, 0), k = min(lane, 62);
+            const double* row = A + (3 * Ic) * ld;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int k = lane + 64 * q;
-                dst[q] = A[max(i, 0) * ld + min(k, n - 1)];
+            for (int q = 0; q < 3; ++q)
+                if (q <= Q) {
+                    const int e = min(k + 63 * q, n - 1);
+                    b.r0[q] = row[e];
+                    b.r1[q] = row[ld + e];
+                    b.r2[q] = row[2 * ld + e];
+                }
+#pragma unroll
+            for (int e = 0; e < 6; ++e) b.w[e] = s_W[Ic][e];
+        };
+        auto apply = [&](int I, auto QC, const Blk& b) {
+            constexpr int Q = decltype(QC)::value;
+            const int base = 3 * (I - 21 * Q);  // lane of the block's first entry in register Q
+            double& zq = Q == 0 ? z0 : (Q == 1 ? z1 : z2);
+            const double s0 = readlane_d(zq, base), s1 = readlane_d(zq, base + 1), s2 = readlane_d(zq, base + 2);
+            const double x0 = fma(b.w[3], s2, fma(b.w[1], s1, b.w[0] * s0));
+            const double x1 = fma(b.w[4], s2, fma(b.w[2], s1, b.w[1] * s0));
+            const double x2 = fma(b.w[5], s2, fma(b.w[4], s1, b.w[3] * s0));
+            const int d = lane - base;
+            if (d < 0) zq = fma(-b.r2[Q], x2, fma(-b.r1[Q], x1, fma(-b.r0[Q], x0, zq)));
+            else if (d < 3) zq = d == 0 ? x0 : (d == 1 ? x1 : x2);
+            if constexpr (Q >= 1) z0 = fma(-b.r2[0], x2, fma(-b.r1[0], x1, fma(-b.r0[0], x0, z0)));
+            if constexpr (Q >= 2) z1 = fma(-b.r2[1], x2, fma(-b.r1[1], x1, fma(-b.r0[1], x0, z1)));
+        };
+        auto phase = [&](auto QC, int I_hi, int I_lo) {  // blocks I_hi .. I_lo (descending), all in register Q
+            constexpr int Q = decltype(QC)::value;
+            if (I_hi < I_lo) return;
+            Blk ba, bb;
+            fetch(I_hi, Q, ba);
+            for (int I = I_hi; I >= I_lo; I -= 2) {
+                fetch(max(I - 1, I_lo), Q, bb);
+                apply(I, QC, ba);
+                if (I - 1 >= I_lo) {
+                    fetch(max(I - 2, I_lo), Q, ba);
+                    apply(I - 1, QC, bb);
+                }
             }
         };
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int k = lane + 64 * q;
-            y[q] = k < n ? A[n * ld + k] : 0.0;
-            iv[q] = k < n ? s_invd[k] : 0.0;
+        const int last = R - 2;
+        phase(std::integral_constant<int, 2>{}, last, 42);
+        phase(std::integral_constant<int, 1>{}, min(last, 41), 21);
+        phase(std::integral_constant<int, 0>{}, min(last, 20), 0);
+        if (lane < 63) {
+            if (lane < n) D.dp[lane] = z0;
+            if (lane + 63 < n) D.dp[lane + 63] = z1;
+            if (lane + 126 < n) D.dp[lane + 126] = z2;
         }
-        row(n - 1, l);
-        row(n - 2, l1);
-        for (int i = n - 1; i >= 0; --i) {
-            row(i - 2, l2);  // two rows of LDS latency are hidden behind the arithmetic
-            const int qi = i >> 6, li = i & 63;
-            const double ysel = qi == 0 ? y[0] : (qi == 1 ? y[1] : y[2]);
-            const double isel = qi == 0 ? iv[0] : (qi == 1 ? iv[1] : iv[2]);
-            const double prod = ysel * isel;
-            const double xi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(prod), li),
-                                               __builtin_amdgcn_readlane(__double2loint(prod), li));
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int k = lane + 64 * q;
-                if (k == i) y[q] = xi;
-                else if (k < i) y[q] -= l[q] * xi;
-                l[q] = l1[q];
-                l1[q] = l2[q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int k = lane + 64 * q;
-            if (k < n) D.dp[k] = y[q];
-        }
-        CHOL_LAP(3)
-        if (lane == 0)
-            for (int q = 0; q < 4; ++q) D.red[D.red_flag_off + 2 + q] = (double)t_acc[q];
     }
 }
 
@@ -1086,7 +1079,7 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
 // Block-Jacobi preconditioned conjugate gradients on the reduced camera system with EVERYTHING in the LDS of one workgroup: the
 // kept 6x6 blocks (36 doubles each), the block-row lists, the inverse diagonal blocks and the five vectors.  A local-BA system
 // (6 * free keyframes <= a few hundred unknowns, <= ~450 blocks) converges to 1e-10 in a few dozen iterations of ~0.4 us each;
-// the dense LL^T this replaces (k_ba_chol_lds) spent 70 us per trial in 12 barrier-separated panel steps.
+// (the solver policy in svgpu_ba.hip says when this is preferred to the dense LL^T, k_ba_chol_tile).
 // Dynamic LDS layout (doubles): blk[36 NB] | Minv[36 nP] | x r z p q [5 n] | part[6 nent] | wsum[48]; then ints: rowoff[nP + 1], ent[2 nent]
 #define PL_THREADS 512
 __global__ __launch_bounds__(PL_THREADS) void k_ba_pcg_lds(BaDev D, int nent) {
@@ -1583,13 +1576,22 @@ __global__ void k_ba_potrf_info(const int* info, BaDev D) {
 }
 }  // namespace
 
-// on-chip dense LL^T (n <= 192)
+size_t sv_ba_chol_bytes(int n) { return sizeof(double) * (size_t)(n + 3) * (n | 1); }
+// on-chip dense LL^T: n <= 186 (two tiles per thread) and sv_ba_chol_bytes(n) within the LDS budget
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP <= 0) return;
     SvProfScope ps(ctx, s, "ba_solve");
-    const size_t lds = sizeof(double) * (size_t)(D.n + 1) * (D.n | 1);
-    (void)sv_allow_dynamic_lds((const void*)k_ba_chol_lds, lds);  // dynamic LDS above 64 KB must be allowed explicitly
-    hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(CHOL_THREADS), lds, s, D);
+    const size_t lds = sv_ba_chol_bytes(D.n);
+    const int R = D.n / 3 + 1, NT = R * (R + 1) / 2;
+    const int threads = std::min(CHOL_MAX_THREADS, (NT + 63) & ~63);
+    if (NT <= threads) {
+        (void)sv_allow_dynamic_lds((const void*)k_ba_chol_tile<1>, lds);  // dynamic LDS above 64 KB must be allowed explicitly
+        hipLaunchKernelGGL(k_ba_chol_tile<1>, dim3(1), dim3(threads), lds, s, D);
+    }
+    else {
+        (void)sv_allow_dynamic_lds((const void*)k_ba_chol_tile<2>, lds);
+        hipLaunchKernelGGL(k_ba_chol_tile<2>, dim3(1), dim3(threads), lds, s, D);
+    }
 }
 
 // dense image + rocSOLVER (or, without it, the one-workgroup global-memory factorisation)

@@ -481,7 +481,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         }
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
-        D.chol_in_lds = D.n <= 192 && sizeof(double) * (size_t)(D.n + 1) * (D.n | 1) <= 160 * 1024 - 12 * 1024;
+        D.chol_in_lds = D.n <= 186 && sv_ba_chol_bytes(D.n) <= 160 * 1024 - 12 * 1024;
         solver = solver_opt;
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;

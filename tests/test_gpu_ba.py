@@ -43,6 +43,9 @@ def _assert_poses(got, ref, tol=TOL):
                                 dict(num_kf=10, num_lm=1500, obs_per_lm=5, num_fixed=3, seed=5),
                                 dict(num_kf=12, num_lm=900, obs_per_lm=6, num_fixed=2, seed=6, stereo=True),
                                 dict(num_kf=20, num_lm=10000, obs_per_lm=6, num_fixed=4, seed=1234),
+                                # the on-chip LL^T at its limits: n = 126 (946 of 1024 tiles, one per thread), n = 132 (two per thread)
+                                dict(num_kf=24, num_lm=3000, obs_per_lm=6, num_fixed=3, seed=21),
+                                dict(num_kf=24, num_lm=3000, obs_per_lm=6, num_fixed=2, seed=22),
                                 # equirectangular cameras (intrinsics rows {0, 0, cols, rows, 0}): equirectangular_reproj_edge.h:64-134
                                 dict(num_kf=8, num_lm=1200, obs_per_lm=5, num_fixed=2, seed=8, equirect=True)])
 def test_local_ba_matches_oracle(ba, kw):
