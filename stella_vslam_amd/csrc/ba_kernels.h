@@ -119,6 +119,7 @@ int sv_ba_lin_split();
 int sv_ba_rhs_split();
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded);
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out);
+void sv_ba_pack_out(hipStream_t s, const BaDev& D, double* out);  // poses | points of the current estimate, contiguous
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale);   // this rank's partial sums -> 4 doubles (sharded solve)
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in);       // start of SparseOptimizer::optimize(it_max)
 void sv_ba_prepare(hipStream_t s, const BaDev& D);                              // lambda init (iteration 0) + start of a trial

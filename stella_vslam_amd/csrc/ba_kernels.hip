@@ -1626,6 +1626,16 @@ void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, in
     if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache, guarded);
 }
 
+// the current estimate (the control block says which of the two state buffers holds it) -> one contiguous output block
+__global__ __launch_bounds__(256) void k_ba_pack_out(BaDev D, double* __restrict__ out) {
+    const int cur = D.ctl->cur & 1;
+    const size_t np = 12 * (size_t)D.P, n = np + 3 * (size_t)D.L;
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = i < np ? D.pose_buf[cur][i] : D.pt_buf[cur][i - np];
+}
+void sv_ba_pack_out(hipStream_t s, const BaDev& D, double* out) {
+    const size_t n = 12 * (size_t)D.P + 3 * (size_t)D.L;
+    if (n) hipLaunchKernelGGL(k_ba_pack_out, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, D, out);
+}
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out) {
     if (D.E > 0) hipLaunchKernelGGL(k_ba_gate, dim3((D.E + 255) / 256), dim3(256), 0, s, D, set_levels, outlier_out);
 }

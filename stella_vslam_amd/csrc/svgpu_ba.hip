@@ -46,7 +46,7 @@ struct HostStructure {
 };
 
 // pose / landmark activity under the current edge levels (the cheap first half of build_structure)
-void activity_only(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, const std::vector<int>& e_point,
+void activity_only(const svgpu_ba_problem& pr, const int* e_pose, const int* e_point,
                    const std::vector<uint8_t>& level, const std::vector<uint8_t>* pose_active_global, HostStructure& H) {
     const int P = pr.num_poses, L = pr.num_points, E = pr.num_obs;
     std::vector<uint8_t> pa(P, 0), la(L, 0);
@@ -74,8 +74,8 @@ void activity_only(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, c
 }
 
 // initializeOptimization(level 0): active vertices = endpoints of active edges; free = active and not fixed.
-void build_structure(const svgpu_ba_problem& pr, const std::vector<int>& e_pose, const std::vector<int>& e_point,
-                     const std::vector<int>& lm_off, const std::vector<uint8_t>& level, const std::vector<uint8_t>* pose_active_global,
+void build_structure(const svgpu_ba_problem& pr, const int* e_pose, const int* e_point,
+                     const int* lm_off, const std::vector<uint8_t>& level, const std::vector<uint8_t>* pose_active_global,
                      HostStructure& H) {
     const int P = pr.num_poses, L = pr.num_points, E = pr.num_obs;
     std::vector<uint8_t> pa(P, 0), la(L, 0);
@@ -220,17 +220,55 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
-    // ---- sort the observations by landmark (stable): landmark-major kernels then read contiguous runs
-    std::vector<int> lm_off(L + 1, 0), perm(E);
+    // ---- page-locked staging laid out exactly like the input block at the head of the device arena (one copy carries everything):
+    //      poses | points | intrinsics | e_pose | e_point | e_uvr | e_w | e_huber | e_robust | lm_off.  The observations are written
+    //      sorted by landmark (stable): landmark-major kernels then read contiguous runs.  Behind it, the output block's host image.
+    struct {
+        size_t pose, points, intr, e_pose, e_point, e_uvr, e_w, e_hub, robust, lm_off, total;
+    } in;
+    {
+        size_t o = 0;
+        auto put = [&](size_t bytes) {
+            const size_t r = o;
+            o += pad(bytes);
+            return r;
+        };
+        in.pose = put(sizeof(double) * 12 * (size_t)P);
+        in.points = put(sizeof(double) * 3 * (size_t)L);
+        in.intr = put(sizeof(double) * 5 * (size_t)P);
+        in.e_pose = put(4 * (size_t)E);
+        in.e_point = put(4 * (size_t)E);
+        in.e_uvr = put(12 * (size_t)E);
+        in.e_w = put(4 * (size_t)E);
+        in.e_hub = put(4 * (size_t)E);
+        in.robust = put(E);
+        in.lm_off = put(4 * (size_t)(L + 1));
+        in.total = o;
+    }
+    const size_t out_ctl = 0, out_state = pad(sizeof(BaCtl)), out_outlier = out_state + pad(sizeof(double) * (12 * (size_t)P + 3 * (size_t)L));
+    const size_t out_total = out_outlier + pad((size_t)E + 1);
+    {
+        const int r = sv_ensure_stage(ctx, in.total + out_total);
+        if (r) return r;
+    }
+    char* const hs = ctx->h_stage;
+    char* const hs_out = hs + in.total;
+    int* const lm_off = (int*)(hs + in.lm_off);
+    int* const e_pose = (int*)(hs + in.e_pose);
+    int* const e_point = (int*)(hs + in.e_point);
+    float* const e_uvr = (float*)(hs + in.e_uvr);
+    float* const e_w = (float*)(hs + in.e_w);
+    float* const e_hub = (float*)(hs + in.e_hub);
+    uint8_t* const robust = (uint8_t*)(hs + in.robust);
+    std::vector<int> perm(E);
+    std::vector<uint8_t> level(E, 0);
+    for (int l = 0; l <= L; ++l) lm_off[l] = 0;
     for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
     for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
     {
-        std::vector<int> fill(lm_off.begin(), lm_off.end() - 1);
+        std::vector<int> fill(lm_off, lm_off + L);
         for (int e = 0; e < E; ++e) perm[fill[pr->obs_point[e]]++] = e;
     }
-    std::vector<int> e_pose(E), e_point(E);
-    std::vector<float> e_uvr(3 * (size_t)E), e_w(E), e_hub(E);
-    std::vector<uint8_t> level(E, 0), robust(E, 0);
     for (int k = 0; k < E; ++k) {
         const int e = perm[k];
         e_pose[k] = pr->obs_pose[e];
@@ -242,6 +280,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         e_hub[k] = pr->obs_huber_delta ? pr->obs_huber_delta[e] : 0.f;
         robust[k] = e_hub[k] > 0.f;
     }
+    memcpy(hs + in.pose, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
+    memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
+    memcpy(hs + in.intr, pr->intrinsics, sizeof(double) * 5 * (size_t)P);
 
     lap("sort observations");
     // ---- solver choice (svgpu_ba_set_solver; SVGPU_BA_SOLVER overrides for experiments)
@@ -278,7 +319,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     const size_t pair_scratch = sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap);
-    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch);
+    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total;
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -289,22 +330,29 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.E = E;
     D.world = world;
     D.rank = rank;
+    // input block (same layout as the staging buffer)
     D.pose_buf[0] = A.take<double>(12 * (size_t)P);
-    D.pose_buf[1] = A.take<double>(12 * (size_t)P);
     D.pt_buf[0] = A.take<double>(3 * (size_t)L);
-    D.pt_buf[1] = A.take<double>(3 * (size_t)L);
+    double* d_intr = A.take<double>(5 * (size_t)P);
     int* d_e_pose = A.take<int>(E);
     int* d_e_point = A.take<int>(E);
     float* d_e_uvr = A.take<float>(3 * (size_t)E);
     float* d_e_w = A.take<float>(E);
     float* d_e_hub = A.take<float>(E);
-    D.e_level = A.take<uint8_t>(E);
     D.e_robust = A.take<uint8_t>(E);
+    int* d_lm_off = A.take<int>(L + 1);
+    if (A.off != in.total) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: internal layout mismatch");
+    // output block: control block | poses | points | outlier flags
+    char* const d_out = A.base + A.off;
+    D.ctl = (BaCtl*)A.take<char>(sizeof(BaCtl));
+    double* d_state_out = A.take<double>(12 * (size_t)P + 3 * (size_t)L);
+    uint8_t* d_outlier = A.take<uint8_t>(E + 1);
+    D.pose_buf[1] = A.take<double>(12 * (size_t)P);
+    D.pt_buf[1] = A.take<double>(3 * (size_t)L);
+    D.e_level = A.take<uint8_t>(E);
     D.e_chi = A.take<double>(E);
-    double* d_intr = A.take<double>(5 * (size_t)P);
     int* d_pose_slot = A.take<int>(P);
     uint8_t* d_pt_free = A.take<uint8_t>(L);
-    int* d_lm_off = A.take<int>(L + 1);
     int* d_pe_off = A.take<int>(P + 1);
     int* d_pe_idx = A.take<int>(E);
     D.W = A.take<double>(18 * (size_t)E);
@@ -319,11 +367,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.S = want_dense ? A.take<double>((size_t)(nmax + 1) * nmax) : nullptr;
     D.dp = A.take<double>(nmax);
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
-    uint8_t* d_outlier = A.take<uint8_t>(E + 1);
     double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
     double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
     double* d_xch = A.take<double>(xch_doubles);                  // sharded: pose-activity / block-presence / point exchange
-    D.ctl = (BaCtl*)A.take<char>(sizeof(BaCtl));
     int* d_prow_off = A.take<int>(P + 1);
     int2* d_prow_ent = A.take<int2>(2 * (nb_cap + 1));
     int* d_diag_blk = A.take<int>(P);
@@ -403,17 +449,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     };
 
 #define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
-    H2D(D.pose_buf[0], pr->pose_cw, sizeof(double) * 12 * (size_t)P);
-    H2D(D.pt_buf[0], pr->points, sizeof(double) * 3 * (size_t)L);
-    H2D(d_e_pose, e_pose.data(), 4 * (size_t)E);
-    H2D(d_e_point, e_point.data(), 4 * (size_t)E);
-    H2D(d_e_uvr, e_uvr.data(), 12 * (size_t)E);
-    H2D(d_e_w, e_w.data(), 4 * (size_t)E);
-    H2D(d_e_hub, e_hub.data(), 4 * (size_t)E);
-    H2D(D.e_level, level.data(), E);
-    H2D(D.e_robust, robust.data(), E);
-    H2D(d_intr, pr->intrinsics, sizeof(double) * 5 * (size_t)P);
-    H2D(d_lm_off, lm_off.data(), 4 * (size_t)(L + 1));
+    H2D(D.pose_buf[0], hs, in.total);
+    SV_HIP(ctx, hipMemsetAsync(D.e_level, 0, E, s));
     SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
     BaCtl ctl0;
     memset(&ctl0, 0, sizeof(ctl0));
@@ -479,6 +516,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             build_structure(*pr, e_pose, e_point, lm_off, level, pa_override, HS);
             have_lists = true;
         }
+        auto sub = [&](const char* what) {
+            if (trace) std::fprintf(stderr, "[ba]     %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+        };
+        sub("host lists");
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
         D.chol_in_lds = D.n <= 186 && sv_ba_chol_bytes(D.n) <= 160 * 1024 - 12 * 1024;
@@ -495,6 +536,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             std::vector<int> dense_off;
             int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, dense_off);
             if (rp) return rp;
+            sub("device pairs");
             std::vector<uint8_t> present(dense_off.size() ? dense_off.size() - 1 : 0, 0);
             for (size_t k = 0; k < present.size(); ++k) present[k] = dense_off[k + 1] > dense_off[k];
             if (sharded && !present.empty()) {  // the kept-block list must be the same on every rank: union of the local patterns
@@ -541,7 +583,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             H2D(d_prow_off, prow_off.data(), 4 * prow_off.size());
             if (!prow_ent.empty()) H2D(d_prow_ent, prow_ent.data(), 8 * prow_ent.size());
             if (!diag.empty()) H2D(d_diag_blk, diag.data(), 4 * diag.size());
+            sub("block rows");
             SV_HIP(ctx, hipStreamSynchronize(s));  // the host vectors above go out of scope
+            sub("sync");
         }
         else sv_ba_zero_inactive(s, D);
         D.NB = (int)HS.blk_ab.size();
@@ -693,19 +737,17 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         st.iters_stage2 = it2;
         lap("stage 2");
     }
-    // ---- outlier list, final chi2, read-back
-    std::vector<uint8_t> outl(E);
-    if (E > 0 && outlier_out) {
-        sv_ba_gate(s, D, 0, d_outlier);
-        SV_HIP(ctx, hipMemcpyAsync(outl.data(), d_outlier, E, hipMemcpyDeviceToHost, s));
-    }
+    // ---- outlier list, final chi2, read-back: ONE copy of the output block (control block | poses | points | outlier flags)
+    if (E > 0 && outlier_out) sv_ba_gate(s, D, 0, d_outlier);
     if ((rc = chi2_begin(0))) return rc;
     sv_ba_begin(s, D, 0, 0);  // folds the chi2 of the final estimate into the control block (phase 2: nothing else happens)
-    if ((rc = read_ctl())) return rc;
-    const int cur = h_ctl->cur & 1;
-    SV_HIP(ctx, hipMemcpyAsync(pose_out, D.pose_buf[cur], sizeof(double) * 12 * (size_t)P, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(points_out, D.pt_buf[cur], sizeof(double) * 3 * (size_t)L, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipStreamSynchronize(s));
+    sv_ba_pack_out(s, D, d_state_out);
+    SV_HIP(ctx, hipMemcpyAsync(hs_out, d_out, out_total, hipMemcpyDeviceToHost, s));
+    if ((rc = wait_stream())) return rc;
+    memcpy(h_ctl, hs_out + out_ctl, sizeof(BaCtl));
+    memcpy(pose_out, hs_out + out_state, sizeof(double) * 12 * (size_t)P);
+    memcpy(points_out, hs_out + out_state + sizeof(double) * 12 * (size_t)P, sizeof(double) * 3 * (size_t)L);
+    const uint8_t* const outl = (const uint8_t*)(hs_out + out_outlier);
     if (sharded) {  // every rank ends with every landmark: owners contribute their points, the rest zeros
         for (int l = 0; l < L; ++l) {
             for (int k = 0; k < 3; ++k) xch_host[3 * (size_t)l + k] = owned[l] ? points_out[3 * (size_t)l + k] : 0.0;

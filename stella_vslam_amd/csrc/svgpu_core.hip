@@ -31,6 +31,20 @@ hipError_t sv_allow_dynamic_lds(const void* kernel, size_t bytes) {
     return e;
 }
 
+int sv_ensure_stage(svgpu_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->stage_bytes) return SVGPU_OK;
+    if (ctx->h_stage) {
+        SV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SV_HIP(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr;
+        ctx->stage_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    SV_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage, want, hipHostMallocDefault));
+    ctx->stage_bytes = want;
+    return SVGPU_OK;
+}
+
 int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return SVGPU_OK;
     if (ctx->d_scratch) {
@@ -143,6 +157,7 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     sv_comm_release(ctx);
     if (ctx->ev_ba) (void)hipEventDestroy(ctx->ev_ba);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

@@ -103,6 +103,8 @@ struct svgpu_ctx {
     void* d_scratch = nullptr;
     double* h_pinned = nullptr;     // page-locked read-back buffer of the BA loops (small per-trial partial sums)
     size_t pinned_doubles = 0;
+    char* h_stage = nullptr;        // page-locked staging of the BA entry points: inputs are written here in device layout, one copy each way
+    size_t stage_bytes = 0;
     size_t scratch_bytes = 0;
     // bundle adjustment
     hipEvent_t ev_ba = nullptr;     // completion event the BA host loop polls (while mirroring the caller's stop flag)
@@ -129,6 +131,7 @@ struct SvProfScope {  // brackets the launches issued inside its lifetime when `
     }
 };
 int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes);
+int sv_ensure_stage(svgpu_ctx* ctx, size_t bytes);  // grow-only page-locked host buffer (ctx->h_stage)
 hipError_t sv_allow_dynamic_lds(const void* kernel, size_t bytes);  // per (device, kernel), thread-safe
 void sv_orb_release(svgpu_ctx* ctx);
 
