@@ -136,3 +136,48 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
     SV_HIP(ctx, hipStreamSynchronize(s));
     return SVGPU_OK;
 }
+
+// Same pipeline with the pair total known to the caller (svgpu_ba.hip: host_pair_total): nothing is read back, nothing synchronises.
+// The dense block offsets (nP (nP + 1) / 2 + 1 ints) are written to `dense_off_dev`.
+int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
+                            int2* pairs_out, int* dense_off_dev) {
+    const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
+    if (L == 0 || D.nP == 0) {
+        SV_HIP(ctx, hipMemsetAsync(dense_off_dev, 0, 4 * ((size_t)nb_dense + 1), s));
+        return SVGPU_OK;
+    }
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += (bytes + 255) & ~size_t(255);
+        return (void*)r;
+    };
+    size_t t1 = 0, t2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
+                                       (unsigned long long*)nullptr, (int)pair_cap);
+    const size_t tbytes = t1 > t2 ? t1 : t2;
+    void* temp = take(tbytes);
+    int* cnt = (int*)take((size_t)(L + 2) * 4);
+    int* off = (int*)take((size_t)(L + 2) * 4);
+    unsigned* keys_in = (unsigned*)take(pair_cap * 4);
+    unsigned* keys_out = (unsigned*)take(pair_cap * 4);
+    unsigned long long* vals_in = (unsigned long long*)take(pair_cap * 8);
+    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list scratch too small");
+    SV_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt);
+    SV_HIP(ctx, hipGetLastError());
+    SV_HIP(ctx, hipMemsetAsync(cnt + L, 0, 4, s));
+    size_t tb = tbytes;
+    SV_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(temp, tb, cnt, off, L + 1, s));
+    if (total > 0) {
+        hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, off, keys_in, vals_in);
+        int bits = 1;
+        while ((1u << bits) < (unsigned)nb_dense + 1u && bits < 32) ++bits;
+        tb = tbytes;
+        SV_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_in, keys_out, vals_in, reinterpret_cast<unsigned long long*>(pairs_out),
+                                                       total, 0, bits, s));
+    }
+    hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys_out, total, nb_dense, dense_off_dev);
+    return SVGPU_OK;
+}

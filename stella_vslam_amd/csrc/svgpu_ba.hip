@@ -19,6 +19,8 @@ void sv_ba_zero_inactive(hipStream_t s, const BaDev& D);
 size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap);
 int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int2* pairs_out,
                       std::vector<int>& dense_off_host);
+int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
+                            int2* pairs_out, int* dense_off_dev);
 
 namespace {
 
@@ -73,33 +75,9 @@ void activity_only(const svgpu_ba_problem& pr, const int* e_pose, const int* e_p
         }
 }
 
-// initializeOptimization(level 0): active vertices = endpoints of active edges; free = active and not fixed.
-void build_structure(const svgpu_ba_problem& pr, const int* e_pose, const int* e_point,
-                     const int* lm_off, const std::vector<uint8_t>& level, const std::vector<uint8_t>* pose_active_global,
-                     HostStructure& H) {
-    const int P = pr.num_poses, L = pr.num_points, E = pr.num_obs;
-    std::vector<uint8_t> pa(P, 0), la(L, 0);
-    for (int e = 0; e < E; ++e)
-        if (!level[e]) {
-            pa[e_pose[e]] = 1;
-            la[e_point[e]] = 1;
-        }
-    if (pose_active_global) pa = *pose_active_global;  // sharded solve: activity summed over all ranks
-    H.pose_slot.assign(P, -1);
-    H.slot_pose.clear();
-    for (int p = 0; p < P; ++p)
-        if (pa[p] && !pr.pose_fixed[p]) {
-            H.pose_slot[p] = (int)H.slot_pose.size();
-            H.slot_pose.push_back(p);
-        }
-    H.nP = (int)H.slot_pose.size();
-    H.pt_free.assign(L, 0);
-    H.nL = 0;
-    for (int l = 0; l < L; ++l)
-        if (la[l] && !(pr.point_fixed && pr.point_fixed[l])) {
-            H.pt_free[l] = 1;
-            ++H.nL;
-        }
+// pose -> edge lists of the free poses (H.pose_slot / H.nP from activity_only)
+void build_pose_lists(const svgpu_ba_problem& pr, const int* e_pose, const std::vector<uint8_t>& level, HostStructure& H) {
+    const int E = pr.num_obs;
     // pose -> active edges
     H.pe_off.assign(H.nP + 1, 0);
     for (int e = 0; e < E; ++e)
@@ -112,6 +90,32 @@ void build_structure(const svgpu_ba_problem& pr, const int* e_pose, const int* e
             if (!level[e] && H.pose_slot[e_pose[e]] >= 0) H.pe_idx[fill[H.pose_slot[e_pose[e]]]++] = e;
     }
     // the (edge, edge) pair lists of the upper blocks (a <= b) are built on the device: sv_ba_build_pairs + compact_blocks
+}
+
+// Number of (edge, edge) pairs k_pair_emit will produce, computed on the host so that the device pipeline needs no read-back: per
+// free landmark with k_s live edges on free pose slot s, sum_{s<t} k_s k_t + sum_s k_s^2 (a pair of two different edges of ONE pose
+// is emitted twice, mirrored) = (K^2 + sum_s k_s^2) / 2 with K = sum_s k_s.  Requires nP <= 64.
+long long host_pair_total(const svgpu_ba_problem& pr, const int* e_pose, const int* lm_off, const std::vector<uint8_t>& level, const HostStructure& H) {
+    long long total = 0;
+    int cnt[64];
+    for (int k = 0; k < 64; ++k) cnt[k] = 0;
+    for (int l = 0; l < pr.num_points; ++l) {
+        if (!H.pt_free[l]) continue;
+        long long K = 0, sq = 0;
+        for (int e = lm_off[l]; e < lm_off[l + 1]; ++e) {
+            const int sl = H.pose_slot[e_pose[e]];
+            if (level[e] || sl < 0) continue;
+            sq += 2 * cnt[sl] + 1;  // (c + 1)^2 - c^2
+            ++cnt[sl];
+            ++K;
+        }
+        for (int e = lm_off[l]; e < lm_off[l + 1]; ++e) {
+            const int sl = H.pose_slot[e_pose[e]];
+            if (sl >= 0) cnt[sl] = 0;
+        }
+        total += (K * K + sq) / 2;
+    }
+    return total;
 }
 
 // dense block offsets (from the device) -> kept blocks: every diagonal block (it carries Hpp + lambda I) and every non-empty
@@ -245,14 +249,19 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         in.lm_off = put(4 * (size_t)(L + 1));
         in.total = o;
     }
+    // structure block (host image only; its pieces go to separate device arrays): pt_free | pose_slot | pe_off, pe_idx | blk_ab, prow_off, diag | prow_ent
+    const size_t nb_cap_h = (size_t)P * (P + 1) / 2;
+    const size_t st_pt_free = 0, st_pose_slot = pad(L), st_pe = st_pose_slot + pad(4 * (size_t)P), st_blk = st_pe + pad(4 * ((size_t)P + 1 + E));
+    const size_t st_prow = st_blk + pad(8 * nb_cap_h + 4 * (2 * (size_t)P + 2)), st_total = st_prow + pad(8 * 2 * (nb_cap_h + 1));
     const size_t out_ctl = 0, out_state = pad(sizeof(BaCtl)), out_outlier = out_state + pad(sizeof(double) * (12 * (size_t)P + 3 * (size_t)L));
     const size_t out_total = out_outlier + pad((size_t)E + 1);
     {
-        const int r = sv_ensure_stage(ctx, in.total + out_total);
+        const int r = sv_ensure_stage(ctx, in.total + out_total + st_total);
         if (r) return r;
     }
     char* const hs = ctx->h_stage;
     char* const hs_out = hs + in.total;
+    char* const hs_struct = hs_out + out_total;
     int* const lm_off = (int*)(hs + in.lm_off);
     int* const e_pose = (int*)(hs + in.e_pose);
     int* const e_point = (int*)(hs + in.e_point);
@@ -505,6 +514,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         // and (edge, edge) pair lists -- only when the free-pose numbering changed.  Lists built for an earlier stage
         // stay valid: edges excluded since then are skipped by level (lin_pose, rhs) or contribute W = Y = 0 (pairs).
         auto tb0 = std::chrono::steady_clock::now();
+        auto sub = [&](const char* what) {
+            if (trace) std::fprintf(stderr, "[ba]     %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+        };
         HostStructure probe;
         activity_only(*pr, e_pose, e_point, level, pa_override, probe);
         const bool reuse = have_lists && probe.pose_slot == HS.pose_slot;
@@ -513,13 +525,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             HS.nL = probe.nL;
         }
         else {
-            build_structure(*pr, e_pose, e_point, lm_off, level, pa_override, HS);
-            have_lists = true;
+            HS.pose_slot = probe.pose_slot;
+            HS.slot_pose = probe.slot_pose;
+            HS.pt_free = probe.pt_free;
+            HS.nP = probe.nP;
+            HS.nL = probe.nL;
         }
-        auto sub = [&](const char* what) {
-            if (trace) std::fprintf(stderr, "[ba]     %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
-        };
-        sub("host lists");
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
         D.chol_in_lds = D.n <= 186 && sv_ba_chol_bytes(D.n) <= 160 * 1024 - 12 * 1024;
@@ -528,48 +539,85 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
         D.add_lambda = (!sharded || rank == 0) ? 1 : 0;
-        H2D(d_pt_free, HS.pt_free.data(), L);
+        memcpy(hs_struct + st_pt_free, HS.pt_free.data(), L);
+        H2D(d_pt_free, hs_struct + st_pt_free, L);
         if (!reuse) {
-            H2D(d_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
-            H2D(d_pe_off, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
-            if (!HS.pe_idx.empty()) H2D(d_pe_idx, HS.pe_idx.data(), 4 * HS.pe_idx.size());
+            memcpy(hs_struct + st_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
+            H2D(d_pose_slot, hs_struct + st_pose_slot, 4 * (size_t)P);
+            // The pair lists are built on the device.  A local-BA sized problem (<= 48 free poses; the count is the same on every rank of
+            // a sharded solve) keeps EVERY upper block -- blocks without a pair are zero blocks, the solvers of that size are dense
+            // anyway, and no union of block patterns has to be agreed between ranks -- so nothing has to come back: the pair total is
+            // computed here, the device pipeline runs unattended and the pose -> edge lists are built on the host meanwhile.
+            // Larger systems synchronise twice (pair total, block offsets) and keep only the blocks that hold a pair.
+            const long long host_total = HS.nP <= 48 ? host_pair_total(*pr, e_pose, lm_off, level, HS) : -1;
             std::vector<int> dense_off;
-            int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, dense_off);
-            if (rp) return rp;
-            sub("device pairs");
-            std::vector<uint8_t> present(dense_off.size() ? dense_off.size() - 1 : 0, 0);
-            for (size_t k = 0; k < present.size(); ++k) present[k] = dense_off[k + 1] > dense_off[k];
-            if (sharded && !present.empty()) {  // the kept-block list must be the same on every rank: union of the local patterns
-                for (size_t k = 0; k < present.size(); ++k) xch_host[k] = present[k];
-                int r = allreduce_host(present.size());
-                if (r) return r;
-                for (size_t k = 0; k < present.size(); ++k) present[k] = xch_host[k] > 0.5;
+            if (host_total >= 0) {
+                if ((size_t)host_total > pair_cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list capacity exceeded");
+                int rp = sv_ba_build_pairs_async(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, (int)host_total, d_blk_pairs, d_blk_off);
+                if (rp) return rp;
+                sub("pairs enqueued");
             }
-            compact_blocks(dense_off, present, HS);
-            H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
-            if (!HS.blk_ab.empty()) H2D(d_blk_ab, HS.blk_ab.data(), 8 * HS.blk_ab.size());
+            build_pose_lists(*pr, e_pose, level, HS);
+            have_lists = true;
+            sub("host lists");
+            int* const h_pe = (int*)(hs_struct + st_pe);
+            memcpy(h_pe, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
+            if (!HS.pe_idx.empty()) memcpy(h_pe + (P + 1), HS.pe_idx.data(), 4 * HS.pe_idx.size());
+            H2D(d_pe_off, h_pe, 4 * (size_t)(HS.nP + 1));
+            if (!HS.pe_idx.empty()) H2D(d_pe_idx, h_pe + (P + 1), 4 * HS.pe_idx.size());
+            if (host_total >= 0) {
+                HS.blk_ab.clear();
+                for (int a = 0; a < HS.nP; ++a)
+                    for (int b = a; b < HS.nP; ++b) {
+                        int2 ab;
+                        ab.x = a;
+                        ab.y = b;
+                        HS.blk_ab.push_back(ab);
+                    }
+                HS.blk_off.clear();  // lives on the device only
+                HS.num_pairs = (size_t)host_total;
+            }
+            else {
+                int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, dense_off);
+                if (rp) return rp;
+                sub("device pairs");
+                std::vector<uint8_t> present(dense_off.size() ? dense_off.size() - 1 : 0, 0);
+                for (size_t k = 0; k < present.size(); ++k) present[k] = dense_off[k + 1] > dense_off[k];
+                if (sharded && !present.empty()) {  // the kept-block list must be the same on every rank: union of the local patterns
+                    for (size_t k = 0; k < present.size(); ++k) xch_host[k] = present[k];
+                    int r = allreduce_host(present.size());
+                    if (r) return r;
+                    for (size_t k = 0; k < present.size(); ++k) present[k] = xch_host[k] > 0.5;
+                }
+                compact_blocks(dense_off, present, HS);
+                H2D(d_blk_off, HS.blk_off.data(), 4 * HS.blk_off.size());
+            }
             // block rows for the PCG: row a lists its kept blocks (a, b) and, transposed, (b, a)
             const int NB = (int)HS.blk_ab.size();
-            std::vector<int> prow_off(HS.nP + 1, 0), diag(HS.nP, 0);
+            int2* const h_blk_ab = (int2*)(hs_struct + st_blk);
+            int* const h_prow_off = (int*)(h_blk_ab + NB);
+            int* const h_diag = h_prow_off + (HS.nP + 1);
+            int2* const h_prow_ent = (int2*)(hs_struct + st_prow);
+            for (int a = 0; a <= HS.nP; ++a) h_prow_off[a] = 0;
             for (int k = 0; k < NB; ++k) {
                 const int2 ab = HS.blk_ab[k];
-                prow_off[ab.x + 1]++;
-                if (ab.x != ab.y) prow_off[ab.y + 1]++;
-                else diag[ab.x] = k;
+                h_blk_ab[k] = ab;
+                h_prow_off[ab.x + 1]++;
+                if (ab.x != ab.y) h_prow_off[ab.y + 1]++;
+                else h_diag[ab.x] = k;
             }
-            for (int a = 0; a < HS.nP; ++a) prow_off[a + 1] += prow_off[a];
-            std::vector<int2> prow_ent(prow_off[HS.nP]);
+            for (int a = 0; a < HS.nP; ++a) h_prow_off[a + 1] += h_prow_off[a];
             {
                 // blk_ab is sorted by (a, b): filling row a with its transposed blocks (c, a), c < a, first (they arrive in c order)
                 // and its own blocks (a, b), b >= a, afterwards leaves every row sorted by column
-                std::vector<int> fill(prow_off.begin(), prow_off.end() - 1);
+                std::vector<int> fill(h_prow_off, h_prow_off + HS.nP);
                 for (int k = 0; k < NB; ++k) {
                     const int2 ab = HS.blk_ab[k];
                     if (ab.x != ab.y) {
                         int2 e2;
                         e2.x = k | (1 << 30);
                         e2.y = ab.x;
-                        prow_ent[fill[ab.y]++] = e2;
+                        h_prow_ent[fill[ab.y]++] = e2;
                     }
                 }
                 for (int k = 0; k < NB; ++k) {
@@ -577,15 +625,14 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                     int2 e1;
                     e1.x = k;
                     e1.y = ab.y;
-                    prow_ent[fill[ab.x]++] = e1;
+                    h_prow_ent[fill[ab.x]++] = e1;
                 }
             }
-            H2D(d_prow_off, prow_off.data(), 4 * prow_off.size());
-            if (!prow_ent.empty()) H2D(d_prow_ent, prow_ent.data(), 8 * prow_ent.size());
-            if (!diag.empty()) H2D(d_diag_blk, diag.data(), 4 * diag.size());
+            if (NB > 0) H2D(d_blk_ab, h_blk_ab, 8 * (size_t)NB);
+            H2D(d_prow_off, h_prow_off, 4 * (size_t)(HS.nP + 1));
+            if (h_prow_off[HS.nP] > 0) H2D(d_prow_ent, h_prow_ent, 8 * (size_t)h_prow_off[HS.nP]);
+            if (HS.nP > 0) H2D(d_diag_blk, h_diag, 4 * (size_t)HS.nP);
             sub("block rows");
-            SV_HIP(ctx, hipStreamSynchronize(s));  // the host vectors above go out of scope
-            sub("sync");
         }
         else sv_ba_zero_inactive(s, D);
         D.NB = (int)HS.blk_ab.size();

@@ -100,6 +100,25 @@ def test_local_ba_fixed_points_and_no_kernel(ba):
     assert np.array_equal(got["outlier"], ref["outlier"])
 
 
+def test_local_ba_landmark_seen_twice_from_one_keyframe(ba):
+    """The flat problem does not forbid two observations of one landmark from one keyframe; their cross terms enter the keyframe's
+    diagonal block twice (mirrored pairs), and the pair count computed on the host has to agree with what the device emits."""
+    sc = S.ba_scene(num_kf=8, num_lm=600, obs_per_lm=4, num_fixed=2, seed=13)
+    rng = np.random.default_rng(5)
+    pick = rng.choice(len(sc["obs_pose"]), 150, replace=False)
+    for key in ("obs_pose", "obs_point", "obs_inv_sigma_sq", "obs_huber"):
+        sc[key] = np.concatenate([sc[key], sc[key][pick]])
+    uvr = sc["obs_uvr"][pick].copy()
+    uvr[:, :2] += rng.normal(0, 0.5, (len(pick), 2)).astype(np.float32)
+    sc["obs_uvr"] = np.concatenate([sc["obs_uvr"], uvr])
+    got, ref = ba.optimize_flat(sc), O.local_ba(sc)
+    gs, rs = got["stats"], ref["stats"]
+    assert gs["iters_stage1"] == rs[2] and gs["iters_stage2"] == rs[3] and gs["num_gated"] == rs[5]
+    assert gs["chi2_final"] == pytest.approx(rs[1], rel=1e-6)
+    _assert_poses(got["pose_cw"], ref["pose_cw"])
+    assert np.array_equal(got["outlier"], ref["outlier"])
+
+
 def test_local_ba_repeatable(ba):
     sc = S.ba_scene(num_kf=8, num_lm=600, obs_per_lm=5, num_fixed=2, seed=11)
     a = ba.optimize_flat(sc)
