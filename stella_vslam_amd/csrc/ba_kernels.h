@@ -46,8 +46,9 @@ struct BaDev {
     const int* pose_slot;  // P: index among free active poses or -1
     const uint8_t* pt_free;  // L: 1 = active, non-fixed landmark vertex
     const int* lm_off;     // L + 1 (edges are sorted by landmark)
-    const int* pe_off;     // nP + 1: pose -> its active edges
+    const int* pe_off;     // P + 1: pose (index, not slot) -> its edges in increasing edge order, whatever their level
     const int* pe_idx;
+    const int* slot_pose;  // nP: free-pose slot -> pose index
     int NB;                // number of non-empty upper blocks (a <= b) of the reduced system
     const int* blk_off;    // NB + 1
     const int2* blk_pairs; // (edge whose pose is a, edge whose pose is b) sharing a landmark

@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    const int lo = D.pe_off[s], n = D.pe_off[s + 1] - lo;
+    const int pose = D.slot_pose[s], lo = D.pe_off[pose], n = D.pe_off[pose + 1] - lo;
     const int q0 = lo + (int)((long long)n * share / LIN_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / LIN_SPLIT);
     for (int q = q0 + threadIdx.x; q < q1; q += 256) {
         const int e = D.pe_idx[q];
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
     if (ru >= D.nP * RHS_SPLIT) return;
     const int s = ru / RHS_SPLIT, share = ru - s * RHS_SPLIT;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    const int lo = D.pe_off[s], n = D.pe_off[s + 1] - lo;
+    const int pose = D.slot_pose[s], lo = D.pe_off[pose], n = D.pe_off[pose + 1] - lo;
     const int q0 = lo + (int)((long long)n * share / RHS_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / RHS_SPLIT);
     for (int q = q0 + lane; q < q1; q += 64) {
         const int e = D.pe_idx[q];

@@ -40,7 +40,6 @@ inline size_t pad(size_t b) { return (b + 255) & ~size_t(255); }
 struct HostStructure {
     std::vector<int> pose_slot, slot_pose;
     std::vector<uint8_t> pt_free;
-    std::vector<int> pe_off, pe_idx;
     std::vector<int> blk_off;
     std::vector<int2> blk_ab;
     size_t num_pairs = 0;  // the pairs themselves live on the device only
@@ -73,23 +72,6 @@ void activity_only(const svgpu_ba_problem& pr, const int* e_pose, const int* e_p
             H.pt_free[l] = 1;
             ++H.nL;
         }
-}
-
-// pose -> edge lists of the free poses (H.pose_slot / H.nP from activity_only)
-void build_pose_lists(const svgpu_ba_problem& pr, const int* e_pose, const std::vector<uint8_t>& level, HostStructure& H) {
-    const int E = pr.num_obs;
-    // pose -> active edges
-    H.pe_off.assign(H.nP + 1, 0);
-    for (int e = 0; e < E; ++e)
-        if (!level[e] && H.pose_slot[e_pose[e]] >= 0) H.pe_off[H.pose_slot[e_pose[e]] + 1]++;
-    for (int s = 0; s < H.nP; ++s) H.pe_off[s + 1] += H.pe_off[s];
-    H.pe_idx.resize(H.pe_off[H.nP]);
-    {
-        std::vector<int> fill(H.pe_off.begin(), H.pe_off.end() - 1);
-        for (int e = 0; e < E; ++e)
-            if (!level[e] && H.pose_slot[e_pose[e]] >= 0) H.pe_idx[fill[H.pose_slot[e_pose[e]]]++] = e;
-    }
-    // the (edge, edge) pair lists of the upper blocks (a <= b) are built on the device: sv_ba_build_pairs + compact_blocks
 }
 
 // Number of (edge, edge) pairs k_pair_emit will produce, computed on the host so that the device pipeline needs no read-back: per
@@ -193,9 +175,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     if (P < 0 || L < 0 || E < 0 || (P > 0 && (!pr->pose_cw || !pr->pose_fixed || !pr->intrinsics)) || (L > 0 && !pr->points)
         || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || (!outlier_out && !single_stage))))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: inconsistent problem");
-    for (int e = 0; e < E; ++e)
+    bool lm_major = true;  // observations already grouped by landmark (the order local_bundle_adjuster_g2o.cc:168-227 creates its edges in)
+    for (int e = 0; e < E; ++e) {
         if (pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L)
             return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+        lm_major = lm_major && (e == 0 || pr->obs_point[e] >= pr->obs_point[e - 1]);
+    }
     const bool sharded = allreduce != nullptr;
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
     if (!sharded) {
@@ -225,10 +210,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     hipStream_t s = ctx->stream;
 
     // ---- page-locked staging laid out exactly like the input block at the head of the device arena (one copy carries everything):
-    //      poses | points | intrinsics | e_pose | e_point | e_uvr | e_w | e_huber | e_robust | lm_off.  The observations are written
-    //      sorted by landmark (stable): landmark-major kernels then read contiguous runs.  Behind it, the output block's host image.
+    //      poses | points | intrinsics | e_pose | e_point | e_uvr | e_w | e_huber | e_robust | lm_off | pe_off | pe_idx.  The observations
+    //      are written sorted by landmark (stable; a plain copy when they arrive that way): landmark-major kernels then read
+    //      contiguous runs.  pe_* = pose -> edge lists.  Behind it, the output block's host image.
     struct {
-        size_t pose, points, intr, e_pose, e_point, e_uvr, e_w, e_hub, robust, lm_off, total;
+        size_t pose, points, intr, e_pose, e_point, e_uvr, e_w, e_hub, robust, lm_off, pe_off, pe_idx, total;
     } in;
     {
         size_t o = 0;
@@ -247,11 +233,13 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         in.e_hub = put(4 * (size_t)E);
         in.robust = put(E);
         in.lm_off = put(4 * (size_t)(L + 1));
+        in.pe_off = put(4 * (size_t)(P + 1));
+        in.pe_idx = put(4 * (size_t)E);
         in.total = o;
     }
-    // structure block (host image only; its pieces go to separate device arrays): pt_free | pose_slot | pe_off, pe_idx | blk_ab, prow_off, diag | prow_ent
+    // structure block (host image only; its pieces go to separate device arrays): pt_free | pose_slot | slot_pose | blk_ab, prow_off, diag | prow_ent
     const size_t nb_cap_h = (size_t)P * (P + 1) / 2;
-    const size_t st_pt_free = 0, st_pose_slot = pad(L), st_pe = st_pose_slot + pad(4 * (size_t)P), st_blk = st_pe + pad(4 * ((size_t)P + 1 + E));
+    const size_t st_pt_free = 0, st_pose_slot = pad(L), st_pe = st_pose_slot + pad(4 * (size_t)P), st_blk = st_pe + pad(4 * (size_t)P);
     const size_t st_prow = st_blk + pad(8 * nb_cap_h + 4 * (2 * (size_t)P + 2)), st_total = st_prow + pad(8 * 2 * (nb_cap_h + 1));
     const size_t out_ctl = 0, out_state = pad(sizeof(BaCtl)), out_outlier = out_state + pad(sizeof(double) * (12 * (size_t)P + 3 * (size_t)L));
     const size_t out_total = out_outlier + pad((size_t)E + 1);
@@ -269,25 +257,44 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     float* const e_w = (float*)(hs + in.e_w);
     float* const e_hub = (float*)(hs + in.e_hub);
     uint8_t* const robust = (uint8_t*)(hs + in.robust);
-    std::vector<int> perm(E);
+    int* const pe_off = (int*)(hs + in.pe_off);
+    int* const pe_idx = (int*)(hs + in.pe_idx);
+    std::vector<int> perm;  // sorted position -> caller's observation index (empty = identity)
     std::vector<uint8_t> level(E, 0);
     for (int l = 0; l <= L; ++l) lm_off[l] = 0;
     for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
     for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
-    {
+    if (lm_major) {
+        memcpy(e_pose, pr->obs_pose, 4 * (size_t)E);
+        memcpy(e_point, pr->obs_point, 4 * (size_t)E);
+        memcpy(e_uvr, pr->obs_uvr, 12 * (size_t)E);
+        memcpy(e_w, pr->obs_inv_sigma_sq, 4 * (size_t)E);
+        if (pr->obs_huber_delta) memcpy(e_hub, pr->obs_huber_delta, 4 * (size_t)E);
+        else memset(e_hub, 0, 4 * (size_t)E);
+    }
+    else {
+        perm.resize(E);
         std::vector<int> fill(lm_off, lm_off + L);
         for (int e = 0; e < E; ++e) perm[fill[pr->obs_point[e]]++] = e;
+        for (int k = 0; k < E; ++k) {
+            const int e = perm[k];
+            e_pose[k] = pr->obs_pose[e];
+            e_point[k] = pr->obs_point[e];
+            e_uvr[3 * k] = pr->obs_uvr[3 * e];
+            e_uvr[3 * k + 1] = pr->obs_uvr[3 * e + 1];
+            e_uvr[3 * k + 2] = pr->obs_uvr[3 * e + 2];
+            e_w[k] = pr->obs_inv_sigma_sq[e];
+            e_hub[k] = pr->obs_huber_delta ? pr->obs_huber_delta[e] : 0.f;
+        }
     }
-    for (int k = 0; k < E; ++k) {
-        const int e = perm[k];
-        e_pose[k] = pr->obs_pose[e];
-        e_point[k] = pr->obs_point[e];
-        e_uvr[3 * k] = pr->obs_uvr[3 * e];
-        e_uvr[3 * k + 1] = pr->obs_uvr[3 * e + 1];
-        e_uvr[3 * k + 2] = pr->obs_uvr[3 * e + 2];
-        e_w[k] = pr->obs_inv_sigma_sq[e];
-        e_hub[k] = pr->obs_huber_delta ? pr->obs_huber_delta[e] : 0.f;
-        robust[k] = e_hub[k] > 0.f;
+    for (int k = 0; k < E; ++k) robust[k] = e_hub[k] > 0.f;
+    // pose -> edges (all poses, all levels: the kernels skip excluded edges), in increasing edge order
+    for (int p = 0; p <= P; ++p) pe_off[p] = 0;
+    for (int k = 0; k < E; ++k) pe_off[e_pose[k] + 1]++;
+    for (int p = 0; p < P; ++p) pe_off[p + 1] += pe_off[p];
+    {
+        std::vector<int> fill(pe_off, pe_off + P);
+        for (int k = 0; k < E; ++k) pe_idx[fill[e_pose[k]]++] = k;
     }
     memcpy(hs + in.pose, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
@@ -350,6 +357,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     float* d_e_hub = A.take<float>(E);
     D.e_robust = A.take<uint8_t>(E);
     int* d_lm_off = A.take<int>(L + 1);
+    int* d_pe_off = A.take<int>(P + 1);
+    int* d_pe_idx = A.take<int>(E);
     if (A.off != in.total) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: internal layout mismatch");
     // output block: control block | poses | points | outlier flags
     char* const d_out = A.base + A.off;
@@ -362,8 +371,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.e_chi = A.take<double>(E);
     int* d_pose_slot = A.take<int>(P);
     uint8_t* d_pt_free = A.take<uint8_t>(L);
-    int* d_pe_off = A.take<int>(P + 1);
-    int* d_pe_idx = A.take<int>(E);
+    int* d_slot_pose = A.take<int>(P);
     D.W = A.take<double>(18 * (size_t)E);
     D.lp_part = A.take<double>(27 * 16 * (size_t)P);
     D.sc_part = A.take<double>(36 * sc_part_blocks);
@@ -403,6 +411,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.lm_off = d_lm_off;
     D.pe_off = d_pe_off;
     D.pe_idx = d_pe_idx;
+    D.slot_pose = d_slot_pose;
     D.blk_pairs = d_blk_pairs;
     D.blk_ab = d_blk_ab;
     D.blk_off = d_blk_off;
@@ -557,14 +566,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                 if (rp) return rp;
                 sub("pairs enqueued");
             }
-            build_pose_lists(*pr, e_pose, level, HS);
             have_lists = true;
-            sub("host lists");
-            int* const h_pe = (int*)(hs_struct + st_pe);
-            memcpy(h_pe, HS.pe_off.data(), 4 * (size_t)(HS.nP + 1));
-            if (!HS.pe_idx.empty()) memcpy(h_pe + (P + 1), HS.pe_idx.data(), 4 * HS.pe_idx.size());
-            H2D(d_pe_off, h_pe, 4 * (size_t)(HS.nP + 1));
-            if (!HS.pe_idx.empty()) H2D(d_pe_idx, h_pe + (P + 1), 4 * HS.pe_idx.size());
+            int* const h_slot_pose = (int*)(hs_struct + st_pe);
+            for (int sl = 0; sl < HS.nP; ++sl) h_slot_pose[sl] = HS.slot_pose[sl];
+            if (HS.nP > 0) H2D(d_slot_pose, h_slot_pose, 4 * (size_t)HS.nP);
             if (host_total >= 0) {
                 HS.blk_ab.clear();
                 for (int a = 0; a < HS.nP; ++a)
@@ -807,7 +812,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                 for (int k = 0; k < 3; ++k) points_out[3 * (size_t)l + k] = xch_host[3 * (size_t)l + k];
     }
     if (outlier_out)
-        for (int k = 0; k < E; ++k) outlier_out[perm[k]] = outl[k];
+        for (int k = 0; k < E; ++k) outlier_out[perm.empty() ? k : perm[k]] = outl[k];
     st.chi2_final = h_ctl->chi_begin;
     st.lm_trials = h_ctl->lm_trials;
     st.cholesky_failures = h_ctl->solve_failures;

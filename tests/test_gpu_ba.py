@@ -119,6 +119,22 @@ def test_local_ba_landmark_seen_twice_from_one_keyframe(ba):
     assert np.array_equal(got["outlier"], ref["outlier"])
 
 
+def test_local_ba_observations_in_any_order(ba):
+    """Observations grouped by landmark (the order the reference creates its edges in) are copied as they are; any other order is
+    sorted by landmark first and the outlier flags come back in the caller's order."""
+    sc = S.ba_scene(num_kf=9, num_lm=800, obs_per_lm=5, num_fixed=2, seed=17)
+    order = np.random.default_rng(3).permutation(len(sc["obs_pose"]))
+    sh = dict(sc)
+    for key in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma_sq", "obs_huber"):
+        sh[key] = np.ascontiguousarray(sc[key][order])
+    got, ref, plain = ba.optimize_flat(sh), O.local_ba(sh), ba.optimize_flat(sc)
+    gs, rs = got["stats"], ref["stats"]
+    assert gs["iters_stage1"] == rs[2] and gs["iters_stage2"] == rs[3] and gs["num_gated"] == rs[5]
+    _assert_poses(got["pose_cw"], ref["pose_cw"])
+    assert np.array_equal(got["outlier"], ref["outlier"]) and np.array_equal(got["outlier"], plain["outlier"][order])
+    _assert_poses(got["pose_cw"], plain["pose_cw"])
+
+
 def test_local_ba_repeatable(ba):
     sc = S.ba_scene(num_kf=8, num_lm=600, obs_per_lm=5, num_fixed=2, seed=11)
     a = ba.optimize_flat(sc)
