@@ -643,6 +643,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.NB = (int)HS.blk_ab.size();
         D.g = D.Sblk + 36 * (size_t)D.NB;
         D.pcg_nparts = (HS.nP + 3) / 4;
+        // shares per block: ~192 pairs per wave (3 per lane); fewer, longer walks are slower (a lane's pairs are a chain of dependent
+        // loads), measured 2.30 / 2.31 / 2.43 / 2.90 / 3.79 ms per config-3 call at 96 / 192 / 384 / 768 / 1536 pairs per wave
         D.nshare = D.NB > 0 ? (int)std::min<size_t>(16, std::max<size_t>(1, (HS.num_pairs / (size_t)D.NB + 191) / 192)) : 1;
         // solver of this stage: PCG inside one workgroup's LDS when the blocks fit, else one launch per PCG iteration
         const bool lds_ok = sv_ba_pcg_lds_bytes(D) > 0;
