@@ -33,6 +33,7 @@ struct BfProblem {
     int *si1, *si2;
     int *bs1, *bs2;
     int* prune_ok;        // pairs * 2: every angle of the side lies in [0, 360]
+    int shared_sort;      // ring mode with one sorted copy per frame (see bf_srow1)
     uint32_t* topk;       // pairs * cap2 * BF_LIST
     int32_t* cnt;         // pairs * cap2
     int32_t* matched;     // pairs * cap1
@@ -40,6 +41,11 @@ struct BfProblem {
 };
 
 __host__ __device__ inline int bf_row1(const BfProblem& P, int pair) { return P.ring1 ? (pair + 1 == P.ring1 ? 0 : pair + 1) : pair; }
+// where the angle-sorted copy of side 1 of `pair` lives.  Ring mode (frame t + 1 against frame t inside ONE set of arrays): a frame is
+// side 1 of one pair and side 2 of the next, so every frame is sorted once (as side 2 of its own pair) and sd1 / sa1 / si1 / bs1
+// alias the side-2 arrays.
+__host__ __device__ inline int bf_srow1(const BfProblem& P, int pair) { return P.shared_sort ? bf_row1(P, pair) : pair; }
+__host__ __device__ inline int bf_prune1(const BfProblem& P, int pair) { return P.shared_sort ? P.prune_ok[bf_row1(P, pair) * 2 + 1] : P.prune_ok[pair * 2]; }
 
 struct CandProblem {
     const uint32_t* qdesc;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_bf_binsort(BfProblem P) {
     __shared__ int s_hist[BF_BINS + 2];
     __shared__ int s_start[BF_BINS + 2];
     __shared__ int s_bad;
-    const int pair = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+    const int pair = blockIdx.x, side = P.shared_sort ? 1 : blockIdx.y, tid = threadIdx.x;
     const int cap = side == 0 ? P.cap1 : P.cap2;
     const int row = side == 0 ? bf_row1(P, pair) : pair;  // where this side of the pair lives in the caller's arrays
     const int nraw = side == 0 ? (P.n1_dev ? P.n1_dev[row * P.n_stride] : P.n1) : (P.n2_dev ? P.n2_dev[pair * P.n_stride] : P.n2);
@@ -149,13 +149,13 @@ __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
     const int n1c = min(n1, P.cap1), n2c = min(n2, P.cap2);
     if (blockIdx.x * BF_QB >= n2c) return;
     const int tid = threadIdx.x;
-    const uint32_t* __restrict__ D1 = P.sd1 + (size_t)pair * P.cap1 * 8;
-    const float* __restrict__ A1 = P.sa1 + (size_t)pair * P.cap1;
-    const int* __restrict__ I1 = P.si1 + (size_t)pair * P.cap1;
+    const uint32_t* __restrict__ D1 = P.sd1 + (size_t)bf_srow1(P, pair) * P.cap1 * 8;
+    const float* __restrict__ A1 = P.sa1 + (size_t)bf_srow1(P, pair) * P.cap1;
+    const int* __restrict__ I1 = P.si1 + (size_t)bf_srow1(P, pair) * P.cap1;
     const uint32_t* __restrict__ D2 = P.sd2 + (size_t)pair * P.cap2 * 8;
     const float* __restrict__ A2 = P.sa2 + (size_t)pair * P.cap2;
     const int* __restrict__ I2 = P.si2 + (size_t)pair * P.cap2;
-    const int* __restrict__ BS1 = P.bs1 + (size_t)pair * (BF_BINS + 2);
+    const int* __restrict__ BS1 = P.bs1 + (size_t)bf_srow1(P, pair) * (BF_BINS + 2);
     const bool ori = P.check_orientation != 0;
     // ---- this lane's query
     const int r = blockIdx.x * BF_QB + tid, rr = min(r, n2c - 1);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_bf_topk(BfProblem P) {
     int cnt = 0;
     // ---- candidate ranges of the block (block-uniform): up to two runs of the angle-sorted side 1
     int seg_lo[2] = {0, 0}, seg_hi[2] = {n1c, 0};
-    if (ori && P.prune_ok[pair * 2] && P.prune_ok[pair * 2 + 1]) {
+    if (ori && bf_prune1(P, pair) && P.prune_ok[pair * 2 + 1]) {
         const int r_lo = blockIdx.x * BF_QB, r_hi = min(r_lo + BF_QB - 1, n2c - 1);
         const int b_lo = min((int)A2[r_lo], BF_BINS - 1) - 31, b_hi = min((int)A2[r_hi], BF_BINS - 1) + 31;
         if (b_hi - b_lo + 1 < BF_BINS) {
@@ -398,15 +398,15 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qb = blockIdx.x * MF_QB, q0 = qb + wave * MF_QW;
     if (qb >= n2c) return;
-    const uint32_t* __restrict__ D1 = P.sd1 + (size_t)pair * P.cap1 * 8;
-    const float* __restrict__ A1 = P.sa1 + (size_t)pair * P.cap1;
-    const int* __restrict__ I1 = P.si1 + (size_t)pair * P.cap1;
+    const uint32_t* __restrict__ D1 = P.sd1 + (size_t)bf_srow1(P, pair) * P.cap1 * 8;
+    const float* __restrict__ A1 = P.sa1 + (size_t)bf_srow1(P, pair) * P.cap1;
+    const int* __restrict__ I1 = P.si1 + (size_t)bf_srow1(P, pair) * P.cap1;
     const uint32_t* __restrict__ D2 = P.sd2 + (size_t)pair * P.cap2 * 8;
     const float* __restrict__ A2 = P.sa2 + (size_t)pair * P.cap2;
     const int* __restrict__ I2 = P.si2 + (size_t)pair * P.cap2;
-    const int* __restrict__ BS1 = P.bs1 + (size_t)pair * (BF_BINS + 2);
+    const int* __restrict__ BS1 = P.bs1 + (size_t)bf_srow1(P, pair) * (BF_BINS + 2);
     const bool ori = P.check_orientation != 0;
-    const bool prune = ori && P.prune_ok[pair * 2] && P.prune_ok[pair * 2 + 1];
+    const bool prune = ori && bf_prune1(P, pair) && P.prune_ok[pair * 2 + 1];
     S.cnt[tid] = 0;
     S.rowmax[tid] = 0xFFFFFFFFu;
     int my_j = 0;  // original idx_2 of this thread's query row (flush)
@@ -1321,7 +1321,15 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     static const bool force_valu = getenv("SVGPU_BF_VALU") != nullptr;
     {
         SvProfScope ps(ctx, s, "k_bf_binsort");
-        hipLaunchKernelGGL(k_bf_binsort, dim3(pairs, 2), dim3(256), 0, s, P);
+        // ring mode over one set of arrays: one sorted copy per frame serves both of its roles
+        P.shared_sort = P.ring1 == pairs && P.desc1 == P.desc2 && P.angle1 == P.angle2 && P.n1_dev == P.n2_dev && P.cap1 == P.cap2;
+        if (P.shared_sort) {
+            P.sd1 = P.sd2;
+            P.sa1 = P.sa2;
+            P.si1 = P.si2;
+            P.bs1 = P.bs2;
+        }
+        hipLaunchKernelGGL(k_bf_binsort, dim3(pairs, P.shared_sort ? 1 : 2), dim3(256), 0, s, P);
     }
     {
         SvProfScope ps(ctx, s, "k_bf_topk");
