@@ -523,6 +523,13 @@ int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const doub
                         int num_trials_robust, int num_trials, int num_each_iter, int reset_stop_flag_each_round,
                         double* pose_out, uint8_t* outlier_flags, int* num_valid, int* lm_iterations);
 
+/* Same with the observations already on the context's device (pos_w_dev n x 3 f64, uvr_dev n x 3 f32, inv_sigma_sq_dev / huber_delta_dev n
+ * f32), e.g. the gathered landmarks a projection matcher just worked on: no input copy; pose, intrinsics and the results stay host-side. */
+int svgpu_pose_optimize_device(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w_dev, const float* uvr_dev,
+                               const float* inv_sigma_sq_dev, const float* huber_delta_dev, const double* intrinsics, int num_trials_robust,
+                               int num_trials, int num_each_iter, int reset_stop_flag_each_round, double* pose_out,
+                               uint8_t* outlier_flags, int* num_valid, int* lm_iterations);
+
 /* Global BA core (optimize/global_bundle_adjuster.cc:26-192, 279-412): the same graph over ALL keyframes (spanning root
  * fixed), ONE Levenberg-Marquardt run of problem->num_first_iter iterations with the terminate rule, optional Huber
  * (obs_huber_delta), no outlier gate (num_second_iter is ignored).  The caller applies the reference's post-conditions

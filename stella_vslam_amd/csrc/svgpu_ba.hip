@@ -833,39 +833,22 @@ int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uin
     return local_ba_impl(ctx, problem, false, 0, 1, nullptr, nullptr, stop, pose_out, points_out, outlier_out, stats);
 }
 
-int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w, const float* uvr,
-                        const float* inv_sigma_sq, const float* huber_delta, const double* intrinsics, int num_trials_robust,
-                        int num_trials, int num_each_iter, int reset_stop_flag_each_round, double* pose_out,
-                        uint8_t* outlier_flags, int* num_valid, int* lm_iterations) {
-    if (!ctx || !pose_cw || !pose_out || !num_valid || n < 0 || num_trials_robust < 0 || num_trials < 0 || num_each_iter < 0
-        || (n > 0 && (!pos_w || !uvr || !inv_sigma_sq || !huber_delta || !intrinsics || !outlier_flags)))
-        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_pose_optimize: bad arguments");
-    memcpy(pose_out, pose_cw, sizeof(double) * 12);
-    *num_valid = 0;
-    if (lm_iterations) *lm_iterations = 0;
-    for (int i = 0; i < n; ++i) outlier_flags[i] = 0;
-    if (n < 5) return SVGPU_OK;  // pose_optimizer_g2o.cc:109-111
-    SV_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t need = pad(24 * (size_t)n) + pad(12 * (size_t)n) + 2 * pad(4 * (size_t)n) + 3 * pad(n) + pad(96) + pad(16) + 1024;
-    int rc = sv_ensure_scratch(ctx, need);
-    if (rc) return rc;
-    Arena A(ctx->d_scratch);
+// Shared tail of the two pose-optimizer entry points: inputs already on the device, results come back in ONE copy
+// (pose | result[4] | outlier flags) through the page-locked staging buffer.
+static int pose_optimize_run(svgpu_ctx* ctx, Arena& A, const double* pose_cw, int n, const double* d_pos, const float* d_uvr, const float* d_w,
+                             const float* d_h, const double* intrinsics, int num_trials_robust, int num_trials, int num_each_iter,
+                             int reset_stop_flag_each_round, char* h_out, double* pose_out, uint8_t* outlier_flags, int* num_valid, int* lm_iterations) {
     PoseOptDev P;
     memset(&P, 0, sizeof(P));
-    double* d_pos = A.take<double>(3 * (size_t)n);
-    float* d_uvr = A.take<float>(3 * (size_t)n);
-    float* d_w = A.take<float>(n);
-    float* d_h = A.take<float>(n);
-    P.outlier = A.take<uint8_t>(n);
-    P.level = A.take<uint8_t>(n);
-    P.robust = A.take<uint8_t>(n);
+    char* const d_out = A.base + A.off;
     P.pose_out = A.take<double>(12);
     P.result = A.take<int>(4);
+    P.outlier = A.take<uint8_t>(n);
+    const size_t out_bytes = (size_t)((A.base + A.off) - d_out), off_result = pad(96), off_outlier = off_result + pad(16);
+    P.level = A.take<uint8_t>(n);
+    P.robust = A.take<uint8_t>(n);
+    if (A.off > ctx->scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_pose_optimize: internal arena overflow");
     hipStream_t s = ctx->stream;
-    SV_HIP(ctx, hipMemcpyAsync(d_pos, pos_w, 24 * (size_t)n, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d_uvr, uvr, 12 * (size_t)n, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d_w, inv_sigma_sq, 4 * (size_t)n, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d_h, huber_delta, 4 * (size_t)n, hipMemcpyHostToDevice, s));
     P.n = n;
     P.pos_w = d_pos;
     P.uvr = d_uvr;
@@ -880,14 +863,68 @@ int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const doub
     P.gain_thr = 1e-3;  // terminateAction->setGainThreshold(1e-3), pose_optimizer_g2o.cc:55
     sv_pose_opt(ctx, s, P);
     SV_HIP(ctx, hipGetLastError());
-    int result[4] = {0, 0, 0, 0};
-    SV_HIP(ctx, hipMemcpyAsync(pose_out, P.pose_out, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(outlier_flags, P.outlier, n, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(result, P.result, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipStreamSynchronize(s));
+    memcpy(pose_out, h_out, sizeof(double) * 12);
+    const int* result = (const int*)(h_out + off_result);
+    memcpy(outlier_flags, h_out + off_outlier, n);
     *num_valid = result[0];
     if (lm_iterations) *lm_iterations = result[1];
     return SVGPU_OK;
+}
+
+int svgpu_pose_optimize(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w, const float* uvr,
+                        const float* inv_sigma_sq, const float* huber_delta, const double* intrinsics, int num_trials_robust,
+                        int num_trials, int num_each_iter, int reset_stop_flag_each_round, double* pose_out,
+                        uint8_t* outlier_flags, int* num_valid, int* lm_iterations) {
+    if (!ctx || !pose_cw || !pose_out || !num_valid || n < 0 || num_trials_robust < 0 || num_trials < 0 || num_each_iter < 0
+        || (n > 0 && (!pos_w || !uvr || !inv_sigma_sq || !huber_delta || !intrinsics || !outlier_flags)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_pose_optimize: bad arguments");
+    memcpy(pose_out, pose_cw, sizeof(double) * 12);
+    *num_valid = 0;
+    if (lm_iterations) *lm_iterations = 0;
+    for (int i = 0; i < n; ++i) outlier_flags[i] = 0;
+    if (n < 5) return SVGPU_OK;  // pose_optimizer_g2o.cc:109-111
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    // inputs: one page-locked image in device layout (pos_w | uvr | inv_sigma_sq | huber), one copy
+    const size_t o_uvr = pad(24 * (size_t)n), o_w = o_uvr + pad(12 * (size_t)n), o_h = o_w + pad(4 * (size_t)n), in_total = o_h + pad(4 * (size_t)n);
+    const size_t out_total = pad(96) + pad(16) + pad(n);
+    int rc = sv_ensure_scratch(ctx, in_total + out_total + 2 * pad(n) + 1024);
+    if (rc) return rc;
+    if ((rc = sv_ensure_stage(ctx, in_total + out_total))) return rc;
+    char* const hs = ctx->h_stage;
+    memcpy(hs, pos_w, 24 * (size_t)n);
+    memcpy(hs + o_uvr, uvr, 12 * (size_t)n);
+    memcpy(hs + o_w, inv_sigma_sq, 4 * (size_t)n);
+    memcpy(hs + o_h, huber_delta, 4 * (size_t)n);
+    Arena A(ctx->d_scratch);
+    char* const d_in = A.take<char>(in_total);
+    SV_HIP(ctx, hipMemcpyAsync(d_in, hs, in_total, hipMemcpyHostToDevice, ctx->stream));
+    return pose_optimize_run(ctx, A, pose_cw, n, (const double*)d_in, (const float*)(d_in + o_uvr), (const float*)(d_in + o_w), (const float*)(d_in + o_h),
+                             intrinsics, num_trials_robust, num_trials, num_each_iter, reset_stop_flag_each_round, hs + in_total, pose_out,
+                             outlier_flags, num_valid, lm_iterations);
+}
+
+int svgpu_pose_optimize_device(svgpu_ctx* ctx, const double* pose_cw, int n, const double* pos_w_dev, const float* uvr_dev,
+                               const float* inv_sigma_sq_dev, const float* huber_delta_dev, const double* intrinsics, int num_trials_robust,
+                               int num_trials, int num_each_iter, int reset_stop_flag_each_round, double* pose_out,
+                               uint8_t* outlier_flags, int* num_valid, int* lm_iterations) {
+    if (!ctx || !pose_cw || !pose_out || !num_valid || n < 0 || num_trials_robust < 0 || num_trials < 0 || num_each_iter < 0
+        || (n > 0 && (!pos_w_dev || !uvr_dev || !inv_sigma_sq_dev || !huber_delta_dev || !intrinsics || !outlier_flags)))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_pose_optimize_device: bad arguments");
+    memcpy(pose_out, pose_cw, sizeof(double) * 12);
+    *num_valid = 0;
+    if (lm_iterations) *lm_iterations = 0;
+    for (int i = 0; i < n; ++i) outlier_flags[i] = 0;
+    if (n < 5) return SVGPU_OK;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t out_total = pad(96) + pad(16) + pad(n);
+    int rc = sv_ensure_scratch(ctx, out_total + 2 * pad(n) + 1024);
+    if (rc) return rc;
+    if ((rc = sv_ensure_stage(ctx, out_total))) return rc;
+    Arena A(ctx->d_scratch);
+    return pose_optimize_run(ctx, A, pose_cw, n, pos_w_dev, uvr_dev, inv_sigma_sq_dev, huber_delta_dev, intrinsics, num_trials_robust, num_trials,
+                             num_each_iter, reset_stop_flag_each_round, ctx->h_stage, pose_out, outlier_flags, num_valid, lm_iterations);
 }
 
 int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out, double* points_out,

@@ -137,3 +137,17 @@ class pose_optimizer:
                                                  self.num_trials_, self.num_each_iter_, int(self.reset_stop_flag_each_round_), p(out),
                                                  p(outl), C.byref(nv), C.byref(it)), "svgpu_pose_optimize")
         return nv.value, out, outl[:n].copy(), it.value
+
+    def optimize_device(self, pose_cw, n: int, pos_w_dev, uvr_dev, inv_sigma_sq_dev, huber_dev, intr):
+        """Same with the observation arrays already on the device (torch tensors or raw device addresses)."""
+        pose = np.ascontiguousarray(pose_cw, np.float64).reshape(12)
+        K = np.ascontiguousarray(intr, np.float64).reshape(5)
+        out, outl = np.zeros(12), np.zeros(max(n, 1), np.uint8)
+        nv, it = C.c_int(0), C.c_int(0)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        d = lambda t: C.c_void_p(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+        self.ctx.check(lib().svgpu_pose_optimize_device(self.ctx.handle, p(pose), n, d(pos_w_dev), d(uvr_dev), d(inv_sigma_sq_dev), d(huber_dev), p(K),
+                                                        self.num_trials_robust_, self.num_trials_, self.num_each_iter_,
+                                                        int(self.reset_stop_flag_each_round_), p(out), p(outl), C.byref(nv), C.byref(it)),
+                       "svgpu_pose_optimize_device")
+        return nv.value, out, outl[:n].copy(), it.value

@@ -253,6 +253,12 @@ def test_pose_optimizer_matches_oracle(ba, seed, stereo, reset):
     assert np.abs(pose - pr["pose_gt"]).max() < np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
     nv0, pose0, outl0, it0 = po.optimize_flat(pr["pose_cw"], pr["pos_w"][:3], pr["uvr"][:3], pr["inv_sigma_sq"][:3], pr["huber"][:3], pr["intr"])
     assert nv0 == 0 and np.array_equal(pose0, pr["pose_cw"].reshape(12))
+    # observations already resident on the device: identical results
+    import torch
+    dev = [torch.from_numpy(np.ascontiguousarray(pr[k], t)).cuda() for k, t in (("pos_w", np.float64), ("uvr", np.float32), ("inv_sigma_sq", np.float32), ("huber", np.float32))]
+    torch.cuda.synchronize()
+    nvd, posed, outld, itd = po.optimize_device(pr["pose_cw"], len(pr["pos_w"]), *dev, pr["intr"])
+    assert nvd == nv and itd == iters and np.array_equal(posed, pose) and np.array_equal(outld, outl)
 
 
 def test_pose_optimizer_equirectangular_matches_oracle():

@@ -125,7 +125,17 @@ pr_ = dict(pose_cw=sc["pose_cw"][1], pos_w=sc["points_gt"][sc["obs_point"][sel]]
 po = optimize.pose_optimizer(ctx=ctx)
 g, _ = timeit(lambda: po.optimize_flat(pr_["pose_cw"], pr_["pos_w"], pr_["uvr"], pr_["w"], pr_["h"], pr_["intr"]), 100)
 c, _ = timeit(lambda: O.pose_optimize(pr_["pose_cw"], pr_["pos_w"], pr_["uvr"], pr_["w"], pr_["h"], pr_["intr"]), 10, 1)
-out["pose_optimizer_ms"] = {"gpu": round(g, 3), "cpu_oracle": round(c, 3), "observations": int(sel.sum())}
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")  # the runtime libsvgpu is linked against (torch would bring a second copy)
+dv = []
+for k, t in (("pos_w", np.float64), ("uvr", np.float32), ("w", np.float32), ("h", np.float32)):
+    a = np.ascontiguousarray(pr_[k], t)
+    ptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(a.nbytes)) == 0
+    assert hip.hipMemcpy(ptr, ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes), 1) == 0
+    dv.append(ptr.value)
+gd, _ = timeit(lambda: po.optimize_device(pr_["pose_cw"], int(sel.sum()), *dv, pr_["intr"]), 100)
+out["pose_optimizer_ms"] = {"gpu": round(g, 3), "gpu_device_resident_inputs": round(gd, 3), "cpu_oracle": round(c, 3), "observations": int(sel.sum())}
 # ---- local BA config 3 and the global-BA sized problem (rocSOLVER path)
 ba = optimize.local_bundle_adjuster(ctx=ctx)
 sc3 = S.ba_scene()
