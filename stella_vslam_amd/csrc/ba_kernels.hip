@@ -794,6 +794,47 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+__device__ __forceinline__ void wave_lds_sync() {  // orders the wave's own LDS writes before its later LDS reads (no workgroup barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Sums of NV per-lane values over the 64 lanes of a wave through a TRANSPOSE in wave-private LDS: 18 values at a time, every lane
+// stores its 18 (conflict-free rows of 64), then lane (k, q) = (lane % 18, lane / 18), q < 3, adds a third of row k with 16-byte
+// reads and lanes k < 18 add the three partials -- ~60 instructions per 18 values in a fixed order (bit-reproducible), against
+// ~20 per VALUE for a DPP butterfly (wave_sum_dpp), which cost more than the arithmetic it followed in k_ba_schur_rhs / k_ba_lin.
+// `sw`: WRED_DOUBLES doubles owned by the wave.  store(k, total) is called by ONE lane per value.
+#define WRED_PITCH 66
+#define WRED_DOUBLES (18 * WRED_PITCH + 18 * 4)
+template <int NV, class Store>
+__device__ __forceinline__ void wave_reduce_lds(const double (&acc)[NV], double* __restrict__ sw, int lane, Store store) {
+    const int k = lane % 18, q = lane / 18;
+    double* part = sw + 18 * WRED_PITCH;
+#pragma unroll
+    for (int h0 = 0; h0 < NV; h0 += 18) {
+        const int nv = NV - h0 < 18 ? NV - h0 : 18;
+#pragma unroll
+        for (int i = 0; i < 18; ++i)
+            if (i < nv) sw[i * WRED_PITCH + lane] = acc[h0 + i];
+        wave_lds_sync();
+        if (q < 3 && k < nv) {
+            const double2* row = reinterpret_cast<const double2*>(sw + k * WRED_PITCH + 22 * q);
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int i = 0; i < 11; ++i)
+                if (q < 2 || i < 10) {  // lanes 0..21 | 22..43 | 44..63
+                    const double2 v = row[i];
+                    a += v.x;
+                    b += v.y;
+                }
+            part[4 * k + q] = a + b;
+        }
+        wave_lds_sync();
+        if (lane < nv) store(h0 + lane, (part[4 * lane] + part[4 * lane + 1]) + part[4 * lane + 2]);
+        wave_lds_sync();
+    }
+}
+
 // (Hll + lambda I)^-1 of a landmark, 6 unique entries; all zero (and *ok = false) when the block is singular
 __device__ __forceinline__ bool lm_dinv(const double* __restrict__ H, double lambda, double* I) {
     const double a = H[0] + lambda, b = H[1], c = H[2], d = H[3] + lambda, e_ = H[4], f = H[5] + lambda;
@@ -903,12 +944,9 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
             acc[21 + i] += o.B[i] * (-o.w * o.r[0]) + o.B[6 + i] * (-o.w * o.r[1]) + o.B[12 + i] * (-o.w * o.r[2]);
     }
     __shared__ double s_w[4][27];
+    __shared__ __attribute__((aligned(16))) double s_red[4][WRED_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-        const double t = wave_sum_dpp(acc[k]);
-        if (lane == 0) s_w[wave][k] = t;
-    }
+    wave_reduce_lds<27>(acc, s_red[wave], lane, [&](int k, double t) { s_w[wave][k] = t; });
     __syncthreads();
     if (threadIdx.x < 27) D.lp_part[((size_t)s * LIN_SPLIT + share) * 27 + threadIdx.x] = ((s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + s_w[2][threadIdx.x]) + s_w[3][threadIdx.x];
 }
@@ -975,6 +1013,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare) {
 #define RHS_SPLIT 16
 __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, double* __restrict__ rhs_part) {
     if (D.ctl->phase != 1) return;
+    __shared__ __attribute__((aligned(16))) double s_red[4][WRED_DOUBLES];
     const double lambda = D.ctl->lambda;
     const int lane = threadIdx.x & 63, unit = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n_schur = D.NB * nshare;
@@ -1013,13 +1052,8 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
         }
-        double mine = 0.0;
-#pragma unroll
-        for (int k = 0; k < 36; ++k) {
-            const double t = wave_sum_dpp(acc[k]);
-            mine = (lane == k) ? t : mine;
-        }
-        if (lane < 36) D.sc_part[(size_t)unit * 36 + lane] = mine;
+        double* const out = D.sc_part + (size_t)unit * 36;
+        wave_reduce_lds<36>(acc, s_red[threadIdx.x >> 6], lane, [&](int k, double t) { out[k] = t; });
         return;
     }
     const int ru = unit - n_schur;
