@@ -634,7 +634,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __syncthreads();
 
     const int tq = min(ini_thr, min_thr);
-    const int lx = 3 + (tid & 63);
     auto load_ring = [&](const uint8_t* c, int (&p)[16]) {
         p[0] = c[3 * FP];
         p[1] = c[3 * FP + 1];
@@ -658,29 +657,77 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     9-arc brighter than v + t needs (p0 | p8) and (p4 | p12) brighter (same for darker): a necessary condition
     //     that ~90 % of the pixels fail.  Survivors are compacted into an LDS queue so that the expensive arc score
     //     below runs on full waves; it is exact, so queueing a superset of the corners is harmless.
-    //     Every wave owns a quarter of the queue (it scores 16 rows x 64 columns) and counts in a register: no atomics.
+    //       brighter on both opposite pairs  <=>  min(max(p0, p8), max(p4, p12)) > v + t
+    //       darker   on both opposite pairs  <=>  max(min(p0, p8), min(p4, p12)) < v - t
+    //     A lane tests FOUR horizontally adjacent pixels at once and owns a 4 x 4 patch: 16 lanes span the 64 scored columns, four
+    //     steps walk the patch's rows, the four lane groups of a wave take four different bands of four rows.  The 10 bytes of the centre row and the 4 bytes of rows +-3 arrive as aligned
+    //     dwords (ds_read2_b32), one v_perm_b32 per pixel pair lifts them straight into packed 16-bit lanes (no byte loads, no
+    //     separate alignment step), and the whole test runs on v_pk_min / max / sub: ~9 instructions per pixel instead of ~16.
+    //     Every wave owns a quarter of the queue.
     int wq = 0;
     unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
-    const bool in_band = lx < w - 3;
-    const unsigned long long band = __builtin_amdgcn_ballot_w64(in_band);
-    for (int ly = __builtin_amdgcn_readfirstlane(3 + (tid >> 6)); ly < h - 3; ly += 4) {  // wave-uniform row
-        // every lane reads (columns beyond the band stay inside the zero-padded FP-byte LDS row); the band test joins the ballot.
-        //   brighter on both opposite pairs  <=>  min(max(p0, p8), max(p4, p12)) > v + t
-        //   darker   on both opposite pairs  <=>  max(min(p0, p8), min(p4, p12)) < v - t
-        const uint8_t* c = &s_img[ly * FP + lx];
-        const int v = c[0];
-        const int p0 = c[3 * FP], p8 = c[-3 * FP], p4 = c[3], p12 = c[-3];
-        const int up = min(max(p0, p8), max(p4, p12)), dn = max(min(p0, p8), min(p4, p12));
-        const bool hit = max(up - v, v - dn) > tq;
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit) & band;  // scalar and: no per-lane re-materialisation
-        if (bal) {
-            if (hit && in_band)  // v_mbcnt: set bits of the ballot below this lane
-                my_q[wq + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)((ly << 7) | lx);
-            wq += __popcll(bal);
+    const int lane = tid & 63;
+    {
+        const int wv = tid >> 6, qrow = lane >> 4, qk = lane & 15;
+        const int x0 = 3 + 4 * qk;  // the lane's columns x0 .. x0 + 3 (ROI coordinates)
+        uint32_t band80 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) band80 |= (x0 + j < w - 3) ? (0x80u << (8 * j)) : 0u;
+        const uint32_t tqq = (uint32_t)(tq + 1) * 0x10001u;
+        const int ly0 = 3 + 4 * (4 * qrow + wv);  // the lane's 4 x 4 patch: rows ly0 .. ly0 + 3 (bands of four rows are dealt round-robin to the waves)
+        uint32_t m = 0;                           // bit 8 j + 4 + g: pixel (row g, column j) of the patch passed
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ly = ly0 + g;
+            const int lyc = max(min(ly, h - 4), 3);  // rows below the band are read somewhere harmless and masked
+            // pixel (ly, x) sits at s_raw[ly * FP + x + 3]; B = address of the aligned dword that holds the lane's first pixel at byte 2
+            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(s_raw + lyc * FP + 4 * qk);  // W0 = [B-4, B), W1, W2, W3
+            const uint32_t* rowd = reinterpret_cast<const uint32_t*>(s_raw + (lyc + 3) * FP + 4 * qk);
+            const uint32_t* rowu = reinterpret_cast<const uint32_t*>(s_raw + (lyc - 3) * FP + 4 * qk);
+            const uint32_t w0 = rowc[0], w1 = rowc[1], w2 = rowc[2], w3 = rowc[3];
+            const uint32_t d1 = rowd[1], d2 = rowd[2], u1 = rowu[1], u2 = rowu[2];
+            auto pk = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi, lo, sel)); };
+            uint32_t e2[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {  // pixels (0, 1) and (2, 3)
+                const s16x2 v = pk(w2, w1, half ? 0x0c050c04u : 0x0c030c02u);
+                const s16x2 p0 = pk(d2, d1, half ? 0x0c050c04u : 0x0c030c02u);
+                const s16x2 p8 = pk(u2, u1, half ? 0x0c050c04u : 0x0c030c02u);
+                const s16x2 p12 = pk(w1, w0, half ? 0x0c060c05u : 0x0c040c03u);
+                const s16x2 p4 = pk(w3, w2, half ? 0x0c040c03u : 0x0c020c01u);
+                const s16x2 up = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
+                const s16x2 dn = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+                const s16x2 mm = __builtin_elementwise_max(up - v, v - dn);
+                e2[half] = __builtin_bit_cast(uint32_t, mm - __builtin_bit_cast(s16x2, tqq));  // >= 0 per half <=> max(..) > tq
+            }
+            // sign bytes of the four results -> one byte per pixel; a clear sign inside the band is a hit
+            const uint32_t sgn = __builtin_amdgcn_perm(e2[1], e2[0], 0x07050301u);
+            m = (m >> 1) | (~sgn & (ly < h - 3 ? band80 : 0u));
+        }
+        // Compaction, once per wave: exclusive prefix of the lanes' hit counts (row-scan adds), then every lane stores the hits of
+        // its patch.  The queue order is patch by patch along a band of four rows -- neighbouring lanes of pass B then work on
+        // neighbouring pixels, which its ring reads need (a queue in which a lane's entries were 16 rows apart cost +8 %).
+        const int cnt = __popc(m);
+        int incl = cnt;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31
+        wq = __builtin_amdgcn_readlane(incl, 63);
+        int pos = incl - cnt;
+        const int e0 = (ly0 << 7) | x0;  // row 0, column 0 of the patch
+        while (m) {
+            const int bit = __ffs((int)m) - 1;  // 8 j + 4 + g
+            m &= m - 1;
+            my_q[pos++] = (unsigned short)(e0 + (((bit & 7) - 4) << 7) + (bit >> 3));
         }
     }
-    // every wave scores and filters ITS quarter of the queue (rows are dealt round-robin, so the quarters are balanced): no index mapping
-    const int lane = tid & 63;
+    // every wave scores and filters ITS quarter of the queue: no index mapping
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the queue entries were written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // --- pass B: arc score of the candidates
     for (int i = lane; i < wq; i += 64) {
         const int e = my_q[i], ly = e >> 7, qx = e & 127;
