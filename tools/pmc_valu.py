@@ -4,7 +4,12 @@
 launch, the kernel's duration in shader cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and the fraction of the chip's
 VALU issue slots those instructions fill at 4 cycles per wave64 integer / packed-16 instruction on 256 CUs x 4 SIMDs
 (measured: SQ_ACTIVE_INST_VALU ~= SQ_INSTS_VALU quad-cycles for these kernels; tools/ubench/bcnt.hip: 4.6 cycles per xor/bcnt).
-usage: tools/pmc_valu.py gpurun_out/pmc_gi profiles/r01_valu_issue.json [frames per launch]"""
+The cost per instruction is calibrated, not assumed: tools/ubench/valu_issue.hip (profiles/r02_ubench_valu.json) measures 3.7-4.2
+cycles per wave64 instruction per SIMD for the opcodes these kernels are made of (v_perm, v_pk_*, v_mad_i24, v_dot*, v_bcnt, v_fma;
+v_add_u32 / v_xor_b32: 2.2), and an optional second pass (`--pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU`) gives the busy quad-cycles per
+instruction of every kernel (`active_cycles_per_valu_inst` = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU).  Under the guide's nominal
+2 cycles per instruction every `valu_issue_frac` below would halve.
+usage: tools/pmc_valu.py gpurun_out/pmc_gi profiles/r02_valu_issue.json [frames per launch] [gpurun_out/pmc_active]"""
 import json, os, sys
 import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,5 +31,13 @@ for k, r in g.iterrows():
     out["kernels"][alias.get(k, k)] = {"valu_wave_insts": round(float(r["SQ_INSTS_VALU"])), "salu_wave_insts": round(float(r["SQ_INSTS_SALU"])),
                                        "lds_wave_insts": round(float(r["SQ_INSTS_LDS"])), "kernel_cycles": round(cyc),
                                        "valu_issue_frac": round(float(r["SQ_INSTS_VALU"]) * CYC / (SIMDS * cyc), 4)}
+if len(sys.argv) > 4:
+    a = pd.read_csv(f"{sys.argv[4]}/p_counter_collection.csv")
+    a["k"] = a["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+    ga = a.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
+    for k, r in ga.iterrows():
+        kk = alias.get(k, k)
+        if kk in out["kernels"] and float(r["SQ_INSTS_VALU"]) > 0:
+            out["kernels"][kk]["active_cycles_per_valu_inst"] = round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / float(r["SQ_INSTS_VALU"]), 3)
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: v["valu_issue_frac"] for k, v in out["kernels"].items() if v["valu_wave_insts"] > 1e6}, indent=1))
