@@ -332,7 +332,7 @@ def algorithmic_bytes(level_px, n_kp, B):
     desc = n_kp * (749 + 512 + 32 + 28)                     # IC-angle patch + BRIEF samples + descriptor + record
     select = n_kp * 16 + 8 * 2463
     bf_ops = 2 * 256 * n_kp * n_kp                          # all pairs x 256 bit positions x (multiply, add): the work of robust.cc:271-314
-    sort = 2 * 2 * n_kp * (32 + 4 + 4)                      # both sides: read + write descriptors, angles, indices
+    sort = 2 * n_kp * (32 + 4 + 4)                          # ring mode: every frame is angle-sorted ONCE (read + write descriptors, angles, indices)
     return {"k_resize": pyr * B, "k_blur": blur * B, "k_fast": fast * B, "k_select": select * B, "k_describe": desc * B,
             "k_bf_binsort": sort * B, "k_bf_topk": bf_ops * B, "k_bf_replay": (n_kp * 16 * 4 + n_kp * 8) * B}
 
