@@ -53,6 +53,7 @@ typedef struct {
 static const int8_t k_pattern[1024] = {
 #include "orb_pattern_i8.inc"
 };
+const int8_t* orc_orb_pattern(void) { return k_pattern; } /* 256 x (x0, y0, x1, y1): feature/orb_point_pairs.h:47 */
 
 /* ---------------------------------------------------------------- small OpenCV primitives */
 

@@ -72,6 +72,21 @@ class orb_params:
         self.scale_factors_, self.inv_scale_factors_, self.level_sigma_sq_, self.inv_level_sigma_sq_ = tabs
 
 
+def rectangle_mask(mask_rects, cols: int, rows: int) -> np.ndarray:
+    """create_rectangle_mask (orb_extractor.cc:138-151): 255 background, every [x_min, x_max, y_min, y_max] ratio rectangle filled with 0,
+    both corner points inclusive (cv::rectangle).  The corners are std::round of a FLOAT product: half away from zero."""
+    def rnd(n, f):
+        x = np.float32(n) * np.float32(f)
+        r = np.floor(x)
+        return int(r) + (1 if x - r >= np.float32(0.5) else 0)
+    m = np.full((rows, cols), 255, np.uint8)
+    for r in mask_rects:
+        x_min, x_max = rnd(cols, r[0]), rnd(cols, r[1])
+        y_min, y_max = rnd(rows, r[2]), rnd(rows, r[3])
+        m[max(y_min, 0):y_max + 1, max(x_min, 0):x_max + 1] = 0
+    return m
+
+
 class orb_extractor:
     """feature/orb_extractor.h:46-71.  extract(image, mask) -> (keypoints, descriptors).
 
@@ -109,17 +124,8 @@ class orb_extractor:
         return w.value, h.value
 
     def _rectangle_mask(self, cols: int, rows: int):
-        """create_rectangle_mask (orb_extractor.cc:138-151): 255 background, rectangles filled with 0
-        (both corner points inclusive, as cv::rectangle)."""
         if self._rect_mask is None:
-            m = np.full((rows, cols), 255, np.uint8)
-            for r in self.mask_rects_:
-                # std::round of a FLOAT product (orb_extractor.cc:145-148): half away from zero, not Python's banker's rounding on doubles
-                rnd = lambda n, f: int(np.floor(np.float32(n) * np.float32(f) + np.float32(0.5)))
-                x_min, x_max = rnd(cols, r[0]), rnd(cols, r[1])
-                y_min, y_max = rnd(rows, r[2]), rnd(rows, r[3])
-                m[max(y_min, 0):y_max + 1, max(x_min, 0):x_max + 1] = 0
-            self._rect_mask = m
+            self._rect_mask = rectangle_mask(self.mask_rects_, cols, rows)
         return self._rect_mask
 
     # -- extract
