@@ -1,0 +1,179 @@
+// The reference's matcher methods (match/robust.cc, bow_tree.cc, projection.cc, fuse.cc, area.cc, compiled where they lie) behind C
+// exports on the flat arrays the tests use.  Every export builds the object graph the method takes (stand-in data classes of shim/),
+// calls the method, and flattens what it wrote back into the per-query index arrays the oracle's functions return.
+// Test infrastructure only (tests/test_ref_local_match.py).
+#include <set>
+
+#include "ref_support.h"
+#include "stella_vslam/match/area.h"
+#include "stella_vslam/match/bow_tree.h"
+#include "stella_vslam/match/fuse.h"
+#include "stella_vslam/match/projection.h"
+#include "stella_vslam/match/robust.h"
+
+using namespace stella_vslam;
+using svref::camera_fixture;
+using svref::feat_vec;
+using svref::fill_observation;
+using svref::make_landmark;
+
+namespace {
+struct Params {
+    feature::orb_params p;
+    Params(float scale_factor, unsigned num_levels) : p("ref", scale_factor, num_levels, 20, 7) {}
+};
+// landmarks on the keypoints flagged in `has` (NULL = every keypoint), id = keypoint index
+void attach_landmarks(std::vector<std::shared_ptr<data::landmark>>& lms, const uint8_t* has, int n) {
+    lms.assign(n, nullptr);
+    for (int i = 0; i < n; ++i)
+        if (!has || has[i]) lms[i] = make_landmark((unsigned)i, nullptr, nullptr, 0.f, 0.f, nullptr);
+}
+}  // namespace
+
+extern "C" {
+
+// robust::brute_force_match (match/robust.cc:232-328): side 1 = the frame observation, side 2 = the keyframe (valid2 = holds a live landmark)
+int svref_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                            float lowe_ratio, int check_orientation, int32_t* matched_2_in_1) {
+    Params P(1.2f, 8);
+    data::frame_observation fo;
+    fill_observation(fo, desc1, nullptr, nullptr, angle1, nullptr, nullptr, n1, 64, 48);
+    auto kf = std::make_shared<data::keyframe>(1, nullptr, &P.p);
+    fill_observation(kf->frm_obs_, desc2, nullptr, nullptr, angle2, nullptr, nullptr, n2, 64, 48);
+    attach_landmarks(kf->landmarks_, valid2, n2);
+    std::vector<std::pair<int, int>> matches;
+    const unsigned num = match::robust(lowe_ratio, check_orientation != 0).brute_force_match(fo, kf, matches);
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    for (const auto& m : matches) matched_2_in_1[m.first] = m.second;
+    return (int)num;
+}
+
+// robust::match_for_triangulation (match/robust.cc:14-146) when node1 == NULL, bow_tree::match_for_triangulation (match/bow_tree.cc:11-167) otherwise.
+// The epipole is computed by the method itself from keyframe 1's centre and keyframe 2's pose / camera.
+int svref_match_for_triangulation(const orc_camera* cam2, const double* rot_1w, const double* trans_1w, const double* rot_2w, const double* trans_2w,
+                                  const uint8_t* desc1, const float* angle1, const int32_t* octave1, const double* bearings1, const uint8_t* has_lm1,
+                                  const float* xright1, int n1, const uint8_t* desc2, const float* angle2, const double* bearings2, const uint8_t* has_lm2,
+                                  const float* xright2, int n2, const int32_t* node1, const int32_t* node2, const double* E_12, float scale_factor,
+                                  unsigned num_levels, float residual_rad_thr, float lowe_ratio, int check_orientation, int32_t* matched_2_in_1) {
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(cam2, true, 0.0);
+    auto k1 = std::make_shared<data::keyframe>(1, &cam, &P.p), k2 = std::make_shared<data::keyframe>(2, &cam, &P.p);
+    k1->set_pose_cw(svref::pose44(rot_1w, trans_1w));
+    k2->set_pose_cw(svref::pose44(rot_2w, trans_2w));
+    fill_observation(k1->frm_obs_, desc1, nullptr, octave1, angle1, xright1, bearings1, n1, 64, 48);
+    fill_observation(k2->frm_obs_, desc2, nullptr, nullptr, angle2, xright2, bearings2, n2, 64, 48);
+    attach_landmarks(k1->landmarks_, has_lm1, n1);
+    attach_landmarks(k2->landmarks_, has_lm2, n2);
+    if (!has_lm1) k1->landmarks_.assign(n1, nullptr);
+    if (!has_lm2) k2->landmarks_.assign(n2, nullptr);
+    k1->bow_feat_vec_ = feat_vec(node1, n1);
+    k2->bow_feat_vec_ = feat_vec(node2, n2);
+    std::vector<std::pair<unsigned int, unsigned int>> pairs;
+    const Mat33_t E = svref::mat33(E_12);
+    const unsigned num = node1 ? match::bow_tree(lowe_ratio, check_orientation != 0).match_for_triangulation(k1, k2, E, pairs, residual_rad_thr)
+                               : match::robust(lowe_ratio, check_orientation != 0).match_for_triangulation(k1, k2, E, pairs, residual_rad_thr);
+    for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
+    for (const auto& m : pairs) matched_2_in_1[m.first] = (int32_t)m.second;
+    return (int)num;
+}
+
+// bow_tree::match_frame_and_keyframe (match/bow_tree.cc:169-256; side 1 = keyframe, side 2 = frame; valid2 must be NULL) and
+// bow_tree::match_keyframes (:258-366; valid2 = keypoint of keyframe 2 holds a live landmark)
+int svref_bow_match(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, const int32_t* node1, int n1, const uint8_t* desc2, const float* angle2,
+                    const uint8_t* valid2, const int32_t* node2, int n2, int keyframes, float lowe_ratio, int check_orientation, int32_t* match_1to2) {
+    Params P(1.2f, 8);
+    auto k1 = std::make_shared<data::keyframe>(1, nullptr, &P.p);
+    fill_observation(k1->frm_obs_, desc1, nullptr, nullptr, angle1, nullptr, nullptr, n1, 64, 48);
+    attach_landmarks(k1->landmarks_, valid1, n1);
+    k1->bow_feat_vec_ = feat_vec(node1, n1);
+    for (int i = 0; i < n1; ++i) match_1to2[i] = -1;
+    std::vector<std::shared_ptr<data::landmark>> matched;
+    unsigned num;
+    const match::bow_tree matcher(lowe_ratio, check_orientation != 0);
+    if (!keyframes) {
+        data::frame frm(2, nullptr, &P.p);
+        fill_observation(frm.frm_obs_, desc2, nullptr, nullptr, angle2, nullptr, nullptr, n2, 64, 48);
+        frm.landmarks_.assign(n2, nullptr);
+        frm.bow_feat_vec_ = feat_vec(node2, n2);
+        num = matcher.match_frame_and_keyframe(k1, frm, matched);
+        for (int j = 0; j < n2; ++j)  // matched[frame keypoint] = the keyframe's landmark (id = its keyframe keypoint)
+            if (matched[j]) match_1to2[matched[j]->id_] = j;
+    }
+    else {
+        auto k2 = std::make_shared<data::keyframe>(2, nullptr, &P.p);
+        fill_observation(k2->frm_obs_, desc2, nullptr, nullptr, angle2, nullptr, nullptr, n2, 64, 48);
+        attach_landmarks(k2->landmarks_, valid2, n2);
+        k2->bow_feat_vec_ = feat_vec(node2, n2);
+        num = matcher.match_keyframes(k1, k2, matched);
+        for (int i = 0; i < n1; ++i)  // matched[keypoint of keyframe 1] = the landmark of keyframe 2 (id = its keypoint there)
+            if (matched[i]) match_1to2[i] = (int32_t)matched[i]->id_;
+    }
+    return (int)num;
+}
+
+// projection::match_current_and_last_frames (match/projection.cc:95-207).  Queries = the last frame's keypoints that hold a landmark (valid).
+// `occupied` current keypoints start with a landmark that has an observation (never replaced).  Out: for every CURRENT keypoint the index of the
+// last-frame keypoint whose landmark it holds at the end (-1 none, -2 still the initial occupant), and the method's return value.
+int svref_match_current_and_last_frames(const orc_camera* camd, const double* rot_cw, const double* trans_cw, const double* rot_lw, const double* trans_lw,
+                                        int is_monocular, float true_baseline, int n_last, const double* pos_w, const uint8_t* valid, const uint8_t* lm_desc,
+                                        const int32_t* octave_last, const float* angle_last, const uint8_t* lm_has_observation, float scale_factor,
+                                        unsigned num_levels, float margin, const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, const float* t_angle,
+                                        int nt, const uint8_t* occupied, const float* t_xright, int grid_cols, int grid_rows, int check_orientation,
+                                        int32_t* holder_of_current) {
+    svref::forget_grids();
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(camd, is_monocular != 0, true_baseline);
+    data::frame curr(2, &cam, &P.p), last(1, &cam, &P.p);
+    curr.set_pose_cw(svref::pose44(rot_cw, trans_cw));
+    last.set_pose_cw(svref::pose44(rot_lw, trans_lw));
+    fill_observation(last.frm_obs_, lm_desc /* unused as keypoint descriptors */, nullptr, octave_last, angle_last, nullptr, nullptr, n_last, grid_cols, grid_rows);
+    last.landmarks_.assign(n_last, nullptr);
+    for (int i = 0; i < n_last; ++i)
+        if (valid[i]) last.landmarks_[i] = make_landmark((unsigned)i, pos_w + 3 * i, lm_desc + 32 * (size_t)i, 0.f, 0.f, nullptr, !lm_has_observation || lm_has_observation[i]);
+    fill_observation(curr.frm_obs_, tdesc, t_xy, t_octave, t_angle, t_xright, nullptr, nt, grid_cols, grid_rows);
+    curr.landmarks_.assign(nt, nullptr);
+    const auto occupant = make_landmark(0xFFFFFFFEu, nullptr, nullptr, 0.f, 0.f, nullptr, true);
+    for (int j = 0; j < nt; ++j)
+        if (occupied && occupied[j]) curr.landmarks_[j] = occupant;
+    const unsigned num = match::projection(0.0f, check_orientation != 0).match_current_and_last_frames(curr, last, margin);
+    for (int j = 0; j < nt; ++j) {
+        const auto lm = curr.landmarks_[j];
+        holder_of_current[j] = !lm ? -1 : (lm == occupant ? -2 : (int32_t)lm->id_);
+    }
+    svref::forget_grids();
+    return (int)num;
+}
+
+// projection::match_frame_and_keyframe (match/projection.cc:209-319).  Queries = the keyframe's keypoints that hold a landmark (valid).
+// Out: for every frame keypoint the keyframe keypoint whose landmark it received (-1 none, -2 initial occupant).
+int svref_match_frame_and_keyframe_projection(const orc_camera* camd, const double* rot_cw, const double* trans_cw, int n_kf, const double* pos_w,
+                                              const uint8_t* valid, const float* min_valid_dist, const float* max_valid_dist, const uint8_t* lm_desc,
+                                              const float* angle_kf, float scale_factor, unsigned num_levels, float margin, unsigned hamm_dist_thr,
+                                              const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, const float* t_angle, int nt,
+                                              const uint8_t* occupied, int grid_cols, int grid_rows, int check_orientation, int32_t* holder_of_current) {
+    svref::forget_grids();
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(camd, true, 0.0);
+    data::frame curr(2, &cam, &P.p);
+    curr.set_pose_cw(svref::pose44(rot_cw, trans_cw));
+    fill_observation(curr.frm_obs_, tdesc, t_xy, t_octave, t_angle, nullptr, nullptr, nt, grid_cols, grid_rows);
+    curr.landmarks_.assign(nt, nullptr);
+    const auto occupant = make_landmark(0xFFFFFFFEu, nullptr, nullptr, 0.f, 0.f, nullptr, true);
+    for (int j = 0; j < nt; ++j)
+        if (occupied && occupied[j]) curr.landmarks_[j] = occupant;
+    auto kf = std::make_shared<data::keyframe>(1, &cam, &P.p);
+    fill_observation(kf->frm_obs_, lm_desc, nullptr, nullptr, angle_kf, nullptr, nullptr, n_kf, grid_cols, grid_rows);
+    kf->landmarks_.assign(n_kf, nullptr);
+    for (int i = 0; i < n_kf; ++i)
+        if (valid[i]) kf->landmarks_[i] = make_landmark((unsigned)i, pos_w + 3 * i, lm_desc + 32 * (size_t)i, min_valid_dist[i], max_valid_dist[i], nullptr);
+    const std::set<std::shared_ptr<data::landmark>> already;
+    const unsigned num = match::projection(0.0f, check_orientation != 0).match_frame_and_keyframe(curr, kf, already, margin, hamm_dist_thr);
+    for (int j = 0; j < nt; ++j) {
+        const auto lm = curr.landmarks_[j];
+        holder_of_current[j] = !lm ? -1 : (lm == occupant ? -2 : (int32_t)lm->id_);
+    }
+    svref::forget_grids();
+    return (int)num;
+}
+
+}  // extern "C"

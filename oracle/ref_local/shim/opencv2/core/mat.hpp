@@ -69,6 +69,17 @@ public:
     const T& at(int y, int x) const { return *reinterpret_cast<const T*>(data + (size_t)y * step.v + x); }
     uchar* ptr(int y = 0) { return data + (size_t)y * step.v; }
     const uchar* ptr(int y = 0) const { return data + (size_t)y * step.v; }
+    template <class T>
+    T* ptr(int y = 0) { return reinterpret_cast<T*>(data + (size_t)y * step.v); }
+    template <class T>
+    const T* ptr(int y = 0) const { return reinterpret_cast<const T*>(data + (size_t)y * step.v); }
+    Mat row(int y) const { return rowRange(y, y + 1); }
+    Mat clone() const {
+        Mat m;
+        m.create(rows, cols, CV_8UC1);
+        for (int y = 0; y < rows; ++y) memcpy(m.data + (size_t)y * m.step.v, data + (size_t)y * step.v, cols);
+        return m;
+    }
 
 private:
     std::shared_ptr<std::vector<uchar>> store_;

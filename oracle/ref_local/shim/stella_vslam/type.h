@@ -1,4 +1,168 @@
-// Stand-in (see ../README.md) for the reference's Eigen typedef header: feature/orb_extractor.cc includes it and uses nothing of it.
+// Stand-in (see ../README.md) for the reference's type.h: its Eigen typedefs over a minimal fixed-size matrix template with exactly the
+// operations the reference's matcher / grid sources use.  Coefficient products are summed left to right ((a0 b0 + a1 b1) + a2 b2), which
+// is what Eigen's fixed-size kernels evaluate for these shapes; -ffp-contract=off keeps them unfused as in the reference's default build.
 #ifndef SVGPU_SHIM_STELLA_TYPE_H
 #define SVGPU_SHIM_STELLA_TYPE_H
+#include <cmath>
+#include <cstddef>
+#include <map>
+#include <memory>
+#include <set>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include <opencv2/core/types.hpp>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+namespace svref_eigen {
+template <int R, int C>
+struct Matrix {
+    double v[R * C];  // column-major, as Eigen's default
+    Matrix() {
+        for (int i = 0; i < R * C; ++i) v[i] = 0.0;
+    }
+    Matrix(double a, double b, double c) {
+        static_assert(R * C == 3, "3-vector");
+        v[0] = a, v[1] = b, v[2] = c;
+    }
+    Matrix(double a, double b) {
+        static_assert(R * C == 2, "2-vector");
+        v[0] = a, v[1] = b;
+    }
+    double& operator()(int i, int j) { return v[j * R + i]; }
+    double operator()(int i, int j) const { return v[j * R + i]; }
+    double& operator()(int i) { return v[i]; }
+    double operator()(int i) const { return v[i]; }
+    double& operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+    double* data() { return v; }
+    const double* data() const { return v; }
+    static Matrix Identity() {
+        Matrix m;
+        for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.0;
+        return m;
+    }
+    static Matrix Zero() { return Matrix(); }
+    Matrix<C, R> transpose() const {
+        Matrix<C, R> t;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < C; ++j) t(j, i) = (*this)(i, j);
+        return t;
+    }
+    template <int BR, int BC>
+    Matrix<BR, BC> block(int r0, int c0) const {
+        Matrix<BR, BC> b;
+        for (int i = 0; i < BR; ++i)
+            for (int j = 0; j < BC; ++j) b(i, j) = (*this)(r0 + i, c0 + j);
+        return b;
+    }
+    template <int OR, int OC>
+    double dot(const Matrix<OR, OC>& o) const {
+        static_assert(OR * OC == R * C, "dot of equal-length vectors");
+        double s = v[0] * o.v[0];
+        for (int i = 1; i < R * C; ++i) s += v[i] * o.v[i];
+        return s;
+    }
+    double squaredNorm() const { return dot(*this); }
+    double norm() const { return std::sqrt(squaredNorm()); }
+    Matrix operator-() const {
+        Matrix m;
+        for (int i = 0; i < R * C; ++i) m.v[i] = -v[i];
+        return m;
+    }
+    Matrix operator+(const Matrix& o) const {
+        Matrix m;
+        for (int i = 0; i < R * C; ++i) m.v[i] = v[i] + o.v[i];
+        return m;
+    }
+    Matrix operator-(const Matrix& o) const {
+        Matrix m;
+        for (int i = 0; i < R * C; ++i) m.v[i] = v[i] - o.v[i];
+        return m;
+    }
+    Matrix operator*(double s) const {
+        Matrix m;
+        for (int i = 0; i < R * C; ++i) m.v[i] = v[i] * s;
+        return m;
+    }
+    Matrix operator/(double s) const {
+        Matrix m;
+        for (int i = 0; i < R * C; ++i) m.v[i] = v[i] / s;
+        return m;
+    }
+    template <int K>
+    Matrix<R, K> operator*(const Matrix<C, K>& o) const {
+        Matrix<R, K> m;
+        for (int i = 0; i < R; ++i)
+            for (int j = 0; j < K; ++j) {
+                double s = (*this)(i, 0) * o(0, j);
+                for (int k = 1; k < C; ++k) s += (*this)(i, k) * o(k, j);
+                m(i, j) = s;
+            }
+        return m;
+    }
+};
+template <int R, int C>
+static inline Matrix<R, C> operator*(double s, const Matrix<R, C>& a) {
+    Matrix<R, C> m;
+    for (int i = 0; i < R * C; ++i) m.v[i] = s * a.v[i];
+    return m;
+}
+}  // namespace svref_eigen
+
+namespace stella_vslam {
+template <typename T, typename... ArgTs>
+std::unique_ptr<T> make_unique(ArgTs&&... args) {
+    return std::unique_ptr<T>(new T(std::forward<ArgTs>(args)...));
+}
+typedef float real_t;
+template <size_t R, size_t C>
+using MatRC_t = svref_eigen::Matrix<(int)R, (int)C>;
+using Mat22_t = svref_eigen::Matrix<2, 2>;
+using Mat33_t = svref_eigen::Matrix<3, 3>;
+using Mat44_t = svref_eigen::Matrix<4, 4>;
+using Mat34_t = svref_eigen::Matrix<3, 4>;
+template <size_t R>
+using VecR_t = svref_eigen::Matrix<(int)R, 1>;
+using Vec2_t = svref_eigen::Matrix<2, 1>;
+using Vec3_t = svref_eigen::Matrix<3, 1>;
+using Vec4_t = svref_eigen::Matrix<4, 1>;
+template <typename T>
+using eigen_alloc_vector = std::vector<T>;
+template <typename T, typename U>
+using eigen_alloc_map = std::map<T, U>;
+template <typename T>
+using eigen_alloc_set = std::set<T>;
+template <typename T, typename U>
+using eigen_alloc_unord_map = std::unordered_map<T, U>;
+template <typename T>
+using eigen_alloc_unord_set = std::unordered_set<T>;
+
+// the id comparators of the reference's type.h:118-170, which the matcher sources use through id_ordered_set / nondeterministic::
+template <class T>
+struct id_less;
+template <class T>
+struct id_less<std::shared_ptr<T>> {
+    bool operator()(const std::shared_ptr<T>& a, const std::shared_ptr<T>& b) const { return a != nullptr && (b == nullptr || a->id_ < b->id_); }
+};
+template <class T>
+struct id_less<std::weak_ptr<T>> {
+    bool operator()(const std::weak_ptr<T>& a, const std::weak_ptr<T>& b) const { return !a.expired() && (b.expired() || a.lock()->id_ < b.lock()->id_); }
+};
+template <class T>
+using id_ordered_set = std::set<T, id_less<T>>;
+template <class T, class U>
+using id_ordered_map = std::map<T, U, id_less<T>>;
+namespace nondeterministic {
+template <class T>
+using unordered_set = std::set<T, id_less<T>>;
+template <class T, class U>
+using unordered_map = std::map<T, U, id_less<T>>;
+}  // namespace nondeterministic
+}  // namespace stella_vslam
 #endif

@@ -1,0 +1,147 @@
+"""Pins the per-method matcher oracles (oracle/match2_oracle.c, match_oracle.c) against the REFERENCE's own matcher code: match/robust.cc,
+bow_tree.cc, projection.cc, fuse.cc and area.cc are compiled where they lie over stand-in Eigen / data:: / camera:: headers
+(oracle/ref_local/shim; the grid lookup and the camera reprojection behind them are the oracle's) into oracle/_ref/libsvref.so, the
+fixtures of oracle/ref_local/ref_match_exports.cc build the object graph each method takes, and the match lists must be identical.
+Where the reference writes into a shared structure (frame landmarks), the oracle's per-query list is replayed into the same structure."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import match_problems as MP
+
+_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libsvref.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(_SO):
+        pytest.skip("oracle/_ref/libsvref.so absent: it is built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    return C.CDLL(_SO)
+
+
+@pytest.fixture(scope="module")
+def sc():
+    return MP.scene(seed=7)
+
+
+@pytest.fixture(scope="module")
+def sc_stereo():
+    return MP.scene(seed=9, stereo=True)
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _c(a, t):
+    return None if a is None else np.ascontiguousarray(a, t)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _replay(out, n_targets, occupied=None):
+    """per-query target list -> who holds every target at the end (later queries overwrite; -2 = the initial occupant)"""
+    holder = np.full(n_targets, -1, np.int32)
+    if occupied is not None:
+        holder[np.asarray(occupied) != 0] = -2
+    for q, t in enumerate(out):
+        if t >= 0:
+            holder[t] = q
+    return holder
+
+
+@pytest.mark.parametrize("ratio,ori", [(0.8, True), (0.75, False), (0.6, True)])
+def test_brute_force_match(ref, sc, ratio, ori):
+    v1, v2 = sc["views"]
+    valid2 = (v2["lm"] >= 0).astype(np.uint8)
+    for valid in (None, valid2):
+        exp = O.brute_force_match(v1["desc"], v1["angle"], v2["desc"], v2["angle"], valid, ratio, ori)
+        d1, d2, a1, a2 = _c(v1["desc"], np.uint8), _c(v2["desc"], np.uint8), _c(v1["angle"], np.float32), _c(v2["angle"], np.float32)
+        out = np.full(len(d1), -1, np.int32)
+        num = ref.svref_brute_force_match(_p(d1), _p(a1), len(d1), _p(d2), _p(a2), _p(valid), len(d2), C.c_float(ratio), int(ori), _p(out))
+        assert num == (exp >= 0).sum() > 100 and np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+@pytest.mark.parametrize("with_nodes", [False, True])
+def test_match_for_triangulation(ref, sc, sc_stereo, stereo, with_nodes):
+    s = sc_stereo if stereo else sc
+    cam = MP.make_cams(s, "oracle")
+    v1, v2 = s["views"]
+    kw = MP.triangulation(s, lambda R, t, c: O.reproject_to_bearing(cam, R, t, c), with_nodes=with_nodes)
+    for ratio, ori in ((0.8, True), (0.6, False)):
+        exp, num = O.match_for_triangulation(ratio, ori, **kw)
+        n1, n2 = len(kw["desc1"]), len(kw["desc2"])
+        out = np.full(n1, -1, np.int32)
+        sf = np.asarray(kw["scale_factors"], np.float32)
+        args = [C.byref(cam), _p(_f64(v1["rot_cw"])), _p(_f64(v1["trans_cw"])), _p(_f64(v2["rot_cw"])), _p(_f64(v2["trans_cw"]))]
+        a = dict(d1=_c(kw["desc1"], np.uint8), a1=_c(kw["angle1"], np.float32), o1=_c(kw["octave1"], np.int32), b1=_f64(kw["bearings1"]),
+                 h1=_c(kw["has_lm1"], np.uint8), x1=_c(kw.get("xright1"), np.float32), d2=_c(kw["desc2"], np.uint8), a2=_c(kw["angle2"], np.float32),
+                 b2=_f64(kw["bearings2"]), h2=_c(kw["has_lm2"], np.uint8), x2=_c(kw.get("xright2"), np.float32), nd1=_c(kw.get("node1"), np.int32),
+                 nd2=_c(kw.get("node2"), np.int32), E=_f64(kw["E_12"]))
+        got = ref.svref_match_for_triangulation(*args, _p(a["d1"]), _p(a["a1"]), _p(a["o1"]), _p(a["b1"]), _p(a["h1"]), _p(a["x1"]), n1, _p(a["d2"]), _p(a["a2"]),
+                                                _p(a["b2"]), _p(a["h2"]), _p(a["x2"]), n2, _p(a["nd1"]), _p(a["nd2"]), _p(a["E"]), C.c_float(float(sf[1] / sf[0])),
+                                                len(sf), C.c_float(kw["residual_rad_thr"]), C.c_float(ratio), int(ori), _p(out))
+        assert got == num > 20 and np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("keyframes", [False, True])
+def test_bow_match(ref, sc, keyframes):
+    kw = MP.bow(sc, keyframes=keyframes)
+    kw.pop("occupied2", None)  # an extension of the oracle's signature; the reference starts with no frame keypoint taken
+    for ratio, ori in ((0.75, True), (0.9, False)):
+        exp, num = O.bow_match(ratio, ori, **kw)
+        d1, d2 = _c(kw["desc1"], np.uint8), _c(kw["desc2"], np.uint8)
+        a1, a2 = _c(kw["angle1"], np.float32), _c(kw["angle2"], np.float32)
+        v1, v2 = _c(kw["valid1"], np.uint8), _c(kw.get("valid2"), np.uint8)
+        n1, n2 = _c(kw["node1"], np.int32), _c(kw["node2"], np.int32)
+        out = np.full(len(d1), -1, np.int32)
+        got = ref.svref_bow_match(_p(d1), _p(a1), _p(v1), _p(n1), len(d1), _p(d2), _p(a2), _p(v2), _p(n2), len(d2), int(keyframes), C.c_float(ratio), int(ori),
+                                  _p(out))
+        assert got == num > 100 and np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_match_current_and_last_frames(ref, sc, sc_stereo, stereo):
+    s = sc_stereo if stereo else sc
+    cam = MP.make_cams(s, "oracle")
+    kw = MP.current_and_last(s)
+    sf = np.asarray(kw["scale_factors"], np.float32)
+    for ori in (True, False):
+        exp, num = O.match_current_and_last_frames(ori, cam, **kw)
+        a = dict(pw=_f64(kw["pos_w"]), valid=_c(kw["valid"], np.uint8), ld=_c(kw["lm_desc"], np.uint8), ol=_c(kw["octave_last"], np.int32),
+                 al=_c(kw["angle_last"], np.float32), ho=_c(kw["lm_has_observation"], np.uint8), td=_c(kw["tdesc"], np.uint8), xy=_c(kw["t_xy"], np.float32),
+                 to=_c(kw["t_octave"], np.int32), ta=_c(kw["t_angle"], np.float32), occ=_c(kw["occupied"], np.uint8), xr=_c(kw.get("t_xright"), np.float32))
+        nt = len(a["td"])
+        holder = np.full(nt, -9, np.int32)
+        got = ref.svref_match_current_and_last_frames(
+            C.byref(cam), _p(_f64(kw["rot_cw"])), _p(_f64(kw["trans_cw"])), _p(_f64(kw["rot_lw"])), _p(_f64(kw["trans_lw"])), int(kw["is_monocular"]),
+            C.c_float(kw["true_baseline"]), len(a["pw"]), _p(a["pw"]), _p(a["valid"]), _p(a["ld"]), _p(a["ol"]), _p(a["al"]), _p(a["ho"]),
+            C.c_float(float(sf[1] / sf[0])), len(sf), C.c_float(kw["margin"]), _p(a["td"]), _p(a["xy"]), _p(a["to"]), _p(a["ta"]), nt, _p(a["occ"]), _p(a["xr"]),
+            64, 48, int(ori), _p(holder))
+        assert got == num > 300
+        assert np.array_equal(holder, _replay(exp, nt, kw["occupied"]))
+
+
+def test_match_frame_and_keyframe_projection(ref, sc):
+    cam = MP.make_cams(sc, "oracle")
+    kw = MP.frame_and_keyframe(sc)
+    sf = np.asarray(kw["scale_factors"], np.float32)
+    for ori in (True, False):
+        exp, num = O.match_frame_and_keyframe_projection(ori, cam, **kw)
+        a = dict(pw=_f64(kw["pos_w"]), valid=_c(kw["valid"], np.uint8), mn=_c(kw["min_valid_dist"], np.float32), mx=_c(kw["max_valid_dist"], np.float32),
+                 ld=_c(kw["lm_desc"], np.uint8), ak=_c(kw["angle_kf"], np.float32), td=_c(kw["tdesc"], np.uint8), xy=_c(kw["t_xy"], np.float32),
+                 to=_c(kw["t_octave"], np.int32), ta=_c(kw["t_angle"], np.float32), occ=_c(kw["occupied"], np.uint8))
+        nt = len(a["td"])
+        holder = np.full(nt, -9, np.int32)
+        got = ref.svref_match_frame_and_keyframe_projection(
+            C.byref(cam), _p(_f64(kw["rot_cw"])), _p(_f64(kw["trans_cw"])), len(a["pw"]), _p(a["pw"]), _p(a["valid"]), _p(a["mn"]), _p(a["mx"]), _p(a["ld"]),
+            _p(a["ak"]), C.c_float(float(sf[1] / sf[0])), len(sf), C.c_float(kw["margin"]), int(kw["hamm_dist_thr"]), _p(a["td"]), _p(a["xy"]), _p(a["to"]),
+            _p(a["ta"]), nt, _p(a["occ"]), 64, 48, int(ori), _p(holder))
+        assert got == num > 300
+        assert np.array_equal(holder, _replay(exp, nt, kw["occupied"]))
