@@ -176,4 +176,149 @@ int svref_match_frame_and_keyframe_projection(const orc_camera* camd, const doub
     return (int)num;
 }
 
+// projection::match_by_Sim3_transform (match/projection.cc:321-416).  Queries = `landmarks` (valid = not about to be erased); `occupied` keypoints of the
+// keyframe start with a match.  Out: for every keyframe keypoint the query it received (-1 none, -2 initial occupant).
+int svref_match_by_sim3_transform(const orc_camera* camd, const double* sim3_cw /* 4 x 4 row-major */, int n, const double* pos_w, const uint8_t* valid,
+                                  const float* min_valid_dist, const float* max_valid_dist, const double* mean_normal, const uint8_t* lm_desc,
+                                  float scale_factor, unsigned num_levels, float margin, const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave,
+                                  int nt, const uint8_t* occupied, int grid_cols, int grid_rows, int32_t* holder_of_target) {
+    svref::forget_grids();
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(camd, true, 0.0);
+    auto kf = std::make_shared<data::keyframe>(1, &cam, &P.p);
+    fill_observation(kf->frm_obs_, tdesc, t_xy, t_octave, nullptr, nullptr, nullptr, nt, grid_cols, grid_rows);
+    Mat44_t S;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) S(i, j) = sim3_cw[4 * i + j];
+    std::vector<std::shared_ptr<data::landmark>> lms;
+    for (int i = 0; i < n; ++i) {
+        auto lm = make_landmark((unsigned)i, pos_w + 3 * i, lm_desc + 32 * (size_t)i, min_valid_dist[i], max_valid_dist[i], mean_normal + 3 * i);
+        lm->will_be_erased_ = valid && !valid[i];
+        lms.push_back(lm);
+    }
+    const auto occupant = make_landmark(0xFFFFFFFEu, nullptr, nullptr, 0.f, 0.f, nullptr);
+    std::vector<std::shared_ptr<data::landmark>> matched(nt, nullptr);
+    for (int j = 0; j < nt; ++j)
+        if (occupied && occupied[j]) matched[j] = occupant;
+    const unsigned num = match::projection(0.0f, false).match_by_Sim3_transform(kf, S, lms, matched, margin);
+    for (int j = 0; j < nt; ++j) holder_of_target[j] = !matched[j] ? -1 : (matched[j] == occupant ? -2 : (int32_t)matched[j]->id_);
+    svref::forget_grids();
+    return (int)num;
+}
+
+// projection::match_keyframes_mutually (match/projection.cc:418-629).  valid* = the keypoint holds a live landmark; no pair is matched beforehand.
+// Out: mutual_2_in_1[i] = keypoint of keyframe 2 whose landmark keyframe 1's keypoint i received, or -1.
+int svref_match_keyframes_mutually(const orc_camera* camd, const double* rot_1w, const double* trans_1w, const double* rot_2w, const double* trans_2w, float s_12,
+                                   const double* rot_12, const double* trans_12, int n1, const double* pos_w1, const uint8_t* valid1, const float* min_valid1,
+                                   const float* max_valid1, const uint8_t* lm_desc1, const uint8_t* desc1, const float* xy1, const int32_t* octave1, int n2,
+                                   const double* pos_w2, const uint8_t* valid2, const float* min_valid2, const float* max_valid2, const uint8_t* lm_desc2,
+                                   const uint8_t* desc2, const float* xy2, const int32_t* octave2, float scale_factor, unsigned num_levels, float margin,
+                                   int grid_cols, int grid_rows, int32_t* mutual_2_in_1) {
+    svref::forget_grids();
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(camd, true, 0.0);
+    auto k1 = std::make_shared<data::keyframe>(1, &cam, &P.p), k2 = std::make_shared<data::keyframe>(2, &cam, &P.p);
+    k1->set_pose_cw(svref::pose44(rot_1w, trans_1w));
+    k2->set_pose_cw(svref::pose44(rot_2w, trans_2w));
+    fill_observation(k1->frm_obs_, desc1, xy1, octave1, nullptr, nullptr, nullptr, n1, grid_cols, grid_rows);
+    fill_observation(k2->frm_obs_, desc2, xy2, octave2, nullptr, nullptr, nullptr, n2, grid_cols, grid_rows);
+    k1->landmarks_.assign(n1, nullptr);
+    k2->landmarks_.assign(n2, nullptr);
+    for (int i = 0; i < n1; ++i)
+        if (valid1[i]) k1->landmarks_[i] = make_landmark((unsigned)i, pos_w1 + 3 * i, lm_desc1 + 32 * (size_t)i, min_valid1[i], max_valid1[i], nullptr);
+    for (int i = 0; i < n2; ++i)
+        if (valid2[i]) k2->landmarks_[i] = make_landmark(1000000u + (unsigned)i, pos_w2 + 3 * i, lm_desc2 + 32 * (size_t)i, min_valid2[i], max_valid2[i], nullptr);
+    std::vector<std::shared_ptr<data::landmark>> matched(n1, nullptr);
+    const float s = s_12;
+    const unsigned num = match::projection(0.0f, false).match_keyframes_mutually(k1, k2, matched, s, svref::mat33(rot_12), svref::vec3(trans_12), margin);
+    for (int i = 0; i < n1; ++i) mutual_2_in_1[i] = matched[i] ? (int32_t)(matched[i]->id_ - 1000000u) : -1;
+    svref::forget_grids();
+    return (int)num;
+}
+
+// fuse::detect_duplication<std::vector<...>> (match/fuse.cc:11-154).  Every second keypoint of the keyframe holds a landmark, so both output
+// maps are exercised: best_idx[i] = the keyframe keypoint landmark i was fused with (from duplicated_lms_in_keyfrm or new_connections), or -1.
+int svref_fuse_detect_duplication(const orc_camera* camd, const double* rot_cw, const double* trans_cw, int n, const double* pos_w, const uint8_t* valid,
+                                  const float* min_valid_dist, const float* max_valid_dist, const double* mean_normal, const uint8_t* lm_desc, float scale_factor,
+                                  unsigned num_levels, float margin, int do_reprojection_matching, const uint8_t* tdesc, const float* t_xy,
+                                  const int32_t* t_octave, const float* t_xright, int nt, int grid_cols, int grid_rows, int32_t* best_idx) {
+    svref::forget_grids();
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(camd, t_xright == nullptr, 0.0);
+    auto kf = std::make_shared<data::keyframe>(1, &cam, &P.p);
+    fill_observation(kf->frm_obs_, tdesc, t_xy, t_octave, nullptr, t_xright, nullptr, nt, grid_cols, grid_rows);
+    kf->landmarks_.assign(nt, nullptr);
+    for (int j = 0; j < nt; j += 2) kf->landmarks_[j] = make_landmark(1000000u + (unsigned)j, nullptr, nullptr, 0.f, 0.f, nullptr);
+    std::vector<std::shared_ptr<data::landmark>> lms(n, nullptr);
+    for (int i = 0; i < n; ++i)
+        if (!valid || valid[i]) lms[i] = make_landmark((unsigned)i, pos_w + 3 * i, lm_desc + 32 * (size_t)i, min_valid_dist[i], max_valid_dist[i], mean_normal + 3 * i);
+    std::unordered_map<std::shared_ptr<data::landmark>, std::shared_ptr<data::landmark>> duplicated;
+    std::unordered_map<unsigned int, std::shared_ptr<data::landmark>> fresh;
+    const unsigned num = match::fuse(0.0f).detect_duplication(kf, svref::mat33(rot_cw), svref::vec3(trans_cw), lms, margin, duplicated, fresh,
+                                                                        do_reprojection_matching != 0);
+    for (int i = 0; i < n; ++i) best_idx[i] = -1;
+    for (const auto& d : duplicated) best_idx[d.first->id_] = (int32_t)(d.second->id_ - 1000000u);
+    for (const auto& f : fresh) best_idx[f.second->id_] = (int32_t)f.first;
+    svref::forget_grids();
+    return (int)num;
+}
+
+// projection::match_frame_and_landmarks (match/projection.cc:13-93) on the maps frame::can_observe filled (given here per landmark: observable,
+// reprojection, x_right, predicted level).  `occupied` frame keypoints hold a landmark with an observation.  Out: holder of every frame keypoint.
+int svref_match_frame_and_landmarks(const orc_camera* camd, int is_monocular, int n, const uint8_t* observable, const double* reproj, const float* x_right,
+                                    const int32_t* pred_level, const uint8_t* lm_desc, float scale_factor, unsigned num_levels, float margin, float lowe_ratio,
+                                    const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, const float* t_xright, int nt, const uint8_t* occupied,
+                                    int grid_cols, int grid_rows, int32_t* holder_of_target) {
+    svref::forget_grids();
+    Params P(scale_factor, num_levels);
+    camera_fixture cam(camd, is_monocular != 0, 0.0);
+    data::frame frm(1, &cam, &P.p);
+    fill_observation(frm.frm_obs_, tdesc, t_xy, t_octave, nullptr, t_xright, nullptr, nt, grid_cols, grid_rows);
+    frm.landmarks_.assign(nt, nullptr);
+    const auto occupant = make_landmark(0xFFFFFFFEu, nullptr, nullptr, 0.f, 0.f, nullptr, true);
+    for (int j = 0; j < nt; ++j)
+        if (occupied && occupied[j]) frm.landmarks_[j] = occupant;
+    std::vector<std::shared_ptr<data::landmark>> lms;
+    eigen_alloc_unord_map<unsigned int, Vec2_t> lm_to_reproj;
+    std::unordered_map<unsigned int, float> lm_to_x_right;
+    std::unordered_map<unsigned int, unsigned int> lm_to_scale;
+    for (int i = 0; i < n; ++i) {
+        lms.push_back(make_landmark((unsigned)i, nullptr, lm_desc + 32 * (size_t)i, 0.f, 0.f, nullptr, false));
+        if (observable[i]) {
+            lm_to_reproj[(unsigned)i] = Vec2_t(reproj[2 * i], reproj[2 * i + 1]);
+            lm_to_x_right[(unsigned)i] = x_right[i];
+            lm_to_scale[(unsigned)i] = (unsigned)pred_level[i];
+        }
+    }
+    const unsigned num = match::projection(lowe_ratio, false).match_frame_and_landmarks(frm, lms, lm_to_reproj, lm_to_x_right, lm_to_scale, margin);
+    for (int j = 0; j < nt; ++j) {
+        const auto lm = frm.landmarks_[j];
+        holder_of_target[j] = !lm ? -1 : (lm == occupant ? -2 : (int32_t)lm->id_);
+    }
+    svref::forget_grids();
+    return (int)num;
+}
+
+// area::match_in_consistent_area (match/area.cc:8-98): the initializer's matcher.  prev_xy is updated in place as the method does.
+int svref_match_in_consistent_area(const orc_camera* camd, const uint8_t* desc1, const int32_t* octave1, const float* angle1, int n1, float* prev_xy,
+                                   const uint8_t* desc2, const float* xy2, const int32_t* octave2, const float* angle2, int n2, int margin, float lowe_ratio,
+                                   int check_orientation, int grid_cols, int grid_rows, int32_t* matched_2_in_1) {
+    svref::forget_grids();
+    Params P(1.2f, 8);
+    camera_fixture cam(camd, true, 0.0);
+    data::frame f1(1, &cam, &P.p), f2(2, &cam, &P.p);
+    fill_observation(f1.frm_obs_, desc1, nullptr, octave1, angle1, nullptr, nullptr, n1, grid_cols, grid_rows);
+    fill_observation(f2.frm_obs_, desc2, xy2, octave2, angle2, nullptr, nullptr, n2, grid_cols, grid_rows);
+    std::vector<cv::Point2f> prev(n1);
+    for (int i = 0; i < n1; ++i) prev[i] = cv::Point2f(prev_xy[2 * i], prev_xy[2 * i + 1]);
+    std::vector<int> out;
+    const unsigned num = match::area(lowe_ratio, check_orientation != 0).match_in_consistent_area(f1, f2, prev, out, margin);
+    for (int i = 0; i < n1; ++i) {
+        matched_2_in_1[i] = out[i];
+        prev_xy[2 * i] = prev[i].x, prev_xy[2 * i + 1] = prev[i].y;
+    }
+    svref::forget_grids();
+    return (int)num;
+}
+
 }  // extern "C"

@@ -145,3 +145,138 @@ def test_match_frame_and_keyframe_projection(ref, sc):
             _p(a["ta"]), nt, _p(a["occ"]), 64, 48, int(ori), _p(holder))
         assert got == num > 300
         assert np.array_equal(holder, _replay(exp, nt, kw["occupied"]))
+
+
+def _sf(kw):
+    sf = np.asarray(kw["scale_factors"], np.float32)
+    return C.c_float(float(sf[1] / sf[0])), len(sf)
+
+
+def test_match_by_sim3_transform(ref, sc):
+    cam = MP.make_cams(sc, "oracle")
+    kw = MP.by_sim3(sc)
+    exp, num = O.match_by_sim3_transform(cam, **kw)
+    a = dict(S=_f64(kw["sim3_cw"]), pw=_f64(kw["pos_w"]), valid=_c(kw["valid"], np.uint8), mn=_c(kw["min_valid_dist"], np.float32),
+             mx=_c(kw["max_valid_dist"], np.float32), nrm=_f64(kw["mean_normal"]), ld=_c(kw["lm_desc"], np.uint8), td=_c(kw["tdesc"], np.uint8),
+             xy=_c(kw["t_xy"], np.float32), to=_c(kw["t_octave"], np.int32), occ=_c(kw["occupied"], np.uint8))
+    nt = len(a["td"])
+    holder = np.full(nt, -9, np.int32)
+    got = ref.svref_match_by_sim3_transform(C.byref(cam), _p(a["S"]), len(a["pw"]), _p(a["pw"]), _p(a["valid"]), _p(a["mn"]), _p(a["mx"]), _p(a["nrm"]), _p(a["ld"]),
+                                            *_sf(kw), C.c_float(kw["margin"]), _p(a["td"]), _p(a["xy"]), _p(a["to"]), nt, _p(a["occ"]), 64, 48, _p(holder))
+    assert got == num > 300
+    assert np.array_equal(holder, _replay(exp, nt, kw["occupied"]))
+
+
+def test_match_keyframes_mutually(ref, sc):
+    cam = MP.make_cams(sc, "oracle")
+    kw = MP.mutually(sc)
+    m21, m12, mut, num = O.match_keyframes_mutually(cam, cam, **kw)
+    k1, k2 = kw["kf1"], kw["kf2"]
+
+    def side(k):
+        return [_f64(k["pos_w"]), _c(k["valid"], np.uint8), _c(k["min_valid_dist"], np.float32), _c(k["max_valid_dist"], np.float32), _c(k["lm_desc"], np.uint8),
+                _c(k["desc"], np.uint8), _c(k["xy"], np.float32), _c(k["octave"], np.int32)]
+    s1, s2 = side(k1), side(k2)
+    out = np.full(len(s1[0]), -9, np.int32)
+    got = ref.svref_match_keyframes_mutually(C.byref(cam), _p(_f64(kw["rot_1w"])), _p(_f64(kw["trans_1w"])), _p(_f64(kw["rot_2w"])), _p(_f64(kw["trans_2w"])),
+                                             C.c_float(kw["s_12"]), _p(_f64(kw["rot_12"])), _p(_f64(kw["trans_12"])), len(s1[0]), *[_p(x) for x in s1], len(s2[0]),
+                                             *[_p(x) for x in s2], *_sf(kw), C.c_float(kw["margin"]), 64, 48, _p(out))
+    assert got == num > 200
+    assert np.array_equal(out, mut)
+
+
+@pytest.mark.parametrize("reproj", [False, True])
+@pytest.mark.parametrize("stereo", [False, True])
+def test_fuse_detect_duplication(ref, sc, sc_stereo, stereo, reproj):
+    s = sc_stereo if stereo else sc
+    cam = MP.make_cams(s, "oracle")
+    kw = MP.fuse(s, do_reprojection_matching=reproj)
+    exp, num = O.fuse_detect_duplication(cam, **kw)
+    a = dict(pw=_f64(kw["pos_w"]), valid=_c(kw["valid"], np.uint8), mn=_c(kw["min_valid_dist"], np.float32), mx=_c(kw["max_valid_dist"], np.float32),
+             nrm=_f64(kw["mean_normal"]), ld=_c(kw["lm_desc"], np.uint8), td=_c(kw["tdesc"], np.uint8), xy=_c(kw["t_xy"], np.float32),
+             to=_c(kw["t_octave"], np.int32), xr=_c(kw.get("t_xright"), np.float32))
+    out = np.full(len(a["pw"]), -9, np.int32)
+    got = ref.svref_fuse_detect_duplication(C.byref(cam), _p(_f64(kw["rot_cw"])), _p(_f64(kw["trans_cw"])), len(a["pw"]), _p(a["pw"]), _p(a["valid"]), _p(a["mn"]),
+                                            _p(a["mx"]), _p(a["nrm"]), _p(a["ld"]), *_sf(kw), C.c_float(kw["margin"]), int(reproj), _p(a["td"]), _p(a["xy"]),
+                                            _p(a["to"]), _p(a["xr"]), len(a["td"]), 64, 48, _p(out))
+    assert got == num > 300
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_match_frame_and_landmarks(ref, sc, sc_stereo, stereo):
+    """projection::match_frame_and_landmarks on the maps frame::can_observe fills: the oracle side is can_observe + the grid lookup + the
+    ratio-within-octave candidate matcher (the composition the device entry point svgpu_match_frame_and_landmarks is tested against)."""
+    s = sc_stereo if stereo else sc
+    cam = MP.make_cams(s, "oracle")
+    frm = s["views"][1]
+    L, T = s["landmarks"], s["tables"]
+    rng = np.random.default_rng(4)
+    R, t = MP._perturb(frm["rot_cw"], frm["trans_cw"], rng)
+    n = len(L["pos_w"])
+    vis, rp, xr, lv = O.can_observe(cam, R, t, L["pos_w"], L["mean_normal"], L["min_valid_dist"], L["max_valid_dist"], 0.5, T["num_levels"], float(T["log_scale_factor"]))
+    vis = (vis.astype(bool) & (rng.uniform(0, 1, n) < 0.9)).astype(np.uint8)
+    occupied = (rng.uniform(0, 1, len(frm["xy"])) < 0.1).astype(np.uint8)
+    margin, ratio = 5.0, 0.8
+    kx, ky = np.ascontiguousarray(frm["xy"][:, 0]), np.ascontiguousarray(frm["xy"][:, 1])
+    bounds = (cam.min_x, cam.max_x, cam.min_y, cam.max_y)
+    off_g, items = O.assign_keypoints_to_grid(kx, ky, bounds)
+    lvq = np.where(vis == 1, lv, 0)
+    qm = (np.float32(margin) * T["scale_factors"][lvq]).astype(np.float32)
+    cand_off, cand = [0], []
+    for q in range(n):
+        if vis[q]:
+            cand += O.get_keypoints_in_cell(kx, ky, frm["octave"], off_g, items, bounds, float(np.float32(rp[q, 0])), float(np.float32(rp[q, 1])), float(qm[q]),
+                                            max(0, int(lv[q]) - 1), min(T["num_levels"] - 1, int(lv[q]) + 1)).tolist()
+        cand_off.append(len(cand))
+    kwx = dict(q_xright=xr, t_xright=frm["x_right"], q_xr_tol=qm) if stereo else {}
+    exp = O.match_candidates(L["desc"], frm["desc"], cand_off, cand, check_orientation=False, thr=100, lowe_ratio=ratio, mode=O.MODE_RATIO_SAME_OCTAVE,
+                             t_octave=frm["octave"], q_valid=vis, occupied=occupied, **kwx)
+    a = dict(vis=_c(vis, np.uint8), rp=_f64(rp), xr=_c(xr, np.float32), lv=_c(lv, np.int32), ld=_c(L["desc"], np.uint8), td=_c(frm["desc"], np.uint8),
+             xy=_c(frm["xy"], np.float32), to=_c(frm["octave"], np.int32), txr=_c(frm["x_right"], np.float32) if stereo else None, occ=occupied)
+    nt = len(a["td"])
+    holder = np.full(nt, -9, np.int32)
+    got = ref.svref_match_frame_and_landmarks(C.byref(cam), int(not stereo), n, _p(a["vis"]), _p(a["rp"]), _p(a["xr"]), _p(a["lv"]), _p(a["ld"]),
+                                              C.c_float(1.2), int(T["num_levels"]), C.c_float(margin), C.c_float(ratio), _p(a["td"]), _p(a["xy"]), _p(a["to"]),
+                                              _p(a["txr"]), nt, _p(a["occ"]), 64, 48, _p(holder))
+    assert got == (exp >= 0).sum() > 300
+    assert np.array_equal(holder, _replay(exp, nt, occupied))
+
+
+@pytest.mark.parametrize("check", [True, False])
+def test_match_in_consistent_area(ref, sc, check):
+    """area::match_in_consistent_area (the initializer's matcher): the oracle side is the grid lookup at level 0 + the sequential area mode.
+    Many frame-1 keypoints compete for the same frame-2 keypoints, so later, closer queries take targets back from their holders."""
+    cam = MP.make_cams(sc, "oracle")
+    rng = np.random.default_rng(6)
+    n1, n2 = 1500, 900
+    xy2 = np.stack([rng.uniform(20, sc["width"] - 20, n2), rng.uniform(20, sc["height"] - 20, n2)], 1).astype(np.float32)
+    o2 = (rng.uniform(0, 1, n2) < 0.15).astype(np.int32)   # most keypoints on level 0
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    a2 = rng.uniform(0, 360, n2).astype(np.float32)
+    src = rng.integers(0, n2 // 2, n1)
+    d1 = d2[src].copy()
+    for i in range(n1):
+        for b in rng.choice(256, int(rng.integers(0, 41)), replace=False):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    a1 = ((a2[src] + rng.normal(0, 12, n1)) % 360).astype(np.float32)
+    o1 = (rng.uniform(0, 1, n1) < 0.15).astype(np.int32)
+    prev = (xy2[src] + rng.normal(0, 6.0, (n1, 2))).astype(np.float32)
+    margin, ratio = 30, 0.9
+    kx, ky = np.ascontiguousarray(xy2[:, 0]), np.ascontiguousarray(xy2[:, 1])
+    bounds = (cam.min_x, cam.max_x, cam.min_y, cam.max_y)
+    off_g, items = O.assign_keypoints_to_grid(kx, ky, bounds)
+    cand_off, cand = [0], []
+    for q in range(n1):
+        if o1[q] == 0:
+            cand += O.get_keypoints_in_cell(kx, ky, o2, off_g, items, bounds, float(prev[q, 0]), float(prev[q, 1]), float(margin), 0, 0).tolist()
+        cand_off.append(len(cand))
+    exp = O.match_candidates(d1, d2, cand_off, cand, q_angle=a1, t_angle=a2, check_orientation=check, thr=50, lowe_ratio=ratio, mode=O.MODE_AREA)
+    work = prev.copy()
+    out = np.full(n1, -9, np.int32)
+    got = ref.svref_match_in_consistent_area(C.byref(cam), _p(d1), _p(o1), _p(a1), n1, _p(work), _p(d2), _p(xy2), _p(o2), _p(a2), n2, margin, C.c_float(ratio),
+                                             int(check), 64, 48, _p(out))
+    assert got == (exp >= 0).sum() > 150
+    assert np.array_equal(out, exp)
+    moved = exp >= 0
+    assert np.array_equal(work[moved], xy2[exp[moved]]) and np.array_equal(work[~moved], prev[~moved])
