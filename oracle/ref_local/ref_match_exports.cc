@@ -10,6 +10,7 @@
 #include "stella_vslam/match/fuse.h"
 #include "stella_vslam/match/projection.h"
 #include "stella_vslam/match/robust.h"
+#include "stella_vslam/match/stereo.h"
 
 using namespace stella_vslam;
 using svref::camera_fixture;
@@ -319,6 +320,35 @@ int svref_match_in_consistent_area(const orc_camera* camd, const uint8_t* desc1,
     }
     svref::forget_grids();
     return (int)num;
+}
+
+// match::stereo::compute (match/stereo.cc:20-251) on two extractor outputs: 28-byte keypoints, descriptors, the two image pyramids.
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} svref_kp28;
+void svref_stereo_compute(const svref_kp28* kl, const uint8_t* dl, int nl, const svref_kp28* kr, const uint8_t* dr, int nr, const uint8_t* const* pyr_left,
+                          const uint8_t* const* pyr_right, const int* lw, const int* lh, const int* ls_l, const int* ls_r, float scale_factor, int num_levels,
+                          float focal_x_baseline, float true_baseline, float* stereo_x_right, float* depths) {
+    Params P(scale_factor, (unsigned)num_levels);
+    std::vector<cv::Mat> pl, pr;
+    for (int l = 0; l < num_levels; ++l) {
+        pl.push_back(cv::Mat(lh[l], lw[l], CV_8UC1, const_cast<uint8_t*>(pyr_left[l]), (size_t)ls_l[l]));
+        pr.push_back(cv::Mat(lh[l], lw[l], CV_8UC1, const_cast<uint8_t*>(pyr_right[l]), (size_t)ls_r[l]));
+    }
+    auto kps = [](const svref_kp28* k, int n) {
+        std::vector<cv::KeyPoint> v(n);
+        for (int i = 0; i < n; ++i) v[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id);
+        return v;
+    };
+    const std::vector<cv::KeyPoint> vl = kps(kl, nl), vr = kps(kr, nr);
+    const cv::Mat descl(nl, 32, CV_8UC1, const_cast<uint8_t*>(dl), 32), descr(nr, 32, CV_8UC1, const_cast<uint8_t*>(dr), 32);
+    std::vector<float> xr, dp;
+    match::stereo(pl, pr, vl, vr, descl, descr, P.p.scale_factors_, P.p.inv_scale_factors_, focal_x_baseline, true_baseline).compute(xr, dp);
+    for (int i = 0; i < nl; ++i) {
+        stereo_x_right[i] = xr[i];
+        depths[i] = dp[i];
+    }
 }
 
 }  // extern "C"

@@ -280,3 +280,36 @@ def test_match_in_consistent_area(ref, sc, check):
     assert np.array_equal(out, exp)
     moved = exp >= 0
     assert np.array_equal(work[moved], xy2[exp[moved]]) and np.array_equal(work[~moved], prev[~moved])
+
+
+@pytest.mark.parametrize("disp,noise", [(12, 0), (31, 2)])
+def test_stereo_compute(ref, disp, noise):
+    """match::stereo::compute (match/stereo.cc): row bins, level / disparity gates, Hamming best, the 11 x 11 L1 patch slide, the parabola and the
+    2 x median rejection -- the reference's own code on two extractor outputs (over the typed stand-in cv::Mat) against the oracle, bit for bit."""
+    from stella_vslam_amd import synthetic as S
+    big = S.frame(640 + 64, 480, 5)
+    left, right = np.ascontiguousarray(big[:, 8:648]), np.ascontiguousarray(big[:, 8 + disp:648 + disp])
+    if noise:
+        rng = np.random.default_rng(disp)
+        right = np.clip(right.astype(np.int16) + rng.integers(-noise, noise + 1, right.shape), 0, 255).astype(np.uint8)
+    kl, dl, _, pl = O.orb_extract(left, want_pyramid=True)
+    kr, dr, _, pr = O.orb_extract(right, want_pyramid=True)
+    fxb, bl = 458.654 * 0.11, 0.11
+    exr, edp = O.stereo_match(kl, dl, kr, dr, pl, pr, fxb, bl)
+    L = len(pl)
+    pl = [np.ascontiguousarray(a) for a in pl]
+    pr = [np.ascontiguousarray(a) for a in pr]
+    PL = (C.c_void_p * L)(*[a.ctypes.data for a in pl])
+    PR = (C.c_void_p * L)(*[a.ctypes.data for a in pr])
+    lw = np.array([a.shape[1] for a in pl], np.int32)
+    lh = np.array([a.shape[0] for a in pl], np.int32)
+    lsl = np.array([a.strides[0] for a in pl], np.int32)
+    lsr = np.array([a.strides[0] for a in pr], np.int32)
+    kl, kr = np.ascontiguousarray(kl), np.ascontiguousarray(kr)
+    dl, dr = np.ascontiguousarray(dl, np.uint8), np.ascontiguousarray(dr, np.uint8)
+    xr, dp = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32)
+    ref.svref_stereo_compute.restype = None
+    ref.svref_stereo_compute(_p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), PL, PR, _p(lw), _p(lh), _p(lsl), _p(lsr), C.c_float(1.2), L, C.c_float(fxb),
+                             C.c_float(bl), _p(xr), _p(dp))
+    assert (exr >= 0).sum() > 500
+    assert np.array_equal(xr.view(np.uint32), exr.view(np.uint32)) and np.array_equal(dp.view(np.uint32), edp.view(np.uint32))
