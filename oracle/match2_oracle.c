@@ -17,7 +17,9 @@
  *                                                                                     equirectangular.cc:75-80, radial_division.cc:135-156
  * They deliberately do NOT go through the generic orc_match_candidates of match_oracle.c: the device path is built from generic
  * candidate-list kernels, so these independent literal loops are what it has to reproduce bit for bit.
- * PARITY UNPINNED against the reference binary itself: its tests hold no vectors for any matcher class.
+ * PARITY: the reference's tests hold no vectors for any matcher class; every function here is pinned against the
+ * reference's own compiled method instead (oracle/ref_local builds match/*.cc where they lie over stand-in data / Eigen headers;
+ * tests/test_ref_local_match.py: identical match lists, mono and stereo).
  * Eigen expressions are taken as ((a0 b0 + a1 b1) + a2 b2) per 3-vector product, norm() = sqrt of that, normalize() = x / norm().
  */
 #include <math.h>

@@ -19,8 +19,9 @@
  * N x 32 bytes, angles, octaves, CSR candidate lists in the reference's scan order.
  *
  * PARITY STATUS: Hamming distance is pinned by the reference's known-answer tests
- * (test/stella_vslam/match/base.cc:11-57: 0 / 256 / 128).  No reference test exercises any matcher
- * class => matcher outputs are "parity unpinned" beyond this line-by-line restatement.
+ * (test/stella_vslam/match/base.cc:11-57: 0 / 256 / 128).  No reference test exercises any matcher class; the matcher
+ * restatements here (brute force, the candidate-list modes incl. area, stereo) are pinned against the reference's own
+ * compiled match/*.cc instead (oracle/ref_local, tests/test_ref_local_match.py).
  */
 #include <math.h>
 #include <stdint.h>

@@ -27,12 +27,14 @@
  *   cv::fastAtan2                       core/src/mathfuncs_core.simd.hpp (atan_f32)
  *   cvRound / cvFloor                   core/fast_math.hpp (round-half-even / floor)
  *
- * PARITY STATUS: "parity unpinned" for keypoint lists and descriptor bits -- the reference's own
- * tests hold no golden keypoints/descriptors and neither OpenCV nor the
- * reference can be built in this container.  What IS pinned against the reference's tests:
- * the scale tables (test/stella_vslam/feature/orb_params.cc:27-70), util::cos/sin within 1e-3
- * (test/stella_vslam/util/trigonometric.cc:8-20), and the structural extractor invariants
- * (test/stella_vslam/feature/orb_extractor.cc).  See tests/test_oracle_*.py.
+ * PARITY STATUS.  Pinned against the reference's own compiled code (oracle/ref_local: feature/orb_extractor.cc, orb_impl.cc,
+ * orb_params.cc, util/angle.cc, util/trigonometric.h and the pattern table compiled where they lie; tests/test_ref_local.py): everything
+ * in this file that restates the REFERENCE -- the extractor's control flow, cell layout, retry, masks, grid selection, orientation
+ * moments, rotated BRIEF and bit order, scale correction, util::cos / sin, the scale tables -- equals it bit for bit.
+ * Pinned by the reference's own tests: the scale tables (test/stella_vslam/feature/orb_params.cc:27-70), util::cos/sin within 1e-3
+ * (test/stella_vslam/util/trigonometric.cc:8-20), the structural extractor invariants (test/stella_vslam/feature/orb_extractor.cc).
+ * "Parity unpinned": the five OpenCV primitives listed above (resize, GaussianBlur, FAST, fastAtan2, cvRound) -- OpenCV cannot be
+ * built here; they are the same code on both sides of the comparison above.  oracle/ref_recipe/ pins them where OpenCV exists.
  *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -fPIC -shared  (x86-64 baseline, no FMA: mirrors the
  * reference default build, CMakeLists.txt:75-81).
