@@ -17,6 +17,9 @@
  *   (MAX_ITER + EPS, 10, 1e-8).  // VERIFY-AGAINST-OPENCV-4.7
  * PARITY UNPINNED for these two: the reference's tests hold no vectors for them; the tests here pin them through the
  * forward distortion model (distort -> undistort round trip) and the zero-distortion identity.
+ * Everything ELSE in this file that restates the reference's camera/*.cc (bounds, marshalling, bearings, the two reprojections, the
+ * radial-division and equirectangular closed forms) is pinned against the reference's own compiled camera sources
+ * (oracle/ref_local -> oracle/_ref/libsvref_cam.so, tests/test_ref_local_camera.py).
  *
  * Pitfall restated on purpose: the reference hands OpenCV a CV_32F camera matrix and CV_32F distortion vector
  * (perspective.cc:21-22, fisheye.cc:21-22), so inside the undistortion fx, fy, cx, cy, k* are the FLOAT-rounded values,
@@ -149,8 +152,10 @@ void orc_keypoints_to_bearings(const orc_camera* c, int n, const float* xy, doub
         const float ux = xy[2 * i], uy = xy[2 * i + 1];
         double* b = bearings + 3 * i;
         if (c->model == CAM_EQUIRECT) {
-            const double lon = (ux / c->cols - 0.5) * (2.0 * pi);
-            const double lat = -(uy / c->rows - 0.5) * pi;
+            /* equirectangular.cc:45-46: `undist_pt.x / cols_` divides a float by an unsigned int, i.e. in FLOAT; only then does "- 0.5"
+             * promote to double (found by pinning against the reference's compiled camera code, tests/test_ref_local_camera.py) */
+            const double lon = ((double)(ux / (float)(unsigned)c->cols) - 0.5) * (2.0 * pi);
+            const double lat = -((double)(uy / (float)(unsigned)c->rows) - 0.5) * pi;
             b[0] = cos(lat) * sin(lon);
             b[1] = -sin(lat);
             b[2] = cos(lat) * cos(lon);

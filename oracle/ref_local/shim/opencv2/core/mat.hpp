@@ -30,12 +30,12 @@ public:
     uchar* data = nullptr;
     Step step;
     Mat() {}
-    Mat(int r, int c, int /*type*/) { create(r, c, CV_8UC1); }
+    Mat(int r, int c, int type) { create(r, c, type); }
     Mat(int r, int c, int /*type*/, const Scalar& s) {
         create(r, c, CV_8UC1);
         memset(data, (int)s.val[0], (size_t)r * c);
     }
-    Mat(int r, int c, int /*type*/, void* ext, size_t step_bytes) : rows(r), cols(c), data((uchar*)ext) { step.v = step_bytes; }  // user data, not owned
+    Mat(int r, int c, int type, void* ext, size_t step_bytes) : rows(r), cols(c), data((uchar*)ext), esz_(type == CV_32F ? 4 : 1) { step.v = step_bytes; }  // user data, not owned
     void create(int r, int c, int type) {
         const int esz = type == CV_32F ? 4 : 1;
         if (data && rows == r && cols == c && esz == esz_) return;  // cv::Mat::create keeps a buffer of the right size and type
@@ -66,6 +66,7 @@ public:
         return *this;
     }
     int depth() const { return esz_ == 4 ? CV_32F : CV_8U; }
+    Mat reshape(int /*cn*/) const { return *this; }  // n x 2 one-channel <-> n x 1 two-channel: the same bytes, which is all the callers use
     Mat& operator=(const MatZeros& z) {
         create(z.rows, z.cols, CV_8UC1);
         for (int y = 0; y < rows; ++y) memset(data + (size_t)y * step.v, 0, cols);
@@ -112,6 +113,26 @@ public:
 private:
     std::shared_ptr<std::vector<uchar>> store_;
     int esz_ = 1;
+};
+// (cv::Mat_<float>(r, c) << a, b, ...): row-major comma initialiser of a float matrix
+template <class T>
+class Mat_ : public Mat {
+public:
+    Mat_(int r, int c) { create(r, c, CV_32F); }
+    struct Comma {
+        Mat_& m;
+        int k;
+        Comma& operator,(double x) {
+            m.template at<T>(k / m.cols, k % m.cols) = (T)x;
+            ++k;
+            return *this;
+        }
+        operator Mat() const { return m; }
+    };
+    Comma operator<<(double x) {
+        this->template at<T>(0, 0) = (T)x;
+        return Comma{*this, 1};
+    }
 };
 enum { NORM_L1 = 2 };
 static inline double norm(const Mat& a, const Mat& b, int /*NORM_L1*/) {  // float matrices; the sum is accumulated in double as cv::norm does

@@ -12,6 +12,7 @@
 #include "opencv2/core/fast_math.hpp"
 typedef unsigned char uchar;
 namespace cv {
+class Mat;
 template <class T>
 struct Point_ {
     T x, y;

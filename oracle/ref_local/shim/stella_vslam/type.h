@@ -70,6 +70,30 @@ struct Matrix {
     }
     double squaredNorm() const { return dot(*this); }
     double norm() const { return std::sqrt(squaredNorm()); }
+    void normalize() {  // Eigen: *this /= norm()
+        const double n = norm();
+        for (int i = 0; i < R * C; ++i) v[i] /= n;
+    }
+    Matrix normalized() const {
+        Matrix m(*this);
+        const double n = norm();
+        if (n > 0.0) m.normalize();
+        return m;
+    }
+    // Eigen's comma initialiser: coefficients in ROW-major order
+    struct CommaInit {
+        Matrix& m;
+        int k;
+        CommaInit& operator,(double x) {
+            m(k / C, k % C) = x;
+            ++k;
+            return *this;
+        }
+    };
+    CommaInit operator<<(double x) {
+        (*this)(0, 0) = x;
+        return CommaInit{*this, 1};
+    }
     Matrix operator-() const {
         Matrix m;
         for (int i = 0; i < R * C; ++i) m.v[i] = -v[i];
@@ -132,6 +156,8 @@ using VecR_t = svref_eigen::Matrix<(int)R, 1>;
 using Vec2_t = svref_eigen::Matrix<2, 1>;
 using Vec3_t = svref_eigen::Matrix<3, 1>;
 using Vec4_t = svref_eigen::Matrix<4, 1>;
+using Vec5_t = svref_eigen::Matrix<5, 1>;
+using Vec6_t = svref_eigen::Matrix<6, 1>;
 template <typename T>
 using eigen_alloc_vector = std::vector<T>;
 template <typename T, typename U>

@@ -7,9 +7,11 @@ class Node {
 public:
     Node operator[](const char*) const { return Node(); }
     template <class T>
+    T as() const { return T(); }
+    template <class T>
     T as(const T& fallback) const { return fallback; }
-    template <class T, class U>
-    T as(const U& fallback) const { return T(fallback); }
+    bool operator!() const { return true; }
+    explicit operator bool() const { return false; }
 };
 }  // namespace YAML
 #endif

@@ -121,8 +121,9 @@ __global__ void __launch_bounds__(256) k_frame_observation(FrameObsProblem P) {
     if (P.bearings) {
         double b0, b1, b2;
         if (P.cam.model == SVGPU_CAM_EQUIRECTANGULAR) {  // equirectangular.cc:41-48
-            const double lon = (ux / P.cam.cols - 0.5) * (2.0 * kPi);
-            const double lat = -(uy / P.cam.rows - 0.5) * kPi;
+            // equirectangular.cc:45-46: `undist_pt.x / cols_` is a FLOAT division (float by unsigned int); "- 0.5" then promotes to double
+            const double lon = ((double)(ux / (float)(unsigned)P.cam.cols) - 0.5) * (2.0 * kPi);
+            const double lat = -((double)(uy / (float)(unsigned)P.cam.rows) - 0.5) * kPi;
             b0 = cos(lat) * sin(lon);
             b1 = -sin(lat);
             b2 = cos(lat) * cos(lon);
