@@ -9,6 +9,8 @@
 #include "stella_vslam/camera/fisheye.h"
 #include "stella_vslam/camera/perspective.h"
 #include "stella_vslam/camera/radial_division.h"
+#include "stella_vslam/data/common.h"
+#include "stella_vslam/data/frame_observation.h"
 
 using namespace stella_vslam;
 
@@ -68,5 +70,32 @@ void svref_camera_reproject(int model, int stereo, unsigned cols, unsigned rows,
         bearing_ok[i] = cam->reproject_to_bearing(R, t, pw, b);
         bearing[3 * i] = b(0), bearing[3 * i + 1] = b(1), bearing[3 * i + 2] = b(2);
     }
+}
+
+// data::assign_keypoints_to_grid + data::get_keypoints_in_cell (data/common.cc:83-190, compiled where it lies) for nq queries
+// {ref_x, ref_y, margin} with level bounds; out: CSR of the returned indices in the returned order.  Returns the total count (or -1: cap).
+int svref_grid_lookup(int model, unsigned cols, unsigned rows, double fx, double fy, double cx, double cy, const double* dist, int n, const float* xy,
+                      const int32_t* octave, unsigned grid_cols, unsigned grid_rows, int nq, const float* q_xym, const int32_t* q_levels, int32_t* out_off,
+                      int32_t* out_idx, int cap) {
+    const auto cam = make(model, 0, cols, rows, fx, fy, cx, cy, dist, 0.0);
+    data::frame_observation fo;
+    fo.undist_keypts_.resize(n);
+    for (int i = 0; i < n; ++i) {
+        fo.undist_keypts_[i].pt.x = xy[2 * i], fo.undist_keypts_[i].pt.y = xy[2 * i + 1];
+        fo.undist_keypts_[i].octave = octave[i];
+    }
+    fo.num_grid_cols_ = grid_cols, fo.num_grid_rows_ = grid_rows;
+    data::assign_keypoints_to_grid(cam.get(), fo.undist_keypts_, fo.keypt_indices_in_cells_, grid_cols, grid_rows);
+    int total = 0;
+    out_off[0] = 0;
+    for (int q = 0; q < nq; ++q) {
+        const auto idx = data::get_keypoints_in_cell(cam.get(), fo, q_xym[3 * q], q_xym[3 * q + 1], q_xym[3 * q + 2], q_levels[2 * q], q_levels[2 * q + 1]);
+        for (const auto i : idx) {
+            if (total >= cap) return -1;
+            out_idx[total++] = (int32_t)i;
+        }
+        out_off[q + 1] = total;
+    }
+    return total;
 }
 }

@@ -34,6 +34,9 @@ struct Matrix {
         static_assert(R * C == 2, "2-vector");
         v[0] = a, v[1] = b;
     }
+    explicit Matrix(const double* p) {  // Eigen: coefficients from a column-major array
+        for (int i = 0; i < R * C; ++i) v[i] = p[i];
+    }
     double& operator()(int i, int j) { return v[j * R + i]; }
     double operator()(int i, int j) const { return v[j * R + i]; }
     double& operator()(int i) { return v[i]; }
@@ -137,6 +140,39 @@ static inline Matrix<R, C> operator*(double s, const Matrix<R, C>& a) {
     for (int i = 0; i < R * C; ++i) m.v[i] = s * a.v[i];
     return m;
 }
+// Eigen::Quaterniond as far as data/common.cc's JSON helpers need it to compile (not exercised by the fixtures)
+struct Quaternion {
+    double q[4] = {0, 0, 0, 1};  // x y z w, Eigen's coefficient order
+    Quaternion() {}
+    explicit Quaternion(const double* xyzw) {
+        for (int i = 0; i < 4; ++i) q[i] = xyzw[i];
+    }
+    explicit Quaternion(const Matrix<3, 3>& R) {
+        const double tr = R(0, 0) + R(1, 1) + R(2, 2);
+        if (tr > 0) {
+            const double s = std::sqrt(tr + 1.0) * 2;
+            q[3] = 0.25 * s, q[0] = (R(2, 1) - R(1, 2)) / s, q[1] = (R(0, 2) - R(2, 0)) / s, q[2] = (R(1, 0) - R(0, 1)) / s;
+        }
+    }
+    double x() const { return q[0]; }
+    double y() const { return q[1]; }
+    double z() const { return q[2]; }
+    double w() const { return q[3]; }
+    Quaternion normalized() const {
+        Quaternion r(*this);
+        const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (int i = 0; i < 4; ++i) r.q[i] /= n;
+        return r;
+    }
+    Matrix<3, 3> toRotationMatrix() const {
+        Matrix<3, 3> R;
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        R(0, 0) = 1 - 2 * (y * y + z * z), R(0, 1) = 2 * (x * y - z * w), R(0, 2) = 2 * (x * z + y * w);
+        R(1, 0) = 2 * (x * y + z * w), R(1, 1) = 1 - 2 * (x * x + z * z), R(1, 2) = 2 * (y * z - x * w);
+        R(2, 0) = 2 * (x * z - y * w), R(2, 1) = 2 * (y * z + x * w), R(2, 2) = 1 - 2 * (x * x + y * y);
+        return R;
+    }
+};
 }  // namespace svref_eigen
 
 namespace stella_vslam {
@@ -158,6 +194,7 @@ using Vec3_t = svref_eigen::Matrix<3, 1>;
 using Vec4_t = svref_eigen::Matrix<4, 1>;
 using Vec5_t = svref_eigen::Matrix<5, 1>;
 using Vec6_t = svref_eigen::Matrix<6, 1>;
+using Quat_t = svref_eigen::Quaternion;
 template <typename T>
 using eigen_alloc_vector = std::vector<T>;
 template <typename T, typename U>

@@ -101,3 +101,32 @@ def test_reprojection(ref, name):
     else:
         bv = bok.astype(bool)
         assert np.abs(bear[bv] - e_bear[bv]).max() <= 1e-14
+
+
+@pytest.mark.parametrize("name", ["perspective", "fisheye", "equirectangular"])
+def test_grid_assignment_and_lookup(ref, name):
+    """data::assign_keypoints_to_grid + data::get_keypoints_in_cell (data/common.cc, the reference's own code): the candidate lists every
+    projection matcher starts from -- same indices in the same order as the oracle's restatement, for windows inside, across and outside
+    the image bounds, with and without level limits."""
+    c = CAMS[name]
+    cam = O.make_camera(c["model"], c["cols"], c["rows"], c["fx"], c["fy"], c["cx"], c["cy"], c["dist"], c["fxb"])
+    rng = np.random.default_rng(3)
+    n, nq = 2500, 1500
+    bounds = (cam.min_x, cam.max_x, cam.min_y, cam.max_y)
+    w, h = cam.max_x - cam.min_x, cam.max_y - cam.min_y
+    xy = np.stack([rng.uniform(cam.min_x - 0.02 * w, cam.max_x + 0.02 * w, n), rng.uniform(cam.min_y - 0.02 * h, cam.max_y + 0.02 * h, n)], 1).astype(np.float32)
+    xy[:8] = [[cam.min_x, cam.min_y], [cam.max_x, cam.max_y], [cam.min_x, cam.max_y], [cam.max_x, cam.min_y], [cam.min_x + w / 64, cam.min_y + h / 48],
+              [cam.min_x + w / 2, cam.min_y + h / 2], [cam.max_x - 1e-3, cam.max_y - 1e-3], [cam.min_x - 1e-3, cam.min_y]]
+    octave = rng.integers(0, 8, n).astype(np.int32)
+    q = np.stack([rng.uniform(cam.min_x - 0.1 * w, cam.max_x + 0.1 * w, nq), rng.uniform(cam.min_y - 0.1 * h, cam.max_y + 0.1 * h, nq),
+                  rng.choice([3.0, 7.5, 15.0, 40.0, 0.5 * w], nq)], 1).astype(np.float32)
+    lv = np.stack([rng.integers(-1, 6, nq), rng.integers(-1, 8, nq)], 1).astype(np.int32)
+    args, keep = _args(c)
+    off, idx = np.zeros(nq + 1, np.int32), np.zeros(4_000_000, np.int32)
+    tot = ref.svref_grid_lookup(args[0], args[2], args[3], *args[4:9], n, _p(xy), _p(octave), 64, 48, nq, _p(q), _p(lv), _p(off), _p(idx), len(idx))
+    assert tot > 10000
+    kx, ky = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
+    goff, items = O.assign_keypoints_to_grid(kx, ky, bounds)
+    for i in range(nq):
+        exp = O.get_keypoints_in_cell(kx, ky, octave, goff, items, bounds, float(q[i, 0]), float(q[i, 1]), float(q[i, 2]), int(lv[i, 0]), int(lv[i, 1]))
+        assert np.array_equal(idx[off[i]:off[i + 1]], exp), i
