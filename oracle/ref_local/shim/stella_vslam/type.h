@@ -22,6 +22,9 @@
 namespace svref_eigen {
 template <int R, int C>
 struct Matrix {
+    typedef double Scalar;
+    static int rows() { return R; }
+    static int cols() { return C; }
     double v[R * C];  // column-major, as Eigen's default
     Matrix() {
         for (int i = 0; i < R * C; ++i) v[i] = 0.0;
