@@ -26,8 +26,12 @@
  * LinearSolverEigen's sparse Cholesky is replaced by a dense LL^T of the same reduced matrix
  * (mathematically identical solution; different rounding order).
  *
- * PARITY STATUS: "parity unpinned" -- the reference has no test under test/stella_vslam/optimize/ and g2o
- * cannot be built here.  The oracle is cross-checked against scipy.optimize.least_squares and known
+ * PARITY STATUS: the reference's OWN part of this path -- the vertex and edge classes and the wrappers that configure them
+ * (optimize/internal/landmark_vertex.h, se3/shot_vertex.h, se3/*_reproj_edge.h, se3/*_pose_opt_edge.h, se3/*_wrapper.h) -- is pinned
+ * bit for bit against the reference's compiled headers (oracle/ref_local -> oracle/_ref/libsvref_opt.so, tests/test_ref_local_optimize.py:
+ * errors, both Jacobian blocks, depth gate, chi2, information, Huber width, levels, oplus).  g2o's side (LM schedule, block solver,
+ * SE3Quat arithmetic, robust weighting) stays "parity unpinned": the reference has no test under test/stella_vslam/optimize/ and g2o
+ * cannot be built here.  That part is cross-checked against scipy.optimize.least_squares and known
  * ground truth on synthetic scenes (tests/test_oracle_ba.py).  Vertex ordering in the reference is
  * unordered_map hash order, so only mathematical (<=1e-4 relative), not bitwise, parity is meaningful.
  */
@@ -405,6 +409,42 @@ typedef struct {
     double* xl;  /* nL x 3 */
 } lin_t;
 
+/* linearizeOplus of the reprojection edges (perspective_reproj_edge.h:67-98 mono, :154-192 stereo rows; equirectangular_reproj_edge.h):
+ * A = d e / d landmark (3 x 3, unused rows zero), Bj = d e / d [omega, upsilon] (3 x 6).  The stereo row is always filled for the
+ * perspective model; callers use D rows. */
+static void reproj_edge_jacobians(const double* K, const double* pc, const double* R, double* A, double* Bj) {
+    const double fx = K[0], fy = K[1], fxb = K[4];
+    const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z;
+    for (int c = 0; A && c < 3; ++c) {
+        A[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_sq;
+        A[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_sq;
+        A[6 + c] = A[c] - fxb * R[6 + c] / z_sq;
+    }
+    Bj[0] = x * y / z_sq * fx;
+    Bj[1] = -(1.0 + (x * x / z_sq)) * fx;
+    Bj[2] = y / z * fx;
+    Bj[3] = -1.0 / z * fx;
+    Bj[4] = 0.0;
+    Bj[5] = x / z_sq * fx;
+    Bj[6] = (1.0 + y * y / z_sq) * fy;
+    Bj[7] = -x * y / z_sq * fy;
+    Bj[8] = -x / z * fy;
+    Bj[9] = 0.0;
+    Bj[10] = -1.0 / z * fy;
+    Bj[11] = y / z_sq * fy;
+    Bj[12] = Bj[0] - fxb * y / z_sq;
+    Bj[13] = Bj[1] + fxb * x / z_sq;
+    Bj[14] = Bj[2];
+    Bj[15] = Bj[3];
+    Bj[16] = 0;
+    Bj[17] = Bj[5] - fxb / z_sq;
+    if (cam_is_equirect(K)) {
+        if (A) memset(A, 0, sizeof(double) * 9);
+        memset(Bj, 0, sizeof(double) * 18);
+        equirect_jacobians(K, pc, A ? R : NULL, A, Bj);
+    }
+}
+
 static void build_system(const ba_t* B, lin_t* S) {
     memset(S->Hpp, 0, sizeof(double) * 36 * (size_t)B->nP);
     memset(S->bp, 0, sizeof(double) * 6 * (size_t)B->nP);
@@ -424,34 +464,8 @@ static void build_system(const ba_t* B, lin_t* S) {
         quat_to_R(B->pose[p].q, R);
         const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z;
         double A[9], Bj[18]; /* A: D x 3 (d e / d landmark), Bj: D x 6 (d e / d pose) */
-        for (int c = 0; c < 3; ++c) {
-            A[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_sq;
-            A[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_sq;
-            A[6 + c] = A[c] - fxb * R[6 + c] / z_sq;
-        }
-        Bj[0] = x * y / z_sq * fx;
-        Bj[1] = -(1.0 + (x * x / z_sq)) * fx;
-        Bj[2] = y / z * fx;
-        Bj[3] = -1.0 / z * fx;
-        Bj[4] = 0.0;
-        Bj[5] = x / z_sq * fx;
-        Bj[6] = (1.0 + y * y / z_sq) * fy;
-        Bj[7] = -x * y / z_sq * fy;
-        Bj[8] = -x / z * fy;
-        Bj[9] = 0.0;
-        Bj[10] = -1.0 / z * fy;
-        Bj[11] = y / z_sq * fy;
-        Bj[12] = Bj[0] - fxb * y / z_sq;
-        Bj[13] = Bj[1] + fxb * x / z_sq;
-        Bj[14] = Bj[2];
-        Bj[15] = Bj[3];
-        Bj[16] = 0;
-        Bj[17] = Bj[5] - fxb / z_sq;
-        if (cam_is_equirect(K)) {
-            memset(A, 0, sizeof(A));
-            memset(Bj, 0, sizeof(Bj));
-            equirect_jacobians(K, pc, R, A, Bj);
-        }
+        (void)x, (void)y, (void)z_sq, (void)fx, (void)fy, (void)fxb;
+        reproj_edge_jacobians(K, pc, R, A, Bj);
         const double* r = &B->err[3 * e];
         double w = (double)B->obs_inv_sigma_sq[e];
         double rw = w; /* weight on the residual in b: rho' * omega */
@@ -884,31 +898,10 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
                 PO_ERR(i, &T)
                 double pc[3];
                 se3_map(&T, &pos_w[3 * i], pc);
-                const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z, fx = intr[0], fy = intr[1], fxb = intr[4];
                 const int stereo = !(uvr[3 * i + 2] < 0) && !cam_is_equirect(intr);
-                double J[18];
-                J[0] = x * y / z_sq * fx;
-                J[1] = -(1.0 + (x * x / z_sq)) * fx;
-                J[2] = y / z * fx;
-                J[3] = -1.0 / z * fx;
-                J[4] = 0;
-                J[5] = x / z_sq * fx;
-                J[6] = (1.0 + y * y / z_sq) * fy;
-                J[7] = -x * y / z_sq * fy;
-                J[8] = -x / z * fy;
-                J[9] = 0.0;
-                J[10] = -1.0 / z * fy;
-                J[11] = y / z_sq * fy;
-                J[12] = stereo ? J[0] - fxb * y / z_sq : 0;
-                J[13] = stereo ? J[1] + fxb * x / z_sq : 0;
-                J[14] = stereo ? J[2] : 0;
-                J[15] = stereo ? J[3] : 0;
-                J[16] = 0;
-                J[17] = stereo ? J[5] - fxb / z_sq : 0;
-                if (cam_is_equirect(intr)) { /* equirectangular_pose_opt_edge.h:70-118 */
-                    memset(J, 0, sizeof(J));
-                    equirect_jacobians(intr, pc, NULL, NULL, J);
-                }
+                double J[18]; /* the unary edges' pose block = the binary edges' (perspective_pose_opt_edge.h:75-98, :175-204; equirectangular_pose_opt_edge.h:70-118) */
+                reproj_edge_jacobians(intr, pc, NULL, NULL, J);
+                if (!stereo) memset(&J[12], 0, 6 * sizeof(double));
                 const double chi = PO_CHI(i);
                 double w = (double)inv_sigma_sq[i], rho[2] = {chi, 1.0};
                 if (robust[i]) huber(chi, (double)huber_delta[i], rho);
@@ -1019,4 +1012,52 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
     free(robust);
     free(err);
     return n - num_bad;
+}
+
+
+/* ---------------------------------------------------------------- test hooks (oracle/ref_local pins these against the reference's edge
+ * and vertex classes; the g2o stand-in's SE3Quat forwards to the first four) */
+void orc_dbg_se3_from_Rt(const double* R_row_major, const double* t, double* q4, double* t3) {
+    se3q T;
+    quat_from_R(R_row_major, T.q);
+    memcpy(T.t, t, sizeof(T.t));
+    quat_normalize(&T);
+    memcpy(q4, T.q, sizeof(T.q));
+    memcpy(t3, T.t, sizeof(T.t));
+}
+void orc_dbg_se3_exp_mul(const double* upd6, const double* q4, const double* t3, double* q4_out, double* t3_out) { /* exp(upd) * T */
+    se3q E, T, O;
+    se3_exp(upd6, &E);
+    memcpy(T.q, q4, sizeof(T.q));
+    memcpy(T.t, t3, sizeof(T.t));
+    se3_mul(&E, &T, &O);
+    memcpy(q4_out, O.q, sizeof(O.q));
+    memcpy(t3_out, O.t, sizeof(O.t));
+}
+void orc_dbg_se3_map(const double* q4, const double* t3, const double* p, double* out) {
+    se3q T;
+    memcpy(T.q, q4, sizeof(T.q));
+    memcpy(T.t, t3, sizeof(T.t));
+    se3_map(&T, p, out);
+}
+void orc_dbg_quat_to_R(const double* q4, double* R_row_major) { quat_to_R(q4, R_row_major); }
+/* one reprojection edge exactly as build_system / edge_error see it: err[3], A[9], Bj[18]; returns D (2 or 3) */
+int orc_dbg_reproj_edge(const double* q4, const double* t3, const double* point, const double* K5, const float* uvr, double* err, double* A, double* Bj) {
+    se3q T;
+    memcpy(T.q, q4, sizeof(T.q));
+    memcpy(T.t, t3, sizeof(T.t));
+    double pc[3], R[9], u, v;
+    se3_map(&T, point, pc);
+    quat_to_R(T.q, R);
+    if (cam_is_equirect(K5)) equirect_project(K5, pc, &u, &v);
+    else {
+        u = K5[0] * pc[0] / pc[2] + K5[2];
+        v = K5[1] * pc[1] / pc[2] + K5[3];
+    }
+    const int stereo = !(uvr[2] < 0) && !cam_is_equirect(K5);
+    err[0] = (double)uvr[0] - u;
+    err[1] = (double)uvr[1] - v;
+    err[2] = stereo ? (double)uvr[2] - (u - K5[4] / pc[2]) : 0.0;
+    reproj_edge_jacobians(K5, pc, R, A, Bj);
+    return stereo ? 3 : 2;
 }

@@ -12,6 +12,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <type_traits>
+
 #include <opencv2/core/types.hpp>
 
 #ifndef M_PI
@@ -66,6 +68,37 @@ struct Matrix {
         for (int i = 0; i < BR; ++i)
             for (int j = 0; j < BC; ++j) b(i, j) = (*this)(r0 + i, c0 + j);
         return b;
+    }
+    // writable block of a non-const matrix: a copy of the coefficients (usable in any expression) that writes back on assignment
+    template <int BR, int BC>
+    struct BlockRef : Matrix<BR, BC> {
+        Matrix& parent;
+        int r0, c0;
+        BlockRef(Matrix& p, int r, int c) : Matrix<BR, BC>(static_cast<const Matrix&>(p).template block<BR, BC>(r, c)), parent(p), r0(r), c0(c) {}
+        BlockRef& operator=(const Matrix<BR, BC>& o) {
+            for (int i = 0; i < BR; ++i)
+                for (int j = 0; j < BC; ++j) parent(r0 + i, c0 + j) = o(i, j);
+            static_cast<Matrix<BR, BC>&>(*this) = o;
+            return *this;
+        }
+        // Eigen lets a column vector be assigned to a row-vector block (and the reverse): the coefficients in order
+        template <int OR, int OC, typename = typename std::enable_if<(OR == BC && OC == BR && (BR == 1 || BC == 1) && BR != BC)>::type>
+        BlockRef& operator=(const Matrix<OR, OC>& o) {
+            Matrix<BR, BC> t;
+            for (int i = 0; i < BR * BC; ++i) t.v[i] = o.v[i];
+            return (*this = t);
+        }
+    };
+    template <int BR, int BC>
+    BlockRef<BR, BC> block(int r0, int c0) {
+        return BlockRef<BR, BC>(*this, r0, c0);
+    }
+    void fill(double x) {
+        for (int i = 0; i < R * C; ++i) v[i] = x;
+    }
+    Matrix& operator+=(const Matrix& o) {
+        for (int i = 0; i < R * C; ++i) v[i] += o.v[i];
+        return *this;
     }
     template <int OR, int OC>
     double dot(const Matrix<OR, OC>& o) const {
@@ -178,6 +211,15 @@ struct Quaternion {
 };
 }  // namespace svref_eigen
 
+namespace Eigen {  // Eigen::Map<const VecN_t>(ptr) as the g2o vertices use it: the coefficients behind the pointer
+template <class M>
+struct Map;
+template <int R, int C>
+struct Map<const svref_eigen::Matrix<R, C>> : svref_eigen::Matrix<R, C> {
+    explicit Map(const double* p) : svref_eigen::Matrix<R, C>(p) {}
+};
+}  // namespace Eigen
+
 namespace stella_vslam {
 template <typename T, typename... ArgTs>
 std::unique_ptr<T> make_unique(ArgTs&&... args) {
@@ -197,6 +239,7 @@ using Vec3_t = svref_eigen::Matrix<3, 1>;
 using Vec4_t = svref_eigen::Matrix<4, 1>;
 using Vec5_t = svref_eigen::Matrix<5, 1>;
 using Vec6_t = svref_eigen::Matrix<6, 1>;
+using Vec7_t = svref_eigen::Matrix<7, 1>;
 using Quat_t = svref_eigen::Quaternion;
 template <typename T>
 using eigen_alloc_vector = std::vector<T>;

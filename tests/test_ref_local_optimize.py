@@ -1,0 +1,116 @@
+"""Pins the oracle's bundle-adjustment graph elements (oracle/ba_oracle.c: edge_error, reproj_edge_jacobians, the vertex updates, the
+information / Huber-width / level conventions) against the REFERENCE's own optimize/internal headers, compiled where they lie into
+oracle/_ref/libsvref_opt.so: landmark_vertex.h, se3/shot_vertex.h, se3/perspective_reproj_edge.h, se3/equirectangular_reproj_edge.h,
+se3/perspective_pose_opt_edge.h, se3/equirectangular_pose_opt_edge.h and the two wrappers (model -> edge type, information = inv_sigma_sq * I,
+Huber delta = sqrt_chi_sq, level 1 = outlier).  g2o itself is absent: the stand-in's SE3Quat forwards to the oracle's SE3 helpers, so what is
+pinned is every formula the reference wrote, evaluated on identical camera-frame points; g2o's own SE3 arithmetic and solver are not."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libsvref_opt.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(_SO):
+        pytest.skip("oracle/_ref/libsvref_opt.so absent: it is built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    return C.CDLL(_SO)
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _random_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    if q[3] < 0:
+        q = -q
+    return np.ascontiguousarray(q), rng.uniform(-1, 1, 3)
+
+
+def _scene(rng, model):
+    """One pose, one landmark in front of (or, for the equirectangular model, anywhere around) the camera, one observation."""
+    q, t = _random_pose(rng)
+    Rr = np.zeros(9)
+    O.lib().orc_dbg_quat_to_R(_p(q), _p(Rr))
+    R = Rr.reshape(3, 3)
+    pc = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(0.5, 20)]) if model != 2 else rng.normal(size=3) * rng.uniform(0.5, 10)
+    if model != 2 and rng.uniform() < 0.1:
+        pc[2] = -pc[2]   # behind the camera: depth_is_positive false
+    pw = R.T @ (pc - t)
+    return q, t, np.ascontiguousarray(pw)
+
+
+@pytest.mark.parametrize("model", [0, 1, 2, 3])
+@pytest.mark.parametrize("stereo", [0, 1])
+def test_reproj_and_pose_opt_edges(ref, model, stereo):
+    if model == 2 and stereo:
+        pytest.skip("the equirectangular model is monocular only (reproj_edge_wrapper.h:143)")
+    rng = np.random.default_rng(100 + 10 * model + stereo)
+    cols, rows = 1280, 640
+    lib = O.lib()
+    for it in range(300):
+        q, t, pw = _scene(rng, model)
+        intr = np.array([rng.uniform(300, 900), rng.uniform(300, 900), rng.uniform(500, 700), rng.uniform(250, 400), rng.uniform(20, 80)])
+        K5 = intr.copy() if model != 2 else np.array([0.0, 0.0, cols, rows, 0.0])
+        right = rng.uniform(0, 1200) if (stereo and rng.uniform() < 0.7) else -1.0
+        uvr = np.array([rng.uniform(0, cols), rng.uniform(0, rows), right], np.float32)
+        inv_sigma_sq = np.float32(1.2 ** (-2 * int(rng.integers(0, 8))))
+        sqrt_chi = np.float32(np.sqrt(5.991) if right < 0 else np.sqrt(7.815))
+        # oracle
+        err_o, A_o, B_o = np.zeros(3), np.zeros(9), np.zeros(18)
+        lib.orc_dbg_reproj_edge.restype = C.c_int
+        D_o = lib.orc_dbg_reproj_edge(_p(q), _p(t), _p(pw), _p(K5), _p(uvr), _p(err_o), _p(A_o), _p(B_o))
+        # reference: binary edge
+        err_r, A_r, B_r, meta = np.zeros(3), np.zeros(9), np.zeros(18), np.zeros(6)
+        use_huber = int(rng.uniform() < 0.8)
+        ref.svref_reproj_edge.restype = C.c_int
+        D_r = ref.svref_reproj_edge(model, stereo, cols, rows, _p(intr), _p(q), _p(t), _p(pw), _p(uvr), C.c_float(inv_sigma_sq), C.c_float(sqrt_chi),
+                                    use_huber, _p(err_r), _p(A_r), _p(B_r), _p(meta))
+        assert D_r == D_o == (3 if right >= 0 else 2)
+        np.testing.assert_array_equal(err_r[:D_r], err_o[:D_r])
+        np.testing.assert_array_equal(A_r[:3 * D_r], A_o[:3 * D_r])
+        np.testing.assert_array_equal(B_r[:6 * D_r], B_o[:6 * D_r])
+        assert meta[0] == float(inv_sigma_sq)                       # information = inv_sigma_sq * Identity
+        assert meta[1] == (float(sqrt_chi) if use_huber else -1.0)   # Huber delta
+        chi_o = float(np.dot(err_o[:D_o], float(inv_sigma_sq) * err_o[:D_o]))
+        assert abs(meta[2] - chi_o) <= 1e-12 * max(chi_o, 1.0)
+        # depth gate as the oracle applies it (depth_ok): camera-frame z, always true for the equirectangular model
+        pc = np.zeros(3)
+        lib.orc_dbg_se3_map(_p(q), _p(t), _p(pw), _p(pc))
+        assert bool(meta[3]) == (model == 2 or pc[2] > 0)
+        assert meta[4] == 11 and meta[5] == 10                        # outlier = level 1, inlier = level 0
+        # reference: unary (pose-only) edge -- same error and the same pose block
+        err_u, B_u, meta_u = np.zeros(3), np.zeros(18), np.zeros(6)
+        ref.svref_pose_opt_edge.restype = C.c_int
+        D_u = ref.svref_pose_opt_edge(model, stereo, cols, rows, _p(intr), _p(q), _p(t), _p(pw), _p(uvr), C.c_float(inv_sigma_sq), C.c_float(sqrt_chi),
+                                      _p(err_u), _p(B_u), _p(meta_u))
+        assert D_u == D_o
+        np.testing.assert_array_equal(err_u[:D_u], err_o[:D_u])
+        np.testing.assert_array_equal(B_u[:6 * D_u], B_o[:6 * D_u])
+        assert meta_u[0] == float(inv_sigma_sq) and meta_u[1] == float(sqrt_chi)
+        assert bool(meta_u[3]) == (model == 2 or pc[2] > 0)
+        assert meta_u[4] == 11 and meta_u[5] == 10
+
+
+def test_vertex_updates(ref):
+    rng = np.random.default_rng(7)
+    lib = O.lib()
+    for it in range(200):
+        q, t = _random_pose(rng)
+        upd6 = rng.normal(size=6) * rng.choice([1e-9, 1e-3, 0.3])
+        pos, upd3 = rng.uniform(-5, 5, 3), rng.normal(size=3)
+        q_r, t_r, p_r, org = np.zeros(4), np.zeros(3), np.zeros(3), np.zeros(10)
+        ref.svref_vertex_oplus(_p(q), _p(t), _p(upd6), _p(q_r), _p(t_r), _p(pos), _p(upd3), _p(p_r), _p(org))
+        q_o, t_o = np.zeros(4), np.zeros(3)
+        lib.orc_dbg_se3_exp_mul(_p(upd6), _p(q), _p(t), _p(q_o), _p(t_o))   # exp(update) * estimate, shot_vertex.h:54
+        np.testing.assert_array_equal(q_r, q_o)
+        np.testing.assert_array_equal(t_r, t_o)
+        np.testing.assert_array_equal(p_r, pos + upd3)                        # landmark_vertex.h:51
+        np.testing.assert_array_equal(org, [0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
