@@ -551,6 +551,22 @@ __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
     return max(max((int)best.x - v, v + 1 + (int)best.y), 0);
 }
 
+#ifdef SV_FAST_PROF  // phase clocks of k_fast (tools/fast_phases.py builds with -DSV_FAST_PROF; never in the shipped library)
+__device__ unsigned long long g_fast_prof[8];
+#define FPROF(i)                                                                                  \
+    do {                                                                                          \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                             \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_fast_prof[i], now_ - prof_t);                   \
+        prof_t = now_;                                                                            \
+    } while (0)
+extern "C" void svgpu_debug_fast_prof(unsigned long long* out8) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fast_prof), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_prof), z, sizeof(z));
+}
+#else
+#define FPROF(i)
+#endif
 #define FAST_KT 12  // selection-grid cells per dimension cached in LDS (a 70-px ROI spans at most ~10 at the coarsest level)
 #define FP 80  // LDS pitch of the ROI arrays: 3 skew bytes + 70, rounded up to whole 16-byte chunks
 __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells,
@@ -566,6 +582,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __shared__ unsigned short s_gx[SV_ROI_MAX], s_gy[SV_ROI_MAX];  // selection-grid column / row of every ROI column / row
     __shared__ int s_count;
     int local, b, ci;
+#ifdef SV_FAST_PROF
+    unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+#endif
     xcd_frame_map(gridDim.x, gridDim.y, ci, b);
     const int lv = find_level(L, num_levels, ci, &OrbLevel::cell_first, &local);
     const OrbLevel lev = L[lv];
@@ -632,8 +651,8 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     if (tid < w) s_gx[tid] = gtab[lev.gtab_x_off + cell.min_x + tid - SV_PATCH_RADIUS];
     else if (tid >= 128 && tid - 128 < h) s_gy[tid - 128] = gtab[lev.gtab_y_off + cell.min_y + (tid - 128) - SV_PATCH_RADIUS];
     __syncthreads();
+    FPROF(0);
 
-    const int tq = min(ini_thr, min_thr);
     auto load_ring = [&](const uint8_t* c, int (&p)[16]) {
         p[0] = c[3 * FP];
         p[1] = c[3 * FP + 1];
@@ -652,7 +671,15 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         p[14] = c[2 * FP - 2];
         p[15] = c[3 * FP - 1];
     };
-    // --- pass A: every pixel of the scored band [3, w-3) x [3, h-3) takes a 5-pixel quick test at the lower threshold.
+    // cv::FAST at ini_thr; if the cell stays empty, once more at min_thr (:228-235).  The quick test, the queue and the arc scores are
+    // rebuilt for the retry (rare: textured cells are never empty), so the common case queues and scores only what can exceed ini_thr.
+    unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
+    const int gx0 = s_gx[3], gy0 = s_gy[3];  // grid cell of the first scored pixel
+    const int lane = tid & 63;
+    unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
+    for (int pass = 0; pass < 2; ++pass) {
+    const int t = pass == 0 ? ini_thr : min_thr, tq = t;
+    // --- pass A: every pixel of the scored band [3, w-3) x [3, h-3) takes a 5-pixel quick test at this pass's threshold.
     //     Nine contiguous ring pixels always contain at least one pixel of every opposite pair (k, k + 8), so a
     //     9-arc brighter than v + t needs (p0 | p8) and (p4 | p12) brighter (same for darker): a necessary condition
     //     that ~90 % of the pixels fail.  Survivors are compacted into an LDS queue so that the expensive arc score
@@ -665,8 +692,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     separate alignment step), and the whole test runs on v_pk_min / max / sub: ~9 instructions per pixel instead of ~16.
     //     Every wave owns a quarter of the queue.
     int wq = 0;
-    unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
-    const int lane = tid & 63;
     {
         const int wv = tid >> 6, qrow = lane >> 4, qk = lane & 15;
         const int x0 = 3 + 4 * qk;  // the lane's columns x0 .. x0 + 3 (ROI coordinates)
@@ -724,6 +749,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             my_q[pos++] = (unsigned short)(e0 + (((bit & 7) - 4) << 7) + (bit >> 3));
         }
     }
+    FPROF(1);
     // every wave scores and filters ITS quarter of the queue: no index mapping
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the queue entries were written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
@@ -736,15 +762,14 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         load_ring(c, p);
         s_a[ly * FP + qx] = (uint8_t)arc_score16(c[0], p);
     }
+    FPROF(2);
     __syncthreads();
+    FPROF(3);
 
-    // --- per-cell NMS at ini_thr; if nothing survives, again at min_thr (:228-235)
-    unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
-    const int gx0 = s_gx[3], gy0 = s_gy[3];  // grid cell of the first scored pixel
-    for (int pass = 0; pass < 2; ++pass) {
-        const int t = pass == 0 ? ini_thr : min_thr;
+    // --- per-cell NMS at this pass's threshold
+    {
         int found = 0;
-        for (int i = lane; i < wq; i += 64) {  // only queued pixels can have A > t (t >= tq)
+        for (int i = lane; i < wq; i += 64) {  // only queued pixels can have A > t
             const int e = my_q[i], ly = e >> 7, qx = e & 127;
             const uint8_t* a = &s_a[ly * FP + qx];
             const int A = a[0];
@@ -769,14 +794,18 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             else atomicMax(&K[gy * lev.grid_x + gx], key);
         }
         if (found) atomicAdd(&s_count, found);
+        FPROF(4);
         __syncthreads();
+        FPROF(5);
         if (s_count > 0) break;
         __syncthreads();
+    }
     }
     if (tid < FAST_KT * FAST_KT) {
         const unsigned long long key = s_key[tid];
         if (key) atomicMax(&K[(gy0 + tid / FAST_KT) * lev.grid_x + gx0 + tid % FAST_KT], key);
     }
+    FPROF(6);
 }
 
 // ------------------------------------------------------------------------------------------------ select
