@@ -80,6 +80,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the latency / stereo legs")
+    ap.add_argument("--leg-timeout", type=int, default=420, help="seconds the secondary legs (latency, stereo, BA, CPU baseline) may take before the line is printed without them")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -276,6 +277,24 @@ def main() -> int:
     del bufs, frames
     torch.cuda.empty_cache()
 
+    # The secondary legs must never cost the headline: if one of them hangs (the sharded global BA is the only code of this file that
+    # cannot be exercised on the one-GPU test box at N > 1), every rank's watchdog ends its process after rank 0 has printed the line
+    # it has.  ctypes and torch.distributed calls release the GIL, so the timer thread runs while the main thread is blocked.
+    import threading
+    legs_done = threading.Event()
+
+    def bail():
+        if legs_done.is_set():
+            return
+        if rank == 0:
+            result.setdefault("global_ba", {"error": "secondary legs timed out after %d s; headline unaffected" % args.leg_timeout})
+            print(json.dumps(result), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.leg_timeout, bail)
+    watchdog.daemon = True
+    watchdog.start()
+
     if rank == 0 and world == 1 and not args.no_extra:
         for key, fn in (("latency", lambda: bench_latency(ctx, frames_np)), ("stereo", lambda: bench_stereo(local_rank))):
             try:
@@ -297,9 +316,14 @@ def main() -> int:
                 result["global_ba"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames_np, want_ba=not args.no_ba)
+    legs_done.set()
+    watchdog.cancel()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        closer = threading.Timer(60, lambda: os._exit(0))  # the line is out: a stuck teardown must not keep the launcher waiting
+        closer.daemon = True
+        closer.start()
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -477,27 +477,40 @@ __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
 }
 
 // ------------------------------------------------------------------------------------------------ errors
-__global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache, int guarded) {
-    if (guarded && D.ctl->phase != 1) return;
-    __shared__ double s4[16];
-    const int e = blockIdx.x * 256 + threadIdx.x;
+// robust chi2 of the observations sub, sub + 8, ... of landmark l (lane `sub` of the landmark's group of 8), poses from `poses` (12 doubles
+// each, global or LDS), the landmark at X.  Shared by k_ba_chi2 and the fused trial tail so that both sum in the same order.
+__device__ __forceinline__ double lm_chi2_lane(const BaDev& D, int l, int sub, const double* poses, const double* X, int store_cache) {
     double v = 0.0;
-    if (e < D.E && !D.e_level[e]) {
-        const int p = D.e_pose[e], l = D.e_point[e];
-        const double* T = st_pose(D, use_trial) + (size_t)p * 12;
-        const double* X = st_pt(D, use_trial) + (size_t)l * 3;
+    for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += 8) {
+        if (D.e_level[e]) continue;
+        const int p = D.e_pose[e];
         double r[3];
-        const double chi = edge_error(T, X, D.intr + (size_t)p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
+        const double chi = edge_error(poses + (size_t)p * 12, X, D.intr + (size_t)p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
         if (store_cache) D.e_chi[e] = chi;
         if (D.e_robust[e]) {
             double rho0, rho1;
             huber(chi, (double)D.e_huber[e], &rho0, &rho1);
-            v = rho0;
+            v += rho0;
         }
-        else v = chi;
+        else v += chi;
     }
-    const double t = block_sum_d(v, s4);
-    if (threadIdx.x == 0) D.red[D.red_chi_off + blockIdx.x] = t;
+    return v;
+}
+
+// 8 lanes per landmark (the observations are sorted by landmark), one partial sum per workgroup of 32 landmarks
+__global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache, int guarded) {
+    if (guarded && D.ctl->phase != 1) return;
+    __shared__ double s4[16];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int l = min(t / 8, D.L - 1), sub = t % 8;
+    double v = 0.0;
+    if (t / 8 < D.L) {
+        const double* Xg = st_pt(D, use_trial) + (size_t)l * 3;
+        const double X[3] = {Xg[0], Xg[1], Xg[2]};
+        v = lm_chi2_lane(D, l, sub, st_pose(D, use_trial), X, store_cache);
+    }
+    const double tsum = block_sum_d(v, s4);
+    if (threadIdx.x == 0) D.red[D.red_chi_off + blockIdx.x] = tsum;
 }
 
 // chi2 / depth gate on the cached chi2 (stale for excluded edges, exactly as g2o's cached _error)
@@ -1273,75 +1286,92 @@ __global__ __launch_bounds__(PL_THREADS) void k_ba_pcg_lds(BaDev D, int nent) {
 }
 
 // back-substitution and trial state: blocks [0, nb_lm) = landmarks (8 lanes each), the rest = poses
+// landmark part of the update, lane `sub` of landmark l's group of 8: X = estimate (+) delta (all lanes of the group return it), the trial
+// state stored by lane 0; returns the landmark's share of delta^T (lambda delta + b) on lane 0, 0 elsewhere
+__device__ __forceinline__ double lm_update_lane(const BaDev& D, int l, int sub, bool in_range, double lambda, double* X) {
+    const double* pt_cur = st_pt(D, 0);
+    double* pt_trial = const_cast<double*>(st_pt(D, 1));
+    const bool lfree = in_range && D.pt_free[l];
+    double sc = 0.0;
+    double c[3] = {0.0, 0.0, 0.0};
+    if (lfree)
+        for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
+            if (D.e_level[e]) continue;
+            const int slot = D.pose_slot[D.e_pose[e]];
+            if (slot < 0) continue;
+            const double* Wd = D.W + (size_t)e * 18;
+            const double* xp = D.dp + (size_t)slot * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                c[0] -= Wd[3 * i] * xp[i];
+                c[1] -= Wd[3 * i + 1] * xp[i];
+                c[2] -= Wd[3 * i + 2] * xp[i];
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
+    X[0] = pt_cur[(size_t)l * 3], X[1] = pt_cur[(size_t)l * 3 + 1], X[2] = pt_cur[(size_t)l * 3 + 2];
+    if (lfree) {  // every lane of the group computes the same step (the sums above are identical on all 8 lanes)
+        const double* b = D.bl + (size_t)l * 3;
+        c[0] += b[0];
+        c[1] += b[1];
+        c[2] += b[2];
+        double I[6];
+        if (!lm_dinv(D.Hll + (size_t)l * 6, lambda, I)) D.ctl->solve_failed = 1;  // benign race: every writer stores 1
+        const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
+        const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
+        const double d2 = I[2] * c[0] + I[4] * c[1] + I[5] * c[2];
+        X[0] += d0;
+        X[1] += d1;
+        X[2] += d2;
+        if (sub == 0) sc = d0 * (lambda * d0 + b[0]) + d1 * (lambda * d1 + b[1]) + d2 * (lambda * d2 + b[2]);
+    }
+    if (in_range && sub == 0) {
+        pt_trial[(size_t)l * 3] = X[0];
+        pt_trial[(size_t)l * 3 + 1] = X[1];
+        pt_trial[(size_t)l * 3 + 2] = X[2];
+    }
+    return sc;
+}
+
+// trial state of pose p into O (12 doubles); returns its share of delta^T (lambda delta + b)
+__device__ __forceinline__ double pose_update(const BaDev& D, int p, double lambda, double* O) {
+    const double* T = st_pose(D, 0) + (size_t)p * 12;
+    const int slot = D.pose_slot[p];
+    double sc = 0.0;
+    if (slot < 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) O[k] = T[k];
+    }
+    else {
+        const double* u = D.dp + (size_t)slot * 6;
+        const double* bpv = D.bp_full + (size_t)slot * 6;
+        if (D.scale_pose)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpv[k]);
+        po_exp_mul(u, T, O);
+    }
+    return sc;
+}
+
 __global__ __launch_bounds__(256) void k_ba_update(BaDev D, int nb_lm) {
     if (D.ctl->phase != 1) return;
     __shared__ double s4[16];
     const double lambda = D.ctl->lambda;
     double sc = 0.0;
     if ((int)blockIdx.x < nb_lm) {
-        const double* pt_cur = st_pt(D, 0);
-        double* pt_trial = const_cast<double*>(st_pt(D, 1));
         const int t = blockIdx.x * 256 + threadIdx.x;
-        const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
-        const bool in_range = t / LM_LANES < D.L;
-        const bool lfree = in_range && D.pt_free[l];
-        double c[3] = {0.0, 0.0, 0.0};
-        if (lfree)
-            for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
-                if (D.e_level[e]) continue;
-                const int slot = D.pose_slot[D.e_pose[e]];
-                if (slot < 0) continue;
-                const double* Wd = D.W + (size_t)e * 18;
-                const double* xp = D.dp + (size_t)slot * 6;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    c[0] -= Wd[3 * i] * xp[i];
-                    c[1] -= Wd[3 * i + 1] * xp[i];
-                    c[2] -= Wd[3 * i + 2] * xp[i];
-                }
-            }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
-        if (in_range && sub == 0) {
-            double X[3] = {pt_cur[(size_t)l * 3], pt_cur[(size_t)l * 3 + 1], pt_cur[(size_t)l * 3 + 2]};
-            if (lfree) {
-                const double* b = D.bl + (size_t)l * 3;
-                c[0] += b[0];
-                c[1] += b[1];
-                c[2] += b[2];
-                double I[6];
-                if (!lm_dinv(D.Hll + (size_t)l * 6, lambda, I)) D.ctl->solve_failed = 1;  // benign race: every writer stores 1
-                const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
-                const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
-                const double d2 = I[2] * c[0] + I[4] * c[1] + I[5] * c[2];
-                X[0] += d0;
-                X[1] += d1;
-                X[2] += d2;
-                sc = d0 * (lambda * d0 + b[0]) + d1 * (lambda * d1 + b[1]) + d2 * (lambda * d2 + b[2]);
-            }
-            pt_trial[(size_t)l * 3] = X[0];
-            pt_trial[(size_t)l * 3 + 1] = X[1];
-            pt_trial[(size_t)l * 3 + 2] = X[2];
-        }
+        double X[3];
+        sc = lm_update_lane(D, min(t / LM_LANES, D.L - 1), t % LM_LANES, t / LM_LANES < D.L, lambda, X);
     }
     else {
         const int p = (blockIdx.x - nb_lm) * 256 + threadIdx.x;
         if (p < D.P) {
-            const double* T = st_pose(D, 0) + (size_t)p * 12;
-            double* O = const_cast<double*>(st_pose(D, 1)) + (size_t)p * 12;
-            const int slot = D.pose_slot[p];
-            if (slot < 0) {
+            double O[12];
+            sc = pose_update(D, p, lambda, O);
+            double* Og = const_cast<double*>(st_pose(D, 1)) + (size_t)p * 12;
 #pragma unroll
-                for (int k = 0; k < 12; ++k) O[k] = T[k];
-            }
-            else {
-                const double* u = D.dp + (size_t)slot * 6;
-                const double* bpv = D.bp_full + (size_t)slot * 6;
-                if (D.scale_pose)
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) sc += u[k] * (lambda * u[k] + bpv[k]);
-                po_exp_mul(u, T, O);
-            }
+            for (int k = 0; k < 12; ++k) Og[k] = O[k];
         }
     }
     const double tsum = block_sum_d(sc, s4);
@@ -1437,9 +1467,7 @@ __global__ void k_ba_prepare(BaDev D) {
 
 // end of a damping trial (OptimizationAlgorithmLevenberg::solve, the do { } while (rho < 0 && qmax < 10 && !terminate()) body)
 // and, when the trial closes the LM iteration, the terminate_action hook (optimize/terminate_action.cc:36-76)
-__global__ __launch_bounds__(256) void k_ba_decide(BaDev D) {
-    if (D.ctl->phase != 1) return;
-    __shared__ double sw[16];
+__device__ __forceinline__ void lm_decide(const BaDev& D, double* sw /* 16 doubles */) {
     double temp_chi, scale;
     int failed, stop_now;
     if (D.xsum) {
@@ -1499,6 +1527,15 @@ __global__ __launch_bounds__(256) void k_ba_decide(BaDev D) {
     c.phase = (c.it < c.it_max && !c.stop && c.ok) ? 0 : 2;
 }
 
+__global__ __launch_bounds__(256) void k_ba_decide(BaDev D) {
+    if (D.ctl->phase != 1) return;
+    __shared__ double sw[16];
+    lm_decide(D, sw);
+}
+
+// (Measured and dropped: update + trial chi2 + decision as ONE launch -- every workgroup recomputing the <= 64 trial poses into LDS, a
+// last-arriver running the decision -- takes 20.3 us against 7.5 + 4.8 + 6 us for the three kernels: the chain of dependent global
+// loads inside the fused kernel is the same chain, and a launch boundary costs only ~3 us here.)
 // dense (n + 1) x n image of the block-sparse system for the rocSOLVER path
 __global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
     if (D.ctl->phase != 1) return;
@@ -1660,7 +1697,7 @@ void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded) {
     SvProfScope ps(ctx, s, "ba_chi2");
-    if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3((D.E + 255) / 256), dim3(256), 0, s, D, use_trial, store_cache, guarded);
+    if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D, use_trial, store_cache, guarded);
 }
 
 // the current estimate (the control block says which of the two state buffers holds it) -> one contiguous output block

@@ -311,7 +311,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     }
     // ---- device arena
     const int nPmax = P, nmax = 6 * nPmax;
-    const int nb_chi = (E + 255) / 256, nb_lm = (8 * L + 255) / 256 /* k_ba_update_lm: 8 lanes per landmark */, nb_pose = (P + 255) / 256;
+    const int nb_lm = (8 * L + 255) / 256 /* k_ba_update / k_ba_chi2: 8 lanes per landmark */, nb_chi = nb_lm, nb_pose = (P + 255) / 256;
     const size_t nb_cap = (size_t)P * (P + 1) / 2;
     // worst-case pair storage: sum over landmarks of k(k+1)/2 (+ duplicates never exceed k^2)
     size_t pair_cap = 0;
