@@ -498,6 +498,10 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                     const int col = t * MF_TT + (lane & 31);
                     const uint32_t ta = __float_as_uint(S.rang[col]);
                     const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24) | (256u << 15);
+                    // (Measured, ablation builds: this per-register test costs ~100 of the kernel's 260 us and the hit handling ~60, the
+                    // 16 MFMAs + expansion + fetch ~70.  A branch-free variant -- every lane folds its 32 compares into a bit mask, the
+                    // wave walks the masks lowest bit first and a lane reads "its" register through a 31-select tree -- is exact but
+                    // slower, 343 us: 96 VALU for the masks + ~55 per round x 2-3 rounds against 32 compares + ~10 hit registers here.)
                     // Append the hits of the patch to the wave's queue.  One round unless the patch alone holds more hits than
                     // the queue has room for (adversarial inputs): then the queue is drained and the walk repeated for the rest.
                     for (int off = 0;;) {

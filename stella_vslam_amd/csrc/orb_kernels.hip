@@ -551,22 +551,6 @@ __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
     return max(max((int)best.x - v, v + 1 + (int)best.y), 0);
 }
 
-#ifdef SV_FAST_PROF  // phase clocks of k_fast (tools/fast_phases.py builds with -DSV_FAST_PROF; never in the shipped library)
-__device__ unsigned long long g_fast_prof[8];
-#define FPROF(i)                                                                                  \
-    do {                                                                                          \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                             \
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_fast_prof[i], now_ - prof_t);                   \
-        prof_t = now_;                                                                            \
-    } while (0)
-extern "C" void svgpu_debug_fast_prof(unsigned long long* out8) {
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fast_prof), sizeof(z));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_prof), z, sizeof(z));
-}
-#else
-#define FPROF(i)
-#endif
 #define FAST_KT 12  // selection-grid cells per dimension cached in LDS (a 70-px ROI spans at most ~10 at the coarsest level)
 #define FP 80  // LDS pitch of the ROI arrays: 3 skew bytes + 70, rounded up to whole 16-byte chunks
 __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells,
@@ -582,9 +566,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __shared__ unsigned short s_gx[SV_ROI_MAX], s_gy[SV_ROI_MAX];  // selection-grid column / row of every ROI column / row
     __shared__ int s_count;
     int local, b, ci;
-#ifdef SV_FAST_PROF
-    unsigned long long prof_t = __builtin_amdgcn_s_memtime();
-#endif
     xcd_frame_map(gridDim.x, gridDim.y, ci, b);
     const int lv = find_level(L, num_levels, ci, &OrbLevel::cell_first, &local);
     const OrbLevel lev = L[lv];
@@ -651,7 +632,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     if (tid < w) s_gx[tid] = gtab[lev.gtab_x_off + cell.min_x + tid - SV_PATCH_RADIUS];
     else if (tid >= 128 && tid - 128 < h) s_gy[tid - 128] = gtab[lev.gtab_y_off + cell.min_y + (tid - 128) - SV_PATCH_RADIUS];
     __syncthreads();
-    FPROF(0);
 
     auto load_ring = [&](const uint8_t* c, int (&p)[16]) {
         p[0] = c[3 * FP];
@@ -749,7 +729,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             my_q[pos++] = (unsigned short)(e0 + (((bit & 7) - 4) << 7) + (bit >> 3));
         }
     }
-    FPROF(1);
     // every wave scores and filters ITS quarter of the queue: no index mapping
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the queue entries were written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
@@ -762,9 +741,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         load_ring(c, p);
         s_a[ly * FP + qx] = (uint8_t)arc_score16(c[0], p);
     }
-    FPROF(2);
     __syncthreads();
-    FPROF(3);
 
     // --- per-cell NMS at this pass's threshold
     {
@@ -794,9 +771,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             else atomicMax(&K[gy * lev.grid_x + gx], key);
         }
         if (found) atomicAdd(&s_count, found);
-        FPROF(4);
         __syncthreads();
-        FPROF(5);
         if (s_count > 0) break;
         __syncthreads();
     }
@@ -805,7 +780,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         const unsigned long long key = s_key[tid];
         if (key) atomicMax(&K[(gy0 + tid / FAST_KT) * lev.grid_x + gx0 + tid % FAST_KT], key);
     }
-    FPROF(6);
 }
 
 // ------------------------------------------------------------------------------------------------ select
