@@ -170,7 +170,8 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid(const OrbLevel* __restr
 // trips.  A thread produces 4 adjacent output pixels.  Per source row it reads two 8-byte windows (dword aligned,
 // positions from the packed column-group record built on the host), lifts each (S[sx], S[sx+1]) byte pair into two
 // 16-bit halves with one v_perm_b32 and forms S[sx]*a0 + S[sx+1]*a1 with one v_dot2_u32_u16.
-// LDS map (dynamic): [images of levels >= 1 (the band's rows), pitch = w rounded up to 4][32-byte column-group records]
+// LDS map (dynamic): [rows of the odd levels (one region, reused)][rows of the even levels (one region, reused)], pitch = w rounded up to 4,
+// [32-byte column-group records]
 // [8-byte row records of the band's rows].  The host picks the band count so that this fits (svgpu_orb_configure).
 enum { PYR_SRC_LDS = 0, PYR_SRC_GLOBAL_WORDS = 1, PYR_SRC_GLOBAL_BYTES = 2 };
 template <int SRC>
@@ -225,11 +226,18 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
     const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int2* BR = band_rows + (size_t)band * num_levels;
     if (tid == 0) {
-        int off = 0;
+        // level l is computed from level l - 1 only: two image regions alternate (odd levels in the first, even levels in the second),
+        // each as large as its largest tenant -- about half of what keeping every level costs, which leaves room for a second
+        // workgroup (or for the matcher's workgroups) on the CU
+        int size_a = 0, size_b = 0;
         for (int l = 1; l < num_levels; ++l) {
-            s_img[l] = off;
-            off += (BR[l].y - BR[l].x) * ((L[l].w + 3) & ~3);
+            const int bytes = (BR[l].y - BR[l].x) * ((L[l].w + 3) & ~3);
+            if (l & 1) size_a = max(size_a, bytes);
+            else size_b = max(size_b, bytes);
         }
+        size_a = (size_a + 15) & ~15;
+        for (int l = 1; l < num_levels; ++l) s_img[l] = (l & 1) ? 0 : size_a;
+        int off = size_a + size_b;
         off = (off + 15) & ~15;
         for (int l = 1; l < num_levels; ++l) {
             s_xt[l] = off;

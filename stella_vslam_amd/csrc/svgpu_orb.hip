@@ -289,11 +289,15 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
                 }
             }
             if (need_hi > need_lo) band_rows[(size_t)k * num_levels] = int2{need_lo, need_hi};  // level-0 rows the band reads
-            size_t bytes = 0;  // must mirror the LDS map of k_pyramid_lds
+            size_t size_a = 0, size_b = 0;  // must mirror the LDS map of k_pyramid_lds: odd / even levels alternate in two regions
             for (int l = 1; l < num_levels; ++l) {
                 const int2 r = band_rows[(size_t)k * num_levels + l];
-                bytes += (size_t)(r.y - r.x) * (size_t)((C.levels[l].w + 3) & ~3);
+                const size_t b = (size_t)(r.y - r.x) * (size_t)((C.levels[l].w + 3) & ~3);
+                if (l & 1) size_a = std::max(size_a, b);
+                else size_b = std::max(size_b, b);
             }
+            size_a = (size_a + 15) & ~(size_t)15;
+            size_t bytes = size_a + size_b;
             bytes = (bytes + 15) & ~(size_t)15;
             for (int l = 1; l < num_levels; ++l) {
                 const int2 r = band_rows[(size_t)k * num_levels + l];

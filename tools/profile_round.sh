@@ -9,20 +9,23 @@ R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+exec < /dev/null
 HEAD="--steps 3 --warmup 1 --no-ba --no-cpu-baseline --no-extra"
-rocprofv3 --kernel-trace --stats -d $OUT/ks -o k --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/ks.log
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_f.log
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_w.log
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_gi -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_gi.log
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc_act -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_act.log
-rocprofv3 --kernel-trace --stats -d $OUT/ba_local -o k --output-format csv -- python $R/tools/ba_prof.py local > /dev/null 2> $OUT/ba_local.log
-rocprofv3 --kernel-trace --stats -d $OUT/ba_global -o k --output-format csv -- python $R/tools/ba_prof.py global > /dev/null 2> $OUT/ba_global.log
+# headline legs only: every launch of a front-end / matcher kernel in this trace is a 256-frame launch, so the averages of the stats file
+# are the per-launch durations the bench line quotes
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks -o k --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-ba > $OUT/bench_under_rocprof.json 2> $OUT/ks.log
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_f.log
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_w.log
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_gi -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_gi.log
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc_act -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_act.log
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_local -o k --output-format csv -- python $R/tools/ba_prof.py local > /dev/null 2> $OUT/ba_local.log
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_global -o k --output-format csv -- python $R/tools/ba_prof.py global > /dev/null 2> $OUT/ba_global.log
 cd $R
 python tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w profiles/${TAG}_traffic.json 256 > /dev/null
 python tools/pmc_valu.py $OUT/pmc_gi profiles/${TAG}_valu_issue.json 256 $OUT/pmc_act > /dev/null
 cp profiles/${TAG}_traffic.json profiles/${TAG}_valu_issue.json $OUT/
-python bench.py 2> $OUT/bench.log | tail -1 > $OUT/bench.json
-python tools/ba_bench.py --global > $OUT/ba_bench.log 2>&1
+timeout 400 python bench.py 2> $OUT/bench.log < /dev/null | tail -1 > $OUT/bench.json
+timeout 300 python tools/ba_bench.py --global > $OUT/ba_bench.log 2>&1 < /dev/null
 cp gpurun_out/ba_bench.json $OUT/ba_bench.json 2>/dev/null
 # keep the merge-back small: the raw traces stay on the box, the summaries travel
 rm -f $OUT/ks/*kernel_trace.csv $OUT/ba_local/*kernel_trace.csv $OUT/ba_global/*kernel_trace.csv
