@@ -335,6 +335,9 @@ struct MfShared {
     uint32_t rowmax[MF_QB];          // largest key of a FULL row once it has been scanned (else all-ones): cheap reject of far candidates
     float qa[MF_QB];                 // query angle, or -1000 for rows that must never match (past n2, !valid2)
     uint2 wq[4][MF_WQ];              // (row << 24 | dist << 16 | idx_1, target angle bits)
+#ifdef SV_MF_PAD
+    uint32_t pad[SV_MF_PAD];
+#endif
 };
 // Drain the wave's hit queue into its rows.  Called by all 64 lanes of the wave.
 __device__ __forceinline__ void mf_drain(MfShared& S, int wave, int lane, int n, bool ori) {

@@ -19,13 +19,14 @@ frames_np = synthetic.frame_sequence(B, W, H, seed=0x5EED)
 
 def run(S, prio_first=True):
     Bs = B // S
-    ctxs = [feature.Context(0, priority=1) for _ in range(S)]
+    import os
+    ctxs = [feature.Context(0, priority=int(os.environ.get("EXP_PRIO", "1"))) for _ in range(S)]
     for c in ctxs:
         c.check(L.svgpu_orb_configure(c.handle, W, H, Bs, C.c_float(params.scale_factor_), NL, params.ini_fast_thr_, params.min_fast_thr_, C.c_uint(800)), "cfg")
     cap = L.svgpu_orb_max_keypoints(ctxs[0].handle)
     nc = 1 + NL
     streams = [torch.cuda.ExternalStream(c.stream) for c in ctxs]
-    stream_b = torch.cuda.Stream()
+    stream_b = torch.cuda.Stream(priority=int(os.environ.get("EXP_PRIO_B", "0")))
     frames = torch.from_numpy(frames_np).cuda()
     bufs = [dict(kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
                  counts=torch.zeros(B * nc, dtype=torch.int32, device="cuda"), matched=torch.zeros(B * cap, dtype=torch.int32, device="cuda"),
