@@ -460,10 +460,41 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
     };
     const int thr = 256 - 2 * (int)P.dmax;  // hit <=> 256 - 2 d >= thr; the launcher keeps dmax < 128, so zero columns never hit
     int wq_n = 0;                           // entries in this wave's hit queue (wave-uniform)
+    // One accumulator register of the wave's 64 x 32 patch: rows 32 a + (r & 3) + 8 (r >> 2) + 4 h (C/D map of the 32x32 shapes), one
+    // target per lane.  The hit lanes append (row, dist, original idx_1, target angle) to the wave's queue with ballot ranks; a register
+    // without a hit costs a compare and a wave-uniform skip.  dist << 16 = (256 - dot) << 15 (dot is even), 256 << 15 is folded into ti.
+    auto test_reg = [&](int dot, int a, int r, uint32_t ti, uint32_t ta) {
+        const bool hit = dot >= thr;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            if (wq_n > MF_WQ - 64) {  // a register adds at most one entry per lane
+                mf_drain(S, wave, lane, wq_n, ori);
+                wq_n = 0;
+            }
+            if (hit) {
+                const int pq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t row = (uint32_t)(32 * a + (r & 3) + 8 * (r >> 2)) << 24;
+                S.wq[wave][wq_n + pq] = make_uint2(ti + row - ((uint32_t)dot << 15), ta);
+            }
+            wq_n += __popcll(m);
+        }
+    };
+    // The two 32-query halves of the wave rotate so that no accumulator is read right behind its own MFMAs (ablation builds: the wave
+    // used to spend ~100 of the kernel's 260 us waiting for the 16 MFMAs of a tile before it could test them): while the eight MFMAs of
+    // half 0 of tile t issue, the accumulators of half 1 of the PREVIOUS tile are tested, two registers per MFMA; while those of half 1
+    // issue, half 0 of tile t.  Half 1 stays pending across the barrier with the two words that describe its tile.
+    v16i acc0 = {}, acc1 = {};
+    bool pend1 = false;
+    uint32_t p_ti = 0, p_ta = 0;
     for (int sg = 0; sg < 2; ++sg) {
         const int lo = blo[sg], hi = bhi[sg];
         for (int cbase = lo; cbase < hi; cbase += MF_CH) {
             const int cn = min(MF_CH, hi - cbase), ntiles = (cn + MF_TT - 1) / MF_TT;
+            if (pend1) {  // its tile's angle / index words live in registers, but keep the schedule simple across chunk boundaries
+#pragma unroll
+                for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
+                pend1 = false;
+            }
             __syncthreads();  // every wave is done with the previous chunk
             if (tid < cn) {   // one descriptor per thread: two 16-byte loads, scattered into the transposed layout
                 const uint4 d0 = *reinterpret_cast<const uint4*>(D1 + (size_t)(cbase + tid) * 8);
@@ -487,65 +518,46 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                 const bool mine = wave_live && ((base < whi[0] && tend > wlo[0]) || (base < whi[1] && tend > wlo[1]));
                 if (mine) {
                     const v4i* Bf = reinterpret_cast<const v4i*>(S.b[buf]) + lane;
-                    v16i acc[2] = {};
-                    v4i b = Bf[0];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const v4i bn = Bf[(s < 7 ? s + 1 : 7) * 64];  // next fragment is in flight while the two MFMAs of this one issue
-                        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc[1], 0, 0, 0);
-                        b = bn;
-                    }
-                    // the next tile's +-1 expansion is pure VALU / LDS work: issued here it runs in the shadow of the 16 MFMAs above
-                    if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                     const int col = t * MF_TT + (lane & 31);
                     const uint32_t ta = __float_as_uint(S.rang[col]);
                     const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24) | (256u << 15);
-                    // (Measured, ablation builds: this per-register test costs ~100 of the kernel's 260 us and the hit handling ~60, the
-                    // 16 MFMAs + expansion + fetch ~70.  A branch-free variant -- every lane folds its 32 compares into a bit mask, the
-                    // wave walks the masks lowest bit first and a lane reads "its" register through a 31-select tree -- is exact but
-                    // slower, 343 us: 96 VALU for the masks + ~55 per round x 2-3 rounds against 32 compares + ~10 hit registers here.)
-                    // Append the hits of the patch to the wave's queue.  One round unless the patch alone holds more hits than
-                    // the queue has room for (adversarial inputs): then the queue is drained and the walk repeated for the rest.
-                    for (int off = 0;;) {
-                        const int cap = MF_WQ - wq_n;
-                        int run = 0;
+                    v4i b = Bf[0];
 #pragma unroll
-                        for (int r = 0; r < 32; ++r) {
-                            const int dot = acc[r >> 4][r & 15];
-                            const bool hit = dot >= thr;
-                            const unsigned long long m = __ballot(hit);
-                            if (m) {  // wave-uniform skip for the registers without a hit
-                                if (hit) {
-                                    int dd = dot;
-                                    asm volatile("" : "+v"(dd));  // keeps the key arithmetic of all 32 registers from being hoisted above the skips
-                                    const int pq = run - off + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                                    // row inside the wave: 32 (r >> 4) + (r & 3) + 8 ((r & 15) >> 2) + 4 h (C/D map of the 32x32 shapes);
-                                    // dist << 16 = (256 - dot) << 15 (dot is even), 256 << 15 is folded into ti
-                                    const uint32_t row = (uint32_t)(32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2)) << 24;
-                                    if ((unsigned)pq < (unsigned)cap) S.wq[wave][wq_n + pq] = make_uint2(ti + row - ((uint32_t)dd << 15), ta);
-                                }
-                                run += __popcll(m);
-                            }
+                    for (int s = 0; s < 8; ++s) {  // half 0 of this tile | test of half 1 of the previous one
+                        const v4i bn = Bf[(s < 7 ? s + 1 : 0) * 64];  // next fragment in flight (after the last one: the first of the second pass)
+                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, s == 0 ? v16i{} : acc0, 0, 0, 0);
+                        b = bn;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pend1) {
+                            test_reg(acc1[2 * s], 1, 2 * s, p_ti, p_ta);
+                            test_reg(acc1[2 * s + 1], 1, 2 * s + 1, p_ti, p_ta);
                         }
-                        const int rem = __builtin_amdgcn_readfirstlane(run) - off;  // hits of the patch not stored before this round
-                        if (rem <= cap) {
-                            wq_n += rem;
-                            break;
-                        }
-                        mf_drain(S, wave, lane, MF_WQ, ori);
-                        wq_n = 0;
-                        off += cap;
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (wq_n > MF_WQ - 64) {  // typical patches add a dozen hits: keep room for the next one
-                        mf_drain(S, wave, lane, wq_n, ori);
-                        wq_n = 0;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {  // half 1 of this tile | test of half 0 of this tile
+                        const v4i bn = Bf[(s < 7 ? s + 1 : 7) * 64];
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, s == 0 ? v16i{} : acc1, 0, 0, 0);
+                        b = bn;
+                        __builtin_amdgcn_sched_barrier(0);
+                        test_reg(acc0[2 * s], 0, 2 * s, ti, ta);
+                        test_reg(acc0[2 * s + 1], 0, 2 * s + 1, ti, ta);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                    pend1 = true;
+                    p_ti = ti;
+                    p_ta = ta;
+                    // the next tile's +-1 expansion is pure VALU / LDS work: it runs in the shadow of the last MFMAs
+                    if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                 }
                 else if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                 __syncthreads();
             }
         }
+    }
+    if (pend1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
     }
     mf_drain(S, wave, lane, wq_n, ori);
     __syncthreads();
