@@ -913,7 +913,9 @@ __device__ __forceinline__ int wave_sum(int v) {
 // (A three-phase variant that computes the angle / cos / sin of 64 keypoints lane-parallel issues half the instructions
 // per keypoint but measured slower, 121-136 us against 109: the longer per-wave chains of dependent patch fetches cost
 // more than the saved issue slots.)
-#define DESC_KPW 4
+#ifndef DESC_KPW
+#define DESC_KPW 4  // keypoints per wave (3 / 2: 67 / 57 VGPRs and 18 / 12 KB of LDS, i.e. more waves per SIMD -- measured: no change, the kernel is not occupancy-limited)
+#endif
 #define DESC_IP 32                     // LDS row pitch of the 31 x 31 patch (8 dwords)
 #define DESC_BP 40                     // LDS row pitch of the 37 x 37 patch
 #define DESC_R 18                      // largest |rounded rotated pattern coordinate| (pattern radius 18.38)
