@@ -486,6 +486,7 @@ def bench_global_ba(device, rank, world):
     return {"metric": "global-BA LM iterations/s @500 KF / 200k landmarks / %d obs" % len(sc["obs_pose"]), "value": round(iters / dt, 2), "unit": "iters/s",
             "ms_per_call": round(dt / reps * 1e3, 2), "iters_per_call": iters / reps, "dtype": "f64", "n_gpus": world,
             "sharding": "none" if world == 1 else "observations by landmark (l % N), all-reduce of the kept Schur blocks per damping trial over RCCL",
+            "linear_solver": "block envelope Cholesky of the reduced camera system (direct)" if res["stats"]["pcg_iterations"] == 0 else "block-Jacobi PCG",
             "pcg_iterations_per_call": res["stats"]["pcg_iterations"], "chi2_final": res["stats"]["chi2_final"],
             "roofline": ba_roofline(sc, iters, dt, free)}
 

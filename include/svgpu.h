@@ -487,6 +487,8 @@ typedef struct svgpu_ba_stats {
  *             its LDS) while the kept 6x6 blocks fit ~150 KB and 6 * free poses <= 512, else one kernel launch per iteration
  *   CHOLESKY  the LDS LL^T (larger systems fall back to PCG)
  *   DENSE     dense image + rocSOLVER dpotrf / dpotrs (loaded on first use)
+ *   ENVELOPE  direct block envelope (skyline) LL^T after a reverse Cuthill-McKee ordering of the keyframe graph -- what AUTO takes beyond
+ *             the on-chip solvers while the envelope stays under 256 MB (the reference factors this system with a sparse Cholesky)
  * pcg_tolerance: relative residual |r| / |g| (<= 0: 1e-10); pcg_max_iterations <= 0: max(2000, 4 n).  A solve that hits the
  * cap is taken as an inexact step when the residual fell below 1e-6, else the damping trial counts as a solver failure. */
 typedef enum svgpu_ba_solver {
@@ -494,7 +496,8 @@ typedef enum svgpu_ba_solver {
     SVGPU_BA_SOLVER_CHOLESKY = 1,
     SVGPU_BA_SOLVER_PCG = 2,
     SVGPU_BA_SOLVER_DENSE = 3,
-    SVGPU_BA_SOLVER_PCG_MULTI = 4 /* PCG with one kernel launch per iteration even when the system would fit one workgroup's LDS */
+    SVGPU_BA_SOLVER_PCG_MULTI = 4, /* PCG with one kernel launch per iteration even when the system would fit one workgroup's LDS */
+    SVGPU_BA_SOLVER_ENVELOPE = 6   /* block envelope Cholesky at any size (falls back to the PCG when the envelope of the ordered block graph exceeds 256 MB) */
 } svgpu_ba_solver;
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations);
 

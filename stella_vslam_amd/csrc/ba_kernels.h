@@ -130,4 +130,12 @@ void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);               
 // block-Jacobi PCG on the block-sparse reduced camera system (ba_pcg.hip)
 void sv_pcg_init(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
 void sv_pcg_iterate(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int first_it, int count);
-enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, SV_BA_SOLVER_DENSE = 3, SV_BA_SOLVER_PCG_MULTI = 4, SV_BA_SOLVER_PCG_LDS = 5 /* internal */ };
+enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, SV_BA_SOLVER_DENSE = 3, SV_BA_SOLVER_PCG_MULTI = 4, SV_BA_SOLVER_PCG_LDS = 5 /* internal */,
+       SV_BA_SOLVER_ENVELOPE = 6 };
+// block envelope Cholesky of large reduced systems (ba_skyline.hip)
+#ifdef __cplusplus
+#include <vector>
+int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable);
+#endif
+void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
+void sv_sky_release(svgpu_ctx* ctx);

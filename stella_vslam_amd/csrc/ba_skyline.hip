@@ -1,0 +1,566 @@
+// Direct solve of large reduced camera systems: block envelope ("skyline") Cholesky on the device.
+//
+// The reference factors the reduced system of global BA with a sparse Cholesky (g2o LinearSolverCSparse / Eigen,
+// optimize/global_bundle_adjuster.cc:26-40); the oracle restates it as an envelope Cholesky.  This is the same method on the GPU,
+// for systems beyond the on-chip dense solver: keyframe graphs are banded up to a few loop-closure rows once ordered (reverse
+// Cuthill-McKee on the host), so the lower envelope of the 6x6 block matrix holds the whole fill -- config 5 (500 keyframes, a closed
+// ring): a few MB, L2 resident.  One workgroup walks the block columns (right-looking LL^T):
+//   pivot      L_jj = chol(D_jj), its inverse kept                      (one wave, lanes = rows)
+//   column     L_ij = S_ij L_jj^-T for the rows i of column j            (one thread per entry, staged in LDS)
+//   update     S_ik -= L_ij L_kj^T for all pairs of rows i >= k of j     (one thread per block pair, operands from LDS)
+// then the forward / backward substitutions over the same column lists.  Every sum has a fixed order: bit-reproducible.
+// A pivot that is not positive marks the damping trial as a solver failure, as g2o's solver returning false does.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "svgpu_internal.h"
+
+#include "ba_kernels.h"
+
+namespace {
+#define SKY_THREADS 1024
+#define SKY_MAXM 200  // rows below the diagonal of one column whose blocks are staged in LDS (200 x 288 B = 56 KB)
+
+struct SkyDev {
+    int nP = 0, NB = 0;
+    const int* pos = nullptr;       // slot -> position in the elimination order
+    const int* first = nullptr;     // position i -> first block column of row i's envelope
+    const int* rowoff = nullptr;    // position i -> index of block (i, first[i]); nP + 1 entries
+    const int* coloff = nullptr;    // position j -> start of its row list; nP + 1 entries
+    const int* colrows = nullptr;   // rows i > j with first[i] <= j, ascending
+    const int* colbase = nullptr;   // beside colrows: rowoff[i] - first[i] (block (i, k) of the envelope = base + k)
+    const int* diag = nullptr;      // position j -> index of block (j, j)
+    int max_m = 0;                  // widest column (rows below the diagonal)
+    int ncr = 0;                    // entries of colrows / colbase
+    const int2* blkmap = nullptr;   // kept block k of the reduced system -> (envelope block index, 1 = store transposed)
+    double* val = nullptr;          // envelope blocks, 36 doubles each, row-major
+    double* dinv = nullptr;         // nP x 36: inverses of the diagonal factors (lower triangular)
+    double* y = nullptr;            // n: right-hand side / solution in elimination order
+    size_t nblocks = 0;
+};
+
+__global__ __launch_bounds__(256) void k_sky_assemble(BaDev D, SkyDev K) {
+    if (D.ctl->phase != 1) return;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < (size_t)K.NB * 36) {
+        const int k = (int)(t / 36), e = (int)(t - (size_t)k * 36), i = e / 6, j = e - 6 * i;
+        const int2 m = K.blkmap[k];
+        K.val[(size_t)m.x * 36 + (m.y ? j * 6 + i : e)] = D.Sblk[t];
+    }
+    if (t < (size_t)D.n) {
+        const int a = (int)(t / 6), c = (int)(t - (size_t)a * 6);
+        K.y[K.pos[a] * 6 + c] = D.g[t];
+    }
+}
+
+// x in [0, m (m + 1) / 2) -> (p, q) with q <= p < m, row-major over the lower triangle
+__device__ __forceinline__ void tri_index(int x, int& p, int& q) {
+    p = (int)((sqrtf(8.0f * (float)x + 1.0f) - 1.0f) * 0.5f);
+    while ((p + 1) * (p + 2) / 2 <= x) ++p;
+    while (p * (p + 1) / 2 > x) --p;
+    q = x - p * (p + 1) / 2;
+}
+__device__ __forceinline__ double lane_bcast(double v, int src) {  // v of lane `src` (a constant) as a wave-uniform value
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Ordering of LDS accesses between the lanes of ONE wave: the LDS unit executes a wave's DS instructions in issue order, so only the
+// compiler has to be kept from moving them; unlike a fence this leaves the prefetched global loads in flight.
+__device__ __forceinline__ void wave_lds_order() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// One workgroup (256 threads while no column has more than 21 rows, else 1024).  What a column costs is a chain of dependent memory
+// round trips, so the chain is kept short: the index arrays live in LDS, every block of a column is addressed through one index
+// (base[i] = rowoff[i] - first[i], block (i, k) = base[i] + k), the 6 x 6 pivot lives in the registers of one wave (rows on lanes,
+// entries exchanged with readlane, one rsqrt per pivot and no division; the inverse factor falls out of the same registers, column c on
+// lane c), and the two substitutions run on the first wave alone with the right-hand side in LDS and the factor rows of the NEXT column
+// already in flight while a column is processed (no workgroup barrier).
+// Measured at config 5 (499 block rows, 5 527 envelope blocks, widest column 11 rows): 3.2 ms per solve -- pivot + column 1.3, update 0.9,
+// substitutions 1.0 -- i.e. ~6 us per column, every phase a global-memory round trip through L2 (~1 us each seen from one wave); the
+// block-Jacobi PCG it replaces as the default took 3.4 ms per solve (~480 iterations) and up to 4 000 iterations when lambda is small.
+// Next: the trailing window of a banded envelope kept in LDS.
+__global__ __launch_bounds__(SKY_THREADS) void k_sky_factor_solve(BaDev D, SkyDev K) {
+    if (D.ctl->phase != 1) return;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [max_m x 36: the scaled column][n: right-hand side][index arrays]
+    __shared__ double s_Li[36];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP;
+    double* const s_col = s_dyn;
+    double* const s_y = s_dyn + (size_t)K.max_m * 36;
+    int* const s_coloff = reinterpret_cast<int*>(s_y + D.n);
+    int* const s_diag = s_coloff + (nP + 1);
+    int* const s_rows = s_diag + nP;
+    int* const s_base = s_rows + K.ncr;
+    if (tid == 0) s_fail = 0;
+    for (int t = tid; t < D.n; t += nt) s_y[t] = K.y[t];
+    for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
+    for (int t = tid; t < nP; t += nt) s_diag[t] = K.diag[t];
+    for (int t = tid; t < K.ncr; t += nt) {
+        s_rows[t] = K.colrows[t];
+        s_base[t] = K.colbase[t];
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- factorisation
+    for (int j = 0; j < nP; ++j) {
+        const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+        const int* rows = s_rows + c0;
+        const int* base = s_base + c0;
+        if (tid < 64) {
+            const int r = min(tid, 5);
+            double* Dj = K.val + (size_t)s_diag[j] * 36;
+            double a[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a[c] = Dj[r * 6 + c];  // lane r < 6: row r (lanes >= 6 mirror row 5 and write nothing)
+            double Lm[6][6], rd[6];  // the finished factor and its reciprocal diagonal, wave-uniform
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double v = a[c];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < c) v -= a[k] * Lm[c][k];  // a[k] = L[r][k] by now
+                const double dcc = lane_bcast(v, c);
+                bad = bad || !(dcc > 0.0);
+                const double rs = rsqrt(dcc);
+                rd[c] = rs;
+                a[c] = v * rs;  // L[r][c]; on lane c: dcc / sqrt(dcc)
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) Lm[rr][c] = rr >= c ? lane_bcast(a[c], rr) : 0.0;
+            }
+            if (bad && tid == 0) s_fail = 1;
+            // column c of L^-1 on lane c: x_c = 1 / L_cc, x_r = -(sum_{k = c}^{r - 1} L_rk x_k) / L_rr
+            const int cc = min(tid, 5);
+            double x[6];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) {
+                double v = rr == cc ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < rr) v -= (k >= cc ? Lm[rr][k] * x[k] : 0.0);
+                x[rr] = rr >= cc ? v * rd[rr] : 0.0;
+            }
+            if (tid < 6) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) Dj[tid * 6 + c] = c <= tid ? a[c] : 0.0;
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    s_Li[rr * 6 + tid] = x[rr];
+                    K.dinv[(size_t)j * 36 + rr * 6 + tid] = x[rr];
+                }
+            }
+        }
+        __syncthreads();
+        if (s_fail) break;
+        // column: L_ij = S_ij L_jj^-T, entry (a, b) = sum_{c <= b} S_ij[a][c] Li[b][c]; staged in LDS (the reads of the old block finish first)
+        for (int t = tid; t < m * 36; t += nt) {
+            const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
+            const double* Bl = K.val + (size_t)(base[r] + j) * 36 + a * 6;
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
+            s_col[t] = v;
+        }
+        __syncthreads();
+        for (int t = tid; t < m * 36; t += nt) {
+            const int r = t / 36, e = t - r * 36;
+            K.val[(size_t)(base[r] + j) * 36 + e] = s_col[t];
+        }
+        // update: one thread per pair of rows (p, q), q <= p: S_{ip, iq} -= L_p L_q^T
+        const int npair = m * (m + 1) / 2;
+        for (int x = tid; x < npair; x += nt) {
+            int p, q;
+            tri_index(x, p, q);
+            double Lq[36];
+#pragma unroll
+            for (int e = 0; e < 36; ++e) Lq[e] = s_col[q * 36 + e];
+            double* Dst = K.val + (size_t)(base[p] + rows[q]) * 36;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double La[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    double v = La[0] * Lq[b * 6];
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) v += La[c] * Lq[b * 6 + c];
+                    Dst[a * 6 + b] -= v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (s_fail) {
+        if (tid == 0) D.ctl->solve_failed = 1;
+        for (int t = tid; t < D.n; t += nt) D.dp[t] = 0.0;
+        return;
+    }
+    // ---------------------------------------------------------------- L z = g (column oriented), then L^T x = z: the first wave alone
+    if (tid < 64) {
+        const int lane = tid;
+        const bool pre = K.max_m * 6 <= 128;  // a lane owns at most two (row, component) items of a column: their factor rows are prefetched
+        // forward.  Lane rr < 6 holds row rr of Li_j, item k of a lane = (row (lane + 64 k) / 6 of the column, component (lane + 64 k) % 6)
+        auto fwd_load = [&](int j, double (&li)[6], double (&bl)[2][6], int (&dst)[2]) {
+            if (j >= nP) return;
+            const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+            const int rr = min(lane, 5);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) li[c] = K.dinv[(size_t)j * 36 + rr * 6 + c];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = lane + 64 * k;
+                dst[k] = -1;
+                if (t < m * 6) {
+                    const int r = t / 6, a = t - 6 * r;
+                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36 + a * 6;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) bl[k][c] = Bl[c];
+                    dst[k] = s_rows[c0 + r] * 6 + a;
+                }
+            }
+        };
+        double li[6], bl[2][6], li_n[6], bl_n[2][6];
+        int dst[2], dst_n[2];
+        if (pre) fwd_load(0, li, bl, dst);
+        for (int j = 0; j < nP; ++j) {
+            if (pre) fwd_load(j + 1, li_n, bl_n, dst_n);
+            else fwd_load(j, li, bl, dst);
+            double v = 0.0;  // z[rr] on lane rr < 6
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (c <= min(lane, 5)) v += li[c] * s_y[j * 6 + c];
+            double z[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) z[c] = lane_bcast(v, c);
+            wave_lds_order();  // every lane has read y_j
+            if (lane < 6) s_y[j * 6 + lane] = v;
+            if (pre) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (dst[k] >= 0) {
+                        double u = bl[k][0] * z[0];
+#pragma unroll
+                        for (int c = 1; c < 6; ++c) u += bl[k][c] * z[c];
+                        s_y[dst[k]] -= u;
+                    }
+            }
+            else {
+                const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+                for (int t = lane; t < m * 6; t += 64) {
+                    const int r = t / 6, a = t - 6 * r;
+                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36 + a * 6;
+                    double u = Bl[0] * z[0];
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) u += Bl[c] * z[c];
+                    s_y[s_rows[c0 + r] * 6 + a] -= u;
+                }
+            }
+            wave_lds_order();
+            if (pre) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    li[c] = li_n[c];
+                    bl[0][c] = bl_n[0][c];
+                    bl[1][c] = bl_n[1][c];
+                }
+                dst[0] = dst_n[0];
+                dst[1] = dst_n[1];
+            }
+        }
+        // backward.  w = z_j - sum_{i in rows(j)} L_ij^T x_i: 6 components x 10 parts on 60 lanes (lane = part * 6 + component), combined in
+        // a fixed order; a lane's up to two rows (m <= 20) have their factor column prefetched.
+        const int a = lane % 6, part = lane / 6;
+        auto bwd_load = [&](int j, double (&lc)[6], double (&bc)[2][6], int (&src)[2]) {
+            if (j < 0) return;
+            const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+            const int ac = min(lane, 5);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) lc[c] = K.dinv[(size_t)j * 36 + c * 6 + ac];  // column `lane` of Li_j
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = part + 10 * k;
+                src[k] = -1;
+                if (part < 10 && r < m) {
+                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) bc[k][c] = Bl[c * 6 + a];
+                    src[k] = s_rows[c0 + r] * 6;
+                }
+            }
+        };
+        const bool preb = K.max_m <= 20;
+        double lc[6], bc[2][6], lc_n[6], bc_n[2][6];
+        int src[2], src_n[2];
+        if (preb) bwd_load(nP - 1, lc, bc, src);
+        for (int j = nP - 1; j >= 0; --j) {
+            double v = 0.0;
+            if (preb) {
+                bwd_load(j - 1, lc_n, bc_n, src_n);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (src[k] >= 0)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) v += bc[k][c] * s_y[src[k] + c];
+            }
+            else {
+                const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+                const int ac = min(lane, 5);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) lc[c] = K.dinv[(size_t)j * 36 + c * 6 + ac];
+                if (part < 10)
+                    for (int r = part; r < m; r += 10) {
+                        const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36;
+                        const double* xi = s_y + s_rows[c0 + r] * 6;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) v += Bl[c * 6 + a] * xi[c];
+                    }
+            }
+            double w[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double tot = 0.0;
+#pragma unroll
+                for (int pp = 0; pp < 10; ++pp) tot += lane_bcast(v, pp * 6 + c);
+                w[c] = s_y[j * 6 + c] - tot;
+            }
+            wave_lds_order();
+            if (lane < 6) {  // x_j = Li_j^T w: component a = sum_{c >= a} Li[c][a] w[c]
+                double x = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    if (c >= lane) x += lc[c] * w[c];
+                s_y[j * 6 + lane] = x;
+            }
+            wave_lds_order();
+            if (preb) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    lc[c] = lc_n[c];
+                    bc[0][c] = bc_n[0][c];
+                    bc[1][c] = bc_n[1][c];
+                }
+                src[0] = src_n[0];
+                src[1] = src_n[1];
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < D.n; t += nt) {
+        const int a = t / 6, c = t - 6 * a;
+        D.dp[t] = s_y[K.pos[a] * 6 + c];
+    }
+}
+
+struct SkyPlan {
+    SkyDev dev;
+    void* d_int = nullptr;
+    size_t int_bytes = 0;
+    void* d_val = nullptr;
+    size_t val_bytes = 0;
+    bool usable = false;
+    int max_m = 0;
+};
+
+// reverse Cuthill-McKee over the block graph (every component from a minimum-degree node of a far BFS level)
+std::vector<int> rcm_order(int n, const std::vector<std::vector<int>>& adj) {
+    std::vector<int> order;
+    order.reserve(n);
+    std::vector<char> seen(n, 0);
+    std::vector<int> level(n);
+    auto bfs = [&](int start, std::vector<int>& out) {
+        out.clear();
+        out.push_back(start);
+        level[start] = 0;
+        std::vector<char> mark(n, 0);
+        mark[start] = 1;
+        for (size_t h = 0; h < out.size(); ++h) {
+            const int u = out[h];
+            std::vector<int> nb;
+            for (int v : adj[u])
+                if (!mark[v] && !seen[v]) nb.push_back(v);
+            std::sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b; });
+            for (int v : nb) {
+                mark[v] = 1;
+                level[v] = level[u] + 1;
+                out.push_back(v);
+            }
+        }
+    };
+    std::vector<int> comp;
+    for (int s0 = 0; s0 < n; ++s0) {
+        if (seen[s0]) continue;
+        int start = s0;
+        bfs(start, comp);
+        for (int rep = 0; rep < 2; ++rep) {  // pseudo-peripheral node: restart from a minimum-degree node of the last level
+            int far = comp.back();
+            for (int v : comp)
+                if (level[v] == level[comp.back()] && adj[v].size() < adj[far].size()) far = v;
+            if (far == start) break;
+            start = far;
+            bfs(start, comp);
+        }
+        for (int v : comp) {
+            seen[v] = 1;
+            order.push_back(v);
+        }
+    }
+    std::reverse(order.begin(), order.end());
+    return order;
+}
+}  // namespace
+
+void sv_sky_release(svgpu_ctx* ctx) {
+    SkyPlan* P = (SkyPlan*)ctx->ba_sky;
+    if (!P) return;
+    if (P->d_int) (void)hipFree(P->d_int);
+    if (P->d_val) (void)hipFree(P->d_val);
+    delete P;
+    ctx->ba_sky = nullptr;
+}
+
+// Plans the envelope factorisation of the reduced system whose kept upper blocks are blk_ab (a <= b, free-pose slots).  *usable = false
+// (and nothing else changes) when the envelope would exceed max_bytes or a column has more than SKY_MAXM rows: the caller keeps the PCG.
+int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable) {
+    *usable = false;
+    if (nP <= 0) return SVGPU_OK;
+    std::vector<std::vector<int>> adj(nP);
+    for (const int2& ab : blk_ab)
+        if (ab.x != ab.y) {
+            adj[ab.x].push_back(ab.y);
+            adj[ab.y].push_back(ab.x);
+        }
+    const std::vector<int> order = rcm_order(nP, adj);  // position -> slot
+    std::vector<int> pos(nP), first(nP), rowoff(nP + 1);
+    for (int i = 0; i < nP; ++i) pos[order[i]] = i;
+    for (int i = 0; i < nP; ++i) {
+        int f = i;
+        for (int v : adj[order[i]]) f = std::min(f, pos[v]);
+        first[i] = f;
+    }
+    size_t nblocks = 0;
+    for (int i = 0; i < nP; ++i) {
+        rowoff[i] = (int)nblocks;
+        nblocks += (size_t)(i - first[i] + 1);
+        if (nblocks * 288 > max_bytes || nblocks > (size_t)1 << 30) return SVGPU_OK;
+    }
+    rowoff[nP] = (int)nblocks;
+    std::vector<int> coloff(nP + 1, 0);
+    for (int i = 0; i < nP; ++i)
+        for (int j = first[i]; j < i; ++j) coloff[j + 1]++;
+    int max_m = 0;
+    for (int j = 0; j < nP; ++j) {
+        max_m = std::max(max_m, coloff[j + 1]);
+        coloff[j + 1] += coloff[j];
+    }
+    if (max_m > SKY_MAXM) return SVGPU_OK;
+    std::vector<int> colrows(coloff[nP]), colbase(coloff[nP]), diag(nP), fill(coloff.begin(), coloff.end() - 1);
+    for (int i = 0; i < nP; ++i) {  // rows ascending
+        diag[i] = rowoff[i] + i - first[i];
+        for (int j = first[i]; j < i; ++j) {
+            colbase[fill[j]] = rowoff[i] - first[i];
+            colrows[fill[j]++] = i;
+        }
+    }
+    // scaled column + right-hand side + index arrays must fit the LDS
+    if ((size_t)max_m * 288 + (size_t)nP * 48 + 4 * ((size_t)2 * nP + 1 + 2 * colrows.size()) > 150 * 1024) return SVGPU_OK;
+    std::vector<int2> blkmap(blk_ab.size());
+    for (size_t k = 0; k < blk_ab.size(); ++k) {
+        const int pa = pos[blk_ab[k].x], pb = pos[blk_ab[k].y];
+        const int row = std::max(pa, pb), col = std::min(pa, pb);
+        int2 m;
+        m.x = rowoff[row] + col - first[row];
+        m.y = pa > pb || pa == pb ? 0 : 1;  // the kept block is S_ab; the envelope stores S_{row, col}: transposed when row = pos[b]
+        blkmap[k] = m;
+    }
+    SkyPlan* P = (SkyPlan*)ctx->ba_sky;
+    if (!P) {
+        P = new SkyPlan();
+        ctx->ba_sky = P;
+    }
+    // one integer arena: pos | first | rowoff | coloff | colrows | blkmap
+    const size_t n_int = (size_t)nP * 3 + (size_t)(nP + 1) * 2 + 2 * colrows.size() + blkmap.size() * 2 + 8;
+    if (n_int * 4 > P->int_bytes) {
+        if (P->d_int) {
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            SV_HIP(ctx, hipFree(P->d_int));
+            P->d_int = nullptr;
+            P->int_bytes = 0;
+        }
+        SV_HIP(ctx, hipMalloc(&P->d_int, n_int * 4 + n_int));
+        P->int_bytes = n_int * 4 + n_int;
+    }
+    const size_t val_need = (nblocks * 36 + (size_t)nP * 36 + (size_t)nP * 6 + 8) * sizeof(double);
+    if (val_need > P->val_bytes) {
+        if (P->d_val) {
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            SV_HIP(ctx, hipFree(P->d_val));
+            P->d_val = nullptr;
+            P->val_bytes = 0;
+        }
+        SV_HIP(ctx, hipMalloc(&P->d_val, val_need + val_need / 4));
+        P->val_bytes = val_need + val_need / 4;
+    }
+    std::vector<int> host;
+    host.reserve(n_int);
+    auto put = [&](const int* p, size_t n) {
+        const size_t at = host.size();
+        host.insert(host.end(), p, p + n);
+        return at;
+    };
+    const size_t o_pos = put(pos.data(), nP), o_first = put(first.data(), nP), o_rowoff = put(rowoff.data(), nP + 1), o_coloff = put(coloff.data(), nP + 1);
+    const size_t o_colrows = put(colrows.data(), colrows.size()), o_colbase = put(colbase.data(), colbase.size()), o_diag = put(diag.data(), nP);
+    if (host.size() & 1) host.push_back(0);  // int2 alignment
+    const size_t o_blkmap = put(reinterpret_cast<const int*>(blkmap.data()), blkmap.size() * 2);
+    SV_HIP(ctx, hipMemcpyAsync(P->d_int, host.data(), host.size() * 4, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));  // `host` is a pageable temporary
+    int* di = (int*)P->d_int;
+    SkyDev& K = P->dev;
+    K.nP = nP;
+    K.NB = (int)blk_ab.size();
+    K.pos = di + o_pos;
+    K.first = di + o_first;
+    K.rowoff = di + o_rowoff;
+    K.coloff = di + o_coloff;
+    K.colrows = di + o_colrows;
+    K.colbase = di + o_colbase;
+    K.diag = di + o_diag;
+    K.max_m = max_m;
+    K.ncr = (int)colrows.size();
+    K.blkmap = reinterpret_cast<const int2*>(di + o_blkmap);
+    K.val = (double*)P->d_val;
+    K.dinv = K.val + nblocks * 36;
+    K.y = K.dinv + (size_t)nP * 36;
+    K.nblocks = nblocks;
+    P->max_m = max_m;
+    P->usable = true;
+    *usable = true;
+    if (std::getenv("SVGPU_BA_TRACE"))
+        std::fprintf(stderr, "[ba]     envelope plan: %d block rows, %zu blocks (%.1f MB), widest column %d rows\n", nP, nblocks, nblocks * 288.0 / 1048576.0, max_m);
+    return SVGPU_OK;
+}
+
+void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+    SkyPlan* P = (SkyPlan*)ctx->ba_sky;
+    SvProfScope ps(ctx, s, "ba_solve");
+    const SkyDev& K = P->dev;
+    // blocks of the envelope the reduced system does not fill must start at zero in every trial
+    (void)hipMemsetAsync(K.val, 0, K.nblocks * 36 * sizeof(double), s);
+    const size_t items = std::max((size_t)K.NB * 36, (size_t)D.n);
+    hipLaunchKernelGGL(k_sky_assemble, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, D, K);
+    const size_t lds = ((size_t)P->max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)2 * K.nP + 1 + 2 * (size_t)K.ncr);
+    (void)sv_allow_dynamic_lds((const void*)k_sky_factor_solve, lds);
+    hipLaunchKernelGGL(k_sky_factor_solve, dim3(1), dim3(P->max_m <= 21 ? 256 : SKY_THREADS), lds, s, D, K);
+}

@@ -42,6 +42,7 @@ struct HostStructure {
     std::vector<uint8_t> pt_free;
     std::vector<int> blk_off;
     std::vector<int2> blk_ab;
+    bool envelope_ok = false;  // the envelope Cholesky has a plan for this block pattern
     size_t num_pairs = 0;  // the pairs themselves live on the device only
     int nP = 0, nL = 0;
 };
@@ -308,6 +309,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         else if (!strcmp(ev, "pcg")) solver_opt = SV_BA_SOLVER_PCG;
         else if (!strcmp(ev, "dense")) solver_opt = SV_BA_SOLVER_DENSE;
         else if (!strcmp(ev, "pcg_multi")) solver_opt = SV_BA_SOLVER_PCG_MULTI;
+        else if (!strcmp(ev, "envelope")) solver_opt = SV_BA_SOLVER_ENVELOPE;
     }
     // ---- device arena
     const int nPmax = P, nmax = 6 * nPmax;
@@ -652,6 +654,17 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         // LDS-resident PCG up to 512 unknowns / ~150 KB of blocks, the one-launch-per-iteration PCG beyond
         if (solver == SV_BA_SOLVER_AUTO && D.chol_in_lds) solver = SV_BA_SOLVER_CHOLESKY;
         if (solver == SV_BA_SOLVER_CHOLESKY && !D.chol_in_lds) solver = SV_BA_SOLVER_AUTO;
+        // beyond the on-chip solvers: the direct envelope factorisation while the envelope of the ordered block graph is small (keyframe
+        // graphs are banded up to a few loop-closure rows), else -- or on request -- the PCG with one launch per iteration
+        if ((solver == SV_BA_SOLVER_AUTO && !lds_ok) || solver == SV_BA_SOLVER_ENVELOPE) {
+            if (!reuse) {
+                bool ok = false;
+                const int rs = sv_sky_plan(ctx, s, HS.nP, HS.blk_ab, (size_t)256 << 20, &ok);
+                if (rs) return rs;
+                HS.envelope_ok = ok;
+            }
+            solver = HS.envelope_ok ? SV_BA_SOLVER_ENVELOPE : SV_BA_SOLVER_AUTO;
+        }
         if (solver == SV_BA_SOLVER_AUTO || solver == SV_BA_SOLVER_PCG) solver = lds_ok ? SV_BA_SOLVER_PCG_LDS : SV_BA_SOLVER_PCG_MULTI;
         if (sv_ba_lin_split() > 16 || sv_ba_rhs_split() > 16) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: partial-sum buffers too small for the kernel splits");
         if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks, n = %d, solver %d)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size(), D.n, solver);
@@ -691,6 +704,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             if (solver == SV_BA_SOLVER_CHOLESKY) sv_ba_solve(ctx, s, D);
             else if (solver == SV_BA_SOLVER_PCG_LDS) sv_ba_solve_pcg_lds(ctx, s, D);
             else if (solver == SV_BA_SOLVER_DENSE) sv_ba_solve_dense(ctx, s, D);
+            else if (solver == SV_BA_SOLVER_ENVELOPE) sv_sky_solve(ctx, s, D);
             else {
                 // PCG: iterations are enqueued in chunks; the control block says when the solve (or the whole optimisation) is over
                 sv_pcg_init(ctx, s, D);
@@ -958,7 +972,7 @@ int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int r
 }
 
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations) {
-    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || solver > SVGPU_BA_SOLVER_PCG_MULTI) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
+    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || (solver > SVGPU_BA_SOLVER_PCG_MULTI && solver != SVGPU_BA_SOLVER_ENVELOPE)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
     ctx->ba_solver = solver;
     ctx->pcg_tol = pcg_tolerance > 0 ? pcg_tolerance : 1e-10;
     ctx->pcg_max_it = pcg_max_iterations > 0 ? pcg_max_iterations : 0;

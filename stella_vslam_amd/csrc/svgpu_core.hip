@@ -159,6 +159,7 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     sv_comm_release(ctx);
+    sv_sky_release(ctx);
     if (ctx->ev_ba) (void)hipEventDestroy(ctx->ev_ba);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

@@ -112,6 +112,7 @@ struct svgpu_ctx {
     double pcg_tol = 1e-10;         // relative residual of the reduced-system PCG
     int pcg_max_it = 0;             // 0 = max(2000, 4 n)
     void* comm = nullptr;           // ncclComm_t of svgpu_comm_init (RCCL, loaded with dlopen)
+    void* ba_sky = nullptr;         // plan + buffers of the envelope Cholesky (ba_skyline.hip)
     int comm_rank = 0, comm_world = 1;
 };
 void sv_comm_release(svgpu_ctx* ctx);
@@ -131,6 +132,7 @@ struct SvProfScope {  // brackets the launches issued inside its lifetime when `
     }
 };
 int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes);
+void sv_sky_release(svgpu_ctx* ctx);  // plan + buffers of the envelope Cholesky (ba_skyline.hip)
 int sv_ensure_stage(svgpu_ctx* ctx, size_t bytes);  // grow-only page-locked host buffer (ctx->h_stage)
 hipError_t sv_allow_dynamic_lds(const void* kernel, size_t bytes);  // per (device, kernel), thread-safe
 void sv_orb_release(svgpu_ctx* ctx);

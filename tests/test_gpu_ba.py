@@ -222,7 +222,7 @@ def test_local_ba_sharded_matches_single(ba, world):
                                 dict(num_kf=40, num_lm=3000, obs_per_lm=6, num_fixed=1, seed=32, loop=True)])
 def test_global_ba_matches_oracle(ba, kw):
     """global_bundle_adjuster core: one LM run over the whole graph, only the spanning root fixed.  The second case has
-    6 * 39 = 234 reduced unknowns (> 192) and goes through the block-Jacobi PCG on the block-sparse reduced system."""
+    6 * 39 = 234 reduced unknowns in 780 blocks: beyond the on-chip solvers, it goes through the block envelope Cholesky."""
     sc = S.ba_scene(**kw)
     got = ba.optimize_global_flat(sc, num_iter=10)
     ref = O.local_ba(sc, iters1=10, iters2=0)  # the oracle's gate after stage 1 does not move any vertex
@@ -232,8 +232,7 @@ def test_global_ba_matches_oracle(ba, kw):
     assert _rel(got["points"], ref["points"]) < TOL
     assert got["stats"]["chi2_final"] < 0.5 * got["stats"]["chi2_initial"]
     assert got["stats"]["stopped_by_terminate_action"] in (0, 1)
-    if 6 * (kw["num_kf"] - kw["num_fixed"]) > 192:
-        assert got["stats"]["pcg_iterations"] > 0  # the large system went through the PCG
+    assert got["stats"]["pcg_iterations"] == 0 and got["stats"]["cholesky_failures"] == 0  # direct solves at both sizes
 
 
 @pytest.mark.parametrize("seed,stereo,reset", [(4, False, False), (5, False, True), (6, True, False)])
@@ -276,15 +275,16 @@ def test_pose_optimizer_equirectangular_matches_oracle():
     assert np.abs(pose - pr["pose_gt"]).max() < 0.1 * np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
 
 
-@pytest.mark.parametrize("solver", ["pcg", "pcg_multi", "dense"])
+@pytest.mark.parametrize("solver", ["pcg", "pcg_multi", "dense", "envelope"])
 @pytest.mark.parametrize("kw", [dict(num_kf=10, num_lm=1500, obs_per_lm=5, num_fixed=3, seed=5),
                                 dict(num_kf=20, num_lm=10000, obs_per_lm=6, num_fixed=4, seed=1234)])
 def test_local_ba_alternative_solvers_match_oracle(kw, solver):
     """A local-BA sized reduced camera system is factored by the dense LL^T in LDS by default.  The other solvers -- the PCG that
     lives in one workgroup's LDS (north_star: "Schur-complement J^T J build + PCG solve"), the one-launch-per-iteration PCG of the
-    global-BA sizes, dense rocSOLVER -- must walk the same LM schedule to the same poses and outliers."""
+    larger sizes, dense rocSOLVER, the block envelope Cholesky of the global-BA sizes -- must walk the same LM schedule to the same poses
+    and outliers."""
     from stella_vslam_amd import optimize
-    code = dict(pcg=optimize.SOLVER_PCG, pcg_multi=optimize.SOLVER_PCG_MULTI, dense=optimize.SOLVER_DENSE)[solver]
+    code = dict(pcg=optimize.SOLVER_PCG, pcg_multi=optimize.SOLVER_PCG_MULTI, dense=optimize.SOLVER_DENSE, envelope=optimize.SOLVER_ENVELOPE)[solver]
     adj = optimize.local_bundle_adjuster().set_solver(code)
     sc = S.ba_scene(**kw)
     got = adj.optimize_flat(sc)
@@ -294,13 +294,13 @@ def test_local_ba_alternative_solvers_match_oracle(kw, solver):
     _assert_poses(got["pose_cw"], ref["pose_cw"])
     assert _rel(got["points"], ref["points"]) < TOL
     assert np.array_equal(got["outlier"], ref["outlier"])
-    assert (gs["pcg_iterations"] > 0) == (solver != "dense") and gs["cholesky_failures"] == 0
+    assert (gs["pcg_iterations"] > 0) == (solver not in ("dense", "envelope")) and gs["cholesky_failures"] == 0
 
 
 def test_global_ba_config5_matches_oracle():
     """BASELINE config 5: 500 keyframes on a loop / 200 k landmarks / 1.2 M observations, only the root fixed
-    (optimize/global_bundle_adjuster.cc:26-192).  2 994 reduced unknowns in ~6.6 k blocks: block-Jacobi PCG to a relative
-    residual of 1e-10 on the device, envelope Cholesky of the same system in the oracle."""
+    (optimize/global_bundle_adjuster.cc:26-192).  2 994 reduced unknowns in ~6.6 k blocks: block envelope Cholesky on the device (what the
+    default takes at this size) and in the oracle; the block-Jacobi PCG (relative residual 1e-10) must land on the same estimate."""
     from stella_vslam_amd import optimize
     sc = S.ba_scene_large()
     adj = optimize.local_bundle_adjuster()
@@ -313,10 +313,14 @@ def test_global_ba_config5_matches_oracle():
     assert gs["chi2_final"] == pytest.approx(last[0], rel=1e-6) and gs["lambda_final"] == pytest.approx(last[1], rel=1e-6)
     _assert_poses(got["pose_cw"], ref["pose_cw"])
     assert _rel(got["points"], ref["points"]) < TOL
-    assert gs["pcg_iterations"] > 0 and gs["cholesky_failures"] == 0
+    assert gs["pcg_iterations"] == 0 and gs["cholesky_failures"] == 0   # direct solve
     assert gs["chi2_final"] < 0.5 * gs["chi2_initial"]
     again = adj.optimize_global_flat(sc, num_iter=10)
     assert np.array_equal(again["pose_cw"], got["pose_cw"]) and np.array_equal(again["points"], got["points"])  # fixed-order reductions
+    pcg = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_PCG).optimize_global_flat(sc, num_iter=10)
+    assert pcg["stats"]["pcg_iterations"] > 0 and pcg["stats"]["iters_stage1"] == gs["iters_stage1"]
+    _assert_poses(pcg["pose_cw"], got["pose_cw"])
+    assert _rel(pcg["points"], got["points"]) < TOL
 
 
 def test_sharded_through_rccl_communicator_world1():

@@ -72,5 +72,5 @@ def test_two_process_sharded_ba_on_one_gpu(tmp_path):
     assert out["identical"]                      # every rank returns the same bits
     assert out["iters"][0] == out["iters"][2] and out["iters"][1] == out["iters"][3] and out["gated"][0] == out["gated"][1]
     assert out["dpose"] < 1e-9 and out["dpts"] < 1e-9 and out["dposeg"] < 1e-7
-    assert out["itersg"][0] == out["itersg"][1] and out["pcg"] > 0
+    assert out["itersg"][0] == out["itersg"][1] and out["pcg"] == 0   # the global solve takes the envelope Cholesky on every rank
     assert out["stopped"] == [7, 7] and out["flags"] == [1, 1]   # SVGPU_STOPPED on both ranks, the flag propagated to rank 0's caller
