@@ -482,7 +482,8 @@ typedef struct svgpu_ba_stats {
 
 /* Linear solver of the reduced camera system (BlockSolver_6_3 + LinearSolverEigen / LinearSolverCSparse in the reference,
  * optimize/local_bundle_adjuster_g2o.cc:151-164, optimize/global_bundle_adjuster.cc:66-85):
- *   AUTO      dense LL^T in one workgroup's LDS while it fits (6 * free poses <= ~135), PCG above
+ *   AUTO      dense LL^T in one workgroup's LDS while it fits (6 * free poses <= ~135), the LDS-resident PCG while THAT fits, the
+ *             block envelope Cholesky beyond (the one-launch-per-iteration PCG only when the envelope is too large)
  *   PCG       block-Jacobi PCG on the block-sparse Schur complement: inside ONE workgroup (blocks, block rows, vectors all in
  *             its LDS) while the kept 6x6 blocks fit ~150 KB and 6 * free poses <= 512, else one kernel launch per iteration
  *   CHOLESKY  the LDS LL^T (larger systems fall back to PCG)
@@ -537,8 +538,8 @@ int svgpu_pose_optimize_device(svgpu_ctx* ctx, const double* pose_cw, int n, con
  * fixed), ONE Levenberg-Marquardt run of problem->num_first_iter iterations with the terminate rule, optional Huber
  * (obs_huber_delta), no outlier gate (num_second_iter is ignored).  The caller applies the reference's post-conditions
  * (`force_stop_flag && *force_stop_flag && !stats->stopped_by_terminate_action` => discard, :341-343).
- * Reduced systems beyond the on-chip solver (6 * free poses > 192) are solved by the block-Jacobi PCG on the block-sparse
- * Schur complement (svgpu_ba_set_solver; the reference uses a sparse CSparse Cholesky there).  Host in/out, synchronous. */
+ * Reduced systems beyond the on-chip solvers are factored by the block envelope Cholesky of the block-sparse Schur complement
+ * (svgpu_ba_set_solver; the reference uses a sparse CSparse Cholesky there; the block-Jacobi PCG stays selectable).  Host in/out, synchronous. */
 int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                     double* points_out, svgpu_ba_stats* stats);
 
