@@ -235,6 +235,56 @@ def test_global_ba_matches_oracle(ba, kw):
     assert got["stats"]["pcg_iterations"] == 0 and got["stats"]["cholesky_failures"] == 0  # direct solves at both sizes
 
 
+def _hub_scene():
+    """A banded (loop) keyframe graph plus one equirectangular hub keyframe that observes landmarks all around the loop -- a dense
+    loop-closure row in the reduced camera system -- joined with a second, disconnected loop that has its own fixed keyframe."""
+    a = S.ba_scene(num_kf=40, num_lm=3000, obs_per_lm=5, num_fixed=1, seed=41, loop=True)
+    hub = 7
+    a["intr"][hub] = [0.0, 0.0, 1920.0, 960.0, 0.0]
+    T = a["pose_gt"][hub].reshape(3, 4)
+    rng = np.random.default_rng(9)
+    keep = a["obs_pose"] != hub   # the hub's perspective observations go, equirectangular ones of every 4th landmark come
+    pc = a["points_gt"][::4] @ T[:, :3].T + T[:, 3]
+    theta = np.arctan2(pc[:, 0], pc[:, 2])
+    ok = (np.abs(theta) < 2.8) & (np.linalg.norm(pc, axis=1) > 0.5)
+    lm = np.arange(0, len(a["points"]), 4)[ok]
+    pc = pc[ok]
+    u = 1920.0 * (0.5 + np.arctan2(pc[:, 0], pc[:, 2]) / (2 * np.pi)) + rng.normal(0, 1, len(lm))
+    v = 960.0 * (0.5 + np.arcsin(pc[:, 1] / np.linalg.norm(pc, axis=1)) / np.pi) + rng.normal(0, 1, len(lm))
+    extra = dict(obs_pose=np.full(len(lm), hub, np.int32), obs_point=lm.astype(np.int32),
+                 obs_uvr=np.stack([u, v, np.full(len(lm), -1.0)], 1).astype(np.float32),
+                 obs_inv_sigma_sq=np.ones(len(lm), np.float32), obs_huber=np.full(len(lm), np.float32(np.sqrt(5.991)), np.float32))
+    for k, x in extra.items():
+        a[k] = np.concatenate([a[k][keep], x])
+    order = np.argsort(a["obs_point"], kind="stable")   # landmark-major, as the adaptors deliver it
+    for k in extra:
+        a[k] = a[k][order]
+    b = S.ba_scene(num_kf=24, num_lm=1500, obs_per_lm=5, num_fixed=1, seed=42, loop=True)
+    out = {}
+    for k in a:
+        if k == "obs_pose":
+            out[k] = np.concatenate([a[k], b[k] + len(a["pose_cw"])]).astype(np.int32)
+        elif k == "obs_point":
+            out[k] = np.concatenate([a[k], b[k] + len(a["points"])]).astype(np.int32)
+        else:
+            out[k] = np.concatenate([a[k], b[k]])
+    return out
+
+
+def test_global_ba_envelope_with_hub_and_two_components():
+    """The envelope Cholesky on a block graph that is not a band: a dense hub row (what a loop closure looks like after the reverse
+    Cuthill-McKee ordering) and two disconnected components (62 free keyframes; at this size the default would be the LDS-resident PCG, the second leg)."""
+    from stella_vslam_amd import optimize
+    sc = _hub_scene()
+    ref = O.local_ba(sc, iters1=10, iters2=0)
+    for solver in (optimize.SOLVER_ENVELOPE, optimize.SOLVER_PCG):
+        got = optimize.local_bundle_adjuster().set_solver(solver).optimize_global_flat(sc, num_iter=10)
+        assert got["stats"]["iters_stage1"] == ref["stats"][2] and got["stats"]["cholesky_failures"] == 0
+        assert (got["stats"]["pcg_iterations"] == 0) == (solver == optimize.SOLVER_ENVELOPE)
+        _assert_poses(got["pose_cw"], ref["pose_cw"])
+        assert _rel(got["points"], ref["points"]) < TOL
+
+
 @pytest.mark.parametrize("seed,stereo,reset", [(4, False, False), (5, False, True), (6, True, False)])
 def test_pose_optimizer_matches_oracle(ba, seed, stereo, reset):
     """pose_optimizer (motion-only BA) as one persistent kernel vs the oracle: same LM iteration count, identical outlier flags,
