@@ -35,6 +35,7 @@ struct SkyDev {
     const int* diag = nullptr;      // position j -> index of block (j, j)
     int max_m = 0;                  // widest column (rows below the diagonal)
     int ncr = 0;                    // entries of colrows / colbase
+    int band = 0;                   // 1 = first[] is non-decreasing and max_m <= SKY_BAND_W: k_sky_band applies
     const int2* blkmap = nullptr;   // kept block k of the reduced system -> (envelope block index, 1 = store transposed)
     double* val = nullptr;          // envelope blocks, 36 doubles each, row-major
     double* dinv = nullptr;         // nP x 36: inverses of the diagonal factors (lower triangular)
@@ -81,135 +82,170 @@ __device__ __forceinline__ void wave_lds_order() {
     asm volatile("" ::: "memory");
 }
 
-// One workgroup (256 threads while no column has more than 21 rows, else 1024).  What a column costs is a chain of dependent memory
-// round trips, so the chain is kept short: the index arrays live in LDS, every block of a column is addressed through one index
-// (base[i] = rowoff[i] - first[i], block (i, k) = base[i] + k), the 6 x 6 pivot lives in the registers of one wave (rows on lanes,
-// entries exchanged with readlane, one rsqrt per pivot and no division; the inverse factor falls out of the same registers, column c on
-// lane c), and the two substitutions run on the first wave alone with the right-hand side in LDS and the factor rows of the NEXT column
-// already in flight while a column is processed (no workgroup barrier).
-// Measured at config 5 (499 block rows, 5 527 envelope blocks, widest column 11 rows): 3.2 ms per solve -- pivot + column 1.3, update 0.9,
-// substitutions 1.0 -- i.e. ~6 us per column, every phase a global-memory round trip through L2 (~1 us each seen from one wave); the
-// block-Jacobi PCG it replaces as the default took 3.4 ms per solve (~480 iterations) and up to 4 000 iterations when lambda is small.
-// Next: the trailing window of a banded envelope kept in LDS (DESIGN section 9).
-__global__ __launch_bounds__(SKY_THREADS) void k_sky_factor_solve(BaDev D, SkyDev K) {
-    if (D.ctl->phase != 1) return;
-    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [max_m x 36: the scaled column][n: right-hand side][index arrays]
-    __shared__ double s_Li[36];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP;
-    double* const s_col = s_dyn;
-    double* const s_y = s_dyn + (size_t)K.max_m * 36;
-    int* const s_coloff = reinterpret_cast<int*>(s_y + D.n);
-    int* const s_diag = s_coloff + (nP + 1);
-    int* const s_rows = s_diag + nP;
-    int* const s_base = s_rows + K.ncr;
-    if (tid == 0) s_fail = 0;
-    for (int t = tid; t < D.n; t += nt) s_y[t] = K.y[t];
-    for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
-    for (int t = tid; t < nP; t += nt) s_diag[t] = K.diag[t];
-    for (int t = tid; t < K.ncr; t += nt) {
-        s_rows[t] = K.colrows[t];
-        s_base[t] = K.colbase[t];
+// The 6 x 6 pivot of a column, on the first wave: L = chol(block at `src`, lower triangle), written to `dstL` (upper triangle zeroed), and
+// L^-1 to `dstInv` (global, for the substitutions) and to s_Li (for the column).  Rows on lanes, entries exchanged with readlane, one
+// rsqrt per pivot and no division; the inverse falls out of the same registers, column c on lane c.
+__device__ __forceinline__ void sky_pivot(const double* src, double* dstL, double* dstInv, double* s_Li, int* s_fail, int tid) {
+    const int r = min(tid, 5);
+    double a[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a[c] = src[r * 6 + c];  // lane r < 6: row r (lanes >= 6 mirror row 5 and write nothing)
+    double Lm[6][6], rd[6];  // the finished factor and its reciprocal diagonal, wave-uniform
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double v = a[c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < c) v -= a[k] * Lm[c][k];  // a[k] = L[r][k] by now
+        const double dcc = lane_bcast(v, c);
+        bad = bad || !(dcc > 0.0);
+        const double rs = rsqrt(dcc);
+        rd[c] = rs;
+        a[c] = v * rs;  // L[r][c]; on lane c: dcc / sqrt(dcc)
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) Lm[rr][c] = rr >= c ? lane_bcast(a[c], rr) : 0.0;
     }
-    __syncthreads();
-    // ---------------------------------------------------------------- factorisation
-    for (int j = 0; j < nP; ++j) {
-        const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
-        const int* rows = s_rows + c0;
-        const int* base = s_base + c0;
-        if (tid < 64) {
-            const int r = min(tid, 5);
-            double* Dj = K.val + (size_t)s_diag[j] * 36;
-            double a[6];
+    if (bad && tid == 0) *s_fail = 1;
+    // column c of L^-1 on lane c: x_c = 1 / L_cc, x_r = -(sum_{k = c}^{r - 1} L_rk x_k) / L_rr
+    const int cc = min(tid, 5);
+    double x[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) a[c] = Dj[r * 6 + c];  // lane r < 6: row r (lanes >= 6 mirror row 5 and write nothing)
-            double Lm[6][6], rd[6];  // the finished factor and its reciprocal diagonal, wave-uniform
-            bool bad = false;
+    for (int rr = 0; rr < 6; ++rr) {
+        double v = rr == cc ? 1.0 : 0.0;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double v = a[c];
+        for (int k = 0; k < 6; ++k)
+            if (k < rr) v -= (k >= cc ? Lm[rr][k] * x[k] : 0.0);
+        x[rr] = rr >= cc ? v * rd[rr] : 0.0;
+    }
+    if (tid < 6) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    if (k < c) v -= a[k] * Lm[c][k];  // a[k] = L[r][k] by now
-                const double dcc = lane_bcast(v, c);
-                bad = bad || !(dcc > 0.0);
-                const double rs = rsqrt(dcc);
-                rd[c] = rs;
-                a[c] = v * rs;  // L[r][c]; on lane c: dcc / sqrt(dcc)
+        for (int c = 0; c < 6; ++c) dstL[tid * 6 + c] = c <= tid ? a[c] : 0.0;
 #pragma unroll
-                for (int rr = 0; rr < 6; ++rr) Lm[rr][c] = rr >= c ? lane_bcast(a[c], rr) : 0.0;
-            }
-            if (bad && tid == 0) s_fail = 1;
-            // column c of L^-1 on lane c: x_c = 1 / L_cc, x_r = -(sum_{k = c}^{r - 1} L_rk x_k) / L_rr
-            const int cc = min(tid, 5);
-            double x[6];
+        for (int rr = 0; rr < 6; ++rr) {
+            s_Li[rr * 6 + tid] = x[rr];
+            dstInv[rr * 6 + tid] = x[rr];
+        }
+    }
+}
+
+// L z = g (column oriented), then L^T x = z, on the first wave alone: the right-hand side lives in LDS, the factor rows of the NEXT
+// column are in flight while a column is processed, no workgroup barrier.
+// Narrow columns (at most 16 rows below the diagonal -- every banded envelope): the factor rows of the next FOUR columns are in flight
+// while a column is processed (a global load takes ~1 us seen from one wave, a column step ~0.2 us), and the backward sums are combined
+// by a shuffle tree inside groups of eight lanes instead of sixty lane broadcasts.
+__device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane) {
+    const int nP = K.nP;
+    constexpr int PD = 4;
+    {   // forward: lane rr < 6 holds row rr of Li_j; item k of a lane = (row (lane + 64 k) / 6 of the column, component (lane + 64 k) % 6)
+        auto load = [&](int j, double (&li)[6], double (&bl)[2][6], int (&dst)[2]) {
+            if (j >= nP) return;
+            const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+            const int rr = min(lane, 5);
 #pragma unroll
-            for (int rr = 0; rr < 6; ++rr) {
-                double v = rr == cc ? 1.0 : 0.0;
+            for (int c = 0; c < 6; ++c) li[c] = K.dinv[(size_t)j * 36 + rr * 6 + c];
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
-                    if (k < rr) v -= (k >= cc ? Lm[rr][k] * x[k] : 0.0);
-                x[rr] = rr >= cc ? v * rd[rr] : 0.0;
-            }
-            if (tid < 6) {
+            for (int k = 0; k < 2; ++k) {
+                const int t = lane + 64 * k;
+                dst[k] = -1;
+                if (t < m * 6) {
+                    const int r = t / 6, a = t - 6 * r;
+                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36 + a * 6;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) Dj[tid * 6 + c] = c <= tid ? a[c] : 0.0;
-#pragma unroll
-                for (int rr = 0; rr < 6; ++rr) {
-                    s_Li[rr * 6 + tid] = x[rr];
-                    K.dinv[(size_t)j * 36 + rr * 6 + tid] = x[rr];
+                    for (int c = 0; c < 6; ++c) bl[k][c] = Bl[c];
+                    dst[k] = s_rows[c0 + r] * 6 + a;
                 }
             }
-        }
-        __syncthreads();
-        if (s_fail) break;
-        // column: L_ij = S_ij L_jj^-T, entry (a, b) = sum_{c <= b} S_ij[a][c] Li[b][c]; staged in LDS (the reads of the old block finish first)
-        for (int t = tid; t < m * 36; t += nt) {
-            const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
-            const double* Bl = K.val + (size_t)(base[r] + j) * 36 + a * 6;
-            double v = 0.0;
+        };
+        double li[PD][6], bl[PD][2][6];
+        int dst[PD][2];
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
-                if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
-            s_col[t] = v;
-        }
-        __syncthreads();
-        for (int t = tid; t < m * 36; t += nt) {
-            const int r = t / 36, e = t - r * 36;
-            K.val[(size_t)(base[r] + j) * 36 + e] = s_col[t];
-        }
-        // update: one thread per pair of rows (p, q), q <= p: S_{ip, iq} -= L_p L_q^T
-        const int npair = m * (m + 1) / 2;
-        for (int x = tid; x < npair; x += nt) {
-            int p, q;
-            tri_index(x, p, q);
-            double Lq[36];
+        for (int d = 0; d < PD; ++d) load(d, li[d], bl[d], dst[d]);
+        for (int j0 = 0; j0 < nP; j0 += PD) {
 #pragma unroll
-            for (int e = 0; e < 36; ++e) Lq[e] = s_col[q * 36 + e];
-            double* Dst = K.val + (size_t)(base[p] + rows[q]) * 36;
+            for (int d = 0; d < PD; ++d) {
+                const int j = j0 + d;
+                if (j >= nP) break;
+                double v = 0.0;  // z[rr] on lane rr < 6
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double La[6];
+                for (int c = 0; c < 6; ++c)
+                    if (c <= min(lane, 5)) v += li[d][c] * s_y[j * 6 + c];
+                double z[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
+                for (int c = 0; c < 6; ++c) z[c] = lane_bcast(v, c);
+                wave_lds_order();  // every lane has read y_j
+                if (lane < 6) s_y[j * 6 + lane] = v;
 #pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    double v = La[0] * Lq[b * 6];
+                for (int k = 0; k < 2; ++k)
+                    if (dst[d][k] >= 0) {
+                        double u = bl[d][k][0] * z[0];
 #pragma unroll
-                    for (int c = 1; c < 6; ++c) v += La[c] * Lq[b * 6 + c];
-                    Dst[a * 6 + b] -= v;
-                }
+                        for (int c = 1; c < 6; ++c) u += bl[d][k][c] * z[c];
+                        s_y[dst[d][k]] -= u;
+                    }
+                wave_lds_order();
+                load(j + PD, li[d], bl[d], dst[d]);
             }
         }
-        __syncthreads();
     }
-    if (s_fail) {
-        if (tid == 0) D.ctl->solve_failed = 1;
-        for (int t = tid; t < D.n; t += nt) D.dp[t] = 0.0;
-        return;
+    {   // backward: w = z_j - sum_{i in rows(j)} L_ij^T x_i, lane = component * 8 + part (48 lanes), a lane's rows: part and part + 8
+        const int a = min(lane >> 3, 5), part = lane & 7;
+        auto load = [&](int j, double (&lc)[6], double (&bc)[2][6], int (&src)[2]) {
+            if (j < 0) return;
+            const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+            const int ac = min(lane, 5);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) lc[c] = K.dinv[(size_t)j * 36 + c * 6 + ac];  // column `lane` of Li_j
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = part + 8 * k;
+                src[k] = -1;
+                if (lane < 48 && r < m) {
+                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) bc[k][c] = Bl[c * 6 + a];
+                    src[k] = s_rows[c0 + r] * 6;
+                }
+            }
+        };
+        double lc[PD][6], bc[PD][2][6];
+        int src[PD][2];
+#pragma unroll
+        for (int d = 0; d < PD; ++d) load(nP - 1 - d, lc[d], bc[d], src[d]);
+        for (int j0 = nP - 1; j0 >= 0; j0 -= PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int j = j0 - d;
+                if (j < 0) break;
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (src[d][k] >= 0)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) v += bc[d][k][c] * s_y[src[d][k] + c];
+                v += __shfl_xor(v, 1, 64);  // fixed tree inside the component's eight lanes
+                v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64);
+                double w[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) w[c] = s_y[j * 6 + c] - lane_bcast(v, 8 * c);
+                wave_lds_order();
+                if (lane < 6) {  // x_j = Li_j^T w: component a = sum_{c >= a} Li[c][a] w[c]
+                    double x = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+                        if (c >= lane) x += lc[d][c] * w[c];
+                    s_y[j * 6 + lane] = x;
+                }
+                wave_lds_order();
+                load(j - PD, lc[d], bc[d], src[d]);
+            }
+        }
     }
-    // ---------------------------------------------------------------- L z = g (column oriented), then L^T x = z: the first wave alone
-    if (tid < 64) {
+}
+
+__device__ __forceinline__ void sky_substitute(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int tid) {
+    const int nP = K.nP;
         const int lane = tid;
         const bool pre = K.max_m * 6 <= 128;  // a lane owns at most two (row, component) items of a column: their factor rows are prefetched
         // forward.  Lane rr < 6 holds row rr of Li_j, item k of a lane = (row (lane + 64 k) / 6 of the column, component (lane + 64 k) % 6)
@@ -356,7 +392,220 @@ __global__ __launch_bounds__(SKY_THREADS) void k_sky_factor_solve(BaDev D, SkyDe
                 src[1] = src_n[1];
             }
         }
+    
+}
+
+// One workgroup (256 threads while no column has more than 21 rows, else 1024).  What a column costs is a chain of dependent memory
+// round trips, so the chain is kept short: the index arrays live in LDS, every block of a column is addressed through one index
+// (base[i] = rowoff[i] - first[i], block (i, k) = base[i] + k), the 6 x 6 pivot lives in the registers of one wave (rows on lanes,
+// entries exchanged with readlane, one rsqrt per pivot and no division; the inverse factor falls out of the same registers, column c on
+// lane c), and the two substitutions run on the first wave alone with the right-hand side in LDS and the factor rows of the NEXT column
+// already in flight while a column is processed (no workgroup barrier).
+// Measured at config 5 (499 block rows, 5 527 envelope blocks, widest column 11 rows): 3.2 ms per solve -- pivot + column 1.3, update 0.9,
+// substitutions 1.0 -- i.e. ~6 us per column, every phase a global-memory round trip through L2 (~1 us each seen from one wave); the
+// block-Jacobi PCG it replaces as the default took 3.4 ms per solve (~480 iterations) and up to 4 000 iterations when lambda is small.
+// Next: the trailing window of a banded envelope kept in LDS (DESIGN section 9).
+__global__ __launch_bounds__(SKY_THREADS) void k_sky_factor_solve(BaDev D, SkyDev K) {
+    if (D.ctl->phase != 1) return;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [max_m x 36: the scaled column][n: right-hand side][index arrays]
+    __shared__ double s_Li[36];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP;
+    double* const s_col = s_dyn;
+    double* const s_y = s_dyn + (size_t)K.max_m * 36;
+    int* const s_coloff = reinterpret_cast<int*>(s_y + D.n);
+    int* const s_diag = s_coloff + (nP + 1);
+    int* const s_rows = s_diag + nP;
+    int* const s_base = s_rows + K.ncr;
+    if (tid == 0) s_fail = 0;
+    for (int t = tid; t < D.n; t += nt) s_y[t] = K.y[t];
+    for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
+    for (int t = tid; t < nP; t += nt) s_diag[t] = K.diag[t];
+    for (int t = tid; t < K.ncr; t += nt) {
+        s_rows[t] = K.colrows[t];
+        s_base[t] = K.colbase[t];
     }
+    __syncthreads();
+    // ---------------------------------------------------------------- factorisation
+    for (int j = 0; j < nP; ++j) {
+        const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
+        const int* rows = s_rows + c0;
+        const int* base = s_base + c0;
+        if (tid < 64) {
+            double* Dj = K.val + (size_t)s_diag[j] * 36;
+            sky_pivot(Dj, Dj, K.dinv + (size_t)j * 36, s_Li, &s_fail, tid);
+        }
+        __syncthreads();
+        if (s_fail) break;
+        // column: L_ij = S_ij L_jj^-T, entry (a, b) = sum_{c <= b} S_ij[a][c] Li[b][c]; staged in LDS (the reads of the old block finish first)
+        for (int t = tid; t < m * 36; t += nt) {
+            const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
+            const double* Bl = K.val + (size_t)(base[r] + j) * 36 + a * 6;
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
+            s_col[t] = v;
+        }
+        __syncthreads();
+        for (int t = tid; t < m * 36; t += nt) {
+            const int r = t / 36, e = t - r * 36;
+            K.val[(size_t)(base[r] + j) * 36 + e] = s_col[t];
+        }
+        // update: one thread per pair of rows (p, q), q <= p: S_{ip, iq} -= L_p L_q^T
+        const int npair = m * (m + 1) / 2;
+        for (int x = tid; x < npair; x += nt) {
+            int p, q;
+            tri_index(x, p, q);
+            double Lq[36];
+#pragma unroll
+            for (int e = 0; e < 36; ++e) Lq[e] = s_col[q * 36 + e];
+            double* Dst = K.val + (size_t)(base[p] + rows[q]) * 36;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double La[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    double v = La[0] * Lq[b * 6];
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) v += La[c] * Lq[b * 6 + c];
+                    Dst[a * 6 + b] -= v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (s_fail) {
+        if (tid == 0) D.ctl->solve_failed = 1;
+        for (int t = tid; t < D.n; t += nt) D.dp[t] = 0.0;
+        return;
+    }
+    // ---------------------------------------------------------------- L z = g (column oriented), then L^T x = z: the first wave alone
+    if (tid < 64) sky_substitute(K, s_y, s_coloff, s_rows, s_base, tid);
+    __syncthreads();
+    for (int t = tid; t < D.n; t += nt) {
+        const int a = t / 6, c = t - 6 * a;
+        D.dp[t] = s_y[K.pos[a] * 6 + c];
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for the global loads in flight (the row that
+// enters the window) nor for the global stores of the finished factor to be acknowledged.
+__device__ __forceinline__ void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Banded envelopes (first[] non-decreasing, so the rows of column j are j + 1 .. j + m_j; bandwidth W <= SKY_BAND_W): the trailing
+// (W + 1) x (W + 1) block window lives in LDS (slot (i mod (W + 1), k mod (W + 1))), so the pivot, the column and the update of a
+// column never wait for global memory: the only global reads are the blocks of the row that enters the window (unmodified so far,
+// requested before the pivot and stored behind the update), the only global writes the finished factor for the substitutions.
+// Config 5 (499 columns, W = 11): 2.05 ms per solve against 3.2 ms for the general kernel below and 3.4 ms for the PCG -- by phase
+// (runs with phases switched off): skeleton (3 barriers per column, window fill, memset + assembly) 0.43, pivots 0.35, columns 0.40,
+// updates 0.53, substitutions 0.35.
+#define SKY_BAND_W 16
+__global__ __launch_bounds__(256) void k_sky_band(BaDev D, SkyDev K) {
+    if (D.ctl->phase != 1) return;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][n: right-hand side][index arrays]
+    __shared__ double s_Li[36];
+    __shared__ int s_fail;
+    __shared__ unsigned short s_pq[SKY_BAND_W * (SKY_BAND_W + 1) / 2];  // pair index -> p | q << 8 (q <= p), row-major over the lower triangle
+    const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP, W = K.max_m, Wn = W + 1;
+    if (tid < SKY_BAND_W * (SKY_BAND_W + 1) / 2) {
+        int p, q;
+        tri_index(tid, p, q);
+        s_pq[tid] = (unsigned short)(p | (q << 8));
+    }
+    double* const s_win = s_dyn;
+    double* const s_col = s_win + (size_t)Wn * Wn * 36;
+    double* const s_y = s_col + (size_t)W * 36;
+    int* const s_coloff = reinterpret_cast<int*>(s_y + D.n);
+    int* const s_first = s_coloff + (nP + 1);
+    int* const s_rbase = s_first + nP;   // rowoff[i] - first[i]: block (i, k) of the envelope = s_rbase[i] + k
+    int* const s_rows = s_rbase + nP;    // for the substitution routine
+    int* const s_base = s_rows + K.ncr;
+    if (tid == 0) s_fail = 0;
+    for (int t = tid; t < D.n; t += nt) s_y[t] = K.y[t];
+    for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
+    for (int t = tid; t < nP; t += nt) {
+        s_first[t] = K.first[t];
+        s_rbase[t] = K.rowoff[t] - K.first[t];
+    }
+    for (int t = tid; t < K.ncr; t += nt) {
+        s_rows[t] = K.colrows[t];
+        s_base[t] = K.colbase[t];
+    }
+    __syncthreads();
+    auto slot = [&](int i, int k) { return s_win + (size_t)((i % Wn) * Wn + (k % Wn)) * 36; };
+    // rows 0 .. W of the assembled system
+    for (int i = 0; i < min(Wn, nP); ++i) {
+        const int f = s_first[i];
+        for (int t = tid; t < (i - f + 1) * 36; t += nt) {
+            const int k = f + t / 36, e = t % 36;
+            slot(i, k)[e] = K.val[(size_t)(s_rbase[i] + k) * 36 + e];
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < nP; ++j) {
+        const int m = s_coloff[j + 1] - s_coloff[j];
+        // the row that enters the window behind this column: requested now, stored in LDS behind the update
+        const int inew = j + Wn;
+        double pre[3];  // (W + 1) x 36 / 256 threads <= 3 entries per thread
+        int npre = 0, fnew = 0;
+        if (inew < nP) {
+            fnew = max(s_first[inew], j + 1);
+            npre = (inew - fnew + 1) * 36;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int t = tid + q * 256;
+                if (t < npre) pre[q] = K.val[(size_t)(s_rbase[inew] + fnew + t / 36) * 36 + t % 36];
+            }
+        }
+        if (tid < 64) sky_pivot(slot(j, j), K.val + (size_t)(s_rbase[j] + j) * 36, K.dinv + (size_t)j * 36, s_Li, &s_fail, tid);
+        block_sync_lds();
+        if (s_fail) break;
+        for (int t = tid; t < m * 36; t += nt) {  // L_ij = S_ij L_jj^-T
+            const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
+            const double* Bl = slot(j + 1 + r, j) + a * 6;
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
+            s_col[t] = v;
+        }
+        block_sync_lds();
+        for (int t = tid; t < m * 36; t += nt) K.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
+        const int npair = m * (m + 1) / 2;
+        for (int t = tid; t < npair * 6; t += nt) {  // S_{ip, iq} -= L_p L_q^T inside the window: one thread per (pair, row of the block)
+            const int x = t / 6, a = t - 6 * x;
+            const int pq = s_pq[x], p = pq & 255, q = pq >> 8;
+            double La[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
+            double* Dst = slot(j + 1 + p, j + 1 + q) + a * 6;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double v = La[0] * s_col[q * 36 + b * 6];
+#pragma unroll
+                for (int c = 1; c < 6; ++c) v += La[c] * s_col[q * 36 + b * 6 + c];
+                Dst[b] -= v;
+            }
+        }
+        if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot before the first barrier)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int t = tid + q * 256;
+                if (t < npre) slot(inew, fnew + t / 36)[t % 36] = pre[q];
+            }
+        }
+        block_sync_lds();
+    }
+    __syncthreads();  // the factor blocks written above are read by the substitutions
+    if (s_fail) {
+        if (tid == 0) D.ctl->solve_failed = 1;
+        for (int t = tid; t < D.n; t += nt) D.dp[t] = 0.0;
+        return;
+    }
+    if (tid < 64) sky_substitute_narrow(K, s_y, s_coloff, s_rows, s_base, tid);  // W <= 16; this kernel has the registers for the 4-deep prefetch
     __syncthreads();
     for (int t = tid; t < D.n; t += nt) {
         const int a = t / 6, c = t - 6 * a;
@@ -450,6 +699,24 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
         for (int v : adj[order[i]]) f = std::min(f, pos[v]);
         first[i] = f;
     }
+    // A non-decreasing first[] makes the rows of every column contiguous (the banded kernel); taking the suffix minimum only adds
+    // blocks, so it is kept when the envelope grows by less than a third and stays narrow.
+    bool band = false;
+    {
+        std::vector<int> fm(first);
+        for (int i = nP - 2; i >= 0; --i) fm[i] = std::min(fm[i], fm[i + 1]);
+        size_t n0 = 0, n1 = 0;
+        int wmax = 0;
+        for (int i = 0; i < nP; ++i) {
+            n0 += (size_t)(i - first[i] + 1);
+            n1 += (size_t)(i - fm[i] + 1);
+            wmax = std::max(wmax, i - fm[i]);
+        }
+        if (wmax <= SKY_BAND_W && 3 * n1 <= 4 * n0 && !std::getenv("SVGPU_SKY_NO_BAND")) {
+            first = fm;
+            band = true;
+        }
+    }
     size_t nblocks = 0;
     for (int i = 0; i < nP; ++i) {
         rowoff[i] = (int)nblocks;
@@ -539,6 +806,7 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
     K.diag = di + o_diag;
     K.max_m = max_m;
     K.ncr = (int)colrows.size();
+    K.band = band ? 1 : 0;
     K.blkmap = reinterpret_cast<const int2*>(di + o_blkmap);
     K.val = (double*)P->d_val;
     K.dinv = K.val + nblocks * 36;
@@ -548,7 +816,7 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
     P->usable = true;
     *usable = true;
     if (std::getenv("SVGPU_BA_TRACE"))
-        std::fprintf(stderr, "[ba]     envelope plan: %d block rows, %zu blocks (%.1f MB), widest column %d rows\n", nP, nblocks, nblocks * 288.0 / 1048576.0, max_m);
+        std::fprintf(stderr, "[ba]     envelope plan: %d block rows, %zu blocks (%.1f MB), widest column %d rows%s\n", nP, nblocks, nblocks * 288.0 / 1048576.0, max_m, band ? ", banded" : "");
     return SVGPU_OK;
 }
 
@@ -560,6 +828,15 @@ void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     (void)hipMemsetAsync(K.val, 0, K.nblocks * 36 * sizeof(double), s);
     const size_t items = std::max((size_t)K.NB * 36, (size_t)D.n);
     hipLaunchKernelGGL(k_sky_assemble, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, D, K);
+    if (K.band) {
+        const size_t wn = (size_t)K.max_m + 1;
+        const size_t lds = (wn * wn * 36 + (size_t)K.max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)3 * K.nP + 1 + 2 * (size_t)K.ncr);
+        if (lds <= 150 * 1024) {
+            (void)sv_allow_dynamic_lds((const void*)k_sky_band, lds);
+            hipLaunchKernelGGL(k_sky_band, dim3(1), dim3(256), lds, s, D, K);
+            return;
+        }
+    }
     const size_t lds = ((size_t)P->max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)2 * K.nP + 1 + 2 * (size_t)K.ncr);
     (void)sv_allow_dynamic_lds((const void*)k_sky_factor_solve, lds);
     hipLaunchKernelGGL(k_sky_factor_solve, dim3(1), dim3(P->max_m <= 21 ? 256 : SKY_THREADS), lds, s, D, K);

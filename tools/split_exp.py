@@ -11,6 +11,8 @@ from stella_vslam_amd import feature, synthetic  # noqa: E402
 from stella_vslam_amd._lib import lib  # noqa: E402
 
 W, H, B, STEPS = 640, 480, 256, 20
+import os
+NBUF = int(os.environ.get("EXP_NBUF", "2"))
 L = lib()
 params = feature.orb_params()
 NL = params.num_levels_
@@ -31,12 +33,12 @@ def run(S, prio_first=True):
     bufs = [dict(kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"), desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
                  counts=torch.zeros(B * nc, dtype=torch.int32, device="cuda"), matched=torch.zeros(B * cap, dtype=torch.int32, device="cuda"),
                  nmatch=torch.zeros(B, dtype=torch.int32, device="cuda"), ev_ext=[torch.cuda.Event() for _ in range(S)], ev_match=torch.cuda.Event(), used=False)
-            for _ in range(2)]
+            for _ in range(NBUF)]
     torch.cuda.synchronize()
     st = {"i": 0}
 
     def step():
-        bf = bufs[st["i"] % 2]
+        bf = bufs[st["i"] % NBUF]
         st["i"] += 1
         for s in range(S):
             if bf["used"]:
