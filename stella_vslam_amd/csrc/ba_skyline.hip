@@ -501,9 +501,12 @@ __device__ __forceinline__ void block_sync_lds() { asm volatile("s_waitcnt lgkmc
 // requested before the pivot and stored behind the update), the only global writes the finished factor for the substitutions.
 // Config 5 (499 columns, W = 11): 2.05 ms per solve against 3.2 ms for the general kernel below and 3.4 ms for the PCG -- by phase
 // (runs with phases switched off): skeleton (3 barriers per column, window fill, memset + assembly) 0.43, pivots 0.35, columns 0.40,
-// updates 0.53, substitutions 0.35.
+// updates 0.53, substitutions 0.35 -- with 256 threads and before the pivot of column j + 1 moved into the shadow of column j's update.
 #define SKY_BAND_W 16
-__global__ __launch_bounds__(256) void k_sky_band(BaDev D, SkyDev K) {
+#ifndef SKY_BAND_THREADS
+#define SKY_BAND_THREADS 512  // 256: 1.81 ms per config-5 solve, 512: 1.59 (the update of a column fits one round), 1024: 2.41 (128 VGPRs: the substitutions spill)
+#endif
+__global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K) {
     if (D.ctl->phase != 1) return;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][n: right-hand side][index arrays]
     __shared__ double s_Li[36];
@@ -545,24 +548,41 @@ __global__ __launch_bounds__(256) void k_sky_band(BaDev D, SkyDev K) {
         }
     }
     __syncthreads();
+    // Column j: [scale] barrier [update of the other waves | first wave: the six rows of block (j + 1, j + 1), then the PIVOT of column
+    // j + 1, which needs nothing else of this update] barrier.  Two barriers per column, the pivots off the critical path.
+    auto update_item = [&](int j, int t) {  // S_{ip, iq} -= L_p L_q^T inside the window: item = (pair, row of the block)
+        const int x = t / 6, a = t - 6 * x;
+        const int pq = s_pq[x], p = pq & 255, q = pq >> 8;
+        double La[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
+        double* Dst = slot(j + 1 + p, j + 1 + q) + a * 6;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            double v = La[0] * s_col[q * 36 + b * 6];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) v += La[c] * s_col[q * 36 + b * 6 + c];
+            Dst[b] -= v;
+        }
+    };
+    if (tid < 64) sky_pivot(slot(0, 0), K.val + (size_t)s_rbase[0] * 36, K.dinv, s_Li, &s_fail, tid);
+    block_sync_lds();
     for (int j = 0; j < nP; ++j) {
+        if (s_fail) break;
         const int m = s_coloff[j + 1] - s_coloff[j];
         // the row that enters the window behind this column: requested now, stored in LDS behind the update
         const int inew = j + Wn;
-        double pre[3];  // (W + 1) x 36 / 256 threads <= 3 entries per thread
+        double pre[3];  // (W + 1) x 36 <= 612 entries over the workgroup's threads
         int npre = 0, fnew = 0;
         if (inew < nP) {
             fnew = max(s_first[inew], j + 1);
             npre = (inew - fnew + 1) * 36;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int t = tid + q * 256;
+                const int t = tid + q * SKY_BAND_THREADS;
                 if (t < npre) pre[q] = K.val[(size_t)(s_rbase[inew] + fnew + t / 36) * 36 + t % 36];
             }
         }
-        if (tid < 64) sky_pivot(slot(j, j), K.val + (size_t)(s_rbase[j] + j) * 36, K.dinv + (size_t)j * 36, s_Li, &s_fail, tid);
-        block_sync_lds();
-        if (s_fail) break;
         for (int t = tid; t < m * 36; t += nt) {  // L_ij = S_ij L_jj^-T
             const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
             const double* Bl = slot(j + 1 + r, j) + a * 6;
@@ -575,25 +595,19 @@ __global__ __launch_bounds__(256) void k_sky_band(BaDev D, SkyDev K) {
         block_sync_lds();
         for (int t = tid; t < m * 36; t += nt) K.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
         const int npair = m * (m + 1) / 2;
-        for (int t = tid; t < npair * 6; t += nt) {  // S_{ip, iq} -= L_p L_q^T inside the window: one thread per (pair, row of the block)
-            const int x = t / 6, a = t - 6 * x;
-            const int pq = s_pq[x], p = pq & 255, q = pq >> 8;
-            double La[6];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
-            double* Dst = slot(j + 1 + p, j + 1 + q) + a * 6;
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                double v = La[0] * s_col[q * 36 + b * 6];
-#pragma unroll
-                for (int c = 1; c < 6; ++c) v += La[c] * s_col[q * 36 + b * 6 + c];
-                Dst[b] -= v;
-            }
+        if (tid < 64) {
+            if (m > 0 && tid < 6) update_item(j, tid);  // pair (0, 0) = block (j + 1, j + 1)
+            wave_lds_order();
+            if (j + 1 < nP)
+                sky_pivot(slot(j + 1, j + 1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li, &s_fail, tid);
         }
-        if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot before the first barrier)
+        else {
+            for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(j, t);
+        }
+        if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot of column j long ago)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int t = tid + q * 256;
+                const int t = tid + q * SKY_BAND_THREADS;
                 if (t < npre) slot(inew, fnew + t / 36)[t % 36] = pre[q];
             }
         }
@@ -833,7 +847,7 @@ void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
         const size_t lds = (wn * wn * 36 + (size_t)K.max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)3 * K.nP + 1 + 2 * (size_t)K.ncr);
         if (lds <= 150 * 1024) {
             (void)sv_allow_dynamic_lds((const void*)k_sky_band, lds);
-            hipLaunchKernelGGL(k_sky_band, dim3(1), dim3(256), lds, s, D, K);
+            hipLaunchKernelGGL(k_sky_band, dim3(1), dim3(SKY_BAND_THREADS), lds, s, D, K);
             return;
         }
     }
