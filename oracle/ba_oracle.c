@@ -29,7 +29,8 @@
  * PARITY STATUS: the reference's OWN part of this path -- the vertex and edge classes and the wrappers that configure them
  * (optimize/internal/landmark_vertex.h, se3/shot_vertex.h, se3/*_reproj_edge.h, se3/*_pose_opt_edge.h, se3/*_wrapper.h) -- is pinned
  * bit for bit against the reference's compiled headers (oracle/ref_local -> oracle/_ref/libsvref_opt.so, tests/test_ref_local_optimize.py:
- * errors, both Jacobian blocks, depth gate, chi2, information, Huber width, levels, oplus).  g2o's side (LM schedule, block solver,
+ * errors, both Jacobian blocks, depth gate, chi2, information, Huber width, levels, oplus; optimize/terminate_action.cc over a scripted
+ * optimizer).  g2o's side (LM schedule, block solver,
  * SE3Quat arithmetic, robust weighting) stays "parity unpinned": the reference has no test under test/stella_vslam/optimize/ and g2o
  * cannot be built here.  That part is cross-checked against scipy.optimize.least_squares and known
  * ground truth on synthetic scenes (tests/test_oracle_ba.py).  Vertex ordering in the reference is
@@ -617,6 +618,18 @@ typedef struct {
     double last_chi; /* terminate_action::_lastChi */
 } lm_t;
 
+/* terminate_action::operator() for iteration >= 0 (optimize/terminate_action.cc:52-73; _maxIterations keeps g2o's default INT_MAX):
+ * iteration 0 stores the chi2, later ones stop when 0 <= (last - now) / now < threshold.  Returns 1 when the stop flag is to be raised. */
+static int terminate_rule(double* last_chi, int it, double chi_now, double gain_thr) {
+    if (it == 0) {
+        *last_chi = chi_now;
+        return 0;
+    }
+    const double gain = (*last_chi - chi_now) / chi_now;
+    *last_chi = chi_now;
+    return gain >= 0 && gain < gain_thr;
+}
+
 /* One SparseOptimizer::optimize(iterations) call incl. the terminate_action post-iteration hook.
  * stop: the optimizer's force-stop flag (never NULL here; see orc_local_ba).  Returns iterations run. */
 static int optimize(ba_t* B, int iterations, double gain_thr, volatile uint8_t* stop, const int* lm_edge_off,
@@ -692,12 +705,7 @@ static int optimize(ba_t* B, int iterations, double gain_thr, volatile uint8_t* 
             trace[2 * it] = chi_now;
             trace[2 * it + 1] = lm.lambda;
         }
-        if (it == 0) lm.last_chi = chi_now;
-        else {
-            const double gain = (lm.last_chi - chi_now) / chi_now;
-            lm.last_chi = chi_now;
-            if (gain >= 0 && gain < gain_thr) *stop = 1;
-        }
+        if (terminate_rule(&lm.last_chi, it, chi_now, gain_thr)) *stop = 1;
     }
     free(S.Hpp);
     free(S.bp);
@@ -969,12 +977,7 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
             } while (rho_ < 0 && qmax < 10 && !flag);
             if (qmax == 10 || rho_ == 0 || !isfinite(lambda)) ok = 0;
             ++total_iters;
-            if (it == 0) last_chi = cur;
-            else {
-                const double gain = (last_chi - cur) / cur;
-                last_chi = cur;
-                if (gain >= 0 && gain < gain_thr) flag = 1;
-            }
+            if (terminate_rule(&last_chi, it, cur, gain_thr)) flag = 1;
         }
         /* ---- re-classification at the current pose (:127-160) */
         num_bad = 0;
@@ -1060,4 +1063,12 @@ int orc_dbg_reproj_edge(const double* q4, const double* t3, const double* point,
     err[2] = stereo ? (double)uvr[2] - (u - K5[4] / pc[2]) : 0.0;
     reproj_edge_jacobians(K5, pc, R, A, Bj);
     return stereo ? 3 : 2;
+}
+/* the post-iteration stop rule over a scripted sequence of (iteration, chi2): stop[k] = 1 where the rule raises the flag */
+void orc_dbg_terminate(int n, const int* iteration, const double* chi2, double gain_thr, uint8_t* stop, double* last_chi_out) {
+    double last = 0.0;
+    for (int k = 0; k < n; ++k) {
+        stop[k] = (uint8_t)terminate_rule(&last, iteration[k], chi2[k], gain_thr);
+        last_chi_out[k] = last;
+    }
 }

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 
+#include "stella_vslam/optimize/terminate_action.h"
 #include "stella_vslam/optimize/internal/se3/pose_opt_edge_wrapper.h"
 #include "stella_vslam/optimize/internal/se3/reproj_edge_wrapper.h"
 
@@ -140,5 +141,27 @@ void svref_vertex_oplus(const double* q4, const double* t3, const double* upd6, 
     std::memcpy(origin7_3, sv.estimate().q, 4 * sizeof(double));
     std::memcpy(origin7_3 + 4, sv.estimate().t, 3 * sizeof(double));
     for (int i = 0; i < 3; ++i) origin7_3[7 + i] = lv.estimate()(i);
+}
+
+// optimize/terminate_action.cc driven over a scripted optimizer: step k reports chi2[k] as the active robust chi2 of iteration[k] (< 0: the
+// "reset" call).  The caller's force-stop flag (install_flag) or the action's own one is cleared before every step; raised[k] = the flag
+// after the step, last_chi[k] = _lastChi, by_action[k] = stopped_by_terminate_action_.
+void svref_terminate_sequence(int n, const int* iteration, const double* chi2, double gain_thr, int install_flag, uint8_t* raised, double* last_chi,
+                              uint8_t* by_action) {
+    optimize::terminate_action act;
+    act.setGainThreshold(gain_thr);
+    g2o::SparseOptimizer opt;
+    bool flag = false;
+    if (install_flag) opt.setForceStopFlag(&flag);
+    g2o::HyperGraphAction* a = &act;  // operator() is private in the derived class, public in the base
+    for (int k = 0; k < n; ++k) {
+        if (opt.forceStopFlag()) *opt.forceStopFlag() = false;
+        opt.scripted_chi2 = chi2[k];
+        g2o::HyperGraphAction::ParametersIteration p(iteration[k]);
+        (*a)(&opt, &p);
+        raised[k] = opt.forceStopFlag() && *opt.forceStopFlag() ? 1 : 0;
+        last_chi[k] = act.lastChi();
+        by_action[k] = act.stopped_by_terminate_action_ ? 1 : 0;
+    }
 }
 }

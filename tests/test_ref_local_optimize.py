@@ -114,3 +114,33 @@ def test_vertex_updates(ref):
         np.testing.assert_array_equal(t_r, t_o)
         np.testing.assert_array_equal(p_r, pos + upd3)                        # landmark_vertex.h:51
         np.testing.assert_array_equal(org, [0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+
+
+def test_terminate_action(ref):
+    """optimize/terminate_action.cc compiled from the reference (over a scripted optimizer that reports the chi2 of each iteration) against
+    the oracle's post-iteration rule: iteration 0 stores the chi2, later iterations raise the force-stop flag when
+    0 <= (last - now) / now < gain threshold -- through the caller's flag or, when the optimizer has none, g2o's own."""
+    rng = np.random.default_rng(11)
+    lib = O.lib()
+    for trial in range(200):
+        n = int(rng.integers(2, 16))
+        it = np.arange(n, dtype=np.int32)
+        chi = np.empty(n)
+        chi[0] = rng.uniform(1e2, 1e6)
+        for k in range(1, n):   # mostly small gains around the threshold, sometimes an increase
+            chi[k] = chi[k - 1] * (1.0 - rng.choice([rng.uniform(-2e-3, 4e-3), rng.uniform(0, 0.5), 0.0, 1e-3]))
+        thr = float(rng.choice([1e-3, 1e-6, 0.05]))
+        raised_o, last_o = np.zeros(n, np.uint8), np.zeros(n)
+        lib.orc_dbg_terminate(n, _p(it), _p(chi), C.c_double(thr), _p(raised_o), _p(last_o))
+        for install in (0, 1):
+            raised_r, last_r, by_r = np.zeros(n, np.uint8), np.zeros(n), np.zeros(n, np.uint8)
+            ref.svref_terminate_sequence(n, _p(it), _p(chi), C.c_double(thr), install, _p(raised_r), _p(last_r), _p(by_r))
+            np.testing.assert_array_equal(raised_r, raised_o)
+            np.testing.assert_array_equal(last_r, last_o)
+            assert by_r[-1] == (1 if raised_o.any() else 0)   # sticky until a "reset" call
+    # the reset call (iteration < 0) lowers the flag and clears stopped_by_terminate_action_
+    it = np.array([0, 1, -1, 0], np.int32)
+    chi = np.array([100.0, 99.99, 50.0, 50.0])
+    raised, last, by = np.zeros(4, np.uint8), np.zeros(4), np.zeros(4, np.uint8)
+    ref.svref_terminate_sequence(4, _p(it), _p(chi), C.c_double(1e-3), 1, _p(raised), _p(last), _p(by))
+    assert list(raised) == [0, 1, 0, 0] and list(by) == [0, 1, 0, 0]
