@@ -914,7 +914,8 @@ __device__ __forceinline__ int wave_sum(int v) {
 // per keypoint but measured slower, 121-136 us against 109: the longer per-wave chains of dependent patch fetches cost
 // more than the saved issue slots.)
 #ifndef DESC_KPW
-#define DESC_KPW 4  // keypoints per wave (3 / 2: 67 / 57 VGPRs and 18 / 12 KB of LDS, i.e. more waves per SIMD -- measured: no change, the kernel is not occupancy-limited)
+#define DESC_KPW 4  // keypoints per wave.  Same-box runs of the pipeline: 2 / 3 / 4 / 5 / 6 / 8 -> 207 / 207.5 / 208.9 / 210.3 / 208.9 / 206 k frames/s: flat (fewer
+                    // keypoints mean more waves per SIMD, more of them amortise the orientation pass: neither is what limits the kernel)
 #endif
 #define DESC_IP 32                     // LDS row pitch of the 31 x 31 patch (8 dwords)
 #define DESC_BP 40                     // LDS row pitch of the 37 x 37 patch
