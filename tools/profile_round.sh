@@ -18,17 +18,19 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f -o p --output-format csv --
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_w.log
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_gi -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_gi.log
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc_act -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_act.log
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_lds.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_local -o k --output-format csv -- python $R/tools/ba_prof.py local > /dev/null 2> $OUT/ba_local.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_global -o k --output-format csv -- python $R/tools/ba_prof.py global > /dev/null 2> $OUT/ba_global.log
 cd $R
 python tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w profiles/${TAG}_traffic.json 256 > /dev/null
 python tools/pmc_valu.py $OUT/pmc_gi profiles/${TAG}_valu_issue.json 256 $OUT/pmc_act > /dev/null
-cp profiles/${TAG}_traffic.json profiles/${TAG}_valu_issue.json $OUT/
+python tools/pmc_lds_mfma.py $OUT/pmc_lds profiles/${TAG}_lds_mfma.json 256 > $OUT/lds_mfma.log 2>&1
+cp profiles/${TAG}_traffic.json profiles/${TAG}_valu_issue.json profiles/${TAG}_lds_mfma.json $OUT/
 timeout 400 python bench.py 2> $OUT/bench.log < /dev/null | tail -1 > $OUT/bench.json
 timeout 300 python tools/ba_bench.py --global > $OUT/ba_bench.log 2>&1 < /dev/null
 cp gpurun_out/ba_bench.json $OUT/ba_bench.json 2>/dev/null
 # keep the merge-back small: the raw traces stay on the box, the summaries travel
 rm -f $OUT/ks/*kernel_trace.csv $OUT/ba_local/*kernel_trace.csv $OUT/ba_global/*kernel_trace.csv
-rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_gi $OUT/pmc_act
+rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_gi $OUT/pmc_act $OUT/pmc_lds
 ls -la $OUT $OUT/ks | head -40
 tail -c 600 $OUT/bench.json
