@@ -219,6 +219,7 @@ def main() -> int:
     # kernel sources they were taken on: every profiles/*_traffic.json / *_valu_issue.json carries the csrc hash of its run
     src_hash = csrc_hash()
     traffic_json, valu_json = load_profile_json("*_traffic.json", src_hash, B, world), load_profile_json("*_valu_issue.json", src_hash, B, world)
+    lds_json = load_profile_json("*_lds_mfma.json", src_hash, B, world)  # LDS busy / bank-conflict and matrix-pipe busy fractions (tools/pmc_lds_mfma.py)
 
     def traffic_of(name):
         return None if traffic_json is None else traffic_json["kernels"].get(name, {}).get("total")
@@ -241,6 +242,11 @@ def main() -> int:
                  "mean_launch_ms": round(kms / kn, 5), "launches_per_step": kn,
                  ("algorithmic_bytes_per_launch" if b_ == "hbm" else "algorithmic_ops_per_launch"): int(per_launch),
                  "traffic": traffic_of(name)}
+        if lds_json is not None and name in lds_json["kernels"]:
+            lk = lds_json["kernels"][name]
+            entry["lds_util"], entry["lds_bank_conflict_frac"] = lk["lds_util"], lk["lds_bank_conflict_frac"]
+            if lk.get("mfma_busy_frac"):
+                entry["mfma_busy_frac"] = lk["mfma_busy_frac"]
         if name == "k_bf_topk":
             # the distance kernel multiplies only the candidate pairs inside the +-30 degree angle windows of robust.cc:279
             entry["note"] = ("algorithmic ops = all N1 x N2 pairs x 256 bit positions x 2 (the reference's work); the kernel multiplies only the "
