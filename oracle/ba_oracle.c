@@ -30,7 +30,7 @@
  * (optimize/internal/landmark_vertex.h, se3/shot_vertex.h, se3/*_reproj_edge.h, se3/*_pose_opt_edge.h, se3/*_wrapper.h) -- is pinned
  * bit for bit against the reference's compiled headers (oracle/ref_local -> oracle/_ref/libsvref_opt.so, tests/test_ref_local_optimize.py:
  * errors, both Jacobian blocks, depth gate, chi2, information, Huber width, levels, oplus; optimize/terminate_action.cc over a scripted
- * optimizer).  g2o's side (LM schedule, block solver,
+ * optimizer; optimize/pose_optimizer_g2o.cc with this file's pose-only LM behind g2o's optimize(): schedule, gating, return value).  g2o's side (LM schedule, block solver,
  * SE3Quat arithmetic, robust weighting) stays "parity unpinned": the reference has no test under test/stella_vslam/optimize/ and g2o
  * cannot be built here.  That part is cross-checked against scipy.optimize.least_squares and known
  * ground truth on synthetic scenes (tests/test_oracle_ba.py).  Vertex ordering in the reference is
@@ -858,45 +858,34 @@ int orc_local_ba(int P, int L, int E, const double* pose_cw, const uint8_t* pose
  * never sends the "iteration -1" reset, hence once the gain rule has fired the later rounds run zero LM iterations
  * (reset_flag_each_round = 0, the literal behaviour; 1 = reset per round, the behaviour if g2o did send that reset).
  * Returns num_valid (0 when fewer than 5 observations), pose_out 3x4 row-major, outlier[n]. */
-int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const float* uvr, const float* inv_sigma_sq,
-                      const float* huber_delta, const double* intr, int num_trials_robust, int num_trials, int num_each_iter,
-                      double gain_thr, int reset_flag_each_round, double* pose_out, uint8_t* outlier, double* stats) {
-    se3q T;
+/* errors of observation i at pose T (pose-only edges: *_pose_opt_edge.h computeError) and its chi2 = e^T (inv_sigma_sq I) e */
+static void po_err(const se3q* T, const double* pos_w, const float* uvr, const double* intr, int i, double* err) {
+    double pc[3];
+    se3_map(T, &pos_w[3 * i], pc);
+    double u = intr[0] * pc[0] / pc[2] + intr[2], v = intr[1] * pc[1] / pc[2] + intr[3];
+    if (cam_is_equirect(intr)) equirect_project(intr, pc, &u, &v);
+    err[3 * i] = (double)uvr[3 * i] - u;
+    err[3 * i + 1] = (double)uvr[3 * i + 1] - v;
+    err[3 * i + 2] = (uvr[3 * i + 2] < 0 || cam_is_equirect(intr)) ? 0.0 : (double)uvr[3 * i + 2] - (u - intr[4] / pc[2]);
+}
+static double po_chi(const double* err, const float* inv_sigma_sq, int i) {
+    return (err[3 * i] * err[3 * i] + err[3 * i + 1] * err[3 * i + 1] + err[3 * i + 2] * err[3 * i + 2]) * (double)inv_sigma_sq[i];
+}
+
+/* One SparseOptimizer::optimize(num_each_iter) of the pose-only graph: Levenberg-Marquardt over the level-0 edges with their kernels,
+ * the terminate rule behind every iteration (its _lastChi and the stop flag outlive the call, as the action object and g2o's flag do).
+ * Returns the LM iterations run. */
+static int po_optimize(se3q* Tp, int n, const double* pos_w, const float* uvr, const float* inv_sigma_sq, const float* huber_delta,
+                       const double* intr, const uint8_t* level, const uint8_t* robust, int num_each_iter, double gain_thr, uint8_t* flagp,
+                       double* last_chip, double* err) {
+    se3q T = *Tp;
+    uint8_t flag = *flagp;
+    double last_chi = *last_chip;
+    int total_iters = 0, nact = 0;
+    for (int i = 0; i < n; ++i) nact += !level[i];
+#define PO_ERR(i, Tq) po_err((Tq), pos_w, uvr, intr, (i), err);
+#define PO_CHI(i) po_chi(err, inv_sigma_sq, (i))
     {
-        const double R[9] = {pose_cw[0], pose_cw[1], pose_cw[2], pose_cw[4], pose_cw[5], pose_cw[6], pose_cw[8], pose_cw[9], pose_cw[10]};
-        quat_from_R(R, T.q);
-        T.t[0] = pose_cw[3];
-        T.t[1] = pose_cw[7];
-        T.t[2] = pose_cw[11];
-        quat_normalize(&T);
-    }
-    memcpy(pose_out, pose_cw, sizeof(double) * 12);
-    for (int i = 0; i < n; ++i) outlier[i] = 0;
-    if (stats) memset(stats, 0, sizeof(double) * 4);
-    if (n < 5) return 0;
-    uint8_t* level = (uint8_t*)calloc(n, 1);
-    uint8_t* robust = (uint8_t*)malloc(n);
-    double* err = (double*)calloc(3 * (size_t)n, sizeof(double));
-    for (int i = 0; i < n; ++i) robust[i] = (num_trials_robust != 0) && huber_delta[i] > 0;
-#define PO_ERR(i, Tq)                                                                     \
-    {                                                                                     \
-        double pc_[3];                                                                    \
-        se3_map((Tq), &pos_w[3 * (i)], pc_);                                              \
-        double u_ = intr[0] * pc_[0] / pc_[2] + intr[2], v_ = intr[1] * pc_[1] / pc_[2] + intr[3]; \
-        if (cam_is_equirect(intr)) equirect_project(intr, pc_, &u_, &v_);                 \
-        err[3 * (i)] = (double)uvr[3 * (i)] - u_;                                         \
-        err[3 * (i) + 1] = (double)uvr[3 * (i) + 1] - v_;                                 \
-        err[3 * (i) + 2] = (uvr[3 * (i) + 2] < 0 || cam_is_equirect(intr)) ? 0.0 : (double)uvr[3 * (i) + 2] - (u_ - intr[4] / pc_[2]); \
-    }
-#define PO_CHI(i) ((err[3 * (i)] * err[3 * (i)] + err[3 * (i) + 1] * err[3 * (i) + 1] + err[3 * (i) + 2] * err[3 * (i) + 2]) * (double)inv_sigma_sq[i])
-    uint8_t flag = 0;
-    double last_chi = 0;
-    int num_bad = 0, total_iters = 0;
-    for (int trial = 0; trial < num_trials_robust + num_trials; ++trial) {
-        if (reset_flag_each_round) flag = 0;
-        int nact = 0;
-        for (int i = 0; i < n; ++i) nact += !level[i];
-        /* ---- optimizer.optimize(num_each_iter) */
         int ok = 1;
         double lambda = 0, ni = 2;
         for (int it = 0; it < num_each_iter && !flag && ok && nact > 0; ++it) {
@@ -979,12 +968,48 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
             ++total_iters;
             if (terminate_rule(&last_chi, it, cur, gain_thr)) flag = 1;
         }
+    }
+#undef PO_ERR
+#undef PO_CHI
+    *Tp = T;
+    *flagp = flag;
+    *last_chip = last_chi;
+    return total_iters;
+}
+
+int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const float* uvr, const float* inv_sigma_sq,
+                      const float* huber_delta, const double* intr, int num_trials_robust, int num_trials, int num_each_iter,
+                      double gain_thr, int reset_flag_each_round, double* pose_out, uint8_t* outlier, double* stats) {
+    se3q T;
+    {
+        const double R[9] = {pose_cw[0], pose_cw[1], pose_cw[2], pose_cw[4], pose_cw[5], pose_cw[6], pose_cw[8], pose_cw[9], pose_cw[10]};
+        quat_from_R(R, T.q);
+        T.t[0] = pose_cw[3];
+        T.t[1] = pose_cw[7];
+        T.t[2] = pose_cw[11];
+        quat_normalize(&T);
+    }
+    memcpy(pose_out, pose_cw, sizeof(double) * 12);
+    for (int i = 0; i < n; ++i) outlier[i] = 0;
+    if (stats) memset(stats, 0, sizeof(double) * 4);
+    if (n < 5) return 0;
+    uint8_t* level = (uint8_t*)calloc(n, 1);
+    uint8_t* robust = (uint8_t*)malloc(n);
+    double* err = (double*)calloc(3 * (size_t)n, sizeof(double));
+    for (int i = 0; i < n; ++i) robust[i] = (num_trials_robust != 0) && huber_delta[i] > 0;
+    uint8_t flag = 0;
+    double last_chi = 0;
+    int num_bad = 0, total_iters = 0;
+    for (int trial = 0; trial < num_trials_robust + num_trials; ++trial) {
+        if (reset_flag_each_round) flag = 0;
+        /* ---- optimizer.optimize(num_each_iter) */
+        total_iters += po_optimize(&T, n, pos_w, uvr, inv_sigma_sq, huber_delta, intr, level, robust, num_each_iter, gain_thr, &flag, &last_chi, err);
         /* ---- re-classification at the current pose (:127-160) */
         num_bad = 0;
         for (int i = 0; i < n; ++i) {
-            PO_ERR(i, &T)
+            po_err(&T, pos_w, uvr, intr, i, err);
             const float thr = uvr[3 * i + 2] < 0 ? 5.99146f : 7.81473f;
-            if ((double)thr < PO_CHI(i)) {
+            if ((double)thr < po_chi(err, inv_sigma_sq, i)) {
                 outlier[i] = 1;
                 level[i] = 1;
                 ++num_bad;
@@ -997,8 +1022,6 @@ int orc_pose_optimize(const double* pose_cw, int n, const double* pos_w, const f
         }
         if (n - num_bad < 5) break;
     }
-#undef PO_ERR
-#undef PO_CHI
     double R[9];
     quat_to_R(T.q, R);
     for (int i = 0; i < 3; ++i) {
@@ -1071,4 +1094,19 @@ void orc_dbg_terminate(int n, const int* iteration, const double* chi2, double g
         stop[k] = (uint8_t)terminate_rule(&last, iteration[k], chi2[k], gain_thr);
         last_chi_out[k] = last;
     }
+}
+/* one optimize(num_each_iter) call of the pose-only graph on caller-held state (q4 / t3 pose, level / robust per observation, the stop flag
+ * and _lastChi): what oracle/ref_local's g2o stand-in runs behind the reference's pose_optimizer_g2o.cc */
+int orc_dbg_pose_lm(double* q4, double* t3, int n, const double* pos_w, const float* uvr, const float* inv_sigma_sq, const float* huber_delta,
+                    const double* intr, const uint8_t* level, const uint8_t* robust, int num_each_iter, double gain_thr, uint8_t* flag,
+                    double* last_chi) {
+    se3q T;
+    memcpy(T.q, q4, sizeof(T.q));
+    memcpy(T.t, t3, sizeof(T.t));
+    double* err = (double*)calloc(3 * (size_t)(n > 0 ? n : 1), sizeof(double));
+    const int iters = po_optimize(&T, n, pos_w, uvr, inv_sigma_sq, huber_delta, intr, level, robust, num_each_iter, gain_thr, flag, last_chi, err);
+    free(err);
+    memcpy(q4, T.q, sizeof(T.q));
+    memcpy(t3, T.t, sizeof(T.t));
+    return iters;
 }

@@ -5,6 +5,10 @@
 #include <cstring>
 #include <memory>
 
+#include "stella_vslam/data/frame.h"
+#include "stella_vslam/data/keyframe.h"
+#include "stella_vslam/feature/orb_params.h"
+#include "stella_vslam/optimize/pose_optimizer_g2o.h"
 #include "stella_vslam/optimize/terminate_action.h"
 #include "stella_vslam/optimize/internal/se3/pose_opt_edge_wrapper.h"
 #include "stella_vslam/optimize/internal/se3/reproj_edge_wrapper.h"
@@ -12,11 +16,9 @@
 using namespace stella_vslam;
 using namespace stella_vslam::optimize::internal;
 
-namespace stella_vslam {
-namespace data {
-class landmark {};
-}  // namespace data
-}  // namespace stella_vslam
+extern "C" int orc_dbg_pose_lm(double* q4, double* t3, int n, const double* pos_w, const float* uvr, const float* inv_sigma_sq, const float* huber_delta,
+                               const double* intr, const uint8_t* level, const uint8_t* robust, int num_each_iter, double gain_thr, uint8_t* flag,
+                               double* last_chi);
 
 namespace {
 // what reproj_edge_wrapper<T> reads of its keyframe (reproj_edge_wrapper.h:61)
@@ -163,5 +165,93 @@ void svref_terminate_sequence(int n, const int* iteration, const double* chi2, d
         last_chi[k] = act.lastChi();
         by_action[k] = act.stopped_by_terminate_action_ ? 1 : 0;
     }
+}
+
+// optimize/pose_optimizer_g2o.cc, compiled from the reference: edge creation (null / erased landmarks skipped, fewer than five -> 0),
+// the rounds of optimize(num_each_iter) + chi-square classification, the removal of the kernels, the early exit and the return value are
+// the reference's code; optimizer.optimize() itself -- g2o -- is the oracle's pose-only Levenberg-Marquardt with its terminate rule
+// (orc_dbg_pose_lm), whose _lastChi and stop flag live in the stand-in optimizer; reset_each_round = g2o sending the "iteration -1" call.
+// lm_state per keypoint: 0 = no landmark, 1 = landmark, 2 = landmark that will be erased.  overload: 0 = frame, 1 = keyframe, 2 = the flat one.
+int svref_pose_optimize(int model, int stereo_cam, unsigned cols, unsigned rows, const double* intr5, const double* pose_cw12, int n_kp,
+                        const float* kp_xy, const int* octave, const float* x_right, const double* pos_w, const uint8_t* lm_state,
+                        float scale_factor, int num_levels, int trials_robust, int trials, int each_iter, int reset_each_round, int overload,
+                        double* pose_out12, uint8_t* outlier_flags, int* lm_iterations) {
+    auto cam = make(model, stereo_cam, cols, rows, intr5);
+    feature::orb_params orb("ref", scale_factor, num_levels, 20, 7);
+    data::keyframe frm;
+    frm.pose_cw_ = Mat44_t::Identity();
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) frm.pose_cw_(i, j) = pose_cw12[4 * i + j];
+    frm.orb_params_ = &orb;
+    frm.camera_ = cam.get();
+    for (int i = 0; i < n_kp; ++i) {
+        cv::KeyPoint kp;
+        kp.pt.x = kp_xy[2 * i];
+        kp.pt.y = kp_xy[2 * i + 1];
+        kp.octave = octave[i];
+        frm.frm_obs_.undist_keypts_.push_back(kp);
+        if (x_right) frm.frm_obs_.stereo_x_right_.push_back(x_right[i]);
+        frm.landmarks_.push_back(lm_state[i] ? std::make_shared<data::landmark>(Vec3_t(pos_w[3 * i], pos_w[3 * i + 1], pos_w[3 * i + 2]), lm_state[i] == 2)
+                                             : std::shared_ptr<data::landmark>());
+    }
+    int total_iters = 0;
+    g2o::SparseOptimizer::default_hook() = [&](g2o::SparseOptimizer& o, int iters) -> int {
+        auto* v = dynamic_cast<se3::shot_vertex*>(o.vertices().at(0));
+        const size_t n = o.edges().size();
+        std::vector<double> pw(3 * n);
+        std::vector<float> uvr(3 * n), w(n), hub(n);
+        std::vector<uint8_t> level(n), robust(n);
+        double K[5] = {intr5[0], intr5[1], intr5[2], intr5[3], intr5[4]};
+        for (size_t k = 0; k < n; ++k) {
+            auto* e = o.edges()[k];
+            level[k] = e->level() != 0;
+            robust[k] = e->robustKernel() != nullptr;
+            hub[k] = robust[k] ? (float)e->robustKernel()->delta() : 0.f;
+            if (auto* m = dynamic_cast<se3::mono_perspective_pose_opt_edge*>(e)) {
+                for (int c = 0; c < 3; ++c) pw[3 * k + c] = m->pos_w_(c);
+                uvr[3 * k] = (float)m->measurement()(0), uvr[3 * k + 1] = (float)m->measurement()(1), uvr[3 * k + 2] = -1.f;
+                w[k] = (float)m->information()(0, 0);
+                K[0] = m->fx_, K[1] = m->fy_, K[2] = m->cx_, K[3] = m->cy_;
+            }
+            else if (auto* s3 = dynamic_cast<se3::stereo_perspective_pose_opt_edge*>(e)) {
+                for (int c = 0; c < 3; ++c) pw[3 * k + c] = s3->pos_w_(c);
+                for (int c = 0; c < 3; ++c) uvr[3 * k + c] = (float)s3->measurement()(c);
+                w[k] = (float)s3->information()(0, 0);
+                K[0] = s3->fx_, K[1] = s3->fy_, K[2] = s3->cx_, K[3] = s3->cy_, K[4] = s3->focal_x_baseline_;
+            }
+            else {
+                auto* q = dynamic_cast<se3::equirectangular_pose_opt_edge*>(e);
+                for (int c = 0; c < 3; ++c) pw[3 * k + c] = q->pos_w_(c);
+                uvr[3 * k] = (float)q->measurement()(0), uvr[3 * k + 1] = (float)q->measurement()(1), uvr[3 * k + 2] = -1.f;
+                w[k] = (float)q->information()(0, 0);
+                K[0] = 0, K[1] = 0, K[2] = q->cols_, K[3] = q->rows_, K[4] = 0;
+            }
+        }
+        double gain_thr = 1e-6;
+        for (auto* a : o.post_iteration_actions)
+            if (auto* t = dynamic_cast<g2o::SparseOptimizerTerminateAction*>(a)) gain_thr = t->gainThreshold();
+        if (reset_each_round) o.lm_stop = 0;
+        g2o::SE3Quat T = v->estimate();
+        const int it = orc_dbg_pose_lm(T.q, T.t, (int)n, pw.data(), uvr.data(), w.data(), hub.data(), K, level.data(), robust.data(), iters, gain_thr,
+                                       &o.lm_stop, &o.lm_last_chi);
+        v->setEstimate(T);
+        for (auto* e : o.edges())
+            if (e->level() == o.active_level) e->computeError();  // what the last computeActiveErrors of the run leaves behind
+        total_iters += it;
+        return it;
+    };
+    optimize::pose_optimizer_g2o opt((unsigned)trials_robust, (unsigned)trials, (unsigned)each_iter);
+    Mat44_t out = frm.pose_cw_;
+    std::vector<bool> flags;
+    unsigned int valid;
+    if (overload == 0) valid = opt.optimize(static_cast<const data::frame&>(frm), out, flags);
+    else if (overload == 1) valid = opt.optimize(&frm, out, flags);
+    else valid = opt.optimize(frm.pose_cw_, frm.frm_obs_, frm.orb_params_, frm.camera_, frm.landmarks_, out, flags);
+    g2o::SparseOptimizer::default_hook() = nullptr;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) pose_out12[4 * i + j] = out(i, j);
+    for (int i = 0; i < n_kp; ++i) outlier_flags[i] = i < (int)flags.size() && flags[i] ? 1 : 0;
+    if (lm_iterations) *lm_iterations = total_iters;
+    return (int)valid;
 }
 }

@@ -35,6 +35,15 @@ public:
     };
     Rot rotation() const { return Rot{q}; }
     stella_vslam::Vec3_t translation() const { return stella_vslam::Vec3_t(t[0], t[1], t[2]); }
+    stella_vslam::Mat44_t to_homogeneous_matrix() const {
+        stella_vslam::Mat44_t M = stella_vslam::Mat44_t::Identity();
+        const stella_vslam::Mat33_t R = rotation().toRotationMatrix();
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) M(i, j) = R(i, j);
+            M(i, 3) = t[i];
+        }
+        return M;
+    }
     stella_vslam::Vec3_t map(const stella_vslam::Vec3_t& p) const {
         stella_vslam::Vec3_t o;
         orc_dbg_se3_map(q, t, p.data(), o.data());

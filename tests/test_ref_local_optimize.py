@@ -144,3 +144,90 @@ def test_terminate_action(ref):
     raised, last, by = np.zeros(4, np.uint8), np.zeros(4), np.zeros(4, np.uint8)
     ref.svref_terminate_sequence(4, _p(it), _p(chi), C.c_double(1e-3), 1, _p(raised), _p(last), _p(by))
     assert list(raised) == [0, 1, 0, 0] and list(by) == [0, 1, 0, 0]
+
+
+def _pose_scene(rng, model, stereo, n):
+    """A camera pose, n keypoints with landmarks around the true pose, a share of gross outliers, some keypoints without a landmark
+    and some whose landmark is about to be erased."""
+    q, t = _random_pose(rng)
+    Rr = np.zeros(9)
+    O.lib().orc_dbg_quat_to_R(_p(q), _p(Rr))
+    R = Rr.reshape(3, 3)
+    cols, rows = (1920, 960) if model == 2 else (1280, 720)
+    intr = np.array([600.0, 610.0, 640.0, 360.0, 45.0 if stereo else 0.0])
+    pc = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(2, 15, n)], 1)
+    if model == 2:
+        pc = rng.normal(size=(n, 3)) * rng.uniform(2, 10, (n, 1))
+        pc = pc[np.abs(np.arctan2(pc[:, 0], pc[:, 2])) < 2.6][: n]
+        n = len(pc)
+    pw = (pc - t) @ R   # R^T (pc - t)
+    octave = rng.integers(0, 8, n).astype(np.int32)
+    sig = 1.2 ** octave
+    if model == 2:
+        L = np.linalg.norm(pc, axis=1)
+        u = cols * (0.5 + np.arctan2(pc[:, 0], pc[:, 2]) / (2 * np.pi))
+        v = rows * (0.5 + np.arcsin(pc[:, 1] / L) / np.pi)
+    else:
+        u = intr[0] * pc[:, 0] / pc[:, 2] + intr[2]
+        v = intr[1] * pc[:, 1] / pc[:, 2] + intr[3]
+    kp = np.stack([u + rng.normal(0, 1, n) * sig, v + rng.normal(0, 1, n) * sig], 1)
+    bad = rng.uniform(size=n) < 0.15
+    kp[bad] += rng.uniform(15, 60, (int(bad.sum()), 2)) * rng.choice([-1, 1], (int(bad.sum()), 2))
+    xr = None
+    if stereo:
+        xr = (kp[:, 0] - intr[4] / pc[:, 2] + rng.normal(0, 1, n) * sig).astype(np.float32)
+        xr[rng.uniform(size=n) < 0.3] = -1.0   # no stereo match for this keypoint
+    state = np.ones(n, np.uint8)
+    state[rng.uniform(size=n) < 0.1] = 0
+    state[rng.uniform(size=n) < 0.05] = 2
+    # the initial pose: the true one, perturbed
+    dq = np.concatenate([rng.normal(0, 0.01, 3), [1.0]])
+    q0 = np.array([dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1], dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0],
+                   dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3], dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2]])
+    q0 /= np.linalg.norm(q0)
+    R0 = np.zeros(9)
+    O.lib().orc_dbg_quat_to_R(_p(np.ascontiguousarray(q0)), _p(R0))
+    pose = np.concatenate([R0.reshape(3, 3), (t + rng.normal(0, 0.05, 3))[:, None]], 1).reshape(-1)
+    return dict(cols=cols, rows=rows, intr=intr, pose=np.ascontiguousarray(pose), kp=np.ascontiguousarray(kp, dtype=np.float32), octave=octave, xr=xr,
+                pw=np.ascontiguousarray(pw), state=state, n=n)
+
+
+@pytest.mark.parametrize("model,stereo", [(0, 0), (0, 1), (1, 0), (2, 0), (3, 1)])
+def test_pose_optimizer_schedule(ref, model, stereo):
+    """optimize/pose_optimizer_g2o.cc compiled from the reference (all three overloads), with g2o's optimize() played by the oracle's own
+    pose-only Levenberg-Marquardt: which keypoints get an edge, the rounds, the chi-square classification with its float thresholds,
+    the kernel removal after the robust rounds, the early exit below five inliers and the returned count must equal the oracle's
+    orc_pose_optimize -- pose and outlier flags bit for bit, for both readings of g2o's "iteration -1" call."""
+    rng = np.random.default_rng(300 + 10 * model + stereo)
+    lib = O.lib()
+    for trial in range(40):
+        n = int(rng.choice([3, 6, 40, 300]))
+        sc = _pose_scene(rng, model, stereo, n)
+        n = sc["n"]
+        tr, tn, each = [(2, 2, 10), (0, 3, 5), (2, 0, 10), (1, 1, 3)][trial % 4]
+        for reset in (0, 1):
+            pose_r, flags_r, its_r = np.zeros(12), np.zeros(n, np.uint8), C.c_int(0)
+            ref.svref_pose_optimize.restype = C.c_int
+            valid_r = ref.svref_pose_optimize(model, stereo, sc["cols"], sc["rows"], _p(sc["intr"]), _p(sc["pose"]), n, _p(sc["kp"]), _p(sc["octave"]),
+                                              None if sc["xr"] is None else _p(sc["xr"]), _p(sc["pw"]), _p(sc["state"]), C.c_float(1.2), 8, tr, tn, each,
+                                              reset, trial % 3, _p(pose_r), _p(flags_r), C.byref(its_r))
+            # the oracle takes the observations that have a live landmark, as the adaptors gather them
+            keep = np.flatnonzero(sc["state"] == 1)
+            m = len(keep)
+            uvr = np.concatenate([sc["kp"][keep], (sc["xr"][keep] if sc["xr"] is not None else np.full(m, -1, np.float32))[:, None]], 1).astype(np.float32)
+            w = np.array([O.scale_tables(1.2, 8)[3][o] for o in sc["octave"][keep]], np.float32)
+            pw_k, uvr = np.ascontiguousarray(sc["pw"][keep]), np.ascontiguousarray(uvr)   # (kept alive across the call)
+            hub = np.full(m, np.float32(np.sqrt(np.float32(7.81473))) if stereo else np.float32(np.sqrt(np.float32(5.99146))), np.float32)
+            K5 = sc["intr"].copy() if model != 2 else np.array([0.0, 0.0, sc["cols"], sc["rows"], 0.0])
+            pose_o, out_o, stats = np.zeros(12), np.zeros(max(m, 1), np.uint8), np.zeros(4)
+            lib.orc_pose_optimize.restype = C.c_int
+            valid_o = lib.orc_pose_optimize(_p(sc["pose"]), m, _p(pw_k), _p(uvr), _p(w), _p(hub), _p(K5),
+                                            tr, tn, each, C.c_double(1e-3), reset, _p(pose_o), _p(out_o), _p(stats))
+            assert valid_r == valid_o
+            if m >= 5:
+                np.testing.assert_array_equal(flags_r[keep], out_o[:m])
+                assert not flags_r[sc["state"] != 1].any()
+                np.testing.assert_allclose(pose_r, pose_o, rtol=0, atol=1e-15)
+                assert its_r.value == int(stats[0])
+            else:
+                np.testing.assert_array_equal(pose_r, sc["pose"])   # fewer than five observations: nothing is touched
