@@ -30,7 +30,8 @@
  * (optimize/internal/landmark_vertex.h, se3/shot_vertex.h, se3/*_reproj_edge.h, se3/*_pose_opt_edge.h, se3/*_wrapper.h) -- is pinned
  * bit for bit against the reference's compiled headers (oracle/ref_local -> oracle/_ref/libsvref_opt.so, tests/test_ref_local_optimize.py:
  * errors, both Jacobian blocks, depth gate, chi2, information, Huber width, levels, oplus; optimize/terminate_action.cc over a scripted
- * optimizer; optimize/pose_optimizer_g2o.cc with this file's pose-only LM behind g2o's optimize(): schedule, gating, return value).  g2o's side (LM schedule, block solver,
+ * optimizer; optimize/pose_optimizer_g2o.cc and optimize/local_bundle_adjuster_g2o.cc with this file's LM behind g2o's optimize(): gather,
+ * graph, schedule, gating, outlier list, write-back, return value -- tests/test_ref_local_ba.py).  g2o's side (LM schedule, block solver,
  * SE3Quat arithmetic, robust weighting) stays "parity unpinned": the reference has no test under test/stella_vslam/optimize/ and g2o
  * cannot be built here.  That part is cross-checked against scipy.optimize.least_squares and known
  * ground truth on synthetic scenes (tests/test_oracle_ba.py).  Vertex ordering in the reference is
@@ -1109,4 +1110,51 @@ int orc_dbg_pose_lm(double* q4, double* t3, int n, const double* pos_w, const fl
     memcpy(q4, T.q, sizeof(T.q));
     memcpy(t3, T.t, sizeof(T.t));
     return iters;
+}
+/* one SparseOptimizer::optimize(iterations) of the BA graph on caller-held state (poses as q4 / t3, points, per-edge level / kernel flags,
+ * cached errors): what oracle/ref_local's g2o stand-in runs behind the reference's local_bundle_adjuster_g2o.cc.  err (E x 3) goes in and
+ * out: the errors g2o would have cached on the edges. */
+int orc_dbg_ba_lm(int P, int L, int E, double* q4, double* t3, const uint8_t* pose_fixed, double* pts, const uint8_t* point_fixed,
+                  const int32_t* obs_pose, const int32_t* obs_point, const float* obs_uvr, const float* obs_inv_sigma_sq, const float* obs_huber,
+                  const uint8_t* level, const uint8_t* robust, const double* intr, int iterations, double gain_thr, uint8_t* stop, double* err) {
+    ba_t B;
+    memset(&B, 0, sizeof(B));
+    B.P = P, B.L = L, B.E = E;
+    B.pose_fixed = pose_fixed, B.point_fixed = point_fixed;
+    B.obs_pose = obs_pose, B.obs_point = obs_point, B.obs_uvr = obs_uvr, B.obs_inv_sigma_sq = obs_inv_sigma_sq, B.obs_huber = obs_huber;
+    B.intr = intr;
+    B.pose = (se3q*)malloc(sizeof(se3q) * (P + 1));
+    B.pt = pts;
+    B.level = (uint8_t*)malloc(E + 1);
+    B.robust = (uint8_t*)malloc(E + 1);
+    B.err = err;
+    B.pose_slot = (int*)malloc(sizeof(int) * (P + 1));
+    B.point_slot = (int*)malloc(sizeof(int) * (L + 1));
+    for (int p = 0; p < P; ++p) {
+        memcpy(B.pose[p].q, q4 + 4 * p, sizeof(double) * 4);
+        memcpy(B.pose[p].t, t3 + 3 * p, sizeof(double) * 3);
+    }
+    memcpy(B.level, level, E);
+    memcpy(B.robust, robust, E);
+    int* off = (int*)calloc(L + 2, sizeof(int));
+    int* items = (int*)malloc(sizeof(int) * (E + 1));
+    for (int e = 0; e < E; ++e) off[obs_point[e] + 1]++;
+    for (int l = 0; l < L; ++l) off[l + 1] += off[l];
+    int* fill = (int*)calloc(L + 1, sizeof(int));
+    for (int e = 0; e < E; ++e) items[off[obs_point[e]] + fill[obs_point[e]]++] = e;
+    free(fill);
+    uint8_t aux = 0;
+    const int it = optimize(&B, iterations, gain_thr, stop ? stop : &aux, off, items, NULL);
+    for (int p = 0; p < P; ++p) {
+        memcpy(q4 + 4 * p, B.pose[p].q, sizeof(double) * 4);
+        memcpy(t3 + 3 * p, B.pose[p].t, sizeof(double) * 3);
+    }
+    free(off);
+    free(items);
+    free(B.pose);
+    free(B.level);
+    free(B.robust);
+    free(B.pose_slot);
+    free(B.point_slot);
+    return it;
 }
