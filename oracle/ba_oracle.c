@@ -30,7 +30,7 @@
  * (optimize/internal/landmark_vertex.h, se3/shot_vertex.h, se3/*_reproj_edge.h, se3/*_pose_opt_edge.h, se3/*_wrapper.h) -- is pinned
  * bit for bit against the reference's compiled headers (oracle/ref_local -> oracle/_ref/libsvref_opt.so, tests/test_ref_local_optimize.py:
  * errors, both Jacobian blocks, depth gate, chi2, information, Huber width, levels, oplus; optimize/terminate_action.cc over a scripted
- * optimizer; optimize/pose_optimizer_g2o.cc and optimize/local_bundle_adjuster_g2o.cc with this file's LM behind g2o's optimize(): gather,
+ * optimizer; optimize/pose_optimizer_g2o.cc, local_bundle_adjuster_g2o.cc and global_bundle_adjuster.cc with this file's LM behind g2o's optimize(): gather,
  * graph, schedule, gating, outlier list, write-back, return value -- tests/test_ref_local_ba.py).  g2o's side (LM schedule, block solver,
  * SE3Quat arithmetic, robust weighting) stays "parity unpinned": the reference has no test under test/stella_vslam/optimize/ and g2o
  * cannot be built here.  That part is cross-checked against scipy.optimize.least_squares and known

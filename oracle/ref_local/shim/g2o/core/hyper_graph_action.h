@@ -62,6 +62,16 @@ public:
         _edges.push_back(e);
         return true;
     }
+    bool removeVertex(OptimizableGraph::Vertex* v) {
+        for (size_t i = 0; i < _vertices.size(); ++i)
+            if (_vertices[i] == v) {
+                _vertices.erase(_vertices.begin() + (long)i);
+                delete v;
+                return true;
+            }
+        return false;
+    }
+    void setVerbose(bool) {}
     bool initializeOptimization(int level = 0) {
         active_level = level;
         ++num_initializations;
@@ -99,6 +109,8 @@ class LinearSolverEigen {
 public:
     virtual ~LinearSolverEigen() = default;
 };
+template <typename M>
+class LinearSolverCSparse : public LinearSolverEigen<M> {};
 class BlockSolverBase {
 public:
     virtual ~BlockSolverBase() = default;

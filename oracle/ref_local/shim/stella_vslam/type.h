@@ -93,6 +93,12 @@ struct Matrix {
     BlockRef<BR, BC> block(int r0, int c0) {
         return BlockRef<BR, BC>(*this, r0, c0);
     }
+    bool operator==(const Matrix& o) const {
+        for (int i = 0; i < R * C; ++i)
+            if (v[i] != o.v[i]) return false;
+        return true;
+    }
+    bool operator!=(const Matrix& o) const { return !(*this == o); }
     void fill(double x) {
         for (int i = 0; i < R * C; ++i) v[i] = x;
     }
