@@ -19,7 +19,8 @@
  * forward distortion model (distort -> undistort round trip) and the zero-distortion identity.
  * Everything ELSE in this file that restates the reference's camera/*.cc (bounds, marshalling, bearings, the two reprojections, the
  * radial-division and equirectangular closed forms) is pinned against the reference's own compiled camera sources
- * (oracle/ref_local -> oracle/_ref/libsvref_cam.so, tests/test_ref_local_camera.py).
+ * (oracle/ref_local -> oracle/_ref/libsvref_cam.so, tests/test_ref_local_camera.py); orc_can_observe against the reference's data/frame.cc
+ * compiled with its real frame.h / landmark.h (libsvref_frm.so, same test file).
  *
  * Pitfall restated on purpose: the reference hands OpenCV a CV_32F camera matrix and CV_32F distortion vector
  * (perspective.cc:21-22, fisheye.cc:21-22), so inside the undistortion fx, fy, cx, cy, k* are the FLOAT-rounded values,

@@ -130,3 +130,48 @@ def test_grid_assignment_and_lookup(ref, name):
     for i in range(nq):
         exp = O.get_keypoints_in_cell(kx, ky, octave, goff, items, bounds, float(q[i, 0]), float(q[i, 1]), float(q[i, 2]), int(lv[i, 0]), int(lv[i, 1]))
         assert np.array_equal(idx[off[i]:off[i + 1]], exp), i
+
+
+_SO_FRM = os.path.join(os.path.dirname(_SO), "libsvref_frm.so")
+
+
+@pytest.mark.parametrize("name", list(CAMS))
+def test_frame_can_observe(name):
+    """data/frame.cc compiled from the reference with its real data/frame.h and data/landmark.h (libsvref_frm.so): frame::set_pose_cw and
+    frame::can_observe -- in-image test through the camera's reproject_to_image, the valid-distance gate with its 1.3 margins, the ray
+    cosine against the landmark's mean normal, the predicted scale level -- against the oracle's can_observe fed with the landmark state
+    the reference's own landmark refresh produced."""
+    if not os.path.exists(_SO_FRM):
+        pytest.skip("oracle/_ref/libsvref_frm.so absent: it is built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    ref = C.CDLL(_SO_FRM)
+    c = CAMS[name]
+    cam = O.make_camera(c["model"], c["cols"], c["rows"], c["fx"], c["fy"], c["cx"], c["cy"], (0,) * len(c["dist"]), c["fxb"])
+    rng = np.random.default_rng(23)
+    n = 6000
+    w = rng.normal(0, 0.3, 3)
+    th = np.linalg.norm(w)
+    Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+    R = np.ascontiguousarray(np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx)
+    t = rng.normal(0, 0.5, 3)
+    pw = np.ascontiguousarray(np.stack([rng.uniform(-8, 8, n), rng.uniform(-5, 5, n), rng.uniform(-3, 14, n)], 1))
+    ref_twc = np.ascontiguousarray(pw + rng.normal(0, 1, (n, 3)) * rng.uniform(0.5, 6, (n, 1)))   # where each landmark was seen from
+    octv = rng.integers(0, 8, n).astype(np.int32)
+    pose = np.ascontiguousarray(np.concatenate([R, t[:, None]], 1).reshape(-1))
+    intr = np.array([c["fx"], c["fy"], c["cx"], c["cy"], c["fxb"]])
+    vis, rp, xr, lv = np.zeros(n, np.uint8), np.zeros((n, 2)), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    nrm, mn, mx, twc = np.zeros((n, 3)), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(3)
+    for thr in (0.5, 0.7):   # the two thresholds the tracker uses (projection.cc / local-map search)
+        ref.svref_frame_can_observe(c["model"], int(c["fxb"] != 0), c["cols"], c["rows"], _p(intr), _p(pose), n, _p(pw), _p(ref_twc), _p(octv), C.c_float(thr),
+                                    C.c_float(1.2), 8, _p(vis), _p(rp), _p(xr), _p(lv), _p(nrm), _p(mn), _p(mx), _p(twc))
+        np.testing.assert_allclose(twc, -R.T @ t, rtol=0, atol=1e-15)
+        e_vis, e_rp, e_xr, e_lv = np.zeros(n, np.uint8), np.zeros((n, 2)), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        O.lib().orc_can_observe(C.byref(cam), _p(R), _p(t), _p(twc), n, _p(pw), _p(nrm), _p(mn), _p(mx), C.c_float(thr), C.c_uint(8),
+                                C.c_float(float(np.log(np.float32(1.2)))), _p(e_vis), _p(e_rp), _p(e_xr), _p(e_lv))
+        assert 50 < vis.sum() < 0.9 * n
+        assert np.array_equal(vis, e_vis)
+        v = vis.astype(bool)
+        assert np.array_equal(lv[v], e_lv[v])
+        tol = 1e-9 if name in ("equirectangular", "fisheye") else 0.0
+        assert np.abs(rp[v] - e_rp[v]).max() <= tol * c["cols"]
+        if tol == 0.0:
+            assert np.array_equal(xr[v].view(np.uint32), e_xr[v].view(np.uint32))
