@@ -71,9 +71,12 @@ svgpu_camera to_svgpu_camera(const camera::base* camera) {
 }  // namespace hip
 
 namespace {
-
 using lm_ptr = std::shared_ptr<data::landmark>;
 using kf_ptr = std::shared_ptr<data::keyframe>;
+}  // namespace
+
+#ifndef SVGPU_DROP_IN_OPTIMIZE_ONLY
+namespace {
 
 // ---- flat views ---------------------------------------------------------------------------------------------------------------
 struct kp_side {  // the keypoint side of a frame / keyframe (data::frame_observation)
@@ -512,6 +515,7 @@ unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm
 
 }  // namespace hip
 }  // namespace match
+#endif  // SVGPU_DROP_IN_OPTIMIZE_ONLY
 
 // ====================================================================================================================== local BA
 namespace optimize {

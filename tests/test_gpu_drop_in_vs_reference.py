@@ -1,0 +1,127 @@
+"""The drop-in bar itself: the reference's optimize::local_bundle_adjuster_g2o (compiled from /root/reference into oracle/_ref/libsvref_ba.so,
+g2o's optimize() played by the oracle's LM) and the PRODUCT's optimize::local_bundle_adjuster_hip (stella_vslam_amd/host/drop_in/hip_backend.cc
+compiled against the very same stand-in data:: headers into oracle/_ref/libsvref_dropin.so, linked to libsvgpu.so) are handed identical
+keyframe / landmark / map objects; the maps they leave behind are compared: which keyframes were written, SE3 poses within 1e-4 relative,
+positions, the erased observations, the landmark refresh calls."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from stella_vslam_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    a, b = os.path.join(_DIR, "libsvref_ba.so"), os.path.join(_DIR, "libsvref_dropin.so")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref/libsvref_{ba,dropin}.so absent: built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    return C.CDLL(a), C.CDLL(b)
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _both(libs, sc, stereo, kf_id, kf_flags, lm_id, lm_erased, covis, curr, threshold, use_additional, iters=(5, 10), stop_in=0):
+    ref, prod = libs
+    K, L, E = len(sc["pose_cw"]), len(sc["points"]), len(sc["obs_pose"])
+    intr = np.ascontiguousarray(sc["intr"][0])
+    idx = np.zeros(E, np.int32)
+    seen = np.zeros(K, np.int64)
+    for e in range(E):
+        idx[e] = seen[sc["obs_pose"][e]]
+        seen[sc["obs_pose"][e]] += 1
+    octv = np.random.default_rng(E).integers(0, 8, E).astype(np.int32)
+    a = dict(kf_id=np.ascontiguousarray(kf_id, np.uint32), kf_pose=np.ascontiguousarray(sc["pose_cw"], np.float64), kf_flags=np.ascontiguousarray(kf_flags, np.uint8),
+             lm_id=np.ascontiguousarray(lm_id, np.uint32), lm_pos=np.ascontiguousarray(sc["points"], np.float64), lm_erased=np.ascontiguousarray(lm_erased, np.uint8),
+             obs_kf=np.ascontiguousarray(sc["obs_pose"], np.int32), obs_lm=np.ascontiguousarray(sc["obs_point"], np.int32), obs_idx=idx,
+             uv=np.ascontiguousarray(sc["obs_uvr"][:, :2], np.float32), xr=np.ascontiguousarray(sc["obs_uvr"][:, 2], np.float32), oct=octv,
+             covis=np.ascontiguousarray(covis, np.int32))
+    head = lambda: (0, stereo, 1280, 720, _p(intr), C.c_float(1.2), 8, K, _p(a["kf_id"]), _p(a["kf_pose"]), _p(a["kf_flags"]), L, _p(a["lm_id"]), _p(a["lm_pos"]),
+                    _p(a["lm_erased"]), E, _p(a["obs_kf"]), _p(a["obs_lm"]), _p(a["obs_idx"]), _p(a["uv"]), _p(a["xr"]), _p(a["oct"]), curr, len(covis),
+                    _p(a["covis"]), threshold, int(use_additional), iters[0], iters[1], stop_in)
+
+    def outs():
+        return dict(kf_pose=np.zeros((K, 12)), lm_pos=np.zeros((L, 3)), n_erased=C.c_int(0), erased=np.zeros(2 * E + 2, np.int32), lm_cnt=np.zeros((L, 4), np.int32),
+                    kf_set=np.zeros(K, np.int32), stop=np.zeros(1, np.uint8))
+    r, g = outs(), outs()
+    r.update(counts=np.zeros(3, np.int32), pose_order=np.full(K, -1, np.int32), point_order=np.full(L, -1, np.int32), edge_order=np.full(2 * E, -1, np.int32),
+             iters=np.zeros(2, np.int32))
+    assert ref.svref_local_ba(*head(), _p(r["counts"]), _p(r["pose_order"]), _p(r["point_order"]), _p(r["edge_order"]), _p(r["kf_pose"]), _p(r["lm_pos"]),
+                              C.byref(r["n_erased"]), _p(r["erased"]), _p(r["lm_cnt"]), _p(r["kf_set"]), _p(r["iters"]), _p(r["stop"])) == 0
+    g["stats"] = np.zeros(6, np.int32)
+    assert prod.svref_dropin_local_ba(*head(), _p(g["kf_pose"]), _p(g["lm_pos"]), C.byref(g["n_erased"]), _p(g["erased"]), _p(g["lm_cnt"]), _p(g["kf_set"]),
+                                      _p(g["stats"]), _p(g["stop"])) == 0
+    return r, g
+
+
+def _pairs(o):
+    return {(int(o["erased"][2 * i]), int(o["erased"][2 * i + 1])) for i in range(o["n_erased"].value)}
+
+
+def _compare(sc, r, g, expect_work=True):
+    np.testing.assert_array_equal(r["kf_set"], g["kf_set"])          # the same keyframes written, once each
+    np.testing.assert_array_equal(r["lm_cnt"], g["lm_cnt"])          # set_pos / update geometry / compute_descriptor / erase_observation calls per landmark
+    assert _pairs(r) == _pairs(g)                                    # the same observations removed from the map
+    assert r["stop"][0] == g["stop"][0]
+    if expect_work:
+        assert g["stats"][0] == 0 and [int(g["stats"][1]), int(g["stats"][2])] == r["iters"].tolist()
+        assert r["kf_set"].sum() > 0 and len(_pairs(r)) > 0
+    for k in range(len(r["kf_pose"])):
+        if r["kf_set"][k] == 0:
+            np.testing.assert_array_equal(g["kf_pose"][k], sc["pose_cw"][k])
+            continue
+        Tr, Tg = r["kf_pose"][k].reshape(3, 4), g["kf_pose"][k].reshape(3, 4)
+        assert np.abs(Tr[:, :3] - Tg[:, :3]).max() <= 1e-4
+        assert np.linalg.norm(Tr[:, 3] - Tg[:, 3]) <= 1e-4 * max(1.0, np.linalg.norm(Tr[:, 3]))
+    moved = r["lm_cnt"][:, 0] > 0
+    np.testing.assert_array_equal(g["lm_pos"][~moved], sc["points"][~moved])
+    if not moved.any():
+        return
+    scale = np.maximum(1.0, np.linalg.norm(r["lm_pos"][moved], axis=1))
+    assert (np.linalg.norm(r["lm_pos"][moved] - g["lm_pos"][moved], axis=1) / scale).max() <= 1e-4
+
+
+@pytest.mark.parametrize("stereo", [0, 1])
+@pytest.mark.parametrize("case", ["plain", "threshold_root_erased"])
+def test_local_bundle_adjuster_hip_against_local_bundle_adjuster_g2o(libs, stereo, case):
+    sc = S.ba_scene(num_kf=12, num_lm=600, obs_per_lm=4, num_fixed=0, seed=90 + stereo, stereo=bool(stereo))
+    K, L = len(sc["pose_cw"]), len(sc["points"])
+    rng = np.random.default_rng(17 + stereo)
+    kf_id = 10 + 3 * np.arange(K)
+    lm_id = 1000 + 7 * rng.permutation(L)
+    kf_flags = np.zeros(K, np.uint8)
+    lm_erased = (rng.uniform(size=L) < 0.03).astype(np.uint8)
+    covis = [int(c) for c in rng.permutation(K - 1)[:7]]
+    threshold = 0
+    if case == "threshold_root_erased":
+        covis += [-1]
+        kf_flags[covis[0]] |= 1
+        kf_flags[covis[1]] |= 2
+        threshold = int(kf_id[sorted(covis[2:7])[0]]) + 1
+    r, g = _both(libs, sc, stereo, kf_id, kf_flags, lm_id, lm_erased, covis, K - 1, threshold, False)
+    _compare(sc, r, g)
+
+
+def test_a_stop_requested_before_the_call_leaves_the_map_untouched(libs):
+    sc = S.ba_scene(num_kf=8, num_lm=300, obs_per_lm=4, num_fixed=0, seed=3)
+    K, L = len(sc["pose_cw"]), len(sc["points"])
+    r, g = _both(libs, sc, 0, 1 + np.arange(K), np.zeros(K, np.uint8), np.arange(L), np.zeros(L, np.uint8), list(range(K - 1)), K - 1, 0, False, stop_in=1)
+    _compare(sc, r, g, expect_work=False)
+    assert g["kf_set"].sum() == 0 and g["lm_cnt"].sum() == 0
+    np.testing.assert_array_equal(g["lm_pos"], sc["points"])
+
+
+def test_larger_window_with_a_null_flag(libs):
+    """force_stop_flag == nullptr (global-optimisation callers) on a 40-keyframe window."""
+    sc = S.ba_scene(num_kf=40, num_lm=4000, obs_per_lm=5, num_fixed=0, seed=11)
+    K, L = len(sc["pose_cw"]), len(sc["points"])
+    rng = np.random.default_rng(2)
+    covis = [int(c) for c in rng.permutation(K - 1)[:25]]
+    r, g = _both(libs, sc, 0, 100 + np.arange(K), np.zeros(K, np.uint8), rng.permutation(L), np.zeros(L, np.uint8), covis, K - 1, 0, False, stop_in=-1)
+    _compare(sc, r, g)
