@@ -5,12 +5,21 @@
 #include <set>
 
 #include "ref_support.h"
+#ifdef SVREF_DROP_IN
+// the same fixtures around the PRODUCT's drop-in classes (stella_vslam_amd/host/drop_in/hip_backend.h, reference-tree mode, compiled against
+// the same stand-in data:: headers): libsvref_mdropin.so, linked to libsvgpu.so; tests/test_gpu_drop_in_matchers.py runs the cases of
+// tests/test_ref_local_match.py through it
+#include "drop_in/hip_backend.h"
+namespace M = stella_vslam::match::hip;
+#else
 #include "stella_vslam/match/area.h"
 #include "stella_vslam/match/bow_tree.h"
 #include "stella_vslam/match/fuse.h"
 #include "stella_vslam/match/projection.h"
 #include "stella_vslam/match/robust.h"
 #include "stella_vslam/match/stereo.h"
+namespace M = stella_vslam::match;
+#endif
 
 using namespace stella_vslam;
 using svref::camera_fixture;
@@ -43,7 +52,7 @@ int svref_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, c
     fill_observation(kf->frm_obs_, desc2, nullptr, nullptr, angle2, nullptr, nullptr, n2, 64, 48);
     attach_landmarks(kf->landmarks_, valid2, n2);
     std::vector<std::pair<int, int>> matches;
-    const unsigned num = match::robust(lowe_ratio, check_orientation != 0).brute_force_match(fo, kf, matches);
+    const unsigned num = M::robust(lowe_ratio, check_orientation != 0).brute_force_match(fo, kf, matches);
     for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
     for (const auto& m : matches) matched_2_in_1[m.first] = m.second;
     return (int)num;
@@ -71,8 +80,8 @@ int svref_match_for_triangulation(const orc_camera* cam2, const double* rot_1w, 
     k2->bow_feat_vec_ = feat_vec(node2, n2);
     std::vector<std::pair<unsigned int, unsigned int>> pairs;
     const Mat33_t E = svref::mat33(E_12);
-    const unsigned num = node1 ? match::bow_tree(lowe_ratio, check_orientation != 0).match_for_triangulation(k1, k2, E, pairs, residual_rad_thr)
-                               : match::robust(lowe_ratio, check_orientation != 0).match_for_triangulation(k1, k2, E, pairs, residual_rad_thr);
+    const unsigned num = node1 ? M::bow_tree(lowe_ratio, check_orientation != 0).match_for_triangulation(k1, k2, E, pairs, residual_rad_thr)
+                               : M::robust(lowe_ratio, check_orientation != 0).match_for_triangulation(k1, k2, E, pairs, residual_rad_thr);
     for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
     for (const auto& m : pairs) matched_2_in_1[m.first] = (int32_t)m.second;
     return (int)num;
@@ -90,7 +99,7 @@ int svref_bow_match(const uint8_t* desc1, const float* angle1, const uint8_t* va
     for (int i = 0; i < n1; ++i) match_1to2[i] = -1;
     std::vector<std::shared_ptr<data::landmark>> matched;
     unsigned num;
-    const match::bow_tree matcher(lowe_ratio, check_orientation != 0);
+    const M::bow_tree matcher(lowe_ratio, check_orientation != 0);
     if (!keyframes) {
         data::frame frm(2, nullptr, &P.p);
         fill_observation(frm.frm_obs_, desc2, nullptr, nullptr, angle2, nullptr, nullptr, n2, 64, 48);
@@ -136,7 +145,7 @@ int svref_match_current_and_last_frames(const orc_camera* camd, const double* ro
     const auto occupant = make_landmark(0xFFFFFFFEu, nullptr, nullptr, 0.f, 0.f, nullptr, true);
     for (int j = 0; j < nt; ++j)
         if (occupied && occupied[j]) curr.landmarks_[j] = occupant;
-    const unsigned num = match::projection(0.0f, check_orientation != 0).match_current_and_last_frames(curr, last, margin);
+    const unsigned num = M::projection(0.0f, check_orientation != 0).match_current_and_last_frames(curr, last, margin);
     for (int j = 0; j < nt; ++j) {
         const auto lm = curr.landmarks_[j];
         holder_of_current[j] = !lm ? -1 : (lm == occupant ? -2 : (int32_t)lm->id_);
@@ -168,7 +177,7 @@ int svref_match_frame_and_keyframe_projection(const orc_camera* camd, const doub
     for (int i = 0; i < n_kf; ++i)
         if (valid[i]) kf->landmarks_[i] = make_landmark((unsigned)i, pos_w + 3 * i, lm_desc + 32 * (size_t)i, min_valid_dist[i], max_valid_dist[i], nullptr);
     const std::set<std::shared_ptr<data::landmark>> already;
-    const unsigned num = match::projection(0.0f, check_orientation != 0).match_frame_and_keyframe(curr, kf, already, margin, hamm_dist_thr);
+    const unsigned num = M::projection(0.0f, check_orientation != 0).match_frame_and_keyframe(curr, kf, already, margin, hamm_dist_thr);
     for (int j = 0; j < nt; ++j) {
         const auto lm = curr.landmarks_[j];
         holder_of_current[j] = !lm ? -1 : (lm == occupant ? -2 : (int32_t)lm->id_);
@@ -201,7 +210,7 @@ int svref_match_by_sim3_transform(const orc_camera* camd, const double* sim3_cw 
     std::vector<std::shared_ptr<data::landmark>> matched(nt, nullptr);
     for (int j = 0; j < nt; ++j)
         if (occupied && occupied[j]) matched[j] = occupant;
-    const unsigned num = match::projection(0.0f, false).match_by_Sim3_transform(kf, S, lms, matched, margin);
+    const unsigned num = M::projection(0.0f, false).match_by_Sim3_transform(kf, S, lms, matched, margin);
     for (int j = 0; j < nt; ++j) holder_of_target[j] = !matched[j] ? -1 : (matched[j] == occupant ? -2 : (int32_t)matched[j]->id_);
     svref::forget_grids();
     return (int)num;
@@ -231,7 +240,7 @@ int svref_match_keyframes_mutually(const orc_camera* camd, const double* rot_1w,
         if (valid2[i]) k2->landmarks_[i] = make_landmark(1000000u + (unsigned)i, pos_w2 + 3 * i, lm_desc2 + 32 * (size_t)i, min_valid2[i], max_valid2[i], nullptr);
     std::vector<std::shared_ptr<data::landmark>> matched(n1, nullptr);
     const float s = s_12;
-    const unsigned num = match::projection(0.0f, false).match_keyframes_mutually(k1, k2, matched, s, svref::mat33(rot_12), svref::vec3(trans_12), margin);
+    const unsigned num = M::projection(0.0f, false).match_keyframes_mutually(k1, k2, matched, s, svref::mat33(rot_12), svref::vec3(trans_12), margin);
     for (int i = 0; i < n1; ++i) mutual_2_in_1[i] = matched[i] ? (int32_t)(matched[i]->id_ - 1000000u) : -1;
     svref::forget_grids();
     return (int)num;
@@ -255,7 +264,7 @@ int svref_fuse_detect_duplication(const orc_camera* camd, const double* rot_cw, 
         if (!valid || valid[i]) lms[i] = make_landmark((unsigned)i, pos_w + 3 * i, lm_desc + 32 * (size_t)i, min_valid_dist[i], max_valid_dist[i], mean_normal + 3 * i);
     std::unordered_map<std::shared_ptr<data::landmark>, std::shared_ptr<data::landmark>> duplicated;
     std::unordered_map<unsigned int, std::shared_ptr<data::landmark>> fresh;
-    const unsigned num = match::fuse(0.0f).detect_duplication(kf, svref::mat33(rot_cw), svref::vec3(trans_cw), lms, margin, duplicated, fresh,
+    const unsigned num = M::fuse(0.0f).detect_duplication(kf, svref::mat33(rot_cw), svref::vec3(trans_cw), lms, margin, duplicated, fresh,
                                                                         do_reprojection_matching != 0);
     for (int i = 0; i < n; ++i) best_idx[i] = -1;
     for (const auto& d : duplicated) best_idx[d.first->id_] = (int32_t)(d.second->id_ - 1000000u);
@@ -291,7 +300,7 @@ int svref_match_frame_and_landmarks(const orc_camera* camd, int is_monocular, in
             lm_to_scale[(unsigned)i] = (unsigned)pred_level[i];
         }
     }
-    const unsigned num = match::projection(lowe_ratio, false).match_frame_and_landmarks(frm, lms, lm_to_reproj, lm_to_x_right, lm_to_scale, margin);
+    const unsigned num = M::projection(lowe_ratio, false).match_frame_and_landmarks(frm, lms, lm_to_reproj, lm_to_x_right, lm_to_scale, margin);
     for (int j = 0; j < nt; ++j) {
         const auto lm = frm.landmarks_[j];
         holder_of_target[j] = !lm ? -1 : (lm == occupant ? -2 : (int32_t)lm->id_);
@@ -313,7 +322,7 @@ int svref_match_in_consistent_area(const orc_camera* camd, const uint8_t* desc1,
     std::vector<cv::Point2f> prev(n1);
     for (int i = 0; i < n1; ++i) prev[i] = cv::Point2f(prev_xy[2 * i], prev_xy[2 * i + 1]);
     std::vector<int> out;
-    const unsigned num = match::area(lowe_ratio, check_orientation != 0).match_in_consistent_area(f1, f2, prev, out, margin);
+    const unsigned num = M::area(lowe_ratio, check_orientation != 0).match_in_consistent_area(f1, f2, prev, out, margin);
     for (int i = 0; i < n1; ++i) {
         matched_2_in_1[i] = out[i];
         prev_xy[2 * i] = prev[i].x, prev_xy[2 * i + 1] = prev[i].y;
@@ -322,6 +331,7 @@ int svref_match_in_consistent_area(const orc_camera* camd, const uint8_t* desc1,
     return (int)num;
 }
 
+#ifndef SVREF_DROP_IN
 // match::stereo::compute (match/stereo.cc:20-251) on two extractor outputs: 28-byte keypoints, descriptors, the two image pyramids.
 typedef struct {
     float x, y, size, angle, response;
@@ -351,4 +361,5 @@ void svref_stereo_compute(const svref_kp28* kl, const uint8_t* dl, int nl, const
     }
 }
 
+#endif
 }  // extern "C"

@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "stella_vslam/camera/base.h"
+#ifdef SVREF_DROP_IN
+#include "stella_vslam/camera/any_model.h"
+#endif
 #include "stella_vslam/data/frame.h"
 #include "stella_vslam/data/keyframe.h"
 #include "stella_vslam/data/landmark.h"
@@ -52,13 +55,24 @@ inline Mat44_t pose44(const double* rot_row_major, const double* trans) {
     return T;
 }
 
-class camera_fixture final : public camera::base {
+#ifdef SVREF_DROP_IN
+using camera_parent = camera::any_model;  // shim_mdrop/: carries the parameter members the product's camera conversion reads
+#else
+using camera_parent = camera::base;
+#endif
+class camera_fixture final : public camera_parent {
 public:
     camera_fixture(const orc_camera* c, bool monocular, double true_baseline)
-        : camera::base(monocular ? camera::setup_type_t::Monocular : camera::setup_type_t::Stereo, (camera::model_type_t)c->model, (unsigned)c->cols,
+        : camera_parent(monocular ? camera::setup_type_t::Monocular : camera::setup_type_t::Stereo, (camera::model_type_t)c->model, (unsigned)c->cols,
                        (unsigned)c->rows, c->focal_x_baseline, true_baseline),
           oc_(*c) {
         img_bounds_.min_x_ = c->min_x, img_bounds_.max_x_ = c->max_x, img_bounds_.min_y_ = c->min_y, img_bounds_.max_y_ = c->max_y;
+#ifdef SVREF_DROP_IN
+        fx_ = c->fx, fy_ = c->fy, cx_ = c->cx, cy_ = c->cy;
+        if (c->model == 0) k1_ = c->dist[0], k2_ = c->dist[1], p1_ = c->dist[2], p2_ = c->dist[3], k3_ = c->dist[4];
+        if (c->model == 1) k1_ = c->dist[0], k2_ = c->dist[1], k3_ = c->dist[2], k4_ = c->dist[3];
+        if (c->model == 3) distortion_ = c->dist[0];
+#endif
     }
     bool reproject_to_image(const Mat33_t& rot_cw, const Vec3_t& trans_cw, const Vec3_t& pos_w, Vec2_t& reproj, float& x_right) const override {
         double R[9], r[2];

@@ -518,6 +518,7 @@ unsigned int area::match_in_consistent_area(data::frame& frm_1, data::frame& frm
 #endif  // SVGPU_DROP_IN_OPTIMIZE_ONLY
 
 // ====================================================================================================================== local BA
+#ifndef SVGPU_DROP_IN_MATCH_ONLY
 namespace optimize {
 
 local_bundle_adjuster_hip::local_bundle_adjuster_hip(const YAML::Node& yaml_node, const unsigned int num_first_iter, const unsigned int num_second_iter)
@@ -684,4 +685,5 @@ std::unique_ptr<local_bundle_adjuster> create_local_bundle_adjuster(const YAML::
 }  // namespace hip_backend
 
 }  // namespace optimize
+#endif  // SVGPU_DROP_IN_MATCH_ONLY
 }  // namespace stella_vslam

@@ -16,10 +16,12 @@
 #include "stella_vslam/data/frame.h"
 #include "stella_vslam/data/keyframe.h"
 #include "stella_vslam/data/landmark.h"
-#include "stella_vslam/data/map_database.h"
 #include "stella_vslam/feature/orb_params.h"
+#ifndef SVGPU_DROP_IN_MATCH_ONLY
+#include "stella_vslam/data/map_database.h"
 #include "stella_vslam/optimize/local_bundle_adjuster.h"
 #include <yaml-cpp/yaml.h>
+#endif
 #else
 #include "standin/stella_standin.h"
 #endif
@@ -129,6 +131,7 @@ public:
 }  // namespace match
 #endif  // SVGPU_DROP_IN_OPTIMIZE_ONLY
 
+#ifndef SVGPU_DROP_IN_MATCH_ONLY  // (... and only the matcher classes against its matcher stand-ins)
 namespace optimize {
 
 #ifndef SVGPU_WITH_STELLA_VSLAM
@@ -163,4 +166,5 @@ std::unique_ptr<local_bundle_adjuster> create_local_bundle_adjuster(const YAML::
 }  // namespace hip_backend
 
 }  // namespace optimize
+#endif  // SVGPU_DROP_IN_MATCH_ONLY
 }  // namespace stella_vslam
