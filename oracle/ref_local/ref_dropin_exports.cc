@@ -3,9 +3,12 @@
 // local_bundle_adjuster_g2o.cc is compiled against in ref_ba_exports.cc) on the toy map of svref_local_ba: the two classes see identical
 // objects, tests/test_gpu_drop_in_vs_reference.py compares the maps they leave behind.  Links libsvgpu.so: needs a GPU to run.
 #include <cstring>
+#include <array>
 #include <memory>
+#include <unordered_set>
 #include <vector>
 
+#include "drop_in/global_bundle_adjuster_hip.h"
 #include "drop_in/hip_backend.h"
 
 using namespace stella_vslam;
@@ -22,6 +25,46 @@ std::unique_ptr<camera::base> make_cam(int model, int stereo, unsigned cols, uns
         default: return std::unique_ptr<camera::base>(new camera::radial_division("ref", setup, col, cols, rows, 30.0, k[0], k[1], k[2], k[3], 0, k[4]));
     }
 }
+struct toy_map {  // the object graph of svref_local_ba / svref_global_ba (ref_ba_exports.cc), from the same flat arrays
+    std::unique_ptr<camera::base> cam;
+    feature::orb_params orb;
+    std::vector<std::shared_ptr<data::keyframe>> kfs;
+    std::vector<std::shared_ptr<data::landmark>> lms;
+    toy_map(int model, int stereo_cam, unsigned cols, unsigned rows, const double* intr5, float scale_factor, int num_levels, int K, const unsigned* kf_id,
+            const double* kf_pose, const uint8_t* kf_flags, int L, const unsigned* lm_id, const double* lm_pos, const uint8_t* lm_erased, int O, const int* obs_kf,
+            const int* obs_lm, const int* obs_idx, const float* obs_uv, const float* obs_xr, const int* obs_oct)
+        : cam(make_cam(model, stereo_cam, cols, rows, intr5)), orb("ref", scale_factor, num_levels, 20, 7), kfs(K), lms(L) {
+        for (int k = 0; k < K; ++k) {
+            kfs[k] = std::make_shared<data::keyframe>();
+            kfs[k]->id_ = kf_id[k];
+            kfs[k]->camera_ = cam.get();
+            kfs[k]->orb_params_ = &orb;
+            kfs[k]->pose_cw_ = Mat44_t::Identity();
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 4; ++j) kfs[k]->pose_cw_(i, j) = kf_pose[12 * k + 4 * i + j];
+            kfs[k]->will_be_erased_ = kf_flags[k] & 1;
+            kfs[k]->graph_node_->is_spanning_root_ = (kf_flags[k] & 2) != 0;
+        }
+        for (int l = 0; l < L; ++l) lms[l] = std::make_shared<data::landmark>(lm_id[l], Vec3_t(lm_pos[3 * l], lm_pos[3 * l + 1], lm_pos[3 * l + 2]), lm_erased[l] != 0);
+        for (int o = 0; o < O; ++o) {
+            auto& kf = kfs[obs_kf[o]];
+            const size_t idx = (size_t)obs_idx[o];
+            if (kf->frm_obs_.undist_keypts_.size() <= idx) {
+                kf->frm_obs_.undist_keypts_.resize(idx + 1);
+                kf->landmarks_.resize(idx + 1);
+                if (stereo_cam) kf->frm_obs_.stereo_x_right_.resize(idx + 1, -1.0f);
+            }
+            cv::KeyPoint kp;
+            kp.pt.x = obs_uv[2 * o];
+            kp.pt.y = obs_uv[2 * o + 1];
+            kp.octave = obs_oct[o];
+            kf->frm_obs_.undist_keypts_[idx] = kp;
+            if (stereo_cam) kf->frm_obs_.stereo_x_right_[idx] = obs_xr[o];
+            kf->landmarks_[idx] = lms[obs_lm[o]];
+            lms[obs_lm[o]]->observations_[kf] = (unsigned)idx;
+        }
+    }
+};
 }  // namespace
 
 extern "C" {
@@ -33,39 +76,10 @@ int svref_dropin_local_ba(int model, int stereo_cam, unsigned cols, unsigned row
                           const int* obs_oct, int curr, int n_covis, const int* covis, unsigned fixed_threshold, int use_additional, int iters1, int iters2,
                           int stop_in, double* kf_pose_out, double* lm_pos_out, int* n_erased, int* erased_pairs, int* lm_counters, int* kf_set_pose,
                           int* stats6, uint8_t* stop_out) {
-    auto cam = make_cam(model, stereo_cam, cols, rows, intr5);
-    feature::orb_params orb("ref", scale_factor, num_levels, 20, 7);
-    std::vector<std::shared_ptr<data::keyframe>> kfs(K);
-    std::vector<std::shared_ptr<data::landmark>> lms(L);
-    for (int k = 0; k < K; ++k) {
-        kfs[k] = std::make_shared<data::keyframe>();
-        kfs[k]->id_ = kf_id[k];
-        kfs[k]->camera_ = cam.get();
-        kfs[k]->orb_params_ = &orb;
-        kfs[k]->pose_cw_ = Mat44_t::Identity();
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 4; ++j) kfs[k]->pose_cw_(i, j) = kf_pose[12 * k + 4 * i + j];
-        kfs[k]->will_be_erased_ = kf_flags[k] & 1;
-        kfs[k]->graph_node_->is_spanning_root_ = (kf_flags[k] & 2) != 0;
-    }
-    for (int l = 0; l < L; ++l) lms[l] = std::make_shared<data::landmark>(lm_id[l], Vec3_t(lm_pos[3 * l], lm_pos[3 * l + 1], lm_pos[3 * l + 2]), lm_erased[l] != 0);
-    for (int o = 0; o < O; ++o) {
-        auto& kf = kfs[obs_kf[o]];
-        const size_t idx = (size_t)obs_idx[o];
-        if (kf->frm_obs_.undist_keypts_.size() <= idx) {
-            kf->frm_obs_.undist_keypts_.resize(idx + 1);
-            kf->landmarks_.resize(idx + 1);
-            if (stereo_cam) kf->frm_obs_.stereo_x_right_.resize(idx + 1, -1.0f);
-        }
-        cv::KeyPoint kp;
-        kp.pt.x = obs_uv[2 * o];
-        kp.pt.y = obs_uv[2 * o + 1];
-        kp.octave = obs_oct[o];
-        kf->frm_obs_.undist_keypts_[idx] = kp;
-        if (stereo_cam) kf->frm_obs_.stereo_x_right_[idx] = obs_xr[o];
-        kf->landmarks_[idx] = lms[obs_lm[o]];
-        lms[obs_lm[o]]->observations_[kf] = (unsigned)idx;
-    }
+    toy_map M(model, stereo_cam, cols, rows, intr5, scale_factor, num_levels, K, kf_id, kf_pose, kf_flags, L, lm_id, lm_pos, lm_erased, O, obs_kf, obs_lm, obs_idx, obs_uv,
+              obs_xr, obs_oct);
+    auto& kfs = M.kfs;
+    auto& lms = M.lms;
     for (int c = 0; c < n_covis; ++c) kfs[curr]->graph_node_->covisibilities_.push_back(covis[c] < 0 ? nullptr : kfs[covis[c]]);
     data::map_database map_db;
     map_db.fixed_keyframe_id_threshold_ = fixed_threshold;
@@ -102,5 +116,38 @@ int svref_dropin_local_ba(int model, int stereo_cam, unsigned cols, unsigned row
         }
     *n_erased = ne;
     return 0;
+}
+
+// optimize::global_bundle_adjuster_hip::optimize on the map of svref_global_ba (ref_ba_exports.cc), same outputs minus the graph-order arrays
+int svref_dropin_global_ba(int model, int stereo_cam, unsigned cols, unsigned rows, const double* intr5, float scale_factor, int num_levels, int K,
+                           const unsigned* kf_id, const double* kf_pose, const uint8_t* kf_flags, int L, const unsigned* lm_id, const double* lm_pos,
+                           const uint8_t* lm_erased, int O, const int* obs_kf, const int* obs_lm, const int* obs_idx, const float* obs_uv, const float* obs_xr,
+                           const int* obs_oct, int n_order, const int* kf_order, int num_iter, int use_huber, int stop_in, double* kf_pose_out,
+                           double* lm_pos_out, uint8_t* kf_opt, uint8_t* lm_opt, int* lm_iters, uint8_t* stop_out) {
+    toy_map M(model, stereo_cam, cols, rows, intr5, scale_factor, num_levels, K, kf_id, kf_pose, kf_flags, L, lm_id, lm_pos, lm_erased, O, obs_kf, obs_lm, obs_idx, obs_uv,
+              obs_xr, obs_oct);
+    std::vector<std::shared_ptr<data::keyframe>> keyfrms;
+    for (int i = 0; i < n_order; ++i) keyfrms.push_back(M.kfs[kf_order[i]]);
+    optimize::global_bundle_adjuster_hip gba((unsigned)num_iter, use_huber != 0, false);
+    std::unordered_set<unsigned int> okf, olm, omk;
+    eigen_alloc_unord_map<unsigned int, Vec3_t> lm_to_pos;
+    eigen_alloc_unord_map<unsigned int, Mat44_t> kf_to_pose;
+    eigen_alloc_unord_map<unsigned int, std::array<Vec3_t, 4>> mk_to_pos;
+    bool stop = stop_in > 0;
+    const bool ok = gba.optimize(keyfrms, okf, olm, omk, lm_to_pos, kf_to_pose, mk_to_pos, stop_in >= 0 ? &stop : nullptr);
+    *stop_out = stop ? 1 : 0;
+    lm_iters[0] = gba.last_stats_.iters_stage1, lm_iters[1] = gba.last_stats_.stopped_by_terminate_action;
+    for (int k = 0; k < K; ++k) {
+        kf_opt[k] = okf.count(kf_id[k]) ? 1 : 0;
+        const Mat44_t T = kf_opt[k] ? kf_to_pose.at(kf_id[k]) : M.kfs[k]->pose_cw_;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) kf_pose_out[12 * k + 4 * i + j] = T(i, j);
+    }
+    for (int l = 0; l < L; ++l) {
+        lm_opt[l] = olm.count(lm_id[l]) ? 1 : 0;
+        const Vec3_t p = lm_opt[l] ? lm_to_pos.at(lm_id[l]) : M.lms[l]->pos_w_;
+        for (int c = 0; c < 3; ++c) lm_pos_out[3 * l + c] = p(c);
+    }
+    return ok ? 1 : 0;
 }
 }

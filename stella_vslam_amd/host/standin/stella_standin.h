@@ -219,8 +219,23 @@ private:
     std::atomic<bool> will_be_erased_{false};
 };
 
+class marker2d {  // data/marker2d.h: the undistorted image corners global BA reads
+public:
+    std::vector<cv::Point2f> undist_corners_;
+};
+class marker {  // data/marker.h:18-48
+public:
+    unsigned int id_ = 0;
+    bool keep_fixed_ = false, initialized_before_ = false;
+    std::map<unsigned int, std::shared_ptr<keyframe>> observations_;
+    eigen_alloc_vector<Vec3_t> corners_pos_w_;
+};
+
 class keyframe : public std::enable_shared_from_this<keyframe> {  // data/keyframe.h:73-325
 public:
+    std::unordered_map<unsigned int, marker2d> markers_2d_;
+    std::vector<std::shared_ptr<marker>> markers_;
+    std::vector<std::shared_ptr<marker>> get_markers() const { return markers_; }
     keyframe(unsigned int id, camera::base* camera, const feature::orb_params* orb_params) : id_(id), camera_(camera), orb_params_(orb_params), graph_node_(new graph_node()) {}
     void set_pose_cw(const Mat44_t& pose_cw) { pose_cw_ = pose_cw; }
     Mat44_t get_pose_cw() const { return pose_cw_; }

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <random>
 
+#include "drop_in/global_bundle_adjuster_hip.h"
 #include "drop_in/hip_backend.h"
+#include "drop_in/pose_optimizer_hip.h"
 
 using namespace stella_vslam;
 using lm_ptr = std::shared_ptr<data::landmark>;
@@ -388,6 +390,94 @@ int main() {
         force_stop = true;
         ba->optimize(&M.db, curr, &force_stop);
         for (int i = 0; i < 3; ++i) REQUIRE(curr->get_pose_cw()(i, 3) == keep(i, 3));
+    }
+    {  // pose_optimizer_hip behind the factory line, frame overload: a perturbed pose comes back to the keyframe's, gross outliers are flagged
+        REQUIRE(optimize::hip_backend::create_pose_optimizer("g2o") == nullptr);
+        auto po = optimize::hip_backend::create_pose_optimizer("hip");
+        REQUIRE(po != nullptr);
+        data::frame f = frame_like(M, 6, true);
+        f.landmarks_ = M.kfs[6]->landmarks_;
+        Mat44_t T0 = M.kfs[6]->get_pose_cw();
+        for (int i = 0; i < 3; ++i) T0(i, 3) += 0.03 * (i + 1);
+        f.set_pose_cw(T0);
+        std::vector<int> moved;
+        for (size_t i = 0; i < f.landmarks_.size() && moved.size() < 8; i += 5)
+            if (f.landmarks_[i]) {
+                f.frm_obs_.undist_keypts_[i].pt.y += 60.f;
+                moved.push_back((int)i);
+            }
+        Mat44_t T1 = T0;
+        std::vector<bool> flags;
+        const unsigned good = po->optimize(f, T1, flags);
+        double e0 = 0, e1 = 0;
+        for (int i = 0; i < 3; ++i) e0 += std::fabs(T0(i, 3) - M.kfs[6]->get_pose_cw()(i, 3)), e1 += std::fabs(T1(i, 3) - M.kfs[6]->get_pose_cw()(i, 3));
+        unsigned flagged = 0;
+        for (int i : moved) flagged += flags.at(i) ? 1 : 0;
+        std::fprintf(stderr, "[pose] %u good observations, translation error %.4f -> %.4f, %u of %zu moved keypoints flagged\n", good, e0, e1, flagged, moved.size());
+        REQUIRE(flags.size() == f.frm_obs_.undist_keypts_.size() && good > 50 && e1 < 0.2 * e0 && flagged == moved.size());
+    }
+    {  // global_bundle_adjuster_hip::optimize over all keyframes with one free and one kept-fixed marker (global_bundle_adjuster.cc:131-181, 380-408)
+        for (int k = 0; k < (int)M.kfs.size(); ++k) M.kfs[k]->graph_node_->spanning_root_ = k == 0;
+        auto make_marker = [&](unsigned id, const Vec3_t& centre, bool keep_fixed, double noise) {
+            auto mk = std::make_shared<data::marker>();
+            mk->id_ = id, mk->keep_fixed_ = keep_fixed, mk->initialized_before_ = true;
+            const double d[4][2] = {{-0.1, -0.1}, {0.1, -0.1}, {0.1, 0.1}, {-0.1, 0.1}};
+            for (int c = 0; c < 4; ++c) {
+                Vec3_t truth;
+                truth(0) = centre(0) + d[c][0], truth(1) = centre(1) + d[c][1], truth(2) = centre(2);
+                for (auto& kf : M.kfs) {
+                    double u, v, z;
+                    project(M, kf->get_pose_cw(), truth, u, v, z);
+                    kf->markers_2d_[id].undist_corners_.resize(4);
+                    kf->markers_2d_[id].undist_corners_[c].x = (float)u, kf->markers_2d_[id].undist_corners_[c].y = (float)v;
+                    mk->observations_[kf->id_] = kf;
+                }
+                Vec3_t start;
+                start(0) = truth(0) + noise, start(1) = truth(1) - noise, start(2) = truth(2) + noise;
+                mk->corners_pos_w_.push_back(start);
+            }
+            for (auto& kf : M.kfs) kf->markers_.push_back(mk);
+            return mk;
+        };
+        const Vec3_t c0 = M.lms[0]->get_pos_in_world(), c1 = M.lms[1]->get_pos_in_world();
+        auto free_mk = make_marker(7, c0, false, 0.05), fixed_mk = make_marker(9, c1, true, 0.05);
+        const auto fixed_before = fixed_mk->corners_pos_w_;
+        optimize::global_bundle_adjuster_hip gba(10, true);
+        std::unordered_set<unsigned int> okf, olm, omk;
+        eigen_alloc_unord_map<unsigned int, Vec3_t> lm_pos;
+        eigen_alloc_unord_map<unsigned int, Mat44_t> kf_pose;
+        eigen_alloc_unord_map<unsigned int, std::array<Vec3_t, 4>> mk_pos;
+        bool stop = false;
+        REQUIRE(gba.optimize(M.kfs, okf, olm, omk, lm_pos, kf_pose, mk_pos, &stop));
+        REQUIRE(okf.size() == M.kfs.size() && !olm.empty() && gba.last_stats_.chi2_final < gba.last_stats_.chi2_initial);
+        REQUIRE(omk.count(7) == 1 && omk.count(9) == 0 && mk_pos.count(7) == 1 && mk_pos.count(9) == 0);  // a kept-fixed marker is neither moved nor reported
+        // (one fixed keyframe of a monocular map leaves the gauge to drift: the corners are judged by their reprojection, not by position)
+        double m0 = 0, m1 = 0;
+        for (int c = 0; c < 4; ++c) {
+            for (auto& kf : M.kfs) {
+                const auto& obs = kf->markers_2d_.at(7).undist_corners_[c];
+                double u, v, z;
+                project(M, kf->get_pose_cw(), free_mk->corners_pos_w_[c], u, v, z);
+                m0 += std::fabs(u - obs.x) + std::fabs(v - obs.y);
+                project(M, kf_pose.at(kf->id_), mk_pos.at(7)[c], u, v, z);
+                m1 += std::fabs(u - obs.x) + std::fabs(v - obs.y);
+            }
+            for (int i = 0; i < 3; ++i) REQUIRE(fixed_mk->corners_pos_w_[c](i) == fixed_before[c](i));
+        }
+        std::fprintf(stderr, "[gba] chi2 %.1f -> %.1f in %d iterations, free marker reprojection error %.1f -> %.1f px (sum)\n", gba.last_stats_.chi2_initial,
+                     gba.last_stats_.chi2_final, gba.last_stats_.iters_stage1, m0, m1);
+        REQUIRE(m1 < 0.2 * m0);
+        const Mat44_t root = M.kfs[0]->get_pose_cw();  // the spanning root is a fixed vertex: its pose comes back bit for bit
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) REQUIRE(kf_pose.at(M.kfs[0]->id_)(i, j) == root(i, j));
+        // optimize_for_initialization writes the map directly; with fix_markers the free marker keeps its corners
+        const auto free_before = free_mk->corners_pos_w_;
+        std::vector<std::shared_ptr<data::marker>> mks{free_mk, fixed_mk};
+        const unsigned refreshes = M.lms[5]->num_geometry_refreshes_;
+        gba.optimize_for_initialization(M.kfs, M.lms, mks, 1e-5f, true, nullptr);
+        REQUIRE(gba.last_status_ == 0 && M.lms[5]->num_geometry_refreshes_ > refreshes);
+        for (int c = 0; c < 4; ++c)
+            for (int i = 0; i < 3; ++i) REQUIRE(free_mk->corners_pos_w_[c](i) == free_before[c](i));
     }
     std::printf("drop-in classes ok\n");
     return 0;

@@ -178,3 +178,69 @@ def test_pose_optimizer_hip_against_pose_optimizer_g2o(pose_libs, model, stereo)
             Rr, Rg = pr.reshape(3, 4), pg.reshape(3, 4)
             assert np.abs(Rr[:, :3] - Rg[:, :3]).max() <= 1e-4
             assert np.linalg.norm(Rr[:, 3] - Rg[:, 3]) <= 1e-4 * max(1.0, np.linalg.norm(Rr[:, 3]))
+
+
+# ---------------------------------------------------------------------------------------------------------------- global bundle adjuster
+def _global_both(libs, sc, stereo, kf_id, kf_flags, lm_id, lm_erased, order, num_iter, use_huber, stop_in):
+    ref, prod = libs
+    B = _load_cases("test_ref_local_ba")
+    r = B._run_global(ref, sc, stereo, kf_id, kf_flags, lm_id, lm_erased, order, num_iter, use_huber, stop_in)
+    K, L, E = len(sc["pose_cw"]), len(sc["points"]), len(sc["obs_pose"])
+    intr = np.ascontiguousarray(sc["intr"][0])
+    idx = np.zeros(E, np.int32)
+    seen = np.zeros(K, np.int64)
+    for e in range(E):
+        idx[e] = seen[sc["obs_pose"][e]]
+        seen[sc["obs_pose"][e]] += 1
+    a = dict(kf_id=np.ascontiguousarray(kf_id, np.uint32), kf_pose=np.ascontiguousarray(sc["pose_cw"], np.float64), kf_flags=np.ascontiguousarray(kf_flags, np.uint8),
+             lm_id=np.ascontiguousarray(lm_id, np.uint32), lm_pos=np.ascontiguousarray(sc["points"], np.float64), lm_erased=np.ascontiguousarray(lm_erased, np.uint8),
+             obs_kf=np.ascontiguousarray(sc["obs_pose"], np.int32), obs_lm=np.ascontiguousarray(sc["obs_point"], np.int32), obs_idx=idx,
+             uv=np.ascontiguousarray(sc["obs_uvr"][:, :2], np.float32), xr=np.ascontiguousarray(sc["obs_uvr"][:, 2], np.float32), oct=r["octave"],
+             order=np.ascontiguousarray(order, np.int32))
+    g = dict(kf_pose=np.zeros((K, 12)), lm_pos=np.zeros((L, 3)), kf_opt=np.zeros(K, np.uint8), lm_opt=np.zeros(L, np.uint8), iters=np.zeros(2, np.int32),
+             stop=np.zeros(1, np.uint8))
+    prod.svref_dropin_global_ba.restype = C.c_int
+    g["ok"] = prod.svref_dropin_global_ba(0, stereo, 1280, 720, _p(intr), C.c_float(1.2), 8, K, _p(a["kf_id"]), _p(a["kf_pose"]), _p(a["kf_flags"]), L, _p(a["lm_id"]),
+                                          _p(a["lm_pos"]), _p(a["lm_erased"]), E, _p(a["obs_kf"]), _p(a["obs_lm"]), _p(a["obs_idx"]), _p(a["uv"]), _p(a["xr"]),
+                                          _p(a["oct"]), len(order), _p(a["order"]), num_iter, int(use_huber), stop_in, _p(g["kf_pose"]), _p(g["lm_pos"]),
+                                          _p(g["kf_opt"]), _p(g["lm_opt"]), _p(g["iters"]), _p(g["stop"]))
+    return r, g
+
+
+@pytest.mark.parametrize("stereo,use_huber,num_iter,messy", [(0, True, 10, False), (1, False, 10, False), (0, True, 10, True), (0, True, 30, False)])
+def test_global_bundle_adjuster_hip_against_global_bundle_adjuster(libs, stereo, use_huber, num_iter, messy):
+    """optimize::global_bundle_adjuster::optimize (the reference's, compiled from global_bundle_adjuster.cc) and
+    optimize::global_bundle_adjuster_hip::optimize (the product's) on identical keyframes: the same return value, the same ids in the
+    optimised sets, the result maps within 1e-4, the same iteration count, the caller's flag written by the gain rule alike."""
+    sc = S.ba_scene(num_kf=14, num_lm=700, obs_per_lm=4, num_fixed=0, seed=70 + stereo + num_iter, stereo=bool(stereo))
+    K, L = len(sc["pose_cw"]), len(sc["points"])
+    rng = np.random.default_rng(5 + num_iter)
+    kf_id, lm_id = 3 + 2 * np.arange(K), 500 + rng.permutation(L)
+    kf_flags, lm_erased = np.zeros(K, np.uint8), np.zeros(L, np.uint8)
+    kf_flags[4] |= 2
+    if messy:
+        kf_flags[7] |= 1
+        lm_erased[rng.uniform(size=L) < 0.05] = 1
+    r, g = _global_both(libs, sc, stereo, kf_id, kf_flags, lm_id, lm_erased, rng.permutation(K), num_iter, use_huber, 0)
+    assert r["ok"] == 1 and g["ok"] == 1
+    np.testing.assert_array_equal(r["kf_opt"], g["kf_opt"])
+    np.testing.assert_array_equal(r["lm_opt"], g["lm_opt"])
+    assert r["iters"][0] == g["iters"][0] and r["stop"][0] == g["stop"][0]
+    if num_iter == 30:
+        assert g["stop"][0] == 1 and g["iters"][0] < 30 and g["iters"][1] == 1   # the gain rule stopped it, through the caller's flag
+    for k in range(K):
+        Tr, Tg = r["kf_pose"][k].reshape(3, 4), g["kf_pose"][k].reshape(3, 4)
+        assert np.abs(Tr[:, :3] - Tg[:, :3]).max() <= 1e-4
+        assert np.linalg.norm(Tr[:, 3] - Tg[:, 3]) <= 1e-4 * max(1.0, np.linalg.norm(Tr[:, 3]))
+    scale = np.maximum(1.0, np.linalg.norm(r["lm_pos"], axis=1))
+    assert (np.linalg.norm(r["lm_pos"] - g["lm_pos"], axis=1) / scale).max() <= 1e-4
+    np.testing.assert_array_equal(g["lm_pos"][g["lm_opt"] == 0], sc["points"][g["lm_opt"] == 0])
+
+
+def test_global_bundle_adjuster_hip_discards_a_run_the_caller_stopped(libs):
+    sc = S.ba_scene(num_kf=8, num_lm=300, obs_per_lm=4, num_fixed=0, seed=61)
+    K, L = len(sc["pose_cw"]), len(sc["points"])
+    flags = np.zeros(K, np.uint8)
+    flags[0] = 2
+    r, g = _global_both(libs, sc, 0, 1 + np.arange(K), flags, 1 + np.arange(L), np.zeros(L, np.uint8), np.arange(K), 10, True, 1)
+    assert r["ok"] == 0 and g["ok"] == 0 and g["kf_opt"].sum() == 0 and g["lm_opt"].sum() == 0 and g["stop"][0] == 1
