@@ -461,7 +461,8 @@ typedef struct svgpu_ba_problem {
     const int32_t* obs_point;        /* num_obs */
     const float* obs_uvr;            /* num_obs x 3: undistorted u, v, u_right (< 0 => monocular edge) */
     const float* obs_inv_sigma_sq;   /* num_obs: orb_params::inv_level_sigma_sq_[octave] */
-    const float* obs_huber_delta;    /* num_obs: sqrt(chi_sq) of the Huber kernel, <= 0 => no kernel */
+    const float* obs_huber_delta;    /* num_obs: sqrt(chi_sq) of the Huber kernel, <= 0 => no kernel; < 0 => a marker-corner edge (no kernel, and
+                                      * outside the chi-square / depth gate and the outlier list: local_bundle_adjuster_g2o.cc:246-304) */
     const double* intrinsics;        /* num_poses x 5: fx fy cx cy focal_x_baseline (perspective / fisheye / radial-division cameras:
                                         all use the perspective edge on undistorted keypoints, reproj_edge_wrapper.h:64-201);
                                         {0, 0, cols, rows, 0} selects the equirectangular edge (equirectangular_reproj_edge.h:64-134,

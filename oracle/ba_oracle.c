@@ -727,7 +727,7 @@ static int optimize(ba_t* B, int iterations, double gain_thr, volatile uint8_t* 
  *   points         L x 3
  *   point_fixed    L       nullable (markers kept fixed)
  *   obs_*          E       pose index, point index, (u, v, u_right<0 => mono) f32, inv_sigma_sq f32,
- *                          huber delta f32 (<= 0 => no kernel)
+ *                          huber delta f32 (<= 0 => no kernel; < 0 => a marker-corner edge: also outside the gate and the outlier list)
  *   intr           P x 5   fx fy cx cy fx*baseline
  *   stop           caller's force_stop_flag, nullable.  Non-NULL: polled between iterations AND written
  *                  by the terminate rule (reference quirk) so stage 2 is skipped after an
@@ -804,7 +804,9 @@ int orc_local_ba(int P, int L, int E, const double* pose_cw, const uint8_t* pose
                 se3_map(&B.pose[obs_pose[e]], &B.pt[3 * obs_point[e]], pc);
                 const int mono = obs_uvr[3 * e + 2] < 0;
                 const float thr = mono ? 5.99146f : 7.81473f;
-                if ((double)thr < chi || !depth_ok(&B.intr[5 * obs_pose[e]], pc)) {
+                /* huber < 0: a marker-corner edge -- its own container (:246-304), which the gate loop :324-343 does not visit */
+                const int marker_edge = obs_huber && obs_huber[e] < 0;
+                if (!marker_edge && ((double)thr < chi || !depth_ok(&B.intr[5 * obs_pose[e]], pc))) {
                     B.level[e] = 1;
                     st[5] += 1;
                 }
@@ -818,7 +820,8 @@ int orc_local_ba(int P, int L, int E, const double* pose_cw, const uint8_t* pose
             se3_map(&B.pose[obs_pose[e]], &B.pt[3 * obs_point[e]], pc);
             const int mono = obs_uvr[3 * e + 2] < 0;
             const float thr = mono ? 5.99146f : 7.81473f;
-            outlier_out[e] = ((double)thr < chi || !depth_ok(&B.intr[5 * obs_pose[e]], pc)) ? 1 : 0;
+            const int marker_edge = obs_huber && obs_huber[e] < 0; /* nor does the outlier loop :354-375 */
+            outlier_out[e] = (!marker_edge && ((double)thr < chi || !depth_ok(&B.intr[5 * obs_pose[e]], pc))) ? 1 : 0;
         }
         /* chi2 over the finally-active set */
         st[1] = active_robust_chi2(&B);

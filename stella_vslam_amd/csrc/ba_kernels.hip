@@ -522,7 +522,9 @@ __global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_
     cam_point(st_pose(D, 0) + (size_t)p * 12, st_pt(D, 0) + (size_t)l * 3, pc);
     const bool mono = D.e_uvr[(size_t)e * 3 + 2] < 0.f;
     const double thr = mono ? (double)5.99146f : (double)7.81473f;
-    const bool out = thr < D.e_chi[e] || !(cam_is_equirect(D.intr + (size_t)p * 5) || 0.0 < pc[2]);
+    // a negative Huber width marks a marker-corner edge: those live in a container of their own that neither the gate loop nor the
+    // outlier loop visits (local_bundle_adjuster_g2o.cc:246-304 against :324-343, :354-375)
+    const bool out = !(D.e_huber[e] < 0.f) && (thr < D.e_chi[e] || !(cam_is_equirect(D.intr + (size_t)p * 5) || 0.0 < pc[2]));
     if (set_levels) {
         if (out) D.e_level[e] = 1;
         D.e_robust[e] = 0;

@@ -543,6 +543,12 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
             if (!local_lm || local_lm->will_be_erased()) continue;
             local_lms.emplace(local_lm->id_, local_lm);
         }
+    std::map<unsigned int, std::shared_ptr<data::marker>> local_mkrs;  // :86-102
+    for (const auto& id_kf : local_keyfrms)
+        for (const auto& local_mkr : id_kf.second->get_markers()) {
+            if (!local_mkr) continue;
+            local_mkrs.emplace(local_mkr->id_, local_mkr);
+        }
     std::map<unsigned int, kf_ptr> fixed_keyfrms;
     for (const auto& id_lm : local_lms)
         for (const auto& obs : id_lm.second->get_observations()) {
@@ -625,13 +631,43 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
             obs_objects.emplace_back(keyfrm, local_lm);
         }
     }
-    const int L = (int)points.size(), E = (int)obs_pose.size();
+    // marker corners (:246-304): four points per marker that was initialised before or is kept fixed (then fixed vertices), one edge per
+    // observing keyframe of the graph and corner, information 1, no kernel -- and outside the gate / outlier list (negative width, svgpu.h)
+    const int L_lm = (int)points.size();
+    std::vector<uint8_t> point_fixed((size_t)L_lm, 0);
+    std::vector<std::pair<std::shared_ptr<data::marker>, int>> marker_slots;
+    for (const auto& id_mkr : local_mkrs) {
+        const auto& mkr = id_mkr.second;
+        if (!mkr->keep_fixed_ && !mkr->initialized_before_) continue;
+        const int first = (int)point_fixed.size();
+        marker_slots.emplace_back(mkr, first);
+        for (unsigned int corner_idx = 0; corner_idx < 4; ++corner_idx) {
+            point_fixed.push_back(mkr->keep_fixed_ ? 1 : 0);
+            const Vec3_t pw = mkr->corners_pos_w_.at(corner_idx);
+            for (int k = 0; k < 3; ++k) pts.push_back(pw(k));
+            for (const auto& id_keyfrm : mkr->observations_) {
+                const auto& keyfrm = id_keyfrm.second;
+                if (!keyfrm || keyfrm->will_be_erased()) continue;
+                const auto it = pose_index.find(keyfrm->id_);
+                if (it == pose_index.end()) continue;
+                const auto& undist_pt = keyfrm->markers_2d_.at(mkr->id_).undist_corners_.at(corner_idx);
+                obs_pose.push_back(it->second);
+                obs_point.push_back(first + (int)corner_idx);
+                obs_uvr.push_back(undist_pt.x);
+                obs_uvr.push_back(undist_pt.y);
+                obs_uvr.push_back(-1.0f);
+                obs_w.push_back(1.0f);
+                obs_huber.push_back(-1.0f);
+            }
+        }
+    }
+    const int L = (int)point_fixed.size(), E = (int)obs_pose.size();
 
     // 5.-6. the two-stage Levenberg-Marquardt schedule on the device (:306-348)
     svgpu_ba_problem pr;
     std::memset(&pr, 0, sizeof(pr));
     pr.num_poses = P, pr.num_points = L, pr.num_obs = E;
-    pr.pose_cw = pose_cw.data(), pr.pose_fixed = pose_fixed.data(), pr.points = pts.data();
+    pr.pose_cw = pose_cw.data(), pr.pose_fixed = pose_fixed.data(), pr.points = pts.data(), pr.point_fixed = point_fixed.data();
     pr.obs_pose = obs_pose.data(), pr.obs_point = obs_point.data(), pr.obs_uvr = obs_uvr.data(), pr.obs_inv_sigma_sq = obs_w.data(), pr.obs_huber_delta = obs_huber.data();
     pr.intrinsics = intr.data();
     pr.num_first_iter = (int)num_first_iter_, pr.num_second_iter = (int)num_second_iter_;
@@ -646,7 +682,7 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     // 7.-8. outlier observations, then poses and positions under the map mutex (:352-411)
     {
         std::lock_guard<std::mutex> lock(data::map_database::mtx_database_);
-        for (int e = 0; e < E; ++e) {
+        for (int e = 0; e < (int)obs_objects.size(); ++e) {  // (landmark edges come first; marker edges are never outliers)
             if (!outlier[e]) continue;
             const auto& keyfrm = obs_objects[e].first;
             const auto& lm = obs_objects[e].second;
@@ -665,13 +701,19 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
                 for (int j = 0; j < 4; ++j) T(i, j) = pose_out[(size_t)p * 12 + 4 * i + j];
             kv.second->set_pose_cw(T);
         }
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; l < L_lm; ++l) {
             const auto& local_lm = points[l];
             if (local_lm->will_be_erased()) continue;
             Vec3_t pw;
             for (int k = 0; k < 3; ++k) pw(k) = pts_out[(size_t)l * 3 + k];
             local_lm->set_pos_in_world(pw);
             local_lm->update_mean_normal_and_obs_scale_variance();
+        }
+        for (const auto& mk_slot : marker_slots) {  // :411-428
+            const auto& mkr = mk_slot.first;
+            if (mkr->keep_fixed_ || !mkr->initialized_before_) continue;
+            for (int corner_idx = 0; corner_idx < 4; ++corner_idx)
+                for (int k = 0; k < 3; ++k) mkr->corners_pos_w_[corner_idx](k) = pts_out[(size_t)(mk_slot.second + corner_idx) * 3 + k];
         }
     }
 }

@@ -19,6 +19,7 @@
 #include "stella_vslam/feature/orb_params.h"
 #ifndef SVGPU_DROP_IN_MATCH_ONLY
 #include "stella_vslam/data/map_database.h"
+#include "stella_vslam/data/marker.h"
 #include "stella_vslam/optimize/local_bundle_adjuster.h"
 #include <yaml-cpp/yaml.h>
 #endif
@@ -143,7 +144,7 @@ public:
 #endif
 
 //! `backend: "hip"` of the LocalBundleAdjuster YAML node: the sibling of local_bundle_adjuster_g2o (optimize/local_bundle_adjuster_g2o.h)
-//! and local_bundle_adjuster_gtsam.  Gather (local / fixed keyframes, local landmarks, marker-free) and write-back are the host
+//! and local_bundle_adjuster_gtsam.  Gather (local / fixed keyframes, local landmarks, marker corners) and write-back are the host
 //! steps 1 and 7-8 of local_bundle_adjuster_g2o.cc:38-147, 352-430; steps 2-6 are one svgpu_local_ba call.
 class local_bundle_adjuster_hip : public local_bundle_adjuster {
 public:

@@ -470,6 +470,30 @@ int main() {
         const Mat44_t root = M.kfs[0]->get_pose_cw();  // the spanning root is a fixed vertex: its pose comes back bit for bit
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 4; ++j) REQUIRE(kf_pose.at(M.kfs[0]->id_)(i, j) == root(i, j));
+        {  // the local bundle adjuster with the two markers in its window (local_bundle_adjuster_g2o.cc:246-304, 411-428)
+            YAML::Node yaml;
+            yaml.kv["backend"] = "hip";
+            auto lba = optimize::hip_backend::create_local_bundle_adjuster(yaml);
+            auto reproj = [&]() {
+                double e = 0;
+                for (int c = 0; c < 4; ++c)
+                    for (int k : {2, 3, 4, 5}) {
+                        const auto& obs = M.kfs[k]->markers_2d_.at(7).undist_corners_[c];
+                        double u, v, z;
+                        project(M, M.kfs[k]->get_pose_cw(), free_mk->corners_pos_w_[c], u, v, z);
+                        e += std::fabs(u - obs.x) + std::fabs(v - obs.y);
+                    }
+                return e;
+            };
+            const double l0 = reproj();
+            bool no_stop = false;
+            lba->optimize(&M.db, M.kfs[4], &no_stop);
+            const double l1 = reproj();
+            std::fprintf(stderr, "[ba+markers] free marker reprojection error in the window %.1f -> %.1f px (sum)\n", l0, l1);
+            REQUIRE(static_cast<const optimize::local_bundle_adjuster_hip*>(lba.get())->last_status_ == 0 && l1 < 0.2 * l0);
+            for (int c = 0; c < 4; ++c)
+                for (int i = 0; i < 3; ++i) REQUIRE(fixed_mk->corners_pos_w_[c](i) == fixed_before[c](i));
+        }
         // optimize_for_initialization writes the map directly; with fix_markers the free marker keeps its corners
         const auto free_before = free_mk->corners_pos_w_;
         std::vector<std::shared_ptr<data::marker>> mks{free_mk, fixed_mk};

@@ -100,6 +100,29 @@ def test_local_ba_fixed_points_and_no_kernel(ba):
     assert np.array_equal(got["outlier"], ref["outlier"])
 
 
+def test_local_ba_marker_corner_edges_stay_out_of_the_gate(ba):
+    """A negative Huber width marks a marker-corner edge (local_bundle_adjuster_g2o.cc:246-304: own container, no kernel, information as given):
+    neither the chi-square / depth gate after stage 1 nor the outlier list sees it, however large its error."""
+    sc = S.ba_scene(num_kf=8, num_lm=500, obs_per_lm=4, num_fixed=2, seed=21)
+    rng = np.random.default_rng(3)
+    mk = np.flatnonzero(sc["obs_point"] % 11 == 0)               # every edge of some points: "corners"
+    sc["obs_huber"][mk] = -1.0
+    sc["obs_inv_sigma_sq"][mk] = 1.0
+    bad = mk[::6]
+    sc["obs_uvr"][bad, 0] += rng.choice([-1, 1], len(bad)).astype(np.float32) * 9.0   # chi-square 81 at information 1: far past 5.99146
+    got = ba.optimize_flat(sc)
+    ref = O.local_ba(sc)
+    assert got["stats"]["num_gated"] == ref["stats"][5] and got["stats"]["iters_stage1"] == ref["stats"][2] and got["stats"]["iters_stage2"] == ref["stats"][3]
+    _assert_poses(got["pose_cw"], ref["pose_cw"])
+    assert _rel(got["points"], ref["points"]) < TOL
+    assert np.array_equal(got["outlier"], ref["outlier"])
+    assert not got["outlier"][mk].any() and got["outlier"].sum() > 0
+    # the same edges with a zero width (no kernel, but ordinary landmark edges) are gated
+    sc["obs_huber"][mk] = 0.0
+    again = ba.optimize_flat(sc)
+    assert again["outlier"][bad].sum() > 0.8 * len(bad)
+
+
 def test_local_ba_landmark_seen_twice_from_one_keyframe(ba):
     """The flat problem does not forbid two observations of one landmark from one keyframe; their cross terms enter the keyframe's
     diagonal block twice (mirrored pairs), and the pair count computed on the host has to agree with what the device emits."""
