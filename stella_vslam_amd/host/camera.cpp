@@ -87,7 +87,7 @@ void compute_descriptors(svgpu_ctx* ctx, const std::vector<int>& obs_off, const 
     if (n <= 0) return;
     std::vector<uint8_t> packed((size_t)obs_desc.rows * 32);
     for (int i = 0; i < obs_desc.rows; ++i) std::memcpy(&packed[(size_t)i * 32], obs_desc.ptr(i), 32);
-    descriptors.create(n, 32, cv::CV_8U);
+    descriptors.create(n, 32, CV_8U);
     const int rc = svgpu_landmarks_compute_descriptor(ctx, n, obs_off.data(), packed.data(), best_obs.data(), descriptors.ptr(0));
     if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_landmarks_compute_descriptor: ") + svgpu_last_error(ctx));
     best_obs.resize((size_t)n);

@@ -48,7 +48,7 @@ void orb_extractor::configure(int cols, int rows) {
 
 void orb_extractor::create_rectangle_mask(unsigned int cols, unsigned int rows) {
     if (rect_mask_.empty()) {
-        rect_mask_.create((int)rows, (int)cols, cv::CV_8UC1);
+        rect_mask_.create((int)rows, (int)cols, CV_8UC1);
         for (unsigned y = 0; y < rows; ++y) std::memset(rect_mask_.ptr((int)y), 255, cols);
     }
     for (const auto& r : mask_rects_) {  // cv::rectangle(..., -1): both corner points are inside the filled area
@@ -91,7 +91,7 @@ void orb_extractor::extract(const cv::_InputArray& in_image, const cv::_InputArr
         out_descriptors.release();
         return;
     }
-    out_descriptors.create(n, 32, cv::CV_8U);
+    out_descriptors.create(n, 32, CV_8U);
     cv::Mat d = out_descriptors.getMat();
     for (int i = 0; i < n; ++i) std::memcpy(d.ptr(i), desc.data() + (size_t)i * 32, 32);
     keypts.resize((size_t)n);
@@ -103,7 +103,7 @@ void orb_extractor::sync_image_pyramid() {
     for (unsigned l = 1; l < orb_params_->num_levels_; ++l) {
         int w = 0, h = 0;
         check(ctx_, svgpu_orb_level_size(ctx_, (int)l, &w, &h), "svgpu_orb_level_size");
-        image_pyramid_.at(l).create(h, w, cv::CV_8UC1);
+        image_pyramid_.at(l).create(h, w, CV_8UC1);
         check(ctx_, svgpu_orb_pyramid_download(ctx_, 0, (int)l, image_pyramid_.at(l).ptr(), (int)image_pyramid_.at(l).step),
               "svgpu_orb_pyramid_download");
     }

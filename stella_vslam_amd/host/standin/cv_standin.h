@@ -8,10 +8,10 @@
 #include <memory>
 #include <vector>
 
+#define CV_8U 0    // macros, as in OpenCV's cvdef.h: the adaptors spell the depth the way code written against OpenCV does
+#define CV_8UC1 0
 namespace cv {
 
-constexpr int CV_8U = 0;
-constexpr int CV_8UC1 = 0;
 
 struct Point2f {
     float x = 0, y = 0;

@@ -306,7 +306,7 @@ inline void landmark::compute_descriptor() {  // median-of-distances representat
             best = i;
         }
     }
-    descriptor_.create(1, 32, cv::CV_8U);
+    descriptor_.create(1, 32, CV_8U);
     std::memcpy(descriptor_.ptr(0), descs[best], 32);
 }
 

@@ -11,7 +11,7 @@
 using namespace stella_vslam_hip;
 
 static cv::Mat synth(int w, int h, unsigned seed) {
-    cv::Mat m(h, w, cv::CV_8UC1);
+    cv::Mat m(h, w, CV_8UC1);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) m.ptr(y)[x] = (uint8_t)(((x + 2 * y) >> 2) & 255);
     unsigned long long s = seed * 2654435761ull + 88172645463325252ull;
@@ -172,7 +172,7 @@ int main() {
     // stereo: right image = left shifted by 20 px -> the recovered disparity is 20
     {
         feature::orb_extractor ext_r(&params, 800);
-        cv::Mat right(480, 640, cv::CV_8UC1);
+        cv::Mat right(480, 640, CV_8UC1);
         for (int y = 0; y < 480; ++y)
             for (int x = 0; x < 640; ++x) right.ptr(y)[x] = img.ptr(y)[std::min(x + 20, 639)];
         std::vector<cv::KeyPoint> kl, kr;
@@ -211,7 +211,7 @@ int main() {
         const Mat33_t R = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         const Vec3_t t = {0.1, -0.05, 0.2}, twc = {-0.1, 0.05, -0.2};
         const int n = (int)k1.size();
-        lms.descriptors.create(n, 32, cv::CV_8U);
+        lms.descriptors.create(n, 32, CV_8U);
         for (int i = 0; i < n; ++i) {
             const double depth = 3.0 + (i % 50) * 0.1;
             const Vec3_t pc = {brg[i][0] / brg[i][2] * depth, brg[i][1] / brg[i][2] * depth, depth};
@@ -246,7 +246,7 @@ int main() {
         // flip away from both others) has the smallest median? medians: row0 {0,1,2}->1, row1 {0,1,1}->1, row2 {0,1,2}->1: first wins
         {
             std::vector<int> off(1, 0), best;
-            cv::Mat od(3 * 100, 32, cv::CV_8U), rep;
+            cv::Mat od(3 * 100, 32, CV_8U), rep;
             std::vector<Vec3_t> cams, pos, refc, mnrm;
             std::vector<float> rsf, mxd, mnd;
             for (int l = 0; l < 100; ++l) {
@@ -273,14 +273,14 @@ int main() {
             // as that leaf's word, through the inner node it hangs under
             std::vector<int> coff = {0, 2, 5, 8, 8, 8, 8, 8, 8, 8}, ch = {1, 2, 3, 4, 5, 6, 7, 8}, wid = {-1, -1, -1, 0, 1, 2, 3, 4, 5};
             std::vector<float> ww = {0, 0, 0, 1.f, 2.f, 3.f, 4.f, 5.f, 6.f};
-            cv::Mat nd(9, 32, cv::CV_8U);
+            cv::Mat nd(9, 32, CV_8U);
             std::memset(nd.ptr(0), 0, 9 * 32);
             const int leaf_kp[6] = {0, 10, 20, 30, 40, 50};
             for (int l = 0; l < 6; ++l) std::memcpy(nd.ptr(3 + l), d1.ptr(leaf_kp[l]), 32);
             std::memcpy(nd.ptr(1), d1.ptr(10), 32);  // inner nodes: one of their leaves
             std::memcpy(nd.ptr(2), d1.ptr(40), 32);
             data::bow_vocabulary_hip voc(ext.context(), coff, ch, nd, ww, wid, 2);
-            cv::Mat qd(6, 32, cv::CV_8U);
+            cv::Mat qd(6, 32, CV_8U);
             for (int l = 0; l < 6; ++l) std::memcpy(qd.ptr(l), d1.ptr(leaf_kp[l]), 32);
             std::map<unsigned int, double> bv;
             std::map<unsigned int, std::vector<unsigned int>> fv;

@@ -115,7 +115,7 @@ static void build(toy_map& M, int n_kf, int n_lm, int n_clutter, unsigned seed) 
         }
         const int n = (int)kps.size();
         kf->frm_obs_.undist_keypts_ = kps;
-        kf->frm_obs_.descriptors_.create(n, 32, cv::CV_8U);
+        kf->frm_obs_.descriptors_.create(n, 32, CV_8U);
         kf->frm_obs_.bearings_.resize(n);
         kf->landmarks_.assign(n, nullptr);
         for (int i = 0; i < n; ++i) {

@@ -244,3 +244,55 @@ def test_global_bundle_adjuster_hip_discards_a_run_the_caller_stopped(libs):
     flags[0] = 2
     r, g = _global_both(libs, sc, 0, 1 + np.arange(K), flags, 1 + np.arange(L), np.zeros(L, np.uint8), np.arange(K), 10, True, 1)
     assert r["ok"] == 0 and g["ok"] == 0 and g["kf_opt"].sum() == 0 and g["lm_opt"].sum() == 0 and g["stop"][0] == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------- extractor
+class _Renamed:
+    """The extractor fixture of the product library under the name the reference-side helper calls."""
+
+    def __init__(self, lib):
+        self.svref_orb_extract = lib.svref_dropin_orb_extract
+
+
+@pytest.fixture(scope="module")
+def extract_libs():
+    a, b = os.path.join(_DIR, "libsvref.so"), os.path.join(_DIR, "libsvref_xdropin.so")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref/libsvref{,_xdropin}.so absent: built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    return C.CDLL(a), _Renamed(C.CDLL(b))
+
+
+@pytest.mark.parametrize("w,h,seed,kw", [(640, 480, 1, {}), (641, 479, 3, {}), (1241, 376, 4, dict(ini_thr=12)), (200, 150, 5, dict(min_area=100)),
+                                         (640, 480, 6, dict(scale_factor=1.5, num_levels=4)), (640, 480, 8, dict(ini_thr=40, min_thr=30))])
+def test_orb_extractor_adaptor_against_the_reference_extractor(extract_libs, w, h, seed, kw):
+    """feature::orb_extractor::extract of the reference (feature/orb_extractor.cc, orb_impl.cc compiled where they lie; the OpenCV primitives
+    behind the stand-in headers are the oracle's) and the product's adaptor class (host/orb_extractor.cpp in its OpenCV mode over the same
+    stand-in cv::Mat / cv::KeyPoint / _InputArray / _OutputArray) on the same image: the seven keypoint fields and the descriptors bit for
+    bit, image_pyramid_ level by level."""
+    ref, prod = extract_libs
+    X = _load_cases("test_ref_local")
+    img = S.frame_sequence(1, w, h, seed=seed)[0]
+    rk, rd, rp = X._ref_extract(ref, img, **kw)
+    gk, gd, gp = X._ref_extract(prod, img, **kw)
+    assert len(rk) > 0
+    np.testing.assert_array_equal(rk.view(np.uint32), gk.view(np.uint32))
+    np.testing.assert_array_equal(rd, gd)
+    for a, b in zip(rp, gp):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_orb_extractor_adaptor_with_masks_against_the_reference_extractor(extract_libs):
+    ref, prod = extract_libs
+    X = _load_cases("test_ref_local")
+    img = S.frame_sequence(1, 640, 480, seed=9)[0]
+    yy, xx = np.mgrid[0:480, 0:640]
+    mask = np.ones((480, 640), np.uint8)
+    mask[(xx - 320) ** 2 + (yy - 200) ** 2 <= 120 ** 2] = 0
+    mask[400:, :] = 0
+    rects = [[0.0, 1.0, 0.0, 0.2], [0.3, 0.55, 0.45, 0.75], [0.8, 1.0, 0.0, 1.0], [0.1, 0.1203125, 0.5, 0.503125]]  # create_rectangle_mask on both sides
+    for kw in (dict(mask=mask), dict(rects=rects)):
+        rk, rd, _ = X._ref_extract(ref, img, **kw)
+        gk, gd, _ = X._ref_extract(prod, img, **kw)
+        assert len(rk) > 0
+        np.testing.assert_array_equal(rk.view(np.uint32), gk.view(np.uint32))
+        np.testing.assert_array_equal(rd, gd)
