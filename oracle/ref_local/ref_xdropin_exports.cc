@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 
+#include "matchers.h"
 #include "orb_extractor.h"
 
 extern "C" int svref_dropin_orb_extract(const unsigned char* img, int w, int h, int stride, const unsigned char* mask, int mask_stride, float scale_factor,
@@ -39,4 +40,49 @@ extern "C" int svref_dropin_orb_extract(const unsigned char* img, int w, int h, 
         }
     }
     return (int)kps.size();
+}
+
+// Both halves of a stereo frame through the product's classes: two extractors (one context each, as system.cc:427-434 runs them), then
+// match::stereo::compute on their device-resident pyramids.  Out: what the two extractors produced -- keypoints (28-byte records), descriptors, the
+// pyramids as image_pyramid_ holds them after sync_image_pyramid() -- so that the test can hand exactly these to the REFERENCE's match::stereo
+// (svref_stereo_compute, ref_match_exports.cc), and the product's x_right / depths.  Returns the number of left keypoints, nr through *n_right.
+extern "C" int svref_dropin_stereo(const unsigned char* left, const unsigned char* right, int w, int h, float scale_factor, unsigned int num_levels,
+                                   unsigned int ini_thr, unsigned int min_thr, float focal_x_baseline, float true_baseline, int cap, float* kl_out,
+                                   unsigned char* dl_out, float* kr_out, unsigned char* dr_out, int* n_right, unsigned char* pyr_left, unsigned char* pyr_right,
+                                   float* stereo_x_right, float* depths) {
+    namespace F = stella_vslam_hip::feature;
+    const F::orb_params params("ref", scale_factor, num_levels, ini_thr, min_thr);
+    F::orb_extractor el(&params, 800), er(&params, 800);
+    std::vector<cv::KeyPoint> kl, kr;
+    cv::Mat dl, dr;
+    el.extract(cv::Mat(h, w, CV_8UC1, const_cast<unsigned char*>(left), (size_t)w), cv::Mat(), kl, dl);
+    er.extract(cv::Mat(h, w, CV_8UC1, const_cast<unsigned char*>(right), (size_t)w), cv::Mat(), kr, dr);
+    if ((int)kl.size() > cap || (int)kr.size() > cap) return -1;
+    std::vector<float> xr, dp;
+    stella_vslam_hip::match::stereo(&el, &er, kl, kr, dl, dr, focal_x_baseline, true_baseline).compute(xr, dp);
+    auto dump = [&](const std::vector<cv::KeyPoint>& k, const cv::Mat& d, float* ko, unsigned char* dd) {
+        for (size_t i = 0; i < k.size(); ++i) {
+            float* o = ko + 7 * i;
+            o[0] = k[i].pt.x, o[1] = k[i].pt.y, o[2] = k[i].size, o[3] = k[i].angle, o[4] = k[i].response;
+            std::memcpy(o + 5, &k[i].octave, 4);  // (the 28-byte record: octave and class_id stay integers)
+            std::memcpy(o + 6, &k[i].class_id, 4);
+            std::memcpy(dd + 32 * i, d.ptr((int)i), 32);
+        }
+    };
+    dump(kl, dl, kl_out, dl_out);
+    dump(kr, dr, kr_out, dr_out);
+    *n_right = (int)kr.size();
+    el.sync_image_pyramid();
+    er.sync_image_pyramid();
+    for (unsigned int l = 0; l < num_levels; ++l)
+        for (int side = 0; side < 2; ++side) {
+            const cv::Mat& m = (side ? er : el).image_pyramid_.at(l);
+            unsigned char*& out = side ? pyr_right : pyr_left;
+            for (int y = 0; y < m.rows; ++y) {
+                std::memcpy(out, m.ptr(y), m.cols);
+                out += m.cols;
+            }
+        }
+    for (size_t i = 0; i < kl.size(); ++i) stereo_x_right[i] = xr[i], depths[i] = dp[i];
+    return (int)kl.size();
 }

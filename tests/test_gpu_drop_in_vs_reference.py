@@ -296,3 +296,52 @@ def test_orb_extractor_adaptor_with_masks_against_the_reference_extractor(extrac
         assert len(rk) > 0
         np.testing.assert_array_equal(rk.view(np.uint32), gk.view(np.uint32))
         np.testing.assert_array_equal(rd, gd)
+
+
+@pytest.mark.parametrize("disp,noise", [(12, 0), (31, 2)])
+def test_stereo_adaptor_against_the_reference_stereo_matcher(disp, noise):
+    """A stereo frame through the product's classes (two feature::orb_extractor adaptors, match::stereo on their device-resident pyramids), then
+    the REFERENCE's match::stereo (match/stereo.cc compiled where it lies) on exactly what the two extractors put out -- keypoints, descriptors,
+    image_pyramid_: x_right and depths bit for bit."""
+    a, b = os.path.join(_DIR, "libsvref.so"), os.path.join(_DIR, "libsvref_xdropin.so")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref/libsvref{,_xdropin}.so absent: built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    ref, prod = C.CDLL(a), C.CDLL(b)
+    from oracle import oracle as O
+    big = S.frame(640 + 64, 480, 5)
+    left, right = np.ascontiguousarray(big[:, 8:648]), np.ascontiguousarray(big[:, 8 + disp:648 + disp])
+    if noise:
+        rng = np.random.default_rng(disp)
+        right = np.clip(right.astype(np.int16) + rng.integers(-noise, noise + 1, right.shape), 0, 255).astype(np.uint8)
+    w, h, L, cap = 640, 480, 8, 4000
+    sizes = O.level_sizes(w, h, 1.2, L)
+    kl, kr = np.zeros((cap, 7), np.float32), np.zeros((cap, 7), np.float32)
+    dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    pyl, pyr = np.zeros(sum(x * y for x, y in sizes), np.uint8), np.zeros(sum(x * y for x, y in sizes), np.uint8)
+    gxr, gdp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nr = C.c_int(0)
+    fxb, bl = 458.654 * 0.11, 0.11
+    prod.svref_dropin_stereo.restype = C.c_int
+    nl = prod.svref_dropin_stereo(_p(left), _p(right), w, h, C.c_float(1.2), L, 20, 7, C.c_float(fxb), C.c_float(bl), cap, _p(kl), _p(dl), _p(kr), _p(dr),
+                                  C.byref(nr), _p(pyl), _p(pyr), _p(gxr), _p(gdp))
+    assert nl > 1500 and nr.value > 1500
+    levels_l, levels_r, off = [], [], 0
+    for (lw_, lh_) in sizes:
+        levels_l.append(np.ascontiguousarray(pyl[off:off + lw_ * lh_].reshape(lh_, lw_)))
+        levels_r.append(np.ascontiguousarray(pyr[off:off + lw_ * lh_].reshape(lh_, lw_)))
+        off += lw_ * lh_
+    np.testing.assert_array_equal(levels_l[0], left)   # image_pyramid_[0] is the caller's image
+    PL = (C.c_void_p * L)(*[x.ctypes.data for x in levels_l])
+    PR = (C.c_void_p * L)(*[x.ctypes.data for x in levels_r])
+    lw = np.array([x.shape[1] for x in levels_l], np.int32)
+    lh = np.array([x.shape[0] for x in levels_l], np.int32)
+    ls = np.array([x.strides[0] for x in levels_l], np.int32)
+    kl28, kr28 = np.ascontiguousarray(kl[:nl]), np.ascontiguousarray(kr[:nr.value])   # 7 x 4 bytes per keypoint: the record svref_stereo_compute takes
+    dl_, dr_ = np.ascontiguousarray(dl[:nl]), np.ascontiguousarray(dr[:nr.value])
+    rxr, rdp = np.zeros(nl, np.float32), np.zeros(nl, np.float32)
+    ref.svref_stereo_compute.restype = None
+    ref.svref_stereo_compute(_p(kl28), _p(dl_), nl, _p(kr28), _p(dr_), nr.value, PL, PR, _p(lw), _p(lh), _p(ls), _p(ls), C.c_float(1.2), L, C.c_float(fxb),
+                             C.c_float(bl), _p(rxr), _p(rdp))
+    assert (rxr >= 0).sum() > 500
+    np.testing.assert_array_equal(rxr.view(np.uint32), gxr[:nl].view(np.uint32))
+    np.testing.assert_array_equal(rdp.view(np.uint32), gdp[:nl].view(np.uint32))
