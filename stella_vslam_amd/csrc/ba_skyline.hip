@@ -41,19 +41,34 @@ struct SkyDev {
     double* dinv = nullptr;         // nP x 36: inverses of the diagonal factors (lower triangular)
     double* y = nullptr;            // n: right-hand side / solution in elimination order
     size_t nblocks = 0;
+    int y_from = 0x7fffffff;        // positions >= y_from get no right-hand side from the assembly (the separator rows of the second half, below)
 };
 
-__global__ __launch_bounds__(256) void k_sky_assemble(BaDev D, SkyDev K) {
+// Two-sided ("twisted") elimination of a banded system: the elimination order is cut into T | S | B with |S| = W block rows (no block
+// couples T and B), one workgroup eliminates T top-down on the plan of [T, S], a second one B bottom-up on the plan of the REVERSED
+// [B, S] -- the same kernel on a second set of arrays --, the Schur complements they leave on S are added, S is factored, and the
+// substitutions run inwards / outwards the same way.  Three flags in global memory carry the hand-overs (value = the solve's epoch,
+// negative = "my half failed"): f[0] second -> first: the S x S window; f[1] second -> first: its share of the right-hand side of S;
+// f[2] first -> second: x_S.  Same arithmetic per block as the one-sided kernel, half the dependent chain.
+struct SkyTwist {
+    int on = 0, m = 0, W = 0, nB = 0;  // first S position in the first plan; separator rows; eliminated columns of the second plan
+    double* xch = nullptr;             // [W (W + 1) / 2 x 36: S x S blocks of the second plan's window][6 W: its y_S][6 W: x_S of the first plan]
+    int* flags = nullptr;
+};
+
+__global__ __launch_bounds__(256) void k_sky_assemble(BaDev D, SkyDev K0, SkyDev K1) {  // blockIdx.y = plan (a block / slot a plan does not hold maps to -1)
     if (D.ctl->phase != 1) return;
+    const SkyDev& K = blockIdx.y ? K1 : K0;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t < (size_t)K.NB * 36) {
         const int k = (int)(t / 36), e = (int)(t - (size_t)k * 36), i = e / 6, j = e - 6 * i;
         const int2 m = K.blkmap[k];
-        K.val[(size_t)m.x * 36 + (m.y ? j * 6 + i : e)] = D.Sblk[t];
+        if (m.x >= 0) K.val[(size_t)m.x * 36 + (m.y ? j * 6 + i : e)] = D.Sblk[t];
     }
     if (t < (size_t)D.n) {
         const int a = (int)(t / 6), c = (int)(t - (size_t)a * 6);
-        K.y[K.pos[a] * 6 + c] = D.g[t];
+        const int p = K.pos[a];
+        if (p >= 0 && p < K.y_from) K.y[p * 6 + c] = D.g[t];
     }
 }
 
@@ -134,12 +149,12 @@ __device__ __forceinline__ void sky_pivot(const double* src, double* dstL, doubl
 // Narrow columns (at most 16 rows below the diagonal -- every banded envelope): the factor rows of the next FOUR columns are in flight
 // while a column is processed (a global load takes ~1 us seen from one wave, a column step ~0.2 us), and the backward sums are combined
 // by a shuffle tree inside groups of eight lanes instead of sixty lane broadcasts.
-__device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane) {
-    const int nP = K.nP;
+// (columns jb .. je - 1 of the forward pass, columns jhi .. jlo of the backward pass: the two-sided kernel runs them in pieces)
+__device__ __forceinline__ void sky_forward_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane, int jb, int je) {
     constexpr int PD = 4;
     {   // forward: lane rr < 6 holds row rr of Li_j; item k of a lane = (row (lane + 64 k) / 6 of the column, component (lane + 64 k) % 6)
         auto load = [&](int j, double (&li)[6], double (&bl)[2][6], int (&dst)[2]) {
-            if (j >= nP) return;
+            if (j >= je) return;
             const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
             const int rr = min(lane, 5);
 #pragma unroll
@@ -160,12 +175,12 @@ __device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s
         double li[PD][6], bl[PD][2][6];
         int dst[PD][2];
 #pragma unroll
-        for (int d = 0; d < PD; ++d) load(d, li[d], bl[d], dst[d]);
-        for (int j0 = 0; j0 < nP; j0 += PD) {
+        for (int d = 0; d < PD; ++d) load(jb + d, li[d], bl[d], dst[d]);
+        for (int j0 = jb; j0 < je; j0 += PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 const int j = j0 + d;
-                if (j >= nP) break;
+                if (j >= je) break;
                 double v = 0.0;  // z[rr] on lane rr < 6
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
@@ -188,10 +203,13 @@ __device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s
             }
         }
     }
+}
+__device__ __forceinline__ void sky_backward_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane, int jhi, int jlo) {
+    constexpr int PD = 4;
     {   // backward: w = z_j - sum_{i in rows(j)} L_ij^T x_i, lane = component * 8 + part (48 lanes), a lane's rows: part and part + 8
         const int a = min(lane >> 3, 5), part = lane & 7;
         auto load = [&](int j, double (&lc)[6], double (&bc)[2][6], int (&src)[2]) {
-            if (j < 0) return;
+            if (j < jlo) return;
             const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
             const int ac = min(lane, 5);
 #pragma unroll
@@ -211,12 +229,12 @@ __device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s
         double lc[PD][6], bc[PD][2][6];
         int src[PD][2];
 #pragma unroll
-        for (int d = 0; d < PD; ++d) load(nP - 1 - d, lc[d], bc[d], src[d]);
-        for (int j0 = nP - 1; j0 >= 0; j0 -= PD) {
+        for (int d = 0; d < PD; ++d) load(jhi - d, lc[d], bc[d], src[d]);
+        for (int j0 = jhi; j0 >= jlo; j0 -= PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 const int j = j0 - d;
-                if (j < 0) break;
+                if (j < jlo) break;
                 double v = 0.0;
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
@@ -242,6 +260,10 @@ __device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s
             }
         }
     }
+}
+__device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane) {
+    sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, 0, K.nP);
+    sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, K.nP - 1, 0);
 }
 
 __device__ __forceinline__ void sky_substitute(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int tid) {
@@ -506,13 +528,27 @@ __device__ __forceinline__ void block_sync_lds() { asm volatile("s_waitcnt lgkmc
 #ifndef SKY_BAND_THREADS
 #define SKY_BAND_THREADS 512  // 256: 1.81 ms per config-5 solve, 512: 1.59 (the update of a column fits one round), 1024: 2.41 (128 VGPRs: the substitutions spill)
 #endif
-__global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K) {
+// hand-over flags of the two-sided elimination (agent scope: the two workgroups sit on different compute units)
+__device__ __forceinline__ void sky_post(int* flag, int value) {
+    __threadfence();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int sky_wait(int* flag, int epoch) {  // +-epoch
+    int v;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != epoch && v != -epoch) __builtin_amdgcn_s_sleep(4);
+    return v;
+}
+__device__ __forceinline__ double sky_peek(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // past this unit's L1
+
+__global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K0, SkyDev K1, SkyTwist T, int epoch) {
     if (D.ctl->phase != 1) return;
-    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][n: right-hand side][index arrays]
+    const int who = blockIdx.x;  // 0: the whole system, or [T, S] of a two-sided elimination; 1: the reversed [B, S]
+    const SkyDev& K = who ? K1 : K0;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][6 nP: right-hand side][index arrays]
     __shared__ double s_Li[36];
-    __shared__ int s_fail;
+    __shared__ int s_fail, s_other;
     __shared__ unsigned short s_pq[SKY_BAND_W * (SKY_BAND_W + 1) / 2];  // pair index -> p | q << 8 (q <= p), row-major over the lower triangle
-    const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP, W = K.max_m, Wn = W + 1;
+    const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP, W = K.max_m, Wn = W + 1, ny = 6 * nP;
     if (tid < SKY_BAND_W * (SKY_BAND_W + 1) / 2) {
         int p, q;
         tri_index(tid, p, q);
@@ -521,13 +557,13 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     double* const s_win = s_dyn;
     double* const s_col = s_win + (size_t)Wn * Wn * 36;
     double* const s_y = s_col + (size_t)W * 36;
-    int* const s_coloff = reinterpret_cast<int*>(s_y + D.n);
+    int* const s_coloff = reinterpret_cast<int*>(s_y + ny);
     int* const s_first = s_coloff + (nP + 1);
     int* const s_rbase = s_first + nP;   // rowoff[i] - first[i]: block (i, k) of the envelope = s_rbase[i] + k
     int* const s_rows = s_rbase + nP;    // for the substitution routine
     int* const s_base = s_rows + K.ncr;
-    if (tid == 0) s_fail = 0;
-    for (int t = tid; t < D.n; t += nt) s_y[t] = K.y[t];
+    if (tid == 0) s_fail = 0, s_other = epoch;
+    for (int t = tid; t < ny; t += nt) s_y[t] = K.y[t];
     for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
     for (int t = tid; t < nP; t += nt) {
         s_first[t] = K.first[t];
@@ -565,76 +601,172 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
             Dst[b] -= v;
         }
     };
+    // columns jb .. je - 1 (the pivot of column jb is in s_Li when it starts; the pivot of column je is NOT taken: it may wait for the other half)
+    auto factor = [&](int jb, int je) {
+        for (int j = jb; j < je; ++j) {
+            if (s_fail) break;
+            const int m = s_coloff[j + 1] - s_coloff[j];
+            // the row that enters the window behind this column: requested now, stored in LDS behind the update
+            const int inew = j + Wn;
+            double pre[3];  // (W + 1) x 36 <= 612 entries over the workgroup's threads
+            int npre = 0, fnew = 0;
+            if (inew < nP) {
+                fnew = max(s_first[inew], j + 1);
+                npre = (inew - fnew + 1) * 36;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int t = tid + q * SKY_BAND_THREADS;
+                    if (t < npre) pre[q] = K.val[(size_t)(s_rbase[inew] + fnew + t / 36) * 36 + t % 36];
+                }
+            }
+            for (int t = tid; t < m * 36; t += nt) {  // L_ij = S_ij L_jj^-T
+                const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
+                const double* Bl = slot(j + 1 + r, j) + a * 6;
+                double v = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
+                s_col[t] = v;
+            }
+            block_sync_lds();
+            for (int t = tid; t < m * 36; t += nt) K.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
+            const int npair = m * (m + 1) / 2;
+            if (tid < 64) {
+                if (m > 0 && tid < 6) update_item(j, tid);  // pair (0, 0) = block (j + 1, j + 1)
+                wave_lds_order();
+                if (j + 1 < je)
+                    sky_pivot(slot(j + 1, j + 1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li, &s_fail, tid);
+            }
+            else {
+                for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(j, t);
+            }
+            if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot of column j long ago)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int t = tid + q * SKY_BAND_THREADS;
+                    if (t < npre) slot(inew, fnew + t / 36)[t % 36] = pre[q];
+                }
+            }
+            block_sync_lds();
+        }
+    };
+    const int nA = T.on ? (who ? T.nB : T.m) : nP;  // columns of the first stretch
+    const int Ws = T.W, npairS = Ws * (Ws + 1) / 2;
+    double* const xS2 = T.xch;                      // the second plan's S x S window blocks, its own (reversed) order
+    double* const xY = T.xch + (size_t)npairS * 36; // its y_S
+    double* const xX = xY + 6 * Ws;                 // x_S of the first plan
     if (tid < 64) sky_pivot(slot(0, 0), K.val + (size_t)s_rbase[0] * 36, K.dinv, s_Li, &s_fail, tid);
     block_sync_lds();
-    for (int j = 0; j < nP; ++j) {
-        if (s_fail) break;
-        const int m = s_coloff[j + 1] - s_coloff[j];
-        // the row that enters the window behind this column: requested now, stored in LDS behind the update
-        const int inew = j + Wn;
-        double pre[3];  // (W + 1) x 36 <= 612 entries over the workgroup's threads
-        int npre = 0, fnew = 0;
-        if (inew < nP) {
-            fnew = max(s_first[inew], j + 1);
-            npre = (inew - fnew + 1) * 36;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int t = tid + q * SKY_BAND_THREADS;
-                if (t < npre) pre[q] = K.val[(size_t)(s_rbase[inew] + fnew + t / 36) * 36 + t % 36];
+    factor(0, nA);
+    __syncthreads();
+    if (T.on && who == 1) {  // hand the Schur complement on S over (rows nB .. nB + W - 1 are the trailing rows of the window)
+        for (int t = tid; t < npairS * 36; t += nt) {
+            const int x = t / 36, e = t - 36 * x;
+            int r, c;
+            tri_index(x, r, c);
+            xS2[t] = slot(nA + r, nA + c)[e];
+        }
+        __syncthreads();
+        if (tid == 0) sky_post(T.flags + 0, s_fail ? -epoch : epoch);
+    }
+    if (T.on && who == 0) {
+        if (tid == 0) {
+            const int v = sky_wait(T.flags + 0, epoch);
+            if (v < 0) s_other = v;
+        }
+        __syncthreads();
+        if (s_other < 0 && tid == 0) s_fail = 1;
+        __syncthreads();
+        if (!s_fail) {  // block (i, k) of S here is the transposed block (k', i') there, i' = nP_total - 1 - i
+            for (int t = tid; t < npairS * 36; t += nt) {
+                const int x = t / 36, e = t - 36 * x, a = e / 6, b = e - 6 * a;
+                int r, c;
+                tri_index(x, r, c);
+                const int k = nA + Ws - 1 - r, i = nA + Ws - 1 - c;
+                slot(i, k)[b * 6 + a] += sky_peek(xS2 + t);
             }
+            __syncthreads();
+            if (tid < 64) sky_pivot(slot(nA, nA), K.val + (size_t)(s_rbase[nA] + nA) * 36, K.dinv + (size_t)nA * 36, s_Li, &s_fail, tid);
+            block_sync_lds();
+            factor(nA, nP);
+            __syncthreads();
         }
-        for (int t = tid; t < m * 36; t += nt) {  // L_ij = S_ij L_jj^-T
-            const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
-            const double* Bl = slot(j + 1 + r, j) + a * 6;
-            double v = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-                if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
-            s_col[t] = v;
+    }
+    // ---- substitutions on the first wave (the factor blocks written above are read back from global memory)
+    if (tid < 64) {
+        const int lane = tid;
+        if (!T.on) {
+            if (!s_fail) sky_substitute_narrow(K, s_y, s_coloff, s_rows, s_base, lane);
         }
-        block_sync_lds();
-        for (int t = tid; t < m * 36; t += nt) K.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
-        const int npair = m * (m + 1) / 2;
-        if (tid < 64) {
-            if (m > 0 && tid < 6) update_item(j, tid);  // pair (0, 0) = block (j + 1, j + 1)
+        else if (who == 1) {
+            if (!s_fail) sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, 0, nA);
             wave_lds_order();
-            if (j + 1 < nP)
-                sky_pivot(slot(j + 1, j + 1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li, &s_fail, tid);
+            for (int t = lane; t < 6 * Ws; t += 64) xY[t] = s_y[nA * 6 + t];
+            if (lane == 0) sky_post(T.flags + 1, s_fail ? -epoch : epoch);
+            int v = 0;
+            if (lane == 0) v = sky_wait(T.flags + 2, epoch);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v < 0 && lane == 0) s_fail = 1;
+            wave_lds_order();
+            if (!s_fail) {  // x of position nB + q here is x of position m + W - 1 - q there
+                for (int t = lane; t < 6 * Ws; t += 64) s_y[(nA + t / 6) * 6 + t % 6] = sky_peek(xX + (Ws - 1 - t / 6) * 6 + t % 6);
+                wave_lds_order();
+                sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nA - 1, 0);
+            }
         }
         else {
-            for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(j, t);
-        }
-        if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot of column j long ago)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int t = tid + q * SKY_BAND_THREADS;
-                if (t < npre) slot(inew, fnew + t / 36)[t % 36] = pre[q];
+            if (!s_fail) sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, 0, nA);
+            int v = 0;
+            if (lane == 0) v = sky_wait(T.flags + 1, epoch);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v < 0 && lane == 0) s_fail = 1;
+            wave_lds_order();
+            if (!s_fail) {
+                for (int t = lane; t < 6 * Ws; t += 64) s_y[(nA + t / 6) * 6 + t % 6] += sky_peek(xY + (Ws - 1 - t / 6) * 6 + t % 6);
+                wave_lds_order();
+                sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nA, nP);
+                sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nP - 1, nA);
+                wave_lds_order();
+                for (int t = lane; t < 6 * Ws; t += 64) xX[t] = s_y[nA * 6 + t];
             }
+            if (lane == 0) sky_post(T.flags + 2, s_fail ? -epoch : epoch);
+            if (!s_fail) sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nA - 1, 0);
         }
-        block_sync_lds();
     }
-    __syncthreads();  // the factor blocks written above are read by the substitutions
+    __syncthreads();
+    const int own_to = T.on && who == 1 ? nA : nP;  // the separator's unknowns are written by the first workgroup
     if (s_fail) {
         if (tid == 0) D.ctl->solve_failed = 1;
-        for (int t = tid; t < D.n; t += nt) D.dp[t] = 0.0;
+        for (int t = tid; t < D.n; t += nt) {
+            const int pa = K.pos[t / 6];
+            if (pa >= 0 && pa < own_to) D.dp[t] = 0.0;
+        }
         return;
     }
-    if (tid < 64) sky_substitute_narrow(K, s_y, s_coloff, s_rows, s_base, tid);  // W <= 16; this kernel has the registers for the 4-deep prefetch
-    __syncthreads();
     for (int t = tid; t < D.n; t += nt) {
-        const int a = t / 6, c = t - 6 * a;
-        D.dp[t] = s_y[K.pos[a] * 6 + c];
+        const int a = t / 6, c = t - 6 * a, pa = K.pos[a];
+        if (pa >= 0 && pa < own_to) D.dp[t] = s_y[pa * 6 + c];
     }
 }
 
 struct SkyPlan {
-    SkyDev dev;
+    SkyDev dev[2];     // [1] only for the two-sided elimination
+    SkyTwist twist;
+    int epoch = 0;
     void* d_int = nullptr;
     size_t int_bytes = 0;
     void* d_val = nullptr;
-    size_t val_bytes = 0;
+    size_t val_bytes = 0, val_used = 0;
     bool usable = false;
-    int max_m = 0;
+};
+
+// the index arrays of one plan on the host: elimination order `order` (position -> slot) over a subset of the slots
+struct HostSky {
+    std::vector<int> pos, first, rowoff, coloff, colrows, colbase, diag;
+    std::vector<int2> blkmap;
+    size_t nblocks = 0;
+    int nP = 0, max_m = 0;
+    bool band = false, ok = false;
 };
 
 // reverse Cuthill-McKee over the block graph (every component from a minimum-degree node of a far BFS level)
@@ -694,6 +826,86 @@ void sv_sky_release(svgpu_ctx* ctx) {
     ctx->ba_sky = nullptr;
 }
 
+// Index arrays of the envelope over `order` (position -> slot; a subset of the nS slots).  Positions >= sep are separator rows of a
+// two-sided elimination: dense among themselves after the elimination (their envelopes reach back to `sep`); with drop_sep their own
+// blocks are not assembled into this plan (the other plan holds them).
+static void host_sky(int nS, const std::vector<int>& order, const std::vector<std::vector<int>>& adj, const std::vector<int2>& blk_ab, int sep, bool drop_sep,
+                     size_t max_bytes, HostSky& H) {
+    const int nP = (int)order.size();
+    H = HostSky();
+    H.nP = nP;
+    H.pos.assign(nS, -1);
+    H.first.resize(nP);
+    H.rowoff.resize(nP + 1);
+    for (int i = 0; i < nP; ++i) H.pos[order[i]] = i;
+    for (int i = 0; i < nP; ++i) {
+        int f = i;
+        for (int v : adj[order[i]])
+            if (H.pos[v] >= 0) f = std::min(f, H.pos[v]);
+        if (i >= sep) f = std::min(f, sep);
+        H.first[i] = f;
+    }
+    // A non-decreasing first[] makes the rows of every column contiguous (the banded kernel); taking the suffix minimum only adds
+    // blocks, so it is kept when the envelope grows by less than a third and stays narrow.
+    {
+        std::vector<int> fm(H.first);
+        for (int i = nP - 2; i >= 0; --i) fm[i] = std::min(fm[i], fm[i + 1]);
+        size_t n0 = 0, n1 = 0;
+        int wmax = 0;
+        for (int i = 0; i < nP; ++i) {
+            n0 += (size_t)(i - H.first[i] + 1);
+            n1 += (size_t)(i - fm[i] + 1);
+            wmax = std::max(wmax, i - fm[i]);
+        }
+        if (wmax <= SKY_BAND_W && 3 * n1 <= 4 * n0 && !std::getenv("SVGPU_SKY_NO_BAND")) {
+            H.first = fm;
+            H.band = true;
+        }
+    }
+    size_t nblocks = 0;
+    for (int i = 0; i < nP; ++i) {
+        H.rowoff[i] = (int)nblocks;
+        nblocks += (size_t)(i - H.first[i] + 1);
+        if (nblocks * 288 > max_bytes || nblocks > (size_t)1 << 30) return;
+    }
+    H.rowoff[nP] = (int)nblocks;
+    H.nblocks = nblocks;
+    H.coloff.assign(nP + 1, 0);
+    for (int i = 0; i < nP; ++i)
+        for (int j = H.first[i]; j < i; ++j) H.coloff[j + 1]++;
+    for (int j = 0; j < nP; ++j) {
+        H.max_m = std::max(H.max_m, H.coloff[j + 1]);
+        H.coloff[j + 1] += H.coloff[j];
+    }
+    if (H.max_m > SKY_MAXM) return;
+    H.colrows.resize(H.coloff[nP]);
+    H.colbase.resize(H.coloff[nP]);
+    H.diag.resize(nP);
+    std::vector<int> fill(H.coloff.begin(), H.coloff.end() - 1);
+    for (int i = 0; i < nP; ++i) {  // rows ascending
+        H.diag[i] = H.rowoff[i] + i - H.first[i];
+        for (int j = H.first[i]; j < i; ++j) {
+            H.colbase[fill[j]] = H.rowoff[i] - H.first[i];
+            H.colrows[fill[j]++] = i;
+        }
+    }
+    // scaled column + right-hand side + index arrays must fit the LDS
+    if ((size_t)H.max_m * 288 + (size_t)nP * 48 + 4 * ((size_t)2 * nP + 1 + 2 * H.colrows.size()) > 150 * 1024) return;
+    H.blkmap.resize(blk_ab.size());
+    for (size_t k = 0; k < blk_ab.size(); ++k) {
+        const int pa = H.pos[blk_ab[k].x], pb = H.pos[blk_ab[k].y];
+        int2 m;
+        m.x = -1, m.y = 0;
+        if (pa >= 0 && pb >= 0 && !(drop_sep && pa >= sep && pb >= sep)) {
+            const int row = std::max(pa, pb), col = std::min(pa, pb);
+            m.x = H.rowoff[row] + col - H.first[row];
+            m.y = pa > pb || pa == pb ? 0 : 1;  // the kept block is S_ab; the envelope stores S_{row, col}: transposed when row = pos[b]
+        }
+        H.blkmap[k] = m;
+    }
+    H.ok = true;
+}
+
 // Plans the envelope factorisation of the reduced system whose kept upper blocks are blk_ab (a <= b, free-pose slots).  *usable = false
 // (and nothing else changes) when the envelope would exceed max_bytes or a column has more than SKY_MAXM rows: the caller keeps the PCG.
 int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable) {
@@ -706,73 +918,40 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
             adj[ab.y].push_back(ab.x);
         }
     const std::vector<int> order = rcm_order(nP, adj);  // position -> slot
-    std::vector<int> pos(nP), first(nP), rowoff(nP + 1);
-    for (int i = 0; i < nP; ++i) pos[order[i]] = i;
-    for (int i = 0; i < nP; ++i) {
-        int f = i;
-        for (int v : adj[order[i]]) f = std::min(f, pos[v]);
-        first[i] = f;
-    }
-    // A non-decreasing first[] makes the rows of every column contiguous (the banded kernel); taking the suffix minimum only adds
-    // blocks, so it is kept when the envelope grows by less than a third and stays narrow.
-    bool band = false;
-    {
-        std::vector<int> fm(first);
-        for (int i = nP - 2; i >= 0; --i) fm[i] = std::min(fm[i], fm[i + 1]);
-        size_t n0 = 0, n1 = 0;
-        int wmax = 0;
-        for (int i = 0; i < nP; ++i) {
-            n0 += (size_t)(i - first[i] + 1);
-            n1 += (size_t)(i - fm[i] + 1);
-            wmax = std::max(wmax, i - fm[i]);
+    HostSky H[2];
+    host_sky(nP, order, adj, blk_ab, nP, false, max_bytes, H[0]);
+    if (!H[0].ok) return SVGPU_OK;
+    // two-sided elimination of a long band: T | S | B with S = as many rows as the band is wide (then no block couples T and B)
+    int nplans = 1, tw_m = 0, tw_W = 0, tw_nB = 0;
+    if (H[0].band && H[0].max_m >= 1 && nP >= 8 * (H[0].max_m + 1) && !std::getenv("SVGPU_SKY_ONE_SIDED")) {
+        const int W = H[0].max_m, m = (nP - W) / 2, nB = nP - m - W;
+        std::vector<int> o0(order.begin(), order.begin() + m + W), o1(order.rbegin(), order.rbegin() + nB + W);
+        HostSky A, B;
+        host_sky(nP, o0, adj, blk_ab, m, false, max_bytes, A);
+        host_sky(nP, o1, adj, blk_ab, nB, true, max_bytes, B);
+        const int Ww = std::max(W, std::max(A.max_m, B.max_m));  // one window size, wide enough for all of S
+        auto band_lds = [&](const HostSky& h) {
+            return ((size_t)(Ww + 1) * (Ww + 1) * 36 + (size_t)Ww * 36 + (size_t)6 * h.nP) * sizeof(double) + 4 * ((size_t)3 * h.nP + 1 + 2 * h.colrows.size());
+        };
+        if (A.ok && B.ok && A.band && B.band && Ww <= SKY_BAND_W && std::max(band_lds(A), band_lds(B)) <= 150 * 1024) {
+            A.max_m = B.max_m = Ww;
+            H[0] = std::move(A);
+            H[1] = std::move(B);
+            nplans = 2, tw_m = m, tw_W = W, tw_nB = nB;
         }
-        if (wmax <= SKY_BAND_W && 3 * n1 <= 4 * n0 && !std::getenv("SVGPU_SKY_NO_BAND")) {
-            first = fm;
-            band = true;
-        }
-    }
-    size_t nblocks = 0;
-    for (int i = 0; i < nP; ++i) {
-        rowoff[i] = (int)nblocks;
-        nblocks += (size_t)(i - first[i] + 1);
-        if (nblocks * 288 > max_bytes || nblocks > (size_t)1 << 30) return SVGPU_OK;
-    }
-    rowoff[nP] = (int)nblocks;
-    std::vector<int> coloff(nP + 1, 0);
-    for (int i = 0; i < nP; ++i)
-        for (int j = first[i]; j < i; ++j) coloff[j + 1]++;
-    int max_m = 0;
-    for (int j = 0; j < nP; ++j) {
-        max_m = std::max(max_m, coloff[j + 1]);
-        coloff[j + 1] += coloff[j];
-    }
-    if (max_m > SKY_MAXM) return SVGPU_OK;
-    std::vector<int> colrows(coloff[nP]), colbase(coloff[nP]), diag(nP), fill(coloff.begin(), coloff.end() - 1);
-    for (int i = 0; i < nP; ++i) {  // rows ascending
-        diag[i] = rowoff[i] + i - first[i];
-        for (int j = first[i]; j < i; ++j) {
-            colbase[fill[j]] = rowoff[i] - first[i];
-            colrows[fill[j]++] = i;
-        }
-    }
-    // scaled column + right-hand side + index arrays must fit the LDS
-    if ((size_t)max_m * 288 + (size_t)nP * 48 + 4 * ((size_t)2 * nP + 1 + 2 * colrows.size()) > 150 * 1024) return SVGPU_OK;
-    std::vector<int2> blkmap(blk_ab.size());
-    for (size_t k = 0; k < blk_ab.size(); ++k) {
-        const int pa = pos[blk_ab[k].x], pb = pos[blk_ab[k].y];
-        const int row = std::max(pa, pb), col = std::min(pa, pb);
-        int2 m;
-        m.x = rowoff[row] + col - first[row];
-        m.y = pa > pb || pa == pb ? 0 : 1;  // the kept block is S_ab; the envelope stores S_{row, col}: transposed when row = pos[b]
-        blkmap[k] = m;
     }
     SkyPlan* P = (SkyPlan*)ctx->ba_sky;
     if (!P) {
         P = new SkyPlan();
         ctx->ba_sky = P;
     }
-    // one integer arena: pos | first | rowoff | coloff | colrows | blkmap
-    const size_t n_int = (size_t)nP * 3 + (size_t)(nP + 1) * 2 + 2 * colrows.size() + blkmap.size() * 2 + 8;
+    // one integer arena per call: for every plan pos | first | rowoff | coloff | colrows | colbase | diag | blkmap; then the flags
+    size_t n_int = 16, n_val = 8;
+    for (int q = 0; q < nplans; ++q) {
+        n_int += (size_t)nP + (size_t)H[q].nP * 2 + (size_t)(H[q].nP + 1) * 2 + 2 * H[q].colrows.size() + H[q].blkmap.size() * 2 + 8;
+        n_val += H[q].nblocks * 36 + (size_t)H[q].nP * 36 + (size_t)H[q].nP * 6;
+    }
+    n_val += (size_t)tw_W * (tw_W + 1) / 2 * 36 + 12 * (size_t)tw_W;
     if (n_int * 4 > P->int_bytes) {
         if (P->d_int) {
             SV_HIP(ctx, hipStreamSynchronize(s));
@@ -783,7 +962,7 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
         SV_HIP(ctx, hipMalloc(&P->d_int, n_int * 4 + n_int));
         P->int_bytes = n_int * 4 + n_int;
     }
-    const size_t val_need = (nblocks * 36 + (size_t)nP * 36 + (size_t)nP * 6 + 8) * sizeof(double);
+    const size_t val_need = n_val * sizeof(double);
     if (val_need > P->val_bytes) {
         if (P->d_val) {
             SV_HIP(ctx, hipStreamSynchronize(s));
@@ -794,64 +973,98 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
         SV_HIP(ctx, hipMalloc(&P->d_val, val_need + val_need / 4));
         P->val_bytes = val_need + val_need / 4;
     }
+    P->val_used = val_need;
     std::vector<int> host;
     host.reserve(n_int);
     auto put = [&](const int* p, size_t n) {
+        if (host.size() & 1) host.push_back(0);  // (int2 alignment for whoever needs it)
         const size_t at = host.size();
         host.insert(host.end(), p, p + n);
         return at;
     };
-    const size_t o_pos = put(pos.data(), nP), o_first = put(first.data(), nP), o_rowoff = put(rowoff.data(), nP + 1), o_coloff = put(coloff.data(), nP + 1);
-    const size_t o_colrows = put(colrows.data(), colrows.size()), o_colbase = put(colbase.data(), colbase.size()), o_diag = put(diag.data(), nP);
-    if (host.size() & 1) host.push_back(0);  // int2 alignment
-    const size_t o_blkmap = put(reinterpret_cast<const int*>(blkmap.data()), blkmap.size() * 2);
+    struct Off {
+        size_t pos, first, rowoff, coloff, colrows, colbase, diag, blkmap;
+    } off[2];
+    for (int q = 0; q < nplans; ++q) {
+        const HostSky& h = H[q];
+        off[q].pos = put(h.pos.data(), h.pos.size());
+        off[q].first = put(h.first.data(), h.nP);
+        off[q].rowoff = put(h.rowoff.data(), h.nP + 1);
+        off[q].coloff = put(h.coloff.data(), h.nP + 1);
+        off[q].colrows = put(h.colrows.data(), h.colrows.size());
+        off[q].colbase = put(h.colbase.data(), h.colbase.size());
+        off[q].diag = put(h.diag.data(), h.nP);
+        off[q].blkmap = put(reinterpret_cast<const int*>(h.blkmap.data()), h.blkmap.size() * 2);
+    }
+    const int zeros[4] = {0, 0, 0, 0};
+    const size_t o_flags = put(zeros, 4);
     SV_HIP(ctx, hipMemcpyAsync(P->d_int, host.data(), host.size() * 4, hipMemcpyHostToDevice, s));
     SV_HIP(ctx, hipStreamSynchronize(s));  // `host` is a pageable temporary
     int* di = (int*)P->d_int;
-    SkyDev& K = P->dev;
-    K.nP = nP;
-    K.NB = (int)blk_ab.size();
-    K.pos = di + o_pos;
-    K.first = di + o_first;
-    K.rowoff = di + o_rowoff;
-    K.coloff = di + o_coloff;
-    K.colrows = di + o_colrows;
-    K.colbase = di + o_colbase;
-    K.diag = di + o_diag;
-    K.max_m = max_m;
-    K.ncr = (int)colrows.size();
-    K.band = band ? 1 : 0;
-    K.blkmap = reinterpret_cast<const int2*>(di + o_blkmap);
-    K.val = (double*)P->d_val;
-    K.dinv = K.val + nblocks * 36;
-    K.y = K.dinv + (size_t)nP * 36;
-    K.nblocks = nblocks;
-    P->max_m = max_m;
+    double* dv = (double*)P->d_val;
+    for (int q = 0; q < 2; ++q) P->dev[q] = SkyDev();
+    for (int q = 0; q < nplans; ++q) {
+        const HostSky& h = H[q];
+        SkyDev& K = P->dev[q];
+        K.nP = h.nP;
+        K.NB = (int)blk_ab.size();
+        K.pos = di + off[q].pos;
+        K.first = di + off[q].first;
+        K.rowoff = di + off[q].rowoff;
+        K.coloff = di + off[q].coloff;
+        K.colrows = di + off[q].colrows;
+        K.colbase = di + off[q].colbase;
+        K.diag = di + off[q].diag;
+        K.max_m = h.max_m;
+        K.ncr = (int)h.colrows.size();
+        K.band = h.band ? 1 : 0;
+        K.blkmap = reinterpret_cast<const int2*>(di + off[q].blkmap);
+        K.val = dv;
+        K.dinv = K.val + h.nblocks * 36;
+        K.y = K.dinv + (size_t)h.nP * 36;
+        K.nblocks = h.nblocks;
+        dv = K.y + (size_t)h.nP * 6;
+    }
+    P->twist = SkyTwist();
+    if (nplans == 2) {
+        P->dev[1].y_from = tw_nB;  // the right-hand side of S goes into the first plan only
+        P->twist.on = 1, P->twist.m = tw_m, P->twist.W = tw_W, P->twist.nB = tw_nB;
+        P->twist.xch = dv;
+        P->twist.flags = di + o_flags;
+    }
+    P->epoch = 0;
     P->usable = true;
     *usable = true;
     if (std::getenv("SVGPU_BA_TRACE"))
-        std::fprintf(stderr, "[ba]     envelope plan: %d block rows, %zu blocks (%.1f MB), widest column %d rows%s\n", nP, nblocks, nblocks * 288.0 / 1048576.0, max_m, band ? ", banded" : "");
+        std::fprintf(stderr, "[ba]     envelope plan: %d block rows, %zu blocks (%.1f MB), widest column %d rows%s%s\n", nP, H[0].nblocks + (nplans == 2 ? H[1].nblocks : 0),
+                     (H[0].nblocks + (nplans == 2 ? H[1].nblocks : 0)) * 288.0 / 1048576.0, H[0].max_m, H[0].band ? ", banded" : "",
+                     nplans == 2 ? ", two-sided elimination" : "");
     return SVGPU_OK;
 }
 
 void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SkyPlan* P = (SkyPlan*)ctx->ba_sky;
     SvProfScope ps(ctx, s, "ba_solve");
-    const SkyDev& K = P->dev;
-    // blocks of the envelope the reduced system does not fill must start at zero in every trial
-    (void)hipMemsetAsync(K.val, 0, K.nblocks * 36 * sizeof(double), s);
+    const SkyDev& K = P->dev[0];
+    const int nplans = P->twist.on ? 2 : 1;
+    // blocks of the envelope the reduced system does not fill must start at zero in every trial (and the right-hand side rows a plan is not given)
+    (void)hipMemsetAsync(P->d_val, 0, P->val_used, s);
     const size_t items = std::max((size_t)K.NB * 36, (size_t)D.n);
-    hipLaunchKernelGGL(k_sky_assemble, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, D, K);
+    hipLaunchKernelGGL(k_sky_assemble, dim3((unsigned)((items + 255) / 256), nplans), dim3(256), 0, s, D, P->dev[0], P->dev[1]);
     if (K.band) {
-        const size_t wn = (size_t)K.max_m + 1;
-        const size_t lds = (wn * wn * 36 + (size_t)K.max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)3 * K.nP + 1 + 2 * (size_t)K.ncr);
+        size_t lds = 0;
+        for (int q = 0; q < nplans; ++q) {
+            const SkyDev& k = P->dev[q];
+            const size_t wn = (size_t)k.max_m + 1;
+            lds = std::max(lds, (wn * wn * 36 + (size_t)k.max_m * 36 + (size_t)6 * k.nP) * sizeof(double) + 4 * ((size_t)3 * k.nP + 1 + 2 * (size_t)k.ncr));
+        }
         if (lds <= 150 * 1024) {
             (void)sv_allow_dynamic_lds((const void*)k_sky_band, lds);
-            hipLaunchKernelGGL(k_sky_band, dim3(1), dim3(SKY_BAND_THREADS), lds, s, D, K);
+            hipLaunchKernelGGL(k_sky_band, dim3(nplans), dim3(SKY_BAND_THREADS), lds, s, D, P->dev[0], P->dev[1], P->twist, ++P->epoch);
             return;
         }
     }
-    const size_t lds = ((size_t)P->max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)2 * K.nP + 1 + 2 * (size_t)K.ncr);
+    const size_t lds = ((size_t)K.max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)2 * K.nP + 1 + 2 * (size_t)K.ncr);
     (void)sv_allow_dynamic_lds((const void*)k_sky_factor_solve, lds);
-    hipLaunchKernelGGL(k_sky_factor_solve, dim3(1), dim3(P->max_m <= 21 ? 256 : SKY_THREADS), lds, s, D, K);
+    hipLaunchKernelGGL(k_sky_factor_solve, dim3(1), dim3(K.max_m <= 21 ? 256 : SKY_THREADS), lds, s, D, K);
 }
