@@ -396,6 +396,25 @@ def test_global_ba_config5_matches_oracle():
     assert _rel(pcg["points"], got["points"]) < TOL
 
 
+def test_global_ba_two_sided_elimination_equals_one_sided(monkeypatch):
+    """A long band is eliminated from both ends by two workgroups (ba_skyline.hip: T | S | B, the Schur complements added on the separator);
+    SVGPU_SKY_ONE_SIDED=1 keeps the single top-down sweep.  Same blocks, same arithmetic per block, another order of the sums on S: the two
+    must agree far below the parity tolerance, with the same LM schedule -- on a ring (the loop closure puts a few wide rows into the band)
+    and on an open chain."""
+    from stella_vslam_amd import optimize
+    for kw in (dict(num_kf=160, num_lm=40000), dict(num_kf=240, num_lm=30000, obs_per_lm=4)):
+        sc = S.ba_scene_large(**kw)
+        monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+        two = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+        monkeypatch.setenv("SVGPU_SKY_ONE_SIDED", "1")
+        one = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+        monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+        assert two["stats"]["iters_stage1"] == one["stats"]["iters_stage1"] and two["stats"]["cholesky_failures"] == 0 == one["stats"]["pcg_iterations"]
+        assert two["stats"]["chi2_final"] == pytest.approx(one["stats"]["chi2_final"], rel=1e-9)
+        assert np.abs(two["pose_cw"] - one["pose_cw"]).max() < 1e-8 and np.abs(two["points"] - one["points"]).max() < 1e-8
+        assert two["stats"]["chi2_final"] < 0.6 * two["stats"]["chi2_initial"]
+
+
 def test_sharded_through_rccl_communicator_world1():
     """svgpu_comm_init (RCCL resolved with dlopen inside the library) + svgpu_local_ba_sharded with allreduce = NULL: one rank is
     all a single GPU allows (RCCL refuses two ranks on one device), but it drives every collective of the sharded solve through
