@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <thread>
 
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
@@ -177,10 +178,23 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || (!outlier_out && !single_stage))))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: inconsistent problem");
     bool lm_major = true;  // observations already grouped by landmark (the order local_bundle_adjuster_g2o.cc:168-227 creates its edges in)
-    for (int e = 0; e < E; ++e) {
-        if (pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L)
-            return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
-        lm_major = lm_major && (e == 0 || pr->obs_point[e] >= pr->obs_point[e - 1]);
+    {
+        const int nv = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD") ? 4 : 1;  // (four host threads at global-BA sizes, as for the staging passes below)
+        int bad[4] = {0, 0, 0, 0}, unsorted[4] = {0, 0, 0, 0};
+        auto check = [&](int q) {
+            int b = 0, u = 0;
+            for (size_t e = (size_t)E * q / nv, end = (size_t)E * (q + 1) / nv; e < end; ++e) {
+                b |= pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L;
+                u |= e != 0 && pr->obs_point[e] < pr->obs_point[e - 1];
+            }
+            bad[q] = b, unsorted[q] = u;
+        };
+        std::vector<std::thread> th;
+        for (int q = 1; q < nv; ++q) th.emplace_back(check, q);
+        check(0);
+        for (auto& t : th) t.join();
+        if (bad[0] | bad[1] | bad[2] | bad[3]) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+        lm_major = !(unsorted[0] | unsorted[1] | unsorted[2] | unsorted[3]);
     }
     const bool sharded = allreduce != nullptr;
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
@@ -262,16 +276,35 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int* const pe_idx = (int*)(hs + in.pe_idx);
     std::vector<int> perm;  // sorted position -> caller's observation index (empty = identity)
     std::vector<uint8_t> level(E, 0);
-    for (int l = 0; l <= L; ++l) lm_off[l] = 0;
-    for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
-    for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
+    if (lm_major) {  // grouped by landmark already: the offsets are the run boundaries (one sequential pass, no histogram)
+        int e = 0;
+        for (int l = 0; l <= L; ++l) {
+            while (e < E && pr->obs_point[e] < l) ++e;
+            lm_off[l] = e;
+        }
+    }
+    else {
+        for (int l = 0; l <= L; ++l) lm_off[l] = 0;
+        for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
+        for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
+    }
+    const int nth = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD") ? 4 : 1;  // host threads of the staging passes at global-BA sizes
+    std::vector<int> pe_cnt((size_t)nth * P, 0);  // observations per (thread range, pose)
     if (lm_major) {
-        memcpy(e_pose, pr->obs_pose, 4 * (size_t)E);
-        memcpy(e_point, pr->obs_point, 4 * (size_t)E);
-        memcpy(e_uvr, pr->obs_uvr, 12 * (size_t)E);
-        memcpy(e_w, pr->obs_inv_sigma_sq, 4 * (size_t)E);
-        if (pr->obs_huber_delta) memcpy(e_hub, pr->obs_huber_delta, 4 * (size_t)E);
-        else memset(e_hub, 0, 4 * (size_t)E);
+        // (a global-BA sized problem is 34 MB of observations: four host threads share the copy into the staging image)
+        auto copy_range = [&](size_t a, size_t b) {
+            memcpy(e_pose + a, pr->obs_pose + a, 4 * (b - a));
+            memcpy(e_point + a, pr->obs_point + a, 4 * (b - a));
+            memcpy(e_uvr + 3 * a, pr->obs_uvr + 3 * a, 12 * (b - a));
+            memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
+            if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
+            else memset(e_hub + a, 0, 4 * (b - a));
+            for (size_t k = a; k < b; ++k) robust[k] = e_hub[k] > 0.f;
+        };
+        std::vector<std::thread> th;
+        for (int q = 1; q < nth; ++q) th.emplace_back(copy_range, (size_t)E * q / nth, (size_t)E * (q + 1) / nth);
+        copy_range(0, (size_t)E / nth);
+        for (auto& t : th) t.join();
     }
     else {
         perm.resize(E);
@@ -288,14 +321,35 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             e_hub[k] = pr->obs_huber_delta ? pr->obs_huber_delta[e] : 0.f;
         }
     }
-    for (int k = 0; k < E; ++k) robust[k] = e_hub[k] > 0.f;
+    if (!lm_major)
+        for (int k = 0; k < E; ++k) robust[k] = e_hub[k] > 0.f;
     // pose -> edges (all poses, all levels: the kernels skip excluded edges), in increasing edge order
-    for (int p = 0; p <= P; ++p) pe_off[p] = 0;
-    for (int k = 0; k < E; ++k) pe_off[e_pose[k] + 1]++;
-    for (int p = 0; p < P; ++p) pe_off[p + 1] += pe_off[p];
+    // (a counting sort by pose whose two passes run on `nth` contiguous ranges of k: range q's entries of a pose follow range q - 1's)
     {
-        std::vector<int> fill(pe_off, pe_off + P);
-        for (int k = 0; k < E; ++k) pe_idx[fill[e_pose[k]]++] = k;
+        auto run = [&](auto&& fn) {
+            std::vector<std::thread> th;
+            for (int q = 1; q < nth; ++q) th.emplace_back(fn, q);
+            fn(0);
+            for (auto& t : th) t.join();
+        };
+        run([&](int q) {
+            int* c = pe_cnt.data() + (size_t)q * P;
+            for (size_t k = (size_t)E * q / nth, b = (size_t)E * (q + 1) / nth; k < b; ++k) c[e_pose[k]]++;
+        });
+        int at = 0;
+        for (int p = 0; p < P; ++p) {
+            pe_off[p] = at;
+            for (int q = 0; q < nth; ++q) {
+                const int c = pe_cnt[(size_t)q * P + p];
+                pe_cnt[(size_t)q * P + p] = at;  // becomes the fill cursor of (range q, pose p)
+                at += c;
+            }
+        }
+        pe_off[P] = at;
+        run([&](int q) {
+            int* c = pe_cnt.data() + (size_t)q * P;
+            for (size_t k = (size_t)E * q / nth, b = (size_t)E * (q + 1) / nth; k < b; ++k) pe_idx[c[e_pose[k]]++] = (int)k;
+        });
     }
     memcpy(hs + in.pose, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
