@@ -402,7 +402,7 @@ def test_global_ba_two_sided_elimination_equals_one_sided(monkeypatch):
     must agree far below the parity tolerance, with the same LM schedule -- on a ring (the loop closure puts a few wide rows into the band)
     and on an open chain."""
     from stella_vslam_amd import optimize
-    for kw in (dict(num_kf=160, num_lm=40000), dict(num_kf=240, num_lm=30000, obs_per_lm=4)):
+    for kw in (dict(num_kf=160, num_lm=40000), dict(num_kf=240, num_lm=30000, obs_per_lm=4), dict(num_kf=200, num_lm=20000, obs_per_lm=2)):  # band widths 11, 7 and a narrow one
         sc = S.ba_scene_large(**kw)
         monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
         two = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
