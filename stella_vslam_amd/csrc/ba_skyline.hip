@@ -47,9 +47,8 @@ struct SkyDev {
 // Two-sided ("twisted") elimination of a banded system: the elimination order is cut into T | S | B with |S| = W block rows (no block
 // couples T and B), one workgroup eliminates T top-down on the plan of [T, S], a second one B bottom-up on the plan of the REVERSED
 // [B, S] -- the same kernel on a second set of arrays --, the Schur complements they leave on S are added, S is factored, and the
-// substitutions run inwards / outwards the same way.  Three flags in global memory carry the hand-overs (value = the solve's epoch,
-// negative = "my half failed"): f[0] second -> first: the S x S window; f[1] second -> first: its share of the right-hand side of S;
-// f[2] first -> second: x_S.  Same arithmetic per block as the one-sided kernel, half the dependent chain.
+// substitutions run inwards / outwards the same way.  Two flags in global memory carry the hand-overs (value = the solve's epoch,
+// negative = "my half failed"): f[0] second -> first: the S x S window and its share of the right-hand side of S; f[2] first -> second: x_S.  Same arithmetic per block as the one-sided kernel, half the dependent chain.
 struct SkyTwist {
     int on = 0, m = 0, W = 0, nB = 0;  // first S position in the first plan; separator rows; eliminated columns of the second plan
     double* xch = nullptr;             // [W (W + 1) / 2 x 36: S x S blocks of the second plan's window][6 W: its y_S][6 W: x_S of the first plan]
@@ -545,7 +544,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     const int who = blockIdx.x;  // 0: the whole system, or [T, S] of a two-sided elimination; 1: the reversed [B, S]
     const SkyDev& K = who ? K1 : K0;
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][6 nP: right-hand side][index arrays]
-    __shared__ double s_Li[36];
+    __shared__ double s_Li[2][36];  // inverse diagonal factors of columns j and j + 1 (the look-ahead pivot writes one while the other is in use)
     __shared__ int s_fail, s_other;
     __shared__ unsigned short s_pq[SKY_BAND_W * (SKY_BAND_W + 1) / 2];  // pair index -> p | q << 8 (q <= p), row-major over the lower triangle
     const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP, W = K.max_m, Wn = W + 1, ny = 6 * nP;
@@ -625,7 +624,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                 double v = 0.0;
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
-                    if (c <= b) v += Bl[c] * s_Li[b * 6 + c];
+                    if (c <= b) v += Bl[c] * s_Li[j & 1][b * 6 + c];
                 s_col[t] = v;
             }
             block_sync_lds();
@@ -635,9 +634,31 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                 if (m > 0 && tid < 6) update_item(j, tid);  // pair (0, 0) = block (j + 1, j + 1)
                 wave_lds_order();
                 if (j + 1 < je)
-                    sky_pivot(slot(j + 1, j + 1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li, &s_fail, tid);
+                    sky_pivot(slot(j + 1, j + 1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li[(j + 1) & 1], &s_fail, tid);
             }
             else {
+                if (tid >= nt - 64) {  // the forward substitution of this column rides along on the last wave: z_j = L_jj^-1 y_j, y_i -= L_ij z_j
+                    const int lane = tid - (nt - 64);  // (the sums in the order of sky_forward_narrow: the same bits)
+                    const double* Li = s_Li[j & 1];
+                    double z[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c)
+                            if (c <= r) v += Li[r * 6 + c] * s_y[j * 6 + c];
+                        z[r] = v;
+                    }
+                    wave_lds_order();  // every lane has read y_j
+                    if (lane < 6) s_y[j * 6 + lane] = lane == 0 ? z[0] : lane == 1 ? z[1] : lane == 2 ? z[2] : lane == 3 ? z[3] : lane == 4 ? z[4] : z[5];
+                    for (int t = lane; t < m * 6; t += 64) {
+                        const double* Bl = s_col + t * 6;  // row (t / 6, t % 6) of the scaled column: s_col[r * 36 + a * 6 + c]
+                        double u = Bl[0] * z[0];
+#pragma unroll
+                        for (int c = 1; c < 6; ++c) u += Bl[c] * z[c];
+                        s_y[(j + 1) * 6 + t] -= u;
+                    }
+                }
                 for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(j, t);
             }
             if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot of column j long ago)
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     double* const xS2 = T.xch;                      // the second plan's S x S window blocks, its own (reversed) order
     double* const xY = T.xch + (size_t)npairS * 36; // its y_S
     double* const xX = xY + 6 * Ws;                 // x_S of the first plan
-    if (tid < 64) sky_pivot(slot(0, 0), K.val + (size_t)s_rbase[0] * 36, K.dinv, s_Li, &s_fail, tid);
+    if (tid < 64) sky_pivot(slot(0, 0), K.val + (size_t)s_rbase[0] * 36, K.dinv, s_Li[0], &s_fail, tid);
     block_sync_lds();
     factor(0, nA);
     __syncthreads();
@@ -666,6 +687,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
             tri_index(x, r, c);
             xS2[t] = slot(nA + r, nA + c)[e];
         }
+        for (int t = tid; t < 6 * Ws; t += nt) xY[t] = s_y[nA * 6 + t];  // ... and its share of the right-hand side of S (the forward pass rode along)
         __syncthreads();
         if (tid == 0) sky_post(T.flags + 0, s_fail ? -epoch : epoch);
     }
@@ -685,24 +707,22 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                 const int k = nA + Ws - 1 - r, i = nA + Ws - 1 - c;
                 slot(i, k)[b * 6 + a] += sky_peek(xS2 + t);
             }
+            for (int t = tid; t < 6 * Ws; t += nt) s_y[(nA + t / 6) * 6 + t % 6] += sky_peek(xY + (Ws - 1 - t / 6) * 6 + t % 6);
             __syncthreads();
-            if (tid < 64) sky_pivot(slot(nA, nA), K.val + (size_t)(s_rbase[nA] + nA) * 36, K.dinv + (size_t)nA * 36, s_Li, &s_fail, tid);
+            if (tid < 64) sky_pivot(slot(nA, nA), K.val + (size_t)(s_rbase[nA] + nA) * 36, K.dinv + (size_t)nA * 36, s_Li[nA & 1], &s_fail, tid);
             block_sync_lds();
             factor(nA, nP);
             __syncthreads();
         }
     }
-    // ---- substitutions on the first wave (the factor blocks written above are read back from global memory)
+    // ---- backward substitutions on the first wave (the factor blocks written above are read back from global memory; the forward
+    // pass went with the factorisation)
     if (tid < 64) {
         const int lane = tid;
         if (!T.on) {
-            if (!s_fail) sky_substitute_narrow(K, s_y, s_coloff, s_rows, s_base, lane);
+            if (!s_fail) sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nP - 1, 0);
         }
         else if (who == 1) {
-            if (!s_fail) sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, 0, nA);
-            wave_lds_order();
-            for (int t = lane; t < 6 * Ws; t += 64) xY[t] = s_y[nA * 6 + t];
-            if (lane == 0) sky_post(T.flags + 1, s_fail ? -epoch : epoch);
             int v = 0;
             if (lane == 0) v = sky_wait(T.flags + 2, epoch);
             v = __builtin_amdgcn_readfirstlane(v);
@@ -715,16 +735,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
             }
         }
         else {
-            if (!s_fail) sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, 0, nA);
-            int v = 0;
-            if (lane == 0) v = sky_wait(T.flags + 1, epoch);
-            v = __builtin_amdgcn_readfirstlane(v);
-            if (v < 0 && lane == 0) s_fail = 1;
-            wave_lds_order();
             if (!s_fail) {
-                for (int t = lane; t < 6 * Ws; t += 64) s_y[(nA + t / 6) * 6 + t % 6] += sky_peek(xY + (Ws - 1 - t / 6) * 6 + t % 6);
-                wave_lds_order();
-                sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nA, nP);
                 sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nP - 1, nA);
                 wave_lds_order();
                 for (int t = lane; t < 6 * Ws; t += 64) xX[t] = s_y[nA * 6 + t];
