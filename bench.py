@@ -74,7 +74,7 @@ def spawn_ranks(args) -> int:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (the latency-bound matcher kernels amortise over a larger batch: 64 -> 256 is +7 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,156 +111,25 @@ def main() -> int:
     B = args.batch
     ctx = feature.Context(local_rank, priority=1)  # extraction is the longer leg of the two-stream pipeline: it gets the CUs first
     L = lib()
-    params = feature.orb_params()
-    NL = params.num_levels_
-    ctx.check(L.svgpu_orb_configure(ctx.handle, W, H, B, C.c_float(params.scale_factor_), NL, params.ini_fast_thr_,
-                                    params.min_fast_thr_, C.c_uint(800)), "svgpu_orb_configure")
-    cap = L.svgpu_orb_max_keypoints(ctx.handle)
-    level_px = []
-    for l in range(NL):
-        w_, h_ = C.c_int(), C.c_int()
-        L.svgpu_orb_level_size(ctx.handle, l, C.byref(w_), C.byref(h_))
-        level_px.append(w_.value * h_.value)
-
-    # ---- synthetic input, resident in HBM before the timed region
-    frames_np = synthetic.frame_sequence(B, W, H, seed=0x5EED + 7919 * rank)
-    # Two HIP streams: extraction of step t+1 (stream A = the context's) overlaps the matcher of step t (stream B), which
-    # leaves most CUs idle during its sort / greedy-replay kernels.  Two output buffer sets alternate; events order
-    # extract(t) -> match(t) and match(t) -> extract(t+2) (the next writer of that set).
-    stream = torch.cuda.ExternalStream(ctx.stream)
-    stream_b = torch.cuda.Stream()
-    NBUF = 2
-    with torch.cuda.stream(stream):
-        frames = torch.from_numpy(frames_np).cuda()
-        bufs = [dict(kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"),
-                     desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
-                     counts=torch.zeros(B * (1 + NL), dtype=torch.int32, device="cuda"),
-                     matched=torch.zeros(B * cap, dtype=torch.int32, device="cuda"),
-                     nmatch=torch.zeros(B, dtype=torch.int32, device="cuda"),
-                     ev_ext=torch.cuda.Event(), ev_match=torch.cuda.Event(), used=False) for _ in range(NBUF)]
-    stream.synchronize()
-    nc = 1 + NL
-    state = {"i": 0}
-
-    def match(bf):
-        kps, desc, counts = bf["kps"], bf["desc"], bf["counts"]
-        stream_b.wait_event(bf["ev_ext"])
-        # pair t = (frame (t + 1) % B, keyframe = frame t), t = 0..B-1, straight from the extractor's batch layout
-        ctx.check(L.svgpu_match_consecutive_batch_device(
-            ctx.handle, B, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()), C.c_void_p(counts.data_ptr()), cap, nc, None,
-            C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()), C.c_void_p(bf["nmatch"].data_ptr()),
-            C.c_void_p(stream_b.cuda_stream)), "match_batch")
-        bf["ev_match"].record(stream_b)
-
-    def step():
-        """Extraction of batch t on stream A, then its matcher on stream B: the matcher of batch t overlaps the extraction of batch
-        t+1.  (Measured alternative, rejected: holding the matcher back until the next batch's pyramid kernel -- whose LDS-resident
-        level bands exclude the matcher's distance kernel from a CU -- has finished: 148 k instead of 157 k frames/s; the
-        latency-bound pyramid is exactly where the matcher's kernels fit best.)"""
-        bf = bufs[state["i"] % NBUF]
-        state["i"] += 1
-        kps, desc, counts = bf["kps"], bf["desc"], bf["counts"]
-        if bf["used"]:
-            stream.wait_event(bf["ev_match"])  # the matcher of two steps ago has finished reading this buffer set
-        bf["used"] = True
-        ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(frames.data_ptr()), B, C.c_size_t(W * H), W, None,
-                                                   C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()),
-                                                   cap, C.c_void_p(counts.data_ptr()), None), "extract_batch")
-        bf["ev_ext"].record(stream)
-        match(bf)
-
-    def sync_all():
-        ctx.synchronize()
-        torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # ---- warm-up (untimed) + per-kernel pre-pass to find the dominant kernel
-    for _ in range(max(args.warmup, 1)):
-        step()
-    sync_all()
-    n_kp = bufs[0]["counts"].view(B, nc)[:, 0].float().mean().item()
-    n_match = bufs[0]["nmatch"].float().mean().item()
-    alg = algorithmic_bytes(level_px, n_kp, B)
-    per_kernel = {}
-    for name in alg:
-        L.svgpu_profile_select(ctx.handle, name.encode())
-        step()
-        ms, n = C.c_double(), C.c_longlong()
-        L.svgpu_profile_read(ctx.handle, C.byref(ms), C.byref(n))
-        per_kernel[name] = (ms.value, n.value)
-    dominant = max(per_kernel, key=lambda k: per_kernel[k][0])
-    L.svgpu_profile_select(ctx.handle, dominant.encode())
-
-    # ---- timed region: exactly K steps between barrier + synchronize
-    sync_all()
-    barrier()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    barrier()
-    dt = time.perf_counter() - t0
-    from stella_vslam_amd.distributed import max_over_ranks
-    dt = max_over_ranks(dt)  # MAX over ranks (RCCL when world > 1)
-    ms, n = C.c_double(), C.c_longlong()
-    L.svgpu_profile_read(ctx.handle, C.byref(ms), C.byref(n))
-    L.svgpu_profile_select(ctx.handle, None)
-    k_ms = ms.value / max(n.value, 1)  # mean duration of one launch of the dominant kernel
-    launches_per_step = max(n.value, 1) / args.steps
-    bytes_per_launch = alg[dominant] / launches_per_step   # bytes, or integer operations for the MFMA-bound kernel
-    bound, unit, peak = ROOFS.get(dominant, ("hbm", "GB/s", HBM_PEAK_GBS))
-    achieved = bytes_per_launch / (k_ms * 1e-3) / (1e9 if bound == "hbm" else 1e12)
-
-    # PMC-derived figures (rocprofv3 passes of this same command, tools/pmc_traffic.py / tools/pmc_valu.py) are valid only for the
-    # kernel sources they were taken on: every profiles/*_traffic.json / *_valu_issue.json carries the csrc hash of its run
+    # ---- synthetic input (SURVEY 8(d)), resident in HBM before the timed region
+    frames_np = synthetic.frame_sequence(B, W, H, seed=0x5EED + 7919 * rank)
+    fe = run_front_end(ctx, L, frames_np, B, args.steps, args.warmup, barrier, world)
     src_hash = csrc_hash()
-    traffic_json, valu_json = load_profile_json("*_traffic.json", src_hash, B, world), load_profile_json("*_valu_issue.json", src_hash, B, world)
-    lds_json = load_profile_json("*_lds_mfma.json", src_hash, B, world)  # LDS busy / bank-conflict and matrix-pipe busy fractions (tools/pmc_lds_mfma.py)
-
-    def traffic_of(name):
-        return None if traffic_json is None else traffic_json["kernels"].get(name, {}).get("total")
-
-    def valu_of(name):
-        if valu_json is None or name not in valu_json["kernels"]:
-            return None
-        kv = valu_json["kernels"][name]
-        return {"wave_insts_per_launch": kv["valu_wave_insts"], "cycles_per_wave_inst": valu_json["cycles_per_valu_wave_inst"],
-                "simds": valu_json["simds"], "kernel_cycles": kv["kernel_cycles"], "frac": kv["valu_issue_frac"]}
-
-    kernels = []
-    for name, (kms, kn) in per_kernel.items():
-        if kn == 0:
-            continue
-        b_, u_, p_ = ROOFS.get(name, ("hbm", "GB/s", HBM_PEAK_GBS))
-        per_launch = alg[name] / kn
-        ach = per_launch / (kms / kn * 1e-3) / (1e9 if b_ == "hbm" else 1e12)
-        entry = {"kernel": name, "bound": b_, "unit": u_, "peak": p_, "achieved": round(ach, 2), "frac": round(ach / p_, 5),
-                 "mean_launch_ms": round(kms / kn, 5), "launches_per_step": kn,
-                 ("algorithmic_bytes_per_launch" if b_ == "hbm" else "algorithmic_ops_per_launch"): int(per_launch),
-                 "traffic": traffic_of(name)}
-        if lds_json is not None and name in lds_json["kernels"]:
-            lk = lds_json["kernels"][name]
-            entry["lds_util"], entry["lds_bank_conflict_frac"] = lk["lds_util"], lk["lds_bank_conflict_frac"]
-            if lk.get("mfma_busy_frac"):
-                entry["mfma_busy_frac"] = lk["mfma_busy_frac"]
-        if name == "k_bf_topk":
-            # the distance kernel multiplies only the candidate pairs inside the +-30 degree angle windows of robust.cc:279
-            entry["note"] = ("algorithmic ops = all N1 x N2 pairs x 256 bit positions x 2 (the reference's work); the kernel multiplies only the "
-                             "pairs inside the orientation windows (~22-28 % of them), so the matrix pipe's own utilisation is ~ frac x 0.25")
-        kernels.append(entry)
+    kernels, dom = roofline_entries(fe, src_hash, B, world)
 
     result = {
         "metric": "frames/s ORB-extract+match @640x480,2k kpts",
-        "value": round(B * world * args.steps / dt, 2),
+        "value": round(B * world * args.steps / fe["dt"], 2),
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "ms_per_step": round(fe["dt"] / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -268,19 +137,17 @@ def main() -> int:
         "data": "synthetic",
         "config": {"workload": "synthetic 640x480 frame sequence (BASELINE configs[1] proxy: EuRoC imagery unavailable "
                                "offline), ORB extract + brute-force match vs previous frame",
-                   "frames_per_gpu_per_step": B, "keypoints_per_frame": round(n_kp, 1),
-                   "matches_per_pair": round(n_match, 1), "parallelism": f"frames sharded x{world}, no collective; extraction and matcher on two HIP streams"},
-        "roofline": {"kernel": dominant, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                     "frac": round(achieved / peak, 5), "traffic": traffic_of(dominant), "valu_issue": valu_of(dominant),
-                     ("algorithmic_bytes_per_launch" if bound == "hbm" else "algorithmic_ops_per_launch"): int(bytes_per_launch),
-                     "mean_launch_ms": round(k_ms, 5), "csrc_hash": src_hash,
-                     "pmc_profiles_match_sources": traffic_json is not None,
-                     "per_kernel_ms_per_step": {k: round(v[0], 4) for k, v in per_kernel.items()},
-                     "kernels": kernels},
+                   "frames_per_gpu_per_step": B, "keypoints_per_frame": round(fe["n_kp"], 1),
+                   "matches_per_pair": round(fe["n_match"], 1), "parallelism": f"frames sharded x{world}, no collective; extraction and matcher on two HIP streams",
+                   "input_residency": "the same %d frames (%.0f MB) are re-read every step: they fit the 256 MB Infinity Cache, so level-0 reads need not reach HBM "
+                                      "(no kernel of the step is byte-bound; see roofline.kernels[].traffic)" % (B, B * W * H / 1e6),
+                   "per_kernel_timing": "HIP events around EVERY kernel class on its launch stream inside the timed region (svgpu_profile_select \"*\"); "
+                                        "the same steps re-timed with the events off: %.4f ms per step" % fe["ms_per_step_unprofiled"]},
+        "roofline": dict(dom, csrc_hash=src_hash, per_kernel_ms_per_step={k["kernel"]: round(k["mean_launch_ms"] * k["launches_per_step"], 4) for k in kernels},
+                         kernels=kernels),
     }
+    del fe
 
-    # free the front-end buffers before the other legs
-    del bufs, frames
     torch.cuda.empty_cache()
 
     # The secondary legs must never cost the headline: if one of them hangs (the sharded global BA is the only code of this file that
@@ -302,16 +169,19 @@ def main() -> int:
     watchdog.start()
 
     if rank == 0 and world == 1 and not args.no_extra:
-        for key, fn in (("latency", lambda: bench_latency(ctx, frames_np)), ("stereo", lambda: bench_stereo(local_rank))):
+        for key, fn in (("natural_images", lambda: bench_natural(ctx, L, B, want_cpu=not args.no_cpu_baseline)),
+                        ("latency", lambda: bench_latency(ctx, frames_np)), ("stereo", lambda: bench_stereo(local_rank))):
             try:
                 result[key] = fn()
             except Exception as e:  # a secondary leg must never hide the headline number
                 result[key] = {"error": repr(e)}
     if not args.no_ba:
-        if rank == 0 and world == 1:
-            try:
-                result["local_ba"] = bench_local_ba(ctx)
-            except Exception as e:
+        try:
+            lb = bench_local_ba(ctx, rank, world)
+            if rank == 0:
+                result["local_ba"] = lb
+        except Exception as e:
+            if rank == 0:
                 result["local_ba"] = {"error": repr(e)}
         try:
             gb = bench_global_ba(local_rank, rank, world)
@@ -333,6 +203,218 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+KERNEL_CLASSES = ("k_resize", "k_blur", "k_fast", "k_select", "k_describe", "k_bf_binsort", "k_bf_topk", "k_bf_replay")
+
+
+def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world):
+    """The step of this bench on one rank: ORB extraction of the B resident frames + brute-force match of each against the previous one
+    (ring of B pairs).  Two HIP streams: extraction of step t+1 (stream A = the context's) overlaps the matcher of step t (stream B),
+    which leaves most CUs idle during its sort / greedy-replay kernels.  Two output buffer sets alternate; events order
+    extract(t) -> match(t) and match(t) -> extract(t+2) (the next writer of that set).
+    The timed region (barrier + synchronize on both sides, MAX over ranks) runs with HIP events around EVERY kernel class, so the
+    per-kernel figures are those of the kernels inside this very pipeline; the same number of steps is then re-timed with the events
+    off to show what the bracketing costs."""
+    import torch
+    from stella_vslam_amd import feature
+    from stella_vslam_amd.distributed import max_over_ranks
+    Wf, Hf = frames_np.shape[2], frames_np.shape[1]
+    params = feature.orb_params()
+    NL = params.num_levels_
+    ctx.check(L.svgpu_orb_configure(ctx.handle, Wf, Hf, B, C.c_float(params.scale_factor_), NL, params.ini_fast_thr_,
+                                    params.min_fast_thr_, C.c_uint(800)), "svgpu_orb_configure")
+    cap = L.svgpu_orb_max_keypoints(ctx.handle)
+    level_px = []
+    for l in range(NL):
+        w_, h_ = C.c_int(), C.c_int()
+        L.svgpu_orb_level_size(ctx.handle, l, C.byref(w_), C.byref(h_))
+        level_px.append(w_.value * h_.value)
+    stream = torch.cuda.ExternalStream(ctx.stream)
+    stream_b = torch.cuda.Stream()
+    NBUF = 2
+    nc = 1 + NL
+    with torch.cuda.stream(stream):
+        frames = torch.from_numpy(np.ascontiguousarray(frames_np)).cuda()
+        bufs = [dict(kps=torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"),
+                     desc=torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda"),
+                     counts=torch.zeros(B * nc, dtype=torch.int32, device="cuda"),
+                     matched=torch.zeros(B * cap, dtype=torch.int32, device="cuda"),
+                     nmatch=torch.zeros(B, dtype=torch.int32, device="cuda"),
+                     ev_ext=torch.cuda.Event(), ev_match=torch.cuda.Event(), used=False) for _ in range(NBUF)]
+    stream.synchronize()
+    state = {"i": 0}
+
+    def step():
+        """Extraction of batch t on stream A, then its matcher on stream B: the matcher of batch t overlaps the extraction of batch
+        t+1.  (Measured alternative, rejected: holding the matcher back until the next batch's pyramid kernel has finished: 148 k
+        instead of 157 k frames/s; the latency-bound pyramid is exactly where the matcher's kernels fit best.)"""
+        bf = bufs[state["i"] % NBUF]
+        state["i"] += 1
+        kps, desc, counts = bf["kps"], bf["desc"], bf["counts"]
+        if bf["used"]:
+            stream.wait_event(bf["ev_match"])  # the matcher of two steps ago has finished reading this buffer set
+        bf["used"] = True
+        ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(frames.data_ptr()), B, C.c_size_t(Wf * Hf), Wf, None,
+                                                   C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()),
+                                                   cap, C.c_void_p(counts.data_ptr()), None), "extract_batch")
+        bf["ev_ext"].record(stream)
+        stream_b.wait_event(bf["ev_ext"])
+        # pair t = (frame (t + 1) % B, keyframe = frame t), t = 0..B-1, straight from the extractor's batch layout
+        ctx.check(L.svgpu_match_consecutive_batch_device(
+            ctx.handle, B, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()), C.c_void_p(counts.data_ptr()), cap, nc, None,
+            C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()), C.c_void_p(bf["nmatch"].data_ptr()),
+            C.c_void_p(stream_b.cuda_stream)), "match_batch")
+        bf["ev_match"].record(stream_b)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    def timed(n):
+        sync_all()
+        barrier()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        sync_all()
+        barrier()
+        return time.perf_counter() - t0
+
+    for _ in range(max(warmup, 1)):
+        step()
+    sync_all()
+    n_kp = bufs[0]["counts"].view(B, nc)[:, 0].float().mean().item()
+    n_match = bufs[0]["nmatch"].float().mean().item()
+    # ---- timed region: exactly K steps between barrier + synchronize, every kernel class bracketed by HIP events on its stream
+    L.svgpu_profile_select(ctx.handle, b"*")
+    dt = max_over_ranks(timed(steps))  # MAX over ranks (RCCL when world > 1)
+    per_kernel = {}
+    for name in KERNEL_CLASSES:
+        ms, n = C.c_double(), C.c_longlong()
+        L.svgpu_profile_read_class(ctx.handle, name.encode(), C.byref(ms), C.byref(n))
+        per_kernel[name] = (ms.value, n.value)
+    ops = C.c_ulonglong()
+    L.svgpu_profile_mfma_ops(ctx.handle, C.byref(ops))
+    L.svgpu_profile_select(ctx.handle, None)
+    dt_plain = max_over_ranks(timed(steps))
+    del bufs, frames
+    return {"dt": dt, "ms_per_step_unprofiled": dt_plain / steps * 1e3, "per_kernel": per_kernel, "mfma_ops": ops.value, "steps": steps,
+            "n_kp": n_kp, "n_match": n_match, "alg": algorithmic_bytes(level_px, n_kp, B), "level_px": level_px}
+
+
+def roofline_entries(fe, src_hash, B, world):
+    """roofline.kernels[] (one entry per kernel class, all from the timed region) and the dominant kernel's object."""
+    # PMC-derived figures (rocprofv3 passes of this same command, tools/pmc_traffic.py / tools/pmc_valu.py) are valid only for the
+    # kernel sources they were taken on: every profiles/*_traffic.json / *_valu_issue.json carries the csrc hash of its run
+    traffic_json, valu_json = load_profile_json("*_traffic.json", src_hash, B, world), load_profile_json("*_valu_issue.json", src_hash, B, world)
+    lds_json = load_profile_json("*_lds_mfma.json", src_hash, B, world)  # LDS busy / bank-conflict and matrix-pipe busy fractions (tools/pmc_lds_mfma.py)
+
+    def traffic_of(name):
+        return None if traffic_json is None else traffic_json["kernels"].get(name, {}).get("total")
+
+    def valu_of(name):
+        if valu_json is None or name not in valu_json["kernels"]:
+            return None
+        kv = valu_json["kernels"][name]
+        return {"wave_insts_per_launch": kv["valu_wave_insts"], "cycles_per_wave_inst": valu_json["cycles_per_valu_wave_inst"],
+                "simds": valu_json["simds"], "kernel_cycles": kv["kernel_cycles"], "frac": kv["valu_issue_frac"]}
+
+    kernels = []
+    for name, (kms, kn) in fe["per_kernel"].items():
+        if kn == 0:
+            continue
+        mean_ms = kms / kn
+        lps = kn / fe["steps"]
+        b_, u_, p_ = ROOFS.get(name, ("hbm", "GB/s", HBM_PEAK_GBS))
+        if b_ == "mfma":
+            # primary figure: the int8 operations the matrix cores EXECUTED (counted by the kernel: it multiplies only the pairs inside
+            # the +-30 degree orientation windows of robust.cc:279); context: the reference's all-pairs work over the same time
+            per_launch = fe["mfma_ops"] / kn
+            allpairs = fe["alg"][name] / lps
+        else:
+            per_launch = fe["alg"][name] / lps
+        ach = per_launch / (mean_ms * 1e-3) / (1e9 if b_ == "hbm" else 1e12)
+        entry = {"kernel": name, "bound": b_, "unit": u_, "peak": p_, "achieved": round(ach, 2), "frac": round(ach / p_, 5),
+                 "mean_launch_ms": round(mean_ms, 5), "launches_per_step": lps,
+                 ("algorithmic_bytes_per_launch" if b_ == "hbm" else "executed_int8_ops_per_launch"): int(per_launch),
+                 "traffic": traffic_of(name), "valu_issue": valu_of(name)}
+        if b_ == "mfma":
+            entry["all_pairs_context"] = {"ops_per_launch": int(allpairs), "achieved": round(allpairs / (mean_ms * 1e-3) / 1e12, 2),
+                                          "frac": round(allpairs / (mean_ms * 1e-3) / 1e12 / p_, 5),
+                                          "note": "2 x 256 x N1 x N2 per pair = the work of robust.cc:271-314 if every pair were multiplied"}
+        if lds_json is not None and name in lds_json["kernels"]:
+            lk = lds_json["kernels"][name]
+            entry["lds_util"], entry["lds_bank_conflict_frac"] = lk["lds_util"], lk["lds_bank_conflict_frac"]
+            if lk.get("mfma_busy_frac"):
+                entry["mfma_busy_frac"] = lk["mfma_busy_frac"]
+        kernels.append(entry)
+    dk = max(kernels, key=lambda k: k["mean_launch_ms"] * k["launches_per_step"])
+    dom = {"kernel": dk["kernel"], "bound": dk["bound"], "achieved": dk["achieved"], "peak": dk["peak"], "unit": dk["unit"], "frac": dk["frac"],
+           "traffic": dk["traffic"], "valu_issue": dk["valu_issue"], "mean_launch_ms": dk["mean_launch_ms"],
+           "pmc_profiles_match_sources": traffic_json is not None}
+    for k in ("algorithmic_bytes_per_launch", "executed_int8_ops_per_launch"):
+        if k in dk:
+            dom[k] = dk[k]
+    return kernels, dom
+
+
+def natural_sequence(B, width=W, height=H):
+    """B frames of NATURAL image statistics: 640x480 crops of the reference's own two 1920x960 test images
+    (tests/golden/equirect_00{1,2}_gray.png = test/data/equirectangular_image_00{1,2}.jpg as 8-bit luma).  16 tracks (8 crop
+    origins per image) of B/16 consecutive frames each; inside a track the crop moves by (3, 1) px per frame, so consecutive frames
+    match like a translating camera.  The ring pair that closes a track (last frame against the next track's first) matches little,
+    as a scene cut would."""
+    from PIL import Image
+    imgs = [np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", f"equirect_00{i}_gray.png")), dtype=np.uint8) for i in (1, 2)]
+    tracks, per = 16, max(1, B // 16)
+    out = np.empty((B, height, width), np.uint8)
+    t = 0
+    origins = [(0, 120), (420, 60), (840, 200), (1230, 150), (100, 440), (520, 400), (900, 430), (1200, 380)]
+    while t < B:
+        k = (t // per) % tracks
+        im = imgs[k // 8]
+        ox, oy = origins[k % 8]
+        f = t % per
+        x0, y0 = min(ox + 3 * f, im.shape[1] - width), min(oy + f, im.shape[0] - height)
+        out[t] = im[y0:y0 + height, x0:x0 + width]
+        t += 1
+    return out
+
+
+def quick_test_pass_rate(img, thr):
+    """Fraction of the interior pixels of one level-0 image that pass k_fast's 5-pixel quick test at threshold thr (the necessary
+    condition for a 9-arc on the 16-ring: (p0 | p8) & (p4 | p12) brighter, or darker)."""
+    v = img[3:-3, 3:-3].astype(np.int16)
+    p0, p8 = img[:-6, 3:-3].astype(np.int16), img[6:, 3:-3].astype(np.int16)
+    p4, p12 = img[3:-3, 6:].astype(np.int16), img[3:-3, :-6].astype(np.int16)
+    br = np.minimum(np.maximum(p0, p8), np.maximum(p4, p12)) - v > thr
+    dk = v - np.maximum(np.minimum(p0, p8), np.minimum(p4, p12)) > thr
+    return float((br | dk).mean())
+
+
+def bench_natural(ctx, L, B, want_cpu=True):
+    """The same two-stream batch pipeline on natural imagery: per-kernel ms, keypoints / frame, quick-test pass
+    rate, and the CPU port on the same frames."""
+    from stella_vslam_amd import synthetic
+    nat = natural_sequence(B)
+    fe = run_front_end(ctx, L, nat, B, 10, 2, lambda: None, 1)
+    kernels, dom = roofline_entries(fe, "-", B, 1)
+    syn = synthetic.frame_sequence(4, W, H, seed=0x5EED)
+    out = {"what": "the headline pipeline on 640x480 crops of the reference's two 1920x960 test images (16 tracks, crop moving (3,1) px per frame)",
+           "frames_per_s": round(B * fe["steps"] / fe["dt"], 1), "ms_per_step": round(fe["dt"] / fe["steps"] * 1e3, 4),
+           "frames_per_step": B, "keypoints_per_frame": round(fe["n_kp"], 1), "matches_per_pair": round(fe["n_match"], 1),
+           "quick_test_pass_rate_level0": {"natural_thr20": round(float(np.mean([quick_test_pass_rate(nat[i], 20) for i in range(0, B, max(1, B // 16))])), 4),
+                                           "natural_thr7": round(float(np.mean([quick_test_pass_rate(nat[i], 7) for i in range(0, B, max(1, B // 16))])), 4),
+                                           "synthetic_thr20": round(float(np.mean([quick_test_pass_rate(f, 20) for f in syn])), 4),
+                                           "synthetic_thr7": round(float(np.mean([quick_test_pass_rate(f, 7) for f in syn])), 4)},
+           "dominant_kernel": dom["kernel"],
+           "kernels": [{k: e[k] for k in ("kernel", "mean_launch_ms", "launches_per_step", "bound", "achieved", "frac", "unit")} for e in kernels]}
+    if want_cpu:
+        per = max(1, B // 16)
+        out["cpu_port"] = cpu_front_end(np.concatenate([nat[0:min(8, per)], nat[9 * per:9 * per + min(8, per)]]), reps=1)
+    return out
 
 
 def load_profile_json(pattern, src_hash, B, world):
@@ -438,21 +520,35 @@ def ba_roofline(sc, iters, seconds, free_poses):
                     "launches (latency-bound), not a byte stream"}
 
 
-def bench_local_ba(ctx):
-    from stella_vslam_amd import optimize, synthetic
-    sc = synthetic.ba_scene()  # 20 KF / 10k landmarks / ~60k observations, seed 1234
+def bench_local_ba(ctx, rank=0, world=1):
+    """Config 3.  With N > 1 ranks: INDEPENDENT windows, one per GPU (replicas) -- a 20-keyframe window cannot beat one GPU when sharded
+    (its all-reduce costs more than its damping trial), and a SLAM system has one mapping thread per map anyway; the figure
+    says how many maps' local BA a node serves."""
+    from stella_vslam_amd import distributed, optimize, synthetic
+    sc = synthetic.ba_scene(seed=1234 + rank)  # 20 KF / 10k landmarks / ~60k observations
     ba = optimize.local_bundle_adjuster(ctx=ctx)
-    ba.optimize_flat(sc)  # warm-up
+    for _ in range(3):
+        ba.optimize_flat(sc)  # warm-up
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    reps, iters, per_call = 20, 0, []
     t0 = time.perf_counter()
-    reps, iters = 5, 0
     for _ in range(reps):
+        t1 = time.perf_counter()
         res = ba.optimize_flat(sc)
+        per_call.append(time.perf_counter() - t1)
         iters += res["stats"]["iters_stage1"] + res["stats"]["iters_stage2"]
     dt = time.perf_counter() - t0
-    return {"metric": "local-BA LM iterations/s @20 KF / 10k landmarks / %d obs" % len(sc["obs_pose"]),
-            "value": round(iters / dt, 2), "unit": "iters/s", "ms_per_call": round(dt / reps * 1e3, 3),
-            "iters_per_call": iters / reps, "dtype": "f64", "lm_trials_per_call": res["stats"]["lm_trials"],
-            "roofline": ba_roofline(sc, iters, dt, int((np.asarray(sc["pose_fixed"]) == 0).sum()))}
+    if world > 1:
+        dt = distributed.max_over_ranks(dt)
+    out = {"metric": "local-BA LM iterations/s @20 KF / 10k landmarks / %d obs" % len(sc["obs_pose"]),
+           "value": round(world * iters / dt, 2), "unit": "iters/s", "ms_per_call": round(dt / reps * 1e3, 3),
+           "median_ms_per_call": round(float(np.median(per_call)) * 1e3, 3),
+           "iters_per_call": iters / reps, "dtype": "f64", "lm_trials_per_call": res["stats"]["lm_trials"], "n_gpus": world,
+           "sharding": "none" if world == 1 else "replicas: one independent config-3 window per GPU, no collective (value = sum over ranks)",
+           "roofline": ba_roofline(sc, iters, dt, int((np.asarray(sc["pose_fixed"]) == 0).sum()))}
+    return out
 
 
 def bench_global_ba(device, rank, world):
@@ -497,29 +593,59 @@ def bench_global_ba(device, rank, world):
             "roofline": ba_roofline(sc, iters, dt, free)}
 
 
-def cpu_baseline(frames_np, want_ba=True):
-    """Oracle (CPU restatement of the reference path), 1 thread, bounded sample (~10-20 s)."""
+def _pin(core):
+    """taskset -c <core> for this process; returns the previous affinity, or None where pinning is not available."""
+    try:
+        old = os.sched_getaffinity(0)
+        if core in old:
+            os.sched_setaffinity(0, {core})
+            return old
+    except (AttributeError, OSError):
+        pass
+    return None
+
+
+def _unpin(old):
+    if old is not None:
+        try:
+            os.sched_setaffinity(0, old)
+        except OSError:
+            pass
+
+
+def cpu_front_end(seq, reps=2, warm=1):
+    """The oracle's orb_extract + brute_force_match (vs the previous frame) over `seq`, pinned to one core: per-frame MEDIANS after warm-up."""
     from oracle import oracle as O
-    n = len(frames_np)
-    budget, done, t_ext, t_bf = 12.0, 0, 0.0, 0.0
-    prev = None
-    t_start = time.perf_counter()
-    while time.perf_counter() - t_start < budget and done < 4 * n:
-        img = frames_np[done % n]
-        t0 = time.perf_counter()
-        k, d, _ = O.orb_extract(img)
-        t1 = time.perf_counter()
-        if prev is not None:
-            O.brute_force_match(d, k["angle"], prev[1], prev[0]["angle"], None, LOWE, bool(CHECK_ORI))
-        t2 = time.perf_counter()
-        t_ext += t1 - t0
-        t_bf += t2 - t1
-        prev = (k, d)
-        done += 1
-    total = t_ext + t_bf
-    out = {"value": round(done / total, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": f"{done} frames of the same synthetic 640x480 sequence: oracle orb_extract "
-                     f"({t_ext / done * 1e3:.1f} ms/frame) + brute_force_match vs previous frame ({t_bf / max(done - 1, 1) * 1e3:.1f} ms/pair), "
+    old = _pin(2)
+    try:
+        for i in range(warm):
+            O.orb_extract(seq[i % len(seq)])
+        t_ext, t_bf, prev = [], [], None
+        for r in range(reps):
+            for img in seq:
+                t0 = time.perf_counter()
+                k, d, _ = O.orb_extract(img)
+                t1 = time.perf_counter()
+                if prev is not None:
+                    O.brute_force_match(d, k["angle"], prev[1], prev[0]["angle"], None, LOWE, bool(CHECK_ORI))
+                    t_bf.append(time.perf_counter() - t1)
+                t_ext.append(t1 - t0)
+                prev = (k, d)
+    finally:
+        _unpin(old)
+    e, b = float(np.median(t_ext)), float(np.median(t_bf)) if t_bf else 0.0
+    return {"value": round(1.0 / (e + b), 3), "unit": "frames/s", "cores": 1, "kind": "port", "pinned_to_core": 2 if old is not None else None,
+            "extract_ms_median": round(e * 1e3, 2), "match_ms_median": round(b * 1e3, 2), "frames": len(t_ext),
+            "keypoints_per_frame": round(float(len(k)), 1)}
+
+
+def cpu_baseline(frames_np, want_ba=True):
+    """Oracle (CPU restatement of the reference path), 1 thread pinned to one core (taskset -c 2), medians after warm-up, bounded samples."""
+    from oracle import oracle as O
+    fe = cpu_front_end(frames_np[:25], reps=2, warm=5)
+    out = {"value": fe["value"], "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{fe['frames']} frame passes (25 frames x 2 after 5 warm-ups) of the same synthetic 640x480 sequence, process pinned to core 2: oracle orb_extract "
+                     f"(median {fe['extract_ms_median']} ms/frame) + brute_force_match vs previous frame (median {fe['match_ms_median']} ms/pair), "
                      "gcc -O3, no -march=native, no OpenMP"}
     # context figure (SURVEY 8(d)): the same port on ALL host cores, frame-parallel (frames are independent; one process per core,
     # each on its own slice of the sequence) -- the reference's optional OpenMP pragmas parallelise inside a frame instead
@@ -542,21 +668,34 @@ def cpu_baseline(frames_np, want_ba=True):
     except Exception as e:
         out["all_host_cores"] = {"error": str(e)}
     if want_ba:
+        old = _pin(2)
         try:
             from stella_vslam_amd import synthetic
             sc = synthetic.ba_scene()
-            t0 = time.perf_counter()
-            r = O.local_ba(sc)
-            dt = time.perf_counter() - t0
-            out["local_ba"] = {"value": round((r["stats"][2] + r["stats"][3]) / dt, 3), "unit": "iters/s", "ms_per_call": round(dt * 1e3, 1), "cores": 1, "kind": "port"}
+            for _ in range(2):
+                O.local_ba(sc)
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                r = O.local_ba(sc)
+                ts.append(time.perf_counter() - t0)
+            dt = float(np.median(ts))
+            out["local_ba"] = {"value": round((r["stats"][2] + r["stats"][3]) / dt, 3), "unit": "iters/s", "ms_per_call": round(dt * 1e3, 1), "cores": 1, "kind": "port",
+                               "sample": "median of 20 calls after 2 warm-ups on the config-3 scene, pinned to core 2"}
             sg = synthetic.ba_scene_large()
-            t0 = time.perf_counter()
-            r = O.local_ba(sg, iters1=10, iters2=0)
-            dt = time.perf_counter() - t0
+            O.local_ba(sg, iters1=10, iters2=0)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r = O.local_ba(sg, iters1=10, iters2=0)
+                ts.append(time.perf_counter() - t0)
+            dt = float(np.median(ts))
             out["global_ba"] = {"value": round(r["stats"][2] / dt, 3), "unit": "iters/s", "ms_per_call": round(dt * 1e3, 1), "cores": 1, "kind": "port",
-                                "sample": "one call on the config-5 scene (500 KF / 200k landmarks); the oracle factors the reduced system with an envelope Cholesky"}
+                                "sample": "median of 3 calls after 1 warm-up on the config-5 scene (500 KF / 200k landmarks), pinned to core 2; the oracle factors the reduced system with an envelope Cholesky"}
         except Exception as e:
-            out["local_ba"] = {"error": str(e)}
+            out.setdefault("local_ba", {"error": str(e)})
+        finally:
+            _unpin(old)
     return out
 
 

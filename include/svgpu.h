@@ -65,11 +65,17 @@ int svgpu_synchronize(svgpu_ctx* ctx);
 void* svgpu_stream(svgpu_ctx* ctx); /* the context's hipStream_t */
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's roofline
- * object).  svgpu_profile_select brackets every later launch of the named kernel class (NULL = off);
- * svgpu_profile_read synchronises and returns the accumulated device time and the number of launches. */
+ * object).  svgpu_profile_select brackets every later launch of the named kernel class (NULL = off, "*" = every class: one timed
+ * region then yields each kernel's mean launch time as it runs inside the caller's pipeline);
+ * svgpu_profile_read synchronises and returns the accumulated device time and the number of launches of the selected class,
+ * svgpu_profile_read_class the same for a named class (the way to read a "*" selection). */
 const char* svgpu_profile_kernels(void); /* comma-separated class names */
 int svgpu_profile_select(svgpu_ctx* ctx, const char* kernel_name);
 int svgpu_profile_read(svgpu_ctx* ctx, double* total_ms, long long* launches);
+int svgpu_profile_read_class(svgpu_ctx* ctx, const char* kernel_name, double* total_ms, long long* launches);
+/* int8 multiply-add operations the matrix cores executed in the profiled launches of the brute-force distance kernel since the
+ * last svgpu_profile_select (counted by the kernel itself: 2 x 64 x 32 x 256 per multiplied patch); 0 when it was not profiled */
+int svgpu_profile_mfma_ops(svgpu_ctx* ctx, unsigned long long* int8_ops);
 
 /* ------------------------------------------------------------------------------------------------ ORB front end
  * Stands behind  stella_vslam::feature::orb_extractor  (feature/orb_extractor.h:46-71):
@@ -556,7 +562,8 @@ int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile ui
  *                       `stream` (stella_vslam_amd/distributed.py binds it to torch.distributed: RCCL, or gloo in CPU-side tests)
  * All ranks return identical poses and points; outlier_out covers the local shard.  A rank's stop flag is a VOTE: the votes are
  * summed inside the per-trial all-reduce and every rank acts on the sum only, so ranks never diverge between two collectives
- * however the callers' flags are raised. */
+ * however the callers' flags are raised.  Whether a stop POINTER was passed is agreed the same way: if any rank passes one, every rank
+ * behaves as if it had (a NULL `stop` on some ranks only is allowed and cannot desynchronise the early return / skipped second stage). */
 typedef int (*svgpu_allreduce_fn)(void* user, double* dev_buf, size_t count, void* stream);
 int svgpu_local_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int rank, int world,
                            svgpu_allreduce_fn allreduce, void* allreduce_user, volatile uint8_t* stop, double* pose_out,

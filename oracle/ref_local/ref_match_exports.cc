@@ -5,6 +5,7 @@
 #include <set>
 
 #include "ref_support.h"
+#include "stella_vslam/solve/essential_solver.h"  // the scripted stand-in of shim_data/ (both class families call it)
 #ifdef SVREF_DROP_IN
 // the same fixtures around the PRODUCT's drop-in classes (stella_vslam_amd/host/drop_in/hip_backend.h, reference-tree mode, compiled against
 // the same stand-in data:: headers): libsvref_mdropin.so, linked to libsvgpu.so; tests/test_gpu_drop_in_matchers.py runs the cases of
@@ -55,6 +56,49 @@ int svref_brute_force_match(const uint8_t* desc1, const float* angle1, int n1, c
     const unsigned num = M::robust(lowe_ratio, check_orientation != 0).brute_force_match(fo, kf, matches);
     for (int i = 0; i < n1; ++i) matched_2_in_1[i] = -1;
     for (const auto& m : matches) matched_2_in_1[m.first] = m.second;
+    return (int)num;
+}
+
+// robust::match_frame_and_keyframe (match/robust.cc:194-230; `keyframes` == 0) and robust::match_keyframes (:148-192; `keyframes` == 1):
+// brute force -> solve::essential_solver -> landmark assignment.  The solver is the scripted stand-in of shim_data/ (Eigen's SVD is not
+// available here): `script_valid` / `script_mod` set its outcome, `rec` returns what the class asked it for
+// {calls, max_num_iter, recompute, use_fixed_seed, matches handed over, bearings_1, bearings_2}.  out_lm_in_frm[i] = id of the landmark
+// written at frame keypoint i (= keyframe keypoint index), -1 = none.
+int svref_robust_match_wrapped(int keyframes, const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2,
+                               int n2, float lowe_ratio, int check_orientation, int validate, int use_fixed_seed, int script_valid, int script_mod,
+                               int32_t* out_lm_in_frm, int32_t* rec) {
+    Params P(1.2f, 8);
+    auto& S = solve::essential_script();
+    S = solve::essential_solver_script();
+    S.valid = script_valid != 0;
+    S.inlier_mod = script_mod;
+    auto kf2 = std::make_shared<data::keyframe>(2, nullptr, &P.p);
+    fill_observation(kf2->frm_obs_, desc2, nullptr, nullptr, angle2, nullptr, nullptr, n2, 64, 48);
+    kf2->frm_obs_.bearings_.resize(n2);
+    attach_landmarks(kf2->landmarks_, valid2, n2);
+    std::vector<std::shared_ptr<data::landmark>> matched(3, nullptr);  // a stale vector: the method must re-size it
+    unsigned num = 0;
+    if (keyframes) {
+        auto kf1 = std::make_shared<data::keyframe>(1, nullptr, &P.p);
+        fill_observation(kf1->frm_obs_, desc1, nullptr, nullptr, angle1, nullptr, nullptr, n1, 64, 48);
+        kf1->frm_obs_.bearings_.resize(n1);
+        num = M::robust(lowe_ratio, check_orientation != 0).match_keyframes(kf1, kf2, matched, validate != 0, use_fixed_seed != 0);
+    }
+    else {
+        data::frame frm(1, nullptr, &P.p);
+        fill_observation(frm.frm_obs_, desc1, nullptr, nullptr, angle1, nullptr, nullptr, n1, 64, 48);
+        frm.frm_obs_.bearings_.resize(n1);
+        num = M::robust(lowe_ratio, check_orientation != 0).match_frame_and_keyframe(frm, kf2, matched, use_fixed_seed != 0);
+    }
+    if ((int)matched.size() != n1) return -1;
+    for (int i = 0; i < n1; ++i) out_lm_in_frm[i] = matched[i] ? (int32_t)matched[i]->id_ : -1;
+    rec[0] = S.calls;
+    rec[1] = (int32_t)S.last_max_num_iter;
+    rec[2] = S.last_recompute;
+    rec[3] = S.last_use_fixed_seed;
+    rec[4] = (int32_t)S.last_num_matches;
+    rec[5] = (int32_t)S.last_bearings_1;
+    rec[6] = (int32_t)S.last_bearings_2;
     return (int)num;
 }
 

@@ -38,6 +38,7 @@ struct BfProblem {
     int32_t* cnt;         // pairs * cap2
     int32_t* matched;     // pairs * cap1
     int32_t* num;         // pairs
+    unsigned long long* mfma_tiles;  // nullable (profiling only): k_bf_mfma adds the 64 x 32 patches its waves multiplied (16 MFMAs of 32x32x32 each)
 };
 
 __host__ __device__ inline int bf_row1(const BfProblem& P, int pair) { return P.ring1 ? (pair + 1 == P.ring1 ? 0 : pair + 1) : pair; }

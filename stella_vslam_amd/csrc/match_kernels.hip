@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
     v16i acc0 = {}, acc1 = {};
     bool pend1 = false;
     uint32_t p_ti = 0, p_ta = 0;
+    unsigned n_mine = 0;  // patches this wave multiplied (profiling counter)
     for (int sg = 0; sg < 2; ++sg) {
         const int lo = blo[sg], hi = bhi[sg];
         for (int cbase = lo; cbase < hi; cbase += MF_CH) {
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                     pend1 = true;
                     p_ti = ti;
                     p_ta = ta;
+                    ++n_mine;
                     // the next tile's +-1 expansion is pure VALU / LDS work: it runs in the shadow of the last MFMAs
                     if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                 }
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
         for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
     }
     mf_drain(S, wave, lane, wq_n, ori);
+    if (P.mfma_tiles && lane == 0 && n_mine) atomicAdd(P.mfma_tiles, (unsigned long long)n_mine);
     __syncthreads();
     // ---- flush: one thread per query: sort the row (ascending (dist, idx_1) = the reference's scan preference) in registers
     //      with a 16-input bitonic network (a data-dependent insertion sort in LDS costs a full row ~250 dependent LDS
@@ -1358,6 +1361,7 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
         }
         else {
             P.list_k = MF_SLOTS;
+            P.mfma_tiles = sv_prof_counter(ctx, "k_bf_topk");
             hipLaunchKernelGGL(k_bf_mfma, dim3((P.cap2 + MF_QB - 1) / MF_QB, pairs), dim3(256), 0, s, P);
         }
     }

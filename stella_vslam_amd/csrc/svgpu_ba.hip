@@ -509,11 +509,16 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     // all-reduced votes inside the control block only.
     auto wait_stream = [&]() -> int {
         SV_HIP(ctx, hipEventRecord(ctx->ev_ba, s));
+        // (the mapping thread must not pin a host core the tracking thread needs: a short spin for the sub-100 us waits of a local
+        //  window, then the poll yields / sleeps ~20 us between queries -- the stop flag is sampled every time)
+        int polls = 0;
         for (;;) {
             if (*flag) *h_mirror = 1;
             const hipError_t q = hipEventQuery(ctx->ev_ba);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return sv_set_error(ctx, SVGPU_ERR_HIP, "hipEventQuery", q);
+            if (++polls > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            else if (polls > 200) std::this_thread::yield();
         }
         return SVGPU_OK;
     };
@@ -550,12 +555,18 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     };
     std::vector<uint8_t> owned(L, 0);  // landmarks whose observations live on this rank
     for (int k = 0; k < E; ++k) owned[e_point[k]] = 1;
+    // Whether "the caller passed a stop pointer" must mean the same on every rank: the early return and the skipped second stage below
+    // branch on it, and a rank that left while the others entered the next collective would hang them.  A sharded solve therefore acts as
+    // if every rank had a pointer as soon as ANY rank has one (the flag rides along with the contract check).
+    bool stop_ptr_any = stop != nullptr;
     if (sharded) {  // contract check: a landmark's observations must not be split over ranks
         for (int l = 0; l < L; ++l) xch_host[l] = owned[l];
-        int r = allreduce_host(L);
+        xch_host[L] = stop ? 1.0 : 0.0;
+        int r = allreduce_host((size_t)L + 1);
         if (r) return r;
         for (int l = 0; l < L; ++l)
             if (xch_host[l] > 1.5) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: observations must be sharded by landmark");
+        stop_ptr_any = xch_host[L] > 0.5;
     }
 
     lap("arena + uploads");
@@ -832,13 +843,14 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     st.chi2_initial = h_ctl->chi_begin;
     st.iters_stage1 = it1;
     lap("stage 1");
-    if (sharded && stop && h_ctl->stop && it1 == 0 && !h_ctl->stopped_by_terminate) {  // raised before any work, agreed by all ranks
+    if (sharded && stop_ptr_any && h_ctl->stop && it1 == 0 && !h_ctl->stopped_by_terminate) {  // raised before any work, agreed by all ranks
         st.lm_trials = h_ctl->lm_trials;
         if (stats) *stats = st;
         return SVGPU_STOPPED;
     }
     bool run_robust = !single_stage;
-    if (stop && (sharded ? h_ctl->stop != 0 : *stop != 0)) run_robust = false;  // :317-321 (only the CALLER's flag is consulted here)
+    // :317-321 (only the CALLER's flag is consulted here); sharded: the all-reduced vote and the all-reduced "a pointer exists", never a local fact
+    if (sharded ? (stop_ptr_any && h_ctl->stop != 0) : (stop && *stop != 0)) run_robust = false;
     if (run_robust) {
         st.stage2_entered = 1;
         if (E > 0) {

@@ -59,23 +59,50 @@ int sv_ensure_scratch(svgpu_ctx* ctx, size_t bytes) {
     return SVGPU_OK;
 }
 
+static inline bool prof_wants(const SvProf& P, const char* name) { return P.name == "*" || P.name == name; }
 void sv_prof_begin(svgpu_ctx* ctx, hipStream_t s, const char* name) {
     SvProf& P = ctx->prof;
-    if (P.name != name) return;
-    if (P.used + 2 > P.ev.size()) {
+    if (!prof_wants(P, name)) return;
+    SvProfClass& K = P.cls[name];
+    if (K.used + 2 > K.ev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
-            P.ev.push_back(e);
+            K.ev.push_back(e);
         }
     }
-    (void)hipEventRecord(P.ev[P.used], s);
+    (void)hipEventRecord(K.ev[K.used], s);
 }
 void sv_prof_end(svgpu_ctx* ctx, hipStream_t s, const char* name) {
     SvProf& P = ctx->prof;
-    if (P.name != name || P.used + 2 > P.ev.size()) return;
-    (void)hipEventRecord(P.ev[P.used + 1], s);
-    P.used += 2;
+    if (!prof_wants(P, name)) return;
+    SvProfClass& K = P.cls[name];
+    if (K.used + 2 > K.ev.size()) return;
+    (void)hipEventRecord(K.ev[K.used + 1], s);
+    K.used += 2;
+}
+unsigned long long* sv_prof_counter(svgpu_ctx* ctx, const char* name) {
+    SvProf& P = ctx->prof;
+    if (!prof_wants(P, name)) return nullptr;
+    if (!P.d_counter) {
+        if (hipMalloc((void**)&P.d_counter, sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipGetLastError();
+            P.d_counter = nullptr;
+            return nullptr;
+        }
+        (void)hipMemset(P.d_counter, 0, sizeof(unsigned long long));
+    }
+    return P.d_counter;
+}
+static void prof_collect(SvProfClass& K) {
+    for (size_t i = 0; i + 1 < K.used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, K.ev[i], K.ev[i + 1]) == hipSuccess) {
+            K.total_ms += ms;
+            K.launches += 1;
+        }
+    }
+    K.used = 0;
 }
 
 extern "C" {
@@ -89,28 +116,53 @@ int svgpu_profile_select(svgpu_ctx* ctx, const char* kernel_name) {
     SV_HIP(ctx, hipSetDevice(ctx->device));
     SV_HIP(ctx, hipDeviceSynchronize());
     ctx->prof.name = kernel_name ? kernel_name : "";
-    ctx->prof.used = 0;
-    ctx->prof.total_ms = 0;
-    ctx->prof.launches = 0;
+    for (auto& kv : ctx->prof.cls) {
+        kv.second.used = 0;
+        kv.second.total_ms = 0;
+        kv.second.launches = 0;
+    }
+    if (ctx->prof.d_counter) SV_HIP(ctx, hipMemset(ctx->prof.d_counter, 0, sizeof(unsigned long long)));
+    return SVGPU_OK;
+}
+
+int svgpu_profile_mfma_ops(svgpu_ctx* ctx, unsigned long long* int8_ops) {
+    if (!ctx || !int8_ops) return SVGPU_ERR_INVALID;
+    *int8_ops = 0;
+    if (!ctx->prof.d_counter) return SVGPU_OK;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipDeviceSynchronize());
+    unsigned long long tiles = 0;
+    SV_HIP(ctx, hipMemcpy(&tiles, ctx->prof.d_counter, sizeof(tiles), hipMemcpyDeviceToHost));
+    // one patch = 64 queries x 32 targets x 256 bit positions, a multiply and an add each (16 x v_mfma_i32_32x32x32_i8)
+    *int8_ops = tiles * 64ull * 32ull * 256ull * 2ull;
+    return SVGPU_OK;
+}
+
+int svgpu_profile_read_class(svgpu_ctx* ctx, const char* kernel_name, double* total_ms, long long* launches) {
+    if (!ctx || !kernel_name) return SVGPU_ERR_INVALID;
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipDeviceSynchronize());
+    double ms = 0;
+    long long n = 0;
+    auto it = ctx->prof.cls.find(kernel_name);
+    if (it != ctx->prof.cls.end()) {
+        prof_collect(it->second);
+        ms = it->second.total_ms;
+        n = it->second.launches;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
     return SVGPU_OK;
 }
 
 int svgpu_profile_read(svgpu_ctx* ctx, double* total_ms, long long* launches) {
     if (!ctx) return SVGPU_ERR_INVALID;
-    SV_HIP(ctx, hipSetDevice(ctx->device));
-    SV_HIP(ctx, hipDeviceSynchronize());
-    SvProf& P = ctx->prof;
-    for (size_t i = 0; i + 1 < P.used; i += 2) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, P.ev[i], P.ev[i + 1]) == hipSuccess) {
-            P.total_ms += ms;
-            P.launches += 1;
-        }
+    if (ctx->prof.name.empty() || ctx->prof.name == "*") {
+        if (total_ms) *total_ms = 0;
+        if (launches) *launches = 0;
+        return SVGPU_OK;
     }
-    P.used = 0;
-    if (total_ms) *total_ms = P.total_ms;
-    if (launches) *launches = P.launches;
-    return SVGPU_OK;
+    return svgpu_profile_read_class(ctx, ctx->prof.name.c_str(), total_ms, launches);
 }
 
 int svgpu_abi_version(void) { return SVGPU_ABI_VERSION; }
@@ -154,7 +206,9 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream_aux) (void)hipStreamSynchronize(ctx->stream_aux);
     sv_orb_release(ctx);
-    for (hipEvent_t e : ctx->prof.ev) (void)hipEventDestroy(e);
+    for (auto& kv : ctx->prof.cls)
+        for (hipEvent_t e : kv.second.ev) (void)hipEventDestroy(e);
+    if (ctx->prof.d_counter) (void)hipFree(ctx->prof.d_counter);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -55,13 +56,19 @@ struct OrbConfig {
     bool configured = false;
 };
 
-// Optional per-kernel timing with HIP events on the launch stream (svgpu_profile_select / _read).
-struct SvProf {
-    std::string name;  // kernel class being bracketed; empty = off
+// Optional per-kernel timing with HIP events on the launch stream (svgpu_profile_select / _read / _read_class).
+// One accumulator per kernel class; the selection "*" brackets EVERY class, so that one timed region yields the mean launch time of
+// each kernel as it runs inside the caller's pipeline (bench.py: roofline.kernels[] comes from the timed region itself).
+struct SvProfClass {
     std::vector<hipEvent_t> ev;  // start/stop pairs
     size_t used = 0;
     double total_ms = 0;
     long long launches = 0;
+};
+struct SvProf {
+    std::string name;  // kernel class being bracketed; "*" = all; empty = off
+    std::map<std::string, SvProfClass> cls;
+    unsigned long long* d_counter = nullptr;  // device word a profiled k_bf_mfma adds its multiplied 64 x 32 patches to
 };
 
 struct svgpu_ctx {
@@ -120,6 +127,7 @@ void sv_comm_release(svgpu_ctx* ctx);
 int sv_set_error(svgpu_ctx* ctx, int status, const char* what, hipError_t e = hipSuccess);
 void sv_prof_begin(svgpu_ctx* ctx, hipStream_t s, const char* name);
 void sv_prof_end(svgpu_ctx* ctx, hipStream_t s, const char* name);
+unsigned long long* sv_prof_counter(svgpu_ctx* ctx, const char* name);  // the device counter when `name` is being profiled, else null
 struct SvProfScope {  // brackets the launches issued inside its lifetime when `name` is the selected kernel class
     svgpu_ctx* c;
     hipStream_t s;

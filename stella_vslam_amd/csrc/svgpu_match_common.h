@@ -66,8 +66,10 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int nt = F.nt, ncell = F.grid_cols * F.grid_rows;
-    const size_t need1 = query_bytes + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 4 * pad((size_t)nt * 4) + pad(nt)
-                         + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4) + 2 * pad((size_t)nt * 4) + 1024;
+    // target side: descriptors, xy, seven nt x 4 arrays (t_octave, t_angle, t_xright, cell_of, cell_items, owner, mdist), occupied;
+    // query side: cand_off, match_q, match; P.num; slack for the alignment of each take
+    const size_t need1 = query_bytes + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 7 * pad((size_t)nt * 4) + pad(nt)
+                         + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4) + pad(4) + 2048;
     int total = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const size_t need = need1 + (pass ? 2 * pad((size_t)total * 4) : 0);

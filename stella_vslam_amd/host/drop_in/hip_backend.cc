@@ -231,6 +231,50 @@ unsigned int robust::brute_force_match(const data::frame_observation& frm_obs, c
     return (unsigned)num;
 }
 
+// The two RANSAC-validated wrappers (match/robust.cc:148-230).  Only the all-pairs distance work is device work; the essential-matrix
+// RANSAC is the reference's own solve::essential_solver on the host (seeded as the caller asks: util/random_array.cc:12-23), fed with the
+// same (idx_1, idx_2) list in the same order as the reference's brute_force_match produces, so its random 8-point sets pick the same matches.
+namespace {
+unsigned int assign_inliers(const std::vector<std::pair<int, int>>& matches, const std::vector<bool>* is_inlier, const std::vector<lm_ptr>& keyfrm_lms,
+                            std::vector<lm_ptr>& matched_lms_in_frm) {
+    unsigned int num_inlier_matches = 0;
+    for (unsigned int i = 0; i < matches.size(); ++i) {
+        if (is_inlier && !is_inlier->at(i)) continue;
+        matched_lms_in_frm.at(matches.at(i).first) = keyfrm_lms.at(matches.at(i).second);  // robust.cc:176-186, :220-226
+        ++num_inlier_matches;
+    }
+    return num_inlier_matches;
+}
+}  // namespace
+
+unsigned int robust::match_keyframes(const kf_ptr& keyfrm1, const kf_ptr& keyfrm2, std::vector<lm_ptr>& matched_lms_in_frm, bool validate_with_essential_solver,
+                                     bool use_fixed_seed) const {
+    const auto num_frm_keypts = keyfrm1->frm_obs_.undist_keypts_.size();
+    const auto keyfrm_lms = keyfrm2->get_landmarks();
+    matched_lms_in_frm = std::vector<lm_ptr>(num_frm_keypts, nullptr);
+    std::vector<std::pair<int, int>> matches;
+    brute_force_match(keyfrm1->frm_obs_, keyfrm2, matches);
+    if (!validate_with_essential_solver) return assign_inliers(matches, nullptr, keyfrm_lms, matched_lms_in_frm);
+    solve::essential_solver solver(keyfrm1->frm_obs_.bearings_, keyfrm2->frm_obs_.bearings_, matches, use_fixed_seed);
+    solver.find_via_ransac(50, false);  // robust.cc:163
+    if (!solver.solution_is_valid()) return 0;
+    const auto is_inlier_matches = solver.get_inlier_matches();
+    return assign_inliers(matches, &is_inlier_matches, keyfrm_lms, matched_lms_in_frm);
+}
+
+unsigned int robust::match_frame_and_keyframe(data::frame& frm, const kf_ptr& keyfrm, std::vector<lm_ptr>& matched_lms_in_frm, bool use_fixed_seed) const {
+    const auto num_frm_keypts = frm.frm_obs_.undist_keypts_.size();
+    const auto keyfrm_lms = keyfrm->get_landmarks();
+    matched_lms_in_frm = std::vector<lm_ptr>(num_frm_keypts, nullptr);
+    std::vector<std::pair<int, int>> matches;
+    brute_force_match(frm.frm_obs_, keyfrm, matches);
+    solve::essential_solver solver(frm.frm_obs_.bearings_, keyfrm->frm_obs_.bearings_, matches, use_fixed_seed);
+    solver.find_via_ransac(1000, true);  // robust.cc:209
+    if (!solver.solution_is_valid()) return 0;
+    const auto is_inlier_matches = solver.get_inlier_matches();
+    return assign_inliers(matches, &is_inlier_matches, keyfrm_lms, matched_lms_in_frm);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------- bow_tree
 unsigned int bow_tree::match_for_triangulation(const kf_ptr& keyfrm_1, const kf_ptr& keyfrm_2, const Mat33_t& E_12,
                                                std::vector<std::pair<unsigned int, unsigned int>>& matched_idx_pairs, const float residual_rad_thr) const {
@@ -296,6 +340,10 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
         qhi[i] = std::min((int)frm.orb_params_->num_levels_ - 1, (int)pred + 1);
         qxr[i] = lm_to_x_right.count(lm->id_) ? lm_to_x_right.at(lm->id_) : 0.f;
         const cv::Mat d = lm->get_descriptor();
+        if (d.empty()) {  // a landmark whose representative descriptor has not been computed yet offers nothing to compare
+            qvalid[i] = 0;
+            continue;
+        }
         std::memcpy(&qdesc[(size_t)i * 32], d.ptr(0), 32);
     }
     for (int k = 0; k < s.n; ++k) {

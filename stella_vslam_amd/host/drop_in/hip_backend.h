@@ -17,6 +17,9 @@
 #include "stella_vslam/data/keyframe.h"
 #include "stella_vslam/data/landmark.h"
 #include "stella_vslam/feature/orb_params.h"
+#ifndef SVGPU_DROP_IN_OPTIMIZE_ONLY
+#include "stella_vslam/solve/essential_solver.h"  // the RANSAC behind robust::match_frame_and_keyframe / match_keyframes stays the reference's (host)
+#endif
 #ifndef SVGPU_DROP_IN_MATCH_ONLY
 #include "stella_vslam/data/map_database.h"
 #include "stella_vslam/data/marker.h"
@@ -64,9 +67,17 @@ protected:
     const bool check_orientation_;
 };
 
-class robust final : public base {  // match/robust.h:20-44 (the essential-matrix RANSAC wrappers stay with the reference)
+class robust final : public base {  // match/robust.h:20-44
 public:
     explicit robust(const float lowe_ratio, const bool check_orientation) : base(lowe_ratio, check_orientation) {}
+    //! match/robust.cc:148-192 (loop_detector.cc:366-388): brute force on the device, then the reference's own solve::essential_solver
+    //! (8-point RANSAC, 50 iterations, no recompute) on the host, then the landmark assignment
+    unsigned int match_keyframes(const std::shared_ptr<data::keyframe>& keyfrm1, const std::shared_ptr<data::keyframe>& keyfrm2,
+                                 std::vector<std::shared_ptr<data::landmark>>& matched_lms_in_frm, bool validate_with_essential_solver = true,
+                                 bool use_fixed_seed = false) const;
+    //! match/robust.cc:194-230 (frame_tracker.cc:98-103, relocalizer.cc:27): the same with 1000 iterations and the recompute
+    unsigned int match_frame_and_keyframe(data::frame& frm, const std::shared_ptr<data::keyframe>& keyfrm,
+                                          std::vector<std::shared_ptr<data::landmark>>& matched_lms_in_frm, bool use_fixed_seed = false) const;
     unsigned int match_for_triangulation(const std::shared_ptr<data::keyframe>& keyfrm_1, const std::shared_ptr<data::keyframe>& keyfrm_2,
                                          const Mat33_t& E_12, std::vector<std::pair<unsigned int, unsigned int>>& matched_idx_pairs,
                                          const float residual_rad_thr) const;

@@ -66,6 +66,33 @@ struct Node {
 };
 }  // namespace yaml_standin
 
+namespace solve {
+// solve/essential_solver.h:12-80 -- INTERFACE stand-in.  The reference's class (5-point / 8-point RANSAC on Eigen's SVD and eigen-solver)
+// is host code the drop-in classes call as it is; without the reference tree this stand-in keeps match::hip::robust compilable and
+// testable: it accepts every match of a large enough set (so the wrappers' own logic -- list order, landmark assignment, return value --
+// runs), and records what it was asked for.
+class essential_solver {
+public:
+    essential_solver(const eigen_alloc_vector<Vec3_t>&, const eigen_alloc_vector<Vec3_t>&, const std::vector<std::pair<int, int>>& matches_12, bool use_fixed_seed = false)
+        : matches_12_(matches_12), use_fixed_seed_(use_fixed_seed) {}
+    void find_via_ransac(const unsigned int max_num_iter, const bool recompute = true, const unsigned int min_set_size = 5) {
+        max_num_iter_ = max_num_iter;
+        recompute_ = recompute;
+        solution_is_valid_ = matches_12_.size() >= min_set_size;  // essential_solver.cc:19-23
+        is_inlier_match_.assign(matches_12_.size(), solution_is_valid_);
+    }
+    bool solution_is_valid() const { return solution_is_valid_; }
+    std::vector<bool> get_inlier_matches() const { return is_inlier_match_; }
+    unsigned int max_num_iter_ = 0;
+    bool recompute_ = false;
+
+private:
+    const std::vector<std::pair<int, int>>& matches_12_;
+    bool use_fixed_seed_, solution_is_valid_ = false;
+    std::vector<bool> is_inlier_match_;
+};
+}  // namespace solve
+
 namespace feature {
 // feature/orb_params.h:13-71
 struct orb_params {

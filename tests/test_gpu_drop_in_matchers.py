@@ -31,6 +31,7 @@ def ref():
 
 test_brute_force_match = _T.test_brute_force_match
 test_match_for_triangulation = _T.test_match_for_triangulation
+test_robust_wrappers = _T.test_robust_wrappers
 test_bow_match = _T.test_bow_match
 test_match_current_and_last_frames = _T.test_match_current_and_last_frames
 test_match_frame_and_keyframe_projection = _T.test_match_frame_and_keyframe_projection

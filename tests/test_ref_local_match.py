@@ -67,6 +67,41 @@ def test_brute_force_match(ref, sc, ratio, ori):
         assert num == (exp >= 0).sum() > 100 and np.array_equal(out, exp)
 
 
+@pytest.mark.parametrize("keyframes", [0, 1])
+def test_robust_wrappers(ref, sc, keyframes):
+    """robust::match_frame_and_keyframe (match/robust.cc:194-230) and robust::match_keyframes (:148-192): brute force, then the essential-matrix
+    RANSAC, then the landmark assignment.  The RANSAC is the scripted stand-in of oracle/ref_local/shim_data (inlier iff (7 i1 + 3 i2) % mod != 0),
+    so what is pinned is everything around it: the match list handed to the solver, its arguments (1000 iterations + recompute / 50 without,
+    the seed flag), the early return for an invalid solution, the landmarks written."""
+    v1, v2 = sc["views"]
+    valid2 = (v2["lm"] >= 0).astype(np.uint8)
+    d1, d2, a1, a2 = _c(v1["desc"], np.uint8), _c(v2["desc"], np.uint8), _c(v1["angle"], np.float32), _c(v2["angle"], np.float32)
+    ratio, ori = 0.8, True
+    bf = O.brute_force_match(d1, a1, d2, a2, valid2, ratio, ori)
+    n_bf = int((bf >= 0).sum())
+    assert n_bf > 100
+    for validate, fixed_seed, s_valid, s_mod in ((1, 1, 1, 3), (1, 0, 1, 1), (1, 1, 0, 3), (0, 0, 1, 3)):
+        if not keyframes and not validate:
+            continue  # match_frame_and_keyframe always validates
+        out = np.full(len(d1), -7, np.int32)
+        rec = np.zeros(8, np.int32)
+        num = ref.svref_robust_match_wrapped(keyframes, _p(d1), _p(a1), len(d1), _p(d2), _p(a2), _p(valid2), len(d2), C.c_float(ratio), int(ori), validate,
+                                             fixed_seed, s_valid, s_mod, _p(out), _p(rec))
+        exp = np.full(len(d1), -1, np.int32)
+        if validate:
+            assert list(rec[:7]) == [1, 50 if keyframes else 1000, 0 if keyframes else 1, fixed_seed, n_bf, len(d1), len(d2)]
+            if s_valid:
+                i1 = np.nonzero(bf >= 0)[0]
+                keep = np.ones(len(i1), bool) if s_mod <= 1 else ((7 * i1 + 3 * bf[i1]) % s_mod != 0)
+                exp[i1[keep]] = bf[i1[keep]]  # the landmark at keyframe keypoint j carries id j
+        else:
+            assert rec[0] == 0
+            exp = bf.copy()
+        assert num == int((exp >= 0).sum()) and np.array_equal(out, exp), (keyframes, validate, s_valid, s_mod)
+        if validate and s_valid:
+            assert num > 50
+
+
 @pytest.mark.parametrize("stereo", [False, True])
 @pytest.mark.parametrize("with_nodes", [False, True])
 def test_match_for_triangulation(ref, sc, sc_stereo, stereo, with_nodes):
