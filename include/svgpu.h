@@ -509,6 +509,19 @@ typedef enum svgpu_ba_solver {
 } svgpu_ba_solver;
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations);
 
+/* How the context's last envelope factorisation was planned (diagnostics for tests / bench.py): info[8] = {0 one-sided | 1 two-sided |
+ * 2 segmented, block rows, widest column; segmented: cuts, jobs, jobs on this rank, separator rows, longest job (columns)}. */
+int svgpu_ba_last_envelope_plan(svgpu_ctx* ctx, int* info);
+
+/* Planner self-test of the segmented envelope factorisation (host arithmetic only, runs without a device; NOT a solver path: the
+ * bundle adjusters never call it).  Plans the elimination of the 6x6-block SPD system {blk_ab[NB] upper blocks a <= b, Sblk NB x 36
+ * row-major, g 6 nP} exactly as the global / sharded bundle adjusters do (RCM order, `cuts` separators or the planner's choice when
+ * <= 0, jobs spread over `world` ranks), walks the same plan arrays and maps the kernels walk and returns the solution x.
+ * info[8] = {segmented, cuts, jobs, separator rows, longest job, separator banded, widest job column, widest column of the unsegmented
+ * envelope}.  Returns 0, 1 = the system is not segmented (too short / not banded), 2 = not positive definite, < 0 = bad arguments. */
+int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab, const double* Sblk, const double* g, int cuts, int world,
+                                   double* x, int* info);
+
 /* Host in/out, synchronous.  The Levenberg-Marquardt loop (damping trials, rho test, terminate_action) runs on the device; the
  * host enqueues the trials of a stage and reads the control block back once per stage (plus once per rejected trial).
  *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled at every damping-trial boundary

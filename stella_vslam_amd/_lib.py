@@ -9,8 +9,11 @@ import ctypes as C
 import pathlib
 import subprocess
 
+import os
+
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libsvgpu.so"
+# SVGPU_LIB_PATH selects an A/B build of the SAME library (tools/build_variant.sh) for kernel experiments; there is still no fallback
+LIB_PATH = pathlib.Path(os.environ["SVGPU_LIB_PATH"]) if os.environ.get("SVGPU_LIB_PATH") else _HERE / "libsvgpu.so"
 _LIB = None
 
 

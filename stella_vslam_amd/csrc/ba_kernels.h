@@ -135,7 +135,7 @@ enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, S
 // block envelope Cholesky of large reduced systems (ba_skyline.hip)
 #ifdef __cplusplus
 #include <vector>
-int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable);
+int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable, int rank, int world);
 #endif
-void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
+int sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
 void sv_sky_release(svgpu_ctx* ctx);

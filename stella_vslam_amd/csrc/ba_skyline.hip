@@ -27,6 +27,7 @@ namespace {
 struct SkyDev {
     int nP = 0, NB = 0;
     const int* pos = nullptr;       // slot -> position in the elimination order
+    const int* order = nullptr;     // position -> slot (the plans of a segmented elimination only)
     const int* first = nullptr;     // position i -> first block column of row i's envelope
     const int* rowoff = nullptr;    // position i -> index of block (i, first[i]); nP + 1 entries
     const int* coloff = nullptr;    // position j -> start of its row list; nP + 1 entries
@@ -54,6 +55,58 @@ struct SkyTwist {
     double* xch = nullptr;             // [W (W + 1) / 2 x 36: S x S blocks of the second plan's window][6 W: its y_S][6 W: x_S of the first plan]
     int* flags = nullptr;
 };
+
+// Segmented elimination (the N-piece generalisation of the two-sided one, and the form in which the factorisation is DISTRIBUTED over the
+// ranks of a sharded solve).  The ordered keyframe graph is cut by vertex separators; every connected piece between the cuts is an
+// independent JOB: a plan over [the piece in an order that ends at its separators, its adjacent separator rows], of which only the
+// piece's own columns are eliminated -- what it leaves on its separator rows (a dense Schur complement and a share of their right-hand
+// side) goes to an exchange buffer.  The separator system (original separator blocks + every job's contribution, summed in job order)
+// is factored and solved on its own plan, and every job finishes with the backward substitution of its columns.  One workgroup per
+// job, jobs of different ranks on different GPUs: the exchange buffer and the solution are the only things that cross ranks, and since
+// every rank contributes zeros outside its own jobs the all-reduce is an all-gather -- results do not depend on the world size.
+struct SegJobDev {
+    SkyDev K;      // plan of [piece, adjacent separator rows]
+    int nC, ns;    // columns to eliminate; separator rows behind them
+    double* xch;   // [ns (ns + 1) / 2 x 36: Schur complement on the separator rows, lower triangle row-major][6 ns: their right-hand side share]
+};
+
+// kept blocks / right-hand side of the reduced system -> the plans of a segmented elimination (ONE map over the whole value arena)
+__global__ __launch_bounds__(256) void k_seg_assemble(BaDev D, const int2* __restrict__ blkmap, const int* __restrict__ yoff, double* __restrict__ arena, int NB) {
+    if (D.ctl->phase != 1) return;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < (size_t)NB * 36) {
+        const int k = (int)(t / 36), e = (int)(t - (size_t)k * 36), i = e / 6, j = e - 6 * i;
+        const int2 m = blkmap[k];
+        if (m.x >= 0) arena[(size_t)m.x * 36 + (m.y ? j * 6 + i : e)] = D.Sblk[t];
+    }
+    if (t < (size_t)D.n) {
+        const int a = (int)(t / 6), c = (int)(t - (size_t)a * 6);
+        const int o = yoff[a];
+        if (o >= 0) arena[(size_t)o + c] = D.g[t];
+    }
+}
+
+// separator system += the jobs' contributions, in job order (fixed order of the sums: bit-reproducible, and the same on every rank)
+__global__ __launch_bounds__(256) void k_seg_gather(BaDev D, SkyDev K, const int* __restrict__ gb_off, const int* __restrict__ gb_src, const int* __restrict__ gy_off,
+                                                     const int* __restrict__ gy_src, const double* __restrict__ xch) {
+    if (D.ctl->phase != 1) return;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < K.nblocks * 36) {
+        const int b = (int)(t / 36), e = (int)(t - (size_t)b * 36), i = e / 6, j = e - 6 * i;
+        double v = K.val[t];
+        for (int q = gb_off[b]; q < gb_off[b + 1]; ++q) {
+            const int src = gb_src[q];
+            v += xch[(size_t)(src & 0x3fffffff) * 36 + ((src >> 30) & 1 ? j * 6 + i : e)];
+        }
+        K.val[t] = v;
+    }
+    if (t < (size_t)K.nP * 6) {
+        const int p = (int)(t / 6), c = (int)(t - (size_t)p * 6);
+        double v = K.y[t];
+        for (int q = gy_off[p]; q < gy_off[p + 1]; ++q) v += xch[(size_t)gy_src[q] + c];
+        K.y[t] = v;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_sky_assemble(BaDev D, SkyDev K0, SkyDev K1) {  // blockIdx.y = plan (a block / slot a plan does not hold maps to -1)
     if (D.ctl->phase != 1) return;
@@ -434,12 +487,13 @@ __global__ __launch_bounds__(SKY_THREADS) void k_sky_factor_solve(BaDev D, SkyDe
     const int tid = threadIdx.x, nt = blockDim.x, nP = K.nP;
     double* const s_col = s_dyn;
     double* const s_y = s_dyn + (size_t)K.max_m * 36;
-    int* const s_coloff = reinterpret_cast<int*>(s_y + D.n);
+    const int ny = 6 * nP;  // (the plan may cover a subset of the slots: the separator system of a segmented elimination)
+    int* const s_coloff = reinterpret_cast<int*>(s_y + ny);
     int* const s_diag = s_coloff + (nP + 1);
     int* const s_rows = s_diag + nP;
     int* const s_base = s_rows + K.ncr;
     if (tid == 0) s_fail = 0;
-    for (int t = tid; t < D.n; t += nt) s_y[t] = K.y[t];
+    for (int t = tid; t < ny; t += nt) s_y[t] = K.y[t];
     for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
     for (int t = tid; t < nP; t += nt) s_diag[t] = K.diag[t];
     for (int t = tid; t < K.ncr; t += nt) {
@@ -500,15 +554,16 @@ __global__ __launch_bounds__(SKY_THREADS) void k_sky_factor_solve(BaDev D, SkyDe
     }
     if (s_fail) {
         if (tid == 0) D.ctl->solve_failed = 1;
-        for (int t = tid; t < D.n; t += nt) D.dp[t] = 0.0;
+        for (int t = tid; t < D.n; t += nt)
+            if (K.pos[t / 6] >= 0) D.dp[t] = 0.0;
         return;
     }
     // ---------------------------------------------------------------- L z = g (column oriented), then L^T x = z: the first wave alone
     if (tid < 64) sky_substitute(K, s_y, s_coloff, s_rows, s_base, tid);
     __syncthreads();
     for (int t = tid; t < D.n; t += nt) {
-        const int a = t / 6, c = t - 6 * a;
-        D.dp[t] = s_y[K.pos[a] * 6 + c];
+        const int a = t / 6, c = t - 6 * a, pa = K.pos[a];
+        if (pa >= 0) D.dp[t] = s_y[pa * 6 + c];  // (a plan over a subset of the slots -- the separator system of a segmented elimination -- writes its own only)
     }
 }
 
@@ -539,10 +594,20 @@ __device__ __forceinline__ int sky_wait(int* flag, int epoch) {  // +-epoch
 }
 __device__ __forceinline__ double sky_peek(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // past this unit's L1
 
-__global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K0, SkyDev K1, SkyTwist T, int epoch) {
+__global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K0, SkyDev K1, SkyTwist T_in, int epoch, const SegJobDev* __restrict__ jobs) {
     if (D.ctl->phase != 1) return;
-    const int who = blockIdx.x;  // 0: the whole system, or [T, S] of a two-sided elimination; 1: the reversed [B, S]
-    const SkyDev& K = who ? K1 : K0;
+    // jobs != null: workgroup b eliminates the nC columns of job b and exports what is left on its separator rows (the role of the
+    // second workgroup of a two-sided elimination, without the hand-over flags: the separator solve and the backward pass are launches
+    // of their own); else 0: the whole system, or [T, S] of a two-sided elimination; 1: the reversed [B, S]
+    const int who = jobs ? 1 : (int)blockIdx.x;
+    SkyDev Kj;
+    SkyTwist T = T_in;
+    if (jobs) {
+        const SegJobDev J = jobs[blockIdx.x];
+        Kj = J.K;
+        T.on = 1, T.m = 0, T.W = J.ns, T.nB = J.nC, T.xch = J.xch;
+    }
+    const SkyDev& K = jobs ? Kj : (who ? K1 : K0);
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][6 nP: right-hand side][index arrays]
     __shared__ double s_Li[2][36];  // inverse diagonal factors of columns j and j + 1 (the look-ahead pivot writes one while the other is in use)
     __shared__ int s_fail, s_other;
@@ -573,7 +638,11 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
         s_base[t] = K.colbase[t];
     }
     __syncthreads();
-    auto slot = [&](int i, int k) { return s_win + (size_t)((i % Wn) * Wn + (k % Wn)) * 36; };
+    auto slot = [&](int i, int k) { return s_win + (size_t)((i % Wn) * Wn + (k % Wn)) * 36; };  // (two integer divisions: set-up and hand-over code only)
+    // inside the column loop the window slots are tracked incrementally -- jm = j mod (W + 1) is carried from column to column and a row
+    // or column at distance d <= W + 1 from it needs one conditional subtraction -- so that no thread divides by a run-time value there
+    auto wrap = [&](int x) { return x >= Wn ? x - Wn : x; };
+    auto slot_at = [&](int rs, int cs) { return s_win + (size_t)(rs * Wn + cs) * 36; };
     // rows 0 .. W of the assembled system
     for (int i = 0; i < min(Wn, nP); ++i) {
         const int f = s_first[i];
@@ -585,13 +654,13 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     __syncthreads();
     // Column j: [scale] barrier [update of the other waves | first wave: the six rows of block (j + 1, j + 1), then the PIVOT of column
     // j + 1, which needs nothing else of this update] barrier.  Two barriers per column, the pivots off the critical path.
-    auto update_item = [&](int j, int t) {  // S_{ip, iq} -= L_p L_q^T inside the window: item = (pair, row of the block)
+    auto update_item = [&](int jm1, int t) {  // S_{ip, iq} -= L_p L_q^T inside the window: item = (pair, row of the block); jm1 = slot of row / column j + 1
         const int x = t / 6, a = t - 6 * x;
         const int pq = s_pq[x], p = pq & 255, q = pq >> 8;
         double La[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
-        double* Dst = slot(j + 1 + p, j + 1 + q) + a * 6;
+        double* Dst = slot_at(wrap(jm1 + p), wrap(jm1 + q)) + a * 6;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             double v = La[0] * s_col[q * 36 + b * 6];
@@ -602,8 +671,10 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     };
     // columns jb .. je - 1 (the pivot of column jb is in s_Li when it starts; the pivot of column je is NOT taken: it may wait for the other half)
     auto factor = [&](int jb, int je) {
-        for (int j = jb; j < je; ++j) {
+        int jm = jb % Wn;
+        for (int j = jb; j < je; ++j, jm = wrap(jm + 1)) {
             if (s_fail) break;
+            const int jm1 = wrap(jm + 1);
             const int m = s_coloff[j + 1] - s_coloff[j];
             // the row that enters the window behind this column: requested now, stored in LDS behind the update
             const int inew = j + Wn;
@@ -620,7 +691,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
             }
             for (int t = tid; t < m * 36; t += nt) {  // L_ij = S_ij L_jj^-T
                 const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
-                const double* Bl = slot(j + 1 + r, j) + a * 6;
+                const double* Bl = slot_at(wrap(jm1 + r), jm) + a * 6;
                 double v = 0.0;
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
@@ -631,10 +702,10 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
             for (int t = tid; t < m * 36; t += nt) K.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
             const int npair = m * (m + 1) / 2;
             if (tid < 64) {
-                if (m > 0 && tid < 6) update_item(j, tid);  // pair (0, 0) = block (j + 1, j + 1)
+                if (m > 0 && tid < 6) update_item(jm1, tid);  // pair (0, 0) = block (j + 1, j + 1)
                 wave_lds_order();
                 if (j + 1 < je)
-                    sky_pivot(slot(j + 1, j + 1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li[(j + 1) & 1], &s_fail, tid);
+                    sky_pivot(slot_at(jm1, jm1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li[(j + 1) & 1], &s_fail, tid);
             }
             else {
                 if (tid >= nt - 64) {  // the forward substitution of this column rides along on the last wave: z_j = L_jj^-1 y_j, y_i -= L_ij z_j
@@ -659,13 +730,13 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                         s_y[(j + 1) * 6 + t] -= u;
                     }
                 }
-                for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(j, t);
+                for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(jm1, t);
             }
             if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot of column j long ago)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int t = tid + q * SKY_BAND_THREADS;
-                    if (t < npre) slot(inew, fnew + t / 36)[t % 36] = pre[q];
+                    if (t < npre) slot_at(jm, wrap(jm1 + (fnew - (j + 1)) + t / 36))[t % 36] = pre[q];  // row j + W + 1 takes the slots of row j
                 }
             }
             block_sync_lds();
@@ -689,6 +760,14 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
         }
         for (int t = tid; t < 6 * Ws; t += nt) xY[t] = s_y[nA * 6 + t];  // ... and its share of the right-hand side of S (the forward pass rode along)
         __syncthreads();
+        if (jobs) {  // a job ends here: z of its columns waits in global memory for k_seg_backward; a failed job contributes zeros
+            if (s_fail) {
+                for (int t = tid; t < npairS * 36 + 6 * Ws; t += nt) xS2[t] = 0.0;
+                if (tid == 0) D.ctl->solve_failed = 1;
+            }
+            for (int t = tid; t < 6 * nA; t += nt) K.y[t] = s_fail ? 0.0 : s_y[t];
+            return;
+        }
         if (tid == 0) sky_post(T.flags + 0, s_fail ? -epoch : epoch);
     }
     if (T.on && who == 0) {
@@ -760,10 +839,52 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     }
 }
 
+// Backward substitution of the eliminated columns of every job, once the separator unknowns are known (D.dp of the separator slots):
+// one wave per job, the right-hand side in LDS, the factor rows of the next four columns in flight (sky_backward_narrow).
+__global__ __launch_bounds__(64) void k_seg_backward(BaDev D, const SegJobDev* __restrict__ jobs, double* __restrict__ out) {
+    if (D.ctl->phase != 1) return;
+    const SegJobDev J = jobs[blockIdx.x];
+    const SkyDev& K = J.K;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    const int lane = threadIdx.x, nP = K.nP, nC = J.nC;
+    double* const s_y = s_dyn;
+    int* const s_coloff = reinterpret_cast<int*>(s_y + 6 * nP);
+    int* const s_rows = s_coloff + (nP + 1);
+    int* const s_base = s_rows + K.ncr;
+    const bool failed = D.ctl->solve_failed != 0;  // (this rank's jobs or its separator solve: the trial is rejected anyway)
+    for (int t = lane; t < 6 * nP; t += 64) s_y[t] = t < 6 * nC ? K.y[t] : D.dp[K.order[t / 6] * 6 + t % 6];
+    for (int t = lane; t <= nP; t += 64) s_coloff[t] = K.coloff[t];
+    for (int t = lane; t < K.ncr; t += 64) {
+        s_rows[t] = K.colrows[t];
+        s_base[t] = K.colbase[t];
+    }
+    wave_lds_fence();
+    if (!failed && nC > 0) sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nC - 1, 0);
+    wave_lds_fence();
+    for (int t = lane; t < 6 * nC; t += 64) out[K.order[t / 6] * 6 + t % 6] = failed ? 0.0 : s_y[t];
+}
+// out[separator slots] = D.dp (rank 0 of a sharded solve puts the separator unknowns into the exchanged solution vector)
+__global__ __launch_bounds__(256) void k_seg_copy_sep(BaDev D, SkyDev K, double* __restrict__ out) {
+    if (D.ctl->phase != 1) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 6 * K.nP) {
+        const int a = K.order[t / 6];
+        out[a * 6 + t % 6] = D.dp[a * 6 + t % 6];
+    }
+}
+
 struct SkyPlan {
-    SkyDev dev[2];     // [1] only for the two-sided elimination
+    SkyDev dev[2];     // [1] only for the two-sided elimination; [0] = the separator system of a segmented elimination
     SkyTwist twist;
     int epoch = 0;
+    // segmented elimination (see SegJobDev): job descriptors of THIS rank (device array), the assembly / gather maps, the exchange buffers
+    int seg = 0, seg_jobs_total = 0, seg_jobs_local = 0, seg_nsep = 0, seg_world = 1, seg_rank = 0;
+    const SegJobDev* seg_jobs = nullptr;
+    const int2* seg_blkmap = nullptr;
+    const int *seg_yoff = nullptr, *seg_gb_off = nullptr, *seg_gb_src = nullptr, *seg_gy_off = nullptr, *seg_gy_src = nullptr;
+    double *seg_arena = nullptr, *seg_xch = nullptr, *seg_dpx = nullptr;
+    size_t seg_xch_doubles = 0, seg_lds_job = 0, seg_lds_back = 0;
+    int seg_NB = 0, seg_n = 0, seg_cuts = 0, seg_longest = 0, plan_rows = 0, plan_width = 0;
     void* d_int = nullptr;
     size_t int_bytes = 0;
     void* d_val = nullptr;
@@ -917,9 +1038,529 @@ static void host_sky(int nS, const std::vector<int>& order, const std::vector<st
     H.ok = true;
 }
 
+// -------------------------------------------------------------------------------------------------- segmented elimination: host planner
+struct HostSeg {
+    std::vector<HostSky> job;             // plan of [piece in elimination order, its adjacent separator rows]
+    std::vector<std::vector<int>> order;  // per job: position -> slot
+    std::vector<int> nC, ns, owner;       // eliminated columns, separator rows, owning rank
+    HostSky sep;                          // the separator system
+    std::vector<int> sep_order;           // position -> slot
+    std::vector<size_t> xch_off;          // per job: its exchange block, in doubles (a multiple of 36)
+    size_t xch_doubles = 0;
+    std::vector<int> gb_off, gb_src, gy_off, gy_src;  // gather lists: separator block -> (exchange block | transposed << 30), separator row -> exchange offset
+    int ncuts = 0, max_nC = 0;
+    bool ok = false;
+};
+static size_t band_lds_bytes(const HostSky& h) {
+    const size_t wn = (size_t)h.max_m + 1;
+    return (wn * wn * 36 + (size_t)h.max_m * 36 + (size_t)6 * h.nP) * sizeof(double) + 4 * ((size_t)3 * h.nP + 1 + 2 * h.colrows.size());
+}
+
+// `ncuts` vertex separators in the RCM order (each a run of consecutive positions, as narrow as the band allows near its target), the
+// connected pieces between them as jobs, the separator system with the fill the jobs leave on it.  G.ok only when every job fits the
+// banded kernel (k_sky_band in job mode) and the separator system has a plan.
+static void plan_segments(int nP, const std::vector<int>& order, const std::vector<std::vector<int>>& adj, const std::vector<int2>& blk_ab, int ncuts, int world,
+                          size_t max_bytes, HostSeg& G) {
+    G = HostSeg();
+    if (ncuts < 1 || nP < 4) return;
+    std::vector<int> pos0(nP);
+    for (int i = 0; i < nP; ++i) pos0[order[i]] = i;
+    // reach[c] = last position coupled to a position before c: a cut that starts at c has to extend that far
+    std::vector<int> maxi_of_lo(nP, -1), reach(nP + 1, -1);
+    for (int i = 0; i < nP; ++i) {
+        int f = i;
+        for (int v : adj[order[i]]) f = std::min(f, pos0[v]);
+        maxi_of_lo[f] = std::max(maxi_of_lo[f], i);
+    }
+    for (int c = 1; c <= nP; ++c) reach[c] = std::max(reach[c - 1], maxi_of_lo[c - 1]);
+    auto width = [&](int c) { return std::max(0, reach[c] - c + 1); };
+    std::vector<char> is_sep(nP, 0);  // by slot
+    int prev_end = 0;
+    const int seg = nP / (ncuts + 1);
+    for (int j = 1; j <= ncuts; ++j) {
+        const int target = (int)((long long)j * nP / (ncuts + 1)), win = std::max(1, seg / 4);
+        int best = -1, bw = 1 << 30, boff = 1 << 30;
+        for (int c = std::max(prev_end + 1, target - win); c <= std::min(nP - 2, target + win); ++c) {
+            const int w = width(c);
+            if (c + w >= nP) continue;  // nothing would be left behind it
+            const int off = std::abs(c + w / 2 - target);
+            if (w < bw || (w == bw && off < boff)) best = c, bw = w, boff = off;
+        }
+        if (best < 0) continue;
+        for (int i = best; i < best + bw; ++i) is_sep[order[i]] = 1;
+        prev_end = best + bw;
+        ++G.ncuts;
+    }
+    if (G.ncuts == 0) return;
+    // connected pieces of the graph without the separator vertices, members in RCM position order
+    std::vector<int> comp(nP, -1);
+    std::vector<std::vector<int>> members;
+    for (int i = 0; i < nP; ++i) {
+        const int s0 = order[i];
+        if (is_sep[s0] || comp[s0] >= 0) continue;
+        const int id = (int)members.size();
+        members.emplace_back();
+        std::vector<int> stack{s0};
+        comp[s0] = id;
+        while (!stack.empty()) {
+            const int u = stack.back();
+            stack.pop_back();
+            members[id].push_back(u);
+            for (int v : adj[u])
+                if (!is_sep[v] && comp[v] < 0) {
+                    comp[v] = id;
+                    stack.push_back(v);
+                }
+        }
+        std::sort(members[id].begin(), members[id].end(), [&](int a, int b) { return pos0[a] < pos0[b]; });
+    }
+    const int nj = (int)members.size();
+    if (nj < 2) return;
+    G.job.resize(nj);
+    G.order.resize(nj);
+    G.nC.resize(nj);
+    G.ns.resize(nj);
+    G.owner.assign(nj, 0);
+    G.xch_off.resize(nj);
+    std::vector<std::vector<int>> adj_sep(nP);  // separator graph: original couplings + the clique every job leaves on its separator rows
+    for (int u = 0; u < nP; ++u)
+        if (is_sep[u])
+            for (int v : adj[u])
+                if (is_sep[v]) adj_sep[u].push_back(v);
+    std::vector<int> jpos(nP, -1);
+    for (int q = 0; q < nj; ++q) {
+        const std::vector<int>& M = members[q];
+        const int n = (int)M.size();
+        std::vector<int> A;
+        for (int u : M)
+            for (int v : adj[u])
+                if (is_sep[v]) A.push_back(v);
+        std::sort(A.begin(), A.end());
+        A.erase(std::unique(A.begin(), A.end()), A.end());
+        bool before = false, after = false;
+        for (int v : A) {
+            before = before || pos0[v] < pos0[M.front()];
+            after = after || pos0[v] > pos0[M.back()];
+        }
+        // elimination order of the piece: it must END at its separators.  Separators on both sides: from the median of the piece
+        // outwards, alternating (a chain folded in the middle: twice the bandwidth, no border rows); one side: towards it.
+        std::vector<int>& ord = G.order[q];
+        ord.reserve(n + A.size());
+        if (before && after) {
+            int l = (n - 1) / 2, r = l + 1;
+            ord.push_back(M[l--]);
+            while (l >= 0 || r < n) {
+                if (r < n) ord.push_back(M[r++]);
+                if (l >= 0) ord.push_back(M[l--]);
+            }
+        }
+        else if (before)
+            for (int k = n - 1; k >= 0; --k) ord.push_back(M[k]);
+        else
+            for (int k = 0; k < n; ++k) ord.push_back(M[k]);
+        // separator rows behind it, those coupled deepest into the piece first (their envelopes then start in non-decreasing columns)
+        for (int k = 0; k < n; ++k) jpos[ord[k]] = k;
+        std::vector<std::pair<std::pair<int, int>, int>> key;
+        for (int v : A) {
+            int f = n;
+            for (int w : adj[v])
+                if (jpos[w] >= 0) f = std::min(f, jpos[w]);
+            key.push_back({{f, pos0[v]}, v});
+        }
+        for (int k = 0; k < n; ++k) jpos[ord[k]] = -1;
+        std::sort(key.begin(), key.end());
+        for (const auto& kv : key) ord.push_back(kv.second);
+        G.nC[q] = n;
+        G.ns[q] = (int)A.size();
+        G.max_nC = std::max(G.max_nC, n);
+        host_sky(nP, ord, adj, blk_ab, n, true, max_bytes, G.job[q]);
+        const HostSky& h = G.job[q];
+        if (!h.ok || !h.band || h.max_m < 1 || h.max_m > SKY_BAND_W || (int)A.size() > h.max_m + 1 || band_lds_bytes(h) > 150 * 1024) return;
+        for (size_t a = 0; a < A.size(); ++a)
+            for (size_t b = 0; b < A.size(); ++b)
+                if (a != b) adj_sep[A[a]].push_back(A[b]);
+        G.xch_off[q] = G.xch_doubles;
+        const size_t sz = (size_t)A.size() * (A.size() + 1) / 2 * 36 + 6 * A.size();
+        G.xch_doubles += (sz + 35) / 36 * 36;
+    }
+    // the separator system in an RCM order of its OWN graph (the cuts of a loop are a ring of half-cuts: taken in the position order of
+    // the original band every row would reach back over a whole cut, twice the width the folded ring has)
+    {
+        std::vector<int> sl, loc(nP, -1);
+        for (int i = 0; i < nP; ++i)
+            if (is_sep[order[i]]) {
+                loc[order[i]] = (int)sl.size();
+                sl.push_back(order[i]);
+            }
+        std::vector<std::vector<int>> a2(sl.size());
+        for (size_t k = 0; k < sl.size(); ++k) {
+            for (int v : adj_sep[sl[k]]) a2[k].push_back(loc[v]);
+            std::sort(a2[k].begin(), a2[k].end());
+            a2[k].erase(std::unique(a2[k].begin(), a2[k].end()), a2[k].end());
+        }
+        for (int k : rcm_order((int)sl.size(), a2)) G.sep_order.push_back(sl[k]);
+    }
+    const int nsep = (int)G.sep_order.size();
+    if (nsep > 0) {
+        host_sky(nP, G.sep_order, adj_sep, blk_ab, nsep, false, max_bytes, G.sep);
+        if (!G.sep.ok) return;
+        std::vector<std::vector<int>> gb(G.sep.nblocks), gy(nsep);
+        for (int q = 0; q < nj; ++q) {
+            const std::vector<int>& ord = G.order[q];
+            const int nC = G.nC[q], ns = G.ns[q];
+            const size_t b0 = G.xch_off[q] / 36, y0 = G.xch_off[q] + (size_t)ns * (ns + 1) / 2 * 36;
+            for (int r = 0; r < ns; ++r) {
+                const int pr = G.sep.pos[ord[nC + r]];
+                gy[pr].push_back((int)(y0 + 6 * (size_t)r));
+                for (int c = 0; c <= r; ++c) {
+                    const int pc = G.sep.pos[ord[nC + c]];
+                    const int row = std::max(pr, pc), col = std::min(pr, pc);
+                    if (col < G.sep.first[row]) return;  // cannot happen: the clique is part of the separator graph
+                    gb[G.sep.rowoff[row] + col - G.sep.first[row]].push_back((int)(b0 + (size_t)r * (r + 1) / 2 + c) | ((pr < pc ? 1 : 0) << 30));
+                }
+            }
+        }
+        G.gb_off.assign(1, 0);
+        for (const auto& v : gb) {
+            G.gb_src.insert(G.gb_src.end(), v.begin(), v.end());
+            G.gb_off.push_back((int)G.gb_src.size());
+        }
+        G.gy_off.assign(1, 0);
+        for (const auto& v : gy) {
+            G.gy_src.insert(G.gy_src.end(), v.begin(), v.end());
+            G.gy_off.push_back((int)G.gy_src.size());
+        }
+    }
+    // owners: longest jobs first onto the least loaded rank (same on every rank: the plan is a function of the block pattern)
+    std::vector<int> idx(nj);
+    for (int q = 0; q < nj; ++q) idx[q] = q;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return G.nC[a] > G.nC[b]; });
+    std::vector<long long> load(std::max(world, 1), 0);
+    for (int q : idx) {
+        int r = 0;
+        for (int k = 1; k < (int)load.size(); ++k)
+            if (load[k] < load[r]) r = k;
+        G.owner[q] = r;
+        load[r] += G.nC[q];
+    }
+    G.ok = true;
+}
+
+// Where everything of a segmented elimination lives inside ONE value arena (doubles; every block array starts at a multiple of 36), and the
+// two maps of the assembly: kept block k -> (arena block, transposed), slot -> arena offset of its right-hand side entry.
+struct SegLayout {
+    std::vector<size_t> job_val, job_dinv, job_y;
+    size_t sep_val = 0, sep_dinv = 0, sep_y = 0, xch = 0, dpx = 0, total = 0;
+    std::vector<int2> blkmap;
+    std::vector<int> yoff;
+    bool ok = false;
+};
+static void seg_layout(int nP, const std::vector<int2>& blk_ab, const HostSeg& G, SegLayout& L) {
+    L = SegLayout();
+    const int nj = (int)G.job.size();
+    size_t at = 0;
+    auto take = [&](size_t doubles) {
+        const size_t r = at;
+        at += (doubles + 35) / 36 * 36;
+        return r;
+    };
+    L.job_val.resize(nj), L.job_dinv.resize(nj), L.job_y.resize(nj);
+    for (int q = 0; q < nj; ++q) {
+        L.job_val[q] = take(G.job[q].nblocks * 36);
+        L.job_dinv[q] = take((size_t)G.job[q].nP * 36);
+        L.job_y[q] = take((size_t)G.job[q].nP * 6);
+    }
+    L.sep_val = take(G.sep.nblocks * 36);
+    L.sep_dinv = take((size_t)G.sep.nP * 36);
+    L.sep_y = take((size_t)G.sep.nP * 6);
+    L.xch = take(G.xch_doubles);
+    L.dpx = take((size_t)nP * 6);
+    L.total = at;
+    // which job holds a slot (separator slots: -1)
+    std::vector<int> job_of(nP, -1);
+    for (int q = 0; q < nj; ++q)
+        for (int k = 0; k < G.nC[q]; ++k) job_of[G.order[q][k]] = q;
+    L.yoff.assign(nP, -1);
+    for (int a = 0; a < nP; ++a) {
+        const int q = job_of[a];
+        if (q >= 0) L.yoff[a] = (int)(L.job_y[q] + 6 * (size_t)G.job[q].pos[a]);
+        else if (!G.sep.pos.empty() && G.sep.pos[a] >= 0) L.yoff[a] = (int)(L.sep_y + 6 * (size_t)G.sep.pos[a]);
+        else return;  // a slot nobody owns
+    }
+    L.blkmap.resize(blk_ab.size());
+    for (size_t k = 0; k < blk_ab.size(); ++k) {
+        const int qa = job_of[blk_ab[k].x], qb = job_of[blk_ab[k].y];
+        int2 m;
+        m.x = -1, m.y = 0;
+        if (qa < 0 && qb < 0) {
+            m = G.sep.blkmap[k];
+            if (m.x < 0) return;
+            m.x += (int)(L.sep_val / 36);
+        }
+        else {
+            const int q = qa >= 0 ? qa : qb;
+            if (qa >= 0 && qb >= 0 && qa != qb) return;  // a block across two pieces: the cuts are not separators
+            m = G.job[q].blkmap[k];
+            if (m.x < 0) return;
+            m.x += (int)(L.job_val[q] / 36);
+        }
+        L.blkmap[k] = m;
+    }
+    if (L.total >= ((size_t)1 << 31)) return;
+    L.ok = true;
+}
+
+// ---- host arithmetic on a plan: used ONLY by svgpu_selftest_segmented_solve (the planner's self-test; the bundle adjusters never call it)
+static bool host_chol6(const double* A, double* Lo, double* Li) {  // lower Cholesky factor and its inverse
+    for (int i = 0; i < 36; ++i) Lo[i] = 0.0, Li[i] = 0.0;
+    for (int c = 0; c < 6; ++c) {
+        double d = A[c * 6 + c];
+        for (int k = 0; k < c; ++k) d -= Lo[c * 6 + k] * Lo[c * 6 + k];
+        if (!(d > 0.0)) return false;
+        const double sd = std::sqrt(d);
+        Lo[c * 6 + c] = sd;
+        for (int r = c + 1; r < 6; ++r) {
+            double v = A[r * 6 + c];
+            for (int k = 0; k < c; ++k) v -= Lo[r * 6 + k] * Lo[c * 6 + k];
+            Lo[r * 6 + c] = v / sd;
+        }
+    }
+    for (int c = 0; c < 6; ++c)
+        for (int r = c; r < 6; ++r) {
+            double v = r == c ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) v -= Lo[r * 6 + k] * Li[k * 6 + c];
+            Li[r * 6 + c] = v / Lo[r * 6 + r];
+        }
+    return true;
+}
+static bool host_env_eliminate(const HostSky& h, double* val, double* dinv, double* y, int ncol) {
+    for (int j = 0; j < ncol; ++j) {
+        double* Dj = val + (size_t)h.diag[j] * 36;
+        double Lo[36], Li[36];
+        if (!host_chol6(Dj, Lo, Li)) return false;
+        for (int e = 0; e < 36; ++e) Dj[e] = Lo[e], dinv[(size_t)j * 36 + e] = Li[e];
+        const int c0 = h.coloff[j], m = h.coloff[j + 1] - c0;
+        for (int r = 0; r < m; ++r) {  // L_ij = S_ij L_jj^-T
+            double* B = val + (size_t)(h.colbase[c0 + r] + j) * 36;
+            double o[36];
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    double v = 0.0;
+                    for (int c = 0; c <= b; ++c) v += B[a * 6 + c] * Li[b * 6 + c];
+                    o[a * 6 + b] = v;
+                }
+            for (int e = 0; e < 36; ++e) B[e] = o[e];
+        }
+        for (int p = 0; p < m; ++p)
+            for (int q = 0; q <= p; ++q) {
+                const double* Lp = val + (size_t)(h.colbase[c0 + p] + j) * 36;
+                const double* Lq = val + (size_t)(h.colbase[c0 + q] + j) * 36;
+                double* Dst = val + (size_t)(h.colbase[c0 + p] + h.colrows[c0 + q]) * 36;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) {
+                        double v = 0.0;
+                        for (int c = 0; c < 6; ++c) v += Lp[a * 6 + c] * Lq[b * 6 + c];
+                        Dst[a * 6 + b] -= v;
+                    }
+            }
+        double z[6];
+        for (int r = 0; r < 6; ++r) {
+            double v = 0.0;
+            for (int c = 0; c <= r; ++c) v += Li[r * 6 + c] * y[j * 6 + c];
+            z[r] = v;
+        }
+        for (int r = 0; r < 6; ++r) y[j * 6 + r] = z[r];
+        for (int r = 0; r < m; ++r) {
+            const double* B = val + (size_t)(h.colbase[c0 + r] + j) * 36;
+            const int i = h.colrows[c0 + r];
+            for (int a = 0; a < 6; ++a) {
+                double u = 0.0;
+                for (int c = 0; c < 6; ++c) u += B[a * 6 + c] * z[c];
+                y[i * 6 + a] -= u;
+            }
+        }
+    }
+    return true;
+}
+static void host_env_backward(const HostSky& h, const double* val, const double* dinv, double* y, int jhi) {
+    for (int j = jhi; j >= 0; --j) {
+        const int c0 = h.coloff[j], m = h.coloff[j + 1] - c0;
+        double w[6];
+        for (int a = 0; a < 6; ++a) w[a] = y[j * 6 + a];
+        for (int r = 0; r < m; ++r) {
+            const double* B = val + (size_t)(h.colbase[c0 + r] + j) * 36;
+            const double* xi = y + (size_t)h.colrows[c0 + r] * 6;
+            for (int a = 0; a < 6; ++a)
+                for (int c = 0; c < 6; ++c) w[a] -= B[c * 6 + a] * xi[c];
+        }
+        const double* Li = dinv + (size_t)j * 36;
+        for (int a = 0; a < 6; ++a) {
+            double x = 0.0;
+            for (int c = a; c < 6; ++c) x += Li[c * 6 + a] * w[c];
+            y[j * 6 + a] = x;
+        }
+    }
+}
+
 // Plans the envelope factorisation of the reduced system whose kept upper blocks are blk_ab (a <= b, free-pose slots).  *usable = false
 // (and nothing else changes) when the envelope would exceed max_bytes or a column has more than SKY_MAXM rows: the caller keeps the PCG.
-int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable) {
+// Uploads a segmented plan: every job's and the separator system's index arrays, the assembly / gather maps and the descriptors of the
+// jobs THIS rank owns into the integer arena, and lays the value arena out (SegLayout).
+static int seg_upload(svgpu_ctx* ctx, hipStream_t s, SkyPlan* P, int nP, const std::vector<int2>& blk_ab, const HostSeg& G, const SegLayout& LY, int rank, int world) {
+    const int nj = (int)G.job.size(), nsep = (int)G.sep_order.size();
+    std::vector<int> host;
+    auto put = [&](const int* p, size_t n) {
+        if (host.size() & 1) host.push_back(0);
+        const size_t at = host.size();
+        host.insert(host.end(), p, p + n);
+        return at;
+    };
+    struct Off {
+        size_t pos, first, rowoff, coloff, colrows, colbase, diag, order;
+    };
+    std::vector<Off> off(nj + 1);
+    auto put_plan = [&](const HostSky& h, const std::vector<int>& ord, Off& o) {
+        o.pos = put(h.pos.data(), h.pos.size());
+        o.first = put(h.first.data(), h.nP);
+        o.rowoff = put(h.rowoff.data(), h.nP + 1);
+        o.coloff = put(h.coloff.data(), h.nP + 1);
+        o.colrows = put(h.colrows.data(), h.colrows.size());
+        o.colbase = put(h.colbase.data(), h.colbase.size());
+        o.diag = put(h.diag.data(), h.nP);
+        o.order = put(ord.data(), ord.size());
+    };
+    for (int q = 0; q < nj; ++q) put_plan(G.job[q], G.order[q], off[q]);
+    if (nsep > 0) put_plan(G.sep, G.sep_order, off[nj]);
+    const size_t o_blkmap = put(reinterpret_cast<const int*>(LY.blkmap.data()), LY.blkmap.size() * 2);
+    const size_t o_yoff = put(LY.yoff.data(), LY.yoff.size());
+    const int zero = 0;
+    const size_t o_gb_off = nsep > 0 ? put(G.gb_off.data(), G.gb_off.size()) : put(&zero, 1);
+    const size_t o_gb_src = nsep > 0 ? put(G.gb_src.data(), G.gb_src.size()) : put(&zero, 1);
+    const size_t o_gy_off = nsep > 0 ? put(G.gy_off.data(), G.gy_off.size()) : put(&zero, 1);
+    const size_t o_gy_src = nsep > 0 ? put(G.gy_src.data(), G.gy_src.size()) : put(&zero, 1);
+    int n_local = 0;
+    for (int q = 0; q < nj; ++q) n_local += G.owner[q] == rank;
+    if (host.size() & 1) host.push_back(0);
+    const size_t o_jobs = host.size();
+    const size_t n_int = o_jobs + (size_t)n_local * (sizeof(SegJobDev) / 4) + 16;
+    if (n_int * 4 > P->int_bytes) {
+        if (P->d_int) {
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            SV_HIP(ctx, hipFree(P->d_int));
+            P->d_int = nullptr;
+            P->int_bytes = 0;
+        }
+        SV_HIP(ctx, hipMalloc(&P->d_int, n_int * 4 + n_int));
+        P->int_bytes = n_int * 4 + n_int;
+    }
+    const size_t val_need = LY.total * sizeof(double);
+    if (val_need > P->val_bytes) {
+        if (P->d_val) {
+            SV_HIP(ctx, hipStreamSynchronize(s));
+            SV_HIP(ctx, hipFree(P->d_val));
+            P->d_val = nullptr;
+            P->val_bytes = 0;
+        }
+        SV_HIP(ctx, hipMalloc(&P->d_val, val_need + val_need / 4));
+        P->val_bytes = val_need + val_need / 4;
+    }
+    int* const di = (int*)P->d_int;
+    double* const dv = (double*)P->d_val;
+    auto dev_of = [&](const HostSky& h, const Off& o, size_t val, size_t dinv, size_t y) {
+        SkyDev K;
+        K.nP = h.nP;
+        K.NB = (int)blk_ab.size();
+        K.pos = di + o.pos;
+        K.order = di + o.order;
+        K.first = di + o.first;
+        K.rowoff = di + o.rowoff;
+        K.coloff = di + o.coloff;
+        K.colrows = di + o.colrows;
+        K.colbase = di + o.colbase;
+        K.diag = di + o.diag;
+        K.max_m = h.max_m;
+        K.ncr = (int)h.colrows.size();
+        K.band = h.band ? 1 : 0;
+        K.val = dv + val;
+        K.dinv = dv + dinv;
+        K.y = dv + y;
+        K.nblocks = h.nblocks;
+        return K;
+    };
+    std::vector<SegJobDev> jobs;
+    size_t lds_job = 0, lds_back = 0;
+    for (int q = 0; q < nj; ++q) {
+        if (G.owner[q] != rank) continue;
+        SegJobDev J;
+        J.K = dev_of(G.job[q], off[q], LY.job_val[q], LY.job_dinv[q], LY.job_y[q]);
+        J.nC = G.nC[q];
+        J.ns = G.ns[q];
+        J.xch = dv + LY.xch + G.xch_off[q];
+        jobs.push_back(J);
+        lds_job = std::max(lds_job, band_lds_bytes(G.job[q]));
+        lds_back = std::max(lds_back, (size_t)6 * G.job[q].nP * sizeof(double) + 4 * ((size_t)G.job[q].nP + 1 + 2 * G.job[q].colrows.size()));
+    }
+    if (!jobs.empty()) {
+        host.resize(o_jobs + jobs.size() * (sizeof(SegJobDev) / 4));
+        memcpy(host.data() + o_jobs, jobs.data(), jobs.size() * sizeof(SegJobDev));
+    }
+    SV_HIP(ctx, hipMemcpyAsync(P->d_int, host.data(), host.size() * 4, hipMemcpyHostToDevice, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));  // `host` is a pageable temporary
+    for (int q = 0; q < 2; ++q) P->dev[q] = SkyDev();
+    if (nsep > 0) P->dev[0] = dev_of(G.sep, off[nj], LY.sep_val, LY.sep_dinv, LY.sep_y);
+    P->twist = SkyTwist();
+    P->seg = 1;
+    P->seg_jobs_total = nj;
+    P->seg_jobs_local = (int)jobs.size();
+    P->seg_nsep = nsep;
+    P->seg_world = world;
+    P->seg_rank = rank;
+    P->seg_jobs = reinterpret_cast<const SegJobDev*>(di + o_jobs);
+    P->seg_blkmap = reinterpret_cast<const int2*>(di + o_blkmap);
+    P->seg_yoff = di + o_yoff;
+    P->seg_gb_off = di + o_gb_off;
+    P->seg_gb_src = di + o_gb_src;
+    P->seg_gy_off = di + o_gy_off;
+    P->seg_gy_src = di + o_gy_src;
+    P->seg_arena = dv;
+    P->seg_xch = dv + LY.xch;
+    P->seg_dpx = dv + LY.dpx;
+    P->seg_xch_doubles = G.xch_doubles;
+    P->seg_lds_job = lds_job;
+    P->seg_lds_back = lds_back;
+    P->seg_NB = (int)blk_ab.size();
+    P->seg_n = 6 * nP;
+    P->val_used = LY.total * sizeof(double);
+    P->epoch = 0;
+    P->usable = true;
+    return SVGPU_OK;
+}
+
+// The segmented plan sv_sky_plan would choose for this block pattern (shared with the self-test): candidates of 2..8 cuts, cheapest by a
+// column-count model -- the longest job at ~3 us per column (jobs run side by side) + the separator system at ~3 us (banded kernel) or
+// ~6.5 us (general kernel) per column; `want` > 0 forces that many cuts.
+static bool choose_segments(int nP, const std::vector<int>& order, const std::vector<std::vector<int>>& adj, const std::vector<int2>& blk_ab, int want, int world,
+                            size_t max_bytes, HostSeg& G, SegLayout& LY) {
+    G = HostSeg();
+    double best = 1e30;
+    for (int nc = want > 0 ? want : 2; nc <= (want > 0 ? want : 8); ++nc) {
+        HostSeg cand;
+        plan_segments(nP, order, adj, blk_ab, nc, world, max_bytes, cand);
+        if (!cand.ok || (int)cand.job.size() < world) continue;
+        const bool sep_band = cand.sep.nP == 0 || (cand.sep.band && cand.sep.max_m <= SKY_BAND_W && band_lds_bytes(cand.sep) <= 150 * 1024);
+        const double cost = 3.0 * cand.max_nC + (sep_band ? 3.0 : 6.5) * cand.sep.nP + 15.0;
+        if (cost < best) {
+            best = cost;
+            G = std::move(cand);
+        }
+    }
+    if (!G.ok) return false;
+    if (want <= 0 && world == 1 && best > 0.8 * 3.0 * nP) return false;  // not worth three launches instead of one
+    seg_layout(nP, blk_ab, G, LY);
+    return LY.ok;
+}
+
+int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable, int rank, int world) {
     *usable = false;
     if (nP <= 0) return SVGPU_OK;
     std::vector<std::vector<int>> adj(nP);
@@ -932,9 +1573,40 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
     HostSky H[2];
     host_sky(nP, order, adj, blk_ab, nP, false, max_bytes, H[0]);
     if (!H[0].ok) return SVGPU_OK;
+    SkyPlan* P = (SkyPlan*)ctx->ba_sky;
+    if (!P) {
+        P = new SkyPlan();
+        ctx->ba_sky = P;
+    }
+    P->seg = 0;
+    // segmented elimination of a long band (the default there; SVGPU_SKY_SEGMENTS=<cuts> forces a cut count, 0 switches it off).  A sharded
+    // solve distributes the jobs over its ranks -- every rank plans the same segments from the same (all-reduced) block pattern.
+    {
+        const char* ev = std::getenv("SVGPU_SKY_SEGMENTS");
+        const int want = ev ? std::atoi(ev) : -1;
+        if (want != 0 && !std::getenv("SVGPU_SKY_ONE_SIDED") && H[0].band && H[0].max_m >= 1 && nP >= 8 * (H[0].max_m + 1)) {
+            HostSeg G;
+            SegLayout LY;
+            if (choose_segments(nP, order, adj, blk_ab, want, world, max_bytes, G, LY)) {
+                const int rs = seg_upload(ctx, s, P, nP, blk_ab, G, LY, rank, world);
+                if (rs) return rs;
+                P->seg_cuts = G.ncuts, P->seg_longest = G.max_nC, P->plan_rows = nP, P->plan_width = H[0].max_m;
+                *usable = true;
+                if (std::getenv("SVGPU_BA_TRACE")) {
+                    std::fprintf(stderr, "[ba]     envelope plan: %d block rows, segmented: %d cuts, %zu jobs (longest %d columns, %d on this rank), separator system %d rows%s\n", nP,
+                                 G.ncuts, G.job.size(), G.max_nC, P->seg_jobs_local, G.sep.nP, G.sep.band ? " (banded)" : "");
+                }
+                return SVGPU_OK;
+            }
+        }
+    }
     // two-sided elimination of a long band: T | S | B with S = as many rows as the band is wide (then no block couples T and B)
     int nplans = 1, tw_m = 0, tw_W = 0, tw_nB = 0;
-    if (H[0].band && H[0].max_m >= 1 && nP >= 8 * (H[0].max_m + 1) && !std::getenv("SVGPU_SKY_ONE_SIDED")) {
+    // (the fallback when the segmented plan does not apply.  Its two workgroups wait for each other on flags, so both must be resident at
+    //  once: any device with at least two compute units -- a device restricted below that keeps the one-sided sweep.)
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    if (cus >= 2 && H[0].band && H[0].max_m >= 1 && nP >= 8 * (H[0].max_m + 1) && !std::getenv("SVGPU_SKY_ONE_SIDED")) {
         const int W = H[0].max_m, m = (nP - W) / 2, nB = nP - m - W;
         std::vector<int> o0(order.begin(), order.begin() + m + W), o1(order.rbegin(), order.rbegin() + nB + W);
         HostSky A, B;
@@ -950,11 +1622,6 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
             H[1] = std::move(B);
             nplans = 2, tw_m = m, tw_W = W, tw_nB = nB;
         }
-    }
-    SkyPlan* P = (SkyPlan*)ctx->ba_sky;
-    if (!P) {
-        P = new SkyPlan();
-        ctx->ba_sky = P;
     }
     // one integer arena per call: for every plan pos | first | rowoff | coloff | colrows | colbase | diag | blkmap; then the flags
     size_t n_int = 16, n_val = 8;
@@ -1045,6 +1712,7 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
     }
     P->epoch = 0;
     P->usable = true;
+    P->plan_rows = nP, P->plan_width = H[0].max_m;
     *usable = true;
     if (std::getenv("SVGPU_BA_TRACE"))
         std::fprintf(stderr, "[ba]     envelope plan: %d block rows, %zu blocks (%.1f MB), widest column %d rows%s%s\n", nP, H[0].nblocks + (nplans == 2 ? H[1].nblocks : 0),
@@ -1053,9 +1721,52 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
     return SVGPU_OK;
 }
 
-void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
+int sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SkyPlan* P = (SkyPlan*)ctx->ba_sky;
     SvProfScope ps(ctx, s, "ba_solve");
+    if (P->seg) {
+        // segmented elimination: assemble -> the jobs of this rank, one workgroup each -> [exchange of what they leave on the separators] ->
+        // separator system -> backward substitution of the jobs -> [exchange of the solution].  The exchanges are sums in which every rank
+        // contributes zeros outside its own jobs: an all-gather through the all-reduce the solve already has.
+        const bool multi = P->seg_world > 1 && ctx->ba_ar_fn;
+        (void)hipMemsetAsync(P->seg_arena, 0, P->val_used, s);
+        const size_t items = std::max((size_t)P->seg_NB * 36, (size_t)D.n);
+        hipLaunchKernelGGL(k_seg_assemble, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, D, P->seg_blkmap, P->seg_yoff, P->seg_arena, P->seg_NB);
+        if (P->seg_jobs_local > 0) {
+            (void)sv_allow_dynamic_lds((const void*)k_sky_band, P->seg_lds_job);
+            hipLaunchKernelGGL(k_sky_band, dim3(P->seg_jobs_local), dim3(SKY_BAND_THREADS), P->seg_lds_job, s, D, SkyDev(), SkyDev(), SkyTwist(), 0, P->seg_jobs);
+        }
+        if (multi && P->seg_xch_doubles > 0 && ctx->ba_ar_fn(ctx->ba_ar_user, P->seg_xch, P->seg_xch_doubles, (void*)s) != 0)
+            return sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed (separator exchange)");
+        if (P->seg_nsep > 0) {
+            const SkyDev& K = P->dev[0];
+            const size_t gitems = std::max(K.nblocks * 36, (size_t)K.nP * 6);
+            hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)((gitems + 255) / 256)), dim3(256), 0, s, D, K, P->seg_gb_off, P->seg_gb_src, P->seg_gy_off, P->seg_gy_src, P->seg_xch);
+            const size_t wn = (size_t)K.max_m + 1;
+            const size_t lds_b = (wn * wn * 36 + (size_t)K.max_m * 36 + (size_t)6 * K.nP) * sizeof(double) + 4 * ((size_t)3 * K.nP + 1 + 2 * (size_t)K.ncr);
+            if (K.band && K.max_m <= SKY_BAND_W && lds_b <= 150 * 1024) {
+                (void)sv_allow_dynamic_lds((const void*)k_sky_band, lds_b);
+                hipLaunchKernelGGL(k_sky_band, dim3(1), dim3(SKY_BAND_THREADS), lds_b, s, D, K, SkyDev(), SkyTwist(), ++P->epoch, (const SegJobDev*)nullptr);
+            }
+            else {
+                const size_t lds_g = ((size_t)K.max_m * 36 + (size_t)6 * K.nP) * sizeof(double) + 4 * ((size_t)2 * K.nP + 1 + 2 * (size_t)K.ncr);
+                (void)sv_allow_dynamic_lds((const void*)k_sky_factor_solve, lds_g);
+                hipLaunchKernelGGL(k_sky_factor_solve, dim3(1), dim3(K.max_m <= 21 ? 256 : SKY_THREADS), lds_g, s, D, K);
+            }
+        }
+        double* const out = multi ? P->seg_dpx : D.dp;
+        if (P->seg_jobs_local > 0) {
+            (void)sv_allow_dynamic_lds((const void*)k_seg_backward, P->seg_lds_back);
+            hipLaunchKernelGGL(k_seg_backward, dim3(P->seg_jobs_local), dim3(64), P->seg_lds_back, s, D, P->seg_jobs, out);
+        }
+        if (multi) {
+            if (P->seg_rank == 0 && P->seg_nsep > 0)
+                hipLaunchKernelGGL(k_seg_copy_sep, dim3((unsigned)((6 * P->dev[0].nP + 255) / 256)), dim3(256), 0, s, D, P->dev[0], P->seg_dpx);
+            if (ctx->ba_ar_fn(ctx->ba_ar_user, P->seg_dpx, (size_t)P->seg_n, (void*)s) != 0) return sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed (solution exchange)");
+            (void)hipMemcpyAsync(D.dp, P->seg_dpx, sizeof(double) * (size_t)P->seg_n, hipMemcpyDeviceToDevice, s);
+        }
+        return SVGPU_OK;
+    }
     const SkyDev& K = P->dev[0];
     const int nplans = P->twist.on ? 2 : 1;
     // blocks of the envelope the reduced system does not fill must start at zero in every trial (and the right-hand side rows a plan is not given)
@@ -1071,11 +1782,109 @@ void sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
         }
         if (lds <= 150 * 1024) {
             (void)sv_allow_dynamic_lds((const void*)k_sky_band, lds);
-            hipLaunchKernelGGL(k_sky_band, dim3(nplans), dim3(SKY_BAND_THREADS), lds, s, D, P->dev[0], P->dev[1], P->twist, ++P->epoch);
-            return;
+            hipLaunchKernelGGL(k_sky_band, dim3(nplans), dim3(SKY_BAND_THREADS), lds, s, D, P->dev[0], P->dev[1], P->twist, ++P->epoch, (const SegJobDev*)nullptr);
+            return SVGPU_OK;
         }
     }
     const size_t lds = ((size_t)K.max_m * 36 + (size_t)D.n) * sizeof(double) + 4 * ((size_t)2 * K.nP + 1 + 2 * (size_t)K.ncr);
     (void)sv_allow_dynamic_lds((const void*)k_sky_factor_solve, lds);
     hipLaunchKernelGGL(k_sky_factor_solve, dim3(1), dim3(K.max_m <= 21 ? 256 : SKY_THREADS), lds, s, D, K);
+    return SVGPU_OK;
+}
+
+extern "C" int svgpu_ba_last_envelope_plan(svgpu_ctx* ctx, int* info) {
+    if (!ctx || !info) return SVGPU_ERR_INVALID;
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    const SkyPlan* P = (const SkyPlan*)ctx->ba_sky;
+    if (!P || !P->usable) return SVGPU_OK;
+    info[0] = P->seg ? 2 : (P->twist.on ? 1 : 0);
+    info[1] = P->plan_rows, info[2] = P->plan_width;
+    if (P->seg) info[3] = P->seg_cuts, info[4] = P->seg_jobs_total, info[5] = P->seg_jobs_local, info[6] = P->seg_nsep, info[7] = P->seg_longest;
+    return SVGPU_OK;
+}
+
+// The planner's self-test (host arithmetic, no device needed; the bundle adjusters never call it): plans the segmented elimination of the
+// block system exactly as sv_sky_plan does, then walks the SAME plan arrays, assembly maps and gather lists the kernels walk -- assemble,
+// eliminate every job's columns, gather what they leave onto the separator system, solve it, substitute backwards -- and returns x.
+// tests/test_sky_segments.py holds it against a dense solve: that pins the orders, the envelopes, the block maps and the transposition
+// flags on the CPU, so that what is left to the GPU tests is the kernels' own mechanics.
+extern "C" int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab_in, const double* Sblk, const double* g, int cuts, int world, double* x, int* info) {
+    if (nP <= 0 || NB <= 0 || !blk_ab_in || !Sblk || !g || !x || !info) return -1;
+    std::vector<int2> blk_ab(NB);
+    std::vector<std::vector<int>> adj(nP);
+    for (int k = 0; k < NB; ++k) {
+        blk_ab[k].x = blk_ab_in[2 * k], blk_ab[k].y = blk_ab_in[2 * k + 1];
+        if (blk_ab[k].x < 0 || blk_ab[k].y >= nP || blk_ab[k].x > blk_ab[k].y) return -1;
+        if (blk_ab[k].x != blk_ab[k].y) {
+            adj[blk_ab[k].x].push_back(blk_ab[k].y);
+            adj[blk_ab[k].y].push_back(blk_ab[k].x);
+        }
+    }
+    const std::vector<int> order = rcm_order(nP, adj);
+    HostSky H0;
+    host_sky(nP, order, adj, blk_ab, nP, false, (size_t)256 << 20, H0);
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    if (!H0.ok) return 1;
+    info[7] = H0.max_m;
+    HostSeg G;
+    SegLayout LY;
+    if (!choose_segments(nP, order, adj, blk_ab, cuts, std::max(world, 1), (size_t)256 << 20, G, LY)) return 1;
+    const int nj = (int)G.job.size(), nsep = (int)G.sep_order.size();
+    info[0] = 1, info[1] = G.ncuts, info[2] = nj, info[3] = nsep, info[4] = G.max_nC, info[5] = G.sep.band ? 1 : 0;
+    for (int q = 0; q < nj; ++q) info[6] = std::max(info[6], G.job[q].max_m);
+    std::vector<double> A(LY.total, 0.0);
+    for (int k = 0; k < NB; ++k) {  // k_seg_assemble
+        const int2 m = LY.blkmap[k];
+        for (int e = 0; e < 36; ++e) A[(size_t)m.x * 36 + (m.y ? (e % 6) * 6 + e / 6 : e)] = Sblk[(size_t)k * 36 + e];
+    }
+    for (int a = 0; a < nP; ++a)
+        for (int c = 0; c < 6; ++c) A[(size_t)LY.yoff[a] + c] = g[a * 6 + c];
+    for (int q = 0; q < nj; ++q) {  // the jobs (k_sky_band in job mode): eliminate nC columns, export the trailing ns x ns blocks and y
+        const HostSky& h = G.job[q];
+        if (!host_env_eliminate(h, A.data() + LY.job_val[q], A.data() + LY.job_dinv[q], A.data() + LY.job_y[q], G.nC[q])) return 2;
+        const int nC = G.nC[q], ns = G.ns[q];
+        double* X = A.data() + LY.xch + G.xch_off[q];
+        for (int r = 0; r < ns; ++r)
+            for (int c = 0; c <= r; ++c) {
+                const double* B = A.data() + LY.job_val[q] + (size_t)(h.rowoff[nC + r] + (nC + c) - h.first[nC + r]) * 36;
+                for (int e = 0; e < 36; ++e) X[((size_t)r * (r + 1) / 2 + c) * 36 + e] = B[e];
+            }
+        if (ns > 0) {  // the diagonal blocks of the window are full symmetric blocks on the device; the host update above fills them the same way
+            for (int r = 0; r < ns; ++r)
+                for (int c = 0; c < 6; ++c) X[(size_t)ns * (ns + 1) / 2 * 36 + 6 * r + c] = A[LY.job_y[q] + (size_t)(nC + r) * 6 + c];
+        }
+    }
+    std::vector<double> sol((size_t)nP * 6, 0.0);
+    if (nsep > 0) {  // k_seg_gather, then the separator solve
+        for (size_t b = 0; b < G.sep.nblocks; ++b)
+            for (int e = 0; e < 36; ++e) {
+                double v = A[LY.sep_val + b * 36 + e];
+                for (int qq = G.gb_off[b]; qq < G.gb_off[b + 1]; ++qq) {
+                    const int src = G.gb_src[qq];
+                    v += A[LY.xch + (size_t)(src & 0x3fffffff) * 36 + (((src >> 30) & 1) ? (e % 6) * 6 + e / 6 : e)];
+                }
+                A[LY.sep_val + b * 36 + e] = v;
+            }
+        for (int p = 0; p < nsep; ++p)
+            for (int c = 0; c < 6; ++c) {
+                double v = A[LY.sep_y + (size_t)p * 6 + c];
+                for (int qq = G.gy_off[p]; qq < G.gy_off[p + 1]; ++qq) v += A[LY.xch + (size_t)G.gy_src[qq] + c];
+                A[LY.sep_y + (size_t)p * 6 + c] = v;
+            }
+        if (!host_env_eliminate(G.sep, A.data() + LY.sep_val, A.data() + LY.sep_dinv, A.data() + LY.sep_y, nsep)) return 2;
+        host_env_backward(G.sep, A.data() + LY.sep_val, A.data() + LY.sep_dinv, A.data() + LY.sep_y, nsep - 1);
+        for (int p = 0; p < nsep; ++p)
+            for (int c = 0; c < 6; ++c) sol[(size_t)G.sep_order[p] * 6 + c] = A[LY.sep_y + (size_t)p * 6 + c];
+    }
+    for (int q = 0; q < nj; ++q) {  // k_seg_backward
+        const HostSky& h = G.job[q];
+        double* y = A.data() + LY.job_y[q];
+        for (int r = 0; r < G.ns[q]; ++r)
+            for (int c = 0; c < 6; ++c) y[(size_t)(G.nC[q] + r) * 6 + c] = sol[(size_t)G.order[q][G.nC[q] + r] * 6 + c];
+        host_env_backward(h, A.data() + LY.job_val[q], A.data() + LY.job_dinv[q], y, G.nC[q] - 1);
+        for (int k = 0; k < G.nC[q]; ++k)
+            for (int c = 0; c < 6; ++c) sol[(size_t)G.order[q][k] * 6 + c] = y[(size_t)k * 6 + c];
+    }
+    for (size_t t = 0; t < sol.size(); ++t) x[t] = sol[t];
+    return 0;
 }

@@ -304,9 +304,6 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
 // Fixed-point separable 7x7, taps {18,34,48,56,48,34,18}/256, out = (sum + 32768) >> 16, reflect-101.
 // Streaming form, no LDS: a thread owns 4 adjacent columns and walks BLUR_ROWS rows downwards, keeping the last
 // seven rows of horizontal sums in registers.  A wave reads/writes 256 contiguous bytes per row.
-#define BLUR_ROWS 32
-#define BLUR_TW 256                 // tile width  = 64 threads x 4 px
-#define BLUR_TH (4 * BLUR_ROWS)     // tile height = 4 strips
 #define BLUR_EDGE_ROWS 8            // rows per thread in the (slow, gather-based) edge tiles
 struct BlurRow {  // the 12 source bytes of pixels [x0-4, x0+8) of one row, image borders already reflected
     uint32_t w0, w1, w2;

@@ -198,6 +198,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     }
     const bool sharded = allreduce != nullptr;
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
+    ctx->ba_ar_fn = allreduce;  // (the segmented envelope solve of ba_skyline.hip exchanges through the same all-reduce)
+    ctx->ba_ar_user = ar_user;
     if (!sharded) {
         world = 1;
         rank = 0;
@@ -724,7 +726,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if ((solver == SV_BA_SOLVER_AUTO && !lds_ok) || solver == SV_BA_SOLVER_ENVELOPE) {
             if (!reuse) {
                 bool ok = false;
-                const int rs = sv_sky_plan(ctx, s, HS.nP, HS.blk_ab, (size_t)256 << 20, &ok);
+                const int rs = sv_sky_plan(ctx, s, HS.nP, HS.blk_ab, (size_t)256 << 20, &ok, rank, world);
                 if (rs) return rs;
                 HS.envelope_ok = ok;
             }
@@ -769,7 +771,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             if (solver == SV_BA_SOLVER_CHOLESKY) sv_ba_solve(ctx, s, D);
             else if (solver == SV_BA_SOLVER_PCG_LDS) sv_ba_solve_pcg_lds(ctx, s, D);
             else if (solver == SV_BA_SOLVER_DENSE) sv_ba_solve_dense(ctx, s, D);
-            else if (solver == SV_BA_SOLVER_ENVELOPE) sv_sky_solve(ctx, s, D);
+            else if (solver == SV_BA_SOLVER_ENVELOPE) {
+                if ((r = sv_sky_solve(ctx, s, D))) return r;
+            }
             else {
                 // PCG: iterations are enqueued in chunks; the control block says when the solve (or the whole optimisation) is over
                 sv_pcg_init(ctx, s, D);

@@ -16,6 +16,12 @@
 #define SV_CELL 64          // orb_extractor.cc:173 cell_size
 #define SV_OVERLAP 6        // orb_extractor.cc:172 overlap
 #define SV_ROI_MAX 70       // SV_CELL + SV_OVERLAP
+// k_blur tiling (shared by the kernel and the host-side tile count): a thread walks BLUR_ROWS rows of 4 columns
+#ifndef BLUR_ROWS
+#define BLUR_ROWS 64
+#endif
+#define BLUR_TW 256                 // tile width  = 64 threads x 4 px
+#define BLUR_TH (4 * BLUR_ROWS)     // tile height = 4 strips
 
 // ---- per-level geometry, read by every ORB kernel (lives in device memory, one array per context)
 struct OrbLevel {
@@ -120,6 +126,8 @@ struct svgpu_ctx {
     int pcg_max_it = 0;             // 0 = max(2000, 4 n)
     void* comm = nullptr;           // ncclComm_t of svgpu_comm_init (RCCL, loaded with dlopen)
     void* ba_sky = nullptr;         // plan + buffers of the envelope Cholesky (ba_skyline.hip)
+    svgpu_allreduce_fn ba_ar_fn = nullptr;  // the all-reduce of the sharded solve in progress (the segmented envelope solve exchanges through it); else null
+    void* ba_ar_user = nullptr;
     int comm_rank = 0, comm_world = 1;
 };
 void sv_comm_release(svgpu_ctx* ctx);

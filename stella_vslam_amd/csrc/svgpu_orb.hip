@@ -202,8 +202,8 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
         }
         // ---- blur tiles
         L.btile_first = btile_first;
-        L.btiles_x = (L.w + 255) / 256;   // BLUR_TW
-        L.btiles_y = (L.h + 127) / 128;   // BLUR_TH
+        L.btiles_x = (L.w + BLUR_TW - 1) / BLUR_TW;
+        L.btiles_y = (L.h + BLUR_TH - 1) / BLUR_TH;
         btile_first += L.btiles_x * L.btiles_y + ((L.h + 7) / 8 + 63) / 64;  // + edge tiles (64 strips of BLUR_EDGE_ROWS rows each)
         // ---- FAST cell lattice and selection grid
         L.cell_first = (int)C.cells.size();

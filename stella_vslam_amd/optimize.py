@@ -53,6 +53,13 @@ class local_bundle_adjuster:
                        "svgpu_ba_set_solver")
         return self
 
+    def last_envelope_plan(self) -> dict:
+        """How the context's last envelope factorisation was planned (svgpu_ba_last_envelope_plan)."""
+        info = np.zeros(8, np.int32)
+        self.ctx.check(lib().svgpu_ba_last_envelope_plan(self.ctx.handle, C.c_void_p(info.ctypes.data)), "svgpu_ba_last_envelope_plan")
+        return dict(kind=("one-sided", "two-sided", "segmented")[int(info[0])], rows=int(info[1]), widest_column=int(info[2]), cuts=int(info[3]),
+                    jobs=int(info[4]), jobs_local=int(info[5]), separator_rows=int(info[6]), longest_job=int(info[7]))
+
     def optimize_global_flat(self, scene: dict, num_iter: int = 10, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
         """global_bundle_adjuster core: one LM run of `num_iter` iterations over the whole graph (no outlier stage)."""
         saved = self.num_first_iter_

@@ -397,22 +397,134 @@ def test_global_ba_config5_matches_oracle():
 
 
 def test_global_ba_two_sided_elimination_equals_one_sided(monkeypatch):
-    """A long band is eliminated from both ends by two workgroups (ba_skyline.hip: T | S | B, the Schur complements added on the separator);
-    SVGPU_SKY_ONE_SIDED=1 keeps the single top-down sweep.  Same blocks, same arithmetic per block, another order of the sums on S: the two
-    must agree far below the parity tolerance, with the same LM schedule -- on a ring (the loop closure puts a few wide rows into the band)
-    and on an open chain."""
+    """A long band can be eliminated from both ends by two workgroups (ba_skyline.hip: T | S | B, the Schur complements added on the
+    separator) -- the fallback where the segmented plan does not apply, forced here with SVGPU_SKY_SEGMENTS=0; SVGPU_SKY_ONE_SIDED=1 keeps the
+    single top-down sweep.  Same blocks, same arithmetic per block, another order of the sums on S: the two must agree far below the parity
+    tolerance, with the same LM schedule -- on a ring (the loop closure puts a few wide rows into the band) and on an open chain."""
     from stella_vslam_amd import optimize
     for kw in (dict(num_kf=160, num_lm=40000), dict(num_kf=240, num_lm=30000, obs_per_lm=4), dict(num_kf=200, num_lm=20000, obs_per_lm=2)):  # band widths 11, 7 and a narrow one
         sc = S.ba_scene_large(**kw)
         monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
-        two = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+        monkeypatch.setenv("SVGPU_SKY_SEGMENTS", "0")
+        adj = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE)
+        two = adj.optimize_global_flat(sc, num_iter=10)
+        assert adj.last_envelope_plan()["kind"] == "two-sided"
+        monkeypatch.delenv("SVGPU_SKY_SEGMENTS", raising=False)
         monkeypatch.setenv("SVGPU_SKY_ONE_SIDED", "1")
-        one = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+        adj = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE)
+        one = adj.optimize_global_flat(sc, num_iter=10)
+        assert adj.last_envelope_plan()["kind"] == "one-sided"
         monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
         assert two["stats"]["iters_stage1"] == one["stats"]["iters_stage1"] and two["stats"]["cholesky_failures"] == 0 == one["stats"]["pcg_iterations"]
         assert two["stats"]["chi2_final"] == pytest.approx(one["stats"]["chi2_final"], rel=1e-9)
         assert np.abs(two["pose_cw"] - one["pose_cw"]).max() < 1e-8 and np.abs(two["points"] - one["points"]).max() < 1e-8
         assert two["stats"]["chi2_final"] < 0.6 * two["stats"]["chi2_initial"]
+
+
+@pytest.mark.parametrize("cuts", [None, 2, 3, 5])
+def test_global_ba_segmented_elimination_equals_one_sided(monkeypatch, cuts):
+    """The default for a long band: vertex separators cut the RCM-ordered keyframe graph, every connected piece is eliminated by its own
+    workgroup towards its separators (k_sky_band in job mode), the separator system collects what they leave and is solved on its own plan,
+    the pieces substitute backwards (ba_skyline.hip; the planner is pinned on the CPU by tests/test_sky_segments.py).  Another elimination
+    ORDER of the same system: estimates within rounding of the one-sided sweep, the same LM schedule -- on rings of three band widths,
+    with the planner's own cut count and forced ones (open chains and disconnected graphs: tests/test_sky_segments.py)."""
+    from stella_vslam_amd import optimize
+    for kw in (dict(num_kf=160, num_lm=40000), dict(num_kf=240, num_lm=30000, obs_per_lm=4), dict(num_kf=200, num_lm=20000, obs_per_lm=2)):
+        sc = S.ba_scene_large(**kw)
+        monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+        if cuts is None:
+            monkeypatch.delenv("SVGPU_SKY_SEGMENTS", raising=False)
+        else:
+            monkeypatch.setenv("SVGPU_SKY_SEGMENTS", str(cuts))
+        adj = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE)
+        seg = adj.optimize_global_flat(sc, num_iter=10)
+        plan = adj.last_envelope_plan()
+        monkeypatch.delenv("SVGPU_SKY_SEGMENTS", raising=False)
+        monkeypatch.setenv("SVGPU_SKY_ONE_SIDED", "1")
+        one = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+        monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+        if cuts is not None and kw["num_kf"] * 1.0 >= 8 * (plan["widest_column"] + 1):
+            assert plan["kind"] == "segmented" and plan["jobs"] >= 2 and plan["jobs_local"] == plan["jobs"], plan
+        assert seg["stats"]["iters_stage1"] == one["stats"]["iters_stage1"] and seg["stats"]["cholesky_failures"] == 0 == seg["stats"]["pcg_iterations"]
+        assert seg["stats"]["chi2_final"] == pytest.approx(one["stats"]["chi2_final"], rel=1e-9)
+        assert np.abs(seg["pose_cw"] - one["pose_cw"]).max() < 1e-8 and np.abs(seg["points"] - one["points"]).max() < 1e-8, plan
+
+
+def _simulated_ranks(world, run_rank):
+    """`world` ranks as threads on the one test GPU; the all-reduce callback sums the ranks' device buffers through a barrier."""
+    import threading
+    import torch
+    from stella_vslam_amd import distributed as D
+    barrier = threading.Barrier(world)
+    slots, total = [None] * world, [None]
+
+    def make_cb(rank):
+        def _cb(user, buf, count, stream):
+            try:
+                t = torch.as_tensor(D._CudaBuf(buf, count), device="cuda")
+                torch.cuda.synchronize()
+                slots[rank] = t
+                barrier.wait()
+                if rank == 0:
+                    acc = slots[0].clone()
+                    for r in range(1, world):
+                        acc += slots[r]
+                    total[0] = acc
+                    torch.cuda.synchronize()
+                barrier.wait()
+                t.copy_(total[0])
+                torch.cuda.synchronize()
+                barrier.wait()
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("cb failed", e)
+                barrier.abort()
+                return 1
+        return D.ALLREDUCE_FN(_cb)
+
+    results = [None] * world
+
+    def run(rank):
+        results[rank] = run_rank(rank, make_cb(rank))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_global_ba_distributed_factorisation_matches_single(world, monkeypatch):
+    """svgpu_global_ba_sharded on a system large enough for the segmented plan: every rank eliminates only the jobs it owns, the separator
+    contributions and the solution cross ranks through the all-reduce (sums with zeros: an all-gather), the separator system is solved by
+    every rank.  `world` ranks simulated on one GPU: every rank owns a strict subset of the jobs, all ranks end bit-identical, and the
+    estimate equals the single-GPU solve (whose factorisation is the same segmented one, all jobs on one rank) to 1e-7."""
+    from stella_vslam_amd import distributed as D, feature, optimize
+    monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+    monkeypatch.setenv("SVGPU_SKY_SEGMENTS", "5")
+    sc = S.ba_scene_large(num_kf=200, num_lm=24000, obs_per_lm=4)
+    adj1 = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE)
+    single = adj1.optimize_global_flat(sc, num_iter=10)
+    assert adj1.last_envelope_plan()["kind"] == "segmented"
+    plans = [None] * world
+
+    def run_rank(rank, cb):
+        adj = optimize.local_bundle_adjuster(ctx=feature.Context()).set_solver(optimize.SOLVER_ENVELOPE)
+        res = adj.optimize_global_flat_sharded(D.shard_by_landmark(sc, rank, world), rank, world, cb, num_iter=10)
+        plans[rank] = adj.last_envelope_plan()
+        return res
+
+    results = _simulated_ranks(world, run_rank)
+    assert all(r is not None and r["rc"] == 0 for r in results)
+    assert all(p["kind"] == "segmented" and 0 < p["jobs_local"] < p["jobs"] for p in plans), plans
+    assert sum(p["jobs_local"] for p in plans) == plans[0]["jobs"]
+    for r in results[1:]:
+        assert np.array_equal(results[0]["pose_cw"], r["pose_cw"]) and np.array_equal(results[0]["points"], r["points"])
+    assert results[0]["stats"]["iters_stage1"] == single["stats"]["iters_stage1"]
+    _assert_poses(results[0]["pose_cw"], single["pose_cw"], 1e-7)
+    assert _rel(results[0]["points"], single["points"]) < 1e-7
 
 
 def test_sharded_through_rccl_communicator_world1():
