@@ -284,6 +284,38 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
                                     int* num_matches, uint8_t* visible, double* reproj, float* x_right,
                                     int32_t* pred_scale_level);
 
+/* ------------------------------------------------------------------------------ device-resident frame observations
+ * data::frame_observation (data/frame_observation.h:12-38) of a frame or keyframe kept ON THE DEVICE: descriptors, undistorted keypoints,
+ * stereo x_right, bearings and the keypoint grid of data::assign_keypoints_to_grid.  A tracked frame (tracking_module.cc:533-608) goes
+ * extract -> match_current_and_last_frames -> pose optimizer -> match_frame_and_landmarks -> pose optimizer; with a resident frame its
+ * descriptors cross PCIe once (down, for the host-side data::frame) and are never uploaded again.
+ *   svgpu_frame_adopt_extraction  what system.cc:384-395 does after extract(): undistort_keypoints, convert_keypoints_to_bearings,
+ *                                 assign_keypoints_to_grid -- on the keypoints / descriptors the context's LAST svgpu_orb_extract left on
+ *                                 the device; undist_kps / bearings (nullable) return the host copies data::frame_observation holds
+ *   svgpu_frame_upload            the same for an observation that exists on the host (keyframes of the map): undistorted keypoint
+ *                                 records, descriptors, stereo x_right (nullable)
+ *   svgpu_frame_set_stereo        stereo_x_right_ once match::stereo has produced it (NULL: monocular again)
+ *   svgpu_frame_bind              ONE-SHOT: the next call of svgpu_match_in_cells / svgpu_match_frame_and_landmarks /
+ *                                 svgpu_match_current_and_last_frames / svgpu_match_frame_and_keyframe_projection /
+ *                                 svgpu_match_by_sim3_transform / svgpu_fuse_detect_duplication on `ctx` takes its keypoint side (tdesc, t_xy,
+ *                                 t_octave, t_angle, t_xright, nt, image bounds, grid) from the frame: those arguments are then ignored (pass
+ *                                 NULL / 0); `occupied` stays a host array of svgpu_frame_size bytes.  A frame may be bound on any context of
+ *                                 its device.
+ *   svgpu_match_set_query_blocks  ONE-SHOT for the next svgpu_match_in_cells: q_blocks[q] = 0 -> an accepted query q does NOT occupy its
+ *                                 keypoint for later queries (the landmark it carries has no observation: `lm && lm->has_observation()`,
+ *                                 projection.cc:52-55); NULL = every accepted query does */
+typedef struct svgpu_frame svgpu_frame;
+int svgpu_frame_create(svgpu_ctx* ctx, svgpu_frame** out);
+void svgpu_frame_destroy(svgpu_frame* frame);
+int svgpu_frame_size(const svgpu_frame* frame);
+int svgpu_frame_adopt_extraction(svgpu_ctx* ctx, svgpu_frame* frame, const svgpu_camera* cam, int grid_cols, int grid_rows,
+                                 svgpu_keypoint* undist_kps, double* bearings);
+int svgpu_frame_upload(svgpu_ctx* ctx, svgpu_frame* frame, const svgpu_camera* cam, const svgpu_keypoint* undist_kps, const uint8_t* desc,
+                       const float* x_right, int n, int grid_cols, int grid_rows);
+int svgpu_frame_set_stereo(svgpu_ctx* ctx, svgpu_frame* frame, const float* x_right);
+int svgpu_frame_bind(svgpu_ctx* ctx, const svgpu_frame* frame);
+int svgpu_match_set_query_blocks(svgpu_ctx* ctx, const uint8_t* q_blocks);
+
 /* ------------------------------------------------------------------------------ function-specific matchers
  * One entry point per reference method: candidate generation (reprojection + grid cells, or BoW buckets), the method's own pair
  * gates and the exact sequential bookkeeping all run on the device; the adaptor classes of stella_vslam_amd/host/ flatten the

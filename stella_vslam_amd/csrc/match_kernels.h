@@ -103,6 +103,8 @@ struct GridProblem {
     int32_t* cand_idx;        // filled by the second walk
 };
 void sv_launch_grid_build(hipStream_t s, const GridProblem& G);                 // cell_of, cell_off, cell_items, cand_off (scanned)
+void sv_launch_grid_frame(hipStream_t s, const GridProblem& G);                 // ... the keypoint side alone (a resident frame is binned once)
+void sv_launch_grid_queries(hipStream_t s, const GridProblem& G);               // ... the query side over an already binned frame
 void sv_launch_grid_fill(hipStream_t s, const GridProblem& G);                  // cand_idx
 
 struct StereoProblem {

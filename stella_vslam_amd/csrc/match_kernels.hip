@@ -1374,14 +1374,20 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     (void)sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_bf_replay), 144 * 1024);
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
 }
-void sv_launch_grid_build(hipStream_t s, const GridProblem& G) {
+void sv_launch_grid_frame(hipStream_t s, const GridProblem& G) {  // the keypoint side: cell_of, cell_off, cell_items
     const int nc = G.cols * G.rows;
     (void)hipMemsetAsync(G.cell_off, 0, (size_t)(nc + 1) * sizeof(int32_t), s);
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_assign, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cell_off, nc);
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_place, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
+}
+void sv_launch_grid_queries(hipStream_t s, const GridProblem& G) {  // the query side over a binned frame: list sizes + their scan
     if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<false>, dim3((G.nq + 3) / 4), dim3(256), 0, s, G);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cand_off, G.nq);
+}
+void sv_launch_grid_build(hipStream_t s, const GridProblem& G) {
+    sv_launch_grid_frame(s, G);
+    sv_launch_grid_queries(s, G);
 }
 void sv_launch_grid_fill(hipStream_t s, const GridProblem& G) {
     if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<true>, dim3((G.nq + 3) / 4), dim3(256), 0, s, G);

@@ -77,6 +77,28 @@ struct SvProf {
     unsigned long long* d_counter = nullptr;  // device word a profiled k_bf_mfma adds its multiplied 64 x 32 patches to
 };
 
+// A frame observation resident on the device (include/svgpu.h svgpu_frame_*): what every projection-family matcher reads of a
+// data::frame / data::keyframe -- descriptors, undistorted keypoints split into the arrays the kernels take, stereo x_right, and the
+// keypoint grid of data::assign_keypoints_to_grid as CSR.  Plain device allocations (grow-only), usable from any context of the device.
+struct svgpu_frame {
+    int device = 0;
+    int n = 0, cap = 0;
+    int grid_cols = 0, grid_rows = 0, cells_cap = 0;
+    float min_x = 0, max_x = 0, min_y = 0, max_y = 0;  // image bounds the grid was binned over
+    bool has_xright = false;
+    uint8_t* desc = nullptr;            // n x 32
+    svgpu_keypoint* undist = nullptr;   // n undistorted keypoint records
+    float* xy = nullptr;                // n x 2
+    int32_t* octave = nullptr;
+    float* angle = nullptr;
+    float* xright = nullptr;            // stereo_x_right_ (valid when has_xright)
+    double* bearings = nullptr;         // n x 3
+    int32_t* cell_of = nullptr;         // n
+    int32_t* cell_off = nullptr;        // grid_cols * grid_rows + 1
+    int32_t* cell_items = nullptr;      // n
+    int32_t* dummy = nullptr;           // 1 int (the query-side scan of a grid build without queries)
+};
+
 struct svgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -109,6 +131,9 @@ struct svgpu_ctx {
     uint8_t* d_desc = nullptr;
     int32_t* d_counts = nullptr;
     int last_batch = 0;
+    int last_extract_n = -1;             // keypoints of the last svgpu_orb_extract, still in d_kps / d_desc (svgpu_frame_adopt_extraction)
+    const svgpu_frame* bound_frame = nullptr;  // svgpu_frame_bind: keypoint side of the NEXT matcher call (one-shot)
+    const uint8_t* next_q_blocks = nullptr;    // svgpu_match_set_query_blocks: per-query "an accepted match occupies its target" of the NEXT svgpu_match_in_cells
     const uint8_t* last_imgs = nullptr;  // level-0 of the last call (device)
     size_t last_frame_stride = 0;
     int last_row_stride = 0;

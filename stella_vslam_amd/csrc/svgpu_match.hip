@@ -264,6 +264,14 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
                          const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_angle, const float* t_xright,
                          float min_x, float max_x, float min_y, float max_y, int grid_cols, int grid_rows,
                          int check_orientation, unsigned thr, float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
+    const svgpu_frame* rf = sv_take_bound_frame(ctx);
+    if (rf) {  // resident keypoint side: the frame's own device arrays, bounds and grid (svgpu_frame_bind)
+        tdesc = rf->desc, t_xy = rf->xy, t_octave = rf->octave, nt = rf->n;
+        t_angle = check_orientation ? rf->angle : nullptr;
+        t_xright = (q_xright && rf->has_xright) ? rf->xright : nullptr;
+        if (!t_xright) q_xright = nullptr, q_xr_tol = nullptr;  // (a monocular frame has no stereo gate: projection.cc:57)
+        min_x = rf->min_x, max_x = rf->max_x, min_y = rf->min_y, max_y = rf->max_y, grid_cols = rf->grid_cols, grid_rows = rf->grid_rows;
+    }
     if (!ctx || nq < 0 || nt < 0 || nt >= (1 << 22) || !num_matches || mode < SVGPU_MATCH_BEST_ONLY || mode > SVGPU_MATCH_AREA || grid_cols < 1 || grid_rows < 1
         || (size_t)grid_cols * grid_rows > (size_t(1) << 22) || !(min_x < max_x) || !(min_y < max_y))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: bad arguments");
@@ -276,7 +284,10 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
         || ((q_xright || t_xright || q_xr_tol) && !(q_xright && t_xright && q_xr_tol)))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: inconsistent inputs");
     InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, min_x, max_x, min_y, max_y, grid_cols, grid_rows};
-    const size_t qbytes = pad((size_t)nq * 32) + pad((size_t)nq * 8) + 6 * pad((size_t)nq * 4) + pad(nq);
+    F.res = rf;
+    const uint8_t* const q_blocks = ctx->next_q_blocks;  // svgpu_match_set_query_blocks (one-shot)
+    ctx->next_q_blocks = nullptr;
+    const size_t qbytes = pad((size_t)nq * 32) + pad((size_t)nq * 8) + 6 * pad((size_t)nq * 4) + 2 * pad(nq);
     hipStream_t s = ctx->stream;
     return in_cells_core(
         ctx, nq, F, qbytes, check_orientation, thr, lowe_ratio, mode,
@@ -296,6 +307,7 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
             UP(d_qa, float, q_angle, nq)
             UP(d_qx, float, q_xright, nq)
             UP(d_qtol, float, q_xr_tol, nq)
+            UP(d_qb, uint8_t, q_blocks, nq)
 #undef UP
             G.q_xy = d_qxy;
             G.q_margin = d_qm;
@@ -307,6 +319,7 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
             P.q_angle = d_qa;
             P.q_xright = d_qx;
             P.q_xr_tol = d_qtol;
+            P.q_blocks = d_qb;
             return SVGPU_OK;
         },
         [&](const CandProblem&) -> int { return SVGPU_OK; }, match_q, num_matches);
@@ -514,6 +527,11 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
                                     int* num_matches, uint8_t* visible, double* reproj, float* x_right,
                                     int32_t* pred_scale_level) {
     ReprojProblem R{};
+    const svgpu_frame* rf = sv_take_bound_frame(ctx);
+    if (rf) {  // resident keypoint side (svgpu_frame_bind)
+        tdesc = rf->desc, t_xy = rf->xy, t_octave = rf->octave, nt = rf->n, grid_cols = rf->grid_cols, grid_rows = rf->grid_rows;
+        t_xright = rf->has_xright ? rf->xright : nullptr;
+    }
     int rc = fill_reproj(ctx, "svgpu_match_frame_and_landmarks: bad arguments", R, cam, rot_cw, trans_cw, trans_wc, n, pos_w, mean_normal,
                          min_valid_dist, max_valid_dist, ray_cos_thr, num_levels, log_scale_factor);
     if (rc) return rc;
@@ -531,6 +549,7 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
     R.margin = margin;
     for (int l = 0; l < num_levels; ++l) R.scale_factors[l] = scale_factors[l];
     InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, nullptr, t_xright, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    if (rf) F.min_x = rf->min_x, F.max_x = rf->max_x, F.min_y = rf->min_y, F.max_y = rf->max_y, F.res = rf;
     const size_t qbytes = pad((size_t)n * 32) + 2 * pad((size_t)n * 24) + 8 * pad((size_t)n * 4) + 2 * pad(n) + pad((size_t)n * 16) + pad((size_t)n * 8);
     hipStream_t s = ctx->stream;
     return in_cells_core(

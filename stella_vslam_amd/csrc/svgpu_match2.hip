@@ -10,6 +10,16 @@ using namespace svm;
 
 namespace {
 
+// keypoint side of a projection-family call: the caller's host arrays, or the resident frame bound with svgpu_frame_bind
+InCellsFrame frame_side(const svgpu_frame* rf, const svgpu_camera* cam, const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, int nt,
+                        const uint8_t* occupied, const float* t_angle, const float* t_xright, bool want_angle, bool want_xright, int grid_cols, int grid_rows) {
+    if (!rf) return InCellsFrame{tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    InCellsFrame F{rf->desc, rf->xy, rf->octave, rf->n, occupied, want_angle ? rf->angle : nullptr, want_xright && rf->has_xright ? rf->xright : nullptr,
+                   rf->min_x, rf->max_x, rf->min_y, rf->max_y, rf->grid_cols, rf->grid_rows};
+    F.res = rf;
+    return F;
+}
+
 struct ProjQueries {  // host pointers: the landmarks that get reprojected (= the queries of the cell matcher)
     int n;
     const double* pos_w;           // n x 3
@@ -362,7 +372,7 @@ int svgpu_match_current_and_last_frames(svgpu_ctx* ctx, const svgpu_camera* cam,
     const bool bwd = is_monocular ? false : -trans_lc[2] > (double)true_baseline;
     ProjQueries Q{n_last, pos_w, nullptr, nullptr, nullptr, valid, octave_last, lm_desc, angle_last, lm_has_observation};
     ProjOpts O{2, 2, 0, fwd ? 1 : (bwd ? 2 : 0), margin, check_orientation, 100u, 0.f, SVGPU_MATCH_BEST_ONLY, 1, 0, 0, nullptr};
-    InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, true, true, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_match_current_and_last_frames: bad arguments", cam, rot_cw, trans_cw, trans_wc, Q, num_levels, scale_factors, 1.f, F, O,
                       match_last, num_matches, nullptr, nullptr, nullptr, nullptr);
 }
@@ -378,7 +388,7 @@ int svgpu_match_frame_and_keyframe_projection(svgpu_ctx* ctx, const svgpu_camera
     cam_center(rot_cw, trans_cw, center);  // projection.cc:223
     ProjQueries Q{n_kf, pos_w, nullptr, min_valid_dist, max_valid_dist, valid, nullptr, lm_desc, angle_kf, nullptr};
     ProjOpts O{1, 2, 0, 0, margin, check_orientation, hamm_dist_thr, 0.f, SVGPU_MATCH_BEST_ONLY, 0, 0, 0, nullptr};
-    InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, t_angle, nullptr, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, occupied, t_angle, nullptr, true, false, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_match_frame_and_keyframe_projection: bad arguments", cam, rot_cw, trans_cw, center, Q, num_levels, scale_factors,
                       log_scale_factor, F, O, match_kf, num_matches, nullptr, nullptr, nullptr, nullptr);
 }
@@ -399,7 +409,7 @@ int svgpu_match_by_sim3_transform(svgpu_ctx* ctx, const svgpu_camera* cam, const
     cam_center(rot, trans, center);
     ProjQueries Q{n, pos_w, mean_normal, min_valid_dist, max_valid_dist, valid, nullptr, lm_desc, nullptr, nullptr};
     ProjOpts O{1, 1, 0, 0, margin, 0, 50u, 0.f, SVGPU_MATCH_BEST_ONLY, 0, 0, 0, nullptr};
-    InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, nullptr, nullptr, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, occupied, nullptr, nullptr, false, false, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_match_by_sim3_transform: bad arguments", cam, rot, trans, center, Q, num_levels, scale_factors, log_scale_factor, F, O,
                       match_lm, num_matches, nullptr, nullptr, nullptr, nullptr);
 }
@@ -476,7 +486,7 @@ int svgpu_fuse_detect_duplication(svgpu_ctx* ctx, const svgpu_camera* cam, const
     cam_center(rot_cw, trans_cw, center);  // fuse.cc:20
     ProjQueries Q{n, pos_w, mean_normal, min_valid_dist, max_valid_dist, valid, nullptr, lm_desc, nullptr, nullptr};
     ProjOpts O{1, 1, 0, 0, margin, 0, 50u, 0.f, SVGPU_MATCH_BEST_ONLY, 0, do_reprojection_matching ? 1 : 0, 0, inv_level_sigma_sq};
-    InCellsFrame F{tdesc, t_xy, t_octave, nt, nullptr, nullptr, t_xright, cam->min_x, cam->max_x, cam->min_y, cam->max_y, grid_cols, grid_rows};
+    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, nullptr, nullptr, t_xright, false, true, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_fuse_detect_duplication: bad arguments", cam, rot_cw, trans_cw, center, Q, num_levels, scale_factors, log_scale_factor, F,
                       O, best_idx, num_fused, nullptr, nullptr, nullptr, nullptr);
 }

@@ -54,7 +54,16 @@ struct InCellsFrame {
     const float* t_xright;
     float min_x, max_x, min_y, max_y;
     int grid_cols, grid_rows;
+    const svgpu_frame* res = nullptr;  // resident frame (svgpu_frame_bind): tdesc / t_xy / t_octave / t_angle / t_xright are then ITS device arrays,
+                                       // nothing of the keypoint side is uploaded and its grid is not rebuilt; `occupied` stays a host array
 };
+// svgpu_frame_bind: the keypoint-side arguments of the entry point that calls this are replaced by the bound frame's (one-shot)
+inline const svgpu_frame* sv_take_bound_frame(svgpu_ctx* ctx) {
+    if (!ctx) return nullptr;
+    const svgpu_frame* f = ctx->bound_frame;
+    ctx->bound_frame = nullptr;
+    return f;
+}
 
 // Candidate lists built on the device + candidate matcher.  `stage(A, fresh, P, G)` places the query-side arrays in the
 // arena (uploading or generating them when `fresh`) and points P / G at them; `finish(P)` enqueues extra read-backs.
@@ -86,13 +95,21 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         dst = A.take<T>(n);                                                                         \
         if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
     }
-        UP(d_t, uint8_t, F.tdesc, (size_t)nt * 32)
-        UP(d_txy, float, F.t_xy, (size_t)nt * 2)
-        UP(d_toct, int32_t, F.t_octave, nt)
+#define UPR(dst, T, src, n)                       \
+    T* dst = nullptr;                             \
+    if (F.res) dst = const_cast<T*>(src);         \
+    else if (src) {                               \
+        dst = A.take<T>(n);                       \
+        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+    }
+        UPR(d_t, uint8_t, F.tdesc, (size_t)nt * 32)
+        UPR(d_txy, float, F.t_xy, (size_t)nt * 2)
+        UPR(d_toct, int32_t, F.t_octave, nt)
         UP(d_occ, uint8_t, F.occupied, nt)
-        UP(d_ta, float, F.t_angle, nt)
-        UP(d_tx, float, F.t_xright, nt)
+        UPR(d_ta, float, F.t_angle, nt)
+        UPR(d_tx, float, F.t_xright, nt)
 #undef UP
+#undef UPR
         rc = stage(A, fresh, P, G);
         if (rc) return rc;
         G.t_xy = d_txy;
@@ -104,9 +121,16 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         G.inv_h = (double)F.grid_rows / (F.max_y - F.min_y);
         G.cols = F.grid_cols;
         G.rows = F.grid_rows;
-        G.cell_of = A.take<int32_t>(nt);
-        G.cell_off = A.take<int32_t>(ncell + 1);
-        G.cell_items = A.take<int32_t>(nt);
+        if (F.res) {  // binned when the frame was created
+            G.cell_of = F.res->cell_of;
+            G.cell_off = F.res->cell_off;
+            G.cell_items = F.res->cell_items;
+        }
+        else {
+            G.cell_of = A.take<int32_t>(nt);
+            G.cell_off = A.take<int32_t>(ncell + 1);
+            G.cell_items = A.take<int32_t>(nt);
+        }
         G.nq = nq;
         G.cand_off = A.take<int32_t>(nq + 1);
         P.match_q = A.take<int32_t>(nq);
@@ -114,7 +138,10 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         int* owner = A.take<int>(nt);
         int* match = A.take<int>(nq);
         unsigned* mdist = A.take<unsigned>(nt);
-        if (fresh) sv_launch_grid_build(s, G);
+        if (fresh) {
+            if (F.res) sv_launch_grid_queries(s, G);
+            else sv_launch_grid_build(s, G);
+        }
         if (!pass) {
             SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
             SV_HIP(ctx, hipStreamSynchronize(s));

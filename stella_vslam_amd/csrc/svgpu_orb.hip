@@ -448,6 +448,7 @@ int svgpu_orb_extract(svgpu_ctx* ctx, const uint8_t* img, int stride, const uint
     SV_HIP(ctx, hipStreamSynchronize(s));
     const int n = counts[0];
     *n_out = n;
+    ctx->last_extract_n = n < icap ? n : icap;
     if (level_counts)
         for (int l = 0; l < C.num_levels; ++l) level_counts[l] = counts[1 + l];
     const int m = n < cap ? n : cap;

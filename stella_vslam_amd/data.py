@@ -37,6 +37,64 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class resident_frame:
+    """A data::frame_observation kept on the device (include/svgpu.h svgpu_frame_*): descriptors, undistorted keypoints, stereo
+    x_right, bearings and the keypoint grid.  `adopt_extraction` builds it from what the extractor's last extract() left on the
+    device (system.cc:384-395 without the upload), `upload` from host arrays (keyframes); `bind(ctx)` makes the NEXT
+    projection-family matcher call of `ctx` read its keypoint side from it."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        ctx.check(lib().svgpu_frame_create(ctx.handle, C.byref(self._h)), "svgpu_frame_create")
+
+    def adopt_extraction(self, camera: _camera.base, num_grid_cols: int = 64, num_grid_rows: int = 48, extractor_ctx: Context | None = None):
+        """-> (undist_keypts, bearings) as data::frame_observation holds them on the host"""
+        from .feature import KEYPOINT_DTYPE as KP_DTYPE
+        ectx = extractor_ctx or self.ctx
+        n_max = lib().svgpu_orb_max_keypoints(ectx.handle)
+        und = np.zeros(max(n_max, 1), KP_DTYPE)
+        brg = np.zeros((max(n_max, 1), 3), np.float64)
+        ectx.check(lib().svgpu_frame_adopt_extraction(ectx.handle, self._h, C.byref(camera.c_), num_grid_cols, num_grid_rows, _p(und), _p(brg)),
+                   "svgpu_frame_adopt_extraction")
+        n = self.size
+        return und[:n].copy(), brg[:n].copy()
+
+    def upload(self, camera: _camera.base, undist_keypts, descriptors, stereo_x_right=None, num_grid_cols: int = 64, num_grid_rows: int = 48):
+        from .feature import KEYPOINT_DTYPE as KP_DTYPE
+        k = np.ascontiguousarray(undist_keypts, KP_DTYPE)
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        xr = None if stereo_x_right is None else np.ascontiguousarray(stereo_x_right, np.float32)
+        self.ctx.check(lib().svgpu_frame_upload(self.ctx.handle, self._h, C.byref(camera.c_), _p(k), _p(d), _p(xr), len(k), num_grid_cols, num_grid_rows),
+                       "svgpu_frame_upload")
+        return self
+
+    def set_stereo(self, stereo_x_right):
+        xr = None if stereo_x_right is None else np.ascontiguousarray(stereo_x_right, np.float32)
+        self.ctx.check(lib().svgpu_frame_set_stereo(self.ctx.handle, self._h, _p(xr)), "svgpu_frame_set_stereo")
+        return self
+
+    @property
+    def size(self) -> int:
+        return int(lib().svgpu_frame_size(self._h))
+
+    def bind(self, ctx: Context | None = None):
+        c = ctx or self.ctx
+        c.check(lib().svgpu_frame_bind(c.handle, self._h), "svgpu_frame_bind")
+        return self
+
+    def close(self):
+        if self._h:
+            lib().svgpu_frame_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def landmarks_compute_descriptor(ctx: Context, obs_off, obs_desc):
     """data::landmark::compute_descriptor (data/landmark.cc:199-254) for every CSR row of observations at once:
     returns (best_obs, descriptors) -- the index inside each landmark's list and the n x 32 representative descriptors."""
