@@ -170,6 +170,7 @@ def main() -> int:
 
     if rank == 0 and world == 1 and not args.no_extra:
         for key, fn in (("natural_images", lambda: bench_natural(ctx, L, B, want_cpu=not args.no_cpu_baseline)),
+                        ("tracked_frame", lambda: bench_tracked_frame(frames_np, want_cpu=not args.no_cpu_baseline)),
                         ("latency", lambda: bench_latency(ctx, frames_np)), ("stereo", lambda: bench_stereo(local_rank))):
             try:
                 result[key] = fn()
@@ -469,6 +470,116 @@ def bench_latency(ctx, frames_np):
     e, b = (t1 - t0) / reps * 1e3, (t2 - t1) / reps * 1e3
     return {"what": "single 640x480 frame, host buffers in and out (PCIe included): svgpu_orb_extract, then svgpu_match_bruteforce vs the previous frame",
             "extract_ms": round(e, 4), "match_ms": round(b, 4), "frames_per_s": round(1e3 / (e + b), 1)}
+
+
+def bench_tracked_frame(frames_np, want_cpu=True):
+    """What tracking_module does per image (tracking_module.cc:533-608), through the C++ DROP-IN CLASSES of stella_vslam_amd/host/drop_in
+    (libsvgpu_host.so, svgpu_host_tracked_frame): extract -> frame observation -> projection::match_current_and_last_frames ->
+    pose_optimizer -> can_observe loop -> projection::match_frame_and_landmarks -> pose_optimizer, on a plane scene that makes the
+    synthetic sequence geometrically consistent.  Run with device-resident frames (the extractor's output is adopted on the device and bound
+    by every matcher: the frame's descriptors cross PCIe once, downwards) and without (every matcher call uploads its frame), next to the
+    CPU oracle chain on the same images."""
+    host = C.CDLL(os.path.join(ROOT, "stella_vslam_amd", "host", "libsvgpu_host.so"))
+    seq = np.ascontiguousarray(frames_np[:4])
+    out = {"what": "one tracked 640x480 frame through the drop-in classes: extract, frame observation, match_current_and_last_frames, pose optimizer, "
+                   "can_observe loop, match_frame_and_landmarks, pose optimizer (host objects in and out, PCIe included)"}
+    names = ("extract", "frame_observation", "match_current_and_last_frames", "pose_optimizer_1", "can_observe", "match_frame_and_landmarks", "pose_optimizer_2", "total")
+    for key, resident in (("resident_frames", 1), ("uploads_per_call", 0)):
+        ms, cnt = np.zeros(8), np.zeros(8, np.int32)
+        rc = host.svgpu_host_tracked_frame(C.c_void_p(seq.ctypes.data), len(seq), W, H, 30, resident, C.c_void_p(ms.ctypes.data), C.c_void_p(cnt.ctypes.data))
+        if rc != 0:
+            out[key] = {"error": "svgpu_host_tracked_frame failed"}
+            continue
+        out[key] = {"ms_per_frame": round(float(ms[7]), 4), "frames_per_s": round(1e3 / float(ms[7]), 1), "ms": {n: round(float(v), 4) for n, v in zip(names[:7], ms[:7])},
+                    "keypoints": int(cnt[0]), "last_frame_landmarks": int(cnt[1]), "matches_1": int(cnt[2]), "inliers_1": int(cnt[3]),
+                    "local_landmarks_visible": int(cnt[4]), "matches_2": int(cnt[5]), "inliers_2": int(cnt[6]), "translation_error_um": int(cnt[7])}
+    if want_cpu:
+        try:
+            out["cpu_port"] = cpu_tracked_frame(seq)
+        except Exception as e:
+            out["cpu_port"] = {"error": repr(e)}
+    return out
+
+
+def cpu_tracked_frame(seq, reps=3):
+    """The same chain with the oracle (C restatements of the reference's methods), pinned to one core: medians over `reps` frames."""
+    from oracle import oracle as O
+    n_frames, h, w = seq.shape
+    fx = fy = 500.0
+    cx, cy, Z, sx, sy = 0.5 * w, 0.5 * h, 5.0, 3.0, 1.0
+    cam = O.make_camera(O.CAM_PERSPECTIVE, w, h, fx, fy, cx, cy, (0, 0, 0, 0, 0))
+    sf, _, lss, _ = O.scale_tables(1.2, 8)
+    sf = np.asarray(sf, np.float32)
+    inv_sigma = (1.0 / np.asarray(lss, np.float32)).astype(np.float32)
+    lsf = float(np.log(np.float32(1.2)))
+
+    def pose(t):
+        return np.eye(3), np.array([-t * sx * Z / fx, -t * sy * Z / fy, 0.0])
+
+    def backproject(t, xy):
+        return np.stack([(xy[:, 0] - cx) / fx * Z + t * sx * Z / fx, (xy[:, 1] - cy) / fy * Z + t * sy * Z / fy, np.full(len(xy), Z)], 1)
+
+    maps = []
+    for t in range(n_frames - 1):
+        k, d, _ = O.orb_extract(seq[t])
+        xy = np.stack([k["x"], k["y"]], 1).astype(np.float64)
+        pw = backproject(t, xy)
+        c = -pose(t)[1]
+        dist = np.linalg.norm(pw - c, axis=1)
+        lvl = k["octave"].astype(np.int64)
+        maps.append(dict(k=k, d=d, pw=pw, nrm=(pw - c) / dist[:, None], mx=(dist * sf[lvl]).astype(np.float32),
+                         mn=((dist * sf[lvl]) / sf[7]).astype(np.float32)))
+    last = maps[-1]
+    loc = {key: np.concatenate([m[key] for m in maps[:-1]]) for key in ("pw", "nrm", "mx", "mn", "d")}
+    Rl, tl = pose(n_frames - 2)
+    Rg, tg = pose(n_frames - 1)
+    tg = tg + np.array([0.004, -0.003, 0.002])
+    K = np.array([fx, fy, cx, cy, 0.0])
+    huber = np.float32(np.sqrt(5.991))
+    old = _pin(2)
+    tt = {n: [] for n in ("extract", "frame_observation", "match_current_and_last_frames", "pose_optimizer_1", "can_observe", "match_frame_and_landmarks", "pose_optimizer_2")}
+    try:
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            k, d, _ = O.orb_extract(seq[-1])
+            t1 = time.perf_counter()
+            xy = np.stack([k["x"], k["y"]], 1)
+            und = O.undistort_keypoints(cam, xy)
+            O.keypoints_to_bearings(cam, und)
+            O.assign_keypoints_to_grid(und[:, 0], und[:, 1], (cam.min_x, cam.max_x, cam.min_y, cam.max_y))
+            t2 = time.perf_counter()
+            m1, n1 = O.match_current_and_last_frames(True, cam, Rg, tg, Rl, tl, last["pw"], np.ones(len(last["pw"]), np.uint8), last["d"], last["k"]["octave"],
+                                                     last["k"]["angle"], sf, 20.0, d, und, k["octave"], k["angle"])
+            t3 = time.perf_counter()
+            sel = m1 >= 0
+            kp = m1[sel]
+            uvr = np.stack([und[kp, 0], und[kp, 1], np.full(len(kp), -1.0)], 1).astype(np.float32)
+            nv1, p1, outl, _ = O.pose_optimize(np.hstack([Rg, tg[:, None]]).reshape(12), last["pw"][sel], uvr, inv_sigma[k["octave"][kp]], np.full(len(kp), huber), K)
+            t4 = time.perf_counter()
+            P = p1.reshape(3, 4)
+            vis, rp, xr, lv = O.can_observe(cam, P[:, :3], P[:, 3], loc["pw"], loc["nrm"], loc["mn"], loc["mx"], 0.5, 8, lsf)
+            t5 = time.perf_counter()
+            occ = np.zeros(len(d), np.uint8)
+            occ[kp[outl == 0]] = 1
+            m2, n2 = O.match_frame_and_landmarks(cam, vis, rp, xr, lv, loc["d"], sf, 5.0, 0.8, d, und, k["octave"], occupied=occ)
+            t6 = time.perf_counter()
+            sel2 = m2 >= 0
+            kp2 = np.concatenate([kp[outl == 0], m2[sel2]])
+            pw2 = np.concatenate([last["pw"][sel][outl == 0], loc["pw"][sel2]])
+            uvr2 = np.stack([und[kp2, 0], und[kp2, 1], np.full(len(kp2), -1.0)], 1).astype(np.float32)
+            nv2, p2, _, _ = O.pose_optimize(p1, pw2, uvr2, inv_sigma[k["octave"][kp2]], np.full(len(kp2), huber), K)
+            t7 = time.perf_counter()
+            if rep == 0:
+                continue
+            for name, dt in zip(tt, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6)):
+                tt[name].append(dt * 1e3)
+    finally:
+        _unpin(old)
+    med = {n: round(float(np.median(v)), 3) for n, v in tt.items()}
+    total = sum(med.values())
+    return {"ms_per_frame": round(total, 3), "frames_per_s": round(1e3 / total, 2), "ms": med, "cores": 1, "kind": "port", "keypoints": int(len(k)), "matches_1": int(n1),
+            "inliers_1": int(nv1), "local_landmarks_visible": int(vis.sum()), "matches_2": int(n2), "inliers_2": int(nv2),
+            "translation_error_um": int(round(float(np.abs(p2.reshape(3, 4)[:, 3] - pose(n_frames - 1)[1]).max()) * 1e6))}
 
 
 def bench_stereo(device):

@@ -341,6 +341,62 @@ int orc_bow_match(const uint8_t* desc1, const float* angle1, const uint8_t* vali
     return num_matches;
 }
 
+/* projection::match_frame_and_landmarks, match/projection.cc:13-93, on the maps frame::can_observe filled (tracking_module.cc:554-594):
+ * visible / reproj / x_right / pred_scale_level per local landmark (visible == 0: the landmark has no entry in lm_to_reproj, or will be
+ * erased).  lm_has_observation (nullable = all 1): what `lm && lm->has_observation()` (:52-55) sees for a landmark this very loop added.
+ * is_stereo_frame = !frm_obs.stereo_x_right_.empty().  match_lm[i] = frm.add_landmark(local_lm, best_idx) or -1, in landmark order. */
+int orc_match_frame_and_landmarks(const orc_camera* cam, int n, const uint8_t* visible, const double* reproj, const float* x_right, const int32_t* pred_scale_level,
+                                  const uint8_t* lm_desc, const uint8_t* lm_has_observation, int num_levels, const float* scale_factors, float margin,
+                                  float lowe_ratio, const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, int nt, const uint8_t* occupied,
+                                  const float* t_xright, int grid_cols, int grid_rows, int32_t* match_lm) {
+    unsigned num_matches = 0;
+    kp_side S;
+    side_init(&S, cam, tdesc, t_xy, t_octave, nt, grid_cols, grid_rows);
+    uint8_t* frm_lm = (uint8_t*)calloc(nt > 0 ? nt : 1, 1); /* 0 none, 1 a landmark without observation, 2 a landmark with observations */
+    for (int i = 0; i < nt; ++i) frm_lm[i] = (occupied && occupied[i]) ? 2 : 0;
+    for (int i = 0; i < n; ++i) {
+        match_lm[i] = -1;
+        if (!visible[i]) continue; /* :23-29 */
+        const unsigned pred = (unsigned)pred_scale_level[i];
+        const int min_level = 0 > (int)pred - 1 ? 0 : (int)pred - 1;
+        const int max_level = num_levels - 1 < (int)(pred + 1) ? num_levels - 1 : (int)(pred + 1);
+        const int n_idx = side_cell(&S, reproj[2 * (size_t)i], reproj[2 * (size_t)i + 1], margin * scale_factors[pred], min_level, max_level);
+        if (n_idx == 0) continue;
+        const uint8_t* d = lm_desc + 32 * (size_t)i;
+        unsigned best_hamm_dist = ORC_MAX_HAMMING_DIST, second_best_hamm_dist = ORC_MAX_HAMMING_DIST;
+        int best_scale_level = -1, second_best_scale_level = -1, best_idx = -1;
+        for (int k = 0; k < n_idx; ++k) {
+            const int idx = S.buf[k];
+            if (frm_lm[idx] == 2) continue; /* :52-55 */
+            if (t_xright && 0 < t_xright[idx]) { /* :57-62 */
+                const float reproj_error = fabsf(x_right[i] - t_xright[idx]);
+                if (margin * scale_factors[pred] < reproj_error) continue;
+            }
+            const unsigned dist = orc_hamming_32(d, tdesc + 32 * (size_t)idx);
+            if (dist < best_hamm_dist) {
+                second_best_hamm_dist = best_hamm_dist;
+                best_hamm_dist = dist;
+                second_best_scale_level = best_scale_level;
+                best_scale_level = t_octave[idx];
+                best_idx = idx;
+            }
+            else if (dist < second_best_hamm_dist) {
+                second_best_scale_level = t_octave[idx];
+                second_best_hamm_dist = dist;
+            }
+        }
+        if (best_hamm_dist <= ORC_HAMMING_DIST_THR_HIGH) {
+            if (best_scale_level == second_best_scale_level && (float)best_hamm_dist > lowe_ratio * (float)second_best_hamm_dist) continue; /* :82 */
+            frm_lm[best_idx] = (!lm_has_observation || lm_has_observation[i]) ? 2 : 1; /* :88 */
+            match_lm[i] = best_idx;
+            ++num_matches;
+        }
+    }
+    side_free(&S);
+    free(frm_lm);
+    return (int)num_matches;
+}
+
 /* projection::match_current_and_last_frames, match/projection.cc:95-207 */
 int orc_match_current_and_last_frames(const orc_camera* cam, const double* rot_cw, const double* trans_cw, const double* rot_lw, const double* trans_lw,
                                       int is_monocular, float true_baseline, int n_last, const double* pos_w, const uint8_t* valid,

@@ -466,6 +466,19 @@ def match_current_and_last_frames(check_orientation, cam, rot_cw, trans_cw, rot_
     return out, num
 
 
+def match_frame_and_landmarks(cam, visible, reproj, x_right, pred_scale_level, lm_desc, scale_factors, margin, lowe_ratio, tdesc, t_xy, t_octave,
+                              occupied=None, t_xright=None, lm_has_observation=None, grid_cols=64, grid_rows=48):
+    """projection::match_frame_and_landmarks (match/projection.cc:13-93) on the outputs of can_observe: (match_lm, num_matches)."""
+    vis = _c(visible, np.uint8)
+    n, sf, td = len(vis), _c(scale_factors, np.float32), _c(tdesc, np.uint8)
+    out = np.full(n, -1, np.int32)
+    num = lib().orc_match_frame_and_landmarks(
+        C.byref(cam), n, _p(vis), _p(_f64(reproj)), _p(_c(x_right, np.float32)), _p(_c(pred_scale_level, np.int32)), _p(_c(lm_desc, np.uint8)),
+        _p(_c(lm_has_observation, np.uint8)), len(sf), _p(sf), C.c_float(margin), C.c_float(lowe_ratio), _p(td), _p(_c(t_xy, np.float32)),
+        _p(_c(t_octave, np.int32)), len(td), _p(_c(occupied, np.uint8)), _p(_c(t_xright, np.float32)), grid_cols, grid_rows, _p(out))
+    return out, num
+
+
 def match_frame_and_keyframe_projection(check_orientation, cam, rot_cw, trans_cw, pos_w, valid, min_valid_dist, max_valid_dist, lm_desc, angle_kf,
                                         scale_factors, log_scale_factor, margin, hamm_dist_thr, tdesc, t_xy, t_octave, t_angle, occupied=None,
                                         grid_cols=64, grid_rows=48):

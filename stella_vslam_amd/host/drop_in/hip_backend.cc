@@ -3,6 +3,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 
 namespace stella_vslam {
@@ -67,6 +69,144 @@ svgpu_camera to_svgpu_camera(const camera::base* camera) {
     c.max_y = camera->img_bounds_.max_y_;
     return c;
 }
+
+#ifndef SVGPU_DROP_IN_OPTIMIZE_ONLY
+// ---- resident frame observations
+namespace {
+static_assert(sizeof(cv::KeyPoint) == sizeof(svgpu_keypoint), "cv::KeyPoint and svgpu_keypoint share the 28-byte layout");
+struct resident_entry {
+    svgpu_frame* f = nullptr;
+    uint64_t fingerprint = 0, stamp = 0;
+    bool adopted = false;  // built by adopt_extraction; the first matcher call completes the fingerprint (and the stereo part)
+};
+struct resident_store {
+    std::mutex mtx;
+    std::map<std::pair<int, unsigned int>, resident_entry> entries;  // (0 frame | 1 keyframe, id)
+    uint64_t clock = 0;
+    ~resident_store() {
+        for (auto& kv : entries) svgpu_frame_destroy(kv.second.f);
+    }
+};
+resident_store& store() {
+    static resident_store s;
+    return s;
+}
+constexpr size_t RESIDENT_CAPACITY = 192;  // ~0.3 MB each: the tracker's frames and the local-map keyframes of a while
+bool resident_enabled() {
+    static const bool off = std::getenv("SVGPU_NO_RESIDENT_FRAMES") != nullptr;
+    return !off;
+}
+uint64_t fnv(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+// cheap identity check of an observation under an id (ids are unique in a running system; test fixtures reuse them)
+uint64_t fingerprint(const data::frame_observation& o, const camera::base* cam) {
+    const size_t n = o.undist_keypts_.size();
+    uint64_t h = 1469598103934665603ull;
+    h = fnv(h, &n, sizeof n);
+    if (n > 0) {
+        h = fnv(h, o.descriptors_.ptr(0), 32);
+        h = fnv(h, o.descriptors_.ptr((int)n - 1), 32);
+        h = fnv(h, o.descriptors_.ptr((int)(n / 2)), 32);
+        h = fnv(h, &o.undist_keypts_[0], sizeof(cv::KeyPoint));
+        h = fnv(h, &o.undist_keypts_[n - 1], sizeof(cv::KeyPoint));
+        h = fnv(h, &o.undist_keypts_[n / 2], sizeof(cv::KeyPoint));
+    }
+    const size_t nx = o.stereo_x_right_.size();
+    h = fnv(h, &nx, sizeof nx);
+    if (nx > 0) h = fnv(h, o.stereo_x_right_.data(), sizeof(float) * std::min<size_t>(nx, 8));
+    h = fnv(h, &cam->img_bounds_, sizeof cam->img_bounds_);
+    h = fnv(h, &o.num_grid_cols_, sizeof o.num_grid_cols_);
+    h = fnv(h, &o.num_grid_rows_, sizeof o.num_grid_rows_);
+    return h;
+}
+void evict_if_full(resident_store& S) {
+    while (S.entries.size() > RESIDENT_CAPACITY) {
+        auto oldest = S.entries.begin();
+        for (auto it = S.entries.begin(); it != S.entries.end(); ++it)
+            if (it->second.stamp < oldest->second.stamp) oldest = it;
+        svgpu_frame_destroy(oldest->second.f);
+        S.entries.erase(oldest);
+    }
+}
+const svgpu_frame* resident_of(int kind, unsigned int id, const data::frame_observation& o, const camera::base* cam) {
+    if (!resident_enabled() || !cam) return nullptr;
+    resident_store& S = store();
+    const uint64_t fp = fingerprint(o, cam);
+    std::lock_guard<std::mutex> lock(S.mtx);
+    resident_entry& e = S.entries[std::make_pair(kind, id)];
+    e.stamp = ++S.clock;
+    if (e.f && e.fingerprint == fp) return e.f;
+    if (e.f && e.adopted && svgpu_frame_size(e.f) == (int)o.undist_keypts_.size()) {
+        e.adopted = false;
+        e.fingerprint = fp;
+        if (!o.stereo_x_right_.empty()) check(svgpu_frame_set_stereo(context(), e.f, o.stereo_x_right_.data()), "svgpu_frame_set_stereo");
+        return e.f;
+    }
+    e.adopted = false;
+    if (!e.f) check(svgpu_frame_create(context(), &e.f), "svgpu_frame_create");
+    const svgpu_camera c = to_svgpu_camera(cam);
+    const int n = (int)o.undist_keypts_.size();
+    std::vector<uint8_t> desc((size_t)n * 32);
+    for (int i = 0; i < n; ++i) std::memcpy(&desc[(size_t)i * 32], o.descriptors_.ptr(i), 32);
+    check(svgpu_frame_upload(context(), e.f, &c, reinterpret_cast<const svgpu_keypoint*>(o.undist_keypts_.data()), desc.data(),
+                             o.stereo_x_right_.empty() ? nullptr : o.stereo_x_right_.data(), n, (int)o.num_grid_cols_, (int)o.num_grid_rows_),
+          "svgpu_frame_upload");
+    e.fingerprint = fp;
+    evict_if_full(S);
+    return e.f;
+}
+}  // namespace
+
+const svgpu_frame* resident(const data::frame& frm) { return resident_of(0, frm.id_, frm.frm_obs_, frm.camera_); }
+const svgpu_frame* resident(const std::shared_ptr<data::keyframe>& keyfrm) { return resident_of(1, keyfrm->id_, keyfrm->frm_obs_, keyfrm->camera_); }
+
+void adopt_extraction(unsigned int frame_id, svgpu_ctx* extractor_ctx, const camera::base* camera, unsigned int num_grid_cols, unsigned int num_grid_rows,
+                      std::vector<cv::KeyPoint>& undist_keypts, eigen_alloc_vector<Vec3_t>& bearings) {
+    const svgpu_camera c = to_svgpu_camera(camera);
+    resident_store& S = store();
+    std::lock_guard<std::mutex> lock(S.mtx);
+    resident_entry& e = S.entries[std::make_pair(0, frame_id)];
+    e.stamp = ++S.clock;
+    if (!e.f) check(svgpu_frame_create(extractor_ctx, &e.f), "svgpu_frame_create");
+    // worst-case sized host buffers: the extractor's count is only known to the device side here
+    const int cap = std::max(1, svgpu_orb_max_keypoints(extractor_ctx));
+    std::vector<svgpu_keypoint> und(cap);
+    std::vector<double> brg((size_t)cap * 3);
+    const int rc = svgpu_frame_adopt_extraction(extractor_ctx, e.f, &c, (int)num_grid_cols, (int)num_grid_rows, und.data(), brg.data());
+    if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_frame_adopt_extraction: ") + svgpu_last_error(extractor_ctx));
+    const int n = svgpu_frame_size(e.f);
+    undist_keypts.resize(n);
+    std::memcpy(static_cast<void*>(undist_keypts.data()), und.data(), (size_t)n * sizeof(svgpu_keypoint));
+    bearings.resize(n);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) bearings[i](k) = brg[3 * (size_t)i + k];
+    e.fingerprint = 0;  // completed by the first matcher call, which sees the caller's host copy of the observation
+    e.adopted = true;
+    evict_if_full(S);
+}
+
+void forget_frame(unsigned int frame_id) {
+    resident_store& S = store();
+    std::lock_guard<std::mutex> lock(S.mtx);
+    auto it = S.entries.find(std::make_pair(0, frame_id));
+    if (it != S.entries.end()) {
+        svgpu_frame_destroy(it->second.f);
+        S.entries.erase(it);
+    }
+}
+void forget_keyframe(unsigned int keyframe_id) {
+    resident_store& S = store();
+    std::lock_guard<std::mutex> lock(S.mtx);
+    auto it = S.entries.find(std::make_pair(1, keyframe_id));
+    if (it != S.entries.end()) {
+        svgpu_frame_destroy(it->second.f);
+        S.entries.erase(it);
+    }
+}
+#endif  // SVGPU_DROP_IN_OPTIMIZE_ONLY
 
 }  // namespace hip
 
@@ -322,8 +462,12 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
                                                    std::unordered_map<unsigned int, unsigned int>& lm_to_scale, const float margin) const {
     // the caller has already run frame::can_observe (tracking_module.cc:554-594): the queries are its reprojections
     const int n = (int)local_landmarks.size();
-    const kp_side s = flatten(frm.frm_obs_);
-    std::vector<uint8_t> qdesc((size_t)n * 32, 0), qvalid(n, 0), occupied(s.n, 0);
+    const svgpu_frame* rf = stella_vslam::hip::resident(frm);  // the frame's keypoint side stays on the device between the matchers of a tracked frame
+    kp_side s;
+    if (rf) s.n = (int)frm.frm_obs_.undist_keypts_.size();
+    else s = flatten(frm.frm_obs_);
+    const bool frame_is_stereo = !frm.frm_obs_.stereo_x_right_.empty();
+    std::vector<uint8_t> qdesc((size_t)n * 32, 0), qvalid(n, 0), occupied(s.n, 0), qblocks(n, 1);
     std::vector<float> qxy((size_t)n * 2, 0.f), qmargin(n, 0.f), qxr(n, 0.f);
     std::vector<int32_t> qlo(n, 0), qhi(n, 0);
     const auto& sf = frm.orb_params_->scale_factors_;
@@ -339,6 +483,7 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
         qlo[i] = std::max(0, static_cast<int>(pred) - 1);
         qhi[i] = std::min((int)frm.orb_params_->num_levels_ - 1, (int)pred + 1);
         qxr[i] = lm_to_x_right.count(lm->id_) ? lm_to_x_right.at(lm->id_) : 0.f;
+        qblocks[i] = lm->has_observation() ? 1 : 0;  // a landmark added without observations does not close its keypoint (:52-55 re-reads the frame)
         const cv::Mat d = lm->get_descriptor();
         if (d.empty()) {  // a landmark whose representative descriptor has not been computed yet offers nothing to compare
             qvalid[i] = 0;
@@ -353,8 +498,11 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
     const auto& b = frm.camera_->img_bounds_;
     std::vector<int32_t> m(n, -1);
     int num = 0;
-    check(svgpu_match_in_cells(context(), qdesc.data(), n, qxy.data(), qmargin.data(), qlo.data(), qhi.data(), qvalid.data(), nullptr, s.xr() ? qxr.data() : nullptr,
-                               s.xr() ? qmargin.data() : nullptr, s.desc.data(), s.xy.data(), s.octave.data(), s.n, occupied.data(), nullptr, s.xr(), b.min_x_,
+    check(svgpu_match_set_query_blocks(context(), qblocks.data()), "svgpu_match_set_query_blocks");
+    if (rf) check(svgpu_frame_bind(context(), rf), "svgpu_frame_bind");
+    check(svgpu_match_in_cells(context(), qdesc.data(), n, qxy.data(), qmargin.data(), qlo.data(), qhi.data(), qvalid.data(), nullptr,
+                               frame_is_stereo ? qxr.data() : nullptr, frame_is_stereo ? qmargin.data() : nullptr, rf ? nullptr : s.desc.data(),
+                               rf ? nullptr : s.xy.data(), rf ? nullptr : s.octave.data(), s.n, occupied.data(), nullptr, rf ? nullptr : s.xr(), b.min_x_,
                                b.max_x_, b.min_y_, b.max_y_, (int)frm.frm_obs_.num_grid_cols_, (int)frm.frm_obs_.num_grid_rows_, 0, HAMMING_DIST_THR_HIGH,
                                lowe_ratio_, SVGPU_MATCH_RATIO_SAME_OCTAVE, m.data(), &num),
           "svgpu_match_in_cells");
@@ -364,7 +512,11 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
 }
 
 unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, const data::frame& last_frm, const float margin) const {
-    const kp_side sl = flatten(last_frm.frm_obs_), sc = flatten(curr_frm.frm_obs_);
+    const svgpu_frame* rf = stella_vslam::hip::resident(curr_frm);
+    const kp_side sl = flatten(last_frm.frm_obs_);
+    kp_side sc;
+    if (rf) sc.n = (int)curr_frm.frm_obs_.undist_keypts_.size();
+    else sc = flatten(curr_frm.frm_obs_);
     const auto last_lms = last_frm.get_landmarks();
     lm_set L = flatten(last_lms, [](const lm_ptr&, int) { return true; });
     std::vector<uint8_t> has_obs(sl.n, 1), occupied(sc.n, 0);
@@ -383,6 +535,7 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
     const auto& sf = curr_frm.orb_params_->scale_factors_;
     std::vector<int32_t> m(sl.n, -1);
     int num = 0;
+    if (rf) check(svgpu_frame_bind(context(), rf), "svgpu_frame_bind");
     check(svgpu_match_current_and_last_frames(context(), &cam, Rc, tc, Rl, tl, curr_frm.camera_->setup_type_ == camera::setup_type_t::Monocular ? 1 : 0,
                                               (float)curr_frm.camera_->true_baseline_, sl.n, L.pos_w.data(), L.valid.data(), L.desc.data(), sl.octave.data(),
                                               sl.angle.data(), has_obs.data(), (int)sf.size(), sf.data(), margin, sc.desc.data(), sc.xy.data(), sc.octave.data(),
@@ -397,6 +550,7 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
 unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, const kf_ptr& keyfrm, const std::set<lm_ptr>& already_matched_lms, const float margin,
                                                   const unsigned int hamm_dist_thr) const {
     auto lms = curr_frm.get_landmarks();  // projection.cc:209-215
+    if (const svgpu_frame* rf = stella_vslam::hip::resident(curr_frm)) check(svgpu_frame_bind(context(), rf), "svgpu_frame_bind");
     auto num_matches = match_frame_and_keyframe(curr_frm.get_pose_cw(), curr_frm.camera_, curr_frm.frm_obs_, curr_frm.orb_params_, lms, keyfrm, already_matched_lms,
                                                 margin, hamm_dist_thr);
     curr_frm.set_landmarks(lms);
@@ -435,6 +589,7 @@ unsigned int projection::match_by_Sim3_transform(const kf_ptr& keyfrm, const Mat
     already_matched.erase(nullptr);
     const lm_set L = flatten(landmarks, [&](const lm_ptr& lm, int) { return already_matched.count(lm) == 0; });
     const kp_side s = flatten(keyfrm->frm_obs_);
+    if (const svgpu_frame* rf = stella_vslam::hip::resident(keyfrm)) check(svgpu_frame_bind(context(), rf), "svgpu_frame_bind");
     std::vector<uint8_t> occupied(s.n, 0);
     for (int k = 0; k < s.n; ++k) occupied[k] = matched_lms_in_keyfrm.at(k) ? 1 : 0;  // :391-393
     const svgpu_camera cam = to_svgpu_camera(keyfrm->camera_);

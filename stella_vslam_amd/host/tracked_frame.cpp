@@ -1,0 +1,228 @@
+// One tracked frame through the DROP-IN CLASSES -- what tracking_module does per image (tracking_module.cc:533-608, system.cc:380-395):
+//   extract                                  feature::orb_extractor::extract
+//   frame observation                        undistort_keypoints + convert_keypoints_to_bearings + assign_keypoints_to_grid
+//   projection::match_current_and_last_frames   (frame_tracker::motion_based_track, module/frame_tracker.cc:22-60)
+//   pose_optimizer::optimize
+//   search_local_landmarks: frame::can_observe loop, then projection::match_frame_and_landmarks
+//   pose_optimizer::optimize
+// on a scene that makes the synthetic frames of stella_vslam_amd/synthetic.py geometrically consistent: the texture is a fronto-parallel
+// plane at depth Z, the camera translates parallel to it so that the image moves by the sequence's (3, 1) pixels per frame, landmarks are
+// the keypoints of earlier frames back-projected onto the plane.  bench.py (leg `tracked_frame`) calls this through ctypes with the
+// resident-frame cache on and off and times the CPU oracle chain on the same images beside it.  Stand-in data:: types (host/standin/).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <unordered_map>
+
+#include "drop_in/hip_backend.h"
+#include "drop_in/pose_optimizer_hip.h"
+#include "orb_extractor.h"
+
+using namespace stella_vslam;
+using lm_ptr = std::shared_ptr<data::landmark>;
+using kf_ptr = std::shared_ptr<data::keyframe>;
+
+namespace {
+struct Scene {
+    int w, h;
+    double fx = 500.0, fy = 500.0, cx, cy, Z = 5.0, sx = 3.0, sy = 1.0;  // pixel shift per frame
+    camera::perspective cam;
+    feature::orb_params orb;
+    Scene(int w_, int h_)
+        : w(w_), h(h_), cx(0.5 * w_), cy(0.5 * h_), cam(camera::setup_type_t::Monocular, (unsigned)w_, (unsigned)h_, 500.0, 500.0, 0.5 * w_, 0.5 * h_, 0, 0, 0, 0, 0) {
+        cam.img_bounds_ = camera::image_bounds{0.f, (float)w_, 0.f, (float)h_};
+    }
+    // frame t shows the canvas window at offset t * (sx, sy): the camera centre sits at t * (sx Z / fx, sy Z / fy, 0), looking down +z
+    Mat44_t pose(double t) const {
+        Mat44_t T = Mat44_t::Identity();
+        T(0, 3) = -t * sx * Z / fx;
+        T(1, 3) = -t * sy * Z / fy;
+        return T;
+    }
+    Vec3_t backproject(double t, double u, double v) const {
+        Vec3_t p;
+        p(0) = (u - cx) / fx * Z + t * sx * Z / fx;
+        p(1) = (v - cy) / fy * Z + t * sy * Z / fy;
+        p(2) = Z;
+        return p;
+    }
+};
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+// imgs: n_frames images of w x h (row stride w), consecutive frames of the synthetic sequence; frame n_frames - 1 is the tracked one, the
+// one before it the "last frame", all earlier ones contribute local-map landmarks.  use_resident: 1 = frames adopted from the extractor and
+// cached on the device (hip::adopt_extraction / hip::resident), 0 = every matcher call uploads its frame (SVGPU_NO_RESIDENT_FRAMES semantics,
+// through the host-buffer svgpu_frame_observation).  ms[8] = {extract, frame observation, match_current_and_last_frames, pose optimizer 1,
+// can_observe loop, match_frame_and_landmarks, pose optimizer 2, total}; counts[8] = {keypoints, landmarks of the last frame, matches 1,
+// inliers 1, local landmarks offered, matches 2, inliers 2, 0}.  Returns 0, or -1 with a message on stderr.
+extern "C" int svgpu_host_tracked_frame(const uint8_t* imgs, int n_frames, int w, int h, int reps, int use_resident, double* ms, int* counts) {
+    try {
+        if (!imgs || n_frames < 3 || reps < 1 || !ms || !counts) return -1;
+        Scene S(w, h);
+        stella_vslam_hip::feature::orb_params hp("tracked");
+        stella_vslam_hip::feature::orb_extractor ext(&hp, 800);
+        svgpu_ctx* const mctx = stella_vslam::hip::context();
+        const svgpu_camera scam = stella_vslam::hip::to_svgpu_camera(&S.cam);
+        // ---- the map: keypoints of the frames before the tracked one, back-projected onto the plane; every landmark is observed by a
+        //      keyframe made of the frame it came from
+        std::vector<kf_ptr> kfs;
+        std::vector<lm_ptr> all_lms;
+        auto observe = [&](const uint8_t* img, std::vector<cv::KeyPoint>& kps, cv::Mat& desc, std::vector<cv::KeyPoint>& und, eigen_alloc_vector<Vec3_t>& brg,
+                           unsigned frame_id, bool resident) {
+            cv::Mat im(h, w, CV_8U, const_cast<uint8_t*>(img), (size_t)w);
+            ext.extract(im, cv::Mat(), kps, desc);
+            if (resident) stella_vslam::hip::adopt_extraction(frame_id, ext.context(), &S.cam, 64, 48, und, brg);
+            else {
+                const int n = (int)kps.size();
+                und.resize(n);
+                std::vector<double> b((size_t)n * 3);
+                stella_vslam::hip::check(svgpu_frame_observation(mctx, &scam, reinterpret_cast<const svgpu_keypoint*>(kps.data()), n, 64, 48,
+                                                                 reinterpret_cast<svgpu_keypoint*>(und.data()), b.data(), nullptr, nullptr),
+                                         "svgpu_frame_observation");
+                brg.resize(n);
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < 3; ++k) brg[i](k) = b[3 * (size_t)i + k];
+            }
+        };
+        unsigned next_lm = 0;
+        for (int t = 0; t < n_frames - 1; ++t) {
+            auto kf = std::make_shared<data::keyframe>((unsigned)t, &S.cam, &S.orb);
+            kf->set_pose_cw(S.pose(t));
+            std::vector<cv::KeyPoint> kps;
+            observe(imgs + (size_t)t * w * h, kps, kf->frm_obs_.descriptors_, kf->frm_obs_.undist_keypts_, kf->frm_obs_.bearings_, 900000u + t, false);
+            const int n = (int)kf->frm_obs_.undist_keypts_.size();
+            kf->landmarks_.assign(n, nullptr);
+            for (int i = 0; i < n; ++i) {
+                const auto& kp = kf->frm_obs_.undist_keypts_[i];
+                auto lm = std::make_shared<data::landmark>(next_lm++, S.backproject(t, kp.pt.x, kp.pt.y));
+                lm->add_observation(kf, (unsigned)i);
+                lm->ref_keyfrm_ = kf;
+                kf->landmarks_[i] = lm;
+                all_lms.push_back(lm);
+            }
+            kfs.push_back(kf);
+        }
+        for (auto& lm : all_lms) {
+            lm->compute_descriptor();
+            lm->update_mean_normal_and_obs_scale_variance();
+        }
+        // the last frame: the keypoints of frame n - 2 with their landmarks
+        const kf_ptr& lastkf = kfs.back();
+        data::frame last_frm(500000u, &S.cam, &S.orb);
+        last_frm.frm_obs_ = lastkf->frm_obs_;
+        last_frm.landmarks_ = lastkf->landmarks_;
+        last_frm.set_pose_cw(S.pose(n_frames - 2));
+        std::vector<lm_ptr> local_lms;  // the local map: the landmarks of the EARLIER keyframes (the last frame's own are matched in step 1)
+        for (size_t k = 0; k + 1 < kfs.size(); ++k)
+            for (auto& lm : kfs[k]->landmarks_) local_lms.push_back(lm);
+        const match::hip::projection proj_last(0.9f, true), proj_map(0.8f, true);  // frame_tracker.cc:24, tracking_module.cc:598
+        const optimize::pose_optimizer_hip pose_opt;
+        for (int k = 0; k < 8; ++k) ms[k] = 0.0, counts[k] = 0;
+        const uint8_t* cur_img = imgs + (size_t)(n_frames - 1) * w * h;
+        for (int rep = -1; rep < reps; ++rep) {  // rep -1 = warm-up
+            double tt[8];
+            const unsigned fid = 1000u + (unsigned)(rep + 1);
+            data::frame cur(fid, &S.cam, &S.orb);
+            std::vector<cv::KeyPoint> kps;
+            double t0 = now_ms();
+            {
+                cv::Mat im(h, w, CV_8U, const_cast<uint8_t*>(cur_img), (size_t)w);
+                ext.extract(im, cv::Mat(), kps, cur.frm_obs_.descriptors_);
+            }
+            tt[0] = now_ms() - t0;
+            t0 = now_ms();
+            if (use_resident) stella_vslam::hip::adopt_extraction(fid, ext.context(), &S.cam, 64, 48, cur.frm_obs_.undist_keypts_, cur.frm_obs_.bearings_);
+            else {
+                const int n = (int)kps.size();
+                cur.frm_obs_.undist_keypts_.resize(n);
+                std::vector<double> b((size_t)n * 3);
+                std::vector<int32_t> cell_off(64 * 48 + 1), cell_items(n);
+                stella_vslam::hip::check(svgpu_frame_observation(mctx, &scam, reinterpret_cast<const svgpu_keypoint*>(kps.data()), n, 64, 48,
+                                                                 reinterpret_cast<svgpu_keypoint*>(cur.frm_obs_.undist_keypts_.data()), b.data(),
+                                                                 cell_off.data(), cell_items.data()),
+                                         "svgpu_frame_observation");
+                cur.frm_obs_.bearings_.resize(n);
+                for (int i = 0; i < n; ++i)
+                    for (int k = 0; k < 3; ++k) cur.frm_obs_.bearings_[i](k) = b[3 * (size_t)i + k];
+            }
+            tt[1] = now_ms() - t0;
+            const int n = (int)cur.frm_obs_.undist_keypts_.size();
+            cur.landmarks_.assign(n, nullptr);
+            // motion model: the true pose, a little off (frame_tracker.cc:29: velocity * last pose)
+            Mat44_t guess = S.pose(n_frames - 1);
+            guess(0, 3) += 0.004, guess(1, 3) -= 0.003, guess(2, 3) += 0.002;
+            cur.set_pose_cw(guess);
+            t0 = now_ms();
+            const unsigned m1 = proj_last.match_current_and_last_frames(cur, last_frm, 20.0f);  // monocular margin, frame_tracker.cc:34
+            tt[2] = now_ms() - t0;
+            t0 = now_ms();
+            Mat44_t opt = guess;
+            std::vector<bool> outl;
+            const unsigned in1 = pose_opt.optimize(cur, opt, outl);
+            tt[3] = now_ms() - t0;
+            cur.set_pose_cw(opt);
+            for (int i = 0; i < n; ++i)
+                if (outl.size() == (size_t)n && outl[i]) cur.landmarks_[i] = nullptr;  // frame_tracker.cc:88-110 discard_outliers
+            // search_local_landmarks (tracking_module.cc:554-594): frame::can_observe for every local landmark the frame does not hold yet
+            t0 = now_ms();
+            eigen_alloc_unord_map<unsigned int, Vec2_t> lm_to_reproj;
+            std::unordered_map<unsigned int, float> lm_to_x_right;
+            std::unordered_map<unsigned int, unsigned int> lm_to_scale;
+            {
+                const int nl = (int)local_lms.size();
+                std::vector<double> pos((size_t)nl * 3), nrm((size_t)nl * 3), rp((size_t)nl * 2);
+                std::vector<float> mn(nl), mx(nl), xr(nl);
+                std::vector<uint8_t> vis(nl);
+                std::vector<int32_t> lvl(nl);
+                for (int i = 0; i < nl; ++i) {
+                    const Vec3_t p = local_lms[i]->get_pos_in_world(), nv = local_lms[i]->get_obs_mean_normal();
+                    for (int k = 0; k < 3; ++k) pos[3 * (size_t)i + k] = p(k), nrm[3 * (size_t)i + k] = nv(k);
+                    mn[i] = local_lms[i]->get_min_valid_distance(), mx[i] = local_lms[i]->get_max_valid_distance();
+                }
+                double R[9], tr[3], twc[3];
+                for (int i = 0; i < 3; ++i) {
+                    for (int j = 0; j < 3; ++j) R[3 * i + j] = opt(i, j);
+                    tr[i] = opt(i, 3);
+                }
+                for (int i = 0; i < 3; ++i) twc[i] = -(R[0 + i] * tr[0] + R[3 + i] * tr[1] + R[6 + i] * tr[2]);
+                stella_vslam::hip::check(svgpu_reproject_landmarks(mctx, &scam, R, tr, twc, nl, pos.data(), nrm.data(), mn.data(), mx.data(), nullptr, 0.5f,
+                                                                   (int)S.orb.num_levels_, S.orb.log_scale_factor_, vis.data(), rp.data(), xr.data(), lvl.data()),
+                                         "svgpu_reproject_landmarks");
+                for (int i = 0; i < nl; ++i)
+                    if (vis[i]) {
+                        Vec2_t q;
+                        q(0) = rp[2 * (size_t)i], q(1) = rp[2 * (size_t)i + 1];
+                        lm_to_reproj[local_lms[i]->id_] = q;
+                        lm_to_x_right[local_lms[i]->id_] = xr[i];
+                        lm_to_scale[local_lms[i]->id_] = (unsigned)lvl[i];
+                    }
+            }
+            tt[4] = now_ms() - t0;
+            t0 = now_ms();
+            const unsigned m2 = proj_map.match_frame_and_landmarks(cur, local_lms, lm_to_reproj, lm_to_x_right, lm_to_scale, 5.0f);
+            tt[5] = now_ms() - t0;
+            t0 = now_ms();
+            const unsigned in2 = pose_opt.optimize(cur, opt, outl);
+            tt[6] = now_ms() - t0;
+            if (use_resident) stella_vslam::hip::forget_frame(fid);
+            if (rep < 0) continue;
+            double tot = 0;
+            for (int k = 0; k < 7; ++k) ms[k] += tt[k] / reps, tot += tt[k];
+            ms[7] += tot / reps;
+            counts[0] = n, counts[1] = (int)last_frm.landmarks_.size(), counts[2] = (int)m1, counts[3] = (int)in1, counts[4] = (int)lm_to_reproj.size(),
+            counts[5] = (int)m2, counts[6] = (int)in2;
+            // sanity: the optimised pose is the true one to a few millimetres
+            const Mat44_t gt = S.pose(n_frames - 1);
+            double err = 0;
+            for (int i = 0; i < 3; ++i) err = std::max(err, std::fabs(opt(i, 3) - gt(i, 3)));
+            counts[7] = (int)std::lround(err * 1e6);  // micrometres
+        }
+        return 0;
+    }
+    catch (const std::exception& e) {
+        std::fprintf(stderr, "svgpu_host_tracked_frame: %s\n", e.what());
+        return -1;
+    }
+}

@@ -276,6 +276,10 @@ def test_match_frame_and_landmarks(ref, sc, sc_stereo, stereo):
                                               _p(a["txr"]), nt, _p(a["occ"]), 64, 48, _p(holder))
     assert got == (exp >= 0).sum() > 300
     assert np.array_equal(holder, _replay(exp, nt, occupied))
+    # the literal per-method oracle (oracle/match2_oracle.c orc_match_frame_and_landmarks, what bench.py's CPU tracked-frame chain times)
+    lit, lnum = O.match_frame_and_landmarks(cam, vis, rp, xr, lv, L["desc"], T["scale_factors"], margin, ratio, frm["desc"], frm["xy"], frm["octave"],
+                                            occupied=occupied, t_xright=frm["x_right"] if stereo else None)
+    assert lnum == got and np.array_equal(lit, exp)
 
 
 @pytest.mark.parametrize("check", [True, False])
