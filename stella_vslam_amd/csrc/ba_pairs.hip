@@ -4,12 +4,13 @@
 // upper block (a <= b), the list of such pairs in a FIXED order (fixed-order fp64 sums = bit-reproducible results).  The lists
 // used to be built on the host (two passes over ~200 k pairs, 1.2 ms at 20 KF / 10 k landmarks); here every landmark emits its
 // pairs in the same sequence (i <= j in edge order, swapped so that a <= b, the mirrored pair right after a same-pose pair),
-// keyed by the dense block index, and a STABLE radix sort (hipcub / rocPRIM) groups them by block: the order inside a
-// block is the landmark-major order the host pass produced.
-#include <hipcub/hipcub.hpp>
+// keyed by the dense block index, and a STABLE least-significant-digit radix sort (below: 6-bit digits, hand-written -- per-block digit
+// histograms, one scan, a scatter with in-block stable ranks from wave ballots) groups them by block: the order inside a block is the
+// landmark-major order the host pass produced.
 
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
+#include "sv_sort.h"
 
 namespace {
 
@@ -75,17 +76,52 @@ __global__ void k_pair_offsets(const unsigned* __restrict__ keys, int n, int nb_
     dense_off[k] = lo;
 }
 
+inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 }  // namespace
 
 size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap) {
-    size_t t1 = 0, t2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
-                                       (unsigned long long*)nullptr, (int)pair_cap);
-    const size_t t = t1 > t2 ? t1 : t2;
-    return ((t + 255) & ~size_t(255)) + 2 * (((size_t)(L + 2) * 4 + 255) & ~size_t(255)) + (((pair_cap * 4) + 255) & ~size_t(255)) * 2
-           + (((pair_cap * 8) + 255) & ~size_t(255)) + (((nb_cap + 1) * 4 + 255) & ~size_t(255)) + 1024;
+    return 2 * pad256((size_t)(L + 2) * 4) + pad256(sv_sort_hist_ints(pair_cap) * 4) + 2 * pad256(pair_cap * 4) + pad256(pair_cap * 8) + pad256((nb_cap + 1) * 4) + 1024;
 }
+
+namespace {
+// count -> scan -> emit -> radix passes -> dense offsets; total_host < 0: the pair total stays on the device (no read-back)
+int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total_host, int2* pairs_out,
+                int* dense_off_dev, bool read_total, int* total_out) {
+    const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += pad256(bytes);
+        return (void*)r;
+    };
+    int* cnt = (int*)take((size_t)(L + 2) * 4);
+    int* hist = (int*)take(sv_sort_hist_ints(pair_cap) * 4);
+    unsigned* keys[2] = {(unsigned*)take(pair_cap * 4), (unsigned*)take(pair_cap * 4)};
+    unsigned long long* vals[2] = {(unsigned long long*)take(pair_cap * 8), reinterpret_cast<unsigned long long*>(pairs_out)};
+    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list scratch too small");
+    SV_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt);
+    sv_scan_i32(s, cnt, L);  // cnt[l] = first pair of landmark l, cnt[L] = the total
+    SV_HIP(ctx, hipGetLastError());
+    int total = total_host;
+    if (read_total) {
+        SV_HIP(ctx, hipMemcpyAsync(&total, cnt + L, 4, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        if ((size_t)total > pair_cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list capacity exceeded");
+        if (total_out) *total_out = total;
+    }
+    int bits = 1;
+    while ((1u << bits) < (unsigned)nb_dense + 1u && bits < 32) ++bits;
+    int cur = sv_sort_passes(bits) & 1 ? 0 : 1;  // so that the last pass lands in buffer 1 = pairs_out
+    if (total > 0) {
+        hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt, keys[cur], vals[cur]);
+        cur = sv_sort_pairs(s, keys, vals, cur, total, bits, hist);
+    }
+    hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys[cur], total, nb_dense, dense_off_dev);
+    SV_HIP(ctx, hipGetLastError());
+    return SVGPU_OK;
+}
+}  // namespace
 
 // D.pose_slot / D.pt_free / D.e_level / D.nP must be current on the device.  Writes the sorted pairs to `pairs_out` (= D.blk_pairs
 // storage) and the dense block offsets (nb_dense + 1 ints) to `dense_off_host`.  Synchronises the stream twice.
@@ -94,44 +130,10 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
     const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
     dense_off_host.assign((size_t)nb_dense + 1, 0);
     if (L == 0 || D.nP == 0) return SVGPU_OK;
-    char* p = (char*)scratch;
-    auto take = [&](size_t bytes) {
-        char* r = p;
-        p += (bytes + 255) & ~size_t(255);
-        return (void*)r;
-    };
-    size_t t1 = 0, t2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
-                                       (unsigned long long*)nullptr, (int)pair_cap);
-    const size_t tbytes = t1 > t2 ? t1 : t2;
-    void* temp = take(tbytes);
-    int* cnt = (int*)take((size_t)(L + 2) * 4);
-    int* off = (int*)take((size_t)(L + 2) * 4);
-    unsigned* keys_in = (unsigned*)take(pair_cap * 4);
-    unsigned* keys_out = (unsigned*)take(pair_cap * 4);
-    unsigned long long* vals_in = (unsigned long long*)take(pair_cap * 8);
-    int* dense_off = (int*)take(((size_t)nb_dense + 1) * 4);
-    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list scratch too small");
-    SV_HIP(ctx, hipGetLastError());  // anything pending from earlier launches is reported here, not by hipcub below
-    hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt);
-    SV_HIP(ctx, hipGetLastError());
-    SV_HIP(ctx, hipMemsetAsync(cnt + L, 0, 4, s));
-    size_t tb = tbytes;
-    SV_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(temp, tb, cnt, off, L + 1, s));
-    int total = 0;
-    SV_HIP(ctx, hipMemcpyAsync(&total, off + L, 4, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipStreamSynchronize(s));
-    if ((size_t)total > pair_cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list capacity exceeded");
-    if (total > 0) {
-        hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, off, keys_in, vals_in);
-        int bits = 1;
-        while ((1u << bits) < (unsigned)nb_dense + 1u && bits < 32) ++bits;
-        tb = tbytes;
-        SV_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_in, keys_out, vals_in, reinterpret_cast<unsigned long long*>(pairs_out),
-                                                       total, 0, bits, s));
-    }
-    hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys_out, total, nb_dense, dense_off);
+    // the dense offsets live at the END of the scratch block (behind what build_pairs takes)
+    int* dense_off = (int*)((char*)scratch + scratch_bytes - pad256(((size_t)nb_dense + 1) * 4));
+    const int rc = build_pairs(ctx, s, D, scratch, scratch_bytes - pad256(((size_t)nb_dense + 1) * 4), pair_cap, 0, pairs_out, dense_off, true, nullptr);
+    if (rc) return rc;
     SV_HIP(ctx, hipMemcpyAsync(dense_off_host.data(), dense_off, 4 * ((size_t)nb_dense + 1), hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipStreamSynchronize(s));
     return SVGPU_OK;
@@ -146,38 +148,5 @@ int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void*
         SV_HIP(ctx, hipMemsetAsync(dense_off_dev, 0, 4 * ((size_t)nb_dense + 1), s));
         return SVGPU_OK;
     }
-    char* p = (char*)scratch;
-    auto take = [&](size_t bytes) {
-        char* r = p;
-        p += (bytes + 255) & ~size_t(255);
-        return (void*)r;
-    };
-    size_t t1 = 0, t2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t1, (int*)nullptr, (int*)nullptr, L + 1);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t2, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned long long*)nullptr,
-                                       (unsigned long long*)nullptr, (int)pair_cap);
-    const size_t tbytes = t1 > t2 ? t1 : t2;
-    void* temp = take(tbytes);
-    int* cnt = (int*)take((size_t)(L + 2) * 4);
-    int* off = (int*)take((size_t)(L + 2) * 4);
-    unsigned* keys_in = (unsigned*)take(pair_cap * 4);
-    unsigned* keys_out = (unsigned*)take(pair_cap * 4);
-    unsigned long long* vals_in = (unsigned long long*)take(pair_cap * 8);
-    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list scratch too small");
-    SV_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt);
-    SV_HIP(ctx, hipGetLastError());
-    SV_HIP(ctx, hipMemsetAsync(cnt + L, 0, 4, s));
-    size_t tb = tbytes;
-    SV_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(temp, tb, cnt, off, L + 1, s));
-    if (total > 0) {
-        hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, off, keys_in, vals_in);
-        int bits = 1;
-        while ((1u << bits) < (unsigned)nb_dense + 1u && bits < 32) ++bits;
-        tb = tbytes;
-        SV_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_in, keys_out, vals_in, reinterpret_cast<unsigned long long*>(pairs_out),
-                                                       total, 0, bits, s));
-    }
-    hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys_out, total, nb_dense, dense_off_dev);
-    return SVGPU_OK;
+    return build_pairs(ctx, s, D, scratch, scratch_bytes, pair_cap, total, pairs_out, dense_off_dev, false, nullptr);
 }

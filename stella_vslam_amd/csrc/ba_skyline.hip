@@ -885,6 +885,9 @@ struct SkyPlan {
     double *seg_arena = nullptr, *seg_xch = nullptr, *seg_dpx = nullptr;
     size_t seg_xch_doubles = 0, seg_lds_job = 0, seg_lds_back = 0;
     int seg_NB = 0, seg_n = 0, seg_cuts = 0, seg_longest = 0, plan_rows = 0, plan_width = 0;
+    // the block pattern the plan was made for: an unchanged pattern (the same window / map optimised again) keeps plan and device arrays
+    unsigned long long pattern_hash = 0;
+    int pattern_nP = 0, pattern_rank = 0, pattern_world = 0, pattern_env = 0;
     void* d_int = nullptr;
     size_t int_bytes = 0;
     void* d_val = nullptr;
@@ -1048,7 +1051,7 @@ struct HostSeg {
     std::vector<size_t> xch_off;          // per job: its exchange block, in doubles (a multiple of 36)
     size_t xch_doubles = 0;
     std::vector<int> gb_off, gb_src, gy_off, gy_src;  // gather lists: separator block -> (exchange block | transposed << 30), separator row -> exchange offset
-    int ncuts = 0, max_nC = 0;
+    int ncuts = 0, max_nC = 0, nsep_rows = 0;
     bool ok = false;
 };
 static size_t band_lds_bytes(const HostSky& h) {
@@ -1059,8 +1062,9 @@ static size_t band_lds_bytes(const HostSky& h) {
 // `ncuts` vertex separators in the RCM order (each a run of consecutive positions, as narrow as the band allows near its target), the
 // connected pieces between them as jobs, the separator system with the fill the jobs leave on it.  G.ok only when every job fits the
 // banded kernel (k_sky_band in job mode) and the separator system has a plan.
+// cuts_only: stop once the pieces are known (G.max_nC, G.nsep_rows, the job count in G.nC.size()) -- what the cost model needs.
 static void plan_segments(int nP, const std::vector<int>& order, const std::vector<std::vector<int>>& adj, const std::vector<int2>& blk_ab, int ncuts, int world,
-                          size_t max_bytes, HostSeg& G) {
+                          size_t max_bytes, HostSeg& G, bool cuts_only = false) {
     G = HostSeg();
     if (ncuts < 1 || nP < 4) return;
     std::vector<int> pos0(nP);
@@ -1116,6 +1120,16 @@ static void plan_segments(int nP, const std::vector<int>& order, const std::vect
     }
     const int nj = (int)members.size();
     if (nj < 2) return;
+    for (int u = 0; u < nP; ++u) G.nsep_rows += is_sep[u] ? 1 : 0;
+    if (cuts_only) {
+        G.nC.resize(nj);
+        for (int q = 0; q < nj; ++q) {
+            G.nC[q] = (int)members[q].size();
+            G.max_nC = std::max(G.max_nC, G.nC[q]);
+        }
+        G.ok = true;
+        return;
+    }
     G.job.resize(nj);
     G.order.resize(nj);
     G.nC.resize(nj);
@@ -1542,17 +1556,27 @@ static int seg_upload(svgpu_ctx* ctx, hipStream_t s, SkyPlan* P, int nP, const s
 static bool choose_segments(int nP, const std::vector<int>& order, const std::vector<std::vector<int>>& adj, const std::vector<int2>& blk_ab, int want, int world,
                             size_t max_bytes, HostSeg& G, SegLayout& LY) {
     G = HostSeg();
-    double best = 1e30;
+    // candidates ranked by the column-count model on their cuts alone (cheap), then planned in full in that order until one holds
+    std::vector<std::pair<double, int>> cand;
     for (int nc = want > 0 ? want : 2; nc <= (want > 0 ? want : 8); ++nc) {
-        HostSeg cand;
-        plan_segments(nP, order, adj, blk_ab, nc, world, max_bytes, cand);
-        if (!cand.ok || (int)cand.job.size() < world) continue;
-        const bool sep_band = cand.sep.nP == 0 || (cand.sep.band && cand.sep.max_m <= SKY_BAND_W && band_lds_bytes(cand.sep) <= 150 * 1024);
-        const double cost = 3.0 * cand.max_nC + (sep_band ? 3.0 : 6.5) * cand.sep.nP + 15.0;
+        HostSeg c;
+        plan_segments(nP, order, adj, blk_ab, nc, world, max_bytes, c, true);
+        if (!c.ok || (int)c.nC.size() < world) continue;
+        cand.push_back({3.0 * c.max_nC + 3.0 * c.nsep_rows + 15.0, nc});
+    }
+    std::sort(cand.begin(), cand.end());
+    double best = 1e30;
+    for (const auto& cn : cand) {
+        HostSeg c;
+        plan_segments(nP, order, adj, blk_ab, cn.second, world, max_bytes, c);
+        if (!c.ok) continue;
+        const bool sep_band = c.sep.nP == 0 || (c.sep.band && c.sep.max_m <= SKY_BAND_W && band_lds_bytes(c.sep) <= 150 * 1024);
+        const double cost = 3.0 * c.max_nC + (sep_band ? 3.0 : 6.5) * c.sep.nP + 15.0;
         if (cost < best) {
             best = cost;
-            G = std::move(cand);
+            G = std::move(c);
         }
+        if (sep_band) break;  // the model's order already prefers it; a plan whose separator system needs the general kernel keeps looking
     }
     if (!G.ok) return false;
     if (want <= 0 && world == 1 && best > 0.8 * 3.0 * nP) return false;  // not worth three launches instead of one
@@ -1563,6 +1587,31 @@ static bool choose_segments(int nP, const std::vector<int>& order, const std::ve
 int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable, int rank, int world) {
     *usable = false;
     if (nP <= 0) return SVGPU_OK;
+    unsigned long long hsh = 1469598103934665603ull;
+    for (const int2& ab : blk_ab) {
+        hsh = (hsh ^ (unsigned)ab.x) * 1099511628211ull;
+        hsh = (hsh ^ (unsigned)ab.y) * 1099511628211ull;
+    }
+    const char* env_seg = std::getenv("SVGPU_SKY_SEGMENTS");
+    const int env_code = (env_seg ? 1000 + std::atoi(env_seg) : 0) + (std::getenv("SVGPU_SKY_ONE_SIDED") ? 100000 : 0) + (std::getenv("SVGPU_SKY_NO_BAND") ? 200000 : 0);
+    if (SkyPlan* Q = (SkyPlan*)ctx->ba_sky) {
+        if (Q->usable && Q->pattern_hash == hsh && Q->pattern_nP == nP && Q->pattern_rank == rank && Q->pattern_world == world && Q->pattern_env == env_code
+            && Q->seg_NB * (Q->seg ? 1 : 0) == (Q->seg ? (int)blk_ab.size() : 0) && (Q->seg || Q->dev[0].NB == (int)blk_ab.size())) {
+            *usable = true;  // (the epoch of the hand-over flags keeps counting)
+            return SVGPU_OK;
+        }
+        Q->usable = false;
+    }
+    struct Remember {  // records what the plan was made for when the function leaves with a usable plan
+        svgpu_ctx* c;
+        bool* ok;
+        unsigned long long h;
+        int nP, rank, world, env;
+        ~Remember() {
+            SkyPlan* Q = (SkyPlan*)c->ba_sky;
+            if (Q && *ok) Q->pattern_hash = h, Q->pattern_nP = nP, Q->pattern_rank = rank, Q->pattern_world = world, Q->pattern_env = env;
+        }
+    } remember{ctx, usable, hsh, nP, rank, world, env_code};
     std::vector<std::vector<int>> adj(nP);
     for (const int2& ab : blk_ab)
         if (ab.x != ab.y) {

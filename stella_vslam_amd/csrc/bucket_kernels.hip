@@ -12,7 +12,7 @@
 // triangulation matchers the Hamming cut-off and the two epipolar tests of match/base.h:67-79 in fp64 -- and emits, per query, the
 // surviving side-2 indices in scan order (count pass, scan, fill pass: one wave per query, ballot + prefix popcount keeps the
 // order).  The sequential part (best / second best, already-matched targets) is the candidate replay of match_kernels.hip.
-#include <hipcub/hipcub.hpp>
+#include "sv_sort.h"
 
 #include "svgpu_internal.h"
 #include "match_kernels.h"
@@ -172,23 +172,30 @@ __global__ __launch_bounds__(1024) void k_bucket_exscan(int32_t* __restrict__ da
 }  // namespace
 
 size_t sv_bucket_sort_bytes(int n) {
-    size_t t = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, n > 0 ? n : 1);
-    return ((t + 255) & ~size_t(255)) + 4 * (((size_t)(n > 0 ? n : 1) * 4 + 255) & ~size_t(255));
+    const size_t m = (size_t)(n > 0 ? n : 1), p4 = (m * 4 + 255) & ~size_t(255), p8 = (m * 8 + 255) & ~size_t(255);
+    return 4 * p4 + 2 * p8 + ((sv_sort_hist_ints(m) * 4 + 255) & ~size_t(255)) + 1024;
 }
 
-// (node, index) order of one side: keys_out / idx_out hold the sorted node ids and the keypoint indices
+__global__ void k_bucket_widen(const int* __restrict__ idx, int n, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (unsigned long long)(unsigned)idx[i];
+}
+__global__ void k_bucket_narrow(const unsigned long long* __restrict__ v, int n, int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (int)(unsigned)v[i];
+}
+
+// (node, index) order of one side: keys_out / idx_out hold the sorted node ids and the keypoint indices (stable: equal nodes keep index order)
 int sv_bucket_sort(svgpu_ctx* ctx, hipStream_t s, const int32_t* node_dev, int n, void* scratch, size_t scratch_bytes, unsigned* keys_out, int* idx_out) {
     if (n <= 0) return SVGPU_OK;
     char* p = (char*)scratch;
-    size_t t = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, n);
-    void* temp = p;
-    p += (t + 255) & ~size_t(255);
-    unsigned* keys_in = (unsigned*)p;
-    p += ((size_t)n * 4 + 255) & ~size_t(255);
-    int* vals_in = (int*)p;
-    p += ((size_t)n * 4 + 255) & ~size_t(255);
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += (bytes + 255) & ~size_t(255);
+        return (void*)r;
+    };
+    unsigned* keys_in = (unsigned*)take((size_t)n * 4);
+    int* vals_in = (int*)take((size_t)n * 4);
     if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "bucket sort scratch too small");
     hipLaunchKernelGGL(k_bucket_keys, dim3((n + 255) / 256), dim3(256), 0, s, node_dev, n, keys_in, vals_in);
     if (!node_dev) {  // one bucket: identity order
@@ -197,7 +204,22 @@ int sv_bucket_sort(svgpu_ctx* ctx, hipStream_t s, const int32_t* node_dev, int n
         return SVGPU_OK;
     }
     SV_HIP(ctx, hipGetLastError());
-    SV_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(temp, t, keys_in, keys_out, vals_in, idx_out, n, 0, 32, s));
+    if (n <= SV_SORT_SMALL_MAX) {  // every frame: one workgroup, the composites in LDS
+        sv_sort_small(s, keys_in, vals_in, n, keys_out, idx_out);
+        return SVGPU_OK;
+    }
+    // beyond that: the general radix sort on widened values
+    unsigned* keys_b = (unsigned*)take((size_t)n * 4);
+    unsigned long long* va = (unsigned long long*)take((size_t)n * 8);
+    unsigned long long* vb = (unsigned long long*)take((size_t)n * 8);
+    int* hist = (int*)take(sv_sort_hist_ints(n) * 4);
+    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "bucket sort scratch too small");
+    hipLaunchKernelGGL(k_bucket_widen, dim3((n + 255) / 256), dim3(256), 0, s, vals_in, n, va);
+    unsigned* const keys[2] = {keys_in, keys_b};
+    unsigned long long* const vals[2] = {va, vb};
+    const int r = sv_sort_pairs(s, keys, vals, 0, n, 32, hist);
+    SV_HIP(ctx, hipMemcpyAsync(keys_out, keys[r], (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_bucket_narrow, dim3((n + 255) / 256), dim3(256), 0, s, vals[r], n, idx_out);
     return SVGPU_OK;
 }
 

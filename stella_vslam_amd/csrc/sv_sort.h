@@ -1,0 +1,17 @@
+// Hand-written device sorts / scans shared by the BA structure builder (ba_pairs.hip) and the BoW merge-join (bucket_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+// in-place exclusive scan of data[0 .. n), total to data[n]; one workgroup, 16 elements per thread
+void sv_scan_i32(hipStream_t s, int* data, int n);
+// stable least-significant-digit radix sort (6-bit digits) of n (u32 key, u64 value) pairs by the low `bits` key bits, ping-ponging between
+// the two buffer sets; `hist` = sv_sort_hist_ints(n) ints of scratch.  The data starts in set `start`; returns the set that holds the result
+// (start ^ (passes & 1)).
+int sv_sort_passes(int bits);
+size_t sv_sort_hist_ints(size_t n);
+int sv_sort_pairs(hipStream_t s, unsigned* const keys[2], unsigned long long* const vals[2], int start, int n, int bits, int* hist);
+// n <= SV_SORT_SMALL_MAX (key, index) pairs sorted by (key, index) in ONE workgroup's LDS (bitonic network on the 64-bit composites)
+#define SV_SORT_SMALL_MAX 16384
+void sv_sort_small(hipStream_t s, const unsigned* keys_in, const int* idx_in, int n, unsigned* keys_out, int* idx_out);
