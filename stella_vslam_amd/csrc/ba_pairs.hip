@@ -76,6 +76,23 @@ __global__ void k_pair_offsets(const unsigned* __restrict__ keys, int n, int nb_
     dense_off[k] = lo;
 }
 
+__global__ void k_iota_u64(unsigned long long* __restrict__ v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (unsigned long long)(unsigned)i;
+}
+__global__ void k_copy_keys(const int* __restrict__ src, int n, unsigned* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (unsigned)src[i];
+}
+__global__ void k_narrow_u64(const unsigned long long* __restrict__ v, int n, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int)(unsigned)v[i];
+}
+__global__ void k_flag_positive(const float* __restrict__ x, int n, uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] > 0.f ? 1 : 0;
+}
+
 inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 }  // namespace
 
@@ -149,4 +166,37 @@ int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void*
         return SVGPU_OK;
     }
     return build_pairs(ctx, s, D, scratch, scratch_bytes, pair_cap, total, pairs_out, dense_off_dev, false, nullptr);
+}
+
+// Pose -> edge lists (every pose's edges in increasing edge order, whatever their level) and the "has a robust kernel" flags, built on
+// the device from the uploaded observations: a stable radix sort of (pose, edge index) + the offsets of the sorted keys.  The host used to
+// do this with a two-pass counting sort over all observations (0.5 ms of a config-5 call on four threads).
+size_t sv_ba_pose_lists_scratch_bytes(size_t E) { return 2 * pad256(E * 4) + 2 * pad256(E * 8) + pad256(sv_sort_hist_ints(E) * 4) + 1024; }
+int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes,
+                           int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev) {
+    if (E <= 0) {
+        SV_HIP(ctx, hipMemsetAsync(pe_off_dev, 0, 4 * ((size_t)P + 1), s));
+        return SVGPU_OK;
+    }
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += pad256(bytes);
+        return (void*)r;
+    };
+    unsigned* keys[2] = {(unsigned*)take((size_t)E * 4), (unsigned*)take((size_t)E * 4)};
+    unsigned long long* vals[2] = {(unsigned long long*)take((size_t)E * 8), (unsigned long long*)take((size_t)E * 8)};
+    int* hist = (int*)take(sv_sort_hist_ints(E) * 4);
+    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pose-list scratch too small");
+    const dim3 g((E + 255) / 256), b(256);
+    hipLaunchKernelGGL(k_flag_positive, g, b, 0, s, e_huber_dev, E, robust_dev);
+    hipLaunchKernelGGL(k_copy_keys, g, b, 0, s, e_pose_dev, E, keys[0]);
+    hipLaunchKernelGGL(k_iota_u64, g, b, 0, s, vals[0], E);
+    int bits = 1;
+    while ((1u << bits) < (unsigned)P && bits < 31) ++bits;
+    const int r = sv_sort_pairs(s, keys, vals, 0, E, bits, hist);
+    hipLaunchKernelGGL(k_narrow_u64, g, b, 0, s, vals[r], E, pe_idx_dev);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((P + 256) / 256), dim3(256), 0, s, keys[r], E, P, pe_off_dev);
+    SV_HIP(ctx, hipGetLastError());
+    return SVGPU_OK;
 }

@@ -22,6 +22,9 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
                       std::vector<int>& dense_off_host);
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
                             int2* pairs_out, int* dense_off_dev);
+size_t sv_ba_pose_lists_scratch_bytes(size_t E);
+int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes,
+                           int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev);
 
 namespace {
 
@@ -177,25 +180,6 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     if (P < 0 || L < 0 || E < 0 || (P > 0 && (!pr->pose_cw || !pr->pose_fixed || !pr->intrinsics)) || (L > 0 && !pr->points)
         || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || (!outlier_out && !single_stage))))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: inconsistent problem");
-    bool lm_major = true;  // observations already grouped by landmark (the order local_bundle_adjuster_g2o.cc:168-227 creates its edges in)
-    {
-        const int nv = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD") ? 4 : 1;  // (four host threads at global-BA sizes, as for the staging passes below)
-        int bad[4] = {0, 0, 0, 0}, unsorted[4] = {0, 0, 0, 0};
-        auto check = [&](int q) {
-            int b = 0, u = 0;
-            for (size_t e = (size_t)E * q / nv, end = (size_t)E * (q + 1) / nv; e < end; ++e) {
-                b |= pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L;
-                u |= e != 0 && pr->obs_point[e] < pr->obs_point[e - 1];
-            }
-            bad[q] = b, unsorted[q] = u;
-        };
-        std::vector<std::thread> th;
-        for (int q = 1; q < nv; ++q) th.emplace_back(check, q);
-        check(0);
-        for (auto& t : th) t.join();
-        if (bad[0] | bad[1] | bad[2] | bad[3]) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
-        lm_major = !(unsorted[0] | unsorted[1] | unsorted[2] | unsorted[3]);
-    }
     const bool sharded = allreduce != nullptr;
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
     ctx->ba_ar_fn = allreduce;  // (the segmented envelope solve of ba_skyline.hip exchanges through the same all-reduce)
@@ -273,25 +257,44 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     float* const e_uvr = (float*)(hs + in.e_uvr);
     float* const e_w = (float*)(hs + in.e_w);
     float* const e_hub = (float*)(hs + in.e_hub);
-    uint8_t* const robust = (uint8_t*)(hs + in.robust);
-    int* const pe_off = (int*)(hs + in.pe_off);
-    int* const pe_idx = (int*)(hs + in.pe_idx);
     std::vector<int> perm;  // sorted position -> caller's observation index (empty = identity)
     std::vector<uint8_t> level(E, 0);
-    if (lm_major) {  // grouped by landmark already: the offsets are the run boundaries (one sequential pass, no histogram)
-        int e = 0;
-        for (int l = 0; l <= L; ++l) {
-            while (e < E && pr->obs_point[e] < l) ++e;
-            lm_off[l] = e;
-        }
+    const int nth = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD") ? 4 : 1;  // host threads of the staging passes at global-BA sizes
+    // ONE pass over the observation indices (nth contiguous ranges): range check, "already grouped by landmark?" (the order
+    // local_bundle_adjuster_g2o.cc:168-227 creates its edges in) and -- valid in that case -- the landmark offsets from the run boundaries
+    bool lm_major = true;
+    {
+        int bad[4] = {0, 0, 0, 0}, unsorted[4] = {0, 0, 0, 0};
+        auto scan_range = [&](int q) {
+            int bd = 0, un = 0;
+            for (size_t e = (size_t)E * q / nth, end = (size_t)E * (q + 1) / nth; e < end; ++e) {
+                const int p = pr->obs_pose[e], l = pr->obs_point[e];
+                if (p < 0 || p >= P || l < 0 || l >= L) {
+                    bd = 1;
+                    continue;
+                }
+                const int prev = e == 0 ? -1 : pr->obs_point[e - 1];
+                if (prev >= L) continue;  // (flagged by the thread that owns e - 1)
+                if (l < prev) un = 1;
+                else if (l != prev)
+                    for (int k = (prev < 0 ? 0 : prev + 1); k <= l; ++k) lm_off[k] = (int)e;  // landmarks prev + 1 .. l start here
+            }
+            bad[q] = bd, unsorted[q] = un;
+        };
+        std::vector<std::thread> th;
+        for (int q = 1; q < nth; ++q) th.emplace_back(scan_range, q);
+        scan_range(0);
+        for (auto& t : th) t.join();
+        if (bad[0] | bad[1] | bad[2] | bad[3]) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+        lm_major = !(unsorted[0] | unsorted[1] | unsorted[2] | unsorted[3]);
+        if (lm_major)
+            for (int k = (E > 0 ? pr->obs_point[E - 1] + 1 : 0); k <= L; ++k) lm_off[k] = E;
     }
-    else {
+    if (!lm_major) {
         for (int l = 0; l <= L; ++l) lm_off[l] = 0;
         for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
         for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
     }
-    const int nth = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD") ? 4 : 1;  // host threads of the staging passes at global-BA sizes
-    std::vector<int> pe_cnt((size_t)nth * P, 0);  // observations per (thread range, pose)
     if (lm_major) {
         // (a global-BA sized problem is 34 MB of observations: four host threads share the copy into the staging image)
         auto copy_range = [&](size_t a, size_t b) {
@@ -301,7 +304,6 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
             if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
             else memset(e_hub + a, 0, 4 * (b - a));
-            for (size_t k = a; k < b; ++k) robust[k] = e_hub[k] > 0.f;
         };
         std::vector<std::thread> th;
         for (int q = 1; q < nth; ++q) th.emplace_back(copy_range, (size_t)E * q / nth, (size_t)E * (q + 1) / nth);
@@ -323,36 +325,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             e_hub[k] = pr->obs_huber_delta ? pr->obs_huber_delta[e] : 0.f;
         }
     }
-    if (!lm_major)
-        for (int k = 0; k < E; ++k) robust[k] = e_hub[k] > 0.f;
-    // pose -> edges (all poses, all levels: the kernels skip excluded edges), in increasing edge order
-    // (a counting sort by pose whose two passes run on `nth` contiguous ranges of k: range q's entries of a pose follow range q - 1's)
-    {
-        auto run = [&](auto&& fn) {
-            std::vector<std::thread> th;
-            for (int q = 1; q < nth; ++q) th.emplace_back(fn, q);
-            fn(0);
-            for (auto& t : th) t.join();
-        };
-        run([&](int q) {
-            int* c = pe_cnt.data() + (size_t)q * P;
-            for (size_t k = (size_t)E * q / nth, b = (size_t)E * (q + 1) / nth; k < b; ++k) c[e_pose[k]]++;
-        });
-        int at = 0;
-        for (int p = 0; p < P; ++p) {
-            pe_off[p] = at;
-            for (int q = 0; q < nth; ++q) {
-                const int c = pe_cnt[(size_t)q * P + p];
-                pe_cnt[(size_t)q * P + p] = at;  // becomes the fill cursor of (range q, pose p)
-                at += c;
-            }
-        }
-        pe_off[P] = at;
-        run([&](int q) {
-            int* c = pe_cnt.data() + (size_t)q * P;
-            for (size_t k = (size_t)E * q / nth, b = (size_t)E * (q + 1) / nth; k < b; ++k) pe_idx[c[e_pose[k]]++] = (int)k;
-        });
-    }
+    // (the pose -> edge lists and the robust-kernel flags are built on the device once the observations are there: sv_ba_build_pose_lists)
     memcpy(hs + in.pose, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
     memcpy(hs + in.intr, pr->intrinsics, sizeof(double) * 5 * (size_t)P);
@@ -392,7 +365,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
-    const size_t pair_scratch = sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap);
+    const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total;
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
@@ -531,6 +504,13 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
 
 #define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
     H2D(D.pose_buf[0], hs, in.total);
+    {   // pose -> edge lists + robust flags on the device; the sort's scratch borrows the (not yet used) W buffer when it fits, else the pair scratch
+        const size_t want = sv_ba_pose_lists_scratch_bytes((size_t)E);
+        void* sc = sizeof(double) * 18 * (size_t)E >= want ? (void*)D.W : (void*)d_pair_scratch;
+        const size_t sc_bytes = sizeof(double) * 18 * (size_t)E >= want ? sizeof(double) * 18 * (size_t)E : pair_scratch;
+        const int rp = sv_ba_build_pose_lists(ctx, s, d_e_pose, d_e_hub, E, P, sc, sc_bytes, d_pe_off, d_pe_idx, D.e_robust);
+        if (rp) return rp;
+    }
     SV_HIP(ctx, hipMemsetAsync(D.e_level, 0, E, s));
     SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
     BaCtl ctl0;
