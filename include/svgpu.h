@@ -460,6 +460,13 @@ int svgpu_bow_vocabulary_upload(svgpu_ctx* ctx, int n_nodes, const int32_t* chil
 void svgpu_bow_vocabulary_free(svgpu_vocabulary* vocab);
 int svgpu_bow_transform(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int node_level, int32_t* word_id,
                         float* weight, int32_t* node_id);
+/* The reference's DEFAULT BoW build: fbow::Vocabulary::transform(features, level = 4, bow_vec, bow_feat_vec) (data/bow_vocabulary.cc:20-22; FBoW =
+ * stella-cv/FBoW, restated from its published sources -- the submodule is empty in the reference checkout, so parity is unpinned).  Same
+ * descent; differences to the DBoW2 form above: `store_level` counts DOWN from the root (DBoW2's levelsup counts up from the leaves), the
+ * bow_feat_vec key is FBoW's PATH CODE of the node ((code << ceil(log2 k)) | child index per level), and a leaf met above the store level
+ * files its feature under the code of the block it was found in.  k = the vocabulary's branching factor. */
+int svgpu_fbow_transform(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int store_level, int k,
+                         int32_t* word_id, float* weight, uint32_t* node_code);
 
 /* match::stereo::compute (match/stereo.cc:20-114): for every left keypoint the closest right keypoint in its row band
  * (rows +-2*scale, octave +-1, disparity in [0, focal_x_baseline / true_baseline], Hamming < 75), then the 11x11 L1 patch

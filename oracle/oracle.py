@@ -341,6 +341,21 @@ def bow_transform(tree, desc, node_level):
     return ow, owt, on
 
 
+def fbow_transform(tree, desc, store_level, k):
+    """fbow::Vocabulary::transform(features, level, r, r2) per descriptor: (word_id, weight, r2 key = path code of the node at `store_level`
+    counted from the root, or of the block in which a leaf was met above it)."""
+    off = np.ascontiguousarray(tree["child_off"], np.int32)
+    ch = np.ascontiguousarray(tree["children"], np.int32)
+    nd = np.ascontiguousarray(tree["node_desc"], np.uint8)
+    nw = np.ascontiguousarray(tree["node_weight"], np.float32)
+    wi = np.ascontiguousarray(tree["word_id"], np.int32)
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(d)
+    ow, owt, on = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    lib().orc_fbow_transform(len(off) - 1, _p(off), _p(ch), _p(nd), _p(nw), _p(wi), int(store_level), int(k), n, _p(d), _p(ow), _p(owt), _p(on))
+    return ow, owt, on
+
+
 # ------------------------------------------------------------------------------------------- landmark refresh
 
 def landmarks_compute_descriptor(obs_off, obs_desc):

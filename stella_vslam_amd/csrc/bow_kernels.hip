@@ -59,6 +59,53 @@ __global__ void __launch_bounds__(256) k_bow_descend(int n, const uint32_t* __re
     }
 }
 
+// fbow::Vocabulary::transform(features, level, r, r2) (the reference's default BoW build, data/bow_vocabulary.cc:20-22): the same descent, but
+// the r2 key is FBoW's: the PATH CODE (child indices, nbits each) of the node at `store_level` counted DOWN from the root, taken before the
+// step of that level; a leaf met above the store level files the feature under the code of the block it was found in.
+__global__ void __launch_bounds__(256) k_fbow_descend(int n, const uint32_t* __restrict__ desc, const int32_t* __restrict__ child_off,
+                                                      const int32_t* __restrict__ children, const uint32_t* __restrict__ node_desc,
+                                                      const float* __restrict__ node_weight, const int32_t* __restrict__ word_id, int store_level,
+                                                      int nbits, int32_t* __restrict__ out_word, float* __restrict__ out_weight,
+                                                      uint32_t* __restrict__ out_code) {
+    const int t = blockIdx.x * 256 + threadIdx.x, f = t >> 3, j = t & 7;
+    const bool live = f < n;
+    const uint32_t mine = live ? desc[(size_t)f * 8 + j] : 0u;
+    int cur = 0, level = 0;
+    uint32_t code = 0, key = 0;
+    int beg = live ? child_off[0] : 0, end = live ? child_off[1] : 0;
+    while (end > beg) {
+        int best = beg;
+        unsigned best_d = 0xFFFFFFFFu;
+        for (int c = beg; c < end; ++c) {
+            unsigned d = __popc(mine ^ node_desc[(size_t)children[c] * 8 + j]);
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            d += __shfl_xor(d, 4);
+            if (d < best_d) {  // strict: the first child keeps ties
+                best_d = d;
+                best = c;
+            }
+        }
+        if (level == store_level) key = code;
+        const int child = children[best];
+        const int cb = child_off[child], ce = child_off[child + 1];
+        cur = child;
+        if (ce == cb) {  // a leaf ends the descent
+            if (level < store_level) key = code;
+            break;
+        }
+        code = (code << nbits) | (uint32_t)(best - beg);
+        ++level;
+        beg = cb;
+        end = ce;
+    }
+    if (live && j == 0) {
+        out_word[f] = word_id[cur];
+        out_weight[f] = node_weight[cur];
+        out_code[f] = key;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -115,8 +162,19 @@ void svgpu_bow_vocabulary_free(svgpu_vocabulary* vocab) {
     delete vocab;
 }
 
+static int bow_transform_impl(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int node_level, int fbow_k, int32_t* word_id,
+                              float* weight, int32_t* node_id);
 int svgpu_bow_transform(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int node_level, int32_t* word_id,
                         float* weight, int32_t* node_id) {
+    return bow_transform_impl(ctx, vocab, desc, n, node_level, 0, word_id, weight, node_id);
+}
+int svgpu_fbow_transform(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int store_level, int k, int32_t* word_id,
+                         float* weight, uint32_t* node_code) {
+    if (k < 2 || store_level < 0) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_fbow_transform: bad arguments");
+    return bow_transform_impl(ctx, vocab, desc, n, store_level, k, word_id, weight, reinterpret_cast<int32_t*>(node_code));
+}
+static int bow_transform_impl(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uint8_t* desc, int n, int node_level, int fbow_k, int32_t* word_id,
+                              float* weight, int32_t* node_id) {
     if (!ctx || !vocab || n < 0 || vocab->device != ctx->device || (n > 0 && (!desc || !word_id || !weight || !node_id)))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_bow_transform: bad arguments");
     if (n == 0) return SVGPU_OK;
@@ -130,8 +188,15 @@ int svgpu_bow_transform(svgpu_ctx* ctx, const svgpu_vocabulary* vocab, const uin
     float* d_w = (float*)((char*)d_word + pad((size_t)n * 4));
     int32_t* d_node = (int32_t*)((char*)d_w + pad((size_t)n * 4));
     SV_HIP(ctx, hipMemcpyAsync(d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_bow_descend, dim3(((size_t)n * 8 + 255) / 256), dim3(256), 0, s, n, d_desc, vocab->child_off, vocab->children, vocab->node_desc,
-                       vocab->node_weight, vocab->word_id, node_level, d_word, d_w, d_node);
+    if (fbow_k > 0) {
+        int nbits = 0;
+        while ((1 << nbits) < fbow_k) ++nbits;
+        hipLaunchKernelGGL(k_fbow_descend, dim3(((size_t)n * 8 + 255) / 256), dim3(256), 0, s, n, d_desc, vocab->child_off, vocab->children, vocab->node_desc,
+                           vocab->node_weight, vocab->word_id, node_level, nbits, d_word, d_w, reinterpret_cast<uint32_t*>(d_node));
+    }
+    else
+        hipLaunchKernelGGL(k_bow_descend, dim3(((size_t)n * 8 + 255) / 256), dim3(256), 0, s, n, d_desc, vocab->child_off, vocab->children, vocab->node_desc,
+                           vocab->node_weight, vocab->word_id, node_level, d_word, d_w, d_node);
     SV_HIP(ctx, hipGetLastError());
     SV_HIP(ctx, hipMemcpyAsync(word_id, d_word, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipMemcpyAsync(weight, d_w, (size_t)n * 4, hipMemcpyDeviceToHost, s));

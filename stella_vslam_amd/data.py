@@ -125,12 +125,24 @@ def landmarks_update_mean_normal_and_obs_scale_variance(ctx: Context, obs_off, o
 class bow_vocabulary:
     """data/bow_vocabulary.h on a flat tree (node 0 = root; `child_off` / `children` CSR; `node_desc` n x 32; `node_weight`,
     `word_id` per node; `depth` = L).  transform() is compute_bow (data/bow_vocabulary.cc:18-24): the tree descent runs on the
-    device, the two sparse maps are assembled here as DBoW2 does (TF-IDF weights summed per word, then L1-normalised)."""
+    device, the two sparse maps are assembled here.  Two frameworks, as in the reference's build switch (USE_DBOW2):
+      framework = "fbow"   the DEFAULT build: fbow::Vocabulary::transform(descriptors, 4, bow_vec, bow_feat_vec) -- the store level counts
+                           DOWN from the root, bow_feat_vec is keyed by FBoW's path code of the node, every word's weight is summed (no
+                           stop-word skip) and the vector is normalised (`norm`: "L2" as upstream FBoW's transform does, or "L1")
+      framework = "dbow2"  USE_DBOW2: TemplatedVocabulary::transform(features, bow_vec, bow_feat_vec, 4) -- levels UP from the leaves,
+                           node index keys, zero-weight words skipped, L1 normalisation
+    Both are restated from the libraries' published sources (neither is in the reference checkout): parity unpinned."""
 
-    def __init__(self, ctx: Context, child_off, children, node_desc, node_weight, word_id, depth: int):
+    def __init__(self, ctx: Context, child_off, children, node_desc, node_weight, word_id, depth: int, framework: str = "dbow2", k: int | None = None,
+                 norm: str | None = None):
         self.ctx = ctx
         self.depth_ = int(depth)
+        if framework not in ("dbow2", "fbow"):
+            raise ValueError(f"unknown BoW framework {framework!r}")
+        self.framework_ = framework
         off, ch = np.ascontiguousarray(child_off, np.int32), np.ascontiguousarray(children, np.int32)
+        self.k_ = int(k) if k is not None else int(np.diff(off).max(initial=2))
+        self.norm_ = norm or ("L2" if framework == "fbow" else "L1")
         nd = np.ascontiguousarray(node_desc, np.uint8).reshape(-1, 32)
         nw, wi = np.ascontiguousarray(node_weight, np.float32), np.ascontiguousarray(word_id, np.int32)
         self._h = C.c_void_p()
@@ -139,32 +151,47 @@ class bow_vocabulary:
 
     @classmethod
     def load_fbow(cls, ctx: Context, path: str) -> "bow_vocabulary":
-        """bow_vocabulary_util::load (data/bow_vocabulary.cc:26-47) for an .fbow file; see read_fbow for what is unverified.
-        NOTE fbow::Vocabulary::transform(features, level, ...) counts `level` DOWN from the root, DBoW2's levelsup counts UP from
-        the leaves: a vocabulary loaded from .fbow records the node at depth `levels_up` (compute_bow passes 4 to both)."""
+        """bow_vocabulary_util::load (data/bow_vocabulary.cc:26-47) for an .fbow file; see read_fbow for what is unverified."""
         t = read_fbow(path)
-        v = cls(ctx, t["child_off"], t["children"], t["node_desc"], t["node_weight"], t["word_id"], t["depth"])
-        v.level_from_root_ = True
-        return v
+        return cls(ctx, t["child_off"], t["children"], t["node_desc"], t["node_weight"], t["word_id"], t["depth"], framework="fbow", k=t.get("k"))
 
     def descend(self, descriptors, levels_up: int = 4):
+        """DBoW2 form: (word, weight, node index at depth L - levels_up).  FBoW form: use descend_fbow."""
         d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
         n = len(d)
         word, weight, node = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.int32)
-        level = min(levels_up, self.depth_) if getattr(self, "level_from_root_", False) else max(self.depth_ - levels_up, 0)
+        level = max(self.depth_ - levels_up, 0)
         self.ctx.check(lib().svgpu_bow_transform(self.ctx.handle, self._h, _p(d), n, level, _p(word), _p(weight), _p(node)),
                        "svgpu_bow_transform")
         return word, weight, node
 
+    def descend_fbow(self, descriptors, store_level: int = 4):
+        """fbow::Vocabulary::transform's descent: (word, weight, bow_feat_vec key = path code at `store_level` from the root)."""
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        word, weight, code = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        self.ctx.check(lib().svgpu_fbow_transform(self.ctx.handle, self._h, _p(d), n, int(store_level), self.k_, _p(word), _p(weight), _p(code)),
+                       "svgpu_fbow_transform")
+        return word, weight, code
+
     def transform(self, descriptors, levels_up: int = 4):
-        """-> (bow_vec: {word_id: weight}, bow_feat_vec: {node_id: [feature indices]})"""
-        word, weight, node = self.descend(descriptors, levels_up)
+        """-> (bow_vec: {word_id: weight}, bow_feat_vec: {node key: [feature indices]}); `levels_up` is the literal 4 compute_bow passes."""
         bow_vec, feat = {}, {}
-        for i in range(len(word)):
-            if weight[i] > 0:  # DBoW2 skips zero-weight words (stop words)
+        if self.framework_ == "fbow":
+            word, weight, node = self.descend_fbow(descriptors, levels_up)
+            for i in range(len(word)):
                 bow_vec[int(word[i])] = bow_vec.get(int(word[i]), 0.0) + float(weight[i])
                 feat.setdefault(int(node[i]), []).append(i)
-        norm = sum(abs(v) for _, v in sorted(bow_vec.items()))
+        else:
+            word, weight, node = self.descend(descriptors, levels_up)
+            for i in range(len(word)):
+                if weight[i] > 0:  # DBoW2 skips zero-weight words (stop words)
+                    bow_vec[int(word[i])] = bow_vec.get(int(word[i]), 0.0) + float(weight[i])
+                    feat.setdefault(int(node[i]), []).append(i)
+        if self.norm_ == "L2":
+            norm = float(np.sqrt(sum(v * v for _, v in sorted(bow_vec.items()))))
+        else:
+            norm = sum(abs(v) for _, v in sorted(bow_vec.items()))
         if norm > 0.0:
             bow_vec = {k: v / norm for k, v in bow_vec.items()}
         return dict(sorted(bow_vec.items())), dict(sorted(feat.items()))

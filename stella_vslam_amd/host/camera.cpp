@@ -110,8 +110,8 @@ void update_mean_normal_and_obs_scale_variance(svgpu_ctx* ctx, const std::vector
 }
 
 bow_vocabulary_hip::bow_vocabulary_hip(svgpu_ctx* ctx, const std::vector<int>& child_off, const std::vector<int>& children, const cv::Mat& node_desc,
-                                       const std::vector<float>& node_weight, const std::vector<int>& word_id, int depth)
-    : ctx_(ctx), depth_(depth) {
+                                       const std::vector<float>& node_weight, const std::vector<int>& word_id, int depth, int fbow_k)
+    : ctx_(ctx), depth_(depth), fbow_k_(fbow_k) {
     const int n = (int)child_off.size() - 1;
     std::vector<uint8_t> packed((size_t)node_desc.rows * 32);
     for (int i = 0; i < node_desc.rows; ++i) std::memcpy(&packed[(size_t)i * 32], node_desc.ptr(i), 32);
@@ -131,6 +131,20 @@ void bow_vocabulary_hip::compute_bow(const cv::Mat& descriptors, std::map<unsign
     for (int i = 0; i < n; ++i) std::memcpy(&packed[(size_t)i * 32], descriptors.ptr(i), 32);
     std::vector<int32_t> word((size_t)n), node((size_t)n);
     std::vector<float> weight((size_t)n);
+    if (fbow_k_ > 0) {  // fbow::Vocabulary::transform(descriptors, levels_up (= 4, counted from the ROOT), bow_vec, bow_feat_vec)
+        std::vector<uint32_t> code((size_t)n);
+        const int rf = svgpu_fbow_transform(ctx_, vocab_, packed.data(), n, levels_up, fbow_k_, word.data(), weight.data(), code.data());
+        if (rf != SVGPU_OK) throw std::runtime_error(std::string("svgpu_fbow_transform: ") + svgpu_last_error(ctx_));
+        for (int i = 0; i < n; ++i) {
+            bow_vec[(unsigned int)word[(size_t)i]] += (double)weight[(size_t)i];
+            bow_feat_vec[code[(size_t)i]].push_back((unsigned int)i);
+        }
+        double norm = 0.0;
+        for (const auto& kv : bow_vec) norm += kv.second * kv.second;
+        if (norm > 0.0)
+            for (auto& kv : bow_vec) kv.second *= 1.0 / std::sqrt(norm);
+        return;
+    }
     const int rc = svgpu_bow_transform(ctx_, vocab_, packed.data(), n, std::max(depth_ - levels_up, 0), word.data(), weight.data(), node.data());
     if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_bow_transform: ") + svgpu_last_error(ctx_));
     for (int i = 0; i < n; ++i)

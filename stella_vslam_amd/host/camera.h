@@ -114,11 +114,13 @@ void update_mean_normal_and_obs_scale_variance(svgpu_ctx* ctx, const std::vector
 //! data::bow_vocabulary (data/bow_vocabulary.h) on a flat tree kept resident on the device: node 0 = root, children of node i =
 //! children[child_off[i] .. child_off[i+1]) (none = leaf), node_desc n x 32, weight / word id per node, `depth` = L.
 //! compute_bow() is bow_vocabulary_util::compute_bow (data/bow_vocabulary.cc:18-24): the descent runs on the device, the two sparse
-//! maps are assembled here (weights summed per word, L1-normalised as the ORB vocabulary's TF-IDF / L1 setting prescribes).
+//! maps are assembled here.  `fbow_k` > 0 selects the reference's DEFAULT build -- fbow::Vocabulary::transform(descriptors, 4, ...): store level
+//! counted from the root, bow_feat_vec keyed by FBoW's path code, every word summed, L2-normalised as upstream FBoW does -- with k = the
+//! vocabulary's branching factor; 0 = the USE_DBOW2 build (levels up from the leaves, node-index keys, stop words skipped, L1).
 class bow_vocabulary_hip {
 public:
     bow_vocabulary_hip(svgpu_ctx* ctx, const std::vector<int>& child_off, const std::vector<int>& children, const cv::Mat& node_desc,
-                       const std::vector<float>& node_weight, const std::vector<int>& word_id, int depth);
+                       const std::vector<float>& node_weight, const std::vector<int>& word_id, int depth, int fbow_k = 0);
     ~bow_vocabulary_hip();
     bow_vocabulary_hip(const bow_vocabulary_hip&) = delete;
     bow_vocabulary_hip& operator=(const bow_vocabulary_hip&) = delete;
@@ -128,7 +130,7 @@ public:
 private:
     svgpu_ctx* ctx_;
     svgpu_vocabulary* vocab_ = nullptr;
-    int depth_;
+    int depth_, fbow_k_ = 0;
 };
 }  // namespace data
 }  // namespace stella_vslam_hip

@@ -105,3 +105,48 @@ def test_fbow_file_round_trip(tmp_path):
     raw[:len(raw) - 100].tofile(str(tmp_path / "short.fbow"))
     with pytest.raises(ValueError, match="truncated"):
         data.read_fbow(str(tmp_path / "short.fbow"))
+
+
+def literal_fbow(tree, d, store_level, k):
+    """fbow::Vocabulary::_transform2 as a plain walk: the r2 key is the path code of the current block's node, filed at the store level
+    (counted from the root) or, when a leaf comes first, under the block the leaf was found in."""
+    nbits = int(np.ceil(np.log2(k)))
+    bits = lambda a: np.unpackbits(a)
+    cur, level, code, key = 0, 0, 0, 0
+    while True:
+        ch = tree["kids"][cur]
+        dist = [int((bits(d) != bits(tree["node_desc"][c])).sum()) for c in ch]
+        bi = int(np.argmin(dist))  # argmin returns the FIRST minimum
+        if level == store_level:
+            key = code
+        child = ch[bi]
+        if not tree["kids"][child]:
+            if level < store_level:
+                key = code
+            return int(tree["word_id"][child]), float(tree["node_weight"][child]), key
+        code = (code << nbits) | bi
+        level += 1
+        cur = child
+
+
+def test_fbow_transform_restated():
+    """The FBoW form of compute_bow (the reference's default build): level from the root, path-code keys, the leaf-above-the-store-level rule."""
+    rng = np.random.default_rng(11)
+    tree = make_tree(rng, k=6, depth=5, prune=0.15)
+    leaves = np.flatnonzero(tree["word_id"] >= 0)
+    q = tree["node_desc"][rng.choice(leaves, 300)].copy()
+    q[::7] = rng.integers(0, 256, (len(q[::7]), 32), dtype=np.uint8)
+    early = 0
+    for store_level in (0, 1, 2, 4, 7):
+        w, wt, key = O.fbow_transform(tree, q, store_level, 6)
+        for i in range(len(q)):
+            lw, lwt, lkey = literal_fbow(tree, q[i], store_level, 6)
+            assert (w[i], np.float32(wt[i]), int(key[i])) == (lw, np.float32(lwt), lkey), (store_level, i)
+        if store_level == 4:
+            # path codes of depth-4 nodes use 3 bits per level: codes of features that stopped early are shorter
+            early = int((key < (1 << 9)).sum())
+    assert early > 0  # the pruned tree does have leaves above level 4
+    # same words as the DBoW2 form (the descent is the same), different keys
+    w2, _, _ = O.bow_transform(tree, q, 1)
+    w, _, _ = O.fbow_transform(tree, q, 4, 6)
+    assert np.array_equal(w, w2)
