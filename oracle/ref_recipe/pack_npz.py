@@ -31,3 +31,12 @@ m = {k: np.load(os.path.join(src, f"ref_{k}.npy")) for k in ("match_a", "match_b
 if m:
     np.savez_compressed(os.path.join(dst, "ref_match_base.npz"), **m)
     print("wrote", os.path.join(dst, "ref_match_base.npz"))
+
+b = {k: np.load(os.path.join(src, f"ref_ba_config3_{k}.npy")) for k in ("pose_cw", "points", "outlier", "stats") if os.path.exists(os.path.join(src, f"ref_ba_config3_{k}.npy"))}
+if len(b) == 4:
+    np.savez_compressed(os.path.join(dst, "ref_ba_config3.npz"), **b)
+    print("wrote", os.path.join(dst, "ref_ba_config3.npz"))
+w = {k: np.load(os.path.join(src, f"ref_{k}.npy")) for k in ("bow_vec", "bow_feat_vec") if os.path.exists(os.path.join(src, f"ref_{k}.npy"))}
+if len(w) == 2:
+    np.savez_compressed(os.path.join(dst, "ref_bow.npz"), **w)
+    print("wrote", os.path.join(dst, "ref_bow.npz"))
