@@ -561,6 +561,14 @@ int svgpu_ba_last_envelope_plan(svgpu_ctx* ctx, int* info);
 int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab, const double* Sblk, const double* g, int cuts, int world,
                                    double* x, int* info);
 
+/* The same walk for ONE RANK of the distributed factorisation (tests/test_distributed_cpu.py drives it over gloo): the rank eliminates only
+ * the jobs it owns; `allreduce(user, host_buf, count, NULL)` sums a HOST buffer of doubles in place across the ranks (the exchange of the
+ * separator contributions and of the solution, as in the sharded bundle adjusters).  Every rank returns the single-rank solution, bit for
+ * bit; info[5] = jobs this rank eliminated.  allreduce == NULL: svgpu_selftest_segmented_solve. */
+int svgpu_selftest_segmented_solve_rank(int nP, int NB, const int* blk_ab, const double* Sblk, const double* g, int cuts, int rank, int world,
+                                        int (*allreduce)(void* user, double* buf, size_t count, void* stream), void* allreduce_user, double* x,
+                                        int* info);
+
 /* Host in/out, synchronous.  The Levenberg-Marquardt loop (damping trials, rho test, terminate_action) runs on the device; the
  * host enqueues the trials of a stage and reads the control block back once per stage (plus once per rejected trial).
  *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled at every damping-trial boundary

@@ -1857,7 +1857,17 @@ extern "C" int svgpu_ba_last_envelope_plan(svgpu_ctx* ctx, int* info) {
 // eliminate every job's columns, gather what they leave onto the separator system, solve it, substitute backwards -- and returns x.
 // tests/test_sky_segments.py holds it against a dense solve: that pins the orders, the envelopes, the block maps and the transposition
 // flags on the CPU, so that what is left to the GPU tests is the kernels' own mechanics.
+extern "C" int svgpu_selftest_segmented_solve_rank(int nP, int NB, const int* blk_ab_in, const double* Sblk, const double* g, int cuts, int rank, int world,
+                                                  svgpu_allreduce_fn allreduce, void* allreduce_user, double* x, int* info);
 extern "C" int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab_in, const double* Sblk, const double* g, int cuts, int world, double* x, int* info) {
+    return svgpu_selftest_segmented_solve_rank(nP, NB, blk_ab_in, Sblk, g, cuts, 0, world, nullptr, nullptr, x, info);
+}
+// One RANK of the distributed form (host arithmetic; `allreduce` sums a HOST buffer of doubles in place across the ranks -- the gloo test of
+// tests/test_distributed_cpu.py): the rank eliminates only the jobs it owns, the exchange buffer and the solution cross ranks exactly as
+// in sv_sky_solve (zeros outside the own jobs, rank 0 contributes the separator unknowns).  allreduce == NULL: every job is local.
+extern "C" int svgpu_selftest_segmented_solve_rank(int nP, int NB, const int* blk_ab_in, const double* Sblk, const double* g, int cuts, int rank, int world,
+                                                  svgpu_allreduce_fn allreduce, void* allreduce_user, double* x, int* info) {
+    if (world < 1 || rank < 0 || rank >= world) return -1;
     if (nP <= 0 || NB <= 0 || !blk_ab_in || !Sblk || !g || !x || !info) return -1;
     std::vector<int2> blk_ab(NB);
     std::vector<std::vector<int>> adj(nP);
@@ -1888,7 +1898,10 @@ extern "C" int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab_
     }
     for (int a = 0; a < nP; ++a)
         for (int c = 0; c < 6; ++c) A[(size_t)LY.yoff[a] + c] = g[a * 6 + c];
+    int owned = 0;
     for (int q = 0; q < nj; ++q) {  // the jobs (k_sky_band in job mode): eliminate nC columns, export the trailing ns x ns blocks and y
+        if (allreduce && G.owner[q] != rank) continue;
+        ++owned;
         const HostSky& h = G.job[q];
         if (!host_env_eliminate(h, A.data() + LY.job_val[q], A.data() + LY.job_dinv[q], A.data() + LY.job_y[q], G.nC[q])) return 2;
         const int nC = G.nC[q], ns = G.ns[q];
@@ -1903,6 +1916,7 @@ extern "C" int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab_
                 for (int c = 0; c < 6; ++c) X[(size_t)ns * (ns + 1) / 2 * 36 + 6 * r + c] = A[LY.job_y[q] + (size_t)(nC + r) * 6 + c];
         }
     }
+    if (allreduce && G.xch_doubles > 0 && allreduce(allreduce_user, A.data() + LY.xch, G.xch_doubles, nullptr) != 0) return -2;
     std::vector<double> sol((size_t)nP * 6, 0.0);
     if (nsep > 0) {  // k_seg_gather, then the separator solve
         for (size_t b = 0; b < G.sep.nblocks; ++b)
@@ -1926,6 +1940,7 @@ extern "C" int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab_
             for (int c = 0; c < 6; ++c) sol[(size_t)G.sep_order[p] * 6 + c] = A[LY.sep_y + (size_t)p * 6 + c];
     }
     for (int q = 0; q < nj; ++q) {  // k_seg_backward
+        if (allreduce && G.owner[q] != rank) continue;
         const HostSky& h = G.job[q];
         double* y = A.data() + LY.job_y[q];
         for (int r = 0; r < G.ns[q]; ++r)
@@ -1934,6 +1949,13 @@ extern "C" int svgpu_selftest_segmented_solve(int nP, int NB, const int* blk_ab_
         for (int k = 0; k < G.nC[q]; ++k)
             for (int c = 0; c < 6; ++c) sol[(size_t)G.order[q][k] * 6 + c] = y[(size_t)k * 6 + c];
     }
+    if (allreduce) {  // the solution exchange: own columns + (rank 0) the separator unknowns, zeros elsewhere
+        if (rank != 0)
+            for (int p = 0; p < nsep; ++p)
+                for (int c = 0; c < 6; ++c) sol[(size_t)G.sep_order[p] * 6 + c] = 0.0;
+        if (allreduce(allreduce_user, sol.data(), sol.size(), nullptr) != 0) return -2;
+    }
+    info[5] = allreduce ? owned : info[5];  // (distributed form: the jobs this rank eliminated)
     for (size_t t = 0; t < sol.size(); ++t) x[t] = sol[t];
     return 0;
 }

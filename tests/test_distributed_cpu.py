@@ -44,6 +44,24 @@ def _worker(rank, world, port, q):
         counts = [None] * world
         dist.all_gather_object(counts, sh["_obs_index"].tolist())
         assert sorted(sum(counts, [])) == list(range(len(sc["obs_pose"])))
+        # 5. the DISTRIBUTED FACTORISATION of the reduced camera system (csrc/ba_skyline.hip: segmented envelope elimination): this rank
+        #    eliminates only the jobs it owns, what they leave on the separators and the solution cross ranks through this very all-reduce
+        #    (host walk of the plan the kernels walk: svgpu_selftest_segmented_solve_rank) -- every rank ends with the single-rank solution, bit for bit
+        from stella_vslam_amd._lib import lib
+        from tests.test_sky_segments import _ring, _system
+        n = 300
+        ab, Sb, g, dense = _system(n, _ring(n, 4), seed=3)
+        x1, xr = np.zeros(6 * n), np.zeros(6 * n)
+        info1, infor = np.zeros(8, np.int32), np.zeros(8, np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        assert lib().svgpu_selftest_segmented_solve(n, len(ab), p(ab), p(Sb), p(g), 5, 1, p(x1), p(info1)) == 0
+        rc = lib().svgpu_selftest_segmented_solve_rank(n, len(ab), p(ab), p(Sb), p(g), 5, rank, world, cb, None, p(xr), p(infor))
+        assert rc == 0 and np.array_equal(xr, x1), (rc, np.abs(xr - x1).max())
+        assert 0 < infor[5] < infor[2]  # a strict subset of the jobs ran here
+        owned = [None] * world
+        dist.all_gather_object(owned, int(infor[5]))
+        assert sum(owned) == int(infor[2])
+        assert np.abs(x1 - np.linalg.solve(dense, g)).max() < 1e-9
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

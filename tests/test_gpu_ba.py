@@ -17,6 +17,11 @@ def ba():
 
 
 def _rel(a, b):
+    """Largest PER-POINT relative error |p_got - p_ref| / |p_ref| for n x 3 point arrays (a far point must not hide the error of a near one);
+    max|delta| / max|ref| for anything else."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    if a.ndim == 2 and a.shape[1] == 3:
+        return float((np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-12)).max())
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
