@@ -696,9 +696,15 @@ def bench_global_ba(device, rank, world):
     if world > 1:
         dt = distributed.max_over_ranks(dt)
     free = int((np.asarray(sc["pose_fixed"]) == 0).sum())
+    try:
+        plan = ba.last_envelope_plan()
+    except Exception:
+        plan = None
     return {"metric": "global-BA LM iterations/s @500 KF / 200k landmarks / %d obs" % len(sc["obs_pose"]), "value": round(iters / dt, 2), "unit": "iters/s",
+            "envelope_plan": plan,
             "ms_per_call": round(dt / reps * 1e3, 2), "iters_per_call": iters / reps, "dtype": "f64", "n_gpus": world,
-            "sharding": "none" if world == 1 else "observations by landmark (l % N), all-reduce of the kept Schur blocks per damping trial over RCCL",
+            "sharding": "none" if world == 1 else "observations by landmark (l % N): all-reduce of the kept Schur blocks per damping trial over RCCL; the factorisation of the "
+                                                  "reduced system is distributed (every rank eliminates the envelope jobs it owns, separator contributions and solution exchanged)",
             "linear_solver": "block envelope Cholesky of the reduced camera system (direct)" if res["stats"]["pcg_iterations"] == 0 else "block-Jacobi PCG",
             "pcg_iterations_per_call": res["stats"]["pcg_iterations"], "chi2_final": res["stats"]["chi2_final"],
             "roofline": ba_roofline(sc, iters, dt, free)}

@@ -74,10 +74,12 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint32_t* __restri
 // the exact gate, which is still evaluated per pair).  Results are keyed by ORIGINAL indices and the per-query
 // lists are sets, so the outcome is identical to the unpruned scan.
 #define BF_BINS 360
+#define BF_ANG_CACHE 4096
 __global__ __launch_bounds__(256) void k_bf_binsort(BfProblem P) {
     __shared__ int s_hist[BF_BINS + 2];
     __shared__ int s_start[BF_BINS + 2];
     __shared__ int s_bad;
+    __shared__ float s_ang[BF_ANG_CACHE];  // the angles of the first pass, so that the keypoint records (28-byte stride) are read once
     const int pair = blockIdx.x, side = P.shared_sort ? 1 : blockIdx.y, tid = threadIdx.x;
     const int cap = side == 0 ? P.cap1 : P.cap2;
     const int row = side == 0 ? bf_row1(P, pair) : pair;  // where this side of the pair lives in the caller's arrays
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(256) void k_bf_binsort(BfProblem P) {
     };
     for (int i = tid; i < n; i += 256) {
         bool ok;
-        const int b = bin_of(A[(size_t)i * P.angle_stride], ok);
+        const float a = A[(size_t)i * P.angle_stride];
+        if (i < BF_ANG_CACHE) s_ang[i] = a;
+        const int b = bin_of(a, ok);
         if (!ok) s_bad = 1;
         atomicAdd(&s_hist[b], 1);
     }
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void k_bf_binsort(BfProblem P) {
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
         bool ok;
-        const float a = A[(size_t)i * P.angle_stride];
+        const float a = i < BF_ANG_CACHE ? s_ang[i] : A[(size_t)i * P.angle_stride];
         const int b = bin_of(a, ok);
         const int dst = s_start[b] + atomicAdd(&s_hist[b], 1);
         const uint4 lo = *reinterpret_cast<const uint4*>(D + (size_t)i * 8), hi = *reinterpret_cast<const uint4*>(D + (size_t)i * 8 + 4);

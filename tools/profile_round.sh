@@ -4,7 +4,7 @@
 #   guide prescribes), the VALU busy-cycle pass, kernel stats of the two bundle adjusters, then the bench line itself (which now
 #   finds traffic / valu_issue files stamped with the hash of the sources it runs).  usage: tools/profile_round.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -21,7 +21,21 @@ timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc_act -o
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_lds.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_local -o k --output-format csv -- python $R/tools/ba_prof.py local > /dev/null 2> $OUT/ba_local.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_global -o k --output-format csv -- python $R/tools/ba_prof.py global > /dev/null 2> $OUT/ba_global.log
+# launches per tracked frame through the drop-in classes: two traces that differ by 20 frames
+for n in 10 30; do
+  timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/tf_$n -o k --output-format csv -- python $R/tools/tracked_frame_prof.py $n 1 > /dev/null 2> $OUT/tf_$n.log
+done
 cd $R
+python - <<PYEOF > $OUT/tracked_frame_launches.json
+import csv, json
+def calls(n):
+    rows = list(csv.DictReader(open("$OUT/tf_%d/k_kernel_stats.csv" % n)))
+    return {r["Name"]: int(r["Calls"]) for r in rows}
+a, b = calls(10), calls(30)
+per = {k.replace("(anonymous namespace)::", "").split("(")[0]: (b.get(k, 0) - a.get(k, 0)) / 20.0 for k in b if b.get(k, 0) != a.get(k, 0)}
+print(json.dumps({"what": "kernel launches (and runtime copy / fill kernels) per tracked frame through the drop-in classes, resident frames: difference of two rocprofv3 kernel traces 20 frames apart", "launches_per_frame": round(sum(per.values()), 2), "by_kernel": per}, indent=1))
+PYEOF
+cp $OUT/tracked_frame_launches.json profiles/${TAG}_tracked_frame_launches.json
 python tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w profiles/${TAG}_traffic.json 256 > /dev/null
 python tools/pmc_valu.py $OUT/pmc_gi profiles/${TAG}_valu_issue.json 256 $OUT/pmc_act > /dev/null
 python tools/pmc_lds_mfma.py $OUT/pmc_lds profiles/${TAG}_lds_mfma.json 256 > $OUT/lds_mfma.log 2>&1
@@ -30,7 +44,7 @@ timeout 400 python bench.py 2> $OUT/bench.log < /dev/null | tail -1 > $OUT/bench
 timeout 300 python tools/ba_bench.py --global > $OUT/ba_bench.log 2>&1 < /dev/null
 cp gpurun_out/ba_bench.json $OUT/ba_bench.json 2>/dev/null
 # keep the merge-back small: the raw traces stay on the box, the summaries travel
-rm -f $OUT/ks/*kernel_trace.csv $OUT/ba_local/*kernel_trace.csv $OUT/ba_global/*kernel_trace.csv
+rm -f $OUT/ks/*kernel_trace.csv $OUT/ba_local/*kernel_trace.csv $OUT/ba_global/*kernel_trace.csv $OUT/tf_*/*kernel_trace.csv
 rm -rf $OUT/pmc_f $OUT/pmc_w $OUT/pmc_gi $OUT/pmc_act $OUT/pmc_lds
 ls -la $OUT $OUT/ks | head -40
 tail -c 600 $OUT/bench.json
