@@ -49,13 +49,21 @@ struct BaDev {
     const int* pe_off;     // P + 1: pose (index, not slot) -> its edges in increasing edge order, whatever their level
     const int* pe_idx;
     const int* slot_pose;  // nP: free-pose slot -> pose index
+    // pose-major copies of the observations (position q of the pose -> edge lists): what the pose side of the linearisation reads
+    const int* pm_point;   // E (nullable: gather by pe_idx instead)
+    const float* pm_uvr;   // E x 3
+    const float* pm_w;     // E
+    const float* pm_hub;   // E
     int NB;                // number of non-empty upper blocks (a <= b) of the reduced system
     const int* blk_off;    // NB + 1
     const int2* blk_pairs; // (edge whose pose is a, edge whose pose is b) sharing a landmark
     const int2* blk_ab;    // NB
     // linear system
     double* W;     // E x 18: Hpl block (6x3, row-major) of every edge with free pose and free landmark, else 0
-    double* lp_part;     // nP x LIN_SPLIT x 27: partial pose blocks of k_ba_lin
+    double* lp_part;     // nP x lin_split x 27: partial pose blocks of k_ba_lin
+    double* lm_max;      // one per landmark-side workgroup of k_ba_lin: its max |diagonal of Hll| (first iteration of an optimize() call)
+    int lin_split;       // workgroups per free pose on the pose side of k_ba_lin (sv_ba_lin_split)
+    int any_equirect;    // 1 = some pose carries the equirectangular model (fx == fy == 0): kernels with the atan2 / asin path
     double* sc_part;     // NB x nshare x 36: partial blocks of k_ba_schur_rhs
     double* rhs_part;    // nP x RHS_SPLIT x 6: partial sums of W Hll^-1 bl
     int nshare;          // shares per block of the reduced system (pairs per share ~200)
@@ -116,7 +124,9 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);   // on-chip de
 size_t sv_ba_chol_bytes(int n);                                    // its dynamic LDS
 size_t sv_ba_pcg_lds_bytes(const BaDev& D);
 void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);  // PCG with the whole system in one workgroup's LDS
-int sv_ba_lin_split();
+int sv_ba_lin_split(int E, int nP);
+int sv_ba_lin_split_max();
+int sv_ba_lm_blocks(int L);  // landmark-side workgroups of k_ba_lin
 int sv_ba_rhs_split();
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded);
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out);

@@ -100,20 +100,30 @@ __device__ __forceinline__ void huber(double e, double delta, double* rho0, doub
 __device__ __forceinline__ const double* st_pose(const BaDev& D, int trial) { return (D.ctl->cur ^ trial) ? D.pose_buf[1] : D.pose_buf[0]; }
 __device__ __forceinline__ const double* st_pt(const BaDev& D, int trial) { return (D.ctl->cur ^ trial) ? D.pt_buf[1] : D.pt_buf[0]; }
 
+// (p, l, uvr, w0, hub: the edge's pose, landmark, observation, information and Huber width -- read by the caller from the landmark-major
+//  arrays by edge index, or from the pose-major copies by position in the pose's list; e: the edge index, for the robust flag)
+//  EQ = false: the problem holds no equirectangular camera (BaDev::any_equirect, decided on the host from the intrinsics): the
+//  atan2 / asin path and its registers are compiled out
+template <bool EQ>
+__device__ __forceinline__ void edge_linearize_core(const BaDev& D, const double* __restrict__ pose_cur, const double* __restrict__ pt_cur, int e, int p, int l,
+                                                    const float* __restrict__ uvr, double w0, float hub, EdgeLin& o);
+template <bool EQ>
 __device__ __forceinline__ void edge_linearize(const BaDev& D, const double* __restrict__ pose_cur, const double* __restrict__ pt_cur, int e, EdgeLin& o) {
-    const int p = D.e_pose[e], l = D.e_point[e];
+    edge_linearize_core<EQ>(D, pose_cur, pt_cur, e, D.e_pose[e], D.e_point[e], D.e_uvr + (size_t)e * 3, (double)D.e_w[e], D.e_huber[e], o);
+}
+template <bool EQ>
+__device__ __forceinline__ void edge_linearize_core(const BaDev& D, const double* __restrict__ pose_cur, const double* __restrict__ pt_cur, int e, int p, int l,
+                                                    const float* __restrict__ uvr, double w0, float hub, EdgeLin& o) {
     const double* T = pose_cur + (size_t)p * 12;
     const double* X = pt_cur + (size_t)l * 3;
     const double* K = D.intr + (size_t)p * 5;
-    const float* uvr = D.e_uvr + (size_t)e * 3;
-    const double w0 = (double)D.e_w[e];
     double pc[3];
     cam_point(T, X, pc);
     const double fx = K[0], fy = K[1], fxb = K[4];
     const double x = pc[0], y = pc[1], z = pc[2];
     // one reciprocal instead of ~25 fp64 divisions (each is a 20-instruction sequence)
     const double iz = 1.0 / z, iz2 = iz * iz, xz = x * iz, yz = y * iz;
-    const bool eq = cam_is_equirect(K);
+    const bool eq = EQ && cam_is_equirect(K);
     double u = fx * xz + K[2], v = fy * yz + K[3];
     if (eq) equirect_project(K, pc, &u, &v);
     const bool stereo = !(uvr[2] < 0.f) && !eq;
@@ -158,7 +168,7 @@ __device__ __forceinline__ void edge_linearize(const BaDev& D, const double* __r
     double rho1 = 1.0;
     if (D.e_robust[e]) {
         double rho0;
-        huber(o.chi, (double)D.e_huber[e], &rho0, &rho1);
+        huber(o.chi, (double)hub, &rho0, &rho1);
     }
     o.w = w0 * rho1;
 }
@@ -873,15 +883,20 @@ __device__ __forceinline__ bool lm_dinv(const double* __restrict__ H, double lam
     return true;
 }
 
-// linearisation: blocks [0, nb_lm) = landmark side (Hll, bl, W; 8 lanes per landmark), the rest = pose side (LIN_SPLIT
-// workgroups per free pose, partial Hpp / bp)
-#define LIN_SPLIT 16
-__global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
+// linearisation: blocks [0, nb_lm) = landmark side (Hll, bl, W; 8 lanes per landmark), the rest = pose side (D.lin_split
+// workgroups per free pose, partial Hpp / bp; the host sizes the split for ~3 edges per lane -- with a fixed split of 16 a
+// config-5 workgroup held 150 edges, one per lane at most, and the 8 k workgroups spent their time in the 27-value reduction and
+// in launch latency at 2 workgroups per CU).  EQ: see edge_linearize_core.
+#define LIN_SPLIT_MAX 16
+#define LIN_EDGES_PER_BLOCK 768
+template <bool EQ>
+__global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm, int blk0) {
     if (D.ctl->phase != 0) return;
     const double* pose_cur = st_pose(D, 0);
     const double* pt_cur = st_pt(D, 0);
-    if ((int)blockIdx.x < nb_lm) {
-        const int t = blockIdx.x * 256 + threadIdx.x;
+    const int bid = blockIdx.x + blk0;
+    if (bid < nb_lm) {
+        const int t = bid * 256 + threadIdx.x;
         const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
         const bool in_range = t / LM_LANES < D.L;
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -892,7 +907,7 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
                 const int slot = D.pose_slot[D.e_pose[e]];
                 if (!lfree && slot < 0) continue;
                 EdgeLin o;
-                edge_linearize(D, pose_cur, pt_cur, e, o);
+                edge_linearize<EQ>(D, pose_cur, pt_cur, e, o);
                 if (lfree) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
@@ -930,24 +945,32 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
             for (int k = 0; k < 3; ++k) D.bl[(size_t)l * 3 + k] = b[k];
             m = fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5])));
         }
-        if (D.ctl->it == 0) {  // computeLambdaInit: the landmark part of max |diagonal| (uniform branch)
+        if (D.ctl->it == 0) {  // computeLambdaInit: the landmark part of max |diagonal| (uniform branch), one value per workgroup;
+            // k_ba_lin_fin folds them.  (An atomicMax per wave on the control block -- 25 k of them on one address at config 5 --
+            // made the first linearisation of every optimize() call 1.37 ms instead of 70 us.)
+            __shared__ double s_mx[4];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-            if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(&D.ctl->max_diag_bits, (unsigned long long)__double_as_longlong(m));
+            if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) D.lm_max[bid] = fmax(fmax(s_mx[0], s_mx[1]), fmax(s_mx[2], s_mx[3]));
         }
         return;
     }
-    const int u = blockIdx.x - nb_lm, s = u / LIN_SPLIT, share = u - s * LIN_SPLIT;
+    const int split = D.lin_split;
+    const int u = bid - nb_lm, s = u / split, share = u - s * split;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
     const int pose = D.slot_pose[s], lo = D.pe_off[pose], n = D.pe_off[pose + 1] - lo;
-    const int q0 = lo + (int)((long long)n * share / LIN_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / LIN_SPLIT);
+    const int q0 = lo + (int)((long long)n * share / split), q1 = lo + (int)((long long)n * (share + 1) / split);
     for (int q = q0 + threadIdx.x; q < q1; q += 256) {
         const int e = D.pe_idx[q];
         if (D.e_level[e]) continue;  // lists are built once per call; excluded edges stay listed
         EdgeLin o;
-        edge_linearize(D, pose_cur, pt_cur, e, o);
+        // the observation comes from the POSE-MAJOR copy (contiguous along the pose's list) when the arena holds one
+        if (D.pm_point) edge_linearize_core<EQ>(D, pose_cur, pt_cur, e, pose, D.pm_point[q], D.pm_uvr + (size_t)q * 3, (double)D.pm_w[q], D.pm_hub[q], o);
+        else edge_linearize<EQ>(D, pose_cur, pt_cur, e, o);
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -961,15 +984,18 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm) {
         for (int i = 0; i < 6; ++i)
             acc[21 + i] += o.B[i] * (-o.w * o.r[0]) + o.B[6 + i] * (-o.w * o.r[1]) + o.B[12 + i] * (-o.w * o.r[2]);
     }
+    // the four waves reduce two at a time through two wave-private transposition buffers (half the LDS => one more workgroup per CU)
     __shared__ double s_w[4][27];
-    __shared__ __attribute__((aligned(16))) double s_red[4][WRED_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double s_red[2][WRED_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    wave_reduce_lds<27>(acc, s_red[wave], lane, [&](int k, double t) { s_w[wave][k] = t; });
+    if (wave < 2) wave_reduce_lds<27>(acc, s_red[wave], lane, [&](int k, double t) { s_w[wave][k] = t; });
     __syncthreads();
-    if (threadIdx.x < 27) D.lp_part[((size_t)s * LIN_SPLIT + share) * 27 + threadIdx.x] = ((s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + s_w[2][threadIdx.x]) + s_w[3][threadIdx.x];
+    if (wave >= 2) wave_reduce_lds<27>(acc, s_red[wave - 2], lane, [&](int k, double t) { s_w[wave][k] = t; });
+    __syncthreads();
+    if (threadIdx.x < 27) D.lp_part[((size_t)s * split + share) * 27 + threadIdx.x] = ((s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + s_w[2][threadIdx.x]) + s_w[3][threadIdx.x];
 }
 
-// one workgroup: pose blocks from their LIN_SPLIT partials (share order), then -- unless the pose blocks still have to be summed
+// one workgroup: pose blocks from their D.lin_split partials (share order), then -- unless the pose blocks still have to be summed
 // over the ranks of a sharded solve -- the pose part of computeLambdaInit and the start-of-trial bookkeeping (k_ba_prepare)
 __device__ __forceinline__ void ctl_prepare(BaDev& D, double max_diag) {
     BaCtl& c = *D.ctl;
@@ -987,7 +1013,7 @@ __device__ __forceinline__ void ctl_prepare(BaDev& D, double max_diag) {
     c.pcg_fail = 0;
     c.pcg_it = 0;
 }
-__global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare) {
+__global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare, int nb_lm) {
     const int phase = D.ctl->phase;
     if (phase == 2) return;
     __shared__ double s_m[4];
@@ -996,7 +1022,8 @@ __global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare) {
         for (int item = threadIdx.x; item < D.nP * 27; item += 256) {
             const int s = item / 27, k = item - 27 * s;
             double t = 0.0;
-            for (int h = 0; h < LIN_SPLIT; ++h) t += D.lp_part[((size_t)s * LIN_SPLIT + h) * 27 + k];
+#pragma unroll 4
+            for (int h = 0; h < D.lin_split; ++h) t += D.lp_part[((size_t)s * D.lin_split + h) * 27 + k];
             if (k < 21) {
                 int i = 0, base = 0;  // k -> (i, j), i <= j, rows of 6, 5, 4, ... entries
                 while (k >= base + (6 - i)) {
@@ -1011,7 +1038,11 @@ __global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare) {
             else D.bp[(size_t)s * 6 + (k - 21)] = t;
         }
     }
-    if (!do_prepare) return;
+    double ml = 0.0;  // landmark part of computeLambdaInit: the per-workgroup maxima of k_ba_lin
+    if (phase == 0 && D.ctl->it == 0)
+        for (int k = threadIdx.x; k < nb_lm; k += 256) ml = fmax(ml, D.lm_max[k]);
+    if (!do_prepare) m = 0.0;  // sharded: the pose part comes from the summed blocks (k_ba_maxdiag)
+    m = fmax(m, ml);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
@@ -1019,7 +1050,8 @@ __global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare) {
     if (threadIdx.x == 0) {
         m = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
         m = fmax(m, __longlong_as_double((long long)D.ctl->max_diag_bits));
-        ctl_prepare(D, m);
+        if (do_prepare) ctl_prepare(D, m);
+        else if (phase == 0 && D.ctl->it == 0) D.ctl->max_diag_bits = (unsigned long long)__double_as_longlong(m);
     }
 }
 
@@ -1565,13 +1597,25 @@ void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
 
 // ------------------------------------------------------------------------------------------------ launchers
 static inline int nb_lm_blocks(const BaDev& D) { return (D.L * LM_LANES + 255) / 256; }
+int sv_ba_lm_blocks(int L) { return (L * LM_LANES + 255) / 256; }
 
 // linearisation (+ pose blocks from their partials; unless the blocks must first be summed over ranks: lambda init and trial start)
 void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int do_prepare) {
     SvProfScope ps(ctx, s, "ba_linearize");
     const int nb = nb_lm_blocks(D);
-    hipLaunchKernelGGL(k_ba_lin, dim3(nb + D.nP * LIN_SPLIT), dim3(256), 0, s, D, nb);
-    hipLaunchKernelGGL(k_ba_lin_fin, dim3(1), dim3(256), 0, s, D, do_prepare);
+    static const bool two_launches = std::getenv("SVGPU_BA_LIN_TWO_LAUNCHES") != nullptr;  // profiling aid: times the two sides apart
+    const int np = D.nP * D.lin_split;
+    auto launch = [&](int blocks, int blk0) {
+        if (blocks <= 0) return;
+        if (D.any_equirect) hipLaunchKernelGGL(k_ba_lin<true>, dim3(blocks), dim3(256), 0, s, D, nb, blk0);
+        else hipLaunchKernelGGL(k_ba_lin<false>, dim3(blocks), dim3(256), 0, s, D, nb, blk0);
+    };
+    if (two_launches) {
+        launch(nb, 0);
+        launch(np, nb);
+    }
+    else launch(nb + np, 0);
+    hipLaunchKernelGGL(k_ba_lin_fin, dim3(1), dim3(256), 0, s, D, do_prepare, nb);
 }
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {  // sharded solve only: pose part over the summed blocks + the rank's slot
@@ -1584,7 +1628,13 @@ void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLa
 void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }
 void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D); }
 
-int sv_ba_lin_split() { return LIN_SPLIT; }
+int sv_ba_lin_split_max() { return LIN_SPLIT_MAX; }
+int sv_ba_lin_split(int E, int nP) {  // workgroups per free pose on the pose side of k_ba_lin
+    if (nP <= 0) return 1;
+    const long long per_pose = ((long long)E + nP - 1) / nP;
+    const int k = (int)((per_pose + LIN_EDGES_PER_BLOCK - 1) / LIN_EDGES_PER_BLOCK);
+    return k < 1 ? 1 : (k > LIN_SPLIT_MAX ? LIN_SPLIT_MAX : k);
+}
 int sv_ba_rhs_split() { return RHS_SPLIT; }
 
 // reduced camera system: shares of the blocks and of the right-hand side, then the kept blocks Sblk and g

@@ -93,6 +93,20 @@ __global__ void k_flag_positive(const float* __restrict__ x, int n, uint8_t* __r
     if (i < n) out[i] = x[i] > 0.f ? 1 : 0;
 }
 
+__global__ void k_pose_major(const int* __restrict__ pe_idx, const int* __restrict__ e_point, const float* __restrict__ e_uvr, const float* __restrict__ e_w,
+                             const float* __restrict__ e_hub, int E, int* __restrict__ pm_point, float* __restrict__ pm_uvr, float* __restrict__ pm_w,
+                             float* __restrict__ pm_hub) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= E) return;
+    const int e = pe_idx[q];
+    pm_point[q] = e_point[e];
+    pm_uvr[3 * (size_t)q] = e_uvr[3 * (size_t)e];
+    pm_uvr[3 * (size_t)q + 1] = e_uvr[3 * (size_t)e + 1];
+    pm_uvr[3 * (size_t)q + 2] = e_uvr[3 * (size_t)e + 2];
+    pm_w[q] = e_w[e];
+    pm_hub[q] = e_hub[e];
+}
+
 inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 }  // namespace
 
@@ -172,6 +186,10 @@ int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void*
 // the device from the uploaded observations: a stable radix sort of (pose, edge index) + the offsets of the sorted keys.  The host used to
 // do this with a two-pass counting sort over all observations (0.5 ms of a config-5 call on four threads).
 size_t sv_ba_pose_lists_scratch_bytes(size_t E) { return 2 * pad256(E * 4) + 2 * pad256(E * 8) + pad256(sv_sort_hist_ints(E) * 4) + 1024; }
+void sv_ba_build_pose_major(hipStream_t s, const int* pe_idx, const int* e_point, const float* e_uvr, const float* e_w, const float* e_hub, int E, int* pm_point,
+                            float* pm_uvr, float* pm_w, float* pm_hub) {
+    if (E > 0) hipLaunchKernelGGL(k_pose_major, dim3((E + 255) / 256), dim3(256), 0, s, pe_idx, e_point, e_uvr, e_w, e_hub, E, pm_point, pm_uvr, pm_w, pm_hub);
+}
 int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes,
                            int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev) {
     if (E <= 0) {

@@ -23,6 +23,8 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
                             int2* pairs_out, int* dense_off_dev);
 size_t sv_ba_pose_lists_scratch_bytes(size_t E);
+void sv_ba_build_pose_major(hipStream_t s, const int* pe_idx, const int* e_point, const float* e_uvr, const float* e_w, const float* e_hub, int E, int* pm_point,
+                            float* pm_uvr, float* pm_w, float* pm_hub);
 int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes,
                            int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev);
 
@@ -366,7 +368,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
-    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total;
+    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -415,6 +417,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.S = want_dense ? A.take<double>((size_t)(nmax + 1) * nmax) : nullptr;
     D.dp = A.take<double>(nmax);
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
+    D.lm_max = A.take<double>(nb_lm);  // nb_lm == sv_ba_lm_blocks(L)
     double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
     double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
     double* d_xch = A.take<double>(xch_doubles);                  // sharded: pose-activity / block-presence / point exchange
@@ -426,6 +429,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.pcg_own = A.take<double>(2 * (size_t)nmax + 8);
     D.pcg_parts = A.take<double>(2 * 4 * nparts_max);
     D.pcg_scal = A.take<double>(8);
+    int* d_pm_point = A.take<int>(E);
+    float* d_pm_uvr = A.take<float>(3 * (size_t)E);
+    float* d_pm_w = A.take<float>(E);
+    float* d_pm_hub = A.take<float>(E);
     int2* d_blk_pairs = A.take<int2>(pair_cap);
     int2* d_blk_ab = A.take<int2>(nb_cap);
     int* d_blk_off = A.take<int>(nb_cap + 1);
@@ -437,6 +444,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.e_w = d_e_w;
     D.e_huber = d_e_hub;
     D.intr = d_intr;
+    D.any_equirect = 0;
+    for (int p = 0; p < P; ++p)
+        if (pr->intrinsics[5 * (size_t)p] == 0.0 && pr->intrinsics[5 * (size_t)p + 1] == 0.0) D.any_equirect = 1;
     D.pose_slot = d_pose_slot;
     D.pt_free = d_pt_free;
     D.lm_off = d_lm_off;
@@ -510,6 +520,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         const size_t sc_bytes = sizeof(double) * 18 * (size_t)E >= want ? sizeof(double) * 18 * (size_t)E : pair_scratch;
         const int rp = sv_ba_build_pose_lists(ctx, s, d_e_pose, d_e_hub, E, P, sc, sc_bytes, d_pe_off, d_pe_idx, D.e_robust);
         if (rp) return rp;
+        sv_ba_build_pose_major(s, d_pe_idx, d_e_point, d_e_uvr, d_e_w, d_e_hub, E, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);
+        D.pm_point = d_pm_point, D.pm_uvr = d_pm_uvr, D.pm_w = d_pm_w, D.pm_hub = d_pm_hub;
     }
     SV_HIP(ctx, hipMemsetAsync(D.e_level, 0, E, s));
     SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
@@ -591,6 +603,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         }
         D.nP = HS.nP;
         D.n = 6 * HS.nP;
+        D.lin_split = sv_ba_lin_split(E, HS.nP);
         D.chol_in_lds = D.n <= 186 && sv_ba_chol_bytes(D.n) <= 160 * 1024 - 12 * 1024;
         solver = solver_opt;
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
@@ -713,7 +726,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             solver = HS.envelope_ok ? SV_BA_SOLVER_ENVELOPE : SV_BA_SOLVER_AUTO;
         }
         if (solver == SV_BA_SOLVER_AUTO || solver == SV_BA_SOLVER_PCG) solver = lds_ok ? SV_BA_SOLVER_PCG_LDS : SV_BA_SOLVER_PCG_MULTI;
-        if (sv_ba_lin_split() > 16 || sv_ba_rhs_split() > 16) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: partial-sum buffers too small for the kernel splits");
+        if (sv_ba_lin_split_max() > 16 || sv_ba_rhs_split() > 16) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: partial-sum buffers too small for the kernel splits");
         if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks, n = %d, solver %d)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size(), D.n, solver);
         return SVGPU_OK;
     };
