@@ -58,6 +58,7 @@ struct BaDev {
     const int* blk_off;    // NB + 1
     const int2* blk_pairs; // (edge whose pose is a, edge whose pose is b) sharing a landmark
     const int2* blk_ab;    // NB
+    const int* blk_pair_l; // landmark of every pair (= e_point[pair.x]), in blk_pairs order
     // linear system
     double* W;     // E x 18: Hpl block (6x3, row-major) of every edge with free pose and free landmark, else 0
     double* lp_part;     // nP x lin_split x 27: partial pose blocks of k_ba_lin

@@ -1013,13 +1013,14 @@ __device__ __forceinline__ void ctl_prepare(BaDev& D, double max_diag) {
     c.pcg_fail = 0;
     c.pcg_it = 0;
 }
-__global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare, int nb_lm) {
+#define LIN_FIN_THREADS 1024
+__global__ __launch_bounds__(LIN_FIN_THREADS) void k_ba_lin_fin(BaDev D, int do_prepare, int nb_lm) {
     const int phase = D.ctl->phase;
     if (phase == 2) return;
-    __shared__ double s_m[4];
+    __shared__ double s_m[LIN_FIN_THREADS / 64];
     double m = 0.0;
     if (phase == 0) {
-        for (int item = threadIdx.x; item < D.nP * 27; item += 256) {
+        for (int item = threadIdx.x; item < D.nP * 27; item += LIN_FIN_THREADS) {
             const int s = item / 27, k = item - 27 * s;
             double t = 0.0;
 #pragma unroll 4
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare, int
     }
     double ml = 0.0;  // landmark part of computeLambdaInit: the per-workgroup maxima of k_ba_lin
     if (phase == 0 && D.ctl->it == 0)
-        for (int k = threadIdx.x; k < nb_lm; k += 256) ml = fmax(ml, D.lm_max[k]);
+        for (int k = threadIdx.x; k < nb_lm; k += LIN_FIN_THREADS) ml = fmax(ml, D.lm_max[k]);
     if (!do_prepare) m = 0.0;  // sharded: the pose part comes from the summed blocks (k_ba_maxdiag)
     m = fmax(m, ml);
 #pragma unroll
@@ -1048,7 +1049,8 @@ __global__ __launch_bounds__(256) void k_ba_lin_fin(BaDev D, int do_prepare, int
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+        m = 0.0;
+        for (int k = 0; k < LIN_FIN_THREADS / 64; ++k) m = fmax(m, s_m[k]);
         m = fmax(m, __longlong_as_double((long long)D.ctl->max_diag_bits));
         if (do_prepare) ctl_prepare(D, m);
         else if (phase == 0 && D.ctl->it == 0) D.ctl->max_diag_bits = (unsigned long long)__double_as_longlong(m);
@@ -1074,9 +1076,23 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
         const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
         const int q0 = lo + (int)((long long)np * share / nshare), q1 = lo + (int)((long long)np * (share + 1) / nshare);
-        for (int q = q0 + lane; q < q1; q += 64) {
-            const int2 pr = D.blk_pairs[q];
-            const int l = D.e_point[pr.x];
+        // The kernel is latency-bound (two waves per SIMD, ~200 pairs per unit): the pair and its landmark (blk_pair_l, so that Hll does not
+        // wait for e_point[pair.x]) are fetched one trip ahead, which leaves ONE dependent memory hop per trip instead of three.
+        int q = q0 + lane;
+        int2 pr = make_int2(0, 0);
+        int l = 0;
+        if (q < q1) {
+            pr = D.blk_pairs[q];
+            l = D.blk_pair_l[q];
+        }
+        while (q < q1) {
+            const int qn = q + 64;
+            int2 prn = pr;
+            int ln = l;
+            if (qn < q1) {
+                prn = D.blk_pairs[qn];
+                ln = D.blk_pair_l[qn];
+            }
             double I[6];
             lm_dinv(D.Hll + (size_t)l * 6, lambda, I);
             const double2* Wi = reinterpret_cast<const double2*>(D.W + (size_t)pr.x * 18);
@@ -1101,6 +1117,9 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
+            pr = prn;
+            l = ln;
+            q = qn;
         }
         double* const out = D.sc_part + (size_t)unit * 36;
         wave_reduce_lds<36>(acc, s_red[threadIdx.x >> 6], lane, [&](int k, double t) { out[k] = t; });
@@ -1114,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
     const int q0 = lo + (int)((long long)n * share / RHS_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / RHS_SPLIT);
     for (int q = q0 + lane; q < q1; q += 64) {
         const int e = D.pe_idx[q];
-        const int l = D.e_point[e];
+        const int l = D.pm_point ? D.pm_point[q] : D.e_point[e];  // pose-major copy: no second hop behind pe_idx
         if (!D.pt_free[l] || D.e_level[e]) continue;
         double I[6];
         lm_dinv(D.Hll + (size_t)l * 6, lambda, I);
@@ -1428,7 +1447,7 @@ __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
 // fixed-order sum of n doubles by one 256-thread workgroup (strided partial sums, shuffle tree, wave partials in wave order)
 __device__ __forceinline__ double ctl_sum(const double* __restrict__ v, int n, double* sw) {
     double t = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) t += v[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t += v[i];
     return block_sum_d(t, sw);
 }
 
@@ -1561,7 +1580,7 @@ __device__ __forceinline__ void lm_decide(const BaDev& D, double* sw /* 16 doubl
     c.phase = (c.it < c.it_max && !c.stop && c.ok) ? 0 : 2;
 }
 
-__global__ __launch_bounds__(256) void k_ba_decide(BaDev D) {
+__global__ __launch_bounds__(1024) void k_ba_decide(BaDev D) {  // one workgroup of 1024: the ~6 k chi2 partials of config 5 are 6 loads deep, not 25
     if (D.ctl->phase != 1) return;
     __shared__ double sw[16];
     lm_decide(D, sw);
@@ -1615,7 +1634,7 @@ void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int do_prepa
         launch(np, nb);
     }
     else launch(nb + np, 0);
-    hipLaunchKernelGGL(k_ba_lin_fin, dim3(1), dim3(256), 0, s, D, do_prepare, nb);
+    hipLaunchKernelGGL(k_ba_lin_fin, dim3(1), dim3(LIN_FIN_THREADS), 0, s, D, do_prepare, nb);
 }
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {  // sharded solve only: pose part over the summed blocks + the rank's slot
@@ -1626,7 +1645,7 @@ void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {  // sharded solve only: pose
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale) { hipLaunchKernelGGL(k_ba_fold, dim3(1), dim3(256), 0, s, D, out4, with_scale); }
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(256), 0, s, D, it_max, stop_in); }
 void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }
-void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(256), 0, s, D); }
+void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D); }
 
 int sv_ba_lin_split_max() { return LIN_SPLIT_MAX; }
 int sv_ba_lin_split(int E, int nP) {  // workgroups per free pose on the pose side of k_ba_lin

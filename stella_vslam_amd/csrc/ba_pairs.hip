@@ -76,6 +76,11 @@ __global__ void k_pair_offsets(const unsigned* __restrict__ keys, int n, int nb_
     dense_off[k] = lo;
 }
 
+// landmark of every sorted pair: what the Schur kernel needs first (Hll), without the hop through e_point[pair.x]
+__global__ void k_pair_landmark(const unsigned long long* __restrict__ vals, int n, const int* __restrict__ e_point, int* __restrict__ pair_l) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pair_l[i] = e_point[(int)(unsigned)vals[i]];
+}
 __global__ void k_iota_u64(unsigned long long* __restrict__ v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (unsigned long long)(unsigned)i;
@@ -117,7 +122,7 @@ size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap) {
 namespace {
 // count -> scan -> emit -> radix passes -> dense offsets; total_host < 0: the pair total stays on the device (no read-back)
 int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total_host, int2* pairs_out,
-                int* dense_off_dev, bool read_total, int* total_out) {
+                int* pair_l_out, int* dense_off_dev, bool read_total, int* total_out) {
     const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
     char* p = (char*)scratch;
     auto take = [&](size_t bytes) {
@@ -147,6 +152,7 @@ int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, si
     if (total > 0) {
         hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt, keys[cur], vals[cur]);
         cur = sv_sort_pairs(s, keys, vals, cur, total, bits, hist);
+        hipLaunchKernelGGL(k_pair_landmark, dim3((total + 255) / 256), dim3(256), 0, s, vals[cur], total, D.e_point, pair_l_out);
     }
     hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys[cur], total, nb_dense, dense_off_dev);
     SV_HIP(ctx, hipGetLastError());
@@ -157,13 +163,13 @@ int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, si
 // D.pose_slot / D.pt_free / D.e_level / D.nP must be current on the device.  Writes the sorted pairs to `pairs_out` (= D.blk_pairs
 // storage) and the dense block offsets (nb_dense + 1 ints) to `dense_off_host`.  Synchronises the stream twice.
 int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int2* pairs_out,
-                      std::vector<int>& dense_off_host) {
+                      int* pair_l_out, std::vector<int>& dense_off_host) {
     const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
     dense_off_host.assign((size_t)nb_dense + 1, 0);
     if (L == 0 || D.nP == 0) return SVGPU_OK;
     // the dense offsets live at the END of the scratch block (behind what build_pairs takes)
     int* dense_off = (int*)((char*)scratch + scratch_bytes - pad256(((size_t)nb_dense + 1) * 4));
-    const int rc = build_pairs(ctx, s, D, scratch, scratch_bytes - pad256(((size_t)nb_dense + 1) * 4), pair_cap, 0, pairs_out, dense_off, true, nullptr);
+    const int rc = build_pairs(ctx, s, D, scratch, scratch_bytes - pad256(((size_t)nb_dense + 1) * 4), pair_cap, 0, pairs_out, pair_l_out, dense_off, true, nullptr);
     if (rc) return rc;
     SV_HIP(ctx, hipMemcpyAsync(dense_off_host.data(), dense_off, 4 * ((size_t)nb_dense + 1), hipMemcpyDeviceToHost, s));
     SV_HIP(ctx, hipStreamSynchronize(s));
@@ -173,13 +179,13 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
 // Same pipeline with the pair total known to the caller (svgpu_ba.hip: host_pair_total): nothing is read back, nothing synchronises.
 // The dense block offsets (nP (nP + 1) / 2 + 1 ints) are written to `dense_off_dev`.
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
-                            int2* pairs_out, int* dense_off_dev) {
+                            int2* pairs_out, int* pair_l_out, int* dense_off_dev) {
     const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
     if (L == 0 || D.nP == 0) {
         SV_HIP(ctx, hipMemsetAsync(dense_off_dev, 0, 4 * ((size_t)nb_dense + 1), s));
         return SVGPU_OK;
     }
-    return build_pairs(ctx, s, D, scratch, scratch_bytes, pair_cap, total, pairs_out, dense_off_dev, false, nullptr);
+    return build_pairs(ctx, s, D, scratch, scratch_bytes, pair_cap, total, pairs_out, pair_l_out, dense_off_dev, false, nullptr);
 }
 
 // Pose -> edge lists (every pose's edges in increasing edge order, whatever their level) and the "has a robust kernel" flags, built on

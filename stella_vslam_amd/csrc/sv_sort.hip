@@ -3,30 +3,36 @@
 
 namespace {
 // In-place exclusive scan of data[0 .. n) with the total written to data[n]: ONE workgroup, 16 consecutive elements per thread (a serial
-// scan in registers), the 64 thread totals of a wave scanned with shuffles, the 16 wave totals by the first wave: three barriers per tile
-// of 16 k elements (a Hillis-Steele scan over the 1024 totals in LDS took twenty: 142 us for 200 k elements against ~20 now).
+// scan in registers), the 64 thread totals of a wave scanned with shuffles, the 16 wave totals by the first wave.  The loads of the next
+// tile of 16 k elements are in flight while the current one is scanned, the wave totals are double-buffered and every thread carries the
+// running total itself: two barriers per tile and no load latency on the critical path (a tile cost ~8 us with four barriers and the load
+// in front of them: 106 us for the 200 k landmark counts of config 5; a Hillis-Steele scan over the 1024 totals in LDS took 142 us).
 #define SCAN_PER_THREAD 16
+__device__ __forceinline__ void scan_load_tile(const int* __restrict__ data, int i0, int n, int (&v)[SCAN_PER_THREAD]) {
+    if (i0 + SCAN_PER_THREAD <= n) {
+        const int4* p4 = reinterpret_cast<const int4*>(data + i0);  // i0 is a multiple of 16: aligned
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD / 4; ++k) {
+            const int4 q = p4[k];
+            v[4 * k] = q.x, v[4 * k + 1] = q.y, v[4 * k + 2] = q.z, v[4 * k + 3] = q.w;
+        }
+    }
+    else {
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; ++k) v[k] = i0 + k < n ? data[i0 + k] : 0;
+    }
+}
 __global__ __launch_bounds__(1024) void k_scan_i32(int* __restrict__ data, const int* __restrict__ n_dev, int n_host) {
-    __shared__ int s_wave[16];
-    __shared__ int s_carry;
+    __shared__ int s_wave[2][17];  // [parity][exclusive prefix of the 16 wave totals | tile total]
     const int n = n_dev ? *n_dev : n_host, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024 * SCAN_PER_THREAD) {
+    constexpr int TILE = 1024 * SCAN_PER_THREAD;
+    int carry = 0, par = 0;
+    int v[SCAN_PER_THREAD], vn[SCAN_PER_THREAD];
+    if (n > 0) scan_load_tile(data, tid * SCAN_PER_THREAD, n, v);
+    for (int base = 0; base < n; base += TILE, par ^= 1) {
         const int i0 = base + tid * SCAN_PER_THREAD;
-        int v[SCAN_PER_THREAD], sum = 0;
-        if (i0 + SCAN_PER_THREAD <= n) {
-            const int4* p4 = reinterpret_cast<const int4*>(data + i0);  // i0 is a multiple of 16: aligned
-#pragma unroll
-            for (int k = 0; k < SCAN_PER_THREAD / 4; ++k) {
-                const int4 q = p4[k];
-                v[4 * k] = q.x, v[4 * k + 1] = q.y, v[4 * k + 2] = q.z, v[4 * k + 3] = q.w;
-            }
-        }
-        else {
-#pragma unroll
-            for (int k = 0; k < SCAN_PER_THREAD; ++k) v[k] = i0 + k < n ? data[i0 + k] : 0;
-        }
+        if (base + TILE < n) scan_load_tile(data, i0 + TILE, n, vn);  // disjoint from this tile's stores
+        int sum = 0;
 #pragma unroll
         for (int k = 0; k < SCAN_PER_THREAD; ++k) sum += v[k];
         int incl = sum;  // inclusive scan of the thread totals inside the wave
@@ -35,30 +41,30 @@ __global__ __launch_bounds__(1024) void k_scan_i32(int* __restrict__ data, const
             const int t = __shfl_up(incl, off, 64);
             if (lane >= off) incl += t;
         }
-        if (lane == 63) s_wave[wave] = incl;
+        if (lane == 63) s_wave[par][wave] = incl;
         __syncthreads();
         if (wave == 0) {
-            int w = lane < 16 ? s_wave[lane] : 0, wi = w;
+            int w = lane < 16 ? s_wave[par][lane] : 0, wi = w;
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) {
                 const int t = __shfl_up(wi, off, 64);
                 if (lane >= off) wi += t;
             }
-            if (lane < 16) s_wave[lane] = wi - w;  // exclusive prefix of the wave totals
+            if (lane < 16) s_wave[par][lane] = wi - w;  // exclusive prefix of the wave totals
+            if (lane == 15) s_wave[par][16] = wi;        // the tile's total
         }
         __syncthreads();
-        const int carry = s_carry;
-        int run = carry + s_wave[wave] + incl - sum;
+        int run = carry + s_wave[par][wave] + incl - sum;
+        carry += s_wave[par][16];
 #pragma unroll
         for (int k = 0; k < SCAN_PER_THREAD; ++k) {
             if (i0 + k < n) data[i0 + k] = run;
             run += v[k];
         }
-        __syncthreads();
-        if (tid == 1023) s_carry = run;  // the last thread's running value = carry + the tile's total
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCAN_PER_THREAD; ++k) v[k] = vn[k];
     }
-    if (tid == 0) data[n] = s_carry;
+    if (tid == 0) data[n] = carry;
 }
 
 // ---- stable LSD radix sort of (key, value) pairs by 6-bit digits

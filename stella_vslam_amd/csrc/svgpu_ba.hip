@@ -19,9 +19,9 @@ void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D);
 size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap);
 int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int2* pairs_out,
-                      std::vector<int>& dense_off_host);
+                      int* pair_l_out, std::vector<int>& dense_off_host);
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
-                            int2* pairs_out, int* dense_off_dev);
+                            int2* pairs_out, int* pair_l_out, int* dense_off_dev);
 size_t sv_ba_pose_lists_scratch_bytes(size_t E);
 void sv_ba_build_pose_major(hipStream_t s, const int* pe_idx, const int* e_point, const float* e_uvr, const float* e_w, const float* e_hub, int E, int* pm_point,
                             float* pm_uvr, float* pm_w, float* pm_hub);
@@ -368,7 +368,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
-    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm);
+    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -434,6 +434,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     float* d_pm_w = A.take<float>(E);
     float* d_pm_hub = A.take<float>(E);
     int2* d_blk_pairs = A.take<int2>(pair_cap);
+    int* d_blk_pair_l = A.take<int>(pair_cap);
     int2* d_blk_ab = A.take<int2>(nb_cap);
     int* d_blk_off = A.take<int>(nb_cap + 1);
     char* d_pair_scratch = A.take<char>(pair_scratch);
@@ -454,6 +455,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.pe_idx = d_pe_idx;
     D.slot_pose = d_slot_pose;
     D.blk_pairs = d_blk_pairs;
+    D.blk_pair_l = d_blk_pair_l;
     D.blk_ab = d_blk_ab;
     D.blk_off = d_blk_off;
     D.prow_off = d_prow_off;
@@ -624,7 +626,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             std::vector<int> dense_off;
             if (host_total >= 0) {
                 if ((size_t)host_total > pair_cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list capacity exceeded");
-                int rp = sv_ba_build_pairs_async(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, (int)host_total, d_blk_pairs, d_blk_off);
+                int rp = sv_ba_build_pairs_async(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, (int)host_total, d_blk_pairs, d_blk_pair_l, d_blk_off);
                 if (rp) return rp;
                 sub("pairs enqueued");
             }
@@ -645,7 +647,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                 HS.num_pairs = (size_t)host_total;
             }
             else {
-                int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, dense_off);
+                int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, d_blk_pair_l, dense_off);
                 if (rp) return rp;
                 sub("device pairs");
                 std::vector<uint8_t> present(dense_off.size() ? dense_off.size() - 1 : 0, 0);
