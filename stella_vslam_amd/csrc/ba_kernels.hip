@@ -1062,12 +1062,54 @@ __global__ __launch_bounds__(LIN_FIN_THREADS) void k_ba_lin_fin(BaDev D, int do_
 //   units [.., + nP * RHS_SPLIT)  share of a pose's edges: sum of W_e Hll^-1 bl -> rhs_part
 // A lane walks several pairs and the 36 (6) sums are reduced once per wave: with one pair per thread the 36 shuffle reductions
 // cost more than the 162 multiply-adds of the pair.
+//
+// COOPERATIVE GATHER.  A lane needs the 144-byte W record of each edge of its pair and the 48-byte Hll of the landmark.  Fetched per
+// lane (nine 16-byte loads from 64 different records) every wave-level load touches 64 cache lines; the vector L1 looks up one line
+// per cycle, and at config 5 its ~1e8 lookups per launch (PMC TCP_TOTAL_CACHE_ACCESSES) were 170 of the kernel's 273 us.  Here the
+// wave fetches the 64 records of a trip TOGETHER: piece g = k * 64 + lane of the 64 * NP pieces belongs to record g / NP, so
+// consecutive lanes read consecutive 16 bytes (a line serves 8 lanes instead of 1), the pieces land in wave-private LDS in linear
+// order (conflict-free) and every lane reads its own record back with ds_read_b128 (144-byte pitch: conflict-free).
 #define RHS_SPLIT 16
-__global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, double* __restrict__ rhs_part) {
+#define SCH_W_DOUBLES (64 * 18)                      // one side's W records of a trip
+#define SCH_H_DOUBLES (64 * 6)                       // the trip's Hll blocks
+#define SCH_WAVE_DOUBLES (2 * SCH_W_DOUBLES + SCH_H_DOUBLES + 96 + 16)  // both sides + three index rows (64 ints each), padded; >= WRED_DOUBLES
+#define SCH_WAVES 1  // waves (= units) per workgroup: nothing is shared between them, and 22 KB of LDS per wave leaves 7 waves per CU
+template <int NP, typename T>
+__device__ __forceinline__ void coop_issue(const T* __restrict__ base, const int* __restrict__ idx, int rec_pitch /* in T */, int lane, T (&v)[NP]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int g = k * 64 + lane, r = g / NP, piece = g - r * NP;
+        v[k] = base[(size_t)idx[r] * rec_pitch + piece];
+    }
+}
+template <int NP, typename T>
+__device__ __forceinline__ void coop_commit(const T (&v)[NP], T* __restrict__ dst, int lane) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) dst[k * 64 + lane] = v[k];
+}
+__global__ __launch_bounds__(64 * SCH_WAVES) void k_ba_schur_rhs(BaDev D, int nshare, double* __restrict__ rhs_part, int xcd_order) {
     if (D.ctl->phase != 1) return;
-    __shared__ __attribute__((aligned(16))) double s_red[4][WRED_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double s_wave[SCH_WAVES][SCH_WAVE_DOUBLES];
+    static_assert(SCH_WAVE_DOUBLES >= WRED_DOUBLES, "the reduction reuses the gather buffer");
     const double lambda = D.ctl->lambda;
-    const int lane = threadIdx.x & 63, unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: workgroup i runs on XCD i % 8, each with its own 4 MB L2.  Consecutive units walk the blocks (a, a), (a, a + 1), ...
+    // of one block row, which all read the W records of pose a and its neighbours: XCD x takes the x-th CONTIGUOUS eighth of the units, so
+    // that the rows in flight on one L2 are ~3 instead of ~21 (half of the L2 requests missed at config 5 with the round-robin order:
+    // 980 MB fetched per launch, 296 MB with this order).  Small grids keep the round-robin order (the cheap right-hand-side units at the end
+    // of the list would all land on the last XCDs).
+    int wg = blockIdx.x;
+    if (xcd_order) {
+        const int chunk = gridDim.x >> 3;  // the launcher pads the grid to a multiple of 8
+        wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, unit = wg * SCH_WAVES + wave;
+    double* const sw = s_wave[wave];
+    double2* const s_W = reinterpret_cast<double2*>(sw);                                  // 64 records x 9 pieces (W_i)
+    double2* const s_W2 = reinterpret_cast<double2*>(sw + SCH_W_DOUBLES);                 // 64 records x 9 pieces (W_j)
+    double2* const s_H = reinterpret_cast<double2*>(sw + 2 * SCH_W_DOUBLES);              // 64 records x 3 pieces
+    int* const s_ix = reinterpret_cast<int*>(sw + 2 * SCH_W_DOUBLES + SCH_H_DOUBLES);     // [0,64) e_i  [64,128) e_j  [128,192) landmark
+    const double2* const Wg = reinterpret_cast<const double2*>(D.W);
+    const double2* const Hg = reinterpret_cast<const double2*>(D.Hll);
     const int n_schur = D.NB * nshare;
     if (unit < n_schur) {
         const int blk = unit / nshare, share = unit - blk * nshare;
@@ -1076,53 +1118,82 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
         const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
         const int q0 = lo + (int)((long long)np * share / nshare), q1 = lo + (int)((long long)np * (share + 1) / nshare);
-        // The kernel is latency-bound (two waves per SIMD, ~200 pairs per unit): the pair and its landmark (blk_pair_l, so that Hll does not
-        // wait for e_point[pair.x]) are fetched one trip ahead, which leaves ONE dependent memory hop per trip instead of three.
-        int q = q0 + lane;
+        // the pair and its landmark (blk_pair_l: Hll does not wait for e_point[pair.x]) are fetched one trip ahead; lanes past the end of the
+        // share repeat its last pair (they take part in the gathers, not in the sums)
         int2 pr = make_int2(0, 0);
         int l = 0;
-        if (q < q1) {
-            pr = D.blk_pairs[q];
-            l = D.blk_pair_l[q];
+        if (q0 < q1) {
+            const int qq = min(q0 + lane, q1 - 1);
+            pr = D.blk_pairs[qq];
+            l = D.blk_pair_l[qq];
         }
-        while (q < q1) {
-            const int qn = q + 64;
+        for (int qb = q0; qb < q1; qb += 64) {  // wave-uniform
+            const bool mine = qb + lane < q1;
             int2 prn = pr;
             int ln = l;
-            if (qn < q1) {
-                prn = D.blk_pairs[qn];
-                ln = D.blk_pair_l[qn];
+            if (qb + 64 < q1) {
+                const int qq = min(qb + 64 + lane, q1 - 1);
+                prn = D.blk_pairs[qq];
+                ln = D.blk_pair_l[qq];
             }
-            double I[6];
-            lm_dinv(D.Hll + (size_t)l * 6, lambda, I);
-            const double2* Wi = reinterpret_cast<const double2*>(D.W + (size_t)pr.x * 18);
-            const double2* Wj = reinterpret_cast<const double2*>(D.W + (size_t)pr.y * 18);
-            double wi[18], w[18], y[18];
+            s_ix[lane] = pr.x;
+            s_ix[64 + lane] = pr.y;
+            s_ix[128 + lane] = l;
+            wave_lds_sync();
+            {
+                double2 hv[3], wa[9], wb[9];
+                coop_issue<3>(Hg, s_ix + 128, 3, lane, hv);
+                coop_issue<9>(Wg, s_ix, 9, lane, wa);
+                coop_issue<9>(Wg, s_ix + 64, 9, lane, wb);
+                coop_commit<3>(hv, s_H, lane);
+                coop_commit<9>(wa, s_W, lane);
+                coop_commit<9>(wb, s_W2, lane);
+            }
+            wave_lds_sync();
+            double I[6], Hl[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double2 t = s_H[3 * lane + k];
+                Hl[2 * k] = t.x;
+                Hl[2 * k + 1] = t.y;
+            }
+            lm_dinv(Hl, lambda, I);
+            double y[18];
+            {
+                double wi[18];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const double2 t = s_W[9 * lane + k];
+                    wi[2 * k] = t.x;
+                    wi[2 * k + 1] = t.y;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double w0 = wi[3 * i], w1 = wi[3 * i + 1], w2 = wi[3 * i + 2];
+                    y[3 * i] = w0 * I[0] + w1 * I[1] + w2 * I[2];
+                    y[3 * i + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
+                    y[3 * i + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+                }
+            }
+            double w[18];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const double2 a = Wi[k], b = Wj[k];
-                wi[2 * k] = a.x;
-                wi[2 * k + 1] = a.y;
-                w[2 * k] = b.x;
-                w[2 * k + 1] = b.y;
+                const double2 t = s_W2[9 * lane + k];
+                w[2 * k] = t.x;
+                w[2 * k + 1] = t.y;
             }
+            if (mine) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double w0 = wi[3 * i], w1 = wi[3 * i + 1], w2 = wi[3 * i + 2];
-                y[3 * i] = w0 * I[0] + w1 * I[1] + w2 * I[2];
-                y[3 * i + 1] = w0 * I[1] + w1 * I[3] + w2 * I[4];
-                y[3 * i + 2] = w0 * I[2] + w1 * I[4] + w2 * I[5];
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[6 * i + j] += y[3 * i] * w[3 * j] + y[3 * i + 1] * w[3 * j + 1] + y[3 * i + 2] * w[3 * j + 2];
+            wave_lds_sync();  // the records are consumed: the next trip may overwrite the buffer
             pr = prn;
             l = ln;
-            q = qn;
         }
         double* const out = D.sc_part + (size_t)unit * 36;
-        wave_reduce_lds<36>(acc, s_red[threadIdx.x >> 6], lane, [&](int k, double t) { out[k] = t; });
+        wave_reduce_lds<36>(acc, sw, lane, [&](int k, double t) { out[k] = t; });
         return;
     }
     const int ru = unit - n_schur;
@@ -1131,27 +1202,52 @@ __global__ __launch_bounds__(256) void k_ba_schur_rhs(BaDev D, int nshare, doubl
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const int pose = D.slot_pose[s], lo = D.pe_off[pose], n = D.pe_off[pose + 1] - lo;
     const int q0 = lo + (int)((long long)n * share / RHS_SPLIT), q1 = lo + (int)((long long)n * (share + 1) / RHS_SPLIT);
-    for (int q = q0 + lane; q < q1; q += 64) {
+    for (int qb = q0; qb < q1; qb += 64) {  // wave-uniform; same cooperative gathers (W, Hll; bl is 24 bytes: per lane)
+        const int q = min(qb + lane, q1 - 1);
         const int e = D.pe_idx[q];
         const int l = D.pm_point ? D.pm_point[q] : D.e_point[e];  // pose-major copy: no second hop behind pe_idx
-        if (!D.pt_free[l] || D.e_level[e]) continue;
-        double I[6];
-        lm_dinv(D.Hll + (size_t)l * 6, lambda, I);
+        const bool mine = qb + lane < q1 && D.pt_free[l] && !D.e_level[e];
+        s_ix[lane] = e;
+        s_ix[128 + lane] = l;
+        wave_lds_sync();
+        double2 hv[3], wa[9];
+        coop_issue<3>(Hg, s_ix + 128, 3, lane, hv);
+        coop_issue<9>(Wg, s_ix, 9, lane, wa);
         const double* bl = D.bl + (size_t)l * 3;
-        const double d0 = I[0] * bl[0] + I[1] * bl[1] + I[2] * bl[2];
-        const double d1 = I[1] * bl[0] + I[3] * bl[1] + I[4] * bl[2];
-        const double d2 = I[2] * bl[0] + I[4] * bl[1] + I[5] * bl[2];
-        const double* Wd = D.W + (size_t)e * 18;
+        const double b0 = bl[0], b1 = bl[1], b2 = bl[2];
+        coop_commit<3>(hv, s_H, lane);
+        coop_commit<9>(wa, s_W, lane);
+        wave_lds_sync();
+        double I[6], Hl[6], Wd[18];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] += Wd[3 * i] * d0 + Wd[3 * i + 1] * d1 + Wd[3 * i + 2] * d2;
+        for (int k = 0; k < 3; ++k) {
+            const double2 t = s_H[3 * lane + k];
+            Hl[2 * k] = t.x;
+            Hl[2 * k + 1] = t.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double2 t = s_W[9 * lane + k];
+            Wd[2 * k] = t.x;
+            Wd[2 * k + 1] = t.y;
+        }
+        wave_lds_sync();  // consumed
+        if (mine) {
+            lm_dinv(Hl, lambda, I);
+            const double d0 = I[0] * b0 + I[1] * b1 + I[2] * b2;
+            const double d1 = I[1] * b0 + I[3] * b1 + I[4] * b2;
+            const double d2 = I[2] * b0 + I[4] * b1 + I[5] * b2;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[i] += Wd[3 * i] * d0 + Wd[3 * i + 1] * d1 + Wd[3 * i + 2] * d2;
+        }
     }
-    double mine = 0.0;
+    double mine_v = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const double t = wave_sum_dpp(acc[k]);
-        mine = (lane == k) ? t : mine;
+        mine_v = (lane == k) ? t : mine_v;
     }
-    if (lane < 6) rhs_part[(size_t)ru * 6 + lane] = mine;
+    if (lane < 6) rhs_part[(size_t)ru * 6 + lane] = mine_v;
 }
 
 // kept blocks S_ab = [a == b](Hpp_a + lambda I) - sum of the shares, right-hand side g_a = bp_a - sum of the shares
@@ -1661,7 +1757,8 @@ void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_schur");
     if (D.nP <= 0) return;
     const int units = D.NB * D.nshare + D.nP * RHS_SPLIT;
-    hipLaunchKernelGGL(k_ba_schur_rhs, dim3((units + 3) / 4), dim3(256), 0, s, D, D.nshare, D.rhs_part);
+    const int wgs = (units + SCH_WAVES - 1) / SCH_WAVES, xcd_order = units >= 8192;  // more than one resident round of units
+    hipLaunchKernelGGL(k_ba_schur_rhs, dim3(xcd_order ? (wgs + 7) / 8 * 8 : wgs), dim3(64 * SCH_WAVES), 0, s, D, D.nshare, D.rhs_part, xcd_order);
     hipLaunchKernelGGL(k_ba_sys_fin, dim3((D.NB * 36 + D.n + 255) / 256), dim3(256), 0, s, D, D.nshare, D.rhs_part);
 }
 

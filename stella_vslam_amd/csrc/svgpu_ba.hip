@@ -709,7 +709,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.pcg_nparts = (HS.nP + 3) / 4;
         // shares per block: ~192 pairs per wave (3 per lane); fewer, longer walks are slower (a lane's pairs are a chain of dependent
         // loads), measured 2.30 / 2.31 / 2.43 / 2.90 / 3.79 ms per config-3 call at 96 / 192 / 384 / 768 / 1536 pairs per wave
-        D.nshare = D.NB > 0 ? (int)std::min<size_t>(16, std::max<size_t>(1, (HS.num_pairs / (size_t)D.NB + 191) / 192)) : 1;
+        static const size_t share_pairs = [] {
+            const char* e = std::getenv("SVGPU_BA_SHARE_PAIRS");  // tuning aid: pairs per share of a block of the reduced system
+            const long v = e ? std::atol(e) : 0;
+            return (size_t)(v >= 192 ? v : 192);  // (>= 192: the partial-sum buffer is sized for it)
+        }();
+        D.nshare = D.NB > 0 ? (int)std::min<size_t>(16, std::max<size_t>(1, (HS.num_pairs / (size_t)D.NB + share_pairs - 1) / share_pairs)) : 1;
         // solver of this stage: PCG inside one workgroup's LDS when the blocks fit, else one launch per PCG iteration
         const bool lds_ok = sv_ba_pcg_lds_bytes(D) > 0;
         // AUTO: dense LL^T in LDS while it fits (n <= ~135: 70 us per trial against 88 us for the LDS-resident PCG at n = 96), the
