@@ -116,7 +116,7 @@ inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 }  // namespace
 
 size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap) {
-    return 2 * pad256((size_t)(L + 2) * 4) + pad256(sv_sort_hist_ints(pair_cap) * 4) + 2 * pad256(pair_cap * 4) + pad256(pair_cap * 8) + pad256((nb_cap + 1) * 4) + 1024;
+    return 2 * pad256((size_t)(L + 2) * 4) + pad256(sv_scan_scratch_ints((size_t)L + 1) * 4) + pad256(sv_sort_hist_ints(pair_cap) * 4) + 2 * pad256(pair_cap * 4) + pad256(pair_cap * 8) + pad256((nb_cap + 1) * 4) + 1024;
 }
 
 namespace {
@@ -131,13 +131,14 @@ int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, si
         return (void*)r;
     };
     int* cnt = (int*)take((size_t)(L + 2) * 4);
+    int* cnt_scan = (int*)take(sv_scan_scratch_ints((size_t)L + 1) * 4);
     int* hist = (int*)take(sv_sort_hist_ints(pair_cap) * 4);
     unsigned* keys[2] = {(unsigned*)take(pair_cap * 4), (unsigned*)take(pair_cap * 4)};
     unsigned long long* vals[2] = {(unsigned long long*)take(pair_cap * 8), reinterpret_cast<unsigned long long*>(pairs_out)};
     if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list scratch too small");
     SV_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt);
-    sv_scan_i32(s, cnt, L);  // cnt[l] = first pair of landmark l, cnt[L] = the total
+    sv_scan_i32(s, cnt, L, cnt_scan);  // cnt[l] = first pair of landmark l, cnt[L] = the total
     SV_HIP(ctx, hipGetLastError());
     int total = total_host;
     if (read_total) {

@@ -4,8 +4,10 @@
 #include <cstddef>
 #include <cstdint>
 
-// in-place exclusive scan of data[0 .. n), total to data[n]; one workgroup, 16 elements per thread
-void sv_scan_i32(hipStream_t s, int* data, int n);
+// in-place exclusive scan of data[0 .. n), total to data[n] (data 16-byte aligned); `scratch` = sv_scan_scratch_ints(n) ints (0 for small n:
+// one workgroup; beyond that tile sums, their scan, and a scan of every tile behind its offset)
+size_t sv_scan_scratch_ints(size_t n);
+void sv_scan_i32(hipStream_t s, int* data, int n, int* scratch);
 // stable least-significant-digit radix sort (6-bit digits) of n (u32 key, u64 value) pairs by the low `bits` key bits, ping-ponging between
 // the two buffer sets; `hist` = sv_sort_hist_ints(n) ints of scratch.  The data starts in set `start`; returns the set that holds the result
 // (start ^ (passes & 1)).

@@ -67,6 +67,76 @@ __global__ __launch_bounds__(1024) void k_scan_i32(int* __restrict__ data, const
     if (tid == 0) data[n] = carry;
 }
 
+// ---- the same scan over many workgroups (n > SCAN_SINGLE_MAX): tile totals, a scan of the totals by the single-workgroup kernel above, then
+// every tile scans itself behind its offset.  A tile is 4096 elements = four rows of 1024; thread t owns elements 4t .. 4t + 3 of every row,
+// so that all loads and stores are 16 bytes per lane at a 16-byte lane pitch (the single-workgroup kernel walks 16 consecutive elements per
+// thread: every wave-level access touches 64 cache lines, ~9 us per 16 k elements -- 111 us for the 200 k landmark counts of config 5 and
+// 72 us for each histogram of its 4.2 M-pair radix passes; this takes ~15 us for either).
+#define SCAN_SINGLE_MAX 16384
+#define SCAN_TILE 4096
+__device__ __forceinline__ void scan_tile_load(const int* __restrict__ data, int base, int n, int tid, int4 (&v)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = base + c * 1024 + tid * 4;
+        if (i + 4 <= n) v[c] = *reinterpret_cast<const int4*>(data + i);
+        else v[c] = make_int4(i < n ? data[i] : 0, i + 1 < n ? data[i + 1] : 0, i + 2 < n ? data[i + 2] : 0, 0);
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const int* __restrict__ data, int n, int* __restrict__ tile_sum) {
+    __shared__ int s_w[4];
+    int4 v[4];
+    scan_tile_load(data, blockIdx.x * SCAN_TILE, n, threadIdx.x, v);
+    int t = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t += v[c].x + v[c].y + v[c].z + v[c].w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void k_scan_tiles(int* __restrict__ data, int n, const int* __restrict__ tile_off, int ntiles) {
+    __shared__ int s_w[4][4];  // [row][wave]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = blockIdx.x * SCAN_TILE;
+    int4 v[4];
+    scan_tile_load(data, base, n, tid, v);
+    int sum[4], incl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) incl[c] = sum[c] = v[c].x + v[c].y + v[c].z + v[c].w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int t = __shfl_up(incl[c], off, 64);
+            if (lane >= off) incl[c] += t;
+        }
+    if (lane == 63)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_w[c][wave] = incl[c];
+    __syncthreads();
+    int run = tile_off[blockIdx.x];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int before = 0, row = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            before += w < wave ? s_w[c][w] : 0;
+            row += s_w[c][w];
+        }
+        const int x0 = run + before + incl[c] - sum[c];
+        const int4 o = make_int4(x0, x0 + v[c].x, x0 + v[c].x + v[c].y, x0 + v[c].x + v[c].y + v[c].z);
+        const int i = base + c * 1024 + tid * 4;
+        if (i + 4 <= n) *reinterpret_cast<int4*>(data + i) = o;
+        else {
+            if (i < n) data[i] = o.x;
+            if (i + 1 < n) data[i + 1] = o.y;
+            if (i + 2 < n) data[i + 2] = o.z;
+        }
+        run += row;
+    }
+    if (blockIdx.x == 0 && tid == 0) data[n] = tile_off[ntiles];  // the total
+}
+
 // ---- stable LSD radix sort of (key, value) pairs by 6-bit digits
 #define RS_BITS 6
 #define RS_BINS 64
@@ -175,16 +245,27 @@ __global__ __launch_bounds__(1024) void k_sort_small(const unsigned* __restrict_
 }
 }  // namespace
 
-void sv_scan_i32(hipStream_t s, int* data, int n) { hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, data, (const int*)nullptr, n); }
+size_t sv_scan_scratch_ints(size_t n) { return n > SCAN_SINGLE_MAX ? (n + SCAN_TILE - 1) / SCAN_TILE + 8 : 0; }
+void sv_scan_i32(hipStream_t s, int* data, int n, int* scratch) {
+    if (n <= SCAN_SINGLE_MAX) {
+        hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, data, (const int*)nullptr, n);
+        return;
+    }
+    const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(256), 0, s, data, n, scratch);
+    hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, scratch, (const int*)nullptr, ntiles);  // scratch[ntiles] = the total
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, s, data, n, scratch, ntiles);
+}
 int sv_sort_passes(int bits) { return (bits + RS_BITS - 1) / RS_BITS; }
-size_t sv_sort_hist_ints(size_t n) { return (size_t)RS_BINS * ((n + RS_TILE - 1) / RS_TILE + 1) + 1; }
+static inline size_t hist_ints(size_t n) { return ((size_t)RS_BINS * ((n + RS_TILE - 1) / RS_TILE + 1) + 1 + 3) & ~size_t(3); }  // the scan's scratch follows, 16-byte aligned
+size_t sv_sort_hist_ints(size_t n) { return hist_ints(n) + sv_scan_scratch_ints(hist_ints(n)); }
 int sv_sort_pairs(hipStream_t s, unsigned* const keys[2], unsigned long long* const vals[2], int start, int n, int bits, int* hist) {
     int cur = start;
     if (n <= 0) return cur ^ (sv_sort_passes(bits) & 1);
     const int nblk = (n + RS_TILE - 1) / RS_TILE, passes = sv_sort_passes(bits);
     for (int pass = 0; pass < passes; ++pass, cur ^= 1) {
         hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], (const int*)nullptr, n, pass * RS_BITS, nblk, hist);
-        hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, s, hist, (const int*)nullptr, RS_BINS * nblk);
+        sv_scan_i32(s, hist, RS_BINS * nblk, hist + hist_ints((size_t)n));
         hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], (const int*)nullptr, n, pass * RS_BITS, nblk, hist, keys[cur ^ 1], vals[cur ^ 1]);
     }
     return cur;
