@@ -1063,8 +1063,12 @@ static size_t band_lds_bytes(const HostSky& h) {
 // connected pieces between them as jobs, the separator system with the fill the jobs leave on it.  G.ok only when every job fits the
 // banded kernel (k_sky_band in job mode) and the separator system has a plan.
 // cuts_only: stop once the pieces are known (G.max_nC, G.nsep_rows, the job count in G.nC.size()) -- what the cost model needs.
+// ends_half: the first and the last stretch of positions are HALF as long as the ones between two cuts.  The RCM order of a loop (config 5:
+// a ring of keyframes) walks both arcs away from its start at once, so a stretch between two cuts falls apart into two pieces (one per arc)
+// of half its length, while the stretch before the first cut (the arc through the start vertex) and the one behind the last stay whole: with
+// equal stretches those two jobs were twice as long as the other twelve (58 columns against 29) and set the time of the whole job launch.
 static void plan_segments(int nP, const std::vector<int>& order, const std::vector<std::vector<int>>& adj, const std::vector<int2>& blk_ab, int ncuts, int world,
-                          size_t max_bytes, HostSeg& G, bool cuts_only = false) {
+                          size_t max_bytes, HostSeg& G, bool cuts_only = false, bool ends_half = false) {
     G = HostSeg();
     if (ncuts < 1 || nP < 4) return;
     std::vector<int> pos0(nP);
@@ -1080,9 +1084,9 @@ static void plan_segments(int nP, const std::vector<int>& order, const std::vect
     auto width = [&](int c) { return std::max(0, reach[c] - c + 1); };
     std::vector<char> is_sep(nP, 0);  // by slot
     int prev_end = 0;
-    const int seg = nP / (ncuts + 1);
+    const int seg = ends_half ? nP / ncuts : nP / (ncuts + 1);
     for (int j = 1; j <= ncuts; ++j) {
-        const int target = (int)((long long)j * nP / (ncuts + 1)), win = std::max(1, seg / 4);
+        const int target = ends_half ? (int)((long long)(2 * j - 1) * nP / (2 * ncuts)) : (int)((long long)j * nP / (ncuts + 1)), win = std::max(1, seg / 4);
         int best = -1, bw = 1 << 30, boff = 1 << 30;
         for (int c = std::max(prev_end + 1, target - win); c <= std::min(nP - 2, target + win); ++c) {
             const int w = width(c);
@@ -1557,18 +1561,19 @@ static bool choose_segments(int nP, const std::vector<int>& order, const std::ve
                             size_t max_bytes, HostSeg& G, SegLayout& LY) {
     G = HostSeg();
     // candidates ranked by the column-count model on their cuts alone (cheap), then planned in full in that order until one holds
-    std::vector<std::pair<double, int>> cand;
-    for (int nc = want > 0 ? want : 2; nc <= (want > 0 ? want : 8); ++nc) {
-        HostSeg c;
-        plan_segments(nP, order, adj, blk_ab, nc, world, max_bytes, c, true);
-        if (!c.ok || (int)c.nC.size() < world) continue;
-        cand.push_back({3.0 * c.max_nC + 3.0 * c.nsep_rows + 15.0, nc});
-    }
+    std::vector<std::pair<double, int>> cand;  // (model cost, cuts * 2 + ends_half)
+    for (int nc = want > 0 ? want : 2; nc <= (want > 0 ? want : 8); ++nc)
+        for (int eh = 0; eh < 2; ++eh) {
+            HostSeg c;
+            plan_segments(nP, order, adj, blk_ab, nc, world, max_bytes, c, true, eh != 0);
+            if (!c.ok || (int)c.nC.size() < world) continue;
+            cand.push_back({3.0 * c.max_nC + 3.0 * c.nsep_rows + 15.0, 2 * nc + eh});
+        }
     std::sort(cand.begin(), cand.end());
     double best = 1e30;
     for (const auto& cn : cand) {
         HostSeg c;
-        plan_segments(nP, order, adj, blk_ab, cn.second, world, max_bytes, c);
+        plan_segments(nP, order, adj, blk_ab, cn.second >> 1, world, max_bytes, c, false, (cn.second & 1) != 0);
         if (!c.ok) continue;
         const bool sep_band = c.sep.nP == 0 || (c.sep.band && c.sep.max_m <= SKY_BAND_W && band_lds_bytes(c.sep) <= 150 * 1024);
         const double cost = 3.0 * c.max_nC + (sep_band ? 3.0 : 6.5) * c.sep.nP + 15.0;
