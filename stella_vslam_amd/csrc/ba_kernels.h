@@ -27,6 +27,7 @@ struct BaDev {
     int nP;        // free, active poses = rows/6 of the reduced system
     int n;         // 6 * nP
     BaCtl* ctl;
+    unsigned long long* dbg;  // SVGPU_BA_DBG: 8 wall_clock64 stamps per workgroup of the last k_ba_tail launch (null otherwise)
     const volatile int* stop_mirror;  // page-locked host word the caller's force_stop_flag is mirrored into while the host waits
     const double* xsum;               // sharded solve: {chi2, step scale, solver failures, stop votes} summed over the ranks; else null
     // state: [R|t] rows (12 doubles per pose), 3 doubles per landmark; buffer ctl->cur = linearisation point, the other = cur (+) delta
@@ -135,7 +136,9 @@ void sv_ba_pack_out(hipStream_t s, const BaDev& D, double* out);  // poses | poi
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale);   // this rank's partial sums -> 4 doubles (sharded solve)
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in);       // start of SparseOptimizer::optimize(it_max)
 void sv_ba_prepare(hipStream_t s, const BaDev& D);                              // lambda init (iteration 0) + start of a trial
-void sv_ba_decide(hipStream_t s, const BaDev& D);                               // rho test, damping update, terminate_action
+void sv_ba_decide(hipStream_t s, const BaDev& D);
+bool sv_ba_tail_ok(const BaDev& D);                                             // local-BA sized, not sharded
+void sv_ba_tail(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);                 // update + chi2 of the trial state in one launch                               // rho test, damping update, terminate_action
 void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);          // rocSOLVER dpotrf / dpotrs (solver = dense)
 void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);               // back-substitution, trial state
 // block-Jacobi PCG on the block-sparse reduced camera system (ba_pcg.hip)

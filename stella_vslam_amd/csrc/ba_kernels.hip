@@ -1542,9 +1542,13 @@ __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
 
 // ------------------------------------------------------------------------------------------------ LM control on the device
 // fixed-order sum of n doubles by one 256-thread workgroup (strided partial sums, shuffle tree, wave partials in wave order)
+// (PEEK: the values were written by OTHER workgroups of the running kernel -- read them past this CU's L1)
+template <bool PEEK>
+__device__ __forceinline__ double ctl_peek(const double* p) { return PEEK ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+template <bool PEEK = false>
 __device__ __forceinline__ double ctl_sum(const double* __restrict__ v, int n, double* sw) {
     double t = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) t += v[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t += PEEK ? __hip_atomic_load(v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v[i];
     return block_sum_d(t, sw);
 }
 
@@ -1617,6 +1621,7 @@ __global__ void k_ba_prepare(BaDev D) {
 
 // end of a damping trial (OptimizationAlgorithmLevenberg::solve, the do { } while (rho < 0 && qmax < 10 && !terminate()) body)
 // and, when the trial closes the LM iteration, the terminate_action hook (optimize/terminate_action.cc:36-76)
+template <bool PEEK = false>
 __device__ __forceinline__ void lm_decide(const BaDev& D, double* sw /* 16 doubles */) {
     double temp_chi, scale;
     int failed, stop_now;
@@ -1627,10 +1632,16 @@ __device__ __forceinline__ void lm_decide(const BaDev& D, double* sw /* 16 doubl
         stop_now = D.xsum[3] > 0.5;
     }
     else {
-        temp_chi = D.E > 0 ? ctl_sum(D.red + D.red_chi_off, D.red_chi_n, sw) : 0.0;
-        scale = ctl_sum(D.red + D.red_scale_off, D.red_scale_n, sw);
-        failed = D.ctl->solve_failed;
-        stop_now = D.ctl->stop || *D.stop_mirror != 0;
+        // every load of the decision is issued before the first one is waited for (the host's stop word is a PCIe read: ~2 us on its own)
+        const int mirror = *D.stop_mirror;
+        failed = PEEK ? __hip_atomic_load(&D.ctl->solve_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : D.ctl->solve_failed;
+        double t_chi = 0.0, t_sc = 0.0;
+        if (D.E > 0)
+            for (int i = threadIdx.x; i < D.red_chi_n; i += blockDim.x) t_chi += ctl_peek<PEEK>(D.red + D.red_chi_off + i);
+        for (int i = threadIdx.x; i < D.red_scale_n; i += blockDim.x) t_sc += ctl_peek<PEEK>(D.red + D.red_scale_off + i);
+        temp_chi = block_sum_d(t_chi, sw);
+        scale = block_sum_d(t_sc, sw);
+        stop_now = D.ctl->stop || mirror != 0;
     }
     if (threadIdx.x != 0) return;
     BaCtl& c = *D.ctl;
@@ -1683,10 +1694,199 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BaDev D) {  // one workgroup
     lm_decide(D, sw);
 }
 
-// (Measured and dropped: update + trial chi2 + decision as ONE launch -- every workgroup recomputing the <= 64 trial poses into LDS, a
-// last-arriver running the decision -- takes 20.3 us against 7.5 + 4.8 + 6 us for the three kernels: the chain of dependent global
-// loads inside the fused kernel is the same chain, and a launch boundary costs only ~3 us here.)
-// dense (n + 1) x n image of the block-sparse system for the rocSOLVER path
+// FUSED TRIAL TAIL of a local-BA sized problem (not sharded, P <= TAIL_MAX_POSES): back-substitution, trial state and its robust chi2 in ONE
+// launch instead of two (k_ba_update, k_ba_chi2); the decision stays a launch of its own.  At this size a kernel's time is the number of
+// DEPENDENT memory round trips on its longest path (~1 us each: the data was written by the previous kernel on other XCDs), so the kernel is
+// laid out by hops:
+//   hop 1   control block | lm_off, pt_free, Hll, bl of the thread's landmark | pose_slot, intrinsics of pose `tid` | dp
+//   hop 2   the landmark's first edge per lane (level, pose, observation, W record) | current landmark | current pose `tid`
+//   LDS     trial poses (every workgroup computes all P exponentials itself), intrinsics, slots, dp
+//   hop 3   (only landmarks with more than 8 observations: the remaining edges of a lane)
+// Stamps (SVGPU_BA_DBG, config 3, 313 workgroups): all workgroups entered by 0.4 us, hop 1 back by 1.1 .. 2.8, table staged by 3.7, trial poses
+// by 5.4, sums written by 7.6 us.
+// The decision is NOT folded in (tried three ways): handing over to a last / deciding workgroup inside the launch needs a device-scope
+// release per workgroup, and on this part that is an L2 write-back towards the other XCDs -- a returning ticket on the control block cost
+// 5 us for 313 workgroups (one or two levels alike), add-only arrivals watched by workgroup 0 cost 3 .. 12 us each -- more than the
+// launch boundary it replaces, which does that write-back once.  Same per-landmark and per-workgroup sums, in the same order, as the two kernels.
+#define TAIL_MAX_POSES 256
+__global__ __launch_bounds__(256) void k_ba_tail(BaDev D) {
+    __shared__ double s4[16];
+    __shared__ double s_pose[TAIL_MAX_POSES * 12];
+    __shared__ double s_intr[TAIL_MAX_POSES * 5];
+    __shared__ double s_dp[TAIL_MAX_POSES * 6];
+    __shared__ int s_slot[TAIL_MAX_POSES];
+    const int tid = threadIdx.x;
+#define TAIL_T(i) do { if (D.dbg && tid == 0) D.dbg[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+    TAIL_T(0);
+    // ---- hop 1 (nothing here depends on a loaded value)
+    const int phase = D.ctl->phase, cur = D.ctl->cur;
+    const double lambda = D.ctl->lambda;
+    const int t = blockIdx.x * 256 + tid;
+    const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
+    const bool in_range = t / LM_LANES < D.L;
+    const int lo = D.lm_off[l], hi = D.lm_off[l + 1];
+    const bool lfree = in_range && D.pt_free[l];
+    double Hl[6], b[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hl[k] = D.Hll[(size_t)l * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) b[k] = D.bl[(size_t)l * 3 + k];
+    const bool has_pose = tid < D.P;
+    const int pq = has_pose ? tid : 0;
+    const int my_slot = D.pose_slot[pq];
+    double my_intr[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) my_intr[k] = D.intr[(size_t)pq * 5 + k];
+    const double my_dp = tid < D.n ? D.dp[tid] : 0.0;  // n = 6 nP <= 6 P; a workgroup of 256 stages up to 256 entries per pass
+    if (phase != 1) return;
+    TAIL_T(1);
+    // ---- hop 2
+    const double* pose_cur = D.pose_buf[cur & 1];
+    const double* pt_cur = D.pt_buf[cur & 1];
+    double* pt_trial = D.pt_buf[(cur & 1) ^ 1];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = pose_cur[(size_t)pq * 12 + k];
+    double X[3] = {pt_cur[(size_t)l * 3], pt_cur[(size_t)l * 3 + 1], pt_cur[(size_t)l * 3 + 2]};
+    const int e0 = lo + sub;
+    const bool has0 = in_range && e0 < hi;
+    const int ee = has0 ? e0 : 0;
+    const int lvl0 = D.e_level[ee], p0 = D.e_pose[ee], rob0 = D.e_robust[ee];
+    const float u0 = D.e_uvr[(size_t)ee * 3], v0 = D.e_uvr[(size_t)ee * 3 + 1], r0 = D.e_uvr[(size_t)ee * 3 + 2], w0 = D.e_w[ee], hub0 = D.e_huber[ee];
+    double W0[18];
+    {
+        const double2* Wd = reinterpret_cast<const double2*>(D.W + (size_t)ee * 18);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double2 q = Wd[k];
+            W0[2 * k] = q.x;
+            W0[2 * k + 1] = q.y;
+        }
+    }
+    // ---- stage the pose table
+    for (int i = tid; i < D.n; i += 256) s_dp[i] = i == tid ? my_dp : D.dp[i];
+    if (has_pose) {
+        s_slot[tid] = my_slot;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_intr[tid * 5 + k] = my_intr[k];
+    }
+    __syncthreads();
+    TAIL_T(2);
+    double scp = 0.0;
+    if (has_pose) {  // pose_update(), from the staged values
+        double O[12];
+        if (my_slot < 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) O[k] = T[k];
+        }
+        else {
+            double u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] = s_dp[my_slot * 6 + k];
+            if (D.scale_pose) {
+                const double* bpv = D.bp_full + (size_t)my_slot * 6;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) scp += u[k] * (lambda * u[k] + bpv[k]);
+            }
+            po_exp_mul(u, T, O);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s_pose[tid * 12 + k] = O[k];
+        if (blockIdx.x == 0) {
+            double* Og = D.pose_buf[(cur & 1) ^ 1] + (size_t)tid * 12;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) Og[k] = O[k];
+        }
+    }
+    if (blockIdx.x == 0) {  // the pose share of delta^T (lambda delta + b): the slot k_ba_update's pose workgroup writes
+        const double ts = block_sum_d(scp, s4);
+        if (tid == 0) D.red[D.red_scale_off + gridDim.x] = ts;
+    }
+    __syncthreads();
+    TAIL_T(3);
+    // ---- back-substitution of the landmark (lm_update_lane)
+    double sc = 0.0;
+    double c[3] = {0.0, 0.0, 0.0};
+    if (lfree) {
+        if (has0 && !lvl0 && s_slot[p0] >= 0) {
+            const double* xp = s_dp + s_slot[p0] * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                c[0] -= W0[3 * i] * xp[i];
+                c[1] -= W0[3 * i + 1] * xp[i];
+                c[2] -= W0[3 * i + 2] * xp[i];
+            }
+        }
+        for (int e = e0 + LM_LANES; e < hi; e += LM_LANES) {
+            if (D.e_level[e]) continue;
+            const int slot = s_slot[D.e_pose[e]];
+            if (slot < 0) continue;
+            const double* Wd = D.W + (size_t)e * 18;
+            const double* xp = s_dp + slot * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                c[0] -= Wd[3 * i] * xp[i];
+                c[1] -= Wd[3 * i + 1] * xp[i];
+                c[2] -= Wd[3 * i + 2] * xp[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = group_sum8(c[k]);
+    if (lfree) {
+        c[0] += b[0];
+        c[1] += b[1];
+        c[2] += b[2];
+        double I[6];
+        if (!lm_dinv(Hl, lambda, I)) D.ctl->solve_failed = 1;  // benign race: every writer stores 1
+        const double d0 = I[0] * c[0] + I[1] * c[1] + I[2] * c[2];
+        const double d1 = I[1] * c[0] + I[3] * c[1] + I[4] * c[2];
+        const double d2 = I[2] * c[0] + I[4] * c[1] + I[5] * c[2];
+        X[0] += d0;
+        X[1] += d1;
+        X[2] += d2;
+        if (sub == 0) sc = d0 * (lambda * d0 + b[0]) + d1 * (lambda * d1 + b[1]) + d2 * (lambda * d2 + b[2]);
+    }
+    if (in_range && sub == 0) {
+        pt_trial[(size_t)l * 3] = X[0];
+        pt_trial[(size_t)l * 3 + 1] = X[1];
+        pt_trial[(size_t)l * 3 + 2] = X[2];
+    }
+    // ---- robust chi2 of the landmark's observations at the trial state (lm_chi2_lane)
+    double v = 0.0;
+    if (has0 && !lvl0) {
+        const float uvr[3] = {u0, v0, r0};
+        double r[3];
+        const double chi = edge_error(s_pose + p0 * 12, X, s_intr + p0 * 5, uvr, (double)w0, r, nullptr);
+        if (rob0) {
+            double rho0, rho1;
+            huber(chi, (double)hub0, &rho0, &rho1);
+            v += rho0;
+        }
+        else v += chi;
+    }
+    if (in_range)
+        for (int e = e0 + LM_LANES; e < hi; e += LM_LANES) {
+            if (D.e_level[e]) continue;
+            const int p = D.e_pose[e];
+            double r[3];
+            const double chi = edge_error(s_pose + p * 12, X, s_intr + p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
+            if (D.e_robust[e]) {
+                double rho0, rho1;
+                huber(chi, (double)D.e_huber[e], &rho0, &rho1);
+                v += rho0;
+            }
+            else v += chi;
+        }
+    const double tsc = block_sum_d(sc, s4);
+    const double tchi = block_sum_d(v, s4);
+    TAIL_T(4);
+    if (tid == 0) {
+        D.red[D.red_scale_off + blockIdx.x] = tsc;
+        D.red[D.red_chi_off + blockIdx.x] = tchi;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
     if (D.ctl->phase != 1) return;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1743,6 +1943,11 @@ void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale) { h
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(256), 0, s, D, it_max, stop_in); }
 void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }
 void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D); }
+bool sv_ba_tail_ok(const BaDev& D) { return D.world <= 1 && D.xsum == nullptr && D.P > 0 && D.P <= TAIL_MAX_POSES && D.L > 0; }
+void sv_ba_tail(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {  // update + chi2 of the trial state + decide (sv_ba_tail_ok)
+    SvProfScope ps(ctx, s, "ba_tail");
+    hipLaunchKernelGGL(k_ba_tail, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D);
+}
 
 int sv_ba_lin_split_max() { return LIN_SPLIT_MAX; }
 int sv_ba_lin_split(int E, int nP) {  // workgroups per free pose on the pose side of k_ba_lin

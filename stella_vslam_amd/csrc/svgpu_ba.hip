@@ -381,7 +381,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
-    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap);
+    need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap) + pad(64 * (size_t)nb_lm);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -431,6 +431,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.dp = A.take<double>(nmax);
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
     D.lm_max = A.take<double>(nb_lm);  // nb_lm == sv_ba_lm_blocks(L)
+    static const bool dbg_stamps = std::getenv("SVGPU_BA_DBG") != nullptr;
+    D.dbg = dbg_stamps ? A.take<unsigned long long>(8 * (size_t)nb_lm) : nullptr;
     double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
     double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
     double* d_xch = A.take<double>(xch_doubles);                  // sharded: pose-activity / block-presence / point exchange
@@ -765,8 +767,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     // one damping trial (preceded by the linearisation when the control block asks for one); everything is guarded by the control
     // block on the device, so a step enqueued behind a finished optimisation costs a dozen empty launches
     const int pcg_max_it = ctx->pcg_max_it > 0 ? ctx->pcg_max_it : 0;
+    static const bool no_fusion = std::getenv("SVGPU_BA_NO_FUSION") != nullptr;  // A/B aid: the separate kernels
     auto enqueue_step = [&](bool* finished_seen) -> int {
         int r;
+        const bool fused_tail = !no_fusion && !sharded && sv_ba_tail_ok(D);
         sv_ba_linearize(ctx, s, D, sharded ? 0 : 1);
         if (sharded) {  // pose blocks summed over the ranks before the damping is initialised from their diagonal
             if (HS.nP > 0) {
@@ -804,8 +808,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                 }
             }
         }
-        sv_ba_update(ctx, s, D);
-        sv_ba_chi2(ctx, s, D, 1, 0, 1);
+        if (fused_tail) sv_ba_tail(ctx, s, D);
+        else {
+            sv_ba_update(ctx, s, D);
+            sv_ba_chi2(ctx, s, D, 1, 0, 1);
+        }
         if (sharded) {
             sv_ba_fold(s, D, d_sc, 1);
             if ((r = allreduce_dev(d_sc, 4))) return r;
@@ -857,6 +864,21 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int it1 = 0, it2 = 0;
     rc = optimize(pr->num_first_iter, &it1);
     if (rc) return rc;
+    if (D.dbg) {  // SVGPU_BA_DBG: where the time of the last fused tail went (100 MHz stamps, relative to the first workgroup's entry)
+        std::vector<unsigned long long> h(8 * (size_t)nb_lm);
+        SV_HIP(ctx, hipMemcpyAsync(h.data(), D.dbg, 8 * h.size(), hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nb_lm; ++b) t0 = std::min(t0, h[8 * (size_t)b]);
+        double mx[7] = {0, 0, 0, 0, 0, 0, 0}, mn[7] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30};
+        for (int b = 0; b < nb_lm; ++b)
+            for (int k = 0; k < 7; ++k) {
+                const double us = (double)(h[8 * (size_t)b + k] - t0) * 0.01;
+                mx[k] = std::max(mx[k], us), mn[k] = std::min(mn[k], us);
+            }
+        std::fprintf(stderr, "[ba] tail stamps (us, min..max over %d workgroups): entry %.2f..%.2f | hop1 %.2f..%.2f | staged %.2f..%.2f | poses %.2f..%.2f | sums %.2f..%.2f\n",
+                     nb_lm, mn[0], mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], mn[4], mx[4]);
+    }
     st.chi2_initial = h_ctl->chi_begin;
     st.iters_stage1 = it1;
     lap("stage 1");
