@@ -569,6 +569,12 @@ int svgpu_selftest_segmented_solve_rank(int nP, int NB, const int* blk_ab, const
                                         int (*allreduce)(void* user, double* buf, size_t count, void* stream), void* allreduce_user, double* x,
                                         int* info);
 
+/* Device self-test of the hand-written scan and radix sort the BA structure builder and the BoW merge-join run on (csrc/sv_sort.hip; NOT a
+ * product entry point).  values[n] >= 0 are scanned in place semantics: scan_out[n + 1] receives the exclusive prefix sums and the total
+ * (n above 16384 takes the many-workgroup path).  keys[n] (low `bits` bits significant) are sorted stably: sorted_idx[n] receives the
+ * permutation.  Either half is skipped when its output pointer is NULL.  Host in / out, synchronous. */
+int svgpu_selftest_scan_sort(svgpu_ctx* ctx, int n, const int32_t* values, int32_t* scan_out, const uint32_t* keys, int bits, int32_t* sorted_idx);
+
 /* Host in/out, synchronous.  The Levenberg-Marquardt loop (damping trials, rho test, terminate_action) runs on the device; the
  * host enqueues the trials of a stage and reads the control block back once per stage (plus once per rejected trial).
  *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled at every damping-trial boundary

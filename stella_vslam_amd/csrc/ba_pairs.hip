@@ -225,3 +225,44 @@ int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev,
     SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
 }
+
+// ---- svgpu_selftest_scan_sort (include/svgpu.h): the scan and the radix sort on caller data
+extern "C" int svgpu_selftest_scan_sort(svgpu_ctx* ctx, int n, const int32_t* values, int32_t* scan_out, const uint32_t* keys, int bits, int32_t* sorted_idx) {
+    if (!ctx || n < 0 || bits < 1 || bits > 32 || (scan_out && !values) || (sorted_idx && !keys)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_selftest_scan_sort: bad arguments");
+    if (n == 0) {
+        if (scan_out) scan_out[0] = 0;
+        return SVGPU_OK;
+    }
+    hipStream_t s = ctx->stream;
+    const size_t N = (size_t)n;
+    const size_t bytes = pad256((N + 2) * 4) + pad256(sv_scan_scratch_ints(N + 1) * 4 + 64) + 2 * pad256(N * 4) + 2 * pad256(N * 8) + pad256(sv_sort_hist_ints(N) * 4) + pad256(N * 4) + 4096;
+    int rc = sv_ensure_scratch(ctx, bytes);
+    if (rc) return rc;
+    char* p = (char*)ctx->d_scratch;
+    auto take = [&](size_t b) {
+        char* r = p;
+        p += pad256(b);
+        return (void*)r;
+    };
+    int* d_scan = (int*)take((N + 2) * 4);
+    int* d_scan_scr = (int*)take(sv_scan_scratch_ints(N + 1) * 4 + 64);
+    unsigned* k2[2] = {(unsigned*)take(N * 4), (unsigned*)take(N * 4)};
+    unsigned long long* v2[2] = {(unsigned long long*)take(N * 8), (unsigned long long*)take(N * 8)};
+    int* hist = (int*)take(sv_sort_hist_ints(N) * 4);
+    int* d_idx = (int*)take(N * 4);
+    if (scan_out) {
+        SV_HIP(ctx, hipMemcpyAsync(d_scan, values, N * 4, hipMemcpyHostToDevice, s));
+        sv_scan_i32(s, d_scan, n, d_scan_scr);
+        SV_HIP(ctx, hipMemcpyAsync(scan_out, d_scan, (N + 1) * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (sorted_idx) {
+        SV_HIP(ctx, hipMemcpyAsync(k2[0], keys, N * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_iota_u64, dim3((n + 255) / 256), dim3(256), 0, s, v2[0], n);
+        const int r = sv_sort_pairs(s, k2, v2, 0, n, bits, hist);
+        hipLaunchKernelGGL(k_narrow_u64, dim3((n + 255) / 256), dim3(256), 0, s, v2[r], n, d_idx);
+        SV_HIP(ctx, hipMemcpyAsync(sorted_idx, d_idx, N * 4, hipMemcpyDeviceToHost, s));
+    }
+    SV_HIP(ctx, hipGetLastError());
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    return SVGPU_OK;
+}

@@ -270,14 +270,20 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     std::vector<int> perm;  // sorted position -> caller's observation index (empty = identity)
     std::vector<uint8_t> level(E, 0);
     bool no_levels = true;  // until the first gate: every edge is at level 0
-    const int nth = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD") ? 4 : 1;  // host threads of the staging passes at global-BA sizes
+    // host threads of the staging pass at global-BA sizes (SVGPU_BA_HOST_THREADS overrides, 1 .. 16)
+    const int nth = [&] {
+        if (E < 400000 || std::getenv("SVGPU_BA_ONE_THREAD")) return 1;
+        const char* ev = std::getenv("SVGPU_BA_HOST_THREADS");
+        const int v = ev ? std::atoi(ev) : 4;
+        return v < 1 ? 1 : (v > 16 ? 16 : v);
+    }();
     // ONE pass over the observation indices (nth contiguous ranges): range check, "already grouped by landmark?" (the order
     // local_bundle_adjuster_g2o.cc:168-227 creates its edges in) and -- valid in that case -- the landmark offsets from the run boundaries
     bool lm_major = true;
     std::vector<uint8_t> pose_seen(P, 0);  // a pose with an observation (the pose half of the first stage's activity pass)
     {
-        int bad[4] = {0, 0, 0, 0}, unsorted[4] = {0, 0, 0, 0};
-        std::vector<uint8_t> seen_q[4];
+        int bad[16] = {0}, unsorted[16] = {0};
+        std::vector<uint8_t> seen_q[16];
         // (a global-BA sized problem is 34 MB of observations: the host threads also share the copy into the staging image -- harmless
         //  when the order turns out not to be landmark-major, the permuted copy below overwrites it)
         auto copy_range = [&](size_t a, size_t b) {
@@ -308,15 +314,20 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             }
             bad[q] = bd, unsorted[q] = un;
             if (!bd) copy_range(e0, end);
+            // (the landmark positions -- 4.8 MB at config 5 -- are shared the same way)
+            const size_t l0 = (size_t)L * q / nth, l1 = (size_t)L * (q + 1) / nth;
+            memcpy(hs + in.points + sizeof(double) * 3 * l0, pr->points + 3 * l0, sizeof(double) * 3 * (l1 - l0));
         };
         std::vector<std::thread> th;
         for (int q = 1; q < nth; ++q) th.emplace_back(scan_range, q);
         scan_range(0);
         for (auto& t : th) t.join();
-        if (bad[0] | bad[1] | bad[2] | bad[3]) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+        int any_bad = 0, any_unsorted = 0;
+        for (int q = 0; q < nth; ++q) any_bad |= bad[q], any_unsorted |= unsorted[q];
+        if (any_bad) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
         for (int q = 1; q < nth; ++q)
             for (int p = 0; p < P; ++p) pose_seen[p] |= seen_q[q][p];
-        lm_major = !(unsorted[0] | unsorted[1] | unsorted[2] | unsorted[3]);
+        lm_major = !any_unsorted;
         if (lm_major)
             for (int k = (E > 0 ? pr->obs_point[E - 1] + 1 : 0); k <= L; ++k) lm_off[k] = E;
     }
@@ -342,7 +353,6 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     }
     // (the pose -> edge lists and the robust-kernel flags are built on the device once the observations are there: sv_ba_build_pose_lists)
     memcpy(hs + in.pose, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
-    memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
     memcpy(hs + in.intr, pr->intrinsics, sizeof(double) * 5 * (size_t)P);
 
     lap("sort observations");
