@@ -837,10 +837,17 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
 
 // ------------------------------------------------------------------------------------------------ candidate lists
 // dist[c] for every CSR entry; 0xFFFF = gated out (stereo / orientation gates of projection.cc:57-62,179-181)
+// are the entries of a list of n candidates kept sorted by (distance, scan position)?  Not beyond 1024 entries, and not in the modes whose outcome depends on the scan
+// ORDER beyond ties: TRIANGULATION skips every candidate farther than the running best (bow_tree.cc:96-98 / robust.cc:89-91), so its
+// "second" is the last superseded best, and AREA replays a non-monotone state.
+#define CAND_SORT_MAX 1024
+__device__ __forceinline__ bool cand_sorted(const CandProblem& P, int n) { return n <= CAND_SORT_MAX && P.mode != SVGPU_MATCH_TRIANGULATION && P.mode != SVGPU_MATCH_AREA; }
 __global__ void k_cand_dist(CandProblem P) {
     const int q = blockIdx.x;
     if (P.q_valid && !P.q_valid[q]) return;
     const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
+    __shared__ unsigned long long s_key[CAND_SORT_MAX];  // composites of a long list (more than one entry per lane)
+    const bool long_sorted = hi - lo > 64 && cand_sorted(P, hi - lo);
     uint32_t qd[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) qd[k] = P.qdesc[(size_t)q * 8 + k];
@@ -865,10 +872,60 @@ __global__ void k_cand_dist(CandProblem P) {
                 if ((double)5.99146f < err * inv_sigma_sq) gated = true;
             }
         }
-        P.dist[c] = gated ? 0xFFFFFFFFu : ((uint32_t)hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
+        const uint32_t e = gated ? 0xFFFFFFFFu : ((uint32_t)hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
+        P.dist[c] = e;
+        if (long_sorted) s_key[c - lo] = e == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(e >> 22) << 32) | ((unsigned long long)(c - lo) << 22) | (e & 0x3FFFFFu);
+    }
+    // Lists of at most 64 entries are left SORTED by (distance, scan position) (cand_sorted): the replay's sweeps then look at the first
+    // one or two still-available entries of a list instead of walking all of it -- the walk, one thread per query through ~50 scattered
+    // entries per sweep, was 250 us of a tracked frame's match_current_and_last_frames.  One entry per lane, a bitonic network on the 64
+    // composite keys (distance | position | target; gated entries and empty lanes sort last).
+    const int n = hi - lo;
+    if (!cand_sorted(P, n)) return;
+    if (n <= 64) {
+        const int c = lo + (int)threadIdx.x;
+        const uint32_t e = c < hi ? P.dist[c] : 0xFFFFFFFFu;  // this lane's own store above
+        unsigned long long key = e == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(e >> 22) << 32) | ((unsigned long long)threadIdx.x << 22) | (e & 0x3FFFFFu);
+        const int lane = threadIdx.x;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const unsigned long long other = __shfl_xor(key, j, 64);
+                const bool up = (lane & k) == 0, low = (lane & j) == 0;  // ascending block, lower element of the pair
+                const bool take_min = up == low;
+                key = take_min ? (key < other ? key : other) : (key < other ? other : key);
+            }
+        if (c < hi) P.dist[c] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
+        return;
+    }
+    // longer lists (wide windows at the coarse levels; a handful per frame, but an unsorted one is walked to its end by ONE thread in every
+    // sweep of the replay, and the slowest thread is what a sweep costs): the same network on the composites in LDS
+    int npow2 = 128;
+    while (npow2 < n) npow2 <<= 1;
+    for (int i = n + threadIdx.x; i < npow2; i += 64) s_key[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += 64) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long a = s_key[i], b = s_key[p];
+                    if ((a > b) == ((i & k) == 0)) {
+                        s_key[i] = b;
+                        s_key[p] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const unsigned long long key = s_key[i];
+        P.dist[lo + i] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
     }
 }
 
+__device__ __forceinline__ int cand_verdict(const CandProblem& P, unsigned best, unsigned second, int best_lvl, int second_lvl, int best_idx);
 __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
     if (P.q_valid && !P.q_valid[q]) return -1;
     const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
@@ -876,6 +933,31 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
     const bool tri = P.mode == SVGPU_MATCH_TRIANGULATION;
     unsigned best = tri ? P.thr : MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
     int best_lvl = -1, second_lvl = -1, best_idx = -1;
+    if (cand_sorted(P, hi - lo)) {
+        // sorted list: the scan below ends with best = the first available entry in (distance, position) order and second = the next one
+        // (a superseded best is the (distance, position)-minimum so far, and an equal distance never replaces an earlier one), both only
+        // when below MAX_HAMMING_DIST -- so the first two available entries decide
+        for (int c = lo; c < hi; ++c) {
+            const uint32_t e = P.dist[c];
+            if (e == 0xFFFFFFFFu) break;  // gated entries sort last
+            const unsigned d = e >> 22;
+            if (d >= MAX_HAMMING_DIST) break;
+            const int t = (int)(e & 0x3FFFFFu);
+            if (owner[t] < q) continue;  // occupied before this query
+            if (best_idx < 0) {
+                best = d;
+                best_idx = t;
+                best_lvl = P.t_octave ? P.t_octave[t] : 0;
+                if (P.mode == SVGPU_MATCH_BEST_ONLY) break;
+            }
+            else {
+                second = d;
+                second_lvl = P.t_octave ? P.t_octave[t] : 0;
+                break;
+            }
+        }
+    }
+    else {
     auto visit = [&](uint32_t e) {
         if (e == 0xFFFFFFFFu) return;
         const unsigned d = e >> 22;
@@ -902,6 +984,12 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
         visit(e2);
         visit(e3);
     }
+    }
+    return cand_verdict(P, best, second, best_lvl, second_lvl, best_idx);  // (RATIO / TRIANGULATION: plain Lowe test, bow_tree.cc:226-233, :133-140)
+}
+
+// The final tests of cand_decide on (best, second) -- shared with the cached form below
+__device__ __forceinline__ int cand_verdict(const CandProblem& P, unsigned best, unsigned second, int best_lvl, int second_lvl, int best_idx) {
     if (P.mode == SVGPU_MATCH_RATIO_SAME_OCTAVE) {
         if (best <= P.thr) {
             if (best_lvl == second_lvl && (float)best > P.lowe_ratio * (float)second) return -1;
@@ -913,27 +1001,157 @@ __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
         if (P.thr < best) return -1;
         return best_idx;
     }
-    // RATIO / TRIANGULATION: plain Lowe test (bow_tree.cc:226-233, :133-140)
     if (P.thr < best || best_idx < 0) return -1;
     if (P.lowe_ratio * (float)second < (float)best) return -1;
     return best_idx;
 }
 
-__global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds) {
+// Fixed-point replay of the reference's sequential greedy loop (a query takes its best target among those no EARLIER query holds): sweeps of
+// "every query decides against the owner table of the previous sweep, then the winners claim" until nothing changes (8 sweeps for a tracked
+// frame's match_current_and_last_frames).  What a sweep costs is the walk of every query through its list until two still-available entries
+// are found -- late in the replay most of a list is taken, and a walk through global memory is one dependent round trip (~1 us) per entry:
+// 12.7 us per sweep, 100 of the kernel's 123 us (time stamps inside the kernel).  So the whole state lives in the workgroup's LDS: owner and
+// match tables, the list offsets, the initial occupancy and the levels as bytes, and the first K entries of every SORTED list (K = what
+// fits: 12 for 2 400 queries, 5 for 4 800); only entries beyond K and unsorted lists (more than 64 candidates, order-dependent modes) are read
+// from global memory, four at a time.
+// (LDS pointers carry their address space: through a generic pointer every access is a FLAT instruction -- global-memory latency for
+//  on-chip data; the replay's decisions are chains of six dependent table look-ups, and they were 12 us per sweep that way)
+#define SV_LDS __attribute__((address_space(3)))
+struct CandLds {
+    SV_LDS int* owner;      // nt
+    SV_LDS int* match;      // nq
+    SV_LDS int* off;        // nq + 1
+    SV_LDS uint32_t* head;  // nq x K
+    SV_LDS uint8_t* occ;    // nt (null: nothing occupied initially)
+    SV_LDS uint8_t* lvl;    // nt (null: no levels)
+    SV_LDS uint8_t* qv;     // nq (null: every query is valid)
+    int K;
+};
+__device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, const CandLds& S) {
+    const int lo = S.off[q], n = S.off[q + 1] - lo;
+    if (n == 0 || (S.qv && !S.qv[q])) return -1;
+    if (!cand_sorted(P, n)) return cand_decide(P, q, (const int*)S.owner);
+    unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
+    int best_lvl = -1, second_lvl = -1, best_idx = -1;
+    bool done = false;
+    auto take = [&](uint32_t e) {  // the first two available entries in (distance, position) order decide (cand_decide)
+        if (done) return;
+        if (e == 0xFFFFFFFFu || (e >> 22) >= MAX_HAMMING_DIST) {
+            done = true;
+            return;
+        }
+        const int t = (int)(e & 0x3FFFFFu);
+        if (S.owner[t] < q) return;
+        const int lv = S.lvl ? (int)S.lvl[t] : 0;
+        if (best_idx < 0) {
+            best = e >> 22;
+            best_idx = t;
+            best_lvl = lv;
+            if (P.mode == SVGPU_MATCH_BEST_ONLY) done = true;
+        }
+        else {
+            second = e >> 22;
+            second_lvl = lv;
+            done = true;
+        }
+    };
+    const int nk = min(n, S.K);
+    const SV_LDS uint32_t* h = S.head + (size_t)q * S.K;
+    for (int k = 0; k < nk && !done; ++k) take(h[k]);
+    for (int c = lo + nk; c < lo + n && !done; c += 4) {  // beyond the staged head: four independent loads per trip
+        const int hi = lo + n;
+        const uint32_t e0 = P.dist[c], e1 = c + 1 < hi ? P.dist[c + 1] : 0xFFFFFFFFu, e2 = c + 2 < hi ? P.dist[c + 2] : 0xFFFFFFFFu,
+                       e3 = c + 3 < hi ? P.dist[c + 3] : 0xFFFFFFFFu;
+        take(e0);
+        take(e1);
+        take(e2);
+        take(e3);
+    }
+    return cand_verdict(P, best, second, best_lvl, second_lvl, best_idx);
+}
+#define CAND_LDS_BUDGET (150 * 1024)
+// bytes of the LDS-resident form for (nq, nt) with K staged entries per list
+__host__ __device__ inline size_t cand_lds_bytes(int nq, int nt, int K) {
+    return (size_t)(nt + nq + nq + 1) * 4 + (size_t)nq * K * 4 + 2 * (((size_t)nt + 3) & ~size_t(3)) + (((size_t)nq + 3) & ~size_t(3)) + 16;
+}
+__global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) {
     extern __shared__ int s_cand[];
     __shared__ int s_changed;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    int* owner = use_lds ? s_cand : g_owner;
-    int* match = use_lds ? s_cand + P.nt : g_match;
+    CandLds S;
+    S.owner = (SV_LDS int*)s_cand;
+    S.match = S.owner + P.nt;
+    S.off = S.match + P.nq;
+    S.head = (SV_LDS uint32_t*)(S.off + P.nq + 1);
+    SV_LDS uint8_t* bytes = (SV_LDS uint8_t*)(S.head + (size_t)P.nq * K);
+    S.occ = P.occupied ? bytes : nullptr;
+    S.lvl = P.t_octave ? bytes + ((P.nt + 3) & ~3) : nullptr;
+    S.qv = P.q_valid ? bytes + 2 * ((P.nt + 3) & ~3) : nullptr;
+    S.K = K;
+    for (int q = tid; q <= P.nq; q += nthr) {
+        S.off[q] = P.cand_off[q];
+        if (S.qv && q < P.nq) S.qv[q] = P.q_valid[q];
+    }
+    for (int t = tid; t < P.nt; t += nthr) {
+        if (S.occ) S.occ[t] = P.occupied[t];
+        if (S.lvl) S.lvl[t] = (uint8_t)P.t_octave[t];
+    }
+    __syncthreads();
+    for (int i = tid; i < P.nq * K; i += nthr) {
+        const int q = i / K, k = i - q * K, lo = S.off[q], n = S.off[q + 1] - lo;
+        if (k < n) S.head[i] = P.dist[lo + k];
+    }
+    auto reset_owner = [&]() {
+        for (int t = tid; t < P.nt; t += nthr) S.owner[t] = (S.occ && S.occ[t]) ? -1 : 0x7FFFFFFF;
+    };
+    reset_owner();
+    for (int q = tid; q < P.nq; q += nthr) S.match[q] = -2;
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep <= P.nq; ++sweep) {  // three barriers per sweep
+        int local_changed = 0;
+        for (int q = tid; q < P.nq; q += nthr) {
+            const int d = cand_decide_lds(P, q, S);
+            if (d != S.match[q]) local_changed = 1;
+            S.match[q] = d;
+        }
+        if (local_changed) s_changed = 1;
+        __syncthreads();
+        if (!s_changed) break;
+        reset_owner();
+        __syncthreads();  // every thread has tested the flag: it can be cleared for the next sweep
+        if (tid == 0) s_changed = 0;
+        if (!P.no_claims)
+            for (int q = tid; q < P.nq; q += nthr) {
+                const int m = S.match[q];
+                if (m >= 0 && (!P.q_blocks || P.q_blocks[q])) __hip_atomic_fetch_min(S.owner + m, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        __syncthreads();
+    }
+    int local = 0;
+    for (int q = tid; q < P.nq; q += nthr) {
+        const int m = S.match[q];
+        P.match_q[q] = m;
+        local += m >= 0;
+    }
+    if (tid == 0) s_changed = 0;
+    __syncthreads();
+    if (local) atomicAdd(&s_changed, local);
+    __syncthreads();
+    if (tid == 0) *P.num = s_changed;
+}
+// the same replay with its tables in global memory (inputs beyond the LDS form)
+__global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __restrict__ owner, int* __restrict__ match) {
+    __shared__ int s_changed;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     auto reset_owner = [&]() {
         for (int t = tid; t < P.nt; t += nthr) owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;
     };
     reset_owner();
     for (int q = tid; q < P.nq; q += nthr) match[q] = -2;
+    if (tid == 0) s_changed = 0;
     __syncthreads();
     for (int sweep = 0; sweep <= P.nq; ++sweep) {
-        if (tid == 0) s_changed = 0;
-        __syncthreads();
         int local_changed = 0;
         for (int q = tid; q < P.nq; q += nthr) {
             const int d = cand_decide(P, q, owner);
@@ -945,6 +1163,7 @@ __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __rest
         if (!s_changed) break;
         reset_owner();
         __syncthreads();
+        if (tid == 0) s_changed = 0;
         if (!P.no_claims)
             for (int q = tid; q < P.nq; q += nthr)
                 if (match[q] >= 0 && (!P.q_blocks || P.q_blocks[q])) atomicMin(&owner[match[q]], q);
@@ -1406,8 +1625,16 @@ void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* ow
         return;
     }
     {
-        const size_t lds = (size_t)(P.nt + P.nq) * sizeof(int);
-        const int use_lds = lds <= 60 * 1024;
-        hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(1024), use_lds ? lds : 0, s, P, owner, match, use_lds);
+        // the LDS-resident form with as many staged entries per list as fit (at most 64: longer lists are not sorted)
+        if (cand_lds_bytes(P.nq, P.nt, 0) <= CAND_LDS_BUDGET) {
+            const int K = P.nq > 0 ? (int)std::min<size_t>(64, (CAND_LDS_BUDGET - cand_lds_bytes(P.nq, P.nt, 0)) / ((size_t)P.nq * 4)) : 0;
+            static bool allowed = false;
+            if (!allowed) {
+                (void)hipFuncSetAttribute((const void*)k_cand_replay_lds, hipFuncAttributeMaxDynamicSharedMemorySize, CAND_LDS_BUDGET);
+                allowed = true;
+            }
+            hipLaunchKernelGGL(k_cand_replay_lds, dim3(1), dim3(1024), cand_lds_bytes(P.nq, P.nt, K), s, P, K);
+        }
+        else hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(1024), 0, s, P, owner, match);
     }
 }

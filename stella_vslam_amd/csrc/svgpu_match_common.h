@@ -2,7 +2,10 @@
 // cell matchers, and the two-pass "grid build -> candidate lists -> candidate matcher" driver.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 #include "svgpu_internal.h"
@@ -74,6 +77,15 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
                   int mode, Stage&& stage, Finish&& finish, int32_t* match_q, int* num_matches) {
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    static const bool mtrace = std::getenv("SVGPU_MATCH_TRACE") != nullptr;  // host-side phase times of a call, to stderr
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t_prev = tnow();
+    auto lap = [&](const char* what) {
+        if (!mtrace) return;
+        const auto t = tnow();
+        std::fprintf(stderr, "[match] %-22s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
+        t_prev = t;
+    };
     const int nt = F.nt, ncell = F.grid_cols * F.grid_rows;
     // target side: descriptors, xy, seven nt x 4 arrays (t_octave, t_angle, t_xright, cell_of, cell_items, owner, mdist), occupied;
     // query side: cand_off, match_q, match; P.num; slack for the alignment of each take
@@ -110,8 +122,10 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         UPR(d_tx, float, F.t_xright, nt)
 #undef UP
 #undef UPR
+        lap(pass ? "target side (pass 1)" : "target side uploads");
         rc = stage(A, fresh, P, G);
         if (rc) return rc;
+        lap(pass ? "stage (pass 1)" : "stage: query uploads");
         G.t_xy = d_txy;
         G.t_octave = d_toct;
         G.nt = nt;
@@ -145,6 +159,8 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         if (!pass) {
             SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
             SV_HIP(ctx, hipStreamSynchronize(s));
+            lap("grid + total read-back");
+            if (mtrace) std::fprintf(stderr, "[match] nq %d nt %d candidates %d (%.1f per query)\n", nq, nt, total, nq ? (double)total / nq : 0.0);
             if (total == 0) {
                 rc = finish(P);
                 if (rc) return rc;
@@ -180,7 +196,9 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
         rc = finish(P);
         if (rc) return rc;
+        lap("lists + matcher enqueued");
         SV_HIP(ctx, hipStreamSynchronize(s));
+        lap("final sync");
         *num_matches = num;
     }
     return SVGPU_OK;
