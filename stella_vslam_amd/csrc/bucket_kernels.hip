@@ -229,7 +229,8 @@ void sv_bucket_rows(hipStream_t s, const BucketProblem& B) {
 void sv_bucket_count(hipStream_t s, const BucketProblem& B) {  // cand_off = exclusive scan of the per-row counts, total in cand_off[n1]
     if (B.n1 <= 0) return;
     hipLaunchKernelGGL(k_bucket_scan<false>, dim3((B.n1 + 3) / 4), dim3(256), 0, s, B);
-    hipLaunchKernelGGL(k_bucket_exscan, dim3(1), dim3(1024), 0, s, B.cand_off, B.n1);
+    if (B.n1 <= 16384) sv_scan_i32(s, B.cand_off, B.n1, nullptr);  // (the shuffle-based one-workgroup scan; the kernel above beyond its size)
+    else hipLaunchKernelGGL(k_bucket_exscan, dim3(1), dim3(1024), 0, s, B.cand_off, B.n1);
 }
 void sv_bucket_fill(hipStream_t s, const BucketProblem& B) {
     if (B.n1 > 0) hipLaunchKernelGGL(k_bucket_scan<true>, dim3((B.n1 + 3) / 4), dim3(256), 0, s, B);

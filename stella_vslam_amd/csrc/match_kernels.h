@@ -80,6 +80,7 @@ struct CandProblem {
     uint32_t* dist;           // one per CSR entry: (distance << 22) | target index, 0xFFFFFFFF = gated out (targets < 2^22)
     int32_t* match_q;
     int32_t* num;
+    int cap;                  // > 0: capacity of dist / cand_idx; the kernels do nothing when cand_off[nq] exceeds it (the host re-runs)
 };
 
 // Device-side candidate lists: data::assign_keypoints_to_grid + data::get_keypoints_in_cell (data/common.cc:83-190)
@@ -101,6 +102,7 @@ struct GridProblem {
     int nq;
     int32_t* cand_off;        // nq + 1 (counts, then their exclusive scan)
     int32_t* cand_idx;        // filled by the second walk
+    int cap;                  // > 0: capacity of cand_idx; the fill does nothing when the lists' total (cand_off[nq]) exceeds it (the host re-runs)
 };
 void sv_launch_grid_build(hipStream_t s, const GridProblem& G);                 // cell_of, cell_off, cell_items, cand_off (scanned)
 void sv_launch_grid_frame(hipStream_t s, const GridProblem& G);                 // ... the keypoint side alone (a resident frame is binned once)

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "match_kernels.h"
+#include "sv_sort.h"
 
 namespace {
 
@@ -843,6 +844,7 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
 #define CAND_SORT_MAX 1024
 __device__ __forceinline__ bool cand_sorted(const CandProblem& P, int n) { return n <= CAND_SORT_MAX && P.mode != SVGPU_MATCH_TRIANGULATION && P.mode != SVGPU_MATCH_AREA; }
 __global__ void k_cand_dist(CandProblem P) {
+    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) return;  // the lists did not fit the guessed capacity: the host re-runs with the exact size
     const int q = blockIdx.x;
     if (P.q_valid && !P.q_valid[q]) return;
     const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
@@ -1077,6 +1079,7 @@ __host__ __device__ inline size_t cand_lds_bytes(int nq, int nt, int K) {
 __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) {
     extern __shared__ int s_cand[];
     __shared__ int s_changed;
+    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     CandLds S;
     S.owner = (SV_LDS int*)s_cand;
@@ -1143,6 +1146,7 @@ __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) 
 // the same replay with its tables in global memory (inputs beyond the LDS form)
 __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __restrict__ owner, int* __restrict__ match) {
     __shared__ int s_changed;
+    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     auto reset_owner = [&]() {
         for (int t = tid; t < P.nt; t += nthr) owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;
@@ -1245,6 +1249,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_grid_walk(GridProblem G) {
     const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // scalar: per-query data via scalar loads
     if (q >= G.nq) return;
+    if (FILL && G.cap > 0 && G.cand_off[G.nq] > G.cap) return;  // capacity guess too small: nothing is written, the host re-runs
     int total = 0;
     const bool live = !G.q_valid || G.q_valid[q];
     if (live) {
@@ -1597,16 +1602,22 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     (void)sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_bf_replay), 144 * 1024);
     hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
 }
+// exclusive scan of the grid's counters: the shuffle-based one-workgroup scan of sv_sort.hip (4.5 us) up to its 16 k elements, the
+// Hillis-Steele kernel above (9 us per 1 024 elements, needs no scratch) beyond
+static void grid_scan(hipStream_t s, int32_t* data, int n) {
+    if (n <= 16384) sv_scan_i32(s, data, n, nullptr);
+    else hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, data, n);
+}
 void sv_launch_grid_frame(hipStream_t s, const GridProblem& G) {  // the keypoint side: cell_of, cell_off, cell_items
     const int nc = G.cols * G.rows;
     (void)hipMemsetAsync(G.cell_off, 0, (size_t)(nc + 1) * sizeof(int32_t), s);
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_assign, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cell_off, nc);
+    grid_scan(s, G.cell_off, nc);
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_place, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
 }
 void sv_launch_grid_queries(hipStream_t s, const GridProblem& G) {  // the query side over a binned frame: list sizes + their scan
     if (G.nq > 0) hipLaunchKernelGGL(k_grid_walk<false>, dim3((G.nq + 3) / 4), dim3(256), 0, s, G);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, G.cand_off, G.nq);
+    grid_scan(s, G.cand_off, G.nq);
 }
 void sv_launch_grid_build(hipStream_t s, const GridProblem& G) {
     sv_launch_grid_frame(s, G);

@@ -133,6 +133,7 @@ struct svgpu_ctx {
     int last_batch = 0;
     int last_extract_n = -1;             // keypoints of the last svgpu_orb_extract, still in d_kps / d_desc (svgpu_frame_adopt_extraction)
     const svgpu_frame* bound_frame = nullptr;  // svgpu_frame_bind: keypoint side of the NEXT matcher call (one-shot)
+    size_t cand_cap_hint = 0;                  // cell matchers: candidate-list capacity that sufficed last time (0: unknown -> exact two-pass sizing)
     const uint8_t* next_q_blocks = nullptr;    // svgpu_match_set_query_blocks: per-query "an accepted match occupies its target" of the NEXT svgpu_match_in_cells
     const uint8_t* last_imgs = nullptr;  // level-0 of the last call (device)
     size_t last_frame_stride = 0;

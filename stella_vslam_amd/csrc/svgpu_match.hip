@@ -202,12 +202,14 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     if (rc) return rc;
     Arena A(ctx->d_scratch);
     hipStream_t s = ctx->stream;
+    if ((rc = sv_ensure_stage(ctx, need))) return rc;
+    A.mirror = ctx->h_stage;  // batched upload / read-back (Arena::upload, Downloads)
     CandProblem P{};
 #define UP(dst, T, src, n)                                                                          \
     T* dst = nullptr;                                                                               \
     if (src) {                                                                                      \
         dst = A.take<T>(n);                                                                         \
-        SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+        if ((rc = A.upload(ctx, s, dst, src, (size_t)(n) * sizeof(T)))) return rc;                  \
     }
     UP(d_q, uint8_t, qdesc, (size_t)nq * 32)
     UP(d_t, uint8_t, tdesc, (size_t)nt * 32)
@@ -223,6 +225,7 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     UP(d_tx, float, t_xright, nt)
     UP(d_qtol, float, q_xr_tol, nq)
 #undef UP
+    if ((rc = A.flush(ctx, s))) return rc;
     P.qdesc = (const uint32_t*)d_q;
     P.tdesc = (const uint32_t*)d_t;
     P.t_octave = d_toct;
@@ -251,9 +254,12 @@ int svgpu_match_candidates(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const u
     sv_launch_cand(ctx, s, P, owner, match, mdist);
     SV_HIP(ctx, hipGetLastError());
     int32_t num = 0;
-    SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
+    Downloads D;
+    D.add(A, match_q, P.match_q, (size_t)nq * 4);
+    D.add(A, &num, P.num, 4);
+    if ((rc = D.fetch(ctx, s, A))) return rc;
     SV_HIP(ctx, hipStreamSynchronize(s));
+    D.scatter(A);
     *num_matches = num;
     return SVGPU_OK;
 }
@@ -296,7 +302,10 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
     T* dst = nullptr;                                                                               \
     if (src) {                                                                                      \
         dst = A.take<T>(n);                                                                         \
-        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+        if (fresh) {                                                                                \
+            const int rcu = A.upload(ctx, s, dst, src, (size_t)(n) * sizeof(T));                    \
+            if (rcu) return rcu;                                                                    \
+        }                                                                                           \
     }
             UP(d_q, uint8_t, qdesc, (size_t)nq * 32)
             UP(d_qxy, float, q_xy, (size_t)nq * 2)
@@ -322,7 +331,7 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
             P.q_blocks = d_qb;
             return SVGPU_OK;
         },
-        [&](const CandProblem&) -> int { return SVGPU_OK; }, match_q, num_matches);
+        [&](const CandProblem&, const Arena&, Downloads&) -> int { return SVGPU_OK; }, match_q, num_matches);
 }
 
 int svgpu_camera_image_bounds(svgpu_ctx* ctx, svgpu_camera* cam) {
@@ -501,19 +510,27 @@ int svgpu_reproject_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, const dou
     R.reproj = A.take<double>((size_t)n * 2);
     R.x_right = A.take<float>(n);
     R.pred_level = A.take<int32_t>(n);
-    SV_HIP(ctx, hipMemcpyAsync(d_pw, pos_w, (size_t)n * 24, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d_nv, mean_normal, (size_t)n * 24, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d_mn, min_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d_mx, max_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (skip) SV_HIP(ctx, hipMemcpyAsync(d_skip, skip, n, hipMemcpyHostToDevice, s));
+    // one upload and one read-back through the page-locked mirror of the arena (Arena::upload / Downloads): nine separate copies from / to
+    // pageable memory were nine staging kernels on the stream
+    if ((rc = sv_ensure_stage(ctx, need))) return rc;
+    A.mirror = ctx->h_stage;
+    if ((rc = A.upload(ctx, s, d_pw, pos_w, (size_t)n * 24))) return rc;
+    if ((rc = A.upload(ctx, s, d_nv, mean_normal, (size_t)n * 24))) return rc;
+    if ((rc = A.upload(ctx, s, d_mn, min_valid_dist, (size_t)n * 4))) return rc;
+    if ((rc = A.upload(ctx, s, d_mx, max_valid_dist, (size_t)n * 4))) return rc;
+    if (skip && (rc = A.upload(ctx, s, d_skip, skip, n))) return rc;
+    if ((rc = A.flush(ctx, s))) return rc;
     R.pos_w = d_pw, R.mean_normal = d_nv, R.min_valid_dist = d_mn, R.max_valid_dist = d_mx, R.skip = d_skip;
     sv_launch_reproject(s, R);
     SV_HIP(ctx, hipGetLastError());
-    SV_HIP(ctx, hipMemcpyAsync(visible, R.visible, n, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(reproj, R.reproj, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(x_right, R.x_right, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(pred_scale_level, R.pred_level, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    Downloads D;
+    D.add(A, visible, R.visible, n);
+    D.add(A, reproj, R.reproj, (size_t)n * 16);
+    D.add(A, x_right, R.x_right, (size_t)n * 4);
+    D.add(A, pred_scale_level, R.pred_level, (size_t)n * 4);
+    if ((rc = D.fetch(ctx, s, A))) return rc;
     SV_HIP(ctx, hipStreamSynchronize(s));
+    D.scatter(A);
     return SVGPU_OK;
 }
 
@@ -570,13 +587,15 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
             R.q_min_level = A.take<int32_t>(n);
             R.q_max_level = A.take<int32_t>(n);
             R.pos_w = d_pw, R.mean_normal = d_nv, R.min_valid_dist = d_mn, R.max_valid_dist = d_mx, R.skip = d_skip;
-            if (fresh) {
-                SV_HIP(ctx, hipMemcpyAsync(d_q, lm_desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-                SV_HIP(ctx, hipMemcpyAsync(d_pw, pos_w, (size_t)n * 24, hipMemcpyHostToDevice, s));
-                SV_HIP(ctx, hipMemcpyAsync(d_nv, mean_normal, (size_t)n * 24, hipMemcpyHostToDevice, s));
-                SV_HIP(ctx, hipMemcpyAsync(d_mn, min_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
-                SV_HIP(ctx, hipMemcpyAsync(d_mx, max_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
-                if (skip) SV_HIP(ctx, hipMemcpyAsync(d_skip, skip, n, hipMemcpyHostToDevice, s));
+            if (fresh) {  // one batched upload (Arena::upload / flush), then the reprojection that consumes it
+                int ru = A.upload(ctx, s, d_q, lm_desc, (size_t)n * 32);
+                if (!ru) ru = A.upload(ctx, s, d_pw, pos_w, (size_t)n * 24);
+                if (!ru) ru = A.upload(ctx, s, d_nv, mean_normal, (size_t)n * 24);
+                if (!ru) ru = A.upload(ctx, s, d_mn, min_valid_dist, (size_t)n * 4);
+                if (!ru) ru = A.upload(ctx, s, d_mx, max_valid_dist, (size_t)n * 4);
+                if (!ru && skip) ru = A.upload(ctx, s, d_skip, skip, n);
+                if (!ru) ru = A.flush(ctx, s);
+                if (ru) return ru;
                 sv_launch_reproject(s, R);
             }
             G.q_xy = R.q_xy;
@@ -592,11 +611,11 @@ int svgpu_match_frame_and_landmarks(svgpu_ctx* ctx, const svgpu_camera* cam, con
             }
             return SVGPU_OK;
         },
-        [&](const CandProblem&) -> int {
-            if (visible) SV_HIP(ctx, hipMemcpyAsync(visible, R.visible, n, hipMemcpyDeviceToHost, s));
-            if (reproj) SV_HIP(ctx, hipMemcpyAsync(reproj, R.reproj, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-            if (x_right) SV_HIP(ctx, hipMemcpyAsync(x_right, R.x_right, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-            if (pred_scale_level) SV_HIP(ctx, hipMemcpyAsync(pred_scale_level, R.pred_level, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        [&](const CandProblem&, const Arena& A, Downloads& D) -> int {
+            D.add(A, visible, R.visible, n);
+            D.add(A, reproj, R.reproj, (size_t)n * 16);
+            D.add(A, x_right, R.x_right, (size_t)n * 4);
+            D.add(A, pred_scale_level, R.pred_level, (size_t)n * 4);
             return SVGPU_OK;
         },
         match_lm, num_matches);

@@ -107,16 +107,18 @@ int proj_match(svgpu_ctx* ctx, const char* who, const svgpu_camera* cam, const d
             R.q_min_level = A.take<int32_t>(n);
             R.q_max_level = A.take<int32_t>(n);
             R.pos_w = d_pw, R.mean_normal = d_nv, R.min_valid_dist = d_mn, R.max_valid_dist = d_mx, R.skip = d_skip, R.q_level = d_lvl;
-            if (fresh) {
-                SV_HIP(ctx, hipMemcpyAsync(d_q, Q.desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
-                SV_HIP(ctx, hipMemcpyAsync(d_pw, Q.pos_w, (size_t)n * 24, hipMemcpyHostToDevice, s));
-                if (d_nv) SV_HIP(ctx, hipMemcpyAsync(d_nv, Q.mean_normal, (size_t)n * 24, hipMemcpyHostToDevice, s));
-                if (d_mn) SV_HIP(ctx, hipMemcpyAsync(d_mn, Q.min_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
-                if (d_mx) SV_HIP(ctx, hipMemcpyAsync(d_mx, Q.max_valid_dist, (size_t)n * 4, hipMemcpyHostToDevice, s));
-                if (d_skip) SV_HIP(ctx, hipMemcpyAsync(d_skip, skip.data(), n, hipMemcpyHostToDevice, s));
-                if (d_lvl) SV_HIP(ctx, hipMemcpyAsync(d_lvl, Q.q_level, (size_t)n * 4, hipMemcpyHostToDevice, s));
-                if (d_qa) SV_HIP(ctx, hipMemcpyAsync(d_qa, Q.q_angle, (size_t)n * 4, hipMemcpyHostToDevice, s));
-                if (d_qb) SV_HIP(ctx, hipMemcpyAsync(d_qb, Q.q_blocks, n, hipMemcpyHostToDevice, s));
+            if (fresh) {  // one batched upload (Arena::upload / flush), then the reprojection that consumes it
+                int ru = A.upload(ctx, s, d_q, Q.desc, (size_t)n * 32);
+                if (!ru) ru = A.upload(ctx, s, d_pw, Q.pos_w, (size_t)n * 24);
+                if (!ru && d_nv) ru = A.upload(ctx, s, d_nv, Q.mean_normal, (size_t)n * 24);
+                if (!ru && d_mn) ru = A.upload(ctx, s, d_mn, Q.min_valid_dist, (size_t)n * 4);
+                if (!ru && d_mx) ru = A.upload(ctx, s, d_mx, Q.max_valid_dist, (size_t)n * 4);
+                if (!ru && d_skip) ru = A.upload(ctx, s, d_skip, skip.data(), n);
+                if (!ru && d_lvl) ru = A.upload(ctx, s, d_lvl, Q.q_level, (size_t)n * 4);
+                if (!ru && d_qa) ru = A.upload(ctx, s, d_qa, Q.q_angle, (size_t)n * 4);
+                if (!ru && d_qb) ru = A.upload(ctx, s, d_qb, Q.q_blocks, n);
+                if (!ru) ru = A.flush(ctx, s);
+                if (ru) return ru;
                 sv_launch_reproject(s, R);
             }
             G.q_xy = R.q_xy;
@@ -141,11 +143,11 @@ int proj_match(svgpu_ctx* ctx, const char* who, const svgpu_camera* cam, const d
             }
             return SVGPU_OK;
         },
-        [&](const CandProblem&) -> int {
-            if (visible) SV_HIP(ctx, hipMemcpyAsync(visible, R.visible, n, hipMemcpyDeviceToHost, s));
-            if (reproj) SV_HIP(ctx, hipMemcpyAsync(reproj, R.reproj, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-            if (x_right) SV_HIP(ctx, hipMemcpyAsync(x_right, R.x_right, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-            if (pred_level) SV_HIP(ctx, hipMemcpyAsync(pred_level, R.pred_level, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        [&](const CandProblem&, const Arena& A, Downloads& D) -> int {
+            D.add(A, visible, R.visible, n);
+            D.add(A, reproj, R.reproj, (size_t)n * 16);
+            D.add(A, x_right, R.x_right, (size_t)n * 4);
+            D.add(A, pred_level, R.pred_level, (size_t)n * 4);
             return SVGPU_OK;
         },
         match_q, num_matches);

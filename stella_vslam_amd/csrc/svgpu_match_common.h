@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
+#include <vector>
 
 #include "svgpu_internal.h"
 #include "match_kernels.h"
@@ -18,7 +20,29 @@ namespace svm {
 struct Arena {
     char* base;
     size_t off = 0;
+    // Batched uploads: with a page-locked mirror of the arena (ctx->h_stage) every host array is copied to the mirror at its arena offset and
+    // ONE host-to-device copy of the touched range follows (flush) -- the runtime turns every small copy from pageable memory into a staging
+    // kernel of its own (~5 us each on the stream: ten of them per cell-matcher call were half of what the call waited for).  Device-only
+    // pieces inside the range receive stale bytes, harmlessly: the kernels that produce them run behind the copy.
+    char* mirror = nullptr;
+    size_t up_lo = ~size_t(0), up_hi = 0;
     explicit Arena(void* p) : base((char*)p) {}
+    int upload(svgpu_ctx* ctx, hipStream_t s, void* dst, const void* src, size_t bytes) {
+        if (!mirror) {
+            SV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+            return SVGPU_OK;
+        }
+        const size_t o = (size_t)((char*)dst - base);
+        memcpy(mirror + o, src, bytes);
+        up_lo = std::min(up_lo, o);
+        up_hi = std::max(up_hi, o + bytes);
+        return SVGPU_OK;
+    }
+    int flush(svgpu_ctx* ctx, hipStream_t s) {
+        if (mirror && up_hi > up_lo) SV_HIP(ctx, hipMemcpyAsync(base + up_lo, mirror + up_lo, up_hi - up_lo, hipMemcpyHostToDevice, s));
+        up_lo = ~size_t(0), up_hi = 0;
+        return SVGPU_OK;
+    }
     template <class T>
     T* take(size_t n) {
         T* r = (T*)(base + off);
@@ -27,6 +51,37 @@ struct Arena {
     }
 };
 inline size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+
+// Batched read-backs, the counterpart of Arena::upload: results that live in the arena are requested with add(), fetch() copies the
+// range(s) that cover them into the page-locked mirror (requests closer than 32 KB share one copy), and after the stream has been
+// synchronised scatter() hands them to the caller's arrays.
+struct Downloads {
+    struct Item {
+        void* dst;
+        size_t off, bytes;
+    };
+    std::vector<Item> items;
+    void add(const Arena& A, void* dst, const void* src, size_t bytes) {
+        if (dst && bytes) items.push_back({dst, (size_t)((const char*)src - A.base), bytes});
+    }
+    int fetch(svgpu_ctx* ctx, hipStream_t s, const Arena& A) {
+        std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.off < b.off; });
+        size_t k = 0;
+        while (k < items.size()) {
+            size_t lo = items[k].off, hi = lo + items[k].bytes;
+            ++k;
+            while (k < items.size() && items[k].off <= hi + 32768) {
+                hi = std::max(hi, items[k].off + items[k].bytes);
+                ++k;
+            }
+            SV_HIP(ctx, hipMemcpyAsync(A.mirror + lo, A.base + lo, hi - lo, hipMemcpyDeviceToHost, s));
+        }
+        return SVGPU_OK;
+    }
+    void scatter(const Arena& A) const {
+        for (const Item& it : items) memcpy(it.dst, A.mirror + it.off, it.bytes);
+    }
+};
 
 // scratch for the angle-bin sorted copies of both sides (see k_bf_binsort)
 inline size_t sort_bytes(int pairs, int cap1, int cap2) {
@@ -92,27 +147,37 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
     const size_t need1 = query_bytes + pad((size_t)nt * 32) + pad((size_t)nt * 8) + 7 * pad((size_t)nt * 4) + pad(nt)
                          + pad((size_t)(ncell + 1) * 4) + pad((size_t)(nq + 1) * 4) + 2 * pad((size_t)nq * 4) + pad(4) + 2048;
     int total = 0;
+    // Sizing of the candidate lists.  Exact: pass 0 builds the grid and the list sizes and reads their total back (a synchronisation in the
+    // middle of the call), pass 1 fills and matches.  Speculative (a capacity that sufficed for this context before, ctx->cand_cap_hint):
+    // everything is enqueued in pass 0 against that capacity, the kernels do nothing if the total exceeds it, and the total comes back with
+    // the results -- one synchronisation per call; a miss falls through to the exact pass 1.
+    const size_t guess = std::getenv("SVGPU_MATCH_EXACT_SIZING") ? 0 : ctx->cand_cap_hint;
     for (int pass = 0; pass < 2; ++pass) {
-        const size_t need = need1 + (pass ? 2 * pad((size_t)total * 4) : 0);
+        const bool speculative = !pass && guess > 0;
+        const size_t cap = pass ? (size_t)total : guess;
+        const size_t need = need1 + ((pass || speculative) ? 2 * pad(cap * 4) : 0);
         const bool regrow = need > ctx->scratch_bytes;  // pass 1 without regrowth: the arena of pass 0 is still valid, same layout
         int rc = sv_ensure_scratch(ctx, need);
         if (rc) return rc;
         const bool fresh = !pass || regrow;
         Arena A(ctx->d_scratch);
+        rc = sv_ensure_stage(ctx, need);  // page-locked mirror of the arena: batched uploads (fresh passes) and read-backs
+        if (rc) return rc;
+        A.mirror = ctx->h_stage;
         CandProblem P{};
         GridProblem G{};
 #define UP(dst, T, src, n)                                                                          \
     T* dst = nullptr;                                                                               \
     if (src) {                                                                                      \
         dst = A.take<T>(n);                                                                         \
-        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+        if (fresh && (rc = A.upload(ctx, s, dst, src, (size_t)(n) * sizeof(T)))) return rc; \
     }
 #define UPR(dst, T, src, n)                       \
     T* dst = nullptr;                             \
     if (F.res) dst = const_cast<T*>(src);         \
     else if (src) {                               \
         dst = A.take<T>(n);                       \
-        if (fresh) SV_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(T), hipMemcpyHostToDevice, s)); \
+        if (fresh && (rc = A.upload(ctx, s, dst, src, (size_t)(n) * sizeof(T)))) return rc; \
     }
         UPR(d_t, uint8_t, F.tdesc, (size_t)nt * 32)
         UPR(d_txy, float, F.t_xy, (size_t)nt * 2)
@@ -125,6 +190,7 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         lap(pass ? "target side (pass 1)" : "target side uploads");
         rc = stage(A, fresh, P, G);
         if (rc) return rc;
+        if ((rc = A.flush(ctx, s))) return rc;
         lap(pass ? "stage (pass 1)" : "stage: query uploads");
         G.t_xy = d_txy;
         G.t_octave = d_toct;
@@ -156,21 +222,25 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
             if (F.res) sv_launch_grid_queries(s, G);
             else sv_launch_grid_build(s, G);
         }
-        if (!pass) {
+        if (!pass && !speculative) {
             SV_HIP(ctx, hipMemcpyAsync(&total, G.cand_off + nq, 4, hipMemcpyDeviceToHost, s));
             SV_HIP(ctx, hipStreamSynchronize(s));
             lap("grid + total read-back");
             if (mtrace) std::fprintf(stderr, "[match] nq %d nt %d candidates %d (%.1f per query)\n", nq, nt, total, nq ? (double)total / nq : 0.0);
             if (total == 0) {
-                rc = finish(P);
+                Downloads D;
+                rc = finish(P, A, D);
+                if (!rc) rc = D.fetch(ctx, s, A);
                 if (rc) return rc;
                 SV_HIP(ctx, hipStreamSynchronize(s));
+                D.scatter(A);
                 return SVGPU_OK;
             }
             continue;
         }
-        G.cand_idx = A.take<int32_t>(total);
-        P.dist = A.take<uint32_t>(total);
+        G.cand_idx = A.take<int32_t>(cap);
+        P.dist = A.take<uint32_t>(cap);
+        G.cap = P.cap = speculative ? (int)cap : 0;
         if (A.off > ctx->scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_INVALID, "cell matcher: internal arena overflow");
         sv_launch_grid_fill(s, G);
         P.tdesc = (const uint32_t*)d_t;
@@ -191,15 +261,28 @@ int in_cells_core(svgpu_ctx* ctx, int nq, const InCellsFrame& F, size_t query_by
         P.mode = mode;
         sv_launch_cand(ctx, s, P, owner, match, mdist);
         SV_HIP(ctx, hipGetLastError());
-        int32_t num = 0;
-        SV_HIP(ctx, hipMemcpyAsync(match_q, P.match_q, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
-        rc = finish(P);
+        int32_t num = 0, total_dev = 0;
+        Downloads D;
+        D.add(A, match_q, P.match_q, (size_t)nq * 4);
+        D.add(A, &num, P.num, 4);
+        if (speculative) D.add(A, &total_dev, G.cand_off + nq, 4);
+        rc = finish(P, A, D);
+        if (!rc) rc = D.fetch(ctx, s, A);
         if (rc) return rc;
         lap("lists + matcher enqueued");
         SV_HIP(ctx, hipStreamSynchronize(s));
+        D.scatter(A);
         lap("final sync");
+        if (speculative) {
+            total = total_dev;
+            if ((size_t)total > cap) {  // the guess was too small: nothing was written; size exactly
+                ctx->cand_cap_hint = (size_t)total + (size_t)total / 4 + 4096;
+                continue;
+            }
+        }
+        ctx->cand_cap_hint = std::max(ctx->cand_cap_hint, (size_t)total + (size_t)total / 4 + 4096);
         *num_matches = num;
+        return SVGPU_OK;
     }
     return SVGPU_OK;
 }
