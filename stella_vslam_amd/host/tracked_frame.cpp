@@ -172,6 +172,7 @@ extern "C" int svgpu_host_tracked_frame(const uint8_t* imgs, int n_frames, int w
             std::unordered_map<unsigned int, unsigned int> lm_to_scale;
             {
                 const int nl = (int)local_lms.size();
+                lm_to_reproj.reserve(nl), lm_to_x_right.reserve(nl), lm_to_scale.reserve(nl);  // (no rehashing while ~5 k entries go in)
                 std::vector<double> pos((size_t)nl * 3), nrm((size_t)nl * 3), rp((size_t)nl * 2);
                 std::vector<float> mn(nl), mx(nl), xr(nl);
                 std::vector<uint8_t> vis(nl);
