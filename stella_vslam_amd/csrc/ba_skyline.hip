@@ -152,7 +152,26 @@ __device__ __forceinline__ void wave_lds_order() {
 // The 6 x 6 pivot of a column, on the first wave: L = chol(block at `src`, lower triangle), written to `dstL` (upper triangle zeroed), and
 // L^-1 to `dstInv` (global, for the substitutions) and to s_Li (for the column).  Rows on lanes, entries exchanged with readlane, one
 // rsqrt per pivot and no division; the inverse falls out of the same registers, column c on lane c.
-__device__ __forceinline__ void sky_pivot(const double* src, double* dstL, double* dstInv, double* s_Li, int* s_fail, int tid) {
+// (SV_LDS: LDS operands carry their address space.  Through generic pointers every LDS access of these kernels was a FLAT instruction --
+//  639 of them in k_sky_band --, which travels the global-memory path: several times the latency of a ds_ access and a wait on the vector
+//  memory counter, i.e. on the factor rows that are deliberately in flight.  The helpers are templates on the pointer types so that the
+//  same code serves operands in LDS and in global memory.)
+#define SV_LDS __attribute__((address_space(3)))
+#define SV_GLB __attribute__((address_space(1)))
+// (the plan's arrays are GLOBAL: in job mode the SkyDev comes out of memory, its pointers are generic to the compiler and every access
+//  through them a FLAT instruction, which counts on the LDS counter too and so serialises the factor rows in flight with the LDS work)
+struct SkyG {
+    SV_GLB double* val;
+    SV_GLB double* dinv;
+    SV_GLB double* y;
+    const SV_GLB int *coloff, *first, *rowoff, *colrows, *colbase, *pos, *order;
+    __device__ __forceinline__ explicit SkyG(const SkyDev& K)
+        : val((SV_GLB double*)K.val), dinv((SV_GLB double*)K.dinv), y((SV_GLB double*)K.y), coloff((const SV_GLB int*)K.coloff), first((const SV_GLB int*)K.first),
+          rowoff((const SV_GLB int*)K.rowoff), colrows((const SV_GLB int*)K.colrows), colbase((const SV_GLB int*)K.colbase), pos((const SV_GLB int*)K.pos),
+          order((const SV_GLB int*)K.order) {}
+};
+template <class SrcP, class DstP, class LiP, class FailP>
+__device__ __forceinline__ void sky_pivot(SrcP src, DstP dstL, DstP dstInv, LiP s_Li, FailP s_fail, int tid) {
     const int r = min(tid, 5);
     double a[6];
 #pragma unroll
@@ -202,22 +221,24 @@ __device__ __forceinline__ void sky_pivot(const double* src, double* dstL, doubl
 // while a column is processed (a global load takes ~1 us seen from one wave, a column step ~0.2 us), and the backward sums are combined
 // by a shuffle tree inside groups of eight lanes instead of sixty lane broadcasts.
 // (columns jb .. je - 1 of the forward pass, columns jhi .. jlo of the backward pass: the two-sided kernel runs them in pieces)
-__device__ __forceinline__ void sky_forward_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane, int jb, int je) {
+template <class YP, class IP>
+__device__ __forceinline__ void sky_forward_narrow(const SkyDev& K, YP s_y, IP s_coloff, IP s_rows, IP s_base, int lane, int jb, int je) {
     constexpr int PD = 4;
+    const SkyG Gk(K);
     {   // forward: lane rr < 6 holds row rr of Li_j; item k of a lane = (row (lane + 64 k) / 6 of the column, component (lane + 64 k) % 6)
         auto load = [&](int j, double (&li)[6], double (&bl)[2][6], int (&dst)[2]) {
             if (j >= je) return;
             const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
             const int rr = min(lane, 5);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) li[c] = K.dinv[(size_t)j * 36 + rr * 6 + c];
+            for (int c = 0; c < 6; ++c) li[c] = Gk.dinv[(size_t)j * 36 + rr * 6 + c];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int t = lane + 64 * k;
                 dst[k] = -1;
                 if (t < m * 6) {
                     const int r = t / 6, a = t - 6 * r;
-                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36 + a * 6;
+                    const SV_GLB double* Bl = Gk.val + (size_t)(s_base[c0 + r] + j) * 36 + a * 6;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) bl[k][c] = Bl[c];
                     dst[k] = s_rows[c0 + r] * 6 + a;
@@ -256,8 +277,10 @@ __device__ __forceinline__ void sky_forward_narrow(const SkyDev& K, double* s_y,
         }
     }
 }
-__device__ __forceinline__ void sky_backward_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane, int jhi, int jlo) {
+template <class YP, class IP>
+__device__ __forceinline__ void sky_backward_narrow(const SkyDev& K, YP s_y, IP s_coloff, IP s_rows, IP s_base, int lane, int jhi, int jlo) {
     constexpr int PD = 4;
+    const SkyG Gk(K);
     {   // backward: w = z_j - sum_{i in rows(j)} L_ij^T x_i, lane = component * 8 + part (48 lanes), a lane's rows: part and part + 8
         const int a = min(lane >> 3, 5), part = lane & 7;
         auto load = [&](int j, double (&lc)[6], double (&bc)[2][6], int (&src)[2]) {
@@ -265,13 +288,13 @@ __device__ __forceinline__ void sky_backward_narrow(const SkyDev& K, double* s_y
             const int c0 = s_coloff[j], m = s_coloff[j + 1] - c0;
             const int ac = min(lane, 5);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) lc[c] = K.dinv[(size_t)j * 36 + c * 6 + ac];  // column `lane` of Li_j
+            for (int c = 0; c < 6; ++c) lc[c] = Gk.dinv[(size_t)j * 36 + c * 6 + ac];  // column `lane` of Li_j
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int r = part + 8 * k;
                 src[k] = -1;
                 if (lane < 48 && r < m) {
-                    const double* Bl = K.val + (size_t)(s_base[c0 + r] + j) * 36;
+                    const SV_GLB double* Bl = Gk.val + (size_t)(s_base[c0 + r] + j) * 36;
 #pragma unroll
                     for (int c = 0; c < 6; ++c) bc[k][c] = Bl[c * 6 + a];
                     src[k] = s_rows[c0 + r] * 6;
@@ -313,12 +336,14 @@ __device__ __forceinline__ void sky_backward_narrow(const SkyDev& K, double* s_y
         }
     }
 }
-__device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int lane) {
+template <class YP, class IP>
+__device__ __forceinline__ void sky_substitute_narrow(const SkyDev& K, YP s_y, IP s_coloff, IP s_rows, IP s_base, int lane) {
     sky_forward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, 0, K.nP);
     sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, K.nP - 1, 0);
 }
 
-__device__ __forceinline__ void sky_substitute(const SkyDev& K, double* s_y, const int* s_coloff, const int* s_rows, const int* s_base, int tid) {
+template <class YP, class IP>
+__device__ __forceinline__ void sky_substitute(const SkyDev& K, YP s_y, IP s_coloff, IP s_rows, IP s_base, int tid) {
     const int nP = K.nP;
         const int lane = tid;
         const bool pre = K.max_m * 6 <= 128;  // a lane owns at most two (row, component) items of a column: their factor rows are prefetched
@@ -608,6 +633,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
         T.on = 1, T.m = 0, T.W = J.ns, T.nB = J.nC, T.xch = J.xch;
     }
     const SkyDev& K = jobs ? Kj : (who ? K1 : K0);
+    const SkyG Gk(K);  // the plan's arrays as global-address-space pointers
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];  // [window (W+1)^2 x 36][column W x 36][6 nP: right-hand side][index arrays]
     __shared__ double s_Li[2][36];  // inverse diagonal factors of columns j and j + 1 (the look-ahead pivot writes one while the other is in use)
     __shared__ int s_fail, s_other;
@@ -618,37 +644,41 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
         tri_index(tid, p, q);
         s_pq[tid] = (unsigned short)(p | (q << 8));
     }
-    double* const s_win = s_dyn;
-    double* const s_col = s_win + (size_t)Wn * Wn * 36;
-    double* const s_y = s_col + (size_t)W * 36;
-    int* const s_coloff = reinterpret_cast<int*>(s_y + ny);
-    int* const s_first = s_coloff + (nP + 1);
-    int* const s_rbase = s_first + nP;   // rowoff[i] - first[i]: block (i, k) of the envelope = s_rbase[i] + k
-    int* const s_rows = s_rbase + nP;    // for the substitution routine
-    int* const s_base = s_rows + K.ncr;
+    SV_LDS double* const s_win = (SV_LDS double*)s_dyn;
+    SV_LDS double* const s_col = s_win + Wn * Wn * 36;
+    SV_LDS double* const s_y = s_col + W * 36;
+    SV_LDS int* const s_coloff = (SV_LDS int*)(s_y + ny);
+    SV_LDS int* const s_first = s_coloff + (nP + 1);
+    SV_LDS int* const s_rbase = s_first + nP;   // rowoff[i] - first[i]: block (i, k) of the envelope = s_rbase[i] + k
+    SV_LDS int* const s_rows = s_rbase + nP;    // for the substitution routine
+    SV_LDS int* const s_base = s_rows + K.ncr;
+    SV_LDS double* const s_Li0 = (SV_LDS double*)s_Li[0];
+    SV_LDS double* const s_Li1 = (SV_LDS double*)s_Li[1];
+    SV_LDS int* const s_failp = (SV_LDS int*)&s_fail;
+    auto Li_of = [&](int j) { return (j & 1) ? s_Li1 : s_Li0; };
     if (tid == 0) s_fail = 0, s_other = epoch;
-    for (int t = tid; t < ny; t += nt) s_y[t] = K.y[t];
-    for (int t = tid; t <= nP; t += nt) s_coloff[t] = K.coloff[t];
+    for (int t = tid; t < ny; t += nt) s_y[t] = Gk.y[t];
+    for (int t = tid; t <= nP; t += nt) s_coloff[t] = Gk.coloff[t];
     for (int t = tid; t < nP; t += nt) {
-        s_first[t] = K.first[t];
-        s_rbase[t] = K.rowoff[t] - K.first[t];
+        s_first[t] = Gk.first[t];
+        s_rbase[t] = Gk.rowoff[t] - Gk.first[t];
     }
     for (int t = tid; t < K.ncr; t += nt) {
-        s_rows[t] = K.colrows[t];
-        s_base[t] = K.colbase[t];
+        s_rows[t] = Gk.colrows[t];
+        s_base[t] = Gk.colbase[t];
     }
     __syncthreads();
-    auto slot = [&](int i, int k) { return s_win + (size_t)((i % Wn) * Wn + (k % Wn)) * 36; };  // (two integer divisions: set-up and hand-over code only)
+    auto slot = [&](int i, int k) { return s_win + ((i % Wn) * Wn + (k % Wn)) * 36; };  // (two integer divisions: set-up and hand-over code only)
     // inside the column loop the window slots are tracked incrementally -- jm = j mod (W + 1) is carried from column to column and a row
     // or column at distance d <= W + 1 from it needs one conditional subtraction -- so that no thread divides by a run-time value there
     auto wrap = [&](int x) { return x >= Wn ? x - Wn : x; };
-    auto slot_at = [&](int rs, int cs) { return s_win + (size_t)(rs * Wn + cs) * 36; };
+    auto slot_at = [&](int rs, int cs) { return s_win + (rs * Wn + cs) * 36; };
     // rows 0 .. W of the assembled system
     for (int i = 0; i < min(Wn, nP); ++i) {
         const int f = s_first[i];
         for (int t = tid; t < (i - f + 1) * 36; t += nt) {
             const int k = f + t / 36, e = t % 36;
-            slot(i, k)[e] = K.val[(size_t)(s_rbase[i] + k) * 36 + e];
+            slot(i, k)[e] = Gk.val[(size_t)(s_rbase[i] + k) * 36 + e];
         }
     }
     __syncthreads();
@@ -660,7 +690,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
         double La[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
-        double* Dst = slot_at(wrap(jm1 + p), wrap(jm1 + q)) + a * 6;
+        SV_LDS double* Dst = slot_at(wrap(jm1 + p), wrap(jm1 + q)) + a * 6;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
             double v = La[0] * s_col[q * 36 + b * 6];
@@ -686,31 +716,32 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int t = tid + q * SKY_BAND_THREADS;
-                    if (t < npre) pre[q] = K.val[(size_t)(s_rbase[inew] + fnew + t / 36) * 36 + t % 36];
+                    if (t < npre) pre[q] = Gk.val[(size_t)(s_rbase[inew] + fnew + t / 36) * 36 + t % 36];
                 }
             }
             for (int t = tid; t < m * 36; t += nt) {  // L_ij = S_ij L_jj^-T
                 const int r = t / 36, e = t - r * 36, a = e / 6, b = e - 6 * a;
-                const double* Bl = slot_at(wrap(jm1 + r), jm) + a * 6;
+                const SV_LDS double* Bl = slot_at(wrap(jm1 + r), jm) + a * 6;
+                const SV_LDS double* Lj = Li_of(j);
                 double v = 0.0;
 #pragma unroll
                 for (int c = 0; c < 6; ++c)
-                    if (c <= b) v += Bl[c] * s_Li[j & 1][b * 6 + c];
+                    if (c <= b) v += Bl[c] * Lj[b * 6 + c];
                 s_col[t] = v;
             }
             block_sync_lds();
-            for (int t = tid; t < m * 36; t += nt) K.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
+            for (int t = tid; t < m * 36; t += nt) Gk.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
             const int npair = m * (m + 1) / 2;
             if (tid < 64) {
                 if (m > 0 && tid < 6) update_item(jm1, tid);  // pair (0, 0) = block (j + 1, j + 1)
                 wave_lds_order();
                 if (j + 1 < je)
-                    sky_pivot(slot_at(jm1, jm1), K.val + (size_t)(s_rbase[j + 1] + j + 1) * 36, K.dinv + (size_t)(j + 1) * 36, s_Li[(j + 1) & 1], &s_fail, tid);
+                    sky_pivot(slot_at(jm1, jm1), Gk.val + (s_rbase[j + 1] + j + 1) * 36, Gk.dinv + (j + 1) * 36, Li_of(j + 1), s_failp, tid);
             }
             else {
                 if (tid >= nt - 64) {  // the forward substitution of this column rides along on the last wave: z_j = L_jj^-1 y_j, y_i -= L_ij z_j
                     const int lane = tid - (nt - 64);  // (the sums in the order of sky_forward_narrow: the same bits)
-                    const double* Li = s_Li[j & 1];
+                    const SV_LDS double* Li = Li_of(j);
                     double z[6];
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
@@ -723,7 +754,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                     wave_lds_order();  // every lane has read y_j
                     if (lane < 6) s_y[j * 6 + lane] = lane == 0 ? z[0] : lane == 1 ? z[1] : lane == 2 ? z[2] : lane == 3 ? z[3] : lane == 4 ? z[4] : z[5];
                     for (int t = lane; t < m * 6; t += 64) {
-                        const double* Bl = s_col + t * 6;  // row (t / 6, t % 6) of the scaled column: s_col[r * 36 + a * 6 + c]
+                        const SV_LDS double* Bl = s_col + t * 6;  // row (t / 6, t % 6) of the scaled column: s_col[r * 36 + a * 6 + c]
                         double u = Bl[0] * z[0];
 #pragma unroll
                         for (int c = 1; c < 6; ++c) u += Bl[c] * z[c];
@@ -744,10 +775,10 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     };
     const int nA = T.on ? (who ? T.nB : T.m) : nP;  // columns of the first stretch
     const int Ws = T.W, npairS = Ws * (Ws + 1) / 2;
-    double* const xS2 = T.xch;                      // the second plan's S x S window blocks, its own (reversed) order
-    double* const xY = T.xch + (size_t)npairS * 36; // its y_S
-    double* const xX = xY + 6 * Ws;                 // x_S of the first plan
-    if (tid < 64) sky_pivot(slot(0, 0), K.val + (size_t)s_rbase[0] * 36, K.dinv, s_Li[0], &s_fail, tid);
+    SV_GLB double* const xS2 = (SV_GLB double*)T.xch;   // the second plan's S x S window blocks, its own (reversed) order
+    SV_GLB double* const xY = xS2 + (size_t)npairS * 36; // its y_S
+    SV_GLB double* const xX = xY + 6 * Ws;              // x_S of the first plan
+    if (tid < 64) sky_pivot(slot(0, 0), Gk.val + s_rbase[0] * 36, Gk.dinv, s_Li0, s_failp, tid);
     block_sync_lds();
     factor(0, nA);
     __syncthreads();
@@ -765,7 +796,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                 for (int t = tid; t < npairS * 36 + 6 * Ws; t += nt) xS2[t] = 0.0;
                 if (tid == 0) D.ctl->solve_failed = 1;
             }
-            for (int t = tid; t < 6 * nA; t += nt) K.y[t] = s_fail ? 0.0 : s_y[t];
+            for (int t = tid; t < 6 * nA; t += nt) Gk.y[t] = s_fail ? 0.0 : s_y[t];
             return;
         }
         if (tid == 0) sky_post(T.flags + 0, s_fail ? -epoch : epoch);
@@ -784,11 +815,11 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                 int r, c;
                 tri_index(x, r, c);
                 const int k = nA + Ws - 1 - r, i = nA + Ws - 1 - c;
-                slot(i, k)[b * 6 + a] += sky_peek(xS2 + t);
+                slot(i, k)[b * 6 + a] += sky_peek((const double*)(xS2 + t));
             }
-            for (int t = tid; t < 6 * Ws; t += nt) s_y[(nA + t / 6) * 6 + t % 6] += sky_peek(xY + (Ws - 1 - t / 6) * 6 + t % 6);
+            for (int t = tid; t < 6 * Ws; t += nt) s_y[(nA + t / 6) * 6 + t % 6] += sky_peek((const double*)(xY + (Ws - 1 - t / 6) * 6 + t % 6));
             __syncthreads();
-            if (tid < 64) sky_pivot(slot(nA, nA), K.val + (size_t)(s_rbase[nA] + nA) * 36, K.dinv + (size_t)nA * 36, s_Li[nA & 1], &s_fail, tid);
+            if (tid < 64) sky_pivot(slot(nA, nA), Gk.val + (s_rbase[nA] + nA) * 36, Gk.dinv + nA * 36, Li_of(nA), s_failp, tid);
             block_sync_lds();
             factor(nA, nP);
             __syncthreads();
@@ -808,7 +839,7 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
             if (v < 0 && lane == 0) s_fail = 1;
             wave_lds_order();
             if (!s_fail) {  // x of position nB + q here is x of position m + W - 1 - q there
-                for (int t = lane; t < 6 * Ws; t += 64) s_y[(nA + t / 6) * 6 + t % 6] = sky_peek(xX + (Ws - 1 - t / 6) * 6 + t % 6);
+                for (int t = lane; t < 6 * Ws; t += 64) s_y[(nA + t / 6) * 6 + t % 6] = sky_peek((const double*)(xX + (Ws - 1 - t / 6) * 6 + t % 6));
                 wave_lds_order();
                 sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nA - 1, 0);
             }
@@ -828,14 +859,14 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     if (s_fail) {
         if (tid == 0) D.ctl->solve_failed = 1;
         for (int t = tid; t < D.n; t += nt) {
-            const int pa = K.pos[t / 6];
-            if (pa >= 0 && pa < own_to) D.dp[t] = 0.0;
+            const int pa = Gk.pos[t / 6];
+            if (pa >= 0 && pa < own_to) ((SV_GLB double*)D.dp)[t] = 0.0;
         }
         return;
     }
     for (int t = tid; t < D.n; t += nt) {
-        const int a = t / 6, c = t - 6 * a, pa = K.pos[a];
-        if (pa >= 0 && pa < own_to) D.dp[t] = s_y[pa * 6 + c];
+        const int a = t / 6, c = t - 6 * a, pa = Gk.pos[a];
+        if (pa >= 0 && pa < own_to) ((SV_GLB double*)D.dp)[t] = s_y[pa * 6 + c];
     }
 }
 
@@ -845,23 +876,24 @@ __global__ __launch_bounds__(64) void k_seg_backward(BaDev D, const SegJobDev* _
     if (D.ctl->phase != 1) return;
     const SegJobDev J = jobs[blockIdx.x];
     const SkyDev& K = J.K;
+    const SkyG Gk(K);
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     const int lane = threadIdx.x, nP = K.nP, nC = J.nC;
-    double* const s_y = s_dyn;
-    int* const s_coloff = reinterpret_cast<int*>(s_y + 6 * nP);
-    int* const s_rows = s_coloff + (nP + 1);
-    int* const s_base = s_rows + K.ncr;
+    SV_LDS double* const s_y = (SV_LDS double*)s_dyn;
+    SV_LDS int* const s_coloff = (SV_LDS int*)(s_y + 6 * nP);
+    SV_LDS int* const s_rows = s_coloff + (nP + 1);
+    SV_LDS int* const s_base = s_rows + K.ncr;
     const bool failed = D.ctl->solve_failed != 0;  // (this rank's jobs or its separator solve: the trial is rejected anyway)
-    for (int t = lane; t < 6 * nP; t += 64) s_y[t] = t < 6 * nC ? K.y[t] : D.dp[K.order[t / 6] * 6 + t % 6];
-    for (int t = lane; t <= nP; t += 64) s_coloff[t] = K.coloff[t];
+    for (int t = lane; t < 6 * nP; t += 64) s_y[t] = t < 6 * nC ? Gk.y[t] : ((const SV_GLB double*)D.dp)[Gk.order[t / 6] * 6 + t % 6];
+    for (int t = lane; t <= nP; t += 64) s_coloff[t] = Gk.coloff[t];
     for (int t = lane; t < K.ncr; t += 64) {
-        s_rows[t] = K.colrows[t];
-        s_base[t] = K.colbase[t];
+        s_rows[t] = Gk.colrows[t];
+        s_base[t] = Gk.colbase[t];
     }
     wave_lds_fence();
     if (!failed && nC > 0) sky_backward_narrow(K, s_y, s_coloff, s_rows, s_base, lane, nC - 1, 0);
     wave_lds_fence();
-    for (int t = lane; t < 6 * nC; t += 64) out[K.order[t / 6] * 6 + t % 6] = failed ? 0.0 : s_y[t];
+    for (int t = lane; t < 6 * nC; t += 64) ((SV_GLB double*)out)[Gk.order[t / 6] * 6 + t % 6] = failed ? 0.0 : s_y[t];
 }
 // out[separator slots] = D.dp (rank 0 of a sharded solve puts the separator unknowns into the exchanged solution vector)
 __global__ __launch_bounds__(256) void k_seg_copy_sep(BaDev D, SkyDev K, double* __restrict__ out) {
