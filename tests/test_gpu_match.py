@@ -290,3 +290,67 @@ def test_stereo_batch_device_matches_oracle():
         assert (xo >= 0).sum() > 800
         assert np.array_equal(xr[b, :n], xo) and np.array_equal(dp[b, :n], dpo)
         assert abs(np.median((ko["x"] - xo)[xo >= 0]) - disp) < 0.1
+
+
+@pytest.mark.parametrize("mode", [O.MODE_BEST_ONLY, O.MODE_RATIO_SAME_OCTAVE, O.MODE_RATIO, O.MODE_TRIANGULATION])
+def test_candidate_matcher_long_and_contended_lists(M, ctx, mode):
+    """The replay's fast paths against the oracle's sequential loop: lists of 1 .. 1 500 candidates (one entry per lane up to 64 --
+    in-register sort --, sorted in LDS up to 1 024, walked unsorted beyond), many duplicate descriptors (ties on distance are decided by the
+    scan position) and few targets for many queries (long chains of queries losing their target to an earlier one: many sweeps)."""
+    rng = np.random.default_rng(100 + mode)
+    nt, nq = 1800, 700
+    base = rng.integers(0, 256, (40, 32), dtype=np.uint8)              # 40 look-alike groups
+    td = _noisy(rng, base[rng.integers(0, 40, nt)], 6)
+    qd = _noisy(rng, base[rng.integers(0, 40, nq)], 6)
+    td[0:1799:7] = td[3:1799:7][: len(td[0:1799:7])]                  # exact duplicates
+    lens = rng.choice([1, 2, 5, 20, 63, 64, 65, 100, 300, 1024, 1025, 1500], nq, p=[.1, .1, .1, .2, .05, .05, .05, .1, .1, .05, .05, .05])
+    cand_off, cand_idx = [0], []
+    for q in range(nq):
+        c = rng.choice(nt, min(int(lens[q]), nt), replace=False)
+        if q % 3 == 0:
+            c = c % 60                                                # contention: many queries over the same 60 targets ...
+            _, first = np.unique(c, return_index=True)
+            c = c[np.sort(first)]                                     # ... each listed once, scan order kept
+        cand_idx += c.tolist()
+        cand_off.append(len(cand_idx))
+    t_oct = rng.integers(0, 8, nt).astype(np.int32)
+    occupied = (rng.uniform(size=nt) < 0.05).astype(np.uint8)
+    kw = dict(t_octave=t_oct, occupied=occupied)
+    got, num = M.projection(0.9, False, ctx).match_candidates(qd, td, cand_off, cand_idx, mode, 120, **kw)
+    exp = O.match_candidates(qd, td, cand_off, cand_idx, check_orientation=False, thr=120, lowe_ratio=0.9, mode=mode, **kw)
+    assert (exp >= 0).sum() > 100
+    assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+
+
+def test_match_in_cells_capacity_guess_miss_reruns(M):
+    """The cell matcher remembers the candidate capacity that sufficed for a context and enqueues the next call against it; a call whose lists
+    outgrow the guess must notice (nothing written) and re-run with the exact size: a small problem first, then a much denser one on the SAME
+    context, both against the oracle, then the small one again."""
+    from stella_vslam_amd import feature
+    own = feature.Context()
+    seq = S.frame_sequence(2, seed=0x5EED + 5)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    bounds = (0.0, 640.0, 0.0, 480.0)
+
+    def run(nq, margin):
+        q_xy = np.stack([k0["x"][:nq] - 3.0, k0["y"][:nq] - 1.0], 1).astype(np.float32)
+        q_margin = np.full(nq, margin, np.float32)
+        lo = np.maximum(k0["octave"][:nq] - 1, 0).astype(np.int32)
+        hi = np.minimum(k0["octave"][:nq] + 1, 7).astype(np.int32)
+        got, num = M.projection(0.8, False, own).match_in_cells(d0[:nq], q_xy, q_margin, d1, np.stack([k1["x"], k1["y"]], 1).astype(np.float32),
+                                                               k1["octave"], bounds, 0, 100, q_min_level=lo, q_max_level=hi)
+        off_g, items = O.assign_keypoints_to_grid(k1["x"], k1["y"], bounds)
+        cand_off, cand_idx = [0], []
+        for q in range(nq):
+            c = O.get_keypoints_in_cell(k1["x"], k1["y"], k1["octave"], off_g, items, bounds, float(q_xy[q, 0]), float(q_xy[q, 1]), margin, int(lo[q]), int(hi[q]))
+            cand_idx += c.tolist()
+            cand_off.append(len(cand_idx))
+        exp = O.match_candidates(d0[:nq], d1, cand_off, cand_idx, check_orientation=False, thr=100, lowe_ratio=0.8, mode=0, t_octave=k1["octave"])
+        assert np.array_equal(got, exp) and num == (exp >= 0).sum()
+        return len(cand_idx)
+
+    small = run(200, 8.0)
+    big = run(len(k0), 60.0)
+    assert big > 20 * small + 4096  # far beyond the remembered capacity (total * 1.25 + 4096)
+    run(200, 8.0)
