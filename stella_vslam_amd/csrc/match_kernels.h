@@ -131,7 +131,15 @@ struct StereoProblem {
     int n_stride, cap;
     size_t img_stride_l, img_stride_r;   // level 0 (the callers' images)
     size_t pyr_stride_l, pyr_stride_r;   // levels >= 1 (the extractors' pyramid blocks)
+    // row index of the right keypoints (get_right_keypoint_indices_in_each_row, stereo.cc:34-60): per pair rows + 1 offsets, a fill cursor per
+    // row and the right-keypoint indices of every row band (rows_per_kp entries per keypoint at most); built by sv_launch_stereo
+    int rows;            // image rows of level 0
+    int rows_per_kp;     // >= rows of the widest band: 2 * ceil(2 * scale_factor[top level]) + 3
+    int32_t* row_off;    // pairs x (rows + 1)
+    int32_t* row_fill;   // pairs x rows
+    int32_t* row_items;  // pairs x nr (cap) x rows_per_kp
 };
+size_t sv_stereo_rows_bytes(int pairs, int rows, int nr_cap, int rows_per_kp);  // scratch for the three arrays above
 void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P, int pairs = 1);
 void sv_launch_stereo_median(hipStream_t s, const StereoProblem& P, int pairs);  // 2 x median correlation filter (stereo.cc:94-113) on the device
 

@@ -1389,41 +1389,103 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// The row index of the right keypoints, as the reference builds it (stereo.cc:34-60): keypoint ir is listed in every row of
+// [floor(y - 2 sf), ceil(y + 2 sf)] of the level-0 image.  k_stereo used to test EVERY right keypoint against every left one (3 700 x 3 700
+// band tests per pair, 0.64 ms for 8 pairs); with the index a left keypoint walks the ~60 entries of its own row.  Count -> scan -> fill;
+// the order inside a row is whatever the atomics give, which is harmless: the matcher takes the minimum of (distance, index).
+struct StereoPair {  // one pair's slice of the batched arrays (the kernel argument itself is never modified: that would send it to scratch)
+    const svgpu_keypoint *kl, *kr;
+    const uint32_t *dl, *dr;
+    int nl, nr;
+    float *xr, *depth, *corr;
+    int32_t *row_off, *row_fill, *row_items;
+};
+__device__ __forceinline__ StereoPair stereo_pair(const StereoProblem& P, int pair) {
+    StereoPair Q;
+    const size_t o = P.nl_dev ? (size_t)pair * P.cap : 0;
+    Q.nl = P.nl_dev ? min(P.nl_dev[(size_t)pair * P.n_stride], P.cap) : P.nl;
+    Q.nr = P.nr_dev ? min(P.nr_dev[(size_t)pair * P.n_stride], P.cap) : P.nr;
+    Q.kl = P.kl + o, Q.kr = P.kr + o, Q.dl = P.dl + o * 8, Q.dr = P.dr + o * 8;
+    Q.xr = P.xr + o, Q.depth = P.depth + o, Q.corr = P.corr + o;
+    const int nr_cap = P.nl_dev ? P.cap : P.nr;
+    Q.row_off = P.row_off + (size_t)pair * (P.rows + 1);
+    Q.row_fill = P.row_fill + (size_t)pair * P.rows;
+    Q.row_items = P.row_items + (size_t)pair * nr_cap * P.rows_per_kp;
+    return Q;
+}
+__device__ __forceinline__ void stereo_band(const StereoProblem& P, const svgpu_keypoint& r, int& min_r, int& max_r) {
+    const float rad = 2.0f * P.sf[r.octave];
+    max_r = min((int)ceil((double)(r.y + rad)), P.rows - 1);
+    min_r = max((int)floor((double)(r.y - rad)), 0);
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_stereo_rows(StereoProblem P) {
+    const StereoPair Q = stereo_pair(P, blockIdx.y);
+    const int ir = blockIdx.x * 256 + threadIdx.x;
+    if (ir >= Q.nr) return;
+    int min_r, max_r;
+    stereo_band(P, Q.kr[ir], min_r, max_r);
+    for (int row = min_r; row <= max_r; ++row) {
+        if (FILL) Q.row_items[Q.row_off[row] + atomicAdd(&Q.row_fill[row], 1)] = ir;
+        else atomicAdd(&Q.row_off[row], 1);
+    }
+}
+__global__ __launch_bounds__(1024) void k_stereo_rows_scan(StereoProblem P) {  // one workgroup per pair: counts -> offsets (rows + 1 entries)
+    __shared__ int s_part[1024];
+    __shared__ int s_carry;
+    int32_t* off = P.row_off + (size_t)blockIdx.x * (P.rows + 1);
+    const int tid = threadIdx.x, n = P.rows;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? off[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d) incl += t;
+        }
+        if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < (tid >> 6); ++w) before += s_part[w];
+        const int carry = s_carry;
+        if (i < n) off[i] = carry + before + incl - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) off[n] = s_carry;
+}
 __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
     const int il = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // scalar: per-keypoint data via scalar loads
     const int pair = blockIdx.y;
-    if (P.nl_dev) {  // batched form: this pair's slice of every array
-        P.nl = min(P.nl_dev[(size_t)pair * P.n_stride], P.cap);
-        P.nr = min(P.nr_dev[(size_t)pair * P.n_stride], P.cap);
-        const size_t o = (size_t)pair * P.cap;
-        P.kl += o, P.kr += o, P.dl += o * 8, P.dr += o * 8, P.xr += o, P.depth += o, P.corr += o;
-    }
-    if (il >= P.nl) return;
-    const svgpu_keypoint k = P.kl[il];
+    const StereoPair Q = stereo_pair(P, pair);
+    if (il >= Q.nl) return;
+    const svgpu_keypoint k = Q.kl[il];
     const int lvl = k.octave;
     float out_xr = -1.0f, out_depth = -1.0f, out_corr = -1.0f;
     const int row = (int)k.y;
     const float min_x_right = k.x - P.max_disp, max_x_right = k.x - P.min_disp;
     uint32_t best = 0xFFFFFFFFu;
-    if (!(max_x_right < 0)) {
+    if (!(max_x_right < 0) && row >= 0 && row < P.rows) {
         uint32_t q[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) q[w] = P.dl[(size_t)il * 8 + w];
-        for (int ir = lane; ir < P.nr; ir += 64) {
-            const svgpu_keypoint r = P.kr[ir];
-            const float rad = 2.0f * P.sf[r.octave];
-            const int max_r = (int)ceil((double)(r.y + rad)), min_r = (int)floor((double)(r.y - rad));
-            if (row < min_r || row > max_r) continue;
+        for (int w = 0; w < 8; ++w) q[w] = Q.dl[(size_t)il * 8 + w];
+        for (int c = Q.row_off[row] + lane; c < Q.row_off[row + 1]; c += 64) {  // the right keypoints whose band holds this row
+            const int ir = Q.row_items[c];
+            const svgpu_keypoint r = Q.kr[ir];
             if (r.octave < lvl - 1 || r.octave > lvl + 1) continue;
             if (r.x < min_x_right || max_x_right < r.x) continue;
-            const unsigned d = hamming256(q, P.dr + (size_t)ir * 8);
+            const unsigned d = hamming256(q, Q.dr + (size_t)ir * 8);
             if (d < P.thr) best = min(best, (d << 16) | (uint32_t)ir);
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
     if (best != 0xFFFFFFFFu) {
-        const float x_right = P.kr[best & 0xFFFFu].x;
+        const float x_right = Q.kr[best & 0xFFFFu].x;
         const float isf = P.isf[lvl];
         const int sxl = __float2int_rn(k.x * isf), syl = __float2int_rn(k.y * isf), sxr = __float2int_rn(x_right * isf);
         const int ini_x = sxr - 10, end_x = sxr + 10;
@@ -1492,32 +1554,50 @@ __global__ __launch_bounds__(256) void k_stereo(StereoProblem P) {
         }
     }
     if (lane == 0) {
-        P.xr[il] = out_xr;
-        P.depth[il] = out_depth;
-        P.corr[il] = out_corr;
+        Q.xr[il] = out_xr;
+        Q.depth[il] = out_depth;
+        Q.corr[il] = out_corr;
     }
 }
 
 // stereo.cc:94-113 per pair: median of the kept correlations = the element of rank size / 2 in ascending order; matches whose
 // correlation exceeds twice the median are dropped.  Correlations are integers below 2^16 (121 absolute differences of bytes, twice),
 // so the rank-size/2 VALUE is found by bisection on the value with a counting pass per step: no sort, one workgroup per pair.
-__global__ __launch_bounds__(256) void k_stereo_median(StereoProblem P) {
-    __shared__ int s_cnt[4];
-    const int pair = blockIdx.x, tid = threadIdx.x;
+#define STEREO_MEDIAN_LDS 32768  // kept correlations staged as 16-bit values: pairs of up to 32 k left keypoints
+__global__ __launch_bounds__(1024) void k_stereo_median(StereoProblem P) {
+    // The 17 counting passes of the bisection used to re-read xr / depth / corr of every keypoint from global memory (8 us per pass, 123 us per
+    // launch); the kept correlations are staged ONCE in LDS (0xFFFF = not kept: correlations stay below 2 * 121 * 255 = 61 710).
+    __shared__ int s_cnt[16];
+    __shared__ unsigned short s_c[STEREO_MEDIAN_LDS];
+    const int pair = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int nl = P.nl_dev ? min(P.nl_dev[(size_t)pair * P.n_stride], P.cap) : P.nl;
     const size_t o = P.nl_dev ? (size_t)pair * P.cap : 0;
     float* xr = P.xr + o;
     float* depth = P.depth + o;
     const float* corr = P.corr + o;
+    const bool staged = nl <= STEREO_MEDIAN_LDS;
+    if (staged)
+        for (int i = tid; i < nl; i += nthr) s_c[i] = (xr[i] != -1.0f || depth[i] != -1.0f) ? (unsigned short)(int)corr[i] : (unsigned short)0xFFFF;
+    __syncthreads();
     auto count_le = [&](int v) -> int {  // kept matches with correlation <= v (v < 0: all kept matches)
         int c = 0;
-        for (int i = tid; i < nl; i += 256)
-            if (xr[i] != -1.0f || depth[i] != -1.0f) c += (v < 0 || (int)corr[i] <= v) ? 1 : 0;
+        if (staged) {
+            for (int i = tid; i < nl; i += nthr) {
+                const int x = s_c[i];
+                c += (x != 0xFFFF && (v < 0 || x <= v)) ? 1 : 0;
+            }
+        }
+        else {
+            for (int i = tid; i < nl; i += nthr)
+                if (xr[i] != -1.0f || depth[i] != -1.0f) c += (v < 0 || (int)corr[i] <= v) ? 1 : 0;
+        }
         for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
         __syncthreads();
         if ((tid & 63) == 0) s_cnt[tid >> 6] = c;
         __syncthreads();
-        return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int t = 0;
+        for (int w = 0; w < (nthr >> 6); ++w) t += s_cnt[w];
+        return t;
     };
     const int kept = count_le(-1);
     if (kept == 0) return;
@@ -1531,7 +1611,7 @@ __global__ __launch_bounds__(256) void k_stereo_median(StereoProblem P) {
     const float thr = (float)(2.0 * (double)(float)lo);
     // The reference walks the sorted list from the median on, so only elements at or behind the median rank are tested; an element
     // in front of it has a correlation <= the median and can never exceed twice the (non-negative) median.
-    for (int i = tid; i < nl; i += 256)
+    for (int i = tid; i < nl; i += nthr)
         if ((xr[i] != -1.0f || depth[i] != -1.0f) && thr < (float)(int)corr[i]) {
             xr[i] = -1.0f;
             depth[i] = -1.0f;
@@ -1540,13 +1620,23 @@ __global__ __launch_bounds__(256) void k_stereo_median(StereoProblem P) {
 
 }  // namespace
 
+size_t sv_stereo_rows_bytes(int pairs, int rows, int nr_cap, int rows_per_kp) {
+    auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+    return pad((size_t)pairs * (rows + 1) * 4) + pad((size_t)pairs * rows * 4) + pad((size_t)pairs * nr_cap * rows_per_kp * 4) + 256;
+}
 void sv_launch_stereo(svgpu_ctx* ctx, hipStream_t s, const StereoProblem& P, int pairs) {
     SvProfScope ps(ctx, s, "k_stereo");
-    const int nl = P.nl_dev ? P.cap : P.nl;
-    if (nl > 0 && pairs > 0) hipLaunchKernelGGL(k_stereo, dim3((nl + 3) / 4, pairs), dim3(256), 0, s, P);
+    const int nl = P.nl_dev ? P.cap : P.nl, nr = P.nl_dev ? P.cap : P.nr;
+    if (nl <= 0 || pairs <= 0) return;
+    (void)hipMemsetAsync(P.row_off, 0, (size_t)pairs * (P.rows + 1) * 4, s);
+    (void)hipMemsetAsync(P.row_fill, 0, (size_t)pairs * P.rows * 4, s);
+    if (nr > 0) hipLaunchKernelGGL(k_stereo_rows<false>, dim3((nr + 255) / 256, pairs), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_stereo_rows_scan, dim3(pairs), dim3(1024), 0, s, P);
+    if (nr > 0) hipLaunchKernelGGL(k_stereo_rows<true>, dim3((nr + 255) / 256, pairs), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_stereo, dim3((nl + 3) / 4, pairs), dim3(256), 0, s, P);
 }
 void sv_launch_stereo_median(hipStream_t s, const StereoProblem& P, int pairs) {
-    if (pairs > 0) hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(256), 0, s, P);
+    if (pairs > 0) hipLaunchKernelGGL(k_stereo_median, dim3(pairs), dim3(1024), 0, s, P);
 }
 
 void sv_launch_hamming_pairs(hipStream_t s, const uint32_t* a, const uint32_t* b, int n, uint32_t* out) {

@@ -647,8 +647,9 @@ int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_ke
     if (n_right == 0) return SVGPU_OK;
     SV_HIP(ctx, hipSetDevice(ctx->device));
     SV_HIP(ctx, hipStreamSynchronize(ctx_right->stream));  // the right pyramid must be complete
+    const int rows = CL.levels[0].h, rows_per_kp = 2 * (int)std::ceil(2.0 * std::pow((double)CL.scale_factor, CL.num_levels - 1)) + 3;  // rows of the widest band, one to spare
     const size_t need = pad((size_t)n_left * 28) + pad((size_t)n_right * 28) + pad((size_t)n_left * 32) + pad((size_t)n_right * 32)
-                        + 3 * pad((size_t)n_left * 4) + 256;
+                        + 3 * pad((size_t)n_left * 4) + sv_stereo_rows_bytes(1, rows, n_right, rows_per_kp) + 256;
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
@@ -660,6 +661,10 @@ int svgpu_stereo_match(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, const svgpu_ke
     P.xr = A.take<float>(n_left);
     P.depth = A.take<float>(n_left);
     P.corr = A.take<float>(n_left);
+    P.rows = rows, P.rows_per_kp = rows_per_kp;
+    P.row_off = A.take<int32_t>((size_t)rows + 1);
+    P.row_fill = A.take<int32_t>(rows);
+    P.row_items = A.take<int32_t>((size_t)n_right * rows_per_kp);
     hipStream_t s = ctx->stream;
     SV_HIP(ctx, hipMemcpyAsync(dkl, kps_left, (size_t)n_left * 28, hipMemcpyHostToDevice, s));
     SV_HIP(ctx, hipMemcpyAsync(dkr, kps_right, (size_t)n_right * 28, hipMemcpyHostToDevice, s));
@@ -722,10 +727,15 @@ int svgpu_stereo_match_batch_device(svgpu_ctx* ctx_left, svgpu_ctx* ctx_right, i
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_stereo_match_batch_device: the two extractors must share device, geometry and ORB parameters");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    int rc = sv_ensure_scratch(ctx, pad((size_t)pairs * cap * 4) + 256);
+    const int rows = CL.levels[0].h, rows_per_kp = 2 * (int)std::ceil(2.0 * std::pow((double)CL.scale_factor, CL.num_levels - 1)) + 3;  // rows of the widest band, one to spare
+    int rc = sv_ensure_scratch(ctx, pad((size_t)pairs * cap * 4) + sv_stereo_rows_bytes(pairs, rows, cap, rows_per_kp) + 256);
     if (rc) return rc;
     Arena A(ctx->d_scratch);
     StereoProblem P{};
+    P.rows = rows, P.rows_per_kp = rows_per_kp;
+    P.row_off = A.take<int32_t>((size_t)pairs * (rows + 1));
+    P.row_fill = A.take<int32_t>((size_t)pairs * rows);
+    P.row_items = A.take<int32_t>((size_t)pairs * cap * rows_per_kp);
     P.kl = kps_left_dev;
     P.kr = kps_right_dev;
     P.dl = (const uint32_t*)desc_left_dev;
