@@ -479,6 +479,8 @@ __device__ __forceinline__ void blur_locate(const OrbLevel* __restrict__ L, int 
 __device__ __forceinline__ bool blur_streamable(const uint8_t* src, int spitch, int w) {
     return ((((size_t)src) | (size_t)spitch) & 3) == 0 && w >= 16;
 }
+template <int ROWS>  // rows a thread walks: 64 for batches (least halo traffic), 16 for a context configured for a few frames (4 x the threads:
+                     // one 640x480 frame is 1 280 strips of 64 rows, a serial walk of 25 us on a chip that holds 500 k threads)
 __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
                                               size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
                                               size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
@@ -492,9 +494,9 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
     if (tile < main_tiles) {
         const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
         // the strip's first row is the same for the whole wave: say so, and the row pointers of blur_strip become scalar
-        const int ys = __builtin_amdgcn_readfirstlane((tile / lev.btiles_x) * BLUR_TH + (int)(threadIdx.x >> 6) * BLUR_ROWS);
+        const int ys = __builtin_amdgcn_readfirstlane((tile / lev.btiles_x) * (4 * ROWS) + (int)(threadIdx.x >> 6) * ROWS);
         if (x0 >= lev.w || ys >= lev.h) return;
-        if (x0 >= 4 && x0 + 6 < lev.w) blur_strip<BLUR_INTERIOR>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
+        if (x0 >= 4 && x0 + 6 < lev.w) blur_strip<BLUR_INTERIOR>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + ROWS, lev.h));
     }
     else {
         // edge groups: x0 = 0 and every group with x0 + 6 >= w (at most two); thread = (strip, which)
@@ -510,6 +512,7 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
         blur_strip<BLUR_EDGE>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_EDGE_ROWS, lev.h));
     }
 }
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_blur_gather(const OrbLevel* __restrict__ L, int num_levels, const uint8_t* __restrict__ img0,
                                                      size_t img0_frame_stride, int img0_pitch, const uint8_t* __restrict__ pyr,
                                                      size_t pyr_frame_bytes, uint8_t* __restrict__ blur, size_t blur_frame_bytes) {
@@ -520,9 +523,9 @@ __global__ __launch_bounds__(256) void k_blur_gather(const OrbLevel* __restrict_
     blur_locate(L, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, lev, tile, src, spitch, dst);
     if (blur_streamable(src, spitch, lev.w) || tile >= lev.btiles_x * lev.btiles_y) return;
     const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
-    const int ys = (tile / lev.btiles_x) * BLUR_TH + (threadIdx.x >> 6) * BLUR_ROWS;
+    const int ys = (tile / lev.btiles_x) * (4 * ROWS) + (threadIdx.x >> 6) * ROWS;
     if (x0 >= lev.w || ys >= lev.h) return;
-    blur_strip<BLUR_GATHER>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + BLUR_ROWS, lev.h));
+    blur_strip<BLUR_GATHER>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + ROWS, lev.h));
 }
 
 // ------------------------------------------------------------------------------------------------ FAST
@@ -1144,12 +1147,18 @@ void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, co
 
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
-                    size_t blur_frame_bytes, int batch, bool need_gather) {
-    hipLaunchKernelGGL(k_blur, dim3(total_tiles, batch), dim3(256), 0, s, levels, num_levels, img0, img0_frame_stride,
-                       img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
-    if (need_gather)
-        hipLaunchKernelGGL(k_blur_gather, dim3(total_tiles, batch), dim3(256), 0, s, levels, num_levels, img0, img0_frame_stride,
-                           img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+                    size_t blur_frame_bytes, int batch, bool need_gather, int rows) {
+    const dim3 grid(total_tiles, batch), block(256);
+    if (rows == BLUR_ROWS_SMALL) {
+        hipLaunchKernelGGL(k_blur<BLUR_ROWS_SMALL>, grid, block, 0, s, levels, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+        if (need_gather)
+            hipLaunchKernelGGL(k_blur_gather<BLUR_ROWS_SMALL>, grid, block, 0, s, levels, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+    }
+    else {
+        hipLaunchKernelGGL(k_blur<BLUR_ROWS>, grid, block, 0, s, levels, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+        if (need_gather)
+            hipLaunchKernelGGL(k_blur_gather<BLUR_ROWS>, grid, block, 0, s, levels, num_levels, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes);
+    }
 }
 
 void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const FastCell* cells, int num_cells,

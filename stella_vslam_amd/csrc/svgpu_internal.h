@@ -20,8 +20,9 @@
 #ifndef BLUR_ROWS
 #define BLUR_ROWS 64
 #endif
-#define BLUR_TW 256                 // tile width  = 64 threads x 4 px
-#define BLUR_TH (4 * BLUR_ROWS)     // tile height = 4 strips
+#define BLUR_ROWS_SMALL 16          // contexts configured for at most BLUR_SMALL_BATCH frames: latency, not halo traffic, is what counts
+#define BLUR_SMALL_BATCH 4
+#define BLUR_TW 256                 // tile width  = 64 threads x 4 px; tile height = 4 strips of OrbConfig::blur_rows rows
 
 // ---- per-level geometry, read by every ORB kernel (lives in device memory, one array per context)
 struct OrbLevel {
@@ -58,6 +59,7 @@ struct OrbConfig {
     std::vector<FastCell> cells;
     int total_grid = 0;    // sum of grid cells over levels = max keypoints per frame
     int total_btiles = 0;
+    int blur_rows = BLUR_ROWS;  // rows per k_blur thread (BLUR_ROWS, or BLUR_ROWS_SMALL for a context of a few frames)
     size_t pyr_frame_bytes = 0, blur_frame_bytes = 0;
     bool configured = false;
 };
@@ -198,7 +200,7 @@ void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, co
 hipError_t sv_pyramid_prepare();
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
-                    size_t blur_frame_bytes, int batch, bool need_gather);
+                    size_t blur_frame_bytes, int batch, bool need_gather, int rows);
 void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const FastCell* cells, int num_cells,
                     const uint8_t* img0, size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr,
                     size_t pyr_frame_bytes, const unsigned short* gtab, unsigned long long* keys, int total_grid,

@@ -100,6 +100,7 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     C.width = width;
     C.height = height;
     C.max_batch = max_batch;
+    C.blur_rows = max_batch <= BLUR_SMALL_BATCH ? BLUR_ROWS_SMALL : BLUR_ROWS;
     C.num_levels = num_levels;
     C.scale_factor = scale_factor;
     C.ini_thr = ini_fast_thr < 0 ? 0 : (ini_fast_thr > 255 ? 255 : ini_fast_thr);  // cv::FAST clamps (fast.cpp)
@@ -203,7 +204,7 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
         // ---- blur tiles
         L.btile_first = btile_first;
         L.btiles_x = (L.w + BLUR_TW - 1) / BLUR_TW;
-        L.btiles_y = (L.h + BLUR_TH - 1) / BLUR_TH;
+        L.btiles_y = (L.h + 4 * C.blur_rows - 1) / (4 * C.blur_rows);
         btile_first += L.btiles_x * L.btiles_y + ((L.h + 7) / 8 + 63) / 64;  // + edge tiles (64 strips of BLUR_EDGE_ROWS rows each)
         // ---- FAST cell lattice and selection grid
         L.cell_first = (int)C.cells.size();
@@ -399,7 +400,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
         bool need_gather = (((size_t)imgs_dev | (size_t)frame_stride | (size_t)row_stride) & 3) != 0;
         for (int l = 0; l < Lc; ++l) need_gather = need_gather || C.levels[l].w < 16;
         sv_launch_blur(sb, ctx->d_levels, Lc, C.total_btiles, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes,
-                       ctx->d_blur, C.blur_frame_bytes, batch, need_gather);
+                       ctx->d_blur, C.blur_frame_bytes, batch, need_gather, C.blur_rows);
     }
     if (sb != s) SV_HIP(ctx, hipEventRecord(ctx->ev_join, sb));
     // 3. FAST per cell + selection-grid arg-max
