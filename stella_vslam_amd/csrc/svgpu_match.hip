@@ -145,13 +145,20 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
     P.num = A.take<int32_t>(1);
     take_sort(A, P, 1, n1, n2);
     hipStream_t s = ctx->stream;
-    SV_HIP(ctx, hipMemcpyAsync(d1, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
-    SV_HIP(ctx, hipMemcpyAsync(d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
-    if (angle1) SV_HIP(ctx, hipMemcpyAsync(a1, angle1, (size_t)n1 * 4, hipMemcpyHostToDevice, s));
-    else SV_HIP(ctx, hipMemsetAsync(a1, 0, (size_t)n1 * 4, s));
-    if (angle2) SV_HIP(ctx, hipMemcpyAsync(a2, angle2, (size_t)n2 * 4, hipMemcpyHostToDevice, s));
-    else SV_HIP(ctx, hipMemsetAsync(a2, 0, (size_t)n2 * 4, s));
-    if (valid2) SV_HIP(ctx, hipMemcpyAsync(v2, valid2, n2, hipMemcpyHostToDevice, s));
+    // inputs through the page-locked mirror of the arena: one copy down (the five arrays are the first takes: one contiguous range), one up
+    if ((rc = sv_ensure_stage(ctx, need))) return rc;
+    A.mirror = ctx->h_stage;
+    if ((rc = A.upload(ctx, s, d1, desc1, (size_t)n1 * 32))) return rc;
+    if ((rc = A.upload(ctx, s, d2, desc2, (size_t)n2 * 32))) return rc;
+    if (angle1) rc = A.upload(ctx, s, a1, angle1, (size_t)n1 * 4);
+    else memset(A.mirror + ((char*)a1 - A.base), 0, (size_t)n1 * 4);
+    if (rc) return rc;
+    if (angle2) rc = A.upload(ctx, s, a2, angle2, (size_t)n2 * 4);
+    else memset(A.mirror + ((char*)a2 - A.base), 0, (size_t)n2 * 4);
+    if (rc) return rc;
+    if (valid2 && (rc = A.upload(ctx, s, v2, valid2, n2))) return rc;
+    if (!angle1 || !angle2) A.up_lo = 0, A.up_hi = std::max(A.up_hi, (size_t)((char*)(a2 + n2) - A.base));  // the zeroed angle rows travel with the range
+    if ((rc = A.flush(ctx, s))) return rc;
     P.desc1 = d1;
     P.desc2 = d2;
     P.angle1 = a1;
@@ -167,9 +174,12 @@ int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* an
     sv_launch_bf(ctx, s, P, 1, g_owner, g_match);
     SV_HIP(ctx, hipGetLastError());
     int32_t num = 0;
-    SV_HIP(ctx, hipMemcpyAsync(matched_2_in_1, P.matched, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-    SV_HIP(ctx, hipMemcpyAsync(&num, P.num, 4, hipMemcpyDeviceToHost, s));
+    Downloads D;
+    D.add(A, matched_2_in_1, P.matched, (size_t)n1 * 4);
+    D.add(A, &num, P.num, 4);
+    if ((rc = D.fetch(ctx, s, A))) return rc;
     SV_HIP(ctx, hipStreamSynchronize(s));
+    D.scatter(A);
     *num_matches = num;
     return SVGPU_OK;
 }
