@@ -700,8 +700,42 @@ def bench_global_ba(device, rank, world):
         plan = ba.last_envelope_plan()
     except Exception:
         plan = None
+    kernels = None
+    if world == 1:
+        # one more call with HIP events around every kernel class of the LM loop (svgpu_profile_select "*"): mean launch time and the
+        # ALGORITHMIC bytes of a launch (what the formulation has to move once: observations, the W blocks at 144 B per edge, landmark
+        # blocks, the pair list) against the 8 TB/s HBM roof; the envelope solve is a dependency chain over 1.5 MB (no byte figure)
+        from stella_vslam_amd._lib import lib
+        L = lib()
+        E, Lm, P = len(sc["obs_pose"]), len(sc["points"]), len(sc["pose_cw"])
+        L.svgpu_profile_select(ctx.handle, b"*")
+        r2 = run()
+        pairs = 0
+        lm_deg = np.bincount(np.asarray(sc["obs_point"]), minlength=Lm).astype(np.int64)
+        pairs = int((lm_deg * (lm_deg + 1) // 2).sum())
+        alg = {"ba_linearize": E * (29 + 24 + 144) + Lm * (24 + 48 + 24) + P * 96,      # observations twice (landmark- and pose-major), W, Hll, bl, points, poses
+               "ba_schur": E * 144 + Lm * 48 + pairs * 12,                               # W and Hll once, the (edge, edge, landmark) pair list
+               "ba_update": E * 144 + Lm * (48 + 24 + 24 + 24) + P * 96,                 # W, Hll, bl, point in / out
+               "ba_chi2": E * 25 + Lm * 24 + P * 96,                                     # observations, points, poses
+               "ba_solve": None}
+        kernels = []
+        for name, nbytes in alg.items():
+            ms, n = C.c_double(), C.c_longlong()
+            L.svgpu_profile_read_class(ctx.handle, name.encode(), C.byref(ms), C.byref(n))
+            if n.value == 0:
+                continue
+            mean = ms.value / n.value
+            ent = {"class": name, "launches_per_call": n.value, "mean_launch_ms": round(mean, 4)}
+            if nbytes is not None:
+                ach = nbytes / (mean * 1e-3) / 1e9
+                ent.update({"bound": "hbm", "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(ach, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                            "frac": round(ach / HBM_PEAK_GBS, 4)})
+            else:
+                ent.update({"bound": "latency", "note": "segmented block envelope Cholesky: jobs + separator system + backward substitution, a dependency chain of ~100 block columns"})
+            kernels.append(ent)
+        L.svgpu_profile_select(ctx.handle, None)
     return {"metric": "global-BA LM iterations/s @500 KF / 200k landmarks / %d obs" % len(sc["obs_pose"]), "value": round(iters / dt, 2), "unit": "iters/s",
-            "envelope_plan": plan,
+            "envelope_plan": plan, "kernels": kernels,
             "ms_per_call": round(dt / reps * 1e3, 2), "iters_per_call": iters / reps, "dtype": "f64", "n_gpus": world,
             "sharding": "none" if world == 1 else "observations by landmark (l % N): all-reduce of the kept Schur blocks per damping trial over RCCL; the factorisation of the "
                                                   "reduced system is distributed (every rank eliminates the envelope jobs it owns, separator contributions and solution exchanged)",
