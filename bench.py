@@ -207,6 +207,8 @@ def main() -> int:
 
 
 KERNEL_CLASSES = ("k_resize", "k_blur", "k_fast", "k_select", "k_describe", "k_bf_binsort", "k_bf_topk", "k_bf_replay")
+# profiling class (svgpu_profile_read_class) -> the kernel symbol rocprofv3 lists for it in profiles/*_kernel_stats.csv, where the two differ
+ROCPROF_KERNEL = {"k_resize": "k_pyramid_lds", "k_bf_topk": "k_bf_mfma"}
 
 
 def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world):
@@ -337,7 +339,7 @@ def roofline_entries(fe, src_hash, B, world):
         else:
             per_launch = fe["alg"][name] / lps
         ach = per_launch / (mean_ms * 1e-3) / (1e9 if b_ == "hbm" else 1e12)
-        entry = {"kernel": name, "bound": b_, "unit": u_, "peak": p_, "achieved": round(ach, 2), "frac": round(ach / p_, 5),
+        entry = {"kernel": name, "rocprof_kernel": ROCPROF_KERNEL.get(name, name), "bound": b_, "unit": u_, "peak": p_, "achieved": round(ach, 2), "frac": round(ach / p_, 5),
                  "mean_launch_ms": round(mean_ms, 5), "launches_per_step": lps,
                  ("algorithmic_bytes_per_launch" if b_ == "hbm" else "executed_int8_ops_per_launch"): int(per_launch),
                  "traffic": traffic_of(name), "valu_issue": valu_of(name)}
@@ -352,7 +354,7 @@ def roofline_entries(fe, src_hash, B, world):
                 entry["mfma_busy_frac"] = lk["mfma_busy_frac"]
         kernels.append(entry)
     dk = max(kernels, key=lambda k: k["mean_launch_ms"] * k["launches_per_step"])
-    dom = {"kernel": dk["kernel"], "bound": dk["bound"], "achieved": dk["achieved"], "peak": dk["peak"], "unit": dk["unit"], "frac": dk["frac"],
+    dom = {"kernel": dk["kernel"], "rocprof_kernel": dk["rocprof_kernel"], "bound": dk["bound"], "achieved": dk["achieved"], "peak": dk["peak"], "unit": dk["unit"], "frac": dk["frac"],
            "traffic": dk["traffic"], "valu_issue": dk["valu_issue"], "mean_launch_ms": dk["mean_launch_ms"],
            "pmc_profiles_match_sources": traffic_json is not None}
     for k in ("algorithmic_bytes_per_launch", "executed_int8_ops_per_launch"):
