@@ -375,7 +375,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         const size_t k = lm_off[l + 1] - lm_off[l];
         pair_cap += k * k;
     }
-    const size_t sc_part_blocks = pair_cap / 192 + nb_cap + 16;  // NB * nshare <= pairs / 192 + NB
+    const size_t sc_part_blocks = pair_cap / 64 + nb_cap + 16;  // NB * nshare <= pairs / 64 + NB (a share holds at least 64 pairs: one trip of a wave)
     const size_t xch_doubles = std::max(std::max((size_t)P, 4 * (size_t)L), nb_cap) + 8;
     const size_t nparts_max = (size_t)(P + 3) / 4 + 1;
     const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE;
@@ -737,9 +737,16 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         static const size_t share_pairs = [] {
             const char* e = std::getenv("SVGPU_BA_SHARE_PAIRS");  // tuning aid: pairs per share of a block of the reduced system
             const long v = e ? std::atol(e) : 0;
-            return (size_t)(v >= 192 ? v : 192);  // (>= 192: the partial-sum buffer is sized for it)
+            return (size_t)(v >= 64 ? v : 192);  // (>= 64: the partial-sum buffer is sized for it)
         }();
         D.nshare = D.NB > 0 ? (int)std::min<size_t>(16, std::max<size_t>(1, (HS.num_pairs / (size_t)D.NB + share_pairs - 1) / share_pairs)) : 1;
+        if (D.NB > 0) {
+            // A small system does not fill the chip with ~192-pair shares (config 3: 136 blocks x 7 shares for 1 792 unit slots): its shares shrink
+            // down to one trip of a wave (64 pairs) while the units still fit one resident round -- 17.7 -> 13.4 us per launch there; a large
+            // system keeps the long shares (config 5 at 64 pairs per share: 314 us instead of 189)
+            const size_t avg = HS.num_pairs / (size_t)D.NB, ns_max = std::min<size_t>(16, std::max<size_t>(1, (avg + 63) / 64));
+            while ((size_t)D.nshare < ns_max && (size_t)D.NB * (D.nshare + 1) <= 2304) ++D.nshare;
+        }
         // solver of this stage: PCG inside one workgroup's LDS when the blocks fit, else one launch per PCG iteration
         const bool lds_ok = sv_ba_pcg_lds_bytes(D) > 0;
         // AUTO: dense LL^T in LDS while it fits (n <= ~135: 70 us per trial against 88 us for the LDS-resident PCG at n = 96), the
