@@ -1953,8 +1953,11 @@ int sv_ba_lin_split_max() { return LIN_SPLIT_MAX; }
 int sv_ba_lin_split(int E, int nP) {  // workgroups per free pose on the pose side of k_ba_lin
     if (nP <= 0) return 1;
     const long long per_pose = ((long long)E + nP - 1) / nP;
-    const int k = (int)((per_pose + LIN_EDGES_PER_BLOCK - 1) / LIN_EDGES_PER_BLOCK);
-    return k < 1 ? 1 : (k > LIN_SPLIT_MAX ? LIN_SPLIT_MAX : k);
+    int k = (int)((per_pose + LIN_EDGES_PER_BLOCK - 1) / LIN_EDGES_PER_BLOCK);
+    k = k < 1 ? 1 : (k > LIN_SPLIT_MAX ? LIN_SPLIT_MAX : k);
+    // a small system (local BA: a few dozen free poses) leaves most of the chip idle at ~3 edges per lane: one edge per lane there
+    while (k < LIN_SPLIT_MAX && nP * (k + 1) <= 512 && per_pose / (k + 1) >= 192) ++k;
+    return k;
 }
 int sv_ba_rhs_split() { return RHS_SPLIT; }
 
