@@ -1258,7 +1258,8 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
     if (k < D.NB * 36) {
         const int blk = k / 36, t = k - 36 * blk;
         double sum = 0.0;
-        for (int h = 0; h < nshare; ++h) sum += D.sc_part[((size_t)blk * nshare + h) * 36 + t];
+#pragma unroll 8
+        for (int h = 0; h < nshare; ++h) sum += D.sc_part[((size_t)blk * nshare + h) * 36 + t];  // (unrolled: the loads of a share run are independent)
         const int2 ab = D.blk_ab[blk];
         double v = -sum;
         if (ab.x == ab.y) {
@@ -1271,6 +1272,7 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
         const int r = k - D.NB * 36;
         const int s = r / 6, i = r - 6 * s;
         double sum = 0.0;
+#pragma unroll
         for (int h = 0; h < RHS_SPLIT; ++h) sum += rhs_part[((size_t)s * RHS_SPLIT + h) * 6 + i];
         D.g[r] = D.bp[r] - sum;
     }
