@@ -8,6 +8,7 @@
 // histograms, one scan, a scatter with in-block stable ranks from wave ballots) groups them by block: the order inside a block is the
 // landmark-major order the host pass produced.
 
+#include <algorithm>
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
 #include "sv_sort.h"
@@ -64,8 +65,8 @@ __global__ void k_pair_emit(BaDev D, const int* __restrict__ off, unsigned* __re
 }
 
 // dense_off[k] = first sorted position with key >= k, k = 0 .. nb_dense
-__global__ void k_pair_offsets(const unsigned* __restrict__ keys, int n, int nb_dense, int* __restrict__ dense_off) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_pair_offsets(const unsigned* __restrict__ keys, const int* __restrict__ n_dev, int n_host, int nb_dense, int* __restrict__ dense_off) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, n = n_dev ? *n_dev : n_host;
     if (k > nb_dense) return;
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -77,8 +78,8 @@ __global__ void k_pair_offsets(const unsigned* __restrict__ keys, int n, int nb_
 }
 
 // landmark of every sorted pair: what the Schur kernel needs first (Hll), without the hop through e_point[pair.x]
-__global__ void k_pair_landmark(const unsigned long long* __restrict__ vals, int n, const int* __restrict__ e_point, int* __restrict__ pair_l) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_pair_landmark(const unsigned long long* __restrict__ vals, const int* __restrict__ n_dev, int n_host, const int* __restrict__ e_point, int* __restrict__ pair_l) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, n = n_dev ? *n_dev : n_host;
     if (i < n) pair_l[i] = e_point[(int)(unsigned)vals[i]];
 }
 __global__ void k_iota_u64(unsigned long long* __restrict__ v, int n) {
@@ -150,12 +151,16 @@ int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, si
     int bits = 1;
     while ((1u << bits) < (unsigned)nb_dense + 1u && bits < 32) ++bits;
     int cur = sv_sort_passes(bits) & 1 ? 0 : 1;  // so that the last pass lands in buffer 1 = pairs_out
-    if (total > 0) {
+    // total < 0 (and nothing read back): the pair total stays ON the device -- cnt[L], the scan's total -- and the launches are sized for the
+    // capacity; the host pass that used to count the pairs of a local-BA sized problem left the device idle for ~0.1 ms
+    const int* const n_dev = total < 0 ? cnt + L : nullptr;
+    const int n_launch = total < 0 ? (int)std::min<size_t>(pair_cap, 0x7fffffff) : total;
+    if (n_launch > 0) {
         hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt, keys[cur], vals[cur]);
-        cur = sv_sort_pairs(s, keys, vals, cur, total, bits, hist);
-        hipLaunchKernelGGL(k_pair_landmark, dim3((total + 255) / 256), dim3(256), 0, s, vals[cur], total, D.e_point, pair_l_out);
+        cur = sv_sort_pairs(s, keys, vals, cur, n_launch, bits, hist, n_dev);
+        hipLaunchKernelGGL(k_pair_landmark, dim3((n_launch + 255) / 256), dim3(256), 0, s, vals[cur], n_dev, n_launch, D.e_point, pair_l_out);
     }
-    hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys[cur], total, nb_dense, dense_off_dev);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((nb_dense + 256) / 256), dim3(256), 0, s, keys[cur], n_dev, n_launch, nb_dense, dense_off_dev);
     SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
 }
@@ -221,7 +226,7 @@ int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev,
     while ((1u << bits) < (unsigned)P && bits < 31) ++bits;
     const int r = sv_sort_pairs(s, keys, vals, 0, E, bits, hist);
     hipLaunchKernelGGL(k_narrow_u64, g, b, 0, s, vals[r], E, pe_idx_dev);
-    hipLaunchKernelGGL(k_pair_offsets, dim3((P + 256) / 256), dim3(256), 0, s, keys[r], E, P, pe_off_dev);
+    hipLaunchKernelGGL(k_pair_offsets, dim3((P + 256) / 256), dim3(256), 0, s, keys[r], (const int*)nullptr, E, P, pe_off_dev);
     SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
 }

@@ -259,14 +259,14 @@ void sv_scan_i32(hipStream_t s, int* data, int n, int* scratch) {
 int sv_sort_passes(int bits) { return (bits + RS_BITS - 1) / RS_BITS; }
 static inline size_t hist_ints(size_t n) { return ((size_t)RS_BINS * ((n + RS_TILE - 1) / RS_TILE + 1) + 1 + 3) & ~size_t(3); }  // the scan's scratch follows, 16-byte aligned
 size_t sv_sort_hist_ints(size_t n) { return hist_ints(n) + sv_scan_scratch_ints(hist_ints(n)); }
-int sv_sort_pairs(hipStream_t s, unsigned* const keys[2], unsigned long long* const vals[2], int start, int n, int bits, int* hist) {
+int sv_sort_pairs(hipStream_t s, unsigned* const keys[2], unsigned long long* const vals[2], int start, int n, int bits, int* hist, const int* n_dev) {
     int cur = start;
     if (n <= 0) return cur ^ (sv_sort_passes(bits) & 1);
     const int nblk = (n + RS_TILE - 1) / RS_TILE, passes = sv_sort_passes(bits);
     for (int pass = 0; pass < passes; ++pass, cur ^= 1) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], (const int*)nullptr, n, pass * RS_BITS, nblk, hist);
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], n_dev, n, pass * RS_BITS, nblk, hist);
         sv_scan_i32(s, hist, RS_BINS * nblk, hist + hist_ints((size_t)n));
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], (const int*)nullptr, n, pass * RS_BITS, nblk, hist, keys[cur ^ 1], vals[cur ^ 1]);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(RS_THREADS), 0, s, keys[cur], vals[cur], n_dev, n, pass * RS_BITS, nblk, hist, keys[cur ^ 1], vals[cur ^ 1]);
     }
     return cur;
 }

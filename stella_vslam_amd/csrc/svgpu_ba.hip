@@ -89,32 +89,6 @@ void activity_only(const svgpu_ba_problem& pr, const int* e_pose, const int* e_p
         }
 }
 
-// Number of (edge, edge) pairs k_pair_emit will produce, computed on the host so that the device pipeline needs no read-back: per
-// free landmark with k_s live edges on free pose slot s, sum_{s<t} k_s k_t + sum_s k_s^2 (a pair of two different edges of ONE pose
-// is emitted twice, mirrored) = (K^2 + sum_s k_s^2) / 2 with K = sum_s k_s.  Requires nP <= 64.
-long long host_pair_total(const svgpu_ba_problem& pr, const int* e_pose, const int* lm_off, const std::vector<uint8_t>& level, const HostStructure& H) {
-    long long total = 0;
-    int cnt[64];
-    for (int k = 0; k < 64; ++k) cnt[k] = 0;
-    for (int l = 0; l < pr.num_points; ++l) {
-        if (!H.pt_free[l]) continue;
-        long long K = 0, sq = 0;
-        for (int e = lm_off[l]; e < lm_off[l + 1]; ++e) {
-            const int sl = H.pose_slot[e_pose[e]];
-            if (level[e] || sl < 0) continue;
-            sq += 2 * cnt[sl] + 1;  // (c + 1)^2 - c^2
-            ++cnt[sl];
-            ++K;
-        }
-        for (int e = lm_off[l]; e < lm_off[l + 1]; ++e) {
-            const int sl = H.pose_slot[e_pose[e]];
-            if (sl >= 0) cnt[sl] = 0;
-        }
-        total += (K * K + sq) / 2;
-    }
-    return total;
-}
-
 // dense block offsets (from the device) -> kept blocks: every diagonal block (it carries Hpp + lambda I) and every non-empty
 // off-diagonal block, in (a, b) order; the sorted pair array needs no compaction (empty blocks hold no pairs)
 void compact_blocks(const std::vector<int>& dense_off, const std::vector<uint8_t>& present, HostStructure& H) {
@@ -644,14 +618,13 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             H2D(d_pose_slot, hs_struct + st_pose_slot, 4 * (size_t)P);
             // The pair lists are built on the device.  A local-BA sized problem (<= 48 free poses; the count is the same on every rank of
             // a sharded solve) keeps EVERY upper block -- blocks without a pair are zero blocks, the solvers of that size are dense
-            // anyway, and no union of block patterns has to be agreed between ranks -- so nothing has to come back: the pair total is
-            // computed here, the device pipeline runs unattended and the pose -> edge lists are built on the host meanwhile.
+            // anyway, and no union of block patterns has to be agreed between ranks -- so nothing has to come back: the pair total stays
+            // on the device (launches sized for the capacity) and the whole structure pipeline runs unattended.
             // Larger systems synchronise twice (pair total, block offsets) and keep only the blocks that hold a pair.
-            const long long host_total = HS.nP <= 48 ? host_pair_total(*pr, e_pose, lm_off, level, HS) : -1;
+            const bool all_blocks = HS.nP <= 48;  // (the pair total stays on the device: the launches are sized for the capacity)
             std::vector<int> dense_off;
-            if (host_total >= 0) {
-                if ((size_t)host_total > pair_cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list capacity exceeded");
-                int rp = sv_ba_build_pairs_async(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, (int)host_total, d_blk_pairs, d_blk_pair_l, d_blk_off);
+            if (all_blocks) {
+                int rp = sv_ba_build_pairs_async(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, -1, d_blk_pairs, d_blk_pair_l, d_blk_off);
                 if (rp) return rp;
                 sub("pairs enqueued");
             }
@@ -659,7 +632,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             int* const h_slot_pose = (int*)(hs_struct + st_pe);
             for (int sl = 0; sl < HS.nP; ++sl) h_slot_pose[sl] = HS.slot_pose[sl];
             if (HS.nP > 0) H2D(d_slot_pose, h_slot_pose, 4 * (size_t)HS.nP);
-            if (host_total >= 0) {
+            if (all_blocks) {
                 HS.blk_ab.clear();
                 for (int a = 0; a < HS.nP; ++a)
                     for (int b = a; b < HS.nP; ++b) {
@@ -669,7 +642,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                         HS.blk_ab.push_back(ab);
                     }
                 HS.blk_off.clear();  // lives on the device only
-                HS.num_pairs = (size_t)host_total;
+                HS.num_pairs = pair_cap;  // (an upper bound: sum over the landmarks of k^2; sizes the Schur shares)
             }
             else {
                 int rp = sv_ba_build_pairs(ctx, s, D, d_pair_scratch, pair_scratch, pair_cap, d_blk_pairs, d_blk_pair_l, dense_off);
