@@ -23,6 +23,9 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
                             int2* pairs_out, int* pair_l_out, int* dense_off_dev);
 size_t sv_ba_pose_lists_scratch_bytes(size_t E);
+int sv_ba_prepare_observations(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const int* e_point_dev, const float* e_uvr_dev, const float* e_w_dev,
+                               const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes, int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev,
+                               uint8_t* e_level_dev, double* e_chi_dev, int* pm_point, float* pm_uvr, float* pm_w, float* pm_hub);
 void sv_ba_build_pose_major(hipStream_t s, const int* pe_idx, const int* e_point, const float* e_uvr, const float* e_w, const float* e_hub, int E, int* pm_point,
                             float* pm_uvr, float* pm_w, float* pm_hub);
 int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes,
@@ -519,13 +522,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         const size_t want = sv_ba_pose_lists_scratch_bytes((size_t)E);
         void* sc = sizeof(double) * 18 * (size_t)E >= want ? (void*)D.W : (void*)d_pair_scratch;
         const size_t sc_bytes = sizeof(double) * 18 * (size_t)E >= want ? sizeof(double) * 18 * (size_t)E : pair_scratch;
-        const int rp = sv_ba_build_pose_lists(ctx, s, d_e_pose, d_e_hub, E, P, sc, sc_bytes, d_pe_off, d_pe_idx, D.e_robust);
+        const int rp = sv_ba_prepare_observations(ctx, s, d_e_pose, d_e_point, d_e_uvr, d_e_w, d_e_hub, E, P, sc, sc_bytes, d_pe_off, d_pe_idx, D.e_robust, D.e_level,
+                                                  D.e_chi, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);  // (also clears e_level / e_chi)
         if (rp) return rp;
-        sv_ba_build_pose_major(s, d_pe_idx, d_e_point, d_e_uvr, d_e_w, d_e_hub, E, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);
         D.pm_point = d_pm_point, D.pm_uvr = d_pm_uvr, D.pm_w = d_pm_w, D.pm_hub = d_pm_hub;
     }
-    SV_HIP(ctx, hipMemsetAsync(D.e_level, 0, E, s));
-    SV_HIP(ctx, hipMemsetAsync(D.e_chi, 0, 8 * (size_t)E, s));
     BaCtl ctl0;
     memset(&ctl0, 0, sizeof(ctl0));
     ctl0.gain_thr = pr->gain_threshold;
