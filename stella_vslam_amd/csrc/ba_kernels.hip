@@ -67,12 +67,13 @@ __device__ __forceinline__ void equirect_jacobians(const double* __restrict__ K,
     }
 }
 
-// error only (computeError); returns chi2 = e^T Omega e
+// error only (computeError); returns chi2 = e^T Omega e.  EQ as in edge_linearize_core below.
+template <bool EQ = true>
 __device__ __forceinline__ double edge_error(const double* __restrict__ T, const double* __restrict__ X, const double* __restrict__ K,
                                              const float* __restrict__ uvr, double w0, double* r, double* z_out) {
     double pc[3];
     cam_point(T, X, pc);
-    const bool eq = cam_is_equirect(K);
+    const bool eq = EQ && cam_is_equirect(K);
     double u = K[0] * pc[0] / pc[2] + K[2];
     double v = K[1] * pc[1] / pc[2] + K[3];
     if (eq) equirect_project(K, pc, &u, &v);
@@ -489,13 +490,14 @@ __global__ __launch_bounds__(1024) void k_ba_chol_global(BaDev D) {
 // ------------------------------------------------------------------------------------------------ errors
 // robust chi2 of the observations sub, sub + 8, ... of landmark l (lane `sub` of the landmark's group of 8), poses from `poses` (12 doubles
 // each, global or LDS), the landmark at X.  Shared by k_ba_chi2 and the fused trial tail so that both sum in the same order.
+template <bool EQ>
 __device__ __forceinline__ double lm_chi2_lane(const BaDev& D, int l, int sub, const double* poses, const double* X, int store_cache) {
     double v = 0.0;
     for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += 8) {
         if (D.e_level[e]) continue;
         const int p = D.e_pose[e];
         double r[3];
-        const double chi = edge_error(poses + (size_t)p * 12, X, D.intr + (size_t)p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
+        const double chi = edge_error<EQ>(poses + (size_t)p * 12, X, D.intr + (size_t)p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
         if (store_cache) D.e_chi[e] = chi;
         if (D.e_robust[e]) {
             double rho0, rho1;
@@ -508,6 +510,7 @@ __device__ __forceinline__ double lm_chi2_lane(const BaDev& D, int l, int sub, c
 }
 
 // 8 lanes per landmark (the observations are sorted by landmark), one partial sum per workgroup of 32 landmarks
+template <bool EQ>
 __global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int store_cache, int guarded) {
     if (guarded && D.ctl->phase != 1) return;
     __shared__ double s4[16];
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void k_ba_chi2(BaDev D, int use_trial, int sto
     if (t / 8 < D.L) {
         const double* Xg = st_pt(D, use_trial) + (size_t)l * 3;
         const double X[3] = {Xg[0], Xg[1], Xg[2]};
-        v = lm_chi2_lane(D, l, sub, st_pose(D, use_trial), X, store_cache);
+        v = lm_chi2_lane<EQ>(D, l, sub, st_pose(D, use_trial), X, store_cache);
     }
     const double tsum = block_sum_d(v, s4);
     if (threadIdx.x == 0) D.red[D.red_chi_off + blockIdx.x] = tsum;
@@ -1711,6 +1714,7 @@ __global__ __launch_bounds__(1024) void k_ba_decide(BaDev D) {  // one workgroup
 // 5 us for 313 workgroups (one or two levels alike), add-only arrivals watched by workgroup 0 cost 3 .. 12 us each -- more than the
 // launch boundary it replaces, which does that write-back once.  Same per-landmark and per-workgroup sums, in the same order, as the two kernels.
 #define TAIL_MAX_POSES 256
+template <bool EQ>
 __global__ __launch_bounds__(256) void k_ba_tail(BaDev D) {
     __shared__ double s4[16];
     __shared__ double s_pose[TAIL_MAX_POSES * 12];
@@ -1859,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_ba_tail(BaDev D) {
     if (has0 && !lvl0) {
         const float uvr[3] = {u0, v0, r0};
         double r[3];
-        const double chi = edge_error(s_pose + p0 * 12, X, s_intr + p0 * 5, uvr, (double)w0, r, nullptr);
+        const double chi = edge_error<EQ>(s_pose + p0 * 12, X, s_intr + p0 * 5, uvr, (double)w0, r, nullptr);
         if (rob0) {
             double rho0, rho1;
             huber(chi, (double)hub0, &rho0, &rho1);
@@ -1872,7 +1876,7 @@ __global__ __launch_bounds__(256) void k_ba_tail(BaDev D) {
             if (D.e_level[e]) continue;
             const int p = D.e_pose[e];
             double r[3];
-            const double chi = edge_error(s_pose + p * 12, X, s_intr + p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
+            const double chi = edge_error<EQ>(s_pose + p * 12, X, s_intr + p * 5, D.e_uvr + (size_t)e * 3, (double)D.e_w[e], r, nullptr);
             if (D.e_robust[e]) {
                 double rho0, rho1;
                 huber(chi, (double)D.e_huber[e], &rho0, &rho1);
@@ -1948,7 +1952,8 @@ void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decid
 bool sv_ba_tail_ok(const BaDev& D) { return D.world <= 1 && D.xsum == nullptr && D.P > 0 && D.P <= TAIL_MAX_POSES && D.L > 0; }
 void sv_ba_tail(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {  // update + chi2 of the trial state + decide (sv_ba_tail_ok)
     SvProfScope ps(ctx, s, "ba_tail");
-    hipLaunchKernelGGL(k_ba_tail, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D);
+    if (D.any_equirect) hipLaunchKernelGGL(k_ba_tail<true>, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D);
+    else hipLaunchKernelGGL(k_ba_tail<false>, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D);
 }
 
 int sv_ba_lin_split_max() { return LIN_SPLIT_MAX; }
@@ -2076,7 +2081,10 @@ void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 
 void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, int store_cache, int guarded) {
     SvProfScope ps(ctx, s, "ba_chi2");
-    if (D.E > 0) hipLaunchKernelGGL(k_ba_chi2, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D, use_trial, store_cache, guarded);
+    if (D.E > 0) {
+        if (D.any_equirect) hipLaunchKernelGGL(k_ba_chi2<true>, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D, use_trial, store_cache, guarded);
+        else hipLaunchKernelGGL(k_ba_chi2<false>, dim3(nb_lm_blocks(D)), dim3(256), 0, s, D, use_trial, store_cache, guarded);
+    }
 }
 
 // the current estimate (the control block says which of the two state buffers holds it) -> one contiguous output block
