@@ -26,6 +26,7 @@ struct BaDev {
     int P, L, E;   // poses (free + fixed), landmarks, observation edges (sorted by landmark)
     int nP;        // free, active poses = rows/6 of the reduced system
     int n;         // 6 * nP
+    int dbg_schur_on;  // SVGPU_BA_DBG=schur: dbg holds 8 stamps per unit of the last k_ba_schur_rhs launch instead (fills the padding: the struct is a kernel argument)
     BaCtl* ctl;
     unsigned long long* dbg;  // SVGPU_BA_DBG: 8 wall_clock64 stamps per workgroup of the last k_ba_tail launch (null otherwise)
     const volatile int* stop_mirror;  // page-locked host word the caller's force_stop_flag is mirrored into while the host waits

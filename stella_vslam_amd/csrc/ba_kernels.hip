@@ -1060,9 +1060,12 @@ __global__ __launch_bounds__(LIN_FIN_THREADS) void k_ba_lin_fin(BaDev D, int do_
     }
 }
 
-// Reduced camera system, one WAVE per work unit (4 units per workgroup, no workgroup barrier):
-//   units [0, NB * nshare)        share `sh` of block (a, b): sum over its (edge, edge) pairs of W_i Hll^-1 W_j^T -> sc_part
-//   units [.., + nP * RHS_SPLIT)  share of a pose's edges: sum of W_e Hll^-1 bl -> rhs_part
+// Reduced camera system, one WAVE per work unit (one unit per workgroup, no workgroup barrier):
+//   unit blk * nshare + sh = share `sh` of block (a, b): sum over its (edge, edge) pairs of W_i Hll^-1 W_j^T -> sc_part
+//   a share of a DIAGONAL block (a, a) walks pairs (i, i) over the edges of pose a: W_i and Hll^-1 are in hand, so the edge's term of
+//   the right-hand side, W_i Hll^-1 bl, is summed along (-> rhs_part, nshare shares per pose) and W_j is not fetched a second time.
+//   (Round 2 ran the right-hand side as nP * 16 units of its own behind the blocks: a second pass over every W record, 28 of the
+//   kernel's 181 us at config 5.)
 // A lane walks several pairs and the 36 (6) sums are reduced once per wave: with one pair per thread the 36 shuffle reductions
 // cost more than the 162 multiply-adds of the pair.  The multiply-adds are explicit fma() (the build runs with -ffp-contract=off for the
 // bit-exact fp32 front end; here contraction is wanted: 40 % fewer VALU instructions, one rounding less per term, still a fixed order).
@@ -1083,7 +1086,10 @@ __device__ __forceinline__ void coop_issue(const T* __restrict__ base, const int
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int g = k * 64 + lane, r = g / NP, piece = g - r * NP;
-        v[k] = base[(size_t)idx[r] * rec_pitch + piece];
+        // 32-bit byte offset from the uniform base (scalar base + vector offset addressing: one address register per load instead of two;
+        // the arrays gathered here stay below 4 GB: svgpu_ba.hip refuses E >= 2^32 / 144)
+        const unsigned off = ((unsigned)idx[r] * (unsigned)rec_pitch + (unsigned)piece) * (unsigned)sizeof(T);
+        v[k] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off);
     }
 }
 template <int NP, typename T>
@@ -1091,116 +1097,148 @@ __device__ __forceinline__ void coop_commit(const T (&v)[NP], T* __restrict__ ds
 #pragma unroll
     for (int k = 0; k < NP; ++k) dst[k * 64 + lane] = v[k];
 }
-__global__ __launch_bounds__(64 * SCH_WAVES) void k_ba_schur_rhs(BaDev D, int nshare, double* __restrict__ rhs_part, int xcd_order) {
-    if (D.ctl->phase != 1) return;
-    __shared__ __attribute__((aligned(16))) double s_wave[SCH_WAVES][SCH_WAVE_DOUBLES];
-    static_assert(SCH_WAVE_DOUBLES >= WRED_DOUBLES, "the reduction reuses the gather buffer");
-    const double lambda = D.ctl->lambda;
-    // XCD-aware order: workgroup i runs on XCD i % 8, each with its own 4 MB L2.  Consecutive units walk the blocks (a, a), (a, a + 1), ...
-    // of one block row, which all read the W records of pose a and its neighbours: XCD x takes the x-th CONTIGUOUS eighth of the units, so
-    // that the rows in flight on one L2 are ~3 instead of ~21 (half of the L2 requests missed at config 5 with the round-robin order:
-    // 980 MB fetched per launch, 296 MB with this order).  Small grids keep the round-robin order (the cheap right-hand-side units at the end
-    // of the list would all land on the last XCDs).
-    int wg = blockIdx.x;
-    if (xcd_order) {
-        const int chunk = gridDim.x >> 3;  // the launcher pads the grid to a multiple of 8
-        wg = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, unit = wg * SCH_WAVES + wave;
-    double* const sw = s_wave[wave];
+#define SCH_T(i) do { if (D.dbg_schur_on && lane == 0) D.dbg[8 * (size_t)unit + (i)] = wall_clock64(); } while (0)
+// pairs [q0, q1) of one block (DIAG: a diagonal block; the two code paths are separate loops so that neither carries the other's registers)
+template <bool DIAG>
+__device__ __forceinline__ void schur_unit(const BaDev& D, int unit, int lane, int q0, int q1, double lambda, double* __restrict__ sw,
+                                           double* __restrict__ out, double* __restrict__ rhs_out) {
     double2* const s_W = reinterpret_cast<double2*>(sw);                                  // 64 records x 9 pieces (W_i)
-    double2* const s_W2 = reinterpret_cast<double2*>(sw + SCH_W_DOUBLES);                 // 64 records x 9 pieces (W_j)
+    double2* const s_W2 = reinterpret_cast<double2*>(sw + SCH_W_DOUBLES);                 // 64 records x 9 pieces (W_j; DIAG: 64 x bl)
     double2* const s_H = reinterpret_cast<double2*>(sw + 2 * SCH_W_DOUBLES);              // 64 records x 3 pieces
     int* const s_ix = reinterpret_cast<int*>(sw + 2 * SCH_W_DOUBLES + SCH_H_DOUBLES);     // [0,64) e_i  [64,128) e_j  [128,192) landmark
     const double2* const Wg = reinterpret_cast<const double2*>(D.W);
     const double2* const Hg = reinterpret_cast<const double2*>(D.Hll);
-    const int n_schur = D.NB * nshare;
-    if (unit < n_schur) {
-        const int blk = unit / nshare, share = unit - blk * nshare;
-        double acc[36];
+    double acc[36], accr[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-        const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
-        const int q0 = lo + (int)((long long)np * share / nshare), q1 = lo + (int)((long long)np * (share + 1) / nshare);
-        // the pair and its landmark (blk_pair_l: Hll does not wait for e_point[pair.x]) are fetched one trip ahead; lanes past the end of the
-        // share repeat its last pair (they take part in the gathers, not in the sums)
-        int2 pr = make_int2(0, 0);
-        int l = 0;
-        if (q0 < q1) {
-            const int qq = min(q0 + lane, q1 - 1);
-            pr = D.blk_pairs[qq];
-            l = D.blk_pair_l[qq];
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    constexpr bool diag = DIAG;
+    // the pair and its landmark (blk_pair_l: Hll does not wait for e_point[pair.x]) are fetched one trip ahead; lanes past the end of the
+    // share repeat its last pair (they take part in the gathers, not in the sums)
+    int2 pr = make_int2(0, 0);
+    int l = 0;
+    SCH_T(1);
+    if (q0 < q1) {
+        const int qq = min(q0 + lane, q1 - 1);
+        pr = D.blk_pairs[qq];
+        l = D.blk_pair_l[qq];
+    }
+    for (int qb = q0; qb < q1; qb += 64) {  // wave-uniform
+        const bool mine = qb + lane < q1;
+        int2 prn = pr;
+        int ln = l;
+        if (qb + 64 < q1) {
+            const int qq = min(qb + 64 + lane, q1 - 1);
+            prn = D.blk_pairs[qq];
+            ln = D.blk_pair_l[qq];
         }
-        for (int qb = q0; qb < q1; qb += 64) {  // wave-uniform
-            const bool mine = qb + lane < q1;
-            int2 prn = pr;
-            int ln = l;
-            if (qb + 64 < q1) {
-                const int qq = min(qb + 64 + lane, q1 - 1);
-                prn = D.blk_pairs[qq];
-                ln = D.blk_pair_l[qq];
-            }
-            s_ix[lane] = pr.x;
-            s_ix[64 + lane] = pr.y;
-            s_ix[128 + lane] = l;
-            wave_lds_sync();
-            {
-                double2 hv[3], wa[9], wb[9];
-                coop_issue<3>(Hg, s_ix + 128, 3, lane, hv);
-                coop_issue<9>(Wg, s_ix, 9, lane, wa);
-                coop_issue<9>(Wg, s_ix + 64, 9, lane, wb);
-                coop_commit<3>(hv, s_H, lane);
-                coop_commit<9>(wa, s_W, lane);
-                coop_commit<9>(wb, s_W2, lane);
-            }
-            wave_lds_sync();
-            double I[6], Hl[6];
+        s_ix[lane] = pr.x;
+        s_ix[64 + lane] = pr.y;
+        s_ix[128 + lane] = l;
+        wave_lds_sync();
+        if (!diag) {
+            double2 hv[3], wa[9], wb[9];
+            coop_issue<3>(Hg, s_ix + 128, 3, lane, hv);
+            coop_issue<9>(Wg, s_ix, 9, lane, wa);
+            coop_issue<9>(Wg, s_ix + 64, 9, lane, wb);
+            coop_commit<3>(hv, s_H, lane);
+            coop_commit<9>(wa, s_W, lane);
+            coop_commit<9>(wb, s_W2, lane);
+        }
+        else {  // W_j is W_i (a pose sees a landmark once; the rare second observation is fetched per lane below); bl rides in its place
+            double2 hv[3], wa[9];
+            double bv[3];
+            coop_issue<3>(Hg, s_ix + 128, 3, lane, hv);
+            coop_issue<9>(Wg, s_ix, 9, lane, wa);
+            coop_issue<3>(D.bl, s_ix + 128, 3, lane, bv);
+            coop_commit<3>(hv, s_H, lane);
+            coop_commit<9>(wa, s_W, lane);
+            coop_commit<3>(bv, reinterpret_cast<double*>(s_W2), lane);
+        }
+        wave_lds_sync();
+        double I[6], Hl[6];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double2 t = s_H[3 * lane + k];
-                Hl[2 * k] = t.x;
-                Hl[2 * k + 1] = t.y;
-            }
-            lm_dinv(Hl, lambda, I);
-            double y[18];
-            {
-                double wi[18];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const double2 t = s_W[9 * lane + k];
-                    wi[2 * k] = t.x;
-                    wi[2 * k + 1] = t.y;
-                }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const double w0 = wi[3 * i], w1 = wi[3 * i + 1], w2 = wi[3 * i + 2];
-                    y[3 * i] = fma(w2, I[2], fma(w1, I[1], w0 * I[0]));
-                    y[3 * i + 1] = fma(w2, I[4], fma(w1, I[3], w0 * I[1]));
-                    y[3 * i + 2] = fma(w2, I[5], fma(w1, I[4], w0 * I[2]));
-                }
-            }
-            double w[18];
+        for (int k = 0; k < 3; ++k) {
+            const double2 t = s_H[3 * lane + k];
+            Hl[2 * k] = t.x;
+            Hl[2 * k + 1] = t.y;
+        }
+        lm_dinv(Hl, lambda, I);
+        double y[18];
+        {
+            double wi[18];
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const double2 t = s_W2[9 * lane + k];
+                const double2 t = s_W[9 * lane + k];
+                wi[2 * k] = t.x;
+                wi[2 * k + 1] = t.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double w0 = wi[3 * i], w1 = wi[3 * i + 1], w2 = wi[3 * i + 2];
+                y[3 * i] = fma(w2, I[2], fma(w1, I[1], w0 * I[0]));
+                y[3 * i + 1] = fma(w2, I[4], fma(w1, I[3], w0 * I[1]));
+                y[3 * i + 2] = fma(w2, I[5], fma(w1, I[4], w0 * I[2]));
+            }
+        }
+        double w[18];
+        {
+            const double2* const src = diag ? s_W : s_W2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double2 t = src[9 * lane + k];
                 w[2 * k] = t.x;
                 w[2 * k + 1] = t.y;
             }
-            if (mine) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[6 * i + j] = fma(y[3 * i + 2], w[3 * j + 2], fma(y[3 * i + 1], w[3 * j + 1], fma(y[3 * i], w[3 * j], acc[6 * i + j])));
-            }
-            wave_lds_sync();  // the records are consumed: the next trip may overwrite the buffer
-            pr = prn;
-            l = ln;
         }
-        double* const out = D.sc_part + (size_t)unit * 36;
-        wave_reduce_lds<36>(acc, sw, lane, [&](int k, double t) { out[k] = t; });
-        return;
+        if (diag) {
+            if (pr.x != pr.y) {  // two observations of one landmark by one keyframe
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const double2 t = Wg[(size_t)pr.y * 9 + k];
+                    w[2 * k] = t.x;
+                    w[2 * k + 1] = t.y;
+                }
+            }
+            else if (mine) {  // the edge's term of the right-hand side: W_i Hll^-1 bl
+                const double* const bl = reinterpret_cast<const double*>(s_W2) + 3 * lane;
+                const double b0 = bl[0], b1 = bl[1], b2 = bl[2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) accr[i] = fma(y[3 * i + 2], b2, fma(y[3 * i + 1], b1, fma(y[3 * i], b0, accr[i])));
+            }
+        }
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[6 * i + j] = fma(y[3 * i + 2], w[3 * j + 2], fma(y[3 * i + 1], w[3 * j + 1], fma(y[3 * i], w[3 * j], acc[6 * i + j])));
+        }
+        wave_lds_sync();  // the records are consumed: the next trip may overwrite the buffer
+        if (qb == q0) SCH_T(2);
+        pr = prn;
+        l = ln;
     }
-    const int ru = unit - n_schur;
+    SCH_T(3);
+    wave_reduce_lds<36>(acc, sw, lane, [&](int k, double t) { out[k] = t; });
+    if (diag) {  // this share of the pose's right-hand side (sys_fin adds the shares in order)
+        double mine_v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double t = wave_sum_dpp(accr[k]);
+            mine_v = (lane == k) ? t : mine_v;
+        }
+        if (lane < 6) rhs_out[lane] = mine_v;
+    }
+    SCH_T(4);
+}
+
+// Right-hand side as units of its own (small systems: the chip is not full, these units run beside the block shares):
+// share `ru % RHS_SPLIT` of the edges of pose slot `ru / RHS_SPLIT`: sum of W_e Hll^-1 bl
+__device__ __forceinline__ void rhs_unit(const BaDev& D, int ru, int lane, double lambda, double* __restrict__ sw, double* __restrict__ rhs_part) {
+    double2* const s_W = reinterpret_cast<double2*>(sw);
+    double2* const s_H = reinterpret_cast<double2*>(sw + 2 * SCH_W_DOUBLES);
+    int* const s_ix = reinterpret_cast<int*>(sw + 2 * SCH_W_DOUBLES + SCH_H_DOUBLES);
+    const double2* const Wg = reinterpret_cast<const double2*>(D.W);
+    const double2* const Hg = reinterpret_cast<const double2*>(D.Hll);
     if (ru >= D.nP * RHS_SPLIT) return;
     const int s = ru / RHS_SPLIT, share = ru - s * RHS_SPLIT;
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1254,8 +1292,48 @@ __global__ __launch_bounds__(64 * SCH_WAVES) void k_ba_schur_rhs(BaDev D, int ns
     if (lane < 6) rhs_part[(size_t)ru * 6 + lane] = mine_v;
 }
 
+// (two waves per SIMD pinned: left alone, the register allocator takes 266 registers for the two unit forms and halves the occupancy)
+__global__ __launch_bounds__(64 * SCH_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ba_schur_rhs(BaDev D, int nshare, double* __restrict__ rhs_part, int xcd_order) {
+    if (D.ctl->phase != 1) return;
+    __shared__ __attribute__((aligned(16))) double s_wave[SCH_WAVES][SCH_WAVE_DOUBLES];
+    static_assert(SCH_WAVE_DOUBLES >= WRED_DOUBLES, "the reduction reuses the gather buffer");
+    const double lambda = D.ctl->lambda;
+    // XCD-aware order: workgroup i runs on XCD i % 8, each with its own 4 MB L2.  Consecutive units walk the blocks (a, a), (a, a + 1), ...
+    // of one block row, which all read the W records of pose a and its neighbours: XCD x takes the x-th CONTIGUOUS eighth of the units, so
+    // that the rows in flight on one L2 are ~3 instead of ~21 (half of the L2 requests missed at config 5 with the round-robin order:
+    // 980 MB fetched per launch, 250 MB with this order; W alone is 173 MB).  The unit count is padded to a multiple of 8 by the launcher.
+    const int n_schur = D.NB * nshare;
+    int wg = blockIdx.x;
+    if (xcd_order) {
+        const int ns8 = (n_schur + 7) & ~7;
+        wg = (wg & 7) * (ns8 >> 3) + (wg >> 3);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, unit = wg * SCH_WAVES + wave;
+    double* const sw = s_wave[wave];
+    SCH_T(0);
+    if (D.dbg_schur_on && lane == 0) D.dbg[8 * (size_t)unit + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) /* HW_ID */ | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */ << 32);
+    if (unit >= n_schur) {
+        if (!xcd_order) rhs_unit(D, unit - n_schur, lane, lambda, sw, rhs_part);  // (folded into the diagonal blocks otherwise)
+        return;
+    }
+    const int blk = unit / nshare, share = unit - blk * nshare;
+    const int lo = D.blk_off[blk], np = D.blk_off[blk + 1] - lo;
+    const int2 ab = D.blk_ab[blk];
+    // (an even split; shares of whole trips -- multiples of 64 pairs, 67 k trips instead of 80 k at config 5 -- measured no faster there and
+    //  slower in local BA, 13.4 -> 14.7 us, and so did the linearisation behind it, 11.6 -> 13.1 us)
+    const int q0 = lo + (int)((long long)np * share / nshare), q1 = lo + (int)((long long)np * (share + 1) / nshare);
+    double* const out = D.sc_part + (size_t)unit * 36;
+    if (q0 >= q1) {  // wave-uniform
+        if (lane < 36) out[lane] = 0.0;
+        if (xcd_order && ab.x == ab.y && lane < 6) rhs_part[((size_t)ab.x * RHS_SPLIT + share) * 6 + lane] = 0.0;
+        return;
+    }
+    if (xcd_order && ab.x == ab.y) schur_unit<true>(D, unit, lane, q0, q1, lambda, sw, out, rhs_part + ((size_t)ab.x * RHS_SPLIT + share) * 6);  // wave-uniform
+    else schur_unit<false>(D, unit, lane, q0, q1, lambda, sw, out, nullptr);
+}
+
 // kept blocks S_ab = [a == b](Hpp_a + lambda I) - sum of the shares, right-hand side g_a = bp_a - sum of the shares
-__global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const double* __restrict__ rhs_part) {
+__global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const double* __restrict__ rhs_part, int rhs_shares) {
     if (D.ctl->phase != 1) return;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k < D.NB * 36) {
@@ -1275,8 +1353,8 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
         const int r = k - D.NB * 36;
         const int s = r / 6, i = r - 6 * s;
         double sum = 0.0;
-#pragma unroll
-        for (int h = 0; h < RHS_SPLIT; ++h) sum += rhs_part[((size_t)s * RHS_SPLIT + h) * 6 + i];
+#pragma unroll 8
+        for (int h = 0; h < rhs_shares; ++h) sum += rhs_part[((size_t)s * RHS_SPLIT + h) * 6 + i];  // nshare shares of block (s, s), or the RHS_SPLIT units of the pose
         D.g[r] = D.bp[r] - sum;
     }
 }
@@ -1722,7 +1800,7 @@ __global__ __launch_bounds__(256) void k_ba_tail(BaDev D) {
     __shared__ double s_dp[TAIL_MAX_POSES * 6];
     __shared__ int s_slot[TAIL_MAX_POSES];
     const int tid = threadIdx.x;
-#define TAIL_T(i) do { if (D.dbg && tid == 0) D.dbg[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#define TAIL_T(i) do { if (D.dbg && !D.dbg_schur_on && tid == 0) D.dbg[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
     TAIL_T(0);
     // ---- hop 1 (nothing here depends on a loaded value)
     const int phase = D.ctl->phase, cur = D.ctl->cur;
@@ -1972,10 +2050,18 @@ int sv_ba_rhs_split() { return RHS_SPLIT; }
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_schur");
     if (D.nP <= 0) return;
-    const int units = D.NB * D.nshare + D.nP * RHS_SPLIT;
-    const int wgs = (units + SCH_WAVES - 1) / SCH_WAVES, xcd_order = units >= 8192;  // more than one resident round of units
-    hipLaunchKernelGGL(k_ba_schur_rhs, dim3(xcd_order ? (wgs + 7) / 8 * 8 : wgs), dim3(64 * SCH_WAVES), 0, s, D, D.nshare, D.rhs_part, xcd_order);
-    hipLaunchKernelGGL(k_ba_sys_fin, dim3((D.NB * 36 + D.n + 255) / 256), dim3(256), 0, s, D, D.nshare, D.rhs_part);
+    if (D.nshare > RHS_SPLIT) return;  // (svgpu_ba.hip caps nshare at 16)
+    static_assert(SCH_WAVES == 1, "the XCD-contiguous order permutes workgroups = units");
+    const int n_schur = D.NB * D.nshare;
+    // A large system (more than one resident round of units): XCD-contiguous unit order, right-hand side summed by the shares of the diagonal
+    // blocks.  A small one (local BA) leaves the chip part-filled: the right-hand side runs beside the blocks as units of its own, which also
+    // leaves the observation arrays warm for the next linearisation (folded there: k_ba_schur_rhs 13.3 -> 13.6 us, k_ba_lin 11.8 -> 13.0 us).
+    int large = n_schur >= 8192;
+    static const char* const order_env = std::getenv("SVGPU_BA_SCHUR_ORDER");  // experiments: 0 = small-system form, 1 = large-system form
+    if (order_env) large = std::atoi(order_env) != 0;
+    const int grid = large ? ((n_schur + 7) & ~7) : n_schur + D.nP * RHS_SPLIT;
+    hipLaunchKernelGGL(k_ba_schur_rhs, dim3(grid), dim3(64 * SCH_WAVES), 0, s, D, D.nshare, D.rhs_part, large);
+    hipLaunchKernelGGL(k_ba_sys_fin, dim3((D.NB * 36 + D.n + 255) / 256), dim3(256), 0, s, D, D.nshare, D.rhs_part, large ? D.nshare : RHS_SPLIT);
 }
 
 // LDS-resident PCG: bytes of dynamic LDS for this system, 0 = does not fit (n > 512 or more than ~150 KB)

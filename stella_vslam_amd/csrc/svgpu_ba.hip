@@ -167,6 +167,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     if (P < 0 || L < 0 || E < 0 || (P > 0 && (!pr->pose_cw || !pr->pose_fixed || !pr->intrinsics)) || (L > 0 && !pr->points)
         || (E > 0 && (!pr->obs_pose || !pr->obs_point || !pr->obs_uvr || !pr->obs_inv_sigma_sq || (!outlier_out && !single_stage))))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: inconsistent problem");
+    // the record gathers of k_ba_schur_rhs address the W / Hll / bl arrays with 32-bit byte offsets (144 bytes per observation, 48 per landmark)
+    if ((size_t)E * 144 >= ((size_t)1 << 32) || (size_t)L * 48 >= ((size_t)1 << 32))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: more than 2^32 / 144 observations per rank (shard the landmarks over more ranks)");
     const bool sharded = allreduce != nullptr;
     if (sharded && (world < 1 || rank < 0 || rank >= world)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: bad rank/world");
     ctx->ba_ar_fn = allreduce;  // (the segmented envelope solve of ba_skyline.hip exchanges through the same all-reduce)
@@ -419,7 +422,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
     D.lm_max = A.take<double>(nb_lm);  // nb_lm == sv_ba_lm_blocks(L)
     static const bool dbg_stamps = std::getenv("SVGPU_BA_DBG") != nullptr;
-    D.dbg = dbg_stamps ? A.take<unsigned long long>(8 * (size_t)nb_lm) : nullptr;
+    static const bool dbg_schur = dbg_stamps && !strcmp(std::getenv("SVGPU_BA_DBG"), "schur");
+    D.dbg_schur_on = dbg_schur ? 1 : 0;
+    D.dbg = dbg_stamps ? A.take<unsigned long long>(8 * (dbg_schur ? sc_part_blocks + 64 : (size_t)nb_lm)) : nullptr;
     double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
     double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
     double* d_xch = A.take<double>(xch_doubles);                  // sharded: pose-activity / block-presence / point exchange
@@ -855,7 +860,40 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int it1 = 0, it2 = 0;
     rc = optimize(pr->num_first_iter, &it1);
     if (rc) return rc;
-    if (D.dbg) {  // SVGPU_BA_DBG: where the time of the last fused tail went (100 MHz stamps, relative to the first workgroup's entry)
+    if (D.dbg_schur_on) {  // SVGPU_BA_DBG=schur: life of the units of the last k_ba_schur_rhs launch (100 MHz stamps)
+        const size_t nu = (size_t)D.NB * D.nshare;
+        std::vector<unsigned long long> h(8 * nu);
+        SV_HIP(ctx, hipMemcpyAsync(h.data(), D.dbg, 8 * h.size(), hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (size_t u = 0; u < nu; ++u)
+            if (h[8 * u + 4] < h[8 * u]) h[8 * u + 1] = h[8 * u + 2] = h[8 * u + 3] = h[8 * u + 4] = h[8 * u];  // an empty share: entry stamp only
+        for (size_t u = 0; u < nu; ++u) t0 = std::min(t0, h[8 * u]), t1 = std::max(t1, h[8 * u + 4]);
+        double sum[5] = {0, 0, 0, 0, 0};
+        std::vector<int> per_cu(8 * 64, 0);
+        std::vector<double> life(nu);
+        for (size_t u = 0; u < nu; ++u) {
+            for (int k = 1; k < 5; ++k) sum[k] += (double)(h[8 * u + k] - h[8 * u + k - 1]) * 0.01;
+            life[u] = (double)(h[8 * u + 4] - h[8 * u]) * 0.01;
+            sum[0] += life[u];
+            const unsigned hw = (unsigned)h[8 * u + 5], xcc = (unsigned)(h[8 * u + 5] >> 32) & 15;
+            per_cu[(xcc & 7) * 64 + (((hw >> 13) & 3) * 16 + ((hw >> 8) & 15))]++;
+        }
+        std::sort(life.begin(), life.end());
+        int cus = 0, mxu = 0;
+        for (int c : per_cu) cus += c > 0, mxu = std::max(mxu, c);
+        std::fprintf(stderr, "[ba] schur stamps: %zu units, span %.1f us, mean life %.2f us (p10 %.2f p50 %.2f p90 %.2f max %.2f) -> mean resident %.0f waves; per unit: setup %.2f | first trip %.2f | other trips %.2f | reduce %.2f us; %d (XCC, SE, CU) slots used, max %d units on one\n",
+                     nu, (double)(t1 - t0) * 0.01, sum[0] / nu, life[nu / 10], life[nu / 2], life[nu * 9 / 10], life[nu - 1], sum[0] / ((double)(t1 - t0) * 0.01),
+                     sum[1] / nu, sum[2] / nu, sum[3] / nu, sum[4] / nu, cus, mxu);
+        // start times per XCC: does every XCC receive units at the same rate?
+        double last_start[8] = {0}, n_x[8] = {0};
+        for (size_t u = 0; u < nu; ++u) {
+            const unsigned xcc = (unsigned)(h[8 * u + 5] >> 32) & 7;
+            last_start[xcc] = std::max(last_start[xcc], (double)(h[8 * u] - t0) * 0.01), n_x[xcc] += 1;
+        }
+        for (int x = 0; x < 8; ++x) std::fprintf(stderr, "[ba]   XCC %d: %.0f units, last start at %.1f us\n", x, n_x[x], last_start[x]);
+    }
+    if (D.dbg && !D.dbg_schur_on) {  // SVGPU_BA_DBG: where the time of the last fused tail went (100 MHz stamps, relative to the first workgroup's entry)
         std::vector<unsigned long long> h(8 * (size_t)nb_lm);
         SV_HIP(ctx, hipMemcpyAsync(h.data(), D.dbg, 8 * h.size(), hipMemcpyDeviceToHost, s));
         SV_HIP(ctx, hipStreamSynchronize(s));
