@@ -2057,7 +2057,7 @@ void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     // blocks.  A small one (local BA) leaves the chip part-filled: the right-hand side runs beside the blocks as units of its own, which also
     // leaves the observation arrays warm for the next linearisation (folded there: k_ba_schur_rhs 13.3 -> 13.6 us, k_ba_lin 11.8 -> 13.0 us).
     int large = n_schur >= 8192;
-    static const char* const order_env = std::getenv("SVGPU_BA_SCHUR_ORDER");  // experiments: 0 = small-system form, 1 = large-system form
+    const char* const order_env = std::getenv("SVGPU_BA_SCHUR_ORDER");  // tests / experiments: 0 = small-system form, 1 = large-system form
     if (order_env) large = std::atoi(order_env) != 0;
     const int grid = large ? ((n_schur + 7) & ~7) : n_schur + D.nP * RHS_SPLIT;
     hipLaunchKernelGGL(k_ba_schur_rhs, dim3(grid), dim3(64 * SCH_WAVES), 0, s, D, D.nshare, D.rhs_part, large);

@@ -147,6 +147,43 @@ def test_local_ba_landmark_seen_twice_from_one_keyframe(ba):
     assert np.array_equal(got["outlier"], ref["outlier"])
 
 
+def test_reduced_system_forms_agree(ba, monkeypatch):
+    """k_ba_schur_rhs has two forms: a small system runs the right-hand side W Hll^-1 bl as units of its own beside the block shares, a large
+    one (>= 8 192 units) sums it inside the shares of the diagonal blocks (pairs (i, i) over a keyframe's observations; W_j is W_i there) and
+    walks the units in XCD-contiguous order.  SVGPU_BA_SCHUR_ORDER forces either form: same sums in another grouping, so the LM schedule must
+    be identical and the estimates agree far below the parity tolerance -- also with a landmark seen twice from one keyframe (pairs (i, j),
+    i != j, inside a diagonal block) and with excluded observations in the second stage (their W is zero, the pair list is reused)."""
+    from stella_vslam_amd import optimize
+    twice = S.ba_scene(num_kf=8, num_lm=600, obs_per_lm=4, num_fixed=2, seed=13)
+    rng = np.random.default_rng(5)
+    pick = rng.choice(len(twice["obs_pose"]), 150, replace=False)
+    for key in ("obs_pose", "obs_point", "obs_inv_sigma_sq", "obs_huber"):
+        twice[key] = np.concatenate([twice[key], twice[key][pick]])
+    uvr = twice["obs_uvr"][pick].copy()
+    uvr[:, :2] += rng.normal(0, 0.5, (len(pick), 2)).astype(np.float32)
+    twice["obs_uvr"] = np.concatenate([twice["obs_uvr"], uvr])
+    for sc, run in ((twice, lambda a, s: a.optimize_flat(s)), (S.ba_scene(), lambda a, s: a.optimize_flat(s)),
+                    (S.ba_scene_large(num_kf=160, num_lm=40000), lambda a, s: a.optimize_global_flat(s, num_iter=10))):
+        out = {}
+        for form in ("0", "1"):
+            monkeypatch.setenv("SVGPU_BA_SCHUR_ORDER", form)
+            out[form] = run(optimize.local_bundle_adjuster(), sc)
+        monkeypatch.delenv("SVGPU_BA_SCHUR_ORDER", raising=False)
+        a, b = out["0"], out["1"]
+        for key in ("iters_stage1", "iters_stage2", "num_gated", "lm_trials", "cholesky_failures"):
+            assert a["stats"][key] == b["stats"][key], key
+        assert a["stats"]["chi2_final"] == pytest.approx(b["stats"]["chi2_final"], rel=1e-9)
+        assert np.abs(a["pose_cw"] - b["pose_cw"]).max() < 1e-8 and np.abs(a["points"] - b["points"]).max() < 1e-8
+        if "outlier" in a: assert np.array_equal(a["outlier"], b["outlier"])
+    ref = O.local_ba(twice)
+    monkeypatch.setenv("SVGPU_BA_SCHUR_ORDER", "1")
+    got = optimize.local_bundle_adjuster().optimize_flat(twice)
+    monkeypatch.delenv("SVGPU_BA_SCHUR_ORDER", raising=False)
+    assert got["stats"]["iters_stage1"] == ref["stats"][2] and got["stats"]["iters_stage2"] == ref["stats"][3] and got["stats"]["num_gated"] == ref["stats"][5]
+    _assert_poses(got["pose_cw"], ref["pose_cw"])
+    assert np.array_equal(got["outlier"], ref["outlier"])
+
+
 def test_local_ba_observations_in_any_order(ba):
     """Observations grouped by landmark (the order the reference creates its edges in) are copied as they are; any other order is
     sorted by landmark first and the outlier flags come back in the caller's order."""
