@@ -893,49 +893,76 @@ __device__ __forceinline__ bool lm_dinv(const double* __restrict__ H, double lam
 #define LIN_SPLIT_MAX 16
 #define LIN_EDGES_PER_BLOCK 768
 template <bool EQ>
-__global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm, int blk0) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EQ ? 2 : 4, 4))) void k_ba_lin(BaDev D, int nb_lm, int blk0) {
     if (D.ctl->phase != 0) return;
     const double* pose_cur = st_pose(D, 0);
     const double* pt_cur = st_pt(D, 0);
     const int bid = blockIdx.x + blk0;
+    // one LDS block for both sides: the landmark side stages the W records of a wave's 64 lanes (144 bytes each), the pose side its reductions
+    __shared__ __attribute__((aligned(16))) double s_buf[4 * 64 * 18];
+    static_assert(4 * 64 * 18 >= 2 * WRED_DOUBLES, "the pose side's two transposition buffers live in the staging block");
     if (bid < nb_lm) {
+        __shared__ int s_we[4][64];
         const int t = bid * 256 + threadIdx.x;
         const int l = min(t / LM_LANES, D.L - 1), sub = t % LM_LANES;
         const bool in_range = t / LM_LANES < D.L;
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        double* const my_w = s_buf + (size_t)wv * (64 * 18) + ln * 18;
         double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
         const bool lfree = D.pt_free[l];
-        if (in_range)
-            for (int e = D.lm_off[l] + sub; e < D.lm_off[l + 1]; e += LM_LANES) {
-                if (D.e_level[e]) continue;
+        const int hi = in_range ? D.lm_off[l + 1] : 0;
+        // wave-uniform trip count: every lane takes part in the store of the wave's records
+        for (int e = in_range ? D.lm_off[l] + sub : 0; __builtin_amdgcn_ballot_w64(e < hi) != 0; e += LM_LANES) {
+            int we = -1;  // the edge whose W record this lane produced in this trip
+            if (e < hi && !D.e_level[e]) {
                 const int slot = D.pose_slot[D.e_pose[e]];
-                if (!lfree && slot < 0) continue;
-                EdgeLin o;
-                edge_linearize<EQ>(D, pose_cur, pt_cur, e, o);
-                if (lfree) {
+                if (lfree || slot >= 0) {
+                    EdgeLin o;
+                    edge_linearize<EQ>(D, pose_cur, pt_cur, e, o);
+                    if (lfree) {
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
-                        const double wr = -o.w * o.r[d];
-                        b[0] += a0 * wr;
-                        b[1] += a1 * wr;
-                        b[2] += a2 * wr;
-                        H[0] += a0 * o.w * a0;
-                        H[1] += a0 * o.w * a1;
-                        H[2] += a0 * o.w * a2;
-                        H[3] += a1 * o.w * a1;
-                        H[4] += a1 * o.w * a2;
-                        H[5] += a2 * o.w * a2;
-                    }
-                    if (slot >= 0) {
-                        double* Wd = D.W + (size_t)e * 18;
+                        for (int d = 0; d < 3; ++d) {
+                            const double a0 = o.A[3 * d], a1 = o.A[3 * d + 1], a2 = o.A[3 * d + 2];
+                            const double wr = -o.w * o.r[d];
+                            b[0] += a0 * wr;
+                            b[1] += a1 * wr;
+                            b[2] += a2 * wr;
+                            H[0] += a0 * o.w * a0;
+                            H[1] += a0 * o.w * a1;
+                            H[2] += a0 * o.w * a2;
+                            H[3] += a1 * o.w * a1;
+                            H[4] += a1 * o.w * a2;
+                            H[5] += a2 * o.w * a2;
+                        }
+                        if (slot >= 0) {
+                            we = e;
 #pragma unroll
-                        for (int i = 0; i < 6; ++i)
+                            for (int i = 0; i < 6; ++i)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j)
-                                Wd[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
+                                for (int j = 0; j < 3; ++j)
+                                    my_w[3 * i + j] = o.B[i] * o.w * o.A[j] + o.B[6 + i] * o.w * o.A[3 + j] + o.B[12 + i] * o.w * o.A[6 + j];
+                        }
                     }
                 }
             }
+            // The records leave through LDS: piece g = k * 64 + lane of the wave's 64 x 9 sixteen-byte pieces belongs to the record of lane
+            // g / 9, so consecutive lanes store consecutive 16 bytes (a wave's edges are contiguous in memory: the observations are sorted by
+            // landmark).  Stored per lane -- nine 16-byte stores 144 bytes apart -- every store instruction put 64 partial lines to the L2:
+            // 10.8 M write requests per config-5 launch, 79 us for the landmark side.
+            s_we[wv][ln] = we;
+            wave_lds_sync();
+            {
+                const double2* const src = reinterpret_cast<const double2*>(s_buf + (size_t)wv * (64 * 18));
+                char* const Wg = reinterpret_cast<char*>(D.W);
+#pragma unroll 3
+                for (int k = 0; k < 9; ++k) {
+                    const int g = k * 64 + ln, r = g / 9, piece = g - 9 * r, er = s_we[wv][r];
+                    // (32-bit byte offset from the uniform base: svgpu_ba.hip refuses E >= 2^32 / 144)
+                    if (er >= 0) *reinterpret_cast<double2*>(Wg + ((unsigned)er * 144u + (unsigned)piece * 16u)) = src[g];
+                }
+            }
+            wave_lds_sync();
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) H[k] = group_sum8(H[k]);
 #pragma unroll
@@ -989,11 +1016,10 @@ __global__ __launch_bounds__(256) void k_ba_lin(BaDev D, int nb_lm, int blk0) {
     }
     // the four waves reduce two at a time through two wave-private transposition buffers (half the LDS => one more workgroup per CU)
     __shared__ double s_w[4][27];
-    __shared__ __attribute__((aligned(16))) double s_red[2][WRED_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave < 2) wave_reduce_lds<27>(acc, s_red[wave], lane, [&](int k, double t) { s_w[wave][k] = t; });
+    if (wave < 2) wave_reduce_lds<27>(acc, s_buf + wave * WRED_DOUBLES, lane, [&](int k, double t) { s_w[wave][k] = t; });
     __syncthreads();
-    if (wave >= 2) wave_reduce_lds<27>(acc, s_red[wave - 2], lane, [&](int k, double t) { s_w[wave][k] = t; });
+    if (wave >= 2) wave_reduce_lds<27>(acc, s_buf + (wave - 2) * WRED_DOUBLES, lane, [&](int k, double t) { s_w[wave][k] = t; });
     __syncthreads();
     if (threadIdx.x < 27) D.lp_part[((size_t)s * split + share) * 27 + threadIdx.x] = ((s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + s_w[2][threadIdx.x]) + s_w[3][threadIdx.x];
 }
