@@ -170,12 +170,19 @@ struct SkyG {
           rowoff((const SV_GLB int*)K.rowoff), colrows((const SV_GLB int*)K.colrows), colbase((const SV_GLB int*)K.colbase), pos((const SV_GLB int*)K.pos),
           order((const SV_GLB int*)K.order) {}
 };
+template <class DstP, class LiP, class FailP>
+__device__ __forceinline__ void sky_pivot_rows(double (&a)[6], DstP dstL, DstP dstInv, LiP s_Li, FailP s_fail, int tid);
 template <class SrcP, class DstP, class LiP, class FailP>
 __device__ __forceinline__ void sky_pivot(SrcP src, DstP dstL, DstP dstInv, LiP s_Li, FailP s_fail, int tid) {
     const int r = min(tid, 5);
     double a[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) a[c] = src[r * 6 + c];  // lane r < 6: row r (lanes >= 6 mirror row 5 and write nothing)
+    sky_pivot_rows(a, dstL, dstInv, s_Li, s_fail, tid);
+}
+// (a: row min(lane, 5) of the block, in registers)
+template <class DstP, class LiP, class FailP>
+__device__ __forceinline__ void sky_pivot_rows(double (&a)[6], DstP dstL, DstP dstInv, LiP s_Li, FailP s_fail, int tid) {
     double Lm[6][6], rd[6];  // the finished factor and its reciprocal diagonal, wave-uniform
     bool bad = false;
 #pragma unroll
@@ -183,7 +190,7 @@ __device__ __forceinline__ void sky_pivot(SrcP src, DstP dstL, DstP dstInv, LiP 
         double v = a[c];
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            if (k < c) v -= a[k] * Lm[c][k];  // a[k] = L[r][k] by now
+            if (k < c) v = fma(-a[k], Lm[c][k], v);  // a[k] = L[r][k] by now (fma: the pivot is the dependent chain of the whole factorisation)
         const double dcc = lane_bcast(v, c);
         bad = bad || !(dcc > 0.0);
         const double rs = rsqrt(dcc);
@@ -201,7 +208,7 @@ __device__ __forceinline__ void sky_pivot(SrcP src, DstP dstL, DstP dstInv, LiP 
         double v = rr == cc ? 1.0 : 0.0;
 #pragma unroll
         for (int k = 0; k < 6; ++k)
-            if (k < rr) v -= (k >= cc ? Lm[rr][k] * x[k] : 0.0);
+            if (k < rr) v = fma(-(k >= cc ? Lm[rr][k] : 0.0), x[k], v);
         x[rr] = rr >= cc ? v * rd[rr] : 0.0;
     }
     if (tid < 6) {
@@ -684,20 +691,36 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
     __syncthreads();
     // Column j: [scale] barrier [update of the other waves | first wave: the six rows of block (j + 1, j + 1), then the PIVOT of column
     // j + 1, which needs nothing else of this update] barrier.  Two barriers per column, the pivots off the critical path.
-    auto update_item = [&](int jm1, int t) {  // S_{ip, iq} -= L_p L_q^T inside the window: item = (pair, row of the block); jm1 = slot of row / column j + 1
-        const int x = t / 6, a = t - 6 * x;
+    // S_{ip, iq} -= L_p L_q^T inside the window; jm1 = slot of row / column j + 1.  Item = (pair, rows a0, a0 + 1 of the block): L_q is read
+    // once per item, so a pair moves 180 doubles through LDS instead of the 324 of one-row items; every entry is one thread's sum in the
+    // same order as before.
+    auto update_rows2 = [&](int jm1, int x, int a0) {
         const int pq = s_pq[x], p = pq & 255, q = pq >> 8;
-        double La[6];
+        // every operand is loaded BEFORE the first store: the compiler cannot tell the window from the column buffer (one LDS block), so a
+        // store inside the loop made every later load wait for it -- six dependent round trips per item, 2 160 cycles for this phase
+        double La[2][6], Lq[6][6], Dv[2][6];
+        SV_LDS double* Dst = slot_at(wrap(jm1 + p), wrap(jm1 + q)) + a0 * 6;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) La[c] = s_col[p * 36 + a * 6 + c];
-        SV_LDS double* Dst = slot_at(wrap(jm1 + p), wrap(jm1 + q)) + a * 6;
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            double v = La[0] * s_col[q * 36 + b * 6];
+            for (int c = 0; c < 6; ++c) La[r][c] = s_col[p * 36 + (a0 + r) * 6 + c], Dv[r][c] = Dst[r * 6 + c];
 #pragma unroll
-            for (int c = 1; c < 6; ++c) v += La[c] * s_col[q * 36 + b * 6 + c];
-            Dst[b] -= v;
-        }
+        for (int bb = 0; bb < 6; ++bb)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Lq[bb][c] = s_col[q * 36 + bb * 6 + c];
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                double v = La[r][0] * Lq[bb][0];  // explicit fma (the build runs with -ffp-contract=off): half the VALU work of this phase
+#pragma unroll
+                for (int c = 1; c < 6; ++c) v = fma(La[r][c], Lq[bb][c], v);
+                Dv[r][bb] -= v;
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Dst[r * 6 + c] = Dv[r][c];
     };
     // columns jb .. je - 1 (the pivot of column jb is in s_Li when it starts; the pivot of column je is NOT taken: it may wait for the other half)
     auto factor = [&](int jb, int je) {
@@ -730,38 +753,92 @@ __global__ __launch_bounds__(SKY_BAND_THREADS) void k_sky_band(BaDev D, SkyDev K
                 s_col[t] = v;
             }
             block_sync_lds();
-            for (int t = tid; t < m * 36; t += nt) Gk.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
+            // (the first wave has the pivot of the next column ahead of it: the other waves store the finished column)
+            if (tid >= 64)
+                for (int t = tid - 64; t < m * 36; t += nt - 64) Gk.val[(size_t)(s_rbase[j + 1 + t / 36] + j) * 36 + t % 36] = s_col[t];
             const int npair = m * (m + 1) / 2;
             if (tid < 64) {
-                if (m > 0 && tid < 6) update_item(jm1, tid);  // pair (0, 0) = block (j + 1, j + 1)
-                wave_lds_order();
-                if (j + 1 < je)
-                    sky_pivot(slot_at(jm1, jm1), Gk.val + (s_rbase[j + 1] + j + 1) * 36, Gk.dinv + (j + 1) * 36, Li_of(j + 1), s_failp, tid);
+                // Block (j + 1, j + 1) and the pivot of column j + 1 in ONE LDS round trip: lane r < 6 loads row r of the block, row r of
+                // L_{j+1,j} and the whole of L_{j+1,j}, subtracts its six sums (update_item's, in its order) in registers and goes straight
+                // into the pivot -- the updated block is not written back (nothing reads it again: the column scaling takes L_jj^-1).  Through
+                // the window (update, store, reload) it was three dependent LDS accesses behind the other waves' update traffic.
+                if (j + 1 < je) {
+                    const int r = min(tid, 5);
+                    double a[6], Lr[6], Lb[6][6];
+                    const SV_LDS double* Dg = slot_at(jm1, jm1) + r * 6;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) a[c] = Dg[c];
+                    if (m > 0) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) Lr[c] = s_col[r * 6 + c];
+#pragma unroll
+                        for (int b = 0; b < 6; ++b)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) Lb[b][c] = s_col[b * 6 + c];
+#pragma unroll
+                        for (int b = 0; b < 6; ++b) {
+                            double v = Lr[0] * Lb[b][0];
+#pragma unroll
+                            for (int c = 1; c < 6; ++c) v = fma(Lr[c], Lb[b][c], v);
+                            a[b] -= v;
+                        }
+                    }
+                    sky_pivot_rows(a, Gk.val + (s_rbase[j + 1] + j + 1) * 36, Gk.dinv + (j + 1) * 36, Li_of(j + 1), s_failp, tid);
+                }
+                else if (m > 0 && tid < 36) {  // last column of the stretch: block (j + 1, j + 1) stays in the window for what follows (hand-over or the next stretch)
+                    const int a = tid / 6, b = tid - 6 * a;
+                    double v = s_col[a * 6] * s_col[b * 6];
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) v = fma(s_col[a * 6 + c], s_col[b * 6 + c], v);
+                    slot_at(jm1, jm1)[tid] -= v;
+                }
             }
             else {
                 if (tid >= nt - 64) {  // the forward substitution of this column rides along on the last wave: z_j = L_jj^-1 y_j, y_i -= L_ij z_j
                     const int lane = tid - (nt - 64);  // (the sums in the order of sky_forward_narrow: the same bits)
                     const SV_LDS double* Li = Li_of(j);
+                    // one LDS round trip for everything the step reads (y_j, L_jj^-1, this lane's rows of the scaled column and their y): the LDS
+                    // pipe is busy with the update of the other waves, a dependent access costs several hundred cycles here
+                    // (m <= SKY_BAND_W = 16: at most two items per lane)
+                    static_assert(SKY_BAND_W * 6 <= 128, "two forward-substitution items per lane");
+                    double Bv[2][6], yv[2], yj[6], Lv[21];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) yj[c] = s_y[j * 6 + c];
+#pragma unroll
+                    for (int r = 0, k = 0; r < 6; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) Lv[k++] = Li[r * 6 + c];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int t = lane + 64 * k;
+                        if (t < m * 6) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) Bv[k][c] = s_col[t * 6 + c];  // row (t / 6, t % 6) of the scaled column: s_col[r * 36 + a * 6 + c]
+                            yv[k] = s_y[(j + 1) * 6 + t];
+                        }
+                    }
                     double z[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) {
+                    for (int r = 0, k = 0; r < 6; ++r) {
                         double v = 0.0;
 #pragma unroll
-                        for (int c = 0; c < 6; ++c)
-                            if (c <= r) v += Li[r * 6 + c] * s_y[j * 6 + c];
+                        for (int c = 0; c <= r; ++c) v += Lv[k++] * yj[c];
                         z[r] = v;
                     }
-                    wave_lds_order();  // every lane has read y_j
                     if (lane < 6) s_y[j * 6 + lane] = lane == 0 ? z[0] : lane == 1 ? z[1] : lane == 2 ? z[2] : lane == 3 ? z[3] : lane == 4 ? z[4] : z[5];
-                    for (int t = lane; t < m * 6; t += 64) {
-                        const SV_LDS double* Bl = s_col + t * 6;  // row (t / 6, t % 6) of the scaled column: s_col[r * 36 + a * 6 + c]
-                        double u = Bl[0] * z[0];
 #pragma unroll
-                        for (int c = 1; c < 6; ++c) u += Bl[c] * z[c];
-                        s_y[(j + 1) * 6 + t] -= u;
+                    for (int k = 0; k < 2; ++k) {
+                        const int t = lane + 64 * k;
+                        if (t < m * 6) {
+                            double u = Bv[k][0] * z[0];
+#pragma unroll
+                            for (int c = 1; c < 6; ++c) u += Bv[k][c] * z[c];
+                            s_y[(j + 1) * 6 + t] = yv[k] - u;
+                        }
                     }
                 }
-                for (int t = 6 + (tid - 64); t < npair * 6; t += nt - 64) update_item(jm1, t);
+                else  // the waves between: the update, two block rows per item (pair 0 went entry by entry on the first wave)
+                    for (int t = 3 + (tid - 64); t < npair * 3; t += nt - 128) update_rows2(jm1, t / 3, 2 * (t - 3 * (t / 3)));
             }
             if (inew < nP) {  // row j's slots are free (its diagonal was read by the pivot of column j long ago)
 #pragma unroll
