@@ -136,6 +136,15 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {  // v of lane 
     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// v of the lane a DPP control selects (a cross-lane move inside the VALU: ~10 cycles; __shfl_xor goes through the LDS crossbar, ~100 cycles,
+// and queues behind the workgroup's LDS traffic -- three of them sat on the dependent chain of every backward-substitution step)
+template <int CTRL>
+__device__ __forceinline__ double dpp_swap(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -317,24 +326,29 @@ __device__ __forceinline__ void sky_backward_narrow(const SkyDev& K, YP s_y, IP 
             for (int d = 0; d < PD; ++d) {
                 const int j = j0 - d;
                 if (j < jlo) break;
-                double v = 0.0;
+                // z_j is read with the x's of the rows below (one LDS round trip per step, not two); the two items of a lane are summed apart
+                // (two chains of six fused multiply-adds instead of one of twelve multiply + add pairs)
+                double zj[6], vk[2] = {0.0, 0.0};
+#pragma unroll
+                for (int c = 0; c < 6; ++c) zj[c] = s_y[j * 6 + c];
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     if (src[d][k] >= 0)
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) v += bc[d][k][c] * s_y[src[d][k] + c];
-                v += __shfl_xor(v, 1, 64);  // fixed tree inside the component's eight lanes
-                v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64);
+                        for (int c = 0; c < 6; ++c) vk[k] = fma(bc[d][k][c], s_y[src[d][k] + c], vk[k]);
+                double v = vk[0] + vk[1];
+                v += dpp_swap<0xB1>(v);   // fixed tree inside the component's eight lanes: lane ^ 1 (quad_perm [1, 0, 3, 2]),
+                v += dpp_swap<0x4E>(v);   // lane ^ 2 (quad_perm [2, 3, 0, 1]),
+                v += dpp_swap<0x141>(v);  // the other quad (row_half_mirror: lane 7 - i; every lane of a quad holds the quad's sum by now)
                 double w[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) w[c] = s_y[j * 6 + c] - lane_bcast(v, 8 * c);
+                for (int c = 0; c < 6; ++c) w[c] = zj[c] - lane_bcast(v, 8 * c);
                 wave_lds_order();
                 if (lane < 6) {  // x_j = Li_j^T w: component a = sum_{c >= a} Li[c][a] w[c]
                     double x = 0.0;
 #pragma unroll
                     for (int c = 0; c < 6; ++c)
-                        if (c >= lane) x += lc[d][c] * w[c];
+                        if (c >= lane) x = fma(lc[d][c], w[c], x);
                     s_y[j * 6 + lane] = x;
                 }
                 wave_lds_order();
