@@ -174,11 +174,10 @@ __device__ __forceinline__ void edge_linearize_core(const BaDev& D, const double
     o.w = w0 * rho1;
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_dpp(double v);  // (below: DPP row scans, VALU only)
+// 64-lane sum, the total in every lane, fixed order.  (Until round 3 a butterfly of __shfl_xor: two LDS-crossbar round trips per step on
+// the critical path of every kernel that ends in a sum.)
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_dpp(v); }
 
 // block-wide sum of one double per thread (blockDim.x <= 1024), fixed order; result valid in every thread
 __device__ __forceinline__ double block_sum_d(double v, double* sw /* 16 doubles */) {
@@ -551,14 +550,23 @@ __global__ __launch_bounds__(256) void k_ba_gate(BaDev D, int set_levels, uint8_
 // rounds, the 6x6 solves (thread 0) and the chi-square re-classification run on the device; the reductions are
 // fixed-order (shuffles + wave partials in LDS).
 #define PO_THREADS 512
-__device__ __forceinline__ void po_reduce(double* vals, int nv, double (*s_part)[32], double* s_out) {
+#define WRED_PITCH 66
+#define WRED_DOUBLES (18 * WRED_PITCH + 18 * 4)
+template <int NV, class Store>
+__device__ __forceinline__ void wave_reduce_lds(const double (&acc)[NV], double* __restrict__ sw, int lane, Store store);  // (below)
+// Workgroup sums of NV per-thread values, fixed order: per wave through a transpose in wave-private LDS (wave_reduce_lds: ~60 instructions
+// per 18 values), then the eight wave partials.  (A butterfly of __shfl_xor per value -- two LDS-crossbar round trips per step, 348 of
+// them per wave for the 29 sums of a linearisation -- was most of an LM iteration of this kernel.)
+template <int NV>
+__device__ __forceinline__ void po_reduce(const double (&vals)[NV], double* __restrict__ s_wred, double (*s_part)[32], double* s_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = 0; k < nv; ++k) {
-        const double t = wave_sum_d(vals[k]);
-        if (lane == 0) s_part[wave][k] = t;
+    if constexpr (NV == 1) {
+        const double t = wave_sum_dpp(vals[0]);
+        if (lane == 0) s_part[wave][0] = t;
     }
+    else wave_reduce_lds<NV>(vals, s_wred + (size_t)wave * WRED_DOUBLES, lane, [&](int k, double t) { s_part[wave][k] = t; });
     __syncthreads();
-    if ((int)threadIdx.x < nv) {
+    if ((int)threadIdx.x < NV) {
         double t = 0.0;
         for (int w = 0; w < PO_THREADS / 64; ++w) t += s_part[w][threadIdx.x];
         s_out[threadIdx.x] = t;
@@ -627,6 +635,7 @@ __device__ __forceinline__ bool po_chol6(const double* H, double lambda, const d
 }
 
 __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
+    extern __shared__ __attribute__((aligned(16))) double s_wred[];  // PO_THREADS / 64 transposition buffers of WRED_DOUBLES (dynamic: 81 KB)
     __shared__ double s_part[PO_THREADS / 64][32];
     __shared__ double s_red[32];
     __shared__ double s_T[12], s_Tt[12], s_x[6];
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 acc[27] += rho0;
                 acc[28] += 1.0;
             }
-            po_reduce(acc, 29, s_part, s_red);
+            po_reduce<29>(acc, s_wred, s_part, s_red);
             if (s_red[28] == 0.0) break;  // no active edge: nothing to optimise in this round (uniform)
             double H[36], b[6];
             {
@@ -744,7 +753,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                     if (P.robust[i]) huber(chi, (double)P.huber[i], &rho0, &rho1);
                     tmp[0] += rho0;
                 }
-                po_reduce(tmp, 1, s_part, s_red);
+                po_reduce<1>(tmp, s_wred, s_part, s_red);
                 double temp_chi = s_red[0];
                 if (!s_ctl[2]) temp_chi = 1.7976931348623157e308;
                 double scale = 1e-3;
@@ -788,7 +797,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
             bad[0] += out;
             if (P.num_trials != 0 && trial + 1 == P.num_trials_robust) P.robust[i] = 0;
         }
-        po_reduce(bad, 1, s_part, s_red);
+        po_reduce<1>(bad, s_wred, s_part, s_red);
         num_bad = (int)s_red[0];
         __syncthreads();
         if (n - num_bad < 5) break;
@@ -835,8 +844,6 @@ __device__ __forceinline__ void wave_lds_sync() {  // orders the wave's own LDS 
 // reads and lanes k < 18 add the three partials -- ~60 instructions per 18 values in a fixed order (bit-reproducible), against
 // ~20 per VALUE for a DPP butterfly (wave_sum_dpp), which cost more than the arithmetic it followed in k_ba_schur_rhs / k_ba_lin.
 // `sw`: WRED_DOUBLES doubles owned by the wave.  store(k, total) is called by ONE lane per value.
-#define WRED_PITCH 66
-#define WRED_DOUBLES (18 * WRED_PITCH + 18 * 4)
 template <int NV, class Store>
 __device__ __forceinline__ void wave_reduce_lds(const double (&acc)[NV], double* __restrict__ sw, int lane, Store store) {
     const int k = lane % 18, q = lane / 18;
@@ -2014,7 +2021,9 @@ __global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
 
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P) {
     SvProfScope ps(ctx, s, "k_pose_opt");
-    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_THREADS), 0, s, P);
+    const size_t lds = sizeof(double) * (PO_THREADS / 64) * WRED_DOUBLES;
+    (void)sv_allow_dynamic_lds((const void*)k_pose_opt, lds);  // dynamic LDS above 64 KB must be allowed explicitly
+    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_THREADS), lds, s, P);
 }
 
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
