@@ -605,40 +605,62 @@ __device__ __forceinline__ void po_exp_mul(const double* u, const double* T, dou
         O[4 * i + 3] = R[3 * i] * T[3] + R[3 * i + 1] * T[7] + R[3 * i + 2] * T[11] + V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
     }
 }
-__device__ __forceinline__ bool po_chol6(const double* H, double lambda, const double* b, double* x) {  // (H + lambda I) x = b
+// (fully unrolled: every index is a compile-time constant, the factor lives in registers -- with run-time loop bounds the 36-entry array sat
+//  in scratch memory.  The divisions stay divisions: with one reciprocal per column the iterates moved by an ulp, and at a converged pose
+//  the gain test of a further LM iteration is decided by exactly that -- the iteration counts left the reference's by two.)
+template <class HP>
+__device__ __forceinline__ bool po_chol6(HP H, double lambda, HP b, double* x) {  // (H + lambda I) x = b
     double A[36];
+#pragma unroll
     for (int i = 0; i < 36; ++i) A[i] = H[i];
+#pragma unroll
     for (int i = 0; i < 6; ++i) A[7 * i] += lambda;
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = A[7 * j];
-        for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
-        if (!(d > 0.0)) return false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < j) d -= A[6 * j + k] * A[6 * j + k];
+        ok = ok && d > 0.0;
         d = sqrt(d);
         A[7 * j] = d;
-        for (int i = j + 1; i < 6; ++i) {
-            double sum = A[6 * i + j];
-            for (int k = 0; k < j; ++k) sum -= A[6 * i + k] * A[6 * j + k];
-            A[6 * i + j] = sum / d;
-        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i > j) {
+                double sum = A[6 * i + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (k < j) sum -= A[6 * i + k] * A[6 * j + k];
+                A[6 * i + j] = sum / d;
+            }
     }
+    if (!ok) return false;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double sum = b[i];
-        for (int k = 0; k < i; ++k) sum -= A[6 * i + k] * x[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < i) sum -= A[6 * i + k] * x[k];
         x[i] = sum / A[7 * i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double sum = x[i];
-        for (int k = i + 1; k < 6; ++k) sum -= A[6 * k + i] * x[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k > i) sum -= A[6 * k + i] * x[k];
         x[i] = sum / A[7 * i];
     }
     return true;
 }
 
+template <bool EQ>  // false: the camera is not equirectangular (decided on the host from the intrinsics): no atan2 / asin path, fewer registers
 __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     extern __shared__ __attribute__((aligned(16))) double s_wred[];  // PO_THREADS / 64 transposition buffers of WRED_DOUBLES (dynamic: 81 KB)
     __shared__ double s_part[PO_THREADS / 64][32];
     __shared__ double s_red[32];
-    __shared__ double s_T[12], s_Tt[12], s_x[6];
+    __shared__ double s_T[12], s_Tt[12], s_x[6], s_H[36], s_b[6];
     __shared__ int s_ctl[4];  // [0] accept, [1] continue trials, [2] ok2
     const int tid = threadIdx.x, n = P.n;
     if (tid < 12) s_T[tid] = P.pose_in[tid];
@@ -651,7 +673,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     auto chi_at = [&](int i, const double* T, double* r, double* pc) {
         cam_point(T, P.pos_w + (size_t)i * 3, pc);
         double u = P.intr[0] * pc[0] / pc[2] + P.intr[2], v = P.intr[1] * pc[1] / pc[2] + P.intr[3];
-        const bool eq = cam_is_equirect(P.intr);
+        const bool eq = EQ && cam_is_equirect(P.intr);
         if (eq) equirect_project(P.intr, pc, &u, &v);
         const float* o = P.uvr + (size_t)i * 3;
         r[0] = (double)o[0] - u;
@@ -676,7 +698,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 double r[3], pc[3];
                 const double chi = chi_at(i, s_T, r, pc);
                 const double x = pc[0], y = pc[1], z = pc[2], z_sq = z * z, fx = P.intr[0], fy = P.intr[1], fxb = P.intr[4];
-                const bool eq = cam_is_equirect(P.intr);
+                const bool eq = EQ && cam_is_equirect(P.intr);
                 const bool stereo = !(P.uvr[(size_t)i * 3 + 2] < 0.f) && !eq;
                 double J[18];
                 J[0] = x * y / z_sq * fx;
@@ -713,21 +735,17 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
             }
             po_reduce<29>(acc, s_wred, s_part, s_red);
             if (s_red[28] == 0.0) break;  // no active edge: nothing to optimise in this round (uniform)
-            double H[36], b[6];
-            {
-                int k = 0;
-                for (int a = 0; a < 6; ++a)
-                    for (int c = a; c < 6; ++c) {
-                        H[6 * a + c] = H[6 * c + a] = s_red[k];
-                        ++k;
-                    }
-                for (int a = 0; a < 6; ++a) b[a] = s_red[21 + a];
+            // H (symmetric, from its 21 unique sums) and b stay in LDS: only the solving thread needs H, every thread reads b for the step scale
+            if (tid < 36) {
+                const int a = tid / 6, c = tid - 6 * a, lo = min(a, c), hi = max(a, c);
+                s_H[tid] = s_red[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
             }
+            else if (tid < 42) s_b[tid - 36] = s_red[21 + (tid - 36)];
             double cur = s_red[27];
             __syncthreads();
             if (it == 0) {
                 double md = 0.0;
-                for (int a = 0; a < 6; ++a) md = fmax(md, fabs(H[7 * a]));
+                for (int a = 0; a < 6; ++a) md = fmax(md, fabs(s_H[7 * a]));
                 lambda = 1e-5 * md;
                 ni = 2.0;
             }
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
             do {
                 if (tid == 0) {
                     double x[6] = {0, 0, 0, 0, 0, 0};
-                    const bool ok2 = po_chol6(H, lambda, b, x);
+                    const bool ok2 = po_chol6((const double*)s_H, lambda, (const double*)s_b, x);
                     if (!ok2)
                         for (int a = 0; a < 6; ++a) x[a] = 0.0;
                     for (int a = 0; a < 6; ++a) s_x[a] = x[a];
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 double temp_chi = s_red[0];
                 if (!s_ctl[2]) temp_chi = 1.7976931348623157e308;
                 double scale = 1e-3;
-                for (int a = 0; a < 6; ++a) scale += s_x[a] * (lambda * s_x[a] + b[a]);
+                for (int a = 0; a < 6; ++a) scale += s_x[a] * (lambda * s_x[a] + s_b[a]);
                 rho = (cur - temp_chi) / scale;
                 __syncthreads();
                 if (rho > 0 && isfinite(temp_chi)) {
@@ -2022,8 +2040,14 @@ __global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P) {
     SvProfScope ps(ctx, s, "k_pose_opt");
     const size_t lds = sizeof(double) * (PO_THREADS / 64) * WRED_DOUBLES;
-    (void)sv_allow_dynamic_lds((const void*)k_pose_opt, lds);  // dynamic LDS above 64 KB must be allowed explicitly
-    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(PO_THREADS), lds, s, P);
+    if (P.intr[0] == 0.0 && P.intr[1] == 0.0) {  // cam_is_equirect
+        (void)sv_allow_dynamic_lds((const void*)k_pose_opt<true>, lds);  // dynamic LDS above 64 KB must be allowed explicitly
+        hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(PO_THREADS), lds, s, P);
+    }
+    else {
+        (void)sv_allow_dynamic_lds((const void*)k_pose_opt<false>, lds);
+        hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(PO_THREADS), lds, s, P);
+    }
 }
 
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {
