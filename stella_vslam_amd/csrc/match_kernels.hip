@@ -1036,15 +1036,14 @@ __device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, cons
     unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
     int best_lvl = -1, second_lvl = -1, best_idx = -1;
     bool done = false;
-    auto take = [&](uint32_t e) {  // the first two available entries in (distance, position) order decide (cand_decide)
+    auto take_loaded = [&](uint32_t e, int own, int lv) {  // the first two available entries in (distance, position) order decide (cand_decide)
         if (done) return;
         if (e == 0xFFFFFFFFu || (e >> 22) >= MAX_HAMMING_DIST) {
             done = true;
             return;
         }
         const int t = (int)(e & 0x3FFFFFu);
-        if (S.owner[t] < q) return;
-        const int lv = S.lvl ? (int)S.lvl[t] : 0;
+        if (own < q) return;
         if (best_idx < 0) {
             best = e >> 22;
             best_idx = t;
@@ -1057,9 +1056,46 @@ __device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, cons
             done = true;
         }
     };
+    auto take = [&](uint32_t e) {
+        if (done || e == 0xFFFFFFFFu) {
+            take_loaded(e, 0, 0);
+            return;
+        }
+        const int t = (int)(e & 0x3FFFFFu);
+        take_loaded(e, S.owner[t], S.lvl ? (int)S.lvl[t] : 0);
+    };
     const int nk = min(n, S.K);
     const SV_LDS uint32_t* h = S.head + (size_t)q * S.K;
-    for (int k = 0; k < nk && !done; ++k) take(h[k]);
+    // The staged head four entries at a time: the four entries, then their four owners and levels, are loaded TOGETHER and decided in
+    // registers -- three LDS round trips per four entries.  Entry by entry the walk was two dependent LDS accesses per entry (the owner's
+    // address comes out of the entry), and a wave walks as long as its slowest lane.  (Measured with stamps in the kernel: the decisions are
+    // 3.8 of a sweep's 6 us at 2 400 queries, NO lane walks past its staged head in the tracked-frame workload -- holding the next four
+    // entries of every list in registers changed nothing --, the rest is the sum of the per-chunk branches of 16 waves on one CU.)
+    for (int k0 = 0; k0 < nk && !done; k0 += 4) {
+        uint32_t e[4];
+        int own[4], lv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = k0 + j < nk ? h[k0 + j] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = e[j] == 0xFFFFFFFFu ? 0 : (int)(e[j] & 0x3FFFFFu);  // (a sentinel's loads are speculative: any valid slot)
+            own[j] = S.owner[t];
+            lv[j] = S.lvl ? (int)S.lvl[t] : 0;
+        }
+        const bool best_only = P.mode == SVGPU_MATCH_BEST_ONLY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // take_loaded without branches (selects): the four decisions of a chunk are straight-line code
+            const unsigned d = e[j] >> 22;
+            const bool stop = e[j] == 0xFFFFFFFFu || d >= MAX_HAMMING_DIST, active = !done;
+            const bool avail = active && !stop && own[j] >= q, first = avail && best_idx < 0, sec = avail && best_idx >= 0;
+            best = first ? d : best;
+            best_lvl = first ? lv[j] : best_lvl;
+            second = sec ? d : second;
+            second_lvl = sec ? lv[j] : second_lvl;
+            best_idx = first ? (int)(e[j] & 0x3FFFFFu) : best_idx;
+            done = done || (active && stop) || sec || (first && best_only);
+        }
+    }
     for (int c = lo + nk; c < lo + n && !done; c += 4) {  // beyond the staged head: four independent loads per trip
         const int hi = lo + n;
         const uint32_t e0 = P.dist[c], e1 = c + 1 < hi ? P.dist[c + 1] : 0xFFFFFFFFu, e2 = c + 2 < hi ? P.dist[c + 2] : 0xFFFFFFFFu,
