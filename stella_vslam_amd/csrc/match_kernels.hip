@@ -1279,6 +1279,74 @@ __global__ __launch_bounds__(256) void k_grid_place(GridProblem G) {
     }
     if (c >= 0) G.cell_items[G.cell_off[c] + rank] = i;
 }
+// The keypoint side of the matcher grid in ONE launch of one workgroup (grids up to GRID_ONE_CELLS cells, i.e. the reference's 64 x 48):
+// cell of every keypoint + its arrival number in the cell (LDS counters), exclusive scan of the counters (-> cell_off), unordered placement,
+// then every cell with more than one keypoint puts its items into increasing order -- the same arrays as the four launches below
+// (memset, k_grid_assign, scan, k_grid_place), whose last one counted, for every keypoint, ALL earlier keypoints of its cell by walking
+// every earlier keypoint: 26 us at 2 400 keypoints.
+#define GRID_ONE_CELLS 8192
+#define GRID_ONE_KPT_ROUNDS 8  // keypoints per thread whose arrival numbers stay in registers (8 192 keypoints)
+__global__ __launch_bounds__(1024) void k_grid_frame_one(GridProblem G) {
+    __shared__ int s_cnt[GRID_ONE_CELLS + 1];
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nc = G.cols * G.rows;
+    for (int c = tid; c <= nc; c += 1024) s_cnt[c] = 0;
+    __syncthreads();
+    int cell[GRID_ONE_KPT_ROUNDS], pos[GRID_ONE_KPT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < GRID_ONE_KPT_ROUNDS; ++r) {
+        const int i = tid + r * 1024;
+        cell[r] = -1, pos[r] = 0;
+        if (i < G.nt) {
+            const int cx = (int)floor((double)(G.t_xy[2 * i] - G.min_x) * G.inv_w), cy = (int)floor((double)(G.t_xy[2 * i + 1] - G.min_y) * G.inv_h);
+            if (0 <= cx && cx < G.cols && 0 <= cy && cy < G.rows) {
+                cell[r] = cx * G.rows + cy;
+                pos[r] = atomicAdd(&s_cnt[cell[r]], 1);  // arrival order inside the cell: arbitrary, put right at the end
+            }
+            G.cell_of[i] = cell[r];
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counters: every thread owns a contiguous run of cells, wave scan of the run sums, then the waves' totals
+    const int per = (nc + 1023) / 1024, c0 = tid * per, c1 = min(c0 + per, nc);
+    int run = 0;
+    for (int c = c0; c < c1; ++c) run += s_cnt[c];
+    int incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {  // counters -> offsets, in place (a thread's own run only)
+        const int k = s_cnt[c];
+        s_cnt[c] = base;
+        base += k;
+    }
+    if (tid == 1023) s_cnt[nc] = base;  // (the last thread's run ends at nc or is empty: its base is the total either way)
+    __syncthreads();
+    for (int c = tid; c <= nc; c += 1024) G.cell_off[c] = s_cnt[c];
+#pragma unroll
+    for (int r = 0; r < GRID_ONE_KPT_ROUNDS; ++r)
+        if (cell[r] >= 0) G.cell_items[s_cnt[cell[r]] + pos[r]] = tid + r * 1024;
+    __syncthreads();  // (workgroup-scope: the placements above are visible to the threads below)
+    for (int c = tid; c < nc; c += 1024) {  // increasing keypoint index inside every cell (= the stable placement)
+        const int lo = s_cnt[c], k = s_cnt[c + 1] - lo;
+        for (int a = 1; a < k; ++a) {  // insertion sort: cells hold a handful of keypoints
+            const int v = G.cell_items[lo + a];
+            int b = a - 1;
+            while (b >= 0 && G.cell_items[lo + b] > v) {
+                G.cell_items[lo + b + 1] = G.cell_items[lo + b];
+                --b;
+            }
+            G.cell_items[lo + b + 1] = v;
+        }
+    }
+}
 // one wave per query: the lanes take the cells of the window (column-major = the reference's scan order), count their
 // keypoints that pass the level and margin tests, and a wave prefix sum gives every cell its place in the query's list
 template <bool FILL>
@@ -1736,6 +1804,10 @@ static void grid_scan(hipStream_t s, int32_t* data, int n) {
 }
 void sv_launch_grid_frame(hipStream_t s, const GridProblem& G) {  // the keypoint side: cell_of, cell_off, cell_items
     const int nc = G.cols * G.rows;
+    if (nc <= GRID_ONE_CELLS && G.nt <= 1024 * GRID_ONE_KPT_ROUNDS && !std::getenv("SVGPU_GRID_FOUR_LAUNCHES")) {
+        hipLaunchKernelGGL(k_grid_frame_one, dim3(1), dim3(1024), 0, s, G);
+        return;
+    }
     (void)hipMemsetAsync(G.cell_off, 0, (size_t)(nc + 1) * sizeof(int32_t), s);
     if (G.nt > 0) hipLaunchKernelGGL(k_grid_assign, dim3((G.nt + 255) / 256), dim3(256), 0, s, G);
     grid_scan(s, G.cell_off, nc);
