@@ -945,7 +945,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     if ((rc = chi2_begin(0))) return rc;
     sv_ba_begin(s, D, 0, 0);  // folds the chi2 of the final estimate into the control block (phase 2: nothing else happens)
     sv_ba_pack_out(s, D, d_state_out);
-    SV_HIP(ctx, hipMemcpyAsync(hs_out, d_out, out_total, hipMemcpyDeviceToHost, s));
+    // (a caller that takes no outlier flags -- global BA: 1.2 MB at config 5 -- gets the block without them)
+    SV_HIP(ctx, hipMemcpyAsync(hs_out, d_out, outlier_out ? out_total : out_outlier, hipMemcpyDeviceToHost, s));
     if ((rc = wait_stream())) return rc;
     memcpy(h_ctl, hs_out + out_ctl, sizeof(BaCtl));
     memcpy(pose_out, hs_out + out_state, sizeof(double) * 12 * (size_t)P);
