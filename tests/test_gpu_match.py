@@ -354,3 +354,35 @@ def test_match_in_cells_capacity_guess_miss_reruns(M):
     big = run(len(k0), 60.0)
     assert big > 20 * small + 4096  # far beyond the remembered capacity (total * 1.25 + 4096)
     run(200, 8.0)
+
+
+def test_matcher_grid_one_launch_equals_four_launches(M, monkeypatch):
+    """The keypoint side of the matcher grid is built by ONE single-workgroup launch (cells on LDS counters, scan, placement, per-cell
+    ordering) for grids up to 8 192 cells and 8 192 keypoints, by memset + assign + scan + stable placement beyond (forced here with
+    SVGPU_GRID_FOUR_LAUNCHES=1): the same cell lists in the same order, so the matcher's output -- which depends on the scan order inside
+    the cells -- is identical, and equal to the oracle's."""
+    from stella_vslam_amd import feature
+    seq = S.frame_sequence(2, seed=0x5EED + 11)
+    k0, d0, _ = O.orb_extract(seq[0])
+    k1, d1, _ = O.orb_extract(seq[1])
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    nq = len(k0)
+    q_xy = np.stack([k0["x"] - 2.0, k0["y"] + 1.0], 1).astype(np.float32)
+    q_margin = np.full(nq, 25.0, np.float32)
+    res = []
+    for four in (False, True):
+        if four: monkeypatch.setenv("SVGPU_GRID_FOUR_LAUNCHES", "1")
+        else: monkeypatch.delenv("SVGPU_GRID_FOUR_LAUNCHES", raising=False)
+        got, num = M.projection(0.8, False, feature.Context()).match_in_cells(d0, q_xy, q_margin, d1, np.stack([k1["x"], k1["y"]], 1).astype(np.float32),
+                                                                            k1["octave"], bounds, 0, 100)
+        res.append((got, num))
+    monkeypatch.delenv("SVGPU_GRID_FOUR_LAUNCHES", raising=False)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    off_g, items = O.assign_keypoints_to_grid(k1["x"], k1["y"], bounds)
+    cand_off, cand_idx = [0], []
+    for q in range(nq):
+        c = O.get_keypoints_in_cell(k1["x"], k1["y"], k1["octave"], off_g, items, bounds, float(q_xy[q, 0]), float(q_xy[q, 1]), 25.0, -1, -1)
+        cand_idx += c.tolist()
+        cand_off.append(len(cand_idx))
+    exp = O.match_candidates(d0, d1, cand_off, cand_idx, check_orientation=False, thr=100, lowe_ratio=0.8, mode=0, t_octave=k1["octave"])
+    assert np.array_equal(res[0][0], exp) and res[0][1] == (exp >= 0).sum()
