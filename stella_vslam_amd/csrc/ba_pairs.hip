@@ -18,48 +18,49 @@ namespace {
 __device__ __forceinline__ bool edge_live(const BaDev& D, int e) { return !D.e_level[e] && D.pose_slot[D.e_pose[e]] >= 0; }
 __device__ __forceinline__ unsigned dense_block(int a, int b, int nP) { return (unsigned)(a * nP - a * (a - 1) / 2 + (b - a)); }  // a <= b
 
+// One thread per ROW of a landmark's pair triangle (= per observation i: its pairs (i, j), j >= i in edge order), counts then slots from a
+// scan over the observations.  (Round 2 / 3 ran both kernels with one thread per LANDMARK: a chain of k (k + 1) / 2 ~ 21 dependent
+// iterations per thread, 124 us for the emission at config 5 whatever its loads and stores were made of -- staged stores and a precomputed
+// slot word per edge were both measured and changed nothing.)  The output order is unchanged: rows in edge order, a row's pairs in j order.
 __global__ void k_pair_count(BaDev D, int* __restrict__ cnt) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= D.L) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.E) return;
     int n = 0;
-    if (D.pt_free[l]) {
-        const int lo = D.lm_off[l], hi = D.lm_off[l + 1];
-        for (int i = lo; i < hi; ++i) {
-            if (!edge_live(D, i)) continue;
-            const int a = D.pose_slot[D.e_pose[i]];
-            for (int j = i; j < hi; ++j) {
-                if (!edge_live(D, j)) continue;
-                n += (j != i && D.pose_slot[D.e_pose[j]] == a) ? 2 : 1;
-            }
+    const int l = D.e_point[i];
+    if (D.pt_free[l] && edge_live(D, i)) {
+        const int hi = D.lm_off[l + 1], a = D.pose_slot[D.e_pose[i]];
+        n = 1;  // (i, i)
+        for (int j = i + 1; j < hi; ++j) {
+            if (!edge_live(D, j)) continue;
+            n += D.pose_slot[D.e_pose[j]] == a ? 2 : 1;
         }
     }
-    cnt[l] = n;
+    cnt[i] = n;
 }
 
 __global__ void k_pair_emit(BaDev D, const int* __restrict__ off, unsigned* __restrict__ keys, unsigned long long* __restrict__ vals) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= D.L || !D.pt_free[l]) return;
-    int o = off[l];
-    const int lo = D.lm_off[l], hi = D.lm_off[l + 1];
-    for (int i = lo; i < hi; ++i) {
-        if (!edge_live(D, i)) continue;
-        for (int j = i; j < hi; ++j) {
-            if (!edge_live(D, j)) continue;
-            int e1 = i, e2 = j, a = D.pose_slot[D.e_pose[i]], b = D.pose_slot[D.e_pose[j]];
-            if (a > b) {
-                const int t = a;
-                a = b;
-                b = t;
-                e1 = j;
-                e2 = i;
-            }
-            const unsigned key = dense_block(a, b, D.nP);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.E) return;
+    const int l = D.e_point[i];
+    if (!D.pt_free[l] || !edge_live(D, i)) return;
+    int o = off[i];
+    const int hi = D.lm_off[l + 1], ai = D.pose_slot[D.e_pose[i]];
+    for (int j = i; j < hi; ++j) {
+        if (j != i && !edge_live(D, j)) continue;
+        int e1 = i, e2 = j, a = ai, b = j == i ? ai : D.pose_slot[D.e_pose[j]];
+        if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+            e1 = j;
+            e2 = i;
+        }
+        const unsigned key = dense_block(a, b, D.nP);
+        keys[o] = key;
+        vals[o++] = (unsigned long long)(unsigned)e1 | ((unsigned long long)(unsigned)e2 << 32);
+        if (a == b && e1 != e2) {  // two observations from one pose: both cross terms
             keys[o] = key;
-            vals[o++] = (unsigned long long)(unsigned)e1 | ((unsigned long long)(unsigned)e2 << 32);
-            if (a == b && e1 != e2) {  // two observations from one pose: both cross terms
-                keys[o] = key;
-                vals[o++] = (unsigned long long)(unsigned)e2 | ((unsigned long long)(unsigned)e1 << 32);
-            }
+            vals[o++] = (unsigned long long)(unsigned)e2 | ((unsigned long long)(unsigned)e1 << 32);
         }
     }
 }
@@ -143,8 +144,8 @@ __global__ void k_pose_major(const int* __restrict__ pe_idx, const int* __restri
 inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 }  // namespace
 
-size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap) {
-    return 2 * pad256((size_t)(L + 2) * 4) + pad256(sv_scan_scratch_ints((size_t)L + 1) * 4) + pad256(sv_sort_hist_ints(pair_cap) * 4) + 2 * pad256(pair_cap * 4) + pad256(pair_cap * 8) + pad256((nb_cap + 1) * 4) + 1024;
+size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int E, size_t nb_cap) {  // E: observations (the counts / slots are per observation)
+    return 2 * pad256((size_t)(E + 2) * 4) + pad256(sv_scan_scratch_ints((size_t)E + 1) * 4) + pad256(sv_sort_hist_ints(pair_cap) * 4) + 2 * pad256(pair_cap * 4) + pad256(pair_cap * 8) + pad256((nb_cap + 1) * 4) + 1024;
 }
 
 namespace {
@@ -158,19 +159,23 @@ int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, si
         p += pad256(bytes);
         return (void*)r;
     };
-    int* cnt = (int*)take((size_t)(L + 2) * 4);
-    int* cnt_scan = (int*)take(sv_scan_scratch_ints((size_t)L + 1) * 4);
+    const int E = D.E;
+    int* cnt = (int*)take((size_t)(E + 2) * 4);
+    int* cnt_scan = (int*)take(sv_scan_scratch_ints((size_t)E + 1) * 4);
     int* hist = (int*)take(sv_sort_hist_ints(pair_cap) * 4);
     unsigned* keys[2] = {(unsigned*)take(pair_cap * 4), (unsigned*)take(pair_cap * 4)};
     unsigned long long* vals[2] = {(unsigned long long*)take(pair_cap * 8), reinterpret_cast<unsigned long long*>(pairs_out)};
     if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list scratch too small");
     SV_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_pair_count, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt);
-    sv_scan_i32(s, cnt, L, cnt_scan);  // cnt[l] = first pair of landmark l, cnt[L] = the total
+    if (E > 0) {
+        hipLaunchKernelGGL(k_pair_count, dim3((E + 255) / 256), dim3(256), 0, s, D, cnt);
+        sv_scan_i32(s, cnt, E, cnt_scan);  // cnt[i] = first pair of row (observation) i, cnt[E] = the total
+    }
+    else SV_HIP(ctx, hipMemsetAsync(cnt, 0, 8, s));  // (a rank of a sharded solve without observations)
     SV_HIP(ctx, hipGetLastError());
     int total = total_host;
     if (read_total) {
-        SV_HIP(ctx, hipMemcpyAsync(&total, cnt + L, 4, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipMemcpyAsync(&total, cnt + E, 4, hipMemcpyDeviceToHost, s));
         SV_HIP(ctx, hipStreamSynchronize(s));
         if ((size_t)total > pair_cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pair-list capacity exceeded");
         if (total_out) *total_out = total;
@@ -180,10 +185,10 @@ int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, si
     int cur = sv_sort_passes(bits) & 1 ? 0 : 1;  // so that the last pass lands in buffer 1 = pairs_out
     // total < 0 (and nothing read back): the pair total stays ON the device -- cnt[L], the scan's total -- and the launches are sized for the
     // capacity; the host pass that used to count the pairs of a local-BA sized problem left the device idle for ~0.1 ms
-    const int* const n_dev = total < 0 ? cnt + L : nullptr;
+    const int* const n_dev = total < 0 ? cnt + E : nullptr;
     const int n_launch = total < 0 ? (int)std::min<size_t>(pair_cap, 0x7fffffff) : total;
     if (n_launch > 0) {
-        hipLaunchKernelGGL(k_pair_emit, dim3((L + 255) / 256), dim3(256), 0, s, D, cnt, keys[cur], vals[cur]);
+        if (E > 0) hipLaunchKernelGGL(k_pair_emit, dim3((E + 255) / 256), dim3(256), 0, s, D, cnt, keys[cur], vals[cur]);
         cur = sv_sort_pairs(s, keys, vals, cur, n_launch, bits, hist, n_dev);
         hipLaunchKernelGGL(k_pair_landmark, dim3((n_launch + 255) / 256), dim3(256), 0, s, vals[cur], n_dev, n_launch, D.e_point, pair_l_out);
     }

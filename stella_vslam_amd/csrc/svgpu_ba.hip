@@ -17,7 +17,7 @@
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D);
-size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int L, size_t nb_cap);
+size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int E, size_t nb_cap);
 int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int2* pairs_out,
                       int* pair_l_out, std::vector<int>& dense_off_host);
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
@@ -370,7 +370,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
-    const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, L, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
+    const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap) + pad(64 * (size_t)nb_lm);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
