@@ -1279,18 +1279,22 @@ __global__ __launch_bounds__(256) void k_grid_place(GridProblem G) {
     }
     if (c >= 0) G.cell_items[G.cell_off[c] + rank] = i;
 }
-// The keypoint side of the matcher grid in ONE launch of one workgroup (grids up to GRID_ONE_CELLS cells, i.e. the reference's 64 x 48):
+// The keypoint side of the matcher grid in ONE launch of one workgroup (grids up to GRID_ONE_CELLS cells; the reference's is 64 x 48):
 // cell of every keypoint + its arrival number in the cell (LDS counters), exclusive scan of the counters (-> cell_off), unordered placement,
 // then every cell with more than one keypoint puts its items into increasing order -- the same arrays as the four launches below
 // (memset, k_grid_assign, scan, k_grid_place), whose last one counted, for every keypoint, ALL earlier keypoints of its cell by walking
 // every earlier keypoint: 26 us at 2 400 keypoints.
-#define GRID_ONE_CELLS 8192
+#define GRID_ONE_CELLS 4096
 #define GRID_ONE_KPT_ROUNDS 8  // keypoints per thread whose arrival numbers stay in registers (8 192 keypoints)
+#define GRID_ONE_SMALL 24      // a cell of at most this many keypoints is ordered by one thread (insertion sort); a larger one by the workgroup
 __global__ __launch_bounds__(1024) void k_grid_frame_one(GridProblem G) {
     __shared__ int s_cnt[GRID_ONE_CELLS + 1];
     __shared__ int s_wsum[16];
+    __shared__ int s_items[1024 * GRID_ONE_KPT_ROUNDS];  // the items of one crowded cell
+    __shared__ int s_big[1024 * GRID_ONE_KPT_ROUNDS / GRID_ONE_SMALL + 1], s_nbig;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nc = G.cols * G.rows;
     for (int c = tid; c <= nc; c += 1024) s_cnt[c] = 0;
+    if (tid == 0) s_nbig = 0;
     __syncthreads();
     int cell[GRID_ONE_KPT_ROUNDS], pos[GRID_ONE_KPT_ROUNDS];
 #pragma unroll
@@ -1336,6 +1340,10 @@ __global__ __launch_bounds__(1024) void k_grid_frame_one(GridProblem G) {
     __syncthreads();  // (workgroup-scope: the placements above are visible to the threads below)
     for (int c = tid; c < nc; c += 1024) {  // increasing keypoint index inside every cell (= the stable placement)
         const int lo = s_cnt[c], k = s_cnt[c + 1] - lo;
+        if (k > GRID_ONE_SMALL) {  // crowded: left to the whole workgroup below (at most nt / GRID_ONE_SMALL such cells)
+            s_big[atomicAdd(&s_nbig, 1)] = c;
+            continue;
+        }
         for (int a = 1; a < k; ++a) {  // insertion sort: cells hold a handful of keypoints
             const int v = G.cell_items[lo + a];
             int b = a - 1;
@@ -1345,6 +1353,23 @@ __global__ __launch_bounds__(1024) void k_grid_frame_one(GridProblem G) {
             }
             G.cell_items[lo + b + 1] = v;
         }
+    }
+    __syncthreads();
+    // crowded cells (a dense patch under a coarse grid; in the limit every keypoint in one cell): rank sort by the workgroup -- the cell's
+    // items staged in LDS, every thread counts the items below its own: k^2 / 1 024 LDS reads per thread, 16 k at the 8 192-keypoint limit
+    // (one thread's insertion sort would be k^2 / 4 global round trips)
+    const int nbig = s_nbig;
+    for (int bi = 0; bi < nbig; ++bi) {
+        const int c = s_big[bi], lo = s_cnt[c], k = s_cnt[c + 1] - lo;
+        for (int a = tid; a < k; a += 1024) s_items[a] = G.cell_items[lo + a];
+        __syncthreads();
+        for (int a = tid; a < k; a += 1024) {
+            const int v = s_items[a];
+            int rank = 0;
+            for (int j = 0; j < k; ++j) rank += s_items[j] < v;  // (indices are distinct)
+            G.cell_items[lo + rank] = v;
+        }
+        __syncthreads();
     }
 }
 // one wave per query: the lanes take the cells of the window (column-major = the reference's scan order), count their

@@ -83,6 +83,46 @@ def test_image_bounds_undistort_bearings_grid(mods):
     assert len(e.undist_keypts_) == 0 and e.cell_off_[-1] == 0
 
 
+def test_matcher_grid_crowded_cells_outside_keypoints_and_large_frames(mods):
+    """The one-launch grid build (k_grid_frame_one) orders a cell's keypoints by one thread while the cell is small and by a rank sort of the
+    whole workgroup when it is crowded (a dense patch under a coarse grid; here up to every keypoint in ONE cell), drops keypoints outside the
+    image bounds, and hands frames beyond 8 192 keypoints to the four-launch form: the cell lists equal the oracle's
+    assign_keypoints_to_grid (data/common.cc) in every case, on the equirectangular model (undistortion = identity)."""
+    cam_mod, data, feature, _ = mods
+    ctx = feature.Context(0)
+    cam = cam_mod.equirectangular("theta", "RGB", 1920, 960, 30.0, ctx=ctx)
+    bounds = cam.img_bounds_.as_tuple()
+    rng = np.random.default_rng(77)
+
+    def check(x, y):
+        k = np.zeros(len(x), O.KEYPOINT_DTYPE)
+        k["x"], k["y"], k["size"], k["class_id"] = np.asarray(x, np.float32), np.asarray(y, np.float32), 31.0, -1
+        obs = data.frame_observation(cam, k, np.zeros((len(k), 32), np.uint8))
+        off, items = O.assign_keypoints_to_grid(k["x"], k["y"], bounds, 64, 48)
+        assert np.array_equal(obs.cell_off_, off) and np.array_equal(obs.cell_items_, items)
+        return off
+
+    # 2 500 keypoints in one 4 x 4 px patch (one cell, far beyond the one-thread limit) among 500 scattered ones, in shuffled order
+    x = np.concatenate([rng.uniform(100, 104, 2500), rng.uniform(0, 1920, 500)])
+    y = np.concatenate([rng.uniform(50, 54, 2500), rng.uniform(0, 960, 500)])
+    perm = rng.permutation(len(x))
+    off = check(x[perm], y[perm])
+    assert np.diff(off).max() >= 2500
+    # several crowded cells of different sizes next to each other + keypoints outside the bounds (negative, beyond the far edges)
+    xs, ys = [], []
+    for cx, cy, n in ((15, 10, 30), (45, 10, 25), (75, 10, 24), (105, 10, 400), (15, 30, 1000)):
+        xs.append(rng.uniform(cx - 5, cx + 5, n)), ys.append(rng.uniform(cy - 5, cy + 5, n))
+    xs.append(rng.uniform(-50, -1, 200)), ys.append(rng.uniform(0, 960, 200))
+    xs.append(rng.uniform(1921, 2100, 200)), ys.append(rng.uniform(961, 1200, 200))
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    perm = rng.permutation(len(x))
+    off = check(x[perm], y[perm])
+    assert off[-1] == len(x) - 400
+    # every keypoint in ONE cell at the one-launch limit, and a frame beyond it (four launches)
+    check(rng.uniform(600, 610, 8192), rng.uniform(300, 310, 8192))
+    check(rng.uniform(0, 1920, 9000), rng.uniform(0, 960, 9000))
+
+
 def test_wide_fisheye_bounds_and_reference_cell_vectors(mods):
     cam_mod, data, feature, _ = mods
     ctx = feature.Context(0)

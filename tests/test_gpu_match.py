@@ -358,7 +358,7 @@ def test_match_in_cells_capacity_guess_miss_reruns(M):
 
 def test_matcher_grid_one_launch_equals_four_launches(M, monkeypatch):
     """The keypoint side of the matcher grid is built by ONE single-workgroup launch (cells on LDS counters, scan, placement, per-cell
-    ordering) for grids up to 8 192 cells and 8 192 keypoints, by memset + assign + scan + stable placement beyond (forced here with
+    ordering) for grids up to 4 096 cells and 8 192 keypoints, by memset + assign + scan + stable placement beyond (forced here with
     SVGPU_GRID_FOUR_LAUNCHES=1): the same cell lists in the same order, so the matcher's output -- which depends on the scan order inside
     the cells -- is identical, and equal to the oracle's."""
     from stella_vslam_amd import feature
