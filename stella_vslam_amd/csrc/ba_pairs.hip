@@ -152,7 +152,7 @@ namespace {
 // count -> scan -> emit -> radix passes -> dense offsets; total_host < 0: the pair total stays on the device (no read-back)
 int build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total_host, int2* pairs_out,
                 int* pair_l_out, int* dense_off_dev, bool read_total, int* total_out) {
-    const int L = D.L, nb_dense = D.nP * (D.nP + 1) / 2;
+    const int nb_dense = D.nP * (D.nP + 1) / 2;
     char* p = (char*)scratch;
     auto take = [&](size_t bytes) {
         char* r = p;
