@@ -580,7 +580,9 @@ int svgpu_selftest_scan_sort(svgpu_ctx* ctx, int n, const int32_t* values, int32
  *   stop        nullable; the caller's force_stop_flag (mapping_module.h:232).  Polled at every damping-trial boundary
  *               (mirrored into page-locked memory while the host waits) and -- reference quirk, terminate_action.cc:36-76 --
  *               SET when the gain rule stops stage 1, so that stage 2 is skipped exactly as in the reference.
- *   pose_out    num_poses x 12, points_out num_points x 3, outlier_out num_obs (1 = outlier observation) */
+ *   pose_out    num_poses x 12, points_out num_points x 3, outlier_out num_obs (1 = outlier observation)
+ * Limits: num_obs < 2^32 / 144 (29.8 M) and num_points < 2^32 / 48 per call -- per RANK of the sharded variants --: the record gathers of the
+ * reduced-system kernel address their arrays with 32-bit byte offsets; beyond, SVGPU_ERR_INVALID (shard the landmarks over more ranks). */
 int svgpu_local_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile uint8_t* stop, double* pose_out,
                    double* points_out, uint8_t* outlier_out, svgpu_ba_stats* stats);
 
