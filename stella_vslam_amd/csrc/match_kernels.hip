@@ -1407,12 +1407,14 @@ __global__ __launch_bounds__(256) void k_grid_walk(GridProblem G) {
                         if (fabsf(dx) < margin && fabsf(dy) < margin) ++n;
                     }
                 }
-                int incl = n;  // inclusive prefix sum over the lanes
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int v = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += v;
-                }
+                // inclusive prefix sum over the lanes: DPP row scans (VALU; six __shfl_up were six LDS-crossbar round trips on every query's chain)
+                int incl = n;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8: scans inside the four rows of 16
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
                 if (FILL && n > 0) {
                     int o = total + incl - n;
                     for (int it = G.cell_off[c]; it < G.cell_off[c + 1]; ++it) {
@@ -1424,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_grid_walk(GridProblem G) {
                         if (fabsf(dx) < margin && fabsf(dy) < margin) out[o++] = idx;
                     }
                 }
-                total += __shfl(incl, 63, 64);
+                total += __builtin_amdgcn_readlane(incl, 63);
             }
         }
     }
