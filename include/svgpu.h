@@ -316,6 +316,102 @@ int svgpu_frame_set_stereo(svgpu_ctx* ctx, svgpu_frame* frame, const float* x_ri
 int svgpu_frame_bind(svgpu_ctx* ctx, const svgpu_frame* frame);
 int svgpu_match_set_query_blocks(svgpu_ctx* ctx, const uint8_t* q_blocks);
 
+/* ------------------------------------------------------------------------------ device-resident local map + tracked-frame chain
+ * What tracking_module does per image between extract() and the keyframe decision (tracking_module.cc:253-275, 333-355, 533-608;
+ * module/frame_tracker.cc:22-60) reads, of every landmark, five things: pos_w_, mean_normal_, the valid-distance range, the
+ * representative descriptor and whether it has observations.  svgpu_map keeps exactly those ON THE DEVICE, indexed by
+ * data::landmark::id_ (ids are dense: one atomic counter hands them out, data/landmark.cc:13), and is kept current by the few
+ * mutators of data::landmark; a tracked frame then hands over landmark IDS -- of the last frame's
+ * keypoints, of the local map -- instead of flattening thousands of records out of the shared_ptr graph, and the two halves of the
+ * per-frame chain are ONE submission each with ONE synchronisation at the end:
+ *   svgpu_track_motion     [extract -> undistort / bearings / grid ->] projection::match_current_and_last_frames -> pose_optimizer
+ *   svgpu_track_local_map  frame::can_observe over the local landmarks -> projection::match_frame_and_landmarks -> pose_optimizer
+ * (between the two the host runs update_local_map on the landmarks the first half matched: object-graph work, stays the reference's).
+ * Results are identical to the separate entry points (svgpu_match_current_and_last_frames, svgpu_pose_optimize,
+ * svgpu_reproject_landmarks, svgpu_match_in_cells) fed from host-flattened arrays: tests/test_gpu_track.py. */
+typedef struct svgpu_map svgpu_map;
+enum {
+    SVGPU_LM_PRESENT = 1,          /* the landmark exists and !will_be_erased() */
+    SVGPU_LM_HAS_OBSERVATION = 2,  /* landmark::has_observation() */
+    SVGPU_LM_HAS_DESCRIPTOR = 4    /* !get_descriptor().empty() */
+};
+typedef struct svgpu_landmark_record { /* 96 bytes */
+    double pos_w[3];                   /* landmark::pos_w_ */
+    double mean_normal[3];             /* landmark::mean_normal_ */
+    float min_valid_dist, max_valid_dist;
+    uint8_t descriptor[32];
+    uint32_t flags;                    /* SVGPU_LM_* */
+    uint32_t reserved;
+} svgpu_landmark_record;
+int svgpu_map_create(svgpu_ctx* ctx, svgpu_map** out);
+void svgpu_map_destroy(svgpu_map* map);
+int svgpu_map_capacity(const svgpu_map* map); /* ids below this are addressable (grows with the largest id upserted) */
+/* whole-record upsert of n landmarks (ids[i] -> records[i]; a later entry of the same id wins); synchronous */
+int svgpu_map_upsert(svgpu_ctx* ctx, svgpu_map* map, int n, const uint32_t* ids, const svgpu_landmark_record* records);
+/* landmark::prepare_for_erasing: flags -> 0 (ids beyond the capacity are ignored) */
+int svgpu_map_erase(svgpu_ctx* ctx, svgpu_map* map, int n, const uint32_t* ids);
+/* test hook: the records as the device holds them (flags 0 for ids it has never seen) */
+int svgpu_map_download(svgpu_ctx* ctx, const svgpu_map* map, int n, const uint32_t* ids, svgpu_landmark_record* records);
+
+typedef struct svgpu_tracker svgpu_tracker;
+typedef struct svgpu_track_config {
+    int num_levels;
+    float scale_factors[16];         /* orb_params::scale_factors_ */
+    float inv_level_sigma_sq[16];    /* orb_params::inv_level_sigma_sq_ */
+    float log_scale_factor;          /* orb_params::log_scale_factor_ */
+    int grid_cols, grid_rows;        /* frame_observation::num_grid_cols_ / rows_ */
+    int is_monocular;                /* camera::setup_type_t::Monocular */
+    float true_baseline;             /* camera::base::true_baseline_ */
+    /* pose_optimizer_factory.h:18-26 (2 / 2 / 10) and the stop-flag reading of svgpu_pose_optimize */
+    int po_num_trials_robust, po_num_trials, po_num_each_iter, po_reset_stop_flag_each_round;
+} svgpu_track_config;
+typedef struct svgpu_track_result {
+    int n_keypoints;     /* of the current frame */
+    int num_matches;     /* the matcher's return value */
+    int num_valid;       /* pose optimizer: observations that are inliers at the end (0: fewer than 5 observations, pose unchanged) */
+    int lm_iterations;
+    int num_observations;/* edges the pose optimizer was given */
+    int num_candidates;  /* entries of the candidate lists (diagnostics) */
+    double pose_cw[12];  /* optimised [R|t], row-major 3x4 */
+} svgpu_track_result;
+/* One tracker per tracking thread: owns the chain's device and page-locked buffers.  `ctx` is the context its launches go to; for the
+ * fused extraction of svgpu_track_motion it must be configured (svgpu_orb_configure). */
+int svgpu_tracker_create(svgpu_ctx* ctx, svgpu_map* map, const svgpu_camera* cam, const svgpu_track_config* cfg, svgpu_tracker** out);
+void svgpu_tracker_destroy(svgpu_tracker* tracker);
+/* frame_tracker::motion_based_track (module/frame_tracker.cc:22-60) up to discard_outliers, as one submission.
+ *   img != NULL   system::create_monocular_frame's device work comes first: ORB extraction of `img` (row stride `stride`), undistortion,
+ *                 bearings and grid -> `cur` becomes the resident observation; kps / desc / undist_kps / bearings (each cap entries)
+ *                 receive the host copies data::frame_observation holds.  img == NULL: `cur` already holds the observation
+ *                 (svgpu_frame_adopt_extraction / svgpu_frame_upload) and those four outputs are ignored.
+ *   last, last_lm_ids   the last frame's resident observation and, per keypoint of it, the landmark id it holds (-1: none)
+ *   pose_guess_cw / pose_last_cw   3x4 [R|t] row-major: velocity * last pose, and the last frame's pose (assume_forward / backward)
+ *   match_last    svgpu_frame_size(last) entries: keypoint of `cur` the landmark of last keypoint i was matched to, or -1; the caller
+ *                 replays curr_frm.add_landmark(lm, match_last[i]) in increasing i (projection.cc:202)
+ *   outlier       per keypoint of `cur` (cap entries): the pose optimizer's outlier flag
+ * The caller compares result->num_matches with its threshold and, below it, calls again with img = NULL and twice the margin
+ * (frame_tracker.cc:36-40): the optimisation that was enqueued behind the first matcher is then simply discarded. */
+int svgpu_track_motion(svgpu_tracker* tracker, svgpu_frame* cur, const uint8_t* img, int stride, const svgpu_frame* last,
+                       const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw, float margin,
+                       int check_orientation, svgpu_keypoint* kps, uint8_t* desc, svgpu_keypoint* undist_kps, double* bearings, int cap,
+                       int32_t* match_last, uint8_t* outlier, svgpu_track_result* result);
+/* tracking_module::search_local_landmarks + optimize_current_frame_with_local_map's optimisation (tracking_module.cc:533-608, 441-446)
+ * as one submission.
+ *   cur_lm_ids    per keypoint of `cur`: the landmark id the frame holds now (-1: none) -- after discard_outliers and update_local_map's
+ *                 clean-up, i.e. curr_frm.get_landmarks() as ids
+ *   local_ids     n_local entries: landmark ids of local_landmarks_ in order; -1 = not offered to can_observe (already in the frame,
+ *                 will_be_erased, temporal-ratio rule :565-580)
+ *   pose_cw       nullable: NULL = the pose the tracker's last optimisation left on the device
+ *   match_local   n_local: keypoint the landmark was matched to or -1 (replay frm.add_landmark in increasing order, projection.cc:88)
+ *   visible       nullable, n_local: can_observe's verdict (increase_num_observable, tracking_module.cc:588)
+ *   outlier       per keypoint of `cur` */
+int svgpu_track_local_map(svgpu_tracker* tracker, const svgpu_frame* cur, const int32_t* cur_lm_ids, int n_local, const int32_t* local_ids,
+                          const double* pose_cw, float margin, float lowe_ratio, float ray_cos_thr, int32_t* match_local, uint8_t* visible,
+                          uint8_t* outlier, svgpu_track_result* result);
+/* lm_to_reproj / lm_to_x_right / lm_to_scale of the last svgpu_track_local_map, fetched only when somebody wants them (each nullable) */
+int svgpu_track_local_map_observability(svgpu_tracker* tracker, int n_local, double* reproj, float* x_right, int32_t* pred_scale_level);
+/* diagnostics: kernel launches + runtime copies the tracker enqueued, and stream synchronisations it waited on, since creation */
+int svgpu_tracker_counters(const svgpu_tracker* tracker, long long* launches, long long* host_syncs);
+
 /* ------------------------------------------------------------------------------ function-specific matchers
  * One entry point per reference method: candidate generation (reprojection + grid cells, or BoW buckets), the method's own pair
  * gates and the exact sequential bookkeeping all run on the device; the adaptor classes of stella_vslam_amd/host/ flatten the

@@ -118,6 +118,36 @@ struct PoseOptDev {
     int* result;              // [0] num_valid, [1] LM iterations run, [2] num_bad
     uint8_t* level;           // n (scratch)
     uint8_t* robust;          // n (scratch)
+    // ---- tracked-frame chain (k_pose_opt<EQ, true>): the kernel gathers its own observations from the frame's keypoints, the matcher's
+    //      result and the resident landmark table, and leaves its results where the host reads them without a copy (svgpu_track.hip)
+    const double* pose_in_dev;     // nullable: the starting pose in device memory (the previous optimisation's result)
+    const int32_t* trk_overflow;   // the candidate-list allocation counter: beyond trk_overflow_cap the matcher did not run -> do nothing
+    int trk_overflow_cap;
+    const int32_t* trk_match_q;    // trk_nq: keypoint a query was matched to or -1 (k_cand_replay*)
+    const int32_t* trk_qid;        // trk_nq: landmark id of a query
+    int trk_nq;
+    int32_t* trk_cur_lm;           // per keypoint: landmark id held (-1 none); the matches are applied to it in increasing query order
+    int trk_reset_cur;             // 1: the frame holds no landmark before the matches (curr_frm.erase_landmarks(), frame_tracker.cc:29)
+    int32_t* trk_who;              // per keypoint scratch (last query that took it)
+    const int32_t* trk_nt_dev;     // nullable: keypoint count in device memory
+    int trk_nt;                    // keypoint count (capacity when trk_nt_dev)
+    const void* trk_map;           // svgpu_landmark_record table
+    int trk_map_cap;
+    const float* trk_xy;           // undistorted keypoints
+    const int32_t* trk_octave;
+    const float* trk_xright;       // nullable
+    float trk_inv_sigma_sq[16];
+    float trk_huber;               // sqrt(5.99146) monocular, sqrt(7.81473) otherwise (pose_optimizer_g2o.cc:98-100)
+    double* trk_pos;               // compacted observations (capacity trk_nt): written here, then read through pos_w / uvr / inv_sigma_sq / huber
+    float* trk_uvr;
+    float* trk_w;
+    float* trk_h;
+    int32_t* trk_kp_of;            // observation -> keypoint
+    uint8_t* trk_outlier_kp;       // per keypoint (device)
+    uint8_t* host_outlier_kp;      // per keypoint (page-locked)
+    double* host_pose;             // 12 (page-locked)
+    int* host_result;              // [0] num_valid [1] LM iterations [2] num_bad [3] observations (page-locked)
+    int32_t* trk_counter_reset;    // nullable: a device word zeroed at the end (the next matcher's list allocation counter)
 };
 struct svgpu_ctx;
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P);

@@ -655,15 +655,95 @@ __device__ __forceinline__ bool po_chol6(HP H, double lambda, HP b, double* x) {
     return true;
 }
 
-template <bool EQ>  // false: the camera is not equirectangular (decided on the host from the intrinsics): no atan2 / asin path, fewer registers
+// TRK: the tracked-frame chain's form (PoseOptDev::trk_*): the workgroup first applies the matcher's result to the frame's landmark ids and
+// compacts the observations (keypoint order = the order pose_optimizer_g2o.cc:88-107 adds its edges in) out of the resident landmark table.
+template <bool EQ, bool TRK = false>  // EQ false: the camera is not equirectangular (decided on the host from the intrinsics): no atan2 / asin path, fewer registers
 __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     extern __shared__ __attribute__((aligned(16))) double s_wred[];  // PO_THREADS / 64 transposition buffers of WRED_DOUBLES (dynamic: 81 KB)
     __shared__ double s_part[PO_THREADS / 64][32];
     __shared__ double s_red[32];
     __shared__ double s_T[12], s_Tt[12], s_x[6], s_H[36], s_b[6];
     __shared__ int s_ctl[4];  // [0] accept, [1] continue trials, [2] ok2
-    const int tid = threadIdx.x, n = P.n;
-    if (tid < 12) s_T[tid] = P.pose_in[tid];
+    const int tid = threadIdx.x;
+    int n = P.n;
+    int trk_nt = 0;
+    if constexpr (TRK) {
+        __shared__ int s_wcount[PO_THREADS / 64], s_nobs;
+        if (*P.trk_overflow > P.trk_overflow_cap) return;  // the lists did not fit: the host re-runs the chain with a larger capacity
+        const int nt = P.trk_nt_dev ? min(*P.trk_nt_dev, P.trk_nt) : P.trk_nt;
+        trk_nt = nt;
+        const svgpu_landmark_record* map = (const svgpu_landmark_record*)P.trk_map;
+        // 1. matches onto the frame: add_landmark in increasing query order, a later query overwrites (projection.cc:88, :202)
+        for (int k = tid; k < nt; k += PO_THREADS) {
+            P.trk_who[k] = -1;
+            if (P.trk_reset_cur) P.trk_cur_lm[k] = -1;
+        }
+        __syncthreads();
+        for (int q = tid; q < P.trk_nq; q += PO_THREADS) {
+            const int m = P.trk_match_q[q];
+            if (m >= 0 && m < nt) atomicMax(&P.trk_who[m], q);
+        }
+        __syncthreads();
+        // 2. compaction in keypoint order: every thread owns a contiguous run of keypoints
+        const int per = (nt + PO_THREADS - 1) / PO_THREADS, k0 = tid * per, k1 = min(k0 + per, nt);
+        int mine = 0;
+        for (int k = k0; k < k1; ++k) {
+            const int w = P.trk_who[k];
+            int id = P.trk_cur_lm[k];
+            if (w >= 0) {
+                id = P.trk_qid[w];
+                P.trk_cur_lm[k] = id;
+            }
+            const bool ok = id >= 0 && id < P.trk_map_cap && (map[id].flags & SVGPU_LM_PRESENT);  // !lm || lm->will_be_erased(): no edge (:81-87)
+            mine += ok;
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_wcount[wave] = incl;
+        __syncthreads();
+        int base = incl - mine;
+        for (int w = 0; w < wave; ++w) base += s_wcount[w];
+        if (tid == PO_THREADS - 1) s_nobs = base + mine;
+        for (int k = k0; k < k1; ++k) {
+            const int id = P.trk_cur_lm[k];
+            if (!(id >= 0 && id < P.trk_map_cap && (map[id].flags & SVGPU_LM_PRESENT))) continue;
+            const int j = base++;
+            P.trk_pos[3 * (size_t)j] = map[id].pos_w[0];
+            P.trk_pos[3 * (size_t)j + 1] = map[id].pos_w[1];
+            P.trk_pos[3 * (size_t)j + 2] = map[id].pos_w[2];
+            P.trk_uvr[3 * (size_t)j] = P.trk_xy[2 * k];
+            P.trk_uvr[3 * (size_t)j + 1] = P.trk_xy[2 * k + 1];
+            P.trk_uvr[3 * (size_t)j + 2] = P.trk_xright ? P.trk_xright[k] : -1.0f;
+            P.trk_w[j] = P.trk_inv_sigma_sq[P.trk_octave[k] & 15];
+            P.trk_h[j] = P.trk_huber;
+            P.trk_kp_of[j] = k;
+        }
+        __syncthreads();
+        n = s_nobs;
+        for (int k = tid; k < nt; k += PO_THREADS) {
+            P.trk_outlier_kp[k] = 0;
+            P.host_outlier_kp[k] = 0;
+        }
+        if (n < 5) {  // pose_optimizer_g2o.cc:109-111: nothing to optimise, the pose is returned as it came
+            if (tid < 12) {
+                const double v = P.pose_in_dev ? P.pose_in_dev[tid] : P.pose_in[tid];
+                P.pose_out[tid] = v;
+                P.host_pose[tid] = v;
+            }
+            if (tid == 0) {
+                P.host_result[0] = 0, P.host_result[1] = 0, P.host_result[2] = 0, P.host_result[3] = n;
+                P.result[0] = 0, P.result[1] = 0, P.result[2] = 0;
+                if (P.trk_counter_reset) *P.trk_counter_reset = 0;
+            }
+            return;
+        }
+    }
+    if (tid < 12) s_T[tid] = (TRK && P.pose_in_dev) ? P.pose_in_dev[tid] : P.pose_in[tid];
     for (int i = tid; i < n; i += PO_THREADS) {
         P.level[i] = 0;
         P.robust[i] = (P.num_trials_robust != 0) && P.huber[i] > 0.f;
@@ -825,6 +905,20 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
         P.result[0] = n - num_bad;
         P.result[1] = total_iters;
         P.result[2] = num_bad;
+    }
+    if constexpr (TRK) {  // results where the host reads them after the chain's one synchronisation: outlier flags per KEYPOINT, pose, counts
+        (void)trk_nt;
+        for (int i = tid; i < n; i += PO_THREADS) {
+            const int k = P.trk_kp_of[i];
+            const uint8_t o = P.outlier[i];
+            P.trk_outlier_kp[k] = o;
+            if (o) P.host_outlier_kp[k] = 1;
+        }
+        if (tid < 12) P.host_pose[tid] = s_T[tid];
+        if (tid == 0) {
+            P.host_result[0] = n - num_bad, P.host_result[1] = total_iters, P.host_result[2] = num_bad, P.host_result[3] = n;
+            if (P.trk_counter_reset) *P.trk_counter_reset = 0;
+        }
     }
 }
 
@@ -2040,14 +2134,17 @@ __global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P) {
     SvProfScope ps(ctx, s, "k_pose_opt");
     const size_t lds = sizeof(double) * (PO_THREADS / 64) * WRED_DOUBLES;
-    if (P.intr[0] == 0.0 && P.intr[1] == 0.0) {  // cam_is_equirect
-        (void)sv_allow_dynamic_lds((const void*)k_pose_opt<true>, lds);  // dynamic LDS above 64 KB must be allowed explicitly
-        hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(PO_THREADS), lds, s, P);
+    const bool eq = P.intr[0] == 0.0 && P.intr[1] == 0.0;  // cam_is_equirect
+    const bool trk = P.trk_map != nullptr;
+    const void* k = trk ? (eq ? (const void*)k_pose_opt<true, true> : (const void*)k_pose_opt<false, true>)
+                        : (eq ? (const void*)k_pose_opt<true, false> : (const void*)k_pose_opt<false, false>);
+    (void)sv_allow_dynamic_lds(k, lds);  // dynamic LDS above 64 KB must be allowed explicitly
+    if (trk) {
+        if (eq) hipLaunchKernelGGL((k_pose_opt<true, true>), dim3(1), dim3(PO_THREADS), lds, s, P);
+        else hipLaunchKernelGGL((k_pose_opt<false, true>), dim3(1), dim3(PO_THREADS), lds, s, P);
     }
-    else {
-        (void)sv_allow_dynamic_lds((const void*)k_pose_opt<false>, lds);
-        hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(PO_THREADS), lds, s, P);
-    }
+    else if (eq) hipLaunchKernelGGL((k_pose_opt<true, false>), dim3(1), dim3(PO_THREADS), lds, s, P);
+    else hipLaunchKernelGGL((k_pose_opt<false, false>), dim3(1), dim3(PO_THREADS), lds, s, P);
 }
 
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D) {

@@ -17,25 +17,10 @@
 #include <cstdlib>
 #include "match_kernels.h"
 #include "sv_sort.h"
+#include "match_device.h"
 
 namespace {
-
-constexpr unsigned HAMMING_DIST_THR_LOW = 50;   // match/base.h:15
-constexpr unsigned MAX_HAMMING_DIST = 256;      // match/base.h:17
-
-__device__ __forceinline__ unsigned hamming256(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
-    unsigned d = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) d += __popc(a[i] ^ b[i]);
-    return d;
-}
-
-__device__ __forceinline__ float angle_diff(float a1, float a2) {  // util/angle.cc:7-16
-    float ret = a1 - a2;
-    if (ret <= -180.0f) ret += 360.0f;
-    if (ret > 180.0f) ret -= 360.0f;
-    return ret;
-}
+using namespace svmd;
 
 __global__ void k_hamming_pairs(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int n, uint32_t* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -930,7 +915,7 @@ __global__ void k_cand_dist(CandProblem P) {
 __device__ __forceinline__ int cand_verdict(const CandProblem& P, unsigned best, unsigned second, int best_lvl, int second_lvl, int best_idx);
 __device__ int cand_decide(const CandProblem& P, int q, const int* owner) {
     if (P.q_valid && !P.q_valid[q]) return -1;
-    const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
+    const int lo = P.cand_off[q], hi = P.cand_cnt ? lo + P.cand_cnt[q] : P.cand_off[q + 1];
     if (lo == hi) return -1;
     const bool tri = P.mode == SVGPU_MATCH_TRIANGULATION;
     unsigned best = tri ? P.thr : MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
@@ -1023,6 +1008,7 @@ struct CandLds {
     SV_LDS int* owner;      // nt
     SV_LDS int* match;      // nq
     SV_LDS int* off;        // nq + 1
+    SV_LDS int* cnt;        // nq (null: CSR offsets, list q ends where list q + 1 begins)
     SV_LDS uint32_t* head;  // nq x K
     SV_LDS uint8_t* occ;    // nt (null: nothing occupied initially)
     SV_LDS uint8_t* lvl;    // nt (null: no levels)
@@ -1030,7 +1016,7 @@ struct CandLds {
     int K;
 };
 __device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, const CandLds& S) {
-    const int lo = S.off[q], n = S.off[q + 1] - lo;
+    const int lo = S.off[q], n = S.cnt ? S.cnt[q] : S.off[q + 1] - lo;
     if (n == 0 || (S.qv && !S.qv[q])) return -1;
     if (!cand_sorted(P, n)) return cand_decide(P, q, (const int*)S.owner);
     unsigned best = MAX_HAMMING_DIST, second = MAX_HAMMING_DIST;
@@ -1086,8 +1072,12 @@ __device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // take_loaded without branches (selects): the four decisions of a chunk are straight-line code
             const unsigned d = e[j] >> 22;
-            const bool stop = e[j] == 0xFFFFFFFFu || d >= MAX_HAMMING_DIST, active = !done;
-            const bool avail = active && !stop && own[j] >= q, first = avail && best_idx < 0, sec = avail && best_idx >= 0;
+            // (slots of the chunk beyond the staged head are neither an entry nor the list's end: the walk goes on in global memory.  Reading
+            //  them as "gated entries sort last -> stop" ended the walk of a list LONGER than its staged head whose staged entries were all
+            //  taken -- with one staged entry per list, 6 000 queries, a handful of wrong decisions per frame)
+            const bool padding = k0 + j >= nk;
+            const bool stop = !padding && (e[j] == 0xFFFFFFFFu || d >= MAX_HAMMING_DIST), active = !done;
+            const bool avail = active && !padding && !stop && own[j] >= q, first = avail && best_idx < 0, sec = avail && best_idx >= 0;
             best = first ? d : best;
             best_lvl = first ? lv[j] : best_lvl;
             second = sec ? d : second;
@@ -1109,19 +1099,24 @@ __device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, cons
 }
 #define CAND_LDS_BUDGET (150 * 1024)
 // bytes of the LDS-resident form for (nq, nt) with K staged entries per list
-__host__ __device__ inline size_t cand_lds_bytes(int nq, int nt, int K) {
-    return (size_t)(nt + nq + nq + 1) * 4 + (size_t)nq * K * 4 + 2 * (((size_t)nt + 3) & ~size_t(3)) + (((size_t)nq + 3) & ~size_t(3)) + 16;
+__host__ __device__ inline size_t cand_lds_bytes(int nq, int nt, int K, bool with_cnt = false) {
+    return (size_t)(nt + nq + nq + 1 + (with_cnt ? nq : 0)) * 4 + (size_t)nq * K * 4 + 2 * (((size_t)nt + 3) & ~size_t(3)) + (((size_t)nq + 3) & ~size_t(3)) + 16;
 }
 __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) {
     extern __shared__ int s_cand[];
     __shared__ int s_changed;
-    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) return;
+    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) {  // the lists did not fit: nothing was written, the host re-runs with the exact size
+        if (P.num_host && threadIdx.x == 0) P.num_host[0] = 0, P.num_host[1] = P.cand_off[P.nq];
+        return;
+    }
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const int nt = P.nt_dev ? min(*P.nt_dev, P.nt) : P.nt;  // (the tables are laid out for P.nt either way)
     CandLds S;
     S.owner = (SV_LDS int*)s_cand;
     S.match = S.owner + P.nt;
     S.off = S.match + P.nq;
-    S.head = (SV_LDS uint32_t*)(S.off + P.nq + 1);
+    S.cnt = P.cand_cnt ? S.off + P.nq + 1 : nullptr;
+    S.head = (SV_LDS uint32_t*)(S.off + P.nq + 1 + (P.cand_cnt ? P.nq : 0));
     SV_LDS uint8_t* bytes = (SV_LDS uint8_t*)(S.head + (size_t)P.nq * K);
     S.occ = P.occupied ? bytes : nullptr;
     S.lvl = P.t_octave ? bytes + ((P.nt + 3) & ~3) : nullptr;
@@ -1129,19 +1124,20 @@ __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) 
     S.K = K;
     for (int q = tid; q <= P.nq; q += nthr) {
         S.off[q] = P.cand_off[q];
+        if (S.cnt && q < P.nq) S.cnt[q] = P.cand_cnt[q];
         if (S.qv && q < P.nq) S.qv[q] = P.q_valid[q];
     }
-    for (int t = tid; t < P.nt; t += nthr) {
+    for (int t = tid; t < nt; t += nthr) {
         if (S.occ) S.occ[t] = P.occupied[t];
         if (S.lvl) S.lvl[t] = (uint8_t)P.t_octave[t];
     }
     __syncthreads();
     for (int i = tid; i < P.nq * K; i += nthr) {
-        const int q = i / K, k = i - q * K, lo = S.off[q], n = S.off[q + 1] - lo;
+        const int q = i / K, k = i - q * K, lo = S.off[q], n = S.cnt ? S.cnt[q] : S.off[q + 1] - lo;
         if (k < n) S.head[i] = P.dist[lo + k];
     }
     auto reset_owner = [&]() {
-        for (int t = tid; t < P.nt; t += nthr) S.owner[t] = (S.occ && S.occ[t]) ? -1 : 0x7FFFFFFF;
+        for (int t = tid; t < nt; t += nthr) S.owner[t] = (S.occ && S.occ[t]) ? -1 : 0x7FFFFFFF;
     };
     reset_owner();
     for (int q = tid; q < P.nq; q += nthr) S.match[q] = -2;
@@ -1171,21 +1167,29 @@ __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) 
     for (int q = tid; q < P.nq; q += nthr) {
         const int m = S.match[q];
         P.match_q[q] = m;
+        if (P.match_host) P.match_host[q] = m;
         local += m >= 0;
     }
     if (tid == 0) s_changed = 0;
     __syncthreads();
     if (local) atomicAdd(&s_changed, local);
     __syncthreads();
-    if (tid == 0) *P.num = s_changed;
+    if (tid == 0) {
+        *P.num = s_changed;
+        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = P.cand_off[P.nq];
+    }
 }
 // the same replay with its tables in global memory (inputs beyond the LDS form)
 __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __restrict__ owner, int* __restrict__ match) {
     __shared__ int s_changed;
-    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) return;
+    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) {
+        if (P.num_host && threadIdx.x == 0) P.num_host[0] = 0, P.num_host[1] = P.cand_off[P.nq];
+        return;
+    }
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const int nt = P.nt_dev ? min(*P.nt_dev, P.nt) : P.nt;
     auto reset_owner = [&]() {
-        for (int t = tid; t < P.nt; t += nthr) owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;
+        for (int t = tid; t < nt; t += nthr) owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;
     };
     reset_owner();
     for (int q = tid; q < P.nq; q += nthr) match[q] = -2;
@@ -1212,13 +1216,17 @@ __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __rest
     int local = 0;
     for (int q = tid; q < P.nq; q += nthr) {
         P.match_q[q] = match[q];
+        if (P.match_host) P.match_host[q] = match[q];
         local += match[q] >= 0;
     }
     if (tid == 0) s_changed = 0;
     __syncthreads();
     if (local) atomicAdd(&s_changed, local);
     __syncthreads();
-    if (tid == 0) *P.num = s_changed;
+    if (tid == 0) {
+        *P.num = s_changed;
+        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = P.cand_off[P.nq];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ grid candidate lists
@@ -1284,93 +1292,8 @@ __global__ __launch_bounds__(256) void k_grid_place(GridProblem G) {
 // then every cell with more than one keypoint puts its items into increasing order -- the same arrays as the four launches below
 // (memset, k_grid_assign, scan, k_grid_place), whose last one counted, for every keypoint, ALL earlier keypoints of its cell by walking
 // every earlier keypoint: 26 us at 2 400 keypoints.
-#define GRID_ONE_CELLS 4096
-#define GRID_ONE_KPT_ROUNDS 8  // keypoints per thread whose arrival numbers stay in registers (8 192 keypoints)
-#define GRID_ONE_SMALL 24      // a cell of at most this many keypoints is ordered by one thread (insertion sort); a larger one by the workgroup
 __global__ __launch_bounds__(1024) void k_grid_frame_one(GridProblem G) {
-    __shared__ int s_cnt[GRID_ONE_CELLS + 1];
-    __shared__ int s_wsum[16];
-    __shared__ int s_items[1024 * GRID_ONE_KPT_ROUNDS];  // the items of one crowded cell
-    __shared__ int s_big[1024 * GRID_ONE_KPT_ROUNDS / GRID_ONE_SMALL + 1], s_nbig;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nc = G.cols * G.rows;
-    for (int c = tid; c <= nc; c += 1024) s_cnt[c] = 0;
-    if (tid == 0) s_nbig = 0;
-    __syncthreads();
-    int cell[GRID_ONE_KPT_ROUNDS], pos[GRID_ONE_KPT_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < GRID_ONE_KPT_ROUNDS; ++r) {
-        const int i = tid + r * 1024;
-        cell[r] = -1, pos[r] = 0;
-        if (i < G.nt) {
-            const int cx = (int)floor((double)(G.t_xy[2 * i] - G.min_x) * G.inv_w), cy = (int)floor((double)(G.t_xy[2 * i + 1] - G.min_y) * G.inv_h);
-            if (0 <= cx && cx < G.cols && 0 <= cy && cy < G.rows) {
-                cell[r] = cx * G.rows + cy;
-                pos[r] = atomicAdd(&s_cnt[cell[r]], 1);  // arrival order inside the cell: arbitrary, put right at the end
-            }
-            G.cell_of[i] = cell[r];
-        }
-    }
-    __syncthreads();
-    // exclusive scan of the counters: every thread owns a contiguous run of cells, wave scan of the run sums, then the waves' totals
-    const int per = (nc + 1023) / 1024, c0 = tid * per, c1 = min(c0 + per, nc);
-    int run = 0;
-    for (int c = c0; c < c1; ++c) run += s_cnt[c];
-    int incl = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - run;
-    for (int w = 0; w < wave; ++w) base += s_wsum[w];
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {  // counters -> offsets, in place (a thread's own run only)
-        const int k = s_cnt[c];
-        s_cnt[c] = base;
-        base += k;
-    }
-    if (tid == 1023) s_cnt[nc] = base;  // (the last thread's run ends at nc or is empty: its base is the total either way)
-    __syncthreads();
-    for (int c = tid; c <= nc; c += 1024) G.cell_off[c] = s_cnt[c];
-#pragma unroll
-    for (int r = 0; r < GRID_ONE_KPT_ROUNDS; ++r)
-        if (cell[r] >= 0) G.cell_items[s_cnt[cell[r]] + pos[r]] = tid + r * 1024;
-    __syncthreads();  // (workgroup-scope: the placements above are visible to the threads below)
-    for (int c = tid; c < nc; c += 1024) {  // increasing keypoint index inside every cell (= the stable placement)
-        const int lo = s_cnt[c], k = s_cnt[c + 1] - lo;
-        if (k > GRID_ONE_SMALL) {  // crowded: left to the whole workgroup below (at most nt / GRID_ONE_SMALL such cells)
-            s_big[atomicAdd(&s_nbig, 1)] = c;
-            continue;
-        }
-        for (int a = 1; a < k; ++a) {  // insertion sort: cells hold a handful of keypoints
-            const int v = G.cell_items[lo + a];
-            int b = a - 1;
-            while (b >= 0 && G.cell_items[lo + b] > v) {
-                G.cell_items[lo + b + 1] = G.cell_items[lo + b];
-                --b;
-            }
-            G.cell_items[lo + b + 1] = v;
-        }
-    }
-    __syncthreads();
-    // crowded cells (a dense patch under a coarse grid; in the limit every keypoint in one cell): rank sort by the workgroup -- the cell's
-    // items staged in LDS, every thread counts the items below its own: k^2 / 1 024 LDS reads per thread, 16 k at the 8 192-keypoint limit
-    // (one thread's insertion sort would be k^2 / 4 global round trips)
-    const int nbig = s_nbig;
-    for (int bi = 0; bi < nbig; ++bi) {
-        const int c = s_big[bi], lo = s_cnt[c], k = s_cnt[c + 1] - lo;
-        for (int a = tid; a < k; a += 1024) s_items[a] = G.cell_items[lo + a];
-        __syncthreads();
-        for (int a = tid; a < k; a += 1024) {
-            const int v = s_items[a];
-            int rank = 0;
-            for (int j = 0; j < k; ++j) rank += s_items[j] < v;  // (indices are distinct)
-            G.cell_items[lo + rank] = v;
-        }
-        __syncthreads();
-    }
+    grid_frame_one(G, G.nt);
 }
 // one wave per query: the lanes take the cells of the window (column-major = the reference's scan order), count their
 // keypoints that pass the level and margin tests, and a wave prefix sum gives every cell its place in the query's list
@@ -1860,17 +1783,15 @@ void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* ow
         hipLaunchKernelGGL(k_area_replay, dim3(1), dim3(64), use_lds ? lds : 0, s, P, owner, match, mdist, use_lds);
         return;
     }
-    {
-        // the LDS-resident form with as many staged entries per list as fit (at most 64: longer lists are not sorted)
-        if (cand_lds_bytes(P.nq, P.nt, 0) <= CAND_LDS_BUDGET) {
-            const int K = P.nq > 0 ? (int)std::min<size_t>(64, (CAND_LDS_BUDGET - cand_lds_bytes(P.nq, P.nt, 0)) / ((size_t)P.nq * 4)) : 0;
-            static bool allowed = false;
-            if (!allowed) {
-                (void)hipFuncSetAttribute((const void*)k_cand_replay_lds, hipFuncAttributeMaxDynamicSharedMemorySize, CAND_LDS_BUDGET);
-                allowed = true;
-            }
-            hipLaunchKernelGGL(k_cand_replay_lds, dim3(1), dim3(1024), cand_lds_bytes(P.nq, P.nt, K), s, P, K);
-        }
-        else hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(1024), 0, s, P, owner, match);
+    sv_launch_cand_replay(ctx, s, P, owner, match);
+}
+void sv_launch_cand_replay(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match) {
+    // the LDS-resident form with as many staged entries per list as fit (at most 64: longer lists are not sorted)
+    const bool wc = P.cand_cnt != nullptr;
+    if (cand_lds_bytes(P.nq, P.nt, 0, wc) <= CAND_LDS_BUDGET) {
+        const int K = P.nq > 0 ? (int)std::min<size_t>(64, (CAND_LDS_BUDGET - cand_lds_bytes(P.nq, P.nt, 0, wc)) / ((size_t)P.nq * 4)) : 0;
+        (void)sv_allow_dynamic_lds((const void*)k_cand_replay_lds, CAND_LDS_BUDGET);
+        hipLaunchKernelGGL(k_cand_replay_lds, dim3(1), dim3(1024), cand_lds_bytes(P.nq, P.nt, K, wc), s, P, K);
     }
+    else hipLaunchKernelGGL(k_cand_replay, dim3(1), dim3(1024), 0, s, P, owner, match);
 }

@@ -20,24 +20,36 @@ __global__ void k_frame_split(const svgpu_keypoint* __restrict__ k, int n, float
     angle[i] = p.angle;
 }
 
-int frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell) {
+}  // namespace
+// (also used by the tracked-frame chain, svgpu_track.hip)
+int sv_frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell) {
     if (n > f->cap) {
         const int cap = n + n / 4 + 64;
-        void* olds[] = {f->desc, f->undist, f->xy, f->octave, f->angle, f->xright, f->bearings, f->cell_of, f->cell_items};
-        for (void* o : olds)
-            if (o) SV_HIP(ctx, hipFree(o));
-        f->desc = nullptr, f->undist = nullptr, f->xy = nullptr, f->octave = nullptr, f->angle = nullptr, f->xright = nullptr, f->bearings = nullptr;
-        f->cell_of = nullptr, f->cell_items = nullptr;
+        if (f->slab) SV_HIP(ctx, hipFree(f->slab));
+        f->slab = nullptr;
         f->cap = 0;
-        SV_HIP(ctx, hipMalloc((void**)&f->desc, (size_t)cap * 32));
-        SV_HIP(ctx, hipMalloc((void**)&f->undist, (size_t)cap * sizeof(svgpu_keypoint)));
-        SV_HIP(ctx, hipMalloc((void**)&f->xy, (size_t)cap * 8));
-        SV_HIP(ctx, hipMalloc((void**)&f->octave, (size_t)cap * 4));
-        SV_HIP(ctx, hipMalloc((void**)&f->angle, (size_t)cap * 4));
-        SV_HIP(ctx, hipMalloc((void**)&f->xright, (size_t)cap * 4));
-        SV_HIP(ctx, hipMalloc((void**)&f->bearings, (size_t)cap * 24));
-        SV_HIP(ctx, hipMalloc((void**)&f->cell_of, (size_t)cap * 4));
-        SV_HIP(ctx, hipMalloc((void**)&f->cell_items, (size_t)cap * 4));
+        size_t off = 0;
+        auto carve = [&](size_t bytes) {
+            const size_t o = off;
+            off += pad256(bytes);
+            return o;
+        };
+        const size_t o_kps = carve((size_t)cap * sizeof(svgpu_keypoint)), o_desc = carve((size_t)cap * 32), o_und = carve((size_t)cap * sizeof(svgpu_keypoint)),
+                     o_brg = carve((size_t)cap * 24), o_xy = carve((size_t)cap * 8), o_oct = carve((size_t)cap * 4), o_ang = carve((size_t)cap * 4),
+                     o_xr = carve((size_t)cap * 4), o_cof = carve((size_t)cap * 4), o_cit = carve((size_t)cap * 4), o_cnt = carve((1 + SV_MAX_LEVELS) * 4);
+        SV_HIP(ctx, hipMalloc((void**)&f->slab, off));
+        f->slab_bytes = off;
+        f->kps_raw = (svgpu_keypoint*)(f->slab + o_kps);
+        f->desc = (uint8_t*)(f->slab + o_desc);
+        f->undist = (svgpu_keypoint*)(f->slab + o_und);
+        f->bearings = (double*)(f->slab + o_brg);
+        f->xy = (float*)(f->slab + o_xy);
+        f->octave = (int32_t*)(f->slab + o_oct);
+        f->angle = (float*)(f->slab + o_ang);
+        f->xright = (float*)(f->slab + o_xr);
+        f->cell_of = (int32_t*)(f->slab + o_cof);
+        f->cell_items = (int32_t*)(f->slab + o_cit);
+        f->counts = (int32_t*)(f->slab + o_cnt);
         f->cap = cap;
     }
     if (ncell + 1 > f->cells_cap) {
@@ -50,6 +62,8 @@ int frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell) {
     if (!f->dummy) SV_HIP(ctx, hipMalloc((void**)&f->dummy, 256));
     return SVGPU_OK;
 }
+namespace {
+inline int frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell) { return sv_frame_reserve(ctx, f, n, ncell); }
 
 // bins the frame's undistorted keypoints (f->xy, f->octave already in place) over the camera's image bounds
 void frame_bin(hipStream_t s, svgpu_frame* f, const svgpu_camera* cam, int grid_cols, int grid_rows) {
@@ -91,7 +105,7 @@ int svgpu_frame_create(svgpu_ctx* ctx, svgpu_frame** out) {
 void svgpu_frame_destroy(svgpu_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    void* p[] = {f->desc, f->undist, f->xy, f->octave, f->angle, f->xright, f->bearings, f->cell_of, f->cell_off, f->cell_items, f->dummy};
+    void* p[] = {f->slab, f->cell_off, f->dummy};
     for (void* q : p)
         if (q) (void)hipFree(q);
     delete f;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,18 +89,39 @@ struct svgpu_frame {
     int grid_cols = 0, grid_rows = 0, cells_cap = 0;
     float min_x = 0, max_x = 0, min_y = 0, max_y = 0;  // image bounds the grid was binned over
     bool has_xright = false;
+    // ONE device allocation (`slab`, `slab_bytes`), carved in this order, so that what the host wants back of a freshly extracted frame
+    // (kps_raw | desc | undist | bearings) is one contiguous copy (svgpu_track_motion)
+    char* slab = nullptr;
+    size_t slab_bytes = 0;
+    svgpu_keypoint* kps_raw = nullptr;  // n distorted keypoints as the extractor wrote them (fused extraction only)
     uint8_t* desc = nullptr;            // n x 32
     svgpu_keypoint* undist = nullptr;   // n undistorted keypoint records
+    double* bearings = nullptr;         // n x 3
     float* xy = nullptr;                // n x 2
     int32_t* octave = nullptr;
     float* angle = nullptr;
     float* xright = nullptr;            // stereo_x_right_ (valid when has_xright)
-    double* bearings = nullptr;         // n x 3
     int32_t* cell_of = nullptr;         // n
-    int32_t* cell_off = nullptr;        // grid_cols * grid_rows + 1
     int32_t* cell_items = nullptr;      // n
+    int32_t* counts = nullptr;          // 1 + SV_MAX_LEVELS ints: the extractor's counts (fused extraction: [0] = n as the device knows it)
+    int32_t* cell_off = nullptr;        // grid_cols * grid_rows + 1 (own allocation: sized by the grid)
     int32_t* dummy = nullptr;           // 1 int (the query-side scan of a grid build without queries)
 };
+
+// The landmark table of the tracked-frame chain (include/svgpu.h svgpu_map_*): records indexed by data::landmark::id_.
+// Writers (upsert / erase: the mapping thread after BA, the tracking thread's flush) and readers (the tracker's chains) may sit on
+// different contexts = streams: `mtx` serialises the host side, ev_write / ev_read order the streams (a reader's stream waits for the
+// last write, a writer's for the last read), and a growth waits for both before the old table is freed.
+struct svgpu_map {
+    int device = 0;
+    int cap = 0;                         // records allocated (ids < cap are addressable)
+    svgpu_landmark_record* rec = nullptr;
+    std::mutex mtx;
+    hipEvent_t ev_write = nullptr, ev_read = nullptr;
+    bool wrote = false, read = false;
+};
+int sv_map_reader_begin(svgpu_ctx* ctx, svgpu_map* map, hipStream_t s);  // the reader's stream waits for the last write (call with map->mtx held)
+int sv_map_reader_end(svgpu_ctx* ctx, svgpu_map* map, hipStream_t s);
 
 struct svgpu_ctx {
     int device = 0;
@@ -180,6 +202,7 @@ void sv_sky_release(svgpu_ctx* ctx);  // plan + buffers of the envelope Cholesky
 int sv_ensure_stage(svgpu_ctx* ctx, size_t bytes);  // grow-only page-locked host buffer (ctx->h_stage)
 hipError_t sv_allow_dynamic_lds(const void* kernel, size_t bytes);  // per (device, kernel), thread-safe
 void sv_orb_release(svgpu_ctx* ctx);
+int sv_frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell);  // grow-only slab of a resident frame (svgpu_frame.hip)
 
 #define SV_HIP(ctx, call)                                                   \
     do {                                                                    \

@@ -64,6 +64,8 @@ void sv_orb_release(svgpu_ctx* ctx) {
     free_dev(ctx->d_desc);
     free_dev(ctx->d_counts);
     ctx->orb.configured = false;
+    ctx->last_extract_n = -1;  // d_kps / d_desc are gone: nothing left to adopt (svgpu_frame_adopt_extraction)
+    ctx->last_batch = 0;
 }
 
 extern "C" {
@@ -379,6 +381,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_orb_extract_batch_device: bad arguments");
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ctx->last_extract_n = -1;  // whatever the last svgpu_orb_extract left behind is stale from here on (it sets the count again after its own call)
     const int Lc = C.num_levels;
     // 1. pyramid: chained bilinear resize (level l from level l-1), all levels in one launch (banded, see k_pyramid)
     if (Lc > 1) {

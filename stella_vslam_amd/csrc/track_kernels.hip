@@ -1,0 +1,254 @@
+// Kernels of the tracked-frame chain (svgpu_track.hip): the steps tracking_module runs per image, fused so that each half of the chain
+// is a handful of launches on ONE stream with no host round trip in between, and fed from the resident landmark table (svgpu_map)
+// instead of host-flattened arrays.
+//   k_track_frame   system.cc:384-395   undistort_keypoints + convert_keypoints_to_bearings + assign_keypoints_to_grid (keypoint count
+//                                       read from device memory)
+//   k_track_cand    data/frame.cc:59-85 (can_observe) / camera::*::reproject_to_image, data/common.cc:127-190 (get_keypoints_in_cell),
+//                   match/projection.cc:40-86, 160-195 (gates + Hamming distances): one wave per query
+// The sequential part (greedy claims) stays k_cand_replay_lds (match_kernels.hip), the optimisation k_pose_opt<EQ, true> (ba_kernels.hip).
+// Every expression is the one the separate kernels evaluate (frame_device.h / match_device.h): the chain's results are bit-identical to
+// svgpu_frame_observation + svgpu_match_current_and_last_frames / svgpu_reproject_landmarks + svgpu_match_in_cells on flattened inputs.
+#include "svgpu_internal.h"
+#include "track_kernels.h"
+#include "frame_device.h"
+#include "match_device.h"
+
+namespace {
+using namespace svfd;
+using namespace svmd;
+
+#define TRACK_FRAME_ROUNDS GRID_ONE_KPT_ROUNDS  // keypoints per thread of the one-workgroup frame kernel (8 192 keypoints)
+
+__global__ __launch_bounds__(1024) void k_track_frame(TrackFrameProblem P) {
+    const int tid = threadIdx.x;
+    const int n = min(*P.n_dev, P.cap);
+    if (tid == 0) {
+        *P.n_host = n;
+        if (P.counter_reset) *P.counter_reset = 0;
+    }
+#pragma unroll 1
+    for (int i = tid; i < n; i += 1024) {
+        ObsOut o;
+        frame_obs_one(P.cam, P.kps[i], false, o);
+        P.undist[i] = o.undist;
+        P.xy[2 * i] = o.ux;
+        P.xy[2 * i + 1] = o.uy;
+        P.octave[i] = o.undist.octave;
+        P.angle[i] = o.undist.angle;
+        P.bearings[3 * i] = o.b0;
+        P.bearings[3 * i + 1] = o.b1;
+        P.bearings[3 * i + 2] = o.b2;
+    }
+    __syncthreads();  // the grid reads xy / octave back (workgroup scope: the only workgroup)
+    grid_frame_one(P.G, n);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {  // orders the wave's own LDS writes before its later LDS reads (no workgroup barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define TRACK_SORT_MAX 1024  // == CAND_SORT_MAX of match_kernels.hip: lists up to this many entries are left sorted by (distance, scan position)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
+    __shared__ unsigned long long s_keys[4][TRACK_SORT_MAX];
+    const svgpu_landmark_record* __restrict__ map = (const svgpu_landmark_record*)P.map;
+    // which keypoints are closed from the start: `lm && lm->has_observation()` of the landmark the frame holds there (projection.cc:52-55)
+    if (MODE == 1 && P.cur_lm) {
+        const int k = blockIdx.x * 256 + threadIdx.x, nt = P.nt_dev ? min(*P.nt_dev, P.nt) : P.nt;
+        if (k < nt) {
+            const int id = P.cur_lm[k];
+            P.occupied[k] = (id >= 0 && id < P.map_cap && (map[id].flags & SVGPU_LM_HAS_OBSERVATION)) ? 1 : 0;
+        }
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= P.nq) return;
+    unsigned long long* s_key = s_keys[wave];
+    // ---- the landmark of this query
+    const int id = P.q_ids[q];
+    const uint32_t flags = (id >= 0 && id < P.map_cap) ? map[id].flags : 0u;
+    const bool present = (flags & SVGPU_LM_PRESENT) != 0, has_desc = (flags & SVGPU_LM_HAS_DESCRIPTOR) != 0;
+    const svgpu_landmark_record* rec = map + (present ? id : 0);
+    // ---- pose: kernel argument, or what the previous optimisation left on the device (trans_wc = -R^T t as Eigen evaluates it)
+    double rot[9], tcw[3], twc[3];
+    if (P.pose_dev) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rot[3 * i + j] = P.pose_dev[4 * i + j];
+            tcw[i] = P.pose_dev[4 * i + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) twc[i] = ((-rot[i]) * tcw[0] + (-rot[3 + i]) * tcw[1]) + (-rot[6 + i]) * tcw[2];
+    }
+    else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rot[i] = P.R.rot_cw[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tcw[i] = P.R.trans_cw[i], twc[i] = P.R.trans_wc[i];
+    }
+    ReprojOut o;
+    const bool offered = MODE == 0 ? (present && has_desc) : present;
+    reproject_one(P.R, rot, tcw, twc, offered, rec->pos_w[0], rec->pos_w[1], rec->pos_w[2], rec->mean_normal[0], rec->mean_normal[1], rec->mean_normal[2],
+                  rec->min_valid_dist, rec->max_valid_dist, MODE == 0 ? P.q_octave[q] : 0, MODE == 0, o);
+    const bool live = MODE == 0 ? o.vis : (o.vis && has_desc);
+    if (lane == 0) {
+        P.q_valid[q] = live ? 1 : 0;
+        P.q_blocks[q] = (flags & SVGPU_LM_HAS_OBSERVATION) ? 1 : 0;
+        if (MODE == 1) {
+            P.visible[q] = o.vis ? 1 : 0;
+            if (P.visible_host) P.visible_host[q] = o.vis ? 1 : 0;
+            P.reproj[2 * q] = o.vis ? o.rx : 0.0;
+            P.reproj[2 * q + 1] = o.vis ? o.ry : 0.0;
+            P.x_right[q] = o.vis ? o.xr : 0.f;
+            P.pred_level[q] = o.vis ? o.level : -1;
+        }
+    }
+    int total = 0, list_off = 0;
+    if (live) {
+        float ref_x, ref_y, margin;
+        int min_level, max_level;
+        reproject_window(P.R, o, ref_x, ref_y, margin, min_level, max_level);
+        uint32_t qd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qd[k] = reinterpret_cast<const uint32_t*>(rec->descriptor)[k];
+        const float q_angle = (MODE == 0 && P.check_orientation) ? P.q_angle[q] : 0.f;
+        // ---- data::get_keypoints_in_cell (data/common.cc:127-190): the window's cells in column-major order over the lanes
+        int lo_x = (int)floor((double)(ref_x - P.min_x - margin) * P.inv_w), hi_x = (int)ceil((double)(ref_x - P.min_x + margin) * P.inv_w);
+        int lo_y = (int)floor((double)(ref_y - P.min_y - margin) * P.inv_h), hi_y = (int)ceil((double)(ref_y - P.min_y + margin) * P.inv_h);
+        lo_x = max(lo_x, 0);
+        lo_y = max(lo_y, 0);
+        hi_x = min(hi_x, P.cols - 1);
+        hi_y = min(hi_y, P.rows - 1);
+        if (lo_x < P.cols && 0 <= hi_x && lo_y < P.rows && 0 <= hi_y && lo_x <= hi_x && lo_y <= hi_y) {
+            const int ny = hi_y - lo_y + 1, ncell = (hi_x - lo_x + 1) * ny;
+            auto passes = [&](int idx) {
+                const int oct = P.t_octave[idx];
+                if (oct < min_level || max_level < oct) return false;
+                const float dx = P.t_xy[2 * idx] - ref_x, dy = P.t_xy[2 * idx + 1] - ref_y;
+                return fabsf(dx) < margin && fabsf(dy) < margin;
+            };
+            // pass 1: the list's length
+            for (int base = 0; base < ncell; base += 64) {
+                const int k = base + lane;
+                int n = 0;
+                if (k < ncell) {
+                    const int c = (lo_x + k / ny) * P.rows + lo_y + k % ny;
+                    for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) n += passes(P.cell_items[it]) ? 1 : 0;
+                }
+                int incl = n;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31
+                total += __builtin_amdgcn_readlane(incl, 63);
+            }
+            if (total > 0) {
+                int off = 0;
+                if (lane == 0) off = atomicAdd(&P.cand_off[P.nq], total);  // the list's place: any order, the replay goes through cand_off / cand_cnt
+                list_off = __builtin_amdgcn_readfirstlane(off);
+                const bool fits = list_off + total <= P.cap;  // beyond the capacity nothing is written: the host re-runs the chain with a larger one
+                const bool in_lds = total <= TRACK_SORT_MAX;
+                // pass 2: gates + distance of every candidate, at its scan position
+                int done = 0;
+                for (int base = 0; base < ncell && fits; base += 64) {
+                    const int k = base + lane;
+                    int n = 0, c = 0;
+                    if (k < ncell) {
+                        c = (lo_x + k / ny) * P.rows + lo_y + k % ny;
+                        for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) n += passes(P.cell_items[it]) ? 1 : 0;
+                    }
+                    int incl = n;
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
+                    if (n > 0) {
+                        int pos = done + incl - n;
+                        for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) {
+                            const int t = P.cell_items[it];
+                            if (!passes(t)) continue;
+                            bool gated = false;
+                            if (P.t_xright && 0.f < P.t_xright[t]) {  // projection.cc:57-62, 172-177
+                                const float err = fabsf(o.xr - P.t_xright[t]);
+                                if (margin < err) gated = true;
+                            }
+                            if (MODE == 0 && P.check_orientation && !gated && fabsf(angle_diff(q_angle, P.t_angle[t])) > 30.0f) gated = true;  // :179-181
+                            const unsigned d = gated ? 0u : hamming256(qd, P.tdesc + (size_t)t * 8);
+                            if (in_lds) s_key[pos] = gated ? ~0ull : ((unsigned long long)d << 32) | ((unsigned long long)pos << 22) | (unsigned)t;
+                            else P.dist[list_off + pos] = gated ? 0xFFFFFFFFu : (d << 22) | (uint32_t)t;
+                            ++pos;
+                        }
+                    }
+                    done += __builtin_amdgcn_readlane(incl, 63);
+                }
+                if (fits && in_lds) {  // (distance, scan position) order: gated entries last (k_cand_dist's order, which the replay's walks rely on)
+                    wave_lds_sync();
+                    if (total <= 64) {
+                        unsigned long long key = lane < total ? s_key[lane] : ~0ull;
+#pragma unroll
+                        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                            for (int j = k >> 1; j > 0; j >>= 1) {
+                                const unsigned long long other = __shfl_xor(key, j, 64);
+                                const bool up = (lane & k) == 0, low = (lane & j) == 0;
+                                const bool take_min = up == low;
+                                key = take_min ? (key < other ? key : other) : (key < other ? other : key);
+                            }
+                        if (lane < total) P.dist[list_off + lane] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
+                    }
+                    else {
+                        int npow2 = 128;
+                        while (npow2 < total) npow2 <<= 1;
+                        for (int i = total + lane; i < npow2; i += 64) s_key[i] = ~0ull;
+                        wave_lds_sync();
+                        for (int k = 2; k <= npow2; k <<= 1)
+                            for (int j = k >> 1; j > 0; j >>= 1) {
+                                for (int i = lane; i < npow2; i += 64) {
+                                    const int p = i ^ j;
+                                    if (p > i) {
+                                        const unsigned long long a = s_key[i], b = s_key[p];
+                                        if ((a > b) == ((i & k) == 0)) {
+                                            s_key[i] = b;
+                                            s_key[p] = a;
+                                        }
+                                    }
+                                }
+                                wave_lds_sync();
+                            }
+                        for (int i = lane; i < total; i += 64) {
+                            const unsigned long long key = s_key[i];
+                            P.dist[list_off + i] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        P.cand_off[q] = list_off;
+        P.cand_cnt[q] = total;
+    }
+}
+
+}  // namespace
+
+void sv_launch_track_frame(svgpu_ctx* ctx, hipStream_t s, const TrackFrameProblem& P) {
+    SvProfScope ps(ctx, s, "k_track_frame");
+    hipLaunchKernelGGL(k_track_frame, dim3(1), dim3(1024), 0, s, P);
+}
+void sv_launch_track_cand(svgpu_ctx* ctx, hipStream_t s, const TrackCandProblem& P) {
+    SvProfScope ps(ctx, s, "k_track_cand");
+    int blocks = (P.nq + 3) / 4;
+    if (P.mode == 1 && P.cur_lm) blocks = std::max(blocks, (P.nt + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (P.mode == 0) hipLaunchKernelGGL(k_track_cand<0>, dim3(blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(k_track_cand<1>, dim3(blocks), dim3(256), 0, s, P);
+}

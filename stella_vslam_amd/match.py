@@ -96,7 +96,7 @@ class projection(base):
 
     def match_in_cells(self, qdesc, q_xy, q_margin, tdesc, t_xy, t_octave, bounds, mode, thr, q_min_level=None, q_max_level=None,
                        q_valid=None, occupied=None, q_angle=None, t_angle=None, q_xright=None, t_xright=None, q_xr_tol=None,
-                       grid_cols=64, grid_rows=48):
+                       grid_cols=64, grid_rows=48, q_blocks=None):
         """Same matcher, candidate lists built on the device: query q scans frm.get_keypoints_in_cell(q_xy[q], q_margin[q],
         q_min_level[q], q_max_level[q]) (data/common.cc:127-190) over the grid of data::assign_keypoints_to_grid."""
         qd, td = _c(qdesc, np.uint8), _c(tdesc, np.uint8)
@@ -107,6 +107,9 @@ class projection(base):
         qx, tx, qt = _c(q_xright, np.float32), _c(t_xright, np.float32), _c(q_xr_tol, np.float32)
         out = np.full(len(qd), -1, np.int32)
         num = C.c_int(0)
+        qb = _c(q_blocks, np.uint8)  # 0 = an accepted query does not close its keypoint (its landmark has no observation, projection.cc:52-55)
+        if qb is not None:
+            self.ctx.check(lib().svgpu_match_set_query_blocks(self.ctx.handle, _p(qb)), "svgpu_match_set_query_blocks")
         self.ctx.check(lib().svgpu_match_in_cells(self.ctx.handle, _p(qd), len(qd), _p(qxy), _p(qm), _p(qlo), _p(qhi), _p(qv), _p(qa), _p(qx),
                                                   _p(qt), _p(td), _p(txy), _p(toct), len(td), _p(occ), _p(ta), _p(tx),
                                                   C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]),
