@@ -486,7 +486,8 @@ def bench_tracked_frame(frames_np, want_cpu=True):
     out = {"what": "one tracked 640x480 frame through the drop-in classes: extract, frame observation, match_current_and_last_frames, pose optimizer, "
                    "can_observe loop, match_frame_and_landmarks, pose optimizer (host objects in and out, PCIe included)"}
     names = ("extract", "frame_observation", "match_current_and_last_frames", "pose_optimizer_1", "can_observe", "match_frame_and_landmarks", "pose_optimizer_2", "total")
-    for key, resident in (("resident_frames", 1), ("uploads_per_call", 0)):
+    host.svgpu_host_tracked_frame_counters.restype = None
+    for key, resident in (("chain", 2), ("resident_frames", 1), ("uploads_per_call", 0)):
         ms, cnt = np.zeros(8), np.zeros(8, np.int32)
         rc = host.svgpu_host_tracked_frame(C.c_void_p(seq.ctypes.data), len(seq), W, H, 30, resident, C.c_void_p(ms.ctypes.data), C.c_void_p(cnt.ctypes.data))
         if rc != 0:
@@ -495,6 +496,15 @@ def bench_tracked_frame(frames_np, want_cpu=True):
         out[key] = {"ms_per_frame": round(float(ms[7]), 4), "frames_per_s": round(1e3 / float(ms[7]), 1), "ms": {n: round(float(v), 4) for n, v in zip(names[:7], ms[:7])},
                     "keypoints": int(cnt[0]), "last_frame_landmarks": int(cnt[1]), "matches_1": int(cnt[2]), "inliers_1": int(cnt[3]),
                     "local_landmarks_visible": int(cnt[4]), "matches_2": int(cnt[5]), "inliers_2": int(cnt[6]), "translation_error_um": int(cnt[7])}
+        if resident == 2:
+            # the chain (svgpu_track_motion / svgpu_track_local_map behind drop_in/tracking_hip.h): landmark ids instead of flattened landmarks, the
+            # resident landmark table, two submissions per frame.  Its two timed legs are the two halves.
+            la, sy = C.c_double(0), C.c_double(0)
+            host.svgpu_host_tracked_frame_counters(C.byref(la), C.byref(sy))
+            out[key]["ms"] = {"motion_half (extract + frame observation + match_current_and_last_frames + pose optimizer)": round(float(ms[0]), 4),
+                              "local_map_half (can_observe + match_frame_and_landmarks + pose optimizer)": round(float(ms[4]), 4)}
+            out[key]["launches_per_frame"] = round(la.value, 2)   # kernel launches + runtime copies
+            out[key]["host_syncs"] = round(sy.value, 2)           # stream synchronisations per frame
     if want_cpu:
         try:
             out["cpu_port"] = cpu_tracked_frame(seq)

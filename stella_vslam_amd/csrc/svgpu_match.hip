@@ -280,7 +280,10 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
                          const int32_t* t_octave, int nt, const uint8_t* occupied, const float* t_angle, const float* t_xright,
                          float min_x, float max_x, float min_y, float max_y, int grid_cols, int grid_rows,
                          int check_orientation, unsigned thr, float lowe_ratio, int mode, int32_t* match_q, int* num_matches) {
+    // both one-shots are consumed FIRST, whatever happens next: an early error return must not leave them armed for an unrelated call
     const svgpu_frame* rf = sv_take_bound_frame(ctx);
+    const uint8_t* const q_blocks = ctx ? ctx->next_q_blocks : nullptr;  // svgpu_match_set_query_blocks
+    if (ctx) ctx->next_q_blocks = nullptr;
     if (rf) {  // resident keypoint side: the frame's own device arrays, bounds and grid (svgpu_frame_bind)
         tdesc = rf->desc, t_xy = rf->xy, t_octave = rf->octave, nt = rf->n;
         t_angle = check_orientation ? rf->angle : nullptr;
@@ -301,8 +304,6 @@ int svgpu_match_in_cells(svgpu_ctx* ctx, const uint8_t* qdesc, int nq, const flo
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_in_cells: inconsistent inputs");
     InCellsFrame F{tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, min_x, max_x, min_y, max_y, grid_cols, grid_rows};
     F.res = rf;
-    const uint8_t* const q_blocks = ctx->next_q_blocks;  // svgpu_match_set_query_blocks (one-shot)
-    ctx->next_q_blocks = nullptr;
     const size_t qbytes = pad((size_t)nq * 32) + pad((size_t)nq * 8) + 6 * pad((size_t)nq * 4) + 2 * pad(nq);
     hipStream_t s = ctx->stream;
     return in_cells_core(

@@ -362,6 +362,7 @@ int svgpu_match_current_and_last_frames(svgpu_ctx* ctx, const svgpu_camera* cam,
                                         const uint8_t* tdesc, const float* t_xy, const int32_t* t_octave, const float* t_angle, int nt,
                                         const uint8_t* occupied, const float* t_xright, int grid_cols, int grid_rows, int check_orientation,
                                         int32_t* match_last, int* num_matches) {
+    const svgpu_frame* const bound = sv_take_bound_frame(ctx);  // one-shot: consumed before anything can fail
     if (!ctx || !cam || !rot_cw || !trans_cw || !rot_lw || !trans_lw || (n_last > 0 && !octave_last))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_current_and_last_frames: bad arguments");
     for (int i = 0; i < n_last; ++i)
@@ -374,7 +375,7 @@ int svgpu_match_current_and_last_frames(svgpu_ctx* ctx, const svgpu_camera* cam,
     const bool bwd = is_monocular ? false : -trans_lc[2] > (double)true_baseline;
     ProjQueries Q{n_last, pos_w, nullptr, nullptr, nullptr, valid, octave_last, lm_desc, angle_last, lm_has_observation};
     ProjOpts O{2, 2, 0, fwd ? 1 : (bwd ? 2 : 0), margin, check_orientation, 100u, 0.f, SVGPU_MATCH_BEST_ONLY, 1, 0, 0, nullptr};
-    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, true, true, grid_cols, grid_rows);
+    const InCellsFrame F = frame_side(bound, cam, tdesc, t_xy, t_octave, nt, occupied, t_angle, t_xright, true, true, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_match_current_and_last_frames: bad arguments", cam, rot_cw, trans_cw, trans_wc, Q, num_levels, scale_factors, 1.f, F, O,
                       match_last, num_matches, nullptr, nullptr, nullptr, nullptr);
 }
@@ -385,12 +386,13 @@ int svgpu_match_frame_and_keyframe_projection(svgpu_ctx* ctx, const svgpu_camera
                                               float log_scale_factor, float margin, unsigned hamm_dist_thr, const uint8_t* tdesc, const float* t_xy,
                                               const int32_t* t_octave, const float* t_angle, int nt, const uint8_t* occupied, int grid_cols,
                                               int grid_rows, int check_orientation, int32_t* match_kf, int* num_matches) {
+    const svgpu_frame* const bound = sv_take_bound_frame(ctx);  // one-shot: consumed before anything can fail
     if (!ctx || !cam || !rot_cw || !trans_cw) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_frame_and_keyframe_projection: bad arguments");
     double center[3];
     cam_center(rot_cw, trans_cw, center);  // projection.cc:223
     ProjQueries Q{n_kf, pos_w, nullptr, min_valid_dist, max_valid_dist, valid, nullptr, lm_desc, angle_kf, nullptr};
     ProjOpts O{1, 2, 0, 0, margin, check_orientation, hamm_dist_thr, 0.f, SVGPU_MATCH_BEST_ONLY, 0, 0, 0, nullptr};
-    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, occupied, t_angle, nullptr, true, false, grid_cols, grid_rows);
+    const InCellsFrame F = frame_side(bound, cam, tdesc, t_xy, t_octave, nt, occupied, t_angle, nullptr, true, false, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_match_frame_and_keyframe_projection: bad arguments", cam, rot_cw, trans_cw, center, Q, num_levels, scale_factors,
                       log_scale_factor, F, O, match_kf, num_matches, nullptr, nullptr, nullptr, nullptr);
 }
@@ -400,6 +402,7 @@ int svgpu_match_by_sim3_transform(svgpu_ctx* ctx, const svgpu_camera* cam, const
                                   int num_levels, const float* scale_factors, float log_scale_factor, float margin, const uint8_t* tdesc,
                                   const float* t_xy, const int32_t* t_octave, int nt, const uint8_t* occupied, int grid_cols, int grid_rows,
                                   int32_t* match_lm, int* num_matches) {
+    const svgpu_frame* const bound = sv_take_bound_frame(ctx);  // one-shot: consumed before anything can fail
     if (!ctx || !cam || !sim3_cw) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_by_sim3_transform: bad arguments");
     // Sim3 -> SE3, projection.cc:326-330
     const double s_cw = std::sqrt((sim3_cw[0] * sim3_cw[0] + sim3_cw[1] * sim3_cw[1]) + sim3_cw[2] * sim3_cw[2]);
@@ -411,7 +414,7 @@ int svgpu_match_by_sim3_transform(svgpu_ctx* ctx, const svgpu_camera* cam, const
     cam_center(rot, trans, center);
     ProjQueries Q{n, pos_w, mean_normal, min_valid_dist, max_valid_dist, valid, nullptr, lm_desc, nullptr, nullptr};
     ProjOpts O{1, 1, 0, 0, margin, 0, 50u, 0.f, SVGPU_MATCH_BEST_ONLY, 0, 0, 0, nullptr};
-    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, occupied, nullptr, nullptr, false, false, grid_cols, grid_rows);
+    const InCellsFrame F = frame_side(bound, cam, tdesc, t_xy, t_octave, nt, occupied, nullptr, nullptr, false, false, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_match_by_sim3_transform: bad arguments", cam, rot, trans, center, Q, num_levels, scale_factors, log_scale_factor, F, O,
                       match_lm, num_matches, nullptr, nullptr, nullptr, nullptr);
 }
@@ -483,12 +486,13 @@ int svgpu_fuse_detect_duplication(svgpu_ctx* ctx, const svgpu_camera* cam, const
                                   float log_scale_factor, float margin, int do_reprojection_matching, const uint8_t* tdesc, const float* t_xy,
                                   const int32_t* t_octave, const float* t_xright, int nt, int grid_cols, int grid_rows, int32_t* best_idx,
                                   int* num_fused) {
+    const svgpu_frame* const bound = sv_take_bound_frame(ctx);  // one-shot: consumed before anything can fail
     if (!ctx || !cam || !rot_cw || !trans_cw) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_fuse_detect_duplication: bad arguments");
     double center[3];
     cam_center(rot_cw, trans_cw, center);  // fuse.cc:20
     ProjQueries Q{n, pos_w, mean_normal, min_valid_dist, max_valid_dist, valid, nullptr, lm_desc, nullptr, nullptr};
     ProjOpts O{1, 1, 0, 0, margin, 0, 50u, 0.f, SVGPU_MATCH_BEST_ONLY, 0, do_reprojection_matching ? 1 : 0, 0, inv_level_sigma_sq};
-    const InCellsFrame F = frame_side(sv_take_bound_frame(ctx), cam, tdesc, t_xy, t_octave, nt, nullptr, nullptr, t_xright, false, true, grid_cols, grid_rows);
+    const InCellsFrame F = frame_side(bound, cam, tdesc, t_xy, t_octave, nt, nullptr, nullptr, t_xright, false, true, grid_cols, grid_rows);
     return proj_match(ctx, "svgpu_fuse_detect_duplication: bad arguments", cam, rot_cw, trans_cw, center, Q, num_levels, scale_factors, log_scale_factor, F,
                       O, best_idx, num_fused, nullptr, nullptr, nullptr, nullptr);
 }

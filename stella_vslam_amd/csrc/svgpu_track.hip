@@ -24,7 +24,7 @@ struct svgpu_tracker {
     // capacities
     int cap_kp = 0;       // keypoints of the current frame
     int cap_q = 0;        // queries (last frame's keypoints / local landmarks)
-    size_t cap_cand = 0;  // candidate-list entries
+    size_t cap_cand = 0;  // candidate-list entries BEHIND the per-query slots (lists longer than TRACK_SLOT)
     size_t img_bytes = 0; // image part of the input block
     // device
     char* d_in = nullptr;    // input block: [image] | ids ...
@@ -93,7 +93,7 @@ int reserve(svgpu_tracker* t, int kp, int q, size_t cand, size_t img_bytes, size
         return o;
     };
     const size_t o_off = take((size_t)(cq + 1) * 4), o_cnt = take((size_t)cq * 4), o_mq = take((size_t)cq * 4), o_num = take(16), o_who = take((size_t)ckp * 4),
-                 o_kpof = take((size_t)ckp * 4), o_pl = take((size_t)cq * 4), o_dist = take(cc * 4), o_qv = take(cq), o_qb = take(cq), o_occ = take(ckp),
+                 o_kpof = take((size_t)ckp * 4), o_pl = take((size_t)cq * 4), o_dist = take(((size_t)cq * TRACK_SLOT + cc) * 4), o_qv = take(cq), o_qb = take(cq), o_occ = take(ckp),
                  o_vis = take(cq), o_okp = take(ckp), o_poo = take(ckp), o_pol = take(ckp), o_por = take(ckp), o_rp = take((size_t)cq * 16),
                  o_pos = take((size_t)ckp * 24), o_xr = take((size_t)cq * 4), o_uvr = take((size_t)ckp * 12), o_w = take((size_t)ckp * 4), o_h = take((size_t)ckp * 4),
                  o_res = take(16), o_clm = take((size_t)ckp * 4), o_pose = take(96), o_gown = take((size_t)ckp * 4), o_gmat = take((size_t)cq * 4);

@@ -59,10 +59,10 @@ struct TrackCandProblem {
     int nt;
     uint8_t* occupied;          // nt
     // outputs
-    int32_t* cand_off;          // nq + 1; [nq] = allocation counter (zero on entry)
+    int32_t* cand_off;          // nq + 1; [nq] = allocation counter of the lists beyond their slot (zero on entry)
     int32_t* cand_cnt;          // nq
-    uint32_t* dist;             // cap entries: (distance << 22) | keypoint, 0xFFFFFFFF = gated out; lists up to 1 024 entries sorted
-    int cap;
+    uint32_t* dist;             // nq * TRACK_SLOT + cap entries: (distance << 22) | keypoint, 0xFFFFFFFF = gated out; lists up to 1 024 entries sorted
+    int cap;                    // entries behind the slots
     uint8_t* q_valid;           // nq
     uint8_t* q_blocks;          // nq: the landmark has observations (an accepted match then closes its keypoint for later queries)
     uint8_t* visible;           // mode 1, nq
@@ -71,4 +71,5 @@ struct TrackCandProblem {
     int32_t* pred_level;        // mode 1
     uint8_t* visible_host;      // nullable, page-locked
 };
+#define TRACK_SLOT 64  // entries of a query's own list slot (longer lists are appended behind the slots)
 void sv_launch_track_cand(svgpu_ctx* ctx, hipStream_t s, const TrackCandProblem& P);

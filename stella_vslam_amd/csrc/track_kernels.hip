@@ -50,7 +50,12 @@ __device__ __forceinline__ void wave_lds_sync() {  // orders the wave's own LDS 
 }
 
 #define TRACK_SORT_MAX 1024  // == CAND_SORT_MAX of match_kernels.hip: lists up to this many entries are left sorted by (distance, scan position)
+#define TRACK_CACHE 4        // passing keypoints of a cell kept in registers between the counting and the distance loop
 
+// List placement.  A list of at most TRACK_SLOT entries lives in its query's own slot (dist[q * TRACK_SLOT ...]): no allocation, no shared
+// counter.  Longer lists (wide windows at the coarse levels: a few per frame) are appended behind the slots through ONE atomic counter
+// (cand_off[nq], counting overflow entries only).  (First form: every list allocated from the counter after a counting walk -- 66 us per
+// launch at 2 400 - 4 800 queries, whatever their number: thousands of same-address atomics and two dependent walks per query.)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
     __shared__ unsigned long long s_keys[4][TRACK_SORT_MAX];
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
             P.pred_level[q] = o.vis ? o.level : -1;
         }
     }
-    int total = 0, list_off = 0;
+    int total = 0, list_off = q * TRACK_SLOT;
     if (live) {
         float ref_x, ref_y, margin;
         int min_level, max_level;
@@ -131,105 +136,107 @@ __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
                 const float dx = P.t_xy[2 * idx] - ref_x, dy = P.t_xy[2 * idx + 1] - ref_y;
                 return fabsf(dx) < margin && fabsf(dy) < margin;
             };
-            // pass 1: the list's length
-            for (int base = 0; base < ncell; base += 64) {
-                const int k = base + lane;
-                int n = 0;
-                if (k < ncell) {
-                    const int c = (lo_x + k / ny) * P.rows + lo_y + k % ny;
-                    for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) n += passes(P.cell_items[it]) ? 1 : 0;
+            auto entry = [&](int t) -> uint32_t {  // gates of projection.cc:52-62, 172-181 + the Hamming distance; 0xFFFFFFFF = gated out
+                if (P.t_xright && 0.f < P.t_xright[t]) {
+                    const float err = fabsf(o.xr - P.t_xright[t]);
+                    if (margin < err) return 0xFFFFFFFFu;
                 }
-                int incl = n;
-                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
-                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
-                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
-                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
-                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15
-                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31
-                total += __builtin_amdgcn_readlane(incl, 63);
-            }
-            if (total > 0) {
-                int off = 0;
-                if (lane == 0) off = atomicAdd(&P.cand_off[P.nq], total);  // the list's place: any order, the replay goes through cand_off / cand_cnt
-                list_off = __builtin_amdgcn_readfirstlane(off);
-                const bool fits = list_off + total <= P.cap;  // beyond the capacity nothing is written: the host re-runs the chain with a larger one
-                const bool in_lds = total <= TRACK_SORT_MAX;
-                // pass 2: gates + distance of every candidate, at its scan position
+                if (MODE == 0 && P.check_orientation && fabsf(angle_diff(q_angle, P.t_angle[t])) > 30.0f) return 0xFFFFFFFFu;
+                return (hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
+            };
+            // `sink(pos, e)` receives every candidate at its scan position (the reference's candidate order)
+            auto walk = [&](auto&& sink) {
                 int done = 0;
-                for (int base = 0; base < ncell && fits; base += 64) {
+                for (int base = 0; base < ncell; base += 64) {
                     const int k = base + lane;
-                    int n = 0, c = 0;
+                    int n = 0, c = 0, cached[TRACK_CACHE];
                     if (k < ncell) {
                         c = (lo_x + k / ny) * P.rows + lo_y + k % ny;
-                        for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) n += passes(P.cell_items[it]) ? 1 : 0;
+                        for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) {
+                            const int idx = P.cell_items[it];
+                            if (!passes(idx)) continue;
+#pragma unroll
+                            for (int u = 0; u < TRACK_CACHE; ++u)
+                                if (n == u) cached[u] = idx;
+                            ++n;
+                        }
                     }
+                    // inclusive prefix sum over the lanes: DPP row scans
                     int incl = n;
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
-                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
-                    if (n > 0) {
-                        int pos = done + incl - n;
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15
+                    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31
+                    int pos = done + incl - n;
+                    if (n > 0 && n <= TRACK_CACHE) {
+#pragma unroll
+                        for (int u = 0; u < TRACK_CACHE; ++u)
+                            if (u < n) sink(pos + u, entry(cached[u]));
+                    }
+                    else if (n > TRACK_CACHE) {  // a crowded cell: walk it again
                         for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) {
                             const int t = P.cell_items[it];
-                            if (!passes(t)) continue;
-                            bool gated = false;
-                            if (P.t_xright && 0.f < P.t_xright[t]) {  // projection.cc:57-62, 172-177
-                                const float err = fabsf(o.xr - P.t_xright[t]);
-                                if (margin < err) gated = true;
-                            }
-                            if (MODE == 0 && P.check_orientation && !gated && fabsf(angle_diff(q_angle, P.t_angle[t])) > 30.0f) gated = true;  // :179-181
-                            const unsigned d = gated ? 0u : hamming256(qd, P.tdesc + (size_t)t * 8);
-                            if (in_lds) s_key[pos] = gated ? ~0ull : ((unsigned long long)d << 32) | ((unsigned long long)pos << 22) | (unsigned)t;
-                            else P.dist[list_off + pos] = gated ? 0xFFFFFFFFu : (d << 22) | (uint32_t)t;
-                            ++pos;
+                            if (passes(t)) sink(pos++, entry(t));
                         }
                     }
                     done += __builtin_amdgcn_readlane(incl, 63);
                 }
-                if (fits && in_lds) {  // (distance, scan position) order: gated entries last (k_cand_dist's order, which the replay's walks rely on)
-                    wave_lds_sync();
-                    if (total <= 64) {
-                        unsigned long long key = lane < total ? s_key[lane] : ~0ull;
+                return done;
+            };
+            // ONE walk: entries go to the wave's LDS strip while they fit it
+            total = walk([&](int pos, uint32_t e) {
+                if (pos < TRACK_SORT_MAX) s_key[pos] = e == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(e >> 22) << 32) | ((unsigned long long)pos << 22) | (e & 0x3FFFFFu);
+            });
+            bool fits = true;
+            if (total > TRACK_SLOT) {  // beyond the slot: appended behind the slots
+                int off = 0;
+                if (lane == 0) off = atomicAdd(&P.cand_off[P.nq], total);
+                off = __builtin_amdgcn_readfirstlane(off);
+                fits = off + total <= P.cap;  // beyond the capacity nothing is written: the host re-runs the chain with a larger one
+                list_off = P.nq * TRACK_SLOT + off;
+            }
+            wave_lds_sync();
+            if (fits && total <= 64) {  // (distance, scan position) order: gated entries last (k_cand_dist's order, which the replay's walks rely on)
+                unsigned long long key = lane < total ? s_key[lane] : ~0ull;
 #pragma unroll
-                        for (int k = 2; k <= 64; k <<= 1)
+                for (int k = 2; k <= 64; k <<= 1)
 #pragma unroll
-                            for (int j = k >> 1; j > 0; j >>= 1) {
-                                const unsigned long long other = __shfl_xor(key, j, 64);
-                                const bool up = (lane & k) == 0, low = (lane & j) == 0;
-                                const bool take_min = up == low;
-                                key = take_min ? (key < other ? key : other) : (key < other ? other : key);
-                            }
-                        if (lane < total) P.dist[list_off + lane] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        const unsigned long long other = __shfl_xor(key, j, 64);
+                        const bool up = (lane & k) == 0, low = (lane & j) == 0;
+                        const bool take_min = up == low;
+                        key = take_min ? (key < other ? key : other) : (key < other ? other : key);
                     }
-                    else {
-                        int npow2 = 128;
-                        while (npow2 < total) npow2 <<= 1;
-                        for (int i = total + lane; i < npow2; i += 64) s_key[i] = ~0ull;
-                        wave_lds_sync();
-                        for (int k = 2; k <= npow2; k <<= 1)
-                            for (int j = k >> 1; j > 0; j >>= 1) {
-                                for (int i = lane; i < npow2; i += 64) {
-                                    const int p = i ^ j;
-                                    if (p > i) {
-                                        const unsigned long long a = s_key[i], b = s_key[p];
-                                        if ((a > b) == ((i & k) == 0)) {
-                                            s_key[i] = b;
-                                            s_key[p] = a;
-                                        }
-                                    }
+                if (lane < total) P.dist[list_off + lane] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
+            }
+            else if (fits && total <= TRACK_SORT_MAX) {
+                int npow2 = 128;
+                while (npow2 < total) npow2 <<= 1;
+                for (int i = total + lane; i < npow2; i += 64) s_key[i] = ~0ull;
+                wave_lds_sync();
+                for (int k = 2; k <= npow2; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = lane; i < npow2; i += 64) {
+                            const int p = i ^ j;
+                            if (p > i) {
+                                const unsigned long long a = s_key[i], b = s_key[p];
+                                if ((a > b) == ((i & k) == 0)) {
+                                    s_key[i] = b;
+                                    s_key[p] = a;
                                 }
-                                wave_lds_sync();
                             }
-                        for (int i = lane; i < total; i += 64) {
-                            const unsigned long long key = s_key[i];
-                            P.dist[list_off + i] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
                         }
+                        wave_lds_sync();
                     }
+                for (int i = lane; i < total; i += 64) {
+                    const unsigned long long key = s_key[i];
+                    P.dist[list_off + i] = key == ~0ull ? 0xFFFFFFFFu : ((uint32_t)(key >> 32) << 22) | (uint32_t)(key & 0x3FFFFFu);
                 }
             }
+            else if (fits)  // longer than the sorted form goes: a second walk writes the list as it is scanned (the replay walks such lists in full)
+                walk([&](int pos, uint32_t e) { P.dist[list_off + pos] = e; });
         }
     }
     if (lane == 0) {

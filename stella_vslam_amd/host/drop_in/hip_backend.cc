@@ -72,20 +72,24 @@ svgpu_camera to_svgpu_camera(const camera::base* camera) {
 
 #ifndef SVGPU_DROP_IN_OPTIMIZE_ONLY
 // ---- resident frame observations
+// Thread model (tracking, mapping and loop-closing threads share this cache): an entry is a REFERENCE-COUNTED handle.  A caller keeps its
+// handle for the duration of its matcher call, so eviction, forget_*() or a replacement on another thread only drop the cache's own
+// reference -- the device arrays live until the last in-flight call has returned.  A stale entry is never re-uploaded in place: a new
+// frame is built (outside the lock: an upload is a synchronous copy) and swapped in.
 namespace {
 static_assert(sizeof(cv::KeyPoint) == sizeof(svgpu_keypoint), "cv::KeyPoint and svgpu_keypoint share the 28-byte layout");
 struct resident_entry {
-    svgpu_frame* f = nullptr;
-    uint64_t fingerprint = 0, stamp = 0;
-    bool adopted = false;  // built by adopt_extraction; the first matcher call completes the fingerprint (and the stereo part)
+    frame_handle f;
+    uint64_t full_hash = 0, kp_hash = 0, stamp = 0;
+    const void *desc_ptr = nullptr, *kp_ptr = nullptr;  // host buffers the hash was taken over: the same buffers + size + samples = verified before
+    uint64_t sample = 0;
+    size_t n = 0;
+    bool adopted = false;  // built on the device from an extraction: the first matcher call completes the identity (and the stereo part)
 };
 struct resident_store {
     std::mutex mtx;
     std::map<std::pair<int, unsigned int>, resident_entry> entries;  // (0 frame | 1 keyframe, id)
     uint64_t clock = 0;
-    ~resident_store() {
-        for (auto& kv : entries) svgpu_frame_destroy(kv.second.f);
-    }
 };
 resident_store& store() {
     static resident_store s;
@@ -96,115 +100,189 @@ bool resident_enabled() {
     static const bool off = std::getenv("SVGPU_NO_RESIDENT_FRAMES") != nullptr;
     return !off;
 }
-uint64_t fnv(uint64_t h, const void* p, size_t n) {
+// 8 bytes per step (the arrays are ~150 KB per frame: a byte-wise FNV would cost more than the upload it saves)
+uint64_t mix(uint64_t h, const void* p, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
-    return h;
-}
-// cheap identity check of an observation under an id (ids are unique in a running system; test fixtures reuse them)
-uint64_t fingerprint(const data::frame_observation& o, const camera::base* cam) {
-    const size_t n = o.undist_keypts_.size();
-    uint64_t h = 1469598103934665603ull;
-    h = fnv(h, &n, sizeof n);
-    if (n > 0) {
-        h = fnv(h, o.descriptors_.ptr(0), 32);
-        h = fnv(h, o.descriptors_.ptr((int)n - 1), 32);
-        h = fnv(h, o.descriptors_.ptr((int)(n / 2)), 32);
-        h = fnv(h, &o.undist_keypts_[0], sizeof(cv::KeyPoint));
-        h = fnv(h, &o.undist_keypts_[n - 1], sizeof(cv::KeyPoint));
-        h = fnv(h, &o.undist_keypts_[n / 2], sizeof(cv::KeyPoint));
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
     }
-    const size_t nx = o.stereo_x_right_.size();
-    h = fnv(h, &nx, sizeof nx);
-    if (nx > 0) h = fnv(h, o.stereo_x_right_.data(), sizeof(float) * std::min<size_t>(nx, 8));
-    h = fnv(h, &cam->img_bounds_, sizeof cam->img_bounds_);
-    h = fnv(h, &o.num_grid_cols_, sizeof o.num_grid_cols_);
-    h = fnv(h, &o.num_grid_rows_, sizeof o.num_grid_rows_);
+    uint64_t tail = 0;
+    if (i < n) std::memcpy(&tail, b + i, n - i);
+    h = (h ^ tail ^ (uint64_t)n) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 32);
+}
+uint64_t keypoint_hash(const std::vector<cv::KeyPoint>& k) { return mix(0x243F6A8885A308D3ull, k.data(), k.size() * sizeof(cv::KeyPoint)); }
+// identity of an observation under an id: EVERY descriptor and keypoint, the stereo column, the camera bounds and the grid
+uint64_t full_hash(const data::frame_observation& o, const camera::base* cam) {
+    const size_t n = o.undist_keypts_.size();
+    uint64_t h = keypoint_hash(o.undist_keypts_);
+    if (n > 0) {
+        if (o.descriptors_.isContinuous()) h = mix(h, o.descriptors_.ptr(0), n * 32);
+        else
+            for (size_t i = 0; i < n; ++i) h = mix(h, o.descriptors_.ptr((int)i), 32);
+    }
+    h = mix(h, o.stereo_x_right_.data(), o.stereo_x_right_.size() * sizeof(float));
+    h = mix(h, &cam->img_bounds_, sizeof cam->img_bounds_);
+    h = mix(h, &o.num_grid_cols_, sizeof o.num_grid_cols_);
+    return mix(h, &o.num_grid_rows_, sizeof o.num_grid_rows_);
+}
+// a few samples: together with unchanged buffer addresses and size, "nothing was edited since the full hash was taken"
+uint64_t sample_hash(const data::frame_observation& o) {
+    const size_t n = o.undist_keypts_.size();
+    uint64_t h = 0x13198A2E03707344ull ^ n ^ ((uint64_t)o.stereo_x_right_.size() << 32);
+    for (size_t k = 0; k < 4 && n > 0; ++k) {
+        const size_t i = (n - 1) * k / 3;
+        h = mix(h, o.descriptors_.ptr((int)i), 32);
+        h = mix(h, &o.undist_keypts_[i], sizeof(cv::KeyPoint));
+    }
     return h;
 }
+// Frames are recycled: a tracked frame lives for one image, and building a svgpu_frame is three device allocations (and releasing it three
+// frees, each a device-wide synchronisation) -- more than the frame's whole matcher chain costs.  The deleter of a handle parks the frame
+// in a small pool (grow-only slabs: a recycled frame is as good as a new one), new_frame() takes from it.
+struct frame_pool {
+    std::mutex mtx;
+    std::vector<svgpu_frame*> parked;
+};
+frame_pool& pool() {
+    // never destroyed: handles held by other statics (the resident cache) are released during static destruction and park their frames
+    // here, in an order nobody controls; the device memory goes with the process
+    static frame_pool* const p = new frame_pool();
+    return *p;
+}
+constexpr size_t FRAME_POOL_CAPACITY = 16;
+void park_frame(svgpu_frame* f) {
+    if (!f) return;
+    frame_pool& P = pool();
+    {
+        std::lock_guard<std::mutex> lock(P.mtx);
+        if (P.parked.size() < FRAME_POOL_CAPACITY) {
+            P.parked.push_back(f);
+            return;
+        }
+    }
+    svgpu_frame_destroy(f);
+}
+}  // namespace
+frame_handle new_frame(svgpu_ctx* ctx) {
+    svgpu_frame* raw = nullptr;
+    {
+        frame_pool& P = pool();
+        std::lock_guard<std::mutex> lock(P.mtx);
+        if (!P.parked.empty()) {
+            raw = P.parked.back();
+            P.parked.pop_back();
+        }
+    }
+    if (!raw) check(svgpu_frame_create(ctx, &raw), "svgpu_frame_create");
+    return frame_handle(raw, park_frame);
+}
+namespace {
+frame_handle make_frame(svgpu_ctx* ctx) { return new_frame(ctx); }
 void evict_if_full(resident_store& S) {
     while (S.entries.size() > RESIDENT_CAPACITY) {
         auto oldest = S.entries.begin();
         for (auto it = S.entries.begin(); it != S.entries.end(); ++it)
             if (it->second.stamp < oldest->second.stamp) oldest = it;
-        svgpu_frame_destroy(oldest->second.f);
-        S.entries.erase(oldest);
+        S.entries.erase(oldest);  // (drops the cache's reference only)
     }
 }
-const svgpu_frame* resident_of(int kind, unsigned int id, const data::frame_observation& o, const camera::base* cam) {
+frame_handle resident_of(int kind, unsigned int id, const data::frame_observation& o, const camera::base* cam) {
     if (!resident_enabled() || !cam) return nullptr;
     resident_store& S = store();
-    const uint64_t fp = fingerprint(o, cam);
-    std::lock_guard<std::mutex> lock(S.mtx);
-    resident_entry& e = S.entries[std::make_pair(kind, id)];
-    e.stamp = ++S.clock;
-    if (e.f && e.fingerprint == fp) return e.f;
-    if (e.f && e.adopted && svgpu_frame_size(e.f) == (int)o.undist_keypts_.size()) {
-        e.adopted = false;
-        e.fingerprint = fp;
-        if (!o.stereo_x_right_.empty()) check(svgpu_frame_set_stereo(context(), e.f, o.stereo_x_right_.data()), "svgpu_frame_set_stereo");
-        return e.f;
+    const size_t n = o.undist_keypts_.size();
+    const void* const dp = n > 0 ? static_cast<const void*>(o.descriptors_.ptr(0)) : nullptr;
+    const void* const kp = static_cast<const void*>(o.undist_keypts_.data());
+    const uint64_t smp = sample_hash(o);
+    const auto key = std::make_pair(kind, id);
+    resident_entry seen;
+    {
+        std::lock_guard<std::mutex> lock(S.mtx);
+        auto it = S.entries.find(key);
+        if (it != S.entries.end()) {
+            resident_entry& e = it->second;
+            e.stamp = ++S.clock;
+            if (e.f && !e.adopted && e.n == n && e.desc_ptr == dp && e.kp_ptr == kp && e.sample == smp) return e.f;
+            seen = e;
+        }
     }
+    // slow path, outside the lock: the full identity, then (if it is a different observation) a NEW resident frame
+    const uint64_t full = full_hash(o, cam);
+    frame_handle f;
+    if (seen.f && !seen.adopted && seen.full_hash == full) f = seen.f;  // the same observation in other host buffers (a frame copy)
+    else if (seen.f && seen.adopted && (size_t)svgpu_frame_size(seen.f.get()) == n && seen.kp_hash == keypoint_hash(o.undist_keypts_)) {
+        // adopted from the extractor: the keypoints are the ones handed back at adoption; the stereo column arrives now
+        if (!o.stereo_x_right_.empty()) check(svgpu_frame_set_stereo(context(), seen.f.get(), o.stereo_x_right_.data()), "svgpu_frame_set_stereo");
+        f = seen.f;
+    }
+    else {
+        f = make_frame(context());
+        const svgpu_camera c = to_svgpu_camera(cam);
+        std::vector<uint8_t> desc(n * 32);
+        for (size_t i = 0; i < n; ++i) std::memcpy(&desc[i * 32], o.descriptors_.ptr((int)i), 32);
+        check(svgpu_frame_upload(context(), f.get(), &c, reinterpret_cast<const svgpu_keypoint*>(o.undist_keypts_.data()), desc.data(),
+                                 o.stereo_x_right_.empty() ? nullptr : o.stereo_x_right_.data(), (int)n, (int)o.num_grid_cols_, (int)o.num_grid_rows_),
+              "svgpu_frame_upload");
+    }
+    std::lock_guard<std::mutex> lock(S.mtx);
+    resident_entry& e = S.entries[key];
+    e.f = f;
+    e.full_hash = full, e.sample = smp, e.desc_ptr = dp, e.kp_ptr = kp, e.n = n;
     e.adopted = false;
-    if (!e.f) check(svgpu_frame_create(context(), &e.f), "svgpu_frame_create");
-    const svgpu_camera c = to_svgpu_camera(cam);
-    const int n = (int)o.undist_keypts_.size();
-    std::vector<uint8_t> desc((size_t)n * 32);
-    for (int i = 0; i < n; ++i) std::memcpy(&desc[(size_t)i * 32], o.descriptors_.ptr(i), 32);
-    check(svgpu_frame_upload(context(), e.f, &c, reinterpret_cast<const svgpu_keypoint*>(o.undist_keypts_.data()), desc.data(),
-                             o.stereo_x_right_.empty() ? nullptr : o.stereo_x_right_.data(), n, (int)o.num_grid_cols_, (int)o.num_grid_rows_),
-          "svgpu_frame_upload");
-    e.fingerprint = fp;
+    e.stamp = ++S.clock;
     evict_if_full(S);
-    return e.f;
+    return f;
 }
 }  // namespace
 
-const svgpu_frame* resident(const data::frame& frm) { return resident_of(0, frm.id_, frm.frm_obs_, frm.camera_); }
-const svgpu_frame* resident(const std::shared_ptr<data::keyframe>& keyfrm) { return resident_of(1, keyfrm->id_, keyfrm->frm_obs_, keyfrm->camera_); }
+frame_handle resident(const data::frame& frm) { return resident_of(0, frm.id_, frm.frm_obs_, frm.camera_); }
+frame_handle resident(const std::shared_ptr<data::keyframe>& keyfrm) { return resident_of(1, keyfrm->id_, keyfrm->frm_obs_, keyfrm->camera_); }
 
 void adopt_extraction(unsigned int frame_id, svgpu_ctx* extractor_ctx, const camera::base* camera, unsigned int num_grid_cols, unsigned int num_grid_rows,
                       std::vector<cv::KeyPoint>& undist_keypts, eigen_alloc_vector<Vec3_t>& bearings) {
     const svgpu_camera c = to_svgpu_camera(camera);
-    resident_store& S = store();
-    std::lock_guard<std::mutex> lock(S.mtx);
-    resident_entry& e = S.entries[std::make_pair(0, frame_id)];
-    e.stamp = ++S.clock;
-    if (!e.f) check(svgpu_frame_create(extractor_ctx, &e.f), "svgpu_frame_create");
+    frame_handle f = make_frame(extractor_ctx);
     // worst-case sized host buffers: the extractor's count is only known to the device side here
     const int cap = std::max(1, svgpu_orb_max_keypoints(extractor_ctx));
     std::vector<svgpu_keypoint> und(cap);
     std::vector<double> brg((size_t)cap * 3);
-    const int rc = svgpu_frame_adopt_extraction(extractor_ctx, e.f, &c, (int)num_grid_cols, (int)num_grid_rows, und.data(), brg.data());
+    const int rc = svgpu_frame_adopt_extraction(extractor_ctx, f.get(), &c, (int)num_grid_cols, (int)num_grid_rows, und.data(), brg.data());
     if (rc != SVGPU_OK) throw std::runtime_error(std::string("svgpu_frame_adopt_extraction: ") + svgpu_last_error(extractor_ctx));
-    const int n = svgpu_frame_size(e.f);
+    const int n = svgpu_frame_size(f.get());
     undist_keypts.resize(n);
     std::memcpy(static_cast<void*>(undist_keypts.data()), und.data(), (size_t)n * sizeof(svgpu_keypoint));
     bearings.resize(n);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) bearings[i](k) = brg[3 * (size_t)i + k];
-    e.fingerprint = 0;  // completed by the first matcher call, which sees the caller's host copy of the observation
+    register_adopted(frame_id, f, undist_keypts);
+}
+
+void register_adopted(unsigned int frame_id, const frame_handle& f, const std::vector<cv::KeyPoint>& undist_keypts) {
+    resident_store& S = store();
+    std::lock_guard<std::mutex> lock(S.mtx);
+    resident_entry& e = S.entries[std::make_pair(0, frame_id)];
+    e = resident_entry();
+    e.f = f;
+    e.kp_hash = keypoint_hash(undist_keypts);  // the first matcher call sees the caller's host copy of the observation: it must be THIS one
+    e.n = undist_keypts.size();
     e.adopted = true;
+    e.stamp = ++S.clock;
     evict_if_full(S);
 }
 
 void forget_frame(unsigned int frame_id) {
     resident_store& S = store();
     std::lock_guard<std::mutex> lock(S.mtx);
-    auto it = S.entries.find(std::make_pair(0, frame_id));
-    if (it != S.entries.end()) {
-        svgpu_frame_destroy(it->second.f);
-        S.entries.erase(it);
-    }
+    S.entries.erase(std::make_pair(0, frame_id));
 }
 void forget_keyframe(unsigned int keyframe_id) {
     resident_store& S = store();
     std::lock_guard<std::mutex> lock(S.mtx);
-    auto it = S.entries.find(std::make_pair(1, keyframe_id));
-    if (it != S.entries.end()) {
-        svgpu_frame_destroy(it->second.f);
-        S.entries.erase(it);
-    }
+    S.entries.erase(std::make_pair(1, keyframe_id));
 }
 #endif  // SVGPU_DROP_IN_OPTIMIZE_ONLY
 
@@ -462,7 +540,8 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
                                                    std::unordered_map<unsigned int, unsigned int>& lm_to_scale, const float margin) const {
     // the caller has already run frame::can_observe (tracking_module.cc:554-594): the queries are its reprojections
     const int n = (int)local_landmarks.size();
-    const svgpu_frame* rf = stella_vslam::hip::resident(frm);  // the frame's keypoint side stays on the device between the matchers of a tracked frame
+    const auto rfh = stella_vslam::hip::resident(frm);  // the frame's keypoint side stays on the device between the matchers of a tracked frame
+    const svgpu_frame* const rf = rfh.get();  // (the handle keeps the device arrays alive for the duration of this call, whatever other threads do to the cache)
     kp_side s;
     if (rf) s.n = (int)frm.frm_obs_.undist_keypts_.size();
     else s = flatten(frm.frm_obs_);
@@ -512,7 +591,8 @@ unsigned int projection::match_frame_and_landmarks(data::frame& frm, const std::
 }
 
 unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, const data::frame& last_frm, const float margin) const {
-    const svgpu_frame* rf = stella_vslam::hip::resident(curr_frm);
+    const auto rfh = stella_vslam::hip::resident(curr_frm);
+    const svgpu_frame* const rf = rfh.get();
     const kp_side sl = flatten(last_frm.frm_obs_);
     kp_side sc;
     if (rf) sc.n = (int)curr_frm.frm_obs_.undist_keypts_.size();
@@ -550,7 +630,8 @@ unsigned int projection::match_current_and_last_frames(data::frame& curr_frm, co
 unsigned int projection::match_frame_and_keyframe(data::frame& curr_frm, const kf_ptr& keyfrm, const std::set<lm_ptr>& already_matched_lms, const float margin,
                                                   const unsigned int hamm_dist_thr) const {
     auto lms = curr_frm.get_landmarks();  // projection.cc:209-215
-    if (const svgpu_frame* rf = stella_vslam::hip::resident(curr_frm)) check(svgpu_frame_bind(context(), rf), "svgpu_frame_bind");
+    const auto rfh = stella_vslam::hip::resident(curr_frm);  // (kept until the matcher below has returned)
+    if (rfh) check(svgpu_frame_bind(context(), rfh.get()), "svgpu_frame_bind");
     auto num_matches = match_frame_and_keyframe(curr_frm.get_pose_cw(), curr_frm.camera_, curr_frm.frm_obs_, curr_frm.orb_params_, lms, keyfrm, already_matched_lms,
                                                 margin, hamm_dist_thr);
     curr_frm.set_landmarks(lms);
@@ -589,7 +670,7 @@ unsigned int projection::match_by_Sim3_transform(const kf_ptr& keyfrm, const Mat
     already_matched.erase(nullptr);
     const lm_set L = flatten(landmarks, [&](const lm_ptr& lm, int) { return already_matched.count(lm) == 0; });
     const kp_side s = flatten(keyfrm->frm_obs_);
-    if (const svgpu_frame* rf = stella_vslam::hip::resident(keyfrm)) check(svgpu_frame_bind(context(), rf), "svgpu_frame_bind");
+    const auto rfh = stella_vslam::hip::resident(keyfrm);  // (kept until the matcher below has returned)
     std::vector<uint8_t> occupied(s.n, 0);
     for (int k = 0; k < s.n; ++k) occupied[k] = matched_lms_in_keyfrm.at(k) ? 1 : 0;  // :391-393
     const svgpu_camera cam = to_svgpu_camera(keyfrm->camera_);
@@ -599,6 +680,7 @@ unsigned int projection::match_by_Sim3_transform(const kf_ptr& keyfrm, const Mat
     const auto* op = keyfrm->orb_params_;
     std::vector<int32_t> m(L.n, -1);
     int num = 0;
+    if (rfh) check(svgpu_frame_bind(context(), rfh.get()), "svgpu_frame_bind");  // bound immediately in front of the call that consumes it
     check(svgpu_match_by_sim3_transform(context(), &cam, S, L.n, L.pos_w.data(), L.valid.data(), L.min_d.data(), L.max_d.data(), L.normal.data(), L.desc.data(),
                                         (int)op->num_levels_, op->scale_factors_.data(), op->log_scale_factor_, margin, s.desc.data(), s.xy.data(), s.octave.data(),
                                         s.n, occupied.data(), (int)keyfrm->frm_obs_.num_grid_cols_, (int)keyfrm->frm_obs_.num_grid_rows_, m.data(), &num),

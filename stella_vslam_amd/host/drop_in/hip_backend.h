@@ -50,17 +50,24 @@ void check(int status, const char* where);
 
 #ifndef SVGPU_DROP_IN_OPTIMIZE_ONLY
 //! Device-resident copy of a frame's / keyframe's observation (include/svgpu.h svgpu_frame_*), kept in a process-wide cache keyed by
-//! data::frame::id_ / data::keyframe::id_ (checked against a fingerprint of the observation): descriptors, undistorted keypoints, stereo
-//! x_right and the keypoint grid are uploaded ONCE per frame, every later matcher call binds the resident copy instead of re-uploading
-//! them (tracking_module.cc:533-608 runs three to four matchers per frame).  nullptr when SVGPU_NO_RESIDENT_FRAMES is set.
-const svgpu_frame* resident(const data::frame& frm);
-const svgpu_frame* resident(const std::shared_ptr<data::keyframe>& keyfrm);
+//! data::frame::id_ / data::keyframe::id_ and verified against a hash of the WHOLE observation (every descriptor and keypoint): descriptors,
+//! undistorted keypoints, stereo x_right and the keypoint grid are uploaded ONCE per frame, every later matcher call binds the resident
+//! copy instead of re-uploading them (tracking_module.cc:533-608 runs three to four matchers per frame).  The cache hands out
+//! REFERENCE-COUNTED handles: keep the handle for as long as a call that reads the frame is in flight -- eviction, forget_*() or a
+//! replacement on another thread then only drop the cache's own reference.  Empty handle when SVGPU_NO_RESIDENT_FRAMES is set.
+using frame_handle = std::shared_ptr<svgpu_frame>;
+frame_handle resident(const data::frame& frm);
+frame_handle resident(const std::shared_ptr<data::keyframe>& keyfrm);
 //! system.cc:384-395 on the device, for a frame whose keypoints come from the HIP extractor: undistort_keypoints, convert_keypoints_to_bearings
 //! and assign_keypoints_to_grid run on what `extractor_ctx`'s last extract() LEFT ON THE DEVICE (stella_vslam_hip::feature::orb_extractor::
 //! context()), the host copies data::frame_observation holds come back in one transfer, and the resident frame is registered under
 //! `frame_id`: the descriptors of a tracked frame then cross PCIe once.  (The one line system::create_*_frame gains: INTEGRATION.md.)
 void adopt_extraction(unsigned int frame_id, svgpu_ctx* extractor_ctx, const camera::base* camera, unsigned int num_grid_cols, unsigned int num_grid_rows,
                       std::vector<cv::KeyPoint>& undist_keypts, eigen_alloc_vector<Vec3_t>& bearings);
+//! an empty resident frame (recycled from a small pool when one is parked there); the handle's deleter parks it again
+frame_handle new_frame(svgpu_ctx* ctx);
+//! registers a resident frame that was built on the device elsewhere (the tracked-frame chain's fused extraction) under `frame_id`
+void register_adopted(unsigned int frame_id, const frame_handle& frame, const std::vector<cv::KeyPoint>& undist_keypts);
 //! drops the cached copies (a frame / keyframe that has been destroyed); the cache also evicts least-recently-used entries by itself
 void forget_frame(unsigned int frame_id);
 void forget_keyframe(unsigned int keyframe_id);

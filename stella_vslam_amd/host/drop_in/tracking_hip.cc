@@ -1,0 +1,322 @@
+// Host side of the tracked-frame chain: the landmark table's shadow + dirty list, and the two reference call sites (tracking_hip.h).
+#include "tracking_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace stella_vslam {
+namespace hip {
+
+// ------------------------------------------------------------------------------------------------------- the landmark table's host shadow
+namespace {
+struct mirror_state {
+    std::mutex mtx;
+    std::vector<svgpu_landmark_record> shadow;  // by landmark id
+    std::vector<uint8_t> is_dirty;
+    std::vector<uint32_t> dirty;
+    svgpu_map* map = nullptr;
+    svgpu_ctx* map_ctx = nullptr;  // (the context the table was created on: only its device matters)
+    std::vector<uint32_t> up_ids;  // flush scratch
+    std::vector<svgpu_landmark_record> up_rec;
+    ~mirror_state() {
+        if (map) svgpu_map_destroy(map);
+    }
+};
+mirror_state& mirror() {
+    static mirror_state s;
+    return s;
+}
+// (called with the mutex held)
+svgpu_landmark_record& touch(mirror_state& M, unsigned int id) {
+    if (id >= M.shadow.size()) {
+        const size_t n = std::max<size_t>((size_t)id + 1, M.shadow.size() * 2 + 1024);
+        svgpu_landmark_record zero;
+        std::memset(&zero, 0, sizeof zero);
+        M.shadow.resize(n, zero);
+        M.is_dirty.resize(n, 0);
+    }
+    if (!M.is_dirty[id]) {
+        M.is_dirty[id] = 1;
+        M.dirty.push_back(id);
+    }
+    return M.shadow[id];
+}
+}  // namespace
+
+namespace map_mirror {
+void landmark_created(unsigned int id, const double* pos_w) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    svgpu_landmark_record& r = touch(M, id);
+    std::memset(&r, 0, sizeof r);
+    for (int k = 0; k < 3; ++k) r.pos_w[k] = pos_w[k];
+    r.flags = SVGPU_LM_PRESENT;
+}
+void set_position(unsigned int id, const double* pos_w) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    svgpu_landmark_record& r = touch(M, id);
+    for (int k = 0; k < 3; ++k) r.pos_w[k] = pos_w[k];
+}
+void set_geometry(unsigned int id, const double* mean_normal, float min_valid_dist, float max_valid_dist) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    svgpu_landmark_record& r = touch(M, id);
+    for (int k = 0; k < 3; ++k) r.mean_normal[k] = mean_normal[k];
+    r.min_valid_dist = min_valid_dist;
+    r.max_valid_dist = max_valid_dist;
+}
+void set_descriptor(unsigned int id, const unsigned char* descriptor32) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    svgpu_landmark_record& r = touch(M, id);
+    if (descriptor32) {
+        std::memcpy(r.descriptor, descriptor32, 32);
+        r.flags |= SVGPU_LM_HAS_DESCRIPTOR;
+    }
+    else r.flags &= ~(uint32_t)SVGPU_LM_HAS_DESCRIPTOR;
+}
+void set_has_observation(unsigned int id, bool has_observation) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    svgpu_landmark_record& r = touch(M, id);
+    if (has_observation) r.flags |= SVGPU_LM_HAS_OBSERVATION;
+    else r.flags &= ~(uint32_t)SVGPU_LM_HAS_OBSERVATION;
+}
+void landmark_erased(unsigned int id) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    touch(M, id).flags = 0;
+}
+}  // namespace map_mirror
+
+svgpu_map* flush_map(svgpu_ctx* ctx) {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);  // (held across the upload: a record must not change between its copy and its dirty mark)
+    if (!M.map) {
+        check(svgpu_map_create(ctx, &M.map), "svgpu_map_create");
+        M.map_ctx = ctx;
+    }
+    if (M.dirty.empty()) return M.map;
+    const size_t n = M.dirty.size();
+    M.up_ids.resize(n);
+    M.up_rec.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t id = M.dirty[i];
+        M.up_ids[i] = id;
+        M.up_rec[i] = M.shadow[id];
+        M.is_dirty[id] = 0;
+    }
+    M.dirty.clear();
+    check(svgpu_map_upsert(ctx, M.map, (int)n, M.up_ids.data(), M.up_rec.data()), "svgpu_map_upsert");
+    return M.map;
+}
+size_t pending_map_updates() {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> lock(M.mtx);
+    return M.dirty.size();
+}
+
+// ------------------------------------------------------------------------------------------------------------------- the chain
+namespace {
+void pose12(const Mat44_t& T, double* out) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = T(i, j);
+}
+Mat44_t pose44(const double* p) {
+    Mat44_t T = Mat44_t::Identity();
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) T(i, j) = p[4 * i + j];
+    return T;
+}
+}  // namespace
+
+tracked_frame_chain::tracked_frame_chain(svgpu_ctx* ctx, const camera::base* camera, const feature::orb_params* orb_params, unsigned int num_grid_cols,
+                                         unsigned int num_grid_rows, unsigned int num_trials_robust, unsigned int num_trials, unsigned int num_each_iter)
+    : ctx_(ctx), camera_(camera), orb_params_(orb_params), num_grid_cols_(num_grid_cols), num_grid_rows_(num_grid_rows) {
+    map_ = flush_map(ctx_);
+    svgpu_track_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.num_levels = (int)orb_params->num_levels_;
+    if (cfg.num_levels < 1 || cfg.num_levels > 16) throw std::runtime_error("tracked_frame_chain: unsupported number of pyramid levels");
+    for (int l = 0; l < cfg.num_levels; ++l) {
+        cfg.scale_factors[l] = orb_params->scale_factors_.at(l);
+        cfg.inv_level_sigma_sq[l] = orb_params->inv_level_sigma_sq_.at(l);
+    }
+    cfg.log_scale_factor = orb_params->log_scale_factor_;
+    cfg.grid_cols = (int)num_grid_cols, cfg.grid_rows = (int)num_grid_rows;
+    cfg.is_monocular = camera->setup_type_ == camera::setup_type_t::Monocular ? 1 : 0;
+    cfg.true_baseline = (float)camera->true_baseline_;
+    cfg.po_num_trials_robust = (int)num_trials_robust, cfg.po_num_trials = (int)num_trials, cfg.po_num_each_iter = (int)num_each_iter;
+    cfg.po_reset_stop_flag_each_round = 0;
+    const svgpu_camera cam = to_svgpu_camera(camera);
+    check(svgpu_tracker_create(ctx_, map_, &cam, &cfg, &tracker_), "svgpu_tracker_create");
+}
+
+tracked_frame_chain::~tracked_frame_chain() { svgpu_tracker_destroy(tracker_); }
+
+void tracked_frame_chain::counters(long long& launches, long long& host_syncs) const { svgpu_tracker_counters(tracker_, &launches, &host_syncs); }
+
+bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::frame& last_frm, const Mat44_t& velocity, unsigned int num_matches_thr, float margin,
+                                             const cv::Mat* img, std::vector<cv::KeyPoint>* keypts) {
+    // Set the initial pose by using the motion model (frame_tracker.cc:25-26)
+    const Mat44_t guess = velocity * last_frm.get_pose_cw();
+    curr_frm.set_pose_cw(guess);
+    double guess12[12], last12[12];
+    pose12(guess, guess12);
+    pose12(last_frm.get_pose_cw(), last12);
+    // the last frame: its resident observation, and per keypoint the id of the landmark it holds (projection.cc:119-127)
+    const frame_handle last_h = resident(last_frm);
+    if (!last_h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
+    const auto& last_lms = last_frm.landmarks_;
+    const int n_last = (int)last_frm.frm_obs_.undist_keypts_.size();
+    last_ids_.resize(n_last);
+    for (int i = 0; i < n_last; ++i) {
+        const auto& lm = last_lms[i];
+        last_ids_[i] = (lm && !lm->will_be_erased()) ? (int32_t)lm->id_ : -1;
+    }
+    match_.resize(std::max(n_last, 1));
+    flush_map(ctx_);
+    frame_handle cur_h;
+    int cap = 0;
+    if (img) {
+        cap = std::max(1, svgpu_orb_max_keypoints(ctx_));
+        kps_.resize(cap), und_.resize(cap), desc_.resize((size_t)cap * 32), brg_.resize((size_t)cap * 3);
+        cur_h = new_frame(ctx_);
+        outlier_.resize(cap);
+    }
+    else {
+        cur_h = resident(curr_frm);
+        if (!cur_h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
+        outlier_.resize(std::max<size_t>(curr_frm.frm_obs_.undist_keypts_.size(), 1));
+    }
+    unsigned int num_matches = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool fused = img && attempt == 0;
+        check(svgpu_track_motion(tracker_, cur_h.get(), fused ? img->ptr(0) : nullptr, fused ? (int)img->step : 0, last_h.get(), last_ids_.data(), guess12, last12,
+                                 attempt == 0 ? margin : 2 * margin, 1 /* projection_matcher(0.9, true) */, fused ? kps_.data() : nullptr,
+                                 fused ? desc_.data() : nullptr, fused ? und_.data() : nullptr, fused ? brg_.data() : nullptr, fused ? cap : 0, match_.data(),
+                                 outlier_.data(), &last_motion_),
+              "svgpu_track_motion");
+        if (fused) {  // system.cc:380-395: the host copies data::frame_observation holds
+            const int n = last_motion_.n_keypoints;
+            auto& o = curr_frm.frm_obs_;
+            o.num_grid_cols_ = num_grid_cols_, o.num_grid_rows_ = num_grid_rows_;
+            o.descriptors_.create(n, 32, CV_8U);
+            if (n > 0) std::memcpy(o.descriptors_.ptr(0), desc_.data(), (size_t)n * 32);
+            o.undist_keypts_.resize(n);
+            if (n > 0) std::memcpy(static_cast<void*>(o.undist_keypts_.data()), und_.data(), (size_t)n * sizeof(svgpu_keypoint));
+            o.bearings_.resize(n);
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k) o.bearings_[i](k) = brg_[3 * (size_t)i + k];
+            if (keypts) {
+                keypts->resize(n);
+                if (n > 0) std::memcpy(static_cast<void*>(keypts->data()), kps_.data(), (size_t)n * sizeof(svgpu_keypoint));
+            }
+            curr_frm.landmarks_.assign(n, nullptr);
+            register_adopted(curr_frm.id_, cur_h, o.undist_keypts_);
+        }
+        // Initialize the 2D-3D matches, then replay them in the reference's order (frame_tracker.cc:29, projection.cc:202)
+        curr_frm.erase_landmarks();
+        for (int i = 0; i < n_last; ++i)
+            if (0 <= match_[i]) curr_frm.add_landmark(last_lms[i], (unsigned int)match_[i]);
+        num_matches = (unsigned int)last_motion_.num_matches;
+        if (num_matches >= num_matches_thr) break;  // else: increment the margin, and search again (:36-40)
+    }
+    if (num_matches < num_matches_thr) return false;
+    // Pose optimization (:48-51) -- already done behind the matcher, on the device
+    curr_frm.set_pose_cw(pose44(last_motion_.pose_cw));
+    // Discard the outliers (:54, :133-151)
+    unsigned int num_valid_matches = 0;
+    const unsigned int n = (unsigned int)curr_frm.frm_obs_.undist_keypts_.size();
+    for (unsigned int idx = 0; idx < n; ++idx) {
+        if (curr_frm.get_landmark(idx) == nullptr) continue;
+        if (outlier_[idx]) curr_frm.erase_landmark_with_index(idx);
+        else ++num_valid_matches;
+    }
+    return num_valid_matches >= num_matches_thr;
+}
+
+bool tracked_frame_chain::track_local_map(data::frame& curr_frm, const std::vector<std::shared_ptr<data::landmark>>& local_landmarks,
+                                          unsigned int fixed_keyframe_id_threshold, float margin, float lowe_ratio) {
+    const frame_handle cur_h = resident(curr_frm);
+    if (!cur_h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
+    // select the landmarks which can be reprojected from the ones observed in the current frame (tracking_module.cc:536-551): the frame's
+    // own landmarks are stamped in a table by id instead of collected in a hash set
+    const unsigned int n = (unsigned int)curr_frm.frm_obs_.undist_keypts_.size();
+    cur_ids_.resize(std::max(n, 1u));
+    ++frame_serial_;
+    for (unsigned int idx = 0; idx < n; ++idx) {
+        const auto& lm = curr_frm.landmarks_[idx];
+        cur_ids_[idx] = lm ? (int32_t)lm->id_ : -1;
+        if (!lm || lm->will_be_erased()) continue;
+        if (lm->id_ >= held_stamp_.size()) held_stamp_.resize((size_t)lm->id_ * 2 + 1024, 0);
+        held_stamp_[lm->id_] = frame_serial_;
+        lm->increase_num_observable();  // :549
+    }
+    const int n_local = (int)local_landmarks.size();
+    local_ids_.resize(std::max(n_local, 1));
+    last_local_lm_ids_.resize(n_local);
+    for (int i = 0; i < n_local; ++i) {
+        const auto& lm = local_landmarks[i];
+        last_local_lm_ids_[i] = lm->id_;
+        bool offered = !(lm->id_ < held_stamp_.size() && held_stamp_[lm->id_] == frame_serial_) && !lm->will_be_erased();  // :560-565
+        if (offered && fixed_keyframe_id_threshold > 0) {  // :566-580
+            const auto observations = lm->get_observations();
+            unsigned int temporal_observations = 0;
+            for (const auto& obs : observations) {
+                const auto keyfrm = obs.first.lock();
+                if (keyfrm && keyfrm->id_ >= fixed_keyframe_id_threshold) ++temporal_observations;
+            }
+            const double temporal_ratio_thr = 0.5;
+            const double temporal_ratio = static_cast<double>(temporal_observations) / observations.size();
+            if (temporal_ratio > temporal_ratio_thr) offered = false;
+        }
+        local_ids_[i] = offered ? (int32_t)lm->id_ : -1;
+    }
+    match_.resize(std::max(n_local, 1));
+    visible_.resize(std::max(n_local, 1));
+    outlier_.resize(std::max(n, 1u));
+    flush_map(ctx_);
+    check(svgpu_track_local_map(tracker_, cur_h.get(), cur_ids_.data(), n_local, local_ids_.data(), nullptr /* the first half's pose, still on the device */, margin,
+                                lowe_ratio, 0.5f, match_.data(), visible_.data(), outlier_.data(), &last_local_),
+          "svgpu_track_local_map");
+    bool found_proj_candidate = false;
+    for (int i = 0; i < n_local; ++i)
+        if (visible_[i]) {
+            local_landmarks[i]->increase_num_observable();  // :588
+            found_proj_candidate = true;
+        }
+    if (!found_proj_candidate) return false;  // :596-599 "projection candidate not found"
+    for (int i = 0; i < n_local; ++i)
+        if (0 <= match_[i]) curr_frm.add_landmark(local_landmarks[i], (unsigned int)match_[i]);  // projection.cc:88
+    // optimize_current_frame_with_local_map (:441-455): the pose, then the outliers
+    curr_frm.set_pose_cw(pose44(last_local_.pose_cw));
+    for (unsigned int idx = 0; idx < n; ++idx) {
+        if (!outlier_[idx]) continue;
+        if (curr_frm.get_landmark(idx)) curr_frm.erase_landmark_with_index(idx);
+    }
+    return true;
+}
+
+void tracked_frame_chain::last_observability(eigen_alloc_unord_map<unsigned int, Vec2_t>& lm_to_reproj, std::unordered_map<unsigned int, float>& lm_to_x_right,
+                                             std::unordered_map<unsigned int, unsigned int>& lm_to_scale) {
+    const int n = (int)last_local_lm_ids_.size();
+    std::vector<double> rp((size_t)std::max(n, 1) * 2);
+    std::vector<float> xr(std::max(n, 1));
+    std::vector<int32_t> lv(std::max(n, 1));
+    check(svgpu_track_local_map_observability(tracker_, n, rp.data(), xr.data(), lv.data()), "svgpu_track_local_map_observability");
+    lm_to_reproj.clear(), lm_to_x_right.clear(), lm_to_scale.clear();
+    for (int i = 0; i < n; ++i)
+        if (visible_[i]) {
+            Vec2_t q;
+            q(0) = rp[2 * (size_t)i], q(1) = rp[2 * (size_t)i + 1];
+            lm_to_reproj[last_local_lm_ids_[i]] = q;
+            lm_to_x_right[last_local_lm_ids_[i]] = xr[i];
+            lm_to_scale[last_local_lm_ids_[i]] = (unsigned int)lv[i];
+        }
+}
+
+}  // namespace hip
+}  // namespace stella_vslam

@@ -48,6 +48,7 @@ public:
         data = nullptr;
     }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    bool isContinuous() const { return step == (size_t)cols; }
     int type() const { return CV_8UC1; }
     uint8_t* ptr(int r = 0) { return data + (size_t)r * step; }
     const uint8_t* ptr(int r = 0) const { return data + (size_t)r * step; }

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cv_standin.h"
+#include "../drop_in/map_mirror.h"
 
 namespace stella_vslam {
 
@@ -37,6 +38,18 @@ struct small_mat {
     }
     static small_mat Zero() { return small_mat(); }
 };
+// matrix product as Eigen evaluates a fixed-size one: every element the dot product of a row and a column, accumulated left to right
+template <int R, int K, int C>
+inline small_mat<R, C> operator*(const small_mat<R, K>& a, const small_mat<K, C>& b) {
+    small_mat<R, C> m;
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            double acc = a(i, 0) * b(0, j);
+            for (int k = 1; k < K; ++k) acc += a(i, k) * b(k, j);
+            m(i, j) = acc;
+        }
+    return m;
+}
 using Mat33_t = small_mat<3, 3>;
 using Mat44_t = small_mat<4, 4>;
 using Vec2_t = small_mat<2, 1>;
@@ -200,8 +213,16 @@ inline std::mutex map_database::mtx_database_;
 class landmark : public std::enable_shared_from_this<landmark> {  // data/landmark.h:29-171
 public:
     using observations_t = std::map<std::weak_ptr<keyframe>, unsigned int, id_less<std::weak_ptr<keyframe>>>;
-    landmark(unsigned int id, const Vec3_t& pos_w) : id_(id), pos_w_(pos_w) {}
-    void set_pos_in_world(const Vec3_t& pos_w) { pos_w_ = pos_w; }
+    // (the hip::map_mirror calls are the lines the reference's data/landmark.cc gains with this backend: drop_in/map_mirror.h)
+    landmark(unsigned int id, const Vec3_t& pos_w) : id_(id), pos_w_(pos_w) {
+        const double p[3] = {pos_w(0), pos_w(1), pos_w(2)};
+        hip::map_mirror::landmark_created(id_, p);
+    }
+    void set_pos_in_world(const Vec3_t& pos_w) {
+        pos_w_ = pos_w;
+        const double p[3] = {pos_w(0), pos_w(1), pos_w(2)};
+        hip::map_mirror::set_position(id_, p);
+    }
     Vec3_t get_pos_in_world() const { return pos_w_; }
     Vec3_t get_obs_mean_normal() const { return mean_normal_; }
     float get_min_valid_distance() const { return min_valid_dist_; }
@@ -216,11 +237,16 @@ public:
         return it == observations_.end() ? -1 : (int)it->second;
     }
     bool is_observed_in_keyframe(const std::shared_ptr<keyframe>& keyfrm) const { return observations_.count(keyfrm) != 0; }
-    void add_observation(const std::shared_ptr<keyframe>& keyfrm, unsigned int idx) { observations_[keyfrm] = idx; }
+    void add_observation(const std::shared_ptr<keyframe>& keyfrm, unsigned int idx) {
+        observations_[keyfrm] = idx;
+        hip::map_mirror::set_has_observation(id_, true);
+    }
     void erase_observation(map_database* map_db, const std::shared_ptr<keyframe>& keyfrm) {  // data/landmark.cc:100-140
         observations_.erase(keyfrm);
+        hip::map_mirror::set_has_observation(id_, !observations_.empty());
         if (observations_.size() <= 2) {
             will_be_erased_ = true;
+            hip::map_mirror::landmark_erased(id_);
             if (map_db) ++map_db->num_erased_landmarks_;
         }
     }
@@ -231,6 +257,9 @@ public:
         else if (num_scale_levels <= static_cast<unsigned int>(pred_scale_level)) return num_scale_levels - 1;
         else return static_cast<unsigned int>(pred_scale_level);
     }
+    void increase_num_observable(unsigned int num_observable = 1) { num_observable_ += num_observable; }   // data/landmark.cc:355-361
+    void increase_num_observed(unsigned int num_observed = 1) { num_observed_ += num_observed; }
+    std::atomic<unsigned int> num_observable_{1}, num_observed_{1};
     void compute_descriptor();                         // defined behind keyframe (data/landmark.cc:199-254)
     void update_mean_normal_and_obs_scale_variance();  // data/landmark.cc:256-318
     unsigned int id_;
@@ -335,6 +364,7 @@ inline void landmark::compute_descriptor() {  // median-of-distances representat
     }
     descriptor_.create(1, 32, CV_8U);
     std::memcpy(descriptor_.ptr(0), descs[best], 32);
+    hip::map_mirror::set_descriptor(id_, descriptor_.ptr(0));
 }
 
 inline void landmark::update_mean_normal_and_obs_scale_variance() {  // data/landmark.cc:256-318
@@ -362,6 +392,8 @@ inline void landmark::update_mean_normal_and_obs_scale_variance() {  // data/lan
             min_valid_dist_ = max_valid_dist_ * ref->orb_params_->inv_scale_factors_.at(ref->orb_params_->num_levels_ - 1);
         }
     }
+    const double nv[3] = {mean_normal_(0), mean_normal_(1), mean_normal_(2)};
+    hip::map_mirror::set_geometry(id_, nv, min_valid_dist_, max_valid_dist_);
 }
 
 class frame {  // data/frame.h:42-183
@@ -381,6 +413,8 @@ public:
         return t;
     }
     void add_landmark(const std::shared_ptr<landmark>& lm, const unsigned int idx) { landmarks_.at(idx) = lm; }
+    void erase_landmark_with_index(const unsigned int idx) { landmarks_.at(idx) = nullptr; }                  // data/frame.cc:101-105
+    void erase_landmarks() { std::fill(landmarks_.begin(), landmarks_.end(), nullptr); }                      // :118-121
     std::shared_ptr<landmark> get_landmark(const unsigned int idx) const { return landmarks_.at(idx); }
     std::vector<std::shared_ptr<landmark>> get_landmarks() const { return landmarks_; }
     void set_landmarks(const std::vector<std::shared_ptr<landmark>>& lms) { landmarks_ = lms; }

@@ -152,7 +152,7 @@ def test_motion_chain_equals_oracle_and_flattened_path(ctx, stereo, margin, seed
     # twice the margin (frame_tracker.cc:36-40) through the same tracker: more candidates, same agreement
     exp2 = _oracle_motion(W, 2 * margin)
     got2 = W.tracker.track_motion(W.rf_cur, W.rf_last, W.last_ids, W.guess, W.pose_last, 2 * margin)
-    assert np.array_equal(got2["match_last"], exp2["match"]) and got2["result"]["num_candidates"] > r["num_candidates"]
+    assert np.array_equal(got2["match_last"], exp2["match"]) and got2["result"]["num_candidates"] >= r["num_candidates"]
     assert np.array_equal(got2["outlier"], exp2["outlier"]) and _rel(got2["result"]["pose_cw"], exp2["pose"]) < TOL
 
 
