@@ -371,7 +371,9 @@ typedef struct svgpu_track_result {
     int num_valid;       /* pose optimizer: observations that are inliers at the end (0: fewer than 5 observations, pose unchanged) */
     int lm_iterations;
     int num_observations;/* edges the pose optimizer was given */
-    int num_candidates;  /* entries of the candidate lists (diagnostics) */
+    int num_candidates;  /* entries of the candidate lists beyond their queries' own slots (diagnostics) */
+    int replay_sweeps;   /* sweeps of the matcher's greedy replay, summed over its chunks (diagnostics) */
+    int reserved;
     double pose_cw[12];  /* optimised [R|t], row-major 3x4 */
 } svgpu_track_result;
 /* One tracker per tracking thread: owns the chain's device and page-locked buffers.  `ctx` is the context its launches go to; for the
@@ -411,6 +413,8 @@ int svgpu_track_local_map(svgpu_tracker* tracker, const svgpu_frame* cur, const 
 int svgpu_track_local_map_observability(svgpu_tracker* tracker, int n_local, double* reproj, float* x_right, int32_t* pred_scale_level);
 /* diagnostics: kernel launches + runtime copies the tracker enqueued, and stream synchronisations it waited on, since creation */
 int svgpu_tracker_counters(const svgpu_tracker* tracker, long long* launches, long long* host_syncs);
+/* debug (SVGPU_TRACK_STAMPS set): 100 MHz wall-clock stamps of the last optimisation kernel's phases, [0] = how many follow; else NULL / zeros */
+const unsigned long long* svgpu_tracker_debug_stamps(const svgpu_tracker* tracker);
 
 /* ------------------------------------------------------------------------------ function-specific matchers
  * One entry point per reference method: candidate generation (reprojection + grid cells, or BoW buckets), the method's own pair

@@ -148,6 +148,7 @@ struct PoseOptDev {
     double* host_pose;             // 12 (page-locked)
     int* host_result;              // [0] num_valid [1] LM iterations [2] num_bad [3] observations (page-locked)
     int32_t* trk_counter_reset;    // nullable: a device word zeroed at the end (the next matcher's list allocation counter)
+    unsigned long long* stamps;    // nullable (SVGPU_TRACK_STAMPS): wall_clock64 at the kernel's phase boundaries, [0] = how many
 };
 struct svgpu_ctx;
 void sv_pose_opt(svgpu_ctx* ctx, hipStream_t s, const PoseOptDev& P);

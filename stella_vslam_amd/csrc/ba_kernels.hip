@@ -667,63 +667,109 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     const int tid = threadIdx.x;
     int n = P.n;
     int trk_nt = 0;
+    int n_stamps = 0;
+    auto stamp = [&]() {  // (debug: 100 MHz wall clock at a phase boundary)
+        if (P.stamps && tid == 0 && n_stamps < 62) P.stamps[++n_stamps] = wall_clock64(), P.stamps[0] = n_stamps;
+    };
+    stamp();
     if constexpr (TRK) {
-        __shared__ int s_wcount[PO_THREADS / 64], s_nobs;
+        __shared__ int s_nobs;
         if (*P.trk_overflow > P.trk_overflow_cap) return;  // the lists did not fit: the host re-runs the chain with a larger capacity
         const int nt = P.trk_nt_dev ? min(*P.trk_nt_dev, P.trk_nt) : P.trk_nt;
         trk_nt = nt;
         const svgpu_landmark_record* map = (const svgpu_landmark_record*)P.trk_map;
-        // 1. matches onto the frame: add_landmark in increasing query order, a later query overwrites (projection.cc:88, :202)
-        for (int k = tid; k < nt; k += PO_THREADS) {
-            P.trk_who[k] = -1;
-            if (P.trk_reset_cur) P.trk_cur_lm[k] = -1;
+        // 1. matches onto the frame: add_landmark in increasing query order, a later query overwrites (projection.cc:88, :202).  The table of
+        //    "last query that took keypoint k" lives in LDS (the reduction buffers are idle until the first linearisation).
+        constexpr int TRK_ROUNDS = (8192 + PO_THREADS - 1) / PO_THREADS;  // <= 8 192 keypoints per frame (checked by the host)
+        int* const s_who = reinterpret_cast<int*>(s_wred);
+        int lm[TRK_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < TRK_ROUNDS; ++r) {
+            const int k = tid + r * PO_THREADS;
+            if (k < nt) s_who[k] = -1;
+            lm[r] = (k < nt && !P.trk_reset_cur) ? P.trk_cur_lm[k] : -1;  // (in flight while the matches are applied)
         }
         __syncthreads();
         for (int q = tid; q < P.trk_nq; q += PO_THREADS) {
             const int m = P.trk_match_q[q];
-            if (m >= 0 && m < nt) atomicMax(&P.trk_who[m], q);
+            if (m >= 0 && m < nt) atomicMax(&s_who[m], q);
         }
         __syncthreads();
-        // 2. compaction in keypoint order: every thread owns a contiguous run of keypoints
-        const int per = (nt + PO_THREADS - 1) / PO_THREADS, k0 = tid * per, k1 = min(k0 + per, nt);
-        int mine = 0;
-        for (int k = k0; k < k1; ++k) {
-            const int w = P.trk_who[k];
-            int id = P.trk_cur_lm[k];
-            if (w >= 0) {
-                id = P.trk_qid[w];
-                P.trk_cur_lm[k] = id;
-            }
-            const bool ok = id >= 0 && id < P.trk_map_cap && (map[id].flags & SVGPU_LM_PRESENT);  // !lm || lm->will_be_erased(): no edge (:81-87)
-            mine += ok;
-        }
-        const int lane = tid & 63, wave = tid >> 6;
-        int incl = mine;
+        // 2. the landmark every keypoint holds now, and whether it yields an edge.  Keypoints are taken STRIDED (coalesced) and every level
+        //    of the dependent chain (query id -> table record) is loaded for ALL of a thread's keypoints before the next level is touched:
+        //    the round trips overlap instead of queueing (a thread walking its own contiguous run paid three per keypoint).
+        unsigned okmask = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
+        for (int r = 0; r < TRK_ROUNDS; ++r) {
+            const int k = tid + r * PO_THREADS;
+            const int w = k < nt ? s_who[k] : -1;
+            if (w >= 0) lm[r] = P.trk_qid[w];
         }
-        if (lane == 63) s_wcount[wave] = incl;
-        __syncthreads();
-        int base = incl - mine;
-        for (int w = 0; w < wave; ++w) base += s_wcount[w];
-        if (tid == PO_THREADS - 1) s_nobs = base + mine;
-        for (int k = k0; k < k1; ++k) {
-            const int id = P.trk_cur_lm[k];
-            if (!(id >= 0 && id < P.trk_map_cap && (map[id].flags & SVGPU_LM_PRESENT))) continue;
-            const int j = base++;
-            P.trk_pos[3 * (size_t)j] = map[id].pos_w[0];
-            P.trk_pos[3 * (size_t)j + 1] = map[id].pos_w[1];
-            P.trk_pos[3 * (size_t)j + 2] = map[id].pos_w[2];
-            P.trk_uvr[3 * (size_t)j] = P.trk_xy[2 * k];
-            P.trk_uvr[3 * (size_t)j + 1] = P.trk_xy[2 * k + 1];
-            P.trk_uvr[3 * (size_t)j + 2] = P.trk_xright ? P.trk_xright[k] : -1.0f;
-            P.trk_w[j] = P.trk_inv_sigma_sq[P.trk_octave[k] & 15];
-            P.trk_h[j] = P.trk_huber;
-            P.trk_kp_of[j] = k;
+        __syncthreads();  // (s_who is dead from here on: the buffer goes back to the reductions)
+#pragma unroll
+        for (int r = 0; r < TRK_ROUNDS; ++r) {
+            const int k = tid + r * PO_THREADS;
+            const bool ok = k < nt && lm[r] >= 0 && lm[r] < P.trk_map_cap && (map[lm[r]].flags & SVGPU_LM_PRESENT);  // !lm || lm->will_be_erased(): no edge (:81-87)
+            okmask |= ok ? 1u << r : 0u;
+            if (k < nt) P.trk_cur_lm[k] = lm[r];
+        }
+        // 3. keypoint order = edge order: exclusive scan of the edge flags over k = tid + r * PO_THREADS, i.e. round-major -- round r's
+        //    PO_THREADS keypoints precede round r + 1's.  Per round a wave ballot + popcount, the waves' counts through LDS.
+        __shared__ int s_wround[TRK_ROUNDS][PO_THREADS / 64];
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int r = 0; r < TRK_ROUNDS; ++r) {
+            const unsigned long long b = __ballot((okmask >> r) & 1u);
+            if (lane == 0) s_wround[r][wave] = __popcll(b);
         }
         __syncthreads();
+        int nobs = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < TRK_ROUNDS; r0 += 4) {  // four rounds at a time: their table reads are issued together, then the stores
+            if (r0 * PO_THREADS >= nt) break;
+            int j4[4];
+            double px[4], py[4], pz[4];
+            float ux[4], uy[4], ur[4], ww[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u;
+                const unsigned long long b = __ballot((okmask >> r) & 1u);
+                int before = 0, round_total = 0;
+#pragma unroll
+                for (int w = 0; w < PO_THREADS / 64; ++w) {
+                    const int c = s_wround[r][w];
+                    before += w < wave ? c : 0;
+                    round_total += c;
+                }
+                j4[u] = -1;
+                if ((okmask >> r) & 1u) {
+                    j4[u] = nobs + before + __popcll(b & ((1ull << lane) - 1ull));
+                    const int k = tid + r * PO_THREADS, id = lm[r];
+                    px[u] = map[id].pos_w[0], py[u] = map[id].pos_w[1], pz[u] = map[id].pos_w[2];
+                    ux[u] = P.trk_xy[2 * k], uy[u] = P.trk_xy[2 * k + 1];
+                    ur[u] = P.trk_xright ? P.trk_xright[k] : -1.0f;
+                    ww[u] = P.trk_inv_sigma_sq[P.trk_octave[k] & 15];
+                }
+                nobs += round_total;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j4[u];
+                if (j < 0) continue;
+                P.trk_pos[3 * (size_t)j] = px[u];
+                P.trk_pos[3 * (size_t)j + 1] = py[u];
+                P.trk_pos[3 * (size_t)j + 2] = pz[u];
+                P.trk_uvr[3 * (size_t)j] = ux[u];
+                P.trk_uvr[3 * (size_t)j + 1] = uy[u];
+                P.trk_uvr[3 * (size_t)j + 2] = ur[u];
+                P.trk_w[j] = ww[u];
+                P.trk_h[j] = P.trk_huber;
+                P.trk_kp_of[j] = tid + (r0 + u) * PO_THREADS;
+            }
+        }
+        if (tid == 0) s_nobs = nobs;
+        __syncthreads();
+        stamp();
         n = s_nobs;
         for (int k = tid; k < nt; k += PO_THREADS) {
             P.trk_outlier_kp[k] = 0;
@@ -763,7 +809,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
     };
     bool flag = false;      // the terminate action's own stop flag (no caller flag exists in this path)
     double last_chi = 0.0;  // terminate_action::_lastChi persists across optimize() calls
-    int num_bad = 0, total_iters = 0;
+    int num_bad = 0, total_iters = 0, iters_at_classification = -1;
     const int rounds = P.num_trials_robust + P.num_trials;
     for (int trial = 0; trial < rounds; ++trial) {
         if (P.reset_flag_each_round) flag = false;
@@ -813,7 +859,9 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 acc[27] += rho0;
                 acc[28] += 1.0;
             }
+            stamp();
             po_reduce<29>(acc, s_wred, s_part, s_red);
+            stamp();
             if (s_red[28] == 0.0) break;  // no active edge: nothing to optimise in this round (uniform)
             // H (symmetric, from its 21 unique sums) and b stay in LDS: only the solving thread needs H, every thread reads b for the step scale
             if (tid < 36) {
@@ -842,6 +890,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                     s_ctl[2] = ok2 ? 1 : 0;
                 }
                 __syncthreads();
+                stamp();
                 double tmp[1] = {0.0};
                 for (int i = tid; i < n; i += PO_THREADS) {
                     if (P.level[i]) continue;
@@ -852,6 +901,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                     tmp[0] += rho0;
                 }
                 po_reduce<1>(tmp, s_wred, s_part, s_red);
+                stamp();
                 double temp_chi = s_red[0];
                 if (!s_ctl[2]) temp_chi = 1.7976931348623157e308;
                 double scale = 1e-3;
@@ -883,21 +933,31 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
                 if (gain >= 0 && gain < P.gain_thr) flag = true;
             }
         }
-        // ---- chi-square re-classification of every edge at the current pose (:127-160)
-        double bad[1] = {0.0};
-        for (int i = tid; i < n; i += PO_THREADS) {
-            double r[3], pc[3];
-            const double chi = chi_at(i, s_T, r, pc);
-            const double thr = P.uvr[(size_t)i * 3 + 2] < 0.f ? (double)5.99146f : (double)7.81473f;
-            const bool out = thr < chi;
-            P.outlier[i] = out;
-            P.level[i] = out;
-            bad[0] += out;
-            if (P.num_trials != 0 && trial + 1 == P.num_trials_robust) P.robust[i] = 0;
+        // ---- chi-square re-classification of every edge at the current pose (:127-160).  A round whose LM loop did not run (the terminate
+        //      action's flag stays up once the gain rule has raised it) leaves the pose where the previous round classified it: the same
+        //      errors, the same flags, the same count -- only the Huber switch-off of :150-157 is left to do
+        if (trial == 0 || total_iters != iters_at_classification) {
+            double bad[1] = {0.0};
+            for (int i = tid; i < n; i += PO_THREADS) {
+                double r[3], pc[3];
+                const double chi = chi_at(i, s_T, r, pc);
+                const double thr = P.uvr[(size_t)i * 3 + 2] < 0.f ? (double)5.99146f : (double)7.81473f;
+                const bool out = thr < chi;
+                P.outlier[i] = out;
+                P.level[i] = out;
+                bad[0] += out;
+                if (P.num_trials != 0 && trial + 1 == P.num_trials_robust) P.robust[i] = 0;
+            }
+            po_reduce<1>(bad, s_wred, s_part, s_red);
+            stamp();
+            num_bad = (int)s_red[0];
+            __syncthreads();
+            iters_at_classification = total_iters;
         }
-        po_reduce<1>(bad, s_wred, s_part, s_red);
-        num_bad = (int)s_red[0];
-        __syncthreads();
+        else if (P.num_trials != 0 && trial + 1 == P.num_trials_robust) {
+            for (int i = tid; i < n; i += PO_THREADS) P.robust[i] = 0;
+            __syncthreads();
+        }
         if (n - num_bad < 5) break;
     }
     if (tid < 12) P.pose_out[tid] = s_T[tid];
@@ -914,6 +974,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_opt(PoseOptDev P) {
             P.trk_outlier_kp[k] = o;
             if (o) P.host_outlier_kp[k] = 1;
         }
+        stamp();
         if (tid < 12) P.host_pose[tid] = s_T[tid];
         if (tid == 0) {
             P.host_result[0] = n - num_bad, P.host_result[1] = total_iters, P.host_result[2] = num_bad, P.host_result[3] = n;

@@ -87,6 +87,7 @@ struct CandProblem {
     const int32_t* nt_dev;    // nullable: the number of targets in device memory (at most nt, which then only sizes the tables)
     int32_t* match_host;      // nullable: page-locked copy of match_q
     int32_t* num_host;        // nullable: page-locked copy of *num, followed by the list total (cand_off[nq])
+    int dbg_phase;            // timing experiments only (SVGPU_REPLAY_DBG): 1 = return after the set-up, 2 = one evaluation per chunk, no sweeps
 };
 void sv_launch_cand_replay(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match);  // the replay alone (lists + distances in place)
 

@@ -840,7 +840,9 @@ __global__ void k_cand_dist(CandProblem P) {
     for (int k = 0; k < 8; ++k) qd[k] = P.qdesc[(size_t)q * 8 + k];
     for (int c = lo + threadIdx.x; c < hi; c += blockDim.x) {
         const int t = P.cand_idx[c];
-        bool gated = P.cand_skip && P.cand_skip[c];
+        // (a target that is occupied from the start is available to no query: gated here, it sorts behind every live entry instead of
+        //  standing in front of them in every sweep of the replay)
+        bool gated = (P.cand_skip && P.cand_skip[c]) || (P.occupied && P.occupied[t]);
         if (!gated && P.t_xright && 0.f < P.t_xright[t]) {
             const float err = fabsf(P.q_xright[q] - P.t_xright[t]);
             if (P.q_xr_tol[q] < err) gated = true;
@@ -859,7 +861,17 @@ __global__ void k_cand_dist(CandProblem P) {
                 if ((double)5.99146f < err * inv_sigma_sq) gated = true;
             }
         }
-        const uint32_t e = gated ? 0xFFFFFFFFu : ((uint32_t)hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
+        uint32_t e = 0xFFFFFFFFu;
+        if (!gated) {
+            const unsigned d = hamming256(qd, P.tdesc + (size_t)t * 8);
+            // a distance that can take part in no verdict (as a best only d <= thr counts, as a second only one that can fail the ratio test
+            // of an acceptable best: lowe_ratio * d < thr) is as good as gated: it sorts behind the entries the replay has to look at.
+            // Unrelated descriptors sit around 128 bits: nine in ten entries of a cell matcher's lists.
+            bool useless = false;
+            if (P.mode == SVGPU_MATCH_BEST_ONLY) useless = P.thr < d;
+            else if (P.mode == SVGPU_MATCH_RATIO_SAME_OCTAVE) useless = !(P.lowe_ratio * (float)d < (float)P.thr) && P.thr < d;
+            e = useless ? 0xFFFFFFFFu : ((uint32_t)d << 22) | (uint32_t)t;
+        }
         P.dist[c] = e;
         if (long_sorted) s_key[c - lo] = e == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(e >> 22) << 32) | ((unsigned long long)(c - lo) << 22) | (e & 0x3FFFFFu);
     }
@@ -1102,6 +1114,13 @@ __device__ __forceinline__ int cand_decide_lds(const CandProblem& P, int q, cons
 __host__ __device__ inline size_t cand_lds_bytes(int nq, int nt, int K, bool with_cnt = false) {
     return (size_t)(nt + nq + nq + 1 + (with_cnt ? nq : 0)) * 4 + (size_t)nq * K * 4 + 2 * (((size_t)nt + 3) & ~size_t(3)) + (((size_t)nq + 3) & ~size_t(3)) + 16;
 }
+// Order of evaluation.  A query's decision depends only on EARLIER queries, so the queries are taken in chunks of increasing index and the
+// fixed point is run chunk by chunk: while a chunk iterates, everything earlier is final (its claimed targets are simply closed, owner -1),
+// and a sweep touches the chunk's queries only.  The sweeps a chunk needs are the depth of the dependency chains INSIDE it (two or three)
+// instead of the depth over the whole frame (eight for a tracked frame's match_current_and_last_frames), and each costs a fraction of a
+// sweep over everything: 67 -> about 30 us at 2 400 - 4 800 queries.  The result is the serial loop's, as before: within a chunk the
+// iteration is the one described above, and across chunks the order is the serial order.
+#define CAND_CHUNK_QPT 1  // queries per thread and chunk
 __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) {
     extern __shared__ int s_cand[];
     __shared__ int s_changed;
@@ -1128,55 +1147,75 @@ __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) 
         if (S.qv && q < P.nq) S.qv[q] = P.q_valid[q];
     }
     for (int t = tid; t < nt; t += nthr) {
-        if (S.occ) S.occ[t] = P.occupied[t];
+        S.owner[t] = (P.occupied && P.occupied[t]) ? -1 : 0x7FFFFFFF;  // -1: closed for every query (initially occupied, or taken by a finished chunk)
         if (S.lvl) S.lvl[t] = (uint8_t)P.t_octave[t];
     }
+    S.occ = nullptr;  // (the owner table carries it)
     __syncthreads();
     for (int i = tid; i < P.nq * K; i += nthr) {
         const int q = i / K, k = i - q * K, lo = S.off[q], n = S.cnt ? S.cnt[q] : S.off[q + 1] - lo;
         if (k < n) S.head[i] = P.dist[lo + k];
     }
-    auto reset_owner = [&]() {
-        for (int t = tid; t < nt; t += nthr) S.owner[t] = (S.occ && S.occ[t]) ? -1 : 0x7FFFFFFF;
-    };
-    reset_owner();
-    for (int q = tid; q < P.nq; q += nthr) S.match[q] = -2;
     if (tid == 0) s_changed = 0;
     __syncthreads();
-    for (int sweep = 0; sweep <= P.nq; ++sweep) {  // three barriers per sweep
-        int local_changed = 0;
-        for (int q = tid; q < P.nq; q += nthr) {
-            const int d = cand_decide_lds(P, q, S);
-            if (d != S.match[q]) local_changed = 1;
-            S.match[q] = d;
-        }
-        if (local_changed) s_changed = 1;
-        __syncthreads();
-        if (!s_changed) break;
-        reset_owner();
-        __syncthreads();  // every thread has tested the flag: it can be cleared for the next sweep
-        if (tid == 0) s_changed = 0;
-        if (!P.no_claims)
-            for (int q = tid; q < P.nq; q += nthr) {
-                const int m = S.match[q];
-                if (m >= 0 && (!P.q_blocks || P.q_blocks[q])) __hip_atomic_fetch_min(S.owner + m, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (P.dbg_phase == 1) return;
+    int local = 0, sweeps_total = 0;
+    const int chunk = nthr * CAND_CHUNK_QPT;
+    for (int lo = 0; lo < P.nq; lo += chunk) {
+        int mine[CAND_CHUNK_QPT], prev[CAND_CHUNK_QPT];
+#pragma unroll
+        for (int u = 0; u < CAND_CHUNK_QPT; ++u) mine[u] = -2, prev[u] = -1;
+        for (int sweep = 0; sweep <= chunk; ++sweep) {  // three barriers per sweep
+            ++sweeps_total;
+            int local_changed = 0;
+#pragma unroll
+            for (int u = 0; u < CAND_CHUNK_QPT; ++u) {
+                const int q = lo + u * nthr + tid;
+                if (q < P.nq) {
+                    const int d = cand_decide_lds(P, q, S);
+                    if (d != mine[u]) local_changed = 1;
+                    mine[u] = d;
+                }
             }
+            if (local_changed) s_changed = 1;
+            __syncthreads();
+            const bool again = s_changed != 0 && !P.no_claims && P.dbg_phase != 2;  // (without claims the queries are independent: one evaluation is the answer)
+            if (!again) break;
+            // the claims of the previous sweep go, the new ones come: owner[t] = the earliest query of the chunk that wants t
+#pragma unroll
+            for (int u = 0; u < CAND_CHUNK_QPT; ++u)
+                if (prev[u] >= 0) S.owner[prev[u]] = 0x7FFFFFFF;
+            __syncthreads();  // every thread has tested the flag and withdrawn: it can be cleared, and the new claims can land
+            if (tid == 0) s_changed = 0;
+#pragma unroll
+            for (int u = 0; u < CAND_CHUNK_QPT; ++u) {
+                const int q = lo + u * nthr + tid;
+                const int m = mine[u];
+                prev[u] = (q < P.nq && m >= 0 && (!P.q_blocks || P.q_blocks[q])) ? m : -1;
+                if (prev[u] >= 0) __hip_atomic_fetch_min(S.owner + prev[u], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+        }
+        // the chunk is final: its targets are closed for everything that follows, its matches go out
+        __syncthreads();  // (every thread is past its last read of the flag and of the owner table)
+        if (tid == 0) s_changed = 0;
+#pragma unroll
+        for (int u = 0; u < CAND_CHUNK_QPT; ++u) {
+            const int q = lo + u * nthr + tid;
+            if (q >= P.nq) continue;
+            if (prev[u] >= 0) S.owner[prev[u]] = -1;
+            const int m = mine[u];
+            P.match_q[q] = m;
+            if (P.match_host) P.match_host[q] = m;
+            local += m >= 0;
+        }
         __syncthreads();
     }
-    int local = 0;
-    for (int q = tid; q < P.nq; q += nthr) {
-        const int m = S.match[q];
-        P.match_q[q] = m;
-        if (P.match_host) P.match_host[q] = m;
-        local += m >= 0;
-    }
-    if (tid == 0) s_changed = 0;
-    __syncthreads();
     if (local) atomicAdd(&s_changed, local);
     __syncthreads();
     if (tid == 0) {
         *P.num = s_changed;
-        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = P.cand_off[P.nq];
+        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = P.cand_off[P.nq], P.num_host[2] = sweeps_total;
     }
 }
 // the same replay with its tables in global memory (inputs beyond the LDS form)
@@ -1785,7 +1824,10 @@ void sv_launch_cand(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* ow
     }
     sv_launch_cand_replay(ctx, s, P, owner, match);
 }
-void sv_launch_cand_replay(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P, int* owner, int* match) {
+void sv_launch_cand_replay(svgpu_ctx* ctx, hipStream_t s, const CandProblem& P0, int* owner, int* match) {
+    CandProblem P = P0;
+    static const int dbg = std::getenv("SVGPU_REPLAY_DBG") ? std::atoi(std::getenv("SVGPU_REPLAY_DBG")) : 0;
+    P.dbg_phase = dbg;
     // the LDS-resident form with as many staged entries per list as fit (at most 64: longer lists are not sorted)
     const bool wc = P.cand_cnt != nullptr;
     if (cand_lds_bytes(P.nq, P.nt, 0, wc) <= CAND_LDS_BUDGET) {

@@ -9,6 +9,7 @@
 // the inputs and the freshly extracted observation.  Between the halves the host runs update_local_map (object graph: the reference's).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "svgpu_internal.h"
@@ -52,6 +53,7 @@ struct svgpu_tracker {
     int* h_result = nullptr;
     double* h_pose = nullptr;
     uint8_t *h_outlier = nullptr, *h_visible = nullptr;
+    unsigned long long* h_stamps = nullptr;  // debug (SVGPU_TRACK_STAMPS): phase stamps of the last k_pose_opt
     char* h_obs = nullptr;  // read-back of the fresh observation (prefix of the frame's slab)
     size_t h_obs_bytes = 0;
     int last_n_local = -1;
@@ -112,12 +114,13 @@ int reserve(svgpu_tracker* t, int kp, int q, size_t cand, size_t img_bytes, size
     if (had_pose) SV_HIP(ctx, hipMemcpy(t->d_pose, pose_keep, sizeof pose_keep, hipMemcpyHostToDevice));
     // host results
     off = 0;
-    const size_t h_n = take(16), h_num = take(16), h_res = take(16), h_pose = take(96), h_out = take(ckp), h_match = take((size_t)cq * 4), h_vis = take(cq),
+    const size_t h_st = take(64 * 8), h_n = take(16), h_num = take(16), h_res = take(16), h_pose = take(96), h_out = take(ckp), h_match = take((size_t)cq * 4), h_vis = take(cq),
                  h_obs = take(ob);
     t->h_out_bytes = off;
     SV_HIP(ctx, hipHostMalloc((void**)&t->h_out, off, hipHostMallocDefault));
     memset(t->h_out, 0, off);
     char* h = t->h_out;
+    t->h_stamps = (unsigned long long*)(h + h_st);
     t->h_n = (int32_t*)(h + h_n), t->h_num = (int32_t*)(h + h_num), t->h_result = (int*)(h + h_res), t->h_pose = (double*)(h + h_pose);
     t->h_outlier = (uint8_t*)(h + h_out), t->h_match = (int32_t*)(h + h_match), t->h_visible = (uint8_t*)(h + h_vis), t->h_obs = h + h_obs;
     t->h_obs_bytes = ob;
@@ -164,6 +167,8 @@ int enqueue_match_and_optimize(svgpu_tracker* t, hipStream_t s, TrackCandProblem
     svgpu_ctx* ctx = t->ctx;
     C.nq = nq;
     C.q_ids = q_ids;
+    C.thr = thr;
+    C.lowe_ratio = lowe_ratio;
     C.map = t->map->rec;
     C.map_cap = t->map->cap;
     fill_cand_frame(C, cur);
@@ -229,6 +234,11 @@ int enqueue_match_and_optimize(svgpu_tracker* t, hipStream_t s, TrackCandProblem
     O.trk_pos = t->po_pos, O.trk_uvr = t->po_uvr, O.trk_w = t->po_w, O.trk_h = t->po_h, O.trk_kp_of = t->kp_of;
     O.trk_outlier_kp = t->outlier_kp, O.host_outlier_kp = t->h_outlier, O.host_pose = t->h_pose, O.host_result = t->h_result;
     O.trk_counter_reset = t->cand_off + nq;
+    static const bool want_stamps = std::getenv("SVGPU_TRACK_STAMPS") != nullptr;
+    if (want_stamps) {
+        O.stamps = t->h_stamps;
+        t->h_stamps[0] = 0;
+    }
     sv_pose_opt(ctx, s, O);
     SV_HIP(ctx, hipGetLastError());
     t->launches += 3;
@@ -239,6 +249,8 @@ void fill_result(const svgpu_tracker* t, int n_kp, svgpu_track_result* r) {
     r->n_keypoints = n_kp;
     r->num_matches = t->h_num[0];
     r->num_candidates = t->h_num[1];
+    r->replay_sweeps = t->h_num[2];
+    r->reserved = 0;
     r->num_valid = t->h_result[0];
     r->lm_iterations = t->h_result[1];
     r->num_observations = t->h_result[3];
@@ -269,6 +281,8 @@ void svgpu_tracker_destroy(svgpu_tracker* t) {
     release(t);
     delete t;
 }
+
+const unsigned long long* svgpu_tracker_debug_stamps(const svgpu_tracker* t) { return t ? t->h_stamps : nullptr; }
 
 int svgpu_tracker_counters(const svgpu_tracker* t, long long* launches, long long* host_syncs) {
     if (!t) return SVGPU_ERR_INVALID;
@@ -359,6 +373,14 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
                 F.n_host = t->h_n;
                 sv_launch_track_frame(ctx, s, F);
                 t->launches += 6;
+                // the observation goes home on the auxiliary stream, beside the matcher and the optimiser (joined before the synchronisation)
+                if (ctx->stream_aux) {
+                    SV_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+                    SV_HIP(ctx, hipStreamWaitEvent(ctx->stream_aux, ctx->ev_fork, 0));
+                    SV_HIP(ctx, hipMemcpyAsync(t->h_obs, cur->slab, obs_bytes, hipMemcpyDeviceToHost, ctx->stream_aux));
+                    SV_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream_aux));
+                    t->launches += 1;
+                }
             }
         }
         TrackCandProblem Cd{};
@@ -372,8 +394,11 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
                                         SVGPU_MATCH_BEST_ONLY, pose_guess_cw);
         if (rc) return rc;
         if (extract) {
-            SV_HIP(ctx, hipMemcpyAsync(t->h_obs, cur->slab, obs_bytes, hipMemcpyDeviceToHost, s));
-            t->launches += 1;
+            if (ctx->stream_aux) SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            else {
+                SV_HIP(ctx, hipMemcpyAsync(t->h_obs, cur->slab, obs_bytes, hipMemcpyDeviceToHost, s));
+                t->launches += 1;
+            }
         }
         if ((rc = sv_map_reader_end(ctx, t->map, s))) return rc;
         lock.unlock();

@@ -42,6 +42,8 @@ struct TrackCandProblem {
     const int32_t* q_octave;    // mode 0: last frame's keypoint octaves / angles
     const float* q_angle;
     int check_orientation;
+    unsigned thr;               // the matcher's distance threshold and ratio (mode 1): candidates that can take part in no verdict are not listed
+    float lowe_ratio;
     // the frame the queries are matched into (resident observation)
     const uint32_t* tdesc;
     const float* t_xy;

@@ -130,34 +130,50 @@ __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
         hi_y = min(hi_y, P.rows - 1);
         if (lo_x < P.cols && 0 <= hi_x && lo_y < P.rows && 0 <= hi_y && lo_x <= hi_x && lo_y <= hi_y) {
             const int ny = hi_y - lo_y + 1, ncell = (hi_x - lo_x + 1) * ny;
+            // (mode 1: a keypoint that holds a landmark with observations is skipped by EVERY query's scan, projection.cc:52-55 -- it never
+            //  enters a list.  Listed and left to the replay's owner table, 60 % of a tracked frame's targets were dead entries in front
+            //  of the live ones, and the replay walked past them in every sweep.)
             auto passes = [&](int idx) {
                 const int oct = P.t_octave[idx];
                 if (oct < min_level || max_level < oct) return false;
+                if (MODE == 1 && P.cur_lm) {
+                    const int held = P.cur_lm[idx];
+                    if (held >= 0 && held < P.map_cap && (map[held].flags & SVGPU_LM_HAS_OBSERVATION)) return false;
+                }
                 const float dx = P.t_xy[2 * idx] - ref_x, dy = P.t_xy[2 * idx + 1] - ref_y;
                 return fabsf(dx) < margin && fabsf(dy) < margin;
             };
-            auto entry = [&](int t) -> uint32_t {  // gates of projection.cc:52-62, 172-181 + the Hamming distance; 0xFFFFFFFF = gated out
+            // gates of projection.cc:52-62, 172-181 + the Hamming distance; 0xFFFFFFFF = the candidate can be left out of the list.  That
+            // covers the reference's own `continue`s AND distances that cannot take part in any verdict: as a best only d <= thr counts
+            // (:81, :198), as a second only one that can fail the ratio test of an acceptable best, lowe_ratio * d < thr (:82) -- unrelated
+            // descriptors sit around 128 bits, so nine in ten candidates of a window end here instead of in a list the replay walks
+            auto entry = [&](int t) -> uint32_t {
                 if (P.t_xright && 0.f < P.t_xright[t]) {
                     const float err = fabsf(o.xr - P.t_xright[t]);
                     if (margin < err) return 0xFFFFFFFFu;
                 }
                 if (MODE == 0 && P.check_orientation && fabsf(angle_diff(q_angle, P.t_angle[t])) > 30.0f) return 0xFFFFFFFFu;
-                return (hamming256(qd, P.tdesc + (size_t)t * 8) << 22) | (uint32_t)t;
+                const unsigned d = hamming256(qd, P.tdesc + (size_t)t * 8);
+                if (P.thr < d && (MODE == 0 || !(P.lowe_ratio * (float)d < (float)P.thr))) return 0xFFFFFFFFu;
+                return (d << 22) | (uint32_t)t;
             };
-            // `sink(pos, e)` receives every candidate at its scan position (the reference's candidate order)
+            // `sink(pos, e)` receives every listed candidate at its position in the reference's scan order
             auto walk = [&](auto&& sink) {
                 int done = 0;
                 for (int base = 0; base < ncell; base += 64) {
                     const int k = base + lane;
-                    int n = 0, c = 0, cached[TRACK_CACHE];
+                    int n = 0, c = 0;
+                    uint32_t cached[TRACK_CACHE];
                     if (k < ncell) {
                         c = (lo_x + k / ny) * P.rows + lo_y + k % ny;
                         for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) {
                             const int idx = P.cell_items[it];
                             if (!passes(idx)) continue;
+                            const uint32_t e = entry(idx);
+                            if (e == 0xFFFFFFFFu) continue;
 #pragma unroll
                             for (int u = 0; u < TRACK_CACHE; ++u)
-                                if (n == u) cached[u] = idx;
+                                if (n == u) cached[u] = e;
                             ++n;
                         }
                     }
@@ -173,12 +189,14 @@ __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
                     if (n > 0 && n <= TRACK_CACHE) {
 #pragma unroll
                         for (int u = 0; u < TRACK_CACHE; ++u)
-                            if (u < n) sink(pos + u, entry(cached[u]));
+                            if (u < n) sink(pos + u, cached[u]);
                     }
                     else if (n > TRACK_CACHE) {  // a crowded cell: walk it again
                         for (int it = P.cell_off[c]; it < P.cell_off[c + 1]; ++it) {
                             const int t = P.cell_items[it];
-                            if (passes(t)) sink(pos++, entry(t));
+                            if (!passes(t)) continue;
+                            const uint32_t e = entry(t);
+                            if (e != 0xFFFFFFFFu) sink(pos++, e);
                         }
                     }
                     done += __builtin_amdgcn_readlane(incl, 63);
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
             };
             // ONE walk: entries go to the wave's LDS strip while they fit it
             total = walk([&](int pos, uint32_t e) {
-                if (pos < TRACK_SORT_MAX) s_key[pos] = e == 0xFFFFFFFFu ? ~0ull : ((unsigned long long)(e >> 22) << 32) | ((unsigned long long)pos << 22) | (e & 0x3FFFFFu);
+                if (pos < TRACK_SORT_MAX) s_key[pos] = ((unsigned long long)(e >> 22) << 32) | ((unsigned long long)pos << 22) | (e & 0x3FFFFFu);
             });
             bool fits = true;
             if (total > TRACK_SLOT) {  // beyond the slot: appended behind the slots

@@ -46,6 +46,7 @@ public:
     svgpu_track_result last_motion_{}, last_local_{};  // statistics of the last calls
     //! launches + copies enqueued and stream synchronisations waited on, since construction
     void counters(long long& launches, long long& host_syncs) const;
+    const unsigned long long* debug_stamps() const { return svgpu_tracker_debug_stamps(tracker_); }
 
 private:
     svgpu_ctx* const ctx_;

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -171,6 +172,17 @@ extern "C" int svgpu_host_tracked_frame(const uint8_t* imgs, int n_frames, int w
                 for (int i = 0; i < 3; ++i) err = std::max(err, std::fabs(opt(i, 3) - gt(i, 3)));
                 counts[7] = (int)std::lround(err * 1e6);
                 if (rep == reps - 1) {
+                    if (std::getenv("SVGPU_TRACK_TRACE"))
+                        std::fprintf(stderr, "[track] motion: sweeps %d lm_iters %d obs %d cand %d | local: sweeps %d lm_iters %d obs %d cand %d\n", chain->last_motion_.replay_sweeps,
+                                     chain->last_motion_.lm_iterations, chain->last_motion_.num_observations, chain->last_motion_.num_candidates,
+                                     chain->last_local_.replay_sweeps, chain->last_local_.lm_iterations, chain->last_local_.num_observations,
+                                     chain->last_local_.num_candidates);
+                    if (const unsigned long long* st = chain->debug_stamps())
+                        if (st[0] > 1) {
+                            std::fprintf(stderr, "[track] k_pose_opt phases (us since its first stamp):");
+                            for (unsigned long long k = 2; k <= st[0]; ++k) std::fprintf(stderr, " %.1f", (double)(st[k] - st[1]) * 0.01);
+                            std::fprintf(stderr, "\n");
+                        }
                     long long l1 = 0, s1 = 0;
                     chain->counters(l1, s1);
                     g_chain_launches = (double)(l1 - launches0) / reps, g_chain_syncs = (double)(s1 - syncs0) / reps;

@@ -89,7 +89,7 @@ class _TrackConfig(C.Structure):
 
 class _TrackResult(C.Structure):
     _fields_ = [("n_keypoints", C.c_int), ("num_matches", C.c_int), ("num_valid", C.c_int), ("lm_iterations", C.c_int), ("num_observations", C.c_int),
-                ("num_candidates", C.c_int), ("pose_cw", C.c_double * 12)]
+                ("num_candidates", C.c_int), ("replay_sweeps", C.c_int), ("reserved", C.c_int), ("pose_cw", C.c_double * 12)]
 
     def as_dict(self):
         d = {f: getattr(self, f) for f, _ in self._fields_ if f != "pose_cw"}
