@@ -383,19 +383,25 @@ void svgpu_tracker_destroy(svgpu_tracker* tracker);
 /* frame_tracker::motion_based_track (module/frame_tracker.cc:22-60) up to discard_outliers, as one submission.
  *   img != NULL   system::create_monocular_frame's device work comes first: ORB extraction of `img` (row stride `stride`), undistortion,
  *                 bearings and grid -> `cur` becomes the resident observation; kps / desc / undist_kps / bearings (each cap entries)
- *                 receive the host copies data::frame_observation holds.  img == NULL: `cur` already holds the observation
+ *                 receive the host copies data::frame_observation holds (all four NULL: left in the tracker's own page-locked buffer,
+ *                 svgpu_tracker_observation).  img == NULL: `cur` already holds the observation
  *                 (svgpu_frame_adopt_extraction / svgpu_frame_upload) and those four outputs are ignored.
  *   last, last_lm_ids   the last frame's resident observation and, per keypoint of it, the landmark id it holds (-1: none)
  *   pose_guess_cw / pose_last_cw   3x4 [R|t] row-major: velocity * last pose, and the last frame's pose (assume_forward / backward)
  *   match_last    svgpu_frame_size(last) entries: keypoint of `cur` the landmark of last keypoint i was matched to, or -1; the caller
  *                 replays curr_frm.add_landmark(lm, match_last[i]) in increasing i (projection.cc:202)
- *   outlier       per keypoint of `cur` (cap entries): the pose optimizer's outlier flag
+ *   outlier       per keypoint of `cur` (with an image: cap entries, cap >= svgpu_orb_max_keypoints covers every frame): the pose optimizer's flag
  * The caller compares result->num_matches with its threshold and, below it, calls again with img = NULL and twice the margin
  * (frame_tracker.cc:36-40): the optimisation that was enqueued behind the first matcher is then simply discarded. */
 int svgpu_track_motion(svgpu_tracker* tracker, svgpu_frame* cur, const uint8_t* img, int stride, const svgpu_frame* last,
                        const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw, float margin,
                        int check_orientation, svgpu_keypoint* kps, uint8_t* desc, svgpu_keypoint* undist_kps, double* bearings, int cap,
                        int32_t* match_last, uint8_t* outlier, svgpu_track_result* result);
+/* The observation the last svgpu_track_motion with an image brought back, where the copy engine left it (page-locked memory of the tracker;
+ * valid until the tracker's next call): pass NULL for kps / desc / undist_kps / bearings there and read it here without a second copy.
+ * Each pointer is nullable; returns the keypoint count (0 when there is none). */
+int svgpu_tracker_observation(const svgpu_tracker* tracker, const svgpu_keypoint** kps, const uint8_t** desc, const svgpu_keypoint** undist_kps,
+                              const double** bearings);
 /* tracking_module::search_local_landmarks + optimize_current_frame_with_local_map's optimisation (tracking_module.cc:533-608, 441-446)
  * as one submission.
  *   cur_lm_ids    per keypoint of `cur`: the landmark id the frame holds now (-1: none) -- after discard_outliers and update_local_map's

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <vector>
 
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
@@ -57,6 +58,8 @@ struct svgpu_tracker {
     char* h_obs = nullptr;  // read-back of the fresh observation (prefix of the frame's slab)
     size_t h_obs_bytes = 0;
     int last_n_local = -1;
+    int obs_n = 0;          // the observation in h_obs (svgpu_tracker_observation)
+    size_t obs_off[4] = {0, 0, 0, 0};
     long long launches = 0, syncs = 0;
 };
 
@@ -82,6 +85,8 @@ int reserve(svgpu_tracker* t, int kp, int q, size_t cand, size_t img_bytes, size
     double pose_keep[12] = {0};
     const bool had_pose = t->d_work != nullptr;
     if (had_pose) SV_HIP(ctx, hipMemcpy(pose_keep, t->d_pose, sizeof pose_keep, hipMemcpyDeviceToHost));  // the last optimisation's pose survives a growth
+    std::vector<char> obs_keep;  // ... and so does the observation svgpu_tracker_observation hands out (a growth between an extraction and its matcher's re-run)
+    if (t->obs_n > 0 && t->h_obs) obs_keep.assign(t->h_obs, t->h_obs + t->h_obs_bytes);
     release(t);
     // input block: image | ids of the frame's keypoints (ckp) | ids of the queries (cq) | pose
     t->in_bytes = pad256(ib) + pad256((size_t)ckp * 4) + pad256((size_t)cq * 4) + 256;
@@ -126,6 +131,7 @@ int reserve(svgpu_tracker* t, int kp, int q, size_t cand, size_t img_bytes, size
     t->h_obs_bytes = ob;
     t->cap_kp = ckp, t->cap_q = cq, t->cap_cand = cc, t->img_bytes = ib;
     t->last_n_local = -1;
+    if (!obs_keep.empty()) memcpy(t->h_obs, obs_keep.data(), std::min(obs_keep.size(), ob));
     return SVGPU_OK;
 }
 
@@ -282,6 +288,15 @@ void svgpu_tracker_destroy(svgpu_tracker* t) {
     delete t;
 }
 
+int svgpu_tracker_observation(const svgpu_tracker* t, const svgpu_keypoint** kps, const uint8_t** desc, const svgpu_keypoint** undist_kps, const double** bearings) {
+    if (!t || !t->h_obs || t->obs_n <= 0) return 0;
+    if (kps) *kps = (const svgpu_keypoint*)(t->h_obs + t->obs_off[0]);
+    if (desc) *desc = (const uint8_t*)(t->h_obs + t->obs_off[1]);
+    if (undist_kps) *undist_kps = (const svgpu_keypoint*)(t->h_obs + t->obs_off[2]);
+    if (bearings) *bearings = (const double*)(t->h_obs + t->obs_off[3]);
+    return t->obs_n;
+}
+
 const unsigned long long* svgpu_tracker_debug_stamps(const svgpu_tracker* t) { return t ? t->h_stamps : nullptr; }
 
 int svgpu_tracker_counters(const svgpu_tracker* t, long long* launches, long long* host_syncs) {
@@ -297,7 +312,7 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
     if (!t) return SVGPU_ERR_INVALID;
     svgpu_ctx* ctx = t->ctx;
     if (!cur || !last || !pose_guess_cw || !pose_last_cw || !result || cur == last || (last->n > 0 && (!last_lm_ids || !match_last)) || !outlier || cap < 0
-        || (img && (!kps || !desc || !undist_kps || !bearings)))
+        || (img && (kps || desc || undist_kps || bearings) && (!kps || !desc || !undist_kps || !bearings)))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: bad arguments");
     if (cur->device != ctx->device || last->device != ctx->device) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: a frame lives on another device");
     const OrbConfig& C = ctx->orb;
@@ -406,12 +421,17 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
         t->syncs += 1;
         if (extract) {  // host copies of the fresh observation (data::frame_observation), out of the slab prefix
             cur->n = t->h_n[0];
-            const int m = std::min(cur->n, cap);
-            const char* o = t->h_obs;
-            memcpy(kps, o + ((char*)cur->kps_raw - cur->slab), (size_t)m * sizeof(svgpu_keypoint));
-            memcpy(desc, o + ((char*)cur->desc - cur->slab), (size_t)m * 32);
-            memcpy(undist_kps, o + ((char*)cur->undist - cur->slab), (size_t)m * sizeof(svgpu_keypoint));
-            memcpy(bearings, o + ((char*)cur->bearings - cur->slab), (size_t)m * 24);
+            t->obs_n = cur->n;
+            t->obs_off[0] = (size_t)((char*)cur->kps_raw - cur->slab), t->obs_off[1] = (size_t)((char*)cur->desc - cur->slab);
+            t->obs_off[2] = (size_t)((char*)cur->undist - cur->slab), t->obs_off[3] = (size_t)((char*)cur->bearings - cur->slab);
+            if (kps) {
+                const int m = std::min(cur->n, cap);
+                const char* o = t->h_obs;
+                memcpy(kps, o + t->obs_off[0], (size_t)m * sizeof(svgpu_keypoint));
+                memcpy(desc, o + t->obs_off[1], (size_t)m * 32);
+                memcpy(undist_kps, o + t->obs_off[2], (size_t)m * sizeof(svgpu_keypoint));
+                memcpy(bearings, o + t->obs_off[3], (size_t)m * 24);
+            }
         }
         if ((size_t)t->h_num[1] <= t->cap_cand) break;
         // the candidate lists did not fit the capacity: nothing ran behind the list kernel.  Grow (fresh buffers, counter at zero) and enqueue
@@ -421,7 +441,7 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
     }
     const int n_kp = cur->n;
     if (n_last > 0) memcpy(match_last, t->h_match, (size_t)n_last * 4);
-    memcpy(outlier, t->h_outlier, (size_t)std::min(n_kp, img ? cap : n_kp));
+    memcpy(outlier, t->h_outlier, (size_t)(img ? std::min(n_kp, cap) : n_kp));
     fill_result(t, n_kp, result);
     if (img && n_kp > cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "svgpu_track_motion: more keypoints than cap");
     return SVGPU_OK;

@@ -1,7 +1,10 @@
 // Host side of the tracked-frame chain: the landmark table's shadow + dirty list, and the two reference call sites (tracking_hip.h).
 #include "tracking_hip.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -120,6 +123,19 @@ size_t pending_map_updates() {
 
 // ------------------------------------------------------------------------------------------------------------------- the chain
 namespace {
+// SVGPU_TRACK_TRACE: host-side phase times of the two calls, to stderr
+struct lap_timer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    const char* who;
+    explicit lap_timer(const char* w) : on(std::getenv("SVGPU_TRACK_TRACE") != nullptr), t(std::chrono::steady_clock::now()), who(w) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[track host] %-10s %-34s %7.1f us\n", who, what, std::chrono::duration<double, std::micro>(n - t).count());
+        t = n;
+    }
+};
 void pose12(const Mat44_t& T, double* out) {
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 4; ++j) out[4 * i + j] = T(i, j);
@@ -158,18 +174,52 @@ tracked_frame_chain::~tracked_frame_chain() { svgpu_tracker_destroy(tracker_); }
 
 void tracked_frame_chain::counters(long long& launches, long long& host_syncs) const { svgpu_tracker_counters(tracker_, &launches, &host_syncs); }
 
+frame_handle tracked_frame_chain::handle_of(const data::frame& frm) {
+    for (const memo& m : memo_)
+        if (m.h && m.id == frm.id_ && (size_t)svgpu_frame_size(m.h.get()) == frm.frm_obs_.undist_keypts_.size()) return m.h;
+    frame_handle h = resident(frm);
+    if (!h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
+    remember(frm.id_, h);
+    return h;
+}
+void tracked_frame_chain::remember(unsigned int frame_id, const frame_handle& h) {
+    for (memo& m : memo_)
+        if (m.h && m.id == frame_id) {
+            m.h = h;
+            return;
+        }
+    memo_[1] = memo_[0];  // (two frames: the current one and the one before)
+    memo_[0].id = frame_id;
+    memo_[0].h = h;
+}
+
+namespace {
+// system.cc:403-404: the frame of a freshly built observation.  data::frame sizes its (private) landmark vector in its constructor -- from
+// the keypoint count alone, so it is constructed from a stub with that many keypoints (the constructor copies its observation twice:
+// 400 KB for a 2 400-keypoint frame) and the observation itself is MOVED into the public frm_obs_ afterwards.
+void rebuild_frame(data::frame& frm, data::frame_observation& frm_obs) {
+    data::frame_observation stub;
+    stub.undist_keypts_.resize(frm_obs.undist_keypts_.size());
+#ifdef SVGPU_WITH_STELLA_VSLAM
+    frm = data::frame(frm.id_, frm.timestamp_, frm.camera_, const_cast<feature::orb_params*>(frm.orb_params_), stub, frm.markers_2d_);
+#else
+    frm = data::frame(frm.id_, frm.camera_, frm.orb_params_, stub);
+#endif
+    frm.frm_obs_ = std::move(frm_obs);
+}
+}  // namespace
+
 bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::frame& last_frm, const Mat44_t& velocity, unsigned int num_matches_thr, float margin,
                                              const cv::Mat* img, std::vector<cv::KeyPoint>* keypts) {
+    lap_timer T("motion");
     // Set the initial pose by using the motion model (frame_tracker.cc:25-26)
     const Mat44_t guess = velocity * last_frm.get_pose_cw();
-    curr_frm.set_pose_cw(guess);
     double guess12[12], last12[12];
     pose12(guess, guess12);
     pose12(last_frm.get_pose_cw(), last12);
     // the last frame: its resident observation, and per keypoint the id of the landmark it holds (projection.cc:119-127)
-    const frame_handle last_h = resident(last_frm);
-    if (!last_h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
-    const auto& last_lms = last_frm.landmarks_;
+    const frame_handle last_h = handle_of(last_frm);
+    const auto last_lms = last_frm.get_landmarks();
     const int n_last = (int)last_frm.frm_obs_.undist_keypts_.size();
     last_ids_.resize(n_last);
     for (int i = 0; i < n_last; ++i) {
@@ -177,53 +227,67 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
         last_ids_[i] = (lm && !lm->will_be_erased()) ? (int32_t)lm->id_ : -1;
     }
     match_.resize(std::max(n_last, 1));
+    T.lap("last frame: resident + ids");
     flush_map(ctx_);
+    T.lap("flush_map");
     frame_handle cur_h;
     int cap = 0;
     if (img) {
         cap = std::max(1, svgpu_orb_max_keypoints(ctx_));
-        kps_.resize(cap), und_.resize(cap), desc_.resize((size_t)cap * 32), brg_.resize((size_t)cap * 3);
         cur_h = new_frame(ctx_);
         outlier_.resize(cap);
     }
     else {
-        cur_h = resident(curr_frm);
-        if (!cur_h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
+        cur_h = handle_of(curr_frm);
         outlier_.resize(std::max<size_t>(curr_frm.frm_obs_.undist_keypts_.size(), 1));
+        cap = (int)outlier_.size();
     }
     unsigned int num_matches = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fused = img && attempt == 0;
         check(svgpu_track_motion(tracker_, cur_h.get(), fused ? img->ptr(0) : nullptr, fused ? (int)img->step : 0, last_h.get(), last_ids_.data(), guess12, last12,
-                                 attempt == 0 ? margin : 2 * margin, 1 /* projection_matcher(0.9, true) */, fused ? kps_.data() : nullptr,
-                                 fused ? desc_.data() : nullptr, fused ? und_.data() : nullptr, fused ? brg_.data() : nullptr, fused ? cap : 0, match_.data(),
+                                 attempt == 0 ? margin : 2 * margin, 1 /* projection_matcher(0.9, true) */, nullptr, nullptr, nullptr, nullptr, cap, match_.data(),
                                  outlier_.data(), &last_motion_),
               "svgpu_track_motion");
-        if (fused) {  // system.cc:380-395: the host copies data::frame_observation holds
-            const int n = last_motion_.n_keypoints;
-            auto& o = curr_frm.frm_obs_;
+        T.lap("svgpu_track_motion");
+        if (fused) {  // system.cc:380-395: the host copies data::frame_observation holds, straight out of the tracker's page-locked buffer
+            const svgpu_keypoint *kps = nullptr, *und = nullptr;
+            const uint8_t* desc = nullptr;
+            const double* brg = nullptr;
+            const int n = svgpu_tracker_observation(tracker_, &kps, &desc, &und, &brg);
+            data::frame_observation o;
             o.num_grid_cols_ = num_grid_cols_, o.num_grid_rows_ = num_grid_rows_;
             o.descriptors_.create(n, 32, CV_8U);
-            if (n > 0) std::memcpy(o.descriptors_.ptr(0), desc_.data(), (size_t)n * 32);
+            if (n > 0) std::memcpy(o.descriptors_.ptr(0), desc, (size_t)n * 32);
             o.undist_keypts_.resize(n);
-            if (n > 0) std::memcpy(static_cast<void*>(o.undist_keypts_.data()), und_.data(), (size_t)n * sizeof(svgpu_keypoint));
+            if (n > 0) std::memcpy(static_cast<void*>(o.undist_keypts_.data()), und, (size_t)n * sizeof(svgpu_keypoint));
             o.bearings_.resize(n);
             for (int i = 0; i < n; ++i)
-                for (int k = 0; k < 3; ++k) o.bearings_[i](k) = brg_[3 * (size_t)i + k];
+                for (int k = 0; k < 3; ++k) o.bearings_[i](k) = brg[3 * (size_t)i + k];
             if (keypts) {
                 keypts->resize(n);
-                if (n > 0) std::memcpy(static_cast<void*>(keypts->data()), kps_.data(), (size_t)n * sizeof(svgpu_keypoint));
+                if (n > 0) std::memcpy(static_cast<void*>(keypts->data()), kps, (size_t)n * sizeof(svgpu_keypoint));
             }
-            curr_frm.landmarks_.assign(n, nullptr);
-            register_adopted(curr_frm.id_, cur_h, o.undist_keypts_);
+            rebuild_frame(curr_frm, o);
+            register_adopted(curr_frm.id_, cur_h, curr_frm.frm_obs_.undist_keypts_);
+            remember(curr_frm.id_, cur_h);
+            T.lap("observation -> frm_obs_, register");
         }
-        // Initialize the 2D-3D matches, then replay them in the reference's order (frame_tracker.cc:29, projection.cc:202)
+        // Initialize the 2D-3D matches, then replay them in the reference's order (frame_tracker.cc:29, projection.cc:202); cur_ids_ mirrors
+        // the ids the frame holds so that the loops below do not copy a shared_ptr per keypoint just to look at it
+        const int n_cur = (int)curr_frm.frm_obs_.undist_keypts_.size();
         curr_frm.erase_landmarks();
+        cur_ids_.assign(std::max(n_cur, 1), -1);
         for (int i = 0; i < n_last; ++i)
-            if (0 <= match_[i]) curr_frm.add_landmark(last_lms[i], (unsigned int)match_[i]);
+            if (0 <= match_[i]) {
+                curr_frm.add_landmark(last_lms[i], (unsigned int)match_[i]);
+                cur_ids_[match_[i]] = last_ids_[i];
+            }
         num_matches = (unsigned int)last_motion_.num_matches;
+        T.lap("add_landmark replay");
         if (num_matches >= num_matches_thr) break;  // else: increment the margin, and search again (:36-40)
     }
+    curr_frm.set_pose_cw(guess);
     if (num_matches < num_matches_thr) return false;
     // Pose optimization (:48-51) -- already done behind the matcher, on the device
     curr_frm.set_pose_cw(pose44(last_motion_.pose_cw));
@@ -231,30 +295,37 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
     unsigned int num_valid_matches = 0;
     const unsigned int n = (unsigned int)curr_frm.frm_obs_.undist_keypts_.size();
     for (unsigned int idx = 0; idx < n; ++idx) {
-        if (curr_frm.get_landmark(idx) == nullptr) continue;
-        if (outlier_[idx]) curr_frm.erase_landmark_with_index(idx);
+        if (cur_ids_[idx] < 0) continue;
+        if (outlier_[idx]) {
+            curr_frm.erase_landmark_with_index(idx);
+            cur_ids_[idx] = -1;
+        }
         else ++num_valid_matches;
     }
+    T.lap("discard_outliers");
     return num_valid_matches >= num_matches_thr;
 }
 
 bool tracked_frame_chain::track_local_map(data::frame& curr_frm, const std::vector<std::shared_ptr<data::landmark>>& local_landmarks,
                                           unsigned int fixed_keyframe_id_threshold, float margin, float lowe_ratio) {
-    const frame_handle cur_h = resident(curr_frm);
-    if (!cur_h) throw std::runtime_error("tracked_frame_chain: resident frames are disabled (SVGPU_NO_RESIDENT_FRAMES)");
+    lap_timer T("local map");
+    const frame_handle cur_h = handle_of(curr_frm);
+    T.lap("resident(curr_frm)");
     // select the landmarks which can be reprojected from the ones observed in the current frame (tracking_module.cc:536-551): the frame's
     // own landmarks are stamped in a table by id instead of collected in a hash set
     const unsigned int n = (unsigned int)curr_frm.frm_obs_.undist_keypts_.size();
+    const auto cur_lms = curr_frm.get_landmarks();
     cur_ids_.resize(std::max(n, 1u));
     ++frame_serial_;
     for (unsigned int idx = 0; idx < n; ++idx) {
-        const auto& lm = curr_frm.landmarks_[idx];
+        const auto& lm = cur_lms[idx];
         cur_ids_[idx] = lm ? (int32_t)lm->id_ : -1;
         if (!lm || lm->will_be_erased()) continue;
         if (lm->id_ >= held_stamp_.size()) held_stamp_.resize((size_t)lm->id_ * 2 + 1024, 0);
         held_stamp_[lm->id_] = frame_serial_;
         lm->increase_num_observable();  // :549
     }
+    T.lap("frame's landmark ids");
     const int n_local = (int)local_landmarks.size();
     local_ids_.resize(std::max(n_local, 1));
     last_local_lm_ids_.resize(n_local);
@@ -278,10 +349,13 @@ bool tracked_frame_chain::track_local_map(data::frame& curr_frm, const std::vect
     match_.resize(std::max(n_local, 1));
     visible_.resize(std::max(n_local, 1));
     outlier_.resize(std::max(n, 1u));
+    T.lap("local landmark ids");
     flush_map(ctx_);
+    T.lap("flush_map");
     check(svgpu_track_local_map(tracker_, cur_h.get(), cur_ids_.data(), n_local, local_ids_.data(), nullptr /* the first half's pose, still on the device */, margin,
                                 lowe_ratio, 0.5f, match_.data(), visible_.data(), outlier_.data(), &last_local_),
           "svgpu_track_local_map");
+    T.lap("svgpu_track_local_map");
     bool found_proj_candidate = false;
     for (int i = 0; i < n_local; ++i)
         if (visible_[i]) {
@@ -290,13 +364,18 @@ bool tracked_frame_chain::track_local_map(data::frame& curr_frm, const std::vect
         }
     if (!found_proj_candidate) return false;  // :596-599 "projection candidate not found"
     for (int i = 0; i < n_local; ++i)
-        if (0 <= match_[i]) curr_frm.add_landmark(local_landmarks[i], (unsigned int)match_[i]);  // projection.cc:88
+        if (0 <= match_[i]) {
+            curr_frm.add_landmark(local_landmarks[i], (unsigned int)match_[i]);  // projection.cc:88
+            cur_ids_[match_[i]] = (int32_t)local_landmarks[i]->id_;
+        }
     // optimize_current_frame_with_local_map (:441-455): the pose, then the outliers
     curr_frm.set_pose_cw(pose44(last_local_.pose_cw));
-    for (unsigned int idx = 0; idx < n; ++idx) {
-        if (!outlier_[idx]) continue;
-        if (curr_frm.get_landmark(idx)) curr_frm.erase_landmark_with_index(idx);
-    }
+    for (unsigned int idx = 0; idx < n; ++idx)
+        if (outlier_[idx] && cur_ids_[idx] >= 0) {
+            curr_frm.erase_landmark_with_index(idx);
+            cur_ids_[idx] = -1;
+        }
+    T.lap("observable marks, add_landmark, outliers");
     return true;
 }
 

@@ -62,6 +62,14 @@ private:
     std::vector<uint8_t> desc_;
     std::vector<double> brg_;
     std::vector<unsigned int> last_local_lm_ids_;
+    // the resident observations of the frames this chain has just handled, by frame id: the second half of a frame and the first half of the
+    // next one take them from here instead of re-verifying a 150 KB observation against the cache (data::frame::frm_obs_ is constant)
+    struct memo {
+        unsigned int id = 0;
+        frame_handle h;
+    } memo_[2];
+    frame_handle handle_of(const data::frame& frm);
+    void remember(unsigned int frame_id, const frame_handle& h);
     uint32_t frame_serial_ = 0;
     std::vector<uint32_t> held_stamp_;  // per landmark id: serial of the frame that holds it (curr_landmark_ids of :536-551 without a hash set)
 };

@@ -399,6 +399,9 @@ inline void landmark::update_mean_normal_and_obs_scale_variance() {  // data/lan
 class frame {  // data/frame.h:42-183
 public:
     frame(unsigned int id, camera::base* camera, const feature::orb_params* orb_params) : id_(id), camera_(camera), orb_params_(orb_params) {}
+    // data/frame.cc:18-22: the frame of an observation -- one (empty) landmark slot per keypoint
+    frame(unsigned int id, camera::base* camera, const feature::orb_params* orb_params, const frame_observation& frm_obs)
+        : id_(id), camera_(camera), orb_params_(orb_params), frm_obs_(frm_obs), landmarks_(frm_obs.undist_keypts_.size(), nullptr) {}
     void set_pose_cw(const Mat44_t& pose_cw) { pose_cw_ = pose_cw; }
     Mat44_t get_pose_cw() const { return pose_cw_; }
     Mat33_t get_rot_cw() const {
