@@ -83,7 +83,8 @@ struct CandProblem {
     int cap;                  // > 0: capacity of dist / cand_idx; the kernels do nothing when cand_off[nq] exceeds it (the host re-runs)
     // tracked-frame chain (track_kernels.hip): lists allocated in arbitrary order, counts known to the device only, results also written
     // where the host reads them without a copy
-    const int32_t* cand_cnt;  // nullable: list q = [cand_off[q], cand_off[q] + cand_cnt[q]); cand_off[nq] is then the allocation counter
+    const int32_t* cand_cnt;  // nullable: list q = [cand_off[q], cand_off[q] + cand_cnt[q])
+    const int32_t* cand_total;// nullable: where the lists' total (or the allocation counter of the slot form) lives; default cand_off + nq
     const int32_t* nt_dev;    // nullable: the number of targets in device memory (at most nt, which then only sizes the tables)
     int32_t* match_host;      // nullable: page-locked copy of match_q
     int32_t* num_host;        // nullable: page-locked copy of *num, followed by the list total (cand_off[nq])

@@ -827,9 +827,10 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
 // ORDER beyond ties: TRIANGULATION skips every candidate farther than the running best (bow_tree.cc:96-98 / robust.cc:89-91), so its
 // "second" is the last superseded best, and AREA replays a non-monotone state.
 #define CAND_SORT_MAX 1024
+__device__ __forceinline__ int cand_total(const CandProblem& P) { return P.cand_total ? *P.cand_total : P.cand_off[P.nq]; }
 __device__ __forceinline__ bool cand_sorted(const CandProblem& P, int n) { return n <= CAND_SORT_MAX && P.mode != SVGPU_MATCH_TRIANGULATION && P.mode != SVGPU_MATCH_AREA; }
 __global__ void k_cand_dist(CandProblem P) {
-    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) return;  // the lists did not fit the guessed capacity: the host re-runs with the exact size
+    if (P.cap > 0 && cand_total(P) > P.cap) return;  // the lists did not fit the guessed capacity: the host re-runs with the exact size
     const int q = blockIdx.x;
     if (P.q_valid && !P.q_valid[q]) return;
     const int lo = P.cand_off[q], hi = P.cand_off[q + 1];
@@ -1124,8 +1125,8 @@ __host__ __device__ inline size_t cand_lds_bytes(int nq, int nt, int K, bool wit
 __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) {
     extern __shared__ int s_cand[];
     __shared__ int s_changed;
-    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) {  // the lists did not fit: nothing was written, the host re-runs with the exact size
-        if (P.num_host && threadIdx.x == 0) P.num_host[0] = 0, P.num_host[1] = P.cand_off[P.nq];
+    if (P.cap > 0 && cand_total(P) > P.cap) {  // the lists did not fit: nothing was written, the host re-runs with the exact size
+        if (P.num_host && threadIdx.x == 0) P.num_host[0] = 0, P.num_host[1] = cand_total(P);
         return;
     }
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1215,14 +1216,14 @@ __global__ __launch_bounds__(1024) void k_cand_replay_lds(CandProblem P, int K) 
     __syncthreads();
     if (tid == 0) {
         *P.num = s_changed;
-        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = P.cand_off[P.nq], P.num_host[2] = sweeps_total;
+        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = cand_total(P), P.num_host[2] = sweeps_total;
     }
 }
 // the same replay with its tables in global memory (inputs beyond the LDS form)
 __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __restrict__ owner, int* __restrict__ match) {
     __shared__ int s_changed;
-    if (P.cap > 0 && P.cand_off[P.nq] > P.cap) {
-        if (P.num_host && threadIdx.x == 0) P.num_host[0] = 0, P.num_host[1] = P.cand_off[P.nq];
+    if (P.cap > 0 && cand_total(P) > P.cap) {
+        if (P.num_host && threadIdx.x == 0) P.num_host[0] = 0, P.num_host[1] = cand_total(P);
         return;
     }
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(1024) void k_cand_replay(CandProblem P, int* __rest
     __syncthreads();
     if (tid == 0) {
         *P.num = s_changed;
-        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = P.cand_off[P.nq];
+        if (P.num_host) P.num_host[0] = s_changed, P.num_host[1] = cand_total(P);
     }
 }
 

@@ -182,6 +182,7 @@ int enqueue_match_and_optimize(svgpu_tracker* t, hipStream_t s, TrackCandProblem
     C.nt_dev = nt_dev;
     C.occupied = t->occupied;
     C.cand_off = t->cand_off;
+    C.counter = t->num + 2;  // (t->num: [0] matches, [2] the list allocation counter)
     C.cand_cnt = t->cand_cnt;
     C.dist = t->dist;
     C.cap = (int)std::min<size_t>(t->cap_cand, 0x7FFFFFFF);
@@ -199,6 +200,7 @@ int enqueue_match_and_optimize(svgpu_tracker* t, hipStream_t s, TrackCandProblem
     P.nt_dev = nt_dev;
     P.cand_off = t->cand_off;
     P.cand_cnt = t->cand_cnt;
+    P.cand_total = t->num + 2;
     P.q_valid = t->q_valid;
     P.occupied = C.cur_lm ? t->occupied : nullptr;
     P.q_blocks = t->q_blocks;
@@ -228,7 +230,7 @@ int enqueue_match_and_optimize(svgpu_tracker* t, hipStream_t s, TrackCandProblem
     O.gain_thr = 1e-3;  // terminateAction->setGainThreshold(1e-3), pose_optimizer_g2o.cc:55
     O.pose_out = t->d_pose;
     O.outlier = t->po_outlier, O.result = t->po_result, O.level = t->po_level, O.robust = t->po_robust;
-    O.trk_overflow = t->cand_off + nq, O.trk_overflow_cap = C.cap;
+    O.trk_overflow = t->num + 2, O.trk_overflow_cap = C.cap;
     O.trk_match_q = t->match_q, O.trk_qid = q_ids, O.trk_nq = nq;
     O.trk_cur_lm = cur_lm, O.trk_reset_cur = reset_cur, O.trk_who = t->who;
     O.trk_nt_dev = nt_dev, O.trk_nt = nt;
@@ -239,7 +241,7 @@ int enqueue_match_and_optimize(svgpu_tracker* t, hipStream_t s, TrackCandProblem
     O.trk_huber = t->cfg.is_monocular ? std::sqrt(chi_sq_2D) : std::sqrt(chi_sq_3D);
     O.trk_pos = t->po_pos, O.trk_uvr = t->po_uvr, O.trk_w = t->po_w, O.trk_h = t->po_h, O.trk_kp_of = t->kp_of;
     O.trk_outlier_kp = t->outlier_kp, O.host_outlier_kp = t->h_outlier, O.host_pose = t->h_pose, O.host_result = t->h_result;
-    O.trk_counter_reset = t->cand_off + nq;
+    O.trk_counter_reset = t->num + 2;
     static const bool want_stamps = std::getenv("SVGPU_TRACK_STAMPS") != nullptr;
     if (want_stamps) {
         O.stamps = t->h_stamps;

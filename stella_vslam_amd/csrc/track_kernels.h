@@ -61,7 +61,8 @@ struct TrackCandProblem {
     int nt;
     uint8_t* occupied;          // nt
     // outputs
-    int32_t* cand_off;          // nq + 1; [nq] = allocation counter of the lists beyond their slot (zero on entry)
+    int32_t* cand_off;          // nq
+    int32_t* counter;           // allocation counter of the lists beyond their slot (zero on entry; a word of its own: the two halves of a frame have different nq)
     int32_t* cand_cnt;          // nq
     uint32_t* dist;             // nq * TRACK_SLOT + cap entries: (distance << 22) | keypoint, 0xFFFFFFFF = gated out; lists up to 1 024 entries sorted
     int cap;                    // entries behind the slots

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_track_cand(TrackCandProblem P) {
             bool fits = true;
             if (total > TRACK_SLOT) {  // beyond the slot: appended behind the slots
                 int off = 0;
-                if (lane == 0) off = atomicAdd(&P.cand_off[P.nq], total);
+                if (lane == 0) off = atomicAdd(P.counter, total);
                 off = __builtin_amdgcn_readfirstlane(off);
                 fits = off + total <= P.cap;  // beyond the capacity nothing is written: the host re-runs the chain with a larger one
                 list_off = P.nq * TRACK_SLOT + off;

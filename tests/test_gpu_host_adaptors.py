@@ -34,3 +34,31 @@ def test_cpp_adaptors_compile_against_standin_headers():
     subprocess.check_call(["make", "-C", str(ROOT / "stella_vslam_amd" / "host"), "-B"], stdout=subprocess.DEVNULL)
     assert (ROOT / "stella_vslam_amd" / "host" / "libsvgpu_host.so").exists()
     assert (ROOT / "stella_vslam_amd" / "host" / "test_drop_in").exists()
+
+
+@pytest.mark.gpu
+def test_tracked_frame_chain_equals_the_per_call_drop_in_classes():
+    """One tracked frame through the C++ drop-in classes three ways (stella_vslam_amd/host/tracked_frame.cpp): the CHAIN (tracked_frame_chain:
+    landmark ids + the device-resident landmark table fed by data::landmark's notifications, two submissions), the per-call classes on
+    resident frames, and the per-call classes uploading every frame.  Same keypoints, matches, inliers and local-map visibility everywhere,
+    the same optimised pose to the micrometre -- and the chain stays within its launch / synchronisation budget."""
+    import ctypes as C
+
+    import numpy as np
+
+    from stella_vslam_amd import synthetic
+    host = C.CDLL(str(ROOT / "stella_vslam_amd" / "host" / "libsvgpu_host.so"))
+    host.svgpu_host_tracked_frame_counters.restype = None
+    seq = np.ascontiguousarray(synthetic.frame_sequence(4, 640, 480, seed=0x5EED))
+    got = {}
+    for mode in (2, 1, 0):
+        ms, cnt = np.zeros(8), np.zeros(8, np.int32)
+        rc = host.svgpu_host_tracked_frame(C.c_void_p(seq.ctypes.data), len(seq), 640, 480, 3, mode, C.c_void_p(ms.ctypes.data), C.c_void_p(cnt.ctypes.data))
+        assert rc == 0, mode
+        got[mode] = cnt.copy()
+    assert got[2][0] > 1800 and got[2][2] > 800 and got[2][3] > 600 and got[2][5] > 100   # keypoints, matches 1, inliers 1, matches 2
+    assert np.array_equal(got[2], got[1]) and np.array_equal(got[1], got[0]), got
+    assert got[2][7] < 5000   # translation error of the optimised pose, micrometres (the guess is off by 4 mm)
+    launches, syncs = C.c_double(0), C.c_double(0)
+    host.svgpu_host_tracked_frame_counters(C.byref(launches), C.byref(syncs))
+    assert syncs.value == 2.0 and launches.value <= 15.0
