@@ -73,6 +73,7 @@ public:
         return *this;
     }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    bool isContinuous() const { return step.v == (size_t)cols * esz_; }
     int type() const { return depth(); }
     size_t step1() const { return step.v; }
     void release() {

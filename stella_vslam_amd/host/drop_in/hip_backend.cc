@@ -288,6 +288,12 @@ void forget_keyframe(unsigned int keyframe_id) {
 
 }  // namespace hip
 
+#if !defined(SVGPU_DROP_IN_OPTIMIZE_ONLY) && !defined(SVGPU_DROP_IN_MATCH_ONLY)
+namespace hip {
+svgpu_map* flush_map(svgpu_ctx* ctx);  // drop_in/tracking_hip.h
+}
+#endif
+
 namespace {
 using lm_ptr = std::shared_ptr<data::landmark>;
 using kf_ptr = std::shared_ptr<data::keyframe>;
@@ -1001,6 +1007,12 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
                 for (int k = 0; k < 3; ++k) mkr->corners_pos_w_[corner_idx](k) = pts_out[(size_t)(mk_slot.second + corner_idx) * 3 + k];
         }
     }
+#if !defined(SVGPU_DROP_IN_OPTIMIZE_ONLY) && !defined(SVGPU_DROP_IN_MATCH_ONLY)
+    // the write-back has moved a few thousand landmarks (set_pos_in_world, update_mean_normal_and_obs_scale_variance, compute_descriptor:
+    // drop_in/map_mirror.h): the device-resident landmark table is brought up to date HERE, on the mapping thread, so that the tracking
+    // thread's next frame finds nothing left to upload
+    hip::flush_map(hip::context());
+#endif
 }
 
 namespace hip_backend {
