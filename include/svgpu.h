@@ -639,7 +639,7 @@ typedef struct svgpu_ba_stats {
  *   PCG       block-Jacobi PCG on the block-sparse Schur complement: inside ONE workgroup (blocks, block rows, vectors all in
  *             its LDS) while the kept 6x6 blocks fit ~150 KB and 6 * free poses <= 512, else one kernel launch per iteration
  *   CHOLESKY  the LDS LL^T (larger systems fall back to PCG)
- *   DENSE     dense image + rocSOLVER dpotrf / dpotrs (loaded on first use)
+ *   DENSE     dense image in global memory + the library's own one-workgroup LL^T (no vendor solver is loaded anywhere)
  *   ENVELOPE  direct block envelope (skyline) LL^T after a reverse Cuthill-McKee ordering of the keyframe graph -- what AUTO takes beyond
  *             the on-chip solvers while the envelope stays under 256 MB (the reference factors this system with a sparse Cholesky)
  * pcg_tolerance: relative residual |r| / |g| (<= 0: 1e-10); pcg_max_iterations <= 0: max(2000, 4 n).  A solve that hits the

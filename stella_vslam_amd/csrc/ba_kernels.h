@@ -76,7 +76,7 @@ struct BaDev {
     double* bp;    // nP x 6
     double* Sblk;  // NB x 36: the kept upper blocks (a <= b) of the reduced camera system, row-major 6x6 each, in blk_ab order
     double* g;     // n: right-hand side of the reduced system (directly behind Sblk: one all-reduce covers both)
-    double* S;     // dense (n + 1) x n image, only for the rocSOLVER path (solver = dense)
+    double* S;     // dense (n + 1) x n image in global memory (solver = dense: k_ba_chol_global)
     double* dp;    // n
     double* dl;    // L x 3
     double* red;   // reduction scratch / read-back: see offsets below
@@ -171,7 +171,7 @@ void sv_ba_prepare(hipStream_t s, const BaDev& D);                              
 void sv_ba_decide(hipStream_t s, const BaDev& D);
 bool sv_ba_tail_ok(const BaDev& D);                                             // local-BA sized, not sharded
 void sv_ba_tail(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);                 // update + chi2 of the trial state in one launch                               // rho test, damping update, terminate_action
-void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);          // rocSOLVER dpotrf / dpotrs (solver = dense)
+void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);          // dense image in global memory + one-workgroup LL^T (solver = dense)
 void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);               // back-substitution, trial state
 // block-Jacobi PCG on the block-sparse reduced camera system (ba_pcg.hip)
 void sv_pcg_init(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);

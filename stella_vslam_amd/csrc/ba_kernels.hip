@@ -6,8 +6,6 @@
 //   k_ba_chi2                     computeActiveErrors + activeRobustChi2
 //   k_ba_gate                     chi2 / depth gate (optimize/local_bundle_adjuster_g2o.cc:323-344, 354-375)
 // Every reduction runs in a fixed order (no floating-point atomics): results are run-to-run reproducible.
-#include <dlfcn.h>
-
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
 
@@ -2295,48 +2293,6 @@ void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     hipLaunchKernelGGL(k_ba_pcg_lds, dim3(1), dim3(PL_THREADS), lds, s, D, 2 * D.NB - D.nP);
 }
 
-// ---- dense factorisation of large reduced systems: rocSOLVER dpotrf / dpotrs, resolved with dlopen on first use so that the
-//      library has no link-time dependency on rocBLAS (solver = dense; the default for large systems is the PCG of ba_pcg.hip)
-namespace {
-struct RocSolver {
-    void* h_blas = nullptr;
-    void* h_solver = nullptr;
-    void* handle = nullptr;
-    int (*create_handle)(void**) = nullptr;
-    int (*set_stream)(void*, hipStream_t) = nullptr;
-    int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
-    int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
-    int* d_info = nullptr;
-    bool tried = false, ok = false;
-};
-RocSolver g_rs;
-bool rocsolver_ready() {
-    if (g_rs.tried) return g_rs.ok;
-    g_rs.tried = true;
-    g_rs.h_blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rs.h_blas) g_rs.h_blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    g_rs.h_solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rs.h_solver) g_rs.h_solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rs.h_blas || !g_rs.h_solver) return false;
-    g_rs.create_handle = (int (*)(void**))dlsym(g_rs.h_blas, "rocblas_create_handle");
-    g_rs.set_stream = (int (*)(void*, hipStream_t))dlsym(g_rs.h_blas, "rocblas_set_stream");
-    g_rs.dpotrf = (int (*)(void*, int, int, double*, int, int*))dlsym(g_rs.h_solver, "rocsolver_dpotrf");
-    g_rs.dpotrs = (int (*)(void*, int, int, int, double*, int, double*, int))dlsym(g_rs.h_solver, "rocsolver_dpotrs");
-    if (!g_rs.create_handle || !g_rs.set_stream || !g_rs.dpotrf || !g_rs.dpotrs) return false;
-    if (g_rs.create_handle(&g_rs.handle) != 0) return false;
-    if (hipMalloc((void**)&g_rs.d_info, sizeof(int)) != hipSuccess) return false;
-    g_rs.ok = true;
-    return true;
-}
-__global__ void k_ba_potrf_info(const int* info, BaDev D) {
-    if (D.ctl->phase != 1) return;
-    if (*info != 0) {
-        D.ctl->solve_failed = 1;
-        for (int i = 0; i < D.n; ++i) D.dp[i] = 0.0;
-    }
-}
-}  // namespace
-
 size_t sv_ba_chol_bytes(int n) { return sizeof(double) * (size_t)(n + 3) * (n | 1); }
 // on-chip dense LL^T: n <= 186 (two tiles per thread) and sv_ba_chol_bytes(n) within the LDS budget
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
@@ -2355,24 +2311,15 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     }
 }
 
-// dense image + rocSOLVER (or, without it, the one-workgroup global-memory factorisation)
+// dense image in global memory + the one-workgroup LL^T on it (solver = dense: systems beyond the on-chip solver's 186 unknowns that are
+// to be factored densely all the same -- the default for those sizes is the block envelope Cholesky).  The library's own code throughout:
+// no vendor solver is loaded anywhere.
 void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP <= 0) return;
     SvProfScope ps(ctx, s, "ba_solve");
     (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
     hipLaunchKernelGGL(k_ba_expand_dense, dim3((D.NB * 36 + 255) / 256), dim3(256), 0, s, D);
-    if (rocsolver_ready()) {
-        // S is symmetric and fully stored, so its row-major image is a valid column-major matrix (lda = n); the right-hand
-        // side is row n of the (n+1) x n buffer = a contiguous vector right behind the matrix.  (The library calls are not
-        // guarded by the control block: on a finished problem they factor a stale matrix and the result is ignored.)
-        const int rocblas_fill_lower = 122;  // rocblas_fill_lower
-        g_rs.set_stream(g_rs.handle, s);
-        g_rs.dpotrf(g_rs.handle, rocblas_fill_lower, D.n, D.S, D.n, g_rs.d_info);
-        g_rs.dpotrs(g_rs.handle, rocblas_fill_lower, D.n, 1, D.S, D.n, D.S + (size_t)D.n * D.n, D.n);
-        (void)hipMemcpyAsync(D.dp, D.S + (size_t)D.n * D.n, sizeof(double) * D.n, hipMemcpyDeviceToDevice, s);
-        hipLaunchKernelGGL(k_ba_potrf_info, dim3(1), dim3(1), 0, s, g_rs.d_info, D);
-    }
-    else hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
+    hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
 }
 
 // back-substitution, trial state

@@ -633,10 +633,18 @@ __device__ __forceinline__ void sky_post(int* flag, int value) {
     __threadfence();
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// (BOUNDED: the two workgroups of a two-sided elimination are launched side by side, not cooperatively -- should the partner never become
+//  resident (an over-subscribed device) the wait gives up after ~0.5 s of polling and reports the partner as failed: the trial is then a
+//  failed factorisation, which the LM loop answers with more damping, instead of a hang in the mapping thread)
+#define SKY_WAIT_POLLS (1 << 21)
 __device__ __forceinline__ int sky_wait(int* flag, int epoch) {  // +-epoch
-    int v;
-    while ((v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != epoch && v != -epoch) __builtin_amdgcn_s_sleep(4);
-    return v;
+    int v = 0;
+    for (int polls = 0; polls < SKY_WAIT_POLLS; ++polls) {
+        v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == epoch || v == -epoch) return v;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    return -epoch;
 }
 __device__ __forceinline__ double sky_peek(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // past this unit's L1
 

@@ -204,10 +204,7 @@ int sv_bucket_sort(svgpu_ctx* ctx, hipStream_t s, const int32_t* node_dev, int n
         return SVGPU_OK;
     }
     SV_HIP(ctx, hipGetLastError());
-    if (n <= SV_SORT_SMALL_MAX) {  // every frame: one workgroup, the composites in LDS
-        sv_sort_small(s, keys_in, vals_in, n, keys_out, idx_out);
-        return SVGPU_OK;
-    }
+    if (n <= SV_SORT_SMALL_MAX && sv_sort_small(s, keys_in, vals_in, n, keys_out, idx_out)) return SVGPU_OK;  // every frame: one workgroup, the composites in LDS
     // beyond that: the general radix sort on widened values
     unsigned* keys_b = (unsigned*)take((size_t)n * 4);
     unsigned long long* va = (unsigned long long*)take((size_t)n * 8);

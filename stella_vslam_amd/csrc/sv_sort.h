@@ -17,4 +17,4 @@ size_t sv_sort_hist_ints(size_t n);
 int sv_sort_pairs(hipStream_t s, unsigned* const keys[2], unsigned long long* const vals[2], int start, int n, int bits, int* hist, const int* n_dev = nullptr);
 // n <= SV_SORT_SMALL_MAX (key, index) pairs sorted by (key, index) in ONE workgroup's LDS (bitonic network on the 64-bit composites)
 #define SV_SORT_SMALL_MAX 16384
-void sv_sort_small(hipStream_t s, const unsigned* keys_in, const int* idx_in, int n, unsigned* keys_out, int* idx_out);
+bool sv_sort_small(hipStream_t s, const unsigned* keys_in, const int* idx_in, int n, unsigned* keys_out, int* idx_out);  // false: not available on this device

@@ -270,14 +270,14 @@ int sv_sort_pairs(hipStream_t s, unsigned* const keys[2], unsigned long long* co
     }
     return cur;
 }
-void sv_sort_small(hipStream_t s, const unsigned* keys_in, const int* idx_in, int n, unsigned* keys_out, int* idx_out) {
-    if (n <= 0) return;
+// false: the device does not grant the LDS this size needs (the caller takes the radix sort instead) -- a refused attribute must not turn
+// into a launch that silently does not run and a merge-join over unsorted keys
+bool sv_sort_small(hipStream_t s, const unsigned* keys_in, const int* idx_in, int n, unsigned* keys_out, int* idx_out) {
+    if (n <= 0) return true;
     int npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
-    static bool allowed = false;
-    if (!allowed) {
-        (void)hipFuncSetAttribute((const void*)k_sort_small, hipFuncAttributeMaxDynamicSharedMemorySize, SV_SORT_SMALL_MAX * 8);
-        allowed = true;
-    }
-    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), (size_t)npow2 * 8, s, keys_in, idx_in, n, npow2, keys_out, idx_out);
+    const size_t lds = (size_t)npow2 * 8;
+    if (lds > 48 * 1024 && sv_allow_dynamic_lds((const void*)k_sort_small, lds) != hipSuccess) return false;  // (per device, checked)
+    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(1024), lds, s, keys_in, idx_in, n, npow2, keys_out, idx_out);
+    return hipGetLastError() == hipSuccess;
 }

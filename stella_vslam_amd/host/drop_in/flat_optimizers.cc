@@ -1,4 +1,4 @@
-#include "local_bundle_adjuster_hip.h"
+#include "flat_optimizers.h"
 
 #include <stdexcept>
 #include <string>

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "local_bundle_adjuster_hip.h"
+#include "drop_in/flat_optimizers.h"
 #include "matchers.h"
 #include "orb_extractor.h"
 

@@ -3,7 +3,7 @@
 Reference interface: optimize/local_bundle_adjuster.h:15-24 -- optimize(map_db, curr_keyfrm, force_stop_flag);
 created by local_bundle_adjuster_factory (backend "g2o" / "gtsam"; this one registers as "hip").  The object
 graph gather (local_bundle_adjuster_g2o.cc:38-147) and the write-back (:352-430) are host-side steps of the C++
-adaptor (stella_vslam_amd/host/local_bundle_adjuster_hip.h); the flat problem they exchange is what
+adaptor (stella_vslam_amd/host/drop_in/flat_optimizers.h); the flat problem they exchange is what
 `optimize_flat` takes.
 """
 from __future__ import annotations
@@ -48,7 +48,7 @@ class local_bundle_adjuster:
         self.ctx = ctx or Context()
 
     def set_solver(self, solver: int = SOLVER_AUTO, pcg_tolerance: float = 1e-10, pcg_max_iterations: int = 0):
-        """Linear solver of the reduced camera system (svgpu_ba_set_solver): on-chip LL^T / block-Jacobi PCG / rocSOLVER."""
+        """Linear solver of the reduced camera system (svgpu_ba_set_solver): on-chip LL^T / block-Jacobi PCG / dense LL^T in global memory / block envelope Cholesky."""
         self.ctx.check(lib().svgpu_ba_set_solver(self.ctx.handle, int(solver), C.c_double(pcg_tolerance), int(pcg_max_iterations)),
                        "svgpu_ba_set_solver")
         return self

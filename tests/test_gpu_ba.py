@@ -396,7 +396,7 @@ def test_pose_optimizer_equirectangular_matches_oracle():
 def test_local_ba_alternative_solvers_match_oracle(kw, solver):
     """A local-BA sized reduced camera system is factored by the dense LL^T in LDS by default.  The other solvers -- the PCG that
     lives in one workgroup's LDS (north_star: "Schur-complement J^T J build + PCG solve"), the one-launch-per-iteration PCG of the
-    larger sizes, dense rocSOLVER, the block envelope Cholesky of the global-BA sizes -- must walk the same LM schedule to the same poses
+    larger sizes, the dense LL^T on the global-memory image, the block envelope Cholesky of the global-BA sizes -- must walk the same LM schedule to the same poses
     and outliers."""
     from stella_vslam_amd import optimize
     code = dict(pcg=optimize.SOLVER_PCG, pcg_multi=optimize.SOLVER_PCG_MULTI, dense=optimize.SOLVER_DENSE, envelope=optimize.SOLVER_ENVELOPE)[solver]
