@@ -1,5 +1,6 @@
 // Hand-written device sorts / scans (sv_sort.h).  No library sort is used anywhere in libsvgpu.
 #include "sv_sort.h"
+#include "svgpu_internal.h"
 
 namespace {
 // In-place exclusive scan of data[0 .. n) with the total written to data[n]: ONE workgroup, 16 consecutive elements per thread (a serial
