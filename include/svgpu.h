@@ -638,7 +638,9 @@ typedef struct svgpu_ba_stats {
  *             block envelope Cholesky beyond (the one-launch-per-iteration PCG only when the envelope is too large)
  *   PCG       block-Jacobi PCG on the block-sparse Schur complement: inside ONE workgroup (blocks, block rows, vectors all in
  *             its LDS) while the kept 6x6 blocks fit ~150 KB and 6 * free poses <= 512, else one kernel launch per iteration
- *   CHOLESKY  the LDS LL^T (larger systems fall back to PCG)
+ *   CHOLESKY  the LDS LL^T (larger systems fall back to PCG): the register-tile LDL^T with 3x3 pivots
+ *   CHOLESKY_MFMA  the same system by a blocked right-looking LL^T, 16-column panels, the trailing update on v_mfma_f64_16x16x4_f64
+ *             (DESIGN section 5 has the measured comparison of the two)
  *   DENSE     dense image in global memory + the library's own one-workgroup LL^T (no vendor solver is loaded anywhere)
  *   ENVELOPE  direct block envelope (skyline) LL^T after a reverse Cuthill-McKee ordering of the keyframe graph -- what AUTO takes beyond
  *             the on-chip solvers while the envelope stays under 256 MB (the reference factors this system with a sparse Cholesky)
@@ -650,6 +652,7 @@ typedef enum svgpu_ba_solver {
     SVGPU_BA_SOLVER_PCG = 2,
     SVGPU_BA_SOLVER_DENSE = 3,
     SVGPU_BA_SOLVER_PCG_MULTI = 4, /* PCG with one kernel launch per iteration even when the system would fit one workgroup's LDS */
+    SVGPU_BA_SOLVER_CHOLESKY_MFMA = 7, /* CHOLESKY with the blocked LL^T whose trailing updates run on the matrix cores (up to 126 unknowns; the register-tile form beyond) */
     SVGPU_BA_SOLVER_ENVELOPE = 6   /* block envelope Cholesky at any size (falls back to the PCG when the envelope of the ordered block graph exceeds 256 MB) */
 } svgpu_ba_solver;
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations);

@@ -88,6 +88,7 @@ struct BaDev {
     const double* bp_full;   // same for bp: step-scale term
     int scale_pose;          // 1 = this rank contributes the pose part of delta^T(lambda delta + b)
     int chol_in_lds;
+    int chol_mfma;           // 1 = the on-chip dense solve takes the blocked MFMA factorisation (k_ba_chol_mfma) where it applies
     int world, rank;         // sharded solve (world > 1): lambda init takes the max over the ranks' one-hot slots
     double* maxslots;        // world doubles (sharded)
     // block-row view of the kept blocks for the PCG solver: row a lists (block index | transposed << 30, column b)
@@ -177,7 +178,7 @@ void sv_ba_update(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);               
 void sv_pcg_init(svgpu_ctx* ctx, hipStream_t s, const BaDev& D);
 void sv_pcg_iterate(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int first_it, int count);
 enum { SV_BA_SOLVER_AUTO = 0, SV_BA_SOLVER_CHOLESKY = 1, SV_BA_SOLVER_PCG = 2, SV_BA_SOLVER_DENSE = 3, SV_BA_SOLVER_PCG_MULTI = 4, SV_BA_SOLVER_PCG_LDS = 5 /* internal */,
-       SV_BA_SOLVER_ENVELOPE = 6 };
+       SV_BA_SOLVER_ENVELOPE = 6, SV_BA_SOLVER_CHOLESKY_MFMA = 7 };
 // block envelope Cholesky of large reduced systems (ba_skyline.hip)
 #ifdef __cplusplus
 #include <vector>

@@ -6,6 +6,9 @@
 //   k_ba_chi2                     computeActiveErrors + activeRobustChi2
 //   k_ba_gate                     chi2 / depth gate (optimize/local_bundle_adjuster_g2o.cc:323-344, 354-375)
 // Every reduction runs in a fixed order (no floating-point atomics): results are run-to-run reproducible.
+#include <cstdlib>
+#include <cstring>
+
 #include "svgpu_internal.h"
 #include "ba_kernels.h"
 
@@ -440,6 +443,205 @@ __global__ __launch_bounds__(CHOL_MAX_THREADS) void k_ba_chol_tile(BaDev D) {
             if (lane + 126 < n) D.dp[lane + 126] = z2;
         }
     }
+}
+
+// ---- Blocked right-looking LL^T of the reduced camera system on the MATRIX CORES (north_star: "MFMA only for the dense reduced-camera-block
+// solve"; local_bundle_adjuster_g2o.cc:151-164 hands this system to Eigen's dense LL^T).  Panels of 16 columns; per panel
+//   1. ONE wave factors the panel with a ROW PER LANE (two rows per lane beyond 64 remaining rows, the right-hand side riding along as row
+//      n): the 16 entries of a row sit in registers, column j's pivot and the multipliers l_cj of the pivot tile travel by v_readlane, every
+//      lane scales and updates its own row.  No barrier, no LDS and no triangular solve inside the panel: the rows below the pivot tile are
+//      finished by the same instructions that factor it;
+//   2. the trailing update A_IJ -= L_Ik L_Jk^T is v_mfma_f64_16x16x4_f64 on 16 x 16 tiles (four k-steps per tile), the tiles of the lower
+//      triangle dealt round-robin to the eight waves, operands read from LDS in the instruction's own layouts (A[l & 15][l >> 4],
+//      B[l >> 4][l & 15], C row = (l >> 4) + 4 reg, col = l & 15).
+// Two barriers per PANEL (6 panels at n = 96) where the register-tile LDL^T below needs one per 3 columns (32), and the update runs at the
+// matrix pipe's rate.  Fixed order everywhere: run-to-run bit-identical.  z = L^-1 g arrives with the factorisation; L^T x = z is one wave,
+// a column per step, the rows prefetched.  A non-positive pivot fails the trial (as a failed LL^T does).
+#define CM_THREADS 512
+#define CM_MAX_N 126  // n + 1 rows fit two rows per lane
+typedef double cm_v4f64 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int cm_ld(int n) { return 16 * ((n + 15) / 16) + 1; }                                  // odd pitch (doubles)
+__host__ __device__ inline size_t cm_lds_bytes(int n) { return sizeof(double) * (size_t)(16 * ((n + 16) / 16)) * cm_ld(n); }  // rows 0 .. n, whole tiles
+__device__ __forceinline__ double cm_rsqrt(double p) {  // 1 / sqrt(p): hardware seed, two Newton steps
+    double y = __builtin_amdgcn_rsq(p);
+    y = y * fma(-0.5 * p * y, y, 1.5);
+    y = y * fma(-0.5 * p * y, y, 1.5);
+    return y;
+}
+__global__ __launch_bounds__(CM_THREADS) void k_ba_chol_mfma(BaDev D) {
+    extern __shared__ double s_M[];  // rows 0 .. n-1 the matrix (lower triangle), row n the right-hand side, then zero rows up to a whole tile
+    __shared__ double s_dinv[128];   // 1 / L_jj
+    __shared__ int s_fail;
+    if (D.ctl->phase != 1) return;
+#define CM_T(i) do { if (D.dbg && D.dbg_schur_on == 2 && threadIdx.x == 0) D.dbg[(i)] = wall_clock64(); } while (0)
+    CM_T(0);
+    const int n = D.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NTc = (n + 15) / 16, NTr = (n + 16) / 16, ld = cm_ld(n), rows = 16 * NTr;
+    double* const M = s_M;
+    for (int k = tid; k < rows * ld; k += CM_THREADS) M[k] = 0.0;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    // the lower triangle from the kept upper blocks: S[6a+i][6b+j] = blk[i][j] (a <= b) sits at row 6b+j, column 6a+i
+    for (int k = tid; k < D.NB * 36; k += CM_THREADS) {
+        const int blk = k / 36, t = k - 36 * blk, i = t / 6, j = t - 6 * i;
+        const int2 ab = D.blk_ab[blk];
+        M[(6 * ab.y + j) * ld + 6 * ab.x + i] = D.Sblk[k];
+    }
+    for (int c = tid; c < n; c += CM_THREADS) M[n * ld + c] = D.g[c];
+    __syncthreads();
+    CM_T(1);
+    for (int k = 0; k < NTc; ++k) {
+        const int c0 = 16 * k;
+        if (wave == 0) {
+            // ---- panel factorisation: lane l owns rows c0 + l and c0 + 64 + l (rows beyond n do not exist: zeros, harmless)
+            const int r0 = c0 + lane, r1 = c0 + 64 + lane;
+            const bool has1 = c0 + 64 <= n;  // (wave-uniform: any second row at all)
+            double a0[16], a1[16];
+            {
+                const double* p0 = M + (size_t)min(r0, rows - 1) * ld + c0;
+                const double* p1 = M + (size_t)min(r1, rows - 1) * ld + c0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    a0[j] = p0[j];
+                    a1[j] = p1[j];  // (no second row: a clamped address, a value nobody stores)
+                }
+            }
+            bool bad = false;
+            double dinv[16];
+            // LEFT-looking inside the panel: column j is brought up to date with the finished columns m < j (multiplier l_jm = row j's entry in
+            // column m, by v_readlane), then its pivot is taken and the column scaled.  Every broadcast value is consumed at once -- written
+            // right-looking, the compiler deferred the updates of the later columns itself and kept all 120 multipliers alive in scalar
+            // registers, spilling them through v_writelane: 15 cycles per instruction.  Two accumulators per row halve the dependent chain.
+            // The second set of rows (more than 64 rows left) follows in a pass of its own with the finished multipliers.
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // the j multipliers first (independent v_readlane pairs, issued back to back), then the multiply-adds: a multiply-add behind
+                // every pair waits out the scalar write each time
+                double l[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    if (m < j) l[m] = readlane_d(a0[m], j);
+                __builtin_amdgcn_sched_barrier(0);
+                double e0 = a0[j], o0 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    if (m < j) {
+                        if (m & 1) o0 = fma(-a0[m], l[m], o0);
+                        else e0 = fma(-a0[m], l[m], e0);
+                    }
+                e0 += o0;
+                const double piv = readlane_d(e0, j);
+                const bool live = c0 + j < n;  // (columns beyond n in the last panel: nothing to eliminate)
+                bad = bad || (live && !(piv > 0.0));
+                const double r0 = cm_rsqrt(live ? piv : 1.0);  // (selects, no branch: the column loop stays one basic block)
+                const double r = live ? r0 : 0.0;
+                a0[j] = e0 * r;  // lane j: sqrt(piv) = L_jj; lanes below: l_rj
+                dinv[j] = r;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (has1) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    double l[16];
+#pragma unroll
+                    for (int m = 0; m < 16; ++m)
+                        if (m < j) l[m] = readlane_d(a0[m], j);
+                    __builtin_amdgcn_sched_barrier(0);
+                    double e1 = a1[j], o1 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m)
+                        if (m < j) {
+                            if (m & 1) o1 = fma(-a1[m], l[m], o1);
+                            else e1 = fma(-a1[m], l[m], e1);
+                        }
+                    a1[j] = (e1 + o1) * dinv[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (lane < 16) {  // 1 / L_jj for the back substitution: lane j stores the j-th (uniform) value
+                double d = dinv[0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) d = lane == j ? dinv[j] : d;
+                s_dinv[c0 + lane] = d;
+            }
+            if (bad && lane == 0) s_fail = 1;
+            if (r0 < rows) {
+                double* p0 = M + (size_t)r0 * ld + c0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j <= lane) p0[j] = a0[j];  // the lower triangle of the pivot tile, whole rows below it
+            }
+            if (has1 && r1 < rows) {
+                double* p1 = M + (size_t)r1 * ld + c0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) p1[j] = a1[j];
+            }
+            CM_T(2 + 3 * k);
+        }
+        __syncthreads();
+        CM_T(3 + 3 * k);
+        if (s_fail) break;
+        // ---- trailing update on the matrix cores: tile (I, J), k < J <= I, J a column tile, I up to the right-hand side's tile
+        {
+            const int nJ = NTc - 1 - k;  // column tiles behind the panel
+            int t = wave;
+            for (int J = k + 1; J < NTc; ++J)
+                for (int I = J; I < NTr; ++I, --t)
+                    if (t == 0) {
+                        t = CM_THREADS / 64;
+                        const double* pa = M + (size_t)(16 * I + (lane & 15)) * ld + c0 + (lane >> 4);
+                        const double* pb = M + (size_t)(16 * J + (lane & 15)) * ld + c0 + (lane >> 4);
+                        double* pc = M + (size_t)(16 * I + (lane >> 4)) * ld + 16 * J + (lane & 15);
+                        const double a0 = pa[0], a1 = pa[4], a2 = pa[8], a3 = pa[12];
+                        const double b0 = pb[0], b1 = pb[4], b2 = pb[8], b3 = pb[12];
+                        cm_v4f64 c;
+                        c[0] = pc[0], c[1] = pc[(size_t)4 * ld], c[2] = pc[(size_t)8 * ld], c[3] = pc[(size_t)12 * ld];
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, c, 0, 0, 0);
+                        pc[0] = c[0], pc[(size_t)4 * ld] = c[1], pc[(size_t)8 * ld] = c[2], pc[(size_t)12 * ld] = c[3];
+                    }
+            (void)nJ;
+        }
+        __syncthreads();
+        CM_T(4 + 3 * k);
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) D.ctl->solve_failed = 1;
+        for (int i = tid; i < n; i += CM_THREADS) D.dp[i] = 0.0;
+        return;
+    }
+    if (wave == 0) {
+        // ---- L^T x = z, a column per step from the last: lane c holds z_c (register A) and z_{64 + c} (register B); x_I = z_I / L_II is
+        //      broadcast, every lane c < I subtracts L[I][c] x_I (row I of L: consecutive addresses over the lanes)
+        const double* zr = M + (size_t)n * ld;
+        double zA = lane < n ? zr[lane] : 0.0, zB = 64 + lane < n ? zr[64 + lane] : 0.0;
+        int I = n - 1;
+        double rowA = M[(size_t)I * ld + min(lane, I)], rowB = I >= 64 ? M[(size_t)I * ld + min(64 + lane, I)] : 0.0, di = s_dinv[I];
+        for (; I >= 64; --I) {
+            const int In = max(I - 1, 0);
+            const double nA = M[(size_t)In * ld + min(lane, In)], nB = In >= 64 ? M[(size_t)In * ld + min(64 + lane, In)] : 0.0, nd = s_dinv[In];
+            const double x = readlane_d(zB, I - 64) * di;
+            if (64 + lane < I) zB = fma(-rowB, x, zB);
+            else if (64 + lane == I) zB = x;
+            zA = fma(-rowA, x, zA);
+            rowA = nA, rowB = nB, di = nd;
+        }
+        for (; I >= 0; --I) {
+            const int In = max(I - 1, 0);
+            const double nA = M[(size_t)In * ld + min(lane, In)], nd = s_dinv[In];
+            const double x = readlane_d(zA, I) * di;
+            if (lane < I) zA = fma(-rowA, x, zA);
+            else if (lane == I) zA = x;
+            rowA = nA, di = nd;
+        }
+        if (lane < n) D.dp[lane] = zA;
+        if (64 + lane < n) D.dp[64 + lane] = zB;
+        CM_T(30);
+    }
+#undef CM_T
 }
 
 // Fallback for systems that do not fit LDS (n > ~140): same arithmetic on the global copy, one column per step.
@@ -2294,10 +2496,18 @@ void sv_ba_solve_pcg_lds(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 }
 
 size_t sv_ba_chol_bytes(int n) { return sizeof(double) * (size_t)(n + 3) * (n | 1); }
-// on-chip dense LL^T: n <= 186 (two tiles per thread) and sv_ba_chol_bytes(n) within the LDS budget
+// on-chip dense LL^T: the register-tile LDL^T while the matrix fits LDS (n <= 186, two tiles per thread); on request (solver
+// CHOLESKY_MFMA, or SVGPU_BA_CHOL=mfma for A/B runs) the blocked MFMA factorisation up to CM_MAX_N unknowns.
 void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP <= 0) return;
     SvProfScope ps(ctx, s, "ba_solve");
+    static const bool force_mfma = std::getenv("SVGPU_BA_CHOL") && !strcmp(std::getenv("SVGPU_BA_CHOL"), "mfma");
+    if (D.n <= CM_MAX_N && (D.chol_mfma || force_mfma)) {
+        const size_t lds = cm_lds_bytes(D.n);
+        (void)sv_allow_dynamic_lds((const void*)k_ba_chol_mfma, lds);
+        hipLaunchKernelGGL(k_ba_chol_mfma, dim3(1), dim3(CM_THREADS), lds, s, D);
+        return;
+    }
     const size_t lds = sv_ba_chol_bytes(D.n);
     const int R = D.n / 3 + 1, NT = R * (R + 1) / 2;
     const int threads = std::min(CHOL_MAX_THREADS, (NT + 63) & ~63);

@@ -369,6 +369,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int solver_opt = ctx->ba_solver;
     if (const char* ev = std::getenv("SVGPU_BA_SOLVER")) {
         if (!strcmp(ev, "cholesky")) solver_opt = SV_BA_SOLVER_CHOLESKY;
+        else if (!strcmp(ev, "cholesky_mfma")) solver_opt = SV_BA_SOLVER_CHOLESKY_MFMA;
         else if (!strcmp(ev, "pcg")) solver_opt = SV_BA_SOLVER_PCG;
         else if (!strcmp(ev, "dense")) solver_opt = SV_BA_SOLVER_DENSE;
         else if (!strcmp(ev, "pcg_multi")) solver_opt = SV_BA_SOLVER_PCG_MULTI;
@@ -452,7 +453,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.lm_max = A.take<double>(nb_lm);  // nb_lm == sv_ba_lm_blocks(L)
     static const bool dbg_stamps = std::getenv("SVGPU_BA_DBG") != nullptr;
     static const bool dbg_schur = dbg_stamps && !strcmp(std::getenv("SVGPU_BA_DBG"), "schur");
-    D.dbg_schur_on = dbg_schur ? 1 : 0;
+    static const bool dbg_chol = dbg_stamps && !strcmp(std::getenv("SVGPU_BA_DBG"), "chol");
+    D.dbg_schur_on = dbg_schur ? 1 : (dbg_chol ? 2 : 0);
     D.dbg = dbg_stamps ? A.take<unsigned long long>(8 * (dbg_schur ? sc_part_blocks + 64 : (size_t)nb_lm)) : nullptr;
     double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
     double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
@@ -642,6 +644,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.lin_split = sv_ba_lin_split(E, HS.nP);
         D.chol_in_lds = D.n <= 186 && sv_ba_chol_bytes(D.n) <= 160 * 1024 - 12 * 1024;
         solver = solver_opt;
+        D.chol_mfma = 0;
+        if (solver == SV_BA_SOLVER_CHOLESKY_MFMA) {  // the same dense on-chip solve, its MFMA form
+            solver = SV_BA_SOLVER_CHOLESKY;
+            D.chol_mfma = 1;
+        }
         D.Hpp_full = sharded ? d_HB_full : D.Hpp;
         D.bp_full = sharded ? d_HB_full + 36 * (size_t)HS.nP : D.bp;
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
@@ -922,6 +929,15 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         }
         for (int x = 0; x < 8; ++x) std::fprintf(stderr, "[ba]   XCC %d: %.0f units, last start at %.1f us\n", x, n_x[x], last_start[x]);
     }
+    if (D.dbg && D.dbg_schur_on == 2) {  // SVGPU_BA_DBG=chol: phase stamps of the last k_ba_chol_mfma (100 MHz): load | per panel factor, barrier, update | end
+        std::vector<unsigned long long> h(32);
+        SV_HIP(ctx, hipMemcpyAsync(h.data(), D.dbg, 8 * h.size(), hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        std::fprintf(stderr, "[ba] chol stamps (us):");
+        for (int k = 1; k < 31; ++k)
+            if (h[k] >= h[0] && h[k] - h[0] < 100000000ull) std::fprintf(stderr, " %d:%.2f", k, (double)(h[k] - h[0]) * 0.01);
+        std::fprintf(stderr, "\n");
+    }
     if (D.dbg && !D.dbg_schur_on) {  // SVGPU_BA_DBG: where the time of the last fused tail went (100 MHz stamps, relative to the first workgroup's entry)
         std::vector<unsigned long long> h(8 * (size_t)nb_lm);
         SV_HIP(ctx, hipMemcpyAsync(h.data(), D.dbg, 8 * h.size(), hipMemcpyDeviceToHost, s));
@@ -1137,7 +1153,7 @@ int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int r
 }
 
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations) {
-    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || (solver > SVGPU_BA_SOLVER_PCG_MULTI && solver != SVGPU_BA_SOLVER_ENVELOPE)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
+    if (!ctx || solver < SVGPU_BA_SOLVER_AUTO || (solver > SVGPU_BA_SOLVER_PCG_MULTI && solver != SVGPU_BA_SOLVER_ENVELOPE && solver != SVGPU_BA_SOLVER_CHOLESKY_MFMA)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_ba_set_solver: bad solver");
     ctx->ba_solver = solver;
     ctx->pcg_tol = pcg_tolerance > 0 ? pcg_tolerance : 1e-10;
     ctx->pcg_max_it = pcg_max_iterations > 0 ? pcg_max_iterations : 0;

@@ -38,7 +38,7 @@ def local_bundle_adjuster_factory_create(backend: str = "hip", **kw):
     return local_bundle_adjuster(**kw)
 
 
-SOLVER_AUTO, SOLVER_CHOLESKY, SOLVER_PCG, SOLVER_DENSE, SOLVER_PCG_MULTI, SOLVER_ENVELOPE = 0, 1, 2, 3, 4, 6  # svgpu_ba_solver
+SOLVER_AUTO, SOLVER_CHOLESKY, SOLVER_PCG, SOLVER_DENSE, SOLVER_PCG_MULTI, SOLVER_ENVELOPE, SOLVER_CHOLESKY_MFMA = 0, 1, 2, 3, 4, 6, 7  # svgpu_ba_solver
 
 
 class local_bundle_adjuster:

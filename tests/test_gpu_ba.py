@@ -390,7 +390,7 @@ def test_pose_optimizer_equirectangular_matches_oracle():
     assert np.abs(pose - pr["pose_gt"]).max() < 0.1 * np.abs(pr["pose_cw"] - pr["pose_gt"]).max()
 
 
-@pytest.mark.parametrize("solver", ["pcg", "pcg_multi", "dense", "envelope"])
+@pytest.mark.parametrize("solver", ["pcg", "pcg_multi", "dense", "envelope", "cholesky_mfma"])
 @pytest.mark.parametrize("kw", [dict(num_kf=10, num_lm=1500, obs_per_lm=5, num_fixed=3, seed=5),
                                 dict(num_kf=20, num_lm=10000, obs_per_lm=6, num_fixed=4, seed=1234)])
 def test_local_ba_alternative_solvers_match_oracle(kw, solver):
@@ -399,7 +399,8 @@ def test_local_ba_alternative_solvers_match_oracle(kw, solver):
     larger sizes, the dense LL^T on the global-memory image, the block envelope Cholesky of the global-BA sizes -- must walk the same LM schedule to the same poses
     and outliers."""
     from stella_vslam_amd import optimize
-    code = dict(pcg=optimize.SOLVER_PCG, pcg_multi=optimize.SOLVER_PCG_MULTI, dense=optimize.SOLVER_DENSE, envelope=optimize.SOLVER_ENVELOPE)[solver]
+    code = dict(pcg=optimize.SOLVER_PCG, pcg_multi=optimize.SOLVER_PCG_MULTI, dense=optimize.SOLVER_DENSE, envelope=optimize.SOLVER_ENVELOPE,
+                cholesky_mfma=optimize.SOLVER_CHOLESKY_MFMA)[solver]
     adj = optimize.local_bundle_adjuster().set_solver(code)
     sc = S.ba_scene(**kw)
     got = adj.optimize_flat(sc)
@@ -409,7 +410,7 @@ def test_local_ba_alternative_solvers_match_oracle(kw, solver):
     _assert_poses(got["pose_cw"], ref["pose_cw"])
     assert _rel(got["points"], ref["points"]) < TOL
     assert np.array_equal(got["outlier"], ref["outlier"])
-    assert (gs["pcg_iterations"] > 0) == (solver not in ("dense", "envelope")) and gs["cholesky_failures"] == 0
+    assert (gs["pcg_iterations"] > 0) == (solver not in ("dense", "envelope", "cholesky_mfma")) and gs["cholesky_failures"] == 0
 
 
 def test_global_ba_config5_matches_oracle():
