@@ -280,14 +280,24 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define MF_CH 256      // targets per fetched chunk
 #define MF_SLOTS 16    // list slots per query (= P.list_k of this path)
 #define MF_WQ 128      // per-wave hit queue entries; drained when fewer than 64 are free
-__device__ __forceinline__ uint32_t mf_expand_pm1(uint32_t nibble) {  // bit b -> byte b = +1 (bit clear) / -1 (bit set)
-    uint32_t m = (nibble * 0x00204081u) & 0x01010101u;  // byte b = bit b
-    m |= m << 1;                                         // smear every set byte to 0xFF with three full-rate shift-ors;
-    asm("" : "+v"(m));                                   // the empty asm keeps the compiler from folding them back into
-    m |= m << 2;                                         // m * 255, a quarter-rate 32-bit multiply
-    asm("" : "+v"(m));
-    m |= m << 4;
-    return m | 0x01010101u;
+// Operand form (round 4).  Bits are expanded to 0 / 2 bytes on the query side and 0 / 1 bytes on the target side, and a NINTH k-step
+// carries the two popcounts, so that the accumulator is the negated distance itself:
+//     sum_k (2 q_k) t_k  -  pop(q)  -  pop(t)  =  -hamming(q, t),
+// the popcounts riding as three int8 pieces each (<= 127 + 127 + 2) against ones on the other side.  "distance <= dmax" stays ONE uniform
+// threshold on the accumulator, and the expansion of a nibble is two shift-ors and a mask (4 instructions with the field extract) where
+// the +-1 form smeared every set bit over its byte (9): 75 -> 34 VALU instructions per thread and tile, for one more MFMA in nine.
+__device__ __forceinline__ uint32_t mf_spread(uint32_t nibble) {  // bit b of the nibble -> bit 0 of byte b (other bits: copies of the nibble, masked by the caller)
+    uint32_t m = nibble | (nibble << 7);
+    return m | (m << 14);
+}
+__device__ __forceinline__ uint32_t mf_expand01(uint32_t nibble) { return mf_spread(nibble) & 0x01010101u; }        // targets: 0 / 1 (expanded per tile: the cheaper form)
+__device__ __forceinline__ uint32_t mf_expand02(uint32_t nibble) { return (mf_spread(nibble) << 1) & 0x02020202u; }  // queries: 0 / 2 (expanded once per kernel)
+// the ninth k-step: -(pop) as three int8 pieces in bytes 0..2 (own side) or 3..5 (other side's ones sit in the complementary bytes)
+__device__ __forceinline__ uint2 mf_pop_pieces(int pop, bool own_first) {
+    const int a = min(pop, 127), b = min(pop - a, 127), c = pop - a - b;
+    const uint32_t na = (uint32_t)(-a) & 0xFFu, nb = (uint32_t)(-b) & 0xFFu, nc = (uint32_t)(-c) & 0xFFu;
+    // query side: bytes [-a -b -c  1 | 1 1 0 0]; target side: bytes [1 1 1 -a | -b -c 0 0]
+    return own_first ? make_uint2(na | (nb << 8) | (nc << 16) | (1u << 24), 0x00000101u) : make_uint2(0x00010101u | (na << 24), nb | (nc << 8));
 }
 // candidate window (in angle-sorted target positions) of the sorted queries [r_lo, r_hi]: up to two runs
 __device__ __forceinline__ void mf_window(const float* __restrict__ A2s, const int* __restrict__ BS1, int r_lo, int r_hi, int n1c,
@@ -319,7 +329,8 @@ struct MfShared {
     uint32_t raw[8][MF_CH];          // fetched chunk, dword-transposed: raw[k-step][target]
     float rang[MF_CH];               // target angles / original indices of the chunk
     int ridx[MF_CH];
-    uint32_t b[2][MF_TT * 64];       // expanded tile: [buffer][k-step 8][lane 64][4 dwords]
+    int rpop[MF_CH];                 // ... and their popcounts
+    uint32_t b[2][9 * 64 * 4];       // expanded tile: [buffer][k-step 8 + the popcount step][lane 64][4 dwords]
     uint32_t list[MF_QB][MF_SLOTS];
     int cnt[MF_QB];
     uint32_t rowmax[MF_QB];          // largest key of a FULL row once it has been scanned (else all-ones): cheap reject of far candidates
@@ -412,18 +423,22 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
         }
         S.qa[tid] = live ? A2[q] : -1000.f;
     }
-    // ---- A fragments: rows = sorted queries q0 + 32a + (lane & 31), k-step s, lane half h -> bits [32s + 16h, +16)
+    // ---- A fragments: rows = sorted queries q0 + 32a + (lane & 31), k-step s, lane half h -> bits [32s + 16h, +16); step 8 = the popcount step
     const int h = lane >> 5;
-    v4i A[2][8];
+    v4i A[2][9];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int q = min(q0 + 32 * a + (lane & 31), n2c - 1);
+        int pq = 0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const uint32_t half = (D2[(size_t)q * 8 + s] >> (16 * h)) & 0xFFFFu;
-            A[a][s] = v4i{(int)mf_expand_pm1(half & 15u), (int)mf_expand_pm1((half >> 4) & 15u), (int)mf_expand_pm1((half >> 8) & 15u),
-                          (int)mf_expand_pm1(half >> 12)};
+            const uint32_t w = D2[(size_t)q * 8 + s];
+            pq += __popc(w);
+            const uint32_t half = (w >> (16 * h)) & 0xFFFFu;
+            A[a][s] = v4i{(int)mf_expand02(half & 15u), (int)mf_expand02((half >> 4) & 15u), (int)mf_expand02((half >> 8) & 15u), (int)mf_expand02(half >> 12)};
         }
+        const uint2 pp = mf_pop_pieces(pq, true);
+        A[a][8] = h == 0 ? v4i{(int)pp.x, (int)pp.y, 0, 0} : v4i{0, 0, 0, 0};
     }
     // ---- candidate windows: the block's (targets to stage) and this wave's (tiles to multiply)
     int blo[2], bhi[2], wlo[2], whi[2];
@@ -431,28 +446,34 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
     const bool wave_live = q0 < n2c;
     mf_window(A2, BS1, min(q0, n2c - 1), min(q0 + MF_QW, n2c) - 1, n1c, prune, wlo, whi);
     const int lt = tid & 31, lw = tid >> 5;  // expansion role: target lt of the tile, descriptor dword lw (= k-step)
-    auto expand = [&](int buf, int tile, int valid) {  // tile of the chunk in S.raw -> S.b[buf]; columns >= valid stay zero (never a hit)
+    auto expand = [&](int buf, int tile, int valid) {  // tile of the chunk in S.raw -> S.b[buf]; columns >= valid can never hit (popcount 381)
         uint4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
         if (lt < valid) {
             const uint32_t w = S.raw[lw][tile * MF_TT + lt];
-            lo.x = mf_expand_pm1(w & 15u);
-            lo.y = mf_expand_pm1((w >> 4) & 15u);
-            lo.z = mf_expand_pm1((w >> 8) & 15u);
-            lo.w = mf_expand_pm1((w >> 12) & 15u);
-            hi.x = mf_expand_pm1((w >> 16) & 15u);
-            hi.y = mf_expand_pm1((w >> 20) & 15u);
-            hi.z = mf_expand_pm1((w >> 24) & 15u);
-            hi.w = mf_expand_pm1(w >> 28);
+            lo.x = mf_expand01(w & 15u);
+            lo.y = mf_expand01((w >> 4) & 15u);
+            lo.z = mf_expand01((w >> 8) & 15u);
+            lo.w = mf_expand01((w >> 12) & 15u);
+            hi.x = mf_expand01((w >> 16) & 15u);
+            hi.y = mf_expand01((w >> 20) & 15u);
+            hi.z = mf_expand01((w >> 24) & 15u);
+            hi.w = mf_expand01(w >> 28);
         }
         uint4* B = reinterpret_cast<uint4*>(S.b[buf]) + lw * 64;
         B[lt] = lo;        // lane half 0: bits [32 lw, +16)
         B[32 + lt] = hi;   // lane half 1: bits [32 lw + 16, +16)
+        if (lw == 0) {     // the popcount step of the tile (one wave-half's worth of threads)
+            const uint2 pp = lt < valid ? mf_pop_pieces(S.rpop[tile * MF_TT + lt], false) : make_uint2(0x81010101u, 0x00008181u);
+            uint4* B8 = reinterpret_cast<uint4*>(S.b[buf]) + 8 * 64;
+            B8[lt] = make_uint4(pp.x, pp.y, 0, 0);
+            B8[32 + lt] = make_uint4(0, 0, 0, 0);
+        }
     };
-    const int thr = 256 - 2 * (int)P.dmax;  // hit <=> 256 - 2 d >= thr; the launcher keeps dmax < 128, so zero columns never hit
+    const int thr = -(int)P.dmax;           // the accumulator is -distance: hit <=> acc >= -dmax
     int wq_n = 0;                           // entries in this wave's hit queue (wave-uniform)
     // One accumulator register of the wave's 64 x 32 patch: rows 32 a + (r & 3) + 8 (r >> 2) + 4 h (C/D map of the 32x32 shapes), one
     // target per lane.  The hit lanes append (row, dist, original idx_1, target angle) to the wave's queue with ballot ranks; a register
-    // without a hit costs a compare and a wave-uniform skip.  dist << 16 = (256 - dot) << 15 (dot is even), 256 << 15 is folded into ti.
+    // without a hit costs a compare and a wave-uniform skip.  dist << 16 = (-dot) << 16.
     auto test_reg = [&](int dot, int a, int r, uint32_t ti, uint32_t ta) {
         const bool hit = dot >= thr;
         const unsigned long long m = __ballot(hit);
@@ -464,10 +485,17 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
             if (hit) {
                 const int pq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const uint32_t row = (uint32_t)(32 * a + (r & 3) + 8 * (r >> 2)) << 24;
-                S.wq[wave][wq_n + pq] = make_uint2(ti + row - ((uint32_t)dot << 15), ta);
+                S.wq[wave][wq_n + pq] = make_uint2(ti + row + ((uint32_t)(-dot) << 16), ta);
             }
             wq_n += __popcll(m);
         }
+    };
+    // a whole half (16 registers = 32 rows x 32 targets) without a hit -- the common case -- costs eight three-way maxima, one compare
+    // and one wave-uniform branch instead of sixteen compare / ballot / branch triples
+    auto any_hit = [&](const v16i& acc) -> bool {
+        int m0 = max(max(acc[0], acc[1]), acc[2]), m1 = max(max(acc[3], acc[4]), acc[5]), m2 = max(max(acc[6], acc[7]), acc[8]);
+        int m3 = max(max(acc[9], acc[10]), acc[11]), m4 = max(max(acc[12], acc[13]), max(acc[14], acc[15]));
+        return __ballot(max(max(max(m0, m1), m2), max(m3, m4)) >= thr) != 0ull;
     };
     // The two 32-query halves of the wave rotate so that no accumulator is read right behind its own MFMAs (ablation builds: the wave
     // used to spend ~100 of the kernel's 260 us waiting for the 16 MFMAs of a tile before it could test them): while the eight MFMAs of
@@ -482,8 +510,10 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
         for (int cbase = lo; cbase < hi; cbase += MF_CH) {
             const int cn = min(MF_CH, hi - cbase), ntiles = (cn + MF_TT - 1) / MF_TT;
             if (pend1) {  // its tile's angle / index words live in registers, but keep the schedule simple across chunk boundaries
+                if (any_hit(acc1)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
+                    for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
+                }
                 pend1 = false;
             }
             __syncthreads();  // every wave is done with the previous chunk
@@ -492,6 +522,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                 const uint4 d1 = *reinterpret_cast<const uint4*>(D1 + (size_t)(cbase + tid) * 8 + 4);
                 S.rang[tid] = A1[cbase + tid];
                 S.ridx[tid] = I1[cbase + tid];
+                S.rpop[tid] = __popc(d0.x) + __popc(d0.y) + __popc(d0.z) + __popc(d0.w) + __popc(d1.x) + __popc(d1.y) + __popc(d1.z) + __popc(d1.w);
                 S.raw[0][tid] = d0.x;
                 S.raw[1][tid] = d0.y;
                 S.raw[2][tid] = d0.z;
@@ -511,28 +542,32 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                     const v4i* Bf = reinterpret_cast<const v4i*>(S.b[buf]) + lane;
                     const int col = t * MF_TT + (lane & 31);
                     const uint32_t ta = __float_as_uint(S.rang[col]);
-                    const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24) | (256u << 15);
+                    const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24);
                     v4i b = Bf[0];
+                    const bool hit1 = pend1;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {  // half 0 of this tile | test of half 1 of the previous one
-                        const v4i bn = Bf[(s < 7 ? s + 1 : 0) * 64];  // next fragment in flight (after the last one: the first of the second pass)
+                    for (int s = 0; s < 9; ++s) {  // half 0 of this tile | test of half 1 of the previous one
+                        const v4i bn = Bf[(s < 8 ? s + 1 : 0) * 64];  // next fragment in flight (after the last one: the first of the second pass)
                         acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, s == 0 ? v16i{} : acc0, 0, 0, 0);
                         b = bn;
                         __builtin_amdgcn_sched_barrier(0);
-                        if (pend1) {
+                        if (hit1 && s < 8) {
                             test_reg(acc1[2 * s], 1, 2 * s, p_ti, p_ta);
                             test_reg(acc1[2 * s + 1], 1, 2 * s + 1, p_ti, p_ta);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    const bool hit0 = true;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {  // half 1 of this tile | test of half 0 of this tile
-                        const v4i bn = Bf[(s < 7 ? s + 1 : 7) * 64];
+                    for (int s = 0; s < 9; ++s) {  // half 1 of this tile | test of half 0 of this tile
+                        const v4i bn = Bf[(s < 8 ? s + 1 : 8) * 64];
                         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, s == 0 ? v16i{} : acc1, 0, 0, 0);
                         b = bn;
                         __builtin_amdgcn_sched_barrier(0);
-                        test_reg(acc0[2 * s], 0, 2 * s, ti, ta);
-                        test_reg(acc0[2 * s + 1], 0, 2 * s + 1, ti, ta);
+                        if (hit0 && s < 8) {
+                            test_reg(acc0[2 * s], 0, 2 * s, ti, ta);
+                            test_reg(acc0[2 * s + 1], 0, 2 * s + 1, ti, ta);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     pend1 = true;
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
             }
         }
     }
-    if (pend1) {
+    if (pend1 && any_hit(acc1)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
     }

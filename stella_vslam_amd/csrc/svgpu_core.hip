@@ -133,8 +133,9 @@ int svgpu_profile_mfma_ops(svgpu_ctx* ctx, unsigned long long* int8_ops) {
     SV_HIP(ctx, hipDeviceSynchronize());
     unsigned long long tiles = 0;
     SV_HIP(ctx, hipMemcpy(&tiles, ctx->prof.d_counter, sizeof(tiles), hipMemcpyDeviceToHost));
-    // one patch = 64 queries x 32 targets x 256 bit positions, a multiply and an add each (16 x v_mfma_i32_32x32x32_i8)
-    *int8_ops = tiles * 64ull * 32ull * 256ull * 2ull;
+    // one patch = 64 queries x 32 targets x (256 bit positions + the popcount k-step of 32), a multiply and an add each: 18 x
+    // v_mfma_i32_32x32x32_i8 -- what the matrix pipe EXECUTES (the distances themselves are 16 / 18 of it)
+    *int8_ops = tiles * 64ull * 32ull * 288ull * 2ull;
     return SVGPU_OK;
 }
 

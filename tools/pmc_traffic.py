@@ -13,7 +13,7 @@ from bench import csrc_hash  # the kernel sources these counters were taken on: 
 
 def per_kernel(d, counter):
     t = pd.read_csv(f"{d}/p_counter_collection.csv")
-    t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+    t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"^void\s+", "", regex=True).str.replace(r"[<(].*$", "", regex=True)  # "void k_blur<64>(...)" -> "k_blur": templated kernels carry their return type and arguments
     t = t[t.Counter_Name == counter]
     return t.groupby("k")["Counter_Value"].mean()
 

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import csrc_hash  # the kernel sources these counters were taken on: bench.py reports them only while the sources still hash to this
 
 t = pd.read_csv(f"{sys.argv[1]}/p_counter_collection.csv")
-t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"^void\s+", "", regex=True).str.replace(r"[<(].*$", "", regex=True)  # "void k_blur<64>(...)" -> "k_blur": templated kernels carry their return type and arguments
 g = t.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
 alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
 SIMDS, CYC = 256 * 4, 4
@@ -33,7 +33,7 @@ for k, r in g.iterrows():
                                        "valu_issue_frac": round(float(r["SQ_INSTS_VALU"]) * CYC / (SIMDS * cyc), 4)}
 if len(sys.argv) > 4:
     a = pd.read_csv(f"{sys.argv[4]}/p_counter_collection.csv")
-    a["k"] = a["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.split("(").str[0]
+    a["k"] = a["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"^void\s+", "", regex=True).str.replace(r"[<(].*$", "", regex=True)  # "void k_blur<64>(...)" -> "k_blur": templated kernels carry their return type and arguments
     ga = a.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
     for k, r in ga.iterrows():
         kk = alias.get(k, k)
