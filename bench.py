@@ -23,6 +23,8 @@ Extra objects on that line:
   local_ba      LM iterations/s on config 3 (20 KF / 10k landmarks / ~60k observations), with its own roofline
   global_ba     LM iterations/s on config 5 (500 KF / 200k landmarks / 1.2M observations; block-Jacobi PCG); with N > 1 the
                 landmark-sharded solve over the library's own RCCL communicator (svgpu_comm_init), all ranks, same problem
+  global_ba_large  the same loop with 1.6 M landmarks / 9.6 M observations (the size at which sharding the observations can pay), with the
+                per-phase projection for 2 / 4 / 8 ranks beside the single-GPU measurement; N > 1: keyframe-segment shards, bytes exchanged
   cpu_baseline  the oracle ("port" of the reference CPU path), single thread, on bounded samples
 """
 from __future__ import annotations
@@ -79,6 +81,7 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (the latency-bound matcher kernels amortise over a larger batch: 64 -> 256 is +7 %)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-ba-large", action="store_true", help="skip the 9.6 M-observation global-BA leg (about 20 s of scene generation per rank)")
     ap.add_argument("--no-extra", action="store_true", help="skip the latency / stereo legs")
     ap.add_argument("--leg-timeout", type=int, default=420, help="seconds the secondary legs (latency, stereo, BA, CPU baseline) may take before the line is printed without them")
     args = ap.parse_args()
@@ -191,6 +194,14 @@ def main() -> int:
         except Exception as e:
             if rank == 0:
                 result["global_ba"] = {"error": repr(e)}
+        if not args.no_ba_large:
+            try:
+                gl = bench_global_ba(local_rank, rank, world, large=True)
+                if rank == 0:
+                    result["global_ba_large"] = gl
+            except Exception as e:
+                if rank == 0:
+                    result["global_ba_large"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(frames_np, want_ba=not args.no_ba)
     legs_done.set()
@@ -674,14 +685,21 @@ def bench_local_ba(ctx, rank=0, world=1):
     return out
 
 
-def bench_global_ba(device, rank, world):
-    """BASELINE config 5.  One rank: svgpu_global_ba.  N ranks: every rank holds the same scene, takes the observations of the landmarks
-    l % N == rank and runs svgpu_global_ba_sharded over the library's own RCCL communicator."""
+XGMI_LINK_GBS = 153.0  # MI355X_MICROARCH.md: per xGMI link and direction (7 links per GPU); a ring all-reduce moves 2 (N - 1) / N of the payload over one
+
+
+def bench_global_ba(device, rank, world, large=False):
+    """BASELINE config 5 (or, `large`, the same 500-keyframe loop with 1.6 M landmarks / 9.6 M observations: the size at which the sharded
+    part of a trial outweighs its serial part).  One rank: svgpu_global_ba.  N ranks: every rank holds the same scene, takes the observations
+    of the landmarks whose keyframe segment it owns (distributed.shard_by_keyframe_segment; SVGPU_BENCH_BA_SHARD=mod: l % N) and runs
+    svgpu_global_ba_sharded over the library's own RCCL communicator."""
     import torch
     from stella_vslam_amd import distributed, feature, optimize, synthetic
-    sc = synthetic.ba_scene_large()   # 500 KF / 200k landmarks / 1.2M observations (seed 5005)
+    sc = synthetic.ba_scene_large(num_lm=1600000) if large else synthetic.ba_scene_large()   # 500 KF / 200k landmarks / 1.2M observations (seed 5005)
     ctx = feature.Context(device)
     ba = optimize.local_bundle_adjuster(ctx=ctx)
+    by_segment = os.environ.get("SVGPU_BENCH_BA_SHARD", "segment") != "mod"
+    partition = None
     if world > 1:
         import torch.distributed as dist
         use_lib_comm = dist.get_backend() == "nccl" and torch.cuda.device_count() >= world
@@ -691,7 +709,8 @@ def bench_global_ba(device, rank, world):
             distributed.init_comm(ctx)
         else:
             cb, keep = distributed.make_allreduce_callback()
-        shard = distributed.shard_by_landmark(sc, rank, world)
+        shard = (distributed.shard_by_keyframe_segment if by_segment else distributed.shard_by_landmark)(sc, rank, world)
+        partition = shard.get("_partition")
         run = lambda: ba.optimize_global_flat_sharded(shard, rank, world, cb, num_iter=10)
     else:
         run = lambda: ba.optimize_global_flat(sc, num_iter=10)
@@ -712,14 +731,15 @@ def bench_global_ba(device, rank, world):
         plan = ba.last_envelope_plan()
     except Exception:
         plan = None
-    kernels = None
+    exchange = ba.last_exchange() if world > 1 else None
+    kernels, projection = None, None
+    E, Lm, P = len(sc["obs_pose"]), len(sc["points"]), len(sc["pose_cw"])
     if world == 1:
         # one more call with HIP events around every kernel class of the LM loop (svgpu_profile_select "*"): mean launch time and the
         # ALGORITHMIC bytes of a launch (what the formulation has to move once: observations, the W blocks at 144 B per edge, landmark
         # blocks, the pair list) against the 8 TB/s HBM roof; the envelope solve is a dependency chain over 1.5 MB (no byte figure)
         from stella_vslam_amd._lib import lib
         L = lib()
-        E, Lm, P = len(sc["obs_pose"]), len(sc["points"]), len(sc["pose_cw"])
         L.svgpu_profile_select(ctx.handle, b"*")
         r2 = run()
         pairs = 0
@@ -731,12 +751,14 @@ def bench_global_ba(device, rank, world):
                "ba_chi2": E * 25 + Lm * 24 + P * 96,                                     # observations, points, poses
                "ba_solve": None}
         kernels = []
+        class_ms = {}
         for name, nbytes in alg.items():
             ms, n = C.c_double(), C.c_longlong()
             L.svgpu_profile_read_class(ctx.handle, name.encode(), C.byref(ms), C.byref(n))
             if n.value == 0:
                 continue
             mean = ms.value / n.value
+            class_ms[name] = ms.value
             ent = {"class": name, "launches_per_call": n.value, "mean_launch_ms": round(mean, 4)}
             if nbytes is not None:
                 ach = nbytes / (mean * 1e-3) / 1e9
@@ -746,11 +768,64 @@ def bench_global_ba(device, rank, world):
                 ent.update({"bound": "latency", "note": "segmented block envelope Cholesky: jobs + separator system + backward substitution, a dependency chain of ~100 block columns"})
             kernels.append(ent)
         L.svgpu_profile_select(ctx.handle, None)
-    return {"metric": "global-BA LM iterations/s @500 KF / 200k landmarks / %d obs" % len(sc["obs_pose"]), "value": round(iters / dt, 2), "unit": "iters/s",
+        # Projection for N ranks from THIS GPU's measurements (nothing here is measured at N > 1):
+        #   set-up       MEASURED: rank 0's real 1/N shard of the partition through svgpu_global_ba_sharded with zero iterations and a null
+        #                exchange (host staging, uploads, structure, first chi2, read-back of a shard are what a rank does before / after its loop)
+        #   loop         the observation-proportional phases scale with the largest shard's share of the observations, the envelope solve and
+        #                the loop's remaining launch gaps stay as measured at N = 1
+        #   exchange     every collective priced as a ring all-reduce over one xGMI link + a fixed cost per call
+        trials = max(int(r2["stats"]["lm_trials"]), 1)
+        call_ms = dt / reps * 1e3
+        shard_ms = sum(class_ms.get(k, 0.0) for k in ("ba_linearize", "ba_schur", "ba_update", "ba_chi2"))
+        solve_ms = class_ms.get("ba_solve", 0.0)
+
+        def timed_ms(fn, n=3):
+            fn()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            return (time.perf_counter() - t) / n * 1e3
+
+        setup1_ms = timed_ms(lambda: ba.optimize_global_flat(sc, num_iter=0))
+        gaps_ms = max(call_ms - setup1_ms - shard_ms - solve_ms, 0.0)
+        null_cb = distributed.ALLREDUCE_FN(lambda user, buf, count, stream: 0)
+        FIXED_US, PER_TRIAL_CALLS = 20.0, 6
+        projection = {"assumptions": {"collective_fixed_us": FIXED_US, "xgmi_link_GBs": XGMI_LINK_GBS, "collectives_per_trial": PER_TRIAL_CALLS,
+                                      "setup": "measured on this GPU: rank 0's shard, zero iterations, null exchange",
+                                      "loop": "observation phases x largest shard share; envelope solve and launch gaps as at N = 1"},
+                      "measured_N1_ms": {"call": round(call_ms, 2), "setup": round(setup1_ms, 2), "observation_phases": round(shard_ms, 2),
+                                         "envelope_solve": round(solve_ms, 2), "loop_gaps": round(gaps_ms, 2)},
+                      "by_ranks": {}}
+        for n in (2, 4, 8):
+            shard0 = distributed.shard_by_keyframe_segment(sc, 0, n)
+            info = shard0["_partition"]
+            lm_rank = sc["_kfseg"][0]
+            share = float(np.bincount(lm_rank[np.asarray(sc["obs_point"])], minlength=n).max()) / max(E, 1)
+            setup_n_ms = timed_ms(lambda: ba.optimize_global_flat_sharded(shard0, 0, n, null_cb, num_iter=0))
+            seg_bytes = 288 * info["separator_blocks"] + 48 * info["separator_keyframes"] + 8 * info["job_exchange_doubles"] + 48 * info["free_keyframes"] + 32 + 8 * n
+            lin_bytes = 42 * 8 * info["free_keyframes"]
+            full_bytes = seg_bytes - 288 * info["separator_blocks"] - 48 * info["separator_keyframes"] + 288 * info["kept_blocks"] + 48 * info["free_keyframes"]
+            setup_xch = 8 * (Lm + 1) + 8 * 4 * Lm  # by-landmark contract check + the points of the other ranks at the end
+            ent = {"segmented": info["segmented"], "largest_shard_share_of_observations": round(share, 4), "separator_keyframes": info["separator_keyframes"],
+                   "landmarks_on_separators": info["landmarks_on_separators"], "setup_ms_of_a_shard": round(setup_n_ms, 2)}
+            ring = lambda nbytes: nbytes * 2.0 * (n - 1) / n / (XGMI_LINK_GBS * 1e9) * 1e3
+            for label, per_trial in (("keyframe_segments", seg_bytes), ("l_mod_N", full_bytes)):
+                wire_ms = trials * (ring(per_trial + lin_bytes) + PER_TRIAL_CALLS * FIXED_US * 1e-3) + ring(setup_xch) + 4 * FIXED_US * 1e-3
+                t_ms = setup_n_ms + gaps_ms + solve_ms + shard_ms * share + wire_ms
+                ent[label] = {"bytes_per_trial": int(per_trial), "bytes_per_linearisation": int(lin_bytes), "setup_exchange_bytes": int(setup_xch),
+                              "exchange_ms_per_call": round(wire_ms, 3), "projected_ms_per_call": round(t_ms, 2), "projected_speedup": round(call_ms / t_ms, 2)}
+            projection["by_ranks"][str(n)] = ent
+    name = "global-BA LM iterations/s @500 KF / %s landmarks / %d obs" % ("1.6M" if large else "200k", len(sc["obs_pose"]))
+    shard_note = "none"
+    if world > 1:
+        shard_note = ("observations by keyframe segment (a landmark follows the piece of the keyframe graph that owns its keyframes): per damping trial only the "
+                      "separator blocks, what the jobs leave on the separators and the solution cross ranks over RCCL") if by_segment else \
+                     ("observations by landmark (l % N): all-reduce of the kept Schur blocks per damping trial over RCCL; the factorisation of the reduced system "
+                      "is distributed (every rank eliminates the envelope jobs it owns, separator contributions and solution exchanged)")
+    return {"metric": name, "value": round(iters / dt, 2), "unit": "iters/s",
             "envelope_plan": plan, "kernels": kernels,
-            "ms_per_call": round(dt / reps * 1e3, 2), "iters_per_call": iters / reps, "dtype": "f64", "n_gpus": world,
-            "sharding": "none" if world == 1 else "observations by landmark (l % N): all-reduce of the kept Schur blocks per damping trial over RCCL; the factorisation of the "
-                                                  "reduced system is distributed (every rank eliminates the envelope jobs it owns, separator contributions and solution exchanged)",
+            "ms_per_call": round(dt / reps * 1e3, 2), "iters_per_call": iters / reps, "lm_trials_per_call": int(res["stats"]["lm_trials"]), "dtype": "f64", "n_gpus": world,
+            "sharding": shard_note, "partition": partition, "exchange": exchange, "projection": projection,
             "linear_solver": "block envelope Cholesky of the reduced camera system (direct)" if res["stats"]["pcg_iterations"] == 0 else "block-Jacobi PCG",
             "pcg_iterations_per_call": res["stats"]["pcg_iterations"], "chi2_final": res["stats"]["chi2_final"],
             "roofline": ba_roofline(sc, iters, dt, free)}

@@ -750,6 +750,27 @@ int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int r
                             svgpu_allreduce_fn allreduce, void* allreduce_user, volatile uint8_t* stop, double* pose_out,
                             double* points_out, svgpu_ba_stats* stats);
 
+/* Keyframe-segment partition of a global-BA problem over `world` ranks (optimize/global_bundle_adjuster.cc:26-192 is the workload):
+ * the ordered keyframe graph is cut by the vertex separators of the segmented envelope solve (the cuts the solve itself will make for
+ * `world` ranks), every piece between two cuts is a job owned by one rank, and a landmark goes to the rank that owns the piece its
+ * keyframes lie in -- co-observation makes a landmark's keyframes a clique of the keyframe graph, so they all lie in ONE piece plus
+ * separator keyframes.  Host only (no device is touched, ctx-free).
+ *   landmark_rank   num_points entries: the rank whose shard gets every observation of that landmark (a valid BY-LANDMARK sharding)
+ *   info            12 ints: [0] 1 = keyframe segments, 0 = no segmented plan for this problem: landmark_rank = l % world;
+ *                   [1] jobs  [2] cuts  [3] separator keyframes  [4] landmarks seen from a separator keyframe (their blocks are what
+ *                   crosses ranks)  [5] of those, seen from separator keyframes only  [6] free keyframes  [7] kept 6x6 blocks
+ *                   [8] kept blocks between two separator keyframes  [9] doubles the jobs leave on the separators per trial  [10..11] 0
+ * svgpu_global_ba_sharded / svgpu_local_ba_sharded RECOGNISE shards cut this way (every observation of a piece's keyframe on the
+ * piece's rank; agreed between the ranks by one flag at set-up) and then exchange, per damping trial, only the separator-by-separator
+ * blocks and separator rows of the reduced system + what the jobs leave on the separators + the solution, instead of the whole
+ * reduced system; any other by-landmark sharding (l % world) keeps the full exchange.  SVGPU_BA_EXCHANGE=full forces the latter. */
+int svgpu_ba_partition_keyframe_segments(const svgpu_ba_problem* problem, int world, int32_t* landmark_rank, int32_t* info);
+/* What the last sharded solve on this context all-reduced, in bytes of payload per rank: info[0] 0 = not sharded, 1 = whole reduced
+ * system per trial, 2 = keyframe-segment exchange; [1] set-up  [2] pose blocks (per linearisation)  [3] reduced system (per trial)
+ * [4] separator contributions of the jobs (per trial)  [5] solution (per trial)  [6] trial sums / damping slots; [7] all-reduce calls
+ * [8] damping trials  [9] linearisations. */
+int svgpu_ba_last_exchange(svgpu_ctx* ctx, int64_t* info);
+
 /* ------------------------------------------------------------------------------------------------ RCCL communicator
  * One communicator per context (= per GPU / process), RCCL over xGMI, loaded with dlopen on first use.  Rank 0 calls
  * svgpu_comm_unique_id and hands the 128 bytes (ncclUniqueId) to the other ranks through whatever channel the host

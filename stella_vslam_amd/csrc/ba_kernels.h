@@ -84,6 +84,8 @@ struct BaDev {
     int red_scale_off, red_scale_n;  // per-block partial sums of delta^T (lambda delta + b)
     int red_flag_off;                // [2..5] cycle counters of the on-chip Cholesky
     int add_lambda;          // 1 = THIS rank adds the damping to the diagonal of S (rank 0 only in a sharded solve)
+    const uint8_t* any_owner; // sharded: per landmark, some rank holds observations of it (the final exchange of the points)
+    const uint8_t* lam_slot; // nullable; keyframe-segment exchange of a sharded solve: per free pose, whether THIS rank adds the damping to its diagonal block
     const double* Hpp_full;  // pose blocks summed over all ranks (== Hpp when not sharded): lambda init
     const double* bp_full;   // same for bp: step-scale term
     int scale_pose;          // 1 = this rank contributes the pose part of delta^T(lambda delta + b)

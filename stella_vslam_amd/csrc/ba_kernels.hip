@@ -1751,7 +1751,7 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
         double v = -sum;
         if (ab.x == ab.y) {
             v += D.Hpp[(size_t)ab.x * 36 + t];
-            if (t % 7 == 0 && D.add_lambda) v += D.ctl->lambda;
+            if (t % 7 == 0 && (D.lam_slot ? D.lam_slot[ab.x] != 0 : D.add_lambda != 0)) v += D.ctl->lambda;
         }
         D.Sblk[k] = v;
     }
@@ -1765,6 +1765,47 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
     }
 }
 
+// ---- landmark-sized exchanges of a sharded solve, on the device (svgpu_ba.hip)
+// contract check: xch[l] = this rank holds observations of landmark l; xch[L] = its stop-pointer vote
+__global__ __launch_bounds__(256) void k_ba_owned_mark(const int* __restrict__ lm_off, int L, double* __restrict__ xch, double stop_vote) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l < L) xch[l] = lm_off[l + 1] > lm_off[l] ? 1.0 : 0.0;
+    else if (l == L) xch[L] = stop_vote;
+}
+// after the sum: verdict[0] = a landmark has two owners, verdict[1] = the summed stop-pointer vote; any_owner[l] for the final exchange
+__global__ __launch_bounds__(256) void k_ba_owned_check(const double* __restrict__ xch, int L, uint8_t* __restrict__ any_owner, double* __restrict__ verdict) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l < L) {
+        const double v = xch[l];
+        any_owner[l] = v > 0.5;
+        if (v > 1.5) verdict[0] = 1.0;  // (benign race: every writer stores 1)
+    }
+    else if (l == L) verdict[1] = xch[L];
+}
+// final estimate of the landmarks: dir 0: xch[3 l ..] = the point when this rank owns it, else 0; dir 1 (after the sum): owned landmarks take the sum
+__global__ __launch_bounds__(256) void k_ba_points_share(BaDev D, double* __restrict__ points_out, double* __restrict__ xch, int dir) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * (size_t)D.L) return;
+    const int l = (int)(i / 3);
+    if (dir == 0) xch[i] = D.lm_off[l + 1] > D.lm_off[l] ? points_out[i] : 0.0;
+    else if (D.any_owner[l]) points_out[i] = xch[i];
+}
+
+// Keyframe-segment exchange of a sharded solve (svgpu_ba.hip): only the kept blocks between two separator rows and the separator rows of
+// the right-hand side cross ranks.  dir 0: Sblk / g -> the compact buffer [36 nb | 6 ns]; dir 1: back.
+__global__ __launch_bounds__(256) void k_ba_xs_move(BaDev D, const int* __restrict__ blk_idx, int nb, const int* __restrict__ slot_idx, int ns, double* __restrict__ buf, int dir) {
+    if (D.ctl->phase != 1) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double* src;
+    if (k < nb * 36) src = D.Sblk + (size_t)blk_idx[k / 36] * 36 + k % 36;
+    else if (k < nb * 36 + ns * 6) {
+        const int r = k - nb * 36;
+        src = D.g + (size_t)slot_idx[r / 6] * 6 + r % 6;
+    }
+    else return;
+    if (dir == 0) buf[k] = *src;
+    else *src = buf[k];
+}
 // Block-Jacobi preconditioned conjugate gradients on the reduced camera system with EVERYTHING in the LDS of one workgroup: the
 // kept 6x6 blocks (36 doubles each), the block-row lists, the inverse diagonal blocks and the five vectors.  A local-BA system
 // (6 * free keyframes <= a few hundred unknowns, <= ~450 blocks) converges to 1e-10 in a few dozen iterations of ~0.4 us each;
@@ -2441,6 +2482,19 @@ void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {  // sharded solve only: pose
 }
 
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale) { hipLaunchKernelGGL(k_ba_fold, dim3(1), dim3(256), 0, s, D, out4, with_scale); }
+void sv_ba_owned_mark(hipStream_t s, const int* lm_off, int L, double* xch, double stop_vote) {
+    hipLaunchKernelGGL(k_ba_owned_mark, dim3((L + 1 + 255) / 256), dim3(256), 0, s, lm_off, L, xch, stop_vote);
+}
+void sv_ba_owned_check(hipStream_t s, const double* xch, int L, uint8_t* any_owner, double* verdict) {
+    hipLaunchKernelGGL(k_ba_owned_check, dim3((L + 1 + 255) / 256), dim3(256), 0, s, xch, L, any_owner, verdict);
+}
+void sv_ba_points_share(hipStream_t s, const BaDev& D, double* points_out, double* xch, int dir) {
+    if (D.L > 0) hipLaunchKernelGGL(k_ba_points_share, dim3((unsigned)((3 * (size_t)D.L + 255) / 256)), dim3(256), 0, s, D, points_out, xch, dir);
+}
+void sv_ba_xs_move(hipStream_t s, const BaDev& D, const int* blk_idx, int nb, const int* slot_idx, int ns, double* buf, int dir) {
+    const int items = nb * 36 + ns * 6;
+    if (items > 0) hipLaunchKernelGGL(k_ba_xs_move, dim3((items + 255) / 256), dim3(256), 0, s, D, blk_idx, nb, slot_idx, ns, buf, dir);
+}
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(256), 0, s, D, it_max, stop_in); }
 void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }
 void sv_ba_decide(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_decide, dim3(1), dim3(1024), 0, s, D); }

@@ -1016,6 +1016,9 @@ struct SkyPlan {
     double *seg_arena = nullptr, *seg_xch = nullptr, *seg_dpx = nullptr;
     size_t seg_xch_doubles = 0, seg_lds_job = 0, seg_lds_back = 0;
     int seg_NB = 0, seg_n = 0, seg_cuts = 0, seg_longest = 0, plan_rows = 0, plan_width = 0;
+    // roles of a segmented plan, host side (the keyframe-segment exchange of a sharded solve, svgpu_ba.hip): slot -> job (-1 = separator
+    // row), job -> owning rank, the kept blocks whose two slots are both separator rows
+    std::vector<int> seg_job_of, seg_owner, seg_sep_blocks;
     // the block pattern the plan was made for: an unchanged pattern (the same window / map optimised again) keeps plan and device arrays
     unsigned long long pattern_hash = 0;
     int pattern_nP = 0, pattern_rank = 0, pattern_world = 0, pattern_env = 0;
@@ -1555,6 +1558,16 @@ static void host_env_backward(const HostSky& h, const double* val, const double*
 // (and nothing else changes) when the envelope would exceed max_bytes or a column has more than SKY_MAXM rows: the caller keeps the PCG.
 // Uploads a segmented plan: every job's and the separator system's index arrays, the assembly / gather maps and the descriptors of the
 // jobs THIS rank owns into the integer arena, and lays the value arena out (SegLayout).
+// slot -> job (-1: separator row) and the kept blocks between two separator rows
+static void seg_roles(int nP, const std::vector<int2>& blk_ab, const HostSeg& G, std::vector<int>& job_of, std::vector<int>& sep_blocks) {
+    job_of.assign(nP, -1);
+    for (size_t q = 0; q < G.job.size(); ++q)
+        for (int k = 0; k < G.nC[q]; ++k) job_of[G.order[q][k]] = (int)q;
+    sep_blocks.clear();
+    for (size_t k = 0; k < blk_ab.size(); ++k)
+        if (job_of[blk_ab[k].x] < 0 && job_of[blk_ab[k].y] < 0) sep_blocks.push_back((int)k);
+}
+
 static int seg_upload(svgpu_ctx* ctx, hipStream_t s, SkyPlan* P, int nP, const std::vector<int2>& blk_ab, const HostSeg& G, const SegLayout& LY, int rank, int world) {
     const int nj = (int)G.job.size(), nsep = (int)G.sep_order.size();
     std::vector<int> host;
@@ -1679,6 +1692,8 @@ static int seg_upload(svgpu_ctx* ctx, hipStream_t s, SkyPlan* P, int nP, const s
     P->seg_lds_back = lds_back;
     P->seg_NB = (int)blk_ab.size();
     P->seg_n = 6 * nP;
+    seg_roles(nP, blk_ab, G, P->seg_job_of, P->seg_sep_blocks);
+    P->seg_owner = G.owner;
     P->val_used = LY.total * sizeof(double);
     P->epoch = 0;
     P->usable = true;
@@ -1720,6 +1735,51 @@ static bool choose_segments(int nP, const std::vector<int>& order, const std::ve
     return LY.ok;
 }
 
+// The front half of sv_sky_plan, free of the device: keyframe graph, RCM order, the one-piece plan H0 and -- when the band is long enough
+// and nothing switches it off -- the segmented plan.  Shared with the keyframe-segment partitioner of a sharded solve, which has to cut
+// the graph exactly where the solve will.
+static bool plan_front(int nP, const std::vector<int2>& blk_ab, int world, size_t max_bytes, std::vector<std::vector<int>>& adj, std::vector<int>& order,
+                       HostSky& H0, HostSeg& G, SegLayout& LY) {
+    adj.assign(nP, {});
+    for (const int2& ab : blk_ab)
+        if (ab.x != ab.y) {
+            adj[ab.x].push_back(ab.y);
+            adj[ab.y].push_back(ab.x);
+        }
+    order = rcm_order(nP, adj);
+    host_sky(nP, order, adj, blk_ab, nP, false, max_bytes, H0);
+    if (!H0.ok) return false;
+    const char* ev = std::getenv("SVGPU_SKY_SEGMENTS");
+    const int want = ev ? std::atoi(ev) : -1;
+    if (want == 0 || std::getenv("SVGPU_SKY_ONE_SIDED") || !H0.band || H0.max_m < 1 || nP < 8 * (H0.max_m + 1)) return false;
+    return choose_segments(nP, order, adj, blk_ab, want, world, max_bytes, G, LY);
+}
+
+// Keyframe-segment roles of a block pattern, host only: slot -> job (-1 = separator row) and job -> owning rank, as the segmented plan of a
+// `world`-rank solve assigns them; false when that pattern gets no segmented plan.
+bool sv_sky_partition_roles(int nP, const std::vector<int2>& blk_ab, int world, std::vector<int>& job_of, std::vector<int>& owner, int* ncuts, int* sep_blocks_n, long long* xch_doubles) {
+    std::vector<std::vector<int>> adj;
+    std::vector<int> order, sep_blocks;
+    HostSky H0;
+    HostSeg G;
+    SegLayout LY;
+    if (nP <= 0 || !plan_front(nP, blk_ab, world, (size_t)256 << 20, adj, order, H0, G, LY)) return false;
+    seg_roles(nP, blk_ab, G, job_of, sep_blocks);
+    owner = G.owner;
+    if (ncuts) *ncuts = G.ncuts;
+    if (sep_blocks_n) *sep_blocks_n = (int)sep_blocks.size();
+    if (xch_doubles) *xch_doubles = (long long)G.xch_doubles;
+    return true;
+}
+
+// roles of the context's current plan (null when it is not a segmented one)
+bool sv_sky_current_roles(svgpu_ctx* ctx, const std::vector<int>** job_of, const std::vector<int>** owner, const std::vector<int>** sep_blocks) {
+    const SkyPlan* P = (const SkyPlan*)ctx->ba_sky;
+    if (!P || !P->usable || !P->seg) return false;
+    *job_of = &P->seg_job_of, *owner = &P->seg_owner, *sep_blocks = &P->seg_sep_blocks;
+    return true;
+}
+
 int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& blk_ab, size_t max_bytes, bool* usable, int rank, int world) {
     *usable = false;
     if (nP <= 0) return SVGPU_OK;
@@ -1748,15 +1808,12 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
             if (Q && *ok) Q->pattern_hash = h, Q->pattern_nP = nP, Q->pattern_rank = rank, Q->pattern_world = world, Q->pattern_env = env;
         }
     } remember{ctx, usable, hsh, nP, rank, world, env_code};
-    std::vector<std::vector<int>> adj(nP);
-    for (const int2& ab : blk_ab)
-        if (ab.x != ab.y) {
-            adj[ab.x].push_back(ab.y);
-            adj[ab.y].push_back(ab.x);
-        }
-    const std::vector<int> order = rcm_order(nP, adj);  // position -> slot
+    std::vector<std::vector<int>> adj;
+    std::vector<int> order;  // position -> slot
     HostSky H[2];
-    host_sky(nP, order, adj, blk_ab, nP, false, max_bytes, H[0]);
+    HostSeg G;
+    SegLayout LY;
+    const bool segmented = plan_front(nP, blk_ab, world, max_bytes, adj, order, H[0], G, LY);
     if (!H[0].ok) return SVGPU_OK;
     SkyPlan* P = (SkyPlan*)ctx->ba_sky;
     if (!P) {
@@ -1766,24 +1823,16 @@ int sv_sky_plan(svgpu_ctx* ctx, hipStream_t s, int nP, const std::vector<int2>& 
     P->seg = 0;
     // segmented elimination of a long band (the default there; SVGPU_SKY_SEGMENTS=<cuts> forces a cut count, 0 switches it off).  A sharded
     // solve distributes the jobs over its ranks -- every rank plans the same segments from the same (all-reduced) block pattern.
-    {
-        const char* ev = std::getenv("SVGPU_SKY_SEGMENTS");
-        const int want = ev ? std::atoi(ev) : -1;
-        if (want != 0 && !std::getenv("SVGPU_SKY_ONE_SIDED") && H[0].band && H[0].max_m >= 1 && nP >= 8 * (H[0].max_m + 1)) {
-            HostSeg G;
-            SegLayout LY;
-            if (choose_segments(nP, order, adj, blk_ab, want, world, max_bytes, G, LY)) {
-                const int rs = seg_upload(ctx, s, P, nP, blk_ab, G, LY, rank, world);
-                if (rs) return rs;
-                P->seg_cuts = G.ncuts, P->seg_longest = G.max_nC, P->plan_rows = nP, P->plan_width = H[0].max_m;
-                *usable = true;
-                if (std::getenv("SVGPU_BA_TRACE")) {
-                    std::fprintf(stderr, "[ba]     envelope plan: %d block rows, segmented: %d cuts, %zu jobs (longest %d columns, %d on this rank), separator system %d rows%s\n", nP,
-                                 G.ncuts, G.job.size(), G.max_nC, P->seg_jobs_local, G.sep.nP, G.sep.band ? " (banded)" : "");
-                }
-                return SVGPU_OK;
-            }
+    if (segmented) {
+        const int rs = seg_upload(ctx, s, P, nP, blk_ab, G, LY, rank, world);
+        if (rs) return rs;
+        P->seg_cuts = G.ncuts, P->seg_longest = G.max_nC, P->plan_rows = nP, P->plan_width = H[0].max_m;
+        *usable = true;
+        if (std::getenv("SVGPU_BA_TRACE")) {
+            std::fprintf(stderr, "[ba]     envelope plan: %d block rows, segmented: %d cuts, %zu jobs (longest %d columns, %d on this rank), separator system %d rows%s\n", nP,
+                         G.ncuts, G.job.size(), G.max_nC, P->seg_jobs_local, G.sep.nP, G.sep.band ? " (banded)" : "");
         }
+        return SVGPU_OK;
     }
     // two-sided elimination of a long band: T | S | B with S = as many rows as the band is wide (then no block couples T and B)
     int nplans = 1, tw_m = 0, tw_W = 0, tw_nB = 0;
@@ -1921,8 +1970,11 @@ int sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
             (void)sv_allow_dynamic_lds((const void*)k_sky_band, P->seg_lds_job);
             hipLaunchKernelGGL(k_sky_band, dim3(P->seg_jobs_local), dim3(SKY_BAND_THREADS), P->seg_lds_job, s, D, SkyDev(), SkyDev(), SkyTwist(), 0, P->seg_jobs);
         }
-        if (multi && P->seg_xch_doubles > 0 && ctx->ba_ar_fn(ctx->ba_ar_user, P->seg_xch, P->seg_xch_doubles, (void*)s) != 0)
-            return sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed (separator exchange)");
+        if (multi && P->seg_xch_doubles > 0) {
+            ctx->ba_xch[4] += 8 * (long long)P->seg_xch_doubles;
+            ++ctx->ba_xch[7];
+            if (ctx->ba_ar_fn(ctx->ba_ar_user, P->seg_xch, P->seg_xch_doubles, (void*)s) != 0) return sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed (separator exchange)");
+        }
         if (P->seg_nsep > 0) {
             const SkyDev& K = P->dev[0];
             const size_t gitems = std::max(K.nblocks * 36, (size_t)K.nP * 6);
@@ -1947,6 +1999,8 @@ int sv_sky_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
         if (multi) {
             if (P->seg_rank == 0 && P->seg_nsep > 0)
                 hipLaunchKernelGGL(k_seg_copy_sep, dim3((unsigned)((6 * P->dev[0].nP + 255) / 256)), dim3(256), 0, s, D, P->dev[0], P->seg_dpx);
+            ctx->ba_xch[5] += 8 * (long long)P->seg_n;
+            ++ctx->ba_xch[7];
             if (ctx->ba_ar_fn(ctx->ba_ar_user, P->seg_dpx, (size_t)P->seg_n, (void*)s) != 0) return sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed (solution exchange)");
             (void)hipMemcpyAsync(D.dp, P->seg_dpx, sizeof(double) * (size_t)P->seg_n, hipMemcpyDeviceToDevice, s);
         }

@@ -16,6 +16,12 @@
 #include "ba_kernels.h"
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
+void sv_ba_owned_mark(hipStream_t s, const int* lm_off, int L, double* xch, double stop_vote);
+void sv_ba_owned_check(hipStream_t s, const double* xch, int L, uint8_t* any_owner, double* verdict);
+void sv_ba_points_share(hipStream_t s, const BaDev& D, double* points_out, double* xch, int dir);
+void sv_ba_xs_move(hipStream_t s, const BaDev& D, const int* blk_idx, int nb, const int* slot_idx, int ns, double* buf, int dir);
+bool sv_sky_partition_roles(int nP, const std::vector<int2>& blk_ab, int world, std::vector<int>& job_of, std::vector<int>& owner, int* ncuts, int* sep_blocks_n, long long* xch_doubles);
+bool sv_sky_current_roles(svgpu_ctx* ctx, const std::vector<int>** job_of, const std::vector<int>** owner, const std::vector<int>** sep_blocks);
 void sv_ba_zero_inactive(hipStream_t s, const BaDev& D);
 size_t sv_ba_pairs_scratch_bytes(size_t pair_cap, int E, size_t nb_cap);
 int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int2* pairs_out,
@@ -401,6 +407,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
+    need += pad(4 * (nb_cap + (size_t)P)) + pad(P) + pad(L);  // keyframe-segment exchange: block / slot lists, damping owners
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap) + pad(64 * (size_t)nb_lm);
     int rc = sv_ensure_scratch(ctx, need);
     if (rc) return rc;
@@ -476,6 +483,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     int2* d_blk_ab = A.take<int2>(nb_cap);
     int* d_blk_off = A.take<int>(nb_cap + 1);
     char* d_pair_scratch = A.take<char>(pair_scratch);
+    int* d_xs_idx = A.take<int>(nb_cap + (size_t)P);
+    uint8_t* d_lam_slot = A.take<uint8_t>(P);
+    uint8_t* d_any_owner = A.take<uint8_t>(L);  // sharded: the landmark has observations on some rank
+    D.any_owner = d_any_owner;
     if (A.off > ctx->scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: internal arena overflow");
     D.e_pose = d_e_pose;
     D.e_point = d_e_point;
@@ -572,37 +583,48 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     SV_HIP(ctx, hipMemsetAsync(d_sc, 0, 8 * (64 + (size_t)world), s));
 
     // ---- exchange helpers (sharded solve; no-ops otherwise)
-    auto allreduce_dev = [&](double* dev, size_t n) -> int {
+    enum { XC_SETUP = 1, XC_POSE_BLOCKS = 2, XC_SYSTEM = 3, XC_SUMS = 6 };  // (4, 5: the separator / solution exchanges of ba_skyline.hip)
+    for (long long& v : ctx->ba_xch) v = 0;
+    ctx->ba_xch[0] = sharded ? 1 : 0;
+    auto allreduce_dev = [&](double* dev, size_t n, int cat) -> int {
         if (!sharded || n == 0) return SVGPU_OK;
+        ctx->ba_xch[cat] += 8 * (long long)n;
+        ++ctx->ba_xch[7];
         return allreduce(ar_user, dev, n, (void*)s) == 0 ? SVGPU_OK : sv_set_error(ctx, SVGPU_ERR_HIP, "all-reduce callback failed");
     };
-    std::vector<double> xch_host(xch_doubles);
+    std::vector<double> xch_host(sharded ? std::max((size_t)P, nb_cap) + 8 : 8);  // (the landmark-sized exchanges stay on the device)
     auto allreduce_host = [&](size_t n) -> int {  // xch_host[0..n) summed over the ranks (set-up steps only)
         H2D(d_xch, xch_host.data(), 8 * n);
-        int r = allreduce_dev(d_xch, n);
+        int r = allreduce_dev(d_xch, n, XC_SETUP);
         if (r) return r;
         SV_HIP(ctx, hipMemcpyAsync(xch_host.data(), d_xch, 8 * n, hipMemcpyDeviceToHost, s));
         SV_HIP(ctx, hipStreamSynchronize(s));
         return SVGPU_OK;
     };
-    std::vector<uint8_t> owned(L, 0);  // landmarks whose observations live on this rank
-    for (int k = 0; k < E; ++k) owned[e_point[k]] = 1;
     // Whether "the caller passed a stop pointer" must mean the same on every rank: the early return and the skipped second stage below
     // branch on it, and a rank that left while the others entered the next collective would hang them.  A sharded solve therefore acts as
     // if every rank had a pointer as soon as ANY rank has one (the flag rides along with the contract check).
     bool stop_ptr_any = stop != nullptr;
-    if (sharded) {  // contract check: a landmark's observations must not be split over ranks
-        for (int l = 0; l < L; ++l) xch_host[l] = owned[l];
-        xch_host[L] = stop ? 1.0 : 0.0;
-        int r = allreduce_host((size_t)L + 1);
+    if (sharded) {
+        // contract check on the device: a landmark's observations must not be split over ranks.  Every rank marks the landmarks it holds
+        // observations of (its landmark offsets are already there), the marks are summed, a landmark with two owners fails the call on
+        // every rank; what comes back is two words.  The sum also says which landmarks have an owner at all (the final exchange of the
+        // points leaves the others alone).
+        sv_ba_owned_mark(s, d_lm_off, L, d_xch, stop ? 1.0 : 0.0);
+        int r = allreduce_dev(d_xch, (size_t)L + 1, XC_SETUP);
         if (r) return r;
-        for (int l = 0; l < L; ++l)
-            if (xch_host[l] > 1.5) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: observations must be sharded by landmark");
-        stop_ptr_any = xch_host[L] > 0.5;
+        sv_ba_owned_check(s, d_xch, L, d_any_owner, d_sc + 32);
+        double verdict[2] = {0.0, 0.0};
+        SV_HIP(ctx, hipMemcpyAsync(verdict, d_sc + 32, 16, hipMemcpyDeviceToHost, s));
+        SV_HIP(ctx, hipStreamSynchronize(s));
+        if (verdict[0] > 0.5) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba_sharded: observations must be sharded by landmark");
+        stop_ptr_any = verdict[1] > 0.5;
     }
 
     lap("arena + uploads");
     HostStructure HS;
+    bool xs_on = false;  // keyframe-segment exchange (decided with the plan, the same on every rank)
+    int xs_nb = 0, xs_ns = 0;
     bool have_lists = false;
     std::vector<uint8_t> pose_active;
     int solver = SV_BA_SOLVER_CHOLESKY;
@@ -780,6 +802,50 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             solver = HS.envelope_ok ? SV_BA_SOLVER_ENVELOPE : SV_BA_SOLVER_AUTO;
         }
         if (solver == SV_BA_SOLVER_AUTO || solver == SV_BA_SOLVER_PCG) solver = lds_ok ? SV_BA_SOLVER_PCG_LDS : SV_BA_SOLVER_PCG_MULTI;
+        // Keyframe-segment exchange.  When the envelope solve is segmented and every observation this rank holds is of a keyframe in one of
+        // ITS jobs' pieces (or of a separator keyframe) -- svgpu_ba_partition_keyframe_segments cuts shards that way -- the blocks and
+        // right-hand side rows of a piece are complete on the rank that eliminates it and no other rank reads them: only the kept blocks
+        // between two separator rows and the separator rows of g have to be summed.  One all-reduced flag makes the decision collective.
+        if (!reuse) {
+            xs_on = false;
+            D.lam_slot = nullptr;
+            const std::vector<int>*job_of = nullptr, *owner = nullptr, *sep_blocks = nullptr;
+            const char* xe = std::getenv("SVGPU_BA_EXCHANGE");
+            const bool candidate = sharded && world > 1 && solver == SV_BA_SOLVER_ENVELOPE && !(xe && !strcmp(xe, "full")) && sv_sky_current_roles(ctx, &job_of, &owner, &sep_blocks);
+            if (sharded && world > 1) {
+                double misplaced = candidate ? 0.0 : 1.0;
+                if (candidate)
+                    for (int e = 0; e < E && misplaced == 0.0; ++e) {
+                        if (level[e]) continue;
+                        const int sl = HS.pose_slot[e_pose[e]];
+                        if (sl >= 0 && (*job_of)[sl] >= 0 && (*owner)[(*job_of)[sl]] != rank) misplaced = 1.0;
+                    }
+                xch_host[0] = misplaced;
+                int r = allreduce_host(1);
+                if (r) return r;
+                std::vector<int> sep_slots;
+                if (candidate)
+                    for (int sl = 0; sl < HS.nP; ++sl)
+                        if ((*job_of)[sl] < 0) sep_slots.push_back(sl);
+                if (candidate && xch_host[0] < 0.5 && 36 * sep_blocks->size() + 6 * sep_slots.size() <= xch_doubles) {
+                    xs_on = true;
+                    xs_nb = (int)sep_blocks->size();
+                    xs_ns = (int)sep_slots.size();
+                    int* const h_idx = (int*)(hs_struct + st_blk);  // (the block-row image has been uploaded and the stream drained by the planner)
+                    uint8_t* const h_lam = (uint8_t*)(h_idx + xs_nb + xs_ns);
+                    SV_HIP(ctx, hipStreamSynchronize(s));
+                    for (int k = 0; k < xs_nb; ++k) h_idx[k] = (*sep_blocks)[k];
+                    for (int k = 0; k < xs_ns; ++k) h_idx[xs_nb + k] = sep_slots[k];
+                    for (int sl = 0; sl < HS.nP; ++sl) h_lam[sl] = (*job_of)[sl] >= 0 ? (*owner)[(*job_of)[sl]] == rank : rank == 0;
+                    H2D(d_xs_idx, h_idx, 4 * (size_t)(xs_nb + xs_ns));
+                    H2D(d_lam_slot, h_lam, (size_t)HS.nP);
+                    SV_HIP(ctx, hipStreamSynchronize(s));  // (the staging image is reused)
+                    D.lam_slot = d_lam_slot;
+                }
+            }
+            ctx->ba_xch[0] = !sharded ? 0 : (xs_on ? 2 : 1);
+            if (trace && sharded) std::fprintf(stderr, "[ba]     exchange per trial: %s (%d separator blocks, %d separator rows of %d)\n", xs_on ? "keyframe segments" : "whole reduced system", xs_nb, xs_ns, HS.nP);
+        }
         if (sv_ba_lin_split_max() > 16 || sv_ba_rhs_split() > 16) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: partial-sum buffers too small for the kernel splits");
         if (trace) std::fprintf(stderr, "[ba]   structure %s     %8.3f ms (%zu pairs, %zu blocks, n = %d, solver %d)\n", reuse ? "reused " : "rebuilt", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(), HS.num_pairs, HS.blk_ab.size(), D.n, solver);
         return SVGPU_OK;
@@ -791,7 +857,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         sv_ba_chi2(ctx, s, D, 0, store_cache, 0);
         if (sharded) {
             sv_ba_fold(s, D, d_sc, 0);
-            return allreduce_dev(d_sc, 4);
+            return allreduce_dev(d_sc, 4, XC_SUMS);
         }
         return SVGPU_OK;
     };
@@ -808,14 +874,21 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             if (HS.nP > 0) {
                 SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
                 SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
-                if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP))) return r;
+                if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP, XC_POSE_BLOCKS))) return r;
             }
             sv_ba_maxdiag(s, D);
-            if ((r = allreduce_dev(D.maxslots, (size_t)world))) return r;
+            if ((r = allreduce_dev(D.maxslots, (size_t)world, XC_SUMS))) return r;
             sv_ba_prepare(s, D);
         }
         sv_ba_reduce(ctx, s, D);
-        if (HS.nP > 0 && (r = allreduce_dev(D.Sblk, 36 * (size_t)D.NB + (size_t)D.n))) return r;
+        if (HS.nP > 0) {
+            if (xs_on) {  // keyframe-segment shards: only what touches two separator rows is shared between ranks
+                sv_ba_xs_move(s, D, d_xs_idx, xs_nb, d_xs_idx + xs_nb, xs_ns, d_xch, 0);
+                if ((r = allreduce_dev(d_xch, 36 * (size_t)xs_nb + 6 * (size_t)xs_ns, XC_SYSTEM))) return r;
+                sv_ba_xs_move(s, D, d_xs_idx, xs_nb, d_xs_idx + xs_nb, xs_ns, d_xch, 1);
+            }
+            else if ((r = allreduce_dev(D.Sblk, 36 * (size_t)D.NB + (size_t)D.n, XC_SYSTEM))) return r;
+        }
         if (HS.nP > 0) {
             if (solver == SV_BA_SOLVER_CHOLESKY) sv_ba_solve(ctx, s, D);
             else if (solver == SV_BA_SOLVER_PCG_LDS) sv_ba_solve_pcg_lds(ctx, s, D);
@@ -847,7 +920,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         }
         if (sharded) {
             sv_ba_fold(s, D, d_sc, 1);
-            if ((r = allreduce_dev(d_sc, 4))) return r;
+            if ((r = allreduce_dev(d_sc, 4, XC_SUMS))) return r;
         }
         sv_ba_decide(s, D);
         return SVGPU_OK;
@@ -990,6 +1063,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     if ((rc = chi2_begin(0))) return rc;
     sv_ba_begin(s, D, 0, 0);  // folds the chi2 of the final estimate into the control block (phase 2: nothing else happens)
     sv_ba_pack_out(s, D, d_state_out);
+    if (sharded) {  // every rank ends with every landmark: owners contribute their points, the rest zeros (an all-gather through the all-reduce), on the device
+        sv_ba_points_share(s, D, d_state_out + 12 * (size_t)P, d_xch, 0);
+        if ((rc = allreduce_dev(d_xch, 3 * (size_t)L, XC_SETUP))) return rc;
+        sv_ba_points_share(s, D, d_state_out + 12 * (size_t)P, d_xch, 1);
+    }
     // (a caller that takes no outlier flags -- global BA: 1.2 MB at config 5 -- gets the block without them)
     SV_HIP(ctx, hipMemcpyAsync(hs_out, d_out, outlier_out ? out_total : out_outlier, hipMemcpyDeviceToHost, s));
     if ((rc = wait_stream())) return rc;
@@ -997,17 +1075,6 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     memcpy(pose_out, hs_out + out_state, sizeof(double) * 12 * (size_t)P);
     memcpy(points_out, hs_out + out_state + sizeof(double) * 12 * (size_t)P, sizeof(double) * 3 * (size_t)L);
     const uint8_t* const outl = (const uint8_t*)(hs_out + out_outlier);
-    if (sharded) {  // every rank ends with every landmark: owners contribute their points, the rest zeros
-        for (int l = 0; l < L; ++l) {
-            for (int k = 0; k < 3; ++k) xch_host[3 * (size_t)l + k] = owned[l] ? points_out[3 * (size_t)l + k] : 0.0;
-            xch_host[3 * (size_t)L + l] = owned[l];
-        }
-        int r = allreduce_host(4 * (size_t)L);
-        if (r) return r;
-        for (int l = 0; l < L; ++l)
-            if (xch_host[3 * (size_t)L + l] > 0.5)
-                for (int k = 0; k < 3; ++k) points_out[3 * (size_t)l + k] = xch_host[3 * (size_t)l + k];
-    }
     if (outlier_out)
         for (int k = 0; k < E; ++k) outlier_out[perm.empty() ? k : perm[k]] = outl[k];
     st.chi2_final = h_ctl->chi_begin;
@@ -1016,6 +1083,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     st.pcg_iterations = h_ctl->pcg_total_it;
     lap("read-back");
     st.lambda_final = h_ctl->lambda;
+    ctx->ba_xch[8] = st.lm_trials;
+    ctx->ba_xch[9] = st.iters_stage1 + st.iters_stage2;
     if (stats) *stats = st;
 #undef H2D
     return SVGPU_OK;
@@ -1150,6 +1219,89 @@ int svgpu_global_ba_sharded(svgpu_ctx* ctx, const svgpu_ba_problem* shard, int r
         allreduce_user = ctx;
     }
     return local_ba_impl(ctx, shard, true, rank, world, allreduce, allreduce_user, stop, pose_out, points_out, nullptr, stats);
+}
+
+int svgpu_ba_last_exchange(svgpu_ctx* ctx, int64_t* info) {
+    if (!ctx || !info) return SVGPU_ERR_INVALID;
+    for (int k = 0; k < 10; ++k) info[k] = ctx->ba_xch[k];
+    return SVGPU_OK;
+}
+
+// include/svgpu.h.  The block pattern is built the way the solve builds it (a kept block (a, b) = a free landmark observed from the free
+// keyframes a and b; every diagonal block), the cuts come from the solve's own planner (sv_sky_partition_roles).
+int svgpu_ba_partition_keyframe_segments(const svgpu_ba_problem* pr, int world, int32_t* landmark_rank, int32_t* info) {
+    if (!pr || !landmark_rank || !info || world < 1) return SVGPU_ERR_INVALID;
+    const int P = pr->num_poses, L = pr->num_points, E = pr->num_obs;
+    for (int k = 0; k < 12; ++k) info[k] = 0;
+    for (int l = 0; l < L; ++l) landmark_rank[l] = l % world;
+    if (P <= 0 || L <= 0 || E <= 0 || world == 1) return SVGPU_OK;
+    for (int e = 0; e < E; ++e)
+        if (pr->obs_pose[e] < 0 || pr->obs_pose[e] >= P || pr->obs_point[e] < 0 || pr->obs_point[e] >= L) return SVGPU_ERR_INVALID;
+    // free keyframes with an observation, numbered in pose order (activity_only above)
+    std::vector<uint8_t> seen(P, 0);
+    for (int e = 0; e < E; ++e) seen[pr->obs_pose[e]] = 1;
+    std::vector<int> slot(P, -1);
+    int nP = 0;
+    for (int p = 0; p < P; ++p)
+        if (seen[p] && !pr->pose_fixed[p]) slot[p] = nP++;
+    info[6] = nP;
+    if (nP < 4 || nP > 16384) return SVGPU_OK;  // (the pattern below is a dense bit table)
+    // observations grouped by landmark
+    std::vector<int> off(L + 1, 0), obs(E);
+    for (int e = 0; e < E; ++e) ++off[pr->obs_point[e] + 1];
+    for (int l = 0; l < L; ++l) off[l + 1] += off[l];
+    {
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int e = 0; e < E; ++e) obs[fill[pr->obs_point[e]]++] = slot[pr->obs_pose[e]];
+    }
+    std::vector<uint8_t> present((size_t)nP * nP, 0);
+    for (int l = 0; l < L; ++l) {
+        if (pr->point_fixed && pr->point_fixed[l]) continue;
+        for (int i = off[l]; i < off[l + 1]; ++i) {
+            const int a = obs[i];
+            if (a < 0) continue;
+            for (int j = i + 1; j < off[l + 1]; ++j) {
+                const int b = obs[j];
+                if (b >= 0) present[(size_t)std::min(a, b) * nP + std::max(a, b)] = 1;
+            }
+        }
+    }
+    std::vector<int2> blk_ab;
+    for (int a = 0; a < nP; ++a)
+        for (int b = a; b < nP; ++b)
+            if (a == b || present[(size_t)a * nP + b]) {
+                int2 ab;
+                ab.x = a, ab.y = b;
+                blk_ab.push_back(ab);
+            }
+    info[7] = (int)blk_ab.size();
+    std::vector<int> job_of, owner;
+    int ncuts = 0, sep_blocks_n = 0;
+    long long xch_doubles = 0;
+    if (!sv_sky_partition_roles(nP, blk_ab, world, job_of, owner, &ncuts, &sep_blocks_n, &xch_doubles)) return SVGPU_OK;
+    // a landmark follows the piece of its keyframes.  (A FIXED landmark couples nothing and may be seen from two pieces: its observations
+    // cannot be placed on one rank without feeding a foreign piece's pose blocks -- such a problem keeps l % world.)
+    std::vector<int32_t> lr(L);
+    int shared = 0, sep_only = 0;
+    for (int l = 0; l < L; ++l) {
+        int job = -1, on_sep = 0;
+        for (int i = off[l]; i < off[l + 1]; ++i) {
+            const int a = obs[i];
+            if (a < 0) continue;
+            if (job_of[a] < 0) on_sep = 1;
+            else if (job < 0) job = job_of[a];
+            else if (job != job_of[a]) return SVGPU_OK;
+        }
+        lr[l] = job >= 0 ? owner[job] : l % world;
+        shared += on_sep;
+        sep_only += on_sep && job < 0;
+    }
+    for (int l = 0; l < L; ++l) landmark_rank[l] = lr[l];
+    int nsep = 0;
+    for (int a = 0; a < nP; ++a) nsep += job_of[a] < 0;
+    info[0] = 1, info[1] = (int)owner.size(), info[2] = ncuts, info[3] = nsep, info[4] = shared, info[5] = sep_only;
+    info[8] = sep_blocks_n, info[9] = (int32_t)std::min<long long>(xch_doubles, 0x7fffffff);
+    return SVGPU_OK;
 }
 
 int svgpu_ba_set_solver(svgpu_ctx* ctx, int solver, double pcg_tolerance, int pcg_max_iterations) {

@@ -178,6 +178,7 @@ struct svgpu_ctx {
     void* ba_sky = nullptr;         // plan + buffers of the envelope Cholesky (ba_skyline.hip)
     svgpu_allreduce_fn ba_ar_fn = nullptr;  // the all-reduce of the sharded solve in progress (the segmented envelope solve exchanges through it); else null
     void* ba_ar_user = nullptr;
+    long long ba_xch[10] = {0};    // svgpu_ba_last_exchange: what the last sharded solve all-reduced (mode | bytes by category | calls | trials | linearisations)
     int comm_rank = 0, comm_world = 1;
 };
 void sv_comm_release(svgpu_ctx* ctx);

@@ -2,8 +2,9 @@
 on CPU for tests).  PyTorch is only the launcher / collective provider here; the data path is the C ABI.
 
 * extract + match shard by frame (no data-path collective): `frame_shard`, `max_over_ranks`
-* local / global BA shards by landmark with one all-reduce of the reduced camera system per damping trial:
-  `shard_by_landmark`, `make_allreduce_callback` (the `svgpu_allreduce_fn` the library calls back into)
+* local / global BA shards by landmark: `shard_by_keyframe_segment` (a landmark follows the keyframe segment that owns its keyframes; per
+  damping trial only the separator blocks, what the segments leave on them and the solution cross ranks) or `shard_by_landmark` (l % world:
+  one all-reduce of the whole reduced camera system per trial); `make_allreduce_callback` = the `svgpu_allreduce_fn` the library calls back into
 """
 from __future__ import annotations
 
@@ -40,6 +41,25 @@ def shard_by_landmark(scene: dict, rank: int, world: int) -> dict:
     for k in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma_sq", "obs_huber"):
         out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
     out["_obs_index"] = np.flatnonzero(keep)
+    return out
+
+
+def shard_by_keyframe_segment(scene: dict, rank: int, world: int) -> dict:
+    """Observation shard along the keyframe segments of the `world`-rank solve (optimize.partition_keyframe_segments): every landmark goes
+    to the rank that owns the piece of the keyframe graph its keyframes lie in, so per damping trial only the separator blocks cross ranks.
+    Falls back to l % world when the problem gets no segmented plan.  The partition is cached in the scene dict (`_kfseg`)."""
+    from . import optimize
+    key = ("_kfseg", world)
+    if scene.get("_kfseg_key") != key:
+        scene["_kfseg"] = optimize.partition_keyframe_segments(scene, world)
+        scene["_kfseg_key"] = key
+    lm_rank, info = scene["_kfseg"]
+    keep = lm_rank[np.asarray(scene["obs_point"])] == rank
+    out = {k: v for k, v in scene.items() if not k.startswith("_kfseg")}
+    for k in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma_sq", "obs_huber"):
+        out[k] = np.ascontiguousarray(np.asarray(scene[k])[keep])
+    out["_obs_index"] = np.flatnonzero(keep)
+    out["_partition"] = info
     return out
 
 

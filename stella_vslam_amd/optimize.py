@@ -31,6 +31,24 @@ class _BaStats(C.Structure):
                 ("stopped_by_terminate_action", C.c_int32), ("pcg_iterations", C.c_int32)]
 
 
+def partition_keyframe_segments(scene: dict, world: int):
+    """svgpu_ba_partition_keyframe_segments: landmark -> rank over the keyframe segments the `world`-rank solve will cut (host only).
+    Returns (landmark_rank int32[L], info dict)."""
+    a = lambda k, t: np.ascontiguousarray(scene[k], t)
+    pose, pts = a("pose_cw", np.float64), a("points", np.float64)
+    keep = [a("pose_fixed", np.uint8), a("obs_pose", np.int32), a("obs_point", np.int32)]
+    pf = scene.get("point_fixed")
+    pf = None if pf is None else np.ascontiguousarray(pf, np.uint8)
+    ptr = lambda x: None if x is None else x.ctypes.data
+    prob = _BaProblem(len(pose), len(pts), len(keep[1]), ptr(pose), ptr(keep[0]), ptr(pts), ptr(pf), ptr(keep[1]), ptr(keep[2]), None, None, None, None, 0, 0, 0.0)
+    ranks, info = np.zeros(max(len(pts), 1), np.int32), np.zeros(12, np.int32)
+    rc = lib().svgpu_ba_partition_keyframe_segments(C.byref(prob), int(world), C.c_void_p(ranks.ctypes.data), C.c_void_p(info.ctypes.data))
+    if rc:
+        raise RuntimeError(f"svgpu_ba_partition_keyframe_segments failed: {rc}")
+    keys = ("segmented", "jobs", "cuts", "separator_keyframes", "landmarks_on_separators", "landmarks_on_separators_only", "free_keyframes", "kept_blocks", "separator_blocks", "job_exchange_doubles")
+    return ranks[:len(pts)], {k: int(v) for k, v in zip(keys, info)}
+
+
 def local_bundle_adjuster_factory_create(backend: str = "hip", **kw):
     """optimize/local_bundle_adjuster_factory.h:17-32 -- the backend switch."""
     if backend != "hip":
@@ -59,6 +77,16 @@ class local_bundle_adjuster:
         self.ctx.check(lib().svgpu_ba_last_envelope_plan(self.ctx.handle, C.c_void_p(info.ctypes.data)), "svgpu_ba_last_envelope_plan")
         return dict(kind=("one-sided", "two-sided", "segmented")[int(info[0])], rows=int(info[1]), widest_column=int(info[2]), cuts=int(info[3]),
                     jobs=int(info[4]), jobs_local=int(info[5]), separator_rows=int(info[6]), longest_job=int(info[7]))
+
+    def last_exchange(self) -> dict:
+        """What the context's last sharded solve all-reduced (svgpu_ba_last_exchange); bytes are payload per rank."""
+        info = np.zeros(10, np.int64)
+        self.ctx.check(lib().svgpu_ba_last_exchange(self.ctx.handle, C.c_void_p(info.ctypes.data)), "svgpu_ba_last_exchange")
+        trials, lins = max(int(info[8]), 1), max(int(info[9]), 1)
+        per_trial = (int(info[3]) + int(info[4]) + int(info[5]) + int(info[6])) / trials + int(info[2]) / lins
+        return dict(mode=("none", "whole reduced system", "keyframe segments")[int(info[0])], setup_bytes=int(info[1]), pose_block_bytes=int(info[2]),
+                    reduced_system_bytes=int(info[3]), separator_bytes=int(info[4]), solution_bytes=int(info[5]), sums_bytes=int(info[6]),
+                    allreduce_calls=int(info[7]), trials=int(info[8]), linearisations=int(info[9]), bytes_per_trial=per_trial)
 
     def optimize_global_flat(self, scene: dict, num_iter: int = 10, force_stop_flag: np.ndarray | None = None, gain_threshold: float = 1e-3):
         """global_bundle_adjuster core: one LM run of `num_iter` iterations over the whole graph (no outlier stage)."""

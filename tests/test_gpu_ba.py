@@ -570,6 +570,65 @@ def test_global_ba_distributed_factorisation_matches_single(world, monkeypatch):
     assert _rel(results[0]["points"], single["points"]) < 1e-7
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_global_ba_keyframe_segment_shards_exchange_only_separators(world, monkeypatch):
+    """north_star's partition: observations sharded by the keyframe segment that owns them (distributed.shard_by_keyframe_segment over
+    svgpu_ba_partition_keyframe_segments).  The solve recognises such shards and, per damping trial, all-reduces only the separator blocks,
+    what the jobs leave on the separators and the solution -- not the reduced camera system.  `world` ranks simulated on one GPU: all ranks
+    bit-identical, equal to the single-GPU solve to 1e-7 with the same LM schedule, and far fewer bytes than the l % world shards move."""
+    from stella_vslam_amd import distributed as D, feature, optimize
+    monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+    monkeypatch.delenv("SVGPU_BA_EXCHANGE", raising=False)
+    monkeypatch.setenv("SVGPU_SKY_SEGMENTS", "5")
+    sc = S.ba_scene_large(num_kf=200, num_lm=24000, obs_per_lm=4)
+    single = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+    lm_rank, info = optimize.partition_keyframe_segments(sc, world)
+    assert info["segmented"] == 1 and info["jobs"] >= world and 0 < info["separator_keyframes"] < info["free_keyframes"] // 4
+    xch = {}
+
+    def run(shard_fn):
+        def run_rank(rank, cb):
+            adj = optimize.local_bundle_adjuster(ctx=feature.Context()).set_solver(optimize.SOLVER_ENVELOPE)
+            res = adj.optimize_global_flat_sharded(shard_fn(sc, rank, world), rank, world, cb, num_iter=10)
+            xch[(shard_fn.__name__, rank)] = adj.last_exchange()
+            return res
+        return _simulated_ranks(world, run_rank)
+
+    seg = run(D.shard_by_keyframe_segment)
+    assert all(r is not None and r["rc"] == 0 for r in seg)
+    for r in seg[1:]:
+        assert np.array_equal(seg[0]["pose_cw"], r["pose_cw"]) and np.array_equal(seg[0]["points"], r["points"])
+    assert seg[0]["stats"]["iters_stage1"] == single["stats"]["iters_stage1"] and seg[0]["stats"]["lm_trials"] == single["stats"]["lm_trials"]
+    _assert_poses(seg[0]["pose_cw"], single["pose_cw"], 1e-7)
+    assert _rel(seg[0]["points"], single["points"]) < 1e-7
+    mod = run(D.shard_by_landmark)
+    assert all(r is not None and r["rc"] == 0 for r in mod)
+    _assert_poses(mod[0]["pose_cw"], single["pose_cw"], 1e-7)
+    for rank in range(world):
+        a, b = xch[("shard_by_keyframe_segment", rank)], xch[("shard_by_landmark", rank)]
+        assert a["mode"] == "keyframe segments" and b["mode"] == "whole reduced system", (a, b)
+        assert a["trials"] == b["trials"] and a["separator_bytes"] == b["separator_bytes"] and a["solution_bytes"] == b["solution_bytes"]
+        assert a["reduced_system_bytes"] * 4 < b["reduced_system_bytes"], (a, b)
+
+
+def test_keyframe_segment_exchange_can_be_switched_off(monkeypatch):
+    """SVGPU_BA_EXCHANGE=full: the same shards, the whole reduced system per trial (the A/B switch DESIGN section 7 quotes)."""
+    from stella_vslam_amd import distributed as D, feature, optimize
+    monkeypatch.setenv("SVGPU_SKY_SEGMENTS", "5")
+    monkeypatch.setenv("SVGPU_BA_EXCHANGE", "full")
+    sc = S.ba_scene_large(num_kf=200, num_lm=24000, obs_per_lm=4)
+    modes = [None, None]
+
+    def run_rank(rank, cb):
+        adj = optimize.local_bundle_adjuster(ctx=feature.Context()).set_solver(optimize.SOLVER_ENVELOPE)
+        res = adj.optimize_global_flat_sharded(D.shard_by_keyframe_segment(sc, rank, 2), rank, 2, cb, num_iter=3)
+        modes[rank] = adj.last_exchange()["mode"]
+        return res
+
+    res = _simulated_ranks(2, run_rank)
+    assert all(r is not None and r["rc"] == 0 for r in res) and modes == ["whole reduced system"] * 2
+
+
 def test_sharded_through_rccl_communicator_world1():
     """svgpu_comm_init (RCCL resolved with dlopen inside the library) + svgpu_local_ba_sharded with allreduce = NULL: one rank is
     all a single GPU allows (RCCL refuses two ranks on one device), but it drives every collective of the sharded solve through

@@ -35,6 +35,14 @@ if rank == 1:
 stopped = adj.optimize_flat_sharded(D.shard_by_landmark(sc, rank, world), rank, world, cb, force_stop_flag=flag)
 sg = S.ba_scene(num_kf=40, num_lm=3000, obs_per_lm=6, num_fixed=1, seed=32, loop=True)
 resg = adj.optimize_global_flat_sharded(D.shard_by_landmark(sg, rank, world), rank, world, cb, num_iter=10)
+# north_star's partition: keyframe-segment shards of a system long enough for the segmented plan; only the separators cross the processes
+os.environ["SVGPU_SKY_SEGMENTS"] = "5"
+adjk = optimize.local_bundle_adjuster(ctx=feature.Context(0)).set_solver(optimize.SOLVER_ENVELOPE)
+sk = S.ba_scene_large(num_kf=200, num_lm=24000, obs_per_lm=4)
+resk = adjk.optimize_global_flat_sharded(D.shard_by_keyframe_segment(sk, rank, world), rank, world, cb, num_iter=10)
+xk = adjk.last_exchange()
+resm = adjk.optimize_global_flat_sharded(D.shard_by_landmark(sk, rank, world), rank, world, cb, num_iter=10)
+xm = adjk.last_exchange()
 if rank == 0:
     single = adj.optimize_flat(sc)
     singleg = adj.optimize_global_flat(sg, num_iter=10)
@@ -44,10 +52,15 @@ if rank == 0:
                gated=[res["stats"]["num_gated"], single["stats"]["num_gated"]],
                dposeg=float(np.abs(resg["pose_cw"] - singleg["pose_cw"]).max()), itersg=[resg["stats"]["iters_stage1"], singleg["stats"]["iters_stage1"]],
                pcg=resg["stats"]["pcg_iterations"])
+    singlek = adjk.optimize_global_flat(sk, num_iter=10)
+    out.update(rck=resk["rc"], dposek=float(np.abs(resk["pose_cw"] - singlek["pose_cw"]).max()),
+               dptsk=float(np.abs(resk["points"] - singlek["points"]).max() / np.abs(singlek["points"]).max()),
+               trialsk=[resk["stats"]["lm_trials"], singlek["stats"]["lm_trials"]], modes=[xk["mode"], xm["mode"]],
+               system_bytes=[xk["reduced_system_bytes"], xm["reduced_system_bytes"]])
 allr = [None] * world
-dist.all_gather_object(allr, [res["pose_cw"].tobytes(), resg["pose_cw"].tobytes(), stopped["rc"], int(flag[0])])
+dist.all_gather_object(allr, [res["pose_cw"].tobytes(), resg["pose_cw"].tobytes(), stopped["rc"], int(flag[0]), resk["pose_cw"].tobytes() + resk["points"].tobytes()])
 if rank == 0:
-    out["identical"] = all(a[0] == allr[0][0] and a[1] == allr[0][1] for a in allr)
+    out["identical"] = all(a[0] == allr[0][0] and a[1] == allr[0][1] and a[4] == allr[0][4] for a in allr)
     out["stopped"] = [a[2] for a in allr]
     out["flags"] = [a[3] for a in allr]
     json.dump(out, open(sys.argv[1], "w"))
@@ -74,3 +87,7 @@ def test_two_process_sharded_ba_on_one_gpu(tmp_path):
     assert out["dpose"] < 1e-9 and out["dpts"] < 1e-9 and out["dposeg"] < 1e-7
     assert out["itersg"][0] == out["itersg"][1] and out["pcg"] == 0   # the global solve takes the envelope Cholesky on every rank
     assert out["stopped"] == [7, 7] and out["flags"] == [1, 1]   # SVGPU_STOPPED on both ranks, the flag propagated to rank 0's caller
+    # keyframe-segment shards: recognised, equal to the single-rank solve, a fraction of the l % N exchange
+    assert out["rck"] == 0 and out["modes"] == ["keyframe segments", "whole reduced system"], out
+    assert out["dposek"] < 1e-7 and out["dptsk"] < 1e-7 and out["trialsk"][0] == out["trialsk"][1], out
+    assert out["system_bytes"][0] * 4 < out["system_bytes"][1], out
