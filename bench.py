@@ -358,6 +358,12 @@ def roofline_entries(fe, src_hash, B, world):
             entry["all_pairs_context"] = {"ops_per_launch": int(allpairs), "achieved": round(allpairs / (mean_ms * 1e-3) / 1e12, 2),
                                           "frac": round(allpairs / (mean_ms * 1e-3) / 1e12 / p_, 5),
                                           "note": "2 x 256 x N1 x N2 per pair = the work of robust.cc:271-314 if every pair were multiplied"}
+        vi = entry["valu_issue"]
+        if b_ == "hbm" and vi is not None and vi["frac"] >= 0.5 and vi["frac"] > entry["frac"]:
+            # the kernel is bound by VALU issue, not by bytes: the issue fraction (VALU wave-instructions x 4 cycles over the SIMD-cycles of the
+            # launch, from the committed PMC pass) is the primary figure; the byte fraction stays as context
+            entry["hbm_context"] = {"achieved": entry["achieved"], "unit": entry["unit"], "peak": entry["peak"], "frac": entry["frac"]}
+            entry.update({"bound": "valu", "unit": "VALU issue slots", "peak": 1.0, "achieved": vi["frac"], "frac": vi["frac"]})
         if lds_json is not None and name in lds_json["kernels"]:
             lk = lds_json["kernels"][name]
             entry["lds_util"], entry["lds_bank_conflict_frac"] = lk["lds_util"], lk["lds_bank_conflict_frac"]

@@ -7,7 +7,8 @@ from stella_vslam_amd import optimize, synthetic
 n = 5
 out = {}
 sc = synthetic.ba_scene()
-for name, solver in (("pcg_lds", optimize.SOLVER_AUTO), ("cholesky", optimize.SOLVER_CHOLESKY), ("pcg_multi", optimize.SOLVER_PCG_MULTI)):
+for name, solver in (("auto", optimize.SOLVER_AUTO), ("cholesky", optimize.SOLVER_CHOLESKY), ("cholesky_mfma", optimize.SOLVER_CHOLESKY_MFMA),
+                     ("pcg", optimize.SOLVER_PCG), ("pcg_multi", optimize.SOLVER_PCG_MULTI)):
     ba = optimize.local_bundle_adjuster().set_solver(solver)
     ba.optimize_flat(sc)
     t0 = time.perf_counter()
@@ -18,7 +19,7 @@ for name, solver in (("pcg_lds", optimize.SOLVER_AUTO), ("cholesky", optimize.SO
     print("local", name, "ms/call", dt * 1e3, r["stats"], flush=True)
 if "--global" in sys.argv:
     sg = synthetic.ba_scene_large()
-    for name, solver in (("pcg", optimize.SOLVER_AUTO),) + ((("dense", optimize.SOLVER_DENSE),) if "--dense" in sys.argv else ()):
+    for name, solver in (("auto", optimize.SOLVER_AUTO),) + ((("dense", optimize.SOLVER_DENSE),) if "--dense" in sys.argv else ()):
         ba = optimize.local_bundle_adjuster().set_solver(solver)
         ba.optimize_global_flat(sg, num_iter=10)
         t0 = time.perf_counter()

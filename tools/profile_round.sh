@@ -4,7 +4,7 @@
 #   guide prescribes), the VALU busy-cycle pass, kernel stats of the two bundle adjusters, then the bench line itself (which now
 #   finds traffic / valu_issue files stamped with the hash of the sources it runs).  usage: tools/profile_round.sh r02
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -21,19 +21,26 @@ timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc_act -o
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_lds.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_local -o k --output-format csv -- python $R/tools/ba_prof.py local > /dev/null 2> $OUT/ba_local.log
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ba_global -o k --output-format csv -- python $R/tools/ba_prof.py global > /dev/null 2> $OUT/ba_global.log
-# launches per tracked frame through the drop-in classes: two traces that differ by 20 frames
+# launches per tracked frame through the drop-in chain (mode 2: svgpu_track_motion + svgpu_track_local_map): two traces that differ by 20 frames;
+# runtime copies count as launches (memory-copy trace)
 for n in 10 30; do
-  timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/tf_$n -o k --output-format csv -- python $R/tools/tracked_frame_prof.py $n 1 > /dev/null 2> $OUT/tf_$n.log
+  timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT/tf_$n -o k --output-format csv -- python $R/tools/tracked_frame_prof.py $n 2 > /dev/null 2> $OUT/tf_$n.log
 done
 cd $R
 python - <<PYEOF > $OUT/tracked_frame_launches.json
-import csv, json
-def calls(n):
-    rows = list(csv.DictReader(open("$OUT/tf_%d/k_kernel_stats.csv" % n)))
-    return {r["Name"]: int(r["Calls"]) for r in rows}
-a, b = calls(10), calls(30)
-per = {k.replace("(anonymous namespace)::", "").split("(")[0]: (b.get(k, 0) - a.get(k, 0)) / 20.0 for k in b if b.get(k, 0) != a.get(k, 0)}
-print(json.dumps({"what": "kernel launches (and runtime copy / fill kernels) per tracked frame through the drop-in classes, resident frames: difference of two rocprofv3 kernel traces 20 frames apart", "launches_per_frame": round(sum(per.values()), 2), "by_kernel": per}, indent=1))
+import csv, json, os
+def calls(n, what):
+    f = "$OUT/tf_%d/k_%s_stats.csv" % (n, what)
+    if not os.path.exists(f):
+        return {}
+    return {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(f))}
+def per_frame(what):
+    a, b = calls(10, what), calls(30, what)
+    return {k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]: (b.get(k, 0) - a.get(k, 0)) / 20.0 for k in b if b.get(k, 0) != a.get(k, 0)}
+k, c = per_frame("kernel"), per_frame("memory_copy")
+print(json.dumps({"what": "kernel launches and runtime copies per tracked frame through the drop-in chain (tracked_frame_chain: one submission per half of tracking_module's per-frame chain): difference of two rocprofv3 traces 20 frames apart",
+                  "launches_per_frame": round(sum(k.values()) + sum(c.values()), 2), "kernels_per_frame": round(sum(k.values()), 2), "copies_per_frame": round(sum(c.values()), 2),
+                  "host_syncs_per_frame": 2, "by_kernel": k, "by_copy": c}, indent=1))
 PYEOF
 cp $OUT/tracked_frame_launches.json profiles/${TAG}_tracked_frame_launches.json
 python tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w profiles/${TAG}_traffic.json 256 > /dev/null
