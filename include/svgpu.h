@@ -728,10 +728,11 @@ int svgpu_global_ba(svgpu_ctx* ctx, const svgpu_ba_problem* problem, volatile ui
                     double* points_out, svgpu_ba_stats* stats);
 
 /* Multi-GPU variant.  Every rank passes the FULL pose / point arrays and ITS SHARD of the observations; the shard
- * must be BY LANDMARK (all observations of one landmark on one rank, e.g. obs_point % world == rank) so that the
- * Schur complement of a landmark is formed locally.  Per damping trial the kept 6x6 blocks of the partial reduced camera
- * systems and their right-hand sides (36 * blocks + 6 * free poses doubles) are summed with ONE all-reduce and solved
- * redundantly on every rank; per linearisation the pose blocks Hpp/bp (42 doubles per free pose) and per trial four scalars
+ * must be BY LANDMARK (all observations of one landmark on one rank) so that the Schur complement of a landmark is formed
+ * locally: either by keyframe segment (svgpu_ba_partition_keyframe_segments below: per damping trial only the separator blocks of the
+ * reduced system cross ranks) or any other way, e.g. obs_point % world == rank -- then, per damping trial, the kept 6x6 blocks of the
+ * partial reduced camera systems and their right-hand sides (36 * blocks + 6 * free poses doubles) are summed with ONE all-reduce.  The
+ * factorisation of a large reduced system is distributed over the ranks (segmented envelope elimination), small ones are solved on every rank; per linearisation the pose blocks Hpp/bp (42 doubles per free pose) and per trial four scalars
  * (chi2, step scale, solver failure, stop votes) are summed as well.  All collectives are enqueued on the context's stream:
  * the damping loop never waits for the host.
  *   allreduce == NULL   the context's own RCCL communicator is used (svgpu_comm_init below: no Python, no callback)
