@@ -19,6 +19,8 @@ struct BaCtl {
     int stopped_by_terminate;
     int lm_trials, solve_failures, solve_failed;
     int pcg_done, pcg_fail, pcg_it, pcg_max_it, pcg_total_it, pcg_solves;
+    int gated;              // edges the gate excluded (k_ba_activity)
+    int structure_changed;  // k_ba_activity: a free pose lost its last active edge -- the pose numbering of the reduced system has to be rebuilt on the host
     int pad1;
 };
 
@@ -169,6 +171,7 @@ void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, in
 void sv_ba_gate(hipStream_t s, const BaDev& D, int set_levels, uint8_t* outlier_out);
 void sv_ba_pack_out(hipStream_t s, const BaDev& D, double* out);  // poses | points of the current estimate, contiguous
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale);   // this rank's partial sums -> 4 doubles (sharded solve)
+void sv_ba_activity(hipStream_t s, const BaDev& D, uint8_t* pt_free);               // after the gate: landmark activity, gated count, "pose numbering changed" on the device
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in);       // start of SparseOptimizer::optimize(it_max)
 void sv_ba_prepare(hipStream_t s, const BaDev& D);                              // lambda init (iteration 0) + start of a trial
 void sv_ba_decide(hipStream_t s, const BaDev& D);

@@ -2070,6 +2070,41 @@ __global__ __launch_bounds__(256) void k_ba_zero_inactive(BaDev D) {
     for (int k = 0; k < 9; ++k) Wd[k] = z;
 }
 
+// The stage boundary of the two-stage schedule without the host (local_bundle_adjuster_g2o.cc:323-344 leaves edge levels behind; what the
+// second stage needs of them): workgroups [0, nb) take 256 landmarks each -- a landmark stays a free vertex while it keeps an active edge,
+// the excluded edges are counted --, workgroups [nb, nb + P) one pose each -- a free pose that lost its last active edge would renumber the
+// reduced system: flagged, and the stage enqueued behind refuses to start (k_ba_begin) so that the host can rebuild the structure.
+__global__ __launch_bounds__(256) void k_ba_activity(BaDev D, uint8_t* __restrict__ pt_free, int nb) {
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if ((int)blockIdx.x < nb) {
+        const int l = blockIdx.x * 256 + threadIdx.x;
+        int gated = 0;
+        if (l < D.L) {
+            bool any = false;
+            for (int e = D.lm_off[l]; e < D.lm_off[l + 1]; ++e) {
+                const int lv = D.e_level[e];
+                any = any || !lv;
+                gated += lv != 0;
+            }
+            if (!any) pt_free[l] = 0;
+        }
+        if (gated) atomicAdd(&s_cnt, gated);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) atomicAdd(&D.ctl->gated, s_cnt);
+    }
+    else {
+        const int p = blockIdx.x - nb;
+        if (D.pose_slot[p] < 0) return;
+        int any = 0;
+        for (int k = D.pe_off[p] + threadIdx.x; k < D.pe_off[p + 1] && !any; k += 256) any = !D.e_level[D.pe_idx[k]];
+        if (any) s_cnt = 1;  // (benign race: every writer stores 1)
+        __syncthreads();
+        if (threadIdx.x == 0 && !s_cnt) D.ctl->structure_changed = 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LM control on the device
 // fixed-order sum of n doubles by one 256-thread workgroup (strided partial sums, shuffle tree, wave partials in wave order)
 // (PEEK: the values were written by OTHER workgroups of the running kernel -- read them past this CU's L1)
@@ -2101,7 +2136,7 @@ __global__ __launch_bounds__(256) void k_ba_fold(BaDev D, double* __restrict__ o
 __global__ __launch_bounds__(256) void k_ba_begin(BaDev D, int it_max, int stop_in) {
     __shared__ double sw[16];
     double chi = 0.0;
-    int stop = stop_in;
+    int stop = stop_in & 1;
     if (D.xsum) {
         chi = D.xsum[0];
         stop |= D.xsum[3] > 0.5;
@@ -2112,6 +2147,10 @@ __global__ __launch_bounds__(256) void k_ba_begin(BaDev D, int it_max, int stop_
     }
     if (threadIdx.x == 0) {
         BaCtl& c = *D.ctl;
+        if ((stop_in & 2) && c.structure_changed) {  // a stage enqueued behind k_ba_activity: the host has to rebuild the structure first
+            c.phase = 2;
+            return;
+        }
         c.current_chi = c.chi_begin = chi;
         c.it = 0;
         c.it_max = it_max;
@@ -2494,6 +2533,10 @@ void sv_ba_points_share(hipStream_t s, const BaDev& D, double* points_out, doubl
 void sv_ba_xs_move(hipStream_t s, const BaDev& D, const int* blk_idx, int nb, const int* slot_idx, int ns, double* buf, int dir) {
     const int items = nb * 36 + ns * 6;
     if (items > 0) hipLaunchKernelGGL(k_ba_xs_move, dim3((items + 255) / 256), dim3(256), 0, s, D, blk_idx, nb, slot_idx, ns, buf, dir);
+}
+void sv_ba_activity(hipStream_t s, const BaDev& D, uint8_t* pt_free) {
+    const int nb = (D.L + 255) / 256;
+    hipLaunchKernelGGL(k_ba_activity, dim3(nb + D.P), dim3(256), 0, s, D, pt_free, nb);
 }
 void sv_ba_begin(hipStream_t s, const BaDev& D, int it_max, int stop_in) { hipLaunchKernelGGL(k_ba_begin, dim3(1), dim3(256), 0, s, D, it_max, stop_in); }
 void sv_ba_prepare(hipStream_t s, const BaDev& D) { hipLaunchKernelGGL(k_ba_prepare, dim3(1), dim3(1), 0, s, D); }

@@ -493,6 +493,34 @@ def test_global_ba_segmented_elimination_equals_one_sided(monkeypatch, cuts):
         assert np.abs(seg["pose_cw"] - one["pose_cw"]).max() < 1e-8 and np.abs(seg["points"] - one["points"]).max() < 1e-8, plan
 
 
+def test_stage_boundary_on_the_device_equals_the_host_boundary(monkeypatch):
+    """The gate -> second stage hand-over without the host (k_ba_activity + the guarded k_ba_begin) against the host-side boundary
+    (SVGPU_BA_HOST_BOUNDARY): same bits, same schedule, same gated count -- on the plain config-3 shaped window, and on one in which a free
+    keyframe loses EVERY observation at the gate, so that the pose numbering changes and the enqueued stage must refuse to start and hand
+    back to the host path."""
+    from stella_vslam_amd import optimize
+    adj = optimize.local_bundle_adjuster()
+    plain = S.ba_scene(num_kf=14, num_lm=3000, obs_per_lm=5, num_fixed=3, seed=77)
+    broken = dict(plain)
+    uvr = np.array(plain["obs_uvr"], np.float32, copy=True)
+    victim = int(np.flatnonzero(np.asarray(plain["pose_fixed"]) == 0)[2])
+    hit = np.asarray(plain["obs_pose"]) == victim
+    rng = np.random.default_rng(5)
+    uvr[hit, :2] += rng.choice([-1.0, 1.0], (int(hit.sum()), 2)).astype(np.float32) * rng.uniform(60, 90, (int(hit.sum()), 2)).astype(np.float32)
+    broken["obs_uvr"] = uvr
+    for sc, expect_all_gated in ((plain, False), (broken, True)):
+        monkeypatch.delenv("SVGPU_BA_HOST_BOUNDARY", raising=False)
+        dev = adj.optimize_flat(sc)
+        monkeypatch.setenv("SVGPU_BA_HOST_BOUNDARY", "1")
+        host = adj.optimize_flat(sc)
+        assert dev["rc"] == 0 and host["rc"] == 0
+        assert dev["stats"] == host["stats"], (dev["stats"], host["stats"])
+        assert np.array_equal(dev["pose_cw"], host["pose_cw"]) and np.array_equal(dev["points"], host["points"]) and np.array_equal(dev["outlier"], host["outlier"])
+        assert dev["stats"]["stage2_entered"] == 1 and dev["stats"]["num_gated"] > 0
+        if expect_all_gated:  # every observation of the keyframe is an outlier in the end: it did drop out of the second stage
+            assert dev["outlier"][hit].all()
+
+
 def _simulated_ranks(world, run_rank):
     """`world` ranks as threads on the one test GPU; the all-reduce callback sums the ranks' device buffers through a barrier."""
     import threading
