@@ -5,13 +5,14 @@
 #   finds traffic / valu_issue files stamped with the hash of the sources it runs).  usage: tools/profile_round.sh r02
 set -u
 TAG=${1:-r04}
+BATCH=${BATCH:-1024}   # frames per launch of the headline legs (bench.py's default batch)
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 exec < /dev/null
 HEAD="--steps 3 --warmup 1 --no-ba --no-cpu-baseline --no-extra"
-# headline legs only: every launch of a front-end / matcher kernel in this trace is a 256-frame launch, so the averages of the stats file
+# headline legs only: every launch of a front-end / matcher kernel in this trace is a $BATCH-frame launch, so the averages of the stats file
 # are the per-launch durations the bench line quotes
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks -o k --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-ba > $OUT/bench_under_rocprof.json 2> $OUT/ks.log
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_f.log
@@ -48,9 +49,9 @@ print(json.dumps({"what": "kernel launches and runtime copies per tracked frame 
                   "host_syncs_per_frame": "2 (counted by the tracker itself: svgpu_tracker_counters, printed in the bench line as tracked_frame.chain.host_syncs)", "by_kernel": k, "by_copy": c}, indent=1))
 PYEOF
 cp $OUT/tracked_frame_launches.json profiles/${TAG}_tracked_frame_launches.json
-python tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w profiles/${TAG}_traffic.json 256 > /dev/null
-python tools/pmc_valu.py $OUT/pmc_gi profiles/${TAG}_valu_issue.json 256 $OUT/pmc_act > /dev/null
-python tools/pmc_lds_mfma.py $OUT/pmc_lds profiles/${TAG}_lds_mfma.json 256 > $OUT/lds_mfma.log 2>&1
+python tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w profiles/${TAG}_traffic.json $BATCH > /dev/null
+python tools/pmc_valu.py $OUT/pmc_gi profiles/${TAG}_valu_issue.json $BATCH $OUT/pmc_act > /dev/null
+python tools/pmc_lds_mfma.py $OUT/pmc_lds profiles/${TAG}_lds_mfma.json $BATCH > $OUT/lds_mfma.log 2>&1
 cp profiles/${TAG}_traffic.json profiles/${TAG}_valu_issue.json profiles/${TAG}_lds_mfma.json $OUT/
 timeout 400 python bench.py 2> $OUT/bench.log < /dev/null | tail -1 > $OUT/bench.json
 timeout 300 python tools/ba_bench.py --global > $OUT/ba_bench.log 2>&1 < /dev/null
