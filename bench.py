@@ -142,8 +142,9 @@ def main() -> int:
                                "offline), ORB extract + brute-force match vs previous frame",
                    "frames_per_gpu_per_step": B, "keypoints_per_frame": round(fe["n_kp"], 1),
                    "matches_per_pair": round(fe["n_match"], 1), "parallelism": f"frames sharded x{world}, no collective; extraction and matcher on two HIP streams",
-                   "input_residency": "the same %d frames (%.0f MB) are re-read every step: they fit the 256 MB Infinity Cache, so level-0 reads need not reach HBM "
-                                      "(no kernel of the step is byte-bound; see roofline.kernels[].traffic)" % (B, B * W * H / 1e6),
+                   "input_residency": ("the same %d frames (%.0f MB) are re-read every step: %s "
+                                      "(no kernel of the step is byte-bound; see roofline.kernels[].traffic)" % (B, B * W * H / 1e6, "they fit the 256 MB Infinity Cache, so level-0 reads need not reach HBM"
+                                                                                                       if B * W * H <= 256e6 else "more than the 256 MB Infinity Cache holds, so level-0 reads do reach HBM")),
                    "per_kernel_timing": "HIP events around EVERY kernel class on its launch stream inside the timed region (svgpu_profile_select \"*\"); "
                                         "the same steps re-timed with the events off: %.4f ms per step" % fe["ms_per_step_unprofiled"]},
         "roofline": dict(dom, csrc_hash=src_hash, per_kernel_ms_per_step={k["kernel"]: round(k["mean_launch_ms"] * k["launches_per_step"], 4) for k in kernels},
