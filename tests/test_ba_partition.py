@@ -58,3 +58,40 @@ def test_small_or_unsegmented_problems_fall_back_to_modulo(monkeypatch):
     assert info["segmented"] == 0 and np.array_equal(lm_rank, np.arange(len(big["points"])) % 2)
     lm_rank, info = optimize.partition_keyframe_segments(big, 1)
     assert info["segmented"] == 0 and not lm_rank.any()
+
+
+def test_a_fixed_landmark_seen_from_two_pieces_keeps_modulo_shards(scene, monkeypatch):
+    """A fixed landmark couples no keyframes, so it may be observed from two pieces of the cut graph; its observations cannot sit on one rank
+    without feeding a foreign piece's pose blocks -- such a problem keeps the l % world shards (the solve then exchanges the whole system)."""
+    monkeypatch.setenv("SVGPU_SKY_SEGMENTS", "5")
+    sc = dict(scene)
+    P, L = len(sc["pose_cw"]), len(sc["points"])
+    pf = np.zeros(L, np.uint8)
+    pf[0] = 1
+    # two keyframes from the INSIDE of two different pieces (every observation of each on one rank, and not the same rank) observe the fixed landmark 0
+    lm_rank0, info0 = optimize.partition_keyframe_segments(scene, 4)
+    assert info0["segmented"] == 1
+    seen = np.zeros((P, 4), bool)
+    seen[np.asarray(scene["obs_pose"]), lm_rank0[np.asarray(scene["obs_point"])]] = True
+    inside = np.flatnonzero((seen.sum(1) == 1) & (np.asarray(scene["pose_fixed"]) == 0))
+    a = int(inside[seen[inside, 0]][0])
+    b = int(inside[seen[inside, 1]][0])
+    far = np.array([a, b], np.int32)
+    keep = np.asarray(sc["obs_point"]) != 0
+    sc["obs_pose"] = np.concatenate([np.asarray(sc["obs_pose"])[keep], far]).astype(np.int32)
+    sc["obs_point"] = np.concatenate([np.asarray(sc["obs_point"])[keep], np.zeros(2, np.int32)]).astype(np.int32)
+    sc["point_fixed"] = pf
+    lm_rank, info = optimize.partition_keyframe_segments(sc, 4)
+    assert info["segmented"] == 0 and np.array_equal(lm_rank, np.arange(L) % 4)
+    sc["point_fixed"] = np.zeros(L, np.uint8)           # the same landmark FREE couples the two keyframes: the graph is no longer a band the planner cuts, or it is cut elsewhere -- either way a valid partition
+    lm_rank, info = optimize.partition_keyframe_segments(sc, 4)
+    assert lm_rank.min() >= 0 and lm_rank.max() <= 3
+
+
+def test_partition_rejects_bad_indices(scene):
+    sc = dict(scene)
+    bad = np.array(sc["obs_pose"], np.int32, copy=True)
+    bad[5] = len(sc["pose_cw"])
+    sc["obs_pose"] = bad
+    with pytest.raises(RuntimeError):
+        optimize.partition_keyframe_segments(sc, 2)
