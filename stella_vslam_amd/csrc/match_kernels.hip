@@ -340,6 +340,14 @@ struct MfShared {
     uint32_t pad[SV_MF_PAD];
 #endif
 };
+// max over every DPP row of 16 lanes, left in all 16 (rotations by 8, 4, 2, 1)
+__device__ __forceinline__ uint32_t mf_row16_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));  // row_ror:8
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));  // row_ror:4
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false));  // row_ror:2
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false));  // row_ror:1
+    return v;
+}
 // Drain the wave's hit queue into its rows.  Called by all 64 lanes of the wave.
 __device__ __forceinline__ void mf_drain(MfShared& S, int wave, int lane, int n, bool ori) {
     for (int e0 = 0; e0 < n; e0 += 64) {
@@ -363,32 +371,20 @@ __device__ __forceinline__ void mf_drain(MfShared& S, int wave, int lane, int n,
         while (ov) {
             const int src = __ffsll((long long)ov) - 1;
             ov &= ov - 1;
-            const uint32_t k = __shfl(key, src, 64);
-            const int row = __shfl(ql, src, 64);
+            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, src);  // (src is wave-uniform: a scalar read, not an LDS shuffle)
+            const int row = __builtin_amdgcn_readlane(ql, src);
             uint32_t* R = S.list[row];
             if (k >= S.rowmax[row]) continue;  // an earlier entry of this batch lowered the maximum
-            uint32_t v = lane < MF_SLOTS ? R[lane] : 0u;
-            int arg = lane;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
-                const uint32_t ovv = __shfl_xor(v, off, 64);
-                const int oa = __shfl_xor(arg, off, 64);
-                if (ovv > v || (ovv == v && oa < arg)) {
-                    v = ovv;
-                    arg = oa;
-                }
-            }
-            v = __shfl(v, 0, 64);
-            arg = __shfl(arg, 0, 64);
+            // the row's maximum and where it sits, on DPP row rotations (the 16 slots are the 16 lanes of DPP row 0; keys of a row are
+            // distinct -- they carry distinct target indices -- so the maximum has one owner): four VALU moves instead of the ten
+            // ds_bpermute round trips of a shuffle tree
+            const uint32_t v = lane < MF_SLOTS ? R[lane] : 0u;
+            const uint32_t vmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)mf_row16_max(v));
+            const int arg = __ffsll((long long)__ballot(lane < MF_SLOTS && v == vmax)) - 1;
             // replace the maximum, then the new maximum of the row = max(k, largest of the other slots)
-            uint32_t w = (lane < MF_SLOTS && lane != arg) ? R[lane] : 0u;
-            if (k < v) {
-                if (lane == 0) R[arg] = k;
-                w = lane == arg ? k : w;
-            }
-            else w = lane == arg ? v : w;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) w = max(w, (uint32_t)__shfl_xor(w, off, 64));
+            uint32_t w = lane == arg ? min(k, vmax) : v;
+            if (k < vmax && lane == 0) R[arg] = k;
+            w = mf_row16_max(w);
             if (lane == 0) S.rowmax[row] = w;
         }
     }
