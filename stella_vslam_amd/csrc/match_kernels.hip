@@ -474,16 +474,19 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
         const bool hit = dot >= thr;
         const unsigned long long m = __ballot(hit);
         if (m) {
-            if (wq_n > MF_WQ - 64) {  // a register adds at most one entry per lane
-                mf_drain(S, wave, lane, wq_n, ori);
-                wq_n = 0;
+            // (the queue fill is wave-uniform; said explicitly, the capacity test and the slot address stay on the scalar unit -- the compiler
+            //  had parked the counter in a vector register and guarded the drain with an exec mask)
+            int wq = __builtin_amdgcn_readfirstlane(wq_n);
+            if (wq > MF_WQ - 64) {  // a register adds at most one entry per lane
+                mf_drain(S, wave, lane, wq, ori);
+                wq = 0;
             }
             if (hit) {
                 const int pq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const uint32_t row = (uint32_t)(32 * a + (r & 3) + 8 * (r >> 2)) << 24;
-                S.wq[wave][wq_n + pq] = make_uint2(ti + row + ((uint32_t)(-dot) << 16), ta);
+                S.wq[wave][wq + pq] = make_uint2(ti + row + ((uint32_t)(-dot) << 16), ta);
             }
-            wq_n += __popcll(m);
+            wq_n = wq + __popcll(m);
         }
     };
     // a whole half (16 registers = 32 rows x 32 targets) without a hit -- the common case -- costs eight three-way maxima, one compare
