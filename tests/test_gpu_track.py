@@ -41,14 +41,57 @@ def _pose12(R, t):
     return np.concatenate([np.asarray(R, np.float64).reshape(3, 3), np.asarray(t, np.float64).reshape(3, 1)], 1).reshape(12)
 
 
+FISHEYE = dict(fx=190.978, fy=190.973, cx=254.93, cy=256.90, k=(0.0034823894, 0.0007150348, -0.0020532361, 0.0002029367), cols=512, rows=512)  # TUM-VI-like
+
+
+def _other_cams(sc, model, ctx):
+    from stella_vslam_amd import camera
+    if model == "equirectangular":
+        return (camera.equirectangular("theta", "Gray", sc["width"], sc["height"], 30.0, ctx=ctx), O.make_camera(O.CAM_EQUIRECTANGULAR, sc["width"], sc["height"]))
+    F = FISHEYE
+    return (camera.fisheye("f", "Monocular", "Gray", F["cols"], F["rows"], 30.0, F["fx"], F["fy"], F["cx"], F["cy"], *F["k"], ctx=ctx),
+            O.make_camera(O.CAM_FISHEYE, F["cols"], F["rows"], F["fx"], F["fy"], F["cx"], F["cy"], F["k"]))
+
+
+def _reproject_scene(sc, model, seed):
+    """map_scene's two views seen through another camera model: the keypoints of the landmarks move to that model's projection of the
+    landmark (+ the same pixel noise), the clutter is spread over its image.  The projection is the ORACLE's own (can_observe's reprojection
+    with every gate opened), so the scene is consistent with the checker by construction; keypoints are stored UNDISTORTED, as frames hold them."""
+    rng = np.random.default_rng(1000 + seed)
+    if model == "equirectangular":
+        sc["width"], sc["height"] = 1920, 960
+    else:
+        sc["width"], sc["height"] = FISHEYE["cols"], FISHEYE["rows"]
+    ocam = (O.make_camera(O.CAM_EQUIRECTANGULAR, 1920, 960) if model == "equirectangular" else
+            O.make_camera(O.CAM_FISHEYE, FISHEYE["cols"], FISHEYE["rows"], FISHEYE["fx"], FISHEYE["fy"], FISHEYE["cx"], FISHEYE["cy"], FISHEYE["k"]))
+    L = sc["landmarks"]
+    for v in sc["views"]:
+        has = v["lm"] >= 0
+        idx = np.where(has, v["lm"], 0)
+        n = len(idx)
+        # every gate of can_observe opened: normals towards the camera, an unbounded distance range
+        normal = L["pos_w"][idx] - v["center"]
+        normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+        vis, rp, _, _ = O.can_observe(ocam, v["rot_cw"], v["trans_cw"], L["pos_w"][idx], normal, np.full(n, 1e-3, np.float32), np.full(n, 1e9, np.float32), -1.0, 8,
+                                      float(sc["tables"]["log_scale_factor"]))
+        ok = has & (vis == 1)
+        noise = rng.normal(0, 1.0, (n, 2)) * sc["tables"]["scale_factors"][v["octave"]][:, None]
+        xy = np.where(ok[:, None], rp + noise, np.stack([rng.uniform(ocam.min_x + 2, ocam.max_x - 2, n), rng.uniform(ocam.min_y + 2, ocam.max_y - 2, n)], 1))
+        v["xy"] = np.ascontiguousarray(xy, np.float32)
+        v["lm"] = np.where(ok, v["lm"], -1)
+
+
 class _World:
     """map_scene + a landmark table whose ids are NOT the scene's indices (id = 3 * index + 5), with a few landmarks erased, a few
     without descriptor and a few without observations -- the three flags the chain's gates read."""
 
-    def __init__(self, ctx, seed, stereo, n_lm=1500, n_extra=600):
+    def __init__(self, ctx, seed, stereo, n_lm=1500, n_extra=600, model="perspective"):
         from stella_vslam_amd import data, tracking
         self.sc = sc = MP.scene(seed=seed, stereo=stereo, n_lm=n_lm, n_extra=n_extra)
         self.stereo = stereo
+        self.model = model
+        if model != "perspective":
+            _reproject_scene(sc, model, seed)
         L = sc["landmarks"]
         n = len(L["pos_w"])
         rng = np.random.default_rng(100 + seed)
@@ -62,8 +105,7 @@ class _World:
         self.flags = flags
         self.rec = tracking.landmark_records(L["pos_w"], L["mean_normal"], L["min_valid_dist"], L["max_valid_dist"], L["desc"], flags)
         self.table = tracking.landmark_table(ctx).upsert(self.ids, self.rec)
-        self.cam = MP.make_cams(sc, "svgpu")
-        self.ocam = MP.make_cams(sc, "oracle")
+        self.cam, self.ocam = (MP.make_cams(sc, "svgpu"), MP.make_cams(sc, "oracle")) if model == "perspective" else _other_cams(sc, model, ctx)
         last, cur = sc["views"]
         self.last, self.cur = last, cur
         self.rf_last = data.resident_frame(ctx).upload(self.cam, _records(last), last["desc"], last["x_right"] if stereo else None)
@@ -79,6 +121,10 @@ class _World:
         self.pose_last = _pose12(last["rot_cw"], last["trans_cw"])
         fx, fy, cx, cy, fxb = sc["K"]
         self.intr = np.array([fx, fy, cx, cy, fxb], np.float64)
+        if model == "equirectangular":   # the row that selects the equirectangular edges (include/svgpu.h)
+            self.intr = np.array([0.0, 0.0, sc["width"], sc["height"], 0.0])
+        elif model == "fisheye":          # pinhole on the undistorted keypoints, with the fisheye camera's own intrinsics
+            self.intr = np.array([FISHEYE["fx"], FISHEYE["fy"], FISHEYE["cx"], FISHEYE["cy"], 0.0])
 
     # ---- the table as the oracle / the flattened path sees it
     def lookup(self, ids):
@@ -225,6 +271,34 @@ def test_local_map_chain_equals_oracle_and_flattened_path(ctx, stereo, margin, s
     pr = exp["pr"]
     nv, pose, outl, iters = optimize.pose_optimizer(ctx=ctx).optimize_flat(pose1, pr["pos_w"], pr["uvr"], pr["inv_sigma_sq"], pr["huber"], W.intr)
     assert nv == r["num_valid"] and iters == r["lm_iterations"] and np.array_equal(pose, r["pose_cw"]) and np.array_equal(outl, got["outlier"][exp["keep"]])
+
+
+@pytest.mark.parametrize("model,seed", [("equirectangular", 11), ("fisheye", 12)])
+def test_chain_on_the_other_camera_models(ctx, model, seed):
+    """Both halves of the chain through the equirectangular and the fisheye model (camera/equirectangular.cc, camera/fisheye.cc;
+    equirectangular_pose_opt_edge.h for the optimiser's edges): the same device functions as the per-call kernels, but k_track_cand's and
+    k_pose_opt<EQ, TRK>'s own instantiations.  Matches and verdicts bit-identical to the oracle, poses to the tolerance of the optimiser tests."""
+    W = _World(ctx, seed, False, model=model)
+    assert (W.last["lm"] >= 0).sum() > 400 and (W.cur["lm"] >= 0).sum() > 400
+    margin = 20.0
+    exp = _oracle_motion(W, margin)
+    got = W.tracker.track_motion(W.rf_cur, W.rf_last, W.last_ids, W.guess, W.pose_last, margin)
+    r = got["result"]
+    assert exp["num"] > 200 and r["num_matches"] == exp["num"] and np.array_equal(got["match_last"], exp["match"])
+    assert r["num_observations"] == exp["n_obs"] and r["num_valid"] == exp["nv"] and r["lm_iterations"] == exp["iters"]
+    assert np.array_equal(got["outlier"], exp["outlier"]) and _rel(r["pose_cw"], exp["pose"]) < TOL
+    cur_lm = np.where(got["outlier"] == 1, -1, exp["cur_lm"]).astype(np.int32)
+    rng = np.random.default_rng(seed)
+    held = set(cur_lm[cur_lm >= 0].tolist())
+    local_ids = np.array([i for i in W.ids[rng.permutation(len(W.ids))] if int(i) not in held], np.int32)
+    pose1 = r["pose_cw"]
+    exp2 = _oracle_local(W, cur_lm, local_ids, pose1, 5.0, 0.8)
+    got2 = W.tracker.track_local_map(W.rf_cur, cur_lm, local_ids, 5.0, 0.8, 0.5)
+    r2 = got2["result"]
+    assert np.array_equal(got2["visible"], exp2["vis"]) and exp2["vis"].sum() > 50
+    assert exp2["num"] > 20 and r2["num_matches"] == exp2["num"] and np.array_equal(got2["match_local"], exp2["match"])
+    assert r2["num_valid"] == exp2["nv"] and r2["lm_iterations"] == exp2["iters"] and np.array_equal(got2["outlier"], exp2["outlier"])
+    assert _rel(r2["pose_cw"], exp2["pose"]) < TOL
 
 
 def test_candidate_lists_beyond_the_first_capacity(ctx):
