@@ -301,6 +301,51 @@ def test_chain_on_the_other_camera_models(ctx, model, seed):
     assert _rel(r2["pose_cw"], exp2["pose"]) < TOL
 
 
+def test_table_written_by_the_mapping_thread_while_the_tracking_thread_reads(ctx):
+    """The mapping thread refreshes landmarks (BA write-backs, new landmarks: the table GROWS, i.e. moves) on its own context while the
+    tracking thread runs the chain on another: svgpu_map orders the two streams (ev_write / ev_read, a growth waits for the readers).
+    200 tracked frames against 200 concurrent upserts with a reallocation every tenth: every frame returns the bits of the quiet run."""
+    import threading
+    from stella_vslam_amd import feature, tracking
+    W = _World(ctx, 3, False)
+    quiet = W.tracker.track_motion(W.rf_cur, W.rf_last, W.last_ids, W.guess, W.pose_last, 20.0)
+    cur_lm = np.where(quiet["outlier"] == 1, -1, _oracle_motion(W, 20.0)["cur_lm"]).astype(np.int32)
+    local_ids = np.array([i for i in W.ids if int(i) not in set(cur_lm[cur_lm >= 0].tolist())], np.int32)
+    quiet2 = W.tracker.track_local_map(W.rf_cur, cur_lm, local_ids, 5.0, 0.8, 0.5)
+    ctx2 = feature.Context()
+    stop, err = threading.Event(), []
+    far = tracking.landmark_records(np.full((1, 3), 1e6), np.array([[0.0, 0.0, 1.0]]), np.array([1.0], np.float32), np.array([2.0], np.float32), np.zeros((1, 32), np.uint8))
+
+    def writer():
+        try:
+            k, cap = 0, W.table.capacity
+            while not stop.is_set():
+                W.table.upsert(W.ids, W.rec, ctx=ctx2)                       # the same records again: a write-back that changes nothing
+                k += 1
+                if k % 10 == 0:                                              # a new landmark far behind the cameras, beyond the capacity: the table moves
+                    cap = max(cap, W.table.capacity) * 2
+                    if cap < (1 << 22):
+                        W.table.upsert(np.array([cap + 7], np.uint32), far, ctx=ctx2)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    th = threading.Thread(target=writer)
+    th.start()
+    try:
+        for _ in range(200):
+            a = W.tracker.track_motion(W.rf_cur, W.rf_last, W.last_ids, W.guess, W.pose_last, 20.0)
+            assert np.array_equal(a["match_last"], quiet["match_last"]) and np.array_equal(a["outlier"], quiet["outlier"])
+            assert np.array_equal(a["result"]["pose_cw"], quiet["result"]["pose_cw"])
+            b = W.tracker.track_local_map(W.rf_cur, cur_lm, local_ids, 5.0, 0.8, 0.5)
+            assert np.array_equal(b["match_local"], quiet2["match_local"]) and np.array_equal(b["visible"], quiet2["visible"])
+            assert np.array_equal(b["result"]["pose_cw"], quiet2["result"]["pose_cw"])
+    finally:
+        stop.set()
+        th.join(timeout=60)
+    assert not err, err
+    assert W.table.capacity > len(W.ids) * 3     # it did move while the frames ran
+
+
 def test_candidate_lists_beyond_the_first_capacity(ctx):
     """more list entries than the tracker's initial capacity (65 536): the chain notices on the device, the host grows and re-runs"""
     W = _World(ctx, 8, False, n_lm=6000, n_extra=2000)
