@@ -164,57 +164,23 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid(const OrbLevel* __restr
     }
 }
 
-// LDS-resident variant (the one normally launched): level 1 is computed straight from the caller's image in global
-// memory; every further level is computed from the previous level's rows in LDS, and each level row is stored to
-// global memory once by the band that owns it, so the chained levels wait on LDS latency instead of on global round
-// trips.  A thread produces 4 adjacent output pixels.  Per source row it reads two 8-byte windows (dword aligned,
-// positions from the packed column-group record built on the host), lifts each (S[sx], S[sx+1]) byte pair into two
-// 16-bit halves with one v_perm_b32 and forms S[sx]*a0 + S[sx+1]*a1 with one v_dot2_u32_u16.
-// LDS map (dynamic): [rows of the odd levels (one region, reused)][rows of the even levels (one region, reused)], pitch = w rounded up to 4,
-// [32-byte column-group records]
-// [8-byte row records of the band's rows].  The host picks the band count so that this fits (svgpu_orb_configure).
-enum { PYR_SRC_LDS = 0, PYR_SRC_GLOBAL_WORDS = 1, PYR_SRC_GLOBAL_BYTES = 2 };
-template <int SRC>
-__device__ __forceinline__ uint32_t pyr_group(const uint8_t* __restrict__ row0, const uint8_t* __restrict__ row1, const uint4 e,
-                                              const uint2 e2, uint32_t b0, uint32_t b1, int last_word, int pw) {
-    const uint32_t coef[4] = {e.z, e.w, e2.x, e2.y};
-    const int i0 = e.x & 0xffff, i2 = e.x >> 16;
-    uint32_t w0[2][2], w1[2][2];
-    if (SRC != PYR_SRC_GLOBAL_BYTES) {
-        const uint32_t* R0 = reinterpret_cast<const uint32_t*>(row0);
-        const uint32_t* R1 = reinterpret_cast<const uint32_t*>(row1);
-        // global rows: the word after the last one of the row may lie outside the caller's buffer; it only ever
-        // carries a zero weight, so the clamped duplicate is as good
-        const int j0 = SRC == PYR_SRC_LDS ? i0 + 1 : min(i0 + 1, last_word), j2 = SRC == PYR_SRC_LDS ? i2 + 1 : min(i2 + 1, last_word);
-        w0[0][0] = R0[i0];
-        w0[0][1] = R0[j0];
-        w0[1][0] = R0[i2];
-        w0[1][1] = R0[j2];
-        w1[0][0] = R1[i0];
-        w1[0][1] = R1[j0];
-        w1[1][0] = R1[i2];
-        w1[1][1] = R1[j2];
-    }
-    uint32_t v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t k = (e.y >> (8 * i)) & 255u;
-        uint32_t q0, q1;
-        if (SRC != PYR_SRC_GLOBAL_BYTES) {
-            const uint32_t sel = 0x0c010c00u + k * 0x00010001u;  // bytes (k, zero, k + 1, zero) of the 8-byte window
-            q0 = __builtin_amdgcn_perm(w0[i >> 1][1], w0[i >> 1][0], sel);
-            q1 = __builtin_amdgcn_perm(w1[i >> 1][1], w1[i >> 1][0], sel);
-        }
-        else {
-            const int sx = 4 * (i < 2 ? i0 : i2) + (int)k, sx1 = min(sx + 1, pw - 1);
-            q0 = (uint32_t)row0[sx] | ((uint32_t)row0[sx1] << 16);
-            q1 = (uint32_t)row1[sx] | ((uint32_t)row1[sx1] << 16);
-        }
-        const uint32_t r0 = __builtin_amdgcn_udot2(as_u16x2(q0), as_u16x2(coef[i]), 0u, false);
-        const uint32_t r1 = __builtin_amdgcn_udot2(as_u16x2(q1), as_u16x2(coef[i]), 0u, false);
-        v[i] = ((__umul24(b0, r0 >> 4) >> 16) + (__umul24(b1, r1 >> 4) >> 16) + 2u) >> 2;  // 2048 * 32640 < 2^32, factors < 2^24
-    }
-    return (v[0] & 255u) | ((v[1] & 255u) << 8) | ((v[2] & 255u) << 16) | (v[3] << 24);
+// LDS-resident variant (the one normally launched).  A workgroup owns a horizontal band of one frame through ALL levels, entirely in LDS:
+//   * the band's level-0 rows (with the halo its level-1 rows read) are staged into LDS with wide coalesced loads;
+//   * level l is computed from level l - 1 in LDS and stored to global memory once, by the band that owns the row;
+//   * a thread owns ONE column group (4 adjacent output pixels) and WALKS a chunk of consecutive output rows downwards.  cv::resize's
+//     bilinear kernel is separable -- H(s) = S[s][sx] * a0 + S[s][sx + 1] * a1 per source row s, then the vertical blend of H(sy) and
+//     H(sy + 1) -- and consecutive output rows share a source row five times out of six at the 1 / 1.2 step, so the walk keeps H(sy + 1)
+//     in registers and forms ~1.3 instead of 2 horizontal rows per output row; the column record (window positions, byte selectors,
+//     coefficient pairs) is loop-invariant and lives in registers, read once per level straight from global memory.
+//   Horizontal: two 8-byte windows per source row (ds_read2_b32), one v_perm_b32 per pixel lifts (S[sx], S[sx + 1]) into two 16-bit
+//   halves, one v_dot2_u32_u16 forms H.  Vertical: ((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) as two v_mul_hi_u32_u24 of
+//   (b << 12) and (H & ~15): (b * 2^12) * ((H >> 4) * 2^4) >> 32 == (b * (H >> 4)) >> 16, both factors below 2^24.
+// LDS map (dynamic): [rows of the odd levels (one region, reused)][rows of the even levels, level 0 included (one region, reused)], pitch = w
+// rounded up to 4, [8-byte row records of the band's rows].  The host picks the band count so that two workgroups fit a CU (svgpu_orb_configure).
+__device__ __forceinline__ uint32_t mul_hi_u24(uint32_t a, uint32_t b) {  // (a * b) >> 32 for a, b < 2^24: full-rate v_mul_hi_u32_u24
+    uint32_t d;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __restrict__ L, int num_levels, const int2* __restrict__ band_rows,
@@ -222,27 +188,22 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
                                                              int img0_pitch, uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                              const uint32_t* __restrict__ xg, const short4* __restrict__ yrow) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
-    __shared__ int s_img[SV_MAX_LEVELS], s_xt[SV_MAX_LEVELS], s_yt[SV_MAX_LEVELS + 1];
+    __shared__ int s_img[SV_MAX_LEVELS], s_yt[SV_MAX_LEVELS + 1];
     const int band = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int2* BR = band_rows + (size_t)band * num_levels;
     if (tid == 0) {
         // level l is computed from level l - 1 only: two image regions alternate (odd levels in the first, even levels in the second),
-        // each as large as its largest tenant -- about half of what keeping every level costs, which leaves room for a second
-        // workgroup (or for the matcher's workgroups) on the CU
+        // each as large as its largest tenant
         int size_a = 0, size_b = 0;
-        for (int l = 1; l < num_levels; ++l) {
+        for (int l = 0; l < num_levels; ++l) {
             const int bytes = (BR[l].y - BR[l].x) * ((L[l].w + 3) & ~3);
             if (l & 1) size_a = max(size_a, bytes);
             else size_b = max(size_b, bytes);
         }
         size_a = (size_a + 15) & ~15;
-        for (int l = 1; l < num_levels; ++l) s_img[l] = (l & 1) ? 0 : size_a;
+        size_b = (size_b + 15) & ~15;
+        for (int l = 0; l < num_levels; ++l) s_img[l] = (l & 1) ? 0 : size_a;
         int off = size_a + size_b;
-        off = (off + 15) & ~15;
-        for (int l = 1; l < num_levels; ++l) {
-            s_xt[l] = off;
-            off += ((L[l].w + 3) >> 2) * 32;
-        }
         s_yt[0] = off;
         for (int l = 1; l < num_levels; ++l) {
             s_yt[l] = off;
@@ -251,11 +212,34 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
         s_yt[num_levels] = off;
     }
     __syncthreads();
-    // ---- column-group records of all levels (contiguous in global memory and in LDS), row records of the band's rows
+    const uint8_t* I0 = img0 + (size_t)b * img0_frame_stride;
     {
-        const int first = L[1].xg_off * 8, words = (s_yt[0] - s_xt[1]) >> 2;
-        uint32_t* D = reinterpret_cast<uint32_t*>(s_mem + s_xt[1]);
-        for (int i = tid; i < words; i += PYR_THREADS) D[i] = xg[first + i];
+        // ---- level-0 rows of the band -> LDS (pitch = w rounded up to 4), row records of the band's rows
+        const int w0 = L[0].w, p0 = (w0 + 3) & ~3, lo0 = BR[0].x, n0 = BR[0].y - lo0;
+        uint8_t* D0 = s_mem + s_img[0];
+        if (((((size_t)I0) | (size_t)img0_pitch) & 15) == 0 && (p0 & 15) == 0) {
+            const int cpr = p0 >> 4, total = n0 * cpr;  // 16-byte chunks (the row pitch covers the rounded-up width)
+            const float inv = 1.0f / (float)cpr;
+            for (int i = tid; i < total; i += PYR_THREADS) {
+                const int r = (int)(((float)i + 0.5f) * inv), c = i - __mul24(r, cpr);
+                reinterpret_cast<uint4*>(D0)[i] = *reinterpret_cast<const uint4*>(I0 + (__umul24(lo0 + r, img0_pitch) + 16 * c));
+            }
+        }
+        else if (((((size_t)I0) | (size_t)img0_pitch) & 3) == 0) {
+            const int wpr = p0 >> 2, total = n0 * wpr;
+            const float inv = 1.0f / (float)wpr;
+            for (int i = tid; i < total; i += PYR_THREADS) {
+                const int r = (int)(((float)i + 0.5f) * inv), c = i - __mul24(r, wpr);
+                reinterpret_cast<uint32_t*>(D0)[i] = *reinterpret_cast<const uint32_t*>(I0 + (__umul24(lo0 + r, img0_pitch) + 4 * c));
+            }
+        }
+        else {
+            const int total = n0 * p0;
+            for (int i = tid; i < total; i += PYR_THREADS) {
+                const int r = i / p0, c = i - r * p0;
+                D0[i] = c < w0 ? I0[(size_t)(lo0 + r) * img0_pitch + c] : (uint8_t)0;
+            }
+        }
         const int rows = (s_yt[num_levels] - s_yt[0]) >> 3;
         for (int i = tid; i < rows; i += PYR_THREADS) {
             int l = 1;
@@ -266,35 +250,56 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
     }
     __syncthreads();
     uint8_t* P = pyr + (size_t)b * pyr_frame_bytes;
-    const uint8_t* I0 = img0 + (size_t)b * img0_frame_stride;
-    const bool words0 = ((((size_t)I0) | (size_t)img0_pitch) & 3) == 0;
     for (int l = 1; l < num_levels; ++l) {
         const OrbLevel lev = L[l];
-        const int pw = L[l - 1].w, sp = (pw + 3) & ~3, dpw = ((lev.w + 3) & ~3) >> 2;  // LDS pitches (bytes, dwords)
+        const int spw = ((L[l - 1].w + 3) & ~3) >> 2, dpw = ((lev.w + 3) & ~3) >> 2;  // LDS pitches in dwords
         const int src_lo = BR[l - 1].x, lo = BR[l].x, hi = BR[l].y;
         const int own_lo = (int)((long long)band * lev.h / bands), own_hi = (int)((long long)(band + 1) * lev.h / bands);
-        const uint8_t* S = s_mem + (l > 1 ? s_img[l - 1] : 0);
+        const uint32_t* S = reinterpret_cast<const uint32_t*>(s_mem + s_img[l - 1]);
         uint32_t* Dl = reinterpret_cast<uint32_t*>(s_mem + s_img[l]);
-        const uint4* xt = reinterpret_cast<const uint4*>(s_mem + s_xt[l]);
         const short4* yt = reinterpret_cast<const short4*>(s_mem + s_yt[l]);
         uint8_t* Dg = P + lev.pyr_off;
-        const int groups = (lev.w + 3) >> 2, ntask = (hi - lo) * groups, last_word = (pw - 1) >> 2;
-        const float inv = 1.0f / (float)groups;
-        for (int t = tid; t < ntask; t += PYR_THREADS) {
-            const int row = (int)(((float)t + 0.5f) * inv), g = t - __mul24(row, groups);
-            const short4 ye = yt[row];
-            const uint4 e = xt[2 * g];
-            const uint2 e2 = reinterpret_cast<const uint2*>(xt + 2 * g + 1)[0];
-            uint32_t packed;
-            if (l > 1)
-                packed = pyr_group<PYR_SRC_LDS>(S + __mul24(ye.x - src_lo, sp), S + __mul24(ye.y - src_lo, sp), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
-            else if (words0)
-                packed = pyr_group<PYR_SRC_GLOBAL_WORDS>(I0 + __umul24(ye.x, img0_pitch), I0 + __umul24(ye.y, img0_pitch), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
-            else
-                packed = pyr_group<PYR_SRC_GLOBAL_BYTES>(I0 + __umul24(ye.x, img0_pitch), I0 + __umul24(ye.y, img0_pitch), e, e2, (uint32_t)ye.z, (uint32_t)ye.w, last_word, pw);
-            Dl[__mul24(row, dpw) + g] = packed;
-            const int dy = lo + row;
-            if (dy >= own_lo && dy < own_hi) *reinterpret_cast<uint32_t*>(Dg + (__umul24(dy, lev.pitch) + 4 * g)) = packed;
+        // thread -> (chunk of consecutive rows, column group)
+        const int groups = (lev.w + 3) >> 2, nrows = hi - lo;
+        const int chunks = max(min(PYR_THREADS / groups, nrows), 1), rc = (nrows + chunks - 1) / chunks;
+        const int c = (int)(((float)tid + 0.5f) * (1.0f / (float)groups)), g = tid - __mul24(c, groups);
+        const int r0 = __mul24(c, rc), r1 = min(r0 + rc, nrows);
+        if (r0 < r1) {
+            const uint4 e = reinterpret_cast<const uint4*>(xg)[2 * (lev.xg_off + g)];
+            const uint2 e2 = reinterpret_cast<const uint2*>(xg)[4 * (lev.xg_off + g) + 2];
+            const int i0 = e.x & 0xffff, i2 = e.x >> 16;
+            const uint32_t coef[4] = {e.z, e.w, e2.x, e2.y};
+            uint32_t sel[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sel[i] = 0x0c010c00u + ((e.y >> (8 * i)) & 255u) * 0x00010001u;  // bytes (k, zero, k + 1, zero) of the 8-byte window
+            auto hrow = [&](int sy, uint32_t (&h)[4]) {
+                const uint32_t* R = S + __mul24(sy - src_lo, spw);
+                const uint32_t a0 = R[i0], a1 = R[i0 + 1], c0 = R[i2], c1 = R[i2 + 1];
+                h[0] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(a1, a0, sel[0])), as_u16x2(coef[0]), 0u, false) & ~15u;
+                h[1] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(a1, a0, sel[1])), as_u16x2(coef[1]), 0u, false) & ~15u;
+                h[2] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(c1, c0, sel[2])), as_u16x2(coef[2]), 0u, false) & ~15u;
+                h[3] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(c1, c0, sel[3])), as_u16x2(coef[3]), 0u, false) & ~15u;
+            };
+            uint32_t hA[4], hB[4] = {0, 0, 0, 0};
+            int prev = -1;  // the source row hB holds
+            for (int row = r0; row < r1; ++row) {
+                const short4 ye = yt[row];
+                if (ye.x == prev) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hA[i] = hB[i];
+                }
+                else hrow(ye.x, hA);
+                hrow(ye.y, hB);
+                prev = ye.y;
+                const uint32_t b0 = (uint32_t)ye.z << 12, b1 = (uint32_t)ye.w << 12;  // 0 .. 2048 each
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (mul_hi_u24(b0, hA[i]) + mul_hi_u24(b1, hB[i]) + 2u) >> 2;
+                const uint32_t packed = (v[0] & 255u) | ((v[1] & 255u) << 8) | ((v[2] & 255u) << 16) | (v[3] << 24);
+                Dl[__mul24(row, dpw) + g] = packed;
+                const int dy = lo + row;
+                if (dy >= own_lo && dy < own_hi) *reinterpret_cast<uint32_t*>(Dg + (__umul24(dy, lev.pitch) + 4 * g)) = packed;
+            }
         }
         __syncthreads();
     }

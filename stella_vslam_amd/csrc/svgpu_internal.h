@@ -214,14 +214,13 @@ int sv_frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell);  // grow
 // ---- kernel launchers (orb_kernels.hip)
 void sv_launch_resize(hipStream_t s, const uint8_t* src, size_t src_frame_stride, int src_pitch, int sw, int sh,
                       uint8_t* dst, size_t dst_frame_stride, int dst_pitch, int dw, int dh, const short* xofs,
-                      const short2* xa, const short2* yofs, const short2* yb, const uint32_t* xg, const short4* yrow, int batch, size_t lds_bytes);
+                      const short2* xa, const short2* yofs, const short2* yb, int batch);
 #define SV_PYR_LDS_MAX (156 * 1024)  // dynamic LDS budget of k_pyramid_lds (160 KB per CU minus its static tables)
+#define SV_PYR_LDS_HALF (78 * 1024)  // ... of which two fit a CU
 hipError_t sv_pyramid_prepare();
 void sv_launch_pyramid(hipStream_t s, const OrbLevel* levels, int num_levels, const int2* band_rows, int bands, const uint8_t* img0,
                        size_t img0_frame_stride, int img0_pitch, uint8_t* pyr, size_t pyr_frame_bytes, const short* xofs,
                        const short2* xa, const short2* yofs, const short2* yb, const uint32_t* xg, const short4* yrow, int batch, size_t lds_bytes);
-#define SV_PYR_LDS_MAX (156 * 1024)  // dynamic LDS budget of k_pyramid_lds (160 KB per CU minus its static tables)
-hipError_t sv_pyramid_prepare();
 void sv_launch_blur(hipStream_t s, const OrbLevel* levels, int num_levels, int total_tiles, const uint8_t* img0,
                     size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, uint8_t* blur,
                     size_t blur_frame_bytes, int batch, bool need_gather, int rows);

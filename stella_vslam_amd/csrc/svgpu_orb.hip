@@ -292,29 +292,43 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
                 }
             }
             if (need_hi > need_lo) band_rows[(size_t)k * num_levels] = int2{need_lo, need_hi};  // level-0 rows the band reads
-            size_t size_a = 0, size_b = 0;  // must mirror the LDS map of k_pyramid_lds: odd / even levels alternate in two regions
-            for (int l = 1; l < num_levels; ++l) {
+            size_t size_a = 0, size_b = 0;  // must mirror the LDS map of k_pyramid_lds: odd / even levels (level 0 included) alternate in two regions
+            for (int l = 0; l < num_levels; ++l) {
                 const int2 r = band_rows[(size_t)k * num_levels + l];
                 const size_t b = (size_t)(r.y - r.x) * (size_t)((C.levels[l].w + 3) & ~3);
                 if (l & 1) size_a = std::max(size_a, b);
                 else size_b = std::max(size_b, b);
             }
             size_a = (size_a + 15) & ~(size_t)15;
+            size_b = (size_b + 15) & ~(size_t)15;
             size_t bytes = size_a + size_b;
-            bytes = (bytes + 15) & ~(size_t)15;
             for (int l = 1; l < num_levels; ++l) {
                 const int2 r = band_rows[(size_t)k * num_levels + l];
-                bytes += (size_t)((C.levels[l].w + 3) / 4) * 32 + (size_t)(r.y - r.x) * 8;
+                bytes += (size_t)(r.y - r.x) * 8;
             }
             worst = std::max(worst, bytes);
         }
         return worst;
     };
     std::vector<int2> band_rows;
-    // few, tall bands recompute the fewest halo rows; small batches need more bands to fill the 256 CUs
+    // few, tall bands recompute the fewest halo rows; small batches need more bands to fill the 256 CUs.  A footprint of at most half the
+    // CU's LDS lets two workgroups share a CU (one computes while the other waits at a level barrier): preferred while <= 32 bands reach it.
     int bands = std::max(8, std::min(32, (512 + max_batch - 1) / std::max(max_batch, 1)));
-    if (const char* e = getenv("SVGPU_PYR_BANDS")) bands = std::max(1, atoi(e));
+    bool forced = false;
+    if (const char* e = getenv("SVGPU_PYR_BANDS")) {
+        bands = std::max(1, atoi(e));
+        forced = true;
+    }
+    xg_ok = xg_ok && (num_levels < 2 || C.levels[1].w <= 4 * 1024);  // one thread per column group of a level: at most 1024 groups
     size_t lds = 0;
+    if (!forced && xg_ok) {
+        std::vector<int2> trial;
+        for (int k = bands; k <= 32; k += 2)
+            if (make_bands(k, trial) <= SV_PYR_LDS_HALF) {
+                bands = k;
+                break;
+            }
+    }
     for (;; bands += 2) {
         lds = make_bands(bands, band_rows);
         if (lds <= SV_PYR_LDS_MAX && xg_ok) break;
