@@ -706,8 +706,11 @@ __device__ int bf_full_row(const BfProblem& P, int pair, int j, int n1c, const i
 // queries j = tid + u * blockDim; count and first four keys of the rows of its first BF_RC queries stay in registers, the rest of long rows in an LDS pool
 // across the sweeps (enough for 4096 keypoints; further queries re-read their rows from global memory every sweep),
 // so a sweep is LDS traffic and a handful of barriers.
-#define BF_RC 4
-__global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds, int pool_rows) {
+// Two shapes: 1024 threads x 4 cached rows (up to 4096 keypoints in registers), and 512 threads x 5 rows for the usual <= 2560 keypoints:
+// in the two-stream pipeline a 16-wave workgroup waits for a CU with 16 free wave slots while the extraction kernels hold them (2.1 ms
+// elapsed for a 0.18 ms kernel at 1024 pairs); 8-wave workgroups find room four times as often.
+template <int BF_RC, int NT>
+__global__ __launch_bounds__(NT) void k_bf_replay(BfProblem P, int* __restrict__ g_owner, int* __restrict__ g_match, int use_lds, int pool_rows) {
     extern __shared__ int s_mem[];
     __shared__ int s_changed, s_nund, s_any_und, s_pool_n;
     __shared__ int s_und[1024];  // one slot per thread of a stride: can never overflow
@@ -793,7 +796,13 @@ __global__ __launch_bounds__(1024) void k_bf_replay(BfProblem P, int* __restrict
                 const int j = j0 + tid, u = j0 / nthr;
                 bool need = false;
                 if (j < n2c) {
-                    if (u < BF_RC) need = (u == 0 ? dec[0] : u == 1 ? dec[1] : u == 2 ? dec[2] : dec[3]) == -3;
+                    if (u < BF_RC) {
+                        int du = dec[0];
+#pragma unroll
+                        for (int v = 1; v < BF_RC; ++v)
+                            if (v == u) du = dec[v];
+                        need = du == -3;
+                    }
                     else need = match[j] <= -8;
                 }
                 if (need) s_und[atomicAdd(&s_nund, 1)] = j;
@@ -1817,8 +1826,14 @@ void sv_launch_bf(svgpu_ctx* ctx, hipStream_t s, const BfProblem& P0, int pairs,
     if (!use_lds) lds = 0;
     const int pool_rows = (int)std::min<size_t>(1024, (128 * 1024 - lds) / ((BF_LIST - 4) * sizeof(uint32_t)));
     lds += (size_t)pool_rows * (BF_LIST - 4) * sizeof(uint32_t);
-    (void)sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_bf_replay), 144 * 1024);
-    hipLaunchKernelGGL(k_bf_replay, dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
+    if (P.cap2 <= 5 * 512) {
+        (void)sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_bf_replay<5, 512>), 144 * 1024);
+        hipLaunchKernelGGL((k_bf_replay<5, 512>), dim3(pairs), dim3(512), lds, s, P, g_owner, g_match, use_lds, pool_rows);
+    }
+    else {
+        (void)sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_bf_replay<4, 1024>), 144 * 1024);
+        hipLaunchKernelGGL((k_bf_replay<4, 1024>), dim3(pairs), dim3(1024), lds, s, P, g_owner, g_match, use_lds, pool_rows);
+    }
 }
 // exclusive scan of the grid's counters: the shuffle-based one-workgroup scan of sv_sort.hip (4.5 us) up to its 16 k elements, the
 // Hillis-Steele kernel above (9 us per 1 024 elements, needs no scratch) beyond
