@@ -272,34 +272,47 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_lds(const OrbLevel* __r
             uint32_t sel[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) sel[i] = 0x0c010c00u + ((e.y >> (8 * i)) & 255u) * 0x00010001u;  // bytes (k, zero, k + 1, zero) of the 8-byte window
+            // row sy of the source level for this thread's first window: S0 + sy * spw (the second window d2 dwords further)
+            const uint32_t* S0 = S + (i0 - __mul24(src_lo, spw));
+            const int d2 = i2 - i0;
             auto hrow = [&](int sy, uint32_t (&h)[4]) {
-                const uint32_t* R = S + __mul24(sy - src_lo, spw);
-                const uint32_t a0 = R[i0], a1 = R[i0 + 1], c0 = R[i2], c1 = R[i2 + 1];
+                const uint32_t* R = S0 + __mul24(sy, spw);
+                const uint32_t a0 = R[0], a1 = R[1], c0 = R[d2], c1 = R[d2 + 1];
                 h[0] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(a1, a0, sel[0])), as_u16x2(coef[0]), 0u, false) & ~15u;
                 h[1] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(a1, a0, sel[1])), as_u16x2(coef[1]), 0u, false) & ~15u;
                 h[2] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(c1, c0, sel[2])), as_u16x2(coef[2]), 0u, false) & ~15u;
                 h[3] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(c1, c0, sel[3])), as_u16x2(coef[3]), 0u, false) & ~15u;
             };
-            uint32_t hA[4], hB[4] = {0, 0, 0, 0};
-            int prev = -1;  // the source row hB holds
-            for (int row = r0; row < r1; ++row) {
+            uint32_t* dl = Dl + (__mul24(r0, dpw) + g);
+            uint32_t goff = __umul24(lo + r0, lev.pitch) + 4 * g;  // byte offset of (row, group) in the level's global image
+            const uint32_t own_n = (uint32_t)(own_hi - own_lo);
+            uint32_t dyo = (uint32_t)(lo + r0 - own_lo);            // row - own_lo: owned <=> dyo < own_n (unsigned)
+            int prev = -1;                                           // the source row the bottom registers of the previous step hold
+            // one output row: `top` already holds H(prev) -- reused when the row's first tap is that source row --, the second tap goes to `bot`;
+            // the two register sets swap roles from row to row (the loop is unrolled by two), so the reuse costs no moves
+            auto step = [&](int row, uint32_t (&top)[4], uint32_t (&bot)[4]) {
                 const short4 ye = yt[row];
-                if (ye.x == prev) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hA[i] = hB[i];
-                }
-                else hrow(ye.x, hA);
-                hrow(ye.y, hB);
+                if (ye.x != prev) hrow(ye.x, top);
+                hrow(ye.y, bot);
                 prev = ye.y;
                 const uint32_t b0 = (uint32_t)ye.z << 12, b1 = (uint32_t)ye.w << 12;  // 0 .. 2048 each
                 uint32_t v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (mul_hi_u24(b0, hA[i]) + mul_hi_u24(b1, hB[i]) + 2u) >> 2;
+                for (int i = 0; i < 4; ++i) v[i] = (mul_hi_u24(b0, top[i]) + mul_hi_u24(b1, bot[i]) + 2u) >> 2;
                 const uint32_t packed = (v[0] & 255u) | ((v[1] & 255u) << 8) | ((v[2] & 255u) << 16) | (v[3] << 24);
-                Dl[__mul24(row, dpw) + g] = packed;
-                const int dy = lo + row;
-                if (dy >= own_lo && dy < own_hi) *reinterpret_cast<uint32_t*>(Dg + (__umul24(dy, lev.pitch) + 4 * g)) = packed;
+                *dl = packed;
+                if (dyo < own_n) *reinterpret_cast<uint32_t*>(Dg + goff) = packed;
+                dl += dpw;
+                goff += (uint32_t)lev.pitch;
+                ++dyo;
+            };
+            uint32_t hX[4], hY[4] = {0, 0, 0, 0};
+            int row = r0;
+            for (; row + 1 < r1; row += 2) {
+                step(row, hY, hX);
+                step(row + 1, hX, hY);
             }
+            if (row < r1) step(row, hY, hX);
         }
         __syncthreads();
     }
