@@ -579,7 +579,10 @@ __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
 
 #define FAST_KT 12  // selection-grid cells per dimension cached in LDS (a 70-px ROI spans at most ~10 at the coarsest level)
 #define FP 80  // LDS pitch of the ROI arrays: 3 skew bytes + 70, rounded up to whole 16-byte chunks
-__global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells,
+// One workgroup works through `cpw` consecutive cells of one frame (persistent over cells: the frame / lane-role set-up, and the row
+// addresses, band masks and clamps of the quick test -- a third of the instructions of a one-cell workgroup -- are paid once per
+// workgroup; the patch rows of the quick test are immediate offsets from one LDS address).
+__global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, int num_levels, const FastCell* __restrict__ cells, int num_cells, int cpw,
                                               const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
                                               const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                               const unsigned short* __restrict__ gtab, unsigned long long* __restrict__ keys,
@@ -591,13 +594,50 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     __shared__ unsigned long long s_key[FAST_KT * FAST_KT];  // per-block arg-max of the selection-grid cells the ROI touches
     __shared__ unsigned short s_gx[SV_ROI_MAX], s_gy[SV_ROI_MAX];  // selection-grid column / row of every ROI column / row
     __shared__ int s_count;
-    int local, b, ci;
-    xcd_frame_map(gridDim.x, gridDim.y, ci, b);
-    const int lv = find_level(L, num_levels, ci, &OrbLevel::cell_first, &local);
-    const OrbLevel lev = L[lv];
-    const FastCell cell = cells[ci];
-    const int tid = threadIdx.x;
+    int b, grp;
+    xcd_frame_map(gridDim.x, gridDim.y, grp, b);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint8_t* M = mask ? mask + (size_t)b * mask_frame_stride : nullptr;
+    const uint8_t* const I0 = img0 + (size_t)b * img0_frame_stride;
+    const uint8_t* const PY = pyr + (size_t)b * pyr_frame_bytes;
+    unsigned long long* const KF = keys + (size_t)b * total_grid;
+    uint8_t* const s_img = s_raw + 3;
+    unsigned short* const my_q = s_q + wv * (SV_CELL * SV_CELL / 4);
+    // ---- lane roles of the quick test (pass A below): a lane owns a 4 x 4 patch; 16 lanes span the 64 scored columns, the four lane
+    //      groups of a wave and the four waves take the sixteen bands of four rows
+    const int qrow = lane >> 4, qk = lane & 15;
+    const int x0 = 3 + 4 * qk;                  // the lane's columns x0 .. x0 + 3 (ROI coordinates)
+    const int ly0 = 3 + 4 * (4 * qrow + wv);    // ... and rows ly0 .. ly0 + 3
+    const int e0 = (ly0 << 7) | x0;             // queue entry of (row 0, column 0) of the patch
+    // pixel (ly, x) sits at s_raw[ly * FP + x + 3]; qbase = the aligned dword that holds the lane's first pixel of patch row 0 at byte 2.
+    // Rows ly0 + g +- 3 <= 69 stay inside the 70-row LDS image whatever the cell's height (rows past the cell are zero-filled and their
+    // results masked), so every row of the patch is an immediate offset from this one address.
+    const uint32_t* const qbase = reinterpret_cast<const uint32_t*>(s_raw + ly0 * FP + 4 * qk);
+
+    auto load_ring = [&](const uint8_t* c, int (&p)[16]) {
+        p[0] = c[3 * FP];
+        p[1] = c[3 * FP + 1];
+        p[2] = c[2 * FP + 2];
+        p[3] = c[FP + 3];
+        p[4] = c[3];
+        p[5] = c[-FP + 3];
+        p[6] = c[-2 * FP + 2];
+        p[7] = c[-3 * FP + 1];
+        p[8] = c[-3 * FP];
+        p[9] = c[-3 * FP - 1];
+        p[10] = c[-2 * FP - 2];
+        p[11] = c[-FP - 3];
+        p[12] = c[-3];
+        p[13] = c[FP - 3];
+        p[14] = c[2 * FP - 2];
+        p[15] = c[3 * FP - 1];
+    };
+
+    const int c_first = grp * cpw, c_last = min(c_first + cpw, num_cells);
+    for (int ci = c_first; ci < c_last; ++ci) {
+    const FastCell cell = cells[ci];
+    const OrbLevel lev = L[cell.lv];
     auto masked = [&](int y, int x) -> bool {  // is_in_mask (orb_extractor.cc:168-170): (int)(y * scale), (int)(x * scale)
         int my = (int)((float)y * lev.scale), mx = (int)((float)x * lev.scale);
         my = min(my, mask_h - 1);
@@ -605,24 +645,24 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         return M[(size_t)my * mask_pitch + mx] == 0;
     };
     if (M) {  // skip the cell if one of its corners is masked (:219-225)
-        const int y0 = cell.min_y, y1 = cell.min_y + cell.h, x0 = cell.min_x, x1 = cell.min_x + cell.w;
-        if (masked(y0, x0) || masked(y1, x0) || masked(y0, x1) || masked(y1, x1)) return;
+        const int y0 = cell.min_y, y1 = cell.min_y + cell.h, xa = cell.min_x, xb = cell.min_x + cell.w;
+        if (masked(y0, xa) || masked(y1, xa) || masked(y0, xb) || masked(y1, xb)) continue;
     }
     const uint8_t* src;
     int spitch;
-    if (lv == 0) {
-        src = img0 + (size_t)b * img0_frame_stride;
+    if (cell.lv == 0) {
+        src = I0;
         spitch = img0_pitch;
     }
     else {
-        src = pyr + (size_t)b * pyr_frame_bytes + lev.pyr_off;
+        src = PY + lev.pyr_off;
         spitch = lev.pitch;
     }
     const int w = cell.w, h = cell.h;
+    if (ci != c_first) __syncthreads();  // the previous cell's flush has read s_key, its last pass s_a / s_raw
     // ROI -> LDS.  The ROI starts at x = 19 + 64j, i.e. 3 bytes past a 16-byte boundary: load the aligned words that
     // cover it (the 3 leading bytes are real pixels of the border band) and address the LDS copy with a +3 skew.
     const uint8_t* rsrc = src + (size_t)cell.min_y * spitch + (cell.min_x - 3);
-    uint8_t* const s_img = s_raw + 3;
     if (((((size_t)rsrc) | (size_t)spitch) & 15) == 0) {
         // 16-byte chunks: the ROI (with its 3 leading bytes) starts on a 16-byte boundary and ends at least 16 px before
         // the row end, so whole chunks stay inside the image row
@@ -657,32 +697,15 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     if (tid < FAST_KT * FAST_KT) s_key[tid] = 0ull;
     if (tid < w) s_gx[tid] = gtab[lev.gtab_x_off + cell.min_x + tid - SV_PATCH_RADIUS];
     else if (tid >= 128 && tid - 128 < h) s_gy[tid - 128] = gtab[lev.gtab_y_off + cell.min_y + (tid - 128) - SV_PATCH_RADIUS];
+    uint32_t band80 = 0;  // 0x80 per column of the patch inside the scored band
+#pragma unroll
+    for (int j = 0; j < 4; ++j) band80 |= (x0 + j < w - 3) ? (0x80u << (8 * j)) : 0u;
     __syncthreads();
 
-    auto load_ring = [&](const uint8_t* c, int (&p)[16]) {
-        p[0] = c[3 * FP];
-        p[1] = c[3 * FP + 1];
-        p[2] = c[2 * FP + 2];
-        p[3] = c[FP + 3];
-        p[4] = c[3];
-        p[5] = c[-FP + 3];
-        p[6] = c[-2 * FP + 2];
-        p[7] = c[-3 * FP + 1];
-        p[8] = c[-3 * FP];
-        p[9] = c[-3 * FP - 1];
-        p[10] = c[-2 * FP - 2];
-        p[11] = c[-FP - 3];
-        p[12] = c[-3];
-        p[13] = c[FP - 3];
-        p[14] = c[2 * FP - 2];
-        p[15] = c[3 * FP - 1];
-    };
     // cv::FAST at ini_thr; if the cell stays empty, once more at min_thr (:228-235).  The quick test, the queue and the arc scores are
     // rebuilt for the retry (rare: textured cells are never empty), so the common case queues and scores only what can exceed ini_thr.
-    unsigned long long* K = keys + (size_t)b * total_grid + lev.grid_first;
+    unsigned long long* K = KF + lev.grid_first;
     const int gx0 = s_gx[3], gy0 = s_gy[3];  // grid cell of the first scored pixel
-    const int lane = tid & 63;
-    unsigned short* const my_q = s_q + (tid >> 6) * (SV_CELL * SV_CELL / 4);
     for (int pass = 0; pass < 2; ++pass) {
     const int t = pass == 0 ? ini_thr : min_thr, tq = t;
     // --- pass A: every pixel of the scored band [3, w-3) x [3, h-3) takes a 5-pixel quick test at this pass's threshold.
@@ -699,24 +722,13 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     Every wave owns a quarter of the queue.
     int wq = 0;
     {
-        const int wv = tid >> 6, qrow = lane >> 4, qk = lane & 15;
-        const int x0 = 3 + 4 * qk;  // the lane's columns x0 .. x0 + 3 (ROI coordinates)
-        uint32_t band80 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) band80 |= (x0 + j < w - 3) ? (0x80u << (8 * j)) : 0u;
         const uint32_t tqq = (uint32_t)(tq + 1) * 0x10001u;
-        const int ly0 = 3 + 4 * (4 * qrow + wv);  // the lane's 4 x 4 patch: rows ly0 .. ly0 + 3 (bands of four rows are dealt round-robin to the waves)
         uint32_t m = 0;                           // bit 8 j + 4 + g: pixel (row g, column j) of the patch passed
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ly = ly0 + g;
-            const int lyc = max(min(ly, h - 4), 3);  // rows below the band are read somewhere harmless and masked
-            // pixel (ly, x) sits at s_raw[ly * FP + x + 3]; B = address of the aligned dword that holds the lane's first pixel at byte 2
-            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(s_raw + lyc * FP + 4 * qk);  // W0 = [B-4, B), W1, W2, W3
-            const uint32_t* rowd = reinterpret_cast<const uint32_t*>(s_raw + (lyc + 3) * FP + 4 * qk);
-            const uint32_t* rowu = reinterpret_cast<const uint32_t*>(s_raw + (lyc - 3) * FP + 4 * qk);
-            const uint32_t w0 = rowc[0], w1 = rowc[1], w2 = rowc[2], w3 = rowc[3];
-            const uint32_t d1 = rowd[1], d2 = rowd[2], u1 = rowu[1], u2 = rowu[2];
+            const uint32_t* const rc = qbase + g * (FP / 4);  // W0 = [B-4, B), W1, W2, W3 of the centre row; rows +3 / -3
+            const uint32_t w0 = rc[0], w1 = rc[1], w2 = rc[2], w3 = rc[3];
+            const uint32_t d1 = rc[3 * (FP / 4) + 1], d2 = rc[3 * (FP / 4) + 2], u1 = rc[-3 * (FP / 4) + 1], u2 = rc[-3 * (FP / 4) + 2];
             auto pk = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi, lo, sel)); };
             uint32_t e2[2];
 #pragma unroll
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             }
             // sign bytes of the four results -> one byte per pixel; a clear sign inside the band is a hit
             const uint32_t sgn = __builtin_amdgcn_perm(e2[1], e2[0], 0x07050301u);
-            m = (m >> 1) | (~sgn & (ly < h - 3 ? band80 : 0u));
+            m = (m >> 1) | (~sgn & (ly0 + g < h - 3 ? band80 : 0u));
         }
         // Compaction, once per wave: exclusive prefix of the lanes' hit counts (row-scan adds), then every lane stores the hits of
         // its patch.  The queue order is patch by patch along a band of four rows -- neighbouring lanes of pass B then work on
@@ -748,7 +760,6 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31
         wq = __builtin_amdgcn_readlane(incl, 63);
         int pos = incl - cnt;
-        const int e0 = (ly0 << 7) | x0;  // row 0, column 0 of the patch
         while (m) {
             const int bit = __ffs((int)m) - 1;  // 8 j + 4 + g
             m &= m - 1;
@@ -805,6 +816,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     if (tid < FAST_KT * FAST_KT) {
         const unsigned long long key = s_key[tid];
         if (key) atomicMax(&K[(gy0 + tid / FAST_KT) * lev.grid_x + gx0 + tid % FAST_KT], key);
+    }
     }
 }
 
@@ -1185,7 +1197,10 @@ void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const
                     int ini_thr, int min_thr, const uint8_t* mask, size_t mask_frame_stride, int mask_pitch, int mask_w,
                     int mask_h, int batch) {
     if (num_cells == 0) return;
-    hipLaunchKernelGGL(k_fast, dim3(num_cells, batch), dim3(256), 0, s, levels, num_levels, cells, img0, img0_frame_stride,
+    // cells per workgroup: four once the batch alone fills the chip many times over, one for a few frames (latency: more workgroups)
+    int cpw = (long long)num_cells * batch >= 16384 ? 4 : 1;
+    if (const char* e = getenv("SVGPU_FAST_CPW")) cpw = std::max(1, atoi(e));
+    hipLaunchKernelGGL(k_fast, dim3((num_cells + cpw - 1) / cpw, batch), dim3(256), 0, s, levels, num_levels, cells, num_cells, cpw, img0, img0_frame_stride,
                        img0_pitch, pyr, pyr_frame_bytes, gtab, keys, total_grid, ini_thr, min_thr, mask, mask_frame_stride,
                        mask_pitch, mask_w, mask_h);
 }

@@ -46,7 +46,7 @@ struct OrbLevel {
 struct FastCell {
     short min_x, min_y;  // ROI origin in level coordinates
     short w, h;          // ROI size (<= 70)
-    short ci, cj;        // cell row / column (i, j in orb_extractor.cc:199-217)
+    short lv, cj;        // pyramid level; cell column (j in orb_extractor.cc:199-217)
     int order_base;      // (ci * num_cols + cj) << 14 : emission order prefix
 };
 

@@ -234,7 +234,7 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
                     c.min_y = (short)min_y;
                     c.w = (short)(max_x - min_x);
                     c.h = (short)(max_y - min_y);
-                    c.ci = (short)i;
+                    c.lv = (short)l;
                     c.cj = (short)j;
                     c.order_base = (int)((i * num_cols + j) << 14);
                     C.cells.push_back(c);
