@@ -110,18 +110,49 @@ struct svgpu_frame {
 
 // The landmark table of the tracked-frame chain (include/svgpu.h svgpu_map_*): records indexed by data::landmark::id_.
 // Writers (upsert / erase: the mapping thread after BA, the tracking thread's flush) and readers (the tracker's chains) may sit on
-// different contexts = streams: `mtx` serialises the host side, ev_write / ev_read order the streams (a reader's stream waits for the
-// last write, a writer's for the last read), and a growth waits for both before the old table is freed.
+// different contexts = streams: `mtx` serialises the host side, ev_write / the pending read events order the streams (a reader's stream
+// waits for the last write, a writer's for EVERY read since the previous writer), and a growth waits for both before the old table is freed.
 struct svgpu_map {
     int device = 0;
     int cap = 0;                         // records allocated (ids < cap are addressable)
     svgpu_landmark_record* rec = nullptr;
     std::mutex mtx;
-    hipEvent_t ev_write = nullptr, ev_read = nullptr;
-    bool wrote = false, read = false;
+    hipEvent_t ev_write = nullptr;
+    bool wrote = false;
+    // one event PER READ that no writer has waited for yet: readers run on any number of streams (two trackers of a stereo rig, a
+    // relocaliser beside the tracker, svgpu_map_download on another context), and a writer -- above all a growth, which frees the old
+    // allocation -- has to wait for every one of them, not for whichever recorded last
+    std::vector<hipEvent_t> reads_pending, reads_pool;
 };
 int sv_map_reader_begin(svgpu_ctx* ctx, svgpu_map* map, hipStream_t s);  // the reader's stream waits for the last write (call with map->mtx held)
-int sv_map_reader_end(svgpu_ctx* ctx, svgpu_map* map, hipStream_t s);
+int sv_map_reader_end(svgpu_ctx* ctx, svgpu_map* map, hipStream_t s);    // records this read for the next writer (mutex still held)
+// Scope of a read of the table on stream s (constructed with map->mtx held, destroyed before it is released): whatever path leaves the
+// scope -- every SV_HIP early return included -- the read is recorded for the writers; a path that did not reach end() also drains the stream,
+// so nothing it enqueued still reads the table when the caller sees the error.
+struct SvMapReadScope {
+    svgpu_ctx* ctx;
+    svgpu_map* map;
+    hipStream_t s;
+    bool open = false;
+    SvMapReadScope(svgpu_ctx* c, svgpu_map* m, hipStream_t st) : ctx(c), map(m), s(st) {}
+    int begin() {
+        const int rc = sv_map_reader_begin(ctx, map, s);
+        open = rc == 0;
+        return rc;
+    }
+    int end() {
+        open = false;
+        return sv_map_reader_end(ctx, map, s);
+    }
+    ~SvMapReadScope() {
+        if (open) {
+            (void)sv_map_reader_end(ctx, map, s);
+            (void)hipStreamSynchronize(s);
+        }
+    }
+    SvMapReadScope(const SvMapReadScope&) = delete;
+    SvMapReadScope& operator=(const SvMapReadScope&) = delete;
+};
 
 struct svgpu_ctx {
     int device = 0;

@@ -35,6 +35,15 @@ __global__ __launch_bounds__(256) void k_map_gather(const uint32_t* __restrict__
     out[k] = id < (uint32_t)cap ? table[(size_t)id * 6 + part] : make_uint4(0, 0, 0, 0);
 }
 
+// stream s waits for every read recorded since the last writer did (mutex held).  An event may be re-recorded once a wait on it has been
+// enqueued (the wait refers to the record that preceded it), so the events go back to the pool right away.
+int map_wait_readers(svgpu_ctx* ctx, svgpu_map* m, hipStream_t s) {
+    for (hipEvent_t e : m->reads_pending) SV_HIP(ctx, hipStreamWaitEvent(s, e, 0));
+    m->reads_pool.insert(m->reads_pool.end(), m->reads_pending.begin(), m->reads_pending.end());
+    m->reads_pending.clear();
+    return SVGPU_OK;
+}
+
 // grows the table to hold `need` records (contents kept); waits for every stream that may still touch the old allocation
 int map_grow(svgpu_ctx* ctx, svgpu_map* m, int need) {
     if (need <= m->cap) return SVGPU_OK;
@@ -45,7 +54,13 @@ int map_grow(svgpu_ctx* ctx, svgpu_map* m, int need) {
     SV_HIP(ctx, hipMalloc((void**)&fresh, cap * sizeof(svgpu_landmark_record)));
     hipStream_t s = ctx->stream;
     if (m->wrote) SV_HIP(ctx, hipStreamWaitEvent(s, m->ev_write, 0));
-    if (m->read) SV_HIP(ctx, hipStreamWaitEvent(s, m->ev_read, 0));
+    {
+        const int rcw = map_wait_readers(ctx, m, s);
+        if (rcw) {
+            (void)hipFree(fresh);
+            return rcw;
+        }
+    }
     if (m->cap > 0) SV_HIP(ctx, hipMemcpyAsync(fresh, m->rec, (size_t)m->cap * sizeof(svgpu_landmark_record), hipMemcpyDeviceToDevice, s));
     SV_HIP(ctx, hipMemsetAsync(fresh + m->cap, 0, (cap - (size_t)m->cap) * sizeof(svgpu_landmark_record), s));
     SV_HIP(ctx, hipStreamSynchronize(s));  // the old table is free of readers and writers from here on
@@ -61,8 +76,26 @@ int sv_map_reader_begin(svgpu_ctx* ctx, svgpu_map* m, hipStream_t s) {
     return SVGPU_OK;
 }
 int sv_map_reader_end(svgpu_ctx* ctx, svgpu_map* m, hipStream_t s) {
-    SV_HIP(ctx, hipEventRecord(m->ev_read, s));
-    m->read = true;
+    if (m->reads_pending.size() >= 64) {  // a long stretch of reads without a write: forget the ones that have completed
+        size_t kept = 0;
+        for (hipEvent_t e : m->reads_pending) {
+            if (hipEventQuery(e) == hipSuccess) m->reads_pool.push_back(e);
+            else m->reads_pending[kept++] = e;
+        }
+        m->reads_pending.resize(kept);
+    }
+    hipEvent_t e = nullptr;
+    if (!m->reads_pool.empty()) {
+        e = m->reads_pool.back();
+        m->reads_pool.pop_back();
+    }
+    else SV_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const hipError_t err = hipEventRecord(e, s);
+    if (err != hipSuccess) {
+        m->reads_pool.push_back(e);
+        return sv_set_error(ctx, SVGPU_ERR_HIP, "hipEventRecord(read event)", err);
+    }
+    m->reads_pending.push_back(e);
     return SVGPU_OK;
 }
 
@@ -74,7 +107,7 @@ int svgpu_map_create(svgpu_ctx* ctx, svgpu_map** out) {
     svgpu_map* m = new (std::nothrow) svgpu_map();
     if (!m) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_map_create: out of memory");
     m->device = ctx->device;
-    if (hipEventCreateWithFlags(&m->ev_write, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&m->ev_read, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&m->ev_write, hipEventDisableTiming) != hipSuccess) {
         svgpu_map_destroy(m);
         return sv_set_error(ctx, SVGPU_ERR_HIP, "svgpu_map_create: hipEventCreate");
     }
@@ -89,10 +122,11 @@ void svgpu_map_destroy(svgpu_map* m) {
         if (m->wrote) (void)hipEventSynchronize(m->ev_write);
         (void)hipEventDestroy(m->ev_write);
     }
-    if (m->ev_read) {
-        if (m->read) (void)hipEventSynchronize(m->ev_read);
-        (void)hipEventDestroy(m->ev_read);
+    for (hipEvent_t e : m->reads_pending) {
+        (void)hipEventSynchronize(e);
+        (void)hipEventDestroy(e);
     }
+    for (hipEvent_t e : m->reads_pool) (void)hipEventDestroy(e);
     if (m->rec) (void)hipFree(m->rec);
     delete m;
 }
@@ -140,7 +174,7 @@ int svgpu_map_upsert(svgpu_ctx* ctx, svgpu_map* m, int n, const uint32_t* ids, c
         }
     }
     hipStream_t s = ctx->stream;
-    if (m->read) SV_HIP(ctx, hipStreamWaitEvent(s, m->ev_read, 0));
+    if ((rc = map_wait_readers(ctx, m, s))) return rc;
     if (m->wrote) SV_HIP(ctx, hipStreamWaitEvent(s, m->ev_write, 0));
     char* d = (char*)ctx->d_scratch;
     SV_HIP(ctx, hipMemcpyAsync(d, ctx->h_stage, o_rec + (size_t)kept * sizeof(svgpu_landmark_record), hipMemcpyHostToDevice, s));
@@ -164,7 +198,7 @@ int svgpu_map_erase(svgpu_ctx* ctx, svgpu_map* m, int n, const uint32_t* ids) {
     if ((rc = sv_ensure_scratch(ctx, (size_t)n * 4))) return rc;
     memcpy(ctx->h_stage, ids, (size_t)n * 4);
     hipStream_t s = ctx->stream;
-    if (m->read) SV_HIP(ctx, hipStreamWaitEvent(s, m->ev_read, 0));
+    if ((rc = map_wait_readers(ctx, m, s))) return rc;
     if (m->wrote) SV_HIP(ctx, hipStreamWaitEvent(s, m->ev_write, 0));
     SV_HIP(ctx, hipMemcpyAsync(ctx->d_scratch, ctx->h_stage, (size_t)n * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_map_erase, dim3((n + 255) / 256), dim3(256), 0, s, (const uint32_t*)ctx->d_scratch, n, m->rec, m->cap);
@@ -188,13 +222,14 @@ int svgpu_map_download(svgpu_ctx* ctx, const svgpu_map* cm, int n, const uint32_
     if ((rc = sv_ensure_scratch(ctx, total))) return rc;
     memcpy(ctx->h_stage, ids, (size_t)n * 4);
     hipStream_t s = ctx->stream;
-    if ((rc = sv_map_reader_begin(ctx, m, s))) return rc;
+    SvMapReadScope scope(ctx, m, s);
+    if ((rc = scope.begin())) return rc;
     char* d = (char*)ctx->d_scratch;
     SV_HIP(ctx, hipMemcpyAsync(d, ctx->h_stage, (size_t)n * 4, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_map_gather, dim3((n * 6 + 255) / 256), dim3(256), 0, s, (const uint32_t*)d, n, (const uint4*)m->rec, m->cap, (uint4*)(d + o_rec));
     SV_HIP(ctx, hipGetLastError());
     SV_HIP(ctx, hipMemcpyAsync(ctx->h_stage + o_rec, d + o_rec, (size_t)n * sizeof(svgpu_landmark_record), hipMemcpyDeviceToHost, s));
-    if ((rc = sv_map_reader_end(ctx, m, s))) return rc;
+    if ((rc = scope.end())) return rc;
     SV_HIP(ctx, hipStreamSynchronize(s));
     memcpy(records, ctx->h_stage + o_rec, (size_t)n * sizeof(svgpu_landmark_record));
     return SVGPU_OK;

@@ -321,8 +321,7 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
     if (img && (!C.configured || stride < C.width)) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_track_motion: fused extraction needs svgpu_orb_configure on the tracker's context");
     if (!img && (cur->grid_cols != t->cfg.grid_cols || cur->grid_rows != t->cfg.grid_rows))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: the current frame was binned over another grid");
-    for (int i = 0; i < last->n; ++i)
-        if (last_lm_ids[i] >= (1 << 30)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: landmark id beyond 2^30");
+    // (landmark ids are validated where they are used: k_track_cand treats an id outside [0, map capacity) as "no landmark")
     SV_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int n_last = last->n, ncell = t->cfg.grid_cols * t->cfg.grid_rows;
@@ -358,7 +357,8 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
         if (n_last > 0) memcpy(t->h_in + o_ids, last_lm_ids, (size_t)n_last * 4);
         std::unique_lock<std::mutex> lock(t->map->mtx);
         if (t->map->cap == 0) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: the map is empty");
-        if ((rc = sv_map_reader_begin(ctx, t->map, s))) return rc;
+        SvMapReadScope reading(ctx, t->map, s);  // (declared behind the lock: every exit path records the read before the mutex is released)
+        if ((rc = reading.begin())) return rc;
         if (extract) SV_HIP(ctx, hipMemcpyAsync(t->d_in, t->h_in, o_ids + (size_t)n_last * 4, hipMemcpyHostToDevice, s));
         else if (n_last > 0) SV_HIP(ctx, hipMemcpyAsync(t->d_in + o_ids, t->h_in + o_ids, (size_t)n_last * 4, hipMemcpyHostToDevice, s));
         t->launches += 1;
@@ -417,7 +417,7 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
                 t->launches += 1;
             }
         }
-        if ((rc = sv_map_reader_end(ctx, t->map, s))) return rc;
+        if ((rc = reading.end())) return rc;
         lock.unlock();
         SV_HIP(ctx, hipStreamSynchronize(s));
         t->syncs += 1;
@@ -473,7 +473,8 @@ int svgpu_track_local_map(svgpu_tracker* t, const svgpu_frame* cur, const int32_
         if (n_local > 0) memcpy(t->h_in + o_loc, local_ids, (size_t)n_local * 4);
         std::unique_lock<std::mutex> lock(t->map->mtx);
         if (t->map->cap == 0) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_local_map: the map is empty");
-        if ((rc = sv_map_reader_begin(ctx, t->map, s))) return rc;
+        SvMapReadScope reading(ctx, t->map, s);
+        if ((rc = reading.begin())) return rc;
         SV_HIP(ctx, hipMemcpyAsync(t->d_in + o_cur, t->h_in + o_cur, (o_loc - o_cur) + (size_t)n_local * 4, hipMemcpyHostToDevice, s));
         t->launches += 1;
         TrackCandProblem Cd{};
@@ -487,7 +488,7 @@ int svgpu_track_local_map(svgpu_tracker* t, const svgpu_frame* cur, const int32_
         rc = enqueue_match_and_optimize(t, s, Cd, cur, nt, nullptr, (int32_t*)(t->d_in + o_cur), 0, (const int32_t*)(t->d_in + o_loc), n_local,
                                         100u /* HAMMING_DIST_THR_HIGH */, lowe_ratio, SVGPU_MATCH_RATIO_SAME_OCTAVE, pose_cw);
         if (rc) return rc;
-        if ((rc = sv_map_reader_end(ctx, t->map, s))) return rc;
+        if ((rc = reading.end())) return rc;
         lock.unlock();
         SV_HIP(ctx, hipStreamSynchronize(s));
         t->syncs += 1;

@@ -20,15 +20,15 @@ struct mirror_state {
     std::vector<uint32_t> dirty;
     svgpu_map* map = nullptr;
     svgpu_ctx* map_ctx = nullptr;  // (the context the table was created on: only its device matters)
-    std::vector<uint32_t> up_ids;  // flush scratch
+    std::mutex upload_mtx;         // one flush uploads at a time: batches reach the table in the order their records were copied
+    std::vector<uint32_t> up_ids;  // flush scratch (under upload_mtx)
     std::vector<svgpu_landmark_record> up_rec;
-    ~mirror_state() {
-        if (map) svgpu_map_destroy(map);
-    }
 };
+// Leaked on purpose (as frame_pool is): a function-local static would destroy the table -- hipEventSynchronize, hipFree -- during static
+// destruction, possibly after the HIP runtime has been torn down.  release_map() is the explicit shutdown.
 mirror_state& mirror() {
-    static mirror_state s;
-    return s;
+    static mirror_state* s = new mirror_state();
+    return *s;
 }
 // (called with the mutex held)
 svgpu_landmark_record& touch(mirror_state& M, unsigned int id) {
@@ -96,24 +96,47 @@ void landmark_erased(unsigned int id) {
 
 svgpu_map* flush_map(svgpu_ctx* ctx) {
     mirror_state& M = mirror();
-    std::lock_guard<std::mutex> lock(M.mtx);  // (held across the upload: a record must not change between its copy and its dirty mark)
-    if (!M.map) {
-        check(svgpu_map_create(ctx, &M.map), "svgpu_map_create");
-        M.map_ctx = ctx;
+    // Two locks: the mirror's is held only while the dirty records are COPIED (every data::landmark mutator takes it under its own landmark
+    // mutex: an upload of thousands of records after a BA write-back -- a copy, a kernel and a stream synchronisation -- must not stall the
+    // mapping, loop-closing and tracking threads behind it); the upload lock keeps the batches in copy order, so a record changed again
+    // during the upload is dirty again and its newer copy reaches the table with the NEXT flush, never before this one.
+    std::lock_guard<std::mutex> uploading(M.upload_mtx);
+    size_t n = 0;
+    svgpu_map* map = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(M.mtx);
+        if (!M.map) {
+            check(svgpu_map_create(ctx, &M.map), "svgpu_map_create");
+            M.map_ctx = ctx;
+        }
+        map = M.map;
+        n = M.dirty.size();
+        M.up_ids.resize(n);
+        M.up_rec.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t id = M.dirty[i];
+            M.up_ids[i] = id;
+            M.up_rec[i] = M.shadow[id];
+            M.is_dirty[id] = 0;
+        }
+        M.dirty.clear();
     }
-    if (M.dirty.empty()) return M.map;
-    const size_t n = M.dirty.size();
-    M.up_ids.resize(n);
-    M.up_rec.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t id = M.dirty[i];
-        M.up_ids[i] = id;
-        M.up_rec[i] = M.shadow[id];
-        M.is_dirty[id] = 0;
-    }
+    if (n > 0) check(svgpu_map_upsert(ctx, map, (int)n, M.up_ids.data(), M.up_rec.data()), "svgpu_map_upsert");
+    return map;
+}
+void release_map() {
+    mirror_state& M = mirror();
+    std::lock_guard<std::mutex> uploading(M.upload_mtx);
+    std::lock_guard<std::mutex> lock(M.mtx);
+    if (M.map) svgpu_map_destroy(M.map);
+    M.map = nullptr;
+    M.map_ctx = nullptr;
+    // every record the shadow holds is dirty again for a table created later
     M.dirty.clear();
-    check(svgpu_map_upsert(ctx, M.map, (int)n, M.up_ids.data(), M.up_rec.data()), "svgpu_map_upsert");
-    return M.map;
+    for (size_t id = 0; id < M.shadow.size(); ++id) {
+        M.is_dirty[id] = M.shadow[id].flags ? 1 : 0;
+        if (M.is_dirty[id]) M.dirty.push_back((uint32_t)id);
+    }
 }
 size_t pending_map_updates() {
     mirror_state& M = mirror();
@@ -197,14 +220,27 @@ namespace {
 // system.cc:403-404: the frame of a freshly built observation.  data::frame sizes its (private) landmark vector in its constructor -- from
 // the keypoint count alone, so it is constructed from a stub with that many keypoints (the constructor copies its observation twice:
 // 400 KB for a 2 400-keypoint frame) and the observation itself is MOVED into the public frm_obs_ afterwards.
+// What the constructor does not take is carried over: the reference keyframe (tracking_module.cc:202 sets it BEFORE track_current_frame; the
+// BoW fallback of a failed motion track dereferences it, :346), the BoW vectors and a pose somebody already set.
 void rebuild_frame(data::frame& frm, data::frame_observation& frm_obs) {
     data::frame_observation stub;
     stub.undist_keypts_.resize(frm_obs.undist_keypts_.size());
+    auto ref_keyfrm = frm.ref_keyfrm_;
+    auto bow_feat_vec = std::move(frm.bow_feat_vec_);
 #ifdef SVGPU_WITH_STELLA_VSLAM
+    auto bow_vec = std::move(frm.bow_vec_);
+    const bool had_pose = frm.pose_is_valid();
+    const Mat44_t pose = had_pose ? frm.get_pose_cw() : Mat44_t::Identity();
     frm = data::frame(frm.id_, frm.timestamp_, frm.camera_, const_cast<feature::orb_params*>(frm.orb_params_), stub, frm.markers_2d_);
+    frm.bow_vec_ = std::move(bow_vec);
+    if (had_pose) frm.set_pose_cw(pose);
 #else
+    const Mat44_t pose = frm.get_pose_cw();
     frm = data::frame(frm.id_, frm.camera_, frm.orb_params_, stub);
+    frm.set_pose_cw(pose);
 #endif
+    frm.ref_keyfrm_ = ref_keyfrm;
+    frm.bow_feat_vec_ = std::move(bow_feat_vec);
     frm.frm_obs_ = std::move(frm_obs);
 }
 }  // namespace
@@ -288,9 +324,12 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
         if (num_matches >= num_matches_thr) break;  // else: increment the margin, and search again (:36-40)
     }
     curr_frm.set_pose_cw(guess);
+    device_pose_valid_ = false;
     if (num_matches < num_matches_thr) return false;
     // Pose optimization (:48-51) -- already done behind the matcher, on the device
     curr_frm.set_pose_cw(pose44(last_motion_.pose_cw));
+    device_pose_valid_ = true;  // the tracker's device pose is this frame's pose -- as long as nobody sets another one (track_local_map checks)
+    device_pose_frame_ = curr_frm.id_;
     // Discard the outliers (:54, :133-151)
     unsigned int num_valid_matches = 0;
     const unsigned int n = (unsigned int)curr_frm.frm_obs_.undist_keypts_.size();
@@ -352,9 +391,16 @@ bool tracked_frame_chain::track_local_map(data::frame& curr_frm, const std::vect
     T.lap("local landmark ids");
     flush_map(ctx_);
     T.lap("flush_map");
-    check(svgpu_track_local_map(tracker_, cur_h.get(), cur_ids_.data(), n_local, local_ids_.data(), nullptr /* the first half's pose, still on the device */, margin,
+    // The pose: the one the first half left on the device ONLY if it is still this frame's pose.  When motion_based_track failed (or was
+    // skipped: no valid motion model, the first frame after initialisation) the reference falls back to the BoW / robust trackers, which set
+    // the pose through the per-call pose optimizer; the device then holds a stale one (or none at all) and the frame's own pose goes down.
+    double pose12_cw[12];
+    pose12(curr_frm.get_pose_cw(), pose12_cw);
+    const bool device_pose_is_current = device_pose_valid_ && device_pose_frame_ == curr_frm.id_ && std::memcmp(pose12_cw, last_motion_.pose_cw, sizeof pose12_cw) == 0;
+    check(svgpu_track_local_map(tracker_, cur_h.get(), cur_ids_.data(), n_local, local_ids_.data(), device_pose_is_current ? nullptr : pose12_cw, margin,
                                 lowe_ratio, 0.5f, match_.data(), visible_.data(), outlier_.data(), &last_local_),
           "svgpu_track_local_map");
+    device_pose_valid_ = false;  // (the second half's optimisation overwrote it)
     T.lap("svgpu_track_local_map");
     bool found_proj_candidate = false;
     for (int i = 0; i < n_local; ++i)

@@ -15,6 +15,9 @@ namespace hip {
 svgpu_map* flush_map(svgpu_ctx* ctx);
 //! number of landmarks whose record is waiting for the next flush (diagnostics / tests)
 size_t pending_map_updates();
+// explicit shutdown: destroys the device table (the mirror itself is never destroyed: no HIP call during static destruction); a later
+// flush_map creates a fresh table and uploads every live record again
+void release_map();
 
 //! One per tracking thread (tracking_module owns it next to frame_tracker_).
 class tracked_frame_chain {
@@ -71,6 +74,8 @@ private:
     frame_handle handle_of(const data::frame& frm);
     void remember(unsigned int frame_id, const frame_handle& h);
     uint32_t frame_serial_ = 0;
+    bool device_pose_valid_ = false;       // the tracker's device pose is the pose motion_based_track gave frame device_pose_frame_
+    unsigned int device_pose_frame_ = 0;
     std::vector<uint32_t> held_stamp_;  // per landmark id: serial of the frame that holds it (curr_landmark_ids of :536-551 without a hash set)
 };
 

@@ -426,6 +426,7 @@ public:
     const feature::orb_params* orb_params_;
     frame_observation frm_obs_;
     bow_feature_vector bow_feat_vec_;
+    std::shared_ptr<keyframe> ref_keyfrm_ = nullptr;  // data/frame.h:183 (set by tracking_module.cc:202 before track_current_frame)
     std::vector<std::shared_ptr<landmark>> landmarks_;
 
 private:

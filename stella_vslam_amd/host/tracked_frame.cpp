@@ -296,3 +296,114 @@ extern "C" void svgpu_host_tracked_frame_counters(double* launches_per_frame, do
     if (launches_per_frame) *launches_per_frame = g_chain_launches;
     if (host_syncs_per_frame) *host_syncs_per_frame = g_chain_syncs;
 }
+
+// The paths around a FAILED (or skipped) motion track (tracking_module.cc:326-370): tracking_module falls back to the BoW / robust
+// trackers, which give the frame another pose through the per-call pose optimizer, and then calls track_local_map.  The chain's second half must
+// start from THAT pose, not from whatever its first half left on the device.  Three runs of track_local_map on the same frame state:
+//   A  chain whose motion_based_track just FAILED (num_matches_thr beyond reach; the device holds the failed attempt's optimised pose),
+//      the frame's pose then set to `fallback` by hand
+//   B  a fresh chain that never ran its first half (the first frame after initialisation: nothing on the device)
+//   C  chain A again after a SUCCESSFUL motion track whose pose the caller then replaced by `fallback`
+// All three must return the same matches / inliers / pose bits; the frame's ref_keyfrm_ must survive the fused extraction's frame rebuild.
+// out[8] = {ok flags (bit 0 A, 1 B, 2 C), matches A, inliers A, matches B, inliers B, matches C, inliers C, ref_keyfrm_ survived}; returns 0 or -1.
+extern "C" int svgpu_host_chain_fallback_test(const uint8_t* imgs, int n_frames, int w, int h, int* out, double* poses36) {
+    try {
+        if (!imgs || n_frames < 3 || !out || !poses36) return -1;
+        Scene S(w, h);
+        stella_vslam_hip::feature::orb_params hp("tracked");
+        stella_vslam_hip::feature::orb_extractor ext(&hp, 800);
+        std::vector<kf_ptr> kfs;
+        std::vector<lm_ptr> all_lms;
+        unsigned next_lm = 700000u;  // (ids of their own: the landmark table is process-wide)
+        for (int t = 0; t < n_frames - 1; ++t) {
+            auto kf = std::make_shared<data::keyframe>(7000u + (unsigned)t, &S.cam, &S.orb);
+            kf->set_pose_cw(S.pose(t));
+            std::vector<cv::KeyPoint> kps;
+            cv::Mat im(h, w, CV_8U, const_cast<uint8_t*>(imgs + (size_t)t * w * h), (size_t)w);
+            ext.extract(im, cv::Mat(), kps, kf->frm_obs_.descriptors_);
+            stella_vslam::hip::adopt_extraction(910000u + t, ext.context(), &S.cam, 64, 48, kf->frm_obs_.undist_keypts_, kf->frm_obs_.bearings_);
+            const int n = (int)kf->frm_obs_.undist_keypts_.size();
+            kf->landmarks_.assign(n, nullptr);
+            for (int i = 0; i < n; ++i) {
+                const auto& kp = kf->frm_obs_.undist_keypts_[i];
+                auto lm = std::make_shared<data::landmark>(next_lm++, S.backproject(t, kp.pt.x, kp.pt.y));
+                lm->add_observation(kf, (unsigned)i);
+                lm->ref_keyfrm_ = kf;
+                kf->landmarks_[i] = lm;
+                all_lms.push_back(lm);
+            }
+            kfs.push_back(kf);
+        }
+        for (auto& lm : all_lms) {
+            lm->compute_descriptor();
+            lm->update_mean_normal_and_obs_scale_variance();
+        }
+        const kf_ptr& lastkf = kfs.back();
+        data::frame last_frm(510000u, &S.cam, &S.orb);
+        last_frm.frm_obs_ = lastkf->frm_obs_;
+        last_frm.landmarks_ = lastkf->landmarks_;
+        last_frm.set_pose_cw(S.pose(n_frames - 2));
+        std::vector<lm_ptr> local_lms;
+        for (size_t k = 0; k + 1 < kfs.size(); ++k)
+            for (auto& lm : kfs[k]->landmarks_) local_lms.push_back(lm);
+        Mat44_t guess = S.pose(n_frames - 1);
+        guess(0, 3) += 0.004, guess(1, 3) -= 0.003, guess(2, 3) += 0.002;
+        Mat44_t last_inv = Mat44_t::Identity();
+        for (int i = 0; i < 3; ++i) last_inv(i, 3) = -last_frm.get_pose_cw()(i, 3);
+        const Mat44_t velocity = guess * last_inv;
+        Mat44_t fallback = S.pose(n_frames - 1);  // what a BoW / robust tracker would have left: a pose of its own, 2 cm off the motion model's
+        fallback(0, 3) -= 0.02, fallback(1, 3) += 0.015;
+        cv::Mat im(h, w, CV_8U, const_cast<uint8_t*>(imgs + (size_t)(n_frames - 1) * w * h), (size_t)w);
+        for (int k = 0; k < 8; ++k) out[k] = 0;
+        auto second_half = [&](stella_vslam::hip::tracked_frame_chain& chain, data::frame& frm, int slot) {
+            frm.erase_landmarks();            // (the fallback trackers rebuild the frame's matches; the same empty state in all three runs)
+            frm.set_pose_cw(fallback);
+            const bool ok = chain.track_local_map(frm, local_lms, 0, 5.0f, 0.8f);
+            out[0] |= ok ? (1 << slot) : 0;
+            out[1 + 2 * slot] = chain.last_local_.num_matches;
+            out[2 + 2 * slot] = chain.last_local_.num_valid;
+            const Mat44_t P = frm.get_pose_cw();
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 4; ++j) poses36[12 * slot + 4 * i + j] = P(i, j);
+        };
+        const kf_ptr ref = kfs.front();
+        std::vector<cv::KeyPoint> kps;
+        {   // A: the first half fails
+            stella_vslam::hip::tracked_frame_chain chain(ext.context(), &S.cam, &S.orb, 64, 48);
+            data::frame cur(2001u, &S.cam, &S.orb);
+            cur.ref_keyfrm_ = ref;
+            const bool ok1 = chain.motion_based_track(cur, last_frm, velocity, 1000000u, 20.0f, &im, &kps);
+            if (ok1) {
+                std::fprintf(stderr, "svgpu_host_chain_fallback_test: the motion track was meant to fail\n");
+                return -1;
+            }
+            out[7] = cur.ref_keyfrm_ == ref ? 1 : 0;
+            second_half(chain, cur, 0);
+            // C: the same chain, a motion track that succeeds, then a caller that replaces its pose
+            data::frame cur2(2002u, &S.cam, &S.orb);
+            cur2.ref_keyfrm_ = ref;
+            if (!chain.motion_based_track(cur2, last_frm, velocity, 20, 20.0f, &im, &kps)) {
+                std::fprintf(stderr, "svgpu_host_chain_fallback_test: the motion track was meant to succeed\n");
+                return -1;
+            }
+            out[7] &= cur2.ref_keyfrm_ == ref ? 1 : 0;
+            second_half(chain, cur2, 2);
+            stella_vslam::hip::forget_frame(2001u);
+            stella_vslam::hip::forget_frame(2002u);
+        }
+        {   // B: a chain that never ran its first half; the frame comes from the per-call path
+            stella_vslam::hip::tracked_frame_chain chain(ext.context(), &S.cam, &S.orb, 64, 48);
+            data::frame cur(2003u, &S.cam, &S.orb);
+            ext.extract(im, cv::Mat(), kps, cur.frm_obs_.descriptors_);
+            stella_vslam::hip::adopt_extraction(2003u, ext.context(), &S.cam, 64, 48, cur.frm_obs_.undist_keypts_, cur.frm_obs_.bearings_);
+            cur.landmarks_.assign(cur.frm_obs_.undist_keypts_.size(), nullptr);
+            second_half(chain, cur, 1);
+            stella_vslam::hip::forget_frame(2003u);
+        }
+        return 0;
+    }
+    catch (const std::exception& e) {
+        std::fprintf(stderr, "svgpu_host_chain_fallback_test: %s\n", e.what());
+        return -1;
+    }
+}

@@ -62,3 +62,30 @@ def test_tracked_frame_chain_equals_the_per_call_drop_in_classes():
     launches, syncs = C.c_double(0), C.c_double(0)
     host.svgpu_host_tracked_frame_counters(C.byref(launches), C.byref(syncs))
     assert syncs.value == 2.0 and launches.value <= 15.0
+
+
+@pytest.mark.gpu
+def test_chain_second_half_after_a_failed_or_skipped_motion_track():
+    """tracking_module's fallback paths (tracking_module.cc:326-370): motion_based_track fails or is skipped, another tracker sets the frame's
+    pose, then track_local_map runs.  The chain's second half must start from the FRAME's pose: the same matches, inliers and pose bits whether
+    the device holds the failed attempt's pose, a successful attempt's pose the caller replaced, or nothing at all (first frame after
+    initialisation).  The fused extraction's frame rebuild keeps ref_keyfrm_ (dereferenced by the BoW fallback, :346)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from stella_vslam_amd import synthetic
+    host = C.CDLL(str(ROOT / "stella_vslam_amd" / "host" / "libsvgpu_host.so"))
+    seq = np.ascontiguousarray(synthetic.frame_sequence(4, 640, 480, seed=0x5EED))
+    out, poses = np.zeros(8, np.int32), np.zeros(36)
+    rc = host.svgpu_host_chain_fallback_test(C.c_void_p(seq.ctypes.data), len(seq), 640, 480, C.c_void_p(out.ctypes.data), C.c_void_p(poses.ctypes.data))
+    assert rc == 0
+    assert out[0] == 7, out            # all three second halves tracked
+    assert out[7] == 1                 # ref_keyfrm_ survived the rebuild
+    assert out[1] > 500 and out[2] > 400, out
+    assert out[1] == out[3] == out[5] and out[2] == out[4] == out[6], out
+    P = poses.reshape(3, 12)
+    assert np.array_equal(P[0], P[1]) and np.array_equal(P[0], P[2])
+    # ... and it is a pose of this frame: the scene's true translation to a few millimetres (the fallback pose was 2 cm off)
+    gt = np.array([-3 * 3.0 * 5.0 / 500.0, -3 * 1.0 * 5.0 / 500.0, 0.0])
+    assert np.abs(P[0].reshape(3, 4)[:, 3] - gt).max() < 5e-3

@@ -346,6 +346,69 @@ def test_table_written_by_the_mapping_thread_while_the_tracking_thread_reads(ctx
     assert W.table.capacity > len(W.ids) * 3     # it did move while the frames ran
 
 
+def test_two_readers_on_two_streams_and_a_growing_writer(ctx):
+    """Two trackers on two contexts (= two streams: the two cameras of a rig, or a relocaliser beside the tracker) read the table while a third
+    context keeps writing and GROWING it.  The table keeps one read event per read a writer has not yet waited for (round 4 kept ONE event: the
+    later reader overwrote the earlier one's record and a growth could free the table under it).  Every frame of both readers returns the
+    bits of the quiet run; a download on the second reader's context joins the reads."""
+    import threading
+    from stella_vslam_amd import data, feature, tracking
+    W = _World(ctx, 3, False)
+    quiet = W.tracker.track_motion(W.rf_cur, W.rf_last, W.last_ids, W.guess, W.pose_last, 20.0)
+    cur_lm = np.where(quiet["outlier"] == 1, -1, _oracle_motion(W, 20.0)["cur_lm"]).astype(np.int32)
+    local_ids = np.array([i for i in W.ids if int(i) not in set(cur_lm[cur_lm >= 0].tolist())], np.int32)
+    quiet2 = W.tracker.track_local_map(W.rf_cur, cur_lm, local_ids, 5.0, 0.8, 0.5)
+    ctx_r2, ctx_w = feature.Context(), feature.Context()
+    T = W.T
+    tracker2 = tracking.tracker(ctx_r2, W.table, W.cam, T["scale_factors"], T["inv_level_sigma_sq"], T["log_scale_factor"], is_monocular=True, true_baseline=0.11)
+    rf_last2 = data.resident_frame(ctx_r2).upload(W.cam, _records(W.last), W.last["desc"], None)
+    rf_cur2 = data.resident_frame(ctx_r2).upload(W.cam, _records(W.cur), W.cur["desc"], None)
+    rec_quiet = W.table.download(W.ids[:64], ctx=ctx_r2)
+    stop, err = threading.Event(), []
+    far = tracking.landmark_records(np.full((1, 3), 1e6), np.array([[0.0, 0.0, 1.0]]), np.array([1.0], np.float32), np.array([2.0], np.float32), np.zeros((1, 32), np.uint8))
+
+    def writer():
+        try:
+            k, cap = 0, W.table.capacity
+            while not stop.is_set():
+                W.table.upsert(W.ids, W.rec, ctx=ctx_w)
+                k += 1
+                if k % 5 == 0:
+                    cap = max(cap, W.table.capacity) * 2
+                    if cap < (1 << 22):
+                        W.table.upsert(np.array([cap + 11], np.uint32), far, ctx=ctx_w)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    def reader(trk, rf_cur, rf_last, with_download):
+        try:
+            for i in range(150):
+                a = trk.track_motion(rf_cur, rf_last, W.last_ids, W.guess, W.pose_last, 20.0)
+                assert np.array_equal(a["match_last"], quiet["match_last"]) and np.array_equal(a["outlier"], quiet["outlier"])
+                assert np.array_equal(a["result"]["pose_cw"], quiet["result"]["pose_cw"])
+                b = trk.track_local_map(rf_cur, cur_lm, local_ids, 5.0, 0.8, 0.5)
+                assert np.array_equal(b["match_local"], quiet2["match_local"]) and np.array_equal(b["visible"], quiet2["visible"])
+                assert np.array_equal(b["result"]["pose_cw"], quiet2["result"]["pose_cw"])
+                if with_download and i % 10 == 0:
+                    assert W.table.download(W.ids[:64], ctx=ctx_r2).tobytes() == rec_quiet.tobytes()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+            stop.set()
+
+    tw = threading.Thread(target=writer)
+    t2 = threading.Thread(target=reader, args=(tracker2, rf_cur2, rf_last2, True))
+    tw.start()
+    t2.start()
+    try:
+        reader(W.tracker, W.rf_cur, W.rf_last, False)
+    finally:
+        t2.join(timeout=120)
+        stop.set()
+        tw.join(timeout=60)
+    assert not err, err
+    assert W.table.capacity > len(W.ids) * 3     # it did move while the frames ran
+
+
 def test_candidate_lists_beyond_the_first_capacity(ctx):
     """more list entries than the tracker's initial capacity (65 536): the chain notices on the device, the host grows and re-runs"""
     W = _World(ctx, 8, False, n_lm=6000, n_extra=2000)
