@@ -8,7 +8,8 @@
 #include <vector>
 
 #include "stella_vslam/camera/base.h"
-#ifdef SVREF_DROP_IN
+#if defined(SVREF_DROP_IN) || defined(SVREF_CAMERA_PARAMS)
+#define SVREF_ANY_MODEL 1  // the camera carries its parameter members (shim_mdrop/): the product's camera conversion and the reference's BA edges read them
 #include "stella_vslam/camera/any_model.h"
 #endif
 #include "stella_vslam/data/frame.h"
@@ -55,7 +56,7 @@ inline Mat44_t pose44(const double* rot_row_major, const double* trans) {
     return T;
 }
 
-#ifdef SVREF_DROP_IN
+#ifdef SVREF_ANY_MODEL
 using camera_parent = camera::any_model;  // shim_mdrop/: carries the parameter members the product's camera conversion reads
 #else
 using camera_parent = camera::base;
@@ -67,7 +68,7 @@ public:
                        (unsigned)c->rows, c->focal_x_baseline, true_baseline),
           oc_(*c) {
         img_bounds_.min_x_ = c->min_x, img_bounds_.max_x_ = c->max_x, img_bounds_.min_y_ = c->min_y, img_bounds_.max_y_ = c->max_y;
-#ifdef SVREF_DROP_IN
+#ifdef SVREF_ANY_MODEL
         fx_ = c->fx, fy_ = c->fy, cx_ = c->cx, cy_ = c->cy;
         if (c->model == 0) k1_ = c->dist[0], k2_ = c->dist[1], p1_ = c->dist[2], p2_ = c->dist[3], k3_ = c->dist[4];
         if (c->model == 1) k1_ = c->dist[0], k2_ = c->dist[1], k3_ = c->dist[2], k4_ = c->dist[3];

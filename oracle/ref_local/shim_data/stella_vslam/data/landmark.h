@@ -23,6 +23,14 @@ public:
     bool will_be_erased() { return will_be_erased_; }
     bool is_observed_in_keyframe(const std::shared_ptr<keyframe>& keyfrm) const;
     int get_index_in_keyframe(const std::shared_ptr<keyframe>& keyfrm) const;
+    // data/landmark.h:88-92
+    bool is_inside_in_orb_scale(const float cam_to_lm_dist, const float margin_far, const float margin_near) const {
+        const float max_dist = margin_far * max_valid_dist_;
+        const float min_dist = margin_near * min_valid_dist_;
+        return (min_dist <= cam_to_lm_dist && cam_to_lm_dist <= max_dist);
+    }
+    void increase_num_observable(unsigned int num_observable = 1) { num_observable_ += num_observable; }  // :416-419
+    observations_t get_observations() const { return observations_; }
     unsigned int predict_scale_level(const float cam_to_lm_dist, float num_scale_levels, float log_scale_factor) const {
         const float ratio = max_valid_dist_ / cam_to_lm_dist;
         const auto pred_scale_level = static_cast<int>(std::ceil(std::log(ratio) / log_scale_factor));
@@ -36,6 +44,8 @@ public:
     cv::Mat descriptor_;
     bool has_observation_ = true;
     bool will_be_erased_ = false;
+    unsigned int num_observable_ = 1;
+    observations_t observations_;
     // observations as (keyframe id -> keypoint index): enough for is_observed_in_keyframe / get_index_in_keyframe
     std::map<unsigned int, unsigned int> obs_by_keyfrm_id_;
 };

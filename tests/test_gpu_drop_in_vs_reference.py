@@ -345,3 +345,124 @@ def test_stereo_adaptor_against_the_reference_stereo_matcher(disp, noise):
     assert (rxr >= 0).sum() > 500
     np.testing.assert_array_equal(rxr.view(np.uint32), gxr[:nl].view(np.uint32))
     np.testing.assert_array_equal(rdp.view(np.uint32), gdp[:nl].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ the per-frame tracker
+@pytest.fixture(scope="module")
+def tracker_libs():
+    a, b = os.path.join(_DIR, "libsvref_trk.so"), os.path.join(_DIR, "libsvref_tdropin.so")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        pytest.skip("oracle/_ref/libsvref_{trk,tdropin}.so absent: built from /root/reference by `make -C oracle/ref_local` (build container only)")
+    return C.CDLL(a), C.CDLL(b)
+
+
+def _track_both(libs, sc, stereo, thr, margin, seed=1, run_local=1, override=None, local=None, margin_local=5.0, lm_flags=None, guess_off=(0.25, 0.01)):
+    """svref_track_frame of both libraries on the same arrays -> (reference outputs, product outputs)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("match_problems", os.path.join(os.path.dirname(os.path.abspath(__file__)), "match_problems.py"))
+    MP = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(MP)
+    ref, prod = libs
+    cam = MP.make_cams(sc, "oracle")
+    L, (last, cur), T = sc["landmarks"], sc["views"], sc["tables"]
+    n_lm = len(L["pos_w"])
+    rng = np.random.default_rng(100 + seed)
+    has_obs, erased = np.ones(n_lm, np.uint8), np.zeros(n_lm, np.uint8)
+    if lm_flags is None:
+        has_obs[rng.uniform(size=n_lm) < 0.15] = 0
+        erased[rng.uniform(size=n_lm) < 0.03] = 1
+    a = dict(id=(3 * np.arange(n_lm) + 5).astype(np.uint32), pos=np.ascontiguousarray(L["pos_w"], np.float64), nrm=np.ascontiguousarray(L["mean_normal"], np.float64),
+             mn=np.ascontiguousarray(L["min_valid_dist"], np.float32), mx=np.ascontiguousarray(L["max_valid_dist"], np.float32), desc=np.ascontiguousarray(L["desc"], np.uint8),
+             ho=has_obs, er=erased, lo=np.ascontiguousarray(last["octave"], np.int32), la=np.ascontiguousarray(last["angle"], np.float32),
+             ll=np.ascontiguousarray(last["lm"], np.int32), cd=np.ascontiguousarray(cur["desc"], np.uint8), cxy=np.ascontiguousarray(cur["xy"], np.float32),
+             co=np.ascontiguousarray(cur["octave"], np.int32), ca=np.ascontiguousarray(cur["angle"], np.float32),
+             cxr=np.ascontiguousarray(cur["x_right"], np.float32) if stereo else None, cb=np.ascontiguousarray(MP._bearings(sc, cur["xy"]), np.float64))
+    pose_last = np.hstack([last["rot_cw"], last["trans_cw"][:, None]]).astype(np.float64)
+    R, t = MP._perturb(cur["rot_cw"], cur["trans_cw"], np.random.default_rng(seed), *guess_off)
+    G, Lw = np.eye(4), np.eye(4)
+    G[:3, :3], G[:3, 3] = R, t
+    Lw[:3, :] = pose_last
+    velocity = np.ascontiguousarray(G @ np.linalg.inv(Lw), np.float64)
+    local_idx = np.ascontiguousarray(np.arange(n_lm) if local is None else local, np.int32)
+    ov = None if override is None else np.ascontiguousarray(override, np.float64)
+    sf = np.asarray(T["scale_factors"], np.float32)
+    n_last, n_cur = len(a["lo"]), len(a["cd"])
+    outs = []
+    for lib in (ref, prod):
+        o = dict(ret=np.full(2, -9, np.int32), lm1=np.full(n_cur, -9, np.int32), p1=np.zeros(12), lm2=np.full(n_cur, -9, np.int32), p2=np.zeros(12),
+                 nobs=np.zeros(n_lm, np.int32))
+        rc = lib.svref_track_frame(C.byref(cam), int(not stereo), C.c_float(0.11), C.c_float(float(sf[1] / sf[0])), len(sf), 64, 48, n_lm, _p(a["id"]), _p(a["pos"]),
+                                   _p(a["nrm"]), _p(a["mn"]), _p(a["mx"]), _p(a["desc"]), _p(a["ho"]), _p(a["er"]), n_last, _p(a["lo"]), _p(a["la"]), _p(a["ll"]),
+                                   _p(np.ascontiguousarray(pose_last.reshape(12))), n_cur, _p(a["cd"]), _p(a["cxy"]), _p(a["co"]), _p(a["ca"]),
+                                   _p(a["cxr"]) if stereo else None, _p(a["cb"]), _p(velocity), int(thr), C.c_float(margin), int(run_local),
+                                   _p(ov) if ov is not None else None, len(local_idx), _p(local_idx), 0, C.c_float(margin_local), C.c_float(0.8), _p(o["ret"]),
+                                   _p(o["lm1"]), _p(o["p1"]), _p(o["lm2"]), _p(o["p2"]), _p(o["nobs"]))
+        assert rc == 0
+        outs.append(o)
+    return outs[0], outs[1], G
+
+
+def _rel_pose(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("stereo", [False, True])
+def test_chain_vs_reference_tracker(tracker_libs, stereo):
+    """hip::tracked_frame_chain::motion_based_track / track_local_map beside the reference's OWN module/frame_tracker.cc (+ match/projection.cc,
+    optimize/pose_optimizer_g2o.cc; search_local_landmarks / optimize_current_frame_with_local_map restated in the fixture) on identical
+    data::frame / data::landmark objects: the same return values, the same landmark per keypoint of curr_frm after each half (matches AND
+    outlier erasures), the same num_observable marks, poses within 1e-4 -- on the plain path, the 2 x margin retry (frame_tracker.cc:32-36),
+    both num_matches_thr failures (:38-41, :53-56), the local-map half behind a failed first half (the frame's pose set by a fallback tracker)
+    and the "no projection candidate" return (tracking_module.cc:596-599)."""
+    sc = S.map_scene(seed=11 if stereo else 7, stereo=stereo)
+    margin = 10.0 if stereo else 20.0   # frame_tracker's margin_ (tracking_module.cc:37-38: 10 for stereo / RGB-D, 20 for monocular)
+
+    def same(r, g, halves=2):
+        assert np.array_equal(r["ret"], g["ret"]), (r["ret"], g["ret"])
+        assert np.array_equal(r["lm1"], g["lm1"])
+        assert _rel_pose(g["p1"], r["p1"]) < 1e-4
+        if halves == 2:
+            assert np.array_equal(r["lm2"], g["lm2"])
+            assert _rel_pose(g["p2"], r["p2"]) < 1e-4
+            assert np.array_equal(r["nobs"], g["nobs"])
+
+    # 1. the plain path: both halves succeed
+    r, g, G = _track_both(tracker_libs, sc, stereo, 20, margin)
+    assert list(r["ret"]) == [1, 1]
+    n1, n2 = int((r["lm1"] >= 0).sum()), int((r["lm2"] >= 0).sum())
+    assert n1 > 200 and n2 > n1 + 50 and (r["nobs"] > 1).sum() > 300
+    same(r, g)
+    # 2. the retry: a margin so small that the first search stays under the threshold and the doubled one passes it
+    tiny = 1.0
+    r_a, _, _ = _track_both(tracker_libs, sc, stereo, 0, tiny, run_local=0, guess_off=(0.6, 0.02))
+    r_b, _, _ = _track_both(tracker_libs, sc, stereo, 0, 2 * tiny, run_local=0, guess_off=(0.6, 0.02))
+    ma, mb = int((r_a["lm1"] >= 0).sum()), int((r_b["lm1"] >= 0).sum())    # inliers of the single-margin and the double-margin searches (thr 0: no retry)
+    assert mb > ma + 20, (ma, mb)
+    thr = (ma + mb) // 2 + 1   # more than the first search can match (matches >= inliers; checked below through the outcome), fewer than the second's inliers
+    r, g, _ = _track_both(tracker_libs, sc, stereo, thr, tiny, guess_off=(0.6, 0.02))
+    same(r, g)
+    if r["ret"][0] == 1:       # the doubled margin was what passed: the frame holds the second search's matches
+        assert int((r["lm1"] >= 0).sum()) >= thr > ma
+    # 3. num_matches_thr beyond both searches (:38-41): false, the frame keeps the motion-model pose and the second search's matches
+    r, g, G = _track_both(tracker_libs, sc, stereo, 100000, margin, run_local=0)
+    assert r["ret"][0] == 0 and (r["lm1"] >= 0).sum() > 200
+    assert np.array_equal(r["p1"], G[:3, :].reshape(12)) and np.array_equal(g["p1"], r["p1"])
+    same(r, g, halves=1)
+    # 4. enough matches, too few inliers (:53-56): false AFTER the optimisation and the outlier erasures
+    r0, _, _ = _track_both(tracker_libs, sc, stereo, 0, margin, run_local=0)
+    inl = int((r0["lm1"] >= 0).sum())
+    r, g, _ = _track_both(tracker_libs, sc, stereo, inl + 1, margin, run_local=0)
+    assert r["ret"][0] == 0 and int((r["lm1"] >= 0).sum()) == inl and not np.array_equal(r["p1"], G[:3, :].reshape(12))
+    same(r, g, halves=1)
+    # 5. the local-map half behind a FAILED first half, from the pose a fallback tracker left (ADVICE r4: not the device's stale one)
+    cur = sc["views"][1]
+    fb = np.hstack([cur["rot_cw"], (cur["trans_cw"] + np.array([0.01, -0.008, 0.004]))[:, None]]).reshape(12)
+    r, g, _ = _track_both(tracker_libs, sc, stereo, 100000, margin, override=fb)
+    assert list(r["ret"]) == [0, 1] and (r["lm2"] >= 0).sum() > 300
+    same(r, g)
+    # 6. no projection candidate (:596-599): every local landmark is already held by the frame
+    r1, _, _ = _track_both(tracker_libs, sc, stereo, 20, margin, run_local=0)
+    held = np.unique((r1["lm1"][r1["lm1"] >= 0] - 5) // 3).astype(np.int32)
+    r, g, _ = _track_both(tracker_libs, sc, stereo, 20, margin, local=held)
+    assert list(r["ret"]) == [1, 0]
+    same(r, g)
