@@ -198,6 +198,11 @@ def main() -> int:
         except Exception as e:
             if rank == 0:
                 result["local_ba"] = {"error": repr(e)}
+        if rank == 0 and world == 1:
+            try:
+                result["mapping_keyframe"] = bench_mapping_keyframe(want_cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                result["mapping_keyframe"] = {"error": repr(e)}
         try:
             gb = bench_global_ba(local_rank, rank, world)
             if rank == 0:
@@ -954,6 +959,73 @@ def bench_global_ba(device, rank, world, large=False):
             "linear_solver": "block envelope Cholesky of the reduced camera system (direct)" if res["stats"]["pcg_iterations"] == 0 else "block-Jacobi PCG",
             "pcg_iterations_per_call": res["stats"]["pcg_iterations"], "chi2_final": res["stats"]["chi2_final"],
             "roofline": ba_roofline(sc, iters, dt, free)}
+
+
+def bench_mapping_keyframe(want_cpu=True):
+    """The mapping thread's per-keyframe call, END TO END on an object graph (mapping_module.cc:206): optimize::local_bundle_adjuster_hip::optimize(
+    map_db, keyfrm, &flag) on the config-3 scene as stand-in keyframe / landmark objects (stella_vslam_amd/host/mapping_keyframe.cpp): gather from
+    the graph, flatten, device solve, write-back under the map mutex, flush of the resident landmark table -- per-phase host milliseconds.
+    Beside it the REFERENCE's own optimize/local_bundle_adjuster_g2o.cc (compiled where it lies into oracle/_ref/libsvref_ba.so; g2o's optimize() is
+    the oracle's LM) on the same map, one core."""
+    from stella_vslam_amd import synthetic
+    host = C.CDLL(os.path.join(ROOT, "stella_vslam_amd", "host", "libsvgpu_host.so"))
+    sc = synthetic.ba_scene()
+    P, Lm, E = len(sc["pose_cw"]), len(sc["points"]), len(sc["obs_pose"])
+    pose = np.ascontiguousarray(sc["pose_cw"], np.float64)
+    fixed = np.ascontiguousarray(sc["pose_fixed"], np.uint8)
+    pts = np.ascontiguousarray(sc["points"], np.float64)
+    op, ol = np.ascontiguousarray(sc["obs_pose"], np.int32), np.ascontiguousarray(sc["obs_point"], np.int32)
+    uvr = np.ascontiguousarray(sc["obs_uvr"], np.float32)
+    octave = np.clip(np.rint(np.log(1.0 / np.asarray(sc["obs_inv_sigma_sq"], np.float64)) / np.log(1.44)), 0, 7).astype(np.int32)
+    intr = np.ascontiguousarray(sc["intr"][0], np.float64)
+    _v = lambda a: C.c_void_p(a.ctypes.data)
+    ms, st = np.zeros(7), np.zeros(8, np.int32)
+    rc = host.svgpu_host_mapping_keyframe(P, Lm, E, _v(pose), _v(fixed), _v(pts), _v(op), _v(ol), _v(uvr), _v(octave), _v(intr), 0, 5, _v(ms), _v(st))
+    if rc != 0:
+        return {"error": "svgpu_host_mapping_keyframe failed"}
+    names = ("gather", "flatten", "solve", "write_back", "flush_map")
+    out = {"what": "local_bundle_adjuster_hip::optimize(map_db, keyfrm, &flag) on %d local + %d fixed keyframes / %d landmarks / %d observations of stand-in objects, mean of 5 calls on fresh maps"
+                   % (st[0], st[1], st[2], st[3]),
+           "ms_per_call": round(float(ms[5]), 3), "gpu_ms": round(float(ms[2]), 3), "host_share": round(float(1.0 - ms[2] / ms[5]), 3),
+           "phase_ms": {n: round(float(v), 3) for n, v in zip(names, ms[:5])}, "iters_stage1": int(st[4]), "iters_stage2": int(st[5]), "observations_erased": int(st[6]),
+           "object_graph_construction_ms_untimed": round(float(ms[6]), 1)}
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libsvref_ba.so")
+    if want_cpu and os.path.exists(ref_so):
+        try:
+            ref = C.CDLL(ref_so)
+            K = P
+            idx, seen = np.zeros(E, np.int32), np.zeros(K, np.int64)
+            for e in range(E):
+                idx[e] = seen[op[e]]
+                seen[op[e]] += 1
+            free = np.flatnonzero(fixed == 0)
+            curr = int(free[-1])
+            covis = np.ascontiguousarray(free[:-1], np.int32)
+            a = dict(kf_id=np.arange(K, dtype=np.uint32), kf_flags=np.zeros(K, np.uint8), lm_id=np.arange(Lm, dtype=np.uint32), lm_erased=np.zeros(Lm, np.uint8),
+                     uv=np.ascontiguousarray(uvr[:, :2]), xr=np.ascontiguousarray(uvr[:, 2]))
+            o = dict(counts=np.zeros(3, np.int32), pose_order=np.full(K, -1, np.int32), point_order=np.full(Lm, -1, np.int32), edge_order=np.full(2 * E, -1, np.int32),
+                     kf_pose=np.zeros((K, 12)), lm_pos=np.zeros((Lm, 3)), n_erased=C.c_int(0), erased=np.zeros(2 * E + 2, np.int32), lm_cnt=np.zeros((Lm, 4), np.int32),
+                     kf_set=np.zeros(K, np.int32), iters=np.zeros(2, np.int32), stop=np.zeros(1, np.uint8))
+            old = _pin(2)
+            try:
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    r = ref.svref_local_ba(0, 0, 752, 480, _v(intr), C.c_float(1.2), 8, K, _v(a["kf_id"]), _v(pose), _v(a["kf_flags"]), Lm, _v(a["lm_id"]), _v(pts),
+                                           _v(a["lm_erased"]), E, _v(op), _v(ol), _v(idx), _v(a["uv"]), _v(a["xr"]), _v(octave), curr, len(covis), _v(covis), 0, 0, 5, 10, 0,
+                                           _v(o["counts"]), _v(o["pose_order"]), _v(o["point_order"]), _v(o["edge_order"]), _v(o["kf_pose"]), _v(o["lm_pos"]),
+                                           C.byref(o["n_erased"]), _v(o["erased"]), _v(o["lm_cnt"]), _v(o["kf_set"]), _v(o["iters"]), _v(o["stop"]))
+                    ts.append(time.perf_counter() - t0)
+                    assert r == 0
+            finally:
+                _unpin(old)
+            out["cpu_ms"] = round(float(np.median(ts)) * 1e3, 1)
+            out["cpu_reference"] = {"ms_per_call": out["cpu_ms"], "cores": 1, "kind": "reference", "iters": [int(o["iters"][0]), int(o["iters"][1])],
+                                    "sample": "median of 3 calls of the reference's compiled local_bundle_adjuster_g2o::optimize (oracle/_ref/libsvref_ba.so: its gather, graph, schedule and "
+                                              "write-back; g2o's optimize() played by the oracle's LM) on the same map, object construction of the fixture included, pinned to core 2"}
+        except Exception as e:
+            out["cpu_reference"] = {"error": repr(e)}
+    return out
 
 
 def _pin(core):

@@ -1,6 +1,8 @@
 // Implementation of the drop-in classes: flatten -> one libsvgpu call -> replay on the object graph (hip_backend.h).
 #include "hip_backend.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -817,6 +819,13 @@ local_bundle_adjuster_hip::local_bundle_adjuster_hip(const YAML::Node& yaml_node
       use_additional_keyframes_for_monocular_(yaml_node["use_additional_keyframes_for_monocular"].as<bool>(false)) {}
 
 void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_ptr& curr_keyfrm, bool* const force_stop_flag) const {
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](int phase) {
+        const auto n = std::chrono::steady_clock::now();
+        last_phase_ms_[phase] = std::chrono::duration<double, std::milli>(n - lap_t).count();
+        lap_t = n;
+    };
+    for (double& v : last_phase_ms_) v = 0.0;
     // 1. Aggregate the local and fixed keyframes, and local landmarks (local_bundle_adjuster_g2o.cc:38-147; id-ordered maps: the
     //    reference's unordered_map order is unspecified, so only the mathematical result is comparable)
     std::map<unsigned int, kf_ptr> local_keyfrms;
@@ -828,12 +837,18 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
         local_keyfrms[local_keyfrm->id_] = local_keyfrm;
         if (local_keyfrm->camera_->setup_type_ != camera::setup_type_t::Monocular) has_scale = true;
     }
-    std::map<unsigned int, lm_ptr> local_lms;
+    // (id-ordered like the map above, but as a sorted vector: ten thousand tree insertions cost a millisecond of the mapping thread; the
+    //  observations of every landmark are copied ONCE here -- get_observations() returns the map by value -- and reused by the flattening below)
+    std::vector<std::pair<unsigned int, lm_ptr>> local_lms;
     for (const auto& id_kf : local_keyfrms)
         for (const auto& local_lm : id_kf.second->get_landmarks()) {
             if (!local_lm || local_lm->will_be_erased()) continue;
-            local_lms.emplace(local_lm->id_, local_lm);
+            local_lms.emplace_back(local_lm->id_, local_lm);
         }
+    std::sort(local_lms.begin(), local_lms.end(), [](const std::pair<unsigned int, lm_ptr>& a, const std::pair<unsigned int, lm_ptr>& b) { return a.first < b.first; });
+    local_lms.erase(std::unique(local_lms.begin(), local_lms.end(), [](const std::pair<unsigned int, lm_ptr>& a, const std::pair<unsigned int, lm_ptr>& b) { return a.first == b.first; }),
+                    local_lms.end());
+    std::vector<data::landmark::observations_t> local_lm_obs(local_lms.size());
     std::map<unsigned int, std::shared_ptr<data::marker>> local_mkrs;  // :86-102
     for (const auto& id_kf : local_keyfrms)
         for (const auto& local_mkr : id_kf.second->get_markers()) {
@@ -841,13 +856,15 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
             local_mkrs.emplace(local_mkr->id_, local_mkr);
         }
     std::map<unsigned int, kf_ptr> fixed_keyfrms;
-    for (const auto& id_lm : local_lms)
-        for (const auto& obs : id_lm.second->get_observations()) {
+    for (size_t k = 0; k < local_lms.size(); ++k) {
+        local_lm_obs[k] = local_lms[k].second->get_observations();
+        for (const auto& obs : local_lm_obs[k]) {
             const auto fixed_keyfrm = obs.first.lock();
             if (!fixed_keyfrm || fixed_keyfrm->will_be_erased()) continue;
             if (local_keyfrms.count(fixed_keyfrm->id_)) continue;
             fixed_keyfrms.emplace(fixed_keyfrm->id_, fixed_keyfrm);
         }
+    }
     if (use_additional_keyframes_for_monocular_) {  // :135-147
         auto additional_keyfrms_size = 2 - fixed_keyfrms.size();
         if (!has_scale && fixed_keyfrms.size() < 2 && local_keyfrms.size() > additional_keyfrms_size) {
@@ -861,6 +878,7 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
         }
     }
     if (force_stop_flag && *force_stop_flag) return;  // :308-310 (nothing has been touched yet)
+    lap(0);
 
     // 2.-4. vertices and reprojection edges as flat arrays (:165-246)
     std::vector<kf_ptr> poses;
@@ -896,9 +914,15 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     std::vector<int32_t> obs_pose, obs_point;
     std::vector<float> obs_uvr, obs_w, obs_huber;
     std::vector<std::pair<kf_ptr, lm_ptr>> obs_objects;
-    for (const auto& id_lm : local_lms) {
-        const auto& local_lm = id_lm.second;
-        const auto observations = local_lm->get_observations();
+    {
+        size_t n_obs = 0;
+        for (const auto& o : local_lm_obs) n_obs += o.size();
+        points.reserve(local_lms.size()), pts.reserve(3 * local_lms.size());
+        obs_pose.reserve(n_obs), obs_point.reserve(n_obs), obs_uvr.reserve(3 * n_obs), obs_w.reserve(n_obs), obs_huber.reserve(n_obs), obs_objects.reserve(n_obs);
+    }
+    for (size_t k_lm = 0; k_lm < local_lms.size(); ++k_lm) {
+        const auto& local_lm = local_lms[k_lm].second;
+        const auto& observations = local_lm_obs[k_lm];
         if (observations.empty()) continue;
         const int l = (int)points.size();
         points.push_back(local_lm);
@@ -966,7 +990,9 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     std::vector<double> pose_out((size_t)P * 12), pts_out((size_t)L * 3);
     std::vector<uint8_t> outlier(E > 0 ? E : 1, 0);
     static_assert(sizeof(bool) == 1, "force_stop_flag is polled as one byte");
+    lap(1);
     last_status_ = svgpu_local_ba(hip::context(), &pr, reinterpret_cast<volatile uint8_t*>(force_stop_flag), pose_out.data(), pts_out.data(), outlier.data(), &last_stats_);
+    lap(2);
     if (last_status_ == SVGPU_STOPPED) return;
     hip::check(last_status_, "svgpu_local_ba");
 
@@ -1007,11 +1033,13 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
                 for (int k = 0; k < 3; ++k) mkr->corners_pos_w_[corner_idx](k) = pts_out[(size_t)(mk_slot.second + corner_idx) * 3 + k];
         }
     }
+    lap(3);
 #if !defined(SVGPU_DROP_IN_OPTIMIZE_ONLY) && !defined(SVGPU_DROP_IN_MATCH_ONLY)
     // the write-back has moved a few thousand landmarks (set_pos_in_world, update_mean_normal_and_obs_scale_variance, compute_descriptor:
     // drop_in/map_mirror.h): the device-resident landmark table is brought up to date HERE, on the mapping thread, so that the tracking
     // thread's next frame finds nothing left to upload
     hip::flush_map(hip::context());
+    lap(4);
 #endif
 }
 

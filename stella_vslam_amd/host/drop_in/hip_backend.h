@@ -190,6 +190,9 @@ public:
     //! statistics of the last call (diagnostics; the reference logs nothing here)
     mutable svgpu_ba_stats last_stats_{};
     mutable int last_status_ = 0;
+    //! host wall-clock of the last call's phases, milliseconds: gather (steps 1), flatten (2-4), solve (svgpu_local_ba: staging, device
+    //! loop, read-back), write-back (7-8, under the map mutex), flush of the device-resident landmark table
+    mutable double last_phase_ms_[5] = {0, 0, 0, 0, 0};
 
 private:
     const unsigned int num_first_iter_, num_second_iter_;

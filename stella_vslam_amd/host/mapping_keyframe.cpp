@@ -1,0 +1,123 @@
+// The mapping thread's per-keyframe call (mapping_module.cc:206: local_bundle_adjuster_->optimize(map_db_, cur_keyfrm_, &abort_local_BA_))
+// through the DROP-IN CLASS, end to end on an object graph: gather of the local window from the keyframe / landmark graph
+// (local_bundle_adjuster_g2o.cc:38-147), flattening, the device solve, the write-back under the map mutex (:352-430: erase_observation,
+// compute_descriptor, set_pose_cw, set_pos_in_world, update_mean_normal_and_obs_scale_variance) and the flush of the device-resident
+// landmark table.  bench.py (leg `mapping_keyframe`) hands over the flat config-3 scene (20 keyframes / 10 k landmarks / 60 k
+// observations), this file builds the stand-in objects from it (untimed, afresh for every repetition: a call leaves a converged map behind)
+// and times optimize() with the per-phase clocks of local_bundle_adjuster_hip::last_phase_ms_.  Stand-in data:: types (host/standin/).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "drop_in/hip_backend.h"
+#include "drop_in/tracking_hip.h"
+
+using namespace stella_vslam;
+using lm_ptr = std::shared_ptr<data::landmark>;
+using kf_ptr = std::shared_ptr<data::keyframe>;
+
+// ms[7] = {gather, flatten, solve, write-back, flush_map, total of optimize(), object-graph construction (untimed part, for the record)};
+// stats[8] = {local keyframes, fixed keyframes, landmarks, observations, LM iterations stage 1, stage 2, outlier observations erased, status}
+extern "C" int svgpu_host_mapping_keyframe(int P, int L, int E, const double* pose_cw, const uint8_t* pose_fixed, const double* points, const int32_t* obs_pose,
+                                           const int32_t* obs_point, const float* obs_uvr, const int32_t* obs_octave, const double* intr5, int stereo, int reps,
+                                           double* ms, int* stats) {
+    try {
+        if (P < 2 || L < 1 || E < 1 || reps < 1 || !ms || !stats) return -1;
+        camera::perspective cam(stereo ? camera::setup_type_t::Stereo : camera::setup_type_t::Monocular, 752u, 480u, intr5[0], intr5[1], intr5[2], intr5[3], 0, 0, 0, 0, 0,
+                                intr5[4]);
+        cam.img_bounds_ = camera::image_bounds{0.f, 752.f, 0.f, 480.f};
+        feature::orb_params orb;
+        YAML::Node yaml;
+        yaml.kv["backend"] = "hip";
+        auto ba = optimize::hip_backend::create_local_bundle_adjuster(yaml);
+        const auto* hipba = static_cast<const optimize::local_bundle_adjuster_hip*>(ba.get());
+        for (int k = 0; k < 7; ++k) ms[k] = 0.0;
+        for (int k = 0; k < 8; ++k) stats[k] = 0;
+        std::vector<int> kp_of_obs(E);
+        std::vector<int> n_kp(P, 0);
+        for (int e = 0; e < E; ++e) kp_of_obs[e] = n_kp[obs_pose[e]]++;
+        for (int rep = -1; rep < reps; ++rep) {  // rep -1 = warm-up
+            const auto t_build = std::chrono::steady_clock::now();
+            data::map_database db;
+            std::mt19937 rng(17);
+            std::vector<kf_ptr> kfs(P);
+            std::vector<lm_ptr> lms(L);
+            const unsigned id0 = 100000u * (unsigned)(rep + 2);  // fresh landmark ids per repetition: the landmark table is process-wide
+            for (int l = 0; l < L; ++l) {
+                Vec3_t p;
+                for (int k = 0; k < 3; ++k) p(k) = points[3 * (size_t)l + k];
+                lms[l] = std::make_shared<data::landmark>(id0 + (unsigned)l, p);
+            }
+            for (int p = 0; p < P; ++p) {
+                kfs[p] = std::make_shared<data::keyframe>((unsigned)p, &cam, &orb);
+                Mat44_t T = Mat44_t::Identity();
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 4; ++j) T(i, j) = pose_cw[12 * (size_t)p + 4 * i + j];
+                kfs[p]->set_pose_cw(T);
+                auto& fo = kfs[p]->frm_obs_;
+                fo.undist_keypts_.resize(n_kp[p]);
+                fo.descriptors_.create(n_kp[p], 32, CV_8U);
+                for (int i = 0; i < n_kp[p]; ++i) {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(fo.descriptors_.ptr(i));
+                    for (int k = 0; k < 8; ++k) d[k] = (uint32_t)rng();
+                }
+                if (stereo) fo.stereo_x_right_.assign(n_kp[p], -1.f);
+                kfs[p]->landmarks_.assign(n_kp[p], nullptr);
+            }
+            for (int e = 0; e < E; ++e) {
+                const int p = obs_pose[e], l = obs_point[e], i = kp_of_obs[e];
+                cv::KeyPoint& kp = kfs[p]->frm_obs_.undist_keypts_[i];
+                kp.pt.x = obs_uvr[3 * (size_t)e], kp.pt.y = obs_uvr[3 * (size_t)e + 1];
+                kp.octave = obs_octave[e];
+                if (stereo) kfs[p]->frm_obs_.stereo_x_right_[i] = obs_uvr[3 * (size_t)e + 2];
+                kfs[p]->landmarks_[i] = lms[l];
+                lms[l]->add_observation(kfs[p], (unsigned)i);
+                if (lms[l]->ref_keyfrm_.expired()) lms[l]->ref_keyfrm_ = kfs[p];
+            }
+            for (auto& lm : lms) {
+                lm->compute_descriptor();
+                lm->update_mean_normal_and_obs_scale_variance();
+            }
+            // the window: the free keyframes; the newest is the current one, the others its covisibilities; the fixed ones are reached
+            // through the landmarks' observations (local_bundle_adjuster_g2o.cc:104-133)
+            kf_ptr curr;
+            for (int p = P - 1; p >= 0 && !curr; --p)
+                if (!pose_fixed[p]) curr = kfs[p];
+            if (!curr) return -1;
+            int n_local = 1, n_fixed = 0;
+            for (int p = 0; p < P; ++p) {
+                if (pose_fixed[p]) ++n_fixed;
+                else if (kfs[p] != curr) curr->graph_node_->covisibilities_.push_back(kfs[p]), ++n_local;
+            }
+            hip::flush_map(hip::context());  // the table as the running system has it when the mapping thread's call arrives
+            const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
+            bool force_stop = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            ba->optimize(&db, curr, &force_stop);
+            const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (hipba->last_status_ != 0) {
+                std::fprintf(stderr, "svgpu_host_mapping_keyframe: optimize status %d\n", hipba->last_status_);
+                return -1;
+            }
+            if (rep >= 0) {
+                for (int k = 0; k < 5; ++k) ms[k] += hipba->last_phase_ms_[k] / reps;
+                ms[5] += total / reps;
+                ms[6] += build_ms / reps;
+            }
+            int erased = 0;
+            for (int e = 0; e < E; ++e)
+                if (!kfs[obs_pose[e]]->landmarks_[kp_of_obs[e]]) ++erased;
+            stats[0] = n_local, stats[1] = n_fixed, stats[2] = L, stats[3] = E, stats[4] = hipba->last_stats_.iters_stage1, stats[5] = hipba->last_stats_.iters_stage2,
+            stats[6] = erased, stats[7] = hipba->last_status_;
+            for (auto& lm : lms) hip::map_mirror::landmark_erased(lm->id_);  // (leave the process-wide table as it was found)
+        }
+        hip::flush_map(hip::context());
+        return 0;
+    }
+    catch (const std::exception& e) {
+        std::fprintf(stderr, "svgpu_host_mapping_keyframe: %s\n", e.what());
+        return -1;
+    }
+}
