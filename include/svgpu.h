@@ -402,6 +402,18 @@ int svgpu_track_motion(svgpu_tracker* tracker, svgpu_frame* cur, const uint8_t* 
  * Each pointer is nullable; returns the keypoint count (0 when there is none). */
 int svgpu_tracker_observation(const svgpu_tracker* tracker, const svgpu_keypoint** kps, const uint8_t** desc, const svgpu_keypoint** undist_kps,
                               const double** bearings);
+/* The same for a STEREO frame (system::create_stereo_frame, system.cc:406-447, then the tracker): both images go down, the right one is
+ * extracted on `ctx_right` (a second context of the tracker's device, configured like the tracker's) and its own stream beside the left
+ * one's, match::stereo::compute (match/stereo.cc:20-114) runs behind both on the device-resident keypoints, descriptors and pyramids, the
+ * left observation (undistortion, bearings, grid) follows, then the matcher and the optimiser with the stereo gates and edges -- still ONE
+ * submission and ONE synchronisation.  The observation stays in the tracker's page-locked buffer: svgpu_tracker_observation for the
+ * keypoints / descriptors / undistorted keypoints / bearings, svgpu_tracker_observation_stereo for stereo_x_right_ / depths_
+ * (-1 where the left keypoint found no partner).  The tracker must have been created with is_monocular = 0. */
+int svgpu_track_motion_stereo(svgpu_tracker* tracker, svgpu_ctx* ctx_right, svgpu_frame* cur, const uint8_t* img_left, int stride_left,
+                              const uint8_t* img_right, int stride_right, const svgpu_frame* last, const int32_t* last_lm_ids,
+                              const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation, int cap,
+                              int32_t* match_last, uint8_t* outlier, svgpu_track_result* result);
+int svgpu_tracker_observation_stereo(const svgpu_tracker* tracker, const float** stereo_x_right, const float** depths);
 /* tracking_module::search_local_landmarks + optimize_current_frame_with_local_map's optimisation (tracking_module.cc:533-608, 441-446)
  * as one submission.
  *   cur_lm_ids    per keypoint of `cur`: the landmark id the frame holds now (-1: none) -- after discard_outliers and update_local_map's

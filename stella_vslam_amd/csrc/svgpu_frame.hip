@@ -35,8 +35,8 @@ int sv_frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell) {
             return o;
         };
         const size_t o_kps = carve((size_t)cap * sizeof(svgpu_keypoint)), o_desc = carve((size_t)cap * 32), o_und = carve((size_t)cap * sizeof(svgpu_keypoint)),
-                     o_brg = carve((size_t)cap * 24), o_xy = carve((size_t)cap * 8), o_oct = carve((size_t)cap * 4), o_ang = carve((size_t)cap * 4),
-                     o_xr = carve((size_t)cap * 4), o_cof = carve((size_t)cap * 4), o_cit = carve((size_t)cap * 4), o_cnt = carve((1 + SV_MAX_LEVELS) * 4);
+                     o_brg = carve((size_t)cap * 24), o_xr = carve((size_t)cap * 4), o_dep = carve((size_t)cap * 4), o_xy = carve((size_t)cap * 8),
+                     o_oct = carve((size_t)cap * 4), o_ang = carve((size_t)cap * 4), o_cof = carve((size_t)cap * 4), o_cit = carve((size_t)cap * 4), o_cnt = carve((1 + SV_MAX_LEVELS) * 4);
         SV_HIP(ctx, hipMalloc((void**)&f->slab, off));
         f->slab_bytes = off;
         f->kps_raw = (svgpu_keypoint*)(f->slab + o_kps);
@@ -47,6 +47,7 @@ int sv_frame_reserve(svgpu_ctx* ctx, svgpu_frame* f, int n, int ncell) {
         f->octave = (int32_t*)(f->slab + o_oct);
         f->angle = (float*)(f->slab + o_ang);
         f->xright = (float*)(f->slab + o_xr);
+        f->depth = (float*)(f->slab + o_dep);
         f->cell_of = (int32_t*)(f->slab + o_cof);
         f->cell_items = (int32_t*)(f->slab + o_cit);
         f->counts = (int32_t*)(f->slab + o_cnt);

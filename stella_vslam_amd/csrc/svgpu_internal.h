@@ -90,7 +90,7 @@ struct svgpu_frame {
     float min_x = 0, max_x = 0, min_y = 0, max_y = 0;  // image bounds the grid was binned over
     bool has_xright = false;
     // ONE device allocation (`slab`, `slab_bytes`), carved in this order, so that what the host wants back of a freshly extracted frame
-    // (kps_raw | desc | undist | bearings) is one contiguous copy (svgpu_track_motion)
+    // (kps_raw | desc | undist | bearings [| xright | depth for a stereo pair]) is one contiguous copy (svgpu_track_motion)
     char* slab = nullptr;
     size_t slab_bytes = 0;
     svgpu_keypoint* kps_raw = nullptr;  // n distorted keypoints as the extractor wrote them (fused extraction only)
@@ -101,6 +101,7 @@ struct svgpu_frame {
     int32_t* octave = nullptr;
     float* angle = nullptr;
     float* xright = nullptr;            // stereo_x_right_ (valid when has_xright)
+    float* depth = nullptr;             // depths_ (written by the fused stereo chain only: svgpu_track_motion_stereo)
     int32_t* cell_of = nullptr;         // n
     int32_t* cell_items = nullptr;      // n
     int32_t* counts = nullptr;          // 1 + SV_MAX_LEVELS ints: the extractor's counts (fused extraction: [0] = n as the device knows it)

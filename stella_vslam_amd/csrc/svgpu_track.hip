@@ -59,12 +59,49 @@ struct svgpu_tracker {
     size_t h_obs_bytes = 0;
     int last_n_local = -1;
     int obs_n = 0;          // the observation in h_obs (svgpu_tracker_observation)
-    size_t obs_off[4] = {0, 0, 0, 0};
+    size_t obs_off[6] = {0, 0, 0, 0, 0, 0};  // kps | desc | undist | bearings | x_right | depth inside h_obs
+    bool obs_stereo = false;
     long long launches = 0, syncs = 0;
+    // the RIGHT camera of a stereo rig (svgpu_track_motion_stereo): its image goes through its own context and stream beside the left one's
+    svgpu_ctx* right_ctx = nullptr;
+    char* d_in_r = nullptr;
+    char* h_in_r = nullptr;
+    size_t in_r_bytes = 0;
+    svgpu_keypoint* r_kps = nullptr;
+    uint8_t* r_desc = nullptr;
+    int32_t* r_counts = nullptr;
+    int r_cap = 0;
+    hipEvent_t ev_right = nullptr;
 };
 
 namespace {
 inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
+
+void release_right(svgpu_tracker* t) {
+    if (t->d_in_r) (void)hipFree(t->d_in_r);
+    if (t->h_in_r) (void)hipHostFree(t->h_in_r);
+    if (t->r_kps) (void)hipFree(t->r_kps);
+    if (t->r_desc) (void)hipFree(t->r_desc);
+    if (t->r_counts) (void)hipFree(t->r_counts);
+    if (t->ev_right) (void)hipEventDestroy(t->ev_right);
+    t->d_in_r = t->h_in_r = nullptr;
+    t->r_kps = nullptr, t->r_desc = nullptr, t->r_counts = nullptr, t->ev_right = nullptr;
+    t->in_r_bytes = 0, t->r_cap = 0;
+}
+// buffers of the right image's extraction (grow-only)
+int reserve_right(svgpu_tracker* t, size_t img_bytes, int cap) {
+    svgpu_ctx* ctx = t->ctx;
+    if (img_bytes <= t->in_r_bytes && cap <= t->r_cap && t->ev_right) return SVGPU_OK;
+    release_right(t);
+    SV_HIP(ctx, hipMalloc((void**)&t->d_in_r, pad256(img_bytes)));
+    SV_HIP(ctx, hipHostMalloc((void**)&t->h_in_r, pad256(img_bytes), hipHostMallocDefault));
+    SV_HIP(ctx, hipMalloc((void**)&t->r_kps, (size_t)cap * sizeof(svgpu_keypoint)));
+    SV_HIP(ctx, hipMalloc((void**)&t->r_desc, (size_t)cap * 32));
+    SV_HIP(ctx, hipMalloc((void**)&t->r_counts, (1 + SV_MAX_LEVELS) * 4));
+    SV_HIP(ctx, hipEventCreateWithFlags(&t->ev_right, hipEventDisableTiming));
+    t->in_r_bytes = pad256(img_bytes), t->r_cap = cap;
+    return SVGPU_OK;
+}
 
 void release(svgpu_tracker* t) {
     if (t->d_in) (void)hipFree(t->d_in);
@@ -287,6 +324,7 @@ void svgpu_tracker_destroy(svgpu_tracker* t) {
     // (every call of the tracker ends with its own synchronisation: nothing is in flight; the context may already be gone)
     (void)hipSetDevice(t->map_device);
     release(t);
+    release_right(t);
     delete t;
 }
 
@@ -308,9 +346,15 @@ int svgpu_tracker_counters(const svgpu_tracker* t, long long* launches, long lon
     return SVGPU_OK;
 }
 
-int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, int stride, const svgpu_frame* last, const int32_t* last_lm_ids,
-                       const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation, svgpu_keypoint* kps, uint8_t* desc,
-                       svgpu_keypoint* undist_kps, double* bearings, int cap, int32_t* match_last, uint8_t* outlier, svgpu_track_result* result) {
+}  // extern "C"
+
+namespace {
+// svgpu_track_motion / svgpu_track_motion_stereo: `ctx_right` + `img_right` make the submission a stereo frame's (system.cc:406-447: the right
+// image's extraction on its own context and stream beside the left one's, match::stereo::compute behind both, then the frame observation)
+int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const uint8_t* img, int stride, const uint8_t* img_right, int stride_right,
+                 const svgpu_frame* last, const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation,
+                 svgpu_keypoint* kps, uint8_t* desc, svgpu_keypoint* undist_kps, double* bearings, int cap, int32_t* match_last, uint8_t* outlier,
+                 svgpu_track_result* result) {
     if (!t) return SVGPU_ERR_INVALID;
     svgpu_ctx* ctx = t->ctx;
     if (!cur || !last || !pose_guess_cw || !pose_last_cw || !result || cur == last || (last->n > 0 && (!last_lm_ids || !match_last)) || !outlier || cap < 0
@@ -319,6 +363,15 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
     if (cur->device != ctx->device || last->device != ctx->device) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: a frame lives on another device");
     const OrbConfig& C = ctx->orb;
     if (img && (!C.configured || stride < C.width)) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_track_motion: fused extraction needs svgpu_orb_configure on the tracker's context");
+    const bool stereo = img && img_right;
+    if (stereo) {
+        if (!ctx_right || ctx_right == ctx || ctx_right->device != ctx->device)
+            return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_stereo: the right image needs a context of its own on the tracker's device");
+        const OrbConfig& CR = ctx_right->orb;
+        if (!CR.configured || CR.width != C.width || CR.height != C.height || CR.num_levels != C.num_levels || CR.total_grid != C.total_grid || stride_right < C.width)
+            return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_track_motion_stereo: the right context must be configured like the left one");
+        if (t->cfg.is_monocular) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_stereo: the tracker was created for a monocular set-up");
+    }
     if (!img && (cur->grid_cols != t->cfg.grid_cols || cur->grid_rows != t->cfg.grid_rows))
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: the current frame was binned over another grid");
     // (landmark ids are validated where they are used: k_track_cand treats an id outside [0, map capacity) as "no landmark")
@@ -332,7 +385,8 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
     const int pitch = img ? C.levels[0].pitch : 0;
     const size_t img_bytes = img ? (size_t)pitch * C.height : 0;
     // what comes back of a fresh observation: the slab's prefix kps_raw | desc | undist | bearings
-    const size_t obs_bytes = img ? (size_t)((char*)cur->bearings - cur->slab) + (size_t)cur->cap * 24 : 0;
+    const size_t obs_bytes = !img ? 0 : stereo ? (size_t)((char*)cur->depth - cur->slab) + (size_t)cur->cap * 4 : (size_t)((char*)cur->bearings - cur->slab) + (size_t)cur->cap * 24;
+    if (stereo && (rc = reserve_right(t, img_bytes, nt_cap))) return rc;
     if ((rc = reserve(t, nt_cap, n_last, t->cap_cand, img_bytes, obs_bytes))) return rc;
     // assume_forward / assume_backward (projection.cc:101-116)
     double Rg[9], tg[3], twc[3], tlc[3];
@@ -355,6 +409,20 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
                 for (int y = 0; y < C.height; ++y) memcpy(t->h_in + (size_t)y * pitch, img + (size_t)y * stride, C.width);
         }
         if (n_last > 0) memcpy(t->h_in + o_ids, last_lm_ids, (size_t)n_last * 4);
+        if (extract && stereo) {  // the right image: its own copy, its own extraction, on the right context's stream -- beside everything below
+            if (stride_right == pitch) memcpy(t->h_in_r, img_right, img_bytes);
+            else
+                for (int y = 0; y < C.height; ++y) memcpy(t->h_in_r + (size_t)y * pitch, img_right + (size_t)y * stride_right, C.width);
+            hipStream_t sr = ctx_right->stream;
+            SV_HIP(ctx, hipMemcpyAsync(t->d_in_r, t->h_in_r, img_bytes, hipMemcpyHostToDevice, sr));
+            rc = svgpu_orb_extract_batch_device(ctx_right, (const uint8_t*)t->d_in_r, 1, img_bytes, pitch, nullptr, 0, pitch, t->r_kps, t->r_desc, nt_cap, t->r_counts, sr);
+            if (rc) {
+                (void)hipStreamSynchronize(sr);
+                return sv_set_error(ctx, rc, "svgpu_track_motion_stereo: extraction of the right image failed");
+            }
+            SV_HIP(ctx, hipEventRecord(t->ev_right, sr));
+            t->launches += 6;
+        }
         std::unique_lock<std::mutex> lock(t->map->mtx);
         if (t->map->cap == 0) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: the map is empty");
         SvMapReadScope reading(ctx, t->map, s);  // (declared behind the lock: every exit path records the read before the mutex is released)
@@ -372,6 +440,14 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
                 cur->grid_cols = t->cfg.grid_cols, cur->grid_rows = t->cfg.grid_rows;
                 cur->min_x = t->cam.min_x, cur->max_x = t->cam.max_x, cur->min_y = t->cam.min_y, cur->max_y = t->cam.max_y;
                 cur->has_xright = false;
+                if (stereo) {  // match::stereo::compute (match/stereo.cc:20-114) on the two extractions' device-resident outputs and pyramids
+                    SV_HIP(ctx, hipStreamWaitEvent(s, t->ev_right, 0));
+                    rc = svgpu_stereo_match_batch_device(ctx, ctx_right, 1, cur->kps_raw, cur->desc, cur->counts, t->r_kps, t->r_desc, t->r_counts, nt_cap,
+                                                         1 + C.num_levels, (float)t->cam.focal_x_baseline, t->cfg.true_baseline, cur->xright, cur->depth, s);
+                    if (rc) return rc;
+                    cur->has_xright = true;
+                    t->launches += 4;
+                }
                 TrackFrameProblem F{};
                 F.cam = t->cam;
                 F.kps = cur->kps_raw;
@@ -426,6 +502,8 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
             t->obs_n = cur->n;
             t->obs_off[0] = (size_t)((char*)cur->kps_raw - cur->slab), t->obs_off[1] = (size_t)((char*)cur->desc - cur->slab);
             t->obs_off[2] = (size_t)((char*)cur->undist - cur->slab), t->obs_off[3] = (size_t)((char*)cur->bearings - cur->slab);
+            t->obs_off[4] = (size_t)((char*)cur->xright - cur->slab), t->obs_off[5] = (size_t)((char*)cur->depth - cur->slab);
+            t->obs_stereo = stereo;
             if (kps) {
                 const int m = std::min(cur->n, cap);
                 const char* o = t->h_obs;
@@ -447,6 +525,32 @@ int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, i
     fill_result(t, n_kp, result);
     if (img && n_kp > cap) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "svgpu_track_motion: more keypoints than cap");
     return SVGPU_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, int stride, const svgpu_frame* last, const int32_t* last_lm_ids,
+                       const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation, svgpu_keypoint* kps, uint8_t* desc,
+                       svgpu_keypoint* undist_kps, double* bearings, int cap, int32_t* match_last, uint8_t* outlier, svgpu_track_result* result) {
+    return track_motion(t, nullptr, cur, img, stride, nullptr, 0, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, check_orientation, kps, desc, undist_kps,
+                        bearings, cap, match_last, outlier, result);
+}
+
+int svgpu_track_motion_stereo(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const uint8_t* img_left, int stride_left, const uint8_t* img_right,
+                              int stride_right, const svgpu_frame* last, const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw,
+                              float margin, int check_orientation, int cap, int32_t* match_last, uint8_t* outlier, svgpu_track_result* result) {
+    if (!t) return SVGPU_ERR_INVALID;
+    if (!img_left || !img_right) return sv_set_error(t->ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_stereo: both images are required");
+    return track_motion(t, ctx_right, cur, img_left, stride_left, img_right, stride_right, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, check_orientation,
+                        nullptr, nullptr, nullptr, nullptr, cap, match_last, outlier, result);
+}
+
+int svgpu_tracker_observation_stereo(const svgpu_tracker* t, const float** x_right, const float** depths) {
+    if (!t || !t->h_obs || t->obs_n <= 0 || !t->obs_stereo) return 0;
+    if (x_right) *x_right = (const float*)(t->h_obs + t->obs_off[4]);
+    if (depths) *depths = (const float*)(t->h_obs + t->obs_off[5]);
+    return t->obs_n;
 }
 
 int svgpu_track_local_map(svgpu_tracker* t, const svgpu_frame* cur, const int32_t* cur_lm_ids, int n_local, const int32_t* local_ids, const double* pose_cw,

@@ -147,6 +147,37 @@ class tracker:
         out.update(match_last=match[:len(ids)].copy(), outlier=outl[:n].copy(), result=res.as_dict())
         return out
 
+    def track_motion_stereo(self, cur: resident_frame, last: resident_frame, last_lm_ids, pose_guess_cw, pose_last_cw, margin: float, img_left: np.ndarray,
+                            img_right: np.ndarray, ctx_right: Context, check_orientation: bool = True):
+        """A stereo frame in one submission (svgpu_track_motion_stereo): both extractions, match::stereo::compute, the left observation, matcher and
+        optimiser.  -> dict(match_last, outlier, result, keypts, descriptors, undist_keypts, bearings, stereo_x_right, depths)"""
+        from .feature import KEYPOINT_DTYPE as KP
+        ids = np.ascontiguousarray(last_lm_ids, np.int32)
+        assert len(ids) == last.size
+        guess = np.ascontiguousarray(pose_guess_cw, np.float64).reshape(12)
+        plast = np.ascontiguousarray(pose_last_cw, np.float64).reshape(12)
+        match = np.full(max(len(ids), 1), -1, np.int32)
+        res = _TrackResult()
+        il, ir = np.ascontiguousarray(img_left, np.uint8), np.ascontiguousarray(img_right, np.uint8)
+        cap = max(int(lib().svgpu_orb_max_keypoints(self.ctx.handle)), 1)
+        outl = np.zeros(cap, np.uint8)
+        self.ctx.check(lib().svgpu_track_motion_stereo(self._h, ctx_right.handle, cur._h, _p(il), il.strides[0], _p(ir), ir.strides[0], last._h, _p(ids), _p(guess),
+                                                       _p(plast), C.c_float(margin), int(check_orientation), cap, _p(match), _p(outl), C.byref(res)),
+                       "svgpu_track_motion_stereo")
+        n = res.n_keypoints
+        pk, pd, pu, pb, px, pz = (C.c_void_p() for _ in range(6))
+        got = lib().svgpu_tracker_observation(self._h, C.byref(pk), C.byref(pd), C.byref(pu), C.byref(pb))
+        assert got == n and lib().svgpu_tracker_observation_stereo(self._h, C.byref(px), C.byref(pz)) == n
+
+        def view(ptr, dtype, shape):
+            if n == 0:
+                return np.zeros(shape, dtype)
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_char * nbytes).from_address(ptr.value), dtype=dtype).reshape(shape).copy()
+        return dict(match_last=match[:len(ids)].copy(), outlier=outl[:n].copy(), result=res.as_dict(), keypts=view(pk, KP, (n,)), descriptors=view(pd, np.uint8, (n, 32)),
+                    undist_keypts=view(pu, KP, (n,)), bearings=view(pb, np.float64, (n, 3)), stereo_x_right=view(px, np.float32, (n,)),
+                    depths=view(pz, np.float32, (n,)))
+
     def track_local_map(self, cur: resident_frame, cur_lm_ids, local_ids, margin: float = 5.0, lowe_ratio: float = 0.8, ray_cos_thr: float = 0.5,
                         pose_cw=None):
         """-> dict(match_local, visible, outlier, result)"""

@@ -523,6 +523,77 @@ def test_fused_extraction_equals_the_separate_steps():
     assert a["visible"].sum() > 300 and a["result"]["num_matches"] > 20 and a["result"]["num_valid"] > 0.95 * got["result"]["num_valid"]
 
 
+def test_fused_stereo_extraction_equals_the_separate_steps():
+    """svgpu_track_motion_stereo: both extractions (two contexts, two streams), match::stereo::compute, the left observation, matcher and
+    optimiser in ONE submission (system.cc:406-447 + frame_tracker.cc:22-60).  stereo_x_right_ / depths_ equal the stand-alone extractors +
+    match::stereo on their pyramids bit for bit, the observation equals the stand-alone one, and the tracking result (stereo gates of
+    projection.cc:179-181, stereo edges of the pose optimizer) equals the chain on a frame adopted from the separate steps."""
+    from stella_vslam_amd import camera, data, feature, match, synthetic, tracking
+    Wk, Hk, disp = 752, 480, 14
+    big = synthetic.frame_sequence(2, Wk + 64, Hk, seed=23)
+    left = [np.ascontiguousarray(b[:, 8:8 + Wk]) for b in big]
+    right = [np.ascontiguousarray(b[:, 8 + disp:8 + disp + Wk]) for b in big]
+    ext_l, ext_r = feature.orb_extractor(feature.orb_params()), feature.orb_extractor(feature.orb_params())
+    ctx = ext_l.ctx
+    fx = fy = 458.654
+    cx, cy, bl = 367.215, 248.375, 0.11
+    fxb = fx * bl
+    cam = camera.perspective("t", "Stereo", "Gray", Wk, Hk, 30.0, fx, fy, cx, cy, 0, 0, 0, 0, 0, focal_x_baseline=fxb, ctx=ctx)
+    T = synthetic.orb_tables(1.2, 8)
+    # the last frame, the usual way: both extractions, stereo matcher, adopted observation; its keypoints with a stereo depth are the map
+    k0, d0 = ext_l.extract(left[0])
+    k0r, d0r = ext_r.extract(right[0])
+    xr0, dp0 = match.stereo(ext_l, ext_r, k0, k0r, d0, d0r, fxb, bl).compute()
+    rf_last = data.resident_frame(ctx)
+    und0, _ = rf_last.adopt_extraction(cam, 64, 48)
+    rf_last.set_stereo(xr0)
+    assert (xr0 >= 0).sum() > 800
+    Z = np.where(dp0 > 0, dp0, 5.0).astype(np.float64)
+    pos = np.stack([(und0["x"] - cx) / fx * Z, (und0["y"] - cy) / fy * Z, Z], 1)
+    dist0 = np.linalg.norm(pos, axis=1)
+    nrm = pos / dist0[:, None]
+    maxd = (dist0 * T["scale_factors"][und0["octave"]]).astype(np.float32)
+    mind = (maxd * T["inv_scale_factors"][7]).astype(np.float32)
+    ids = np.where(dp0 > 0, np.arange(len(und0)) * 2 + 1, -1).astype(np.int32)
+    have = ids >= 0
+    table = tracking.landmark_table(ctx).upsert(ids[have], tracking.landmark_records(pos[have], nrm[have], mind[have], maxd[have], d0[have]))
+    trk = tracking.tracker(ctx, table, cam, T["scale_factors"], T["inv_level_sigma_sq"], T["log_scale_factor"], is_monocular=False, true_baseline=bl)
+    pose_last = _pose12(np.eye(3), np.zeros(3))
+    zbar = float(np.median(Z[have]))
+    guess = _pose12(np.eye(3), np.array([-3.0 * zbar / fx, -1.0 * zbar / fy, 0.0]))   # the sequence shifts by (3, 1) px per frame: exact for the median depth only
+    rf_cur = data.resident_frame(ctx)
+    got = trk.track_motion_stereo(rf_cur, rf_last, ids, guess, pose_last, 15.0, left[1], right[1], ext_r.ctx)
+    # the stereo observation against the separate steps
+    k1, d1 = ext_l.extract(left[1])
+    k1r, d1r = ext_r.extract(right[1])
+    xr1, dp1 = match.stereo(ext_l, ext_r, k1, k1r, d1, d1r, fxb, bl).compute()
+    assert len(k1) == got["result"]["n_keypoints"] > 1500 and rf_cur.size == len(k1)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(got["keypts"][f], k1[f]), f
+    assert np.array_equal(got["descriptors"], d1)
+    assert (xr1 >= 0).sum() > 800
+    assert np.array_equal(got["stereo_x_right"].view(np.uint32), xr1.view(np.uint32))
+    assert np.array_equal(got["depths"].view(np.uint32), dp1.view(np.uint32))
+    obs = data.frame_observation(cam, k1, d1)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(got["undist_keypts"][f], obs.undist_keypts_[f]), f
+    assert np.array_equal(got["bearings"], obs.bearings_)
+    # the tracking result: the same chain on a frame adopted from the stand-alone extraction + stereo matcher
+    rf_ref = data.resident_frame(ctx)
+    rf_ref.adopt_extraction(cam, 64, 48)   # (of ext_l's last extraction = left[1])
+    rf_ref.set_stereo(xr1)
+    ref = trk.track_motion(rf_ref, rf_last, ids, guess, pose_last, 15.0)
+    assert got["result"]["num_matches"] == ref["result"]["num_matches"] > 300
+    assert np.array_equal(got["match_last"], ref["match_last"]) and np.array_equal(got["outlier"], ref["outlier"])
+    assert np.array_equal(got["result"]["pose_cw"], ref["result"]["pose_cw"]) and got["result"]["num_valid"] == ref["result"]["num_valid"] > 200
+    # ... a monocular tracker refuses the stereo entry point, and so does a right context that is the left one
+    trk_mono = tracking.tracker(ctx, table, cam, T["scale_factors"], T["inv_level_sigma_sq"], T["log_scale_factor"], is_monocular=True)
+    with pytest.raises(RuntimeError):
+        trk_mono.track_motion_stereo(data.resident_frame(ctx), rf_last, ids, guess, pose_last, 15.0, left[1], right[1], ext_r.ctx)
+    with pytest.raises(RuntimeError):
+        trk.track_motion_stereo(data.resident_frame(ctx), rf_last, ids, guess, pose_last, 15.0, left[1], right[1], ctx)
+
+
 def test_track_entry_points_reject_bad_arguments(ctx):
     from stella_vslam_amd import tracking
     from stella_vslam_amd._lib import SvgpuError
