@@ -651,16 +651,42 @@ def bench_tracked_frame(frames_np, want_cpu=True):
             out["cpu_port"] = cpu_tracked_frame(seq)
         except Exception as e:
             out["cpu_port"] = {"error": repr(e)}
+    # ---- the same chain for a STEREO frame (BASELINE configs[3] shape: 1241 x 376, ini_fast_threshold 12): svgpu_track_motion_stereo + svgpu_track_local_map
+    try:
+        from stella_vslam_amd import synthetic
+        Wk, Hk, disp = 1241, 376, 17
+        big = synthetic.frame_sequence(4, Wk + 64, Hk, seed=0x5EED + 4)
+        sl, sr = np.ascontiguousarray(big[:, :, 8:8 + Wk]), np.ascontiguousarray(big[:, :, 8 + disp:8 + disp + Wk])
+        ms, cnt = np.zeros(8), np.zeros(8, np.int32)
+        rc = host.svgpu_host_tracked_frame_stereo(C.c_void_p(sl.ctypes.data), C.c_void_p(sr.ctypes.data), len(sl), Wk, Hk, C.c_double(disp), 12, 30, C.c_void_p(ms.ctypes.data),
+                                                  C.c_void_p(cnt.ctypes.data))
+        if rc != 0:
+            out["chain_stereo"] = {"error": "svgpu_host_tracked_frame_stereo failed"}
+        else:
+            out["chain_stereo"] = {"what": "one tracked 1241x376 STEREO frame through tracked_frame_chain: left + right extraction, stereo::compute, frame observation, "
+                                           "match_current_and_last_frames, pose optimizer | can_observe, match_frame_and_landmarks, pose optimizer (two submissions, PCIe included)",
+                                   "ms_per_frame": round(float(ms[7]), 4), "frames_per_s": round(1e3 / float(ms[7]), 1),
+                                   "ms": {"motion_half": round(float(ms[0]), 4), "local_map_half": round(float(ms[4]), 4)}, "keypoints": int(cnt[0]),
+                                   "last_frame_landmarks": int(cnt[1]), "matches_1": int(cnt[2]), "inliers_1": int(cnt[3]), "keypoints_with_stereo_partner": int(cnt[4]),
+                                   "matches_2": int(cnt[5]), "inliers_2": int(cnt[6]), "translation_error_um": int(cnt[7])}
+        if want_cpu:
+            out["cpu_port_stereo"] = cpu_tracked_frame(sl, seq_right=sr, disparity=disp, fx=718.856, ini_thr=12, margin1=10.0, reps=2)
+    except Exception as e:
+        out.setdefault("chain_stereo", {"error": repr(e)})
     return out
 
 
-def cpu_tracked_frame(seq, reps=3):
-    """The same chain with the oracle (C restatements of the reference's methods), pinned to one core: medians over `reps` frames."""
+def cpu_tracked_frame(seq, reps=3, seq_right=None, disparity=0.0, fx=500.0, ini_thr=20, margin1=20.0):
+    """The same chain with the oracle (C restatements of the reference's methods), pinned to one core: medians over `reps` frames.
+    With seq_right: the stereo frame's (both extractions + match::stereo::compute in the `extract` leg, stereo gates / edges behind)."""
     from oracle import oracle as O
     n_frames, h, w = seq.shape
-    fx = fy = 500.0
+    fy = fx
     cx, cy, Z, sx, sy = 0.5 * w, 0.5 * h, 5.0, 3.0, 1.0
-    cam = O.make_camera(O.CAM_PERSPECTIVE, w, h, fx, fy, cx, cy, (0, 0, 0, 0, 0))
+    stereo = seq_right is not None
+    bl = disparity * Z / fx if stereo else 0.0
+    fxb = fx * bl
+    cam = O.make_camera(O.CAM_PERSPECTIVE, w, h, fx, fy, cx, cy, (0, 0, 0, 0, 0), fxb) if stereo else O.make_camera(O.CAM_PERSPECTIVE, w, h, fx, fy, cx, cy, (0, 0, 0, 0, 0))
     sf, _, lss, _ = O.scale_tables(1.2, 8)
     sf = np.asarray(sf, np.float32)
     inv_sigma = (1.0 / np.asarray(lss, np.float32)).astype(np.float32)
@@ -674,7 +700,7 @@ def cpu_tracked_frame(seq, reps=3):
 
     maps = []
     for t in range(n_frames - 1):
-        k, d, _ = O.orb_extract(seq[t])
+        k, d, _ = O.orb_extract(seq[t], ini_thr=ini_thr)
         xy = np.stack([k["x"], k["y"]], 1).astype(np.float64)
         pw = backproject(t, xy)
         c = -pose(t)[1]
@@ -687,14 +713,20 @@ def cpu_tracked_frame(seq, reps=3):
     Rl, tl = pose(n_frames - 2)
     Rg, tg = pose(n_frames - 1)
     tg = tg + np.array([0.004, -0.003, 0.002])
-    K = np.array([fx, fy, cx, cy, 0.0])
-    huber = np.float32(np.sqrt(5.991))
+    K = np.array([fx, fy, cx, cy, fxb])
+    huber = np.float32(np.sqrt(7.81473 if stereo else 5.991))
     old = _pin(2)
     tt = {n: [] for n in ("extract", "frame_observation", "match_current_and_last_frames", "pose_optimizer_1", "can_observe", "match_frame_and_landmarks", "pose_optimizer_2")}
     try:
         for rep in range(reps + 1):
             t0 = time.perf_counter()
-            k, d, _ = O.orb_extract(seq[-1])
+            if stereo:
+                k, d, _, pl = O.orb_extract(seq[-1], ini_thr=ini_thr, want_pyramid=True)
+                kr, dr, _, pr = O.orb_extract(seq_right[-1], ini_thr=ini_thr, want_pyramid=True)
+                xr_cur, _ = O.stereo_match(k, d, kr, dr, pl, pr, fxb, bl)
+            else:
+                k, d, _ = O.orb_extract(seq[-1])
+                xr_cur = None
             t1 = time.perf_counter()
             xy = np.stack([k["x"], k["y"]], 1)
             und = O.undistort_keypoints(cam, xy)
@@ -702,11 +734,11 @@ def cpu_tracked_frame(seq, reps=3):
             O.assign_keypoints_to_grid(und[:, 0], und[:, 1], (cam.min_x, cam.max_x, cam.min_y, cam.max_y))
             t2 = time.perf_counter()
             m1, n1 = O.match_current_and_last_frames(True, cam, Rg, tg, Rl, tl, last["pw"], np.ones(len(last["pw"]), np.uint8), last["d"], last["k"]["octave"],
-                                                     last["k"]["angle"], sf, 20.0, d, und, k["octave"], k["angle"])
+                                                     last["k"]["angle"], sf, margin1, d, und, k["octave"], k["angle"], **(dict(t_xright=xr_cur, is_monocular=False, true_baseline=bl) if stereo else {}))
             t3 = time.perf_counter()
             sel = m1 >= 0
             kp = m1[sel]
-            uvr = np.stack([und[kp, 0], und[kp, 1], np.full(len(kp), -1.0)], 1).astype(np.float32)
+            uvr = np.stack([und[kp, 0], und[kp, 1], xr_cur[kp] if stereo else np.full(len(kp), -1.0)], 1).astype(np.float32)
             nv1, p1, outl, _ = O.pose_optimize(np.hstack([Rg, tg[:, None]]).reshape(12), last["pw"][sel], uvr, inv_sigma[k["octave"][kp]], np.full(len(kp), huber), K)
             t4 = time.perf_counter()
             P = p1.reshape(3, 4)
@@ -714,12 +746,12 @@ def cpu_tracked_frame(seq, reps=3):
             t5 = time.perf_counter()
             occ = np.zeros(len(d), np.uint8)
             occ[kp[outl == 0]] = 1
-            m2, n2 = O.match_frame_and_landmarks(cam, vis, rp, xr, lv, loc["d"], sf, 5.0, 0.8, d, und, k["octave"], occupied=occ)
+            m2, n2 = O.match_frame_and_landmarks(cam, vis, rp, xr, lv, loc["d"], sf, 5.0, 0.8, d, und, k["octave"], occupied=occ, **(dict(t_xright=xr_cur) if stereo else {}))
             t6 = time.perf_counter()
             sel2 = m2 >= 0
             kp2 = np.concatenate([kp[outl == 0], m2[sel2]])
             pw2 = np.concatenate([last["pw"][sel][outl == 0], loc["pw"][sel2]])
-            uvr2 = np.stack([und[kp2, 0], und[kp2, 1], np.full(len(kp2), -1.0)], 1).astype(np.float32)
+            uvr2 = np.stack([und[kp2, 0], und[kp2, 1], xr_cur[kp2] if stereo else np.full(len(kp2), -1.0)], 1).astype(np.float32)
             nv2, p2, _, _ = O.pose_optimize(p1, pw2, uvr2, inv_sigma[k["octave"][kp2]], np.full(len(kp2), huber), K)
             t7 = time.perf_counter()
             if rep == 0:

@@ -367,6 +367,10 @@ int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const
     if (stereo) {
         if (!ctx_right || ctx_right == ctx || ctx_right->device != ctx->device)
             return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_stereo: the right image needs a context of its own on the tracker's device");
+        if (!ctx_right->orb.configured) {  // the right extractor has not run yet: configure its context like the left one
+            const int rcc = svgpu_orb_configure(ctx_right, C.width, C.height, C.max_batch, C.scale_factor, C.num_levels, C.ini_thr, C.min_thr, C.min_area_sqrt * C.min_area_sqrt);
+            if (rcc) return sv_set_error(ctx, rcc, "svgpu_track_motion_stereo: configuring the right context failed");
+        }
         const OrbConfig& CR = ctx_right->orb;
         if (!CR.configured || CR.width != C.width || CR.height != C.height || CR.num_levels != C.num_levels || CR.total_grid != C.total_grid || stride_right < C.width)
             return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_track_motion_stereo: the right context must be configured like the left one");

@@ -246,7 +246,8 @@ void rebuild_frame(data::frame& frm, data::frame_observation& frm_obs) {
 }  // namespace
 
 bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::frame& last_frm, const Mat44_t& velocity, unsigned int num_matches_thr, float margin,
-                                             const cv::Mat* img, std::vector<cv::KeyPoint>* keypts) {
+                                             const cv::Mat* img, std::vector<cv::KeyPoint>* keypts, const cv::Mat* img_right) {
+    if (img_right && (!img || !ctx_right_)) throw std::runtime_error("tracked_frame_chain: a stereo frame needs the left image and set_right_context()");
     lap_timer T("motion");
     // Set the initial pose by using the motion model (frame_tracker.cc:25-26)
     const Mat44_t guess = velocity * last_frm.get_pose_cw();
@@ -281,10 +282,15 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
     unsigned int num_matches = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fused = img && attempt == 0;
-        check(svgpu_track_motion(tracker_, cur_h.get(), fused ? img->ptr(0) : nullptr, fused ? (int)img->step : 0, last_h.get(), last_ids_.data(), guess12, last12,
-                                 attempt == 0 ? margin : 2 * margin, 1 /* projection_matcher(0.9, true) */, nullptr, nullptr, nullptr, nullptr, cap, match_.data(),
-                                 outlier_.data(), &last_motion_),
-              "svgpu_track_motion");
+        if (fused && img_right)
+            check(svgpu_track_motion_stereo(tracker_, ctx_right_, cur_h.get(), img->ptr(0), (int)img->step, img_right->ptr(0), (int)img_right->step, last_h.get(),
+                                            last_ids_.data(), guess12, last12, margin, 1, cap, match_.data(), outlier_.data(), &last_motion_),
+                  "svgpu_track_motion_stereo");
+        else
+            check(svgpu_track_motion(tracker_, cur_h.get(), fused ? img->ptr(0) : nullptr, fused ? (int)img->step : 0, last_h.get(), last_ids_.data(), guess12, last12,
+                                     attempt == 0 ? margin : 2 * margin, 1 /* projection_matcher(0.9, true) */, nullptr, nullptr, nullptr, nullptr, cap, match_.data(),
+                                     outlier_.data(), &last_motion_),
+                  "svgpu_track_motion");
         T.lap("svgpu_track_motion");
         if (fused) {  // system.cc:380-395: the host copies data::frame_observation holds, straight out of the tracker's page-locked buffer
             const svgpu_keypoint *kps = nullptr, *und = nullptr;
@@ -300,6 +306,12 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
             o.bearings_.resize(n);
             for (int i = 0; i < n; ++i)
                 for (int k = 0; k < 3; ++k) o.bearings_[i](k) = brg[3 * (size_t)i + k];
+            if (img_right) {  // system.cc:443-447
+                const float *xr = nullptr, *dp = nullptr;
+                if (svgpu_tracker_observation_stereo(tracker_, &xr, &dp) != n) throw std::runtime_error("tracked_frame_chain: the stereo observation is missing");
+                o.stereo_x_right_.assign(xr, xr + n);
+                o.depths_.assign(dp, dp + n);
+            }
             if (keypts) {
                 keypts->resize(n);
                 if (n > 0) std::memcpy(static_cast<void*>(keypts->data()), kps, (size_t)n * sizeof(svgpu_keypoint));

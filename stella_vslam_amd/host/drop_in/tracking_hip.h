@@ -33,8 +33,12 @@ public:
     //! twice the margin), pose optimisation, discard_outliers.  With `img` the frame's observation is created in the same submission
     //! (system.cc:380-395: extract, undistort_keypoints, convert_keypoints_to_bearings, assign_keypoints_to_grid): curr_frm.frm_obs_ is
     //! filled here, `keypts` receives the extractor's (distorted) keypoints, and the resident copy is registered under curr_frm.id_.
+    //! With `img_right` as well (and a right context, set_right_context) the frame is a STEREO frame (system.cc:406-447): the right image is
+    //! extracted on the right context beside the left one, match::stereo::compute fills frm_obs_.stereo_x_right_ / depths_ -- same submission.
     bool motion_based_track(data::frame& curr_frm, const data::frame& last_frm, const Mat44_t& velocity, unsigned int num_matches_thr, float margin,
-                            const cv::Mat* img = nullptr, std::vector<cv::KeyPoint>* keypts = nullptr);
+                            const cv::Mat* img = nullptr, std::vector<cv::KeyPoint>* keypts = nullptr, const cv::Mat* img_right = nullptr);
+    //! the context of the RIGHT camera's extractor (feature::orb_extractor::context() of extractor_right_; configured like the left one)
+    void set_right_context(svgpu_ctx* ctx_right) { ctx_right_ = ctx_right; }
 
     //! tracking_module::search_local_landmarks (tracking_module.cc:533-608) followed by the optimisation and outlier rejection of
     //! optimize_current_frame_with_local_map (:441-455).  Returns false when no local landmark can be projected ("projection candidate
@@ -74,6 +78,7 @@ private:
     frame_handle handle_of(const data::frame& frm);
     void remember(unsigned int frame_id, const frame_handle& h);
     uint32_t frame_serial_ = 0;
+    svgpu_ctx* ctx_right_ = nullptr;
     bool device_pose_valid_ = false;       // the tracker's device pose is the pose motion_based_track gave frame device_pose_frame_
     unsigned int device_pose_frame_ = 0;
     std::vector<uint32_t> held_stamp_;  // per landmark id: serial of the frame that holds it (curr_landmark_ids of :536-551 without a hash set)

@@ -407,3 +407,107 @@ extern "C" int svgpu_host_chain_fallback_test(const uint8_t* imgs, int n_frames,
         return -1;
     }
 }
+
+// A tracked STEREO frame through the chain (BASELINE configs[3] shape: KITTI 00 stereo, 1241 x 376, ini_fast_threshold 12): left + right
+// extraction, match::stereo::compute, frame observation, match_current_and_last_frames with the stereo gates, pose optimizer with stereo edges,
+// then the local-map half -- system.cc:406-447 + frame_tracker.cc:22-60 + tracking_module.cc:533-608, two submissions.
+// imgs_left / imgs_right: n_frames images each (row stride w); the right images show the same fronto-parallel plane `disparity` pixels further left
+// (plane at depth Z: baseline = disparity * Z / fx).  ms[8] = {motion half, 0, 0, 0, local-map half, 0, 0, total}; counts[8] = {keypoints,
+// landmarks of the last frame, matches 1, inliers 1, keypoints with a stereo partner, matches 2, inliers 2, translation error in um}.
+extern "C" int svgpu_host_tracked_frame_stereo(const uint8_t* imgs_left, const uint8_t* imgs_right, int n_frames, int w, int h, double disparity, int ini_fast_thr,
+                                               int reps, double* ms, int* counts) {
+    try {
+        if (!imgs_left || !imgs_right || n_frames < 3 || reps < 1 || !ms || !counts) return -1;
+        const double fx = 718.856, fy = 718.856, cx = 0.5 * w, cy = 0.5 * h, Z = 5.0, sx = 3.0, sy = 1.0;  // KITTI 00's focal length
+        const double bl = disparity * Z / fx;
+        camera::perspective cam(camera::setup_type_t::Stereo, (unsigned)w, (unsigned)h, fx, fy, cx, cy, 0, 0, 0, 0, 0, fx * bl);
+        cam.img_bounds_ = camera::image_bounds{0.f, (float)w, 0.f, (float)h};
+        feature::orb_params orb;
+        stella_vslam_hip::feature::orb_params hp("tracked stereo", 1.2f, 8, (unsigned)ini_fast_thr, 7);
+        stella_vslam_hip::feature::orb_extractor ext_l(&hp, 800), ext_r(&hp, 800);
+        auto pose = [&](double t) {
+            Mat44_t T = Mat44_t::Identity();
+            T(0, 3) = -t * sx * Z / fx;
+            T(1, 3) = -t * sy * Z / fy;
+            return T;
+        };
+        std::vector<kf_ptr> kfs;
+        std::vector<lm_ptr> all_lms;
+        unsigned next_lm = 1400000u;
+        for (int t = 0; t < n_frames - 1; ++t) {
+            auto kf = std::make_shared<data::keyframe>(14000u + (unsigned)t, &cam, &orb);
+            kf->set_pose_cw(pose(t));
+            std::vector<cv::KeyPoint> kps;
+            cv::Mat im(h, w, CV_8U, const_cast<uint8_t*>(imgs_left + (size_t)t * w * h), (size_t)w);
+            ext_l.extract(im, cv::Mat(), kps, kf->frm_obs_.descriptors_);
+            stella_vslam::hip::adopt_extraction(920000u + t, ext_l.context(), &cam, 64, 48, kf->frm_obs_.undist_keypts_, kf->frm_obs_.bearings_);
+            const int n = (int)kf->frm_obs_.undist_keypts_.size();
+            kf->landmarks_.assign(n, nullptr);
+            for (int i = 0; i < n; ++i) {
+                const auto& kp = kf->frm_obs_.undist_keypts_[i];
+                Vec3_t p;
+                p(0) = (kp.pt.x - cx) / fx * Z + t * sx * Z / fx, p(1) = (kp.pt.y - cy) / fy * Z + t * sy * Z / fy, p(2) = Z;
+                auto lm = std::make_shared<data::landmark>(next_lm++, p);
+                lm->add_observation(kf, (unsigned)i);
+                lm->ref_keyfrm_ = kf;
+                kf->landmarks_[i] = lm;
+                all_lms.push_back(lm);
+            }
+            kfs.push_back(kf);
+        }
+        for (auto& lm : all_lms) {
+            lm->compute_descriptor();
+            lm->update_mean_normal_and_obs_scale_variance();
+        }
+        const kf_ptr& lastkf = kfs.back();
+        data::frame last_frm(520000u, &cam, &orb);
+        last_frm.frm_obs_ = lastkf->frm_obs_;
+        last_frm.landmarks_ = lastkf->landmarks_;
+        last_frm.set_pose_cw(pose(n_frames - 2));
+        std::vector<lm_ptr> local_lms;
+        for (size_t k = 0; k + 1 < kfs.size(); ++k)
+            for (auto& lm : kfs[k]->landmarks_) local_lms.push_back(lm);
+        stella_vslam::hip::tracked_frame_chain chain(ext_l.context(), &cam, &orb, 64, 48);
+        chain.set_right_context(ext_r.context());
+        for (int k = 0; k < 8; ++k) ms[k] = 0.0, counts[k] = 0;
+        cv::Mat im_l(h, w, CV_8U, const_cast<uint8_t*>(imgs_left + (size_t)(n_frames - 1) * w * h), (size_t)w);
+        cv::Mat im_r(h, w, CV_8U, const_cast<uint8_t*>(imgs_right + (size_t)(n_frames - 1) * w * h), (size_t)w);
+        Mat44_t guess = pose(n_frames - 1);
+        guess(0, 3) += 0.004, guess(1, 3) -= 0.003, guess(2, 3) += 0.002;
+        Mat44_t last_inv = Mat44_t::Identity();
+        for (int i = 0; i < 3; ++i) last_inv(i, 3) = -last_frm.get_pose_cw()(i, 3);
+        const Mat44_t velocity = guess * last_inv;
+        for (int rep = -1; rep < reps; ++rep) {
+            const unsigned fid = 3000u + (unsigned)(rep + 1);
+            data::frame cur(fid, &cam, &orb);
+            std::vector<cv::KeyPoint> kps;
+            double t0 = now_ms();
+            const bool ok1 = chain.motion_based_track(cur, last_frm, velocity, 20, 10.0f /* stereo margin, tracking_module.cc:37-38 */, &im_l, &kps, &im_r);
+            const double t_motion = now_ms() - t0;
+            t0 = now_ms();
+            const bool ok2 = ok1 && chain.track_local_map(cur, local_lms, 0, 5.0f, 0.8f);
+            const double t_local = now_ms() - t0;
+            stella_vslam::hip::forget_frame(fid);
+            if (!ok1 || !ok2) {
+                std::fprintf(stderr, "svgpu_host_tracked_frame_stereo: the chain lost track (%d %d)\n", (int)ok1, (int)ok2);
+                return -1;
+            }
+            if (rep < 0) continue;
+            ms[0] += t_motion / reps, ms[4] += t_local / reps, ms[7] += (t_motion + t_local) / reps;
+            int with_partner = 0;
+            for (float x : cur.frm_obs_.stereo_x_right_) with_partner += x >= 0.f;
+            counts[0] = chain.last_motion_.n_keypoints, counts[1] = (int)last_frm.landmarks_.size(), counts[2] = chain.last_motion_.num_matches,
+            counts[3] = chain.last_motion_.num_valid, counts[4] = with_partner, counts[5] = chain.last_local_.num_matches, counts[6] = chain.last_local_.num_valid;
+            const Mat44_t gt = pose(n_frames - 1), opt = cur.get_pose_cw();
+            double err = 0;
+            for (int i = 0; i < 3; ++i) err = std::max(err, std::fabs(opt(i, 3) - gt(i, 3)));
+            counts[7] = (int)std::lround(err * 1e6);
+        }
+        for (auto& lm : all_lms) stella_vslam::hip::map_mirror::landmark_erased(lm->id_);
+        return 0;
+    }
+    catch (const std::exception& e) {
+        std::fprintf(stderr, "svgpu_host_tracked_frame_stereo: %s\n", e.what());
+        return -1;
+    }
+}
