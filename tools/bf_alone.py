@@ -30,3 +30,13 @@ for _ in range(n):
                                                      C.c_float(0.8), 1, C.c_void_p(matched.data_ptr()), C.c_void_p(nmatch.data_ptr()), None), "match")
 ctx.synchronize()
 print("matches per pair", nmatch.float().mean().item())
+# per-kernel times of the matcher alone (HIP events through svgpu_profile_*)
+for name in ("k_bf_binsort", "k_bf_topk", "k_bf_replay"):
+    L.svgpu_profile_select(ctx.handle, name.encode())
+    for _ in range(n):
+        ctx.check(L.svgpu_match_consecutive_batch_device(ctx.handle, B, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()), C.c_void_p(counts.data_ptr()), cap, nc, None,
+                                                         C.c_float(0.8), 1, C.c_void_p(matched.data_ptr()), C.c_void_p(nmatch.data_ptr()), None), "match")
+    ms, cnt = C.c_double(), C.c_longlong()
+    L.svgpu_profile_read(ctx.handle, C.byref(ms), C.byref(cnt))
+    print(name, "us per launch of %d pairs:" % B, round(ms.value / max(cnt.value, 1) * 1000, 1))
+L.svgpu_profile_select(ctx.handle, None)
