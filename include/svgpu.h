@@ -95,6 +95,13 @@ int svgpu_orb_scale_tables(float scale_factor, int num_levels, float* scale_fact
 int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, float scale_factor, int num_levels,
                         int ini_fast_thr, int min_fast_thr, unsigned min_area);
 
+/* Pipeline scheduling aid for callers that run other work beside a batch extraction on a second stream: `stream` waits until the LAST
+ * svgpu_orb_extract_batch_device enqueued on `ctx` has reached a stage -- 0: pyramid and blur done, FAST about to start; 1: FAST and the
+ * selection done, the descriptor kernel about to start.  bench.py holds the matcher of batch t back until the extraction of batch t+1 is
+ * at its descriptor kernel: that kernel waits on patch fetches and leaves issue slots to the matcher, the pyramid does not.
+ * No extraction enqueued yet: returns at once. */
+int svgpu_orb_stream_wait_stage(svgpu_ctx* ctx, int stage, void* stream);
+
 /* Upper bound on keypoints per frame for the configured geometry (= number of selection-grid cells). */
 int svgpu_orb_max_keypoints(const svgpu_ctx* ctx);
 /* Level geometry of the configured pyramid. */

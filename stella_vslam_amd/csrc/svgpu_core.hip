@@ -190,7 +190,8 @@ int svgpu_create_with_priority(int device, int priority, svgpu_ctx** out) {
     // the auxiliary stream carries the blur of a batch beside its FAST pass (svgpu_orb_extract*): same priority
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio) != hipSuccess
         || hipStreamCreateWithPriority(&ctx->stream_aux, hipStreamNonBlocking, prio) != hipSuccess
-        || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess
+        || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_stage[0], hipEventDisableTiming) != hipSuccess
+        || hipEventCreateWithFlags(&ctx->ev_stage[1], hipEventDisableTiming) != hipSuccess
         || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         svgpu_destroy(ctx);
         return SVGPU_ERR_HIP;
@@ -217,6 +218,8 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     sv_sky_release(ctx);
     if (ctx->ev_ba) (void)hipEventDestroy(ctx->ev_ba);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (hipEvent_t e : ctx->ev_stage)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream_aux) (void)hipStreamDestroy(ctx->stream_aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

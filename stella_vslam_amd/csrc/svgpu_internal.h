@@ -160,6 +160,8 @@ struct svgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_aux = nullptr;  // blur of a batch runs here beside FAST + selection on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};  // recorded inside svgpu_orb_extract_batch_device: [0] before k_fast, [1] before k_describe (svgpu_orb_stream_wait_stage)
+    bool stage_recorded = false;
     std::string last_error;
     SvProf prof;
     OrbConfig orb;

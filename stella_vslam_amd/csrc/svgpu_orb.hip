@@ -421,6 +421,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     }
     if (sb != s) SV_HIP(ctx, hipEventRecord(ctx->ev_join, sb));
     // 3. FAST per cell + selection-grid arg-max
+    SV_HIP(ctx, hipEventRecord(ctx->ev_stage[0], s));
     {
         SvProfScope ps(ctx, s, "k_fast");
         sv_launch_fast(s, ctx->d_levels, Lc, ctx->d_cells, (int)C.cells.size(), imgs_dev, frame_stride, row_stride, ctx->d_pyr,
@@ -434,6 +435,8 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     }
     // 5. orientation, descriptor, scale correction
     if (sb != s) SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    SV_HIP(ctx, hipEventRecord(ctx->ev_stage[1], s));
+    ctx->stage_recorded = true;
     SvProfScope ps(ctx, s, "k_describe");
     sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
                        ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch);
@@ -442,6 +445,14 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     ctx->last_imgs = imgs_dev;
     ctx->last_frame_stride = frame_stride;
     ctx->last_row_stride = row_stride;
+    return SVGPU_OK;
+}
+
+int svgpu_orb_stream_wait_stage(svgpu_ctx* ctx, int stage, void* stream) {
+    if (!ctx || stage < 0 || stage > 1 || !stream) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_orb_stream_wait_stage: bad arguments");
+    if (!ctx->stage_recorded) return SVGPU_OK;  // no extraction enqueued yet: nothing to wait for
+    SV_HIP(ctx, hipSetDevice(ctx->device));
+    SV_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_stage[stage], 0));
     return SVGPU_OK;
 }
 
