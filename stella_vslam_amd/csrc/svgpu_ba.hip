@@ -958,6 +958,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             if (h_ctl->phase == 2 || steps >= max_steps) break;
             todo = trace2 ? 1 : std::max(1, std::min(h_ctl->it_max - h_ctl->it, max_steps - steps));
         }
+        if (device_boundary && h_ctl->structure_changed) {
+            // the stage refused to start (a pose lost its last edge): the control block still carries the PREVIOUS stage's iteration count and
+            // terminate verdict -- nothing of it belongs to this stage; the caller rebuilds the structure on the host and runs the stage again
+            *iters_done = 0;
+            return SVGPU_OK;
+        }
         *iters_done = h_ctl->it;
         // errors cached by the last computeActiveErrors (used by the gate and the outlier list)
         if (*iters_done > 0) sv_ba_chi2(ctx, s, D, 0, 1, 0);
@@ -1264,7 +1270,7 @@ int svgpu_ba_partition_keyframe_segments(const svgpu_ba_problem* pr, int world, 
     for (int p = 0; p < P; ++p)
         if (seen[p] && !pr->pose_fixed[p]) slot[p] = nP++;
     info[6] = nP;
-    if (nP < 4 || nP > 16384) return SVGPU_OK;  // (the pattern below is a dense bit table)
+    if (nP < 4 || nP > 65536) return SVGPU_OK;  // (the pattern below is a dense BIT table: nP^2 / 8 bytes, 32 MB at 16 384 keyframes)
     // observations grouped by landmark
     std::vector<int> off(L + 1, 0), obs(E);
     for (int e = 0; e < E; ++e) ++off[pr->obs_point[e] + 1];
@@ -1273,7 +1279,9 @@ int svgpu_ba_partition_keyframe_segments(const svgpu_ba_problem* pr, int world, 
         std::vector<int> fill(off.begin(), off.end() - 1);
         for (int e = 0; e < E; ++e) obs[fill[pr->obs_point[e]]++] = slot[pr->obs_pose[e]];
     }
-    std::vector<uint8_t> present((size_t)nP * nP, 0);
+    std::vector<uint64_t> present(((size_t)nP * nP + 63) / 64, 0);
+    auto mark = [&](size_t k) { present[k >> 6] |= 1ull << (k & 63); };
+    auto marked = [&](size_t k) -> bool { return (present[k >> 6] >> (k & 63)) & 1ull; };
     for (int l = 0; l < L; ++l) {
         if (pr->point_fixed && pr->point_fixed[l]) continue;
         for (int i = off[l]; i < off[l + 1]; ++i) {
@@ -1281,14 +1289,14 @@ int svgpu_ba_partition_keyframe_segments(const svgpu_ba_problem* pr, int world, 
             if (a < 0) continue;
             for (int j = i + 1; j < off[l + 1]; ++j) {
                 const int b = obs[j];
-                if (b >= 0) present[(size_t)std::min(a, b) * nP + std::max(a, b)] = 1;
+                if (b >= 0) mark((size_t)std::min(a, b) * nP + std::max(a, b));
             }
         }
     }
     std::vector<int2> blk_ab;
     for (int a = 0; a < nP; ++a)
         for (int b = a; b < nP; ++b)
-            if (a == b || present[(size_t)a * nP + b]) {
+            if (a == b || marked((size_t)a * nP + b)) {
                 int2 ab;
                 ab.x = a, ab.y = b;
                 blk_ab.push_back(ab);
