@@ -11,10 +11,10 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 exec < /dev/null
-HEAD="--steps 3 --warmup 1 --no-ba --no-cpu-baseline --no-extra"
+HEAD="--steps 3 --warmup 1 --no-ba --no-cpu-baseline --no-extra --batch2 0"  # (one batch size per trace: the averages below are per-launch figures)
 # headline legs only: every launch of a front-end / matcher kernel in this trace is a $BATCH-frame launch, so the averages of the stats file
 # are the per-launch durations the bench line quotes
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks -o k --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-ba > $OUT/bench_under_rocprof.json 2> $OUT/ks.log
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks -o k --output-format csv -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-ba --batch2 0 > $OUT/bench_under_rocprof.json 2> $OUT/ks.log
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_f -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_f.log
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_w -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_w.log
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/pmc_gi -o p --output-format csv -- python $R/bench.py $HEAD > /dev/null 2> $OUT/pmc_gi.log
