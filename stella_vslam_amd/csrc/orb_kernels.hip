@@ -721,6 +721,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     //     separate alignment step), and the whole test runs on v_pk_min / max / sub: ~9 instructions per pixel instead of ~16.
     //     Every wave owns a quarter of the queue.
     int wq = 0;
+#if defined(FAST_ABLATE) && FAST_ABLATE >= 2  // profiling build only: no quick test either (staging, set-up and the empty passes remain)
+    if (mask_h == -12345)
+#endif
     {
         const uint32_t tqq = (uint32_t)(tq + 1) * 0x10001u;
         uint32_t m = 0;                           // bit 8 j + 4 + g: pixel (row g, column j) of the patch passed
@@ -766,6 +769,9 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
             my_q[pos++] = (unsigned short)(e0 + (((bit & 7) - 4) << 7) + (bit >> 3));
         }
     }
+#if defined(FAST_ABLATE) && FAST_ABLATE >= 1  // profiling build only (tools/build_variant.sh NAME -DFAST_ABLATE=1): nothing survives the quick test (opaque to the compiler)
+    if (mask_h != -12345) wq = 0;
+#endif
     // every wave scores and filters ITS quarter of the queue: no index mapping
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the queue entries were written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
