@@ -352,7 +352,7 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
         L.svgpu_orb_level_size(ctx.handle, l, C.byref(w_), C.byref(h_))
         level_px.append(w_.value * h_.value)
     stream = torch.cuda.ExternalStream(ctx.stream)
-    stream_b = torch.cuda.Stream()
+    stream_b = torch.cuda.Stream(priority=int(os.environ.get("BENCH_MATCH_PRIORITY", "0")))
     # the matcher of batch t is enqueued one step LATE, behind a stage of the extraction of batch t+1 (svgpu_orb_stream_wait_stage): -1 = right
     # behind its own extraction (rounds 1-4), 0 = when FAST starts, 1 = when the descriptor kernel starts
     # Measured (same box, 100 steps, twice each): -1: 218.4 / 218.6 k frames/s, 0: 224.1 / 224.0 k, 1: 218.7 k.  Since the pyramid became an efficient kernel

@@ -421,6 +421,13 @@ int svgpu_track_motion_stereo(svgpu_tracker* tracker, svgpu_ctx* ctx_right, svgp
                               const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation, int cap,
                               int32_t* match_last, uint8_t* outlier, svgpu_track_result* result);
 int svgpu_tracker_observation_stereo(const svgpu_tracker* tracker, const float** stereo_x_right, const float** depths);
+/* ... and for an RGB-D frame (system::create_RGBD_frame, system.cc:466-526): `depth` = the depth image in metres as CV_32F
+ * (util::convert_to_true_depth already applied by the caller), `depth_stride` in FLOATS per row.  The depth is sampled at the distorted
+ * keypoint (img_depth.at<float>(y, x), coordinates truncated), stereo_x_right_ = undist.x - focal_x_baseline / depth (-1 where depth <= 0),
+ * inside the frame-observation kernel of the same submission; read back with svgpu_tracker_observation_stereo. */
+int svgpu_track_motion_rgbd(svgpu_tracker* tracker, svgpu_frame* cur, const uint8_t* img, int stride, const float* depth, int depth_stride,
+                            const svgpu_frame* last, const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw,
+                            float margin, int check_orientation, int cap, int32_t* match_last, uint8_t* outlier, svgpu_track_result* result);
 /* tracking_module::search_local_landmarks + optimize_current_frame_with_local_map's optimisation (tracking_module.cc:533-608, 441-446)
  * as one submission.
  *   cur_lm_ids    per keypoint of `cur`: the landmark id the frame holds now (-1: none) -- after discard_outliers and update_local_map's

@@ -352,7 +352,7 @@ namespace {
 // svgpu_track_motion / svgpu_track_motion_stereo: `ctx_right` + `img_right` make the submission a stereo frame's (system.cc:406-447: the right
 // image's extraction on its own context and stream beside the left one's, match::stereo::compute behind both, then the frame observation)
 int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const uint8_t* img, int stride, const uint8_t* img_right, int stride_right,
-                 const svgpu_frame* last, const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation,
+                 const float* depth_img, int depth_stride, const svgpu_frame* last, const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation,
                  svgpu_keypoint* kps, uint8_t* desc, svgpu_keypoint* undist_kps, double* bearings, int cap, int32_t* match_last, uint8_t* outlier,
                  svgpu_track_result* result) {
     if (!t) return SVGPU_ERR_INVALID;
@@ -363,7 +363,9 @@ int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const
     if (cur->device != ctx->device || last->device != ctx->device) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: a frame lives on another device");
     const OrbConfig& C = ctx->orb;
     if (img && (!C.configured || stride < C.width)) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_track_motion: fused extraction needs svgpu_orb_configure on the tracker's context");
-    const bool stereo = img && img_right;
+    const bool stereo = img && img_right, rgbd = img && depth_img;
+    if (rgbd && (stereo || depth_stride < C.width || t->cfg.is_monocular))
+        return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_rgbd: needs a depth image of the frame's size and a tracker created with is_monocular = 0");
     if (stereo) {
         if (!ctx_right || ctx_right == ctx || ctx_right->device != ctx->device)
             return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_stereo: the right image needs a context of its own on the tracker's device");
@@ -389,8 +391,9 @@ int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const
     const int pitch = img ? C.levels[0].pitch : 0;
     const size_t img_bytes = img ? (size_t)pitch * C.height : 0;
     // what comes back of a fresh observation: the slab's prefix kps_raw | desc | undist | bearings
-    const size_t obs_bytes = !img ? 0 : stereo ? (size_t)((char*)cur->depth - cur->slab) + (size_t)cur->cap * 4 : (size_t)((char*)cur->bearings - cur->slab) + (size_t)cur->cap * 24;
-    if (stereo && (rc = reserve_right(t, img_bytes, nt_cap))) return rc;
+    const size_t obs_bytes = !img ? 0 : (stereo || rgbd) ? (size_t)((char*)cur->depth - cur->slab) + (size_t)cur->cap * 4 : (size_t)((char*)cur->bearings - cur->slab) + (size_t)cur->cap * 24;
+    const size_t depth_bytes = rgbd ? (size_t)C.width * C.height * sizeof(float) : 0;
+    if ((stereo || rgbd) && (rc = reserve_right(t, std::max(img_bytes, depth_bytes), nt_cap))) return rc;
     if ((rc = reserve(t, nt_cap, n_last, t->cap_cand, img_bytes, obs_bytes))) return rc;
     // assume_forward / assume_backward (projection.cc:101-116)
     double Rg[9], tg[3], twc[3], tlc[3];
@@ -426,6 +429,9 @@ int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const
             }
             SV_HIP(ctx, hipEventRecord(t->ev_right, sr));
             t->launches += 6;
+        }
+        if (extract && rgbd) {  // the depth image rides down on the main stream behind the colour image (dense rows of C.width floats)
+            for (int y = 0; y < C.height; ++y) memcpy(t->h_in_r + (size_t)y * C.width * 4, depth_img + (size_t)y * depth_stride, (size_t)C.width * 4);
         }
         std::unique_lock<std::mutex> lock(t->map->mtx);
         if (t->map->cap == 0) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_track_motion: the map is empty");
@@ -468,6 +474,13 @@ int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const
                 F.G.rows = t->cfg.grid_rows;
                 F.G.cell_of = cur->cell_of, F.G.cell_off = cur->cell_off, F.G.cell_items = cur->cell_items;
                 F.n_host = t->h_n;
+                if (rgbd) {
+                    SV_HIP(ctx, hipMemcpyAsync(t->d_in_r, t->h_in_r, depth_bytes, hipMemcpyHostToDevice, s));
+                    t->launches += 1;
+                    F.depth_img = (const float*)t->d_in_r, F.depth_pitch = C.width, F.focal_x_baseline = t->cam.focal_x_baseline;
+                    F.xright = cur->xright, F.depth_out = cur->depth;
+                    cur->has_xright = true;
+                }
                 sv_launch_track_frame(ctx, s, F);
                 t->launches += 6;
                 // the observation goes home on the auxiliary stream, beside the matcher and the optimiser (joined before the synchronisation)
@@ -507,7 +520,7 @@ int track_motion(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_frame* cur, const
             t->obs_off[0] = (size_t)((char*)cur->kps_raw - cur->slab), t->obs_off[1] = (size_t)((char*)cur->desc - cur->slab);
             t->obs_off[2] = (size_t)((char*)cur->undist - cur->slab), t->obs_off[3] = (size_t)((char*)cur->bearings - cur->slab);
             t->obs_off[4] = (size_t)((char*)cur->xright - cur->slab), t->obs_off[5] = (size_t)((char*)cur->depth - cur->slab);
-            t->obs_stereo = stereo;
+            t->obs_stereo = stereo || rgbd;
             if (kps) {
                 const int m = std::min(cur->n, cap);
                 const char* o = t->h_obs;
@@ -537,7 +550,7 @@ extern "C" {
 int svgpu_track_motion(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, int stride, const svgpu_frame* last, const int32_t* last_lm_ids,
                        const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation, svgpu_keypoint* kps, uint8_t* desc,
                        svgpu_keypoint* undist_kps, double* bearings, int cap, int32_t* match_last, uint8_t* outlier, svgpu_track_result* result) {
-    return track_motion(t, nullptr, cur, img, stride, nullptr, 0, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, check_orientation, kps, desc, undist_kps,
+    return track_motion(t, nullptr, cur, img, stride, nullptr, 0, nullptr, 0, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, check_orientation, kps, desc, undist_kps,
                         bearings, cap, match_last, outlier, result);
 }
 
@@ -546,7 +559,16 @@ int svgpu_track_motion_stereo(svgpu_tracker* t, svgpu_ctx* ctx_right, svgpu_fram
                               float margin, int check_orientation, int cap, int32_t* match_last, uint8_t* outlier, svgpu_track_result* result) {
     if (!t) return SVGPU_ERR_INVALID;
     if (!img_left || !img_right) return sv_set_error(t->ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_stereo: both images are required");
-    return track_motion(t, ctx_right, cur, img_left, stride_left, img_right, stride_right, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, check_orientation,
+    return track_motion(t, ctx_right, cur, img_left, stride_left, img_right, stride_right, nullptr, 0, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin,
+                        check_orientation, nullptr, nullptr, nullptr, nullptr, cap, match_last, outlier, result);
+}
+
+int svgpu_track_motion_rgbd(svgpu_tracker* t, svgpu_frame* cur, const uint8_t* img, int stride, const float* depth, int depth_stride, const svgpu_frame* last,
+                            const int32_t* last_lm_ids, const double* pose_guess_cw, const double* pose_last_cw, float margin, int check_orientation, int cap,
+                            int32_t* match_last, uint8_t* outlier, svgpu_track_result* result) {
+    if (!t) return SVGPU_ERR_INVALID;
+    if (!img || !depth) return sv_set_error(t->ctx, SVGPU_ERR_INVALID, "svgpu_track_motion_rgbd: the image and the depth image are required");
+    return track_motion(t, nullptr, cur, img, stride, nullptr, 0, depth, depth_stride, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, check_orientation,
                         nullptr, nullptr, nullptr, nullptr, cap, match_last, outlier, result);
 }
 

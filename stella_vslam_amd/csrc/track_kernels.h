@@ -21,6 +21,12 @@ struct TrackFrameProblem {
     GridProblem G;              // bounds, grid size, cell_of / cell_off / cell_items (nt ignored)
     int32_t* n_host;            // page-locked: the count, for the host
     int32_t* counter_reset;     // nullable: device word zeroed here (the matcher's list allocation counter)
+    // RGB-D frames (system.cc:492-510): depth image in metres (convert_to_true_depth already applied), sampled at the DISTORTED keypoint
+    const float* depth_img;     // nullable
+    int depth_pitch;            // floats per row
+    double focal_x_baseline;
+    float* xright;              // stereo_x_right_ = undist.x - focal_x_baseline / depth, -1 where depth <= 0
+    float* depth_out;           // depths_
 };
 void sv_launch_track_frame(svgpu_ctx* ctx, hipStream_t s, const TrackFrameProblem& P);
 

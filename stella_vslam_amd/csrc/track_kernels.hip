@@ -38,6 +38,17 @@ __global__ __launch_bounds__(1024) void k_track_frame(TrackFrameProblem P) {
         P.bearings[3 * i] = o.b0;
         P.bearings[3 * i + 1] = o.b1;
         P.bearings[3 * i + 2] = o.b2;
+        if (P.depth_img) {  // system.cc:498-510: img_depth.at<float>(y, x) with the keypoint's float coordinates truncated to int
+            const svgpu_keypoint kp = P.kps[i];
+            const float depth = P.depth_img[(size_t)(int)kp.y * P.depth_pitch + (int)kp.x];
+            float xr = -1.f, dp = -1.f;
+            if (!(depth <= 0)) {
+                dp = depth;
+                xr = (float)((double)o.ux - P.focal_x_baseline / (double)depth);  // float - double / float: evaluated in double, stored as float
+            }
+            P.xright[i] = xr;
+            P.depth_out[i] = dp;
+        }
     }
     __syncthreads();  // the grid reads xy / octave back (workgroup scope: the only workgroup)
     grid_frame_one(P.G, n);

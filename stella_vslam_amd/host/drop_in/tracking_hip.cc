@@ -246,8 +246,9 @@ void rebuild_frame(data::frame& frm, data::frame_observation& frm_obs) {
 }  // namespace
 
 bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::frame& last_frm, const Mat44_t& velocity, unsigned int num_matches_thr, float margin,
-                                             const cv::Mat* img, std::vector<cv::KeyPoint>* keypts, const cv::Mat* img_right) {
+                                             const cv::Mat* img, std::vector<cv::KeyPoint>* keypts, const cv::Mat* img_right, const cv::Mat* img_depth) {
     if (img_right && (!img || !ctx_right_)) throw std::runtime_error("tracked_frame_chain: a stereo frame needs the left image and set_right_context()");
+    if (img_depth && (!img || img_right)) throw std::runtime_error("tracked_frame_chain: an RGB-D frame is an image plus its depth map");
     lap_timer T("motion");
     // Set the initial pose by using the motion model (frame_tracker.cc:25-26)
     const Mat44_t guess = velocity * last_frm.get_pose_cw();
@@ -282,7 +283,12 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
     unsigned int num_matches = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fused = img && attempt == 0;
-        if (fused && img_right)
+        if (fused && img_depth)
+            check(svgpu_track_motion_rgbd(tracker_, cur_h.get(), img->ptr(0), (int)img->step, reinterpret_cast<const float*>(img_depth->ptr(0)),
+                                          (int)(img_depth->step / sizeof(float)), last_h.get(), last_ids_.data(), guess12, last12, margin, 1, cap, match_.data(),
+                                          outlier_.data(), &last_motion_),
+                  "svgpu_track_motion_rgbd");
+        else if (fused && img_right)
             check(svgpu_track_motion_stereo(tracker_, ctx_right_, cur_h.get(), img->ptr(0), (int)img->step, img_right->ptr(0), (int)img_right->step, last_h.get(),
                                             last_ids_.data(), guess12, last12, margin, 1, cap, match_.data(), outlier_.data(), &last_motion_),
                   "svgpu_track_motion_stereo");
@@ -306,7 +312,7 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
             o.bearings_.resize(n);
             for (int i = 0; i < n; ++i)
                 for (int k = 0; k < 3; ++k) o.bearings_[i](k) = brg[3 * (size_t)i + k];
-            if (img_right) {  // system.cc:443-447
+            if (img_right || img_depth) {  // system.cc:443-447 / :492-510
                 const float *xr = nullptr, *dp = nullptr;
                 if (svgpu_tracker_observation_stereo(tracker_, &xr, &dp) != n) throw std::runtime_error("tracked_frame_chain: the stereo observation is missing");
                 o.stereo_x_right_.assign(xr, xr + n);

@@ -36,7 +36,8 @@ public:
     //! With `img_right` as well (and a right context, set_right_context) the frame is a STEREO frame (system.cc:406-447): the right image is
     //! extracted on the right context beside the left one, match::stereo::compute fills frm_obs_.stereo_x_right_ / depths_ -- same submission.
     bool motion_based_track(data::frame& curr_frm, const data::frame& last_frm, const Mat44_t& velocity, unsigned int num_matches_thr, float margin,
-                            const cv::Mat* img = nullptr, std::vector<cv::KeyPoint>* keypts = nullptr, const cv::Mat* img_right = nullptr);
+                            const cv::Mat* img = nullptr, std::vector<cv::KeyPoint>* keypts = nullptr, const cv::Mat* img_right = nullptr,
+                            const cv::Mat* img_depth = nullptr);  //!< RGB-D (system.cc:466-526): CV_32F depth in metres instead of a right image
     //! the context of the RIGHT camera's extractor (feature::orb_extractor::context() of extractor_right_; configured like the left one)
     void set_right_context(svgpu_ctx* ctx_right) { ctx_right_ = ctx_right; }
 

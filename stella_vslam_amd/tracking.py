@@ -147,8 +147,13 @@ class tracker:
         out.update(match_last=match[:len(ids)].copy(), outlier=outl[:n].copy(), result=res.as_dict())
         return out
 
+    def track_motion_rgbd(self, cur: resident_frame, last: resident_frame, last_lm_ids, pose_guess_cw, pose_last_cw, margin: float, img: np.ndarray,
+                          depth: np.ndarray, check_orientation: bool = True):
+        """An RGB-D frame in one submission (svgpu_track_motion_rgbd): `depth` = float32 metres, same shape as `img`.  Same outputs as track_motion_stereo."""
+        return self.track_motion_stereo(cur, last, last_lm_ids, pose_guess_cw, pose_last_cw, margin, img, None, None, check_orientation, depth=depth)
+
     def track_motion_stereo(self, cur: resident_frame, last: resident_frame, last_lm_ids, pose_guess_cw, pose_last_cw, margin: float, img_left: np.ndarray,
-                            img_right: np.ndarray, ctx_right: Context, check_orientation: bool = True):
+                            img_right: np.ndarray, ctx_right: Context, check_orientation: bool = True, depth: np.ndarray | None = None):
         """A stereo frame in one submission (svgpu_track_motion_stereo): both extractions, match::stereo::compute, the left observation, matcher and
         optimiser.  -> dict(match_last, outlier, result, keypts, descriptors, undist_keypts, bearings, stereo_x_right, depths)"""
         from .feature import KEYPOINT_DTYPE as KP
@@ -158,12 +163,19 @@ class tracker:
         plast = np.ascontiguousarray(pose_last_cw, np.float64).reshape(12)
         match = np.full(max(len(ids), 1), -1, np.int32)
         res = _TrackResult()
-        il, ir = np.ascontiguousarray(img_left, np.uint8), np.ascontiguousarray(img_right, np.uint8)
+        il = np.ascontiguousarray(img_left, np.uint8)
         cap = max(int(lib().svgpu_orb_max_keypoints(self.ctx.handle)), 1)
         outl = np.zeros(cap, np.uint8)
-        self.ctx.check(lib().svgpu_track_motion_stereo(self._h, ctx_right.handle, cur._h, _p(il), il.strides[0], _p(ir), ir.strides[0], last._h, _p(ids), _p(guess),
-                                                       _p(plast), C.c_float(margin), int(check_orientation), cap, _p(match), _p(outl), C.byref(res)),
-                       "svgpu_track_motion_stereo")
+        if depth is not None:
+            dm = np.ascontiguousarray(depth, np.float32)
+            assert dm.shape == il.shape
+            self.ctx.check(lib().svgpu_track_motion_rgbd(self._h, cur._h, _p(il), il.strides[0], _p(dm), dm.strides[0] // 4, last._h, _p(ids), _p(guess), _p(plast),
+                                                         C.c_float(margin), int(check_orientation), cap, _p(match), _p(outl), C.byref(res)), "svgpu_track_motion_rgbd")
+        else:
+            ir = np.ascontiguousarray(img_right, np.uint8)
+            self.ctx.check(lib().svgpu_track_motion_stereo(self._h, ctx_right.handle, cur._h, _p(il), il.strides[0], _p(ir), ir.strides[0], last._h, _p(ids), _p(guess),
+                                                           _p(plast), C.c_float(margin), int(check_orientation), cap, _p(match), _p(outl), C.byref(res)),
+                           "svgpu_track_motion_stereo")
         n = res.n_keypoints
         pk, pd, pu, pb, px, pz = (C.c_void_p() for _ in range(6))
         got = lib().svgpu_tracker_observation(self._h, C.byref(pk), C.byref(pd), C.byref(pu), C.byref(pb))

@@ -594,6 +594,70 @@ def test_fused_stereo_extraction_equals_the_separate_steps():
         trk.track_motion_stereo(data.resident_frame(ctx), rf_last, ids, guess, pose_last, 15.0, left[1], right[1], ctx)
 
 
+def test_fused_rgbd_frame_equals_the_separate_steps():
+    """svgpu_track_motion_rgbd: extraction, undistortion, the depth sampled at the distorted keypoint (system.cc:492-510), bearings, grid, matcher and
+    optimiser in one submission.  stereo_x_right_ / depths_ equal the reference's arithmetic (float coordinates truncated, float - double / float)
+    bit for bit; the tracking result equals the chain on a frame adopted from the separate steps."""
+    from stella_vslam_amd import camera, data, feature, synthetic, tracking
+    Wk, Hk = 640, 480
+    imgs = synthetic.frame_sequence(2, Wk, Hk, seed=31)
+    ext = feature.orb_extractor(feature.orb_params())
+    ctx = ext.ctx
+    fx = fy = 517.3
+    cx, cy, fxb = 318.6, 255.3, 40.0
+    dist = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)     # TUM fr1-like distortion
+    cam = camera.perspective("t", "RGBD", "Gray", Wk, Hk, 30.0, fx, fy, cx, cy, *dist, focal_x_baseline=fxb, ctx=ctx)
+    T = synthetic.orb_tables(1.2, 8)
+    yy, xx = np.mgrid[0:Hk, 0:Wk]
+    depth = (4.0 + 1.5 * np.sin(xx / 70.0) + 0.8 * np.cos(yy / 55.0)).astype(np.float32)
+    depth[(xx // 40 + yy // 40) % 7 == 0] = 0.0            # holes of the sensor
+    depth[100:140, 300:360] = -1.0
+
+    def stereo_of(k, und):
+        d = depth[k["y"].astype(np.int32), k["x"].astype(np.int32)]      # at<float>(y, x): float -> int truncation
+        ok = ~(d <= 0)
+        dd = np.where(ok, d, np.float32(1)).astype(np.float64)
+        xr = np.where(ok, (und["x"].astype(np.float64) - fxb / dd).astype(np.float32), np.float32(-1))
+        return xr.astype(np.float32), np.where(ok, d, np.float32(-1)).astype(np.float32)
+
+    k0, d0 = ext.extract(imgs[0])
+    rf_last = data.resident_frame(ctx)
+    und0, _ = rf_last.adopt_extraction(cam, 64, 48)
+    xr0, dp0 = stereo_of(k0, und0)
+    rf_last.set_stereo(xr0)
+    Z = np.where(dp0 > 0, dp0, 4.0).astype(np.float64)
+    pos = np.stack([(und0["x"] - cx) / fx * Z, (und0["y"] - cy) / fy * Z, Z], 1)
+    dist0 = np.linalg.norm(pos, axis=1)
+    nrm = pos / dist0[:, None]
+    maxd = (dist0 * T["scale_factors"][und0["octave"]]).astype(np.float32)
+    mind = (maxd * T["inv_scale_factors"][7]).astype(np.float32)
+    ids = np.where(dp0 > 0, np.arange(len(und0)) * 2 + 1, -1).astype(np.int32)
+    have = ids >= 0
+    table = tracking.landmark_table(ctx).upsert(ids[have], tracking.landmark_records(pos[have], nrm[have], mind[have], maxd[have], d0[have]))
+    trk = tracking.tracker(ctx, table, cam, T["scale_factors"], T["inv_level_sigma_sq"], T["log_scale_factor"], is_monocular=False, true_baseline=fxb / fx)
+    pose_last = _pose12(np.eye(3), np.zeros(3))
+    zbar = float(np.median(Z[have]))
+    guess = _pose12(np.eye(3), np.array([-3.0 * zbar / fx, -1.0 * zbar / fy, 0.0]))
+    rf_cur = data.resident_frame(ctx)
+    got = trk.track_motion_rgbd(rf_cur, rf_last, ids, guess, pose_last, 15.0, imgs[1], depth)
+    k1, d1 = ext.extract(imgs[1])
+    assert len(k1) == got["result"]["n_keypoints"] > 1500
+    obs = data.frame_observation(cam, k1, d1)
+    for f in ("x", "y", "octave", "angle"):
+        assert np.array_equal(got["undist_keypts"][f], obs.undist_keypts_[f]), f
+    xr1, dp1 = stereo_of(k1, obs.undist_keypts_)
+    assert (xr1 >= 0).sum() > 1000 and (dp1 < 0).sum() > 100
+    assert np.array_equal(got["stereo_x_right"].view(np.uint32), xr1.view(np.uint32))
+    assert np.array_equal(got["depths"].view(np.uint32), dp1.view(np.uint32))
+    rf_ref = data.resident_frame(ctx)
+    rf_ref.adopt_extraction(cam, 64, 48)
+    rf_ref.set_stereo(xr1)
+    ref = trk.track_motion(rf_ref, rf_last, ids, guess, pose_last, 15.0)
+    assert got["result"]["num_matches"] == ref["result"]["num_matches"] > 300
+    assert np.array_equal(got["match_last"], ref["match_last"]) and np.array_equal(got["outlier"], ref["outlier"])
+    assert np.array_equal(got["result"]["pose_cw"], ref["result"]["pose_cw"])
+
+
 def test_track_entry_points_reject_bad_arguments(ctx):
     from stella_vslam_amd import tracking
     from stella_vslam_amd._lib import SvgpuError
