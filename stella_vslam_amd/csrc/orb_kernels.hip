@@ -950,7 +950,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 // per keypoint but measured slower, 121-136 us against 109: the longer per-wave chains of dependent patch fetches cost
 // more than the saved issue slots.)
 #ifndef DESC_KPW
-#define DESC_KPW 4  // keypoints per wave.  Same-box runs of the pipeline: 2 / 3 / 4 / 5 / 6 / 8 -> 207 / 207.5 / 208.9 / 210.3 / 208.9 / 206 k frames/s: flat (fewer
+#define DESC_KPW 5  // keypoints per wave.  Stand-alone per 1 024 frames (round 5): 3 / 4 / 5 / 6 -> 1.29 / 1.25 / 1.20 / 1.22 ms; round 4, pipeline: 2 / 3 / 4 / 5 / 6 / 8 -> 207 / 207.5 / 208.9 / 210.3 / 208.9 / 206 k frames/s: flat (fewer
                     // keypoints mean more waves per SIMD, more of them amortise the orientation pass: neither is what limits the kernel)
 #endif
 #define DESC_IP 32                     // LDS row pitch of the 31 x 31 patch (8 dwords)
