@@ -54,6 +54,7 @@ python tools/pmc_valu.py $OUT/pmc_gi profiles/${TAG}_valu_issue.json $BATCH $OUT
 python tools/pmc_lds_mfma.py $OUT/pmc_lds profiles/${TAG}_lds_mfma.json $BATCH > $OUT/lds_mfma.log 2>&1
 cp profiles/${TAG}_traffic.json profiles/${TAG}_valu_issue.json profiles/${TAG}_lds_mfma.json $OUT/
 timeout 400 python bench.py 2> $OUT/bench.log < /dev/null | tail -1 > $OUT/bench.json
+cp bench_detail.json $OUT/bench_detail.json 2>/dev/null
 timeout 300 python tools/ba_bench.py --global > $OUT/ba_bench.log 2>&1 < /dev/null
 cp gpurun_out/ba_bench.json $OUT/ba_bench.json 2>/dev/null
 # keep the merge-back small: the raw traces stay on the box, the summaries travel
