@@ -254,6 +254,8 @@ def compact_line(r):
     for key in ("overlapped_stream_longest", "matrix_core_kernel"):
         if isinstance(rf.get(key), dict):
             alts[rf[key].get("kernel", key)] = _pick(rf[key], ("achieved", "frac", "mean_launch_ms"))
+            if isinstance(rf[key].get("standalone"), dict):  # the kernel's own duration (extraction stream idle) beside its elapsed time in the pipeline
+                alts[rf[key].get("kernel", key)]["standalone"] = _pick(rf[key]["standalone"], ("achieved", "frac", "mean_launch_ms"))
     for k in rf.get("kernels", []):   # the two kernels north_star's 0.6 bar names beside the matcher's
         if k["kernel"] in ("k_describe", "k_fast") and k["kernel"] != ro.get("kernel"):
             hb = k.get("hbm_context") or k
@@ -423,7 +425,7 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
     n_kp = bufs[0]["counts"].view(B, nc)[:, 0].float().mean().item()
     n_match = bufs[0]["nmatch"].float().mean().item()
     # ---- timed region: exactly K steps between barrier + synchronize, every kernel class bracketed by HIP events on its stream
-    per_kernel, ops = {}, C.c_ulonglong()
+    per_kernel, ops, alone = {}, C.c_ulonglong(), {}
     if profile:
         L.svgpu_profile_select(ctx.handle, b"*")
         dt = max_over_ranks(timed(steps))  # MAX over ranks (RCCL when world > 1)
@@ -434,10 +436,26 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
         L.svgpu_profile_mfma_ops(ctx.handle, C.byref(ops))
         L.svgpu_profile_select(ctx.handle, None)
         dt_plain = max_over_ranks(timed(steps))
+        # the matcher kernels ALONE (outside the timed region, on the buffers of the last batch): inside the pipeline they run on the issue slots the
+        # extraction stream leaves, so their elapsed time there is 2 - 3 x their own; both figures are reported
+        sync_all()
+        bf = bufs[(state["i"] - 1) % NBUF]
+        L.svgpu_profile_select(ctx.handle, b"*")
+        for _ in range(4):
+            ctx.check(L.svgpu_match_consecutive_batch_device(
+                ctx.handle, B, C.c_void_p(bf["desc"].data_ptr()), C.c_void_p(bf["kps"].data_ptr()), C.c_void_p(bf["counts"].data_ptr()), cap, nc, None,
+                C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()), C.c_void_p(bf["nmatch"].data_ptr()), C.c_void_p(stream_b.cuda_stream)), "match_batch")
+        sync_all()
+        for name in ("k_bf_binsort", "k_bf_topk", "k_bf_replay"):
+            ms, n = C.c_double(), C.c_longlong()
+            L.svgpu_profile_read_class(ctx.handle, name.encode(), C.byref(ms), C.byref(n))
+            if n.value:
+                alone[name] = ms.value / n.value
+        L.svgpu_profile_select(ctx.handle, None)
     else:
         dt = dt_plain = max_over_ranks(timed(steps))
     del bufs, frames
-    return {"dt": dt, "ms_per_step_unprofiled": dt_plain / steps * 1e3, "per_kernel": per_kernel, "mfma_ops": ops.value, "steps": steps,
+    return {"dt": dt, "ms_per_step_unprofiled": dt_plain / steps * 1e3, "per_kernel": per_kernel, "mfma_ops": ops.value, "steps": steps, "matcher_alone_ms": alone,
             "n_kp": n_kp, "n_match": n_match, "alg": algorithmic_bytes(level_px, n_kp, B), "level_px": level_px}
 
 
@@ -481,6 +499,10 @@ def roofline_entries(fe, src_hash, B, world):
             entry["all_pairs_context"] = {"ops_per_launch": int(allpairs), "achieved": round(allpairs / (mean_ms * 1e-3) / 1e12, 2),
                                           "frac": round(allpairs / (mean_ms * 1e-3) / 1e12 / p_, 5),
                                           "note": "2 x 256 x N1 x N2 per pair = the work of robust.cc:271-314 if every pair were multiplied"}
+        if name in fe.get("matcher_alone_ms", {}):  # overlapped stream: the kernel's own duration, measured with the extraction stream idle
+            a_ms = fe["matcher_alone_ms"][name]
+            a_ach = per_launch / (a_ms * 1e-3) / (1e9 if b_ == "hbm" else 1e12)
+            entry["standalone"] = {"mean_launch_ms": round(a_ms, 5), "achieved": round(a_ach, 2), "frac": round(a_ach / p_, 5)}
         vi = entry["valu_issue"]
         if b_ == "hbm" and vi is not None and vi["frac"] >= 0.5 and vi["frac"] > entry["frac"]:
             # the kernel is bound by VALU issue, not by bytes: the issue fraction (VALU wave-instructions x 4 cycles over the SIMD-cycles of the
@@ -511,10 +533,10 @@ def roofline_entries(fe, src_hash, B, world):
     over = [k for k in kernels if k["kernel"] not in CRITICAL_STREAM]
     if over:
         ok = max(over, key=lambda k: k["mean_launch_ms"] * k["launches_per_step"])
-        dom["overlapped_stream_longest"] = {k: ok[k] for k in ("kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms") if k in ok}
+        dom["overlapped_stream_longest"] = {k: ok[k] for k in ("kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms", "standalone") if k in ok}
         mf = next((k for k in over if k["bound"] == "mfma"), None)
         if mf is not None:
-            dom["matrix_core_kernel"] = {k: mf[k] for k in ("kernel", "rocprof_kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms", "executed_int8_ops_per_launch", "mfma_busy_frac") if k in mf}
+            dom["matrix_core_kernel"] = {k: mf[k] for k in ("kernel", "rocprof_kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms", "executed_int8_ops_per_launch", "mfma_busy_frac", "standalone") if k in mf}
     for k in ("algorithmic_bytes_per_launch", "executed_int8_ops_per_launch"):
         if k in dk:
             dom[k] = dk[k]
