@@ -331,6 +331,21 @@ KERNEL_CLASSES = ("k_resize", "k_blur", "k_fast", "k_select", "k_describe", "k_b
 ROCPROF_KERNEL = {"k_resize": "k_pyramid_lds", "k_bf_topk": "k_bf_mfma"}
 
 
+_MATCHER_STREAM = None
+
+
+def matcher_stream():
+    """The matcher's stream, created ONCE per process (as a tracking thread would).  Measured (round 5, tools/scratch/streams.py, 256 frames/step, 8 calls
+    in one process): with one stream kept, 212-215 k frames/s on every call; with a fresh torch.cuda.Stream per call, calls 2 and 5 drop to 163-166 k —
+    some streams of torch's pool land on a hardware queue that serialises against the extraction stream's (k_select doubles, k_resize gets faster:
+    the overlap pattern changes, not the kernels).  Rounds 1-5's 'second_batch_point' was such a second stream."""
+    global _MATCHER_STREAM
+    import torch
+    if _MATCHER_STREAM is None:
+        _MATCHER_STREAM = torch.cuda.Stream(priority=int(os.environ.get("BENCH_MATCH_PRIORITY", "0")))
+    return _MATCHER_STREAM
+
+
 def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=True):
     """The step of this bench on one rank: ORB extraction of the B resident frames + brute-force match of each against the previous one
     (ring of B pairs).  Two HIP streams: extraction of step t+1 (stream A = the context's) overlaps the matcher of step t (stream B),
@@ -354,7 +369,7 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
         L.svgpu_orb_level_size(ctx.handle, l, C.byref(w_), C.byref(h_))
         level_px.append(w_.value * h_.value)
     stream = torch.cuda.ExternalStream(ctx.stream)
-    stream_b = torch.cuda.Stream(priority=int(os.environ.get("BENCH_MATCH_PRIORITY", "0")))
+    stream_b = matcher_stream()
     # the matcher of batch t is enqueued one step LATE, behind a stage of the extraction of batch t+1 (svgpu_orb_stream_wait_stage): -1 = right
     # behind its own extraction (rounds 1-4), 0 = when FAST starts, 1 = when the descriptor kernel starts
     # Measured (same box, 100 steps, twice each): -1: 218.4 / 218.6 k frames/s, 0: 224.1 / 224.0 k, 1: 218.7 k.  Since the pyramid became an efficient kernel
