@@ -97,11 +97,10 @@ __global__ void k_narrow_u64(const unsigned long long* __restrict__ v, int n, in
 }
 // everything the set-up does once per observation, in one launch: the robust-kernel flag, the (pose, index) sort records, level and cached
 // chi2 cleared (five launches -- three kernels and two memsets -- at ~5 us each before)
-__global__ void k_obs_prepare(const float* __restrict__ e_huber, const int* __restrict__ e_pose, int n, uint8_t* __restrict__ robust, unsigned* __restrict__ keys,
+__global__ void k_obs_prepare(const int* __restrict__ e_pose, int n, unsigned* __restrict__ keys,
                               unsigned long long* __restrict__ vals, uint8_t* __restrict__ e_level, double* __restrict__ e_chi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    robust[i] = e_huber[i] > 0.f ? 1 : 0;
     keys[i] = (unsigned)e_pose[i];
     vals[i] = (unsigned long long)(unsigned)i;
     e_level[i] = 0;
@@ -110,11 +109,12 @@ __global__ void k_obs_prepare(const float* __restrict__ e_huber, const int* __re
 // the pose-major copies straight from the sorted records (position q of the pose -> edge lists): pe_idx and the observation it points at
 __global__ void k_pose_major_sorted(const unsigned long long* __restrict__ vals, const int* __restrict__ e_point, const float* __restrict__ e_uvr,
                                     const float* __restrict__ e_w, const float* __restrict__ e_hub, int E, int* __restrict__ pe_idx, int* __restrict__ pm_point,
-                                    float* __restrict__ pm_uvr, float* __restrict__ pm_w, float* __restrict__ pm_hub) {
+                                    float* __restrict__ pm_uvr, float* __restrict__ pm_w, float* __restrict__ pm_hub, uint8_t* __restrict__ robust) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= E) return;
     const int e = (int)(unsigned)vals[q];
     pe_idx[q] = e;
+    robust[e] = e_hub[e] > 0.f ? 1 : 0;  // (every edge is at exactly one position of the pose -> edge lists)
     pm_point[q] = e_point[e];
     pm_uvr[3 * (size_t)q] = e_uvr[3 * (size_t)e];
     pm_uvr[3 * (size_t)q + 1] = e_uvr[3 * (size_t)e + 1];
@@ -235,10 +235,14 @@ void sv_ba_build_pose_major(hipStream_t s, const int* pe_idx, const int* e_point
     if (E > 0) hipLaunchKernelGGL(k_pose_major, dim3((E + 255) / 256), dim3(256), 0, s, pe_idx, e_point, e_uvr, e_w, e_hub, E, pm_point, pm_uvr, pm_w, pm_hub);
 }
 // The pose -> edge lists, the robust flags, the cleared level / chi2 arrays and the pose-major observation copies in 2 + 3 per radix pass + 1
-// launches (sv_ba_build_pose_lists + sv_ba_build_pose_major + two memsets took 5 more)
-int sv_ba_prepare_observations(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const int* e_point_dev, const float* e_uvr_dev, const float* e_w_dev,
-                               const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes, int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev,
-                               uint8_t* e_level_dev, double* e_chi_dev, int* pm_point, float* pm_uvr, float* pm_w, float* pm_hub) {
+// launches (sv_ba_build_pose_lists + sv_ba_build_pose_major + two memsets took 5 more).  Two halves, so that a global-BA sized call can
+// run the first one -- it needs the observations' POSE INDICES only -- while the measurements are still on their way to the device:
+//   sv_ba_prepare_lists       level / chi2 cleared, edges sorted by pose, pe_off; *sorted_out = the sorted (pose, edge) records, which stay
+//                             in `scratch` until the second half has run
+//   sv_ba_prepare_pose_major  pe_idx, the pose-major copies of point / measurement / information / kernel width, the robust flags
+int sv_ba_prepare_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, int E, int P, void* scratch, size_t scratch_bytes, int* pe_off_dev, uint8_t* e_level_dev,
+                        double* e_chi_dev, const void** sorted_out) {
+    *sorted_out = nullptr;
     if (E <= 0) {
         SV_HIP(ctx, hipMemsetAsync(pe_off_dev, 0, 4 * ((size_t)P + 1), s));
         return SVGPU_OK;
@@ -254,12 +258,20 @@ int sv_ba_prepare_observations(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_
     int* hist = (int*)take(sv_sort_hist_ints(E) * 4);
     if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "pose-list scratch too small");
     const dim3 g((E + 255) / 256), b(256);
-    hipLaunchKernelGGL(k_obs_prepare, g, b, 0, s, e_huber_dev, e_pose_dev, E, robust_dev, keys[0], vals[0], e_level_dev, e_chi_dev);
+    hipLaunchKernelGGL(k_obs_prepare, g, b, 0, s, e_pose_dev, E, keys[0], vals[0], e_level_dev, e_chi_dev);
     int bits = 1;
     while ((1u << bits) < (unsigned)P && bits < 31) ++bits;
     const int r = sv_sort_pairs(s, keys, vals, 0, E, bits, hist);
-    hipLaunchKernelGGL(k_pose_major_sorted, g, b, 0, s, vals[r], e_point_dev, e_uvr_dev, e_w_dev, e_huber_dev, E, pe_idx_dev, pm_point, pm_uvr, pm_w, pm_hub);
     hipLaunchKernelGGL(k_pair_offsets, dim3((P + 256) / 256), dim3(256), 0, s, keys[r], (const int*)nullptr, E, P, pe_off_dev);
+    SV_HIP(ctx, hipGetLastError());
+    *sorted_out = vals[r];
+    return SVGPU_OK;
+}
+int sv_ba_prepare_pose_major(svgpu_ctx* ctx, hipStream_t s, const void* sorted, const int* e_point_dev, const float* e_uvr_dev, const float* e_w_dev, const float* e_huber_dev,
+                             int E, int* pe_idx_dev, uint8_t* robust_dev, int* pm_point, float* pm_uvr, float* pm_w, float* pm_hub) {
+    if (E <= 0 || !sorted) return SVGPU_OK;
+    hipLaunchKernelGGL(k_pose_major_sorted, dim3((E + 255) / 256), dim3(256), 0, s, (const unsigned long long*)sorted, e_point_dev, e_uvr_dev, e_w_dev, e_huber_dev, E, pe_idx_dev,
+                       pm_point, pm_uvr, pm_w, pm_hub, robust_dev);
     SV_HIP(ctx, hipGetLastError());
     return SVGPU_OK;
 }

@@ -29,9 +29,10 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
                             int2* pairs_out, int* pair_l_out, int* dense_off_dev);
 size_t sv_ba_pose_lists_scratch_bytes(size_t E);
-int sv_ba_prepare_observations(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const int* e_point_dev, const float* e_uvr_dev, const float* e_w_dev,
-                               const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes, int* pe_off_dev, int* pe_idx_dev, uint8_t* robust_dev,
-                               uint8_t* e_level_dev, double* e_chi_dev, int* pm_point, float* pm_uvr, float* pm_w, float* pm_hub);
+int sv_ba_prepare_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, int E, int P, void* scratch, size_t scratch_bytes, int* pe_off_dev, uint8_t* e_level_dev,
+                        double* e_chi_dev, const void** sorted_out);
+int sv_ba_prepare_pose_major(svgpu_ctx* ctx, hipStream_t s, const void* sorted, const int* e_point_dev, const float* e_uvr_dev, const float* e_w_dev, const float* e_huber_dev,
+                             int E, int* pe_idx_dev, uint8_t* robust_dev, int* pm_point, float* pm_uvr, float* pm_w, float* pm_hub);
 void sv_ba_build_pose_major(hipStream_t s, const int* pe_idx, const int* e_point, const float* e_uvr, const float* e_w, const float* e_hub, int E, int* pm_point,
                             float* pm_uvr, float* pm_w, float* pm_hub);
 int sv_ba_build_pose_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, const float* e_huber_dev, int E, int P, void* scratch, size_t scratch_bytes,
@@ -253,6 +254,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     float* const e_uvr = (float*)(hs + in.e_uvr);
     float* const e_w = (float*)(hs + in.e_w);
     float* const e_hub = (float*)(hs + in.e_hub);
+    auto copy_measurements = [&](size_t a, size_t b) {
+        memcpy(e_uvr + 3 * a, pr->obs_uvr + 3 * a, 12 * (b - a));
+        memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
+        if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
+        else memset(e_hub + a, 0, 4 * (b - a));
+    };
     std::vector<int> perm;  // sorted position -> caller's observation index (empty = identity)
     std::vector<uint8_t> level(E, 0);
     bool no_levels = true;  // until the first gate: every edge is at level 0
@@ -272,9 +279,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         std::vector<uint8_t> seen_q[16];
         // (a global-BA sized problem is 34 MB of observations: the host threads also share the copy into the staging image -- harmless
         //  when the order turns out not to be landmark-major, the permuted copy below overwrites it)
-        auto copy_range = [&](size_t a, size_t b) {
+        auto copy_range = [&](size_t a, size_t b, bool indices_only) {
             memcpy(e_pose + a, pr->obs_pose + a, 4 * (b - a));
             memcpy(e_point + a, pr->obs_point + a, 4 * (b - a));
+            if (indices_only) return;  // (the measurements follow in the second, pipelined pass: stage_measurements below)
             memcpy(e_uvr + 3 * a, pr->obs_uvr + 3 * a, 12 * (b - a));
             memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
             if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
@@ -299,10 +307,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                     for (int k = (prev < 0 ? 0 : prev + 1); k <= l; ++k) lm_off[k] = (int)e;  // landmarks prev + 1 .. l start here
             }
             bad[q] = bd, unsorted[q] = un;
-            if (!bd) copy_range(e0, end);
-            // (the landmark positions -- 4.8 MB at config 5 -- are shared the same way)
-            const size_t l0 = (size_t)L * q / nth, l1 = (size_t)L * (q + 1) / nth;
-            memcpy(hs + in.points + sizeof(double) * 3 * l0, pr->points + 3 * l0, sizeof(double) * 3 * (l1 - l0));
+            if (!bd) copy_range(e0, end, true);
         };
         // One thread (local-BA sizes): the same facts from straight-line passes -- flag reductions the compiler vectorises, then the landmark
         // offsets as "end of landmark l = index behind its last observation" stored unconditionally and closed over the empty landmarks by
@@ -327,7 +332,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                     lm_off[k] = v;
                 }
             }
-            copy_range(0, (size_t)E);
+            copy_range(0, (size_t)E, false);
             memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
         };
         std::vector<std::thread> th;
@@ -351,6 +356,12 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
         for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
     }
+    // Global-BA sizes, observations grouped by landmark (the order global_bundle_adjuster.cc:66-118 creates its edges in): the host threads
+    // have staged the INDEX arrays only.  The measurements (uvr, information, kernel width: 20 of the 28 bytes of an observation) and the
+    // landmark positions are staged by the same threads in a second pass that runs BESIDE the device's structure work (pose -> edge lists,
+    // (edge, edge) pair lists, block rows: they read indices only) and go up on a copy stream, chunk by chunk as they are staged.
+    const bool pipelined = nth > 1 && lm_major;
+    if (nth > 1 && !lm_major) memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
     if (!lm_major) {
         perm.resize(E);
         std::vector<int> fill(lm_off, lm_off + L);
@@ -564,15 +575,96 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     };
 
 #define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
-    H2D(D.pose_buf[0], hs, in.total);
-    {   // pose -> edge lists + robust flags on the device; the sort's scratch borrows the (not yet used) W buffer when it fits, else the pair scratch
+    // second pass of a pipelined set-up: thread q stages its range in chunks and uploads each chunk on the copy stream as soon as it is staged
+    struct Stager {
+        std::vector<std::thread> th;
+        int err[16] = {0};
+        bool pending = false;
+        ~Stager() {
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+        }
+    } stager;
+    const void* sorted_edges = nullptr;  // the (pose, edge) records of sv_ba_prepare_lists, kept in the W buffer until the measurements are there
+    char* const d_in = (char*)D.pose_buf[0];
+    {
         const size_t want = sv_ba_pose_lists_scratch_bytes((size_t)E);
-        void* sc = sizeof(double) * 18 * (size_t)E >= want ? (void*)D.W : (void*)d_pair_scratch;
-        const size_t sc_bytes = sizeof(double) * 18 * (size_t)E >= want ? sizeof(double) * 18 * (size_t)E : pair_scratch;
-        const int rp = sv_ba_prepare_observations(ctx, s, d_e_pose, d_e_point, d_e_uvr, d_e_w, d_e_hub, E, P, sc, sc_bytes, d_pe_off, d_pe_idx, D.e_robust, D.e_level,
-                                                  D.e_chi, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);  // (also clears e_level / e_chi)
+        const bool in_W = sizeof(double) * 18 * (size_t)E >= want;  // (the pair lists are built in the pair scratch: the records survive them only in W)
+        void* sc = in_W ? (void*)D.W : (void*)d_pair_scratch;
+        const size_t sc_bytes = in_W ? sizeof(double) * 18 * (size_t)E : pair_scratch;
+        if (pipelined && in_W) {
+            if (!ctx->ba_copy_stream) SV_HIP(ctx, hipStreamCreateWithFlags(&ctx->ba_copy_stream, hipStreamNonBlocking));
+            if (!ctx->ev_ba_copy) SV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ba_copy, hipEventDisableTiming));
+            // (the staging image may still be the source of the previous call's copies on the copy stream only if that call failed half-way)
+            SV_HIP(ctx, hipStreamSynchronize(ctx->ba_copy_stream));
+            H2D(d_in + in.pose, hs + in.pose, in.points - in.pose);          // poses
+            H2D(d_in + in.intr, hs + in.intr, in.e_uvr - in.intr);            // intrinsics | e_pose | e_point
+            H2D(d_in + in.lm_off, hs + in.lm_off, in.pe_off - in.lm_off);     // landmark offsets
+            hipStream_t s2 = ctx->ba_copy_stream;
+            stager.pending = true;
+            auto stage_measurements = [&, s2](int q) {
+                const size_t CH = (size_t)128 << 10;  // observations per chunk: 2.6 MB of measurements
+                const size_t e0 = (size_t)E * q / nth, e1 = (size_t)E * (q + 1) / nth;
+                hipError_t he = hipSuccess;
+                auto up = [&](size_t off, size_t bytes) {
+                    if (bytes && he == hipSuccess) he = hipMemcpyAsync(d_in + off, hs + off, bytes, hipMemcpyHostToDevice, s2);
+                };
+                for (size_t a = e0; a < e1; a += CH) {
+                    const size_t b = std::min(e1, a + CH);
+                    memcpy(e_uvr + 3 * a, pr->obs_uvr + 3 * a, 12 * (b - a));
+                    memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
+                    if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
+                    else memset(e_hub + a, 0, 4 * (b - a));
+                    up(in.e_uvr + 12 * a, 12 * (b - a));
+                    up(in.e_w + 4 * a, 4 * (b - a));
+                    up(in.e_hub + 4 * a, 4 * (b - a));
+                }
+                const size_t LCH = (size_t)256 << 10;  // landmark positions: 6 MB per chunk
+                const size_t l0 = (size_t)L * q / nth, l1 = (size_t)L * (q + 1) / nth;
+                for (size_t a = l0; a < l1; a += LCH) {
+                    const size_t b = std::min(l1, a + LCH);
+                    memcpy(hs + in.points + 24 * a, pr->points + 3 * a, 24 * (b - a));
+                    up(in.points + 24 * a, 24 * (b - a));
+                }
+                stager.err[q] = (int)he;
+            };
+            for (int q = 0; q < nth; ++q) stager.th.emplace_back(stage_measurements, q);
+        }
+        else {
+            if (nth > 1 && lm_major) {  // (not pipelined after all: the second pass in line)
+                for (int q = 0; q < nth; ++q) {
+                    const size_t e0 = (size_t)E * q / nth, e1 = (size_t)E * (q + 1) / nth;
+                    copy_measurements(e0, e1);
+                }
+                memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
+            }
+            H2D(d_in, hs, in.total);
+        }
+        // pose -> edge lists on the device (they need the pose indices only)
+        const int rp = sv_ba_prepare_lists(ctx, s, d_e_pose, E, P, sc, sc_bytes, d_pe_off, D.e_level, D.e_chi, &sorted_edges);  // (also clears e_level / e_chi)
         if (rp) return rp;
         D.pm_point = d_pm_point, D.pm_uvr = d_pm_uvr, D.pm_w = d_pm_w, D.pm_hub = d_pm_hub;
+    }
+    // the measurements are on the device (pipelined: the stream waits for the copy stream) -> pose-major copies + robust flags
+    auto finish_observations = [&]() -> int {
+        if (stager.pending) {
+            for (auto& t : stager.th) t.join();
+            stager.th.clear();
+            stager.pending = false;
+            for (int q = 0; q < nth; ++q)
+                if (stager.err[q]) return sv_set_error(ctx, SVGPU_ERR_HIP, "hipMemcpyAsync (measurements)", (hipError_t)stager.err[q]);
+            SV_HIP(ctx, hipEventRecord(ctx->ev_ba_copy, ctx->ba_copy_stream));
+            SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_ba_copy, 0));
+        }
+        const int rp = sv_ba_prepare_pose_major(ctx, s, sorted_edges, d_e_point, d_e_uvr, d_e_w, d_e_hub, E, d_pe_idx, D.e_robust, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);
+        sorted_edges = nullptr;
+        return rp;
+    };
+    bool observations_finished = false;
+    if (!stager.pending) {
+        const int rp = finish_observations();
+        if (rp) return rp;
+        observations_finished = true;
     }
     BaCtl ctl0;
     memset(&ctl0, 0, sizeof(ctl0));
@@ -937,6 +1029,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if (device_boundary) sv_ba_zero_inactive(s, D);
         else r = upload_structure();
         if (r) return r;
+        if (!observations_finished) {
+            if ((r = finish_observations())) return r;
+            observations_finished = true;
+        }
         const bool nothing = !sharded && HS.nP + HS.nL == 0;
         // the PCG iteration cap depends on the size of the reduced system of this stage
         pcg_mi = pcg_max_it > 0 ? pcg_max_it : std::max(2000, 4 * D.n);

@@ -217,6 +217,8 @@ void svgpu_destroy(svgpu_ctx* ctx) {
     sv_comm_release(ctx);
     sv_sky_release(ctx);
     if (ctx->ev_ba) (void)hipEventDestroy(ctx->ev_ba);
+    if (ctx->ev_ba_copy) (void)hipEventDestroy(ctx->ev_ba_copy);
+    if (ctx->ba_copy_stream) (void)hipStreamDestroy(ctx->ba_copy_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (hipEvent_t e : ctx->ev_stage)
         if (e) (void)hipEventDestroy(e);

@@ -204,6 +204,8 @@ struct svgpu_ctx {
     size_t stage_bytes = 0;
     size_t scratch_bytes = 0;
     // bundle adjustment
+    hipStream_t ba_copy_stream = nullptr;  // second stream of a global-BA sized call: the measurements' upload runs beside the structure kernels
+    hipEvent_t ev_ba_copy = nullptr;
     hipEvent_t ev_ba = nullptr;     // completion event the BA host loop polls (while mirroring the caller's stop flag)
     int ba_solver = 0;              // svgpu_ba_solver
     double pcg_tol = 1e-10;         // relative residual of the reduced-system PCG
