@@ -4,6 +4,7 @@
 //   OptimizationAlgorithmLevenberg     g2o (pinned 20230223_git): lambda init 1e-5 * max diag, rho test, 10 trials
 //   terminate_action                   optimize/terminate_action.cc:36-76 (writes through the force-stop pointer)
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 
@@ -195,8 +196,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         std::fprintf(stderr, "[ba] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_start).count());
         t_start = now;
     };
+    // (the outputs start as the inputs: every early return leaves the estimate untouched.  At global-BA sizes the copy of the landmark
+    //  positions -- 38 MB at 1.6 M landmarks -- is left to the host team below)
+    const bool team_sized = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD");
     memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
-    memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+    if (!team_sized || (stop && *stop && !(allreduce != nullptr)) || E == 0 || P == 0 || L == 0) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
     if (E > 0 && outlier_out) memset(outlier_out, 0, E);
     if (stats) *stats = st;
     if (!sharded) {
@@ -243,7 +247,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     const size_t out_total = out_outlier + pad((size_t)E + 1);
     {
         const int r = sv_ensure_stage(ctx, in.total + out_total + st_total);
-        if (r) return r;
+        if (r) {
+            if (team_sized) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+            return r;
+        }
     }
     char* const hs = ctx->h_stage;
     char* const hs_out = hs + in.total;
@@ -261,107 +268,196 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         else memset(e_hub + a, 0, 4 * (b - a));
     };
     std::vector<int> perm;  // sorted position -> caller's observation index (empty = identity)
-    std::vector<uint8_t> level(E, 0);
+    std::vector<uint8_t> level((sharded || !single_stage) ? E : 0, 0);  // (host image of the edge levels: the stage boundary and the sharded set-up read it)
     bool no_levels = true;  // until the first gate: every edge is at level 0
     // host threads of the staging pass at global-BA sizes (SVGPU_BA_HOST_THREADS overrides, 1 .. 16)
     const int nth = [&] {
-        if (E < 400000 || std::getenv("SVGPU_BA_ONE_THREAD")) return 1;
+        if (!team_sized) return 1;
         const char* ev = std::getenv("SVGPU_BA_HOST_THREADS");
         const int v = ev ? std::atoi(ev) : 8;  // (config 5: 1.28 ms with 4 threads, 0.69 with 8, flat beyond)
         return v < 1 ? 1 : (v > 16 ? 16 : v);
     }();
-    // ONE pass over the observation indices (nth contiguous ranges): range check, "already grouped by landmark?" (the order
-    // local_bundle_adjuster_g2o.cc:168-227 creates its edges in) and -- valid in that case -- the landmark offsets from the run boundaries
+    // The host team of a global-BA sized call: nth threads (this one included) scan the observation indices -- range check, "already grouped
+    // by landmark?" (the order local_bundle_adjuster_g2o.cc:168-227 and global_bundle_adjuster.cc:66-118 create their edges in) and,
+    // valid in that case, the landmark offsets -- and stage the two index arrays; the nth - 1 workers then go on staging the measurements
+    // and the landmark positions while this thread runs the device's structure work, and upload them on the copy stream once the arena
+    // is known (`go`).  One spawn per call; the phases of the scan are separated by spin barriers (a few microseconds each).
+    struct HostTeam {
+        std::vector<std::thread> th;
+        std::atomic<int> arrived{0};
+        std::atomic<int> staged{0};  // workers whose share of the measurements is in the staging image
+        std::atomic<int> go{0};  // 0: the arena is not known yet, 1: upload, 2: abandon (the caller returns early or stages the observations itself)
+        char* d_in = nullptr;
+        hipStream_t s2 = nullptr;
+        int err[16] = {0};
+        bool running = false;
+        void join() {
+            for (auto& t : th)
+                if (t.joinable()) t.join();
+            th.clear();
+            running = false;
+        }
+        void abandon_and_join() {
+            int z = 0;
+            go.compare_exchange_strong(z, 2);
+            join();
+        }
+    } team;
     bool lm_major = true;
     std::vector<uint8_t> pose_seen(P, 0);  // a pose with an observation (the pose half of the first stage's activity pass)
-    {
+    // (function scope: the workers run these closures until the team is joined -- TeamGuard below, declared behind them, goes first)
         int bad[16] = {0}, unsorted[16] = {0};
         std::vector<uint8_t> seen_q[16];
-        // (a global-BA sized problem is 34 MB of observations: the host threads also share the copy into the staging image -- harmless
-        //  when the order turns out not to be landmark-major, the permuted copy below overwrites it)
+        const int32_t* const op = pr->obs_pose;
+        const int32_t* const ol = pr->obs_point;
         auto copy_range = [&](size_t a, size_t b, bool indices_only) {
             memcpy(e_pose + a, pr->obs_pose + a, 4 * (b - a));
             memcpy(e_point + a, pr->obs_point + a, 4 * (b - a));
-            if (indices_only) return;  // (the measurements follow in the second, pipelined pass: stage_measurements below)
-            memcpy(e_uvr + 3 * a, pr->obs_uvr + 3 * a, 12 * (b - a));
-            memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
-            if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
-            else memset(e_hub + a, 0, 4 * (b - a));
+            if (indices_only) return;  // (the measurements follow in the team's second phase)
+            copy_measurements(a, b);
         };
+        auto barrier = [&](int k) {  // the k-th barrier of the call (k = 1, 2, ...): every thread of the team arrives once
+            team.arrived.fetch_add(1);
+            for (int spins = 0; team.arrived.load() < k * nth; ++spins)
+                if (spins > 4000) std::this_thread::yield();
+        };
+        // Phase 1 of thread q: straight-line passes over its range (flag reductions the compiler vectorises), the landmark offsets as "end of
+        // landmark l = index behind its last observation", stored where a landmark's run ends and closed over the empty landmarks by a running
+        // maximum (shares of the offsets array, seeded by a backward look at the shares before)
         auto scan_range = [&](int q) {
-            int bd = 0, un = 0;
-            std::vector<uint8_t>& seen = q == 0 ? pose_seen : seen_q[q];
-            if (q) seen.assign(P, 0);
             const size_t e0 = (size_t)E * q / nth, end = (size_t)E * (q + 1) / nth;
-            for (size_t e = e0; e < end; ++e) {
-                const int p = pr->obs_pose[e], l = pr->obs_point[e];
-                if (p < 0 || p >= P || l < 0 || l >= L) {
-                    bd = 1;
-                    continue;
-                }
-                seen[p] = 1;
-                const int prev = e == 0 ? -1 : pr->obs_point[e - 1];
-                if (prev >= L) continue;  // (flagged by the thread that owns e - 1)
-                if (l < prev) un = 1;
-                else if (l != prev)
-                    for (int k = (prev < 0 ? 0 : prev + 1); k <= l; ++k) lm_off[k] = (int)e;  // landmarks prev + 1 .. l start here
-            }
-            bad[q] = bd, unsorted[q] = un;
-            if (!bd) copy_range(e0, end, true);
-        };
-        // One thread (local-BA sizes): the same facts from straight-line passes -- flag reductions the compiler vectorises, then the landmark
-        // offsets as "end of landmark l = index behind its last observation" stored unconditionally and closed over the empty landmarks by
-        // a running maximum; the per-observation "does a new landmark start here?" branch of scan_range mispredicts on every boundary
-        // (0.11 -> 0.07 ms of a config-3 call).
-        auto scan_one_thread = [&]() {
-            const int32_t* const op = pr->obs_pose;
-            const int32_t* const ol = pr->obs_point;
+            const size_t k0 = ((size_t)L + 1) * q / nth, k1 = ((size_t)L + 1) * (q + 1) / nth;
             unsigned bd = 0, un = 0;
-            for (int e = 0; e < E; ++e) bd |= (unsigned)((unsigned)op[e] >= (unsigned)P) | (unsigned)((unsigned)ol[e] >= (unsigned)L);
-            bad[0] = bd != 0;
-            if (bd) return;
-            for (int e = 1; e < E; ++e) un |= (unsigned)(ol[e] < ol[e - 1]);
-            unsorted[0] = un != 0;
-            for (int e = 0; e < E; ++e) pose_seen[op[e]] = 1;
-            if (!un) {
-                for (int k = 0; k <= L; ++k) lm_off[k] = 0;
-                for (int e = 0; e < E; ++e) lm_off[ol[e] + 1] = e + 1;
-                int v = 0;
-                for (int k = 0; k <= L; ++k) {
+            for (size_t e = e0; e < end; ++e) bd |= (unsigned)((unsigned)op[e] >= (unsigned)P) | (unsigned)((unsigned)ol[e] >= (unsigned)L);
+            for (size_t e = std::max<size_t>(e0, 1); e < end; ++e) un |= (unsigned)(ol[e] < ol[e - 1]);
+            bad[q] = bd != 0, unsorted[q] = un != 0;
+            if (!bd) {
+                std::vector<uint8_t>& seen = q == 0 ? pose_seen : seen_q[q];
+                if (q) seen.assign(P, 0);
+                uint8_t* const sn = seen.data();
+                for (size_t e = e0; e < end; ++e) sn[op[e]] = 1;
+                copy_range(e0, end, nth > 1);
+            }
+            for (size_t k = k0; k < k1; ++k) lm_off[k] = 0;
+            if (nth > 1) barrier(1);
+            int any_bad = 0, any_un = 0;
+            for (int t = 0; t < nth; ++t) any_bad |= bad[t], any_un |= unsorted[t];
+            const bool ok = !any_bad && !any_un;
+            if (ok && nth == 1)  // (one thread: stored unconditionally, the last observation of a landmark wins -- no branch to mispredict)
+                for (size_t e = e0; e < end; ++e) lm_off[ol[e] + 1] = (int)(e + 1);
+            else if (ok)
+                for (size_t e = e0; e < end; ++e) {
+                    const int l = ol[e], nxt = e + 1 < (size_t)E ? ol[e + 1] : -1;
+                    if (nxt != l) lm_off[l + 1] = (int)(e + 1);
+                }
+            if (nth > 1) barrier(2);
+            int v = 0;
+            if (ok)
+                for (size_t k = k0; k-- > 0;)
+                    if (lm_off[k]) {
+                        v = lm_off[k];
+                        break;
+                    }
+            if (nth > 1) barrier(3);
+            if (ok)
+                for (size_t k = k0; k < k1; ++k) {
                     v = std::max(v, lm_off[k]);
                     lm_off[k] = v;
                 }
-            }
-            copy_range(0, (size_t)E, false);
-            memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
+            if (nth > 1) barrier(4);
         };
-        std::vector<std::thread> th;
-        if (nth == 1) scan_one_thread();
-        else {
-            for (int q = 1; q < nth; ++q) th.emplace_back(scan_range, q);
+        // Phase 2 of worker q (1 .. nth - 1): its share of the measurements and of the landmark positions into the staging image, chunk by
+        // chunk; a staged chunk is uploaded as soon as `go` says where to
+        auto stage_measurements = [&](int q) {
+            const int W = nth - 1, w = q - 1;
+            const size_t CH = (size_t)128 << 10;   // observations per chunk: 2.6 MB of measurements
+            const size_t LCH = (size_t)256 << 10;  // landmark positions: 6 MB per chunk
+            const size_t e0 = (size_t)E * w / W, e1 = (size_t)E * (w + 1) / W, l0 = (size_t)L * w / W, l1 = (size_t)L * (w + 1) / W;
+            memcpy(points_out + 3 * l0, pr->points + 3 * l0, 24 * (l1 - l0));  // (the caller's output starts as its input)
+            hipError_t he = hipSetDevice(ctx->device);  // (the current device is a per-thread setting)
+            size_t e_up = e0, l_up = l0;  // uploaded so far
+            // (every hipMemcpyAsync holds the runtime's lock for ~15 us, and this thread's launches queue behind it: below 4 M observations the
+            //  worker that finishes LAST uploads the whole image in four copies; beyond, every worker uploads its chunks as they are staged)
+            const bool chunked = E >= (4 << 20);
+            auto flush = [&](size_t e_staged, size_t l_staged) {
+                if (!chunked || team.go.load() != 1 || he != hipSuccess) return;
+                auto up = [&](size_t off, size_t bytes) {
+                    if (bytes && he == hipSuccess) he = hipMemcpyAsync(team.d_in + off, hs + off, bytes, hipMemcpyHostToDevice, team.s2);
+                };
+                if (e_staged > e_up) {
+                    up(in.e_uvr + 12 * e_up, 12 * (e_staged - e_up));
+                    up(in.e_w + 4 * e_up, 4 * (e_staged - e_up));
+                    up(in.e_hub + 4 * e_up, 4 * (e_staged - e_up));
+                    e_up = e_staged;
+                }
+                if (l_staged > l_up) {
+                    up(in.points + 24 * l_up, 24 * (l_staged - l_up));
+                    l_up = l_staged;
+                }
+            };
+            for (size_t a = e0; a < e1 && team.go.load() != 2; a += CH) {
+                const size_t b = std::min(e1, a + CH);
+                copy_measurements(a, b);
+                flush(b, l0);
+            }
+            for (size_t a = l0; a < l1 && team.go.load() != 2; a += LCH) {
+                const size_t b = std::min(l1, a + LCH);
+                memcpy(hs + in.points + 24 * a, pr->points + 3 * a, 24 * (b - a));
+                flush(e1, b);
+            }
+            const bool last = team.staged.fetch_add(1) + 1 == W;
+            for (int spins = 0; team.go.load() == 0; ++spins)
+                if (spins > 2000) std::this_thread::yield();
+            if (team.go.load() == 1) {
+                if (chunked) flush(e1, l1);
+                else if (last) {  // (every share is staged: fetch_add orders the others' writes before this thread's reads)
+                    const size_t offs[4] = {in.e_uvr, in.e_w, in.e_hub, in.points}, bytes[4] = {12 * (size_t)E, 4 * (size_t)E, 4 * (size_t)E, 24 * (size_t)L};
+                    for (int k = 0; k < 4 && he == hipSuccess; ++k) he = hipMemcpyAsync(team.d_in + offs[k], hs + offs[k], bytes[k], hipMemcpyHostToDevice, team.s2);
+                }
+            }
+            team.err[q] = (int)he;
+        };
+        struct TeamGuard {
+            HostTeam& t;
+            ~TeamGuard() { t.abandon_and_join(); }
+        } team_guard{team};
+        if (nth == 1) {
+            if (team_sized) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);  // (SVGPU_BA_HOST_THREADS=1)
             scan_range(0);
+            if (!bad[0]) memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
         }
-        for (auto& t : th) t.join();
+        else {
+            team.running = true;
+            for (int q = 1; q < nth; ++q)
+                team.th.emplace_back([&, q] {
+                    scan_range(q);
+                    stage_measurements(q);
+                });
+            scan_range(0);  // (returns behind the last barrier: the whole scan is done)
+        }
         int any_bad = 0, any_unsorted = 0;
         for (int q = 0; q < nth; ++q) any_bad |= bad[q], any_unsorted |= unsorted[q];
-        if (any_bad) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+        if (any_bad) {
+            if (team_sized) {
+                team.go.store(2);
+                team.join();
+                memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+            }
+            return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: observation index out of range");
+        }
         for (int q = 1; q < nth; ++q)
             for (int p = 0; p < P; ++p) pose_seen[p] |= seen_q[q][p];
         lm_major = !any_unsorted;
-        if (lm_major)
-            for (int k = (E > 0 ? pr->obs_point[E - 1] + 1 : 0); k <= L; ++k) lm_off[k] = E;
-    }
+        if (!lm_major && team.running) {  // (rare at this size: the permuted copy below writes the whole staging image itself)
+            team.go.store(2);
+            team.join();
+            memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
+        }
     if (!lm_major) {
         for (int l = 0; l <= L; ++l) lm_off[l] = 0;
         for (int e = 0; e < E; ++e) lm_off[pr->obs_point[e] + 1]++;
         for (int l = 0; l < L; ++l) lm_off[l + 1] += lm_off[l];
     }
-    // Global-BA sizes, observations grouped by landmark (the order global_bundle_adjuster.cc:66-118 creates its edges in): the host threads
-    // have staged the INDEX arrays only.  The measurements (uvr, information, kernel width: 20 of the 28 bytes of an observation) and the
-    // landmark positions are staged by the same threads in a second pass that runs BESIDE the device's structure work (pose -> edge lists,
-    // (edge, edge) pair lists, block rows: they read indices only) and go up on a copy stream, chunk by chunk as they are staged.
-    const bool pipelined = nth > 1 && lm_major;
-    if (nth > 1 && !lm_major) memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
     if (!lm_major) {
         perm.resize(E);
         std::vector<int> fill(lm_off, lm_off + L);
@@ -575,16 +671,6 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     };
 
 #define H2D(dst, src, bytes) SV_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, s))
-    // second pass of a pipelined set-up: thread q stages its range in chunks and uploads each chunk on the copy stream as soon as it is staged
-    struct Stager {
-        std::vector<std::thread> th;
-        int err[16] = {0};
-        bool pending = false;
-        ~Stager() {
-            for (auto& t : th)
-                if (t.joinable()) t.join();
-        }
-    } stager;
     const void* sorted_edges = nullptr;  // the (pose, edge) records of sv_ba_prepare_lists, kept in the W buffer until the measurements are there
     char* const d_in = (char*)D.pose_buf[0];
     {
@@ -592,54 +678,26 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         const bool in_W = sizeof(double) * 18 * (size_t)E >= want;  // (the pair lists are built in the pair scratch: the records survive them only in W)
         void* sc = in_W ? (void*)D.W : (void*)d_pair_scratch;
         const size_t sc_bytes = in_W ? sizeof(double) * 18 * (size_t)E : pair_scratch;
-        if (pipelined && in_W) {
+        if (team.running && !in_W) {  // (cannot happen at these sizes; the team's work is then uploaded in one piece)
+            team.go.store(2);
+            team.join();
+            copy_measurements(0, (size_t)E);
+            memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
+        }
+        if (team.running) {
             if (!ctx->ba_copy_stream) SV_HIP(ctx, hipStreamCreateWithFlags(&ctx->ba_copy_stream, hipStreamNonBlocking));
             if (!ctx->ev_ba_copy) SV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_ba_copy, hipEventDisableTiming));
-            // (the staging image may still be the source of the previous call's copies on the copy stream only if that call failed half-way)
-            SV_HIP(ctx, hipStreamSynchronize(ctx->ba_copy_stream));
             H2D(d_in + in.pose, hs + in.pose, in.points - in.pose);          // poses
             H2D(d_in + in.intr, hs + in.intr, in.e_uvr - in.intr);            // intrinsics | e_pose | e_point
             H2D(d_in + in.lm_off, hs + in.lm_off, in.pe_off - in.lm_off);     // landmark offsets
-            hipStream_t s2 = ctx->ba_copy_stream;
-            stager.pending = true;
-            auto stage_measurements = [&, s2](int q) {
-                const size_t CH = (size_t)128 << 10;  // observations per chunk: 2.6 MB of measurements
-                const size_t e0 = (size_t)E * q / nth, e1 = (size_t)E * (q + 1) / nth;
-                hipError_t he = hipSuccess;
-                auto up = [&](size_t off, size_t bytes) {
-                    if (bytes && he == hipSuccess) he = hipMemcpyAsync(d_in + off, hs + off, bytes, hipMemcpyHostToDevice, s2);
-                };
-                for (size_t a = e0; a < e1; a += CH) {
-                    const size_t b = std::min(e1, a + CH);
-                    memcpy(e_uvr + 3 * a, pr->obs_uvr + 3 * a, 12 * (b - a));
-                    memcpy(e_w + a, pr->obs_inv_sigma_sq + a, 4 * (b - a));
-                    if (pr->obs_huber_delta) memcpy(e_hub + a, pr->obs_huber_delta + a, 4 * (b - a));
-                    else memset(e_hub + a, 0, 4 * (b - a));
-                    up(in.e_uvr + 12 * a, 12 * (b - a));
-                    up(in.e_w + 4 * a, 4 * (b - a));
-                    up(in.e_hub + 4 * a, 4 * (b - a));
-                }
-                const size_t LCH = (size_t)256 << 10;  // landmark positions: 6 MB per chunk
-                const size_t l0 = (size_t)L * q / nth, l1 = (size_t)L * (q + 1) / nth;
-                for (size_t a = l0; a < l1; a += LCH) {
-                    const size_t b = std::min(l1, a + LCH);
-                    memcpy(hs + in.points + 24 * a, pr->points + 3 * a, 24 * (b - a));
-                    up(in.points + 24 * a, 24 * (b - a));
-                }
-                stager.err[q] = (int)he;
-            };
-            for (int q = 0; q < nth; ++q) stager.th.emplace_back(stage_measurements, q);
+            // (the link is shared: the measurements queue behind the index arrays, which the structure kernels are waiting for)
+            SV_HIP(ctx, hipEventRecord(ctx->ev_ba_copy, s));
+            SV_HIP(ctx, hipStreamWaitEvent(ctx->ba_copy_stream, ctx->ev_ba_copy, 0));
+            team.d_in = d_in;
+            team.s2 = ctx->ba_copy_stream;
+            team.go.store(1);
         }
-        else {
-            if (nth > 1 && lm_major) {  // (not pipelined after all: the second pass in line)
-                for (int q = 0; q < nth; ++q) {
-                    const size_t e0 = (size_t)E * q / nth, e1 = (size_t)E * (q + 1) / nth;
-                    copy_measurements(e0, e1);
-                }
-                memcpy(hs + in.points, pr->points, sizeof(double) * 3 * (size_t)L);
-            }
-            H2D(d_in, hs, in.total);
-        }
+        else H2D(d_in, hs, in.total);
         // pose -> edge lists on the device (they need the pose indices only)
         const int rp = sv_ba_prepare_lists(ctx, s, d_e_pose, E, P, sc, sc_bytes, d_pe_off, D.e_level, D.e_chi, &sorted_edges);  // (also clears e_level / e_chi)
         if (rp) return rp;
@@ -647,12 +705,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     }
     // the measurements are on the device (pipelined: the stream waits for the copy stream) -> pose-major copies + robust flags
     auto finish_observations = [&]() -> int {
-        if (stager.pending) {
-            for (auto& t : stager.th) t.join();
-            stager.th.clear();
-            stager.pending = false;
+        if (team.running) {
+            team.join();
             for (int q = 0; q < nth; ++q)
-                if (stager.err[q]) return sv_set_error(ctx, SVGPU_ERR_HIP, "hipMemcpyAsync (measurements)", (hipError_t)stager.err[q]);
+                if (team.err[q]) return sv_set_error(ctx, SVGPU_ERR_HIP, "hipMemcpyAsync (measurements)", (hipError_t)team.err[q]);
             SV_HIP(ctx, hipEventRecord(ctx->ev_ba_copy, ctx->ba_copy_stream));
             SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_ba_copy, 0));
         }
@@ -661,7 +717,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         return rp;
     };
     bool observations_finished = false;
-    if (!stager.pending) {
+    if (!team.running) {
         const int rp = finish_observations();
         if (rp) return rp;
         observations_finished = true;
