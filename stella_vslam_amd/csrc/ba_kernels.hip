@@ -2648,7 +2648,14 @@ void sv_ba_chi2(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int use_trial, in
 __global__ __launch_bounds__(256) void k_ba_pack_out(BaDev D, double* __restrict__ out) {
     const int cur = D.ctl->cur & 1;
     const size_t np = 12 * (size_t)D.P, n = np + 3 * (size_t)D.L;
-    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = i < np ? D.pose_buf[cur][i] : D.pt_buf[cur][i - np];
+    for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (i < np) out[i] = D.pose_buf[cur][i];
+        else if (!D.lm_order) out[i] = D.pt_buf[cur][i - np];
+        else {
+            const size_t j = i - np, r = j / 3;
+            out[np + 3 * (size_t)D.lm_order[r] + (j - 3 * r)] = D.pt_buf[cur][j];
+        }
+    }
 }
 void sv_ba_pack_out(hipStream_t s, const BaDev& D, double* out) {
     const size_t n = 12 * (size_t)D.P + 3 * (size_t)D.L;

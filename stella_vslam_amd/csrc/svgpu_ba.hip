@@ -30,6 +30,12 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
                             int2* pairs_out, int* pair_l_out, int* dense_off_dev);
 size_t sv_ba_pose_lists_scratch_bytes(size_t E);
+size_t sv_ba_renumber_scratch_bytes(size_t L);
+int sv_ba_renumber_landmarks(svgpu_ctx* ctx, hipStream_t s, const int* lm_off_old, const int* e_pose_old, int L, int P, int E, void* scratch, size_t scratch_bytes,
+                             int* order_out, int* lm_off_new, int* e_pose_new, int* e_point_new, int* src_edge);
+void sv_ba_permute_measurements(hipStream_t s, const int* src_edge, int E, const float* uvr_old, const float* w_old, const float* hub_old, float* uvr_new, float* w_new, float* hub_new);
+void sv_ba_permute_points(hipStream_t s, const int* order, int L, const double* pts_old, double* pts_new);
+void sv_ba_permute_flags(hipStream_t s, const int* order, int L, const uint8_t* old_flags, uint8_t* new_flags);
 int sv_ba_prepare_lists(svgpu_ctx* ctx, hipStream_t s, const int* e_pose_dev, int E, int P, void* scratch, size_t scratch_bytes, int* pe_off_dev, uint8_t* e_level_dev,
                         double* e_chi_dev, const void** sorted_out);
 int sv_ba_prepare_pose_major(svgpu_ctx* ctx, hipStream_t s, const void* sorted, const int* e_point_dev, const float* e_uvr_dev, const float* e_w_dev, const float* e_huber_dev,
@@ -513,7 +519,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
-    const size_t pair_scratch = std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E));
+    // the solve's own landmark numbering (ba_pairs.hip): one rank, one stage, the host team's sizes, observations grouped by landmark
+    const bool renumber = team.running && single_stage && !sharded && !std::getenv("SVGPU_BA_NO_RENUMBER");
+    const size_t pair_scratch = std::max(std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E)), renumber ? sv_ba_renumber_scratch_bytes((size_t)L) : 0);
+    if (renumber) need += 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + 2 * pad(4 * (size_t)E) + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)L) + pad(24 * (size_t)L) + pad(L) + 4096;
     need += pad(4 * (nb_cap + (size_t)P)) + pad(P) + pad(L);  // keyframe-segment exchange: block / slot lists, damping owners
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap) + pad(64 * (size_t)nb_lm);
     int rc = sv_ensure_scratch(ctx, need);
@@ -594,6 +603,18 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     uint8_t* d_lam_slot = A.take<uint8_t>(P);
     uint8_t* d_any_owner = A.take<uint8_t>(L);  // sharded: the landmark has observations on some rank
     D.any_owner = d_any_owner;
+    // renumbered solve: the uploaded arrays (caller's order) are the sources, these the arrays the kernels read
+    int *rn_e_pose = nullptr, *rn_e_point = nullptr, *rn_src = nullptr, *rn_lm_off = nullptr, *rn_order = nullptr;
+    float *rn_uvr = nullptr, *rn_w = nullptr, *rn_hub = nullptr;
+    double* rn_pts = nullptr;
+    uint8_t* rn_pt_free_in = nullptr;
+    if (renumber) {
+        rn_e_pose = A.take<int>(E), rn_e_point = A.take<int>(E), rn_src = A.take<int>(E);
+        rn_uvr = A.take<float>(3 * (size_t)E), rn_w = A.take<float>(E), rn_hub = A.take<float>(E);
+        rn_lm_off = A.take<int>(L + 1), rn_order = A.take<int>(L);
+        rn_pts = A.take<double>(3 * (size_t)L);
+        rn_pt_free_in = A.take<uint8_t>(L);
+    }
     if (A.off > ctx->scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_local_ba: internal arena overflow");
     D.e_pose = d_e_pose;
     D.e_point = d_e_point;
@@ -698,8 +719,16 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             team.go.store(1);
         }
         else H2D(d_in, hs, in.total);
+        if (renumber) {
+            const int rr = sv_ba_renumber_landmarks(ctx, s, d_lm_off, d_e_pose, L, P, E, d_pair_scratch, pair_scratch, rn_order, rn_lm_off, rn_e_pose, rn_e_point, rn_src);
+            if (rr) return rr;
+            D.e_pose = rn_e_pose, D.e_point = rn_e_point, D.lm_off = rn_lm_off;
+            D.e_uvr = rn_uvr, D.e_w = rn_w, D.e_huber = rn_hub;
+            D.pt_buf[0] = rn_pts;
+            D.lm_order = rn_order;
+        }
         // pose -> edge lists on the device (they need the pose indices only)
-        const int rp = sv_ba_prepare_lists(ctx, s, d_e_pose, E, P, sc, sc_bytes, d_pe_off, D.e_level, D.e_chi, &sorted_edges);  // (also clears e_level / e_chi)
+        const int rp = sv_ba_prepare_lists(ctx, s, D.e_pose, E, P, sc, sc_bytes, d_pe_off, D.e_level, D.e_chi, &sorted_edges);  // (also clears e_level / e_chi)
         if (rp) return rp;
         D.pm_point = d_pm_point, D.pm_uvr = d_pm_uvr, D.pm_w = d_pm_w, D.pm_hub = d_pm_hub;
     }
@@ -712,7 +741,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             SV_HIP(ctx, hipEventRecord(ctx->ev_ba_copy, ctx->ba_copy_stream));
             SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_ba_copy, 0));
         }
-        const int rp = sv_ba_prepare_pose_major(ctx, s, sorted_edges, d_e_point, d_e_uvr, d_e_w, d_e_hub, E, d_pe_idx, D.e_robust, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);
+        if (renumber) {  // measurements and positions into the solve's numbering
+            sv_ba_permute_measurements(s, rn_src, E, d_e_uvr, d_e_w, d_e_hub, rn_uvr, rn_w, rn_hub);
+            sv_ba_permute_points(s, rn_order, L, (const double*)(d_in + in.points), rn_pts);
+        }
+        const int rp = sv_ba_prepare_pose_major(ctx, s, sorted_edges, D.e_point, D.e_uvr, D.e_w, D.e_huber, E, d_pe_idx, D.e_robust, d_pm_point, d_pm_uvr, d_pm_w, d_pm_hub);
         sorted_edges = nullptr;
         return rp;
     };
@@ -824,7 +857,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         D.scale_pose = (!sharded || rank == 0) ? 1 : 0;
         D.add_lambda = (!sharded || rank == 0) ? 1 : 0;
         memcpy(hs_struct + st_pt_free, HS.pt_free.data(), L);
-        H2D(d_pt_free, hs_struct + st_pt_free, L);
+        if (renumber) {
+            H2D(rn_pt_free_in, hs_struct + st_pt_free, L);
+            sv_ba_permute_flags(s, rn_order, L, rn_pt_free_in, d_pt_free);
+        }
+        else H2D(d_pt_free, hs_struct + st_pt_free, L);
         if (!reuse) {
             memcpy(hs_struct + st_pose_slot, HS.pose_slot.data(), 4 * (size_t)P);
             H2D(d_pose_slot, hs_struct + st_pose_slot, 4 * (size_t)P);
@@ -1250,7 +1287,18 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     if ((rc = wait_stream())) return rc;
     memcpy(h_ctl, hs_out + out_ctl, sizeof(BaCtl));
     memcpy(pose_out, hs_out + out_state, sizeof(double) * 12 * (size_t)P);
-    memcpy(points_out, hs_out + out_state + sizeof(double) * 12 * (size_t)P, sizeof(double) * 3 * (size_t)L);
+    {
+        const char* const src = hs_out + out_state + sizeof(double) * 12 * (size_t)P;
+        const size_t bytes = sizeof(double) * 3 * (size_t)L;
+        if (bytes < ((size_t)16 << 20)) memcpy(points_out, src, bytes);
+        else {  // (38 MB at 1.6 M landmarks: one core copies them in ~2 ms)
+            const int nt = 4;
+            std::vector<std::thread> th;
+            for (int q = 1; q < nt; ++q) th.emplace_back([=] { memcpy((char*)points_out + bytes * q / nt, src + bytes * q / nt, bytes * (q + 1) / nt - bytes * q / nt); });
+            memcpy(points_out, src, bytes / nt);
+            for (auto& t : th) t.join();
+        }
+    }
     const uint8_t* const outl = (const uint8_t*)(hs_out + out_outlier);
     if (outlier_out)
         for (int k = 0; k < E; ++k) outlier_out[perm.empty() ? k : perm[k]] = outl[k];
