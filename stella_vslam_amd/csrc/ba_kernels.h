@@ -72,6 +72,12 @@ struct BaDev {
     double* sc_part;     // NB x nshare x 36: partial blocks of k_ba_schur_rhs
     double* rhs_part;    // nP x RHS_SPLIT x 6: partial sums of W Hll^-1 bl
     int nshare;          // shares per block of the reduced system (pairs per share ~200)
+    // chunk-major units (global-BA sizes, ba_pairs.hip sv_ba_build_units): a unit = the pairs of ONE block whose landmarks lie in ONE chunk of
+    // consecutive landmark ranks, executed chunk by chunk; null = the arithmetic shares above
+    const int4* unit_rec;      // execution position -> {first pair, end pair, block, unit id (block-major)}
+    const int* blk_unit_off;   // NB + 1: units of block b = [blk_unit_off[b], blk_unit_off[b + 1]) -- the rows of sc_part / rhs_unit k_ba_sys_fin sums
+    double* rhs_unit;          // 6 per unit: W Hll^-1 bl summed over the pairs (i, i) of a diagonal block's unit
+    int num_units;
     double* Hll;   // L x 6 (xx xy xz yy yz zz)
     double* bl;    // L x 3
     double* Hpp;   // nP x 36

@@ -1708,6 +1708,21 @@ __global__ __launch_bounds__(64 * SCH_WAVES) __attribute__((amdgpu_waves_per_eu(
     // of one block row, which all read the W records of pose a and its neighbours: XCD x takes the x-th CONTIGUOUS eighth of the units, so
     // that the rows in flight on one L2 are ~3 instead of ~21 (half of the L2 requests missed at config 5 with the round-robin order:
     // 980 MB fetched per launch, 250 MB with this order; W alone is 173 MB).  The unit count is padded to a multiple of 8 by the launcher.
+    if (D.unit_rec) {  // chunk-major units: XCD x walks the x-th contiguous eighth of the execution order, i.e. its own sequence of landmark chunks
+        const int nu8 = (D.num_units + 7) & ~7;
+        const int pos = ((int)blockIdx.x & 7) * (nu8 >> 3) + ((int)blockIdx.x >> 3);
+        if (pos >= D.num_units) return;
+        const int lane = threadIdx.x & 63;
+        const int4 rec = D.unit_rec[pos];
+        const int2 ab = D.blk_ab[rec.z];
+        const int unit = rec.w;
+        double* const sw = s_wave[0];
+        SCH_T(0);
+        if (D.dbg_schur_on && lane == 0) D.dbg[8 * (size_t)unit + 5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        if (ab.x == ab.y) schur_unit<true>(D, unit, lane, rec.x, rec.y, lambda, sw, D.sc_part + (size_t)unit * 36, D.rhs_unit + (size_t)unit * 6);
+        else schur_unit<false>(D, unit, lane, rec.x, rec.y, lambda, sw, D.sc_part + (size_t)unit * 36, nullptr);
+        return;
+    }
     const int n_schur = D.NB * nshare;
     int wg = blockIdx.x;
     if (xcd_order) {
@@ -1745,6 +1760,12 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
     if (k < D.NB * 36) {
         const int blk = k / 36, t = k - 36 * blk;
         double sum = 0.0;
+        if (D.unit_rec) {  // the units of the block, in landmark-chunk order
+            const int u0 = D.blk_unit_off[blk], u1 = D.blk_unit_off[blk + 1];
+#pragma unroll 4
+            for (int u = u0; u < u1; ++u) sum += D.sc_part[(size_t)u * 36 + t];
+        }
+        else
 #pragma unroll 8
         for (int h = 0; h < nshare; ++h) sum += D.sc_part[((size_t)blk * nshare + h) * 36 + t];  // (unrolled: the loads of a share run are independent)
         const int2 ab = D.blk_ab[blk];
@@ -1759,6 +1780,11 @@ __global__ __launch_bounds__(256) void k_ba_sys_fin(BaDev D, int nshare, const d
         const int r = k - D.NB * 36;
         const int s = r / 6, i = r - 6 * s;
         double sum = 0.0;
+        if (D.unit_rec) {
+            const int blk = D.diag_blk[s], u0 = D.blk_unit_off[blk], u1 = D.blk_unit_off[blk + 1];
+            for (int u = u0; u < u1; ++u) sum += D.rhs_unit[(size_t)u * 6 + i];
+        }
+        else
 #pragma unroll 8
         for (int h = 0; h < rhs_shares; ++h) sum += rhs_part[((size_t)s * RHS_SPLIT + h) * 6 + i];  // nshare shares of block (s, s), or the RHS_SPLIT units of the pose
         D.g[r] = D.bp[r] - sum;
@@ -2564,8 +2590,13 @@ int sv_ba_rhs_split() { return RHS_SPLIT; }
 void sv_ba_reduce(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     SvProfScope ps(ctx, s, "ba_schur");
     if (D.nP <= 0) return;
-    if (D.nshare > RHS_SPLIT) return;  // (svgpu_ba.hip caps nshare at 16)
     static_assert(SCH_WAVES == 1, "the XCD-contiguous order permutes workgroups = units");
+    if (D.unit_rec) {
+        hipLaunchKernelGGL(k_ba_schur_rhs, dim3((D.num_units + 7) & ~7), dim3(64 * SCH_WAVES), 0, s, D, D.nshare, D.rhs_part, 1);
+        hipLaunchKernelGGL(k_ba_sys_fin, dim3((D.NB * 36 + D.n + 255) / 256), dim3(256), 0, s, D, D.nshare, D.rhs_part, D.nshare);
+        return;
+    }
+    if (D.nshare > RHS_SPLIT) return;  // (svgpu_ba.hip caps nshare at 16)
     const int n_schur = D.NB * D.nshare;
     // A large system (more than one resident round of units): XCD-contiguous unit order, right-hand side summed by the shares of the diagonal
     // blocks.  A small one (local BA) leaves the chip part-filled: the right-hand side runs beside the blocks as units of its own, which also

@@ -398,6 +398,93 @@ void sv_ba_permute_flags(hipStream_t s, const int* order, int L, const uint8_t* 
     if (L > 0) hipLaunchKernelGGL(k_lm_permute_flags, dim3((L + 255) / 256), dim3(256), 0, s, order, L, old_flags, new_flags);
 }
 
+// ---- Chunk-major units of the Schur kernel (global-BA sizes, renumbered landmarks).  The pair list is sorted by (block, landmark rank); it is
+// cut wherever the block or the landmark CHUNK (rank >> shift) changes.  A unit then gathers W records of one chunk only, and executing the
+// units chunk by chunk keeps that stretch of W (~1 MB) in the XCD's L2 while all its pairs -- in every block they fall into -- are worked on:
+// a record is fetched once per chunk instead of once per pair.  The block sums stay fixed-order: k_ba_sys_fin adds a block's units in chunk order.
+__global__ void k_unit_mark_chunk(const int* __restrict__ pair_l, int n, int shift, int* __restrict__ flag) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) flag[q] = (q == 0 || (pair_l[q] >> shift) != (pair_l[q - 1] >> shift)) ? 1 : 0;
+}
+__global__ void k_unit_mark_blk(const int* __restrict__ blk_off, int NB, int n, int* __restrict__ flag) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < NB) {
+        const int q = blk_off[b];
+        if (q < n) flag[q] = 1;
+    }
+}
+__global__ void k_unit_offsets(const int* __restrict__ uid, int n, int* __restrict__ unit_off) {  // uid = exclusive scan of the flags, total at [n]
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n && uid[q + 1] != uid[q]) unit_off[uid[q]] = q;
+    if (q == 0) unit_off[uid[n]] = n;
+}
+__global__ void k_unit_blk_off(const int* __restrict__ blk_off, int NB, const int* __restrict__ uid, int* __restrict__ blk_unit_off) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= NB) blk_unit_off[b] = uid[blk_off[b]];
+}
+__global__ void k_unit_blk(const int* __restrict__ blk_unit_off, int NB, int* __restrict__ unit_blk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= NB) return;
+    for (int u = blk_unit_off[b]; u < blk_unit_off[b + 1]; ++u) unit_blk[u] = b;
+}
+__global__ void k_unit_keys(const int* __restrict__ unit_off, const int* __restrict__ pair_l, int U, int shift, unsigned* __restrict__ keys, unsigned long long* __restrict__ vals) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= U) return;
+    keys[u] = (unsigned)(pair_l[unit_off[u]] >> shift);
+    vals[u] = (unsigned long long)(unsigned)u;
+}
+__global__ void k_unit_rec(const unsigned long long* __restrict__ vals, const int* __restrict__ unit_off, const int* __restrict__ unit_blk, int U, int4* __restrict__ rec) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= U) return;
+    const int u = (int)(unsigned)vals[pos];
+    rec[pos] = make_int4(unit_off[u], unit_off[u + 1], unit_blk[u], u);
+}
+size_t sv_ba_units_scratch_bytes(size_t num_pairs, size_t unit_cap) {
+    return pad256((num_pairs + 2) * 4) + pad256(sv_scan_scratch_ints(num_pairs + 1) * 4 + 64) + pad256((unit_cap + 1) * 4) + pad256(unit_cap * 4) + 2 * pad256(unit_cap * 4) + 2 * pad256(unit_cap * 8)
+           + pad256(sv_sort_hist_ints(unit_cap) * 4) + 2048;
+}
+// *num_units_out = 0 when the cut would need more than unit_cap units (the caller keeps the arithmetic shares).  One host synchronisation.
+int sv_ba_build_units(svgpu_ctx* ctx, hipStream_t s, const int* blk_off_dev, int NB, const int* pair_l_dev, int num_pairs, int L, int chunk_shift, int unit_cap, void* scratch,
+                      size_t scratch_bytes, int4* unit_rec_out, int* blk_unit_off_out, int* num_units_out) {
+    *num_units_out = 0;
+    if (num_pairs <= 0 || NB <= 0 || unit_cap <= 0) return SVGPU_OK;
+    char* p = (char*)scratch;
+    auto take = [&](size_t bytes) {
+        char* r = p;
+        p += pad256(bytes);
+        return (void*)r;
+    };
+    int* uid = (int*)take(((size_t)num_pairs + 2) * 4);
+    int* scan_scr = (int*)take(sv_scan_scratch_ints((size_t)num_pairs + 1) * 4 + 64);
+    int* unit_off = (int*)take(((size_t)unit_cap + 1) * 4);
+    int* unit_blk = (int*)take((size_t)unit_cap * 4);
+    unsigned* keys[2] = {(unsigned*)take((size_t)unit_cap * 4), (unsigned*)take((size_t)unit_cap * 4)};
+    unsigned long long* vals[2] = {(unsigned long long*)take((size_t)unit_cap * 8), (unsigned long long*)take((size_t)unit_cap * 8)};
+    int* hist = (int*)take(sv_sort_hist_ints((size_t)unit_cap) * 4);
+    if ((size_t)(p - (char*)scratch) > scratch_bytes) return sv_set_error(ctx, SVGPU_ERR_CAPACITY, "unit scratch too small");
+    const dim3 b(256), gq((num_pairs + 255) / 256);
+    hipLaunchKernelGGL(k_unit_mark_chunk, gq, b, 0, s, pair_l_dev, num_pairs, chunk_shift, uid);
+    hipLaunchKernelGGL(k_unit_mark_blk, dim3((NB + 255) / 256), b, 0, s, blk_off_dev, NB, num_pairs, uid);
+    SV_HIP(ctx, hipMemsetAsync(uid + num_pairs, 0, 4, s));
+    sv_scan_i32(s, uid, num_pairs, scan_scr);
+    int U = 0;
+    SV_HIP(ctx, hipMemcpyAsync(&U, uid + num_pairs, 4, hipMemcpyDeviceToHost, s));
+    SV_HIP(ctx, hipStreamSynchronize(s));
+    if (U <= 0 || U > unit_cap) return SVGPU_OK;
+    hipLaunchKernelGGL(k_unit_offsets, gq, b, 0, s, uid, num_pairs, unit_off);
+    hipLaunchKernelGGL(k_unit_blk_off, dim3((NB + 256) / 256), b, 0, s, blk_off_dev, NB, uid, blk_unit_off_out);
+    hipLaunchKernelGGL(k_unit_blk, dim3((NB + 255) / 256), b, 0, s, blk_unit_off_out, NB, unit_blk);
+    const dim3 gu((U + 255) / 256);
+    hipLaunchKernelGGL(k_unit_keys, gu, b, 0, s, unit_off, pair_l_dev, U, chunk_shift, keys[0], vals[0]);
+    int bits = 1;
+    while ((1u << bits) < (unsigned)((L >> chunk_shift) + 1) && bits < 31) ++bits;
+    const int r = sv_sort_pairs(s, keys, vals, 0, U, bits, hist);
+    hipLaunchKernelGGL(k_unit_rec, gu, b, 0, s, vals[r], unit_off, unit_blk, U, unit_rec_out);
+    SV_HIP(ctx, hipGetLastError());
+    *num_units_out = U;
+    return SVGPU_OK;
+}
+
 // ---- svgpu_selftest_scan_sort (include/svgpu.h): the scan and the radix sort on caller data
 extern "C" int svgpu_selftest_scan_sort(svgpu_ctx* ctx, int n, const int32_t* values, int32_t* scan_out, const uint32_t* keys, int bits, int32_t* sorted_idx) {
     if (!ctx || n < 0 || bits < 1 || bits > 32 || (scan_out && !values) || (sorted_idx && !keys)) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_selftest_scan_sort: bad arguments");

@@ -30,6 +30,9 @@ int sv_ba_build_pairs(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scrat
 int sv_ba_build_pairs_async(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, void* scratch, size_t scratch_bytes, size_t pair_cap, int total,
                             int2* pairs_out, int* pair_l_out, int* dense_off_dev);
 size_t sv_ba_pose_lists_scratch_bytes(size_t E);
+size_t sv_ba_units_scratch_bytes(size_t num_pairs, size_t unit_cap);
+int sv_ba_build_units(svgpu_ctx* ctx, hipStream_t s, const int* blk_off_dev, int NB, const int* pair_l_dev, int num_pairs, int L, int chunk_shift, int unit_cap, void* scratch,
+                      size_t scratch_bytes, int4* unit_rec_out, int* blk_unit_off_out, int* num_units_out);
 size_t sv_ba_renumber_scratch_bytes(size_t L);
 int sv_ba_renumber_landmarks(svgpu_ctx* ctx, hipStream_t s, const int* lm_off_old, const int* e_pose_old, int L, int P, int E, void* scratch, size_t scratch_bytes,
                              int* order_out, int* lm_off_new, int* e_pose_new, int* e_point_new, int* src_edge);
@@ -521,7 +524,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
     // the solve's own landmark numbering (ba_pairs.hip): one rank, one stage, the host team's sizes, observations grouped by landmark
     const bool renumber = team.running && single_stage && !sharded && !std::getenv("SVGPU_BA_NO_RENUMBER");
-    const size_t pair_scratch = std::max(std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E)), renumber ? sv_ba_renumber_scratch_bytes((size_t)L) : 0);
+    const bool chunk_units = renumber && pair_cap < ((size_t)1 << 31) && !std::getenv("SVGPU_BA_NO_UNITS");  // chunk-major units of the Schur kernel (ba_pairs.hip)
+    const size_t unit_cap = chunk_units ? sc_part_blocks : 0;
+    const size_t pair_scratch = std::max(std::max(std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E)), renumber ? sv_ba_renumber_scratch_bytes((size_t)L) : 0),
+                                         chunk_units ? sv_ba_units_scratch_bytes(pair_cap, unit_cap) : 0);
+    if (chunk_units) need += pad(16 * unit_cap) + pad(4 * (nb_cap + 2)) + pad(48 * unit_cap) + 1024;
     if (renumber) need += 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + 2 * pad(4 * (size_t)E) + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)L) + pad(24 * (size_t)L) + pad(L) + 4096;
     need += pad(4 * (nb_cap + (size_t)P)) + pad(P) + pad(L);  // keyframe-segment exchange: block / slot lists, damping owners
     need += pad(8 * pair_cap) + pad(8 * nb_cap) + pad(4 * (nb_cap + 1)) + pad(pair_scratch) + in.total + out_total + 3 * pad(4 * (size_t)E) + pad(12 * (size_t)E) + pad(8 * (size_t)nb_lm) + pad(4 * pair_cap) + pad(64 * (size_t)nb_lm);
@@ -608,6 +615,14 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     float *rn_uvr = nullptr, *rn_w = nullptr, *rn_hub = nullptr;
     double* rn_pts = nullptr;
     uint8_t* rn_pt_free_in = nullptr;
+    int4* d_unit_rec = nullptr;
+    int* d_blk_unit_off = nullptr;
+    double* d_rhs_unit = nullptr;
+    if (chunk_units) {
+        d_unit_rec = A.take<int4>(unit_cap);
+        d_blk_unit_off = A.take<int>(nb_cap + 2);
+        d_rhs_unit = A.take<double>(6 * unit_cap);
+    }
     if (renumber) {
         rn_e_pose = A.take<int>(E), rn_e_point = A.take<int>(E), rn_src = A.take<int>(E);
         rn_uvr = A.take<float>(3 * (size_t)E), rn_w = A.take<float>(E), rn_hub = A.take<float>(E);
@@ -969,6 +984,25 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             const size_t avg = HS.num_pairs / (size_t)D.NB, ns_max = std::min<size_t>(16, std::max<size_t>(1, (avg + 63) / 64));
             while ((size_t)D.nshare < ns_max && (size_t)D.NB * (D.nshare + 1) <= 2304) ++D.nshare;
         }
+        if (!reuse) {
+            D.unit_rec = nullptr;
+            D.num_units = 0;
+            if (chunk_units && HS.nP > 48 && (size_t)D.NB * D.nshare >= 8192 && HS.num_pairs > 0) {
+                // ~0.5 MB of W records per chunk of consecutive landmark ranks (SVGPU_BA_CHUNK_SHIFT overrides: chunk = 2^shift landmarks).  Measured,
+                // Schur launch at config 5 / 9.6 M observations: 256 landmarks 125 / 930 us, 512: 122 / 880, 1 024: 132 / 882, 2 048: 158 / 973; arithmetic shares 144 / 1 537
+                int shift = 4;
+                while (((size_t)2 << shift) * 144 * ((size_t)E / (size_t)std::max(L, 1) + 1) <= ((size_t)1 << 19)) ++shift;
+                if (const char* ev = std::getenv("SVGPU_BA_CHUNK_SHIFT")) shift = std::max(0, std::min(30, std::atoi(ev)));
+                int U = 0;
+                const int ru = sv_ba_build_units(ctx, s, d_blk_off, D.NB, d_blk_pair_l, (int)HS.num_pairs, L, shift, (int)unit_cap, d_pair_scratch, pair_scratch, d_unit_rec, d_blk_unit_off, &U);
+                if (ru) return ru;
+                if (U > 0) {
+                    D.unit_rec = d_unit_rec, D.blk_unit_off = d_blk_unit_off, D.rhs_unit = d_rhs_unit, D.num_units = U;
+                }
+                if (trace) std::fprintf(stderr, "[ba]     chunk-major units: %d (chunks of %d landmarks)\n", U, 1 << shift);
+                sub("units");
+            }
+        }
         // solver of this stage: PCG inside one workgroup's LDS when the blocks fit, else one launch per PCG iteration
         const bool lds_ok = sv_ba_pcg_lds_bytes(D) > 0;
         // AUTO: dense LL^T in LDS while it fits (n <= ~135: 70 us per trial against 88 us for the LDS-resident PCG at n = 96), the
@@ -1169,7 +1203,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     rc = optimize(pr->num_first_iter, &it1);
     if (rc) return rc;
     if (D.dbg_schur_on) {  // SVGPU_BA_DBG=schur: life of the units of the last k_ba_schur_rhs launch (100 MHz stamps)
-        const size_t nu = (size_t)D.NB * D.nshare;
+        const size_t nu = D.unit_rec ? (size_t)D.num_units : (size_t)D.NB * D.nshare;
         std::vector<unsigned long long> h(8 * nu);
         SV_HIP(ctx, hipMemcpyAsync(h.data(), D.dbg, 8 * h.size(), hipMemcpyDeviceToHost, s));
         SV_HIP(ctx, hipStreamSynchronize(s));
