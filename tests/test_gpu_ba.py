@@ -439,6 +439,40 @@ def test_global_ba_config5_matches_oracle():
     assert _rel(pcg["points"], got["points"]) < TOL
 
 
+def test_global_ba_set_up_paths_agree(monkeypatch):
+    """The set-up of a global-BA sized call (csrc/svgpu_ba.hip): a team of host threads stages the index arrays first and the measurements
+    beside the device's structure work; the solve runs on its own landmark numbering (first observing keyframe) with chunk-major units of the
+    Schur kernel.  Every way through that set-up -- one host thread, an odd team, no renumbering, arithmetic shares, observations that arrive
+    in random order (the team is abandoned, the permuted copy stages everything) -- must land on the same estimate; the default path is
+    repeatable bit for bit (test_global_ba_config5_matches_oracle)."""
+    from stella_vslam_amd import optimize
+    sc = S.ba_scene_large()
+    adj = optimize.local_bundle_adjuster()
+    ref = adj.optimize_global_flat(sc, num_iter=10)
+    def same(got):
+        assert got["stats"]["iters_stage1"] == ref["stats"]["iters_stage1"]
+        assert got["stats"]["chi2_final"] == pytest.approx(ref["stats"]["chi2_final"], rel=1e-12)
+        assert np.abs(got["pose_cw"] - ref["pose_cw"]).max() < 1e-10 and np.abs(got["points"] - ref["points"]).max() < 1e-10
+    for env in ({"SVGPU_BA_HOST_THREADS": "1"}, {"SVGPU_BA_HOST_THREADS": "3"}, {"SVGPU_BA_ONE_THREAD": "1"}, {"SVGPU_BA_NO_RENUMBER": "1"}, {"SVGPU_BA_NO_UNITS": "1"},
+                {"SVGPU_BA_CHUNK_SHIFT": "6"}):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            same(adj.optimize_global_flat(sc, num_iter=10))
+    perm = np.random.default_rng(7).permutation(len(sc["obs_pose"]))
+    shuffled = dict(sc)
+    for k in ("obs_pose", "obs_point", "obs_uvr", "obs_inv_sigma_sq", "obs_huber"):
+        shuffled[k] = np.ascontiguousarray(sc[k][perm])
+    same(adj.optimize_global_flat(shuffled, num_iter=10))
+    bad = dict(sc)
+    bad["obs_point"] = sc["obs_point"].copy()
+    bad["obs_point"][len(bad["obs_point"]) // 2] = len(sc["points"])  # out of range, found by a worker of the team
+    pts_before = bad["points"].copy()
+    with pytest.raises(Exception):
+        adj.optimize_global_flat(bad, num_iter=10)
+    assert np.array_equal(bad["points"], pts_before)
+
+
 def test_global_ba_two_sided_elimination_equals_one_sided(monkeypatch):
     """A long band can be eliminated from both ends by two workgroups (ba_skyline.hip: T | S | B, the Schur complements added on the
     separator) -- the fallback where the segmented plan does not apply, forced here with SVGPU_SKY_SEGMENTS=0; SVGPU_SKY_ONE_SIDED=1 keeps the
