@@ -130,7 +130,7 @@ class local_bundle_adjuster:
         prob = _BaProblem(P, L, E, ptr(pose), ptr(keep[2]), ptr(pts), ptr(pf), ptr(keep[3]), ptr(keep[4]), ptr(keep[5]),
                           ptr(keep[6]), ptr(keep[7]), ptr(keep[8]), self.num_first_iter_, self.num_second_iter_, gain_threshold)
         pose_out, pts_out = np.zeros_like(pose), np.zeros_like(pts)
-        outl = np.zeros(max(E, 1), np.uint8)
+        outl = np.zeros(1 if _global else max(E, 1), np.uint8)  # (the global adjuster has no outlier list: no 10 MB of flags to fault in and copy at 9.6 M observations)
         st = _BaStats()
         stop = None if force_stop_flag is None else C.c_void_p(force_stop_flag.ctypes.data)
         outs = (C.c_void_p(pose_out.ctypes.data), C.c_void_p(pts_out.ctypes.data), C.c_void_p(outl.ctypes.data), C.byref(st))
@@ -145,7 +145,7 @@ class local_bundle_adjuster:
             rank, world, cb = _sharded
             rc = lib().svgpu_local_ba_sharded(self.ctx.handle, C.byref(prob), rank, world, cb, None, stop, *outs)
         self.ctx.check(rc, "svgpu_local_ba", ok=(0, 7))
-        return dict(rc=rc, pose_cw=pose_out, points=pts_out, outlier=outl[:E].copy(),
+        return dict(rc=rc, pose_cw=pose_out, points=pts_out, outlier=(np.zeros(0, np.uint8) if _global else outl[:E].copy()),
                     stats={f: getattr(st, f) for f, _ in _BaStats._fields_})
 
 
