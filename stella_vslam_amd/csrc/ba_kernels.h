@@ -93,6 +93,7 @@ struct BaDev {
     int red_flag_off;                // [2..5] cycle counters of the on-chip Cholesky
     int add_lambda;          // 1 = THIS rank adds the damping to the diagonal of S (rank 0 only in a sharded solve)
     const uint8_t* any_owner; // sharded: per landmark, some rank holds observations of it (the final exchange of the points)
+    const int* lm_off_caller; // renumbered solve: the landmark offsets in the CALLER's numbering (which landmarks this rank holds observations of: k_ba_points_share); else null
     const int* lm_order;      // renumbered solve (ba_pairs.hip): caller's index of the landmark at rank r (k_ba_pack_out writes the positions back in the caller's order); else null
     const uint8_t* lam_slot; // nullable; keyframe-segment exchange of a sharded solve: per free pose, whether THIS rank adds the damping to its diagonal block
     const double* Hpp_full;  // pose blocks summed over all ranks (== Hpp when not sharded): lambda init

@@ -1813,7 +1813,8 @@ __global__ __launch_bounds__(256) void k_ba_points_share(BaDev D, double* __rest
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= 3 * (size_t)D.L) return;
     const int l = (int)(i / 3);
-    if (dir == 0) xch[i] = D.lm_off[l + 1] > D.lm_off[l] ? points_out[i] : 0.0;
+    const int* const off = D.lm_off_caller ? D.lm_off_caller : D.lm_off;  // (points_out and xch are in the caller's numbering)
+    if (dir == 0) xch[i] = off[l + 1] > off[l] ? points_out[i] : 0.0;
     else if (D.any_owner[l]) points_out[i] = xch[i];
 }
 

@@ -207,7 +207,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     };
     // (the outputs start as the inputs: every early return leaves the estimate untouched.  At global-BA sizes the copy of the landmark
     //  positions -- 38 MB at 1.6 M landmarks -- is left to the host team below)
-    const bool team_sized = E >= 400000 && !std::getenv("SVGPU_BA_ONE_THREAD");
+    const int team_min_obs = [] {  // (SVGPU_BA_TEAM_MIN_OBS, read per call: the tests take small problems through the team's set-up)
+        const char* ev = std::getenv("SVGPU_BA_TEAM_MIN_OBS");
+        return ev ? std::max(64, std::atoi(ev)) : 400000;
+    }();
+    const bool team_sized = E >= team_min_obs && !std::getenv("SVGPU_BA_ONE_THREAD");
     memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
     if (!team_sized || (stop && *stop && !(allreduce != nullptr)) || E == 0 || P == 0 || L == 0) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
     if (E > 0 && outlier_out) memset(outlier_out, 0, E);
@@ -522,8 +526,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
                   + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
                   + pad(8 * 2 * (size_t)nmax + 64) + pad(8 * 2 * 4 * nparts_max) + pad(64) + 8192;
-    // the solve's own landmark numbering (ba_pairs.hip): one rank, one stage, the host team's sizes, observations grouped by landmark
-    const bool renumber = team.running && single_stage && !sharded && !std::getenv("SVGPU_BA_NO_RENUMBER");
+    // the solve's own landmark numbering (ba_pairs.hip): one stage, the host team's sizes, observations grouped by landmark
+    // (a sharded solve renumbers the landmarks of ITS shard: the numbering is private to the rank's kernels, every landmark-sized exchange
+    //  between ranks -- ownership marks, the final positions -- stays in the caller's numbering)
+    const bool renumber = team.running && single_stage && !std::getenv("SVGPU_BA_NO_RENUMBER");
     const bool chunk_units = renumber && pair_cap < ((size_t)1 << 31) && !std::getenv("SVGPU_BA_NO_UNITS");  // chunk-major units of the Schur kernel (ba_pairs.hip)
     const size_t unit_cap = chunk_units ? sc_part_blocks : 0;
     const size_t pair_scratch = std::max(std::max(std::max(sv_ba_pairs_scratch_bytes(pair_cap, E, nb_cap), sv_ba_pose_lists_scratch_bytes((size_t)E)), renumber ? sv_ba_renumber_scratch_bytes((size_t)L) : 0),
@@ -741,6 +747,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             D.e_uvr = rn_uvr, D.e_w = rn_w, D.e_huber = rn_hub;
             D.pt_buf[0] = rn_pts;
             D.lm_order = rn_order;
+            D.lm_off_caller = d_lm_off;
         }
         // pose -> edge lists on the device (they need the pose indices only)
         const int rp = sv_ba_prepare_lists(ctx, s, D.e_pose, E, P, sc, sc_bytes, d_pe_off, D.e_level, D.e_chi, &sorted_edges);  // (also clears e_level / e_chi)
@@ -987,7 +994,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if (!reuse) {
             D.unit_rec = nullptr;
             D.num_units = 0;
-            if (chunk_units && HS.nP > 48 && (size_t)D.NB * D.nshare >= 8192 && HS.num_pairs > 0) {
+            const size_t units_min = [] {  // (SVGPU_BA_UNITS_MIN, read per call: arithmetic shares below this many; the tests lower it)
+                const char* ev = std::getenv("SVGPU_BA_UNITS_MIN");
+                return ev ? (size_t)std::max(1, std::atoi(ev)) : (size_t)8192;
+            }();
+            if (chunk_units && HS.nP > 48 && (size_t)D.NB * D.nshare >= units_min && HS.num_pairs > 0) {
                 // ~0.5 MB of W records per chunk of consecutive landmark ranks (SVGPU_BA_CHUNK_SHIFT overrides: chunk = 2^shift landmarks).  Measured,
                 // Schur launch at config 5 / 9.6 M observations: 256 landmarks 125 / 930 us, 512: 122 / 880, 1 024: 132 / 882, 2 048: 158 / 973; arithmetic shares 144 / 1 537
                 int shift = 4;

@@ -632,6 +632,37 @@ def test_global_ba_distributed_factorisation_matches_single(world, monkeypatch):
     assert _rel(results[0]["points"], single["points"]) < 1e-7
 
 
+@pytest.mark.parametrize("shard", ["landmark", "keyframe_segment"])
+def test_global_ba_sharded_through_the_team_set_up(shard, monkeypatch):
+    """A sharded solve whose shards go through the global-BA sized set-up (host team, the shard's own landmark numbering, chunk-major Schur
+    units): forced onto a small scene with SVGPU_BA_TEAM_MIN_OBS / SVGPU_BA_UNITS_MIN.  The numbering is private to a rank's kernels --
+    ownership marks and the final positions cross ranks in the caller's numbering -- so: all ranks bit-identical, equal to the single-GPU
+    solve (itself through the same set-up) to 1e-7, and to the plain set-up of the same shards to 1e-7."""
+    from stella_vslam_amd import distributed as D, feature, optimize
+    monkeypatch.delenv("SVGPU_SKY_ONE_SIDED", raising=False)
+    monkeypatch.setenv("SVGPU_SKY_SEGMENTS", "5")
+    world = 2
+    sc = S.ba_scene_large(num_kf=200, num_lm=24000, obs_per_lm=4)
+    shard_fn = D.shard_by_landmark if shard == "landmark" else D.shard_by_keyframe_segment
+
+    def run_rank(rank, cb):
+        adj = optimize.local_bundle_adjuster(ctx=feature.Context()).set_solver(optimize.SOLVER_ENVELOPE)
+        return adj.optimize_global_flat_sharded(shard_fn(sc, rank, world), rank, world, cb, num_iter=10)
+
+    plain = _simulated_ranks(world, run_rank)
+    monkeypatch.setenv("SVGPU_BA_TEAM_MIN_OBS", "1000")
+    monkeypatch.setenv("SVGPU_BA_UNITS_MIN", "1")
+    single = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_global_flat(sc, num_iter=10)
+    team = _simulated_ranks(world, run_rank)
+    assert all(r is not None and r["rc"] == 0 for r in plain + team)
+    for r in team[1:]:
+        assert np.array_equal(team[0]["pose_cw"], r["pose_cw"]) and np.array_equal(team[0]["points"], r["points"])
+    for other in (single, plain[0]):
+        assert team[0]["stats"]["iters_stage1"] == other["stats"]["iters_stage1"]
+        _assert_poses(team[0]["pose_cw"], other["pose_cw"], 1e-7)
+        assert _rel(team[0]["points"], other["points"]) < 1e-7
+
+
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_global_ba_keyframe_segment_shards_exchange_only_separators(world, monkeypatch):
     """north_star's partition: observations sharded by the keyframe segment that owns them (distributed.shard_by_keyframe_segment over
