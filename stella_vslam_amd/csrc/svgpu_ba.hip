@@ -298,6 +298,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     struct HostTeam {
         std::vector<std::thread> th;
         std::atomic<int> arrived{0};
+        std::atomic<int> gate{0};    // 0: the team is being created, 1: run, 2: creation failed, leave
         std::atomic<int> staged{0};  // workers whose share of the measurements is in the staging image
         std::atomic<int> go{0};  // 0: the arena is not known yet, 1: upload, 2: abandon (the caller returns early or stages the observations itself)
         char* d_in = nullptr;
@@ -441,11 +442,27 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         }
         else {
             team.running = true;
-            for (int q = 1; q < nth; ++q)
-                team.th.emplace_back([&, q] {
-                    scan_range(q);
-                    stage_measurements(q);
-                });
+            // (the workers wait at a gate until the whole team exists: a thread the system refuses to create must not leave the others at a
+            //  barrier that counts nth arrivals -- the call fails instead, the caller's estimate untouched)
+            bool spawned = true;
+            try {
+                for (int q = 1; q < nth; ++q)
+                    team.th.emplace_back([&, q] {
+                        for (int spins = 0; team.gate.load() == 0; ++spins)
+                            if (spins > 2000) std::this_thread::yield();
+                        if (team.gate.load() != 1) return;
+                        scan_range(q);
+                        stage_measurements(q);
+                    });
+            } catch (...) {
+                spawned = false;
+            }
+            team.gate.store(spawned ? 1 : 2);
+            if (!spawned) {
+                team.join();
+                memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+                return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_global_ba: could not start the host threads of the set-up (SVGPU_BA_ONE_THREAD=1 runs it on the caller's thread)");
+            }
             scan_range(0);  // (returns behind the last barrier: the whole scan is done)
         }
         int any_bad = 0, any_unsorted = 0;
