@@ -340,7 +340,7 @@ _MATCHER_STREAM = None
 
 
 def matcher_stream():
-    """The matcher's stream, created ONCE per process (as a tracking thread would).  Measured (round 5, tools/scratch/streams.py, 256 frames/step, 8 calls
+    """The matcher's stream, created ONCE per process (as a tracking thread would).  Measured (round 5, tools/stream_alias_exp.py, 256 frames/step, 8 calls
     in one process): with one stream kept, 212-215 k frames/s on every call; with a fresh torch.cuda.Stream per call, calls 2 and 5 drop to 163-166 k —
     some streams of torch's pool land on a hardware queue that serialises against the extraction stream's (k_select doubles, k_resize gets faster:
     the overlap pattern changes, not the kernels).  Rounds 1-5's 'second_batch_point' was such a second stream."""
