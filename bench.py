@@ -167,6 +167,16 @@ def main() -> int:
         result["second_batch_point"] = {"frames_per_gpu_per_step": B2, "value": round(B2 * world * args.steps / fe2["dt"], 2), "unit": "frames/s",
                                         "ms_per_step": round(fe2["dt"] / args.steps * 1e3, 4), "keypoints_per_frame": round(fe2["n_kp"], 1)}
         del fe2
+    # the same step fed from page-locked host memory (the upload of the next batch on a copy stream): what the link allows, beside `value`
+    if not args.no_extra:
+        try:
+            n_h = max(4, args.steps // 4)
+            feh = run_front_end(ctx, L, frames_np, B, n_h, 2, barrier, world, profile=False, h2d=True)
+            result["with_h2d"] = {"value": round(B * world * n_h / feh["dt"], 2), "unit": "frames/s", "ms_per_step": round(feh["dt"] / n_h * 1e3, 4), "steps": n_h,
+                                  "what": "the headline step with the batch uploaded from page-locked host memory every step (copy stream, two device images): %.0f MB per step" % (B * W * H / 1e6)}
+            del feh
+        except Exception as e:  # (a secondary leg)
+            result["with_h2d"] = {"error": repr(e)}
 
     torch.cuda.empty_cache()
 
@@ -272,6 +282,8 @@ def compact_line(r):
     out["roofline"] = ro
     if "second_batch_point" in r:
         out["second_batch_point"] = _pick(r["second_batch_point"], ("frames_per_gpu_per_step", "value", "ms_per_step"))
+    if "with_h2d" in r:
+        out["with_h2d"] = _pick(r["with_h2d"], ("value", "ms_per_step", "error"))
     cb = r.get("cpu_baseline")
     if isinstance(cb, dict):
         c = _pick(cb, ("value", "unit", "cores", "kind", "error"))
@@ -310,7 +322,7 @@ def compact_line(r):
     out["detail"] = "bench_detail.json (full per-kernel arrays, projections and per-phase legs; also on stderr)"
     line = json.dumps(out, separators=(",", ":"))
     if len(line) > 4000:   # never let a leg's growth cost the headline again: drop the summaries, keep the contract keys
-        for k in ("natural_images", "latency", "stereo", "tracked_frame", "mapping_keyframe", "global_ba_large", "second_batch_point"):
+        for k in ("natural_images", "latency", "stereo", "tracked_frame", "mapping_keyframe", "global_ba_large", "with_h2d", "second_batch_point"):
             out.pop(k, None)
             line = json.dumps(out, separators=(",", ":"))
             if len(line) <= 4000:
@@ -351,7 +363,7 @@ def matcher_stream():
     return _MATCHER_STREAM
 
 
-def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=True):
+def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=True, h2d=False):
     """The step of this bench on one rank: ORB extraction of the B resident frames + brute-force match of each against the previous one
     (ring of B pairs).  Two HIP streams: extraction of step t+1 (stream A = the context's) overlaps the matcher of step t (stream B),
     which leaves most CUs idle during its sort / greedy-replay kernels.  Two output buffer sets alternate; events order
@@ -393,6 +405,23 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
                      ev_ext=torch.cuda.Event(), ev_match=torch.cuda.Event(), used=False) for _ in range(NBUF)]
     stream.synchronize()
     state = {"i": 0}
+    up = None
+    if h2d:
+        # the PCIe-inclusive variant: the batch lives in page-locked HOST memory and goes up every step -- the upload of batch t + 1 on a copy
+        # stream beside the work on batch t, two device images of the batch alternating
+        stream_c = torch.cuda.Stream()
+        host = torch.from_numpy(np.ascontiguousarray(frames_np)).pin_memory()
+        with torch.cuda.stream(stream_c):
+            dev = [frames, torch.empty_like(frames)]
+        up = dict(stream=stream_c, host=host, dev=dev, ev_up=[torch.cuda.Event(), torch.cuda.Event()], ev_free=[torch.cuda.Event(), torch.cuda.Event()], primed=False)
+        stream_c.synchronize()
+
+    def upload(j):
+        with torch.cuda.stream(up["stream"]):
+            if up["primed"]:
+                up["stream"].wait_event(up["ev_free"][j])  # the extraction that read this image has finished
+            up["dev"][j].copy_(up["host"], non_blocking=True)
+            up["ev_up"][j].record(up["stream"])
 
     def step():
         """Extraction of batch t on stream A, then its matcher on stream B: the matcher of batch t overlaps the extraction of batch
@@ -404,10 +433,22 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
         if bf["used"]:
             stream.wait_event(bf["ev_match"])  # the matcher of two steps ago has finished reading this buffer set
         bf["used"] = True
-        ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(frames.data_ptr()), B, C.c_size_t(Wf * Hf), Wf, None,
+        src = frames
+        if up is not None:
+            j = (state["i"] - 1) & 1
+            if not up["primed"]:
+                upload(j)
+            stream.wait_event(up["ev_up"][j])
+            src = up["dev"][j]
+        ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(src.data_ptr()), B, C.c_size_t(Wf * Hf), Wf, None,
                                                    C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()),
                                                    cap, C.c_void_p(counts.data_ptr()), None), "extract_batch")
         bf["ev_ext"].record(stream)
+        if up is not None:
+            up["ev_free"][j].record(stream)
+            up["ev_free"][j ^ 1].record(stream) if not up["primed"] else None
+            up["primed"] = True
+            upload(j ^ 1)  # the next step's batch, while this one is worked on
         if match_stage >= 0:
             prev = state.get("pending")
             state["pending"] = bf
