@@ -750,10 +750,16 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
             H2D(d_in + in.intr, hs + in.intr, in.e_uvr - in.intr);            // intrinsics | e_pose | e_point
             H2D(d_in + in.lm_off, hs + in.lm_off, in.pe_off - in.lm_off);     // landmark offsets
             // (the link is shared: the measurements queue behind the index arrays, which the structure kernels are waiting for)
-            SV_HIP(ctx, hipEventRecord(ctx->ev_ba_copy, s));
-            SV_HIP(ctx, hipStreamWaitEvent(ctx->ba_copy_stream, ctx->ev_ba_copy, 0));
+            // SVGPU_BA_COPY_ON_MAIN: the measurements on the solve's own stream instead.  Measured over 150 config-5 calls: copy stream median
+            // 7.50 ms, but 2 calls of 15 ms (the stream's first synchronisation arrives ~8 ms late: two DMA users of one process); own stream
+            // 8.06 ms, no call above 8.9.  The default keeps the better mean (7.6 against 8.1); a caller that minds the tail sets the variable.
+            const bool copy_on_main = std::getenv("SVGPU_BA_COPY_ON_MAIN") != nullptr;
+            if (!copy_on_main) {
+                SV_HIP(ctx, hipEventRecord(ctx->ev_ba_copy, s));
+                SV_HIP(ctx, hipStreamWaitEvent(ctx->ba_copy_stream, ctx->ev_ba_copy, 0));
+            }
             team.d_in = d_in;
-            team.s2 = ctx->ba_copy_stream;
+            team.s2 = copy_on_main ? s : ctx->ba_copy_stream;
             team.go.store(1);
         }
         else H2D(d_in, hs, in.total);
