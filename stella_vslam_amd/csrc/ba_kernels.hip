@@ -2491,8 +2491,12 @@ __global__ __launch_bounds__(256) void k_ba_expand_dense(BaDev D) {
     if (k < D.NB * 36) {
         const int blk = k / 36, t = k - 36 * blk, i = t / 6, j = t - 6 * i;
         const int2 ab = D.blk_ab[blk];
-        D.S[(size_t)(6 * ab.x + i) * n + 6 * ab.y + j] = D.Sblk[k];
-        D.S[(size_t)(6 * ab.y + j) * n + 6 * ab.x + i] = D.Sblk[k];
+        // (a diagonal block is symmetric up to the last bits of its two triangles' sums: written by BOTH of its entries (i, j) and (j, i),
+        //  the dense matrix would hold whichever landed last -- run-to-run differences of 1e-13 in the estimate.  Its lower triangle decides.)
+        if (ab.x != ab.y || j <= i) {
+            D.S[(size_t)(6 * ab.x + i) * n + 6 * ab.y + j] = D.Sblk[k];
+            D.S[(size_t)(6 * ab.y + j) * n + 6 * ab.x + i] = D.Sblk[k];
+        }
     }
     if (k < D.n) D.S[n * n + k] = D.g[k];
 }
@@ -2653,12 +2657,15 @@ void sv_ba_solve(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
 // dense image in global memory + the one-workgroup LL^T on it (solver = dense: systems beyond the on-chip solver's 186 unknowns that are
 // to be factored densely all the same -- the default for those sizes is the block envelope Cholesky).  The library's own code throughout:
 // no vendor solver is loaded anywhere.
+void sv_ba_dense_tiled(hipStream_t s, const BaDev& D);
 void sv_ba_solve_dense(svgpu_ctx* ctx, hipStream_t s, const BaDev& D) {
     if (D.nP <= 0) return;
     SvProfScope ps(ctx, s, "ba_solve");
     (void)hipMemsetAsync(D.S, 0, sizeof(double) * (size_t)(D.n + 1) * D.n, s);
     hipLaunchKernelGGL(k_ba_expand_dense, dim3((D.NB * 36 + 255) / 256), dim3(256), 0, s, D);
-    hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);
+    static const bool one_wg = std::getenv("SVGPU_BA_DENSE_ONE_WG") != nullptr;  // A/B aid: the one-workgroup column-by-column form
+    if (one_wg || D.n > 1536) hipLaunchKernelGGL(k_ba_chol_global, dim3(1), dim3(1024), 0, s, D);  // (the tiled form keeps the right-hand side in LDS: n <= 1536)
+    else sv_ba_dense_tiled(s, D);  // ba_dense_tiled.hip: tiles of 48, panel + MFMA update per tile column
 }
 
 // back-substitution, trial state

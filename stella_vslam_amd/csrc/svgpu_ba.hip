@@ -531,14 +531,15 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     const size_t sc_part_blocks = pair_cap / 64 + nb_cap + 16;  // NB * nshare <= pairs / 64 + NB (a share holds at least 64 pairs: one trip of a wave)
     const size_t xch_doubles = std::max(std::max((size_t)P, 4 * (size_t)L), nb_cap) + 8;
     const size_t nparts_max = (size_t)(P + 3) / 4 + 1;
-    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE;
+    // the dense matrix of the tiled LL^T (ba_dense_tiled.hip): on request, and as a candidate of AUTO for windows of 32 - 256 keyframes on one rank
+    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE || (solver_opt == SV_BA_SOLVER_AUTO && !sharded && P > 31 && P <= 256 && !std::getenv("SVGPU_BA_NO_DENSE_TILED"));
     size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
                   + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
                   + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + pad(sizeof(double) * 18 * E)
                   + pad(sizeof(double) * 27 * 16 * (size_t)P) + pad(sizeof(double) * 36 * sc_part_blocks) + pad(sizeof(double) * 6 * 16 * (size_t)P)
                   + pad(sizeof(double) * 6 * L) + pad(sizeof(double) * 3 * L) + pad(sizeof(double) * 36 * P)
                   + pad(sizeof(double) * 6 * P) + pad(sizeof(double) * (36 * nb_cap + 6 * (size_t)P + 8)) + pad(sizeof(double) * nmax)
-                  + (want_dense ? pad(sizeof(double) * (size_t)(nmax + 1) * nmax) : 0)
+                  + (want_dense ? pad(sizeof(double) * ((size_t)(nmax + 1) * nmax + (size_t)(nmax / 48 + 1) * 48 * 48)) : 0)
                   + pad(sizeof(double) * (nb_chi + nb_lm + nb_pose + 8)) + pad(E + 1) + pad(8 * 42 * (size_t)P)
                   + pad(8 * (size_t)(64 + world + 1)) + pad(8 * xch_doubles) + pad(sizeof(BaCtl))
                   + pad(4 * (size_t)(P + 1)) + pad(8 * 2 * (nb_cap + 1)) + pad(4 * (size_t)P) + pad(8 * 36 * (size_t)P) + pad(8 * 6 * (size_t)nmax + 64)
@@ -600,7 +601,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     D.Hpp = A.take<double>(36 * (size_t)P);
     D.bp = A.take<double>(6 * (size_t)P);
     D.Sblk = A.take<double>(36 * nb_cap + 6 * (size_t)P + 8);
-    D.S = want_dense ? A.take<double>((size_t)(nmax + 1) * nmax) : nullptr;
+    D.S = want_dense ? A.take<double>((size_t)(nmax + 1) * nmax + (size_t)(nmax / 48 + 1) * 48 * 48) : nullptr;  // (+ the inverted diagonal tiles of ba_dense_tiled.hip)
     D.dp = A.take<double>(nmax);
     D.red = A.take<double>(nb_chi + nb_lm + nb_pose + 8);
     D.lm_max = A.take<double>(nb_lm);  // nb_lm == sv_ba_lm_blocks(L)
@@ -1043,6 +1044,10 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         // LDS-resident PCG up to 512 unknowns / ~150 KB of blocks, the one-launch-per-iteration PCG beyond
         if (solver == SV_BA_SOLVER_AUTO && D.chol_in_lds) solver = SV_BA_SOLVER_CHOLESKY;
         if (solver == SV_BA_SOLVER_CHOLESKY && !D.chol_in_lds) solver = SV_BA_SOLVER_AUTO;
+        // beyond one workgroup's LDS, a window whose block pattern is close to full (every keyframe of a local window shares landmarks with
+        // most others): the tiled dense LL^T -- 2 launches per 48 columns, MFMA updates.  Measured per damping trial, auto before / tiled:
+        // see DESIGN section 6 (windows of 40 - 100 keyframes).
+        if (solver == SV_BA_SOLVER_AUTO && D.S && D.n > 186 && D.n <= 1536 && (size_t)D.NB * 5 >= (size_t)HS.nP * (HS.nP + 1)) solver = SV_BA_SOLVER_DENSE;  // >= 40 % of the upper blocks kept
         // beyond the on-chip solvers: the direct envelope factorisation while the envelope of the ordered block graph is small (keyframe
         // graphs are banded up to a few loop-closure rows), else -- or on request -- the PCG with one launch per iteration
         if ((solver == SV_BA_SOLVER_AUTO && !lds_ok) || solver == SV_BA_SOLVER_ENVELOPE) {

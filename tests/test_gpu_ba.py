@@ -51,6 +51,10 @@ def _assert_poses(got, ref, tol=TOL):
                                 # the on-chip LL^T at its limits: n = 126 (946 of 1024 tiles, one per thread), n = 132 (two per thread)
                                 dict(num_kf=24, num_lm=3000, obs_per_lm=6, num_fixed=3, seed=21),
                                 dict(num_kf=24, num_lm=3000, obs_per_lm=6, num_fixed=2, seed=22),
+                                # windows beyond one workgroup's LDS with a dense block pattern: the tiled LL^T of ba_dense_tiled.hip (n = 192: four
+                                # whole tile columns; n = 228: a part-filled last tile with the right-hand side inside its row range)
+                                dict(num_kf=34, num_lm=4000, obs_per_lm=6, num_fixed=2, seed=31),
+                                dict(num_kf=40, num_lm=5000, obs_per_lm=6, num_fixed=2, seed=32),
                                 # equirectangular cameras (intrinsics rows {0, 0, cols, rows, 0}): equirectangular_reproj_edge.h:64-134
                                 dict(num_kf=8, num_lm=1200, obs_per_lm=5, num_fixed=2, seed=8, equirect=True)])
 def test_local_ba_matches_oracle(ba, kw):
@@ -68,6 +72,29 @@ def test_local_ba_matches_oracle(ba, kw):
     # and the optimisation did its job
     assert gs["chi2_final"] < 0.5 * gs["chi2_initial"]
     assert np.abs(got["pose_cw"] - sc["pose_gt"]).mean() < np.abs(sc["pose_cw"] - sc["pose_gt"]).mean()
+
+
+def test_tiled_dense_solver_is_what_auto_takes_and_agrees_with_the_others(ba, monkeypatch):
+    """A 40-keyframe window (n = 228, every upper block kept): AUTO hands the reduced system to the tiled dense LL^T (ba_dense_tiled.hip: the
+    only solver of this size that leaves the envelope plan empty); the envelope factorisation and the one-workgroup dense form must land on
+    the same estimate with the same LM schedule."""
+    from stella_vslam_amd import optimize
+    sc = S.ba_scene(num_kf=40, num_lm=5000, obs_per_lm=6, num_fixed=2, seed=32)
+    auto = optimize.local_bundle_adjuster()
+    got = auto.optimize_flat(sc)
+    assert got["stats"]["cholesky_failures"] == 0 and got["stats"]["pcg_iterations"] == 0
+    env = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_flat(sc)
+    monkeypatch.setenv("SVGPU_BA_NO_DENSE_TILED", "1")
+    before = optimize.local_bundle_adjuster().optimize_flat(sc)  # what AUTO took before: the envelope factorisation
+    monkeypatch.delenv("SVGPU_BA_NO_DENSE_TILED")
+    for other in (env, before):
+        for key in ("iters_stage1", "iters_stage2", "num_gated", "lm_trials"):
+            assert got["stats"][key] == other["stats"][key], key
+        assert got["stats"]["chi2_final"] == pytest.approx(other["stats"]["chi2_final"], rel=1e-9)
+        assert np.abs(got["pose_cw"] - other["pose_cw"]).max() < 1e-8 and np.abs(got["points"] - other["points"]).max() < 1e-8
+        assert np.array_equal(got["outlier"], other["outlier"])
+    again = auto.optimize_flat(sc)
+    assert np.array_equal(again["pose_cw"], got["pose_cw"]) and np.array_equal(again["points"], got["points"])  # fixed-order sums
 
 
 def test_local_ba_stop_flag_semantics(ba):
