@@ -14,7 +14,8 @@
 // matrix-vector product, no sequential triangle), the update of the rows above as a coalesced matrix-vector product, z in LDS.  Every sum
 // has a fixed order: run-to-run bit-identical.  A pivot that is not positive fails the damping trial (ctl.solve_failed), as a failed LL^T
 // does in the reference; the later launches of the solve then return at once.
-// Measured per launch at n = 228 (rocprofv3): panel 25 us, update 9 us, backward 23 us (5 tile columns).
+// Measured per launch at n = 228 (rocprofv3): panel 22.6 us, update 8.1 us, backward 25 us (5 tile columns); per damping trial 290 us against
+// 467 us with the envelope factorisation (257 against 370 at n = 192).
 // Launches: 2 nt + 2 (nt = tile columns): 12 at n = 228, 28 at n = 588 -- against a chain of n / 6 block columns at ~6 - 10 us each in the
 // general envelope kernel, which is what AUTO took for these windows before (svgpu_ba.hip).
 #include <algorithm>
@@ -58,7 +59,12 @@ __device__ __forceinline__ bool dt_factor_invert(const double* __restrict__ A, i
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int i = ti + 16 * (p % 3), c = tj + 16 * q;
-            if (p < 3) a[p][q] = (c <= i && c0 + i < n && c0 + c < n) ? A[(size_t)(c0 + i) * ld + c0 + c] : (i == c ? 1.0 : 0.0);
+            if (p < 3) {  // (an unconditional load from a clamped address, masked afterwards: a conditional load is a branch, and the compiler waits
+                          //  for each one before the next -- eight memory round trips in a row at the head of every panel launch)
+                const bool in = c <= i && c0 + i < n && c0 + c < n;
+                const double v = A[in ? (size_t)(c0 + i) * ld + c0 + c : (size_t)0];
+                a[p][q] = in ? v : (i == c ? 1.0 : 0.0);
+            }
             else a[p][q] = i == c ? 1.0 : 0.0;
         }
     if (tid == 0) *s_flag = 0;
@@ -121,7 +127,9 @@ __global__ __launch_bounds__(256) void k_dt_panel(BaDev D, int k) {
     for (int it = 0; it < DT * DT / 256; ++it) {
         const int t = tid + 256 * it;
         const int i = t / DT, j = t - DT * i, ri = I * DT + i;
-        pa[it] = (ri <= n && ri >= c0 + w && j < w) ? A[(size_t)ri * ld + c0 + j] : 0.0;
+        const bool in = ri <= n && ri >= c0 + w && j < w;
+        const double v = A[in ? (size_t)ri * ld + c0 + j : (size_t)0];
+        pa[it] = in ? v : 0.0;
     }
     if (!dt_factor_invert(A, n, c0, s_L, s_W, s_col, &s_flag)) {
         if (blockIdx.x == 0 && tid == 0) D.ctl->solve_failed = 1;
@@ -178,8 +186,10 @@ __global__ __launch_bounds__(256) void k_dt_update(BaDev D, int k, int nrt) {
         const int t = tid + 256 * it;
         const int i = t / DT, j = t - DT * i;
         const int ri = I * DT + i, rj = J * DT + i;
-        s_a[i][j] = (ri <= n && j < w) ? A[(size_t)ri * ld + c0 + j] : 0.0;
-        s_b[i][j] = (rj < n && j < w) ? A[(size_t)rj * ld + c0 + j] : 0.0;  // (columns of the result: rows of L_Jk, inside the matrix only)
+        const bool ina = ri <= n && j < w, inb = rj < n && j < w;  // (b: columns of the result = rows of L_Jk, inside the matrix only)
+        const double va = A[ina ? (size_t)ri * ld + c0 + j : (size_t)0], vb = A[inb ? (size_t)rj * ld + c0 + j : (size_t)0];
+        s_a[i][j] = ina ? va : 0.0;
+        s_b[i][j] = inb ? vb : 0.0;
     }
     __syncthreads();
     // nine 16 x 16 sub-tiles, wave w takes w, w + 4, w + 8
@@ -191,7 +201,9 @@ __global__ __launch_bounds__(256) void k_dt_update(BaDev D, int k, int nrt) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int rowg = I * DT + 16 * si + (lane >> 4) + 4 * reg;
-            c[reg] = (rowg <= n && col < n) ? A[(size_t)rowg * ld + col] : 0.0;
+            const bool in = rowg <= n && col < n;
+            const double v = A[in ? (size_t)rowg * ld + col : (size_t)0];
+            c[reg] = in ? v : 0.0;
         }
 #pragma unroll
         for (int kk = 0; kk < DT / 4; ++kk) {
@@ -244,7 +256,11 @@ __global__ __launch_bounds__(256) void k_dt_backward(BaDev D, int nct) {
         double l[DT];
         const bool first = tid < c0;
 #pragma unroll
-        for (int r = 0; r < DT; ++r) l[r] = (first && r < w) ? A[(size_t)(c0 + r) * ld + tid] : 0.0;
+        for (int r = 0; r < DT; ++r) {
+            const bool in = first && r < w;
+            const double v = A[in ? (size_t)(c0 + r) * ld + tid : (size_t)0];
+            l[r] = in ? v : 0.0;
+        }
         dt_sync_lds();
         if (tid < DT) {  // x_j = sum_{m >= j} U[j][m] z_m  (U = L_KK^-T, upper triangular; the identity tail beyond the matrix contributes z = 0)
             double v = 0.0;
@@ -263,7 +279,10 @@ __global__ __launch_bounds__(256) void k_dt_backward(BaDev D, int nct) {
         for (int c = tid + 256; c < c0; c += 256) {  // further passes (n > 304)
             double l2[DT];
 #pragma unroll
-            for (int r = 0; r < DT; ++r) l2[r] = r < w ? A[(size_t)(c0 + r) * ld + c] : 0.0;
+            for (int r = 0; r < DT; ++r) {
+                const double v = A[r < w ? (size_t)(c0 + r) * ld + c : (size_t)0];
+                l2[r] = r < w ? v : 0.0;
+            }
             double v = s_z[c];
 #pragma unroll
             for (int r = 0; r < DT; ++r) v = fma(-l2[r], s_x[r], v);
