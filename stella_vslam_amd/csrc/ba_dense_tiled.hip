@@ -1,5 +1,5 @@
-// Dense LL^T of the reduced camera system for local windows that outgrow one workgroup's LDS (n = 6 x free keyframes beyond ~186: windows
-// of 32 - 200 keyframes, whose block pattern is close to full -- every keyframe of a local window shares landmarks with most others).
+// Dense LL^T of the reduced camera system for local windows that outgrow one workgroup's LDS (n = 6 x free keyframes from 138: windows
+// of 25 - 200 keyframes, whose block pattern is close to full -- every keyframe of a local window shares landmarks with most others).
 // local_bundle_adjuster_g2o.cc:151-164 hands this system to a dense LL^T (Eigen); north_star asks for the matrix cores here.
 //
 // Right-looking, tiles of DT = 48 (8 keyframes), the matrix in global memory (n = 588: 2.8 MB, L2 resident), row n = the right-hand side

@@ -531,8 +531,8 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     const size_t sc_part_blocks = pair_cap / 64 + nb_cap + 16;  // NB * nshare <= pairs / 64 + NB (a share holds at least 64 pairs: one trip of a wave)
     const size_t xch_doubles = std::max(std::max((size_t)P, 4 * (size_t)L), nb_cap) + 8;
     const size_t nparts_max = (size_t)(P + 3) / 4 + 1;
-    // the dense matrix of the tiled LL^T (ba_dense_tiled.hip): on request, and as a candidate of AUTO for windows of 32 - 256 keyframes on one rank
-    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE || (solver_opt == SV_BA_SOLVER_AUTO && !sharded && P > 31 && P <= 256 && !std::getenv("SVGPU_BA_NO_DENSE_TILED"));
+    // the dense matrix of the tiled LL^T (ba_dense_tiled.hip): on request, and as a candidate of AUTO for windows of 24 - 256 keyframes on one rank
+    const bool want_dense = solver_opt == SV_BA_SOLVER_DENSE || (solver_opt == SV_BA_SOLVER_AUTO && !sharded && P >= 24 && P <= 256 && !std::getenv("SVGPU_BA_NO_DENSE_TILED"));
     size_t need = 4 * pad(sizeof(double) * 12 * P) + 4 * pad(sizeof(double) * 3 * L) + 2 * pad(4 * (size_t)E) + pad(12 * (size_t)E)
                   + 2 * pad(4 * (size_t)E) + 2 * pad(E) + pad(8 * (size_t)E) + pad(40 * (size_t)P) + pad(4 * (size_t)P) + pad(L)
                   + pad(4 * (size_t)(L + 1)) + pad(4 * (size_t)(P + 1)) + pad(4 * (size_t)E) + pad(sizeof(double) * 18 * E)
@@ -1047,7 +1047,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         // beyond one workgroup's LDS, a window whose block pattern is close to full (every keyframe of a local window shares landmarks with
         // most others): the tiled dense LL^T -- 2 launches per 48 columns, MFMA updates.  Measured per damping trial, auto before / tiled:
         // see DESIGN section 6 (windows of 40 - 100 keyframes).
-        if (solver == SV_BA_SOLVER_AUTO && D.S && D.n > 186 && D.n <= 1536 && (size_t)D.NB * 5 >= (size_t)HS.nP * (HS.nP + 1)) solver = SV_BA_SOLVER_DENSE;  // >= 40 % of the upper blocks kept
+        // (from where the register-tile solve no longer fits LDS -- n = 138: per trial 232 us at n = 156 against 386 for the LDS-resident PCG AUTO
+        //  took there and 282 for the envelope factorisation; at n = 132, where the register-tile solve still fits, the two tie at ~200 us)
+        if (solver == SV_BA_SOLVER_AUTO && D.S && !D.chol_in_lds && D.n <= 1536 && (size_t)D.NB * 5 >= (size_t)HS.nP * (HS.nP + 1)) solver = SV_BA_SOLVER_DENSE;  // >= 40 % of the upper blocks kept
         // beyond the on-chip solvers: the direct envelope factorisation while the envelope of the ordered block graph is small (keyframe
         // graphs are banded up to a few loop-closure rows), else -- or on request -- the PCG with one launch per iteration
         if ((solver == SV_BA_SOLVER_AUTO && !lds_ok) || solver == SV_BA_SOLVER_ENVELOPE) {
