@@ -97,6 +97,25 @@ def test_tiled_dense_solver_is_what_auto_takes_and_agrees_with_the_others(ba, mo
     assert np.array_equal(again["pose_cw"], got["pose_cw"]) and np.array_equal(again["points"], got["points"])  # fixed-order sums
 
 
+def test_tiled_dense_solver_fails_trials_where_the_envelope_solver_does():
+    """A pivot that is not positive fails the damping trial (ctl.solve_failed; g2o's solver returning false): an INDEFINITE problem -- a third of
+    the observations with negative information -- makes a dozen factorisations fail.  The tiled dense LL^T (AUTO at n = 228) and the envelope
+    factorisation must fail the same trials: same failure count, same LM schedule, same damping at the end, same estimate."""
+    from stella_vslam_amd import optimize
+    sc = dict(S.ba_scene(num_kf=40, num_lm=5000, obs_per_lm=6, num_fixed=2, seed=32))
+    w = sc["obs_inv_sigma_sq"].copy()
+    w[np.random.default_rng(3).random(len(w)) < 0.3] *= -3.0
+    sc["obs_inv_sigma_sq"] = w
+    tiled = optimize.local_bundle_adjuster().optimize_flat(sc)
+    env = optimize.local_bundle_adjuster().set_solver(optimize.SOLVER_ENVELOPE).optimize_flat(sc)
+    assert tiled["stats"]["cholesky_failures"] >= 5
+    for key in ("iters_stage1", "iters_stage2", "lm_trials", "cholesky_failures", "num_gated"):
+        assert tiled["stats"][key] == env["stats"][key], key
+    assert tiled["stats"]["lambda_final"] == pytest.approx(env["stats"]["lambda_final"], rel=1e-9)
+    assert tiled["stats"]["chi2_final"] == pytest.approx(env["stats"]["chi2_final"], rel=1e-9)
+    assert np.abs(tiled["pose_cw"] - env["pose_cw"]).max() < 1e-7 and np.abs(tiled["points"] - env["points"]).max() < 1e-6
+
+
 def test_local_ba_stop_flag_semantics(ba):
     sc = S.ba_scene(num_kf=6, num_lm=200, obs_per_lm=4, num_fixed=2, seed=3, outlier_frac=0.0, pose_noise=(1e-4, 1e-3),
                     point_noise=1e-4)
