@@ -348,6 +348,7 @@ KERNEL_CLASSES = ("k_resize", "k_blur", "k_fast", "k_select", "k_describe", "k_b
 ROCPROF_KERNEL = {"k_resize": "k_pyramid_lds", "k_bf_topk": "k_bf_mfma"}
 
 
+PACKED_ANGLES = os.environ.get("BENCH_PACKED_ANGLES", "1") != "0"  # (A/B aid: 0 = the matcher reads the angles out of the keypoint records)
 _MATCHER_STREAM = None
 
 
@@ -402,6 +403,7 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
                      counts=torch.zeros(B * nc, dtype=torch.int32, device="cuda"),
                      matched=torch.zeros(B * cap, dtype=torch.int32, device="cuda"),
                      nmatch=torch.zeros(B, dtype=torch.int32, device="cuda"),
+                     angles=torch.zeros(B * cap, dtype=torch.float32, device="cuda"),
                      ev_ext=torch.cuda.Event(), ev_match=torch.cuda.Event(), used=False) for _ in range(NBUF)]
     stream.synchronize()
     state = {"i": 0}
@@ -440,9 +442,10 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
                 upload(j)
             stream.wait_event(up["ev_up"][j])
             src = up["dev"][j]
-        ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(src.data_ptr()), B, C.c_size_t(Wf * Hf), Wf, None,
-                                                   C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()),
-                                                   cap, C.c_void_p(counts.data_ptr()), None), "extract_batch")
+        # (the extractor also leaves the angles as a packed array: the matcher's angle-bin sort then reads 4 instead of 28 bytes per keypoint)
+        ctx.check(L.svgpu_orb_extract_batch_device_angles(ctx.handle, C.c_void_p(src.data_ptr()), B, C.c_size_t(Wf * Hf), Wf, None,
+                                                          C.c_size_t(0), 0, C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()),
+                                                          cap, C.c_void_p(counts.data_ptr()), C.c_void_p(bf["angles"].data_ptr()) if PACKED_ANGLES else None, None), "extract_batch")
         bf["ev_ext"].record(stream)
         if up is not None:
             up["ev_free"][j].record(stream)
@@ -459,8 +462,9 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
             ctx.check(L.svgpu_orb_stream_wait_stage(ctx.handle, match_stage, C.c_void_p(stream_b.cuda_stream)), "stream_wait_stage")
         stream_b.wait_event(bf["ev_ext"])
         # pair t = (frame (t + 1) % B, keyframe = frame t), t = 0..B-1, straight from the extractor's batch layout
-        ctx.check(L.svgpu_match_consecutive_batch_device(
-            ctx.handle, B, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()), C.c_void_p(counts.data_ptr()), cap, nc, None,
+        ctx.check(L.svgpu_match_consecutive_batch_device_angles(
+            ctx.handle, B, C.c_void_p(desc.data_ptr()), C.c_void_p(kps.data_ptr()), C.c_void_p(bf["angles"].data_ptr()) if PACKED_ANGLES else None,
+            C.c_void_p(counts.data_ptr()), cap, nc, None,
             C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()), C.c_void_p(bf["nmatch"].data_ptr()),
             C.c_void_p(stream_b.cuda_stream)), "match_batch")
         bf["ev_match"].record(stream_b)
@@ -503,8 +507,9 @@ def run_front_end(ctx, L, frames_np, B, steps, warmup, barrier, world, profile=T
         bf = bufs[(state["i"] - 1) % NBUF]
         L.svgpu_profile_select(ctx.handle, b"*")
         for _ in range(4):
-            ctx.check(L.svgpu_match_consecutive_batch_device(
-                ctx.handle, B, C.c_void_p(bf["desc"].data_ptr()), C.c_void_p(bf["kps"].data_ptr()), C.c_void_p(bf["counts"].data_ptr()), cap, nc, None,
+            ctx.check(L.svgpu_match_consecutive_batch_device_angles(
+                ctx.handle, B, C.c_void_p(bf["desc"].data_ptr()), C.c_void_p(bf["kps"].data_ptr()), C.c_void_p(bf["angles"].data_ptr()) if PACKED_ANGLES else None,
+                C.c_void_p(bf["counts"].data_ptr()), cap, nc, None,
                 C.c_float(LOWE), CHECK_ORI, C.c_void_p(bf["matched"].data_ptr()), C.c_void_p(bf["nmatch"].data_ptr()), C.c_void_p(stream_b.cuda_stream)), "match_batch")
         sync_all()
         for name in ("k_bf_binsort", "k_bf_topk", "k_bf_replay"):

@@ -128,6 +128,13 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
                                    int mask_row_stride, svgpu_keypoint* kps_dev, uint8_t* desc_dev, int cap,
                                    int32_t* counts_dev, void* stream);
 
+/* The same, and the keypoint angles once more as a packed float array (batch * cap; nullable): what the angle-bin sort of the batched
+ * matcher wants to read -- 4 bytes per keypoint instead of walking the 28-byte records (svgpu_match_consecutive_batch_device_angles). */
+int svgpu_orb_extract_batch_device_angles(svgpu_ctx* ctx, const uint8_t* imgs_dev, int batch, size_t frame_stride,
+                                          int row_stride, const uint8_t* mask_dev, size_t mask_frame_stride,
+                                          int mask_row_stride, svgpu_keypoint* kps_dev, uint8_t* desc_dev, int cap,
+                                          int32_t* counts_dev, float* angles_dev, void* stream);
+
 /* image_pyramid_[level] of frame `frame` of the last extract call, copied to host (level 0 is the
  * caller's own image and is not stored).  Synchronous. */
 int svgpu_orb_pyramid_download(svgpu_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride);
@@ -176,6 +183,12 @@ int svgpu_match_bruteforce_batch_device(svgpu_ctx* ctx, int pairs, const uint8_t
 int svgpu_match_consecutive_batch_device(svgpu_ctx* ctx, int frames, const uint8_t* desc_dev, const svgpu_keypoint* kps_dev,
                                          const int32_t* n_dev, int cap, int n_stride, const uint8_t* valid_dev, float lowe_ratio,
                                          int check_orientation, int32_t* matched_dev, int32_t* num_dev, void* stream);
+
+/* The same with the keypoint angles as the packed array svgpu_orb_extract_batch_device_angles wrote (kps_dev is still what the orientation
+ * check of robust.cc:283-287 is defined on: the two hold the same values; angles_dev == NULL reads the records). */
+int svgpu_match_consecutive_batch_device_angles(svgpu_ctx* ctx, int frames, const uint8_t* desc_dev, const svgpu_keypoint* kps_dev,
+                                                const float* angles_dev, const int32_t* n_dev, int cap, int n_stride, const uint8_t* valid_dev,
+                                                float lowe_ratio, int check_orientation, int32_t* matched_dev, int32_t* num_dev, void* stream);
 
 typedef enum svgpu_match_mode {
     SVGPU_MATCH_BEST_ONLY = 0,        /* projection::match_current_and_last_frames (match/projection.cc:95-207) */

@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
                                                   const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
                                                   const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
                                                   const uint8_t* __restrict__ blur, size_t blur_frame_bytes,
-                                                  svgpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap) {
+                                                  svgpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap, float* __restrict__ angles) {
     __shared__ __attribute__((aligned(16))) uint8_t s_slab[4][DESC_SLAB];
     int b, blk;
     xcd_frame_map(gridDim.x, gridDim.y, blk, b);
@@ -1151,6 +1151,7 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
         k.octave = lv;
         k.class_id = -1;
         kps[(size_t)b * cap + i0 + lane] = k;
+        if (angles) angles[(size_t)b * cap + i0 + lane] = angle;  // the packed copy the batched matcher's angle-bin sort reads (4 instead of 28 bytes per keypoint)
     }
 }
 
@@ -1219,8 +1220,8 @@ void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, uns
 void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
                         const int32_t* counts, const uint8_t* img0, size_t img0_frame_stride, int img0_pitch,
                         const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur, size_t blur_frame_bytes,
-                        svgpu_keypoint* kps, uint8_t* desc, int cap, int batch) {
+                        svgpu_keypoint* kps, uint8_t* desc, int cap, int batch, float* angles) {
     if (total_grid == 0) return;
     hipLaunchKernelGGL(k_describe, dim3((total_grid + 4 * DESC_KPW - 1) / (4 * DESC_KPW), batch), dim3(256), 0, s, levels, num_levels, sel, total_grid,
-                       counts, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, kps, desc, cap);
+                       counts, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, kps, desc, cap, angles);
 }

@@ -270,4 +270,4 @@ void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, uns
 void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
                         const int32_t* counts, const uint8_t* img0, size_t img0_frame_stride, int img0_pitch,
                         const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur, size_t blur_frame_bytes,
-                        svgpu_keypoint* kps, uint8_t* desc, int cap, int batch);
+                        svgpu_keypoint* kps, uint8_t* desc, int cap, int batch, float* angles);

@@ -55,7 +55,7 @@ namespace {
 int bf_batch_device(svgpu_ctx* ctx, int pairs, int ring1, const uint8_t* desc1_dev, const svgpu_keypoint* kps1_dev, const int32_t* n1_dev,
                     int cap1, const uint8_t* desc2_dev, const svgpu_keypoint* kps2_dev, const int32_t* n2_dev, int cap2, int n_stride,
                     const uint8_t* valid2_dev, float lowe_ratio, int check_orientation, int32_t* matched_dev, int32_t* num_dev,
-                    void* stream) {
+                    void* stream, const float* angles1_dev = nullptr, const float* angles2_dev = nullptr) {
     if (!ctx || pairs < 1 || !desc1_dev || !kps1_dev || !n1_dev || !desc2_dev || !kps2_dev || !n2_dev || cap1 < 1 || cap2 < 1
         || cap1 > 65535 || cap2 > 65535 || !matched_dev || !num_dev)
         return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_bruteforce_batch_device: bad arguments");
@@ -68,9 +68,16 @@ int bf_batch_device(svgpu_ctx* ctx, int pairs, int ring1, const uint8_t* desc1_d
     BfProblem P{};
     P.desc1 = (const uint32_t*)desc1_dev;
     P.desc2 = (const uint32_t*)desc2_dev;
-    P.angle1 = &kps1_dev->angle;
-    P.angle2 = &kps2_dev->angle;
-    P.angle_stride = sizeof(svgpu_keypoint) / sizeof(float);
+    if (angles1_dev && angles2_dev) {  // packed copies (svgpu_orb_extract_batch_device_angles): 4 bytes per keypoint instead of a 28-byte stride
+        P.angle1 = angles1_dev;
+        P.angle2 = angles2_dev;
+        P.angle_stride = 1;
+    }
+    else {
+        P.angle1 = &kps1_dev->angle;
+        P.angle2 = &kps2_dev->angle;
+        P.angle_stride = sizeof(svgpu_keypoint) / sizeof(float);
+    }
     P.n1_dev = n1_dev;
     P.n2_dev = n2_dev;
     P.n_stride = n_stride;
@@ -111,6 +118,14 @@ int svgpu_match_consecutive_batch_device(svgpu_ctx* ctx, int frames, const uint8
     if (frames < 2) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_consecutive_batch_device: needs at least two frames");
     return bf_batch_device(ctx, frames, frames, desc_dev, kps_dev, n_dev, cap, desc_dev, kps_dev, n_dev, cap, n_stride, valid_dev, lowe_ratio,
                            check_orientation, matched_dev, num_dev, stream);
+}
+
+int svgpu_match_consecutive_batch_device_angles(svgpu_ctx* ctx, int frames, const uint8_t* desc_dev, const svgpu_keypoint* kps_dev, const float* angles_dev,
+                                                const int32_t* n_dev, int cap, int n_stride, const uint8_t* valid_dev, float lowe_ratio,
+                                                int check_orientation, int32_t* matched_dev, int32_t* num_dev, void* stream) {
+    if (frames < 2) return sv_set_error(ctx, SVGPU_ERR_INVALID, "svgpu_match_consecutive_batch_device: needs at least two frames");
+    return bf_batch_device(ctx, frames, frames, desc_dev, kps_dev, n_dev, cap, desc_dev, kps_dev, n_dev, cap, n_stride, valid_dev, lowe_ratio,
+                           check_orientation, matched_dev, num_dev, stream, angles_dev, angles_dev);
 }
 
 int svgpu_match_bruteforce(svgpu_ctx* ctx, const uint8_t* desc1, const float* angle1, int n1, const uint8_t* desc2,

@@ -387,6 +387,14 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
                                    int row_stride, const uint8_t* mask_dev, size_t mask_frame_stride,
                                    int mask_row_stride, svgpu_keypoint* kps_dev, uint8_t* desc_dev, int cap,
                                    int32_t* counts_dev, void* stream) {
+    return svgpu_orb_extract_batch_device_angles(ctx, imgs_dev, batch, frame_stride, row_stride, mask_dev, mask_frame_stride, mask_row_stride, kps_dev, desc_dev, cap,
+                                                 counts_dev, nullptr, stream);
+}
+
+int svgpu_orb_extract_batch_device_angles(svgpu_ctx* ctx, const uint8_t* imgs_dev, int batch, size_t frame_stride,
+                                          int row_stride, const uint8_t* mask_dev, size_t mask_frame_stride,
+                                          int mask_row_stride, svgpu_keypoint* kps_dev, uint8_t* desc_dev, int cap,
+                                          int32_t* counts_dev, float* angles_dev, void* stream) {
     if (!ctx) return SVGPU_ERR_INVALID;
     OrbConfig& C = ctx->orb;
     if (!C.configured) return sv_set_error(ctx, SVGPU_ERR_NOT_CONFIGURED, "svgpu_orb_configure has not been called");
@@ -439,7 +447,7 @@ int svgpu_orb_extract_batch_device(svgpu_ctx* ctx, const uint8_t* imgs_dev, int 
     ctx->stage_recorded = true;
     SvProfScope ps(ctx, s, "k_describe");
     sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
-                       ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch);
+                       ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch, angles_dev);
     SV_HIP(ctx, hipGetLastError());
     ctx->last_batch = batch;
     ctx->last_imgs = imgs_dev;

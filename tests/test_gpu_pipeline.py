@@ -64,6 +64,22 @@ def test_batch_extract_then_ring_match_equals_oracle(priority):
         n = cnt[t, 0]
         assert n == len(ko) and np.array_equal(cnt[t, 1:], lv)
         assert np.array_equal(k_all[t, :n], ko) and np.array_equal(d_all[t, :n], do)
+    # the packed-angle forms: the extractor leaves the angles as a float array beside the records (the same values), the ring matcher reads that
+    angles = torch.full((B * cap,), -1.0, dtype=torch.float32, device="cuda")
+    kps2, desc2, counts2 = torch.zeros_like(kps), torch.zeros_like(desc), torch.zeros_like(counts)
+    matched.fill_(-7)
+    ctx.check(L.svgpu_orb_extract_batch_device_angles(ctx.handle, C.c_void_p(frames.data_ptr()), B, C.c_size_t(W * H), W, None, C.c_size_t(0), 0,
+                                                      C.c_void_p(kps2.data_ptr()), C.c_void_p(desc2.data_ptr()), cap, C.c_void_p(counts2.data_ptr()),
+                                                      C.c_void_p(angles.data_ptr()), None), "extract + angles")
+    ctx.check(L.svgpu_match_consecutive_batch_device_angles(ctx.handle, B, C.c_void_p(desc2.data_ptr()), C.c_void_p(kps2.data_ptr()), C.c_void_p(angles.data_ptr()),
+                                                            C.c_void_p(counts2.data_ptr()), cap, nc, None, C.c_float(0.8), 1,
+                                                            C.c_void_p(matched.data_ptr()), C.c_void_p(nmatch.data_ptr()), None), "ring match, packed angles")
+    ctx.synchronize()
+    packed_matched, packed_n = matched.cpu().numpy().reshape(B, cap).copy(), nmatch.cpu().numpy().copy()
+    assert torch.equal(kps2[: B * cap * 28], kps[: B * cap * 28]) and torch.equal(desc2[: B * cap * 32], desc[: B * cap * 32])
+    ang = angles.cpu().numpy().reshape(B, cap)
+    for t in range(B):
+        assert np.array_equal(ang[t, :cnt[t, 0]], k_all[t, :cnt[t, 0]]["angle"])
     for t in range(B):
         f, kf = (t + 1) % B, t
         exp = O.brute_force_match(ref[f][1], ref[f][0]["angle"], ref[kf][1], ref[kf][0]["angle"], None, 0.8, True)
@@ -71,6 +87,7 @@ def test_batch_extract_then_ring_match_equals_oracle(priority):
         assert (exp >= 0).sum() > (600 if f == kf + 1 else 50)
         assert np.array_equal(ring_matched[t, :n1], exp) and ring_n[t] == (exp >= 0).sum(), t
         assert np.array_equal(two_matched[t, :n1], exp) and two_n[t] == ring_n[t], t
+        assert np.array_equal(packed_matched[t, :n1], exp) and packed_n[t] == ring_n[t], t
 
 
 def test_opt_in_paths_keep_parity_in_a_fresh_process():
