@@ -288,7 +288,9 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if (!team_sized) return 1;
         const char* ev = std::getenv("SVGPU_BA_HOST_THREADS");
         const int v = ev ? std::atoi(ev) : 8;  // (config 5: 1.28 ms with 4 threads, 0.69 with 8, flat beyond)
-        return v < 1 ? 1 : (v > 16 ? 16 : v);
+        const unsigned hw = std::thread::hardware_concurrency();  // (the team spins at its barriers: never more threads than cores)
+        const int cap = hw == 0 ? 16 : (int)std::min(16u, hw);
+        return v < 1 ? 1 : (v > cap ? cap : v);
     }();
     // The host team of a global-BA sized call: nth threads (this one included) scan the observation indices -- range check, "already grouped
     // by landmark?" (the order local_bundle_adjuster_g2o.cc:168-227 and global_bundle_adjuster.cc:66-118 create their edges in) and,
