@@ -10,6 +10,7 @@
 // operation order with contraction disabled (-ffp-contract=off, checked in the disassembly).
 #include "svgpu_internal.h"
 #include <cstdlib>
+#include <utility>
 
 #pragma clang fp contract(off)
 
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
 // One block per frame: walk the selection grids level by level in cell-index order, compact the
 // non-empty cells (this IS the output order of distribute_keypoints + extract), clear the keys.
 __global__ __launch_bounds__(1024) void k_select(const OrbLevel* __restrict__ L, int num_levels, unsigned long long* __restrict__ keys,
-                                                 int total_grid, int4* __restrict__ sel, int32_t* __restrict__ counts) {
+                                                 int total_grid, int4* __restrict__ sel, int32_t* __restrict__ counts, int32_t* __restrict__ cellpos) {
     __shared__ int s_wave[16], s_lvcnt[SV_MAX_LEVELS];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long* K = keys + (size_t)b * total_grid;
@@ -856,6 +857,8 @@ __global__ __launch_bounds__(1024) void k_select(const OrbLevel* __restrict__ L,
             if (k < wave) woff += s_wave[k];
             total += s_wave[k];
         }
+        // position of every grid cell in the emission order (= keypoints in the cells before it): k_describe_bands finds the run of a band with it
+        if (cellpos && idx < total_grid) cellpos[(size_t)b * (total_grid + 1) + idx] = running + woff + before;
         if (key) {
             int lv = 0;
             while (lv + 1 < num_levels && idx >= L[lv + 1].grid_first) ++lv;
@@ -875,7 +878,10 @@ __global__ __launch_bounds__(1024) void k_select(const OrbLevel* __restrict__ L,
     }
     __syncthreads();
     if (tid < num_levels) counts[b * (1 + num_levels) + 1 + tid] = s_lvcnt[tid];
-    if (tid == 0) counts[b * (1 + num_levels)] = running;
+    if (tid == 0) {
+        counts[b * (1 + num_levels)] = running;
+        if (cellpos) cellpos[(size_t)b * (total_grid + 1) + total_grid] = running;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ describe
@@ -1155,6 +1161,211 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
     }
 }
 
+
+// ---- orientation + descriptors from LDS-resident BANDS (round 6).  Measured on MI355X (profiles/r06_ubench_tcp_patterns.json,
+// tools/pmc_kernel.sh): the per-keypoint patch fetches of k_describe above are bound by the vector-memory front end -- a wave-level
+// load whose lanes touch 16-32 different image rows costs 28-100 cycles in the TA / TCP whatever its width, and every 32-48-byte
+// patch row pulls a whole 128-byte line from L2 (4.5 cycles each): 300 cycles per keypoint per CU, of which the arithmetic is 110.
+// LDS-DMA per patch (global_load_lds_dwordx4 into a per-wave ring, built and measured: 1.39 ms against 1.20) does not change that count.
+// So the image goes to LDS in full rows instead, once per group of neighbouring keypoints:
+//   * a BAND = a few consecutive rows of the selection grid of one level (svgpu_orb.hip builds the table); its keypoints are one
+//     contiguous run of the selection order (k_select writes every cell's position), its pixels the level's rows
+//     [y_min - 18, y_max + 18], full width: one workgroup of 8 waves copies them with 1 KB `global_load_lds_dwordx4` instructions
+//     (lane-linear: LDS pitch = 16 x pieces per row, chosen = 32 mod 64 so that eight rows of dword reads hit 64 different banks);
+//   * phase U: un-blurred rows -> moments of every keypoint of the band (three accumulating v_dot4_u32_u8 per dword), one wave per
+//     keypoint, results to LDS;  phase A: thread t computes keypoint t's orientation / cos / sin / record (lane-parallel: the chain
+//     runs once per 64 keypoints) while the blurred rows replace the un-blurred ones;  phase B: rotated BRIEF, one wave per keypoint,
+//     byte gathers straight from the band.
+// Same arithmetic as k_describe (orb_impl.cc:68-154); k_describe stays for configurations whose bands do not fit (very wide images).
+#define DB_THREADS 512
+#define DB_WAVES (DB_THREADS / 64)
+#define DB_MAX_KP 128  // keypoints per band (svgpu_orb.hip keeps bands below it): phase A gives each keypoint one thread of waves 0-1
+struct IcWeights3 {
+    uint32_t w1[256], wu[256], wv[256];  // per (row, dword) item: disc mask bytes, (u + 15) x mask, (v + 15) x mask
+};
+constexpr IcWeights3 make_ic_weights3() {
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // orb_impl.cc:51-66
+    IcWeights3 t{};
+    for (int row = 0; row < 31; ++row)
+        for (int j = 0; j < 8; ++j) {
+            uint32_t w1 = 0, wu = 0, wv = 0;
+            const int v = row - 15, av = v < 0 ? -v : v;
+            for (int k = 0; k < 4; ++k) {
+                const int col = 4 * j + k, u = col - 15, au = u < 0 ? -u : u;
+                if (col < 31 && au <= umax[av]) {
+                    w1 |= 1u << (8 * k);
+                    wu |= (uint32_t)(u + 15) << (8 * k);
+                    wv |= (uint32_t)row << (8 * k);
+                }
+            }
+            t.w1[row * 8 + j] = w1;
+            t.wu[row * 8 + j] = wu;
+            t.wv[row * 8 + j] = wv;
+        }
+    return t;
+}
+__device__ __constant__ IcWeights3 c_icw3 = make_ic_weights3();
+
+// one LDS-DMA instruction: lane i copies the 16 bytes at base + voff[i] (any byte address: profiles/r06_ubench_glds.json) to LDS byte
+// lds_dst + 16 i.  M0 carries the LDS address and is written in the statement that reads it (the compiler does not preserve it); the two
+// moves + s_nop 2 are also the five wait states a VMEM instruction needs behind a VALU instruction that produced its scalar base
+// (hipcc does not look for hazards inside an asm statement).
+__device__ __forceinline__ void sv_glds16(unsigned long long base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
+// rows [y0, y0 + nrows) of an image (row pitch gp, any alignment) -> LDS at lds0 with row pitch 16 * cpr, by the whole workgroup:
+// piece q = row * cpr + c goes to LDS byte 16 q; instruction i of the band covers pieces [64 i, 64 i + 64), wave w takes i = w, w + 8, ...
+__device__ __forceinline__ void db_stage_rows(const uint8_t* img, int gp, int y0, int nrows, int cpr, uint32_t lds0, int lane, int wave) {
+    const int total = nrows * cpr;
+    int q = wave * 64 + lane;
+    int row = q / cpr, c = q - row * cpr;
+    const int drow = (DB_WAVES * 64) / cpr, dc = (DB_WAVES * 64) - drow * cpr;
+    const unsigned long long base = (unsigned long long)(uintptr_t)(img + (size_t)y0 * gp);
+    uint32_t dst = lds0 + wave * 1024;
+    for (int i = wave * 64; i < total; i += DB_WAVES * 64) {  // wave-uniform trip count
+        if (q < total) sv_glds16(base, (uint32_t)(row * gp + c * 16), dst);
+        q += DB_WAVES * 64;
+        row += drow;
+        c += dc;
+        if (c >= cpr) {
+            c -= cpr;
+            ++row;
+        }
+        dst += DB_WAVES * 1024;
+    }
+}
+
+__global__ __launch_bounds__(DB_THREADS) void k_describe_bands(const OrbLevel* __restrict__ L, int num_levels, const DescBand* __restrict__ bands, int num_bands,
+                                                               const int4* __restrict__ sel, int total_grid, const int32_t* __restrict__ cellpos,
+                                                               const int32_t* __restrict__ counts,
+                                                               const uint8_t* __restrict__ img0, size_t img0_frame_stride, int img0_pitch,
+                                                               const uint8_t* __restrict__ pyr, size_t pyr_frame_bytes,
+                                                               const uint8_t* __restrict__ blur, size_t blur_frame_bytes,
+                                                               svgpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc, int cap, float* __restrict__ angles) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_band[];  // the band's rows; behind them the per-keypoint arrays
+    int b, bi;
+    xcd_frame_map(gridDim.x, gridDim.y, bi, b);
+    const DescBand bd = bands[bi];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int32_t* const P = cellpos + (size_t)b * (total_grid + 1);
+    const int n = min(counts[b * (1 + num_levels)], cap);
+    const int p0 = P[bd.cell0], nkp = min(P[bd.cell1], n) - p0;  // the band's keypoints: selection entries [p0, p0 + nkp)
+    if (nkp <= 0) return;
+    const int lv = bd.lv, lp = bd.lp, cpr = lp >> 4;
+    int2* const s_xy = reinterpret_cast<int2*>(s_band + bd.img_bytes);  // (x, y) of keypoint j
+    int2* const s_aux = s_xy + DB_MAX_KP;                               // (m10, m01), later (cos, sin) as float bits
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)s_band);
+    const int4* const S = sel + (size_t)b * total_grid + p0;
+    int4 sv = make_int4(0, 0, 0, 0);
+    if (tid < nkp) {
+        sv = S[tid];
+        s_xy[tid] = make_int2(sv.x, sv.y);
+    }
+    // disc weights of this lane's (row, dword) items (lane = 8 * row + dword, four row groups); rBRIEF pattern of its four pairs
+    uint32_t w1[4], wu[4], wv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int item = lane + 64 * m;  // items 248..255 (patch row 31) carry zero weights
+        w1[m] = c_icw3.w1[item];
+        wu[m] = c_icw3.wu[item];
+        wv[m] = c_icw3.wv[item];
+    }
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float4 q = reinterpret_cast<const float4*>(c_pattern_f)[r * 64 + lane];
+        px0[r] = q.x;
+        py0[r] = q.y;
+        px1[r] = q.z;
+        py1[r] = q.w;
+    }
+    // ---- phase U: un-blurred rows -> LDS, moments (orb_impl.cc:68-91): m10 = SU - 15 S1, m01 = SV - 15 S1, exact integers
+    {
+        const uint8_t* img = lv == 0 ? img0 + (size_t)b * img0_frame_stride : pyr + (size_t)b * pyr_frame_bytes + L[lv].pyr_off;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the loads above are not counted against the DMA below
+        db_stage_rows(img, lv == 0 ? img0_pitch : L[lv].pitch, bd.yu0, bd.nru, cpr, lds0, lane, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    {
+        const int lane_off = (lane >> 3) * lp + 4 * (lane & 7), step = 8 * lp;
+        for (int j = wave; j < nkp; j += DB_WAVES) {
+            const int2 xy = s_xy[j];
+            const int x = __builtin_amdgcn_readfirstlane(xy.x), y = __builtin_amdgcn_readfirstlane(xy.y);
+            // the patch starts at any byte; misaligned ds_read_b32 is served several times slower by the LDS (SQ_LDS_IDX_ACTIVE: 17 cycles per
+            // LDS instruction with them), so: the two aligned dwords around each item (ds_read2_b32) + one v_alignbit
+            const int org = (y - 15 - bd.yu0) * lp + (x - 15);
+            const uint32_t* U = reinterpret_cast<const uint32_t*>(s_band + ((org & ~3) + lane_off));
+            const uint32_t sh = (org & 3) * 8;
+            uint32_t s1 = 0, su = 0, sw = 0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t lo = U[m * (step >> 2)], hi = U[m * (step >> 2) + 1];
+                const uint32_t px = __builtin_amdgcn_alignbit(hi, lo, sh);
+                s1 = __builtin_amdgcn_udot4(px, w1[m], s1, false);
+                su = __builtin_amdgcn_udot4(px, wu[m], su, false);
+                sw = __builtin_amdgcn_udot4(px, wv[m], sw, false);
+            }
+            const int m10 = wave_sum((int)su - __mul24(15, (int)s1)), m01 = wave_sum((int)sw - __mul24(15, (int)s1));
+            if (lane == 0) s_aux[j] = make_int2(m10, m01);
+        }
+    }
+    __syncthreads();  // every wave is done with the un-blurred rows; the moments are in LDS
+    // ---- phase A: blurred rows -> LDS (same region); meanwhile thread t: orientation, cos / sin and the record of keypoint t
+    db_stage_rows(blur + (size_t)b * blur_frame_bytes + L[lv].blur_off, L[lv].pitch, bd.yb0, bd.nrb, cpr, lds0, lane, wave);
+    if (tid < nkp) {
+        const int2 mm = s_aux[tid];
+        const float angle = dev_fast_atan2((float)mm.y, (float)mm.x);
+        const float rad = (float)((double)angle * 3.14159265358979323846 / 180.0);
+        s_aux[tid] = make_int2(__float_as_int(dev_util_cos(rad)), __float_as_int(dev_util_sin(rad)));
+        svgpu_keypoint k;
+        k.x = (float)sv.x;
+        k.y = (float)sv.y;
+        if (lv != 0) {  // correct_keypoint_scale (orb_extractor.cc:337-345)
+            k.x = k.x * L[lv].scale;
+            k.y = k.y * L[lv].scale;
+        }
+        k.size = L[lv].kp_size;
+        k.angle = angle;
+        k.response = (float)sv.w;
+        k.octave = lv;
+        k.class_id = -1;
+        kps[(size_t)b * cap + p0 + tid] = k;
+        if (angles) angles[(size_t)b * cap + p0 + tid] = angle;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- phase B: rotated BRIEF on the blurred rows (orb_impl.cc:93-154)
+    {
+        constexpr float RN = 12582912.0f;  // cvRound = round half to even: adding 1.5 * 2^23 leaves the integer in the low mantissa bits
+        const int rk = 0x400000 * lp + 0x4B400000;  // what the biased (row, column) pair adds to row * lp + column
+        for (int j = wave; j < nkp; j += DB_WAVES) {
+            const int2 xy = s_xy[j], cs2 = s_aux[j];
+            const int x = __builtin_amdgcn_readfirstlane(xy.x), y = __builtin_amdgcn_readfirstlane(xy.y);
+            const float ca = __int_as_float(__builtin_amdgcn_readfirstlane(cs2.x)), sa = __int_as_float(__builtin_amdgcn_readfirstlane(cs2.y));
+            const uint8_t* B = s_band + ((y - bd.yb0) * lp + x - rk);
+            unsigned long long bits[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 sc = {sa, ca}, cs = {ca, -sa}, rn = {RN, RN};
+                const f32x2 q0 = (f32x2{px0[r], px0[r]} * sc + f32x2{py0[r], py0[r]} * cs) + rn;  // (x sa + y ca, x ca - y sa)
+                const f32x2 q1 = (f32x2{px1[r], px1[r]} * sc + f32x2{py1[r], py1[r]} * cs) + rn;
+                const int a = B[__mul24(__float_as_int(q0.x), lp) + __float_as_int(q0.y)];
+                const int bb = B[__mul24(__float_as_int(q1.x), lp) + __float_as_int(q1.y)];
+                bits[r] = __builtin_amdgcn_ballot_w64(a < bb);
+            }
+            uint8_t* D = desc + ((size_t)b * cap + p0 + j) * 32;
+            if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1213,8 +1424,8 @@ void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const
 }
 
 void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,
-                      int4* sel, int32_t* counts, int batch) {
-    hipLaunchKernelGGL(k_select, dim3(batch), dim3(1024), 0, s, levels, num_levels, keys, total_grid, sel, counts);
+                      int4* sel, int32_t* counts, int32_t* cellpos, int batch) {
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(1024), 0, s, levels, num_levels, keys, total_grid, sel, counts, cellpos);
 }
 
 void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
@@ -1224,4 +1435,16 @@ void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, c
     if (total_grid == 0) return;
     hipLaunchKernelGGL(k_describe, dim3((total_grid + 4 * DESC_KPW - 1) / (4 * DESC_KPW), batch), dim3(256), 0, s, levels, num_levels, sel, total_grid,
                        counts, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, kps, desc, cap, angles);
+}
+
+hipError_t sv_describe_bands_prepare(size_t lds_bytes) {  // once per device: allow the band kernel its dynamic LDS
+    return sv_allow_dynamic_lds(reinterpret_cast<const void*>(k_describe_bands), lds_bytes);
+}
+void sv_launch_describe_bands(hipStream_t s, const OrbLevel* levels, int num_levels, const DescBand* bands, int num_bands, size_t lds_bytes,
+                              const int4* sel, int total_grid, const int32_t* cellpos, const int32_t* counts, const uint8_t* img0,
+                              size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur,
+                              size_t blur_frame_bytes, svgpu_keypoint* kps, uint8_t* desc, int cap, int batch, float* angles) {
+    if (num_bands == 0) return;
+    hipLaunchKernelGGL(k_describe_bands, dim3(num_bands, batch), dim3(DB_THREADS), lds_bytes, s, levels, num_levels, bands, num_bands, sel, total_grid,
+                       cellpos, counts, img0, img0_frame_stride, img0_pitch, pyr, pyr_frame_bytes, blur, blur_frame_bytes, kps, desc, cap, angles);
 }

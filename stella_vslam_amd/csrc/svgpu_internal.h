@@ -50,6 +50,15 @@ struct FastCell {
     int order_base;      // (ci * num_cols + cj) << 14 : emission order prefix
 };
 
+// k_describe_bands: a band = consecutive rows of one level's selection grid whose pixels one workgroup stages in LDS (orb_kernels.hip)
+struct DescBand {
+    int cell0, cell1;  // selection-grid cells [cell0, cell1) (indices into the per-frame key / position arrays)
+    int img_bytes;     // LDS bytes of the staged rows (the larger of the two phases), a multiple of 16
+    short lv, lp;      // level; LDS row pitch (multiple of 16, = 32 mod 64)
+    short yu0, nru;    // un-blurred rows [yu0, yu0 + nru)  (every keypoint's y - 15 .. y + 16)
+    short yb0, nrb;    // blurred rows    [yb0, yb0 + nrb)  (every keypoint's y - 18 .. y + 18)
+};
+
 struct OrbConfig {
     int width = 0, height = 0, max_batch = 0, num_levels = 0;
     float scale_factor = 0;
@@ -62,6 +71,8 @@ struct OrbConfig {
     int total_btiles = 0;
     int blur_rows = BLUR_ROWS;  // rows per k_blur thread (BLUR_ROWS, or BLUR_ROWS_SMALL for a context of a few frames)
     size_t pyr_frame_bytes = 0, blur_frame_bytes = 0;
+    std::vector<DescBand> dbands;  // empty: the configuration does not fit the band kernel, k_describe takes it
+    size_t dband_lds_bytes = 0;    // dynamic LDS of k_describe_bands
     bool configured = false;
 };
 
@@ -182,6 +193,8 @@ struct svgpu_ctx {
     uint8_t* d_blur = nullptr;      // max_batch * blur_frame_bytes
     unsigned long long* d_keys = nullptr;  // max_batch * total_grid
     int4* d_sel = nullptr;          // max_batch * total_grid  (x, y, level, response)
+    int32_t* d_cellpos = nullptr;   // max_batch * (total_grid + 1): emission position of every selection-grid cell
+    DescBand* d_dbands = nullptr;
     // staging for the host-buffer entry points
     uint8_t* d_img = nullptr;
     uint8_t* d_mask = nullptr;
@@ -266,7 +279,12 @@ void sv_launch_fast(hipStream_t s, const OrbLevel* levels, int num_levels, const
                     int ini_thr, int min_thr, const uint8_t* mask, size_t mask_frame_stride, int mask_pitch, int mask_w,
                     int mask_h, int batch);
 void sv_launch_select(hipStream_t s, const OrbLevel* levels, int num_levels, unsigned long long* keys, int total_grid,
-                      int4* sel, int32_t* counts, int batch);
+                      int4* sel, int32_t* counts, int32_t* cellpos, int batch);
+hipError_t sv_describe_bands_prepare(size_t lds_bytes);
+void sv_launch_describe_bands(hipStream_t s, const OrbLevel* levels, int num_levels, const DescBand* bands, int num_bands, size_t lds_bytes,
+                              const int4* sel, int total_grid, const int32_t* cellpos, const int32_t* counts, const uint8_t* img0,
+                              size_t img0_frame_stride, int img0_pitch, const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur,
+                              size_t blur_frame_bytes, svgpu_keypoint* kps, uint8_t* desc, int cap, int batch, float* angles);
 void sv_launch_describe(hipStream_t s, const OrbLevel* levels, int num_levels, const int4* sel, int total_grid,
                         const int32_t* counts, const uint8_t* img0, size_t img0_frame_stride, int img0_pitch,
                         const uint8_t* pyr, size_t pyr_frame_bytes, const uint8_t* blur, size_t blur_frame_bytes,

@@ -58,6 +58,8 @@ void sv_orb_release(svgpu_ctx* ctx) {
     free_dev(ctx->d_blur);
     free_dev(ctx->d_keys);
     free_dev(ctx->d_sel);
+    free_dev(ctx->d_cellpos);
+    free_dev(ctx->d_dbands);
     free_dev(ctx->d_img);
     free_dev(ctx->d_mask);
     free_dev(ctx->d_kps);
@@ -118,6 +120,7 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     bool xg_ok = true;          // false: a level shrinks by more than 3x, the byte windows of the records do not fit
     size_t pyr_off = 0, blur_off = 0;
     int grid_first = 0, btile_first = 0;
+    std::vector<std::pair<int, int>> grid_rows[SV_MAX_LEVELS];  // per level and selection-grid row: first / last level row its keypoints can lie on
     for (int l = 0; l < num_levels; ++l) {
         OrbLevel& L = C.levels[l];
         memset(&L, 0, sizeof(L));
@@ -253,9 +256,13 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
                 gtab.push_back((unsigned short)(ix < gx ? ix : gx - 1));
             }
             L.gtab_y_off = (int)gtab.size();
+            grid_rows[l].assign(gy, std::make_pair(1 << 30, -1));
             for (unsigned y = 0; y < rh; ++y) {
                 unsigned iy = (unsigned)((float)y / delta_y);
-                gtab.push_back((unsigned short)(iy < gy ? iy : gy - 1));
+                iy = iy < gy ? iy : gy - 1;
+                gtab.push_back((unsigned short)iy);
+                grid_rows[l][iy].first = std::min(grid_rows[l][iy].first, (int)(min_by + y));
+                grid_rows[l][iy].second = std::max(grid_rows[l][iy].second, (int)(min_by + y));
             }
             grid_first += (int)(gx * gy);
         }
@@ -263,6 +270,63 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     }
     C.total_grid = grid_first;
     C.total_btiles = btile_first;
+    // ---- bands of k_describe_bands: as many consecutive selection-grid rows of a level as fit the LDS budget (and DB_MAX_KP = 128 keypoints).
+    //      A keypoint of grid row g lies on level rows [first(g), last(g)]; its patches need rows y - 15 .. y + 16 (un-blurred; row y + 16 carries
+    //      zero weights but is read) and y - 18 .. y + 18 (blurred).  LDS pitch: the level width rounded up to 16-byte pieces, then to 32 mod 64
+    //      (eight rows of dword reads then fall into 64 different banks); pieces beyond the level's own pitch read the next row's first bytes.
+    {
+        C.dbands.clear();
+        C.dband_lds_bytes = 0;
+        size_t budget = 48 * 1024;  // three 512-thread workgroups per CU
+        if (const char* e = getenv("SVGPU_DESC_BAND_KB")) budget = (size_t)std::max(1, atoi(e)) * 1024;
+        const size_t hard_limit = 80 * 1024;  // two workgroups per CU; wider images than that take k_describe
+        bool ok = C.total_grid > 0 && getenv("SVGPU_DESCRIBE_LEGACY") == nullptr;
+        for (int l = 0; l < num_levels && ok; ++l) {
+            const OrbLevel& L = C.levels[l];
+            if (!L.has_cells) continue;
+            int lp = (L.w + 15) / 16 * 16;
+            while (lp % 64 != 32) lp += 16;
+            if (lp > 32000) ok = false;
+            const int gy = L.grid_y, gx = L.grid_x;
+            auto band_bytes = [&](int g0, int g1, DescBand* out) {  // rows of grid rows [g0, g1)
+                int y0 = 1 << 30, y1 = -1;
+                for (int g = g0; g < g1; ++g)
+                    if (grid_rows[l][g].second >= 0) {
+                        y0 = std::min(y0, grid_rows[l][g].first);
+                        y1 = std::max(y1, grid_rows[l][g].second);
+                    }
+                if (y1 < 0) y0 = y1 = SV_PATCH_RADIUS;  // (grid rows no level row maps to: no keypoints either)
+                const int nru = y1 - y0 + 32, nrb = y1 - y0 + 37;
+                const size_t bytes = (size_t)std::max(nru, nrb) * lp;
+                if (out) {
+                    out->lv = (short)l;
+                    out->lp = (short)lp;
+                    out->yu0 = (short)(y0 - 15);
+                    out->nru = (short)nru;
+                    out->yb0 = (short)(y0 - 18);
+                    out->nrb = (short)nrb;
+                    out->img_bytes = (int)bytes;
+                    out->cell0 = L.grid_first + g0 * gx;
+                    out->cell1 = L.grid_first + g1 * gx;
+                }
+                return bytes;
+            };
+            if (gx > 128) ok = false;
+            for (int g0 = 0; g0 < gy && ok;) {
+                int g1 = g0 + 1;
+                if (band_bytes(g0, g1, nullptr) > hard_limit) ok = false;
+                while (g1 < gy && (g1 + 1 - g0) * gx <= 128 && band_bytes(g0, g1 + 1, nullptr) <= budget) ++g1;
+                DescBand bd;
+                C.dband_lds_bytes = std::max(C.dband_lds_bytes, band_bytes(g0, g1, &bd));
+                C.dbands.push_back(bd);
+                g0 = g1;
+            }
+        }
+        if (!ok) C.dbands.clear();
+        // heaviest bands first (level 0 stages the most bytes per keypoint): the tail of the launch is made of the light ones
+        std::stable_sort(C.dbands.begin(), C.dbands.end(), [](const DescBand& a, const DescBand& b) { return a.img_bytes > b.img_bytes; });
+        if (!C.dbands.empty()) C.dband_lds_bytes += 2 * 128 * sizeof(int2);  // + the per-keypoint arrays (DB_MAX_KP)
+    }
     C.pyr_frame_bytes = pyr_off ? pyr_off : 256;
     C.blur_frame_bytes = blur_off;
 
@@ -357,9 +421,14 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
     if ((rc = upload(ctx, &ctx->d_xg, xg))) return rc;
     if ((rc = upload(ctx, &ctx->d_yrow, yrow))) return rc;
     if ((rc = upload(ctx, &ctx->d_gtab, gtab))) return rc;
+    if (!C.dbands.empty()) {
+        if ((rc = upload(ctx, &ctx->d_dbands, C.dbands))) return rc;
+        SV_HIP(ctx, sv_describe_bands_prepare(C.dband_lds_bytes));
+    }
     const size_t B = (size_t)max_batch, G = (size_t)(C.total_grid > 0 ? C.total_grid : 1);
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_pyr, B * C.pyr_frame_bytes + 256));
-    SV_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * C.blur_frame_bytes + 256));
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_blur, B * C.blur_frame_bytes + 4096));  // + slack: the band kernel's row pieces run past the last row's end
+    SV_HIP(ctx, hipMalloc((void**)&ctx->d_cellpos, B * (G + 1) * sizeof(int32_t)));
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_keys, B * G * sizeof(unsigned long long)));
     SV_HIP(ctx, hipMemset(ctx->d_keys, 0, B * G * sizeof(unsigned long long)));
     SV_HIP(ctx, hipMalloc((void**)&ctx->d_sel, (B * G + 8) * sizeof(int4)));  // + slack: k_describe reads whole groups of DESC_KPW entries
@@ -439,15 +508,20 @@ int svgpu_orb_extract_batch_device_angles(svgpu_ctx* ctx, const uint8_t* imgs_de
     // 4. ordered compaction (+ key reset for the next call)
     {
         SvProfScope ps(ctx, s, "k_select");
-        sv_launch_select(s, ctx->d_levels, Lc, ctx->d_keys, C.total_grid, ctx->d_sel, counts_dev, batch);
+        sv_launch_select(s, ctx->d_levels, Lc, ctx->d_keys, C.total_grid, ctx->d_sel, counts_dev, C.dbands.empty() ? nullptr : ctx->d_cellpos, batch);
     }
     // 5. orientation, descriptor, scale correction
     if (sb != s) SV_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     SV_HIP(ctx, hipEventRecord(ctx->ev_stage[1], s));
     ctx->stage_recorded = true;
     SvProfScope ps(ctx, s, "k_describe");
-    sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
-                       ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch, angles_dev);
+    if (!C.dbands.empty())
+        sv_launch_describe_bands(s, ctx->d_levels, Lc, ctx->d_dbands, (int)C.dbands.size(), C.dband_lds_bytes, ctx->d_sel, C.total_grid, ctx->d_cellpos,
+                                 counts_dev, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes,
+                                 kps_dev, desc_dev, cap, batch, angles_dev);
+    else
+        sv_launch_describe(s, ctx->d_levels, Lc, ctx->d_sel, C.total_grid, counts_dev, imgs_dev, frame_stride, row_stride,
+                           ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes, kps_dev, desc_dev, cap, batch, angles_dev);
     SV_HIP(ctx, hipGetLastError());
     ctx->last_batch = batch;
     ctx->last_imgs = imgs_dev;
