@@ -1177,7 +1177,9 @@ __global__ __launch_bounds__(256) void k_describe(const OrbLevel* __restrict__ L
 //     runs once per 64 keypoints) while the blurred rows replace the un-blurred ones;  phase B: rotated BRIEF, one wave per keypoint,
 //     byte gathers straight from the band.
 // Same arithmetic as k_describe (orb_impl.cc:68-154); k_describe stays for configurations whose bands do not fit (very wide images).
+#ifndef DB_THREADS
 #define DB_THREADS 512
+#endif
 #define DB_WAVES (DB_THREADS / 64)
 #define DB_MAX_KP 128  // keypoints per band (svgpu_orb.hip keeps bands below it): phase A gives each keypoint one thread of waves 0-1
 struct IcWeights3 {
@@ -1206,6 +1208,18 @@ constexpr IcWeights3 make_ic_weights3() {
 }
 __device__ __constant__ IcWeights3 c_icw3 = make_ic_weights3();
 
+// v_writelane_b32 has no builtin in this compiler.  gfx950 wants two wait states between a VALU instruction that writes an SGPR / VCC
+// (v_cmp, v_readlane) and a VALU instruction that reads it; hipcc inserts them for its own instructions but does not look inside an asm
+// statement, so the statement opens with s_nop 1 (without it the lanes written right behind a v_cmp took the OLD mask).
+template <int LANE>
+__device__ __forceinline__ void sv_writelane8(uint32_t& lo, uint32_t& hi, const unsigned long long (&m)[4]) {  // (lo, hi)[LANE + r] = m[r], r = 0..3
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\tv_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+        "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\tv_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)m[0]), "s"((uint32_t)(m[0] >> 32)), "s"((uint32_t)m[1]), "s"((uint32_t)(m[1] >> 32)), "s"((uint32_t)m[2]), "s"((uint32_t)(m[2] >> 32)),
+          "s"((uint32_t)m[3]), "s"((uint32_t)(m[3] >> 32)), "n"(LANE), "n"(LANE + 1), "n"(LANE + 2), "n"(LANE + 3));
+}
+
 // one LDS-DMA instruction: lane i copies the 16 bytes at base + voff[i] (any byte address: profiles/r06_ubench_glds.json) to LDS byte
 // lds_dst + 16 i.  M0 carries the LDS address and is written in the statement that reads it (the compiler does not preserve it); the two
 // moves + s_nop 2 are also the five wait states a VMEM instruction needs behind a VALU instruction that produced its scalar base
@@ -1218,9 +1232,23 @@ __device__ __forceinline__ void sv_glds16(unsigned long long base, uint32_t voff
                  : "memory");
 }
 
-// rows [y0, y0 + nrows) of an image (row pitch gp, any alignment) -> LDS at lds0 with row pitch 16 * cpr, by the whole workgroup:
-// piece q = row * cpr + c goes to LDS byte 16 q; instruction i of the band covers pieces [64 i, 64 i + 64), wave w takes i = w, w + 8, ...
+// rows [y0, y0 + nrows) of an image (row pitch gp, any alignment) -> LDS at lds0 with row pitch 16 * cpr, by the whole workgroup.
+// An instruction carries `rpi` = 64 / cpr whole rows (lane = row_in_group * cpr + piece, so that LDS byte 16 * lane continues the linear
+// image; the lanes behind rpi * cpr rest): the lane's source offset is loop-invariant and the group's base address advances in scalar
+// registers -- no vector instruction per DMA.  Wave w takes the row groups w, w + 8, ...  (Rows wider than 1 KB: see db_stage_rows_wide.)
 __device__ __forceinline__ void db_stage_rows(const uint8_t* img, int gp, int y0, int nrows, int cpr, uint32_t lds0, int lane, int wave) {
+    const int rpi = 64 / cpr;                       // rows per instruction (>= 1: cpr <= 64)
+    const int rsub = lane / cpr, csub = lane - rsub * cpr;
+    const uint32_t voff = (uint32_t)(rsub * gp + csub * 16);
+    const int groups = (nrows + rpi - 1) / rpi;
+    const unsigned long long base = (unsigned long long)(uintptr_t)(img + (size_t)y0 * gp);
+    if (rsub < rpi)  // (rows beyond nrows in the last group: a few more rows of the level, inside the buffers; their LDS rows are allocated)
+        for (int g = wave; g < groups; g += DB_WAVES)
+            sv_glds16(base + (unsigned long long)(g * rpi) * (unsigned)gp, voff, lds0 + (uint32_t)(g * rpi * cpr) * 16);
+}
+// the general form (pieces of a row spread over several instructions): piece q = row * cpr + c goes to LDS byte 16 q, instruction i covers
+// pieces [64 i, 64 i + 64)
+__device__ __forceinline__ void db_stage_rows_wide(const uint8_t* img, int gp, int y0, int nrows, int cpr, uint32_t lds0, int lane, int wave) {
     const int total = nrows * cpr;
     int q = wave * 64 + lane;
     int row = q / cpr, c = q - row * cpr;
@@ -1288,7 +1316,8 @@ __global__ __launch_bounds__(DB_THREADS) void k_describe_bands(const OrbLevel* _
     {
         const uint8_t* img = lv == 0 ? img0 + (size_t)b * img0_frame_stride : pyr + (size_t)b * pyr_frame_bytes + L[lv].pyr_off;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the loads above are not counted against the DMA below
-        db_stage_rows(img, lv == 0 ? img0_pitch : L[lv].pitch, bd.yu0, bd.nru, cpr, lds0, lane, wave);
+        if (cpr <= 64) db_stage_rows(img, lv == 0 ? img0_pitch : L[lv].pitch, bd.yu0, bd.nru, cpr, lds0, lane, wave);
+        else db_stage_rows_wide(img, lv == 0 ? img0_pitch : L[lv].pitch, bd.yu0, bd.nru, cpr, lds0, lane, wave);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -1317,7 +1346,8 @@ __global__ __launch_bounds__(DB_THREADS) void k_describe_bands(const OrbLevel* _
     }
     __syncthreads();  // every wave is done with the un-blurred rows; the moments are in LDS
     // ---- phase A: blurred rows -> LDS (same region); meanwhile thread t: orientation, cos / sin and the record of keypoint t
-    db_stage_rows(blur + (size_t)b * blur_frame_bytes + L[lv].blur_off, L[lv].pitch, bd.yb0, bd.nrb, cpr, lds0, lane, wave);
+    if (cpr <= 64) db_stage_rows(blur + (size_t)b * blur_frame_bytes + L[lv].blur_off, L[lv].pitch, bd.yb0, bd.nrb, cpr, lds0, lane, wave);
+    else db_stage_rows_wide(blur + (size_t)b * blur_frame_bytes + L[lv].blur_off, L[lv].pitch, bd.yb0, bd.nrb, cpr, lds0, lane, wave);
     if (tid < nkp) {
         const int2 mm = s_aux[tid];
         const float angle = dev_fast_atan2((float)mm.y, (float)mm.x);
@@ -1360,8 +1390,9 @@ __global__ __launch_bounds__(DB_THREADS) void k_describe_bands(const OrbLevel* _
                 const int bb = B[__mul24(__float_as_int(q1.x), lp) + __float_as_int(q1.y)];
                 bits[r] = __builtin_amdgcn_ballot_w64(a < bb);
             }
-            uint8_t* D = desc + ((size_t)b * cap + p0 + j) * 32;
-            if (lane < 4) reinterpret_cast<unsigned long long*>(D)[lane] = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            uint32_t d_lo = 0, d_hi = 0;  // lane r: bits 64 r .. 64 r + 63
+            sv_writelane8<0>(d_lo, d_hi, bits);
+            if (lane < 4) reinterpret_cast<uint2*>(desc + ((size_t)b * cap + p0 + j) * 32)[lane] = make_uint2(d_lo, d_hi);
         }
     }
 }

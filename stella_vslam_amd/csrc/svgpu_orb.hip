@@ -297,7 +297,8 @@ int svgpu_orb_configure(svgpu_ctx* ctx, int width, int height, int max_batch, fl
                     }
                 if (y1 < 0) y0 = y1 = SV_PATCH_RADIUS;  // (grid rows no level row maps to: no keypoints either)
                 const int nru = y1 - y0 + 32, nrb = y1 - y0 + 37;
-                const size_t bytes = (size_t)std::max(nru, nrb) * lp;
+                const int rpi = std::max(1, 64 / (lp / 16));  // a staging instruction carries whole groups of rpi rows: room for the last group
+                const size_t bytes = (size_t)((std::max(nru, nrb) + rpi - 1) / rpi * rpi) * lp;
                 if (out) {
                     out->lv = (short)l;
                     out->lp = (short)lp;
