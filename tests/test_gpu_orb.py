@@ -173,3 +173,60 @@ def test_two_extractors_on_two_threads(F):
         t.join()
     for i in range(2):
         _assert_same(out[i][0], out[i][1], ref[i][0], ref[i][1])
+
+
+def _batch_extract(F, frames, stride_pad=0, cap=None, legacy=False):
+    """svgpu_orb_extract_batch_device on device-resident frames with row stride w + stride_pad; returns per-frame records, descriptors, counts."""
+    import ctypes as C
+    import os
+    import torch
+    from stella_vslam_amd._lib import lib
+    B, h, w = frames.shape
+    old = os.environ.pop("SVGPU_DESCRIBE_LEGACY", None)
+    if legacy:
+        os.environ["SVGPU_DESCRIBE_LEGACY"] = "1"  # read by svgpu_orb_configure: the per-keypoint kernel k_describe instead of k_describe_bands
+    try:
+        ctx = F.Context(0)
+        L, p = lib(), F.orb_params()
+        ctx.check(L.svgpu_orb_configure(ctx.handle, w, h, B, C.c_float(p.scale_factor_), p.num_levels_, p.ini_fast_thr_, p.min_fast_thr_, C.c_uint(800)), "cfg")
+    finally:
+        os.environ.pop("SVGPU_DESCRIBE_LEGACY", None)
+        if old is not None:
+            os.environ["SVGPU_DESCRIBE_LEGACY"] = old
+    full = L.svgpu_orb_max_keypoints(ctx.handle)
+    cap = cap or full
+    stride = w + stride_pad
+    buf = np.zeros((B, h, stride), np.uint8)
+    buf[:, :, :w] = frames
+    img = torch.from_numpy(buf.reshape(-1)).cuda()
+    off = 3 if stride_pad else 0  # and a base address that is not a multiple of 4
+    if off:
+        img = torch.cat([torch.zeros(off, dtype=torch.uint8, device="cuda"), img])
+    kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    desc = torch.full((B * cap * 32,), 0xAB, dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(B * (1 + p.num_levels_), dtype=torch.int32, device="cuda")
+    ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(img.data_ptr() + off), B, C.c_size_t(h * stride), stride, None, C.c_size_t(0), 0,
+                                               C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), cap, C.c_void_p(counts.data_ptr()), None), "extract")
+    ctx.synchronize()
+    return (kps.cpu().numpy().view(O.KEYPOINT_DTYPE).reshape(B, cap), desc.cpu().numpy().reshape(B, cap, 32),
+            counts.cpu().numpy().reshape(B, 1 + p.num_levels_), full)
+
+
+@pytest.mark.parametrize("w,h,pad", [(640, 480, 0), (203, 157, 5), (1241, 376, 0), (331, 250, 1)])
+def test_describe_bands_equal_per_keypoint_kernel(F, w, h, pad):
+    """k_describe_bands (LDS-resident bands) and k_describe (per-keypoint patches) are two routes to the same bytes: orientation, records and
+    descriptors of a batch, with an unaligned strided image, and with a capacity that cuts a band's run of keypoints short."""
+    frames = S.frame_sequence(3, w, h, seed=w + h)
+    kb, db, cb, full = _batch_extract(F, frames, pad)
+    kl, dl, cl, _ = _batch_extract(F, frames, pad, legacy=True)
+    assert np.array_equal(cb, cl) and cb[:, 0].min() > 50
+    for b in range(3):
+        n = cb[b, 0]
+        assert np.array_equal(kb[b, :n], kl[b, :n]) and np.array_equal(db[b, :n], dl[b, :n])
+        ko, do, _ = O.orb_extract(frames[b])
+        assert np.array_equal(db[b, :n], do) and np.array_equal(kb[b, :n]["angle"], ko["angle"])
+    cap = int(cb[:, 0].min()) * 2 // 3  # fewer slots than keypoints: the first `cap` of the emission order, nothing written behind them
+    kc, dc, cc, _ = _batch_extract(F, frames, pad, cap=cap)
+    assert np.array_equal(cc, cb)
+    for b in range(3):
+        assert np.array_equal(kc[b], kb[b, :cap]) and np.array_equal(dc[b], db[b, :cap])
