@@ -280,6 +280,13 @@ def compact_line(r):
     if rf.get("per_kernel_ms_per_step"):
         ro["ms_per_step"] = rf["per_kernel_ms_per_step"]
     out["roofline"] = ro
+    # the rule is frozen: `roofline` = the longest kernel of the critical (extraction) stream, `roofline_overlapped` = the longest
+    # kernel per step of the stream that runs beside it (the matcher), each with the name it carries in a rocprofv3 trace
+    if isinstance(rf.get("overlapped_stream_longest"), dict):
+        out["roofline_overlapped"] = dict(_pick(rf["overlapped_stream_longest"], ("kernel", "rocprof_kernel", "bound", "achieved", "peak", "unit", "frac", "mean_launch_ms", "mfma_busy_frac")),
+                                          selection="largest time per step among the kernels of the overlapped (matcher) stream; elapsed time beside the extraction stream")
+        if isinstance(rf["overlapped_stream_longest"].get("standalone"), dict):
+            out["roofline_overlapped"]["standalone"] = _pick(rf["overlapped_stream_longest"]["standalone"], ("achieved", "frac", "mean_launch_ms"))
     if "second_batch_point" in r:
         out["second_batch_point"] = _pick(r["second_batch_point"], ("frames_per_gpu_per_step", "value", "ms_per_step"))
     if "with_h2d" in r:
@@ -345,7 +352,9 @@ def emit(result, detail_path):
 CRITICAL_STREAM = ("k_resize", "k_blur", "k_fast", "k_select", "k_describe")  # the extraction chain: its kernels add up to the step
 KERNEL_CLASSES = ("k_resize", "k_blur", "k_fast", "k_select", "k_describe", "k_bf_binsort", "k_bf_topk", "k_bf_replay")
 # profiling class (svgpu_profile_read_class) -> the kernel symbol rocprofv3 lists for it in profiles/*_kernel_stats.csv, where the two differ
-ROCPROF_KERNEL = {"k_resize": "k_pyramid_lds", "k_bf_topk": "k_bf_mfma"}
+# class name of the profiler (svgpu_profile_*) -> kernel name in a rocprofv3 trace (profiles/r06_kernel_stats.csv)
+ROCPROF_KERNEL = {"k_resize": "k_pyramid_lds", "k_blur": "k_blur<64>", "k_fast": "k_fast", "k_select": "k_select", "k_describe": "k_describe_bands",
+                  "k_bf_binsort": "k_bf_binsort", "k_bf_topk": "k_bf_mfma", "k_bf_replay": "k_bf_replay<5, 512>"}
 
 
 PACKED_ANGLES = os.environ.get("BENCH_PACKED_ANGLES", "1") != "0"  # (A/B aid: 0 = the matcher reads the angles out of the keypoint records)
@@ -599,7 +608,7 @@ def roofline_entries(fe, src_hash, B, world):
     over = [k for k in kernels if k["kernel"] not in CRITICAL_STREAM]
     if over:
         ok = max(over, key=lambda k: k["mean_launch_ms"] * k["launches_per_step"])
-        dom["overlapped_stream_longest"] = {k: ok[k] for k in ("kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms", "standalone") if k in ok}
+        dom["overlapped_stream_longest"] = {k: ok[k] for k in ("kernel", "rocprof_kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms", "standalone", "mfma_busy_frac") if k in ok}
         mf = next((k for k in over if k["bound"] == "mfma"), None)
         if mf is not None:
             dom["matrix_core_kernel"] = {k: mf[k] for k in ("kernel", "rocprof_kernel", "bound", "unit", "peak", "achieved", "frac", "mean_launch_ms", "executed_int8_ops_per_launch", "mfma_busy_frac", "standalone") if k in mf}

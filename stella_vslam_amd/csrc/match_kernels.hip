@@ -279,7 +279,7 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define MF_TT 32       // targets per MFMA tile
 #define MF_CH 256      // targets per fetched chunk
 #define MF_SLOTS 16    // list slots per query (= P.list_k of this path)
-#define MF_WQ 128      // per-wave hit queue entries; drained when fewer than 64 are free
+#define MF_WQ 256      // per-wave hit queue entries (row << 16 | column of the chunk); drained when fewer than 64 are free and at the end of every chunk
 // Operand form (round 4).  Bits are expanded to 0 / 2 bytes on the query side and 0 / 1 bytes on the target side, and a NINTH k-step
 // carries the two popcounts, so that the accumulator is the negated distance itself:
 //     sum_k (2 q_k) t_k  -  pop(q)  -  pop(t)  =  -hamming(q, t),
@@ -292,12 +292,16 @@ __device__ __forceinline__ uint32_t mf_spread(uint32_t nibble) {  // bit b of th
 }
 __device__ __forceinline__ uint32_t mf_expand01(uint32_t nibble) { return mf_spread(nibble) & 0x01010101u; }        // targets: 0 / 1 (expanded per tile: the cheaper form)
 __device__ __forceinline__ uint32_t mf_expand02(uint32_t nibble) { return (mf_spread(nibble) << 1) & 0x02020202u; }  // queries: 0 / 2 (expanded once per kernel)
-// the ninth k-step: -(pop) as three int8 pieces in bytes 0..2 (own side) or 3..5 (other side's ones sit in the complementary bytes)
-__device__ __forceinline__ uint2 mf_pop_pieces(int pop, bool own_first) {
+// the ninth k-step: -(pop) as three int8 pieces in bytes 0..2 (own side) or 3..5 (other side's ones sit in the complementary bytes); bytes 6, 7
+// carry the threshold: the query side holds dmax in two pieces (<= 127 each) against ones on the target side, so that the accumulator
+// is dmax - distance and "hit" is its SIGN BIT (round 6: the hit mask of a lane is then one v_alignbit_b32 per accumulator register)
+__device__ __forceinline__ uint2 mf_pop_pieces(int pop, bool own_first, int dmax) {
     const int a = min(pop, 127), b = min(pop - a, 127), c = pop - a - b;
     const uint32_t na = (uint32_t)(-a) & 0xFFu, nb = (uint32_t)(-b) & 0xFFu, nc = (uint32_t)(-c) & 0xFFu;
-    // query side: bytes [-a -b -c  1 | 1 1 0 0]; target side: bytes [1 1 1 -a | -b -c 0 0]
-    return own_first ? make_uint2(na | (nb << 8) | (nc << 16) | (1u << 24), 0x00000101u) : make_uint2(0x00010101u | (na << 24), nb | (nc << 8));
+    const uint32_t d0 = (uint32_t)min(dmax, 127), d1 = (uint32_t)(dmax - (int)d0);
+    // query side: bytes [-a -b -c  1 | 1 1 d0 d1]; target side: bytes [1 1 1 -a | -b -c 1 1]
+    return own_first ? make_uint2(na | (nb << 8) | (nc << 16) | (1u << 24), 0x00000101u | (d0 << 16) | (d1 << 24))
+                     : make_uint2(0x00010101u | (na << 24), nb | (nc << 8) | 0x01010000u);
 }
 // candidate window (in angle-sorted target positions) of the sorted queries [r_lo, r_hi]: up to two runs
 __device__ __forceinline__ void mf_window(const float* __restrict__ A2s, const int* __restrict__ BS1, int r_lo, int r_hi, int n1c,
@@ -335,7 +339,7 @@ struct MfShared {
     int cnt[MF_QB];
     uint32_t rowmax[MF_QB];          // largest key of a FULL row once it has been scanned (else all-ones): cheap reject of far candidates
     float qa[MF_QB];                 // query angle, or -1000 for rows that must never match (past n2, !valid2)
-    uint2 wq[4][MF_WQ];              // (row << 24 | dist << 16 | idx_1, target angle bits)
+    uint32_t wq[4][MF_WQ];           // (query row of the wave << 16 | target column of the chunk): the drain recomputes the distance
 #ifdef SV_MF_PAD
     uint32_t pad[SV_MF_PAD];
 #endif
@@ -348,20 +352,27 @@ __device__ __forceinline__ uint32_t mf_row16_max(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false));  // row_ror:1
     return v;
 }
-// Drain the wave's hit queue into its rows.  Called by all 64 lanes of the wave.
-__device__ __forceinline__ void mf_drain(MfShared& S, int wave, int lane, int n, bool ori) {
+// Drain the wave's hit queue into its rows.  Called by all 64 lanes of the wave, while the chunk the entries point into is still in LDS.
+// An entry names (query row, target column); the distance is recomputed here (xor + popcount of the two descriptors: the same number the
+// accumulator held), so the hit path of the multiply loop carries no payload and no accumulator has to be indexed by a run-time register.
+__device__ __forceinline__ void mf_drain(MfShared& S, const uint32_t* __restrict__ D2, int q_first, int n2c, int wave, int lane, int n, bool ori) {
     for (int e0 = 0; e0 < n; e0 += 64) {
         const int e = e0 + lane;
         bool live = e < n;
         uint32_t key = 0;
         int ql = 0, slot = 0;
         if (live) {
-            const uint2 ent = S.wq[wave][e];
-            ql = (int)(ent.x >> 24) + wave * MF_QW;
-            key = ent.x & 0x00FFFFFFu;
+            const uint32_t ent = S.wq[wave][e];
+            const int row = (int)(ent >> 16), col = (int)(ent & 0xFFFFu);
+            ql = row + wave * MF_QW;
+            const uint32_t* q = D2 + (size_t)min(q_first + row, n2c - 1) * 8;
+            const uint4 q0 = *reinterpret_cast<const uint4*>(q), q1 = *reinterpret_cast<const uint4*>(q + 4);
+            const uint32_t dist = __popc(q0.x ^ S.raw[0][col]) + __popc(q0.y ^ S.raw[1][col]) + __popc(q0.z ^ S.raw[2][col]) + __popc(q0.w ^ S.raw[3][col])
+                                  + __popc(q1.x ^ S.raw[4][col]) + __popc(q1.y ^ S.raw[5][col]) + __popc(q1.z ^ S.raw[6][col]) + __popc(q1.w ^ S.raw[7][col]);
+            key = (dist << 16) | (uint32_t)S.ridx[col];
             const float qa = S.qa[ql];
             live = qa > -500.f;
-            if (ori) live = live && !(fabsf(angle_diff(__uint_as_float(ent.y), qa)) > 30.0f);
+            if (ori) live = live && !(fabsf(angle_diff(S.rang[col], qa)) > 30.0f);
             if (live) slot = atomicAdd(&S.cnt[ql], 1);  // several lanes may hold hits of the same row
             if (live && slot < MF_SLOTS) S.list[ql][slot] = key;
         }
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
             const uint32_t half = (w >> (16 * h)) & 0xFFFFu;
             A[a][s] = v4i{(int)mf_expand02(half & 15u), (int)mf_expand02((half >> 4) & 15u), (int)mf_expand02((half >> 8) & 15u), (int)mf_expand02(half >> 12)};
         }
-        const uint2 pp = mf_pop_pieces(pq, true);
+        const uint2 pp = mf_pop_pieces(pq, true, min((int)P.dmax, 254));
         A[a][8] = h == 0 ? v4i{(int)pp.x, (int)pp.y, 0, 0} : v4i{0, 0, 0, 0};
     }
     // ---- candidate windows: the block's (targets to stage) and this wave's (tiles to multiply)
@@ -459,63 +470,26 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
         B[lt] = lo;        // lane half 0: bits [32 lw, +16)
         B[32 + lt] = hi;   // lane half 1: bits [32 lw + 16, +16)
         if (lw == 0) {     // the popcount step of the tile (one wave-half's worth of threads)
-            const uint2 pp = lt < valid ? mf_pop_pieces(S.rpop[tile * MF_TT + lt], false) : make_uint2(0x81010101u, 0x00008181u);
+            const uint2 pp = lt < valid ? mf_pop_pieces(S.rpop[tile * MF_TT + lt], false, 0) : make_uint2(0x81010101u, 0x01018181u);
             uint4* B8 = reinterpret_cast<uint4*>(S.b[buf]) + 8 * 64;
             B8[lt] = make_uint4(pp.x, pp.y, 0, 0);
             B8[32 + lt] = make_uint4(0, 0, 0, 0);
         }
     };
-    const int thr = -(int)P.dmax;           // the accumulator is -distance: hit <=> acc >= -dmax
     int wq_n = 0;                           // entries in this wave's hit queue (wave-uniform)
-    // One accumulator register of the wave's 64 x 32 patch: rows 32 a + (r & 3) + 8 (r >> 2) + 4 h (C/D map of the 32x32 shapes), one
-    // target per lane.  The hit lanes append (row, dist, original idx_1, target angle) to the wave's queue with ballot ranks; a register
-    // without a hit costs a compare and a wave-uniform skip.  dist << 16 = (-dot) << 16.
-    auto test_reg = [&](int dot, int a, int r, uint32_t ti, uint32_t ta) {
-        const bool hit = dot >= thr;
-        const unsigned long long m = __ballot(hit);
-        if (m) {
-            // (the queue fill is wave-uniform; said explicitly, the capacity test and the slot address stay on the scalar unit -- the compiler
-            //  had parked the counter in a vector register and guarded the drain with an exec mask)
-            int wq = __builtin_amdgcn_readfirstlane(wq_n);
-            if (wq > MF_WQ - 64) {  // a register adds at most one entry per lane
-                mf_drain(S, wave, lane, wq, ori);
-                wq = 0;
-            }
-            if (hit) {
-                const int pq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t row = (uint32_t)(32 * a + (r & 3) + 8 * (r >> 2)) << 24;
-                S.wq[wave][wq + pq] = make_uint2(ti + row + ((uint32_t)(-dot) << 16), ta);
-            }
-            wq_n = wq + __popcll(m);
-        }
-    };
-    // a whole half (16 registers = 32 rows x 32 targets) without a hit -- the common case -- costs eight three-way maxima, one compare
-    // and one wave-uniform branch instead of sixteen compare / ballot / branch triples
-    auto any_hit = [&](const v16i& acc) -> bool {
-        int m0 = max(max(acc[0], acc[1]), acc[2]), m1 = max(max(acc[3], acc[4]), acc[5]), m2 = max(max(acc[6], acc[7]), acc[8]);
-        int m3 = max(max(acc[9], acc[10]), acc[11]), m4 = max(max(acc[12], acc[13]), max(acc[14], acc[15]));
-        return __ballot(max(max(max(m0, m1), m2), max(m3, m4)) >= thr) != 0ull;
-    };
-    // The two 32-query halves of the wave rotate so that no accumulator is read right behind its own MFMAs (ablation builds: the wave
-    // used to spend ~100 of the kernel's 260 us waiting for the 16 MFMAs of a tile before it could test them): while the eight MFMAs of
-    // half 0 of tile t issue, the accumulators of half 1 of the PREVIOUS tile are tested, two registers per MFMA; while those of half 1
-    // issue, half 0 of tile t.  Half 1 stays pending across the barrier with the two words that describe its tile.
-    v16i acc0 = {}, acc1 = {};
-    bool pend1 = false;
-    uint32_t p_ti = 0, p_ta = 0;
     unsigned n_mine = 0;  // patches this wave multiplied (profiling counter)
+    // A wave's 64 x 32 patch of a tile: every B fragment is read from LDS ONCE and feeds both 32-query halves (eighteen MFMAs back to back).
+    // The 32 accumulator registers of a lane (rows 32 a + (r & 3) + 8 (r >> 2) + 4 h of the C/D map, one target column per lane) then
+    // leave a lane-LOCAL hit mask -- one v_alignbit_b32 per register (the ninth k-step carries + dmax, so a hit is a clear sign bit), no
+    // compare, no ballot, no branch -- and the patch costs one wave-uniform
+    // test; the few lanes that hold hits append (row, column) words to the wave's queue, one per lane and round.
+    // (Round 5 tested every register with a ballot and a branch and appended row, distance, index and angle from inside the multiply loop:
+    //  130 M scalar instructions per 1 024 pairs, the matrix pipe 17 % busy.)
     for (int sg = 0; sg < 2; ++sg) {
         const int lo = blo[sg], hi = bhi[sg];
         for (int cbase = lo; cbase < hi; cbase += MF_CH) {
             const int cn = min(MF_CH, hi - cbase), ntiles = (cn + MF_TT - 1) / MF_TT;
-            if (pend1) {  // its tile's angle / index words live in registers, but keep the schedule simple across chunk boundaries
-                if (any_hit(acc1)) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
-                }
-                pend1 = false;
-            }
-            __syncthreads();  // every wave is done with the previous chunk
+            __syncthreads();  // every wave is done with the previous chunk (its queue entries are drained)
             if (tid < cn) {   // one descriptor per thread: two 16-byte loads, scattered into the transposed layout
                 const uint4 d0 = *reinterpret_cast<const uint4*>(D1 + (size_t)(cbase + tid) * 8);
                 const uint4 d1 = *reinterpret_cast<const uint4*>(D1 + (size_t)(cbase + tid) * 8 + 4);
@@ -539,53 +513,50 @@ __global__ __launch_bounds__(256, 3) void k_bf_mfma(BfProblem P) {
                 const bool mine = wave_live && ((base < whi[0] && tend > wlo[0]) || (base < whi[1] && tend > wlo[1]));
                 if (mine) {
                     const v4i* Bf = reinterpret_cast<const v4i*>(S.b[buf]) + lane;
-                    const int col = t * MF_TT + (lane & 31);
-                    const uint32_t ta = __float_as_uint(S.rang[col]);
-                    const uint32_t ti = (uint32_t)S.ridx[col] | ((uint32_t)(4 * h) << 24);
+                    v16i acc0 = {}, acc1 = {};
                     v4i b = Bf[0];
-                    const bool hit1 = pend1;
 #pragma unroll
-                    for (int s = 0; s < 9; ++s) {  // half 0 of this tile | test of half 1 of the previous one
-                        const v4i bn = Bf[(s < 8 ? s + 1 : 0) * 64];  // next fragment in flight (after the last one: the first of the second pass)
-                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, s == 0 ? v16i{} : acc0, 0, 0, 0);
+                    for (int s = 0; s < 9; ++s) {
+                        const v4i bn = Bf[(s < 8 ? s + 1 : 0) * 64];  // next fragment in flight
+                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][s], b, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, acc1, 0, 0, 0);
                         b = bn;
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (hit1 && s < 8) {
-                            test_reg(acc1[2 * s], 1, 2 * s, p_ti, p_ta);
-                            test_reg(acc1[2 * s + 1], 1, 2 * s + 1, p_ti, p_ta);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    const bool hit0 = true;
-#pragma unroll
-                    for (int s = 0; s < 9; ++s) {  // half 1 of this tile | test of half 0 of this tile
-                        const v4i bn = Bf[(s < 8 ? s + 1 : 8) * 64];
-                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][s], b, s == 0 ? v16i{} : acc1, 0, 0, 0);
-                        b = bn;
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (hit0 && s < 8) {
-                            test_reg(acc0[2 * s], 0, 2 * s, ti, ta);
-                            test_reg(acc0[2 * s + 1], 0, 2 * s + 1, ti, ta);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    pend1 = true;
-                    p_ti = ti;
-                    p_ta = ta;
                     ++n_mine;
-                    // the next tile's +-1 expansion is pure VALU / LDS work: it runs in the shadow of the last MFMAs
+                    // the next tile's expansion is pure VALU / LDS work: it runs in the shadow of the MFMAs
                     if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
+                    uint32_t m = 0;  // the accumulator is dmax - distance: shift the sign bits in; then bit r: acc0[r] is a hit, bit 16 + r: acc1[r]
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, (uint32_t)acc1[r], 31);
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, (uint32_t)acc0[r], 31);
+                    m = ~m;
+                    unsigned long long any = __ballot(m != 0);
+                    while (any) {  // one entry per lane and round (a dozen hits per patch: one or two rounds)
+                        int wq = __builtin_amdgcn_readfirstlane(wq_n);
+                        if (wq > MF_WQ - 64) {
+                            mf_drain(S, D2, q0, n2c, wave, lane, wq, ori);
+                            wq = 0;
+                        }
+                        if (m) {
+                            const uint32_t bit = (uint32_t)__ffs((int)m) - 1u;
+                            m &= m - 1u;
+                            const uint32_t row = ((bit >> 4) << 5) + (bit & 3u) + ((bit & 12u) << 1) + 4u * (uint32_t)h;
+                            const int pq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                            S.wq[wave][wq + pq] = (row << 16) | (uint32_t)(t * MF_TT + (lane & 31));
+                        }
+                        wq_n = wq + __popcll(any);
+                        any = __ballot(m != 0);
+                    }
                 }
                 else if (t + 1 < ntiles) expand(buf ^ 1, t + 1, min(MF_TT, cn - (t + 1) * MF_TT));
                 __syncthreads();
             }
+            // the entries point into this chunk's LDS copy: drain before the next chunk replaces it
+            mf_drain(S, D2, q0, n2c, wave, lane, __builtin_amdgcn_readfirstlane(wq_n), ori);
+            wq_n = 0;
         }
     }
-    if (pend1 && any_hit(acc1)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) test_reg(acc1[r], 1, r, p_ti, p_ta);
-    }
-    mf_drain(S, wave, lane, wq_n, ori);
     if (P.mfma_tiles && lane == 0 && n_mine) atomicAdd(P.mfma_tiles, (unsigned long long)n_mine);
     __syncthreads();
     // ---- flush: one thread per query: sort the row (ascending (dist, idx_1) = the reference's scan preference) in registers

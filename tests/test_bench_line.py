@@ -31,10 +31,24 @@ def test_line_fits():
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["bound"] in ("hbm", "mfma")
+    assert rf["selection"].startswith("largest time per step among the kernels of the critical")  # the rule stays fixed
+    ro = back["roofline_overlapped"]  # the longest kernel of the matcher stream, printed beside it
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "mean_launch_ms", "selection"):
+        assert k in ro, k
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and ro["kernel"] != rf["kernel"]
     cb = back["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert "workload" in back["config"] and "model" not in back["config"]
+
+
+def test_every_kernel_class_has_its_rocprof_name():
+    """From the line (class names of svgpu_profile_*) to profiles/rNN_kernel_stats.csv (kernel names) without reading the source."""
+    for cls in bench.KERNEL_CLASSES:
+        assert cls in bench.ROCPROF_KERNEL, cls
+    src = open(os.path.join(ROOT, "stella_vslam_amd", "csrc", "orb_kernels.hip")).read() + open(os.path.join(ROOT, "stella_vslam_amd", "csrc", "match_kernels.hip")).read()
+    for cls, name in bench.ROCPROF_KERNEL.items():
+        assert ("void " + name.split("<")[0] + "(") in src, name
 
 
 def test_line_survives_bloated_legs():
