@@ -435,7 +435,8 @@ int svgpu_track_motion_stereo(svgpu_tracker* tracker, svgpu_ctx* ctx_right, svgp
                               int32_t* match_last, uint8_t* outlier, svgpu_track_result* result);
 int svgpu_tracker_observation_stereo(const svgpu_tracker* tracker, const float** stereo_x_right, const float** depths);
 /* ... and for an RGB-D frame (system::create_RGBD_frame, system.cc:466-526): `depth` = the depth image in metres as CV_32F
- * (util::convert_to_true_depth already applied by the caller), `depth_stride` in FLOATS per row.  The depth is sampled at the distorted
+ * (util::convert_to_true_depth already applied by the caller) with the SAME height and width as `img` (the library reads height rows of
+ * width floats; it cannot check the size of the buffer behind the pointer), `depth_stride` in FLOATS per row (>= width).  The depth is sampled at the distorted
  * keypoint (img_depth.at<float>(y, x), coordinates truncated), stereo_x_right_ = undist.x - focal_x_baseline / depth (-1 where depth <= 0),
  * inside the frame-observation kernel of the same submission; read back with svgpu_tracker_observation_stereo. */
 int svgpu_track_motion_rgbd(svgpu_tracker* tracker, svgpu_frame* cur, const uint8_t* img, int stride, const float* depth, int depth_stride,

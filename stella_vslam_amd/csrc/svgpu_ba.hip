@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <dlfcn.h>
+#include <sched.h>
 #include <thread>
 
 #include "svgpu_internal.h"
@@ -213,15 +214,25 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     }();
     const bool team_sized = E >= team_min_obs && !std::getenv("SVGPU_BA_ONE_THREAD");
     memcpy(pose_out, pr->pose_cw, sizeof(double) * 12 * (size_t)P);
-    if (!team_sized || (stop && *stop && !(allreduce != nullptr)) || E == 0 || P == 0 || L == 0) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+    // (the flag is volatile and another thread raises it: ONE read decides both the copy and the return, so that no path leaves
+    //  points_out unwritten -- ADVICE r5)
+    const bool stopped_at_entry = !sharded && stop && *stop;  // local_bundle_adjuster_g2o.cc:308-310
+    const bool team_copies_points = team_sized && !stopped_at_entry && E > 0 && P > 0 && L > 0;
+    if (!team_copies_points) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
     if (E > 0 && outlier_out) memset(outlier_out, 0, E);
     if (stats) *stats = st;
     if (!sharded) {
-        if (stop && *stop) return SVGPU_STOPPED;  // local_bundle_adjuster_g2o.cc:308-310
+        if (stopped_at_entry) return SVGPU_STOPPED;
         if (E == 0 || P == 0 || L == 0) return SVGPU_OK;
     }
     else if (P == 0 || L == 0) return SVGPU_OK;  // same on every rank
-    SV_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        const hipError_t e_dev = hipSetDevice(ctx->device);
+        if (e_dev != hipSuccess) {  // an early return before the team exists: the estimate leaves as it came
+            if (team_copies_points) memcpy(points_out, pr->points, sizeof(double) * 3 * (size_t)L);
+            SV_HIP(ctx, e_dev);
+        }
+    }
     hipStream_t s = ctx->stream;
 
     // ---- page-locked staging laid out exactly like the input block at the head of the device arena (one copy carries everything):
@@ -288,7 +299,11 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         if (!team_sized) return 1;
         const char* ev = std::getenv("SVGPU_BA_HOST_THREADS");
         const int v = ev ? std::atoi(ev) : 8;  // (config 5: 1.28 ms with 4 threads, 0.69 with 8, flat beyond)
-        const unsigned hw = std::thread::hardware_concurrency();  // (the team spins at its barriers: never more threads than cores)
+        // (the team spins at its barriers: never more threads than CPUs this process may run on -- the affinity mask, which is what a
+        //  container's cpuset leaves, not the machine's core count)
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t cpus;
+        if (sched_getaffinity(0, sizeof(cpus), &cpus) == 0 && CPU_COUNT(&cpus) > 0) hw = hw == 0 ? (unsigned)CPU_COUNT(&cpus) : std::min(hw, (unsigned)CPU_COUNT(&cpus));
         const int cap = hw == 0 ? 16 : (int)std::min(16u, hw);
         return v < 1 ? 1 : (v > cap ? cap : v);
     }();
@@ -1371,8 +1386,19 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         else {  // (38 MB at 1.6 M landmarks: one core copies them in ~2 ms)
             const int nt = 4;
             std::vector<std::thread> th;
-            for (int q = 1; q < nt; ++q) th.emplace_back([=] { memcpy((char*)points_out + bytes * q / nt, src + bytes * q / nt, bytes * (q + 1) / nt - bytes * q / nt); });
-            memcpy(points_out, src, bytes / nt);
+            auto share = [=](int q) { memcpy((char*)points_out + bytes * q / nt, src + bytes * q / nt, bytes * (q + 1) / nt - bytes * q / nt); };
+            int started = 1;  // shares [0, started) have an owner (this thread takes 0)
+            try {  // (no exception may cross the C ABI with joinable threads behind it: a share that finds no thread is copied here)
+                th.reserve(nt - 1);
+                for (int q = 1; q < nt; ++q) {
+                    th.emplace_back(share, q);
+                    started = q + 1;
+                }
+            }
+            catch (...) {
+            }
+            share(0);
+            for (int q = started; q < nt; ++q) share(q);
             for (auto& t : th) t.join();
         }
     }
@@ -1547,7 +1573,7 @@ int svgpu_ba_partition_keyframe_segments(const svgpu_ba_problem* pr, int world, 
     for (int p = 0; p < P; ++p)
         if (seen[p] && !pr->pose_fixed[p]) slot[p] = nP++;
     info[6] = nP;
-    if (nP < 4 || nP > 65536) return SVGPU_OK;  // (the pattern below is a dense BIT table: nP^2 / 8 bytes, 32 MB at 16 384 keyframes)
+    if (nP < 4 || nP > 32768) return SVGPU_OK;  // (the pattern below is a dense BIT table, nP^2 / 8 bytes: 32 MB at 16 384 free keyframes, 128 MB at the 32 768 cap; the a/b scan behind it is O(nP^2); larger graphs keep the whole problem in one segment)
     // observations grouped by landmark
     std::vector<int> off(L + 1, 0), obs(E);
     for (int e = 0; e < E; ++e) ++off[pr->obs_point[e] + 1];

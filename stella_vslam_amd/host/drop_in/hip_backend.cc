@@ -914,11 +914,15 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     std::vector<int32_t> obs_pose, obs_point;
     std::vector<float> obs_uvr, obs_w, obs_huber;
     std::vector<std::pair<kf_ptr, lm_ptr>> obs_objects;
+    std::vector<unsigned int> obs_kpidx;      // keypoint index of the observation in its keyframe
+    std::vector<int> lm_edge_first;           // edges of landmark l = [lm_edge_first[l], lm_edge_first[l + 1]) (appended landmark by landmark, in observations_ order)
+    std::vector<uint8_t> lm_partial;          // an observation of l was NOT turned into an edge (expired / erased keyframe): the batched refresh leaves l to the object's own methods
     {
         size_t n_obs = 0;
         for (const auto& o : local_lm_obs) n_obs += o.size();
         points.reserve(local_lms.size()), pts.reserve(3 * local_lms.size());
         obs_pose.reserve(n_obs), obs_point.reserve(n_obs), obs_uvr.reserve(3 * n_obs), obs_w.reserve(n_obs), obs_huber.reserve(n_obs), obs_objects.reserve(n_obs);
+        obs_kpidx.reserve(n_obs), lm_edge_first.reserve(local_lms.size() + 1), lm_partial.reserve(local_lms.size());
     }
     for (size_t k_lm = 0; k_lm < local_lms.size(); ++k_lm) {
         const auto& local_lm = local_lms[k_lm].second;
@@ -926,14 +930,22 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
         if (observations.empty()) continue;
         const int l = (int)points.size();
         points.push_back(local_lm);
+        lm_edge_first.push_back((int)obs_pose.size());
+        lm_partial.push_back(0);
         const Vec3_t pw = local_lm->get_pos_in_world();
         for (int k = 0; k < 3; ++k) pts.push_back(pw(k));
         for (const auto& obs : observations) {
             const auto keyfrm = obs.first.lock();
             const auto idx = obs.second;
-            if (!keyfrm || keyfrm->will_be_erased()) continue;
+            if (!keyfrm || keyfrm->will_be_erased()) {
+                lm_partial.back() = 1;
+                continue;
+            }
             const auto it = pose_index.find(keyfrm->id_);
-            if (it == pose_index.end()) continue;
+            if (it == pose_index.end()) {
+                lm_partial.back() = 1;
+                continue;
+            }
             const auto& undist_keypt = keyfrm->frm_obs_.undist_keypts_.at(idx);
             const float x_right = keyfrm->frm_obs_.stereo_x_right_.empty() ? -1.0f : keyfrm->frm_obs_.stereo_x_right_.at(idx);
             obs_pose.push_back(it->second);
@@ -944,8 +956,10 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
             obs_w.push_back(keyfrm->orb_params_->inv_level_sigma_sq_.at(undist_keypt.octave));
             obs_huber.push_back(keyfrm->camera_->setup_type_ == camera::setup_type_t::Monocular ? sqrt_chi_sq_2D : sqrt_chi_sq_3D);
             obs_objects.emplace_back(keyfrm, local_lm);
+            obs_kpidx.push_back(idx);
         }
     }
+    lm_edge_first.push_back((int)obs_pose.size());
     // marker corners (:246-304): four points per marker that was initialised before or is kept fixed (then fixed vertices), one edge per
     // observing keyframe of the graph and corner, information 1, no kernel -- and outside the gate / outlier list (negative width, svgpu.h)
     const int L_lm = (int)points.size();
@@ -999,6 +1013,100 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     // 7.-8. outlier observations, then poses and positions under the map mutex (:352-411)
     {
         std::lock_guard<std::mutex> lock(data::map_database::mtx_database_);
+#ifdef SVGPU_LANDMARK_HAS_BATCH_SETTERS
+        // The reference refreshes every touched landmark through its own methods (compute_descriptor after an erased observation,
+        // update_mean_normal_and_obs_scale_variance after a moved position: data/landmark.cc:199-318) -- ten thousand calls that each copy
+        // the observation map and lock every observing keyframe.  Here the graph mutations stay per object, the refreshes are ONE call of
+        // svgpu_landmarks_update_geometry (+ one of svgpu_landmarks_compute_descriptor for the landmarks that lost an observation) on the flat
+        // observation lists the flattening above already holds, and the results are stored through two setters.
+        std::vector<uint8_t> edge_erased(obs_objects.size(), 0), desc_dirty((size_t)L_lm, 0);
+        for (int e = 0; e < (int)obs_objects.size(); ++e) {
+            if (!outlier[e]) continue;
+            const auto& keyfrm = obs_objects[e].first;
+            const auto& lm = obs_objects[e].second;
+            if (lm->will_be_erased()) continue;  // :358-361
+            keyfrm->erase_landmark(lm);
+            lm->erase_observation(map_db, keyfrm);
+            edge_erased[e] = 1;
+            desc_dirty[obs_point[e]] = 1;
+        }
+        std::vector<double> centre((size_t)P * 3);  // camera centres -R^T t of the window's keyframes after the solve (fixed ones: unchanged)
+        for (int p = 0; p < P; ++p) {
+            const double* T = pose_fixed[p] ? &pose_cw[(size_t)p * 12] : &pose_out[(size_t)p * 12];
+            for (int k = 0; k < 3; ++k) centre[(size_t)p * 3 + k] = -(T[k] * T[3] + T[4 + k] * T[7] + T[8 + k] * T[11]);
+        }
+        for (const auto& kv : local_keyfrms) {
+            const int p = pose_index.at(kv.first);
+            Mat44_t T = Mat44_t::Identity();
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 4; ++j) T(i, j) = pose_out[(size_t)p * 12 + 4 * i + j];
+            kv.second->set_pose_cw(T);
+        }
+        const auto* orb0 = curr_keyfrm->orb_params_;
+        const float inv_last = orb0->inv_scale_factors_.at(orb0->num_levels_ - 1);
+        std::vector<int> g_lm, d_lm;                 // landmarks of the geometry batch / of the descriptor batch
+        std::vector<int32_t> g_off(1, 0), d_off(1, 0);
+        std::vector<double> g_trans, g_pos, g_ref;
+        std::vector<float> g_scale;
+        std::vector<uint8_t> d_rows;
+        g_lm.reserve(L_lm), g_off.reserve(L_lm + 1), g_trans.reserve(3 * obs_objects.size()), g_pos.reserve(3 * (size_t)L_lm), g_ref.reserve(3 * (size_t)L_lm), g_scale.reserve(L_lm);
+        for (int l = 0; l < L_lm; ++l) {
+            const auto& local_lm = points[l];
+            if (local_lm->will_be_erased()) continue;
+            Vec3_t pw;
+            for (int k = 0; k < 3; ++k) pw(k) = pts_out[(size_t)l * 3 + k];
+            local_lm->set_pos_in_world(pw);
+            // the landmark's observation list as it is NOW = its edges minus the erased ones; its reference keyframe must be among them
+            const auto ref = local_lm->get_ref_keyframe();
+            int n_kept = 0, ref_edge = -1;
+            for (int e = lm_edge_first[l]; e < lm_edge_first[l + 1]; ++e) {
+                if (edge_erased[e]) continue;
+                ++n_kept;
+                if (obs_objects[e].first == ref) ref_edge = e;
+            }
+            if (lm_partial[l] || n_kept == 0 || ref_edge < 0 || ref->orb_params_->inv_scale_factors_.at(ref->orb_params_->num_levels_ - 1) != inv_last) {
+                if (desc_dirty[l]) local_lm->compute_descriptor();  // the object's own methods for the odd ones
+                local_lm->update_mean_normal_and_obs_scale_variance();
+                continue;
+            }
+            for (int e = lm_edge_first[l]; e < lm_edge_first[l + 1]; ++e)
+                if (!edge_erased[e])
+                    for (int k = 0; k < 3; ++k) g_trans.push_back(centre[(size_t)obs_pose[e] * 3 + k]);
+            g_off.push_back(g_off.back() + n_kept);
+            for (int k = 0; k < 3; ++k) g_pos.push_back(pw(k)), g_ref.push_back(centre[(size_t)obs_pose[ref_edge] * 3 + k]);
+            g_scale.push_back(ref->orb_params_->scale_factors_.at(ref->frm_obs_.undist_keypts_.at(obs_kpidx[ref_edge]).octave));
+            g_lm.push_back(l);
+            if (desc_dirty[l]) {
+                for (int e = lm_edge_first[l]; e < lm_edge_first[l + 1]; ++e)
+                    if (!edge_erased[e]) {
+                        const unsigned char* row = obs_objects[e].first->frm_obs_.descriptors_.ptr((int)obs_kpidx[e]);
+                        d_rows.insert(d_rows.end(), row, row + 32);
+                    }
+                d_off.push_back(d_off.back() + n_kept);
+                d_lm.push_back(l);
+            }
+        }
+        if (!g_lm.empty()) {
+            const int n = (int)g_lm.size();
+            std::vector<double> mean_normal((size_t)n * 3);
+            std::vector<float> max_d(n), min_d(n);
+            hip::check(svgpu_landmarks_update_geometry(hip::context(), n, g_off.data(), g_trans.data(), g_pos.data(), g_ref.data(), g_scale.data(), inv_last,
+                                                       mean_normal.data(), max_d.data(), min_d.data()),
+                       "svgpu_landmarks_update_geometry");
+            for (int i = 0; i < n; ++i) {
+                Vec3_t mn;
+                for (int k = 0; k < 3; ++k) mn(k) = mean_normal[(size_t)i * 3 + k];
+                points[g_lm[i]]->set_prediction_parameters(mn, min_d[i], max_d[i]);
+            }
+        }
+        if (!d_lm.empty()) {
+            const int n = (int)d_lm.size();
+            std::vector<int32_t> best(n);
+            std::vector<uint8_t> rep((size_t)n * 32);
+            hip::check(svgpu_landmarks_compute_descriptor(hip::context(), n, d_off.data(), d_rows.data(), best.data(), rep.data()), "svgpu_landmarks_compute_descriptor");
+            for (int i = 0; i < n; ++i) points[d_lm[i]]->set_representative_descriptor(&rep[(size_t)i * 32]);
+        }
+#else
         for (int e = 0; e < (int)obs_objects.size(); ++e) {  // (landmark edges come first; marker edges are never outliers)
             if (!outlier[e]) continue;
             const auto& keyfrm = obs_objects[e].first;
@@ -1026,6 +1134,7 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
             local_lm->set_pos_in_world(pw);
             local_lm->update_mean_normal_and_obs_scale_variance();
         }
+#endif
         for (const auto& mk_slot : marker_slots) {  // :411-428
             const auto& mkr = mk_slot.first;
             if (mkr->keep_fixed_ || !mkr->initialized_before_) continue;

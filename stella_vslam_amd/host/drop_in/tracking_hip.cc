@@ -249,6 +249,14 @@ bool tracked_frame_chain::motion_based_track(data::frame& curr_frm, const data::
                                              const cv::Mat* img, std::vector<cv::KeyPoint>* keypts, const cv::Mat* img_right, const cv::Mat* img_depth) {
     if (img_right && (!img || !ctx_right_)) throw std::runtime_error("tracked_frame_chain: a stereo frame needs the left image and set_right_context()");
     if (img_depth && (!img || img_right)) throw std::runtime_error("tracked_frame_chain: an RGB-D frame is an image plus its depth map");
+    // (svgpu_track_motion_rgbd reads height x width floats behind the pointer: the raw CV_16U map before util::convert_to_true_depth, or a smaller
+    //  map, would be read out of bounds -- ADVICE r5)
+#ifdef CV_32FC1
+    if (img_depth && (img_depth->type() != CV_32FC1 || img_depth->rows != img->rows || img_depth->cols != img->cols))
+#else  // (the stand-in cv::Mat of host/standin/ is untyped bytes: every row must at least hold the image's width in floats)
+    if (img_depth && (img_depth->rows != img->rows || img_depth->step < (size_t)img->cols * sizeof(float)))
+#endif
+        throw std::runtime_error("tracked_frame_chain: the depth map must be CV_32FC1 (metres, util::convert_to_true_depth applied) of the image's size");
     lap_timer T("motion");
     // Set the initial pose by using the motion model (frame_tracker.cc:25-26)
     const Mat44_t guess = velocity * last_frm.get_pose_cw();

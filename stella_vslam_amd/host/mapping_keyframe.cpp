@@ -18,6 +18,14 @@ using namespace stella_vslam;
 using lm_ptr = std::shared_ptr<data::landmark>;
 using kf_ptr = std::shared_ptr<data::keyframe>;
 
+// What the warm-up call's write-back left behind, checked against the landmark's OWN methods (the stand-in restatement of
+// data/landmark.cc:199-318) run afterwards on the same objects: {live landmarks compared, landmarks whose mean normal / distance limits differ
+// (> 1e-12 / > 1e-6 relative), landmarks whose representative descriptor differs, landmarks that lost an observation}.
+static int g_refresh_check[4] = {-1, -1, -1, -1};
+extern "C" void svgpu_host_mapping_keyframe_refresh_check(int* out4) {
+    for (int k = 0; k < 4; ++k) out4[k] = g_refresh_check[k];
+}
+
 // ms[7] = {gather, flatten, solve, write-back, flush_map, total of optimize(), object-graph construction (untimed part, for the record)};
 // stats[8] = {local keyframes, fixed keyframes, landmarks, observations, LM iterations stage 1, stage 2, outlier observations erased, status}
 extern "C" int svgpu_host_mapping_keyframe(int P, int L, int E, const double* pose_cw, const uint8_t* pose_fixed, const double* points, const int32_t* obs_pose,
@@ -109,6 +117,30 @@ extern "C" int svgpu_host_mapping_keyframe(int P, int L, int E, const double* po
             int erased = 0;
             for (int e = 0; e < E; ++e)
                 if (!kfs[obs_pose[e]]->landmarks_[kp_of_obs[e]]) ++erased;
+            if (rep < 0) {  // (untimed) the batched refresh of the write-back against the per-object methods
+                int compared = 0, bad_geom = 0, bad_desc = 0, lost = 0;
+                std::vector<uint8_t> lost_obs(L, 0);
+                for (int e = 0; e < E; ++e)
+                    if (!kfs[obs_pose[e]]->landmarks_[kp_of_obs[e]]) lost_obs[obs_point[e]] = 1;
+                for (int l = 0; l < L; ++l) {
+                    auto& lm = lms[l];
+                    if (lm->will_be_erased() || !lm->has_observation()) continue;
+                    const Vec3_t mn = lm->get_obs_mean_normal();
+                    const float mx = lm->get_max_valid_distance(), mi = lm->get_min_valid_distance();
+                    uint8_t d[32];
+                    std::memcpy(d, lm->get_descriptor().ptr(0), 32);
+                    lm->compute_descriptor();
+                    lm->update_mean_normal_and_obs_scale_variance();
+                    const Vec3_t mn2 = lm->get_obs_mean_normal();
+                    bool g = std::fabs(lm->get_max_valid_distance() - mx) > 1e-6f * std::fabs(mx) || std::fabs(lm->get_min_valid_distance() - mi) > 1e-6f * std::fabs(mi);
+                    for (int k = 0; k < 3; ++k) g = g || std::fabs(mn2(k) - mn(k)) > 1e-12;
+                    ++compared;
+                    bad_geom += g ? 1 : 0;
+                    bad_desc += std::memcmp(d, lm->get_descriptor().ptr(0), 32) != 0 ? 1 : 0;
+                    lost += lost_obs[l];
+                }
+                g_refresh_check[0] = compared, g_refresh_check[1] = bad_geom, g_refresh_check[2] = bad_desc, g_refresh_check[3] = lost;
+            }
             stats[0] = n_local, stats[1] = n_fixed, stats[2] = L, stats[3] = E, stats[4] = hipba->last_stats_.iters_stage1, stats[5] = hipba->last_stats_.iters_stage2,
             stats[6] = erased, stats[7] = hipba->last_status_;
             for (auto& lm : lms) hip::map_mirror::landmark_erased(lm->id_);  // (leave the process-wide table as it was found)

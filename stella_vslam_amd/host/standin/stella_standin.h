@@ -262,6 +262,25 @@ public:
     std::atomic<unsigned int> num_observable_{1}, num_observed_{1};
     void compute_descriptor();                         // defined behind keyframe (data/landmark.cc:199-254)
     void update_mean_normal_and_obs_scale_variance();  // data/landmark.cc:256-318
+    std::shared_ptr<keyframe> get_ref_keyframe() const { return ref_keyfrm_.lock(); }  // data/landmark.cc:66-69
+    // The two setters the batched write-back of optimize::local_bundle_adjuster_hip needs (what data/landmark.h gains):
+    // they store what update_mean_normal_and_obs_scale_variance() / compute_descriptor() would have computed -- the values come from
+    // svgpu_landmarks_update_geometry / svgpu_landmarks_compute_descriptor, one device call for all landmarks of the window.
+#define SVGPU_LANDMARK_HAS_BATCH_SETTERS 1
+    void set_prediction_parameters(const Vec3_t& mean_normal, float min_valid_dist, float max_valid_dist) {
+        ++num_geometry_refreshes_;
+        mean_normal_ = mean_normal;
+        min_valid_dist_ = min_valid_dist;
+        max_valid_dist_ = max_valid_dist;
+        const double nv[3] = {mean_normal(0), mean_normal(1), mean_normal(2)};
+        hip::map_mirror::set_geometry(id_, nv, min_valid_dist_, max_valid_dist_);
+    }
+    void set_representative_descriptor(const unsigned char* descriptor32) {
+        ++num_descriptor_refreshes_;
+        descriptor_.create(1, 32, CV_8U);
+        std::memcpy(descriptor_.ptr(0), descriptor32, 32);
+        hip::map_mirror::set_descriptor(id_, descriptor_.ptr(0));
+    }
     unsigned int id_;
     // test bookkeeping
     unsigned int num_descriptor_refreshes_ = 0, num_geometry_refreshes_ = 0;

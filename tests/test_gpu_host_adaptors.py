@@ -89,3 +89,33 @@ def test_chain_second_half_after_a_failed_or_skipped_motion_track():
     # ... and it is a pose of this frame: the scene's true translation to a few millimetres (the fallback pose was 2 cm off)
     gt = np.array([-3 * 3.0 * 5.0 / 500.0, -3 * 1.0 * 5.0 / 500.0, 0.0])
     assert np.abs(P[0].reshape(3, 4)[:, 3] - gt).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_mapping_keyframe_batched_refresh_equals_the_per_landmark_methods():
+    """local_bundle_adjuster_hip::optimize writes its window back with ONE svgpu_landmarks_update_geometry (+ one svgpu_landmarks_compute_descriptor for
+    the landmarks that lost an outlier observation) instead of update_mean_normal_and_obs_scale_variance / compute_descriptor per landmark
+    (optimize/local_bundle_adjuster_g2o.cc:352-411, data/landmark.cc:199-318).  On an object graph of stand-in keyframes / landmarks: what the batched
+    write-back stored in every live landmark equals what the landmark's own methods compute afterwards on the same objects."""
+    import ctypes as C
+
+    import numpy as np
+    from stella_vslam_amd import synthetic
+    lib = ROOT / "stella_vslam_amd" / "host" / "libsvgpu_host.so"
+    if not lib.exists():
+        subprocess.check_call(["make", "-C", str(lib.parent)])
+    host = C.CDLL(str(lib))
+    sc = synthetic.ba_scene(num_kf=10, num_lm=1500, obs_per_lm=5, num_fixed=3, seed=77, outlier_frac=0.05)
+    P, Lm, E = len(sc["pose_cw"]), len(sc["points"]), len(sc["obs_pose"])
+    a = dict(pose=np.ascontiguousarray(sc["pose_cw"], np.float64), fixed=np.ascontiguousarray(sc["pose_fixed"], np.uint8), pts=np.ascontiguousarray(sc["points"], np.float64),
+             op=np.ascontiguousarray(sc["obs_pose"], np.int32), ol=np.ascontiguousarray(sc["obs_point"], np.int32), uvr=np.ascontiguousarray(sc["obs_uvr"], np.float32),
+             octave=np.clip(np.rint(np.log(1.0 / np.asarray(sc["obs_inv_sigma_sq"], np.float64)) / np.log(1.44)), 0, 7).astype(np.int32),
+             intr=np.ascontiguousarray(sc["intr"][0], np.float64))
+    v = lambda x: C.c_void_p(x.ctypes.data)
+    ms, st, chk = np.zeros(7), np.zeros(8, np.int32), np.zeros(4, np.int32)
+    assert host.svgpu_host_mapping_keyframe(P, Lm, E, v(a["pose"]), v(a["fixed"]), v(a["pts"]), v(a["op"]), v(a["ol"]), v(a["uvr"]), v(a["octave"]), v(a["intr"]), 0, 1,
+                                            v(ms), v(st)) == 0
+    host.svgpu_host_mapping_keyframe_refresh_check(v(chk))
+    compared, bad_geometry, bad_descriptor, lost = (int(x) for x in chk)
+    assert st[6] > 0 and lost > 0          # outlier observations were erased: the descriptor batch had work
+    assert compared > 1000 and bad_geometry == 0 and bad_descriptor == 0, chk
