@@ -14,7 +14,7 @@ from bench import csrc_hash
 t = pd.read_csv(f"{sys.argv[1]}/p_counter_collection.csv")
 t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"^void\s+", "", regex=True).str.replace(r"[<(].*$", "", regex=True)  # "void k_blur<64>(...)" -> "k_blur": templated kernels carry their return type and arguments
 g = t.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
-alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
+alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk", "k_describe_bands": "k_describe"}
 out = {"csrc_hash": csrc_hash(), "batch": int(sys.argv[3]) if len(sys.argv) > 3 else 256, "kernels": {}}
 for k, r in g.iterrows():
     if not k.startswith("k_"):

@@ -22,7 +22,7 @@ FETCH_CORRECTION = 2.0  # profiles/r01_pmc_calibration.json
 out = {"csrc_hash": csrc_hash(), "batch": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "unit": "bytes per launch (FETCH_SIZE KiB x 1024 x 2, WRITE_SIZE KiB x 1024; mean over the launches of the run)",
        "caveat": "gfx950: FETCH_SIZE counts half of the streamed bytes at every access width (calibrated, factor 2 applied); "
                  "Infinity-Cache hits are included", "kernels": {}}
-alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
+alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk", "k_describe_bands": "k_describe"}
 for k in sorted(set(f.index) | set(w.index)):
     if not k.startswith("k_"):
         continue

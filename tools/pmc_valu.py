@@ -18,7 +18,7 @@ from bench import csrc_hash  # the kernel sources these counters were taken on: 
 t = pd.read_csv(f"{sys.argv[1]}/p_counter_collection.csv")
 t["k"] = t["Kernel_Name"].str.replace("(anonymous namespace)::", "", regex=False).str.replace(r"^void\s+", "", regex=True).str.replace(r"[<(].*$", "", regex=True)  # "void k_blur<64>(...)" -> "k_blur": templated kernels carry their return type and arguments
 g = t.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
-alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk"}
+alias = {"k_pyramid": "k_resize", "k_pyramid_lds": "k_resize", "k_bf_mfma": "k_bf_topk", "k_describe_bands": "k_describe"}
 SIMDS, CYC = 256 * 4, 4
 out = {"csrc_hash": csrc_hash(), "batch": int(sys.argv[3]) if len(sys.argv) > 3 else 256, "simds": SIMDS, "cycles_per_valu_wave_inst": CYC,
        "note": "valu_issue_frac = SQ_INSTS_VALU * 4 / (1024 SIMDs * kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; both legs of the "
