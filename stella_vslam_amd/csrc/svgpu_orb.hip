@@ -516,7 +516,10 @@ int svgpu_orb_extract_batch_device_angles(svgpu_ctx* ctx, const uint8_t* imgs_de
     SV_HIP(ctx, hipEventRecord(ctx->ev_stage[1], s));
     ctx->stage_recorded = true;
     SvProfScope ps(ctx, s, "k_describe");
-    if (!C.dbands.empty())
+    // bands when the batch alone fills the chip (they are bound by throughput: 0.80 against 1.20 ms per 1 024 frames); for a few frames the
+    // per-keypoint kernel's many short workgroups finish sooner (one frame: 11 against 17 us, break-even near 16 frames of 2 400 keypoints)
+    const bool bands = !C.dbands.empty() && ((long long)batch * C.total_grid >= 32768 || getenv("SVGPU_DESCRIBE_BANDS") != nullptr);
+    if (bands)
         sv_launch_describe_bands(s, ctx->d_levels, Lc, ctx->d_dbands, (int)C.dbands.size(), C.dband_lds_bytes, ctx->d_sel, C.total_grid, ctx->d_cellpos,
                                  counts_dev, imgs_dev, frame_stride, row_stride, ctx->d_pyr, C.pyr_frame_bytes, ctx->d_blur, C.blur_frame_bytes,
                                  kps_dev, desc_dev, cap, batch, angles_dev);

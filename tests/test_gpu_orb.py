@@ -21,8 +21,15 @@ def _assert_same(kg, dg, ko, do):
     assert np.array_equal(dg, do)
 
 
+@pytest.mark.parametrize("bands", [False, True])
 @pytest.mark.parametrize("w,h,seed", [(640, 480, 0x5EED), (752, 480, 7), (1241, 376, 8), (320, 240, 9), (203, 157, 10), (1920, 1080, 11)])
-def test_extract_bit_exact(F, w, h, seed):
+def test_extract_bit_exact(F, w, h, seed, bands, monkeypatch):
+    # one frame takes the per-keypoint describe kernel by default (latency); SVGPU_DESCRIBE_BANDS forces the batch kernel k_describe_bands onto it
+    # (1920x1080: its bands do not fit LDS, the per-keypoint kernel serves it either way)
+    if bands:
+        monkeypatch.setenv("SVGPU_DESCRIBE_BANDS", "1")
+    else:
+        monkeypatch.delenv("SVGPU_DESCRIBE_BANDS", raising=False)
     img = S.frame(w, h, seed)
     ext = F.orb_extractor(F.orb_params())
     kg, dg = ext.extract(img)
@@ -183,6 +190,9 @@ def _batch_extract(F, frames, stride_pad=0, cap=None, legacy=False):
     from stella_vslam_amd._lib import lib
     B, h, w = frames.shape
     old = os.environ.pop("SVGPU_DESCRIBE_LEGACY", None)
+    old_b = os.environ.pop("SVGPU_DESCRIBE_BANDS", None)
+    if not legacy:
+        os.environ["SVGPU_DESCRIBE_BANDS"] = "1"   # read at every launch: k_describe_bands even for a batch of three (the library would take k_describe: latency)
     if legacy:
         os.environ["SVGPU_DESCRIBE_LEGACY"] = "1"  # read by svgpu_orb_configure: the per-keypoint kernel k_describe instead of k_describe_bands
     try:
@@ -208,6 +218,9 @@ def _batch_extract(F, frames, stride_pad=0, cap=None, legacy=False):
     ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(img.data_ptr() + off), B, C.c_size_t(h * stride), stride, None, C.c_size_t(0), 0,
                                                C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), cap, C.c_void_p(counts.data_ptr()), None), "extract")
     ctx.synchronize()
+    os.environ.pop("SVGPU_DESCRIBE_BANDS", None)
+    if old_b is not None:
+        os.environ["SVGPU_DESCRIBE_BANDS"] = old_b
     return (kps.cpu().numpy().view(O.KEYPOINT_DTYPE).reshape(B, cap), desc.cpu().numpy().reshape(B, cap, 32),
             counts.cpu().numpy().reshape(B, 1 + p.num_levels_), full)
 
