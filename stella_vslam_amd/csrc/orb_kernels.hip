@@ -511,9 +511,29 @@ __global__ __launch_bounds__(256) void k_blur(const OrbLevel* __restrict__ L, in
     if (!blur_streamable(src, spitch, lev.w)) return;  // k_blur_gather's level
     const int main_tiles = lev.btiles_x * lev.btiles_y;
     if (tile < main_tiles) {
-        const int x0 = (tile % lev.btiles_x) * BLUR_TW + (threadIdx.x & 63) * 4;
+        const int tx = tile % lev.btiles_x, ty = tile / lev.btiles_x;
+        // The last column tile of a level is rarely full (640 px: 32 of its 64 column groups, 533 px: 6, 370 px: 29, 309 px: 14): with one strip
+        // per wave the level widths fill 77 % of the lanes of this kernel, which is bound by instruction issue.  When the tile's interior groups fit
+        // `g` <= 32 lanes, a wave takes 64 / g STRIPS at once (lane = strip_in_wave * g + group): the strip's first row is then per lane and
+        // blur_strip's row pointers become vector registers (a few more instructions in these waves, which do 2-8 x the work) -- 95 % of the lanes.
+        const int rem_groups = tx == lev.btiles_x - 1 ? (min(lev.w - 6, (tx + 1) * BLUR_TW) - tx * BLUR_TW + 3) / 4 : 64;  // groups x0 with x0 + 6 < w
+        int g = 64;
+        while (g > 1 && (g >> 1) >= rem_groups) g >>= 1;
+#ifdef BLUR_NO_MULTISTRIP
+        g = 64;
+#endif
+        if (g <= 32 && rem_groups > 0) {
+            const int spw = 64 / g, lane = threadIdx.x & 63;
+            if (ty * spw >= lev.btiles_y) return;  // (this tile's strips are carried by an earlier tile's waves)
+            const int strip = (ty * 4 + (int)(threadIdx.x >> 6)) * spw + lane / g;
+            const int x0 = tx * BLUR_TW + (lane % g) * 4, ys = strip * ROWS;
+            if (x0 >= lev.w || ys >= lev.h) return;
+            if (x0 >= 4 && x0 + 6 < lev.w) blur_strip<BLUR_INTERIOR>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + ROWS, lev.h));
+            return;
+        }
+        const int x0 = tx * BLUR_TW + (threadIdx.x & 63) * 4;
         // the strip's first row is the same for the whole wave: say so, and the row pointers of blur_strip become scalar
-        const int ys = __builtin_amdgcn_readfirstlane((tile / lev.btiles_x) * (4 * ROWS) + (int)(threadIdx.x >> 6) * ROWS);
+        const int ys = __builtin_amdgcn_readfirstlane(ty * (4 * ROWS) + (int)(threadIdx.x >> 6) * ROWS);
         if (x0 >= lev.w || ys >= lev.h) return;
         if (x0 >= 4 && x0 + 6 < lev.w) blur_strip<BLUR_INTERIOR>(src, spitch, lev.w, lev.h, dst, lev.pitch, x0, ys, min(ys + ROWS, lev.h));
     }
