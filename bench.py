@@ -1067,7 +1067,7 @@ def bench_global_ba(device, rank, world, large=False):
         setup1_ms = timed_ms(lambda: ba.optimize_global_flat(sc, num_iter=0))
         gaps_ms = max(call_ms - setup1_ms - shard_ms - solve_ms, 0.0)
         null_cb = distributed.ALLREDUCE_FN(lambda user, buf, count, stream: 0)
-        FIXED_US, PER_TRIAL_CALLS = 20.0, 6
+        FIXED_US, PER_TRIAL_CALLS = 20.0, 5  # pose blocks + damping slots | system (separator blocks) | job contributions | solution | trial sums (round 6: the slots ride with the pose blocks)
         projection = {"assumptions": {"collective_fixed_us": FIXED_US, "xgmi_link_GBs": XGMI_LINK_GBS, "collectives_per_trial": PER_TRIAL_CALLS,
                                       "setup": "measured on this GPU: rank 0's shard, zero iterations, null exchange",
                                       "loop": "observation phases x largest shard share; envelope solve and launch gaps as at N = 1"},

@@ -2197,11 +2197,11 @@ __global__ void k_ba_prepare(BaDev D) {
     if (c.phase == 2) return;
     if (c.phase == 0) {
         if (c.it == 0) {
+            // (sharded: the control block holds max(pose diagonals of the summed blocks -- the same on every rank --, this rank's landmarks);
+            //  the slots hold every rank's landmark maximum)
             double md = __longlong_as_double((long long)c.max_diag_bits);
-            if (D.world > 1) {
-                md = 0.0;
+            if (D.world > 1)
                 for (int r = 0; r < D.world; ++r) md = fmax(md, D.maxslots[r]);
-            }
             c.lambda = 1e-5 * md;
             c.ni = 2.0;
         }
@@ -2546,9 +2546,13 @@ void sv_ba_linearize(svgpu_ctx* ctx, hipStream_t s, const BaDev& D, int do_prepa
     hipLaunchKernelGGL(k_ba_lin_fin, dim3(1), dim3(LIN_FIN_THREADS), 0, s, D, do_prepare, nb);
 }
 
-void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {  // sharded solve only: pose part over the summed blocks + the rank's slot
-    if (D.nP > 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D.nP + 255) / 256), dim3(256), 0, s, D);
+// sharded solve only.  Before the pose blocks are summed over the ranks: the rank's slot = the largest diagonal of ITS landmarks (k_ba_lin left it in
+// the control block); the slots ride behind the blocks in the same all-reduce.  After it: the pose part of the maximum from the summed blocks.
+void sv_ba_maxslot(hipStream_t s, const BaDev& D) {
     if (D.world > 1) hipLaunchKernelGGL(k_ba_maxslot, dim3(1), dim3(64 > D.world ? 64 : D.world), 0, s, D);
+}
+void sv_ba_maxdiag(hipStream_t s, const BaDev& D) {
+    if (D.nP > 0) hipLaunchKernelGGL(k_ba_maxdiag, dim3((D.nP + 255) / 256), dim3(256), 0, s, D);
 }
 
 void sv_ba_fold(hipStream_t s, const BaDev& D, double* out4, int with_scale) { hipLaunchKernelGGL(k_ba_fold, dim3(1), dim3(256), 0, s, D, out4, with_scale); }

@@ -18,6 +18,7 @@
 #include "ba_kernels.h"
 
 void sv_ba_maxdiag(hipStream_t s, const BaDev& D);
+void sv_ba_maxslot(hipStream_t s, const BaDev& D);
 void sv_ba_owned_mark(hipStream_t s, const int* lm_off, int L, double* xch, double stop_vote);
 void sv_ba_owned_check(hipStream_t s, const double* xch, int L, uint8_t* any_owner, double* verdict);
 void sv_ba_points_share(hipStream_t s, const BaDev& D, double* points_out, double* xch, int dir);
@@ -627,7 +628,7 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
     static const bool dbg_chol = dbg_stamps && !strcmp(std::getenv("SVGPU_BA_DBG"), "chol");
     D.dbg_schur_on = dbg_schur ? 1 : (dbg_chol ? 2 : 0);
     D.dbg = dbg_stamps ? A.take<unsigned long long>(8 * (dbg_schur ? sc_part_blocks + 64 : (size_t)nb_lm)) : nullptr;
-    double* d_HB_full = A.take<double>(42 * (size_t)P);           // sharded: Hpp | bp summed over ranks
+    double* d_HB_full = A.take<double>(42 * (size_t)P + (size_t)std::max(64, world));     // sharded: Hpp | bp summed over ranks | one slot per rank: its landmarks' largest diagonal (computeLambdaInit)
     double* d_sc = A.take<double>(64 + (size_t)world);            // sharded: [0..3] per-trial sums, [8..8+world) lambda-init slots
     double* d_xch = A.take<double>(xch_doubles);                  // sharded: pose-activity / block-presence / point exchange
     int* d_prow_off = A.take<int>(P + 1);
@@ -1148,13 +1149,17 @@ static int local_ba_impl(svgpu_ctx* ctx, const svgpu_ba_problem* pr, bool single
         const bool fused_tail = !no_fusion && !sharded && sv_ba_tail_ok(D);
         sv_ba_linearize(ctx, s, D, sharded ? 0 : 1);
         if (sharded) {  // pose blocks summed over the ranks before the damping is initialised from their diagonal
+            // ONE collective (round 6; it was two): the rank's slot of the damping initialisation -- the largest diagonal entry of ITS landmarks,
+            // which k_ba_lin has just left in the control block -- rides behind the pose blocks.  The pose part of the maximum is taken from the
+            // SUMMED blocks afterwards, identically on every rank; k_ba_prepare takes the largest of that and the slots.
             if (HS.nP > 0) {
                 SV_HIP(ctx, hipMemcpyAsync(d_HB_full, D.Hpp, 8 * 36 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
                 SV_HIP(ctx, hipMemcpyAsync(d_HB_full + 36 * (size_t)HS.nP, D.bp, 8 * 6 * (size_t)HS.nP, hipMemcpyDeviceToDevice, s));
-                if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP, XC_POSE_BLOCKS))) return r;
             }
+            D.maxslots = d_HB_full + 42 * (size_t)HS.nP;
+            sv_ba_maxslot(s, D);
+            if ((r = allreduce_dev(d_HB_full, 42 * (size_t)HS.nP + (size_t)world, XC_POSE_BLOCKS))) return r;
             sv_ba_maxdiag(s, D);
-            if ((r = allreduce_dev(D.maxslots, (size_t)world, XC_SUMS))) return r;
             sv_ba_prepare(s, D);
         }
         sv_ba_reduce(ctx, s, D);
