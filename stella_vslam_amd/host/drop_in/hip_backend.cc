@@ -848,7 +848,16 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     std::sort(local_lms.begin(), local_lms.end(), [](const std::pair<unsigned int, lm_ptr>& a, const std::pair<unsigned int, lm_ptr>& b) { return a.first < b.first; });
     local_lms.erase(std::unique(local_lms.begin(), local_lms.end(), [](const std::pair<unsigned int, lm_ptr>& a, const std::pair<unsigned int, lm_ptr>& b) { return a.first == b.first; }),
                     local_lms.end());
-    std::vector<data::landmark::observations_t> local_lm_obs(local_lms.size());
+    // every landmark's observations, flat: the keyframe (locked once, nullptr if it has expired) and the keypoint index of observation o of
+    // landmark k at all_obs[lm_obs_first[k] .. lm_obs_first[k + 1]), in the order of the landmark's observations_ map.  get_observations() returns
+    // the map BY VALUE; the copy lives for one loop trip (round 5 kept ten thousand of them for the flattening below and walked them twice).
+    struct obs_rec {
+        kf_ptr keyfrm;
+        unsigned int idx;
+    };
+    std::vector<obs_rec> all_obs;
+    std::vector<int> lm_obs_first(local_lms.size() + 1, 0);
+    all_obs.reserve(8 * local_lms.size());
     std::map<unsigned int, std::shared_ptr<data::marker>> local_mkrs;  // :86-102
     for (const auto& id_kf : local_keyfrms)
         for (const auto& local_mkr : id_kf.second->get_markers()) {
@@ -857,14 +866,16 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
         }
     std::map<unsigned int, kf_ptr> fixed_keyfrms;
     for (size_t k = 0; k < local_lms.size(); ++k) {
-        local_lm_obs[k] = local_lms[k].second->get_observations();
-        for (const auto& obs : local_lm_obs[k]) {
-            const auto fixed_keyfrm = obs.first.lock();
+        lm_obs_first[k] = (int)all_obs.size();
+        for (const auto& obs : local_lms[k].second->get_observations()) {
+            all_obs.push_back(obs_rec{obs.first.lock(), obs.second});
+            const auto& fixed_keyfrm = all_obs.back().keyfrm;
             if (!fixed_keyfrm || fixed_keyfrm->will_be_erased()) continue;
             if (local_keyfrms.count(fixed_keyfrm->id_)) continue;
             fixed_keyfrms.emplace(fixed_keyfrm->id_, fixed_keyfrm);
         }
     }
+    lm_obs_first[local_lms.size()] = (int)all_obs.size();
     if (use_additional_keyframes_for_monocular_) {  // :135-147
         auto additional_keyfrms_size = 2 - fixed_keyfrms.size();
         if (!has_scale && fixed_keyfrms.size() < 2 && local_keyfrms.size() > additional_keyfrms_size) {
@@ -918,25 +929,23 @@ void local_bundle_adjuster_hip::optimize(data::map_database* map_db, const kf_pt
     std::vector<int> lm_edge_first;           // edges of landmark l = [lm_edge_first[l], lm_edge_first[l + 1]) (appended landmark by landmark, in observations_ order)
     std::vector<uint8_t> lm_partial;          // an observation of l was NOT turned into an edge (expired / erased keyframe): the batched refresh leaves l to the object's own methods
     {
-        size_t n_obs = 0;
-        for (const auto& o : local_lm_obs) n_obs += o.size();
+        const size_t n_obs = all_obs.size();
         points.reserve(local_lms.size()), pts.reserve(3 * local_lms.size());
         obs_pose.reserve(n_obs), obs_point.reserve(n_obs), obs_uvr.reserve(3 * n_obs), obs_w.reserve(n_obs), obs_huber.reserve(n_obs), obs_objects.reserve(n_obs);
         obs_kpidx.reserve(n_obs), lm_edge_first.reserve(local_lms.size() + 1), lm_partial.reserve(local_lms.size());
     }
     for (size_t k_lm = 0; k_lm < local_lms.size(); ++k_lm) {
         const auto& local_lm = local_lms[k_lm].second;
-        const auto& observations = local_lm_obs[k_lm];
-        if (observations.empty()) continue;
+        if (lm_obs_first[k_lm] == lm_obs_first[k_lm + 1]) continue;
         const int l = (int)points.size();
         points.push_back(local_lm);
         lm_edge_first.push_back((int)obs_pose.size());
         lm_partial.push_back(0);
         const Vec3_t pw = local_lm->get_pos_in_world();
         for (int k = 0; k < 3; ++k) pts.push_back(pw(k));
-        for (const auto& obs : observations) {
-            const auto keyfrm = obs.first.lock();
-            const auto idx = obs.second;
+        for (int o = lm_obs_first[k_lm]; o < lm_obs_first[k_lm + 1]; ++o) {
+            const auto& keyfrm = all_obs[o].keyfrm;
+            const auto idx = all_obs[o].idx;
             if (!keyfrm || keyfrm->will_be_erased()) {
                 lm_partial.back() = 1;
                 continue;
