@@ -598,6 +598,18 @@ __device__ __forceinline__ int arc_score16(int v, const int (&p)[16]) {
     return max(max((int)best.x - v, v + 1 + (int)best.y), 0);
 }
 
+// one LDS-DMA instruction: lane i copies the 16 bytes at base + voff[i] (any byte address: profiles/r06_ubench_glds.json) to LDS byte
+// lds_dst + 16 i.  M0 carries the LDS address and is written in the statement that reads it (the compiler does not preserve it); the two
+// moves + s_nop 2 are also the five wait states a VMEM instruction needs behind a VALU instruction that produced its scalar base
+// (hipcc does not look for hazards inside an asm statement).
+__device__ __forceinline__ void sv_glds16(unsigned long long base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
 #define FAST_KT 12  // selection-grid cells per dimension cached in LDS (a 70-px ROI spans at most ~10 at the coarsest level)
 #define FP 80  // LDS pitch of the ROI arrays: 3 skew bytes + 70, rounded up to whole 16-byte chunks
 // One workgroup works through `cpw` consecutive cells of one frame (persistent over cells: the frame / lane-role set-up, and the row
@@ -681,35 +693,23 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     }
     const int w = cell.w, h = cell.h;
     if (ci != c_first) __syncthreads();  // the previous cell's flush has read s_key, its last pass s_a / s_raw
-    // ROI -> LDS.  The ROI starts at x = 19 + 64j, i.e. 3 bytes past a 16-byte boundary: load the aligned words that
-    // cover it (the 3 leading bytes are real pixels of the border band) and address the LDS copy with a +3 skew.
+    // ROI -> LDS by LDS-DMA (round 6: global_load_lds_dwordx4, no staging registers, no ds_write pass, any source alignment -- the three
+    // load variants of rounds 1-5 were one per alignment class).  The ROI starts at x = 19 + 64j, i.e. 3 bytes past a 16-byte boundary of an
+    // aligned level: the pieces start 3 bytes early (real pixels of the border band) and the LDS copy is addressed with a +3 skew.  Piece q = row * 5 +
+    // piece-of-row goes to LDS byte 16 q (the rows are FP = 80 bytes apart); a thread owns pieces tid and tid + 256, so its row and column are the same
+    // for every cell.  Rows past the cell and pieces past its width are NOT fetched: what the previous cell left there is never used (the quick test masks
+    // those positions, the arc score and the NMS only visit queued pixels, whose rings lie inside the cell).
     const uint8_t* rsrc = src + (size_t)cell.min_y * spitch + (cell.min_x - 3);
-    if (((((size_t)rsrc) | (size_t)spitch) & 15) == 0) {
-        // 16-byte chunks: the ROI (with its 3 leading bytes) starts on a 16-byte boundary and ends at least 16 px before
-        // the row end, so whole chunks stay inside the image row
-        for (int i = tid; i < SV_ROI_MAX * (FP / 16); i += 256) {
-            const int r = i / (FP / 16), c = i - r * (FP / 16);
-            uint4 v = {0, 0, 0, 0};
-            if (r < h && 16 * c < w + 3) v = *reinterpret_cast<const uint4*>(rsrc + (__umul24(r, spitch) + 16 * c));
-            reinterpret_cast<uint4*>(s_raw)[i] = v;
-            reinterpret_cast<uint4*>(s_a)[i] = make_uint4(0, 0, 0, 0);
-        }
-    }
-    else if (((((size_t)src) | (size_t)spitch) & 3) == 0) {
-        const int words = (w + 3 + 3) >> 2;  // bytes [-3, w) rounded up to words; the row pitch (multiple of 4) covers it
-        for (int i = tid; i < SV_ROI_MAX * (FP / 4); i += 256) {
-            const int r = i / (FP / 4), c = i - r * (FP / 4);
-            uint32_t v = 0;
-            if (r < h && c < words) v = *reinterpret_cast<const uint32_t*>(rsrc + (__umul24(r, spitch) + 4 * c));
-            reinterpret_cast<uint32_t*>(s_raw)[i] = v;
-            reinterpret_cast<uint32_t*>(s_a)[i] = 0;
-        }
-    }
-    else {
-        for (int i = tid; i < SV_ROI_MAX * FP; i += 256) {
-            const int r = i / FP, c = i - r * FP;
-            s_raw[i] = (r < h && c < w + 3) ? rsrc[__umul24(r, spitch) + c] : 0;
-            s_a[i] = 0;
+    {
+        const unsigned long long rbase = (unsigned long long)(uintptr_t)rsrc;
+        const uint32_t lds_raw = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)s_raw) + (uint32_t)wv * 1024u;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q = tid + 256 * it, r = q / 5, c = q - 5 * r;  // (compile-time divisor)
+            if (it == 0 || wv < 2) {                                   // pieces 256..349 belong to waves 0 and 1
+                if (q < SV_ROI_MAX * (FP / 16) && r < h && 16 * c < w + 3) sv_glds16(rbase, (uint32_t)(__umul24(r, spitch) + 16 * c), lds_raw + 4096u * it);
+            }
+            if (q < SV_ROI_MAX * (FP / 16)) reinterpret_cast<uint4*>(s_a)[q] = make_uint4(0, 0, 0, 0);
         }
     }
     if (tid == 0) {
@@ -721,6 +721,7 @@ __global__ __launch_bounds__(256) void k_fast(const OrbLevel* __restrict__ L, in
     uint32_t band80 = 0;  // 0x80 per column of the patch inside the scored band
 #pragma unroll
     for (int j = 0; j < 4; ++j) band80 |= (x0 + j < w - 3) ? (0x80u << (8 * j)) : 0u;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own DMA pieces have landed; the barrier publishes them to the other waves
     __syncthreads();
 
     // cv::FAST at ini_thr; if the cell stays empty, once more at min_thr (:228-235).  The quick test, the queue and the arc scores are
@@ -1238,18 +1239,6 @@ __device__ __forceinline__ void sv_writelane8(uint32_t& lo, uint32_t& hi, const 
         : "+v"(lo), "+v"(hi)
         : "s"((uint32_t)m[0]), "s"((uint32_t)(m[0] >> 32)), "s"((uint32_t)m[1]), "s"((uint32_t)(m[1] >> 32)), "s"((uint32_t)m[2]), "s"((uint32_t)(m[2] >> 32)),
           "s"((uint32_t)m[3]), "s"((uint32_t)(m[3] >> 32)), "n"(LANE), "n"(LANE + 1), "n"(LANE + 2), "n"(LANE + 3));
-}
-
-// one LDS-DMA instruction: lane i copies the 16 bytes at base + voff[i] (any byte address: profiles/r06_ubench_glds.json) to LDS byte
-// lds_dst + 16 i.  M0 carries the LDS address and is written in the statement that reads it (the compiler does not preserve it); the two
-// moves + s_nop 2 are also the five wait states a VMEM instruction needs behind a VALU instruction that produced its scalar base
-// (hipcc does not look for hazards inside an asm statement).
-__device__ __forceinline__ void sv_glds16(unsigned long long base, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(base), "s"(lds_dst)
-                 : "memory");
 }
 
 // rows [y0, y0 + nrows) of an image (row pitch gp, any alignment) -> LDS at lds0 with row pitch 16 * cpr, by the whole workgroup.
