@@ -1251,9 +1251,11 @@ __device__ __forceinline__ void db_stage_rows(const uint8_t* img, int gp, int y0
     const uint32_t voff = (uint32_t)(rsub * gp + csub * 16);
     const int groups = (nrows + rpi - 1) / rpi;
     const unsigned long long base = (unsigned long long)(uintptr_t)(img + (size_t)y0 * gp);
-    if (rsub < rpi)  // (rows beyond nrows in the last group: a few more rows of the level, inside the buffers; their LDS rows are allocated)
+    // (the last group may hold fewer than rpi rows: its surplus lanes stay out -- the rows behind a level's last one belong to somebody else, and
+    //  behind a caller's image to nobody)
+    if (rsub < rpi)
         for (int g = wave; g < groups; g += DB_WAVES)
-            sv_glds16(base + (unsigned long long)(g * rpi) * (unsigned)gp, voff, lds0 + (uint32_t)(g * rpi * cpr) * 16);
+            if (g * rpi + rsub < nrows) sv_glds16(base + (unsigned long long)(g * rpi) * (unsigned)gp, voff, lds0 + (uint32_t)(g * rpi * cpr) * 16);
 }
 // the general form (pieces of a row spread over several instructions): piece q = row * cpr + c goes to LDS byte 16 q, instruction i covers
 // pieces [64 i, 64 i + 64)

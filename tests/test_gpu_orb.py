@@ -225,14 +225,14 @@ def _batch_extract(F, frames, stride_pad=0, cap=None, legacy=False):
             counts.cpu().numpy().reshape(B, 1 + p.num_levels_), full)
 
 
-@pytest.mark.parametrize("w,h,pad", [(640, 480, 0), (203, 157, 5), (1241, 376, 0), (331, 250, 1)])
+@pytest.mark.parametrize("w,h,pad", [(640, 480, 0), (203, 157, 5), (1241, 376, 0), (331, 250, 1), (131, 100, 3)])  # (131 px: up to ten rows per staging instruction)
 def test_describe_bands_equal_per_keypoint_kernel(F, w, h, pad):
     """k_describe_bands (LDS-resident bands) and k_describe (per-keypoint patches) are two routes to the same bytes: orientation, records and
     descriptors of a batch, with an unaligned strided image, and with a capacity that cuts a band's run of keypoints short."""
     frames = S.frame_sequence(3, w, h, seed=w + h)
     kb, db, cb, full = _batch_extract(F, frames, pad)
     kl, dl, cl, _ = _batch_extract(F, frames, pad, legacy=True)
-    assert np.array_equal(cb, cl) and cb[:, 0].min() > 50
+    assert np.array_equal(cb, cl) and cb[:, 0].min() > 20
     for b in range(3):
         n = cb[b, 0]
         assert np.array_equal(kb[b, :n], kl[b, :n]) and np.array_equal(db[b, :n], dl[b, :n])
