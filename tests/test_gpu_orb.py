@@ -243,3 +243,52 @@ def test_describe_bands_equal_per_keypoint_kernel(F, w, h, pad):
     assert np.array_equal(cc, cb)
     for b in range(3):
         assert np.array_equal(kc[b], kb[b, :cap]) and np.array_equal(dc[b], db[b, :cap])
+
+
+def test_describe_bands_equal_per_keypoint_kernel_on_random_geometries(F):
+    """The band table (level pitches, rows per staging instruction, grid rows per band, wide-row staging) depends on every extractor parameter: sixteen random
+    geometries -- 90..1400 x 80..700 px, scale factor 1.1..2.0, 1..9 levels, FAST thresholds, min_area, batch 1..3, row stride and base address off
+    alignment -- give byte-identical records, descriptors and counts from k_describe_bands and k_describe (160 such draws were run once by hand: no mismatch)."""
+    import ctypes as C
+    import os
+    import torch
+    from stella_vslam_amd._lib import lib
+    L = lib()
+    rng = np.random.default_rng(2026)
+    saved = {k: os.environ.pop(k, None) for k in ("SVGPU_DESCRIBE_LEGACY", "SVGPU_DESCRIBE_BANDS")}
+    try:
+        total = 0
+        for _ in range(16):
+            w, h = int(rng.integers(90, 1400)), int(rng.integers(80, 700))
+            sf, nl = float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0])), int(rng.integers(1, 10))
+            ini = int(rng.integers(8, 40))
+            mn, area = int(rng.integers(3, ini)), int(rng.choice([200, 800, 2000]))
+            B, pad, off = int(rng.integers(1, 4)), int(rng.integers(0, 9)), int(rng.integers(0, 4))
+            frames = S.frame_sequence(B, w, h, seed=int(rng.integers(1 << 12)))
+            outs = []
+            for env in ("SVGPU_DESCRIBE_BANDS", "SVGPU_DESCRIBE_LEGACY"):
+                os.environ.pop("SVGPU_DESCRIBE_BANDS", None)
+                os.environ.pop("SVGPU_DESCRIBE_LEGACY", None)
+                os.environ[env] = "1"
+                ctx = F.Context(0)
+                ctx.check(L.svgpu_orb_configure(ctx.handle, w, h, B, C.c_float(sf), nl, ini, mn, C.c_uint(area)), "cfg")
+                cap, stride = max(L.svgpu_orb_max_keypoints(ctx.handle), 1), w + pad
+                buf = np.zeros((B, h, stride), np.uint8)
+                buf[:, :, :w] = frames
+                img = torch.cat([torch.zeros(off, dtype=torch.uint8, device="cuda"), torch.from_numpy(buf.reshape(-1)).cuda()])
+                kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+                desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+                counts = torch.zeros(B * (1 + nl), dtype=torch.int32, device="cuda")
+                ctx.check(L.svgpu_orb_extract_batch_device(ctx.handle, C.c_void_p(img.data_ptr() + off), B, C.c_size_t(h * stride), stride, None, C.c_size_t(0), 0,
+                                                           C.c_void_p(kps.data_ptr()), C.c_void_p(desc.data_ptr()), cap, C.c_void_p(counts.data_ptr()), None), "extract")
+                ctx.synchronize()
+                outs.append((kps.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()))
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b), (w, h, sf, nl, ini, mn, area, B, pad, off)
+            total += int(outs[0][2].reshape(B, -1)[:, 0].sum())
+        assert total > 5000
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
