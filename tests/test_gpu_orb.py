@@ -292,3 +292,13 @@ def test_describe_bands_equal_per_keypoint_kernel_on_random_geometries(F):
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_describe_bands_equal_per_keypoint_kernel_at_bench_size(F):
+    """The bench workload itself (640x480 synthetic sequence, one launch of 128 frames -- the library routes batches of this size to k_describe_bands on its own):
+    every record, descriptor and count equal to the per-keypoint kernel's, ~310 k keypoints."""
+    frames = S.frame_sequence(128, 640, 480, seed=0x5EED)
+    kb, db, cb, _ = _batch_extract(F, frames)
+    kl, dl, cl, _ = _batch_extract(F, frames, legacy=True)
+    assert np.array_equal(cb, cl) and cb[:, 0].sum() > 300000
+    assert np.array_equal(kb, kl) and np.array_equal(db, dl)

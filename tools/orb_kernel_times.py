@@ -7,7 +7,7 @@ import torch
 from stella_vslam_amd import feature, synthetic
 from stella_vslam_amd._lib import lib
 
-W, H, B = 640, 480, int(os.environ.get("ORB_B", "64"))
+W, H, B = int(os.environ.get("ORB_W", "640")), int(os.environ.get("ORB_H", "480")), int(os.environ.get("ORB_B", "64"))
 ctx = feature.Context(0)
 L = lib()
 p = feature.orb_params()
